@@ -1,0 +1,173 @@
+/*
+ * jxlo -- CPU ORACLE for the jxl-rs VarDCT / Modular reconstruction hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is a plain-C restatement of the reference's
+ * (libjxl/jxl-rs v0.6.0, Rust) arithmetic, function by function, written to be
+ * the *checker* for the HIP kernels under jxl_rs_amd/csrc/.  Nothing in the
+ * product path may link, import or call it; only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg do.
+ *
+ * Pinning status (see DESIGN.md "Oracle"): the reference is Rust and cannot be
+ * built here (no cargo/rustc), so the oracle is pinned against every in-tree
+ * known-answer vector the reference's own tests hold for this path
+ * (tests/golden/reference_kat.json, extracted by
+ * oracle/tools/extract_reference_constants.py):
+ *   - f64 matrix-definition IDCT / reinterpreting-DCT with the reference's own
+ *     per-shape tolerances (jxl_transforms/src/tests.rs:24-173, :281-492),
+ *   - default dequant matrices, 891 libjxl samples (quant_weights.rs:1231-2137),
+ *   - natural coefficient orders (coeff_order.rs:157-171),
+ *   - Gaborish checkerboard (gaborish.rs:132-145),
+ *   - IDCT / reinterpreting-DCT constant tables (idct_large.rs:17-248, ...).
+ * EPF, adaptive LF smoothing, RCT, Palette and regular Unsqueeze have NO numeric
+ * goldens in the reference tree ("parity unpinned" for those at value level);
+ * they are restated line by line from the scalar definitions and checked
+ * through the reference's structural properties (chunk invariance, mirror
+ * semantics, i64 scalar definition == i32 SIMD definition).
+ *
+ * Two builds of the same source:
+ *   JXLO_FUSED=1  mul_add == fmaf   (reference AVX2/AVX-512/NEON back-ends)
+ *   JXLO_FUSED=0  mul_add == a*b+c  (reference ScalarDescriptor / SSE4.2 back-end,
+ *                                    jxl_simd/src/scalar.rs:118-125)
+ * Both are compiled with -ffp-contract=off so nothing else is contracted.
+ */
+#ifndef JXLO_H_
+#define JXLO_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- transform type table (jxl_transforms/src/transform_map.rs:12-116) ---- */
+#define JXLO_NUM_TRANSFORMS 27
+#define JXLO_NUM_QUANT_TABLES 17
+int jxlo_covered_blocks_x(int type);
+int jxlo_covered_blocks_y(int type);
+int jxlo_quant_table_for_type(int type);           /* quant_weights.rs:321-343 */
+int jxlo_quant_table_size(int table);              /* floats per channel */
+int jxlo_is_fused(void);
+
+/* ---- 1-D / 2-D transforms (jxl_transforms) ---- */
+/* in-place 1-D IDCT of n in {2,4,...,256} samples at data[i*stride] */
+void jxlo_idct1d(float* data, int n, int stride);
+/* in-place 1-D "reinterpreting" forward DCT, n in {1,2,4,8,16,32} */
+void jxlo_rdct1d(float* data, int n, int stride);
+/* in-place 2-D IDCT, rows x cols pixels; layout contract of
+ * jxl_transforms/src/tests.rs:119-132 (input wide / transposed, output row-major) */
+void jxlo_idct2d(float* data, int rows, int cols);
+/* LLF-from-LF: lf is rows x cols (cy x cx) row-major, destroyed; result goes to
+ * the top-left min x max corner of out with row stride 8*max(rows, cols) */
+void jxlo_rdct2d(float* lf, int rows, int cols, float* out);
+/* transform_to_pixels (transform.rs:377-664): lf = cy*cx samples (destroyed),
+ * buf = cx*cy*64 dequantised coefficients in, pixels (row-major R x C) out */
+void jxlo_transform_to_pixels(int type, float* lf, float* buf);
+
+/* f64 matrix definitions (jxl_transforms/src/tests.rs:24-173) */
+void jxlo_slow_idct2d(const double* in, int rows, int cols, double* out);
+void jxlo_slow_rdct2d(const double* in, int rows, int cols, double* out /* min x max */);
+void jxlo_slow_idct1d(const double* in, int n, double* out);
+void jxlo_slow_dct1d(const double* in, int n, double* out);
+
+/* constant tables, for pinning */
+const float* jxlo_idct_weights(int n);   /* n/2 floats: 1/(2cos((2i+1)pi/2n)) */
+const float* jxlo_rdct_scales(int n);    /* n floats */
+
+/* ---- dequant tables & coefficient order (host-side inputs of the path) ---- */
+/* library default table t (0..16), 3 * jxlo_quant_table_size(t) floats, inverse weights */
+int jxlo_library_dequant_table(int table, float* out);
+void jxlo_natural_coeff_order(int type, uint32_t* out /* cx*cy*64 */);
+
+/* ---- VarDCT frame-level restatement ---- */
+typedef struct {
+  /* geometry */
+  int32_t xsize, ysize;          /* unpadded frame size in pixels */
+  int32_t xsize_blocks, ysize_blocks;
+  int32_t group_dim;             /* 256 */
+  /* quantizer (quantizer.rs:56-85) */
+  uint32_t global_scale, quant_lf;
+  float lf_quant_factors[3];     /* LfQuantFactors.quant_factors, order X,Y,B */
+  float quant_biases[4];         /* headers/transform_data.rs:30-31 */
+  uint32_t x_qm_scale, b_qm_scale;
+  /* chroma from luma (color_correlation_map.rs:21-94) */
+  uint32_t color_factor;
+  float base_correlation_x, base_correlation_b;
+  int32_t ytox_lf, ytob_lf;
+  /* restoration filter (headers/frame_header.rs:146-233) */
+  int32_t gab;
+  float gab_w1[3], gab_w2[3];
+  int32_t epf_iters;
+  float epf_sharp_lut[8];
+  float epf_channel_scale[3];
+  float epf_quant_mul, epf_pass0_sigma_scale, epf_pass2_sigma_scale, epf_border_sad_mul;
+  int32_t do_lf_smoothing;
+} JxloFrameParams;
+
+void jxlo_default_frame_params(JxloFrameParams* p, int xsize, int ysize);
+
+/* K0a dequant_lf (frame/modular/mod.rs:837-929), 4:4:4 branch.
+ * q[0]=Y, q[1]=X, q[2]=B quantised planes (the modular channel order), n samples,
+ * mul = 1/(1<<extra_precision).  out[0]=X, out[1]=Y, out[2]=B. */
+void jxlo_dequant_lf(const JxloFrameParams* p, const int32_t* qy, const int32_t* qx,
+                     const int32_t* qb, float mul, size_t n, float* out_x, float* out_y,
+                     float* out_b);
+/* K0b adaptive_lf_smoothing (frame/adaptive_lf_smoothing.rs:44-125); planes w x h, tight */
+void jxlo_adaptive_lf_smoothing(const JxloFrameParams* p, const float* const in[3], int w, int h,
+                                float* const out[3]);
+/* K3sigma SigmaSource::new (features/epf.rs:35-87): inv-sigma image, stride = xsize_blocks */
+void jxlo_sigma_map(const JxloFrameParams* p, const int32_t* raw_quant, const uint8_t* epf_map,
+                    float* inv_sigma);
+/* K1 dequant + LLF + IDCT for one group (frame/group.rs:85-253, :454-613).
+ * coeffs: 3 * group_dim^2 i32 (X,Y,B), varblocks back to back.
+ * maps are whole-frame, stride xsize_blocks (cmap stride = ceil(xsize_blocks/8)).
+ * lf: 3 planes, stride xsize_blocks.  tables: 17 pointers.
+ * planes: 3 output planes, stride `stride` floats, >= xsize_blocks*8 wide.  */
+void jxlo_decode_group(const JxloFrameParams* p, int group, const int32_t* coeffs,
+                       const uint8_t* transform_map, const int32_t* raw_quant,
+                       const int8_t* ytox_map, const int8_t* ytob_map,
+                       const float* const lf[3], const float* const tables[17],
+                       float* const planes[3], size_t stride);
+/* stages on whole-frame planes with the pipeline's per-stage mirror semantics
+ * (render/simple_pipeline/run_stage.rs:129-146, util/mirror.rs:8-19). */
+void jxlo_gaborish(const float* in, int w, int h, size_t stride, float w1, float w2, float* out);
+void jxlo_epf(int stage /*0,1,2*/, const JxloFrameParams* p, const float* const in[3], int w,
+              int h, size_t stride, const float* inv_sigma, size_t sigma_stride,
+              float* const out[3]);
+/* same stages restricted to rows [y0, y1) (used by the threaded baseline) */
+void jxlo_gaborish_rows(const float* in, int w, int h, size_t stride, float w1, float w2,
+                        float* out, int y0, int y1);
+void jxlo_epf_rows(int stage, const JxloFrameParams* p, const float* const in[3], int w, int h,
+                   size_t stride, const float* inv_sigma, size_t sigma_stride,
+                   float* const out[3], int y0, int y1);
+
+/* whole chain K0b..K3 on num_threads host threads (the cpu_baseline harness).
+ * lf is smoothed in place when do_lf_smoothing.  planes/tmp: 3 planes each.  */
+void jxlo_vardct_frame(const JxloFrameParams* p, const int32_t* coeffs /* ngroups*3*65536 */,
+                       const uint8_t* transform_map, const int32_t* raw_quant,
+                       const uint8_t* epf_map, const int8_t* ytox_map, const int8_t* ytob_map,
+                       float* const lf[3], const float* const tables[17], float* const planes[3],
+                       float* const tmp[3], size_t stride, int num_threads);
+
+/* ---- Modular inverse transforms (wrapping i32) ---- */
+/* rct.rs:14-157; planes are permuted by swapping contents so that the caller's
+ * pointers keep their meaning (out[perm] = in) */
+void jxlo_rct(int32_t* p0, int32_t* p1, int32_t* p2, size_t n, int op, int perm);
+/* palette.rs:45-199 (num_deltas == 0, predictor Zero); palette is nb_channels rows x
+ * palette_stride; out channel c at out + c*n */
+void jxlo_palette(const int32_t* index, size_t n, const int32_t* palette, int num_colors,
+                  size_t palette_stride, int nb_channels, int bit_depth, int32_t* out);
+int32_t jxlo_palette_value(const int32_t* palette, size_t palette_stride, int64_t index, int c,
+                           int palette_size, int bit_depth);
+/* squeeze.rs:143-194,389-481,576-682 whole-plane (no neighbour tiles) */
+void jxlo_unsqueeze_h(const int32_t* avg, size_t avg_stride, const int32_t* res, size_t res_stride,
+                      int out_w, int h, int32_t* out, size_t out_stride);
+void jxlo_unsqueeze_v(const int32_t* avg, size_t avg_stride, const int32_t* res, size_t res_stride,
+                      int w, int out_h, int32_t* out, size_t out_stride);
+int64_t jxlo_smooth_tendency(int64_t b, int64_t a, int64_t n);
+int32_t jxlo_smooth_tendency_i32(int32_t a, int32_t b, int32_t c); /* SIMD formulation */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JXLO_H_ */

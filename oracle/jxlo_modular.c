@@ -1,0 +1,208 @@
+/*
+ * ORACLE (test infrastructure, see jxlo.h) -- Modular inverse transforms,
+ * whole-plane form (the GPU path does not tile; neighbour-tile borders of
+ * step.rs collapse to the "no neighbour" branches).
+ *
+ * Reference map:
+ *   RCT ............. jxl/src/frame/modular/transforms/rct.rs:14-157
+ *   Palette ......... jxl/src/frame/modular/transforms/palette.rs:24-199
+ *   Squeeze ......... jxl/src/frame/modular/transforms/squeeze.rs:107-194 (tendency, unsqueeze),
+ *                     :389-437 (hsqueeze_scalar), :576-644 (vsqueeze_scalar)
+ * All arithmetic is wrapping i32 (jxl_simd/src/scalar.rs Wrapping<i32>); the
+ * scalar squeeze definition uses i64 intermediates and truncating division.
+ */
+#include <stdlib.h>
+#include <string.h>
+
+#include "jxlo.h"
+
+static inline int32_t wadd(int32_t a, int32_t b) { return (int32_t)((uint32_t)a + (uint32_t)b); }
+static inline int32_t wsub(int32_t a, int32_t b) { return (int32_t)((uint32_t)a - (uint32_t)b); }
+static inline int32_t sar(int32_t a, int s) { return a >> s; } /* arithmetic on gcc/clang */
+
+void jxlo_rct(int32_t* p0, int32_t* p1, int32_t* p2, size_t n, int op, int perm) {
+  for (size_t i = 0; i < n; i++) {
+    int32_t v0 = p0[i], v1 = p1[i], v2 = p2[i];
+    int32_t w0 = v0, w1 = v1, w2 = v2;
+    switch (op) { /* rct.rs:22-45 */
+      case 0: break;
+      case 1: w2 = wadd(v2, v0); break;
+      case 2: w1 = wadd(v1, v0); break;
+      case 3: w1 = wadd(v1, v0); w2 = wadd(v2, v0); break;
+      case 4: w1 = wadd(v1, sar(wadd(v0, v2), 1)); break;
+      case 5: {
+        int32_t t2 = wadd(v0, v2);
+        w1 = wadd(v1, sar(wadd(v0, t2), 1));
+        w2 = t2;
+        break;
+      }
+      case 6: {
+        int32_t y = v0, co = v1, cg = v2;
+        y = wsub(y, sar(cg, 1));
+        int32_t g = wadd(cg, y);
+        y = wsub(y, sar(co, 1));
+        int32_t r = wadd(y, co);
+        w0 = r; w1 = g; w2 = y;
+        break;
+      }
+    }
+    /* permutation rct.rs:132-156: buffer contents after the pointer swaps */
+    int32_t o0, o1, o2;
+    switch (perm) {
+      default:
+      case 0: o0 = w0; o1 = w1; o2 = w2; break;             /* Rgb */
+      case 1: o1 = w0; o2 = w1; o0 = w2; break;             /* Gbr: out[1,2,0] = in[0,1,2] */
+      case 2: o2 = w0; o0 = w1; o1 = w2; break;             /* Brg: out[2,0,1] = in[0,1,2] */
+      case 3: o0 = w0; o2 = w1; o1 = w2; break;             /* Rbg */
+      case 4: o1 = w0; o0 = w1; o2 = w2; break;             /* Grb */
+      case 5: o2 = w0; o1 = w1; o0 = w2; break;             /* Bgr */
+    }
+    p0[i] = o0; p1[i] = o1; p2[i] = o2;
+  }
+}
+
+/* ---- palette ---- */
+static const int16_t kDelta[72][3] = { /* palette.rs:46-119 (spec data) */
+#include "delta_palette.inc"
+};
+static int32_t delta_entry(int idx, int c) { return kDelta[idx][c]; }
+
+int32_t jxlo_palette_value(const int32_t* palette, size_t palette_stride, int64_t index, int c,
+                           int palette_size, int bit_depth) { /* palette.rs:39-199 */
+  if (index < 0) {
+    if (c >= 3) return 0;
+    uint64_t i = (uint64_t)(-(index + 1));
+    i %= 1 + 2 * (72 - 1);
+    static const int mult[2] = {-1, 1};
+    int32_t result = delta_entry((int)((i + 1) >> 1), c) * mult[i & 1];
+    if (bit_depth > 8) result *= 1 << (bit_depth - 8);
+    return result;
+  }
+  uint64_t i = (uint64_t)index;
+  const uint64_t ps = (uint64_t)palette_size;
+  if (ps <= i && i < ps + 64) {
+    if (c >= 3) return 0;
+    i -= ps;
+    i >>= c * 2;
+    int sh = bit_depth - 3;
+    if (sh < 0) sh = 0;
+    return (int32_t)(((i % 4) * (uint64_t)((1 << bit_depth) - 1)) >> 2) + (1 << sh);
+  } else if (ps + 64 <= i) {
+    if (c >= 3) return 0;
+    i -= ps + 64;
+    if (c == 1) i /= 5;
+    if (c == 2) i /= 25;
+    return (int32_t)(((i % 5) * (uint64_t)((1 << bit_depth) - 1)) >> 2);
+  }
+  return palette[(size_t)c * palette_stride + i];
+}
+
+void jxlo_palette(const int32_t* index, size_t n, const int32_t* palette, int num_colors,
+                  size_t palette_stride, int nb_channels, int bit_depth, int32_t* out) {
+  for (int c = 0; c < nb_channels; c++)
+    for (size_t i = 0; i < n; i++)
+      out[(size_t)c * n + i] =
+          jxlo_palette_value(palette, palette_stride, (int64_t)index[i], c, num_colors, bit_depth);
+}
+
+/* ---- squeeze ---- */
+int64_t jxlo_smooth_tendency(int64_t b, int64_t a, int64_t n) { /* squeeze.rs:143-168 */
+  int64_t diff = 0;
+  if (b >= a && a >= n) {
+    diff = (4 * b - 3 * n - a + 6) / 12;
+    if (diff - (diff & 1) > 2 * (b - a)) diff = 2 * (b - a) + 1;
+    if (diff + (diff & 1) > 2 * (a - n)) diff = 2 * (a - n);
+  } else if (b <= a && a <= n) {
+    diff = (4 * b - 3 * n - a - 6) / 12;
+    if (diff + (diff & 1) < 2 * (b - a)) diff = 2 * (b - a) - 1;
+    if (diff - (diff & 1) < 2 * (a - n)) diff = 2 * (a - n);
+  }
+  return diff;
+}
+
+/* 32-bit formulation used by the SIMD back-ends (squeeze.rs:107-141); the
+ * reference requires it to equal the scalar definition wherever nothing overflows. */
+int32_t jxlo_smooth_tendency_i32(int32_t a, int32_t b, int32_t c) {
+  const int32_t a_b = wsub(a, b), b_c = wsub(b, c), a_c = wsub(a, c);
+  const int32_t abs_a_b = a_b < 0 ? wsub(0, a_b) : a_b;
+  const int32_t abs_b_c = b_c < 0 ? wsub(0, b_c) : b_c;
+  const int32_t abs_a_c = a_c < 0 ? wsub(0, a_c) : a_c;
+  const int non_monotonic = (a_b ^ b_c) < 0;
+  int skip = (a_b != 0) && non_monotonic;   /* a_b.eq_zero().andnot(non_monotonic) */
+  skip = (b_c != 0) && skip;                /* b_c.eq_zero().andnot(skip) */
+  const int32_t abs_a_b_3 = (int32_t)(((int64_t)abs_a_b * 0x55555556LL) >> 32);
+  int32_t x = sar(wadd(wadd(2, abs_a_c), abs_a_b_3), 2);
+  const int32_t abs_a_b_2_add_x = wadd((int32_t)((uint32_t)abs_a_b << 1), x & 1);
+  if (x > abs_a_b_2_add_x) x = wadd((int32_t)((uint32_t)abs_a_b << 1), 1);
+  const int32_t abs_b_c_2 = (int32_t)((uint32_t)abs_b_c << 1);
+  if (wadd(x, x & 1) > abs_b_c_2) x = abs_b_c_2;
+  if (skip) x = 0; /* maskz */
+  return a_c < 0 ? wsub(0, x) : x;
+}
+
+static inline void unsqueeze(int32_t avg, int32_t res, int32_t next_avg, int32_t prev, int32_t* a,
+                             int32_t* b) { /* squeeze.rs:187-194 */
+  const int64_t tendency = jxlo_smooth_tendency((int64_t)prev, (int64_t)avg, (int64_t)next_avg);
+  const int64_t diff = (int64_t)res + tendency;
+  const int64_t aa = (int64_t)avg + (diff / 2);
+  const int64_t bb = aa - diff;
+  *a = (int32_t)aa;
+  *b = (int32_t)bb;
+}
+
+void jxlo_unsqueeze_h(const int32_t* avg, size_t avg_stride, const int32_t* res, size_t res_stride,
+                      int out_w, int h, int32_t* out, size_t out_stride) {
+  const int w = out_w / 2; /* residual width; avg width = out_w - w */
+  if (out_w == 0 || h == 0) return;
+  if (w == 0) { /* do_hsqueeze_step :468-476 */
+    for (int y = 0; y < h; y++) out[(size_t)y * out_stride] = avg[(size_t)y * avg_stride];
+    return;
+  }
+  const int has_tail = out_w & 1;
+  for (int y = 0; y < h; y++) { /* hsqueeze_scalar :408-437, out_prev/in_next_avg = None */
+    const int32_t* ar = avg + (size_t)y * avg_stride;
+    const int32_t* rr = res + (size_t)y * res_stride;
+    int32_t* o = out + (size_t)y * out_stride;
+    int32_t prev_b = ar[0];
+    const int x_end = has_tail ? w : w - 1;
+    for (int x = 0; x < x_end; x++) {
+      int32_t a, b;
+      unsqueeze(ar[x], rr[x], ar[x + 1], prev_b, &a, &b);
+      o[2 * x] = a;
+      o[2 * x + 1] = b;
+      prev_b = b;
+    }
+    if (!has_tail) {
+      int32_t a, b;
+      unsqueeze(ar[w - 1], rr[w - 1], ar[w - 1], prev_b, &a, &b);
+      o[2 * w - 2] = a;
+      o[2 * w - 1] = b;
+    } else {
+      o[2 * w] = ar[w];
+    }
+  }
+}
+
+void jxlo_unsqueeze_v(const int32_t* avg, size_t avg_stride, const int32_t* res, size_t res_stride,
+                      int w, int out_h, int32_t* out, size_t out_stride) {
+  const int h = out_h / 2;
+  if (out_h == 0 || w == 0) return;
+  if (h == 0) { /* do_vsqueeze_step :672-675 */
+    memcpy(out, avg, sizeof(int32_t) * w);
+    return;
+  }
+  const int has_tail = out_h & 1;
+  for (int y = 0; y < h; y++) { /* vsqueeze_scalar :591-640 */
+    const int32_t* ar = avg + (size_t)y * avg_stride;
+    const int32_t* rr = res + (size_t)y * res_stride;
+    const int32_t* an = (has_tail || y < h - 1) ? avg + (size_t)(y + 1) * avg_stride : ar;
+    const int32_t* pb = y == 0 ? ar : out + (size_t)(2 * y - 1) * out_stride;
+    for (int x = 0; x < w; x++) {
+      int32_t a, b;
+      unsqueeze(ar[x], rr[x], an[x], pb[x], &a, &b);
+      out[(size_t)(2 * y) * out_stride + x] = a;
+      out[(size_t)(2 * y + 1) * out_stride + x] = b;
+    }
+  }
+  if (has_tail) memcpy(out + (size_t)(2 * h) * out_stride, avg + (size_t)h * avg_stride, sizeof(int32_t) * w);
+}

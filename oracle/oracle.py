@@ -1,0 +1,315 @@
+"""ctypes binding of the CPU oracle (oracle/jxlo.h).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  The product package (jxl_rs_amd) never imports it.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+NUM_TRANSFORMS = 27
+NUM_QUANT_TABLES = 17
+
+
+class FrameParams(C.Structure):
+    """Mirror of JxloFrameParams (jxlo.h)."""
+    _fields_ = [
+        ("xsize", C.c_int32), ("ysize", C.c_int32),
+        ("xsize_blocks", C.c_int32), ("ysize_blocks", C.c_int32),
+        ("group_dim", C.c_int32),
+        ("global_scale", C.c_uint32), ("quant_lf", C.c_uint32),
+        ("lf_quant_factors", C.c_float * 3),
+        ("quant_biases", C.c_float * 4),
+        ("x_qm_scale", C.c_uint32), ("b_qm_scale", C.c_uint32),
+        ("color_factor", C.c_uint32),
+        ("base_correlation_x", C.c_float), ("base_correlation_b", C.c_float),
+        ("ytox_lf", C.c_int32), ("ytob_lf", C.c_int32),
+        ("gab", C.c_int32),
+        ("gab_w1", C.c_float * 3), ("gab_w2", C.c_float * 3),
+        ("epf_iters", C.c_int32),
+        ("epf_sharp_lut", C.c_float * 8),
+        ("epf_channel_scale", C.c_float * 3),
+        ("epf_quant_mul", C.c_float), ("epf_pass0_sigma_scale", C.c_float),
+        ("epf_pass2_sigma_scale", C.c_float), ("epf_border_sad_mul", C.c_float),
+        ("do_lf_smoothing", C.c_int32),
+    ]
+
+
+def build(force=False):
+    """Compile both oracle builds in place (make is incremental)."""
+    args = ["make", "-C", _HERE, "-s"]
+    if force:
+        args.append("-B")
+    subprocess.run(args, check=True)
+
+
+def _ptr(a, ty):
+    return a.ctypes.data_as(C.POINTER(ty))
+
+
+def _f32(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a
+
+
+class Oracle:
+    def __init__(self, fused=True):
+        name = "libjxlo_fused.so" if fused else "libjxlo_unfused.so"
+        path = os.path.join(_HERE, name)
+        if not os.path.exists(path):
+            build()
+        self.lib = L = C.CDLL(path)
+        self.fused = fused
+        assert bool(L.jxlo_is_fused()) == fused
+        fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int32)
+        dp = C.POINTER(C.c_double)
+        L.jxlo_idct1d.argtypes = [fp, C.c_int, C.c_int]
+        L.jxlo_rdct1d.argtypes = [fp, C.c_int, C.c_int]
+        L.jxlo_idct2d.argtypes = [fp, C.c_int, C.c_int]
+        L.jxlo_rdct2d.argtypes = [fp, C.c_int, C.c_int, fp]
+        L.jxlo_transform_to_pixels.argtypes = [C.c_int, fp, fp]
+        L.jxlo_slow_idct2d.argtypes = [dp, C.c_int, C.c_int, dp]
+        L.jxlo_slow_rdct2d.argtypes = [dp, C.c_int, C.c_int, dp]
+        L.jxlo_slow_idct1d.argtypes = [dp, C.c_int, dp]
+        L.jxlo_slow_dct1d.argtypes = [dp, C.c_int, dp]
+        L.jxlo_idct_weights.restype = fp
+        L.jxlo_rdct_scales.restype = fp
+        L.jxlo_library_dequant_table.argtypes = [C.c_int, fp]
+        L.jxlo_natural_coeff_order.argtypes = [C.c_int, C.POINTER(C.c_uint32)]
+        L.jxlo_default_frame_params.argtypes = [C.POINTER(FrameParams), C.c_int, C.c_int]
+        L.jxlo_dequant_lf.argtypes = [C.POINTER(FrameParams), ip, ip, ip, C.c_float, C.c_size_t, fp, fp, fp]
+        pf3 = C.POINTER(fp)
+        L.jxlo_adaptive_lf_smoothing.argtypes = [C.POINTER(FrameParams), pf3, C.c_int, C.c_int, pf3]
+        L.jxlo_sigma_map.argtypes = [C.POINTER(FrameParams), ip, C.POINTER(C.c_uint8), fp]
+        L.jxlo_decode_group.argtypes = [C.POINTER(FrameParams), C.c_int, ip, C.POINTER(C.c_uint8), ip,
+                                        C.POINTER(C.c_int8), C.POINTER(C.c_int8), pf3, pf3, pf3, C.c_size_t]
+        L.jxlo_gaborish.argtypes = [fp, C.c_int, C.c_int, C.c_size_t, C.c_float, C.c_float, fp]
+        L.jxlo_epf.argtypes = [C.c_int, C.POINTER(FrameParams), pf3, C.c_int, C.c_int, C.c_size_t, fp,
+                               C.c_size_t, pf3]
+        L.jxlo_vardct_frame.argtypes = [C.POINTER(FrameParams), ip, C.POINTER(C.c_uint8), ip,
+                                        C.POINTER(C.c_uint8), C.POINTER(C.c_int8), C.POINTER(C.c_int8),
+                                        pf3, pf3, pf3, pf3, C.c_size_t, C.c_int]
+        L.jxlo_rct.argtypes = [ip, ip, ip, C.c_size_t, C.c_int, C.c_int]
+        L.jxlo_palette.argtypes = [ip, C.c_size_t, ip, C.c_int, C.c_size_t, C.c_int, C.c_int, ip]
+        L.jxlo_unsqueeze_h.argtypes = [ip, C.c_size_t, ip, C.c_size_t, C.c_int, C.c_int, ip, C.c_size_t]
+        L.jxlo_unsqueeze_v.argtypes = [ip, C.c_size_t, ip, C.c_size_t, C.c_int, C.c_int, ip, C.c_size_t]
+        L.jxlo_smooth_tendency.argtypes = [C.c_int64] * 3
+        L.jxlo_smooth_tendency.restype = C.c_int64
+        L.jxlo_smooth_tendency_i32.argtypes = [C.c_int32] * 3
+        L.jxlo_smooth_tendency_i32.restype = C.c_int32
+        self.covered_x = [L.jxlo_covered_blocks_x(t) for t in range(NUM_TRANSFORMS)]
+        self.covered_y = [L.jxlo_covered_blocks_y(t) for t in range(NUM_TRANSFORMS)]
+        self.table_for_type = [L.jxlo_quant_table_for_type(t) for t in range(NUM_TRANSFORMS)]
+        self.table_size = [L.jxlo_quant_table_size(t) for t in range(NUM_QUANT_TABLES)]
+        self._tables = None
+
+    # ---- transforms ----
+    def idct1d(self, x):
+        a = _f32(x).copy()
+        self.lib.jxlo_idct1d(_ptr(a, C.c_float), a.size, 1)
+        return a
+
+    def rdct1d(self, x):
+        a = _f32(x).copy()
+        self.lib.jxlo_rdct1d(_ptr(a, C.c_float), a.size, 1)
+        return a
+
+    def idct2d(self, coeffs, rows, cols):
+        a = _f32(coeffs).reshape(-1).copy()
+        assert a.size == rows * cols
+        self.lib.jxlo_idct2d(_ptr(a, C.c_float), rows, cols)
+        return a.reshape(rows, cols)
+
+    def rdct2d(self, lf):
+        lf = _f32(lf)
+        rows, cols = lf.shape
+        mn, mx = min(rows, cols), max(rows, cols)
+        out = np.zeros(mn * 8 * mx + mx, dtype=np.float32)
+        out = np.zeros((mn, 8 * mx), dtype=np.float32)
+        tmp = lf.copy()
+        self.lib.jxlo_rdct2d(_ptr(tmp, C.c_float), rows, cols, _ptr(out, C.c_float))
+        return out[:, :mx].copy()
+
+    def transform_to_pixels(self, ttype, lf, coeffs):
+        cx, cy = self.covered_x[ttype], self.covered_y[ttype]
+        lfb = _f32(lf).reshape(-1).copy()
+        assert lfb.size == cx * cy
+        buf = _f32(coeffs).reshape(-1).copy()
+        assert buf.size == cx * cy * 64
+        self.lib.jxlo_transform_to_pixels(ttype, _ptr(lfb, C.c_float), _ptr(buf, C.c_float))
+        return buf.reshape(cy * 8, cx * 8)
+
+    def slow_idct2d(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        rows, cols = x.shape
+        out = np.zeros((rows, cols), dtype=np.float64)
+        self.lib.jxlo_slow_idct2d(_ptr(x, C.c_double), rows, cols, _ptr(out, C.c_double))
+        return out
+
+    def slow_rdct2d(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        rows, cols = x.shape
+        out = np.zeros((min(rows, cols), max(rows, cols)), dtype=np.float64)
+        self.lib.jxlo_slow_rdct2d(_ptr(x, C.c_double), rows, cols, _ptr(out, C.c_double))
+        return out
+
+    def slow_idct1d(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        out = np.zeros_like(x)
+        self.lib.jxlo_slow_idct1d(_ptr(x, C.c_double), x.size, _ptr(out, C.c_double))
+        return out
+
+    def slow_dct1d(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        out = np.zeros_like(x)
+        self.lib.jxlo_slow_dct1d(_ptr(x, C.c_double), x.size, _ptr(out, C.c_double))
+        return out
+
+    def idct_weights(self, n):
+        p = self.lib.jxlo_idct_weights(n)
+        return np.ctypeslib.as_array(p, shape=(n // 2,)).copy()
+
+    def rdct_scales(self, n):
+        p = self.lib.jxlo_rdct_scales(n)
+        return np.ctypeslib.as_array(p, shape=(n,)).copy()
+
+    # ---- tables ----
+    def library_dequant_table(self, t):
+        out = np.zeros(3 * self.table_size[t], dtype=np.float32)
+        rc = self.lib.jxlo_library_dequant_table(t, _ptr(out, C.c_float))
+        assert rc == 0
+        return out
+
+    def library_dequant_tables(self):
+        if self._tables is None:
+            self._tables = [self.library_dequant_table(t) for t in range(NUM_QUANT_TABLES)]
+        return self._tables
+
+    def natural_coeff_order(self, ttype):
+        n = self.covered_x[ttype] * self.covered_y[ttype] * 64
+        out = np.zeros(n, dtype=np.uint32)
+        self.lib.jxlo_natural_coeff_order(ttype, _ptr(out, C.c_uint32))
+        return out
+
+    # ---- frame level ----
+    def default_params(self, xsize, ysize):
+        p = FrameParams()
+        self.lib.jxlo_default_frame_params(C.byref(p), xsize, ysize)
+        return p
+
+    @staticmethod
+    def _p3(arrs, ty=C.c_float):
+        T = C.POINTER(ty) * len(arrs)
+        return T(*[_ptr(a, ty) for a in arrs])
+
+    def dequant_lf(self, p, qy, qx, qb, mul=1.0):
+        qy, qx, qb = [np.ascontiguousarray(a, dtype=np.int32) for a in (qy, qx, qb)]
+        out = [np.zeros(qy.shape, dtype=np.float32) for _ in range(3)]
+        self.lib.jxlo_dequant_lf(C.byref(p), _ptr(qy, C.c_int32), _ptr(qx, C.c_int32), _ptr(qb, C.c_int32),
+                                 C.c_float(mul), qy.size, *[_ptr(o, C.c_float) for o in out])
+        return out  # X, Y, B
+
+    def adaptive_lf_smoothing(self, p, lf):
+        lf = [_f32(a) for a in lf]
+        h, w = lf[0].shape
+        out = [np.zeros((h, w), dtype=np.float32) for _ in range(3)]
+        self.lib.jxlo_adaptive_lf_smoothing(C.byref(p), self._p3(lf), w, h, self._p3(out))
+        return out
+
+    def sigma_map(self, p, raw_quant, epf_map):
+        rq = np.ascontiguousarray(raw_quant, dtype=np.int32)
+        em = np.ascontiguousarray(epf_map, dtype=np.uint8)
+        out = np.zeros(rq.shape, dtype=np.float32)
+        self.lib.jxlo_sigma_map(C.byref(p), _ptr(rq, C.c_int32), _ptr(em, C.c_uint8), _ptr(out, C.c_float))
+        return out
+
+    def decode_group(self, p, group, coeffs, transform_map, raw_quant, ytox, ytob, lf, tables, planes):
+        """planes: list of 3 float32 2-D arrays (modified in place), contiguous rows."""
+        stride = planes[0].strides[0] // 4
+        tm = np.ascontiguousarray(transform_map, dtype=np.uint8)
+        rq = np.ascontiguousarray(raw_quant, dtype=np.int32)
+        yx = np.ascontiguousarray(ytox, dtype=np.int8)
+        yb = np.ascontiguousarray(ytob, dtype=np.int8)
+        co = np.ascontiguousarray(coeffs, dtype=np.int32)
+        lf = [_f32(a) for a in lf]
+        self.lib.jxlo_decode_group(C.byref(p), group, _ptr(co, C.c_int32), _ptr(tm, C.c_uint8),
+                                   _ptr(rq, C.c_int32), _ptr(yx, C.c_int8), _ptr(yb, C.c_int8),
+                                   self._p3(lf), self._p3(tables), self._p3(planes), stride)
+
+    def gaborish(self, plane, w1, w2, w=None, h=None):
+        plane = _f32(plane)
+        H, S = plane.shape
+        w = S if w is None else w
+        h = H if h is None else h
+        out = np.zeros_like(plane)
+        self.lib.jxlo_gaborish(_ptr(plane, C.c_float), w, h, S, C.c_float(w1), C.c_float(w2),
+                               _ptr(out, C.c_float))
+        return out
+
+    def epf(self, stage, p, planes, inv_sigma, w=None, h=None):
+        planes = [_f32(a) for a in planes]
+        H, S = planes[0].shape
+        w = S if w is None else w
+        h = H if h is None else h
+        sig = _f32(inv_sigma)
+        out = [np.zeros_like(planes[0]) for _ in range(3)]
+        self.lib.jxlo_epf(stage, C.byref(p), self._p3(planes), w, h, S, _ptr(sig, C.c_float),
+                          sig.shape[1], self._p3(out))
+        return out
+
+    def vardct_frame(self, p, coeffs, transform_map, raw_quant, epf_map, ytox, ytob, lf, tables,
+                     num_threads=1):
+        """Runs the whole chain; returns 3 planes (padded to whole blocks)."""
+        bw, bh = p.xsize_blocks, p.ysize_blocks
+        stride = bw * 8
+        planes = [np.zeros((bh * 8, stride), dtype=np.float32) for _ in range(3)]
+        tmp = [np.zeros((bh * 8, stride), dtype=np.float32) for _ in range(3)]
+        lf = [_f32(a).copy() for a in lf]
+        tm = np.ascontiguousarray(transform_map, dtype=np.uint8)
+        rq = np.ascontiguousarray(raw_quant, dtype=np.int32)
+        em = np.ascontiguousarray(epf_map, dtype=np.uint8)
+        yx = np.ascontiguousarray(ytox, dtype=np.int8)
+        yb = np.ascontiguousarray(ytob, dtype=np.int8)
+        co = np.ascontiguousarray(coeffs, dtype=np.int32)
+        self.lib.jxlo_vardct_frame(C.byref(p), _ptr(co, C.c_int32), _ptr(tm, C.c_uint8), _ptr(rq, C.c_int32),
+                                   _ptr(em, C.c_uint8), _ptr(yx, C.c_int8), _ptr(yb, C.c_int8),
+                                   self._p3(lf), self._p3(tables), self._p3(planes), self._p3(tmp),
+                                   stride, num_threads)
+        return planes, lf
+
+    # ---- modular ----
+    def rct(self, planes, op, perm):
+        ps = [np.ascontiguousarray(a, dtype=np.int32).copy() for a in planes]
+        self.lib.jxlo_rct(_ptr(ps[0], C.c_int32), _ptr(ps[1], C.c_int32), _ptr(ps[2], C.c_int32),
+                          ps[0].size, op, perm)
+        return ps
+
+    def palette(self, index, palette, num_colors, nb_channels, bit_depth):
+        idx = np.ascontiguousarray(index, dtype=np.int32)
+        pal = np.ascontiguousarray(palette, dtype=np.int32)
+        out = np.zeros((nb_channels,) + idx.shape, dtype=np.int32)
+        self.lib.jxlo_palette(_ptr(idx, C.c_int32), idx.size, _ptr(pal, C.c_int32), num_colors,
+                              pal.shape[1], nb_channels, bit_depth, _ptr(out, C.c_int32))
+        return out
+
+    def unsqueeze_h(self, avg, res, out_w):
+        avg = np.ascontiguousarray(avg, dtype=np.int32)
+        res = np.ascontiguousarray(res, dtype=np.int32)
+        h = avg.shape[0]
+        out = np.zeros((h, out_w), dtype=np.int32)
+        self.lib.jxlo_unsqueeze_h(_ptr(avg, C.c_int32), avg.shape[1], _ptr(res, C.c_int32),
+                                  max(res.shape[1], 1), out_w, h, _ptr(out, C.c_int32), out_w)
+        return out
+
+    def unsqueeze_v(self, avg, res, out_h):
+        avg = np.ascontiguousarray(avg, dtype=np.int32)
+        res = np.ascontiguousarray(res, dtype=np.int32)
+        w = avg.shape[1]
+        out = np.zeros((out_h, w), dtype=np.int32)
+        self.lib.jxlo_unsqueeze_v(_ptr(avg, C.c_int32), w, _ptr(res, C.c_int32), w, w, out_h,
+                                  _ptr(out, C.c_int32), w)
+        return out

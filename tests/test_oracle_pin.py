@@ -1,0 +1,149 @@
+"""Pins the CPU oracle against every known-answer vector the reference's own tests hold
+for the hot path (tests/golden/reference_kat.json).
+
+Mirrors jxl_transforms/src/tests.rs (IDCT / reinterpreting DCT vs f64 matrix definitions
+with the reference's per-shape tolerances), frame/quant_weights.rs:1221-2139,
+frame/coeff_order.rs:154-178, render/stages/gaborish.rs:132-145 and
+modular/transforms/squeeze.rs:107-168 (SIMD tendency == scalar tendency).
+"""
+import numpy as np
+import pytest
+
+
+def check_close(a, b, tol):
+    """tests.rs:175-183: abs OR rel error below tol."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    ab = np.abs(a - b)
+    rel = ab / np.maximum(np.maximum(np.abs(a), np.abs(b)), 1e-300)
+    bad = ~((ab < tol) | (rel < tol))
+    assert not bad.any(), f"max abs {ab.max()} (tol {tol}), {bad.sum()} bad"
+
+
+# The reference's tolerances are calibrated on ONE draw (ChaCha12Rng::seed_from_u64(0),
+# tests.rs:246-255), which cannot be reproduced here without the rand crates; on other
+# uniform(-1,1) draws f32 rounding noise of a *correct* implementation reaches ~3x those
+# figures for a few shapes (measured over 20 seeds for both oracle builds).  A layout or
+# constant error shows up at >= 1e-2, i.e. > 1000x.  We therefore accept 4x.
+SLACK = 4.0
+
+
+def rnd(shape, seed):
+    return np.random.default_rng(seed).uniform(-1.0, 1.0, size=shape)
+
+
+def test_idct_weight_tables_match_reference_constants(oracle, kat):
+    for n in (64, 128, 256):
+        ref = np.array(kat["idct_weights"][str(n)], dtype=np.float32)
+        assert np.array_equal(oracle.idct_weights(n), ref)
+    have = set()
+    for n in (4, 8, 16, 32):
+        have |= set(oracle.idct_weights(n).tolist())
+    want = set(np.array(kat["idct_weights"]["idct32_muls_in_order"], dtype=np.float32).tolist())
+    assert have == want
+
+
+def test_rdct_scale_tables_match_reference_constants(oracle, kat):
+    for n in (2, 4, 8, 16, 32):
+        ref = np.array(kat["rdct_scales"][str(n)], dtype=np.float32)
+        assert np.array_equal(oracle.rdct_scales(n), ref), n
+
+
+def test_idct1d_vs_f64_definition(oracle_any, kat):
+    for n, tol in kat["tolerances"]["idct1d"]:
+        x = rnd(n, 100 + n)
+        got = oracle_any.idct1d(x.astype(np.float32))
+        want = oracle_any.slow_idct1d(x.astype(np.float32).astype(np.float64))
+        check_close(got, want, SLACK * tol)
+
+
+def test_rdct1d_vs_f64_definition(oracle_any):
+    # tests.rs:185-244
+    for n, tol in ((2, 1e-6), (4, 1e-6), (8, 1e-6), (16, 5e-6), (32, 5e-6)):
+        x = rnd(n, 200 + n).astype(np.float32)
+        got = oracle_any.rdct1d(x)
+        slow = oracle_any.slow_dct1d(x.astype(np.float64))
+        i = np.arange(n)
+        scales = np.cos(i / (16 * n) * np.pi) * np.cos(i / (8 * n) * np.pi) * np.cos(i / (4 * n) * np.pi) * n
+        check_close(got, slow / scales, tol)
+
+
+def test_idct2d_all_shapes_vs_f64_definition(oracle_any, kat):
+    shapes = kat["tolerances"]["idct2d"]
+    assert len(shapes) == 22
+    for rows, cols, tol in shapes:
+        x = rnd((rows, cols), 1000 * rows + cols).astype(np.float32)
+        got = oracle_any.idct2d(x.reshape(-1), rows, cols)
+        want = oracle_any.slow_idct2d(x.astype(np.float64))
+        check_close(got, want, SLACK * tol)
+
+
+def test_rdct2d_all_shapes_vs_f64_definition(oracle_any, kat):
+    shapes = kat["tolerances"]["rdct2d"]
+    assert len(shapes) == 17
+    for rows, cols, tol in shapes:
+        x = rnd((rows, cols), 7000 * rows + cols).astype(np.float32)
+        got = oracle_any.rdct2d(x)
+        want = oracle_any.slow_rdct2d(x.astype(np.float64))
+        assert got.shape == want.shape == (min(rows, cols), max(rows, cols))
+        check_close(got, want, SLACK * tol)
+
+
+def test_idct2d_layout_is_transpose_detecting(oracle):
+    # a single horizontal-frequency coefficient must produce a pattern varying along x only
+    for rows, cols in ((8, 8), (16, 8), (8, 16), (32, 32), (64, 32)):
+        c = np.zeros(rows * cols, dtype=np.float32)
+        # horizontal frequency u=1, vertical v=0
+        if rows < cols:
+            c[0 * cols + 1] = 1.0
+        else:
+            c[1 * rows + 0] = 1.0
+        px = oracle.idct2d(c, rows, cols)
+        assert np.allclose(px, px[0:1, :], atol=1e-6), (rows, cols)
+        assert px[0, 0] > 0 > px[0, -1]
+
+
+def test_default_dequant_tables_vs_libjxl_samples(oracle, kat):
+    target = kat["dequant_default_samples"]
+    idx = 0
+    for t in range(27):
+        tab = oracle.table_for_type[t]
+        size = oracle.table_size[tab]
+        table = oracle.library_dequant_table(tab)
+        for c in range(3):
+            for j in range(0, size, size // 10):
+                assert abs(table[c * size + j] - target[idx]) < 1e-5, (t, c, j)
+                idx += 1
+    assert idx == len(target)
+
+
+def test_dequant_table_sizes(oracle):
+    assert sum(oracle.table_size) == 2056 * 64  # quant_weights.rs:1135
+
+
+def test_natural_coeff_order_goldens(oracle, kat):
+    assert oracle.natural_coeff_order(0).tolist() == kat["coeff_orders"]["COEFF_ORDER_1X1"]
+    assert oracle.natural_coeff_order(7).tolist() == kat["coeff_orders"]["COEFF_ORDER_2X1"]
+    for t in range(27):
+        o = oracle.natural_coeff_order(t)
+        assert sorted(o.tolist()) == list(range(o.size))  # a permutation
+        cx, cy = oracle.covered_x[t], oracle.covered_y[t]
+        # the first cx*cy entries are the LLF corner: min(cx,cy) rows x max cols, stride 8*max
+        mx, mn = max(cx, cy), min(cx, cy)
+        llf = sorted(o[: cx * cy].tolist())
+        assert llf == sorted(y * 8 * mx + x for y in range(mn) for x in range(mx))
+
+
+def test_gaborish_checkerboard(oracle_any, kat):
+    g = kat["gaborish_checkerboard"]
+    out = oracle_any.gaborish(np.array(g["input"], dtype=np.float32), g["w1"], g["w2"])
+    assert np.abs(out - np.array(g["output"])).max() < g["tol"]
+
+
+def test_squeeze_tendency_simd_form_equals_scalar_definition(oracle):
+    rng = np.random.default_rng(5)
+    L = oracle.lib
+    for scale in (4, 300, 70000, 1 << 24):
+        v = rng.integers(-scale, scale + 1, size=(20000, 3))
+        for a, b, c in v:
+            assert L.jxlo_smooth_tendency_i32(int(a), int(b), int(c)) == L.jxlo_smooth_tendency(int(a), int(b), int(c))
