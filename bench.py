@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""bench.py -- megapixels/s of the JPEG XL VarDCT reconstruction hot path on MI355X.
+
+A "step" is one pass of the whole device chain (K0b LF smoothing, K3 sigma map, K1
+dequant+CfL+LLF+IDCT, Gaborish, EPF1, EPF2) over one synthetic 8192x8192 VarDCT d1 frame
+(BASELINE.json configs[2]) whose inputs -- 805 MB of i32 coefficients, the HfMetadata maps,
+the quantised LF, the dequant tables -- are resident in HBM before the timed region starts.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--size 8192] [--cpu-sample 2048]
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): frames are independent units, so
+every rank reconstructs its own frame of the same shape with no data-path collective
+("weak" scaling; value = all ranks' pixels / max-over-ranks time).  --strong shards ONE
+frame by bands of group rows and all-gathers the finished planes over RCCL (the layout
+north_star describes); it is reported with "scaling": "strong".
+
+Rank 0 prints ONE JSON line: metric/value/... + "roofline" (dominant kernel, HIP-event
+timed on the kernels' own stream) + "cpu_baseline" (the CPU oracle, a C port of the
+reference, all host cores, on a bounded crop of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+# algorithmic (compulsory) HBM bytes per pixel of each kernel, SURVEY.md section 8(d) / DESIGN.md
+ALGO_BYTES_PER_PX = {
+    "k1_vardct_group": 24.3,   # 12 B coeffs in + 12 B planes out + maps/LF
+    "k2_gaborish": 24.0,       # 3 ch x (4 in + 4 out)
+    "k3a_epf0": 24.06, "k3b_epf1": 24.06, "k3c_epf2": 24.06,
+    "k23_fused_filters": 24.06,
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--size", type=int, default=8192)
+    ap.add_argument("--cpu-sample", type=int, default=2048)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--strong", action="store_true")
+    ap.add_argument("--seed", type=int, default=3)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import jxl_rs_amd
+    from jxl_rs_amd import synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    n_gpus = max(world, 1)
+    assert n_gpus == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N"
+
+    size = args.size
+    # ---- synthetic frame (config 3): d1-like type mix DCT8..32, CfL, LF smoothing, Gaborish, EPF x2
+    t0 = time.time()
+    wl = synth.make_vardct(size, size, mix=synth.MIX_D1, seed=args.seed + rank, unique_groups=24,
+                           epf_iters=2, gab=True, lf_smoothing=True)
+    gen_s = time.time() - t0
+    ctx = jxl_rs_amd.Context(local_rank, n_slots=1)
+    params = synth.apply_opts(ctx.default_params(size, size), wl)
+    ctx.frame_begin(params)
+    ctx.set_dequant_tables(wl.tables)
+    ctx.set_lf_quantized(*wl.lf_q)
+    ctx.set_hf_meta(wl.transform_map, wl.raw_quant, wl.epf_map, wl.ytox, wl.ytob)
+    t0 = time.time()
+    for g in range(wl.coeffs.shape[0]):
+        ctx.submit_group(g, wl.coeffs[g])
+    ctx.slot_wait(0)
+    h2d_s = time.time() - t0
+
+    ygroups = wl.ygroups
+    if args.strong and world > 1:
+        per = (ygroups + world - 1) // world
+        row0, row1 = min(rank * per, ygroups), min((rank + 1) * per, ygroups)
+    else:
+        row0, row1 = 0, ygroups
+
+    def step():
+        ctx.frame_run(row0, row1)
+
+    def gather():
+        if not (args.strong and world > 1):
+            return
+        # RCCL all-gather of the finished band (planes are device-resident; torch only wraps the
+        # pointers' contents via a staging tensor)
+        ptrs, stride = ctx.device_planes()
+        y0, y1 = row0 * 256, min(row1 * 256, size)
+        band = torch.empty((3, per * 256, size), dtype=torch.float32, device=f"cuda:{local_rank}")
+        full = torch.empty((world, 3, per * 256, size), dtype=torch.float32, device=f"cuda:{local_rank}")
+        import ctypes as C
+        hip = C.CDLL("libamdhip64.so")
+        for c in range(3):
+            hip.hipMemcpy2D(C.c_void_p(band[c].data_ptr()), C.c_size_t(size * 4),
+                            C.c_void_p(ptrs[c] + y0 * stride * 4), C.c_size_t(stride * 4),
+                            C.c_size_t(size * 4), C.c_size_t(y1 - y0), C.c_int(3))
+        dist.all_gather_into_tensor(full, band)
+
+    for _ in range(args.warmup):
+        step()
+        ctx.sync()
+        gather()
+    ctx.sync()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize() if torch.cuda.is_available() else None
+    t_wall0 = time.perf_counter()
+    ctx.timer_start()
+    for _ in range(args.steps):
+        step()
+        if args.strong and world > 1:
+            ctx.sync()
+            gather()
+    ev_ms = ctx.timer_stop()
+    ctx.sync()
+    torch.cuda.synchronize() if torch.cuda.is_available() else None
+    wall_s = time.perf_counter() - t_wall0
+    if dist is not None:
+        dist.barrier()
+        t = torch.tensor([wall_s], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall_s = float(t.item())
+    ms_per_step = wall_s * 1e3 / args.steps
+    px_per_step = size * size * (1 if (args.strong and world > 1) else n_gpus)
+    value = px_per_step / 1e6 / (ms_per_step / 1e3)
+
+    # ---- per-kernel HIP-event timing (separate steps; not part of the timed region)
+    roofline = None
+    kernels = {}
+    if rank == 0:
+        ctx.kernel_timing_reset()
+        ctx.kernel_timing(True)
+        nprof = max(3, min(args.steps, 10))
+        for _ in range(nprof):
+            ctx.frame_run(0, ygroups)
+        ctx.sync()
+        kt = ctx.kernel_times()
+        ctx.kernel_timing(False)
+        for name, (ms, n) in kt.items():
+            per_step_ms = ms / nprof
+            kernels[name] = {"ms_per_step": round(per_step_ms, 4), "launches_per_step": n // nprof}
+        cand = {k: v for k, v in kernels.items() if k in ALGO_BYTES_PER_PX}
+        if cand:
+            dom = max(cand, key=lambda k: cand[k]["ms_per_step"])
+            algo_bytes = ALGO_BYTES_PER_PX[dom] * size * size
+            ach = algo_bytes / (cand[dom]["ms_per_step"] * 1e-3) / 1e9
+            roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                        "algorithmic_bytes_per_launch": int(algo_bytes),
+                        "avg_launch_ms": cand[dom]["ms_per_step"], "all_kernels_ms_per_step": kernels}
+
+    # ---- CPU baseline: the oracle (C port of the reference path) on all host cores, bounded crop
+    cpu = None
+    if rank == 0 and not args.no_cpu:
+        from oracle.oracle import Oracle
+        o = Oracle(fused=True)
+        cs = min(args.cpu_sample, size)
+        cwl = synth.make_vardct(cs, cs, mix=synth.MIX_D1, seed=args.seed, unique_groups=24, epf_iters=2)
+        p = o.default_params(cs, cs)
+        lf = o.dequant_lf(p, *cwl.lf_q)
+        cores = os.cpu_count() or 1
+        o.vardct_frame(p, cwl.coeffs, cwl.transform_map, cwl.raw_quant, cwl.epf_map, cwl.ytox, cwl.ytob, lf,
+                       cwl.tables, num_threads=cores)  # warm-up
+        reps, t0 = 0, time.perf_counter()
+        while True:
+            o.vardct_frame(p, cwl.coeffs, cwl.transform_map, cwl.raw_quant, cwl.epf_map, cwl.ytox, cwl.ytob, lf,
+                           cwl.tables, num_threads=cores)
+            reps += 1
+            el = time.perf_counter() - t0
+            if el > 10.0 or reps >= 20:
+                break
+        cpu = {"value": round(cs * cs * reps / 1e6 / el, 2), "unit": "MP/s", "cores": cores, "kind": "port",
+               "sample": f"{reps} reps of a {cs}x{cs} crop-sized frame of the same synthetic workload "
+                         f"(same type mix / filters), C oracle -O3 x86-64-v3, pthreads over groups and row bands"}
+
+    if rank == 0:
+        out = {
+            "metric": "megapixels/sec decoded (8K VarDCT d1 reconstruction: dequant+CfL+IDCT+LF smoothing+Gaborish+EPF)",
+            "value": round(value, 1), "unit": "MP/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "strong" if (args.strong and world > 1) else "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{size}x{size} VarDCT d1 full pipeline (DCT8..32 mix, CfL, LF smoothing, "
+                                   f"Gaborish, EPF iters=2), inputs HBM-resident", "groups": int(wl.coeffs.shape[0]),
+                       "sharding": ("group-row bands + RCCL all-gather" if (args.strong and world > 1)
+                                    else "independent frames per GPU, no collective")},
+            "hip_event_ms_per_step_rank0": round(ev_ms / args.steps, 4),
+            "setup": {"host_generate_s": round(gen_s, 2), "h2d_coeffs_s": round(h2d_s, 2)},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

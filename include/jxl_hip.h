@@ -1,0 +1,228 @@
+/*
+ * jxl_hip.h -- C ABI of the MI355X-native JPEG XL reconstruction hot path.
+ *
+ * This is the drop-in boundary for libjxl/jxl-rs (v0.6.0).  jxl-rs has no FFI of
+ * its own (`#![deny(unsafe_code)]`, jxl/src/lib.rs:6): the path sits behind Rust
+ * traits, so each entry point below names the reference call site it replaces;
+ * INTEGRATION.md shows the Rust `extern "C"` block and the
+ * `HipRenderPipeline: RenderPipeline` shim that binds them.
+ *
+ * Conventions
+ *   - every function returns jxlh_status (0 = OK, <0 = error class); nothing
+ *     throws or aborts across the ABI (reference: Result<T, Error>, error.rs:15-276)
+ *   - all pointers are caller-owned; a pointer argument may be a host pointer or a
+ *     device (HIP) pointer -- uploads/downloads use hipMemcpyDefault
+ *   - plane descriptor == RawImageBuffer / JxlOutputBuffer::new_from_ptr
+ *     (jxl/src/image/internal.rs:15-31, image/output_buffer.rs:32-52)
+ *   - frame-level calls are single-threaded; jxlh_submit_group is re-entrant per
+ *     `slot` (one HIP stream + one pinned staging slab per slot, mirroring
+ *     PerThreadStorage, jxl/src/util/per_thread_storage.rs:13-60)
+ *   - channel order is X, Y, B everywhere (pipeline channels 0, 1, 2)
+ */
+#ifndef JXL_HIP_H_
+#define JXL_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JXLH_ABI_VERSION 1
+#define JXLH_NUM_TRANSFORMS 27   /* HfTransformType::CARDINALITY, transform_map.rs:59-61 */
+#define JXLH_NUM_QUANT_TABLES 17 /* NUM_QUANT_TABLES, quantizer.rs:11 */
+#define JXLH_GROUP_DIM 256       /* GROUP_DIM, jxl/src/lib.rs:24-26 */
+
+typedef int32_t jxlh_status;
+enum {
+  JXLH_OK = 0,
+  JXLH_ERR_INVALID_ARGUMENT = -1, /* -> Error::Gpu(InvalidArgument) */
+  JXLH_ERR_OUT_OF_MEMORY = -2,    /* hipMalloc failed (reference: try_reserve, group.rs:47-55) */
+  JXLH_ERR_DEVICE = -3,           /* any other HIP runtime error; see jxlh_last_error */
+  JXLH_ERR_BAD_STATE = -4,        /* call order violated (e.g. submit before frame_begin) */
+  JXLH_ERR_INVALID_TRANSFORM = -5,/* transform_map holds an id >= 27 (Error::InvalidVarDCTTransform) */
+  JXLH_ERR_UNSUPPORTED = -6       /* valid stream feature outside the device path (caller falls back) */
+};
+
+typedef struct jxlh_ctx jxlh_ctx;
+
+/* RawImageBuffer (image/internal.rs:15-31). */
+typedef struct {
+  void* ptr;
+  size_t bytes_per_row;
+  size_t num_rows;
+  size_t bytes_between_rows;
+} jxlh_plane;
+
+/* Everything the device needs that the reference keeps in FrameHeader /
+ * LfGlobalState / HfGlobalState.  Field by field:
+ *   xsize, ysize .......... frame_header.size_upsampled() == pipeline image size
+ *                           (frame/render.rs:541-545)
+ *   global_scale, quant_lf . QuantizerParams (frame/quantizer.rs:56-85)
+ *   lf_quant_factors ....... LfQuantFactors::quant_factors (quantizer.rs:14-51)
+ *   quant_biases ........... OpsinInverseMatrix::quant_biases (headers/transform_data.rs:30-31)
+ *   x_qm_scale, b_qm_scale . FrameHeader (headers/frame_header.rs:308-315); the device computes
+ *                           0.8^(scale-2) exactly like group.rs:395-396
+ *   color_factor .. ytob_lf  ColorCorrelationParams (frame/color_correlation_map.rs:21-94)
+ *   gab .. epf_border_sad_mul RestorationFilter (headers/frame_header.rs:146-233)
+ *   do_lf_smoothing ........ FrameHeader::should_do_adaptive_lf_smoothing (:496-500)
+ */
+typedef struct {
+  uint32_t abi_version; /* JXLH_ABI_VERSION */
+  uint32_t xsize, ysize;
+  uint32_t global_scale, quant_lf;
+  float lf_quant_factors[3];
+  float quant_biases[4];
+  uint32_t x_qm_scale, b_qm_scale;
+  uint32_t color_factor;
+  float base_correlation_x, base_correlation_b;
+  int32_t ytox_lf, ytob_lf;
+  uint32_t gab;
+  float gab_w1[3], gab_w2[3];
+  uint32_t epf_iters;
+  float epf_sharp_lut[8];
+  float epf_channel_scale[3];
+  float epf_quant_mul, epf_pass0_sigma_scale, epf_pass2_sigma_scale, epf_border_sad_mul;
+  uint32_t do_lf_smoothing;
+  uint32_t flags; /* JXLH_FRAME_* */
+} jxlh_frame_params;
+
+enum {
+  JXLH_FRAME_UNFUSED_FILTERS = 1u << 0, /* run Gaborish/EPF as one kernel per stage (debug/parity) */
+};
+
+/* Header defaults of the reference (RestorationFilter / ColorCorrelationParams /
+ * quant_biases defaults), for callers that only override a few fields. */
+jxlh_status jxlh_default_frame_params(jxlh_frame_params* p, uint32_t xsize, uint32_t ysize);
+
+/* ---------------------------------------------------------------- context */
+/* n_slots = number of host threads that will call jxlh_submit_group concurrently
+ * (the JxlParallelRunner's thread count, jxl/src/api/mod.rs:77-81). */
+jxlh_status jxlh_ctx_create(int32_t device_ordinal, int32_t n_slots, jxlh_ctx** out);
+void jxlh_ctx_destroy(jxlh_ctx* ctx);
+const char* jxlh_status_string(jxlh_status s);
+/* human-readable detail of the last JXLH_ERR_DEVICE on this context (thread-unsafe, debugging) */
+const char* jxlh_last_error(const jxlh_ctx* ctx);
+/* pinned host memory for coefficient slabs (replaces VarDctBuffers::coeffs_storage,
+ * frame/group.rs:27-67) */
+jxlh_status jxlh_alloc_pinned(jxlh_ctx* ctx, size_t bytes, void** out);
+jxlh_status jxlh_free_pinned(jxlh_ctx* ctx, void* p);
+
+/* ---------------------------------------------------------------- VarDCT frame */
+/* Replaces Frame::from_header_and_toc's LF / HfMetadata allocation
+ * (frame/decode.rs:172-204) + prepare_render_pipeline (frame/render.rs:907). */
+jxlh_status jxlh_frame_begin(jxlh_ctx* ctx, const jxlh_frame_params* p);
+
+/* HfGlobalState::dequant_matrices (frame/quant_weights.rs:347-351): 17 tables, table t holds
+ * 3 * n[t] inverse weights, channel-major (matrix(type, c), :1081-1086). */
+jxlh_status jxlh_frame_set_dequant_tables(jxlh_ctx* ctx, const float* const tables[JXLH_NUM_QUANT_TABLES],
+                                          const size_t n[JXLH_NUM_QUANT_TABLES]);
+
+/* decode_vardct_lf -> dequant_lf (frame/modular/mod.rs:837-929), one LF-group rect at a time.
+ * Rect in blocks.  qy/qx/qb are the three modular channels in coded order (Y, X, B), row stride
+ * `stride` samples.  Runs K0a on the device. */
+jxlh_status jxlh_frame_set_lf_quantized(jxlh_ctx* ctx, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
+                                        const int32_t* qy, const int32_t* qx, const int32_t* qb,
+                                        size_t stride, uint32_t extra_precision);
+/* Alternative: LF already dequantised by the host (lf_image, frame/mod.rs). */
+jxlh_status jxlh_frame_set_lf(jxlh_ctx* ctx, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
+                              const float* x, const float* y, const float* b, size_t stride);
+
+/* decode_hf_metadata (frame/modular/mod.rs:984-1081): HfMetadata maps for a rect in blocks
+ * (frame/mod.rs:169-176).  ytox/ytob cover ceil(w/8) x ceil(h/8) colour tiles starting at
+ * (x0/8, y0/8); x0, y0 must be multiples of 8. */
+jxlh_status jxlh_frame_set_hf_meta(jxlh_ctx* ctx, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
+                                   const uint8_t* transform_map, const int32_t* raw_quant,
+                                   const uint8_t* epf_map, size_t map_stride, const int8_t* ytox,
+                                   const int8_t* ytob, size_t cmap_stride);
+
+/* Replaces the `if let Some(pixels)` branch of decode_vardct_group (frame/group.rs:579-611)
+ * + pipeline.set_buffer_for_group for channels 0..2 (frame/decode.rs:776-784).
+ * coeffs: 3 * 65536 i32 (X, Y, B planes of the group, varblocks back to back in raster order
+ * of their top-left block, group.rs:437-440, :612).  Asynchronous: returns after enqueueing the
+ * H2D copy on slot's stream; the slab may be reused after jxlh_slot_wait(slot). */
+jxlh_status jxlh_submit_group(jxlh_ctx* ctx, int32_t slot, uint32_t group_id, const int32_t* coeffs,
+                              uint32_t flags);
+enum { JXLH_GROUP_COMPLETE = 1u << 0 /* set_buffer_for_group(.., complete = true, ..) */ };
+jxlh_status jxlh_slot_wait(jxlh_ctx* ctx, int32_t slot);
+
+/* Device-resident coefficient store of the current frame (ngroups * 3 * 65536 i32), for callers
+ * that already hold coefficients in HBM (bench harness, multi-GPU shards). */
+jxlh_status jxlh_frame_coeff_buffer(jxlh_ctx* ctx, int32_t** device_ptr, size_t* n_int32);
+
+/* Runs everything that has not run yet for the frame on the context's main stream:
+ * K0b adaptive LF smoothing (Frame::finalize_lf, frame/mod.rs:360-378), K3sigma
+ * (SigmaSource::new, features/epf.rs:35-87), K1 for every submitted group, then the stage list
+ * of frame/render.rs:569-622 (Gaborish x3, EPF0/1/2).  group range [g0, g1) restricts K1 and the
+ * filters to a band of group rows (multi-GPU sharding); pass 0, UINT32_MAX for the whole frame. */
+jxlh_status jxlh_frame_run(jxlh_ctx* ctx, uint32_t group_row0, uint32_t group_row1);
+/* blocks until the main stream is idle */
+jxlh_status jxlh_ctx_sync(jxlh_ctx* ctx);
+/* Copies the finished planes out (host or device destination).  Replaces the save stage for
+ * f32 XYB output; xsize x ysize samples per plane. */
+jxlh_status jxlh_frame_read_planes(jxlh_ctx* ctx, const jxlh_plane out[3]);
+/* device-resident result (row stride in floats), valid until the next frame_begin */
+jxlh_status jxlh_frame_device_planes(jxlh_ctx* ctx, float* planes[3], size_t* stride);
+/* smoothed LF image as used by K1 (tests) */
+jxlh_status jxlh_frame_read_lf(jxlh_ctx* ctx, float* x, float* y, float* b, size_t stride);
+
+/* ---------------------------------------------------------------- timing / profiling */
+/* HIP-event timing on the stream the kernels are launched on. */
+jxlh_status jxlh_timer_start(jxlh_ctx* ctx);
+jxlh_status jxlh_timer_stop(jxlh_ctx* ctx, float* elapsed_ms);
+/* per-kernel event pairs; accumulates while enabled */
+jxlh_status jxlh_kernel_timing_enable(jxlh_ctx* ctx, int32_t enable);
+/* i-th kernel that ran while timing was enabled: name, total ms, launches. Returns
+ * JXLH_ERR_INVALID_ARGUMENT past the end. */
+jxlh_status jxlh_kernel_timing_get(jxlh_ctx* ctx, int32_t i, const char** name, float* total_ms,
+                                   int32_t* launches);
+jxlh_status jxlh_kernel_timing_reset(jxlh_ctx* ctx);
+
+/* ---------------------------------------------------------------- stage-level hooks */
+/* Whole-image single stages with the pipeline's mirror edge semantics; the analogue of
+ * make_and_run_simple_pipeline (jxl/src/render/test.rs:83-179).  Planes: w x h f32, row stride
+ * `stride` floats, host or device pointers. */
+jxlh_status jxlh_stage_gaborish(jxlh_ctx* ctx, const float* in, float* out, uint32_t w, uint32_t h,
+                                size_t stride, float w1, float w2);
+/* stage = 0, 1, 2 (Epf0Stage / Epf1Stage / Epf2Stage); inv_sigma: ceil(w/8) x ceil(h/8) floats,
+ * row stride sigma_stride; uses the epf_* fields of p */
+jxlh_status jxlh_stage_epf(jxlh_ctx* ctx, int32_t stage, const jxlh_frame_params* p,
+                           const float* const in[3], float* const out[3], uint32_t w, uint32_t h,
+                           size_t stride, const float* inv_sigma, size_t sigma_stride);
+/* adaptive_lf_smoothing on w x h tight planes (frame/adaptive_lf_smoothing.rs:44-125) */
+jxlh_status jxlh_stage_lf_smooth(jxlh_ctx* ctx, const jxlh_frame_params* p, const float* const in[3],
+                                 float* const out[3], uint32_t w, uint32_t h);
+/* transform_to_pixels on a batch of independent varblocks of one type (transform.rs:666-677):
+ * coeffs n * cx*cy*64 dequantised coefficients, lf n * cx*cy samples, pixels n * (cy*8)*(cx*8). */
+jxlh_status jxlh_stage_transform_to_pixels(jxlh_ctx* ctx, int32_t type, uint32_t n, const float* coeffs,
+                                           const float* lf, float* pixels);
+
+/* ---------------------------------------------------------------- Modular (wrapping i32) */
+/* do_rct_step (modular/transforms/rct.rs:118-157) on whole planes of n samples, in place. */
+jxlh_status jxlh_rct(jxlh_ctx* ctx, int32_t* p0, int32_t* p1, int32_t* p2, size_t n, int32_t op,
+                     int32_t perm);
+/* do_palette_step_general, num_deltas == 0 && predictor == Zero branch (palette.rs:182-199).
+ * palette: nb_channels rows x palette_stride; out: nb_channels planes of n samples, contiguous. */
+jxlh_status jxlh_palette(jxlh_ctx* ctx, const int32_t* index, size_t n, const int32_t* palette,
+                         int32_t num_colors, size_t palette_stride, int32_t nb_channels,
+                         int32_t bit_depth, int32_t* out);
+/* do_hsqueeze_step / do_vsqueeze_step (squeeze.rs:456-481, :661-682), whole plane.
+ * horizontal: avg is ceil(out_w/2) x h, res floor(out_w/2) x h; vertical likewise in y. */
+jxlh_status jxlh_unsqueeze(jxlh_ctx* ctx, int32_t horizontal, const int32_t* avg, size_t avg_stride,
+                           const int32_t* res, size_t res_stride, uint32_t out_w, uint32_t out_h,
+                           int32_t* out, size_t out_stride);
+
+/* library info */
+uint32_t jxlh_abi_version(void);
+/* covered_blocks_x / _y and the type -> dequant table map (transform_map.rs:97-107,
+ * quant_weights.rs:321-343), for hosts that build coefficient slabs */
+int32_t jxlh_covered_blocks_x(int32_t type);
+int32_t jxlh_covered_blocks_y(int32_t type);
+int32_t jxlh_quant_table_for_type(int32_t type);
+int32_t jxlh_quant_table_size(int32_t table);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JXL_HIP_H_ */

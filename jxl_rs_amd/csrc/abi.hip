@@ -1,0 +1,896 @@
+// C ABI of the MI355X JPEG XL reconstruction path (include/jxl_hip.h): context, device
+// memory, streams, uploads and kernel sequencing.  No compute happens on the host here and
+// there is no CPU fallback: every entry point either launches HIP kernels or fails.
+//
+// Sequencing mirrors the reference's frame flow: decode_lf_group ->
+// set_lf* / set_hf_meta; decode_hf_global -> set_dequant_tables; decode_hf_group ->
+// submit_group (async H2D on the caller's slot stream, overlapping the host's entropy decode
+// of the next group); finalize_lf + render -> frame_run.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "jxlh_internal.h"
+
+using namespace jxlh;
+
+namespace {
+
+struct Slot {
+  hipStream_t stream = nullptr;
+  hipEvent_t done = nullptr;
+  bool used = false;
+};
+
+struct KernelTime {
+  std::string name;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+  float total_ms = 0.f;
+  int launches = 0;
+};
+
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;  // elements
+};
+
+}  // namespace
+
+struct jxlh_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::vector<Slot> slots;
+  hipEvent_t t0 = nullptr, t1 = nullptr;
+  std::string last_error;
+  // frame state
+  bool in_frame = false;
+  bool tables_set = false, lf_smoothed = false;
+  jxlh_frame_params params;
+  FrameDev fd;
+  size_t ngroups = 0;
+  DevBuf<float> planes[3], tmp[3], lf_raw[3], lf_sm[3], sigma, tables;
+  int table_offset[JXLH_NUM_QUANT_TABLES] = {0};
+  DevBuf<int32_t> coeffs, raw_quant, lfq;
+  DevBuf<uint8_t> transform_map, epf_map;
+  DevBuf<int8_t> ytox, ytob;
+  DevBuf<int> error_flag;
+  float* result[3] = {nullptr, nullptr, nullptr};
+  // stage hooks scratch
+  DevBuf<float> hook_f[8];
+  DevBuf<int32_t> hook_i[4];
+  // profiling
+  bool timing = false;
+  std::vector<KernelTime> ktimes;
+};
+
+namespace {
+
+jxlh_status fail(jxlh_ctx* ctx, hipError_t e, const char* what) {
+  if (ctx) {
+    ctx->last_error = std::string(what) + ": " + hipGetErrorString(e);
+  }
+  return e == hipErrorOutOfMemory ? JXLH_ERR_OUT_OF_MEMORY : JXLH_ERR_DEVICE;
+}
+
+#define HIPCHK(ctx, expr)                               \
+  do {                                                  \
+    hipError_t e_ = (expr);                             \
+    if (e_ != hipSuccess) return fail(ctx, e_, #expr);  \
+  } while (0)
+
+template <class T>
+jxlh_status ensure(jxlh_ctx* ctx, DevBuf<T>& b, size_t n) {
+  if (b.n >= n && b.p) return JXLH_OK;
+  if (b.p) {
+    HIPCHK(ctx, hipFree(b.p));
+    b.p = nullptr;
+    b.n = 0;
+  }
+  if (n == 0) return JXLH_OK;
+  HIPCHK(ctx, hipMalloc(reinterpret_cast<void**>(&b.p), n * sizeof(T)));
+  b.n = n;
+  return JXLH_OK;
+}
+
+template <class T>
+void release(DevBuf<T>& b) {
+  if (b.p) (void)hipFree(b.p);
+  b.p = nullptr;
+  b.n = 0;
+}
+
+struct ScopedKernelTimer {
+  jxlh_ctx* ctx;
+  hipEvent_t a = nullptr, b = nullptr;
+  KernelTime* kt = nullptr;
+  ScopedKernelTimer(jxlh_ctx* c, const char* name) : ctx(c) {
+    if (!ctx->timing) return;
+    for (auto& k : ctx->ktimes)
+      if (k.name == name) kt = &k;
+    if (!kt) {
+      ctx->ktimes.push_back(KernelTime{name, {}, 0.f, 0});
+      kt = &ctx->ktimes.back();
+    }
+    (void)hipEventCreate(&a);
+    (void)hipEventCreate(&b);
+    (void)hipEventRecord(a, ctx->stream);
+  }
+  ~ScopedKernelTimer() {
+    if (!kt) return;
+    (void)hipEventRecord(b, ctx->stream);
+    kt->pending.emplace_back(a, b);
+  }
+};
+
+void drain_timers(jxlh_ctx* ctx) {
+  for (auto& k : ctx->ktimes) {
+    for (auto& pr : k.pending) {
+      (void)hipEventSynchronize(pr.second);
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+        k.total_ms += ms;
+        k.launches += 1;
+      }
+      (void)hipEventDestroy(pr.first);
+      (void)hipEventDestroy(pr.second);
+    }
+    k.pending.clear();
+  }
+}
+
+size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
+
+// plane -> device 2-D copy helper (pointers may be host or device)
+jxlh_status copy2d(jxlh_ctx* ctx, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width_bytes,
+                   size_t height, hipStream_t s) {
+  if (width_bytes == 0 || height == 0) return JXLH_OK;
+  HIPCHK(ctx, hipMemcpy2DAsync(dst, dpitch, src, spitch, width_bytes, height, hipMemcpyDefault, s));
+  return JXLH_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t jxlh_abi_version(void) { return JXLH_ABI_VERSION; }
+int32_t jxlh_covered_blocks_x(int32_t t) { return (t >= 0 && t < 27) ? covered_x(t) : -1; }
+int32_t jxlh_covered_blocks_y(int32_t t) { return (t >= 0 && t < 27) ? covered_y(t) : -1; }
+int32_t jxlh_quant_table_for_type(int32_t t) { return (t >= 0 && t < 27) ? quant_table_for_type(t) : -1; }
+int32_t jxlh_quant_table_size(int32_t q) { return (q >= 0 && q < 17) ? quant_table_size(q) : -1; }
+
+const char* jxlh_status_string(jxlh_status s) {
+  switch (s) {
+    case JXLH_OK: return "ok";
+    case JXLH_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case JXLH_ERR_OUT_OF_MEMORY: return "out of device memory";
+    case JXLH_ERR_DEVICE: return "HIP runtime error";
+    case JXLH_ERR_BAD_STATE: return "call order violated";
+    case JXLH_ERR_INVALID_TRANSFORM: return "invalid VarDCT transform id";
+    case JXLH_ERR_UNSUPPORTED: return "unsupported on the device path";
+    default: return "unknown status";
+  }
+}
+
+const char* jxlh_last_error(const jxlh_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+jxlh_status jxlh_default_frame_params(jxlh_frame_params* p, uint32_t xsize, uint32_t ysize) {
+  if (!p) return JXLH_ERR_INVALID_ARGUMENT;
+  std::memset(p, 0, sizeof *p);
+  p->abi_version = JXLH_ABI_VERSION;
+  p->xsize = xsize;
+  p->ysize = ysize;
+  p->global_scale = 21845;  // not a header default; a typical d1 value
+  p->quant_lf = 16;         // QuantizerParams::read default branch (quantizer.rs:67)
+  p->lf_quant_factors[0] = 1.0f / 4096.0f;  // quant_weights.rs:24-30
+  p->lf_quant_factors[1] = 1.0f / 512.0f;
+  p->lf_quant_factors[2] = 1.0f / 256.0f;
+  p->quant_biases[0] = 1.0f - 0.05465007330715401f;  // headers/transform_data.rs:30-31
+  p->quant_biases[1] = 1.0f - 0.07005449891748593f;
+  p->quant_biases[2] = 1.0f - 0.049935103337343655f;
+  p->quant_biases[3] = 0.145f;
+  p->x_qm_scale = 3;  // frame_header.rs:308-315
+  p->b_qm_scale = 2;
+  p->color_factor = 84;  // color_correlation_map.rs:18, :31-40
+  p->base_correlation_x = 0.0f;
+  p->base_correlation_b = 1.0f;
+  p->gab = 1;  // frame_header.rs:150-177
+  for (int c = 0; c < 3; c++) {
+    p->gab_w1[c] = 0.115169525f;
+    p->gab_w2[c] = 0.061248592f;
+  }
+  p->epf_iters = 2;
+  for (int i = 0; i < 8; i++) p->epf_sharp_lut[i] = (float)i / 7.0f;
+  p->epf_sharp_lut[7] = 1.0f;
+  p->epf_channel_scale[0] = 40.0f;
+  p->epf_channel_scale[1] = 5.0f;
+  p->epf_channel_scale[2] = 3.5f;
+  p->epf_quant_mul = 0.46f;
+  p->epf_pass0_sigma_scale = 0.9f;
+  p->epf_pass2_sigma_scale = 6.5f;
+  p->epf_border_sad_mul = 2.0f / 3.0f;
+  p->do_lf_smoothing = 1;
+  return JXLH_OK;
+}
+
+jxlh_status jxlh_ctx_create(int32_t device_ordinal, int32_t n_slots, jxlh_ctx** out) {
+  if (!out || n_slots < 1 || n_slots > 1024) return JXLH_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device_ordinal < 0 || device_ordinal >= ndev)
+    return JXLH_ERR_DEVICE;
+  jxlh_ctx* ctx = new (std::nothrow) jxlh_ctx();
+  if (!ctx) return JXLH_ERR_OUT_OF_MEMORY;
+  ctx->device = device_ordinal;
+  if (hipSetDevice(device_ordinal) != hipSuccess ||
+      hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreate(&ctx->t0) != hipSuccess || hipEventCreate(&ctx->t1) != hipSuccess) {
+    delete ctx;
+    return JXLH_ERR_DEVICE;
+  }
+  ctx->slots.resize(n_slots);
+  for (auto& s : ctx->slots) {
+    if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess) {
+      jxlh_ctx_destroy(ctx);
+      return JXLH_ERR_DEVICE;
+    }
+  }
+  *out = ctx;
+  return JXLH_OK;
+}
+
+void jxlh_ctx_destroy(jxlh_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipDeviceSynchronize();
+  drain_timers(ctx);
+  for (auto& s : ctx->slots) {
+    if (s.done) (void)hipEventDestroy(s.done);
+    if (s.stream) (void)hipStreamDestroy(s.stream);
+  }
+  for (int c = 0; c < 3; c++) {
+    release(ctx->planes[c]);
+    release(ctx->tmp[c]);
+    release(ctx->lf_raw[c]);
+    release(ctx->lf_sm[c]);
+  }
+  release(ctx->sigma);
+  release(ctx->tables);
+  release(ctx->coeffs);
+  release(ctx->raw_quant);
+  release(ctx->lfq);
+  release(ctx->transform_map);
+  release(ctx->epf_map);
+  release(ctx->ytox);
+  release(ctx->ytob);
+  release(ctx->error_flag);
+  for (auto& b : ctx->hook_f) release(b);
+  for (auto& b : ctx->hook_i) release(b);
+  if (ctx->t0) (void)hipEventDestroy(ctx->t0);
+  if (ctx->t1) (void)hipEventDestroy(ctx->t1);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+jxlh_status jxlh_alloc_pinned(jxlh_ctx* ctx, size_t bytes, void** out) {
+  if (!ctx || !out) return JXLH_ERR_INVALID_ARGUMENT;
+  HIPCHK(ctx, hipHostMalloc(out, bytes, hipHostMallocDefault));
+  return JXLH_OK;
+}
+
+jxlh_status jxlh_free_pinned(jxlh_ctx* ctx, void* p) {
+  if (!ctx) return JXLH_ERR_INVALID_ARGUMENT;
+  if (p) HIPCHK(ctx, hipHostFree(p));
+  return JXLH_OK;
+}
+
+jxlh_status jxlh_frame_begin(jxlh_ctx* ctx, const jxlh_frame_params* p) {
+  if (!ctx || !p || p->abi_version != JXLH_ABI_VERSION) return JXLH_ERR_INVALID_ARGUMENT;
+  if (p->xsize == 0 || p->ysize == 0 || p->xsize > (1u << 20) || p->ysize > (1u << 20) || p->global_scale == 0 ||
+      p->quant_lf == 0 || p->color_factor == 0 || p->epf_iters > 3)
+    return JXLH_ERR_INVALID_ARGUMENT;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  ctx->params = *p;
+  FrameDev& f = ctx->fd;
+  std::memset(&f, 0, sizeof f);
+  f.xsize = (int)p->xsize;
+  f.ysize = (int)p->ysize;
+  f.xblocks = (int)((p->xsize + 7) / 8);
+  f.yblocks = (int)((p->ysize + 7) / 8);
+  f.xgroups = (int)((p->xsize + kGroupDim - 1) / kGroupDim);
+  f.ygroups = (int)((p->ysize + kGroupDim - 1) / kGroupDim);
+  f.cmap_stride = (f.xblocks + 7) / 8;
+  f.plane_stride = round_up((size_t)f.xblocks * 8, 64);
+  const size_t plane_elems = f.plane_stride * (size_t)f.yblocks * 8;
+  if (plane_elems >= (1ull << 31)) return JXLH_ERR_UNSUPPORTED;  // 32-bit pixel offsets in K1
+  ctx->ngroups = (size_t)f.xgroups * f.ygroups;
+  const size_t nblocks = (size_t)f.xblocks * f.yblocks;
+  const size_t ncmap = (size_t)f.cmap_stride * ((f.yblocks + 7) / 8);
+  jxlh_status st;
+  for (int c = 0; c < 3; c++) {
+    if ((st = ensure(ctx, ctx->planes[c], plane_elems)) != JXLH_OK) return st;
+    if ((st = ensure(ctx, ctx->tmp[c], plane_elems)) != JXLH_OK) return st;
+    if ((st = ensure(ctx, ctx->lf_raw[c], nblocks)) != JXLH_OK) return st;
+    if ((st = ensure(ctx, ctx->lf_sm[c], nblocks)) != JXLH_OK) return st;
+  }
+  if ((st = ensure(ctx, ctx->sigma, nblocks)) != JXLH_OK) return st;
+  if ((st = ensure(ctx, ctx->coeffs, ctx->ngroups * 3 * kGroupArea)) != JXLH_OK) return st;
+  if ((st = ensure(ctx, ctx->raw_quant, nblocks)) != JXLH_OK) return st;
+  if ((st = ensure(ctx, ctx->transform_map, nblocks)) != JXLH_OK) return st;
+  if ((st = ensure(ctx, ctx->epf_map, nblocks)) != JXLH_OK) return st;
+  if ((st = ensure(ctx, ctx->ytox, ncmap)) != JXLH_OK) return st;
+  if ((st = ensure(ctx, ctx->ytob, ncmap)) != JXLH_OK) return st;
+  if ((st = ensure(ctx, ctx->error_flag, 1)) != JXLH_OK) return st;
+  HIPCHK(ctx, hipMemsetAsync(ctx->error_flag.p, 0, sizeof(int), ctx->stream));
+  for (int c = 0; c < 3; c++) {
+    f.planes[c] = ctx->planes[c].p;
+    f.tmp[c] = ctx->tmp[c].p;
+    f.lf[c] = ctx->lf_raw[c].p;
+  }
+  f.coeffs = ctx->coeffs.p;
+  f.transform_map = ctx->transform_map.p;
+  f.raw_quant = ctx->raw_quant.p;
+  f.epf_map = ctx->epf_map.p;
+  f.ytox = ctx->ytox.p;
+  f.ytob = ctx->ytob.p;
+  f.inv_sigma = ctx->sigma.p;
+  // scalars, evaluated like the reference does on the host
+  f.inv_global_scale = (float)(1 << 16) / (float)p->global_scale;        // quantizer.rs:79-81
+  f.x_dm = powf(1.0f / 1.25f, (float)p->x_qm_scale - 2.0f);              // group.rs:395
+  f.b_dm = powf(1.0f / 1.25f, (float)p->b_qm_scale - 2.0f);              // group.rs:396
+  for (int i = 0; i < 4; i++) f.quant_biases[i] = p->quant_biases[i];
+  f.color_factor = (float)p->color_factor;
+  f.base_x = p->base_correlation_x;
+  f.base_b = p->base_correlation_b;
+  for (int c = 0; c < 3; c++) {  // GaborishStage::new, gaborish.rs:20-27
+    const float total = 1.0f + p->gab_w1[c] * 4.0f + p->gab_w2[c] * 4.0f;
+    f.gab_k[c][0] = 1.0f / total;
+    f.gab_k[c][1] = p->gab_w1[c] / total;
+    f.gab_k[c][2] = p->gab_w2[c] / total;
+    f.epf_channel_scale[c] = p->epf_channel_scale[c];
+  }
+  const float sigma_scale[3] = {p->epf_pass0_sigma_scale, 1.0f, p->epf_pass2_sigma_scale};  // render.rs:599-621
+  for (int s = 0; s < 3; s++) {
+    f.epf_sm[s] = sigma_scale[s] * 1.65f;  // epf1.rs:67-68
+    f.epf_bsm[s] = f.epf_sm[s] * p->epf_border_sad_mul;
+  }
+  f.epf_iters = (int)p->epf_iters;
+  f.gab = (int)p->gab;
+  ctx->in_frame = true;
+  // dequant tables persist across frames until replaced (library tables are per-decoder,
+  // quant_weights.rs:356-374)
+  ctx->tables_set = ctx->tables.p != nullptr && ctx->tables_set;
+  if (ctx->tables_set) {
+    f.tables = ctx->tables.p;
+    for (int q = 0; q < JXLH_NUM_QUANT_TABLES; q++) f.table_offset[q] = ctx->table_offset[q];
+  }
+  ctx->lf_smoothed = false;
+  for (auto& s : ctx->slots) s.used = false;
+  for (int c = 0; c < 3; c++) ctx->result[c] = nullptr;
+  return JXLH_OK;
+}
+
+jxlh_status jxlh_frame_set_dequant_tables(jxlh_ctx* ctx, const float* const tables[JXLH_NUM_QUANT_TABLES],
+                                          const size_t n[JXLH_NUM_QUANT_TABLES]) {
+  if (!ctx || !tables || !n) return JXLH_ERR_INVALID_ARGUMENT;
+  if (!ctx->in_frame) return JXLH_ERR_BAD_STATE;
+  size_t total = 0;
+  for (int q = 0; q < JXLH_NUM_QUANT_TABLES; q++) {
+    if (!tables[q] || n[q] != (size_t)quant_table_size(q)) return JXLH_ERR_INVALID_ARGUMENT;
+    total += 3 * n[q];
+  }
+  jxlh_status st = ensure(ctx, ctx->tables, total);
+  if (st != JXLH_OK) return st;
+  size_t off = 0;
+  for (int q = 0; q < JXLH_NUM_QUANT_TABLES; q++) {
+    ctx->fd.table_offset[q] = (int)off;
+    ctx->table_offset[q] = (int)off;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->tables.p + off, tables[q], 3 * n[q] * sizeof(float), hipMemcpyDefault,
+                               ctx->stream));
+    off += 3 * n[q];
+  }
+  ctx->fd.tables = ctx->tables.p;
+  ctx->tables_set = true;
+  return JXLH_OK;
+}
+
+static bool rect_ok(const jxlh_ctx* ctx, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h) {
+  return (uint64_t)x0 + w <= (uint64_t)ctx->fd.xblocks && (uint64_t)y0 + h <= (uint64_t)ctx->fd.yblocks;
+}
+
+jxlh_status jxlh_frame_set_lf_quantized(jxlh_ctx* ctx, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
+                                        const int32_t* qy, const int32_t* qx, const int32_t* qb, size_t stride,
+                                        uint32_t extra_precision) {
+  if (!ctx || !qy || !qx || !qb || stride < w || extra_precision > 3) return JXLH_ERR_INVALID_ARGUMENT;
+  if (!ctx->in_frame) return JXLH_ERR_BAD_STATE;
+  if (!rect_ok(ctx, x0, y0, w, h)) return JXLH_ERR_INVALID_ARGUMENT;
+  if (w == 0 || h == 0) return JXLH_OK;
+  const size_t n = (size_t)w * h;
+  jxlh_status st = ensure(ctx, ctx->lfq, 3 * n);
+  if (st != JXLH_OK) return st;
+  // the scratch is reused by the next call: order uploads and kernel on the main stream
+  const int32_t* src[3] = {qy, qx, qb};
+  for (int c = 0; c < 3; c++) {
+    st = copy2d(ctx, ctx->lfq.p + c * n, w * sizeof(int32_t), src[c], stride * sizeof(int32_t), w * sizeof(int32_t), h,
+                ctx->stream);
+    if (st != JXLH_OK) return st;
+  }
+  const jxlh_frame_params& p = ctx->params;
+  // dequant_lf, modular/mod.rs:849-879
+  const float inv_quant_lf = (float)(1 << 16) / ((float)p.global_scale * (float)p.quant_lf);
+  const float mul = 1.0f / (float)(1u << extra_precision);
+  const float fac_x = (p.lf_quant_factors[0] * inv_quant_lf) * mul;
+  const float fac_y = (p.lf_quant_factors[1] * inv_quant_lf) * mul;
+  const float fac_b = (p.lf_quant_factors[2] * inv_quant_lf) * mul;
+  const float cfl_x = p.base_correlation_x + (float)p.ytox_lf / (float)p.color_factor;
+  const float cfl_b = p.base_correlation_b + (float)p.ytob_lf / (float)p.color_factor;
+  const size_t off = (size_t)y0 * ctx->fd.xblocks + x0;
+  {
+    ScopedKernelTimer t(ctx, "k0a_dequant_lf");
+    launch_dequant_lf(ctx->stream, ctx->lfq.p, ctx->lfq.p + n, ctx->lfq.p + 2 * n, w, ctx->lf_raw[0].p + off,
+                      ctx->lf_raw[1].p + off, ctx->lf_raw[2].p + off, ctx->fd.xblocks, (int)w, (int)h, fac_x, fac_y,
+                      fac_b, cfl_x, cfl_b);
+  }
+  HIPCHK(ctx, hipGetLastError());
+  // the host buffers may be reused by the caller as soon as we return
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->lf_smoothed = false;
+  return JXLH_OK;
+}
+
+jxlh_status jxlh_frame_set_lf(jxlh_ctx* ctx, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, const float* x,
+                              const float* y, const float* b, size_t stride) {
+  if (!ctx || !x || !y || !b || stride < w) return JXLH_ERR_INVALID_ARGUMENT;
+  if (!ctx->in_frame) return JXLH_ERR_BAD_STATE;
+  if (!rect_ok(ctx, x0, y0, w, h)) return JXLH_ERR_INVALID_ARGUMENT;
+  const float* src[3] = {x, y, b};
+  const size_t off = (size_t)y0 * ctx->fd.xblocks + x0;
+  for (int c = 0; c < 3; c++) {
+    jxlh_status st = copy2d(ctx, ctx->lf_raw[c].p + off, ctx->fd.xblocks * sizeof(float), src[c],
+                            stride * sizeof(float), w * sizeof(float), h, ctx->stream);
+    if (st != JXLH_OK) return st;
+  }
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->lf_smoothed = false;
+  return JXLH_OK;
+}
+
+jxlh_status jxlh_frame_set_hf_meta(jxlh_ctx* ctx, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
+                                   const uint8_t* transform_map, const int32_t* raw_quant, const uint8_t* epf_map,
+                                   size_t map_stride, const int8_t* ytox, const int8_t* ytob, size_t cmap_stride) {
+  if (!ctx || !transform_map || !raw_quant || !epf_map || !ytox || !ytob || map_stride < w)
+    return JXLH_ERR_INVALID_ARGUMENT;
+  if (!ctx->in_frame) return JXLH_ERR_BAD_STATE;
+  if (!rect_ok(ctx, x0, y0, w, h) || (x0 % 8) || (y0 % 8)) return JXLH_ERR_INVALID_ARGUMENT;
+  const size_t cw = (w + 7) / 8, ch = (h + 7) / 8;
+  if (cmap_stride < cw) return JXLH_ERR_INVALID_ARGUMENT;
+  const size_t off = (size_t)y0 * ctx->fd.xblocks + x0;
+  const size_t coff = (size_t)(y0 / 8) * ctx->fd.cmap_stride + x0 / 8;
+  jxlh_status st;
+  if ((st = copy2d(ctx, ctx->transform_map.p + off, ctx->fd.xblocks, transform_map, map_stride, w, h, ctx->stream)))
+    return st;
+  if ((st = copy2d(ctx, ctx->epf_map.p + off, ctx->fd.xblocks, epf_map, map_stride, w, h, ctx->stream))) return st;
+  if ((st = copy2d(ctx, ctx->raw_quant.p + off, ctx->fd.xblocks * sizeof(int32_t), raw_quant,
+                   map_stride * sizeof(int32_t), w * sizeof(int32_t), h, ctx->stream)))
+    return st;
+  if ((st = copy2d(ctx, ctx->ytox.p + coff, ctx->fd.cmap_stride, ytox, cmap_stride, cw, ch, ctx->stream))) return st;
+  if ((st = copy2d(ctx, ctx->ytob.p + coff, ctx->fd.cmap_stride, ytob, cmap_stride, cw, ch, ctx->stream))) return st;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return JXLH_OK;
+}
+
+jxlh_status jxlh_submit_group(jxlh_ctx* ctx, int32_t slot, uint32_t group_id, const int32_t* coeffs, uint32_t flags) {
+  if (!ctx || !coeffs || slot < 0 || (size_t)slot >= ctx->slots.size()) return JXLH_ERR_INVALID_ARGUMENT;
+  if (!ctx->in_frame) return JXLH_ERR_BAD_STATE;
+  if (group_id >= ctx->ngroups) return JXLH_ERR_INVALID_ARGUMENT;
+  if (!(flags & JXLH_GROUP_COMPLETE)) return JXLH_ERR_UNSUPPORTED;  // progressive partial renders stay on the CPU path
+  Slot& s = ctx->slots[slot];
+  int32_t* dst = ctx->coeffs.p + (size_t)group_id * 3 * kGroupArea;
+  if (dst != coeffs) {
+    HIPCHK(ctx, hipMemcpyAsync(dst, coeffs, (size_t)3 * kGroupArea * sizeof(int32_t), hipMemcpyDefault, s.stream));
+  }
+  HIPCHK(ctx, hipEventRecord(s.done, s.stream));
+  s.used = true;
+  return JXLH_OK;
+}
+
+jxlh_status jxlh_slot_wait(jxlh_ctx* ctx, int32_t slot) {
+  if (!ctx || slot < 0 || (size_t)slot >= ctx->slots.size()) return JXLH_ERR_INVALID_ARGUMENT;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->slots[slot].stream));
+  return JXLH_OK;
+}
+
+jxlh_status jxlh_frame_coeff_buffer(jxlh_ctx* ctx, int32_t** device_ptr, size_t* n_int32) {
+  if (!ctx || !device_ptr) return JXLH_ERR_INVALID_ARGUMENT;
+  if (!ctx->in_frame) return JXLH_ERR_BAD_STATE;
+  *device_ptr = ctx->coeffs.p;
+  if (n_int32) *n_int32 = ctx->ngroups * 3 * kGroupArea;
+  return JXLH_OK;
+}
+
+jxlh_status jxlh_frame_run(jxlh_ctx* ctx, uint32_t group_row0, uint32_t group_row1) {
+  if (!ctx) return JXLH_ERR_INVALID_ARGUMENT;
+  if (!ctx->in_frame || !ctx->tables_set) return JXLH_ERR_BAD_STATE;
+  FrameDev& f = ctx->fd;
+  const jxlh_frame_params& p = ctx->params;
+  if (group_row1 > (uint32_t)f.ygroups) group_row1 = (uint32_t)f.ygroups;
+  if (group_row0 >= group_row1) return JXLH_ERR_INVALID_ARGUMENT;
+  // coefficient uploads issued on slot streams must land before K1
+  for (auto& s : ctx->slots) {
+    if (s.used) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, s.done, 0));
+  }
+  // ---- K0b: Frame::finalize_lf (frame/mod.rs:360-378)
+  const bool smooth = p.do_lf_smoothing && f.xblocks > 2 && f.yblocks > 2;  // adaptive_lf_smoothing.rs:51-53
+  if (smooth) {
+    {  // out of place (raw -> smoothed), so re-running a frame repeats the full work
+      const float inv_quant_lf = f.inv_global_scale / (float)p.quant_lf;  // quantizer.rs:82-84
+      const float lf_factors[3] = {inv_quant_lf * p.lf_quant_factors[0], inv_quant_lf * p.lf_quant_factors[1],
+                                   inv_quant_lf * p.lf_quant_factors[2]};
+      const float* in[3] = {ctx->lf_raw[0].p, ctx->lf_raw[1].p, ctx->lf_raw[2].p};
+      float* out[3] = {ctx->lf_sm[0].p, ctx->lf_sm[1].p, ctx->lf_sm[2].p};
+      ScopedKernelTimer t(ctx, "k0b_lf_smooth");
+      launch_lf_smooth(ctx->stream, in, out, f.xblocks, f.yblocks, lf_factors);
+      ctx->lf_smoothed = true;
+    }
+    for (int c = 0; c < 3; c++) f.lf[c] = ctx->lf_sm[c].p;
+  } else {
+    for (int c = 0; c < 3; c++) f.lf[c] = ctx->lf_raw[c].p;
+  }
+  // ---- K3 sigma: SigmaSource::new (features/epf.rs:35-87)
+  if (f.epf_iters > 0) {
+    ScopedKernelTimer t(ctx, "k3_sigma_map");
+    launch_sigma_map(ctx->stream, f, p.epf_quant_mul, p.epf_sharp_lut);
+  }
+  // ---- K1 on the band plus one halo group row on each side (filters read across it)
+  const int halo_px = (f.gab ? 1 : 0) + (f.epf_iters >= 3 ? 3 : 0) + (f.epf_iters >= 1 ? 2 : 0) +
+                      (f.epf_iters >= 2 ? 1 : 0);
+  const int gr0 = halo_px > 0 && group_row0 > 0 ? (int)group_row0 - 1 : (int)group_row0;
+  const int gr1 = halo_px > 0 && group_row1 < (uint32_t)f.ygroups ? (int)group_row1 + 1 : (int)group_row1;
+  {
+    const int ngroups = (gr1 - gr0) * f.xgroups;
+    int split = 1;
+    while (split < 8 && ngroups * split < 2048) split *= 2;
+    ScopedKernelTimer t(ctx, "k1_vardct_group");
+    launch_vardct_groups(ctx->stream, f, gr0, gr1, split, ctx->error_flag.p);
+  }
+  // ---- stage list of frame/render.rs:569-622
+  const int y_lo = (int)group_row0 * kGroupDim;
+  const int y_hi = min((int)group_row1 * kGroupDim, f.ysize);
+  int stages[4], borders[4], ns = 0;
+  if (f.gab) { stages[ns] = -1; borders[ns++] = 1; }
+  if (f.epf_iters >= 3) { stages[ns] = 0; borders[ns++] = 3; }
+  if (f.epf_iters >= 1) { stages[ns] = 1; borders[ns++] = 2; }
+  if (f.epf_iters >= 2) { stages[ns] = 2; borders[ns++] = 1; }
+  float* cur[3] = {f.planes[0], f.planes[1], f.planes[2]};
+  float* oth[3] = {f.tmp[0], f.tmp[1], f.tmp[2]};
+  for (int s = 0; s < ns; s++) {
+    int later = 0;
+    for (int k = s + 1; k < ns; k++) later += borders[k];
+    const int y0 = max(0, y_lo - later), y1 = min(f.ysize, y_hi + later);
+    if (stages[s] < 0) {
+      ScopedKernelTimer t(ctx, "k2_gaborish");
+      for (int c = 0; c < 3; c++)
+        launch_gaborish(ctx->stream, cur[c], oth[c], f.xsize, f.ysize, f.plane_stride, f.gab_k[c][0], f.gab_k[c][1],
+                        f.gab_k[c][2], y0, y1);
+    } else {
+      EpfArgs a;
+      for (int c = 0; c < 3; c++) {
+        a.in[c] = cur[c];
+        a.out[c] = oth[c];
+        a.scale[c] = f.epf_channel_scale[c];
+      }
+      a.inv_sigma = f.inv_sigma;
+      a.stride = f.plane_stride;
+      a.sigma_stride = (size_t)f.xblocks;
+      a.w = f.xsize;
+      a.h = f.ysize;
+      a.sm = f.epf_sm[stages[s]];
+      a.bsm = f.epf_bsm[stages[s]];
+      static const char* names[3] = {"k3a_epf0", "k3b_epf1", "k3c_epf2"};
+      ScopedKernelTimer t(ctx, names[stages[s]]);
+      launch_epf(ctx->stream, stages[s], a, y0, y1);
+    }
+    for (int c = 0; c < 3; c++) {
+      float* t = cur[c];
+      cur[c] = oth[c];
+      oth[c] = t;
+    }
+  }
+  for (int c = 0; c < 3; c++) ctx->result[c] = cur[c];
+  HIPCHK(ctx, hipGetLastError());
+  return JXLH_OK;
+}
+
+jxlh_status jxlh_ctx_sync(jxlh_ctx* ctx) {
+  if (!ctx) return JXLH_ERR_INVALID_ARGUMENT;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->in_frame && ctx->error_flag.p) {
+    int flag = 0;
+    HIPCHK(ctx, hipMemcpy(&flag, ctx->error_flag.p, sizeof(int), hipMemcpyDeviceToHost));
+    if (flag != 0) return (jxlh_status)flag;
+  }
+  return JXLH_OK;
+}
+
+jxlh_status jxlh_frame_read_planes(jxlh_ctx* ctx, const jxlh_plane out[3]) {
+  if (!ctx || !out) return JXLH_ERR_INVALID_ARGUMENT;
+  if (!ctx->in_frame || !ctx->result[0]) return JXLH_ERR_BAD_STATE;
+  const FrameDev& f = ctx->fd;
+  for (int c = 0; c < 3; c++) {
+    if (!out[c].ptr || out[c].bytes_per_row < (size_t)f.xsize * sizeof(float) || out[c].num_rows < (size_t)f.ysize ||
+        out[c].bytes_between_rows < out[c].bytes_per_row)
+      return JXLH_ERR_INVALID_ARGUMENT;
+    jxlh_status st = copy2d(ctx, out[c].ptr, out[c].bytes_between_rows, ctx->result[c],
+                            f.plane_stride * sizeof(float), (size_t)f.xsize * sizeof(float), f.ysize, ctx->stream);
+    if (st != JXLH_OK) return st;
+  }
+  return jxlh_ctx_sync(ctx);
+}
+
+jxlh_status jxlh_frame_device_planes(jxlh_ctx* ctx, float* planes[3], size_t* stride) {
+  if (!ctx || !planes) return JXLH_ERR_INVALID_ARGUMENT;
+  if (!ctx->in_frame || !ctx->result[0]) return JXLH_ERR_BAD_STATE;
+  for (int c = 0; c < 3; c++) planes[c] = ctx->result[c];
+  if (stride) *stride = ctx->fd.plane_stride;
+  return JXLH_OK;
+}
+
+jxlh_status jxlh_frame_read_lf(jxlh_ctx* ctx, float* x, float* y, float* b, size_t stride) {
+  if (!ctx || !x || !y || !b) return JXLH_ERR_INVALID_ARGUMENT;
+  if (!ctx->in_frame) return JXLH_ERR_BAD_STATE;
+  const FrameDev& f = ctx->fd;
+  if (stride < (size_t)f.xblocks) return JXLH_ERR_INVALID_ARGUMENT;
+  float* dst[3] = {x, y, b};
+  for (int c = 0; c < 3; c++) {
+    jxlh_status st = copy2d(ctx, dst[c], stride * sizeof(float), f.lf[c], f.xblocks * sizeof(float),
+                            f.xblocks * sizeof(float), f.yblocks, ctx->stream);
+    if (st != JXLH_OK) return st;
+  }
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return JXLH_OK;
+}
+
+// ---------------------------------------------------------------- timing
+jxlh_status jxlh_timer_start(jxlh_ctx* ctx) {
+  if (!ctx) return JXLH_ERR_INVALID_ARGUMENT;
+  HIPCHK(ctx, hipEventRecord(ctx->t0, ctx->stream));
+  return JXLH_OK;
+}
+
+jxlh_status jxlh_timer_stop(jxlh_ctx* ctx, float* elapsed_ms) {
+  if (!ctx || !elapsed_ms) return JXLH_ERR_INVALID_ARGUMENT;
+  HIPCHK(ctx, hipEventRecord(ctx->t1, ctx->stream));
+  HIPCHK(ctx, hipEventSynchronize(ctx->t1));
+  HIPCHK(ctx, hipEventElapsedTime(elapsed_ms, ctx->t0, ctx->t1));
+  return JXLH_OK;
+}
+
+jxlh_status jxlh_kernel_timing_enable(jxlh_ctx* ctx, int32_t enable) {
+  if (!ctx) return JXLH_ERR_INVALID_ARGUMENT;
+  ctx->timing = enable != 0;
+  return JXLH_OK;
+}
+
+jxlh_status jxlh_kernel_timing_get(jxlh_ctx* ctx, int32_t i, const char** name, float* total_ms, int32_t* launches) {
+  if (!ctx || i < 0) return JXLH_ERR_INVALID_ARGUMENT;
+  drain_timers(ctx);
+  if ((size_t)i >= ctx->ktimes.size()) return JXLH_ERR_INVALID_ARGUMENT;
+  if (name) *name = ctx->ktimes[i].name.c_str();
+  if (total_ms) *total_ms = ctx->ktimes[i].total_ms;
+  if (launches) *launches = ctx->ktimes[i].launches;
+  return JXLH_OK;
+}
+
+jxlh_status jxlh_kernel_timing_reset(jxlh_ctx* ctx) {
+  if (!ctx) return JXLH_ERR_INVALID_ARGUMENT;
+  drain_timers(ctx);
+  ctx->ktimes.clear();
+  return JXLH_OK;
+}
+
+// ---------------------------------------------------------------- stage hooks
+// Each hook stages its arguments into context-owned device scratch (so host pointers work),
+// runs the kernel(s) on the main stream and copies the result back.
+}  // extern "C"
+namespace {
+template <class T>
+jxlh_status stage_in(jxlh_ctx* ctx, DevBuf<T>& b, const T* src, size_t n) {
+  jxlh_status st = ensure(ctx, b, n);
+  if (st != JXLH_OK) return st;
+  HIPCHK(ctx, hipMemcpyAsync(b.p, src, n * sizeof(T), hipMemcpyDefault, ctx->stream));
+  return JXLH_OK;
+}
+template <class T>
+jxlh_status stage_out(jxlh_ctx* ctx, T* dst, const T* src, size_t n) {
+  HIPCHK(ctx, hipMemcpyAsync(dst, src, n * sizeof(T), hipMemcpyDefault, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return JXLH_OK;
+}
+bool is_device_ptr(const void* p) {
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return attr.type == hipMemoryTypeDevice;
+}
+}  // namespace
+extern "C" {
+
+jxlh_status jxlh_stage_gaborish(jxlh_ctx* ctx, const float* in, float* out, uint32_t w, uint32_t h, size_t stride,
+                                float w1, float w2) {
+  if (!ctx || !in || !out || stride < w) return JXLH_ERR_INVALID_ARGUMENT;
+  if (w == 0 || h == 0) return JXLH_OK;
+  const size_t n = stride * h;
+  jxlh_status st;
+  if ((st = stage_in(ctx, ctx->hook_f[0], in, n))) return st;
+  if ((st = ensure(ctx, ctx->hook_f[1], n))) return st;
+  const float total = 1.0f + w1 * 4.0f + w2 * 4.0f;
+  launch_gaborish(ctx->stream, ctx->hook_f[0].p, ctx->hook_f[1].p, (int)w, (int)h, stride, 1.0f / total, w1 / total,
+                  w2 / total, 0, (int)h);
+  HIPCHK(ctx, hipGetLastError());
+  return stage_out(ctx, out, ctx->hook_f[1].p, n);
+}
+
+jxlh_status jxlh_stage_epf(jxlh_ctx* ctx, int32_t stage, const jxlh_frame_params* p, const float* const in[3],
+                           float* const out[3], uint32_t w, uint32_t h, size_t stride, const float* inv_sigma,
+                           size_t sigma_stride) {
+  if (!ctx || !p || !in || !out || !inv_sigma || stage < 0 || stage > 2 || stride < w || sigma_stride < (w + 7) / 8)
+    return JXLH_ERR_INVALID_ARGUMENT;
+  if (w == 0 || h == 0) return JXLH_OK;
+  const size_t n = stride * h;
+  const size_t ns = sigma_stride * ((h + 7) / 8);
+  jxlh_status st;
+  EpfArgs a;
+  for (int c = 0; c < 3; c++) {
+    if (!in[c] || !out[c]) return JXLH_ERR_INVALID_ARGUMENT;
+    if ((st = stage_in(ctx, ctx->hook_f[c], in[c], n))) return st;
+    if ((st = ensure(ctx, ctx->hook_f[3 + c], n))) return st;
+    a.in[c] = ctx->hook_f[c].p;
+    a.out[c] = ctx->hook_f[3 + c].p;
+    a.scale[c] = p->epf_channel_scale[c];
+  }
+  if ((st = stage_in(ctx, ctx->hook_f[6], inv_sigma, ns))) return st;
+  a.inv_sigma = ctx->hook_f[6].p;
+  a.stride = stride;
+  a.sigma_stride = sigma_stride;
+  a.w = (int)w;
+  a.h = (int)h;
+  const float sigma_scale = stage == 0 ? p->epf_pass0_sigma_scale : (stage == 1 ? 1.0f : p->epf_pass2_sigma_scale);
+  a.sm = sigma_scale * 1.65f;
+  a.bsm = a.sm * p->epf_border_sad_mul;
+  launch_epf(ctx->stream, stage, a, 0, (int)h);
+  HIPCHK(ctx, hipGetLastError());
+  for (int c = 0; c < 3; c++)
+    if ((st = stage_out(ctx, out[c], ctx->hook_f[3 + c].p, n))) return st;
+  return JXLH_OK;
+}
+
+jxlh_status jxlh_stage_lf_smooth(jxlh_ctx* ctx, const jxlh_frame_params* p, const float* const in[3],
+                                 float* const out[3], uint32_t w, uint32_t h) {
+  if (!ctx || !p || !in || !out || p->global_scale == 0 || p->quant_lf == 0) return JXLH_ERR_INVALID_ARGUMENT;
+  if (w == 0 || h == 0) return JXLH_OK;
+  const size_t n = (size_t)w * h;
+  jxlh_status st;
+  const float* din[3];
+  float* dout[3];
+  for (int c = 0; c < 3; c++) {
+    if (!in[c] || !out[c]) return JXLH_ERR_INVALID_ARGUMENT;
+    if ((st = stage_in(ctx, ctx->hook_f[c], in[c], n))) return st;
+    if ((st = ensure(ctx, ctx->hook_f[3 + c], n))) return st;
+    din[c] = ctx->hook_f[c].p;
+    dout[c] = ctx->hook_f[3 + c].p;
+  }
+  if (w <= 2 || h <= 2) {  // adaptive_lf_smoothing.rs:51-53: untouched
+    for (int c = 0; c < 3; c++)
+      if ((st = stage_out(ctx, out[c], din[c], n))) return st;
+    return JXLH_OK;
+  }
+  const float inv_quant_lf = ((float)(1 << 16) / (float)p->global_scale) / (float)p->quant_lf;
+  const float lf_factors[3] = {inv_quant_lf * p->lf_quant_factors[0], inv_quant_lf * p->lf_quant_factors[1],
+                               inv_quant_lf * p->lf_quant_factors[2]};
+  launch_lf_smooth(ctx->stream, din, dout, (int)w, (int)h, lf_factors);
+  HIPCHK(ctx, hipGetLastError());
+  for (int c = 0; c < 3; c++)
+    if ((st = stage_out(ctx, out[c], dout[c], n))) return st;
+  return JXLH_OK;
+}
+
+jxlh_status jxlh_stage_transform_to_pixels(jxlh_ctx* ctx, int32_t type, uint32_t n, const float* coeffs,
+                                           const float* lf, float* pixels) {
+  if (!ctx || type < 0 || type >= JXLH_NUM_TRANSFORMS || !coeffs || !lf || !pixels) return JXLH_ERR_INVALID_ARGUMENT;
+  if (n == 0) return JXLH_OK;
+  const size_t nb = (size_t)covered_x(type) * covered_y(type);
+  jxlh_status st;
+  if ((st = stage_in(ctx, ctx->hook_f[0], coeffs, n * nb * 64))) return st;
+  if ((st = stage_in(ctx, ctx->hook_f[1], lf, n * nb))) return st;
+  if ((st = ensure(ctx, ctx->hook_f[2], n * nb * 64))) return st;
+  launch_transform_to_pixels(ctx->stream, type, n, ctx->hook_f[0].p, ctx->hook_f[1].p, ctx->hook_f[2].p);
+  HIPCHK(ctx, hipGetLastError());
+  return stage_out(ctx, pixels, ctx->hook_f[2].p, n * nb * 64);
+}
+
+// ---------------------------------------------------------------- Modular
+// In-place / out-of-place on the caller's buffers when they are device pointers; host
+// pointers are staged through context scratch.
+jxlh_status jxlh_rct(jxlh_ctx* ctx, int32_t* p0, int32_t* p1, int32_t* p2, size_t n, int32_t op, int32_t perm) {
+  if (!ctx || !p0 || !p1 || !p2 || op < 0 || op > 6 || perm < 0 || perm > 5) return JXLH_ERR_INVALID_ARGUMENT;
+  if (n == 0) return JXLH_OK;
+  if (is_device_ptr(p0) && is_device_ptr(p1) && is_device_ptr(p2)) {
+    ScopedKernelTimer t(ctx, "k4_rct");
+    launch_rct(ctx->stream, p0, p1, p2, n, op, perm);
+    HIPCHK(ctx, hipGetLastError());
+    return JXLH_OK;
+  }
+  jxlh_status st;
+  int32_t* h[3] = {p0, p1, p2};
+  for (int c = 0; c < 3; c++)
+    if ((st = stage_in(ctx, ctx->hook_i[c], (const int32_t*)h[c], n))) return st;
+  launch_rct(ctx->stream, ctx->hook_i[0].p, ctx->hook_i[1].p, ctx->hook_i[2].p, n, op, perm);
+  HIPCHK(ctx, hipGetLastError());
+  for (int c = 0; c < 3; c++)
+    if ((st = stage_out(ctx, h[c], (const int32_t*)ctx->hook_i[c].p, n))) return st;
+  return JXLH_OK;
+}
+
+jxlh_status jxlh_palette(jxlh_ctx* ctx, const int32_t* index, size_t n, const int32_t* palette, int32_t num_colors,
+                         size_t palette_stride, int32_t nb_channels, int32_t bit_depth, int32_t* out) {
+  if (!ctx || !index || !palette || !out || num_colors < 0 || nb_channels < 1 || nb_channels > 64 || bit_depth < 1 ||
+      bit_depth > 24 || palette_stride < (size_t)num_colors)
+    return JXLH_ERR_INVALID_ARGUMENT;
+  if (n == 0) return JXLH_OK;
+  const size_t pal_n = palette_stride * (size_t)nb_channels;
+  if (is_device_ptr(index) && is_device_ptr(palette) && is_device_ptr(out)) {
+    ScopedKernelTimer t(ctx, "k5_palette");
+    launch_palette(ctx->stream, index, n, palette, num_colors, palette_stride, nb_channels, bit_depth, out);
+    HIPCHK(ctx, hipGetLastError());
+    return JXLH_OK;
+  }
+  jxlh_status st;
+  if ((st = stage_in(ctx, ctx->hook_i[0], index, n))) return st;
+  if ((st = stage_in(ctx, ctx->hook_i[1], palette, pal_n ? pal_n : 1))) return st;
+  if ((st = ensure(ctx, ctx->hook_i[2], n * nb_channels))) return st;
+  launch_palette(ctx->stream, ctx->hook_i[0].p, n, ctx->hook_i[1].p, num_colors, palette_stride, nb_channels,
+                 bit_depth, ctx->hook_i[2].p);
+  HIPCHK(ctx, hipGetLastError());
+  return stage_out(ctx, out, (const int32_t*)ctx->hook_i[2].p, n * nb_channels);
+}
+
+jxlh_status jxlh_unsqueeze(jxlh_ctx* ctx, int32_t horizontal, const int32_t* avg, size_t avg_stride,
+                           const int32_t* res, size_t res_stride, uint32_t out_w, uint32_t out_h, int32_t* out,
+                           size_t out_stride) {
+  if (!ctx || !avg || !out || out_stride < out_w) return JXLH_ERR_INVALID_ARGUMENT;
+  if (out_w == 0 || out_h == 0) return JXLH_OK;
+  const uint32_t avg_w = horizontal ? (out_w + 1) / 2 : out_w, avg_h = horizontal ? out_h : (out_h + 1) / 2;
+  const uint32_t res_w = horizontal ? out_w / 2 : out_w, res_h = horizontal ? out_h : out_h / 2;
+  if (avg_stride < avg_w || (res_w * res_h > 0 && (!res || res_stride < res_w))) return JXLH_ERR_INVALID_ARGUMENT;
+  if (is_device_ptr(avg) && is_device_ptr(out) && (res_w * res_h == 0 || is_device_ptr(res))) {
+    ScopedKernelTimer t(ctx, horizontal ? "k6_unsqueeze_h" : "k6_unsqueeze_v");
+    launch_unsqueeze(ctx->stream, horizontal, avg, avg_stride, res ? res : avg, res_stride, out_w, out_h, out,
+                     out_stride);
+    HIPCHK(ctx, hipGetLastError());
+    return JXLH_OK;
+  }
+  jxlh_status st;
+  if ((st = stage_in(ctx, ctx->hook_i[0], avg, avg_stride * avg_h))) return st;
+  const size_t res_n = res_stride * res_h;
+  if (res_n) {
+    if ((st = stage_in(ctx, ctx->hook_i[1], res, res_n))) return st;
+  } else if ((st = ensure(ctx, ctx->hook_i[1], 1))) {
+    return st;
+  }
+  if ((st = ensure(ctx, ctx->hook_i[2], out_stride * out_h))) return st;
+  launch_unsqueeze(ctx->stream, horizontal, ctx->hook_i[0].p, avg_stride, ctx->hook_i[1].p, res_stride, out_w, out_h,
+                   ctx->hook_i[2].p, out_stride);
+  HIPCHK(ctx, hipGetLastError());
+  return stage_out(ctx, out, (const int32_t*)ctx->hook_i[2].p, out_stride * out_h);
+}
+
+}  // extern "C"

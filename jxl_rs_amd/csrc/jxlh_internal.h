@@ -1,0 +1,115 @@
+// Internal declarations shared by the HIP kernels and the C-ABI host code.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/jxl_hip.h"
+
+namespace jxlh {
+
+constexpr int kBlockDim = 8;
+constexpr int kGroupDim = 256;
+constexpr int kGroupBlocks = 32;           // blocks per group side
+constexpr int kGroupArea = 256 * 256;      // coefficients per channel per group
+constexpr int kColorTileBlocks = 8;        // COLOR_TILE_DIM_IN_BLOCKS, color_correlation_map.rs:16
+constexpr float kMinSigma = -3.90524291751269967465540850526868f;  // jxl/src/lib.rs:28
+constexpr float kInvSigmaNum = -1.1715728752538099024f;            // features/epf.rs:26
+
+// transform_map.rs:97-116
+__host__ __device__ constexpr int covered_x(int t) {
+  constexpr int lut[27] = {1, 1, 1, 1, 2, 4, 1, 2, 1, 4, 2, 4, 1, 1, 1, 1, 1, 1, 8, 4, 8, 16, 8, 16, 32, 16, 32};
+  return lut[t];
+}
+__host__ __device__ constexpr int covered_y(int t) {
+  constexpr int lut[27] = {1, 1, 1, 1, 2, 4, 2, 1, 4, 1, 4, 2, 1, 1, 1, 1, 1, 1, 8, 8, 4, 16, 16, 8, 32, 32, 16};
+  return lut[t];
+}
+// quant_weights.rs:321-343
+__host__ __device__ constexpr int quant_table_for_type(int t) {
+  constexpr int lut[27] = {0, 1, 2, 3, 4, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 10, 10, 11, 12, 12, 13, 14, 14, 15, 16, 16};
+  return lut[t];
+}
+// quant_weights.rs:1128-1132, floats per channel
+__host__ __device__ constexpr int quant_table_size(int q) {
+  constexpr int rx[17] = {1, 1, 1, 1, 2, 4, 1, 1, 2, 1, 1, 8, 4, 16, 8, 32, 16};
+  constexpr int ry[17] = {1, 1, 1, 1, 2, 4, 2, 4, 4, 1, 1, 8, 8, 16, 16, 32, 32};
+  return rx[q] * ry[q] * 64;
+}
+
+// util/mirror.rs:8-19
+__host__ __device__ inline int mirror(int v, int s) {
+  while (true) {
+    if (v < 0) {
+      v = -v - 1;
+    } else if (v >= s) {
+      v = s * 2 - v - 1;
+    } else {
+      return v;
+    }
+  }
+}
+
+// Device view of one VarDCT frame (passed by value to kernels).
+struct FrameDev {
+  int xsize, ysize;               // unpadded pixels
+  int xblocks, yblocks;           // size in 8x8 blocks
+  int xgroups, ygroups;
+  int cmap_stride;                // colour tiles per row
+  size_t plane_stride;            // floats; planes are yblocks*8 rows
+  float* planes[3];               // X, Y, B
+  float* tmp[3];                  // second set for out-of-place stages
+  const int32_t* coeffs;          // ngroups * 3 * 65536
+  const uint8_t* transform_map;   // stride xblocks
+  const int32_t* raw_quant;       // stride xblocks
+  const uint8_t* epf_map;         // stride xblocks
+  const int8_t* ytox;             // stride cmap_stride
+  const int8_t* ytob;
+  const float* lf[3];             // stride xblocks (smoothed LF)
+  float* inv_sigma;               // stride xblocks
+  const float* tables;            // 17 tables back to back
+  int table_offset[17];           // float offset of table q
+  // scalars
+  float inv_global_scale;         // 65536 / global_scale
+  float x_dm, b_dm;               // 0.8^(qm_scale - 2)
+  float quant_biases[4];
+  float color_factor;             // as f32
+  float base_x, base_b;
+  float gab_k[3][3];              // per channel normalised w0, w1, w2 (gaborish.rs:20-27)
+  float epf_channel_scale[3];
+  float epf_sm[3], epf_bsm[3];    // per pass: sigma_scale*1.65 and *border_sad_mul
+  int epf_iters;
+  int gab;
+};
+
+// kernels (k_*.hip); all take an explicit stream
+void launch_dequant_lf(hipStream_t s, const int32_t* qy, const int32_t* qx, const int32_t* qb, size_t qstride,
+                       float* ox, float* oy, float* ob, size_t ostride, int w, int h, float fac_x, float fac_y,
+                       float fac_b, float cfl_x, float cfl_b);
+void launch_lf_smooth(hipStream_t s, const float* const in[3], float* const out[3], int w, int h,
+                      const float lf_factors[3]);
+void launch_sigma_map(hipStream_t s, const FrameDev& f, float epf_quant_mul, const float* sharp_lut);
+void launch_vardct_groups(hipStream_t s, const FrameDev& f, int group_row0, int group_row1, int split,
+                          int* error_flag);
+void launch_gaborish(hipStream_t s, const float* in, float* out, int w, int h, size_t stride, float k0, float k1,
+                     float k2, int y0, int y1);
+struct EpfArgs {
+  const float* in[3];
+  float* out[3];
+  const float* inv_sigma;
+  size_t stride, sigma_stride;
+  int w, h;
+  float scale[3];
+  float sm, bsm;
+};
+void launch_epf(hipStream_t s, int stage, const EpfArgs& a, int y0, int y1);
+void launch_fused_filters(hipStream_t s, const FrameDev& f, int y0, int y1);
+void launch_transform_to_pixels(hipStream_t s, int type, uint32_t n, const float* coeffs, const float* lf,
+                                float* pixels);
+void launch_rct(hipStream_t s, int32_t* p0, int32_t* p1, int32_t* p2, size_t n, int op, int perm);
+void launch_palette(hipStream_t s, const int32_t* index, size_t n, const int32_t* palette, int num_colors,
+                    size_t palette_stride, int nb_channels, int bit_depth, int32_t* out);
+void launch_unsqueeze(hipStream_t s, int horizontal, const int32_t* avg, size_t avg_stride, const int32_t* res,
+                      size_t res_stride, uint32_t out_w, uint32_t out_h, int32_t* out, size_t out_stride);
+
+}  // namespace jxlh

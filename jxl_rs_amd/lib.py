@@ -1,0 +1,337 @@
+"""ctypes binding of the C ABI in include/jxl_hip.h (libjxl_hip.so, built in-tree by
+jxl_rs_amd/csrc/Makefile).  This is the same surface a Rust `extern "C"` block binds
+(INTEGRATION.md); Python is only the test / bench harness language here.
+
+There is no fallback: if the shared library is missing, importing this module raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libjxl_hip.so")
+
+NUM_TRANSFORMS = 27
+NUM_QUANT_TABLES = 17
+GROUP_DIM = 256
+
+OK = 0
+ERR_INVALID_ARGUMENT = -1
+ERR_OUT_OF_MEMORY = -2
+ERR_DEVICE = -3
+ERR_BAD_STATE = -4
+ERR_INVALID_TRANSFORM = -5
+ERR_UNSUPPORTED = -6
+FRAME_UNFUSED_FILTERS = 1
+GROUP_COMPLETE = 1
+
+# every symbol include/jxl_hip.h declares (checked by tests/test_abi_symbols.py)
+ABI_SYMBOLS = [
+    "jxlh_default_frame_params", "jxlh_ctx_create", "jxlh_ctx_destroy", "jxlh_status_string", "jxlh_last_error",
+    "jxlh_alloc_pinned", "jxlh_free_pinned", "jxlh_frame_begin", "jxlh_frame_set_dequant_tables",
+    "jxlh_frame_set_lf_quantized", "jxlh_frame_set_lf", "jxlh_frame_set_hf_meta", "jxlh_submit_group",
+    "jxlh_slot_wait", "jxlh_frame_coeff_buffer", "jxlh_frame_run", "jxlh_ctx_sync", "jxlh_frame_read_planes",
+    "jxlh_frame_device_planes", "jxlh_frame_read_lf", "jxlh_timer_start", "jxlh_timer_stop",
+    "jxlh_kernel_timing_enable", "jxlh_kernel_timing_get", "jxlh_kernel_timing_reset", "jxlh_stage_gaborish",
+    "jxlh_stage_epf", "jxlh_stage_lf_smooth", "jxlh_stage_transform_to_pixels", "jxlh_rct", "jxlh_palette",
+    "jxlh_unsqueeze", "jxlh_abi_version", "jxlh_covered_blocks_x", "jxlh_covered_blocks_y",
+    "jxlh_quant_table_for_type", "jxlh_quant_table_size",
+]
+
+
+class FrameParams(C.Structure):
+    """jxlh_frame_params."""
+    _fields_ = [
+        ("abi_version", C.c_uint32),
+        ("xsize", C.c_uint32), ("ysize", C.c_uint32),
+        ("global_scale", C.c_uint32), ("quant_lf", C.c_uint32),
+        ("lf_quant_factors", C.c_float * 3),
+        ("quant_biases", C.c_float * 4),
+        ("x_qm_scale", C.c_uint32), ("b_qm_scale", C.c_uint32),
+        ("color_factor", C.c_uint32),
+        ("base_correlation_x", C.c_float), ("base_correlation_b", C.c_float),
+        ("ytox_lf", C.c_int32), ("ytob_lf", C.c_int32),
+        ("gab", C.c_uint32),
+        ("gab_w1", C.c_float * 3), ("gab_w2", C.c_float * 3),
+        ("epf_iters", C.c_uint32),
+        ("epf_sharp_lut", C.c_float * 8),
+        ("epf_channel_scale", C.c_float * 3),
+        ("epf_quant_mul", C.c_float), ("epf_pass0_sigma_scale", C.c_float),
+        ("epf_pass2_sigma_scale", C.c_float), ("epf_border_sad_mul", C.c_float),
+        ("do_lf_smoothing", C.c_uint32),
+        ("flags", C.c_uint32),
+    ]
+
+
+class Plane(C.Structure):
+    """jxlh_plane == RawImageBuffer."""
+    _fields_ = [("ptr", C.c_void_p), ("bytes_per_row", C.c_size_t), ("num_rows", C.c_size_t),
+                ("bytes_between_rows", C.c_size_t)]
+
+
+class JxlHipError(RuntimeError):
+    def __init__(self, status, where, detail=""):
+        self.status = status
+        super().__init__(f"{where}: status {status} {detail}")
+
+
+def load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `make -C jxl_rs_amd/csrc` (or __graft_entry__.build()); "
+            "there is no CPU fallback for the device path")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, u32, sz, fp = C.c_void_p, C.c_int32, C.c_uint32, C.c_size_t, C.POINTER(C.c_float)
+    L.jxlh_default_frame_params.argtypes = [C.POINTER(FrameParams), u32, u32]
+    L.jxlh_ctx_create.argtypes = [i32, i32, C.POINTER(vp)]
+    L.jxlh_ctx_destroy.argtypes = [vp]
+    L.jxlh_ctx_destroy.restype = None
+    L.jxlh_status_string.argtypes = [i32]
+    L.jxlh_status_string.restype = C.c_char_p
+    L.jxlh_last_error.argtypes = [vp]
+    L.jxlh_last_error.restype = C.c_char_p
+    L.jxlh_alloc_pinned.argtypes = [vp, sz, C.POINTER(vp)]
+    L.jxlh_free_pinned.argtypes = [vp, vp]
+    L.jxlh_frame_begin.argtypes = [vp, C.POINTER(FrameParams)]
+    L.jxlh_frame_set_dequant_tables.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
+    L.jxlh_frame_set_lf_quantized.argtypes = [vp, u32, u32, u32, u32, vp, vp, vp, sz, u32]
+    L.jxlh_frame_set_lf.argtypes = [vp, u32, u32, u32, u32, vp, vp, vp, sz]
+    L.jxlh_frame_set_hf_meta.argtypes = [vp, u32, u32, u32, u32, vp, vp, vp, sz, vp, vp, sz]
+    L.jxlh_submit_group.argtypes = [vp, i32, u32, vp, u32]
+    L.jxlh_slot_wait.argtypes = [vp, i32]
+    L.jxlh_frame_coeff_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
+    L.jxlh_frame_run.argtypes = [vp, u32, u32]
+    L.jxlh_ctx_sync.argtypes = [vp]
+    L.jxlh_frame_read_planes.argtypes = [vp, C.POINTER(Plane)]
+    L.jxlh_frame_device_planes.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
+    L.jxlh_frame_read_lf.argtypes = [vp, vp, vp, vp, sz]
+    L.jxlh_timer_start.argtypes = [vp]
+    L.jxlh_timer_stop.argtypes = [vp, fp]
+    L.jxlh_kernel_timing_enable.argtypes = [vp, i32]
+    L.jxlh_kernel_timing_get.argtypes = [vp, i32, C.POINTER(C.c_char_p), fp, C.POINTER(i32)]
+    L.jxlh_kernel_timing_reset.argtypes = [vp]
+    L.jxlh_stage_gaborish.argtypes = [vp, vp, vp, u32, u32, sz, C.c_float, C.c_float]
+    L.jxlh_stage_epf.argtypes = [vp, i32, C.POINTER(FrameParams), C.POINTER(vp), C.POINTER(vp), u32, u32, sz, vp, sz]
+    L.jxlh_stage_lf_smooth.argtypes = [vp, C.POINTER(FrameParams), C.POINTER(vp), C.POINTER(vp), u32, u32]
+    L.jxlh_stage_transform_to_pixels.argtypes = [vp, i32, u32, vp, vp, vp]
+    L.jxlh_rct.argtypes = [vp, vp, vp, vp, sz, i32, i32]
+    L.jxlh_palette.argtypes = [vp, vp, sz, vp, i32, sz, i32, i32, vp]
+    L.jxlh_unsqueeze.argtypes = [vp, i32, vp, sz, vp, sz, u32, u32, vp, sz]
+    L.jxlh_abi_version.restype = u32
+    for name in ("jxlh_covered_blocks_x", "jxlh_covered_blocks_y", "jxlh_quant_table_for_type",
+                 "jxlh_quant_table_size"):
+        getattr(L, name).argtypes = [i32]
+        getattr(L, name).restype = i32
+    return L
+
+
+def _addr(a):
+    """Address of a numpy array or a raw integer device pointer."""
+    if isinstance(a, (int, np.integer)):
+        return C.c_void_p(int(a))
+    if hasattr(a, "data_ptr"):  # torch tensor (device memory plumbing only)
+        return C.c_void_p(a.data_ptr())
+    return C.c_void_p(a.ctypes.data)
+
+
+class Context:
+    """jxlh_ctx wrapper; raises JxlHipError on any non-zero status."""
+
+    def __init__(self, device=0, n_slots=1):
+        self.L = load()
+        self._ctx = C.c_void_p()
+        st = self.L.jxlh_ctx_create(device, n_slots, C.byref(self._ctx))
+        if st != OK:
+            raise JxlHipError(st, "jxlh_ctx_create", self.L.jxlh_status_string(st).decode())
+        self._keep = []
+
+    def close(self):
+        if self._ctx:
+            self.L.jxlh_ctx_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, st, where):
+        if st != OK:
+            raise JxlHipError(st, where, self.L.jxlh_status_string(st).decode() + " / " +
+                              self.L.jxlh_last_error(self._ctx).decode())
+
+    def default_params(self, xsize, ysize):
+        p = FrameParams()
+        self._chk(self.L.jxlh_default_frame_params(C.byref(p), xsize, ysize), "default_frame_params")
+        return p
+
+    # ---- frame ----
+    def frame_begin(self, params):
+        self.params = params
+        self.xblocks = (params.xsize + 7) // 8
+        self.yblocks = (params.ysize + 7) // 8
+        self._chk(self.L.jxlh_frame_begin(self._ctx, C.byref(params)), "frame_begin")
+
+    def set_dequant_tables(self, tables):
+        tabs = [np.ascontiguousarray(t, dtype=np.float32) for t in tables]
+        ptrs = (C.c_void_p * NUM_QUANT_TABLES)(*[t.ctypes.data for t in tabs])
+        sizes = (C.c_size_t * NUM_QUANT_TABLES)(*[t.size // 3 for t in tabs])
+        self._chk(self.L.jxlh_frame_set_dequant_tables(self._ctx, ptrs, sizes), "set_dequant_tables")
+
+    def set_lf_quantized(self, qy, qx, qb, x0=0, y0=0, extra_precision=0):
+        qy, qx, qb = [np.ascontiguousarray(a, dtype=np.int32) for a in (qy, qx, qb)]
+        h, w = qy.shape
+        self._chk(self.L.jxlh_frame_set_lf_quantized(self._ctx, x0, y0, w, h, _addr(qy), _addr(qx), _addr(qb), w,
+                                                     extra_precision), "set_lf_quantized")
+
+    def set_lf(self, x, y, b, x0=0, y0=0):
+        x, y, b = [np.ascontiguousarray(a, dtype=np.float32) for a in (x, y, b)]
+        h, w = x.shape
+        self._chk(self.L.jxlh_frame_set_lf(self._ctx, x0, y0, w, h, _addr(x), _addr(y), _addr(b), w), "set_lf")
+
+    def set_hf_meta(self, transform_map, raw_quant, epf_map, ytox, ytob, x0=0, y0=0):
+        tm = np.ascontiguousarray(transform_map, dtype=np.uint8)
+        rq = np.ascontiguousarray(raw_quant, dtype=np.int32)
+        em = np.ascontiguousarray(epf_map, dtype=np.uint8)
+        yx = np.ascontiguousarray(ytox, dtype=np.int8)
+        yb = np.ascontiguousarray(ytob, dtype=np.int8)
+        h, w = tm.shape
+        self._chk(self.L.jxlh_frame_set_hf_meta(self._ctx, x0, y0, w, h, _addr(tm), _addr(rq), _addr(em), w,
+                                                _addr(yx), _addr(yb), yx.shape[1]), "set_hf_meta")
+
+    def submit_group(self, group_id, coeffs, slot=0, flags=GROUP_COMPLETE):
+        if isinstance(coeffs, np.ndarray):
+            coeffs = np.ascontiguousarray(coeffs, dtype=np.int32)
+            assert coeffs.size == 3 * 65536
+            self._keep.append(coeffs)  # async H2D: keep alive until the slot is waited on
+        self._chk(self.L.jxlh_submit_group(self._ctx, slot, group_id, _addr(coeffs), flags), "submit_group")
+
+    def slot_wait(self, slot=0):
+        self._chk(self.L.jxlh_slot_wait(self._ctx, slot), "slot_wait")
+        self._keep.clear()
+
+    def coeff_buffer(self):
+        p, n = C.c_void_p(), C.c_size_t()
+        self._chk(self.L.jxlh_frame_coeff_buffer(self._ctx, C.byref(p), C.byref(n)), "frame_coeff_buffer")
+        return p.value, n.value
+
+    def frame_run(self, group_row0=0, group_row1=0xFFFFFFFF):
+        self._chk(self.L.jxlh_frame_run(self._ctx, group_row0, group_row1), "frame_run")
+
+    def sync(self):
+        self._chk(self.L.jxlh_ctx_sync(self._ctx), "ctx_sync")
+
+    def read_planes(self):
+        w, h = self.params.xsize, self.params.ysize
+        out = [np.zeros((h, w), dtype=np.float32) for _ in range(3)]
+        planes = (Plane * 3)(*[Plane(o.ctypes.data, w * 4, h, w * 4) for o in out])
+        self._chk(self.L.jxlh_frame_read_planes(self._ctx, planes), "frame_read_planes")
+        return out
+
+    def device_planes(self):
+        ptrs = (C.c_void_p * 3)()
+        stride = C.c_size_t()
+        self._chk(self.L.jxlh_frame_device_planes(self._ctx, ptrs, C.byref(stride)), "frame_device_planes")
+        return [ptrs[i] for i in range(3)], stride.value
+
+    def read_lf(self):
+        out = [np.zeros((self.yblocks, self.xblocks), dtype=np.float32) for _ in range(3)]
+        self._chk(self.L.jxlh_frame_read_lf(self._ctx, _addr(out[0]), _addr(out[1]), _addr(out[2]), self.xblocks),
+                  "frame_read_lf")
+        return out
+
+    # ---- timing ----
+    def timer_start(self):
+        self._chk(self.L.jxlh_timer_start(self._ctx), "timer_start")
+
+    def timer_stop(self):
+        ms = C.c_float()
+        self._chk(self.L.jxlh_timer_stop(self._ctx, C.byref(ms)), "timer_stop")
+        return ms.value
+
+    def kernel_timing(self, enable):
+        self._chk(self.L.jxlh_kernel_timing_enable(self._ctx, 1 if enable else 0), "kernel_timing_enable")
+
+    def kernel_timing_reset(self):
+        self._chk(self.L.jxlh_kernel_timing_reset(self._ctx), "kernel_timing_reset")
+
+    def kernel_times(self):
+        out = {}
+        i = 0
+        while True:
+            name, ms, n = C.c_char_p(), C.c_float(), C.c_int32()
+            st = self.L.jxlh_kernel_timing_get(self._ctx, i, C.byref(name), C.byref(ms), C.byref(n))
+            if st != OK:
+                break
+            out[name.value.decode()] = (ms.value, n.value)
+            i += 1
+        return out
+
+    # ---- stage hooks ----
+    def stage_gaborish(self, plane, w1, w2, w=None, h=None):
+        plane = np.ascontiguousarray(plane, dtype=np.float32)
+        H, S = plane.shape
+        w = S if w is None else w
+        h = H if h is None else h
+        out = np.zeros_like(plane)
+        self._chk(self.L.jxlh_stage_gaborish(self._ctx, _addr(plane), _addr(out), w, h, S, w1, w2), "stage_gaborish")
+        return out
+
+    def stage_epf(self, stage, params, planes, inv_sigma, w=None, h=None):
+        planes = [np.ascontiguousarray(a, dtype=np.float32) for a in planes]
+        H, S = planes[0].shape
+        w = S if w is None else w
+        h = H if h is None else h
+        sig = np.ascontiguousarray(inv_sigma, dtype=np.float32)
+        out = [np.zeros_like(planes[0]) for _ in range(3)]
+        pin = (C.c_void_p * 3)(*[a.ctypes.data for a in planes])
+        pout = (C.c_void_p * 3)(*[a.ctypes.data for a in out])
+        self._chk(self.L.jxlh_stage_epf(self._ctx, stage, C.byref(params), pin, pout, w, h, S, _addr(sig),
+                                        sig.shape[1]), "stage_epf")
+        return out
+
+    def stage_lf_smooth(self, params, lf):
+        lf = [np.ascontiguousarray(a, dtype=np.float32) for a in lf]
+        h, w = lf[0].shape
+        out = [np.zeros_like(lf[0]) for _ in range(3)]
+        pin = (C.c_void_p * 3)(*[a.ctypes.data for a in lf])
+        pout = (C.c_void_p * 3)(*[a.ctypes.data for a in out])
+        self._chk(self.L.jxlh_stage_lf_smooth(self._ctx, C.byref(params), pin, pout, w, h), "stage_lf_smooth")
+        return out
+
+    def stage_transform_to_pixels(self, ttype, coeffs, lf):
+        """coeffs [n, cx*cy*64], lf [n, cx*cy] -> pixels [n, cy*8, cx*8]."""
+        cx, cy = self.L.jxlh_covered_blocks_x(ttype), self.L.jxlh_covered_blocks_y(ttype)
+        coeffs = np.ascontiguousarray(coeffs, dtype=np.float32).reshape(-1, cx * cy * 64)
+        lf = np.ascontiguousarray(lf, dtype=np.float32).reshape(-1, cx * cy)
+        n = coeffs.shape[0]
+        assert lf.shape[0] == n
+        out = np.zeros((n, cy * 8, cx * 8), dtype=np.float32)
+        self._chk(self.L.jxlh_stage_transform_to_pixels(self._ctx, ttype, n, _addr(coeffs), _addr(lf), _addr(out)),
+                  "stage_transform_to_pixels")
+        return out
+
+    # ---- modular ----
+    def rct(self, planes, op, perm):
+        ps = [np.ascontiguousarray(a, dtype=np.int32).copy() for a in planes]
+        self._chk(self.L.jxlh_rct(self._ctx, _addr(ps[0]), _addr(ps[1]), _addr(ps[2]), ps[0].size, op, perm), "rct")
+        return ps
+
+    def palette(self, index, palette, num_colors, nb_channels, bit_depth):
+        idx = np.ascontiguousarray(index, dtype=np.int32)
+        pal = np.ascontiguousarray(palette, dtype=np.int32)
+        out = np.zeros((nb_channels,) + idx.shape, dtype=np.int32)
+        self._chk(self.L.jxlh_palette(self._ctx, _addr(idx), idx.size, _addr(pal), num_colors, pal.shape[1],
+                                      nb_channels, bit_depth, _addr(out)), "palette")
+        return out
+
+    def unsqueeze(self, horizontal, avg, res, out_w, out_h):
+        avg = np.ascontiguousarray(avg, dtype=np.int32)
+        res = np.ascontiguousarray(res, dtype=np.int32)
+        out = np.zeros((out_h, out_w), dtype=np.int32)
+        self._chk(self.L.jxlh_unsqueeze(self._ctx, 1 if horizontal else 0, _addr(avg), avg.shape[1],
+                                        _addr(res) if res.size else None, max(res.shape[1], 1) if res.ndim == 2 else 1,
+                                        out_w, out_h, _addr(out), out_w), "unsqueeze")
+        return out

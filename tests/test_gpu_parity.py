@@ -1,0 +1,239 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every kernel, called through the C ABI,
+against the CPU oracle on the same seeded inputs.
+
+Bar: bit-exact vs the oracle's FMA build (which models the reference's AVX2 back-end; GPU
+v_fma_f32 == fmaf) for all float stages, within the reference's own tolerance table vs the
+unfused build and the f64 definitions; bit-exact for the integer Modular transforms.
+"""
+import numpy as np
+import pytest
+
+from helpers import (bit_equal, diff_report, forward_squeeze_h, forward_squeeze_v, gpu_params_from,
+                     oracle_params_from, run_gpu_frame, run_oracle_frame, upload_frame)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from jxl_rs_amd import Context
+    c = Context(0, n_slots=2)
+    yield c
+    c.close()
+
+
+def _sparse_coeffs(rng, n, size, scale=1.0, density=0.15):
+    c = rng.normal(size=(n, size)).astype(np.float32) * scale
+    mask = rng.random((n, size)) < density
+    return np.where(mask, c, 0).astype(np.float32)
+
+
+# ------------------------------------------------------------------ K1 cores, per type
+@pytest.mark.parametrize("ttype", list(range(27)))
+def test_transform_to_pixels_bit_exact(ctx, oracle, oracle_unfused, kat, ttype):
+    cx, cy = oracle.covered_x[ttype], oracle.covered_y[ttype]
+    size = cx * cy * 64
+    n = 37 if size <= 1024 else (5 if size <= 16384 else 2)
+    rng = np.random.default_rng(100 + ttype)
+    coeffs = _sparse_coeffs(rng, n, size, density=0.3 if size <= 1024 else 0.05)
+    coeffs[0] = rng.uniform(-1, 1, size).astype(np.float32)  # one dense block
+    lf = rng.uniform(0, 1, size=(n, cx * cy)).astype(np.float32)
+    got = ctx.stage_transform_to_pixels(ttype, coeffs, lf)
+    want = np.stack([oracle.transform_to_pixels(ttype, lf[i], coeffs[i]) for i in range(n)])
+    assert got.shape == want.shape
+    assert bit_equal(got, want), f"type {ttype}: {diff_report(got, want)}"
+    # vs the unfused (scalar back-end) build: within the reference's per-shape tolerance
+    tol = {(r, c): t for r, c, t in kat["tolerances"]["idct2d"]}.get((cy * 8, cx * 8), 1e-5)
+    wantu = np.stack([oracle_unfused.transform_to_pixels(ttype, lf[i], coeffs[i]) for i in range(n)])
+    err = np.abs(got.astype(np.float64) - wantu)
+    scale = max(1.0, float(np.abs(wantu).max()))
+    assert err.max() <= 8 * tol * scale, f"type {ttype} vs unfused: {err.max()} (tol {tol}, scale {scale})"
+
+
+# ------------------------------------------------------------------ stage hooks
+@pytest.mark.parametrize("size", [(2, 2), (37, 23), (256, 64), (500, 300)])
+def test_gaborish_stage_bit_exact(ctx, oracle, size):
+    w, h = size
+    rng = np.random.default_rng(w * 7 + h)
+    img = rng.uniform(-1, 1, size=(h, w)).astype(np.float32)
+    got = ctx.stage_gaborish(img, 0.115169525, 0.061248592)
+    want = oracle.gaborish(img, 0.115169525, 0.061248592)
+    assert bit_equal(got, want), diff_report(got, want)
+
+
+def test_gaborish_checkerboard_golden(ctx, kat):
+    g = kat["gaborish_checkerboard"]
+    out = ctx.stage_gaborish(np.array(g["input"], dtype=np.float32), g["w1"], g["w2"])
+    assert np.abs(out - np.array(g["output"])).max() < g["tol"]
+
+
+@pytest.mark.parametrize("stage", [0, 1, 2])
+@pytest.mark.parametrize("size", [(9, 7), (40, 24), (333, 129)])
+def test_epf_stage_bit_exact(ctx, oracle, stage, size):
+    w, h = size
+    rng = np.random.default_rng(stage * 100 + w)
+    planes = [rng.uniform(0, 1, size=(h, w)).astype(np.float32) * s for s in (0.05, 1.0, 1.0)]
+    # sigma image like epf/test.rs: random, including values below MIN_SIGMA (passthrough)
+    sig = -rng.uniform(0.05, 6.0, size=((h + 7) // 8, (w + 7) // 8)).astype(np.float32)
+    po = oracle.default_params(w, h)
+    pg = ctx.default_params(w, h)
+    got = ctx.stage_epf(stage, pg, planes, sig)
+    want = oracle.epf(stage, po, planes, sig)
+    for c in range(3):
+        assert bit_equal(got[c], want[c]), f"epf{stage} ch{c}: {diff_report(got[c], want[c])}"
+
+
+@pytest.mark.parametrize("size", [(2, 2), (3, 3), (65, 40), (128, 128)])
+def test_lf_smoothing_bit_exact(ctx, oracle, size):
+    w, h = size
+    rng = np.random.default_rng(w + h)
+    lf = [rng.uniform(0, 1, size=(h, w)).astype(np.float32) * s for s in (0.02, 1.0, 1.0)]
+    got = ctx.stage_lf_smooth(ctx.default_params(w * 8, h * 8), lf)
+    want = oracle.adaptive_lf_smoothing(oracle.default_params(w * 8, h * 8), lf)
+    for c in range(3):
+        assert bit_equal(got[c], want[c]), f"ch{c}: {diff_report(got[c], want[c])}"
+
+
+# ------------------------------------------------------------------ whole frames
+FRAME_CASES = [
+    # (w, h, mix, opts)
+    (256, 256, "MIX_DCT8", dict(epf_iters=2, gab=True, lf_smoothing=True)),     # BASELINE config 1
+    (520, 300, "MIX_D1", dict(epf_iters=0, gab=True, lf_smoothing=True)),       # config-2 style
+    (520, 300, "MIX_D1", dict(epf_iters=2, gab=True, lf_smoothing=True)),       # config-3 style
+    (777, 513, "MIX_ALL", dict(epf_iters=3, gab=True, lf_smoothing=True)),      # config-5 style, ragged
+    (512, 512, "MIX_ALL", dict(epf_iters=1, gab=False, lf_smoothing=False)),
+    (9, 9, "MIX_D1", dict(epf_iters=2, gab=True, lf_smoothing=True)),           # tiny: smoothing skipped path
+    (1024, 768, "MIX_D1", dict(epf_iters=2, gab=True, lf_smoothing=True)),
+]
+
+
+@pytest.mark.parametrize("case", FRAME_CASES, ids=lambda c: f"{c[0]}x{c[1]}-{c[2]}-epf{c[3]['epf_iters']}")
+def test_vardct_frame_bit_exact(ctx, oracle, case):
+    from jxl_rs_amd import synth
+    w, h, mix, opts = case
+    wl = synth.make_vardct(w, h, mix=getattr(synth, mix), seed=w + h, **opts)
+    want, want_lf = run_oracle_frame(oracle, wl)
+    got, got_lf = run_gpu_frame(ctx, wl)
+    for c in range(3):
+        assert bit_equal(got_lf[c], want_lf[c]), f"LF ch{c}: {diff_report(got_lf[c], want_lf[c])}"
+    for c in range(3):
+        assert bit_equal(got[c], want[c]), f"plane {c}: {diff_report(got[c], want[c])}"
+
+
+def test_vardct_frame_prefilter_planes_and_determinism(ctx, oracle):
+    """K1 alone (no filters) vs jxlo_decode_group, and run-to-run bit-identical output
+    (result independent of launch geometry / scheduling)."""
+    from jxl_rs_amd import synth
+    wl = synth.make_vardct(600, 520, mix=synth.MIX_ALL, seed=9, epf_iters=0, gab=False, lf_smoothing=True)
+    want, _ = run_oracle_frame(oracle, wl)
+    a, _ = run_gpu_frame(ctx, wl)
+    b, _ = run_gpu_frame(ctx, wl)
+    for c in range(3):
+        assert bit_equal(a[c], want[c]), f"plane {c}: {diff_report(a[c], want[c])}"
+        assert bit_equal(a[c], b[c])
+
+
+def test_vardct_frame_vs_unfused_oracle_within_tolerance(ctx, oracle_unfused):
+    """Against the scalar-back-end behaviour of the reference (unfused mul_add)."""
+    from jxl_rs_amd import synth
+    wl = synth.make_vardct(520, 300, mix=synth.MIX_D1, seed=4)
+    want, _ = run_oracle_frame(oracle_unfused, wl)
+    got, _ = run_gpu_frame(ctx, wl)
+    for c in range(3):
+        err = np.abs(got[c].astype(np.float64) - want[c])
+        assert err.max() < 2e-5, f"plane {c}: max abs err {err.max()}"
+
+
+def test_invalid_transform_id_is_reported(ctx):
+    from jxl_rs_amd import synth, JxlHipError
+    from jxl_rs_amd import lib
+    wl = synth.make_vardct(256, 256, mix=synth.MIX_DCT8, seed=1)
+    wl.transform_map = wl.transform_map.copy()
+    wl.transform_map[3, 3] = 0x80 | 40
+    upload_frame(ctx, wl)
+    ctx.frame_run()
+    with pytest.raises(JxlHipError) as e:
+        ctx.sync()
+    assert e.value.status == lib.ERR_INVALID_TRANSFORM
+
+
+def test_call_order_errors(ctx):
+    from jxl_rs_amd import lib, Context
+    c2 = Context(0, 1)
+    try:
+        assert c2.L.jxlh_frame_run(c2._ctx, 0, 1) == lib.ERR_BAD_STATE
+        assert c2.L.jxlh_submit_group(c2._ctx, 0, 0, c2._ctx, 1) == lib.ERR_BAD_STATE
+        p = c2.default_params(64, 64)
+        c2.frame_begin(p)
+        assert c2.L.jxlh_frame_run(c2._ctx, 0, 1) == lib.ERR_BAD_STATE  # no dequant tables yet
+        assert c2.L.jxlh_submit_group(c2._ctx, 5, 0, c2._ctx, 1) == lib.ERR_INVALID_ARGUMENT  # bad slot
+        assert c2.L.jxlh_submit_group(c2._ctx, 0, 99, c2._ctx, 1) == lib.ERR_INVALID_ARGUMENT  # bad group
+        assert c2.L.jxlh_submit_group(c2._ctx, 0, 0, c2._ctx, 0) == lib.ERR_UNSUPPORTED  # partial render
+    finally:
+        c2.close()
+
+
+# ------------------------------------------------------------------ Modular
+@pytest.mark.parametrize("op", range(7))
+def test_rct_bit_exact(ctx, oracle, op):
+    rng = np.random.default_rng(op)
+    n = 10007
+    planes = [rng.integers(-70000, 70000, size=n).astype(np.int32) for _ in range(3)]
+    planes[0][:4] = [2**31 - 1, -2**31, 2**31 - 1, 0]  # wrapping arithmetic
+    planes[1][:4] = [2**31 - 1, -2**31, 1, -1]
+    for perm in range(6):
+        got = ctx.rct(planes, op, perm)
+        want = oracle.rct(planes, op, perm)
+        for c in range(3):
+            assert np.array_equal(got[c], want[c]), (op, perm, c)
+
+
+@pytest.mark.parametrize("bit_depth", [8, 12, 16])
+def test_palette_bit_exact(ctx, oracle, bit_depth):
+    rng = np.random.default_rng(bit_depth)
+    ncol = 200
+    pal = rng.integers(0, 1 << bit_depth, size=(3, ncol)).astype(np.int32)
+    idx = rng.integers(-150, ncol + 64 + 130, size=(61, 47)).astype(np.int32)
+    got = ctx.palette(idx, pal, ncol, 3, bit_depth)
+    want = oracle.palette(idx, pal, ncol, 3, bit_depth)
+    assert np.array_equal(got, want)
+    got1 = ctx.palette(idx, pal[:1], ncol, 1, bit_depth)
+    assert np.array_equal(got1[0], want[0])
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (1, 2), (2, 1), (5, 9), (64, 64), (67, 129), (300, 255)])
+def test_unsqueeze_bit_exact_and_round_trip(ctx, oracle, shape):
+    h, w = shape
+    rng = np.random.default_rng(h * 31 + w)
+    img = rng.integers(-5000, 5000, size=(h, w)).astype(np.int32)
+    a, r = forward_squeeze_h(img)
+    got = ctx.unsqueeze(True, a, r, w, h)
+    assert np.array_equal(got, oracle.unsqueeze_h(a, r, w))
+    assert np.array_equal(got, img)
+    a, r = forward_squeeze_v(img)
+    got = ctx.unsqueeze(False, a, r, w, h)
+    assert np.array_equal(got, oracle.unsqueeze_v(a, r, h))
+    assert np.array_equal(got, img)
+    # arbitrary (non-encoder) residuals: only parity, no round trip
+    avg = rng.integers(0, 256, size=(h, (w + 1) // 2)).astype(np.int32)
+    res = np.round(rng.laplace(0, 30, size=(h, w // 2))).astype(np.int32)
+    assert np.array_equal(ctx.unsqueeze(True, avg, res, w, h), oracle.unsqueeze_h(avg, res, w))
+
+
+def test_modular_chain_config4_style(ctx, oracle):
+    """Default squeeze chain + YCoCg RCT + palette on a mid-size image, bit-exact end to end."""
+    from jxl_rs_amd import synth
+    w, h = 700, 500
+    base, residuals, steps = synth.make_modular_planes(w, h, seed=3)
+    cur_g = [b.copy() for b in base]
+    cur_o = [b.copy() for b in base]
+    for (horizontal, ow, oh), res in zip(steps, residuals):
+        for c in range(3):
+            cur_g[c] = ctx.unsqueeze(horizontal, cur_g[c], res[c], ow, oh)
+            cur_o[c] = oracle.unsqueeze_h(cur_o[c], res[c], ow) if horizontal else oracle.unsqueeze_v(cur_o[c], res[c], oh)
+            assert np.array_equal(cur_g[c], cur_o[c]), (horizontal, ow, oh, c)
+    assert cur_g[0].shape == (h, w)
+    got = ctx.rct(cur_g, 6, 0)
+    want = oracle.rct(cur_o, 6, 0)
+    for c in range(3):
+        assert np.array_equal(got[c], want[c])
