@@ -43,7 +43,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=8192)
-    ap.add_argument("--cpu-sample", type=int, default=2048)
+    ap.add_argument("--cpu-sample", type=int, default=4096)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--strong", action="store_true")
     ap.add_argument("--seed", type=int, default=3)

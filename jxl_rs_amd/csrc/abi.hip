@@ -76,6 +76,7 @@ jxlh_status fail(jxlh_ctx* ctx, hipError_t e, const char* what) {
   if (ctx) {
     ctx->last_error = std::string(what) + ": " + hipGetErrorString(e);
   }
+  (void)hipGetLastError();  // clear the sticky per-thread error so later checks start clean
   return e == hipErrorOutOfMemory ? JXLH_ERR_OUT_OF_MEMORY : JXLH_ERR_DEVICE;
 }
 
@@ -880,7 +881,7 @@ jxlh_status jxlh_unsqueeze(jxlh_ctx* ctx, int32_t horizontal, const int32_t* avg
   }
   jxlh_status st;
   if ((st = stage_in(ctx, ctx->hook_i[0], avg, avg_stride * avg_h))) return st;
-  const size_t res_n = res_stride * res_h;
+  const size_t res_n = (res_w * res_h > 0) ? res_stride * res_h : 0;
   if (res_n) {
     if ((st = stage_in(ctx, ctx->hook_i[1], res, res_n))) return st;
   } else if ((st = ensure(ctx, ctx->hook_i[1], 1))) {
