@@ -571,6 +571,17 @@ jxlh_status jxlh_frame_run(jxlh_ctx* ctx, uint32_t group_row0, uint32_t group_ro
   if (f.epf_iters >= 2) { stages[ns] = 2; borders[ns++] = 1; }
   float* cur[3] = {f.planes[0], f.planes[1], f.planes[2]};
   float* oth[3] = {f.tmp[0], f.tmp[1], f.tmp[2]};
+  if (!(p.flags & JXLH_FRAME_UNFUSED_FILTERS) && ns > 0 && f.epf_iters < 3) {
+    // production path: the whole stage list in one pass over HBM
+    ScopedKernelTimer t(ctx, "k23_fused_filters");
+    if (launch_fused_filters(ctx->stream, f, y_lo, y_hi)) {
+      for (int c = 0; c < 3; c++) {
+        cur[c] = f.tmp[c];
+        oth[c] = f.planes[c];
+      }
+      ns = 0;
+    }
+  }
   for (int s = 0; s < ns; s++) {
     int later = 0;
     for (int k = s + 1; k < ns; k++) later += borders[k];

@@ -104,6 +104,10 @@ FRAME_CASES = [
     (512, 512, "MIX_ALL", dict(epf_iters=1, gab=False, lf_smoothing=False)),
     (9, 9, "MIX_D1", dict(epf_iters=2, gab=True, lf_smoothing=True)),           # tiny: smoothing skipped path
     (1024, 768, "MIX_D1", dict(epf_iters=2, gab=True, lf_smoothing=True)),
+    (333, 77, "MIX_D1", dict(epf_iters=2, gab=False, lf_smoothing=True)),      # fused variant without Gaborish
+    (333, 77, "MIX_D1", dict(epf_iters=1, gab=True, lf_smoothing=True)),       # Gaborish + EPF1
+    (66, 34, "MIX_D1", dict(epf_iters=2, gab=True, lf_smoothing=True)),        # frame edge inside a filter tile
+    (3, 2, "MIX_DCT8", dict(epf_iters=2, gab=True, lf_smoothing=True)),        # frame smaller than every halo
 ]
 
 
@@ -113,11 +117,13 @@ def test_vardct_frame_bit_exact(ctx, oracle, case):
     w, h, mix, opts = case
     wl = synth.make_vardct(w, h, mix=getattr(synth, mix), seed=w + h, **opts)
     want, want_lf = run_oracle_frame(oracle, wl)
-    got, got_lf = run_gpu_frame(ctx, wl)
-    for c in range(3):
-        assert bit_equal(got_lf[c], want_lf[c]), f"LF ch{c}: {diff_report(got_lf[c], want_lf[c])}"
-    for c in range(3):
-        assert bit_equal(got[c], want[c]), f"plane {c}: {diff_report(got[c], want[c])}"
+    # production path (fused Gaborish+EPF kernel) and the one-kernel-per-stage path
+    for flags in (0, 1):
+        got, got_lf = run_gpu_frame(ctx, wl, flags=flags)
+        for c in range(3):
+            assert bit_equal(got_lf[c], want_lf[c]), f"flags={flags} LF ch{c}: {diff_report(got_lf[c], want_lf[c])}"
+        for c in range(3):
+            assert bit_equal(got[c], want[c]), f"flags={flags} plane {c}: {diff_report(got[c], want[c])}"
 
 
 def test_vardct_frame_prefilter_planes_and_determinism(ctx, oracle):
