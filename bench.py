@@ -30,7 +30,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # algorithmic (compulsory) HBM bytes per pixel of each kernel, SURVEY.md section 8(d) / DESIGN.md
 ALGO_BYTES_PER_PX = {
-    "k1_vardct_group": 24.3,   # 12 B coeffs in + 12 B planes out + maps/LF
+    "k1_vardct": 24.3,         # 12 B coeffs in + 12 B planes out + maps/LF (scan + class kernels)
     "k2_gaborish": 24.0,       # 3 ch x (4 in + 4 out)
     "k3a_epf0": 24.06, "k3b_epf1": 24.06, "k3c_epf2": 24.06,
     "k23_fused_filters": 24.06,
@@ -47,6 +47,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--strong", action="store_true")
     ap.add_argument("--seed", type=int, default=3)
+    ap.add_argument("--mix", default="d1", choices=["d1", "dct8", "all"],
+                    help="transform-type mix of the synthetic frame (d1 = BASELINE config 3)")
     args = ap.parse_args()
 
     import numpy as np
@@ -69,7 +71,8 @@ def main():
     size = args.size
     # ---- synthetic frame (config 3): d1-like type mix DCT8..32, CfL, LF smoothing, Gaborish, EPF x2
     t0 = time.time()
-    wl = synth.make_vardct(size, size, mix=synth.MIX_D1, seed=args.seed + rank, unique_groups=24,
+    mix = {"d1": synth.MIX_D1, "dct8": synth.MIX_DCT8, "all": synth.MIX_ALL}[args.mix]
+    wl = synth.make_vardct(size, size, mix=mix, seed=args.seed + rank, unique_groups=24,
                            epf_iters=2, gab=True, lf_smoothing=True)
     gen_s = time.time() - t0
     ctx = jxl_rs_amd.Context(local_rank, n_slots=1)

@@ -61,6 +61,7 @@ struct jxlh_ctx {
   DevBuf<uint8_t> transform_map, epf_map;
   DevBuf<int8_t> ytox, ytob;
   DevBuf<int> error_flag;
+  DevBuf<uint8_t> worklist;
   float* result[3] = {nullptr, nullptr, nullptr};
   // stage hooks scratch
   DevBuf<float> hook_f[8];
@@ -272,6 +273,7 @@ void jxlh_ctx_destroy(jxlh_ctx* ctx) {
   release(ctx->ytox);
   release(ctx->ytob);
   release(ctx->error_flag);
+  release(ctx->worklist);
   for (auto& b : ctx->hook_f) release(b);
   for (auto& b : ctx->hook_i) release(b);
   if (ctx->t0) (void)hipEventDestroy(ctx->t0);
@@ -310,7 +312,9 @@ jxlh_status jxlh_frame_begin(jxlh_ctx* ctx, const jxlh_frame_params* p) {
   f.cmap_stride = (f.xblocks + 7) / 8;
   f.plane_stride = round_up((size_t)f.xblocks * 8, 64);
   const size_t plane_elems = f.plane_stride * (size_t)f.yblocks * 8;
-  if (plane_elems >= (1ull << 31)) return JXLH_ERR_UNSUPPORTED;  // 32-bit pixel offsets in K1
+  // K1 uses 32-bit pixel and coefficient offsets
+  if (plane_elems >= (1ull << 31) || (size_t)f.xgroups * f.ygroups * 3 * kGroupArea >= (1ull << 31))
+    return JXLH_ERR_UNSUPPORTED;
   ctx->ngroups = (size_t)f.xgroups * f.ygroups;
   const size_t nblocks = (size_t)f.xblocks * f.yblocks;
   const size_t ncmap = (size_t)f.cmap_stride * ((f.yblocks + 7) / 8);
@@ -329,6 +333,7 @@ jxlh_status jxlh_frame_begin(jxlh_ctx* ctx, const jxlh_frame_params* p) {
   if ((st = ensure(ctx, ctx->ytox, ncmap)) != JXLH_OK) return st;
   if ((st = ensure(ctx, ctx->ytob, ncmap)) != JXLH_OK) return st;
   if ((st = ensure(ctx, ctx->error_flag, 1)) != JXLH_OK) return st;
+  if ((st = ensure(ctx, ctx->worklist, vardct_worklist_bytes(f))) != JXLH_OK) return st;
   HIPCHK(ctx, hipMemsetAsync(ctx->error_flag.p, 0, sizeof(int), ctx->stream));
   for (int c = 0; c < 3; c++) {
     f.planes[c] = ctx->planes[c].p;
@@ -555,11 +560,8 @@ jxlh_status jxlh_frame_run(jxlh_ctx* ctx, uint32_t group_row0, uint32_t group_ro
   const int gr0 = halo_px > 0 && group_row0 > 0 ? (int)group_row0 - 1 : (int)group_row0;
   const int gr1 = halo_px > 0 && group_row1 < (uint32_t)f.ygroups ? (int)group_row1 + 1 : (int)group_row1;
   {
-    const int ngroups = (gr1 - gr0) * f.xgroups;
-    int split = 1;
-    while (split < 8 && ngroups * split < 2048) split *= 2;
-    ScopedKernelTimer t(ctx, "k1_vardct_group");
-    launch_vardct_groups(ctx->stream, f, gr0, gr1, split, ctx->error_flag.p);
+    ScopedKernelTimer t(ctx, "k1_vardct");
+    launch_vardct_groups(ctx->stream, f, gr0, gr1, ctx->worklist.p, ctx->error_flag.p);
   }
   // ---- stage list of frame/render.rs:569-622
   const int y_lo = (int)group_row0 * kGroupDim;

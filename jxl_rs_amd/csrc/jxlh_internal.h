@@ -89,7 +89,10 @@ void launch_dequant_lf(hipStream_t s, const int32_t* qy, const int32_t* qx, cons
 void launch_lf_smooth(hipStream_t s, const float* const in[3], float* const out[3], int w, int h,
                       const float lf_factors[3]);
 void launch_sigma_map(hipStream_t s, const FrameDev& f, float epf_quant_mul, const float* sharp_lut);
-void launch_vardct_groups(hipStream_t s, const FrameDev& f, int group_row0, int group_row1, int split,
+// K1: work-list scan + per-class kernels over group rows [group_row0, group_row1).
+// worklist_mem: device scratch of vardct_worklist_bytes(f) bytes.
+size_t vardct_worklist_bytes(const FrameDev& f);
+void launch_vardct_groups(hipStream_t s, const FrameDev& f, int group_row0, int group_row1, void* worklist_mem,
                           int* error_flag);
 void launch_gaborish(hipStream_t s, const float* in, float* out, int w, int h, size_t stride, float k0, float k1,
                      float k2, int y0, int y1);

@@ -1,11 +1,13 @@
 // K2+K3 fused: Gaborish -> EPF1 -> EPF2 in ONE pass over HBM (12 B/px in, 12 B/px out).
 //
-// One 256-thread workgroup owns a 64x32 output tile.  The three XYB channels of the tile plus
+// One 512-thread workgroup owns a 56x32 output tile.  The three XYB channels of the tile plus
 // a 4-pixel halo (1 Gaborish + 2 EPF1 + 1 EPF2, jxl/src/render/mod.rs:28-36) are staged once
 // in LDS with 16-byte coalesced loads; every stage then runs LDS -> LDS on a region that
 // shrinks by its own border, and only the last stage writes to HBM.  Each thread produces
-// 4-pixel row strips: taps come in as ds_read_b128/b64, and for EPF1 the 16 absolute
-// differences per pixel and channel collapse to two shared difference maps
+// 4-pixel row strips; a staged row is exactly 16 strips = one 16-lane DPP row, so the strip
+// itself comes in as one conflict-free ds_read_b128 and its left/right neighbour taps are
+// DPP row shifts of the adjacent lanes' registers (no second trip to LDS).  For EPF1 the 16
+// absolute differences per pixel and channel collapse to two shared difference maps
 //   V(x,y) = |P(x,y) - P(x,y+1)|,  H(x,y) = |P(x,y) - P(x+1,y)|
 // (every |a-b| of epf1.rs:100-115 is one of them), summed in the reference's order, so the
 // result stays bit-identical to the per-stage kernels / the oracle.
@@ -23,12 +25,13 @@
 namespace jxlh {
 namespace {
 
-constexpr int kTW = 64, kTH = 32, kB = 4;
-constexpr int kBW = kTW + 2 * kB;  // 72
+constexpr int kTW = 56, kTH = 32, kB = 4;
+constexpr int kBW = kTW + 2 * kB;  // 64 floats = 16 strips = one DPP row of lanes
 constexpr int kBH = kTH + 2 * kB;  // 40
-constexpr int kStrips = kBW / 4;   // 18
+constexpr int kStrips = kBW / 4;   // 16
 constexpr int kPlane = kBW * kBH;  // floats per channel
-constexpr int kFusedThreads = 256;
+constexpr int kFusedThreads = 512;
+static_assert(kStrips == 16, "lane <-> strip mapping relies on 16-lane DPP rows");
 
 struct FusedArgs {
   const float* in[3];
@@ -42,18 +45,25 @@ struct FusedArgs {
   float sm1, bsm1, sm2, bsm2;
 };
 
+// DPP row shifts: lane i takes the value of lane i-1 / i+1 of its 16-lane row (the edge lanes
+// of a row get 0; those taps only feed edge strips nobody consumes).
+__device__ __forceinline__ float dpp_from_left(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float dpp_from_right(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x101, 0xf, 0xf, true));
+}
+
 // 8 consecutive values of a tile row around a strip: v[0..1] = cols bx0-2,-1; v[2..5] = strip;
-// v[6..7] = cols bx0+4,+5.  Edge strips re-read the strip itself (those taps only feed pixels
-// nobody consumes).
+// v[6..7] = cols bx0+4,+5.  Lane l of a 16-lane row holds strip l of one tile row, so the
+// neighbours are the adjacent lanes' strip registers.  Must be called by all 64 lanes.
 __device__ __forceinline__ void load8(const float* __restrict__ row, int bx0, float (&v)[8]) {
   const float4 c = *reinterpret_cast<const float4*>(row + bx0);
-  const int lx = bx0 >= 4 ? bx0 - 2 : bx0;
-  const int rx = bx0 + 4 < kBW ? bx0 + 4 : bx0;
-  const float2 l = *reinterpret_cast<const float2*>(row + lx);
-  const float2 r = *reinterpret_cast<const float2*>(row + rx);
-  v[0] = l.x; v[1] = l.y;
+  v[0] = dpp_from_left(c.z);
+  v[1] = dpp_from_left(c.w);
   v[2] = c.x; v[3] = c.y; v[4] = c.z; v[5] = c.w;
-  v[6] = r.x; v[7] = r.y;
+  v[6] = dpp_from_right(c.x);
+  v[7] = dpp_from_right(c.y);
 }
 __device__ __forceinline__ void load4(const float* __restrict__ row, int bx0, float (&v)[4]) {
   const float4 c = *reinterpret_cast<const float4*>(row + bx0);
@@ -253,7 +263,7 @@ __global__ __launch_bounds__(kFusedThreads) void k23_fused_filters(const FusedAr
   // ---- stage the input tile (region margin = kBorder) with mirrored coordinates
   {
     constexpr int m = kBorder;
-    constexpr int sx0 = (kB - m) / 4, sx1 = (kB + kTW + m + 3) / 4;  // strips touched
+    constexpr int sx0 = 0, sx1 = kStrips;  // whole rows (16-byte aligned, coalesced)
     constexpr int nsx = sx1 - sx0, rows = kTH + 2 * m;
     for (int idx = tid; idx < nsx * rows * 3; idx += kFusedThreads) {
       const int c = idx / (nsx * rows);
@@ -284,9 +294,12 @@ __global__ __launch_bounds__(kFusedThreads) void k23_fused_filters(const FusedAr
     margin -= border;
     const bool last = margin == 0;
     const int rows = kTH + 2 * margin;
-    const int s0 = last ? kB / 4 : 0, ns = last ? kTW / 4 : kStrips;
-    for (int t = tid; t < rows * ns; t += kFusedThreads) {
-      const int by = kB - margin + t / ns, bx0 = (s0 + t % ns) * 4;
+    // every row is 16 strips; whole waves run (DPP needs all lanes), stores are guarded
+    for (int t0 = 0; t0 < rows * kStrips; t0 += kFusedThreads) {
+      if (t0 + (tid & ~63) >= rows * kStrips) break;  // wave-uniform: nothing left for this wave
+      const int t = t0 + tid;
+      const bool live = t < rows * kStrips;
+      const int by = kB - margin + (live ? t / kStrips : 0), bx0 = (t % kStrips) * 4;
       const int fy = ty0 - kB + by, fx0 = tx0 - kB + bx0;
       float4 o[3];
       if constexpr (STAGE == 0) {
@@ -302,8 +315,9 @@ __global__ __launch_bounds__(kFusedThreads) void k23_fused_filters(const FusedAr
           epf2_strip(src, by, bx0, fx0, fy, sigma, a, o);
         }
       }
+      if (!live) continue;
       if (last) {
-        if (fy < a.y1 && fy < a.h && fx0 < a.w) {
+        if (bx0 >= kB && bx0 < kB + kTW && fy < a.y1 && fy < a.h && fx0 < a.w) {
 #pragma unroll
           for (int c = 0; c < 3; c++) *reinterpret_cast<float4*>(a.out[c] + (size_t)fy * a.stride + fx0) = o[c];
         }

@@ -1,0 +1,549 @@
+// K1 -- dequantisation + chroma-from-luma + LLF-from-LF + variable-size IDCT for a frame.
+//
+// Replaces the `if let Some(pixels)` branch of decode_vardct_group
+// (jxl/src/frame/group.rs:579-611): dequant_block (:137-177), dequant_lane (:100-133),
+// adjust_quant_bias (:85-96), the LF patch copy (:227-235), transform_to_pixels and
+// the copy into the group planes (:237-250).
+//
+// Varblock sizes and positions are data dependent, so the work is first *binned*:
+//
+//   k1_scan   one 256-thread workgroup per 256x256 group: loads the group's 32x32 transform
+//             map, prefix-scans the varblock sizes in raster order -> coefficient offset of
+//             every varblock (the reference lays varblocks back to back in decode order,
+//             group.rs:440, :612), evaluates the per-varblock scalars (inv_global_scale /
+//             raw_quant, the two chroma-from-luma multipliers) and appends one 32-byte work
+//             item per varblock to a frame-wide list per transform class.
+//   k1_dct*   one kernel per class family, sized for that family's registers/LDS: wavefronts
+//             stride over batches of same-shape varblocks; a batch's dequantised coefficients
+//             are staged channel by channel in the wave's private LDS tile with 16-byte
+//             coalesced loads and run through the wave-level cores of varblock_core.h.  For
+//             the small shapes all three channels' loads are issued up front and the dequant
+//             weights stay in registers across batches.
+//   k1_special / k1_large  the 8x8 special transforms and the 64..256 transforms.
+//
+// HBM traffic is the compulsory 12 B/px in + 12 B/px out (+ maps, + 32 B per varblock of
+// work items); arithmetic is f32 in the reference's operation order (bit-exact vs the FMA
+// build of the oracle).  Output is independent of the order in which work items land in
+// the lists (each varblock is independent).
+#include "varblock_core.h"
+#include "varblock_large.h"
+
+namespace jxlh {
+namespace {
+
+constexpr int kWaves = 4;
+constexpr int kThreads = kWaves * 64;
+
+// class ids of the work lists
+enum : int {
+  kClsDct8 = 0, kClsDct16x8, kClsDct8x16, kClsDct16x16, kClsDct32x8, kClsDct8x32, kClsDct32x16, kClsDct16x32,
+  kClsDct32x32, kClsSpecial, kClsLarge, kNumClasses
+};
+
+__host__ __device__ constexpr int class_of_type(int t) {
+  constexpr int lut[27] = {kClsDct8,    kClsSpecial, kClsSpecial, kClsSpecial,  kClsDct16x16, kClsDct32x32, kClsDct16x8,
+                           kClsDct8x16, kClsDct32x8, kClsDct8x32, kClsDct32x16, kClsDct16x32, kClsSpecial,  kClsSpecial,
+                           kClsSpecial, kClsSpecial, kClsSpecial, kClsSpecial,  kClsLarge,    kClsLarge,    kClsLarge,
+                           kClsLarge,   kClsLarge,   kClsLarge,   kClsLarge,    kClsLarge,    kClsLarge};
+  return lut[t];
+}
+// worst-case number of varblocks of a class per 8x8 block of frame area, as a divisor
+__host__ __device__ constexpr int class_min_area(int c) {
+  constexpr int lut[kNumClasses] = {1, 2, 2, 4, 4, 4, 8, 8, 16, 1, 32};
+  return lut[c];
+}
+
+// 32-byte work item
+struct __attribute__((aligned(16))) WorkItem {
+  uint32_t packed;  // bx | by << 5 | off64 << 10 | type << 20   (bx, by in blocks inside the group)
+  uint32_t group;
+  float sdy;        // inv_global_scale / raw_quant          (group.rs:153)
+  float x_cc;       // base_x + ytox / color_factor          (color_correlation_map.rs:76-78)
+  float b_cc;
+  uint32_t pad[3];
+};
+static_assert(sizeof(WorkItem) == 32, "work item layout");
+
+struct BlockInfo {
+  int coef_off;  // offset of the varblock inside the frame's coefficient store (channel X)
+  int px_off;    // y*stride + x of the top-left pixel
+  int lf_off;    // by*xblocks + bx of the top-left block
+  float sdy, x_cc, b_cc;
+};
+
+}  // namespace
+
+struct WorkLists {
+  WorkItem* items[kNumClasses];
+  int* counts;  // kNumClasses ints, zeroed before k1_scan
+};
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k1_scan(const FrameDev f, const WorkLists wl, const int group_row0,
+                                                     int* __restrict__ error_flag) {
+  __shared__ int s_wave_sum[kWaves];
+  __shared__ int s_count[kNumClasses], s_base[kNumClasses];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int group = group_row0 * f.xgroups + blockIdx.x;
+  const int bx0 = (group % f.xgroups) * kGroupBlocks, by0 = (group / f.xgroups) * kGroupBlocks;
+  const int bw = min(kGroupBlocks, f.xblocks - bx0), bh = min(kGroupBlocks, f.yblocks - by0);
+  if (tid < kNumClasses) s_count[tid] = 0;
+  // 4 consecutive blocks of the 32x32 raster per thread
+  int sizes[4], types[4], local = 0;
+  const int by = tid >> 3, bx4 = (tid & 7) * 4;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int bx = bx4 + i;
+    uint8_t raw = 0;
+    if (bx < bw && by < bh) raw = f.transform_map[(size_t)(by0 + by) * f.xblocks + bx0 + bx];
+    const int type = raw & 127;
+    int sz = 0;
+    if (raw >= 128) {  // first (top-left) block of a varblock, group.rs:468-473
+      if (type < JXLH_NUM_TRANSFORMS) {
+        sz = covered_x(type) * covered_y(type);
+      } else {
+        atomicExch(error_flag, JXLH_ERR_INVALID_TRANSFORM);  // Error::InvalidVarDCTTransform
+      }
+    }
+    sizes[i] = sz;
+    types[i] = type;
+    local += sz;
+  }
+  int incl = local;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int n = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += n;
+  }
+  if (lane == 63) s_wave_sum[wave] = incl;
+  __syncthreads();
+  int off64 = incl - local;
+#pragma unroll
+  for (int w = 0; w < kWaves; w++)
+    if (w < wave) off64 += s_wave_sum[w];
+  // per-class rank of every varblock in raster order (stable: neighbouring blocks stay
+  // neighbours in the lists -> contiguous coefficient reads, full-line pixel writes)
+  int slot[4];
+  {
+    int mine[kNumClasses];
+#pragma unroll
+    for (int c = 0; c < kNumClasses; c++) mine[c] = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int cls = sizes[i] > 0 ? class_of_type(types[i]) : -1;
+      slot[i] = 0;
+#pragma unroll
+      for (int c = 0; c < kNumClasses; c++) {
+        if (cls == c) {
+          slot[i] = mine[c];
+          mine[c]++;
+        }
+      }
+    }
+    __shared__ int s_wcls[kWaves][kNumClasses];
+    int excl[kNumClasses];
+#pragma unroll
+    for (int c = 0; c < kNumClasses; c++) {
+      int inc = mine[c];
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int n = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += n;
+      }
+      excl[c] = inc - mine[c];
+      if (lane == 63) s_wcls[wave][c] = inc;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < kNumClasses; c++) {
+      int woff = 0, total = 0;
+#pragma unroll
+      for (int w = 0; w < kWaves; w++) {
+        if (w < wave) woff += s_wcls[w][c];
+        total += s_wcls[w][c];
+      }
+      excl[c] += woff;
+      if (tid == c) s_count[c] = total;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int cls = sizes[i] > 0 ? class_of_type(types[i]) : -1;
+#pragma unroll
+      for (int c = 0; c < kNumClasses; c++)
+        if (cls == c) slot[i] += excl[c];
+    }
+  }
+  __syncthreads();
+  if (tid < kNumClasses) s_base[tid] = s_count[tid] > 0 ? atomicAdd(&wl.counts[tid], s_count[tid]) : 0;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    if (sizes[i] > 0) {
+      const int gbx = bx0 + bx4 + i, gby = by0 + by;
+      const int rq = f.raw_quant[(size_t)gby * f.xblocks + gbx];
+      const int ci = (gby / kColorTileBlocks) * f.cmap_stride + gbx / kColorTileBlocks;
+      WorkItem it;
+      it.packed = (uint32_t)(bx4 + i) | ((uint32_t)by << 5) | ((uint32_t)off64 << 10) | ((uint32_t)types[i] << 20);
+      it.group = (uint32_t)group;
+      it.sdy = f.inv_global_scale / (float)(uint32_t)rq;
+      it.x_cc = f.base_x + (float)f.ytox[ci] / f.color_factor;
+      it.b_cc = f.base_b + (float)f.ytob[ci] / f.color_factor;
+      it.pad[0] = it.pad[1] = it.pad[2] = 0;
+      const int cls = class_of_type(types[i]);
+      wl.items[cls][s_base[cls] + slot[i]] = it;
+    }
+    off64 += sizes[i];
+  }
+}
+
+__device__ __forceinline__ void decode_item(const FrameDev& f, const WorkItem& it, BlockInfo* bi) {
+  const int bx = it.packed & 31, by = (it.packed >> 5) & 31, off64 = (it.packed >> 10) & 1023;
+  const int g = (int)it.group;
+  const int gbx = (g % f.xgroups) * kGroupBlocks + bx, gby = (g / f.xgroups) * kGroupBlocks + by;
+  bi->coef_off = g * 3 * kGroupArea + off64 * 64;  // < 2^31: jxlh_frame_begin bounds the frame
+  bi->px_off = (int)((size_t)(gby * 8) * f.plane_stride + (size_t)gbx * 8);
+  bi->lf_off = gby * f.xblocks + gbx;
+  bi->sdy = it.sdy;
+  bi->x_cc = it.x_cc;
+  bi->b_cc = it.b_cc;
+}
+
+// group.rs:85-96
+__device__ __forceinline__ float adjust_quant_bias(int q, float bias_c, float bias3) {
+  const float quant = (float)q;
+  const float adjusted = quant - bias3 / quant;
+  return (q > -2 && q < 2) ? quant * bias_c : adjusted;
+}
+
+// Dequantise four consecutive coefficients of channel CH (0 = X, 1 = Y, 2 = B); dy = the
+// dequantised Y at the same positions (in for X/B, out for Y).  dequant_lane, group.rs:100-133.
+template <int CH>
+__device__ __forceinline__ float4 dequant4(const FrameDev& f, const int4 q, const float4 t, const BlockInfo& bi,
+                                           float (&dy)[4]) {
+  const float bias3 = f.quant_biases[3];
+  const float bias = f.quant_biases[CH];
+  float sd = bi.sdy;
+  if constexpr (CH == 0) sd = bi.sdy * f.x_dm;
+  if constexpr (CH == 2) sd = bi.sdy * f.b_dm;
+  const int qq[4] = {q.x, q.y, q.z, q.w};
+  const float tt[4] = {t.x, t.y, t.z, t.w};
+  float r[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const float mul = tt[i] * sd;
+    const float v = adjust_quant_bias(qq[i], bias, bias3) * mul;
+    if constexpr (CH == 1) {
+      dy[i] = v;
+      r[i] = v;
+    } else if constexpr (CH == 0) {
+      r[i] = __builtin_fmaf(bi.x_cc, dy[i], v);
+    } else {
+      r[i] = __builtin_fmaf(bi.b_cc, dy[i], v);
+    }
+  }
+  return make_float4(r[0], r[1], r[2], r[3]);
+}
+
+template <class S>
+__device__ __forceinline__ void stage4(float* __restrict__ buf, int b, int k, float4 v) {
+  if constexpr (S::kWide) {
+    buf[m_addr<S>(b, k)] = v.x;
+    buf[m_addr<S>(b, k + 1)] = v.y;
+    buf[m_addr<S>(b, k + 2)] = v.z;
+    buf[m_addr<S>(b, k + 3)] = v.w;
+  } else {
+    *reinterpret_cast<float4*>(buf + m_addr<S>(b, k)) = v;
+  }
+}
+
+// All batches of one DCT shape assigned to this wave.  PREFETCH: issue the coefficient
+// loads of all three channels before touching any (small shapes; 3*E/4 int4 in flight per lane).
+template <class S, bool PREFETCH>
+__device__ __forceinline__ void run_dct_class(const FrameDev& f, const WorkItem* __restrict__ items, int count, int type,
+                                              float* __restrict__ buf, BlockInfo* __restrict__ binfo, int gwave,
+                                              int nwaves, int lane) {
+  constexpr int NCH = S::E / 4;  // 16-byte chunks per lane per channel
+  const int q = quant_table_for_type(type);
+  const float* __restrict__ table = f.tables + f.table_offset[q];
+  const int tsize = quant_table_size(q);
+  const int nbatches = (count + S::NB - 1) / S::NB;
+  // the weights a lane needs do not depend on the batch
+  float4 tw[PREFETCH ? 3 : 1][NCH];
+  if constexpr (PREFETCH) {
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+      for (int j = 0; j < NCH; j++)
+        tw[c][j] = *reinterpret_cast<const float4*>(table + c * tsize + ((j * 64 + lane) * 4) % S::N);
+  }
+  for (int batch = gwave; batch < nbatches; batch += nwaves) {
+    const int nb = min(S::NB, count - batch * S::NB);
+    if (lane < nb) {
+      const WorkItem it = items[batch * S::NB + lane];
+      decode_item(f, it, &binfo[lane]);
+    }
+    wave_sync();
+    int4 qv[PREFETCH ? 3 : 1][NCH];
+    if constexpr (PREFETCH) {
+#pragma unroll
+      for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int j = 0; j < NCH; j++) {
+          const int fl = (j * 64 + lane) * 4;
+          const int b = fl / S::N, k = fl % S::N;
+          qv[c][j] = make_int4(0, 0, 0, 0);
+          if (b < nb) qv[c][j] = *reinterpret_cast<const int4*>(f.coeffs + binfo[b].coef_off + c * kGroupArea + k);
+        }
+    }
+    float dy[S::E];
+    auto run_channel = [&](auto ch_tag) {
+      constexpr int CH = decltype(ch_tag)::value;
+#pragma unroll
+      for (int j = 0; j < NCH; j++) {
+        const int fl = (j * 64 + lane) * 4;
+        const int b = fl / S::N, k = fl % S::N;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        float d4[4] = {dy[j * 4], dy[j * 4 + 1], dy[j * 4 + 2], dy[j * 4 + 3]};
+        if (b < nb) {
+          const BlockInfo bi = binfo[b];
+          int4 qq;
+          float4 tt;
+          if constexpr (PREFETCH) {
+            qq = qv[CH][j];
+            tt = tw[CH][j];
+          } else {
+            qq = *reinterpret_cast<const int4*>(f.coeffs + bi.coef_off + CH * kGroupArea + k);
+            tt = *reinterpret_cast<const float4*>(table + CH * tsize + k);
+          }
+          v = dequant4<CH>(f, qq, tt, bi, d4);
+        }
+        if constexpr (CH == 1) {
+          dy[j * 4] = d4[0];
+          dy[j * 4 + 1] = d4[1];
+          dy[j * 4 + 2] = d4[2];
+          dy[j * 4 + 3] = d4[3];
+        }
+        stage4<S>(buf, b, k, v);
+      }
+      wave_sync();
+      const float* __restrict__ lfp = f.lf[CH];
+      float* __restrict__ plane = f.planes[CH];
+      const size_t stride = f.plane_stride;
+      const int xblocks = f.xblocks;
+      idct_batch<S>(
+          buf, nb, lane, [&](int b, int y, int x) { return lfp[binfo[b].lf_off + y * xblocks + x]; },
+          [&](int b, int y, int x, float val) { plane[(size_t)binfo[b].px_off + (size_t)y * stride + x] = val; });
+    };
+    // channel order of the reference: Y, X, B (group.rs:223)
+    run_channel(std::integral_constant<int, 1>{});
+    run_channel(std::integral_constant<int, 0>{});
+    run_channel(std::integral_constant<int, 2>{});
+  }
+}
+
+using S8x8 = Shape<8, 8>;
+using S16x16 = Shape<16, 16>;
+using S32x32 = Shape<32, 32>;
+using S16x8 = Shape<16, 8>;
+using S8x16 = Shape<8, 16>;
+using S32x8 = Shape<32, 8, 4>;  // tall 32x8 at NB = 8 would need a 3136-word tile
+using S8x32 = Shape<8, 32>;
+using S32x16 = Shape<32, 16>;
+using S16x32 = Shape<16, 32>;
+
+constexpr int kTileA = S8x8::kTile;                                               // 832 words
+constexpr int kTileB = cmax(cmax(S16x8::kTile, S8x16::kTile), S16x16::kTile);     // 1600
+constexpr int kTileC = cmax(cmax(cmax(S32x8::kTile, S8x32::kTile), cmax(S32x16::kTile, S16x32::kTile)),
+                            S32x32::kTile);                                       // 2624
+
+// family A: DCT 8x8 -- the dominant transform
+__global__ __launch_bounds__(kThreads) void k1_dct8(const FrameDev f, const WorkLists wl) {
+  __shared__ __attribute__((aligned(16))) float s_buf[kWaves * kTileA];
+  __shared__ BlockInfo s_binfo[kWaves][S8x8::NB];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  run_dct_class<S8x8, true>(f, wl.items[kClsDct8], wl.counts[kClsDct8], 0, s_buf + wave * kTileA, s_binfo[wave],
+                            blockIdx.x * kWaves + wave, gridDim.x * kWaves, lane);
+}
+
+// family B: 16x8, 8x16, 16x16
+__global__ __launch_bounds__(kThreads) void k1_dct16(const FrameDev f, const WorkLists wl) {
+  __shared__ __attribute__((aligned(16))) float s_buf[kWaves * kTileB];
+  __shared__ BlockInfo s_binfo[kWaves][8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* buf = s_buf + wave * kTileB;
+  const int gw = blockIdx.x * kWaves + wave, nw = gridDim.x * kWaves;
+  run_dct_class<S16x8, true>(f, wl.items[kClsDct16x8], wl.counts[kClsDct16x8], 6, buf, s_binfo[wave], gw, nw, lane);
+  run_dct_class<S8x16, true>(f, wl.items[kClsDct8x16], wl.counts[kClsDct8x16], 7, buf, s_binfo[wave], gw, nw, lane);
+  run_dct_class<S16x16, true>(f, wl.items[kClsDct16x16], wl.counts[kClsDct16x16], 4, buf, s_binfo[wave], gw, nw, lane);
+}
+
+// family C: everything with a 32-point side
+__global__ __launch_bounds__(kThreads) void k1_dct32(const FrameDev f, const WorkLists wl) {
+  __shared__ __attribute__((aligned(16))) float s_buf[kWaves * kTileC];
+  __shared__ BlockInfo s_binfo[kWaves][8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* buf = s_buf + wave * kTileC;
+  const int gw = blockIdx.x * kWaves + wave, nw = gridDim.x * kWaves;
+  run_dct_class<S32x8, false>(f, wl.items[kClsDct32x8], wl.counts[kClsDct32x8], 8, buf, s_binfo[wave], gw, nw, lane);
+  run_dct_class<S8x32, false>(f, wl.items[kClsDct8x32], wl.counts[kClsDct8x32], 9, buf, s_binfo[wave], gw, nw, lane);
+  run_dct_class<S32x16, false>(f, wl.items[kClsDct32x16], wl.counts[kClsDct32x16], 10, buf, s_binfo[wave], gw, nw,
+                               lane);
+  run_dct_class<S16x32, false>(f, wl.items[kClsDct16x32], wl.counts[kClsDct16x32], 11, buf, s_binfo[wave], gw, nw,
+                               lane);
+  run_dct_class<S32x32, false>(f, wl.items[kClsDct32x32], wl.counts[kClsDct32x32], 5, buf, s_binfo[wave], gw, nw,
+                               lane);
+}
+
+// family D: the nine 8x8 special transform types (IDENTITY, DCT2X2, DCT4X4, DCT4X8, DCT8X4, AFV0-3).
+// Work items of different types share one list; each lane transforms its own block.
+__global__ __launch_bounds__(kThreads) void k1_special(const FrameDev f, const WorkLists wl) {
+  __shared__ float s_buf[kWaves * 2 * kSpecNB * kSpecPitch];
+  __shared__ BlockInfo s_binfo[kWaves][kSpecNB];
+  __shared__ int s_type[kWaves][kSpecNB];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const WorkItem* __restrict__ items = wl.items[kClsSpecial];
+  const int count = wl.counts[kClsSpecial];
+  float* tin = s_buf + wave * 2 * kSpecNB * kSpecPitch;
+  float* tout = tin + kSpecNB * kSpecPitch;
+  BlockInfo* binfo = s_binfo[wave];
+  int* btype = s_type[wave];
+  const int nbatches = (count + kSpecNB - 1) / kSpecNB;
+  constexpr int NCH = kSpecNB * 64 / 256;
+  for (int batch = blockIdx.x * kWaves + wave; batch < nbatches; batch += gridDim.x * kWaves) {
+    const int nb = min(kSpecNB, count - batch * kSpecNB);
+    if (lane < nb) {
+      const WorkItem it = items[batch * kSpecNB + lane];
+      decode_item(f, it, &binfo[lane]);
+      btype[lane] = (int)(it.packed >> 20) & 31;
+    }
+    wave_sync();
+    float dy[4 * NCH];
+    auto run_channel = [&](auto ch_tag) {
+      constexpr int CH = decltype(ch_tag)::value;
+#pragma unroll
+      for (int j = 0; j < NCH; j++) {
+        const int fl = (j * 64 + lane) * 4;
+        const int b = fl / 64, k = fl % 64;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        float d4[4] = {dy[j * 4], dy[j * 4 + 1], dy[j * 4 + 2], dy[j * 4 + 3]};
+        if (b < nb) {
+          const BlockInfo bi = binfo[b];
+          const int qt = quant_table_for_type(btype[b]);
+          const float* tab = f.tables + f.table_offset[qt] + CH * 64;
+          const int4 qv = *reinterpret_cast<const int4*>(f.coeffs + bi.coef_off + CH * kGroupArea + k);
+          const float4 tv = *reinterpret_cast<const float4*>(tab + k);
+          v = dequant4<CH>(f, qv, tv, bi, d4);
+        }
+        if constexpr (CH == 1) {
+          dy[j * 4] = d4[0];
+          dy[j * 4 + 1] = d4[1];
+          dy[j * 4 + 2] = d4[2];
+          dy[j * 4 + 3] = d4[3];
+        }
+        float* dst = tin + b * kSpecPitch + k;
+        dst[0] = v.x;
+        dst[1] = v.y;
+        dst[2] = v.z;
+        dst[3] = v.w;
+      }
+      wave_sync();
+      if (lane < nb) {
+        float* c = tin + lane * kSpecPitch;
+        c[0] = f.lf[CH][binfo[lane].lf_off];  // transform_buffer[0] = lf[0]
+        special_8x8(btype[lane], c, tout + lane * kSpecPitch);
+      }
+      wave_sync();
+      float* __restrict__ plane = f.planes[CH];
+#pragma unroll
+      for (int j = 0; j < NCH; j++) {
+        const int fl = (j * 64 + lane) * 4;
+        const int b = fl / 64, p = fl % 64;
+        if (b < nb) {
+          const float* src = tout + b * kSpecPitch + p;
+          float* dst = plane + (size_t)binfo[b].px_off + (size_t)(p / 8) * f.plane_stride + (p % 8);
+          *reinterpret_cast<float4*>(dst) = make_float4(src[0], src[1], src[2], src[3]);
+        }
+      }
+      wave_sync();
+    };
+    run_channel(std::integral_constant<int, 1>{});
+    run_channel(std::integral_constant<int, 0>{});
+    run_channel(std::integral_constant<int, 2>{});
+  }
+}
+
+// family E: DCT64X64 .. DCT256X256, one varblock per workgroup at a time
+__global__ __launch_bounds__(kLargeThreads) void k1_large(const FrameDev f, const WorkLists wl) {
+  __shared__ float s_lds[2 * (kLargeSlab + 256) + 1024];
+  const int count = wl.counts[kClsLarge];
+  const int tid = threadIdx.x;
+  const float b0 = f.quant_biases[0], b1 = f.quant_biases[1], b2 = f.quant_biases[2], b3 = f.quant_biases[3];
+  for (int e = blockIdx.x; e < count; e += gridDim.x) {
+    const WorkItem it = wl.items[kClsLarge][e];
+    BlockInfo bi;
+    decode_item(f, it, &bi);
+    const int type = (int)(it.packed >> 20) & 31;
+    const int q = quant_table_for_type(type);
+    const float* __restrict__ table = f.tables + f.table_offset[q];
+    const int tsize = quant_table_size(q);
+    const int32_t* __restrict__ qx = f.coeffs + bi.coef_off;
+    const int32_t* __restrict__ qy = qx + kGroupArea;
+    const int32_t* __restrict__ qb = qx + 2 * kGroupArea;
+    const float sdy = bi.sdy, sdx = bi.sdy * f.x_dm, sdb = bi.sdy * f.b_dm;
+    const float x_cc = bi.x_cc, b_cc = bi.b_cc;
+    auto deq_y = [&](int k) { return adjust_quant_bias(qy[k], b1, b3) * (table[tsize + k] * sdy); };
+    large_varblock_channel(type, deq_y, f.lf[1] + bi.lf_off, f.xblocks, f.planes[1] + bi.px_off, f.plane_stride,
+                           s_lds, tid);
+    large_varblock_channel(
+        type, [&](int k) { return __builtin_fmaf(x_cc, deq_y(k), adjust_quant_bias(qx[k], b0, b3) * (table[k] * sdx)); },
+        f.lf[0] + bi.lf_off, f.xblocks, f.planes[0] + bi.px_off, f.plane_stride, s_lds, tid);
+    large_varblock_channel(
+        type,
+        [&](int k) {
+          return __builtin_fmaf(b_cc, deq_y(k), adjust_quant_bias(qb[k], b2, b3) * (table[2 * tsize + k] * sdb));
+        },
+        f.lf[2] + bi.lf_off, f.xblocks, f.planes[2] + bi.px_off, f.plane_stride, s_lds, tid);
+  }
+}
+
+}  // namespace
+
+// ---- host side -----------------------------------------------------------------------------
+size_t vardct_worklist_bytes(const FrameDev& f) {
+  const size_t nblocks = (size_t)f.xblocks * f.yblocks;
+  size_t items = 0;
+  for (int c = 0; c < kNumClasses; c++) items += nblocks / class_min_area(c) + 1;
+  return items * sizeof(WorkItem) + 256;
+}
+
+void launch_vardct_groups(hipStream_t s, const FrameDev& f, int group_row0, int group_row1, void* worklist_mem,
+                          int* error_flag) {
+  const int ngroups = (group_row1 - group_row0) * f.xgroups;
+  if (ngroups <= 0) return;
+  // carve the work-list memory: [counts (256 B)] [class 0 items] [class 1 items] ...
+  WorkLists wl;
+  wl.counts = reinterpret_cast<int*>(worklist_mem);
+  char* p = reinterpret_cast<char*>(worklist_mem) + 256;
+  const size_t nblocks = (size_t)f.xblocks * f.yblocks;
+  for (int c = 0; c < kNumClasses; c++) {
+    wl.items[c] = reinterpret_cast<WorkItem*>(p);
+    p += (nblocks / class_min_area(c) + 1) * sizeof(WorkItem);
+  }
+  (void)hipMemsetAsync(wl.counts, 0, kNumClasses * sizeof(int), s);
+  hipLaunchKernelGGL(k1_scan, dim3(ngroups), dim3(kThreads), 0, s, f, wl, group_row0, error_flag);
+  // grids: enough waves to fill the chip; kernels stride over their lists (counts are device-side)
+  const int nblk = ngroups * kGroupBlocks * kGroupBlocks;
+  auto grid_for = [](long work_items, int items_per_wg, int cap) {
+    long g = (work_items + items_per_wg - 1) / items_per_wg;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+  };
+  hipLaunchKernelGGL(k1_dct8, dim3(grid_for(nblk, kWaves * S8x8::NB * 2, 4096)), dim3(kThreads), 0, s, f, wl);
+  hipLaunchKernelGGL(k1_dct16, dim3(grid_for(nblk / 2, kWaves * 8 * 2, 2048)), dim3(kThreads), 0, s, f, wl);
+  hipLaunchKernelGGL(k1_dct32, dim3(grid_for(nblk / 4, kWaves * 4 * 2, 2048)), dim3(kThreads), 0, s, f, wl);
+  hipLaunchKernelGGL(k1_special, dim3(grid_for(nblk, kWaves * kSpecNB * 4, 1024)), dim3(kThreads), 0, s, f, wl);
+  hipLaunchKernelGGL(k1_large, dim3(grid_for(nblk / 32, 1, 1024)), dim3(kLargeThreads), 0, s, f, wl);
+}
+
+}  // namespace jxlh
