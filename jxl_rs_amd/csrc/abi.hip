@@ -559,6 +559,9 @@ jxlh_status jxlh_frame_run(jxlh_ctx* ctx, uint32_t group_row0, uint32_t group_ro
                       (f.epf_iters >= 2 ? 1 : 0);
   const int gr0 = halo_px > 0 && group_row0 > 0 ? (int)group_row0 - 1 : (int)group_row0;
   const int gr1 = halo_px > 0 && group_row1 < (uint32_t)f.ygroups ? (int)group_row1 + 1 : (int)group_row1;
+  // K1 writes the 8x8-tiled layout whenever the fused filter kernel is its only consumer
+  const bool will_fuse = !(p.flags & JXLH_FRAME_UNFUSED_FILTERS) && f.epf_iters < 3 && (f.gab || f.epf_iters > 0);
+  f.tiled = will_fuse ? 1 : 0;
   {
     ScopedKernelTimer t(ctx, "k1_vardct");
     launch_vardct_groups(ctx->stream, f, gr0, gr1, ctx->worklist.p, ctx->error_flag.p);

@@ -80,7 +80,34 @@ struct FrameDev {
   float epf_sm[3], epf_bsm[3];    // per pass: sigma_scale*1.65 and *border_sad_mul
   int epf_iters;
   int gab;
+  // Layout of planes[] as written by K1: 0 = raster (row pitch plane_stride); 1 = 8x8-tiled,
+  // column-major inside the block: pixel (x, y) of block (bx, by) lives at
+  // (by*xblocks + bx)*64 + (x&7)*8 + (y&7).  Used between K1 and the fused filter kernel: every
+  // varblock then completes whole 256-byte chunks instead of sharing 128-byte lines with its
+  // neighbours, and an IDCT lane (which owns a pixel column) stores 32 contiguous bytes.
+  int tiled;
 };
+
+// pixel (x, y) relative to a varblock's top-left pixel, for either layout:
+//   addr = base + xoff(x) + (y >> 3) * ystep_blk + (y & 7) * ystep8
+struct PixLayout {
+  int ystep8;     // raster: plane_stride      tiled: 1
+  int ystep_blk;  // raster: 8 * plane_stride  tiled: xblocks * 64
+  int tiled;
+  __host__ __device__ int xoff(int x) const { return tiled ? ((x >> 3) * 64 + (x & 7) * 8) : x; }
+  __host__ __device__ int at(int x, int y) const { return xoff(x) + (y >> 3) * ystep_blk + (y & 7) * ystep8; }
+};
+__host__ __device__ inline PixLayout pix_layout(const FrameDev& f) {
+  PixLayout l;
+  l.tiled = f.tiled;
+  l.ystep8 = f.tiled ? 1 : (int)f.plane_stride;
+  l.ystep_blk = f.tiled ? f.xblocks * 64 : 8 * (int)f.plane_stride;
+  return l;
+}
+// offset of the top-left pixel of block (gbx, gby)
+__host__ __device__ inline int block_px_offset(const FrameDev& f, int gbx, int gby) {
+  return f.tiled ? (gby * f.xblocks + gbx) * 64 : (int)((size_t)(gby * 8) * f.plane_stride + (size_t)gbx * 8);
+}
 
 // kernels (k_*.hip); all take an explicit stream
 void launch_dequant_lf(hipStream_t s, const int32_t* qy, const int32_t* qx, const int32_t* qb, size_t qstride,

@@ -43,7 +43,14 @@ struct FusedArgs {
   float gab_k[3][3];
   float scale[3];
   float sm1, bsm1, sm2, bsm2;
+  int tiled_in, xblocks;  // input layout (see FrameDev::tiled)
 };
+
+// float offset of frame pixel (fx, fy) in an input plane
+__device__ __forceinline__ size_t in_offset(const FusedArgs& a, int fx, int fy) {
+  return a.tiled_in ? ((size_t)((fy >> 3) * a.xblocks + (fx >> 3)) * 64 + (size_t)((fx & 7) * 8 + (fy & 7)))
+                    : ((size_t)fy * a.stride + (size_t)fx);
+}
 
 // DPP row shifts: lane i takes the value of lane i-1 / i+1 of its 16-lane row (the edge lanes
 // of a row get 0; those taps only feed edge strips nobody consumes).
@@ -57,8 +64,22 @@ __device__ __forceinline__ float dpp_from_right(float v) {
 // 8 consecutive values of a tile row around a strip: v[0..1] = cols bx0-2,-1; v[2..5] = strip;
 // v[6..7] = cols bx0+4,+5.  Lane l of a 16-lane row holds strip l of one tile row, so the
 // neighbours are the adjacent lanes' strip registers.  Must be called by all 64 lanes.
+// LDS tiles are 16-byte aligned and every strip starts on a 4-float boundary; say so, or the
+// compiler splits the access into ds_read2_b32 pairs (2-way bank conflicts).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 lds_load4(const float* p) {
+  f32x4 v = *reinterpret_cast<const f32x4*>(__builtin_assume_aligned(p, 16));
+  // keep the 128-bit load whole: without this the optimiser scalarises it and the backend
+  // re-pairs the pieces as ds_read2_b32 {0,3},{1,2} -> 4-way bank conflicts
+  asm volatile("" : "+v"(v));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void lds_store4(float* p, float4 v) {
+  *reinterpret_cast<float4*>(__builtin_assume_aligned(p, 16)) = v;
+}
+
 __device__ __forceinline__ void load8(const float* __restrict__ row, int bx0, float (&v)[8]) {
-  const float4 c = *reinterpret_cast<const float4*>(row + bx0);
+  const float4 c = lds_load4(row + bx0);
   v[0] = dpp_from_left(c.z);
   v[1] = dpp_from_left(c.w);
   v[2] = c.x; v[3] = c.y; v[4] = c.z; v[5] = c.w;
@@ -66,7 +87,7 @@ __device__ __forceinline__ void load8(const float* __restrict__ row, int bx0, fl
   v[7] = dpp_from_right(c.y);
 }
 __device__ __forceinline__ void load4(const float* __restrict__ row, int bx0, float (&v)[4]) {
-  const float4 c = *reinterpret_cast<const float4*>(row + bx0);
+  const float4 c = lds_load4(row + bx0);
   v[0] = c.x; v[1] = c.y; v[2] = c.z; v[3] = c.w;
 }
 
@@ -255,7 +276,19 @@ __global__ __launch_bounds__(kFusedThreads) void k23_fused_filters(const FusedAr
   __shared__ __attribute__((aligned(16))) float s_a[3 * kPlane];
   __shared__ __attribute__((aligned(16))) float s_b[3 * kPlane];
   const int tid = threadIdx.x;
-  const int tx0 = blockIdx.x * kTW, ty0 = a.y0 + blockIdx.y * kTH;
+  // blockIdx.x enumerates tiles so that the workgroups one XCD receives (ids congruent mod 8)
+  // walk along a tile row: neighbouring tiles share 128-byte output lines and halo input
+  // lines, which then meet in the same (non-coherent) L2.
+  const int tiles_x = (a.w + kTW - 1) / kTW;
+  const int tiles_y = (a.y1 - a.y0 + kTH - 1) / kTH;
+  int tile_x, tile_y;
+  {
+    const int b = blockIdx.x, k = b & 7, j = b >> 3;
+    tile_y = (j / tiles_x) * 8 + k;
+    tile_x = j % tiles_x;
+  }
+  if (tile_y >= tiles_y) return;
+  const int tx0 = tile_x * kTW, ty0 = a.y0 + tile_y * kTH;
   const bool edge = tx0 - kB < 0 || ty0 - kB < 0 || tx0 + kTW + kB > a.w || ty0 + kTH + kB > a.h;
   constexpr int kBorder = (GAB ? 1 : 0) + (E1 ? 2 : 0) + (E2 ? 1 : 0);
   static_assert(kBorder >= 1 && kBorder <= kB, "at least one stage");
@@ -263,25 +296,54 @@ __global__ __launch_bounds__(kFusedThreads) void k23_fused_filters(const FusedAr
   // ---- stage the input tile (region margin = kBorder) with mirrored coordinates
   {
     constexpr int m = kBorder;
-    constexpr int sx0 = 0, sx1 = kStrips;  // whole rows (16-byte aligned, coalesced)
-    constexpr int nsx = sx1 - sx0, rows = kTH + 2 * m;
-    for (int idx = tid; idx < nsx * rows * 3; idx += kFusedThreads) {
-      const int c = idx / (nsx * rows);
-      const int rem = idx % (nsx * rows);
-      const int by = kB - m + rem / nsx, bx0 = (sx0 + rem % nsx) * 4;
-      const int fy = mirror(ty0 - kB + by, a.h);
-      const int fx0 = tx0 - kB + bx0;
-      const float* __restrict__ row = a.in[c] + (size_t)fy * a.stride;
-      float4 v;
-      if (fx0 >= 0 && fx0 + 3 < a.w) {
-        v = *reinterpret_cast<const float4*>(row + fx0);
-      } else {
-        v.x = row[mirror(fx0, a.w)];
-        v.y = row[mirror(fx0 + 1, a.w)];
-        v.z = row[mirror(fx0 + 2, a.w)];
-        v.w = row[mirror(fx0 + 3, a.w)];
+    constexpr int rows = kTH + 2 * m;
+    if (!edge && a.tiled_in) {
+      // interior tile, 8x8-tiled column-major input: a lane fetches 4 rows of one pixel column
+      // (16 contiguous bytes); a wave covers 32 columns x 8 rows = four whole 256-byte blocks
+      // per channel, and scatters into the raster LDS tile with conflict-free ds_write_b32.
+      constexpr int yg0 = (kB - m) / 4, ygn = (rows + 2 * ((kB - m) % 4) + 3) / 4;  // 4-row groups touched
+      for (int idx = tid; idx < kBW * ygn; idx += kFusedThreads) {
+        // idx -> (pair of row groups, half of the columns): lanes 0-31 / 32-63 = the two 4-row
+        // halves of the same 32 columns
+        const int w64 = idx >> 6, l = idx & 63;
+        const int xh = w64 % 2, ypair = w64 / 2;
+        const int bx = xh * 32 + (l & 31), yg = yg0 + ypair * 2 + (l >> 5);
+        if (yg * 4 >= kBH) continue;
+        const int by = yg * 4;
+        const size_t off = in_offset(a, tx0 - kB + bx, ty0 - kB + by);
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+          const float4 v = *reinterpret_cast<const float4*>(a.in[c] + off);
+          float* d = s_a + c * kPlane + by * kBW + bx;
+          d[0] = v.x;
+          d[kBW] = v.y;
+          d[2 * kBW] = v.z;
+          d[3 * kBW] = v.w;
+        }
       }
-      *reinterpret_cast<float4*>(s_a + c * kPlane + by * kBW + bx0) = v;
+    } else if (!edge) {  // interior tile, raster input: pure 16-byte coalesced rows
+      for (int idx = tid; idx < kStrips * rows; idx += kFusedThreads) {
+        const int by = kB - m + idx / kStrips, bx0 = (idx % kStrips) * 4;
+        const size_t off = in_offset(a, tx0 - kB + bx0, ty0 - kB + by);
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+          lds_store4(s_a + c * kPlane + by * kBW + bx0, *reinterpret_cast<const float4*>(a.in[c] + off));
+      }
+    } else {
+      for (int idx = tid; idx < kStrips * rows; idx += kFusedThreads) {
+        const int by = kB - m + idx / kStrips, bx0 = (idx % kStrips) * 4;
+        const int fy = mirror(ty0 - kB + by, a.h);
+        const int fx0 = tx0 - kB + bx0;
+        const int x0 = mirror(fx0, a.w), x1 = mirror(fx0 + 1, a.w), x2 = mirror(fx0 + 2, a.w),
+                  x3 = mirror(fx0 + 3, a.w);
+        const size_t o0 = in_offset(a, x0, fy), o1 = in_offset(a, x1, fy), o2 = in_offset(a, x2, fy),
+                     o3 = in_offset(a, x3, fy);
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+          const float* __restrict__ pl = a.in[c];
+          lds_store4(s_a + c * kPlane + by * kBW + bx0, make_float4(pl[o0], pl[o1], pl[o2], pl[o3]));
+        }
+      }
     }
   }
   __syncthreads();
@@ -323,7 +385,7 @@ __global__ __launch_bounds__(kFusedThreads) void k23_fused_filters(const FusedAr
         }
       } else {
 #pragma unroll
-        for (int c = 0; c < 3; c++) *reinterpret_cast<float4*>(dst + c * kPlane + by * kBW + bx0) = o[c];
+        for (int c = 0; c < 3; c++) lds_store4(dst + c * kPlane + by * kBW + bx0, o[c]);
       }
     }
     if (!last) {
@@ -344,7 +406,8 @@ __global__ __launch_bounds__(kFusedThreads) void k23_fused_filters(const FusedAr
 
 template <bool GAB, bool E1, bool E2>
 void launch_variant(hipStream_t s, const FusedArgs& a) {
-  const dim3 grid((a.w + kTW - 1) / kTW, (a.y1 - a.y0 + kTH - 1) / kTH);
+  const int tiles_x = (a.w + kTW - 1) / kTW, tiles_y = (a.y1 - a.y0 + kTH - 1) / kTH;
+  const dim3 grid(tiles_x * ((tiles_y + 7) / 8) * 8);
   hipLaunchKernelGGL((k23_fused_filters<GAB, E1, E2>), grid, dim3(kFusedThreads), 0, s, a);
 }
 
@@ -375,6 +438,8 @@ bool launch_fused_filters(hipStream_t s, const FrameDev& f, int y0, int y1) {
   a.bsm1 = f.epf_bsm[1];
   a.sm2 = f.epf_sm[2];
   a.bsm2 = f.epf_bsm[2];
+  a.tiled_in = f.tiled;
+  a.xblocks = f.xblocks;
   if (gab && e1 && e2) launch_variant<true, true, true>(s, a);
   else if (gab && e1) launch_variant<true, true, false>(s, a);
   else if (gab) launch_variant<true, false, false>(s, a);

@@ -37,7 +37,10 @@ __global__ __launch_bounds__(64) void k_t2p_dct(uint32_t n, const float* __restr
     wave_sync();
     idct_batch<S>(
         buf, nb, lane, [&](int b, int y, int x) { return lf[(size_t)(base + b) * (CY * CX) + y * CX + x]; },
-        [&](int b, int y, int x, float val) { pixels[(size_t)(base + b) * S::N + y * S::C + x] = val; });
+        [&](int b, int x, int yb, const float(&v)[8]) {
+#pragma unroll
+          for (int i = 0; i < 8; i++) pixels[(size_t)(base + b) * S::N + (yb * 8 + i) * S::C + x] = v[i];
+        });
   }
 }
 
@@ -73,8 +76,8 @@ __global__ __launch_bounds__(kLargeThreads) void k_t2p_large(int type, uint32_t 
   for (uint32_t blk = blockIdx.x; blk < n; blk += gridDim.x) {
     const float* c = coeffs + blk * N;
     large_varblock_channel(
-        type, [&](int k) { return c[k]; }, lf + (size_t)blk * cx * cy, cx, pixels + blk * N, (size_t)cx * 8, lds,
-        threadIdx.x);
+        type, [&](int k) { return c[k]; }, lf + (size_t)blk * cx * cy, cx, pixels + blk * N,
+        PixLayout{cx * 8, 8 * cx * 8, 0}, lds, threadIdx.x);
   }
 }
 

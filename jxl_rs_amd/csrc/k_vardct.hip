@@ -203,7 +203,7 @@ __device__ __forceinline__ void decode_item(const FrameDev& f, const WorkItem& i
   const int g = (int)it.group;
   const int gbx = (g % f.xgroups) * kGroupBlocks + bx, gby = (g / f.xgroups) * kGroupBlocks + by;
   bi->coef_off = g * 3 * kGroupArea + off64 * 64;  // < 2^31: jxlh_frame_begin bounds the frame
-  bi->px_off = (int)((size_t)(gby * 8) * f.plane_stride + (size_t)gbx * 8);
+  bi->px_off = block_px_offset(f, gbx, gby);
   bi->lf_off = gby * f.xblocks + gbx;
   bi->sdy = it.sdy;
   bi->x_cc = it.x_cc;
@@ -330,11 +330,20 @@ __device__ __forceinline__ void run_dct_class(const FrameDev& f, const WorkItem*
       wave_sync();
       const float* __restrict__ lfp = f.lf[CH];
       float* __restrict__ plane = f.planes[CH];
-      const size_t stride = f.plane_stride;
+      const PixLayout lay = pix_layout(f);
       const int xblocks = f.xblocks;
       idct_batch<S>(
           buf, nb, lane, [&](int b, int y, int x) { return lfp[binfo[b].lf_off + y * xblocks + x]; },
-          [&](int b, int y, int x, float val) { plane[(size_t)binfo[b].px_off + (size_t)y * stride + x] = val; });
+          [&](int b, int x, int yb, const float(&v)[8]) {
+            float* dst = plane + binfo[b].px_off + lay.xoff(x) + yb * lay.ystep_blk;
+            if (lay.tiled) {  // the lane's 8 rows are contiguous: two 16-byte stores
+              *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+              *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            } else {
+#pragma unroll
+              for (int i = 0; i < 8; i++) dst[i * lay.ystep8] = v[i];
+            }
+          });
     };
     // channel order of the reference: Y, X, B (group.rs:223)
     run_channel(std::integral_constant<int, 1>{});
@@ -461,9 +470,15 @@ __global__ __launch_bounds__(kThreads) void k1_special(const FrameDev f, const W
         const int fl = (j * 64 + lane) * 4;
         const int b = fl / 64, p = fl % 64;
         if (b < nb) {
-          const float* src = tout + b * kSpecPitch + p;
-          float* dst = plane + (size_t)binfo[b].px_off + (size_t)(p / 8) * f.plane_stride + (p % 8);
-          *reinterpret_cast<float4*>(dst) = make_float4(src[0], src[1], src[2], src[3]);
+          if (f.tiled) {  // memory order inside the block is x*8 + y
+            const int x = p / 8, y0 = p % 8;
+            const float* src = tout + b * kSpecPitch + y0 * 8 + x;
+            *reinterpret_cast<float4*>(plane + binfo[b].px_off + p) = make_float4(src[0], src[8], src[16], src[24]);
+          } else {
+            const float* src = tout + b * kSpecPitch + p;
+            float* dst = plane + binfo[b].px_off + (p / 8) * (int)f.plane_stride + (p % 8);
+            *reinterpret_cast<float4*>(dst) = make_float4(src[0], src[1], src[2], src[3]);
+          }
         }
       }
       wave_sync();
@@ -494,17 +509,17 @@ __global__ __launch_bounds__(kLargeThreads) void k1_large(const FrameDev f, cons
     const float sdy = bi.sdy, sdx = bi.sdy * f.x_dm, sdb = bi.sdy * f.b_dm;
     const float x_cc = bi.x_cc, b_cc = bi.b_cc;
     auto deq_y = [&](int k) { return adjust_quant_bias(qy[k], b1, b3) * (table[tsize + k] * sdy); };
-    large_varblock_channel(type, deq_y, f.lf[1] + bi.lf_off, f.xblocks, f.planes[1] + bi.px_off, f.plane_stride,
-                           s_lds, tid);
+    const PixLayout lay = pix_layout(f);
+    large_varblock_channel(type, deq_y, f.lf[1] + bi.lf_off, f.xblocks, f.planes[1] + bi.px_off, lay, s_lds, tid);
     large_varblock_channel(
         type, [&](int k) { return __builtin_fmaf(x_cc, deq_y(k), adjust_quant_bias(qx[k], b0, b3) * (table[k] * sdx)); },
-        f.lf[0] + bi.lf_off, f.xblocks, f.planes[0] + bi.px_off, f.plane_stride, s_lds, tid);
+        f.lf[0] + bi.lf_off, f.xblocks, f.planes[0] + bi.px_off, lay, s_lds, tid);
     large_varblock_channel(
         type,
         [&](int k) {
           return __builtin_fmaf(b_cc, deq_y(k), adjust_quant_bias(qb[k], b2, b3) * (table[2 * tsize + k] * sdb));
         },
-        f.lf[2] + bi.lf_off, f.xblocks, f.planes[2] + bi.px_off, f.plane_stride, s_lds, tid);
+        f.lf[2] + bi.lf_off, f.xblocks, f.planes[2] + bi.px_off, lay, s_lds, tid);
   }
 }
 

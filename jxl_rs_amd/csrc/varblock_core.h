@@ -122,7 +122,7 @@ __device__ __forceinline__ void llf_from_lf(float (&a)[CY * CX]) {
 
 // Runs LLF + both IDCT passes on a staged batch.
 //   lf_load(b, y, x) -> LF sample of block b at (row y, col x) of its cy x cx patch
-//   store(b, y, x, value)   pixel (row y, col x) of block b
+//   store8(b, x, yb, v)     pixels (rows 8*yb .. 8*yb+7, col x) of block b
 // Lanes of blocks b >= nb compute on whatever is in the tile and are masked at the store.
 template <class S, class LfLoad, class Store>
 __device__ __forceinline__ void idct_batch(float* __restrict__ buf, int nb, int lane, LfLoad lf_load,
@@ -179,7 +179,11 @@ __device__ __forceinline__ void idct_batch(float* __restrict__ buf, int nb, int 
     idct1d<R, true>(col);
     if (b < nb) {
 #pragma unroll
-      for (int y = 0; y < R; y++) store(b, y, x, col[y]);
+      for (int yb = 0; yb < R / 8; yb++) {
+        const float v8[8] = {col[yb * 8],     col[yb * 8 + 1], col[yb * 8 + 2], col[yb * 8 + 3],
+                             col[yb * 8 + 4], col[yb * 8 + 5], col[yb * 8 + 6], col[yb * 8 + 7]};
+        store(b, x, yb, v8);
+      }
     }
   }
   wave_sync();  // tile may be restaged

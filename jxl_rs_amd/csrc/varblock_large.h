@@ -152,11 +152,11 @@ __device__ __forceinline__ float adjust_quant_bias_s(int q, float bias_c, float 
 
 // One channel of one large varblock.  coef(k) returns the dequantised coefficient at stored
 // index k; lf points at the cy x cx LF patch (row pitch lf_stride); plane at the top-left
-// output pixel (row pitch `stride`).  lds: >= 2*(kLargeSlab + 256) + 1024 floats.
+// output pixel (addressing given by `lay`).  lds: >= 2*(kLargeSlab + 256) + 1024 floats.
 // All threads of the (256-thread) workgroup must call with identical arguments.
 template <class CoefFn>
 __device__ void large_varblock_channel(int type, CoefFn coef, const float* __restrict__ lf, int lf_stride,
-                                       float* __restrict__ plane, size_t stride, float* lds, int tid) {
+                                       float* __restrict__ plane, const PixLayout lay, float* lds, int tid) {
   const int cx = covered_x(type), cy = covered_y(type);
   const int R = cy * 8, C = cx * 8;
   const bool wide = R < C;
@@ -191,7 +191,7 @@ __device__ void large_varblock_channel(int type, CoefFn coef, const float* __res
       // park tmp[x][v] at pixel (row v, col x) of the output rectangle
       for (int idx = tid; idx < C * LV; idx += kLargeThreads) {
         const int x = idx % C, line = idx / C;
-        plane[(size_t)(v0 + line) * stride + x] = res[x * Lp + line];
+        plane[lay.at(x, v0 + line)] = res[x * Lp + line];
       }
       __syncthreads();
     }
@@ -205,57 +205,19 @@ __device__ void large_varblock_channel(int type, CoefFn coef, const float* __res
     for (int x0 = 0; x0 < C; x0 += LX) {
       for (int idx = tid; idx < R * LX; idx += kLargeThreads) {
         const int line = idx % LX, v = idx / LX;
-        bufA[v * Lp + line] = plane[(size_t)v * stride + x0 + line];
+        bufA[v * Lp + line] = plane[lay.at(x0 + line, v)];
       }
       __syncthreads();
       float* res = lds_idct_dyn(R, bufA, bufB, LX, Lp, tid);
       for (int idx = tid; idx < R * LX; idx += kLargeThreads) {
         const int line = idx % LX, y = idx / LX;
-        plane[(size_t)y * stride + x0 + line] = res[y * Lp + line];
+        plane[lay.at(x0 + line, y)] = res[y * Lp + line];
       }
       __syncthreads();
     }
   }
   __threadfence_block();
   __syncthreads();
-}
-
-// Frame path: dequantisation + chroma-from-luma feed the cores (group.rs:100-177).
-__device__ inline void process_large_class(const FrameDev& f, int gbx0, int gby0,
-                                           const int32_t* __restrict__ coef_group, int type,
-                                           const uint32_t* __restrict__ list, int count, float* lds, int tid) {
-  const int q = quant_table_for_type(type);
-  const float* __restrict__ table = f.tables + f.table_offset[q];
-  const int tsize = quant_table_size(q);
-  for (int e = 0; e < count; e++) {
-    const uint32_t ent = list[e];
-    const int bx = ent & 31, by = (ent >> 5) & 31, off64 = (ent >> 10) & 1023;
-    const int gbx = gbx0 + bx, gby = gby0 + by;
-    const int lf_off = gby * f.xblocks + gbx;
-    const size_t px_off = (size_t)(gby * 8) * f.plane_stride + (size_t)gbx * 8;
-    const float sdy = f.inv_global_scale / (float)(uint32_t)f.raw_quant[lf_off];
-    const int ci = (gby / kColorTileBlocks) * f.cmap_stride + gbx / kColorTileBlocks;
-    const float x_cc = f.base_x + (float)f.ytox[ci] / f.color_factor;
-    const float b_cc = f.base_b + (float)f.ytob[ci] / f.color_factor;
-    const int32_t* __restrict__ qx = coef_group + off64 * 64;
-    const int32_t* __restrict__ qy = coef_group + kGroupArea + off64 * 64;
-    const int32_t* __restrict__ qb = coef_group + 2 * kGroupArea + off64 * 64;
-    const float b0 = f.quant_biases[0], b1 = f.quant_biases[1], b2 = f.quant_biases[2], b3 = f.quant_biases[3];
-    auto deq_y = [&](int k) { return adjust_quant_bias_s(qy[k], b1, b3) * (table[tsize + k] * sdy); };
-    const float sdx = sdy * f.x_dm, sdb = sdy * f.b_dm;
-    // channel order Y, X, B (group.rs:223)
-    large_varblock_channel(type, deq_y, f.lf[1] + lf_off, f.xblocks, f.planes[1] + px_off, f.plane_stride, lds, tid);
-    large_varblock_channel(
-        type,
-        [&](int k) { return __builtin_fmaf(x_cc, deq_y(k), adjust_quant_bias_s(qx[k], b0, b3) * (table[k] * sdx)); },
-        f.lf[0] + lf_off, f.xblocks, f.planes[0] + px_off, f.plane_stride, lds, tid);
-    large_varblock_channel(
-        type,
-        [&](int k) {
-          return __builtin_fmaf(b_cc, deq_y(k), adjust_quant_bias_s(qb[k], b2, b3) * (table[2 * tsize + k] * sdb));
-        },
-        f.lf[2] + lf_off, f.xblocks, f.planes[2] + px_off, f.plane_stride, lds, tid);
-  }
 }
 
 }  // namespace jxlh
