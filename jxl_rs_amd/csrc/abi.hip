@@ -48,6 +48,8 @@ struct jxlh_ctx {
   hipStream_t stream = nullptr;
   std::vector<Slot> slots;
   hipEvent_t t0 = nullptr, t1 = nullptr;
+  K1Streams k1s{};
+  bool k1s_ok = false;
   std::string last_error;
   // frame state
   bool in_frame = false;
@@ -236,6 +238,11 @@ jxlh_status jxlh_ctx_create(int32_t device_ordinal, int32_t n_slots, jxlh_ctx** 
     delete ctx;
     return JXLH_ERR_DEVICE;
   }
+  ctx->k1s_ok = true;
+  for (int i = 0; i < 3; i++)
+    ctx->k1s_ok = ctx->k1s_ok && hipStreamCreateWithFlags(&ctx->k1s.aux[i], hipStreamNonBlocking) == hipSuccess;
+  for (int i = 0; i < 4; i++)
+    ctx->k1s_ok = ctx->k1s_ok && hipEventCreateWithFlags(&ctx->k1s.ev[i], hipEventDisableTiming) == hipSuccess;
   ctx->slots.resize(n_slots);
   for (auto& s : ctx->slots) {
     if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess ||
@@ -276,6 +283,10 @@ void jxlh_ctx_destroy(jxlh_ctx* ctx) {
   release(ctx->worklist);
   for (auto& b : ctx->hook_f) release(b);
   for (auto& b : ctx->hook_i) release(b);
+  for (int i = 0; i < 3; i++)
+    if (ctx->k1s.aux[i]) (void)hipStreamDestroy(ctx->k1s.aux[i]);
+  for (int i = 0; i < 4; i++)
+    if (ctx->k1s.ev[i]) (void)hipEventDestroy(ctx->k1s.ev[i]);
   if (ctx->t0) (void)hipEventDestroy(ctx->t0);
   if (ctx->t1) (void)hipEventDestroy(ctx->t1);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -564,7 +575,8 @@ jxlh_status jxlh_frame_run(jxlh_ctx* ctx, uint32_t group_row0, uint32_t group_ro
   f.tiled = will_fuse ? 1 : 0;
   {
     ScopedKernelTimer t(ctx, "k1_vardct");
-    launch_vardct_groups(ctx->stream, f, gr0, gr1, ctx->worklist.p, ctx->error_flag.p);
+    launch_vardct_groups(ctx->stream, ctx->k1s_ok ? &ctx->k1s : nullptr, f, gr0, gr1, ctx->worklist.p,
+                         ctx->error_flag.p);
   }
   // ---- stage list of frame/render.rs:569-622
   const int y_lo = (int)group_row0 * kGroupDim;

@@ -272,7 +272,7 @@ __device__ __forceinline__ void mirror_fill(float* __restrict__ buf, int m, int 
 }
 
 template <bool GAB, bool E1, bool E2>
-__global__ __launch_bounds__(kFusedThreads) void k23_fused_filters(const FusedArgs a) {
+__global__ __launch_bounds__(kFusedThreads, 4) void k23_fused_filters(const FusedArgs a) {
   __shared__ __attribute__((aligned(16))) float s_a[3 * kPlane];
   __shared__ __attribute__((aligned(16))) float s_b[3 * kPlane];
   const int tid = threadIdx.x;

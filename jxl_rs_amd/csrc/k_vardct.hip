@@ -533,8 +533,8 @@ size_t vardct_worklist_bytes(const FrameDev& f) {
   return items * sizeof(WorkItem) + 256;
 }
 
-void launch_vardct_groups(hipStream_t s, const FrameDev& f, int group_row0, int group_row1, void* worklist_mem,
-                          int* error_flag) {
+void launch_vardct_groups(hipStream_t s, const K1Streams* aux, const FrameDev& f, int group_row0, int group_row1,
+                          void* worklist_mem, int* error_flag) {
   const int ngroups = (group_row1 - group_row0) * f.xgroups;
   if (ngroups <= 0) return;
   // carve the work-list memory: [counts (256 B)] [class 0 items] [class 1 items] ...
@@ -554,11 +554,25 @@ void launch_vardct_groups(hipStream_t s, const FrameDev& f, int group_row0, int 
     long g = (work_items + items_per_wg - 1) / items_per_wg;
     return (int)(g < 1 ? 1 : (g > cap ? cap : g));
   };
+  hipStream_t s16 = s, s32 = s, smisc = s;
+  if (aux) {  // fork
+    (void)hipEventRecord(aux->ev[0], s);
+    for (int i = 0; i < 3; i++) (void)hipStreamWaitEvent(aux->aux[i], aux->ev[0], 0);
+    s16 = aux->aux[0];
+    s32 = aux->aux[1];
+    smisc = aux->aux[2];
+  }
   hipLaunchKernelGGL(k1_dct8, dim3(grid_for(nblk, kWaves * S8x8::NB * 2, 4096)), dim3(kThreads), 0, s, f, wl);
-  hipLaunchKernelGGL(k1_dct16, dim3(grid_for(nblk / 2, kWaves * 8 * 2, 2048)), dim3(kThreads), 0, s, f, wl);
-  hipLaunchKernelGGL(k1_dct32, dim3(grid_for(nblk / 4, kWaves * 4 * 2, 2048)), dim3(kThreads), 0, s, f, wl);
-  hipLaunchKernelGGL(k1_special, dim3(grid_for(nblk, kWaves * kSpecNB * 4, 1024)), dim3(kThreads), 0, s, f, wl);
-  hipLaunchKernelGGL(k1_large, dim3(grid_for(nblk / 32, 1, 1024)), dim3(kLargeThreads), 0, s, f, wl);
+  hipLaunchKernelGGL(k1_dct16, dim3(grid_for(nblk / 2, kWaves * 8 * 2, 2048)), dim3(kThreads), 0, s16, f, wl);
+  hipLaunchKernelGGL(k1_dct32, dim3(grid_for(nblk / 4, kWaves * 4 * 2, 2048)), dim3(kThreads), 0, s32, f, wl);
+  hipLaunchKernelGGL(k1_special, dim3(grid_for(nblk, kWaves * kSpecNB * 4, 1024)), dim3(kThreads), 0, smisc, f, wl);
+  hipLaunchKernelGGL(k1_large, dim3(grid_for(nblk / 32, 1, 1024)), dim3(kLargeThreads), 0, smisc, f, wl);
+  if (aux) {  // join
+    for (int i = 0; i < 3; i++) {
+      (void)hipEventRecord(aux->ev[1 + i], aux->aux[i]);
+      (void)hipStreamWaitEvent(s, aux->ev[1 + i], 0);
+    }
+  }
 }
 
 }  // namespace jxlh
