@@ -575,8 +575,8 @@ jxlh_status jxlh_frame_run(jxlh_ctx* ctx, uint32_t group_row0, uint32_t group_ro
   f.tiled = will_fuse ? 1 : 0;
   {
     ScopedKernelTimer t(ctx, "k1_vardct");
-    launch_vardct_groups(ctx->stream, ctx->k1s_ok ? &ctx->k1s : nullptr, f, gr0, gr1, ctx->worklist.p,
-                         ctx->error_flag.p);
+    // forked class kernels measured no gain on the d1 mix (event overhead ~ tail savings): run in order
+    launch_vardct_groups(ctx->stream, nullptr, f, gr0, gr1, ctx->worklist.p, ctx->error_flag.p);
   }
   // ---- stage list of frame/render.rs:569-622
   const int y_lo = (int)group_row0 * kGroupDim;
