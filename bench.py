@@ -105,7 +105,7 @@ def main():
         ptrs, stride = ctx.device_planes()
         y0, y1 = row0 * 256, min(row1 * 256, size)
         band = torch.empty((3, per * 256, size), dtype=torch.float32, device=f"cuda:{local_rank}")
-        full = torch.empty((world, 3, per * 256, size), dtype=torch.float32, device=f"cuda:{local_rank}")
+        full = torch.empty((world * 3, per * 256, size), dtype=torch.float32, device=f"cuda:{local_rank}")
         import ctypes as C
         hip = C.CDLL("libamdhip64.so")
         for c in range(3):

@@ -1,0 +1,30 @@
+"""Sharding of one VarDCT frame across ranks: contiguous bands of group rows.
+
+K1 has no cross-group dependence; the filters need a 4..7 pixel halo, which the C ABI provides by
+running K1 on one extra group row on each side of the band (`jxlh_frame_run(row0, row1)`), so no
+GPU<->GPU exchange happens before the final all-gather of the finished planes."""
+
+
+def band_for_rank(ygroups, rank, world):
+    """[row0, row1) group rows owned by `rank`; the last ranks may be empty on tiny frames."""
+    per = (ygroups + world - 1) // world
+    row0 = min(rank * per, ygroups)
+    row1 = min((rank + 1) * per, ygroups)
+    return row0, row1, per
+
+
+def band_pixel_rows(row0, row1, ysize, group_dim=256):
+    return row0 * group_dim, min(row1 * group_dim, ysize)
+
+
+def assemble(gathered, ygroups, world, ysize, group_dim=256):
+    """gathered: [world][3][per*group_dim][xsize] (all_gather output) -> [3][ysize][xsize]."""
+    import numpy as np
+    per = (ygroups + world - 1) // world
+    chunks = []
+    for r in range(world):
+        row0, row1, _ = band_for_rank(ygroups, r, world)
+        y0, y1 = band_pixel_rows(row0, row1, ysize, group_dim)
+        if y1 > y0:
+            chunks.append(gathered[r][:, : y1 - y0, :])
+    return np.concatenate(chunks, axis=1) if chunks else None

@@ -90,6 +90,9 @@ class Oracle:
         L.jxlo_gaborish.argtypes = [fp, C.c_int, C.c_int, C.c_size_t, C.c_float, C.c_float, fp]
         L.jxlo_epf.argtypes = [C.c_int, C.POINTER(FrameParams), pf3, C.c_int, C.c_int, C.c_size_t, fp,
                                C.c_size_t, pf3]
+        L.jxlo_gaborish_rows.argtypes = [fp, C.c_int, C.c_int, C.c_size_t, C.c_float, C.c_float, fp, C.c_int, C.c_int]
+        L.jxlo_epf_rows.argtypes = [C.c_int, C.POINTER(FrameParams), pf3, C.c_int, C.c_int, C.c_size_t, fp,
+                                    C.c_size_t, pf3, C.c_int, C.c_int]
         L.jxlo_vardct_frame.argtypes = [C.POINTER(FrameParams), ip, C.POINTER(C.c_uint8), ip,
                                         C.POINTER(C.c_uint8), C.POINTER(C.c_int8), C.POINTER(C.c_int8),
                                         pf3, pf3, pf3, pf3, C.c_size_t, C.c_int]
@@ -260,6 +263,46 @@ class Oracle:
         self.lib.jxlo_epf(stage, C.byref(p), self._p3(planes), w, h, S, _ptr(sig, C.c_float),
                           sig.shape[1], self._p3(out))
         return out
+
+    def vardct_band(self, p, coeffs, transform_map, raw_quant, epf_map, ytox, ytob, lf, tables, row0, row1):
+        """Band of group rows [row0, row1) the way a rank computes it: K1 on the band plus one halo
+        group row on each side, every stage on the band's rows extended by the later stages' borders
+        (mirrors jxlh_frame_run).  lf must already be smoothed.  Returns 3 planes holding valid data
+        on the band's pixel rows."""
+        bw, bh = p.xsize_blocks, p.ysize_blocks
+        stride = bw * 8
+        xg = (p.xsize + 255) // 256
+        yg = (p.ysize + 255) // 256
+        cur = [np.zeros((bh * 8, stride), dtype=np.float32) for _ in range(3)]
+        oth = [np.zeros((bh * 8, stride), dtype=np.float32) for _ in range(3)]
+        co = np.ascontiguousarray(coeffs, dtype=np.int32)
+        gr0, gr1 = max(row0 - 1, 0), min(row1 + 1, yg)
+        for g in range(gr0 * xg, gr1 * xg):
+            self.decode_group(p, g, co[g], transform_map, raw_quant, ytox, ytob, lf, tables, cur)
+        sigma = self.sigma_map(p, raw_quant, epf_map)
+        stages, borders = [], []
+        if p.gab:
+            stages.append(-1); borders.append(1)
+        if p.epf_iters >= 3:
+            stages.append(0); borders.append(3)
+        if p.epf_iters >= 1:
+            stages.append(1); borders.append(2)
+        if p.epf_iters >= 2:
+            stages.append(2); borders.append(1)
+        y_lo, y_hi = row0 * 256, min(row1 * 256, p.ysize)
+        for i, st in enumerate(stages):
+            later = sum(borders[i + 1:])
+            y0, y1 = max(0, y_lo - later), min(p.ysize, y_hi + later)
+            if st < 0:
+                for c in range(3):
+                    self.lib.jxlo_gaborish_rows(_ptr(cur[c], C.c_float), p.xsize, p.ysize, stride,
+                                                C.c_float(p.gab_w1[c]), C.c_float(p.gab_w2[c]),
+                                                _ptr(oth[c], C.c_float), y0, y1)
+            else:
+                self.lib.jxlo_epf_rows(st, C.byref(p), self._p3(cur), p.xsize, p.ysize, stride,
+                                       _ptr(sigma, C.c_float), sigma.shape[1], self._p3(oth), y0, y1)
+            cur, oth = oth, cur
+        return cur
 
     def vardct_frame(self, p, coeffs, transform_map, raw_quant, epf_map, ytox, ytob, lf, tables,
                      num_threads=1):

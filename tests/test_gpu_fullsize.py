@@ -1,0 +1,83 @@
+"""GPU tests at BASELINE.json's full sizes, through size-independent checks the oracle can afford:
+* 8192x8192 VarDCT d1 full pipeline: one band of group rows (picked by seed) recomputed by the
+  oracle exactly the way a rank would (K1 on band + halo group rows, every stage on the band's rows)
+  must equal the same rows of the GPU's whole-frame output bit for bit; plus run-to-run identity.
+* 8192x8192 Modular: encode -> decode round trips (forward squeeze / forward YCoCg are independent
+  numpy code), i.e. losslessness at full size, for one horizontal and one vertical full-resolution
+  unsqueeze step and the RCT."""
+import numpy as np
+import pytest
+
+from helpers import (bit_equal, diff_report, forward_squeeze_h, forward_squeeze_v, oracle_params_from, run_gpu_frame)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from jxl_rs_amd import Context
+    c = Context(0, n_slots=1)
+    yield c
+    c.close()
+
+
+def test_8k_vardct_band_parity_and_determinism(ctx, oracle):
+    from jxl_rs_amd import synth
+    wl = synth.make_vardct(8192, 8192, mix=synth.MIX_D1, seed=77, unique_groups=16, epf_iters=2)
+    got, got_lf = run_gpu_frame(ctx, wl)
+    p = oracle_params_from(oracle, wl)
+    lf = oracle.adaptive_lf_smoothing(p, oracle.dequant_lf(p, *wl.lf_q))
+    for c in range(3):
+        assert bit_equal(got_lf[c], lf[c]), f"LF ch{c}"
+    row = 13  # one interior band; plus the bottom edge band
+    for row0, row1 in ((row, row + 1), (31, 32)):
+        band = oracle.vardct_band(p, wl.coeffs, wl.transform_map, wl.raw_quant, wl.epf_map, wl.ytox, wl.ytob, lf,
+                                  wl.tables, row0, row1)
+        y0, y1 = row0 * 256, min(row1 * 256, wl.ysize)
+        for c in range(3):
+            a, b = got[c][y0:y1], band[c][y0:y1, : wl.xsize]
+            assert bit_equal(a, b), f"rows {y0}:{y1} ch{c}: {diff_report(a, b)}"
+    ctx.frame_run()
+    ctx.sync()
+    again = ctx.read_planes()
+    for c in range(3):
+        assert bit_equal(again[c], got[c])
+    assert all(np.isfinite(g).all() for g in got)
+
+
+def test_8k_modular_round_trips(ctx, oracle):
+    rng = np.random.default_rng(8192)
+    n = 8192
+    img = rng.integers(0, 256, size=(n, n)).astype(np.int32)
+    img[:, ::7] += rng.integers(-40, 40, size=(n, (n + 6) // 7)).astype(np.int32)
+    a, r = forward_squeeze_h(img)
+    assert np.array_equal(ctx.unsqueeze(True, a, r, n, n), img)
+    a, r = forward_squeeze_v(img)
+    assert np.array_equal(ctx.unsqueeze(False, a, r, n, n), img)
+    # YCoCg-R: forward in numpy, inverse on the device
+    r_, g_, b_ = img, np.roll(img, 3, axis=1), np.roll(img, 5, axis=0)
+    co = r_ - b_
+    tmp = b_ + (co >> 1)
+    cg = g_ - tmp
+    y = tmp + (cg >> 1)
+    out = ctx.rct([y, co, cg], 6, 0)
+    assert np.array_equal(out[0], r_) and np.array_equal(out[1], g_) and np.array_equal(out[2], b_)
+
+
+def test_2k_default_squeeze_chain_round_trip(ctx):
+    """Whole default-squeeze chain (squeeze.rs:39-105) at 2048x1536: forward in numpy, inverse on the GPU."""
+    from jxl_rs_amd import synth
+    rng = np.random.default_rng(5)
+    w, h = 2048, 1536
+    img = rng.integers(0, 1024, size=(h, w)).astype(np.int32)
+    steps, _ = synth.default_squeeze_steps(w, h)
+    cur = img
+    residuals = []
+    for horizontal, ow, oh in reversed(steps):  # encoder order
+        assert cur.shape == (oh, ow)
+        a, r = forward_squeeze_h(cur) if horizontal else forward_squeeze_v(cur)
+        residuals.append(r)
+        cur = a
+    for (horizontal, ow, oh), r in zip(steps, reversed(residuals)):
+        cur = ctx.unsqueeze(horizontal, cur, r, ow, oh)
+    assert np.array_equal(cur, img)

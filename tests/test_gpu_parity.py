@@ -150,6 +150,23 @@ def test_vardct_frame_vs_unfused_oracle_within_tolerance(ctx, oracle_unfused):
         assert err.max() < 2e-5, f"plane {c}: max abs err {err.max()}"
 
 
+def test_band_runs_equal_whole_frame(ctx, oracle):
+    """jxlh_frame_run(row0, row1): a band of group rows (multi-GPU sharding unit) produces exactly
+    the rows the whole-frame run produces -- halo group rows are recomputed, nothing is exchanged."""
+    from jxl_rs_amd import synth
+    wl = synth.make_vardct(520, 700, mix=synth.MIX_D1, seed=31, epf_iters=2)
+    want, _ = run_oracle_frame(oracle, wl)
+    for flags in (0, 1):
+        upload_frame(ctx, wl, flags=flags)
+        for row0, row1 in ((0, 1), (1, 2), (2, 3), (1, 3)):
+            ctx.frame_run(row0, row1)
+            ctx.sync()
+            got = ctx.read_planes()
+            y0, y1 = row0 * 256, min(row1 * 256, wl.ysize)
+            for c in range(3):
+                assert bit_equal(got[c][y0:y1], want[c][y0:y1]), (flags, row0, row1, c, diff_report(got[c][y0:y1], want[c][y0:y1]))
+
+
 def test_invalid_transform_id_is_reported(ctx):
     from jxl_rs_amd import synth, JxlHipError
     from jxl_rs_amd import lib

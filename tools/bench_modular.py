@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""GPU micro-benchmark of the Modular kernels at BASELINE config-4 size (8192x8192 x 3 ch i32),
+device-resident buffers (torch only provides the device memory)."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+import jxl_rs_amd
+from jxl_rs_amd import lib
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+    ctx = jxl_rs_amd.Context(0, 1)
+    L = ctx.L
+    dev = "cuda:0"
+    g = torch.Generator(device=dev).manual_seed(1)
+    planes = [torch.randint(0, 256, (n, n), dtype=torch.int32, device=dev, generator=g) for _ in range(3)]
+    res_h = torch.randint(-8, 9, (n, n // 2), dtype=torch.int32, device=dev, generator=g)
+    avg_h = torch.randint(0, 256, (n, n - n // 2), dtype=torch.int32, device=dev, generator=g)
+    res_v = torch.randint(-8, 9, (n // 2, n), dtype=torch.int32, device=dev, generator=g)
+    avg_v = torch.randint(0, 256, (n - n // 2, n), dtype=torch.int32, device=dev, generator=g)
+    out = torch.empty((n, n), dtype=torch.int32, device=dev)
+    pal = torch.randint(0, 256, (3, 256), dtype=torch.int32, device=dev, generator=g)
+    idx = torch.randint(0, 256, (n, n), dtype=torch.int32, device=dev, generator=g)
+    pout = torch.empty((3, n, n), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    P = lambda t: lib._addr(t)
+    results = {}
+
+    def timeit(name, fn, bytes_moved, reps=5):
+        fn()
+        ctx.sync()
+        ctx.timer_start()
+        for _ in range(reps):
+            fn()
+        ms = ctx.timer_stop() / reps
+        results[name] = {"ms": round(ms, 4), "GB/s": round(bytes_moved / ms / 1e6, 1),
+                         "frac_of_8TBs": round(bytes_moved / ms / 1e6 / 8000, 4)}
+
+    timeit("rct_ycocg", lambda: ctx._chk(L.jxlh_rct(ctx._ctx, P(planes[0]), P(planes[1]), P(planes[2]), n * n, 6, 0), "rct"),
+           24.0 * n * n)
+    timeit("palette_256", lambda: ctx._chk(L.jxlh_palette(ctx._ctx, P(idx), n * n, P(pal), 256, 256, 3, 8, P(pout)), "pal"),
+           16.0 * n * n)
+    timeit("unsqueeze_h", lambda: ctx._chk(L.jxlh_unsqueeze(ctx._ctx, 1, P(avg_h), avg_h.shape[1], P(res_h), res_h.shape[1],
+                                                             n, n, P(out), n), "uh"), 8.0 * n * n)
+    timeit("unsqueeze_v", lambda: ctx._chk(L.jxlh_unsqueeze(ctx._ctx, 0, P(avg_v), n, P(res_v), n, n, n, P(out), n), "uv"),
+           8.0 * n * n)
+    print(json.dumps({"size": n, "kernels": results}))
+
+
+if __name__ == "__main__":
+    main()
