@@ -213,6 +213,14 @@ jxlh_status jxlh_unsqueeze(jxlh_ctx* ctx, int32_t horizontal, const int32_t* avg
                            const int32_t* res, size_t res_stride, uint32_t out_w, uint32_t out_h,
                            int32_t* out, size_t out_stride);
 
+/* Batched form: the n_planes (1..3) channels one squeeze step covers (SqueezeParams::num_channels,
+ * modular/transforms/squeeze.rs:20-37) in a single launch -- the recurrence is latency bound, so
+ * extra planes are almost free.  All planes share geometry; device pointers only. */
+jxlh_status jxlh_unsqueeze_planes(jxlh_ctx* ctx, int32_t horizontal, int32_t n_planes,
+                                  const int32_t* const avg[], size_t avg_stride, const int32_t* const res[],
+                                  size_t res_stride, uint32_t out_w, uint32_t out_h, int32_t* const out[],
+                                  size_t out_stride);
+
 /* library info */
 uint32_t jxlh_abi_version(void);
 /* covered_blocks_x / _y and the type -> dequant table map (transform_map.rs:97-107,

@@ -902,8 +902,10 @@ jxlh_status jxlh_unsqueeze(jxlh_ctx* ctx, int32_t horizontal, const int32_t* avg
   if (avg_stride < avg_w || (res_w * res_h > 0 && (!res || res_stride < res_w))) return JXLH_ERR_INVALID_ARGUMENT;
   if (is_device_ptr(avg) && is_device_ptr(out) && (res_w * res_h == 0 || is_device_ptr(res))) {
     ScopedKernelTimer t(ctx, horizontal ? "k6_unsqueeze_h" : "k6_unsqueeze_v");
-    launch_unsqueeze(ctx->stream, horizontal, avg, avg_stride, res ? res : avg, res_stride, out_w, out_h, out,
-                     out_stride);
+    const int32_t* av[1] = {avg};
+    const int32_t* rv[1] = {res ? res : avg};
+    int32_t* ov[1] = {out};
+    launch_unsqueeze(ctx->stream, horizontal, 1, av, avg_stride, rv, res_stride, out_w, out_h, ov, out_stride);
     HIPCHK(ctx, hipGetLastError());
     return JXLH_OK;
   }
@@ -916,10 +918,35 @@ jxlh_status jxlh_unsqueeze(jxlh_ctx* ctx, int32_t horizontal, const int32_t* avg
     return st;
   }
   if ((st = ensure(ctx, ctx->hook_i[2], out_stride * out_h))) return st;
-  launch_unsqueeze(ctx->stream, horizontal, ctx->hook_i[0].p, avg_stride, ctx->hook_i[1].p, res_stride, out_w, out_h,
-                   ctx->hook_i[2].p, out_stride);
+  {
+    const int32_t* av[1] = {ctx->hook_i[0].p};
+    const int32_t* rv[1] = {ctx->hook_i[1].p};
+    int32_t* ov[1] = {ctx->hook_i[2].p};
+    launch_unsqueeze(ctx->stream, horizontal, 1, av, avg_stride, rv, res_stride, out_w, out_h, ov, out_stride);
+  }
   HIPCHK(ctx, hipGetLastError());
   return stage_out(ctx, out, (const int32_t*)ctx->hook_i[2].p, out_stride * out_h);
+}
+
+jxlh_status jxlh_unsqueeze_planes(jxlh_ctx* ctx, int32_t horizontal, int32_t n_planes, const int32_t* const avg[],
+                                  size_t avg_stride, const int32_t* const res[], size_t res_stride, uint32_t out_w,
+                                  uint32_t out_h, int32_t* const out[], size_t out_stride) {
+  if (!ctx || !avg || !res || !out || n_planes < 1 || n_planes > 3 || out_stride < out_w)
+    return JXLH_ERR_INVALID_ARGUMENT;
+  if (out_w == 0 || out_h == 0) return JXLH_OK;
+  const uint32_t avg_w = horizontal ? (out_w + 1) / 2 : out_w;
+  const uint32_t res_w = horizontal ? out_w / 2 : out_w, res_h = horizontal ? out_h : out_h / 2;
+  if (avg_stride < avg_w || (res_w * res_h > 0 && res_stride < res_w)) return JXLH_ERR_INVALID_ARGUMENT;
+  const int32_t* rv[3];
+  for (int i = 0; i < n_planes; i++) {
+    if (!avg[i] || !out[i] || !is_device_ptr(avg[i]) || !is_device_ptr(out[i])) return JXLH_ERR_INVALID_ARGUMENT;
+    rv[i] = res[i] ? res[i] : avg[i];
+    if (res_w * res_h > 0 && (!res[i] || !is_device_ptr(res[i]))) return JXLH_ERR_INVALID_ARGUMENT;
+  }
+  ScopedKernelTimer t(ctx, horizontal ? "k6_unsqueeze_h" : "k6_unsqueeze_v");
+  launch_unsqueeze(ctx->stream, horizontal, n_planes, avg, avg_stride, rv, res_stride, out_w, out_h, out, out_stride);
+  HIPCHK(ctx, hipGetLastError());
+  return JXLH_OK;
 }
 
 }  // extern "C"

@@ -123,7 +123,24 @@ __global__ void k5_palette(const int32_t* __restrict__ index, size_t n, const in
                            int num_colors, size_t pstride, int nb_channels, int bit_depth,
                            int32_t* __restrict__ out) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+  const size_t nvec = n / 4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+    const int4 idx = reinterpret_cast<const int4*>(index)[i];
+    for (int c = 0; c < nb_channels; c++) {
+      int4 v;
+      v.x = palette_value(palette, pstride, idx.x, c, num_colors, bit_depth);
+      v.y = palette_value(palette, pstride, idx.y, c, num_colors, bit_depth);
+      v.z = palette_value(palette, pstride, idx.z, c, num_colors, bit_depth);
+      v.w = palette_value(palette, pstride, idx.w, c, num_colors, bit_depth);
+      if ((n & 3) == 0) {
+        reinterpret_cast<int4*>(out + (size_t)c * n)[i] = v;
+      } else {  // channel planes are only 4-byte aligned
+        int32_t* o = out + (size_t)c * n + i * 4;
+        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+      }
+    }
+  }
+  for (size_t i = nvec * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const int32_t idx = index[i];
     for (int c = 0; c < nb_channels; c++)
       out[(size_t)c * n + i] = palette_value(palette, pstride, idx, c, num_colors, bit_depth);
@@ -158,16 +175,27 @@ __device__ __forceinline__ void unsqueeze(int32_t avg, int32_t res, int32_t next
   b = wsub(a, diff);
 }
 
-// One lane per line.  Element i of line l lives at p[l*line_pitch + i*elem_pitch].
-// n_res = floor(n_out/2) residuals per line, n_avg = n_out - n_res averages.
-__global__ void k6_unsqueeze(const int32_t* __restrict__ avg, size_t avg_lp, size_t avg_ep,
-                             const int32_t* __restrict__ res, size_t res_lp, size_t res_ep, int32_t* __restrict__ out,
-                             size_t out_lp, size_t out_ep, int n_lines, int n_out) {
+// One lane per line; up to 3 planes (the channels of one squeeze step) per launch via blockIdx.y.
+// Element i of line l lives at p[l*line_pitch + i*elem_pitch].  n_res = floor(n_out/2) residuals
+// per line, n_avg = n_out - n_res averages.  The recurrence itself is ~100 dependent cycles per
+// step; what must not be exposed is memory latency, so the loads of the NEXT block of U steps
+// are in flight while the current block runs (register double buffering).  HVEC: horizontal step
+// with 16-byte aligned rows -> int4 loads / stores (a lane walks along its row).
+struct SqueezePlanes {
+  const int32_t* avg[3];
+  const int32_t* res[3];
+  int32_t* out[3];
+};
+
+template <bool HVEC>
+__global__ __launch_bounds__(64) void k6_unsqueeze(const SqueezePlanes pl, size_t avg_lp, size_t avg_ep, size_t res_lp,
+                                                   size_t res_ep, size_t out_lp, size_t out_ep, int n_lines,
+                                                   int n_out) {
   const int l = blockIdx.x * blockDim.x + threadIdx.x;
   if (l >= n_lines) return;
-  const int32_t* __restrict__ a = avg + (size_t)l * avg_lp;
-  const int32_t* __restrict__ r = res + (size_t)l * res_lp;
-  int32_t* __restrict__ o = out + (size_t)l * out_lp;
+  const int32_t* __restrict__ a = pl.avg[blockIdx.y] + (size_t)l * avg_lp;
+  const int32_t* __restrict__ r = pl.res[blockIdx.y] + (size_t)l * res_lp;
+  int32_t* __restrict__ o = pl.out[blockIdx.y] + (size_t)l * out_lp;
   const int w = n_out / 2;
   if (w == 0) {  // single output sample (squeeze.rs:468-476, :672-675)
     o[0] = a[0];
@@ -176,35 +204,78 @@ __global__ void k6_unsqueeze(const int32_t* __restrict__ avg, size_t avg_lp, siz
   const bool has_tail = n_out & 1;
   int32_t cur = a[0];
   int32_t prev_b = cur;  // first `prev` is avg[0] (squeeze.rs:411-414, :591-594)
-  constexpr int U = 8;
-  int i = 0;
+  constexpr int U = 16;
   // main body: next_avg = avg[i+1] exists for i < w-1 (or i < w with a tail)
   const int n_main = has_tail ? w : w - 1;
-  for (; i + U <= n_main; i += U) {
-    int32_t na[U], rr[U];
+  const int n_blocks = n_main / U;
+  int32_t na[U], rr[U], nb[U], rb[U];
+  auto load_block = [&](int i0, int32_t(&xa)[U], int32_t(&xr)[U]) {
+    if constexpr (HVEC) {
+      // avg[i0+1 .. i0+U] is misaligned by one element: fetch avg[i0 .. i0+U+3] as int4 and shift
+      int32_t t[U + 4];
+#pragma unroll
+      for (int k = 0; k < U / 4 + 1; k++) {
+        const int4 v = *reinterpret_cast<const int4*>(a + i0 + 4 * k);
+        t[4 * k] = v.x; t[4 * k + 1] = v.y; t[4 * k + 2] = v.z; t[4 * k + 3] = v.w;
+      }
+#pragma unroll
+      for (int k = 0; k < U; k++) xa[k] = t[k + 1];
+#pragma unroll
+      for (int k = 0; k < U / 4; k++) {
+        const int4 v = *reinterpret_cast<const int4*>(r + i0 + 4 * k);
+        xr[4 * k] = v.x; xr[4 * k + 1] = v.y; xr[4 * k + 2] = v.z; xr[4 * k + 3] = v.w;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < U; k++) {
+        xa[k] = a[(size_t)(i0 + k + 1) * avg_ep];
+        xr[k] = r[(size_t)(i0 + k) * res_ep];
+      }
+    }
+  };
+  auto run_block = [&](int i0, const int32_t(&xa)[U], const int32_t(&xr)[U]) {
+    int32_t va[U], vb[U];
 #pragma unroll
     for (int k = 0; k < U; k++) {
-      na[k] = a[(size_t)(i + k + 1) * avg_ep];
-      rr[k] = r[(size_t)(i + k) * res_ep];
+      unsqueeze(cur, xr[k], xa[k], prev_b, va[k], vb[k]);
+      prev_b = vb[k];
+      cur = xa[k];
     }
+    if constexpr (HVEC) {
 #pragma unroll
-    for (int k = 0; k < U; k++) {
-      int32_t va, vb;
-      unsqueeze(cur, rr[k], na[k], prev_b, va, vb);
-      o[(size_t)(2 * (i + k)) * out_ep] = va;
-      o[(size_t)(2 * (i + k) + 1) * out_ep] = vb;
-      prev_b = vb;
-      cur = na[k];
+      for (int k = 0; k < U; k += 2)
+        *reinterpret_cast<int4*>(o + 2 * (i0 + k)) = make_int4(va[k], vb[k], va[k + 1], vb[k + 1]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < U; k++) {
+        o[(size_t)(2 * (i0 + k)) * out_ep] = va[k];
+        o[(size_t)(2 * (i0 + k) + 1) * out_ep] = vb[k];
+      }
     }
+  };
+  // HVEC over-reads avg by up to 3 elements past i0+U: keep the last block(s) for the scalar tail
+  const int vec_blocks = HVEC ? max(0, (n_main - 4) / U) : n_blocks;
+  int i = 0;
+  if (vec_blocks > 0) {
+    load_block(0, na, rr);
+    int blk = 0;
+    for (; blk + 2 <= vec_blocks; blk += 2) {
+      load_block((blk + 1) * U, nb, rb);
+      run_block(blk * U, na, rr);
+      if (blk + 2 < vec_blocks) load_block((blk + 2) * U, na, rr);
+      run_block((blk + 1) * U, nb, rb);
+    }
+    if (blk < vec_blocks) run_block(blk * U, na, rr);
+    i = vec_blocks * U;
   }
   for (; i < n_main; i++) {
-    const int32_t na = a[(size_t)(i + 1) * avg_ep];
+    const int32_t nxt = a[(size_t)(i + 1) * avg_ep];
     int32_t va, vb;
-    unsqueeze(cur, r[(size_t)i * res_ep], na, prev_b, va, vb);
+    unsqueeze(cur, r[(size_t)i * res_ep], nxt, prev_b, va, vb);
     o[(size_t)(2 * i) * out_ep] = va;
     o[(size_t)(2 * i + 1) * out_ep] = vb;
     prev_b = vb;
-    cur = na;
+    cur = nxt;
   }
   if (!has_tail) {  // last pair: next_avg = avg itself (squeeze.rs:423-433, :608-616)
     int32_t va, vb;
@@ -240,17 +311,33 @@ void launch_palette(hipStream_t s, const int32_t* index, size_t n, const int32_t
                      nb_channels, bit_depth, out);
 }
 
-void launch_unsqueeze(hipStream_t s, int horizontal, const int32_t* avg, size_t avg_stride, const int32_t* res,
-                      size_t res_stride, uint32_t out_w, uint32_t out_h, int32_t* out, size_t out_stride) {
-  if (out_w == 0 || out_h == 0) return;
+void launch_unsqueeze(hipStream_t s, int horizontal, int n_planes, const int32_t* const avg[], size_t avg_stride,
+                      const int32_t* const res[], size_t res_stride, uint32_t out_w, uint32_t out_h,
+                      int32_t* const out[], size_t out_stride) {
+  if (out_w == 0 || out_h == 0 || n_planes <= 0) return;
+  SqueezePlanes pl{};
+  bool aligned = (avg_stride % 4 == 0) && (res_stride % 4 == 0) && (out_stride % 4 == 0);
+  for (int i = 0; i < n_planes && i < 3; i++) {
+    pl.avg[i] = avg[i];
+    pl.res[i] = res[i];
+    pl.out[i] = out[i];
+    aligned = aligned && ((uintptr_t)avg[i] % 16 == 0) && ((uintptr_t)res[i] % 16 == 0) && ((uintptr_t)out[i] % 16 == 0);
+  }
   if (horizontal) {
     const int n_lines = (int)out_h;
-    hipLaunchKernelGGL(k6_unsqueeze, dim3((n_lines + 63) / 64), dim3(64), 0, s, avg, avg_stride, (size_t)1, res,
-                       res_stride, (size_t)1, out, out_stride, (size_t)1, n_lines, (int)out_w);
+    const dim3 grid((n_lines + 63) / 64, n_planes);
+    if (aligned) {
+      hipLaunchKernelGGL(k6_unsqueeze<true>, grid, dim3(64), 0, s, pl, avg_stride, (size_t)1, res_stride, (size_t)1,
+                         out_stride, (size_t)1, n_lines, (int)out_w);
+    } else {
+      hipLaunchKernelGGL(k6_unsqueeze<false>, grid, dim3(64), 0, s, pl, avg_stride, (size_t)1, res_stride, (size_t)1,
+                         out_stride, (size_t)1, n_lines, (int)out_w);
+    }
   } else {
     const int n_lines = (int)out_w;
-    hipLaunchKernelGGL(k6_unsqueeze, dim3((n_lines + 63) / 64), dim3(64), 0, s, avg, (size_t)1, avg_stride, res,
-                       (size_t)1, res_stride, out, (size_t)1, out_stride, n_lines, (int)out_h);
+    const dim3 grid((n_lines + 63) / 64, n_planes);
+    hipLaunchKernelGGL(k6_unsqueeze<false>, grid, dim3(64), 0, s, pl, (size_t)1, avg_stride, (size_t)1, res_stride,
+                       (size_t)1, out_stride, n_lines, (int)out_h);
   }
 }
 

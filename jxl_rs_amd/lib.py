@@ -35,7 +35,7 @@ ABI_SYMBOLS = [
     "jxlh_frame_device_planes", "jxlh_frame_read_lf", "jxlh_timer_start", "jxlh_timer_stop",
     "jxlh_kernel_timing_enable", "jxlh_kernel_timing_get", "jxlh_kernel_timing_reset", "jxlh_stage_gaborish",
     "jxlh_stage_epf", "jxlh_stage_lf_smooth", "jxlh_stage_transform_to_pixels", "jxlh_rct", "jxlh_palette",
-    "jxlh_unsqueeze", "jxlh_abi_version", "jxlh_covered_blocks_x", "jxlh_covered_blocks_y",
+    "jxlh_unsqueeze", "jxlh_unsqueeze_planes", "jxlh_abi_version", "jxlh_covered_blocks_x", "jxlh_covered_blocks_y",
     "jxlh_quant_table_for_type", "jxlh_quant_table_size",
 ]
 
@@ -118,6 +118,7 @@ def load():
     L.jxlh_rct.argtypes = [vp, vp, vp, vp, sz, i32, i32]
     L.jxlh_palette.argtypes = [vp, vp, sz, vp, i32, sz, i32, i32, vp]
     L.jxlh_unsqueeze.argtypes = [vp, i32, vp, sz, vp, sz, u32, u32, vp, sz]
+    L.jxlh_unsqueeze_planes.argtypes = [vp, i32, i32, C.POINTER(vp), sz, C.POINTER(vp), sz, u32, u32, C.POINTER(vp), sz]
     L.jxlh_abi_version.restype = u32
     for name in ("jxlh_covered_blocks_x", "jxlh_covered_blocks_y", "jxlh_quant_table_for_type",
                  "jxlh_quant_table_size"):
@@ -326,6 +327,15 @@ class Context:
         self._chk(self.L.jxlh_palette(self._ctx, _addr(idx), idx.size, _addr(pal), num_colors, pal.shape[1],
                                       nb_channels, bit_depth, _addr(out)), "palette")
         return out
+
+    def unsqueeze_planes(self, horizontal, avg, res, out, out_w, out_h, avg_stride, res_stride, out_stride):
+        """Device-resident batched step: avg/res/out are lists (<= 3) of device pointers / tensors."""
+        n = len(avg)
+        av = (C.c_void_p * n)(*[_addr(a).value for a in avg])
+        rv = (C.c_void_p * n)(*[_addr(a).value for a in res])
+        ov = (C.c_void_p * n)(*[_addr(a).value for a in out])
+        self._chk(self.L.jxlh_unsqueeze_planes(self._ctx, 1 if horizontal else 0, n, av, avg_stride, rv, res_stride,
+                                               out_w, out_h, ov, out_stride), "unsqueeze_planes")
 
     def unsqueeze(self, horizontal, avg, res, out_w, out_h):
         avg = np.ascontiguousarray(avg, dtype=np.int32)

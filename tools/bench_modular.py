@@ -49,6 +49,13 @@ def main():
                                                              n, n, P(out), n), "uh"), 8.0 * n * n)
     timeit("unsqueeze_v", lambda: ctx._chk(L.jxlh_unsqueeze(ctx._ctx, 0, P(avg_v), n, P(res_v), n, n, n, P(out), n), "uv"),
            8.0 * n * n)
+    # the three channels of a squeeze step in one launch
+    avg3h = [avg_h.clone() for _ in range(3)]; res3h = [res_h.clone() for _ in range(3)]
+    avg3v = [avg_v.clone() for _ in range(3)]; res3v = [res_v.clone() for _ in range(3)]
+    out3 = [torch.empty((n, n), dtype=torch.int32, device=dev) for _ in range(3)]
+    timeit("unsqueeze_h_x3", lambda: ctx.unsqueeze_planes(True, avg3h, res3h, out3, n, n, avg_h.shape[1], res_h.shape[1], n),
+           3 * 8.0 * n * n)
+    timeit("unsqueeze_v_x3", lambda: ctx.unsqueeze_planes(False, avg3v, res3v, out3, n, n, n, n, n), 3 * 8.0 * n * n)
     print(json.dumps({"size": n, "kernels": results}))
 
 
