@@ -158,12 +158,29 @@ def main():
             per_step_ms = ms / nprof
             kernels[name] = {"ms_per_step": round(per_step_ms, 4), "launches_per_step": n // nprof}
         cand = {k: v for k, v in kernels.items() if k in ALGO_BYTES_PER_PX}
+        # HBM traffic of the dominant kernel from the committed rocprofv3 --pmc passes of this same
+        # command (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; tools/gpu_profile.sh, tools/pmc_summary.py).
+        # PMC needs its own profiler run, so the value is the latest committed measurement, not live.
+        pmc = {}
+        try:
+            import glob
+            files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+            if files and size == 8192 and args.mix == "d1":
+                pmc = json.load(open(files[-1]))
+                pmc["_file"] = os.path.relpath(files[-1], ROOT)
+        except Exception:
+            pmc = {}
         if cand:
             dom = max(cand, key=lambda k: cand[k]["ms_per_step"])
             algo_bytes = ALGO_BYTES_PER_PX[dom] * size * size
             ach = algo_bytes / (cand[dom]["ms_per_step"] * 1e-3) / 1e9
+            traffic = None
+            for k, v in pmc.items():
+                if k.startswith(dom) and isinstance(v, dict):
+                    traffic = int(v["hbm_bytes"])
             roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                        "traffic_source": pmc.get("_file"),
                         "algorithmic_bytes_per_launch": int(algo_bytes),
                         "avg_launch_ms": cand[dom]["ms_per_step"], "all_kernels_ms_per_step": kernels}
 
