@@ -275,6 +275,9 @@ template <bool GAB, bool E1, bool E2>
 __global__ __launch_bounds__(kFusedThreads, 4) void k23_fused_filters(const FusedArgs a) {
   __shared__ __attribute__((aligned(16))) float s_a[3 * kPlane];
   __shared__ __attribute__((aligned(16))) float s_b[3 * kPlane];
+  // 1/sigma of the 8x8 blocks this tile touches (block columns/rows relative to the tile's first block)
+  constexpr int kSigW = kBW / 8 + 2, kSigH = kBH / 8 + 2;
+  __shared__ float s_sigma[kSigH * kSigW];
   const int tid = threadIdx.x;
   // blockIdx.x enumerates tiles so that the workgroups one XCD receives (ids congruent mod 8)
   // walk along a tile row: neighbouring tiles share 128-byte output lines and halo input
@@ -293,6 +296,13 @@ __global__ __launch_bounds__(kFusedThreads, 4) void k23_fused_filters(const Fuse
   constexpr int kBorder = (GAB ? 1 : 0) + (E1 ? 2 : 0) + (E2 ? 1 : 0);
   static_assert(kBorder >= 1 && kBorder <= kB, "at least one stage");
 
+  const int sbx0 = max(tx0 - kB, 0) >> 3, sby0 = max(ty0 - kB, 0) >> 3;
+  if constexpr (E1 || E2) {
+    if (tid < kSigH * kSigW) {
+      const int sx = min(sbx0 + tid % kSigW, (a.w - 1) >> 3), sy = min(sby0 + tid / kSigW, (a.h - 1) >> 3);
+      s_sigma[tid] = a.inv_sigma[(size_t)sy * a.sigma_stride + sx];
+    }
+  }
   // ---- stage the input tile (region margin = kBorder) with mirrored coordinates
   {
     constexpr int m = kBorder;
@@ -369,9 +379,14 @@ __global__ __launch_bounds__(kFusedThreads, 4) void k23_fused_filters(const Fuse
         for (int c = 0; c < 3; c++)
           o[c] = gab_strip(src + c * kPlane, by, bx0, a.gab_k[c][0], a.gab_k[c][1], a.gab_k[c][2]);
       } else {
-        const int sy = clampi(fy, 0, a.h - 1) >> 3, sx = clampi(fx0, 0, a.w - 1) >> 3;
-        const float sigma = a.inv_sigma[(size_t)sy * a.sigma_stride + sx];
-        if constexpr (STAGE == 1) {
+        const int sy = (clampi(fy, 0, a.h - 1) >> 3) - sby0, sx = (clampi(fx0, 0, a.w - 1) >> 3) - sbx0;
+        const float sigma = s_sigma[sy * kSigW + sx];
+        if (__all(sigma < kMinSigma)) {
+          // every strip of this wave is below MIN_SIGMA: the stage is the identity here (the
+          // reference takes the same shortcut per SIMD vector, epf1.rs:72-78)
+#pragma unroll
+          for (int c = 0; c < 3; c++) o[c] = lds_load4(src + c * kPlane + by * kBW + bx0);
+        } else if constexpr (STAGE == 1) {
           epf1_strip(src, by, bx0, fx0, fy, sigma, a, o);
         } else {
           epf2_strip(src, by, bx0, fx0, fy, sigma, a, o);
