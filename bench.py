@@ -49,6 +49,10 @@ def main():
     ap.add_argument("--seed", type=int, default=3)
     ap.add_argument("--inflight", type=int, default=2,
                     help="frames in flight per GPU (contexts with their own stream and buffers, used round-robin)")
+    ap.add_argument("--epf", default="spec", choices=["spec", "active", "passthrough"],
+                    help="EPF sigma population: spec = SURVEY 8(d) draws (raw_quant U[2,16], sharpness U{0..7}: 93%% of "
+                         "blocks fall below MIN_SIGMA and pass through); active = every block filtered "
+                         "(sharpness 7); passthrough = none")
     ap.add_argument("--mix", default="d1", choices=["d1", "dct8", "all"],
                     help="transform-type mix of the synthetic frame (d1 = BASELINE config 3)")
     args = ap.parse_args()
@@ -77,6 +81,11 @@ def main():
     wl = synth.make_vardct(size, size, mix=mix, seed=args.seed + rank, unique_groups=24,
                            epf_iters=2, gab=True, lf_smoothing=True)
     gen_s = time.time() - t0
+    if args.epf == "active":
+        wl.epf_map[:] = 7
+        wl.raw_quant[:] = np.minimum(wl.raw_quant, 4)
+    elif args.epf == "passthrough":
+        wl.epf_map[:] = 0
     ctxs = []
     h2d_s = 0.0
     for _ in range(max(1, args.inflight)):
@@ -197,6 +206,26 @@ def main():
                         "algorithmic_bytes_per_launch": int(algo_bytes),
                         "avg_launch_ms": cand[dom]["ms_per_step"], "all_kernels_ms_per_step": kernels}
 
+    # ---- on-device copy ceiling: a device-to-device copy of one frame's worth of planes
+    copy_gbs = None
+    if rank == 0 and torch.cuda.is_available():
+        n = size * size * 3
+        a_t = torch.empty(n, dtype=torch.float32, device=f"cuda:{local_rank}").normal_()
+        b_t = torch.empty_like(a_t)
+        for _ in range(3):
+            b_t.copy_(a_t)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            b_t.copy_(a_t)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbs = 2 * n * 4 * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del a_t, b_t
+        if roofline is not None:
+            roofline["copy_ceiling_GBs"] = round(copy_gbs, 1)
+            roofline["frac_of_copy_ceiling"] = round(roofline["achieved"] / copy_gbs, 4)
+
     # ---- CPU baseline: the oracle (C port of the reference path) on all host cores, bounded crop
     cpu = None
     if rank == 0 and not args.no_cpu:
@@ -232,7 +261,7 @@ def main():
                                    f"Gaborish, EPF iters=2), inputs HBM-resident", "groups": int(wl.coeffs.shape[0]),
                        "sharding": ("group-row bands + RCCL all-gather" if (args.strong and world > 1)
                                     else "independent frames per GPU, no collective"),
-                       "frames_in_flight_per_gpu": len(ctxs)},
+                       "frames_in_flight_per_gpu": len(ctxs), "epf_population": args.epf},
             "hip_event_ms_per_step_rank0": round(ev_ms / args.steps, 4),
             "setup": {"host_generate_s": round(gen_s, 2), "h2d_coeffs_s": round(h2d_s, 2)},
             "roofline": roofline, "cpu_baseline": cpu,

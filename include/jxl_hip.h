@@ -198,6 +198,12 @@ jxlh_status jxlh_stage_lf_smooth(jxlh_ctx* ctx, const jxlh_frame_params* p, cons
 jxlh_status jxlh_stage_transform_to_pixels(jxlh_ctx* ctx, int32_t type, uint32_t n, const float* coeffs,
                                            const float* lf, float* pixels);
 
+/* Device self-test of the EPF weight normalisation: the filters compute 1/(1 + sum of weights)
+ * (epf0.rs:208, epf1.rs:140, epf2.rs:130 divide) with rcp + two FMA refinement steps.  Counts the
+ * floats whose bit pattern lies in [lo_bits, hi_bits) for which that differs from the IEEE
+ * quotient 1.0f / w; the filters rely on 0 mismatches over [1.0f, 16.0f). */
+jxlh_status jxlh_selftest_recip(jxlh_ctx* ctx, uint32_t lo_bits, uint32_t hi_bits, uint64_t* mismatches);
+
 /* ---------------------------------------------------------------- Modular (wrapping i32) */
 /* do_rct_step (modular/transforms/rct.rs:118-157) on whole planes of n samples, in place. */
 jxlh_status jxlh_rct(jxlh_ctx* ctx, int32_t* p0, int32_t* p1, int32_t* p2, size_t n, int32_t op,

@@ -753,6 +753,21 @@ bool is_device_ptr(const void* p) {
 }  // namespace
 extern "C" {
 
+jxlh_status jxlh_selftest_recip(jxlh_ctx* ctx, uint32_t lo_bits, uint32_t hi_bits, uint64_t* mismatches) {
+  if (!ctx || !mismatches || hi_bits < lo_bits) return JXLH_ERR_INVALID_ARGUMENT;
+  jxlh_status st;
+  if ((st = ensure(ctx, ctx->hook_i[0], 2))) return st;
+  unsigned long long* d = reinterpret_cast<unsigned long long*>(ctx->hook_i[0].p);
+  HIPCHK(ctx, hipMemsetAsync(d, 0, sizeof(unsigned long long), ctx->stream));
+  launch_selftest_recip(ctx->stream, lo_bits, hi_bits, d);
+  HIPCHK(ctx, hipGetLastError());
+  unsigned long long host = 0;
+  HIPCHK(ctx, hipMemcpyAsync(&host, d, sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  *mismatches = host;
+  return JXLH_OK;
+}
+
 jxlh_status jxlh_stage_gaborish(jxlh_ctx* ctx, const float* in, float* out, uint32_t w, uint32_t h, size_t stride,
                                 float w1, float w2) {
   if (!ctx || !in || !out || stride < w) return JXLH_ERR_INVALID_ARGUMENT;

@@ -1,37 +1,67 @@
 // K2+K3 fused: Gaborish -> EPF1 -> EPF2 in ONE pass over HBM (12 B/px in, 12 B/px out).
 //
-// One 512-thread workgroup owns a 56x32 output tile.  The three XYB channels of the tile plus
-// a 4-pixel halo (1 Gaborish + 2 EPF1 + 1 EPF2, jxl/src/render/mod.rs:28-36) are staged once
-// in LDS with 16-byte coalesced loads; every stage then runs LDS -> LDS on a region that
-// shrinks by its own border, and only the last stage writes to HBM.  Each thread produces
-// 4-pixel row strips; a staged row is exactly 16 strips = one 16-lane DPP row, so the strip
-// itself comes in as one conflict-free ds_read_b128 and its left/right neighbour taps are
-// DPP row shifts of the adjacent lanes' registers (no second trip to LDS).  For EPF1 the 16
-// absolute differences per pixel and channel collapse to two shared difference maps
-//   V(x,y) = |P(x,y) - P(x,y+1)|,  H(x,y) = |P(x,y) - P(x+1,y)|
-// (every |a-b| of epf1.rs:100-115 is one of them), summed in the reference's order, so the
-// result stays bit-identical to the per-stage kernels / the oracle.
+// One workgroup owns a 56 x kTH output tile.  The three XYB channels of the tile plus a 4-pixel
+// halo (1 Gaborish + 2 EPF1 + 1 EPF2, jxl/src/render/mod.rs:28-36) are staged once in LDS with
+// 16-byte coalesced loads; every stage then runs LDS -> LDS *in place* on a region that shrinks by
+// its own border (all threads compute their outputs into registers, barrier, write back), and
+// only the last stage writes to HBM.  One buffer instead of a ping-pong pair halves the LDS per
+// pixel, which pays for tall tiles (less halo work) at the same number of waves per CU.
 //
-// Edge semantics (jxl/src/render/simple_pipeline/run_stage.rs:129-146): each stage sees ITS
-// OWN input mirrored at the frame border.  The staged input is loaded with mirrored
-// coordinates; after each intermediate stage the out-of-frame part of its output region is
-// overwritten with the mirrored in-frame values (they are inside the same tile), so the
-// next stage reads exactly what the reference's pipeline would hand it.
+// Work items are 4x2 micro-tiles: one 4-pixel strip of two consecutive rows.  A staged row is 16
+// strips = one 16-lane DPP row, so a strip comes in as one conflict-free ds_read_b128 and its
+// left/right neighbour taps are DPP row shifts of the adjacent lanes' registers.  Two rows per
+// item let the EPF stages share work the reference repeats per pixel while keeping its order of
+// operations, hence its bits:
+//   EPF1 (epf1.rs:100-119): every |a-b| is an entry of one of two difference maps
+//       V(x,y) = |P(x,y) - P(x,y+1)|,   H(x,y) = |P(x,y) - P(x+1,y)|
+//     and the four 5-term sums are plus-shaped sums over those maps taken in the order
+//     (top, left, centre, right, bottom):  PV(x,y) = V(x,y-1)+V(x-1,y)+V(x,y)+V(x+1,y)+V(x,y+1).
+//     SAD_N(x,y) = sum_c scale_c*PV_c(x,y-1), SAD_S(x,y) = sum_c scale_c*PV_c(x,y) = SAD_N(x,y+1);
+//     SAD_E(x,y) = sum_c scale_c*PH_c(x,y),   SAD_W(x,y) = SAD_E(x-1,y)  -- bit for bit, because
+//     the reference adds the same five numbers in the same order for both.
+//   EPF2 (epf2.rs:95-109): the single-pixel SAD between two pixels is symmetric, so the S term
+//     of (x,y) is the N term of (x,y+1) and the E term of (x,y) the W term of (x+1,y).
+// 1/(1+sum w) uses rcp + two FMA refinement steps that round exactly like IEEE division on the
+// weights' range [1,16) (checked exhaustively on the device by jxlh_selftest_recip).
+//
+// Edge semantics (jxl/src/render/simple_pipeline/run_stage.rs:129-146): each stage sees ITS OWN
+// input mirrored at the frame border.  The staged input is loaded with mirrored coordinates; after
+// each intermediate stage the out-of-frame part of its output region is overwritten with the
+// mirrored in-frame values (they are inside the same tile), so the next stage reads exactly what
+// the reference's pipeline would hand it.
 //
 // Stage subsets (gab on/off, epf_iters 0..2) are compile-time variants of the same kernel;
 // epf_iters == 3 (EPF0, 7-pixel halo) uses the per-stage kernels of k_filters.hip.
 #include "jxlh_internal.h"
 
+#ifndef JXLH_FUSED_TH
+#define JXLH_FUSED_TH 56
+#endif
+#ifndef JXLH_FUSED_THREADS
+#define JXLH_FUSED_THREADS 512
+#endif
+#ifndef JXLH_FUSED_WAVES_PER_EU
+#define JXLH_FUSED_WAVES_PER_EU 4
+#endif
+#ifndef JXLH_FAST_RECIP
+#define JXLH_FAST_RECIP 1
+#endif
+#ifndef JXLH_E1_ROLLED
+#define JXLH_E1_ROLLED 1
+#endif
+
 namespace jxlh {
 namespace {
 
-constexpr int kTW = 56, kTH = 32, kB = 4;
+constexpr int kTW = 56, kTH = JXLH_FUSED_TH, kB = 4;
 constexpr int kBW = kTW + 2 * kB;  // 64 floats = 16 strips = one DPP row of lanes
-constexpr int kBH = kTH + 2 * kB;  // 40
+constexpr int kBH = kTH + 2 * kB;
 constexpr int kStrips = kBW / 4;   // 16
 constexpr int kPlane = kBW * kBH;  // floats per channel
-constexpr int kFusedThreads = 512;
+constexpr int kT = JXLH_FUSED_THREADS;
 static_assert(kStrips == 16, "lane <-> strip mapping relies on 16-lane DPP rows");
+static_assert(kTH % 4 == 0 && kT % 64 == 0, "tiled staging fetches 4-row groups");
+constexpr int kSigW = kBW / 8 + 2, kSigH = kBH / 8 + 2;
 
 struct FusedArgs {
   const float* in[3];
@@ -61,11 +91,8 @@ __device__ __forceinline__ float dpp_from_right(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x101, 0xf, 0xf, true));
 }
 
-// 8 consecutive values of a tile row around a strip: v[0..1] = cols bx0-2,-1; v[2..5] = strip;
-// v[6..7] = cols bx0+4,+5.  Lane l of a 16-lane row holds strip l of one tile row, so the
-// neighbours are the adjacent lanes' strip registers.  Must be called by all 64 lanes.
 // LDS tiles are 16-byte aligned and every strip starts on a 4-float boundary; say so, or the
-// compiler splits the access into ds_read2_b32 pairs (2-way bank conflicts).
+// compiler splits the access into ds_read2_b32 pairs (bank conflicts).
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 lds_load4(const float* p) {
   f32x4 v = *reinterpret_cast<const f32x4*>(__builtin_assume_aligned(p, 16));
@@ -78,189 +105,270 @@ __device__ __forceinline__ void lds_store4(float* p, float4 v) {
   *reinterpret_cast<float4*>(__builtin_assume_aligned(p, 16)) = v;
 }
 
-__device__ __forceinline__ void load8(const float* __restrict__ row, int bx0, float (&v)[8]) {
-  const float4 c = lds_load4(row + bx0);
+// 8 consecutive values of a tile row around a strip: v[0..1] = cols bx0-2,-1; v[2..5] = strip;
+// v[6..7] = cols bx0+4,+5.  Lane l of a 16-lane row holds strip l of one tile row, so the
+// neighbours are the adjacent lanes' strip registers (unused taps are dead code).  Must be
+// called by all 64 lanes.
+__device__ __forceinline__ void load8(const float* __restrict__ strip, float (&v)[8]) {
+  const float4 c = lds_load4(strip);
   v[0] = dpp_from_left(c.z);
   v[1] = dpp_from_left(c.w);
   v[2] = c.x; v[3] = c.y; v[4] = c.z; v[5] = c.w;
   v[6] = dpp_from_right(c.x);
   v[7] = dpp_from_right(c.y);
 }
-__device__ __forceinline__ void load4(const float* __restrict__ row, int bx0, float (&v)[4]) {
-  const float4 c = lds_load4(row + bx0);
+__device__ __forceinline__ void load4(const float* __restrict__ strip, float (&v)[4]) {
+  const float4 c = lds_load4(strip);
   v[0] = c.x; v[1] = c.y; v[2] = c.z; v[3] = c.w;
 }
 
-__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
-
 #define FAD(a, b) __builtin_fabsf((a) - (b))
 
-// ---- Gaborish on one 4-px strip of one channel (gaborish.rs:83-85)
-__device__ __forceinline__ float4 gab_strip(const float* __restrict__ src, int by, int bx0, float k0, float k1,
-                                            float k2) {
-  float t[8], m[8], b[8];
-  load8(src + clampi(by - 1, 0, kBH - 1) * kBW, bx0, t);
-  load8(src + by * kBW, bx0, m);
-  load8(src + clampi(by + 1, 0, kBH - 1) * kBW, bx0, b);
-  float o[4];
+// Correctly rounded 1/w for w in [1, 16) (1 + up to 12 weights in [0,1]); equals the IEEE
+// quotient 1.0f / w bit for bit on that range -- jxlh_selftest_recip checks every float.
+__device__ __forceinline__ float recip_weight_sum(float w) {
+#if JXLH_FAST_RECIP
+  float r = __builtin_amdgcn_rcpf(w);
+  float e = __builtin_fmaf(-w, r, 1.0f);
+  r = __builtin_fmaf(e, r, r);
+  e = __builtin_fmaf(-w, r, 1.0f);
+  return __builtin_fmaf(e, r, r);
+#else
+  return 1.0f / w;
+#endif
+}
+
+// sigma * sad_mul for the four pixels of a strip in frame row fy (common.rs:31-41): the border
+// multiplier applies to the first/last row and column of every 8x8 block.  fx0 % 4 == 0, so only
+// pixel 0 (fx0 % 8 == 0) or pixel 3 (fx0 % 8 == 4) can sit on a block's border column.
+__device__ __forceinline__ void strip_inv_sigma(float sigma, int fx0, int fy, float sm, float bsm, float (&is)[4]) {
+  const int ym = fy & 7;
+  const bool rowb = ym == 0 || ym == 7;
+  const float inner = sigma * sm, border = sigma * bsm;
+  const float mid = rowb ? border : inner;
+  const bool left = (fx0 & 4) == 0;
+  is[0] = left ? border : mid;
+  is[1] = mid;
+  is[2] = mid;
+  is[3] = left ? mid : border;
+}
+
+
+// ---- Gaborish on a 4x2 micro-tile of one channel (gaborish.rs:83-85); p = strip in the first row
+template <class Emit>
+__device__ __forceinline__ void gab_pair(const float* __restrict__ p, int c, float k0, float k1, float k2,
+                                         Emit&& emit) {
+  float t[8], m0[8], m1[8], b[8];  // rows y-1 .. y+2
+  load8(p - kBW, t);
+  load8(p, m0);
+  load8(p + kBW, m1);
+  load8(p + 2 * kBW, b);
+  float o0[4], o1[4];
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     const int j = i + 2;
-    float sum = m[j] * k0;
-    sum = __builtin_fmaf(k1, t[j] + m[j - 1] + b[j] + m[j + 1], sum);
-    sum = __builtin_fmaf(k2, t[j - 1] + t[j + 1] + b[j - 1] + b[j + 1], sum);
-    o[i] = sum;
+    float sum = m0[j] * k0;
+    sum = __builtin_fmaf(k1, t[j] + m0[j - 1] + m1[j] + m0[j + 1], sum);
+    sum = __builtin_fmaf(k2, t[j - 1] + t[j + 1] + m1[j - 1] + m1[j + 1], sum);
+    o0[i] = sum;
+    sum = m1[j] * k0;
+    sum = __builtin_fmaf(k1, m0[j] + m1[j - 1] + b[j] + m1[j + 1], sum);
+    sum = __builtin_fmaf(k2, m0[j - 1] + m0[j + 1] + b[j - 1] + b[j + 1], sum);
+    o1[i] = sum;
   }
-  return make_float4(o[0], o[1], o[2], o[3]);
+  emit(0, c, make_float4(o0[0], o0[1], o0[2], o0[3]));
+  emit(1, c, make_float4(o1[0], o1[1], o1[2], o1[3]));
 }
 
-__device__ __forceinline__ float sad_mul_px(int fx, int fy, float sm, float bsm) {
-  const int xm = fx & 7, ym = fy & 7;
-  return (xm == 0 || xm == 7 || ym == 0 || ym == 7) ? bsm : sm;
-}
-
-// ---- EPF1 on one strip, all three channels (epf1.rs:84-146)
-__device__ __forceinline__ void epf1_strip(const float* __restrict__ src, int by, int bx0, int fx0, int fy,
-                                           float sigma, const FusedArgs& a, float4 (&out)[3]) {
-  const int rm2 = clampi(by - 2, 0, kBH - 1), rm1 = clampi(by - 1, 0, kBH - 1);
-  const int rp1 = clampi(by + 1, 0, kBH - 1), rp2 = clampi(by + 2, 0, kBH - 1);
-  float sads[4][4];  // [neighbour][pixel]
-#pragma unroll
-  for (int k = 0; k < 4; k++)
-#pragma unroll
-    for (int i = 0; i < 4; i++) sads[k][i] = 0.0f;
-  float ctr[3][4], pn[3][4], ps[3][4], pw[3][4], pe[3][4];
-#pragma unroll
-  for (int c = 0; c < 3; c++) {
-    const float* p = src + c * kPlane;
-    float r0[4], r1[8], r2[8], r3[8], r4[4];
-    load4(p + rm2 * kBW, bx0, r0);
-    load8(p + rm1 * kBW, bx0, r1);
-    load8(p + by * kBW, bx0, r2);
-    load8(p + rp1 * kBW, bx0, r3);
-    load4(p + rp2 * kBW, bx0, r4);
-    // vertical difference map V(x, r) = |P(x,r) - P(x,r+1)|, x in -1..4 (index x+1)
-    float vm2[4], vm1[6], v0[6], vp1[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      vm2[i] = FAD(r0[i], r1[i + 2]);
-      vp1[i] = FAD(r3[i + 2], r4[i]);
-    }
-#pragma unroll
-    for (int x = 0; x < 6; x++) {
-      vm1[x] = FAD(r1[x + 1], r2[x + 1]);
-      v0[x] = FAD(r2[x + 1], r3[x + 1]);
-    }
-    // horizontal difference map H(x, r) = |P(x,r) - P(x+1,r)|
-    float hm1[5], h0[7], hp1[5];  // x from -1 (hm1, hp1) / -2 (h0)
-#pragma unroll
-    for (int x = 0; x < 5; x++) {
-      hm1[x] = FAD(r1[x + 1], r1[x + 2]);
-      hp1[x] = FAD(r3[x + 1], r3[x + 2]);
-    }
-#pragma unroll
-    for (int x = 0; x < 7; x++) h0[x] = FAD(r2[x], r2[x + 1]);
-    const float scale = a.scale[c];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      // order of the five terms == epf1.rs:116-119
-      const float sN = vm2[i] + vm1[i] + vm1[i + 1] + vm1[i + 2] + v0[i + 1];
-      const float sW = hm1[i] + h0[i] + h0[i + 1] + h0[i + 2] + hp1[i];
-      const float sE = hm1[i + 1] + h0[i + 1] + h0[i + 2] + h0[i + 3] + hp1[i + 1];
-      const float sS = vm1[i + 1] + v0[i] + v0[i + 1] + v0[i + 2] + vp1[i];
-      sads[0][i] = __builtin_fmaf(sN, scale, sads[0][i]);
-      sads[1][i] = __builtin_fmaf(sW, scale, sads[1][i]);
-      sads[2][i] = __builtin_fmaf(sE, scale, sads[2][i]);
-      sads[3][i] = __builtin_fmaf(sS, scale, sads[3][i]);
-      ctr[c][i] = r2[i + 2];
-      pn[c][i] = r1[i + 2];
-      ps[c][i] = r3[i + 2];
-      pw[c][i] = r2[i + 1];
-      pe[c][i] = r2[i + 3];
-    }
-  }
-  float o[3][4];
+// ---- EPF1 on a 4x2 micro-tile, all three channels (epf1.rs:84-146).
+// p0 = the strip in the first row (plane 0); fy = frame row of the first row; emit(r, c, strip).
+template <class Emit>
+__device__ __forceinline__ void epf1_pair(const float* __restrict__ p0, int fx0, int fy, float sigma0, float sigma1,
+                                          const FusedArgs& a, Emit&& emit) {
+  float wv[3][4], wh[2][4];  // scaled plus-sums of V at rows y-1, y, y+1 and of H at rows y, y+1
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    if (sigma < kMinSigma) {
+    wv[0][i] = wv[1][i] = wv[2][i] = 0.0f;
+    wh[0][i] = wh[1][i] = 0.0f;
+  }
+  // one channel at a time (a rolled loop): unrolled, the scheduler interleaves the three
+  // channels' loads and difference maps and triples the live registers
+#if JXLH_E1_ROLLED
+#pragma unroll 1
+#else
 #pragma unroll
-      for (int c = 0; c < 3; c++) o[c][i] = ctr[c][i];
-      continue;
-    }
-    const float inv_sigma = sigma * sad_mul_px(fx0 + i, fy, a.sm1, a.bsm1);
-    float wsum = 1.0f, wgt[4];
+#endif
+  for (int c = 0; c < 3; c++) {
+    const float* p = p0 + c * kPlane;
+    const float scale = a.scale[c];
+    // rows y-2 .. y+3 stream through; V(x', r) = |P(x',r) - P(x',r+1)| and H(x', r) = |P(x',r) - P(x'+1,r)|
+    // are kept for x' = x-1 .. x+4 (index j = x'-x+1) on the rows whose plus-sums need the side taps
+    float A[4], B[8], C[8], D[8], E[8], F[4];
+    float vm2[4], vm1[6], v0[6], vp1[6], vp2[4];
+    float hm1[4], h0[6], hp1[6], hp2[4];
+    load4(p - 2 * kBW, A);
+    load8(p - kBW, B);
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      wgt[k] = fmaxf(__builtin_fmaf(sads[k][i], inv_sigma, 1.0f), 0.0f);
-      wsum += wgt[k];
+    for (int i = 0; i < 4; i++) {
+      vm2[i] = FAD(A[i], B[i + 2]);
+      hm1[i] = FAD(B[i + 2], B[i + 3]);
     }
-    const float inv_w = 1.0f / wsum;
+    load8(p, C);
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      vm1[j] = FAD(B[j + 1], C[j + 1]);
+      h0[j] = FAD(C[j + 1], C[j + 2]);
+    }
+    load8(p + kBW, D);
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      v0[j] = FAD(C[j + 1], D[j + 1]);
+      hp1[j] = FAD(D[j + 1], D[j + 2]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      // order of the five terms == epf1.rs:116-119 (top, left, centre, right, bottom)
+      const float pv0 = vm2[i] + vm1[i] + vm1[i + 1] + vm1[i + 2] + v0[i + 1];
+      const float ph0 = hm1[i] + h0[i] + h0[i + 1] + h0[i + 2] + hp1[i + 1];
+      wv[0][i] = __builtin_fmaf(pv0, scale, wv[0][i]);
+      wh[0][i] = __builtin_fmaf(ph0, scale, wh[0][i]);
+    }
+    load8(p + 2 * kBW, E);
+#pragma unroll
+    for (int j = 0; j < 6; j++) vp1[j] = FAD(D[j + 1], E[j + 1]);
+#pragma unroll
+    for (int i = 0; i < 4; i++) hp2[i] = FAD(E[i + 2], E[i + 3]);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const float pv1 = vm1[i + 1] + v0[i] + v0[i + 1] + v0[i + 2] + vp1[i + 1];
+      const float ph1 = h0[i + 1] + hp1[i] + hp1[i + 1] + hp1[i + 2] + hp2[i];
+      wv[1][i] = __builtin_fmaf(pv1, scale, wv[1][i]);
+      wh[1][i] = __builtin_fmaf(ph1, scale, wh[1][i]);
+    }
+    load4(p + 3 * kBW, F);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      vp2[i] = FAD(E[i + 2], F[i]);
+      const float pv2 = v0[i + 1] + vp1[i] + vp1[i + 1] + vp1[i + 2] + vp2[i];
+      wv[2][i] = __builtin_fmaf(pv2, scale, wv[2][i]);
+    }
+  }
+  // per row: the weights of its 4 pixels (neighbours N, W, E, S, epf1.rs:96), then the channels
+#pragma unroll
+  for (int r = 0; r < 2; r++) {
+    const float sigma = r ? sigma1 : sigma0;
+    const bool pass = sigma < kMinSigma;
+    float is[4], wgt[4][4], inv_w[4];
+    strip_inv_sigma(sigma, fx0, fy + r, a.sm1, a.bsm1, is);
+    const float from_left = dpp_from_left(wh[r][3]);  // SAD_E of the pixel left of the strip
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const float sad[4] = {wv[r][i], i ? wh[r][i - 1] : from_left, wh[r][i], wv[r + 1][i]};
+      float wsum = 1.0f;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        wgt[i][k] = fmaxf(__builtin_fmaf(sad[k], is[i], 1.0f), 0.0f);
+        wsum += wgt[i][k];
+      }
+      inv_w[i] = recip_weight_sum(wsum);
+    }
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-      float acc = ctr[c][i];
-      acc = __builtin_fmaf(ps[c][i], wgt[3], acc);
-      acc = __builtin_fmaf(pe[c][i], wgt[2], acc);
-      acc = __builtin_fmaf(pw[c][i], wgt[1], acc);
-      acc = __builtin_fmaf(pn[c][i], wgt[0], acc);
-      o[c][i] = acc * inv_w;
+      const float* p = p0 + c * kPlane + r * kBW;
+      float N[4], M[8], S[4];
+      load4(p - kBW, N);
+      load8(p, M);
+      load4(p + kBW, S);
+      float o[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        float acc = M[i + 2];
+        acc = __builtin_fmaf(S[i], wgt[i][3], acc);
+        acc = __builtin_fmaf(M[i + 3], wgt[i][2], acc);
+        acc = __builtin_fmaf(M[i + 1], wgt[i][1], acc);
+        acc = __builtin_fmaf(N[i], wgt[i][0], acc);
+        o[i] = pass ? M[i + 2] : acc * inv_w[i];
+      }
+      emit(r, c, make_float4(o[0], o[1], o[2], o[3]));
     }
   }
-#pragma unroll
-  for (int c = 0; c < 3; c++) out[c] = make_float4(o[c][0], o[c][1], o[c][2], o[c][3]);
 }
 
-// ---- EPF2 on one strip (epf2.rs:84-136)
-__device__ __forceinline__ void epf2_strip(const float* __restrict__ src, int by, int bx0, int fx0, int fy,
-                                           float sigma, const FusedArgs& a, float4 (&out)[3]) {
-  const int rm1 = clampi(by - 1, 0, kBH - 1), rp1 = clampi(by + 1, 0, kBH - 1);
-  float t[3][4], m[3][8], b[3][4];
+// ---- EPF2 on a 4x2 micro-tile (epf2.rs:84-136)
+template <class Emit>
+__device__ __forceinline__ void epf2_pair(const float* __restrict__ p0, int fx0, int fy, float sigma0, float sigma1,
+                                          const FusedArgs& a, Emit&& emit) {
+  float T[3][4], M0[3][8], M1[3][8], Bt[3][4];  // rows y-1, y, y+1, y+2
 #pragma unroll
   for (int c = 0; c < 3; c++) {
-    const float* p = src + c * kPlane;
-    load4(p + rm1 * kBW, bx0, t[c]);
-    load8(p + by * kBW, bx0, m[c]);
-    load4(p + rp1 * kBW, bx0, b[c]);
+    const float* p = p0 + c * kPlane;
+    load4(p - kBW, T[c]);
+    load8(p, M0[c]);
+    load8(p + kBW, M1[c]);
+    load4(p + 2 * kBW, Bt[c]);
   }
-  float o[3][4];
+  const float s0 = a.scale[0], s1 = a.scale[1], s2 = a.scale[2];
+  // the SAD of epf2.rs:103-109 between two pixels (symmetric in its arguments)
+  auto sad3 = [&](float ax, float ay, float ab, float bx, float by, float bb) {
+    return __builtin_fmaf(FAD(ax, bx), s0, __builtin_fmaf(FAD(ay, by), s1, FAD(ab, bb) * s2));
+  };
+  float dv[3][4];  // between rows (y-1,y), (y,y+1), (y+1,y+2)
+  float dh[2][4];  // between columns x+i and x+i+1, rows y and y+1
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    const float xc = m[0][i + 2], yc = m[1][i + 2], bc = m[2][i + 2];
-    if (sigma < kMinSigma) {
-      o[0][i] = xc;
-      o[1][i] = yc;
-      o[2][i] = bc;
-      continue;
-    }
-    const float inv_sigma = sigma * sad_mul_px(fx0 + i, fy, a.sm2, a.bsm2);
-    float wacc = 1.0f, xa = xc, ya = yc, ba = bc;
-    // neighbour order N, W, E, S (epf2.rs:95)
-    const float nx[4] = {t[0][i], m[0][i + 1], m[0][i + 3], b[0][i]};
-    const float ny[4] = {t[1][i], m[1][i + 1], m[1][i + 3], b[1][i]};
-    const float nb[4] = {t[2][i], m[2][i + 1], m[2][i + 3], b[2][i]};
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const float sad = __builtin_fmaf(FAD(nx[k], xc), a.scale[0],
-                                       __builtin_fmaf(FAD(ny[k], yc), a.scale[1], FAD(nb[k], bc) * a.scale[2]));
-      const float wgt = fmaxf(__builtin_fmaf(sad, inv_sigma, 1.0f), 0.0f);
-      wacc += wgt;
-      xa = __builtin_fmaf(wgt, nx[k], xa);
-      ya = __builtin_fmaf(wgt, ny[k], ya);
-      ba = __builtin_fmaf(wgt, nb[k], ba);
-    }
-    const float inv_w = 1.0f / wacc;
-    o[0][i] = xa * inv_w;
-    o[1][i] = ya * inv_w;
-    o[2][i] = ba * inv_w;
+    const int j = i + 2;
+    dv[0][i] = sad3(T[0][i], T[1][i], T[2][i], M0[0][j], M0[1][j], M0[2][j]);
+    dv[1][i] = sad3(M1[0][j], M1[1][j], M1[2][j], M0[0][j], M0[1][j], M0[2][j]);
+    dv[2][i] = sad3(Bt[0][i], Bt[1][i], Bt[2][i], M1[0][j], M1[1][j], M1[2][j]);
+    dh[0][i] = sad3(M0[0][j + 1], M0[1][j + 1], M0[2][j + 1], M0[0][j], M0[1][j], M0[2][j]);
+    dh[1][i] = sad3(M1[0][j + 1], M1[1][j + 1], M1[2][j + 1], M1[0][j], M1[1][j], M1[2][j]);
   }
+  // per row: the four weights of each pixel, then the channels.  The outer rows (y-1, y+2) are
+  // only needed once more, as N / S neighbours: re-read them instead of holding 24 registers.
 #pragma unroll
-  for (int c = 0; c < 3; c++) out[c] = make_float4(o[c][0], o[c][1], o[c][2], o[c][3]);
+  for (int r = 0; r < 2; r++) {
+    const float sigma = r ? sigma1 : sigma0;
+    const bool pass = sigma < kMinSigma;
+    float is[4], wgt[4][4], inv_w[4];
+    strip_inv_sigma(sigma, fx0, fy + r, a.sm2, a.bsm2, is);
+    const float from_left = dpp_from_left(dh[r][3]);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      // neighbour order N, W, E, S (epf2.rs:95)
+      const float sad[4] = {dv[r][i], i ? dh[r][i - 1] : from_left, dh[r][i], dv[r + 1][i]};
+      float wacc = 1.0f;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        wgt[i][k] = fmaxf(__builtin_fmaf(sad[k], is[i], 1.0f), 0.0f);
+        wacc += wgt[i][k];
+      }
+      inv_w[i] = recip_weight_sum(wacc);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const float(&M)[8] = r ? M1[c] : M0[c];
+      float outer[4];
+      load4(p0 + c * kPlane + (r ? 2 : -1) * kBW, outer);
+      float o[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int j = i + 2;
+        const float n[4] = {r ? M0[c][j] : outer[i], M[j - 1], M[j + 1], r ? outer[i] : M1[c][j]};
+        float acc = M[j];
+#pragma unroll
+        for (int k = 0; k < 4; k++) acc = __builtin_fmaf(wgt[i][k], n[k], acc);
+        o[i] = pass ? M[j] : acc * inv_w[i];
+      }
+      emit(r, c, make_float4(o[0], o[1], o[2], o[3]));
+    }
+  }
 }
 
 // Overwrites out-of-frame positions of a stage's output region [B-m, B+T+m) with the values
 // at their mirrored in-frame coordinates.  Only called by tiles that touch the frame border.
 __device__ __forceinline__ void mirror_fill(float* __restrict__ buf, int m, int tx0, int ty0, int w, int h, int tid) {
   const int rw = kTW + 2 * m, rh = kTH + 2 * m;
-  for (int idx = tid; idx < rw * rh; idx += kFusedThreads) {
+  for (int idx = tid; idx < rw * rh; idx += kT) {
     const int bx = kB - m + idx % rw, by = kB - m + idx / rw;
     const int fx = tx0 - kB + bx, fy = ty0 - kB + by;
     if (fx >= 0 && fx < w && fy >= 0 && fy < h) continue;
@@ -272,11 +380,9 @@ __device__ __forceinline__ void mirror_fill(float* __restrict__ buf, int m, int 
 }
 
 template <bool GAB, bool E1, bool E2>
-__global__ __launch_bounds__(kFusedThreads, 4) void k23_fused_filters(const FusedArgs a) {
-  __shared__ __attribute__((aligned(16))) float s_a[3 * kPlane];
-  __shared__ __attribute__((aligned(16))) float s_b[3 * kPlane];
+__global__ __launch_bounds__(kT, JXLH_FUSED_WAVES_PER_EU) void k23_fused_filters(const FusedArgs a) {
+  __shared__ __attribute__((aligned(16))) float s_buf[3 * kPlane];
   // 1/sigma of the 8x8 blocks this tile touches (block columns/rows relative to the tile's first block)
-  constexpr int kSigW = kBW / 8 + 2, kSigH = kBH / 8 + 2;
   __shared__ float s_sigma[kSigH * kSigW];
   const int tid = threadIdx.x;
   // blockIdx.x enumerates tiles so that the workgroups one XCD receives (ids congruent mod 8)
@@ -312,19 +418,22 @@ __global__ __launch_bounds__(kFusedThreads, 4) void k23_fused_filters(const Fuse
       // (16 contiguous bytes); a wave covers 32 columns x 8 rows = four whole 256-byte blocks
       // per channel, and scatters into the raster LDS tile with conflict-free ds_write_b32.
       constexpr int yg0 = (kB - m) / 4, ygn = (rows + 2 * ((kB - m) % 4) + 3) / 4;  // 4-row groups touched
-      for (int idx = tid; idx < kBW * ygn; idx += kFusedThreads) {
+      constexpr int items = kBW * ((ygn + 1) / 2) * 2;
+#pragma unroll
+      for (int it = 0; it < (items + kT - 1) / kT; it++) {
         // idx -> (pair of row groups, half of the columns): lanes 0-31 / 32-63 = the two 4-row
         // halves of the same 32 columns
+        const int idx = it * kT + tid;
         const int w64 = idx >> 6, l = idx & 63;
         const int xh = w64 % 2, ypair = w64 / 2;
         const int bx = xh * 32 + (l & 31), yg = yg0 + ypair * 2 + (l >> 5);
-        if (yg * 4 >= kBH) continue;
+        if (idx >= items || yg * 4 >= kBH) continue;
         const int by = yg * 4;
         const size_t off = in_offset(a, tx0 - kB + bx, ty0 - kB + by);
 #pragma unroll
         for (int c = 0; c < 3; c++) {
           const float4 v = *reinterpret_cast<const float4*>(a.in[c] + off);
-          float* d = s_a + c * kPlane + by * kBW + bx;
+          float* d = s_buf + c * kPlane + by * kBW + bx;
           d[0] = v.x;
           d[kBW] = v.y;
           d[2 * kBW] = v.z;
@@ -332,15 +441,15 @@ __global__ __launch_bounds__(kFusedThreads, 4) void k23_fused_filters(const Fuse
         }
       }
     } else if (!edge) {  // interior tile, raster input: pure 16-byte coalesced rows
-      for (int idx = tid; idx < kStrips * rows; idx += kFusedThreads) {
+      for (int idx = tid; idx < kStrips * rows; idx += kT) {
         const int by = kB - m + idx / kStrips, bx0 = (idx % kStrips) * 4;
         const size_t off = in_offset(a, tx0 - kB + bx0, ty0 - kB + by);
 #pragma unroll
         for (int c = 0; c < 3; c++)
-          lds_store4(s_a + c * kPlane + by * kBW + bx0, *reinterpret_cast<const float4*>(a.in[c] + off));
+          lds_store4(s_buf + c * kPlane + by * kBW + bx0, *reinterpret_cast<const float4*>(a.in[c] + off));
       }
     } else {
-      for (int idx = tid; idx < kStrips * rows; idx += kFusedThreads) {
+      for (int idx = tid; idx < kStrips * rows; idx += kT) {
         const int by = kB - m + idx / kStrips, bx0 = (idx % kStrips) * 4;
         const int fy = mirror(ty0 - kB + by, a.h);
         const int fx0 = tx0 - kB + bx0;
@@ -351,82 +460,114 @@ __global__ __launch_bounds__(kFusedThreads, 4) void k23_fused_filters(const Fuse
 #pragma unroll
         for (int c = 0; c < 3; c++) {
           const float* __restrict__ pl = a.in[c];
-          lds_store4(s_a + c * kPlane + by * kBW + bx0, make_float4(pl[o0], pl[o1], pl[o2], pl[o3]));
+          lds_store4(s_buf + c * kPlane + by * kBW + bx0, make_float4(pl[o0], pl[o1], pl[o2], pl[o3]));
         }
       }
     }
   }
   __syncthreads();
-  float* src = s_a;
-  float* dst = s_b;
-  int margin = kBorder;
 
-  auto run_stage = [&](auto stage_tag, int border) {
+  // One stage, in place: margin = the output region's margin around the tile (the input region's
+  // minus the stage's border).  Every 4x2 item of the region is computed into registers, then
+  // (after a barrier: all reads done) written back over the input.
+  auto run_stage = [&](auto stage_tag, auto margin_tag) {
     constexpr int STAGE = decltype(stage_tag)::value;  // 0 gaborish, 1 epf1, 2 epf2
-    margin -= border;
-    const bool last = margin == 0;
-    const int rows = kTH + 2 * margin;
-    // every row is 16 strips; whole waves run (DPP needs all lanes), stores are guarded
-    for (int t0 = 0; t0 < rows * kStrips; t0 += kFusedThreads) {
-      if (t0 + (tid & ~63) >= rows * kStrips) break;  // wave-uniform: nothing left for this wave
-      const int t = t0 + tid;
-      const bool live = t < rows * kStrips;
-      const int by = kB - margin + (live ? t / kStrips : 0), bx0 = (t % kStrips) * 4;
+    constexpr int margin = decltype(margin_tag)::value;
+    constexpr bool last = margin == 0;
+    constexpr int rows = kTH + 2 * margin;
+    constexpr int n = (rows / 2) * kStrips;
+    constexpr int kPasses = (n + kT - 1) / kT;
+    static_assert(rows % 2 == 0, "4x2 items");
+    float4 held[last ? 1 : kPasses][2][3];
+#pragma unroll
+    for (int pass = 0; pass < kPasses; pass++) {
+      if (pass * kT + (tid & ~63) >= n) continue;  // wave-uniform: nothing left for this wave
+      const int t = pass * kT + tid;
+      const bool live = t < n;
+      const int by = kB - margin + (live ? (t / kStrips) * 2 : 0), bx0 = (t % kStrips) * 4;
       const int fy = ty0 - kB + by, fx0 = tx0 - kB + bx0;
-      float4 o[3];
+      const float* p = s_buf + by * kBW + bx0;
+      auto put = [&](int r, int c, float4 o) {
+        if constexpr (last) {
+          const int fyr = fy + r;
+          if (live && bx0 >= kB && bx0 < kB + kTW && fyr < a.y1 && fyr < a.h && fx0 < a.w)
+            *reinterpret_cast<float4*>(a.out[c] + (size_t)fyr * a.stride + fx0) = o;
+        } else {
+          held[pass][r][c] = o;
+        }
+      };
       if constexpr (STAGE == 0) {
 #pragma unroll
-        for (int c = 0; c < 3; c++)
-          o[c] = gab_strip(src + c * kPlane, by, bx0, a.gab_k[c][0], a.gab_k[c][1], a.gab_k[c][2]);
+        for (int c = 0; c < 3; c++) gab_pair(p + c * kPlane, c, a.gab_k[c][0], a.gab_k[c][1], a.gab_k[c][2], put);
       } else {
-        const int sy = (clampi(fy, 0, a.h - 1) >> 3) - sby0, sx = (clampi(fx0, 0, a.w - 1) >> 3) - sbx0;
-        const float sigma = s_sigma[sy * kSigW + sx];
-        if (__all(sigma < kMinSigma)) {
-          // every strip of this wave is below MIN_SIGMA: the stage is the identity here (the
-          // reference takes the same shortcut per SIMD vector, epf1.rs:72-78)
+        const int sx = (min(max(fx0, 0), a.w - 1) >> 3) - sbx0;
+        const int sy0 = (min(max(fy, 0), a.h - 1) >> 3) - sby0, sy1 = (min(max(fy + 1, 0), a.h - 1) >> 3) - sby0;
+        const float sigma0 = s_sigma[sy0 * kSigW + sx], sigma1 = s_sigma[sy1 * kSigW + sx];
+        if (__all(sigma0 < kMinSigma && sigma1 < kMinSigma)) {
+          // every micro-tile of this wave is below MIN_SIGMA: the stage is the identity here
+          // (the reference takes the same shortcut per SIMD vector, epf1.rs:72-78)
 #pragma unroll
-          for (int c = 0; c < 3; c++) o[c] = lds_load4(src + c * kPlane + by * kBW + bx0);
+          for (int c = 0; c < 3; c++) {
+            put(0, c, lds_load4(p + c * kPlane));
+            put(1, c, lds_load4(p + c * kPlane + kBW));
+          }
         } else if constexpr (STAGE == 1) {
-          epf1_strip(src, by, bx0, fx0, fy, sigma, a, o);
+          epf1_pair(p, fx0, fy, sigma0, sigma1, a, put);
         } else {
-          epf2_strip(src, by, bx0, fx0, fy, sigma, a, o);
+          epf2_pair(p, fx0, fy, sigma0, sigma1, a, put);
         }
-      }
-      if (!live) continue;
-      if (last) {
-        if (bx0 >= kB && bx0 < kB + kTW && fy < a.y1 && fy < a.h && fx0 < a.w) {
-#pragma unroll
-          for (int c = 0; c < 3; c++) *reinterpret_cast<float4*>(a.out[c] + (size_t)fy * a.stride + fx0) = o[c];
-        }
-      } else {
-#pragma unroll
-        for (int c = 0; c < 3; c++) lds_store4(dst + c * kPlane + by * kBW + bx0, o[c]);
       }
     }
-    if (!last) {
+    if constexpr (!last) {
+      __syncthreads();  // every read of the stage's input is done
+#pragma unroll
+      for (int pass = 0; pass < kPasses; pass++) {
+        const int t = pass * kT + tid;
+        if (t >= n) continue;
+        float* d = s_buf + (kB - margin + (t / kStrips) * 2) * kBW + (t % kStrips) * 4;
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+          for (int c = 0; c < 3; c++) lds_store4(d + c * kPlane + r * kBW, held[pass][r][c]);
+      }
       __syncthreads();
       if (edge) {
-        mirror_fill(dst, margin, tx0, ty0, a.w, a.h, tid);
+        mirror_fill(s_buf, margin, tx0, ty0, a.w, a.h, tid);
         __syncthreads();
       }
-      float* t = src;
-      src = dst;
-      dst = t;
     }
   };
-  if constexpr (GAB) run_stage(std::integral_constant<int, 0>{}, 1);
-  if constexpr (E1) run_stage(std::integral_constant<int, 1>{}, 2);
-  if constexpr (E2) run_stage(std::integral_constant<int, 2>{}, 1);
+  constexpr int kMg = kBorder - (GAB ? 1 : 0);      // margin after Gaborish
+  constexpr int kMe1 = kMg - (E1 ? 2 : 0);          // after EPF1
+  if constexpr (GAB) run_stage(std::integral_constant<int, 0>{}, std::integral_constant<int, kMg>{});
+  if constexpr (E1) run_stage(std::integral_constant<int, 1>{}, std::integral_constant<int, kMe1>{});
+  if constexpr (E2) run_stage(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{});
 }
 
 template <bool GAB, bool E1, bool E2>
 void launch_variant(hipStream_t s, const FusedArgs& a) {
   const int tiles_x = (a.w + kTW - 1) / kTW, tiles_y = (a.y1 - a.y0 + kTH - 1) / kTH;
   const dim3 grid(tiles_x * ((tiles_y + 7) / 8) * 8);
-  hipLaunchKernelGGL((k23_fused_filters<GAB, E1, E2>), grid, dim3(kFusedThreads), 0, s, a);
+  hipLaunchKernelGGL((k23_fused_filters<GAB, E1, E2>), grid, dim3(kT), 0, s, a);
+}
+
+__global__ void k_selftest_recip(uint32_t lo_bits, uint32_t hi_bits, unsigned long long* mismatches) {
+  const uint32_t stride = gridDim.x * blockDim.x;
+  unsigned long long bad = 0;
+  for (uint64_t b = (uint64_t)lo_bits + blockIdx.x * blockDim.x + threadIdx.x; b < hi_bits; b += stride) {
+    const float w = __builtin_bit_cast(float, (uint32_t)b);
+    const float fast = recip_weight_sum(w);
+    const float ref = 1.0f / w;
+    bad += __builtin_bit_cast(uint32_t, fast) != __builtin_bit_cast(uint32_t, ref);
+  }
+  if (bad) atomicAdd(mismatches, bad);
 }
 
 }  // namespace
+
+void launch_selftest_recip(hipStream_t s, uint32_t lo_bits, uint32_t hi_bits, unsigned long long* mismatches) {
+  hipLaunchKernelGGL(k_selftest_recip, dim3(2048), dim3(256), 0, s, lo_bits, hi_bits, mismatches);
+}
 
 // Runs the frame's stage list (gab?, epf1?, epf2?) fused; planes -> tmp.  Returns false if the
 // combination is not covered (epf_iters == 3 or nothing to do).

@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libjxl_hip.so")
+# JXLH_LIBRARY: developer override used to A/B kernel build variants (tools/build_variant.sh)
+LIB_PATH = os.environ.get("JXLH_LIBRARY") or os.path.join(_HERE, "libjxl_hip.so")
 
 NUM_TRANSFORMS = 27
 NUM_QUANT_TABLES = 17
@@ -33,7 +34,8 @@ ABI_SYMBOLS = [
     "jxlh_frame_set_lf_quantized", "jxlh_frame_set_lf", "jxlh_frame_set_hf_meta", "jxlh_submit_group",
     "jxlh_slot_wait", "jxlh_frame_coeff_buffer", "jxlh_frame_run", "jxlh_ctx_sync", "jxlh_frame_read_planes",
     "jxlh_frame_device_planes", "jxlh_frame_read_lf", "jxlh_timer_start", "jxlh_timer_stop",
-    "jxlh_kernel_timing_enable", "jxlh_kernel_timing_get", "jxlh_kernel_timing_reset", "jxlh_stage_gaborish",
+    "jxlh_kernel_timing_enable", "jxlh_kernel_timing_get", "jxlh_kernel_timing_reset", "jxlh_selftest_recip",
+    "jxlh_stage_gaborish",
     "jxlh_stage_epf", "jxlh_stage_lf_smooth", "jxlh_stage_transform_to_pixels", "jxlh_rct", "jxlh_palette",
     "jxlh_unsqueeze", "jxlh_unsqueeze_planes", "jxlh_abi_version", "jxlh_covered_blocks_x", "jxlh_covered_blocks_y",
     "jxlh_quant_table_for_type", "jxlh_quant_table_size",
@@ -94,6 +96,7 @@ def load():
     L.jxlh_alloc_pinned.argtypes = [vp, sz, C.POINTER(vp)]
     L.jxlh_free_pinned.argtypes = [vp, vp]
     L.jxlh_frame_begin.argtypes = [vp, C.POINTER(FrameParams)]
+    L.jxlh_selftest_recip.argtypes = [vp, u32, u32, C.POINTER(C.c_uint64)]
     L.jxlh_frame_set_dequant_tables.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
     L.jxlh_frame_set_lf_quantized.argtypes = [vp, u32, u32, u32, u32, vp, vp, vp, sz, u32]
     L.jxlh_frame_set_lf.argtypes = [vp, u32, u32, u32, u32, vp, vp, vp, sz]
@@ -271,6 +274,15 @@ class Context:
         return out
 
     # ---- stage hooks ----
+    def selftest_recip(self, lo=1.0, hi=16.0):
+        """Number of floats in [lo, hi) whose fast EPF reciprocal differs from IEEE 1/w."""
+        lo_b = int(np.float32(lo).view(np.uint32))
+        hi_b = int(np.float32(hi).view(np.uint32))
+        bad = C.c_uint64(0)
+        self._chk(self.L.jxlh_selftest_recip(self._ctx, C.c_uint32(lo_b), C.c_uint32(hi_b), C.byref(bad)),
+                  "selftest_recip")
+        return int(bad.value)
+
     def stage_gaborish(self, plane, w1, w2, w=None, h=None):
         plane = np.ascontiguousarray(plane, dtype=np.float32)
         H, S = plane.shape

@@ -260,3 +260,15 @@ def test_modular_chain_config4_style(ctx, oracle):
     want = oracle.rct(cur_o, 6, 0)
     for c in range(3):
         assert np.array_equal(got[c], want[c])
+
+
+@pytest.mark.gpu
+def test_epf_fast_reciprocal_is_ieee_exact_on_weight_range():
+    """1/(1 + sum w) in the EPF kernels uses rcp + FMA refinement; it must equal IEEE division for
+    EVERY float the weight sum can take: [1, 5] for EPF1/2, [1, 13] for EPF0 -> checked on [1, 16)."""
+    from jxl_rs_amd import Context
+    c = Context(0, 1)
+    try:
+        assert c.selftest_recip(1.0, 16.0) == 0
+    finally:
+        c.close()
