@@ -41,13 +41,16 @@
 #define JXLH_FUSED_THREADS 512
 #endif
 #ifndef JXLH_FUSED_WAVES_PER_EU
-#define JXLH_FUSED_WAVES_PER_EU 4
+#define JXLH_FUSED_WAVES_PER_EU 6
 #endif
 #ifndef JXLH_FAST_RECIP
 #define JXLH_FAST_RECIP 1
 #endif
 #ifndef JXLH_E1_ROLLED
 #define JXLH_E1_ROLLED 1
+#endif
+#ifndef JXLH_E2_STRIPS
+#define JXLH_E2_STRIPS 1
 #endif
 
 namespace jxlh {
@@ -364,6 +367,50 @@ __device__ __forceinline__ void epf2_pair(const float* __restrict__ p0, int fx0,
   }
 }
 
+// ---- EPF2 on one strip (epf2.rs:84-136): the form used when EPF2 is the last stage and
+// register pressure matters more than the shared SADs of the 4x2 form
+template <class Emit>
+__device__ __forceinline__ void epf2_strip(const float* __restrict__ p0, int fx0, int fy, float sigma,
+                                           const FusedArgs& a, Emit&& emit) {
+  float t[3][4], m[3][8], b[3][4];
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    const float* p = p0 + c * kPlane;
+    load4(p - kBW, t[c]);
+    load8(p, m[c]);
+    load4(p + kBW, b[c]);
+  }
+  const bool pass = sigma < kMinSigma;
+  float is[4];
+  strip_inv_sigma(sigma, fx0, fy, a.sm2, a.bsm2, is);
+  float o[3][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const float xc = m[0][i + 2], yc = m[1][i + 2], bc = m[2][i + 2];
+    float wacc = 1.0f, xa = xc, ya = yc, ba = bc;
+    // neighbour order N, W, E, S (epf2.rs:95)
+    const float nx[4] = {t[0][i], m[0][i + 1], m[0][i + 3], b[0][i]};
+    const float ny[4] = {t[1][i], m[1][i + 1], m[1][i + 3], b[1][i]};
+    const float nb[4] = {t[2][i], m[2][i + 1], m[2][i + 3], b[2][i]};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const float sad = __builtin_fmaf(FAD(nx[k], xc), a.scale[0],
+                                       __builtin_fmaf(FAD(ny[k], yc), a.scale[1], FAD(nb[k], bc) * a.scale[2]));
+      const float wgt = fmaxf(__builtin_fmaf(sad, is[i], 1.0f), 0.0f);
+      wacc += wgt;
+      xa = __builtin_fmaf(wgt, nx[k], xa);
+      ya = __builtin_fmaf(wgt, ny[k], ya);
+      ba = __builtin_fmaf(wgt, nb[k], ba);
+    }
+    const float inv_w = recip_weight_sum(wacc);
+    o[0][i] = pass ? xc : xa * inv_w;
+    o[1][i] = pass ? yc : ya * inv_w;
+    o[2][i] = pass ? bc : ba * inv_w;
+  }
+#pragma unroll
+  for (int c = 0; c < 3; c++) emit(c, make_float4(o[c][0], o[c][1], o[c][2], o[c][3]));
+}
+
 // Overwrites out-of-frame positions of a stage's output region [B-m, B+T+m) with the values
 // at their mirrored in-frame coordinates.  Only called by tiles that touch the frame border.
 __device__ __forceinline__ void mirror_fill(float* __restrict__ buf, int m, int tx0, int ty0, int w, int h, int tid) {
@@ -478,6 +525,31 @@ __global__ __launch_bounds__(kT, JXLH_FUSED_WAVES_PER_EU) void k23_fused_filters
     constexpr int n = (rows / 2) * kStrips;
     constexpr int kPasses = (n + kT - 1) / kT;
     static_assert(rows % 2 == 0, "4x2 items");
+    if constexpr (STAGE == 2 && last && JXLH_E2_STRIPS) {
+      constexpr int ns = rows * kStrips;
+#pragma unroll 1
+      for (int t0 = 0; t0 < ns; t0 += kT) {
+        if (t0 + (tid & ~63) >= ns) break;
+        const int t = t0 + tid;
+        const bool live = t < ns;
+        const int by = kB + (live ? t / kStrips : 0), bx0 = (t % kStrips) * 4;
+        const int fy = ty0 - kB + by, fx0 = tx0 - kB + bx0;
+        const int sx = (min(max(fx0, 0), a.w - 1) >> 3) - sbx0, sy = (min(max(fy, 0), a.h - 1) >> 3) - sby0;
+        const float sigma = s_sigma[sy * kSigW + sx];
+        const float* p = s_buf + by * kBW + bx0;
+        auto put = [&](int c, float4 o) {
+          if (live && bx0 >= kB && bx0 < kB + kTW && fy < a.y1 && fy < a.h && fx0 < a.w)
+            *reinterpret_cast<float4*>(a.out[c] + (size_t)fy * a.stride + fx0) = o;
+        };
+        if (__all(sigma < kMinSigma)) {
+#pragma unroll
+          for (int c = 0; c < 3; c++) put(c, lds_load4(p + c * kPlane));
+        } else {
+          epf2_strip(p, fx0, fy, sigma, a, put);
+        }
+      }
+      return;
+    }
     float4 held[last ? 1 : kPasses][2][3];
 #pragma unroll
     for (int pass = 0; pass < kPasses; pass++) {
