@@ -70,7 +70,7 @@ struct FusedArgs {
   const float* in[3];
   float* out[3];
   const float* inv_sigma;
-  size_t stride, sigma_stride;
+  uint32_t stride, sigma_stride;  // floats; a plane is < 4 GiB (jxlh_frame_begin bounds the frame)
   int w, h;
   int y0, y1;  // output rows [y0, y1) (band sharding); tiles start at y0
   float gab_k[3][3];
@@ -79,10 +79,20 @@ struct FusedArgs {
   int tiled_in, xblocks;  // input layout (see FrameDev::tiled)
 };
 
-// float offset of frame pixel (fx, fy) in an input plane
-__device__ __forceinline__ size_t in_offset(const FusedArgs& a, int fx, int fy) {
-  return a.tiled_in ? ((size_t)((fy >> 3) * a.xblocks + (fx >> 3)) * 64 + (size_t)((fx & 7) * 8 + (fy & 7)))
-                    : ((size_t)fy * a.stride + (size_t)fx);
+// BYTE offset of frame pixel (fx, fy) in an input plane.  32-bit on purpose: with a uniform base
+// pointer the access becomes "SGPR base + 32-bit VGPR offset" instead of a 64-bit address pair
+// per lane and channel (the kernel is register-bound at 80 VGPRs).
+__device__ __forceinline__ uint32_t in_offset(const FusedArgs& a, int fx, int fy) {
+  return 4u * (a.tiled_in ? ((uint32_t)((fy >> 3) * a.xblocks + (fx >> 3)) * 64u + (uint32_t)((fx & 7) * 8 + (fy & 7)))
+                          : ((uint32_t)fy * a.stride + (uint32_t)fx));
+}
+template <class T>
+__device__ __forceinline__ const T& at_bytes(const float* base, uint32_t byte_off) {
+  return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+template <class T>
+__device__ __forceinline__ T& at_bytes(float* base, uint32_t byte_off) {
+  return *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off);
 }
 
 // DPP row shifts: lane i takes the value of lane i-1 / i+1 of its 16-lane row (the edge lanes
@@ -157,6 +167,15 @@ __device__ __forceinline__ void strip_inv_sigma(float sigma, int fx0, int fy, fl
 }
 
 
+// Where a work item sits: strip pointer in the LDS tile (plane 0, first row), frame coordinates
+// of its first pixel, 1/sigma of the block(s) its row(s) fall in.
+struct Geom {
+  const float* p;
+  int bx0, fx0, fy;
+  bool live;
+  float sigma0, sigma1;
+};
+
 // ---- Gaborish on a 4x2 micro-tile of one channel (gaborish.rs:83-85); p = strip in the first row
 template <class Emit>
 __device__ __forceinline__ void gab_pair(const float* __restrict__ p, int c, float k0, float k1, float k2,
@@ -184,10 +203,11 @@ __device__ __forceinline__ void gab_pair(const float* __restrict__ p, int c, flo
 }
 
 // ---- EPF1 on a 4x2 micro-tile, all three channels (epf1.rs:84-146).
-// p0 = the strip in the first row (plane 0); fy = frame row of the first row; emit(r, c, strip).
-template <class Emit>
-__device__ __forceinline__ void epf1_pair(const float* __restrict__ p0, int fx0, int fy, float sigma0, float sigma1,
-                                          const FusedArgs& a, Emit&& emit) {
+// p0 = the strip in the first row (plane 0); emit(geom, r, c, strip).  regeom() recomputes the
+// item's Geom from the thread id: cheaper than carrying seven registers across the map phase.
+template <class Regeom, class Emit>
+__device__ __forceinline__ void epf1_pair(const float* __restrict__ p0, Regeom&& regeom, const FusedArgs& a,
+                                          Emit&& emit) {
   float wv[3][4], wh[2][4];  // scaled plus-sums of V at rows y-1, y, y+1 and of H at rows y, y+1
 #pragma unroll
   for (int i = 0; i < 4; i++) {
@@ -256,10 +276,13 @@ __device__ __forceinline__ void epf1_pair(const float* __restrict__ p0, int fx0,
       wv[2][i] = __builtin_fmaf(pv2, scale, wv[2][i]);
     }
   }
+  const Geom g = regeom();
+  const int fx0 = g.fx0, fy = g.fy;
+  p0 = g.p;
   // per row: the weights of its 4 pixels (neighbours N, W, E, S, epf1.rs:96), then the channels
 #pragma unroll
   for (int r = 0; r < 2; r++) {
-    const float sigma = r ? sigma1 : sigma0;
+    const float sigma = r ? g.sigma1 : g.sigma0;
     const bool pass = sigma < kMinSigma;
     float is[4], wgt[4][4], inv_w[4];
     strip_inv_sigma(sigma, fx0, fy + r, a.sm1, a.bsm1, is);
@@ -292,7 +315,7 @@ __device__ __forceinline__ void epf1_pair(const float* __restrict__ p0, int fx0,
         acc = __builtin_fmaf(N[i], wgt[i][0], acc);
         o[i] = pass ? M[i + 2] : acc * inv_w[i];
       }
-      emit(r, c, make_float4(o[0], o[1], o[2], o[3]));
+      emit(g, r, c, make_float4(o[0], o[1], o[2], o[3]));
     }
   }
 }
@@ -431,7 +454,7 @@ __global__ __launch_bounds__(kT, JXLH_FUSED_WAVES_PER_EU) void k23_fused_filters
   __shared__ __attribute__((aligned(16))) float s_buf[3 * kPlane];
   // 1/sigma of the 8x8 blocks this tile touches (block columns/rows relative to the tile's first block)
   __shared__ float s_sigma[kSigH * kSigW];
-  const int tid = threadIdx.x;
+  const int tid_kernel = threadIdx.x, tid = tid_kernel;
   // blockIdx.x enumerates tiles so that the workgroups one XCD receives (ids congruent mod 8)
   // walk along a tile row: neighbouring tiles share 128-byte output lines and halo input
   // lines, which then meet in the same (non-coherent) L2.
@@ -453,7 +476,7 @@ __global__ __launch_bounds__(kT, JXLH_FUSED_WAVES_PER_EU) void k23_fused_filters
   if constexpr (E1 || E2) {
     if (tid < kSigH * kSigW) {
       const int sx = min(sbx0 + tid % kSigW, (a.w - 1) >> 3), sy = min(sby0 + tid / kSigW, (a.h - 1) >> 3);
-      s_sigma[tid] = a.inv_sigma[(size_t)sy * a.sigma_stride + sx];
+      s_sigma[tid] = at_bytes<float>(a.inv_sigma, 4u * ((uint32_t)sy * a.sigma_stride + (uint32_t)sx));
     }
   }
   // ---- stage the input tile (region margin = kBorder) with mirrored coordinates
@@ -476,10 +499,10 @@ __global__ __launch_bounds__(kT, JXLH_FUSED_WAVES_PER_EU) void k23_fused_filters
         const int bx = xh * 32 + (l & 31), yg = yg0 + ypair * 2 + (l >> 5);
         if (idx >= items || yg * 4 >= kBH) continue;
         const int by = yg * 4;
-        const size_t off = in_offset(a, tx0 - kB + bx, ty0 - kB + by);
+        const uint32_t off = in_offset(a, tx0 - kB + bx, ty0 - kB + by);
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-          const float4 v = *reinterpret_cast<const float4*>(a.in[c] + off);
+          const float4 v = at_bytes<float4>(a.in[c], off);
           float* d = s_buf + c * kPlane + by * kBW + bx;
           d[0] = v.x;
           d[kBW] = v.y;
@@ -490,10 +513,10 @@ __global__ __launch_bounds__(kT, JXLH_FUSED_WAVES_PER_EU) void k23_fused_filters
     } else if (!edge) {  // interior tile, raster input: pure 16-byte coalesced rows
       for (int idx = tid; idx < kStrips * rows; idx += kT) {
         const int by = kB - m + idx / kStrips, bx0 = (idx % kStrips) * 4;
-        const size_t off = in_offset(a, tx0 - kB + bx0, ty0 - kB + by);
+        const uint32_t off = in_offset(a, tx0 - kB + bx0, ty0 - kB + by);
 #pragma unroll
         for (int c = 0; c < 3; c++)
-          lds_store4(s_buf + c * kPlane + by * kBW + bx0, *reinterpret_cast<const float4*>(a.in[c] + off));
+          lds_store4(s_buf + c * kPlane + by * kBW + bx0, at_bytes<float4>(a.in[c], off));
       }
     } else {
       for (int idx = tid; idx < kStrips * rows; idx += kT) {
@@ -502,12 +525,12 @@ __global__ __launch_bounds__(kT, JXLH_FUSED_WAVES_PER_EU) void k23_fused_filters
         const int fx0 = tx0 - kB + bx0;
         const int x0 = mirror(fx0, a.w), x1 = mirror(fx0 + 1, a.w), x2 = mirror(fx0 + 2, a.w),
                   x3 = mirror(fx0 + 3, a.w);
-        const size_t o0 = in_offset(a, x0, fy), o1 = in_offset(a, x1, fy), o2 = in_offset(a, x2, fy),
-                     o3 = in_offset(a, x3, fy);
+        const uint32_t o0 = in_offset(a, x0, fy), o1 = in_offset(a, x1, fy), o2 = in_offset(a, x2, fy),
+                       o3 = in_offset(a, x3, fy);
 #pragma unroll
         for (int c = 0; c < 3; c++) {
           const float* __restrict__ pl = a.in[c];
-          lds_store4(s_buf + c * kPlane + by * kBW + bx0, make_float4(pl[o0], pl[o1], pl[o2], pl[o3]));
+          lds_store4(s_buf + c * kPlane + by * kBW + bx0, make_float4(at_bytes<float>(pl, o0), at_bytes<float>(pl, o1), at_bytes<float>(pl, o2), at_bytes<float>(pl, o3)));
         }
       }
     }
@@ -525,6 +548,11 @@ __global__ __launch_bounds__(kT, JXLH_FUSED_WAVES_PER_EU) void k23_fused_filters
     constexpr int n = (rows / 2) * kStrips;
     constexpr int kPasses = (n + kT - 1) / kT;
     static_assert(rows % 2 == 0, "4x2 items");
+    // Opaque copy of the thread id: everything a stage derives from it (item coordinates, sigma
+    // indices, store offsets) is then computed inside the stage instead of being hoisted above
+    // the previous stage, where it would sit in registers the 80-VGPR budget does not have.
+    int tid = tid_kernel;
+    asm volatile("" : "+v"(tid));
     if constexpr (STAGE == 2 && last && JXLH_E2_STRIPS) {
       constexpr int ns = rows * kStrips;
 #pragma unroll 1
@@ -539,7 +567,7 @@ __global__ __launch_bounds__(kT, JXLH_FUSED_WAVES_PER_EU) void k23_fused_filters
         const float* p = s_buf + by * kBW + bx0;
         auto put = [&](int c, float4 o) {
           if (live && bx0 >= kB && bx0 < kB + kTW && fy < a.y1 && fy < a.h && fx0 < a.w)
-            *reinterpret_cast<float4*>(a.out[c] + (size_t)fy * a.stride + fx0) = o;
+            at_bytes<float4>(a.out[c], 4u * ((uint32_t)fy * a.stride + (uint32_t)fx0)) = o;
         };
         if (__all(sigma < kMinSigma)) {
 #pragma unroll
@@ -554,39 +582,54 @@ __global__ __launch_bounds__(kT, JXLH_FUSED_WAVES_PER_EU) void k23_fused_filters
 #pragma unroll
     for (int pass = 0; pass < kPasses; pass++) {
       if (pass * kT + (tid & ~63) >= n) continue;  // wave-uniform: nothing left for this wave
-      const int t = pass * kT + tid;
-      const bool live = t < n;
-      const int by = kB - margin + (live ? (t / kStrips) * 2 : 0), bx0 = (t % kStrips) * 4;
-      const int fy = ty0 - kB + by, fx0 = tx0 - kB + bx0;
-      const float* p = s_buf + by * kBW + bx0;
-      auto put = [&](int r, int c, float4 o) {
+      auto geom = [&]() -> Geom {
+        int tl = tid_kernel;
+        asm volatile("" : "+v"(tl));  // recomputed where needed, not kept (see epf1_pair)
+        const int t = pass * kT + tl;
+        Geom g;
+        g.live = t < n;
+        const int by = kB - margin + (g.live ? (t / kStrips) * 2 : 0);
+        g.bx0 = (t % kStrips) * 4;
+        g.fy = ty0 - kB + by;
+        g.fx0 = tx0 - kB + g.bx0;
+        g.p = s_buf + by * kBW + g.bx0;
+        if constexpr (STAGE != 0) {
+          const int sx = (min(max(g.fx0, 0), a.w - 1) >> 3) - sbx0;
+          const int sy0 = (min(max(g.fy, 0), a.h - 1) >> 3) - sby0, sy1 = (min(max(g.fy + 1, 0), a.h - 1) >> 3) - sby0;
+          g.sigma0 = s_sigma[sy0 * kSigW + sx];
+          g.sigma1 = s_sigma[sy1 * kSigW + sx];
+        } else {
+          g.sigma0 = g.sigma1 = 0.0f;
+        }
+        return g;
+      };
+      auto put = [&](const Geom& g, int r, int c, float4 o) {
         if constexpr (last) {
-          const int fyr = fy + r;
-          if (live && bx0 >= kB && bx0 < kB + kTW && fyr < a.y1 && fyr < a.h && fx0 < a.w)
-            *reinterpret_cast<float4*>(a.out[c] + (size_t)fyr * a.stride + fx0) = o;
+          const int fyr = g.fy + r;
+          if (g.live && g.bx0 >= kB && g.bx0 < kB + kTW && fyr < a.y1 && fyr < a.h && g.fx0 < a.w)
+            at_bytes<float4>(a.out[c], 4u * ((uint32_t)fyr * a.stride + (uint32_t)g.fx0)) = o;
         } else {
           held[pass][r][c] = o;
         }
       };
+      const Geom g = geom();
+      auto put_g = [&](int r, int c, float4 o) { put(g, r, c, o); };
       if constexpr (STAGE == 0) {
 #pragma unroll
-        for (int c = 0; c < 3; c++) gab_pair(p + c * kPlane, c, a.gab_k[c][0], a.gab_k[c][1], a.gab_k[c][2], put);
+        for (int c = 0; c < 3; c++) gab_pair(g.p + c * kPlane, c, a.gab_k[c][0], a.gab_k[c][1], a.gab_k[c][2], put_g);
       } else {
-        const int sx = (min(max(fx0, 0), a.w - 1) >> 3) - sbx0;
-        const int sy0 = (min(max(fy, 0), a.h - 1) >> 3) - sby0, sy1 = (min(max(fy + 1, 0), a.h - 1) >> 3) - sby0;
-        const float sigma0 = s_sigma[sy0 * kSigW + sx], sigma1 = s_sigma[sy1 * kSigW + sx];
-        if (__all(sigma0 < kMinSigma && sigma1 < kMinSigma)) {
+        if (__all(g.sigma0 < kMinSigma && g.sigma1 < kMinSigma)) {
           // every micro-tile of this wave is below MIN_SIGMA: the stage is the identity here
           // (the reference takes the same shortcut per SIMD vector, epf1.rs:72-78)
 #pragma unroll
           for (int c = 0; c < 3; c++) {
-            put(0, c, lds_load4(p + c * kPlane));
-            put(1, c, lds_load4(p + c * kPlane + kBW));
+            put_g(0, c, lds_load4(g.p + c * kPlane));
+            put_g(1, c, lds_load4(g.p + c * kPlane + kBW));
           }
         } else if constexpr (STAGE == 1) {
-          epf1_pair(p, fx0, fy, sigma0, sigma1, a, put);
+          epf1_pair(g.p, geom, a, put);
         } else {
-          epf2_pair(p, fx0, fy, sigma0, sigma1, a, put);
+          epf2_pair(g.p, g.fx0, g.fy, g.sigma0, g.sigma1, a, put_g);
         }
       }
     }
@@ -656,8 +699,8 @@ bool launch_fused_filters(hipStream_t s, const FrameDev& f, int y0, int y1) {
     for (int k = 0; k < 3; k++) a.gab_k[c][k] = f.gab_k[c][k];
   }
   a.inv_sigma = f.inv_sigma;
-  a.stride = f.plane_stride;
-  a.sigma_stride = (size_t)f.xblocks;
+  a.stride = (uint32_t)f.plane_stride;
+  a.sigma_stride = (uint32_t)f.xblocks;
   a.w = f.xsize;
   a.h = f.ysize;
   a.y0 = y0;

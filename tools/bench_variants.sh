@@ -2,7 +2,7 @@
 # runs bench.py (kernel times only) for the product library and every variant under jxl_rs_amd/variants
 cd "$(dirname "$0")/.."
 modes=${MODES:-"spec passthrough"}
-for lib in jxl_rs_amd/libjxl_hip.so jxl_rs_amd/variants/*.so; do
+for lib in jxl_rs_amd/libjxl_hip.so $(ls jxl_rs_amd/variants/*.so 2>/dev/null); do
   for m in $modes; do
     JXLH_LIBRARY=$PWD/$lib timeout 200 python bench.py --no-cpu --inflight 1 --epf $m ${BENCH_ARGS} 2>&1 | tail -1 | python -c "
 import sys,json
