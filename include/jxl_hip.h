@@ -145,6 +145,35 @@ jxlh_status jxlh_frame_set_hf_meta(jxlh_ctx* ctx, uint32_t x0, uint32_t y0, uint
 jxlh_status jxlh_submit_group(jxlh_ctx* ctx, int32_t slot, uint32_t group_id, const int32_t* coeffs,
                               uint32_t flags);
 enum { JXLH_GROUP_COMPLETE = 1u << 0 /* set_buffer_for_group(.., complete = true, ..) */ };
+
+/* Sparse form of jxlh_submit_group (the dense i32 slab is ~90 % zeros at d1 and
+ * its PCIe transfer bounds end-to-end decode).  The entropy loop of decode_vardct_group
+ * (frame/group.rs:560-575: `coeffs[c][offset + order[k]] += v`) emits one pair per non-zero
+ * coefficient instead of writing a dense slab:
+ *   pairs   n[0] pairs of channel X, then n[1] of Y, then n[2] of B, contiguous; pos = index inside
+ *           the channel's 65536-entry slab (the same index space as the dense form)
+ *   wide    values that do not fit i16 (the reference stores i32), pos = channel * 65536 + index
+ * Duplicate positions accumulate with wrapping i32 adds (multi-pass accumulation).  The device
+ * zero-fills the group's slab and scatters the pairs when the frame is run; everything downstream
+ * is identical to the dense path.  Asynchronous like jxlh_submit_group (H2D on the slot's stream;
+ * pinned host memory from jxlh_alloc_pinned overlaps with compute). */
+typedef struct jxlh_coeff16 {
+  uint16_t pos;
+  int16_t val;
+} jxlh_coeff16;
+typedef struct jxlh_coeff32 {
+  uint32_t pos;
+  int32_t val;
+} jxlh_coeff32;
+jxlh_status jxlh_submit_group_sparse(jxlh_ctx* ctx, int32_t slot, uint32_t group_id, const jxlh_coeff16* pairs,
+                                     const uint32_t n[3], const jxlh_coeff32* wide, uint32_t n_wide,
+                                     uint32_t flags);
+/* The same for `count` groups decoded by one host thread: one H2D copy for all of them.
+ * pairs holds the groups' pair runs back to back in the order of group_ids; n is count x 3;
+ * wide positions carry the group: pos = (group_id * 3 + channel) * 65536 + index. */
+jxlh_status jxlh_submit_groups_sparse(jxlh_ctx* ctx, int32_t slot, uint32_t count, const uint32_t* group_ids,
+                                      const jxlh_coeff16* pairs, const uint32_t* n, const jxlh_coeff32* wide,
+                                      uint32_t n_wide, uint32_t flags);
 jxlh_status jxlh_slot_wait(jxlh_ctx* ctx, int32_t slot);
 
 /* Device-resident coefficient store of the current frame (ngroups * 3 * 65536 i32), for callers

@@ -63,11 +63,23 @@ struct jxlh_ctx {
   DevBuf<uint8_t> transform_map, epf_map;
   DevBuf<int8_t> ytox, ytob;
   DevBuf<int> error_flag;
+  int* host_flag = nullptr;  // pinned
   DevBuf<uint8_t> worklist;
   float* result[3] = {nullptr, nullptr, nullptr};
   // stage hooks scratch
   DevBuf<float> hook_f[8];
   DevBuf<int32_t> hook_i[4];
+  // sparse coefficient transport (jxlh_submit_group(s)_sparse): pairs land in sp_pairs (bump
+  // allocated, sized for a frame's worst case), are expanded by the next jxlh_frame_run
+  std::mutex sp_mutex;
+  DevBuf<uint32_t> sp_pairs;
+  DevBuf<SparseGroup> sp_groups_dev;
+  DevBuf<uint2> sp_wide_dev;
+  std::vector<SparseGroup> sp_pending, sp_upload;
+  std::vector<uint2> sp_wide, sp_wide_upload;
+  size_t sp_used = 0;
+  hipEvent_t sp_expanded = nullptr;
+  bool sp_expanded_valid = false;
   // profiling
   bool timing = false;
   std::vector<KernelTime> ktimes;
@@ -273,6 +285,10 @@ void jxlh_ctx_destroy(jxlh_ctx* ctx) {
   release(ctx->sigma);
   release(ctx->tables);
   release(ctx->coeffs);
+  release(ctx->sp_pairs);
+  release(ctx->sp_groups_dev);
+  release(ctx->sp_wide_dev);
+  if (ctx->sp_expanded) (void)hipEventDestroy(ctx->sp_expanded);
   release(ctx->raw_quant);
   release(ctx->lfq);
   release(ctx->transform_map);
@@ -280,6 +296,7 @@ void jxlh_ctx_destroy(jxlh_ctx* ctx) {
   release(ctx->ytox);
   release(ctx->ytob);
   release(ctx->error_flag);
+  if (ctx->host_flag) (void)hipHostFree(ctx->host_flag);
   release(ctx->worklist);
   for (auto& b : ctx->hook_f) release(b);
   for (auto& b : ctx->hook_i) release(b);
@@ -324,9 +341,16 @@ jxlh_status jxlh_frame_begin(jxlh_ctx* ctx, const jxlh_frame_params* p) {
   f.plane_stride = round_up((size_t)f.xblocks * 8, 64);
   const size_t plane_elems = f.plane_stride * (size_t)f.yblocks * 8;
   // K1 uses 32-bit pixel and coefficient offsets
-  if (plane_elems >= (1ull << 31) || (size_t)f.xgroups * f.ygroups * 3 * kGroupArea >= (1ull << 31))
+  // planes are addressed with 32-bit BYTE offsets in the filter kernels, coefficients with 32-bit indices
+  if (plane_elems >= (1ull << 30) || (size_t)f.xgroups * f.ygroups * 3 * kGroupArea >= (1ull << 31))
     return JXLH_ERR_UNSUPPORTED;
   ctx->ngroups = (size_t)f.xgroups * f.ygroups;
+  {
+    std::lock_guard<std::mutex> lock(ctx->sp_mutex);
+    ctx->sp_pending.clear();
+    ctx->sp_wide.clear();
+    ctx->sp_used = 0;
+  }
   const size_t nblocks = (size_t)f.xblocks * f.yblocks;
   const size_t ncmap = (size_t)f.cmap_stride * ((f.yblocks + 7) / 8);
   jxlh_status st;
@@ -518,6 +542,73 @@ jxlh_status jxlh_submit_group(jxlh_ctx* ctx, int32_t slot, uint32_t group_id, co
   return JXLH_OK;
 }
 
+jxlh_status jxlh_submit_groups_sparse(jxlh_ctx* ctx, int32_t slot, uint32_t count, const uint32_t* group_ids,
+                                      const jxlh_coeff16* pairs, const uint32_t* n, const jxlh_coeff32* wide,
+                                      uint32_t n_wide, uint32_t flags) {
+  if (!ctx || slot < 0 || (size_t)slot >= ctx->slots.size() || !group_ids || !n || (n_wide && !wide))
+    return JXLH_ERR_INVALID_ARGUMENT;
+  if (!ctx->in_frame) return JXLH_ERR_BAD_STATE;
+  if (!(flags & JXLH_GROUP_COMPLETE)) return JXLH_ERR_UNSUPPORTED;
+  if (count == 0) return JXLH_OK;
+  size_t total = 0;
+  for (uint32_t i = 0; i < count; i++) {
+    if (group_ids[i] >= ctx->ngroups) return JXLH_ERR_INVALID_ARGUMENT;
+    total += (size_t)n[3 * i] + n[3 * i + 1] + n[3 * i + 2];
+  }
+  if (total && !pairs) return JXLH_ERR_INVALID_ARGUMENT;
+  const size_t wide_limit = ctx->ngroups * 3 * (size_t)kGroupArea;
+  for (uint32_t i = 0; i < n_wide; i++)
+    if (wide[i].pos >= wide_limit) return JXLH_ERR_INVALID_ARGUMENT;
+  Slot& s = ctx->slots[slot];
+  size_t offset;
+  {
+    std::lock_guard<std::mutex> lock(ctx->sp_mutex);
+    const size_t capacity = ctx->ngroups * 3 * (size_t)kGroupArea;  // one pair per coefficient
+    if (jxlh_status st = ensure(ctx, ctx->sp_pairs, capacity)) return st;
+    if (!ctx->sp_expanded) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->sp_expanded, hipEventDisableTiming));
+    if (ctx->sp_used + total > capacity) return JXLH_ERR_INVALID_ARGUMENT;  // more pairs than coefficients
+    offset = ctx->sp_used;
+    ctx->sp_used += total;
+    size_t o = offset;
+    for (uint32_t i = 0; i < count; i++) {
+      SparseGroup g;
+      g.group = group_ids[i];
+      g.offset = (uint32_t)o;
+      for (int c = 0; c < 3; c++) {
+        g.n[c] = n[3 * i + c];
+        o += g.n[c];
+      }
+      ctx->sp_pending.push_back(g);
+    }
+    for (uint32_t i = 0; i < n_wide; i++) ctx->sp_wide.push_back(make_uint2(wide[i].pos, (uint32_t)wide[i].val));
+  }
+  // the pair buffer is recycled per frame: the previous frame's expansion must have read it
+  if (ctx->sp_expanded_valid) HIPCHK(ctx, hipStreamWaitEvent(s.stream, ctx->sp_expanded, 0));
+  if (total)
+    HIPCHK(ctx, hipMemcpyAsync(ctx->sp_pairs.p + offset, pairs, total * sizeof(uint32_t), hipMemcpyDefault, s.stream));
+  HIPCHK(ctx, hipEventRecord(s.done, s.stream));
+  s.used = true;
+  return JXLH_OK;
+}
+
+jxlh_status jxlh_submit_group_sparse(jxlh_ctx* ctx, int32_t slot, uint32_t group_id, const jxlh_coeff16* pairs,
+                                     const uint32_t n[3], const jxlh_coeff32* wide, uint32_t n_wide,
+                                     uint32_t flags) {
+  if (!ctx || !n) return JXLH_ERR_INVALID_ARGUMENT;
+  if (group_id >= ctx->ngroups) return JXLH_ERR_INVALID_ARGUMENT;
+  // the single-group form addresses wide entries relative to the group
+  std::vector<jxlh_coeff32> w;
+  if (n_wide) {
+    if (!wide) return JXLH_ERR_INVALID_ARGUMENT;
+    w.assign(wide, wide + n_wide);
+    for (auto& e : w) {
+      if (e.pos >= 3u * kGroupArea) return JXLH_ERR_INVALID_ARGUMENT;
+      e.pos += group_id * 3u * kGroupArea;
+    }
+  }
+  return jxlh_submit_groups_sparse(ctx, slot, 1, &group_id, pairs, n, w.data(), n_wide, flags);
+}
+
 jxlh_status jxlh_slot_wait(jxlh_ctx* ctx, int32_t slot) {
   if (!ctx || slot < 0 || (size_t)slot >= ctx->slots.size()) return JXLH_ERR_INVALID_ARGUMENT;
   HIPCHK(ctx, hipStreamSynchronize(ctx->slots[slot].stream));
@@ -542,6 +633,33 @@ jxlh_status jxlh_frame_run(jxlh_ctx* ctx, uint32_t group_row0, uint32_t group_ro
   // coefficient uploads issued on slot streams must land before K1
   for (auto& s : ctx->slots) {
     if (s.used) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, s.done, 0));
+  }
+  // ---- sparse coefficient transport: zero-fill + scatter the pairs submitted since the last run
+  {
+    std::lock_guard<std::mutex> lock(ctx->sp_mutex);
+    if (!ctx->sp_pending.empty() || !ctx->sp_wide.empty()) {
+      ctx->sp_upload.swap(ctx->sp_pending);  // stays alive until the next run: the H2D copies read it
+      ctx->sp_wide_upload.swap(ctx->sp_wide);
+      ctx->sp_pending.clear();
+      ctx->sp_wide.clear();
+      const size_t ng = ctx->sp_upload.size(), nw = ctx->sp_wide_upload.size();
+      if (jxlh_status st = ensure(ctx, ctx->sp_groups_dev, ng)) return st;
+      if (jxlh_status st = ensure(ctx, ctx->sp_wide_dev, nw)) return st;
+      if (ng)
+        HIPCHK(ctx, hipMemcpyAsync(ctx->sp_groups_dev.p, ctx->sp_upload.data(), ng * sizeof(SparseGroup),
+                                   hipMemcpyHostToDevice, ctx->stream));
+      if (nw)
+        HIPCHK(ctx, hipMemcpyAsync(ctx->sp_wide_dev.p, ctx->sp_wide_upload.data(), nw * sizeof(uint2),
+                                   hipMemcpyHostToDevice, ctx->stream));
+      {
+        ScopedKernelTimer t(ctx, "k_expand_sparse");
+        launch_expand_sparse(ctx->stream, ctx->coeffs.p, ctx->sp_pairs.p, ctx->sp_groups_dev.p, (int)ng,
+                             ctx->sp_wide_dev.p, (uint32_t)nw);
+      }
+      HIPCHK(ctx, hipEventRecord(ctx->sp_expanded, ctx->stream));
+      ctx->sp_expanded_valid = true;
+      ctx->sp_used = 0;
+    }
   }
   // ---- K0b: Frame::finalize_lf (frame/mod.rs:360-378)
   const bool smooth = p.do_lf_smoothing && f.xblocks > 2 && f.yblocks > 2;  // adaptive_lf_smoothing.rs:51-53
@@ -639,12 +757,16 @@ jxlh_status jxlh_frame_run(jxlh_ctx* ctx, uint32_t group_row0, uint32_t group_ro
 
 jxlh_status jxlh_ctx_sync(jxlh_ctx* ctx) {
   if (!ctx) return JXLH_ERR_INVALID_ARGUMENT;
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   if (ctx->in_frame && ctx->error_flag.p) {
-    int flag = 0;
-    HIPCHK(ctx, hipMemcpy(&flag, ctx->error_flag.p, sizeof(int), hipMemcpyDeviceToHost));
-    if (flag != 0) return (jxlh_status)flag;
+    // read the flag on the context's own stream into pinned memory: a synchronous hipMemcpy would
+    // go through the null stream and serialise against other contexts' work
+    if (!ctx->host_flag) HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->host_flag), sizeof(int), hipHostMallocDefault));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->host_flag, ctx->error_flag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (*ctx->host_flag != 0) return (jxlh_status)*ctx->host_flag;
+    return JXLH_OK;
   }
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return JXLH_OK;
 }
 

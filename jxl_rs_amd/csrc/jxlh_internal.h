@@ -142,6 +142,14 @@ void launch_epf(hipStream_t s, int stage, const EpfArgs& a, int y0, int y1);
 // Gaborish/EPF1/EPF2 of the frame's stage list in one LDS-tiled pass, planes -> tmp, output rows [y0, y1).
 // Returns false when the stage list is not covered (EPF0, i.e. epf_iters == 3, or no stage at all).
 bool launch_fused_filters(hipStream_t s, const FrameDev& f, int y0, int y1);
+// sparse coefficient transport (k_coeffs.hip): one descriptor per submitted group
+struct SparseGroup {
+  uint32_t group;   // group id
+  uint32_t offset;  // index of the group's first pair in the pair buffer (X pairs, then Y, then B)
+  uint32_t n[3];    // pairs per channel
+};
+void launch_expand_sparse(hipStream_t s, int32_t* coeffs, const uint32_t* pairs, const SparseGroup* groups,
+                          int n_groups, const uint2* wide, uint32_t n_wide);
 // counts floats with bit patterns in [lo_bits, hi_bits) whose fast reciprocal differs from 1.0f / w
 void launch_selftest_recip(hipStream_t s, uint32_t lo_bits, uint32_t hi_bits, unsigned long long* mismatches);
 void launch_transform_to_pixels(hipStream_t s, int type, uint32_t n, const float* coeffs, const float* lf,

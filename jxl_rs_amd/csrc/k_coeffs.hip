@@ -1,0 +1,73 @@
+// Sparse coefficient transport: on-device zero-fill + scatter of the entropy decoder's
+// (position, value) stream into the dense per-group slabs K1 reads.
+//
+// The reference keeps coeffs[3][65536] i32 dense per group (frame/group.rs:437-440, with the TODO
+// "use 16 bits if possible", :53-55, :428) and fills it with `coeffs[c][offset + order[k]] += v`
+// while decoding (:560-575); at d1 about 90 % of the slab stays zero.  Shipping the dense slab over
+// PCIe (12 B/px) is the end-to-end limiter, so the host sends only the
+// non-zero entries as 4-byte (u16 position, i16 value) pairs per channel -- values outside i16
+// travel in a side list of 8-byte pairs -- and this kernel rebuilds the slab in HBM:
+//   one 1024-thread workgroup per quarter of a (group, channel) slab: the 64 KB quarter is built in
+//   LDS (zero, then ds_add scatter of the channel's pairs that fall into it -- wrapping i32 `+=`:
+//   duplicate positions accumulate like the reference's multi-pass accumulation, and the result
+//   is order independent) and leaves as 16-byte coalesced stores, so HBM sees exactly one dense
+//   write of the slab and one read of the pairs per quarter (the pair runs are tiny and L2-hot).
+#include "jxlh_internal.h"
+
+namespace jxlh {
+namespace {
+
+constexpr int kExpandThreads = 1024;
+constexpr int kQuarter = kGroupArea / 4;  // 16384 coefficients = 64 KB of LDS
+
+__global__ __launch_bounds__(kExpandThreads) void k_expand_sparse(int32_t* __restrict__ coeffs,
+                                                                  const uint32_t* __restrict__ pairs,
+                                                                  const SparseGroup* __restrict__ groups) {
+  __shared__ __attribute__((aligned(16))) int32_t s_q[kQuarter];
+  const int q = blockIdx.x & 3, c = (blockIdx.x >> 2) % 3, tid = threadIdx.x;
+  const SparseGroup sg = groups[blockIdx.x / 12];
+  int4* s4 = reinterpret_cast<int4*>(s_q);
+#pragma unroll
+  for (int i = 0; i < kQuarter / 4 / kExpandThreads; i++) s4[i * kExpandThreads + tid] = make_int4(0, 0, 0, 0);
+  __syncthreads();
+  const uint32_t n = sg.n[c];
+  const uint32_t first = sg.offset + (c > 0 ? sg.n[0] : 0u) + (c > 1 ? sg.n[1] : 0u);
+  const uint32_t* __restrict__ src = pairs + first;
+  // 8 independent loads in flight per thread: the scan is latency bound otherwise
+  for (uint32_t base = 0; base < n; base += 8 * kExpandThreads) {
+    uint32_t v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const uint32_t i = base + j * kExpandThreads + tid;
+      v[j] = i < n ? src[i] : 0xffffffffu;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const uint32_t i = base + j * kExpandThreads + tid;
+      const uint32_t pos = v[j] & 0xffffu;  // little endian {u16 pos; i16 val}
+      if (i < n && (int)(pos >> 14) == q) atomicAdd(&s_q[pos & (kQuarter - 1)], (int32_t)(int16_t)(v[j] >> 16));
+    }
+  }
+  __syncthreads();
+  int4* d4 = reinterpret_cast<int4*>(coeffs + ((size_t)sg.group * 3 + c) * kGroupArea + q * kQuarter);
+#pragma unroll
+  for (int i = 0; i < kQuarter / 4 / kExpandThreads; i++) d4[i * kExpandThreads + tid] = s4[i * kExpandThreads + tid];
+}
+
+// values outside i16: pos = (group * 3 + channel) * 65536 + position
+__global__ void k_expand_wide(int32_t* __restrict__ coeffs, const uint2* __restrict__ wide, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) atomicAdd(&coeffs[wide[i].x], (int32_t)wide[i].y);
+}
+
+}  // namespace
+
+void launch_expand_sparse(hipStream_t s, int32_t* coeffs, const uint32_t* pairs, const SparseGroup* groups,
+                          int n_groups, const uint2* wide, uint32_t n_wide) {
+  if (n_groups > 0)
+    hipLaunchKernelGGL(k_expand_sparse, dim3(n_groups * 12), dim3(kExpandThreads), 0, s, coeffs, pairs, groups);
+  if (n_wide > 0)
+    hipLaunchKernelGGL(k_expand_wide, dim3((n_wide + 255) / 256), dim3(256), 0, s, coeffs, wide, n_wide);
+}
+
+}  // namespace jxlh

@@ -32,7 +32,7 @@ ABI_SYMBOLS = [
     "jxlh_default_frame_params", "jxlh_ctx_create", "jxlh_ctx_destroy", "jxlh_status_string", "jxlh_last_error",
     "jxlh_alloc_pinned", "jxlh_free_pinned", "jxlh_frame_begin", "jxlh_frame_set_dequant_tables",
     "jxlh_frame_set_lf_quantized", "jxlh_frame_set_lf", "jxlh_frame_set_hf_meta", "jxlh_submit_group",
-    "jxlh_slot_wait", "jxlh_frame_coeff_buffer", "jxlh_frame_run", "jxlh_ctx_sync", "jxlh_frame_read_planes",
+    "jxlh_submit_group_sparse", "jxlh_submit_groups_sparse", "jxlh_slot_wait", "jxlh_frame_coeff_buffer", "jxlh_frame_run", "jxlh_ctx_sync", "jxlh_frame_read_planes",
     "jxlh_frame_device_planes", "jxlh_frame_read_lf", "jxlh_timer_start", "jxlh_timer_stop",
     "jxlh_kernel_timing_enable", "jxlh_kernel_timing_get", "jxlh_kernel_timing_reset", "jxlh_selftest_recip",
     "jxlh_stage_gaborish",
@@ -103,6 +103,8 @@ def load():
     L.jxlh_frame_set_hf_meta.argtypes = [vp, u32, u32, u32, u32, vp, vp, vp, sz, vp, vp, sz]
     L.jxlh_submit_group.argtypes = [vp, i32, u32, vp, u32]
     L.jxlh_slot_wait.argtypes = [vp, i32]
+    L.jxlh_submit_group_sparse.argtypes = [vp, i32, u32, vp, vp, vp, u32, u32]
+    L.jxlh_submit_groups_sparse.argtypes = [vp, i32, u32, vp, vp, vp, vp, u32, u32]
     L.jxlh_frame_coeff_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
     L.jxlh_frame_run.argtypes = [vp, u32, u32]
     L.jxlh_ctx_sync.argtypes = [vp]
@@ -152,6 +154,9 @@ class Context:
 
     def close(self):
         if self._ctx:
+            for addr in getattr(self, "_pinned", []):
+                self.L.jxlh_free_pinned(self._ctx, C.c_void_p(addr))
+            self._pinned = []
             self.L.jxlh_ctx_destroy(self._ctx)
             self._ctx = C.c_void_p()
 
@@ -212,6 +217,38 @@ class Context:
             self._keep.append(coeffs)  # async H2D: keep alive until the slot is waited on
         self._chk(self.L.jxlh_submit_group(self._ctx, slot, group_id, _addr(coeffs), flags), "submit_group")
 
+    def submit_group_sparse(self, group_id, pairs, n, wide=None, slot=0, flags=GROUP_COMPLETE):
+        """pairs: uint32 array of little-endian {u16 pos; i16 val} (X run, Y run, B run); n: 3 counts;
+        wide: uint32 array [k, 2] of (channel*65536 + pos, value) for values outside i16."""
+        pairs = np.ascontiguousarray(pairs, dtype=np.uint32)
+        n = np.ascontiguousarray(n, dtype=np.uint32)
+        nw = 0 if wide is None else len(wide)
+        wide = None if nw == 0 else np.ascontiguousarray(wide, dtype=np.uint32)
+        self._keep.append((pairs, n, wide))
+        self._chk(self.L.jxlh_submit_group_sparse(self._ctx, slot, group_id, _addr(pairs) if pairs.size else None,
+                                                  _addr(n), None if wide is None else _addr(wide), nw, flags),
+                  "submit_group_sparse")
+
+    def submit_groups_sparse(self, group_ids, pairs, n, wide=None, slot=0, flags=GROUP_COMPLETE):
+        """Batched form; pairs may be a numpy array or a raw host address (pinned memory)."""
+        group_ids = np.ascontiguousarray(group_ids, dtype=np.uint32)
+        n = np.ascontiguousarray(n, dtype=np.uint32)
+        nw = 0 if wide is None else len(wide)
+        wide = None if nw == 0 else np.ascontiguousarray(wide, dtype=np.uint32)
+        addr = pairs if isinstance(pairs, int) else _addr(np.ascontiguousarray(pairs, dtype=np.uint32))
+        self._keep.append((group_ids, pairs, n, wide))
+        self._chk(self.L.jxlh_submit_groups_sparse(self._ctx, slot, len(group_ids), _addr(group_ids), addr, _addr(n),
+                                                   None if wide is None else _addr(wide), nw, flags),
+                  "submit_groups_sparse")
+
+    def alloc_pinned(self, nbytes):
+        """Pinned host buffer (jxlh_alloc_pinned) as a uint8 numpy view; freed with the context."""
+        p = C.c_void_p()
+        self._chk(self.L.jxlh_alloc_pinned(self._ctx, nbytes, C.byref(p)), "alloc_pinned")
+        buf = (C.c_uint8 * nbytes).from_address(p.value)
+        self._pinned = getattr(self, "_pinned", []) + [p.value]
+        return np.frombuffer(buf, dtype=np.uint8), p.value
+
     def slot_wait(self, slot=0):
         self._chk(self.L.jxlh_slot_wait(self._ctx, slot), "slot_wait")
         self._keep.clear()
@@ -226,6 +263,7 @@ class Context:
 
     def sync(self):
         self._chk(self.L.jxlh_ctx_sync(self._ctx), "ctx_sync")
+        self._keep.clear()
 
     def read_planes(self):
         w, h = self.params.xsize, self.params.ysize

@@ -409,3 +409,24 @@ def make_modular_planes(w, h, seed=0, nchan=3):
         rw, rh = (ow // 2, oh) if horizontal else (ow, oh // 2)
         residuals.append([np.round(rng.laplace(0.0, 3.0, size=(rh, rw))).astype(np.int32) for _ in range(nchan)])
     return base, residuals, steps
+
+
+def to_sparse(group_coeffs):
+    """Sparse transport form of one group's dense [3, 65536] i32 slab (include/jxl_hip.h,
+    jxlh_submit_group_sparse): (pairs uint32 [n0+n1+n2] little-endian {u16 pos; i16 val}, n[3],
+    wide uint32 [k, 2] = (channel * 65536 + pos, value) for values outside i16)."""
+    g = np.asarray(group_coeffs).reshape(3, -1)
+    runs, n, wide = [], [], []
+    for c in range(3):
+        pos = np.flatnonzero(g[c])
+        val = g[c][pos]
+        fits = (val >= -32768) & (val <= 32767)
+        p16, v16 = pos[fits].astype(np.uint32), val[fits].astype(np.int64)
+        runs.append(p16 | ((v16 & 0xFFFF).astype(np.uint32) << np.uint32(16)))
+        n.append(len(p16))
+        if (~fits).any():
+            wide.append(np.stack([(c * 65536 + pos[~fits]).astype(np.uint32),
+                                  val[~fits].astype(np.int32).view(np.uint32)], axis=1))
+    pairs = np.concatenate(runs).astype(np.uint32) if runs else np.zeros(0, np.uint32)
+    widea = np.concatenate(wide).astype(np.uint32) if wide else np.zeros((0, 2), np.uint32)
+    return pairs, np.asarray(n, dtype=np.uint32), widea

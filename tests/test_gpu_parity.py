@@ -272,3 +272,118 @@ def test_epf_fast_reciprocal_is_ieee_exact_on_weight_range():
         assert c.selftest_recip(1.0, 16.0) == 0
     finally:
         c.close()
+
+
+# ---------------------------------------------------------------- sparse coefficient transport
+def _sparse_frame_equals_dense(ctx, wl, mutate=None):
+    """Runs the frame twice -- dense submit vs sparse submit -- and checks identical planes."""
+    from jxl_rs_amd import synth
+    coeffs = wl.coeffs.copy()
+    if mutate is not None:
+        mutate(coeffs)
+    outs = []
+    for sparse in (False, True):
+        params = synth.apply_opts(ctx.default_params(wl.xsize, wl.ysize), wl)
+        ctx.frame_begin(params)
+        ctx.set_dequant_tables(wl.tables)
+        ctx.set_lf_quantized(*wl.lf_q)
+        ctx.set_hf_meta(wl.transform_map, wl.raw_quant, wl.epf_map, wl.ytox, wl.ytob)
+        if sparse:
+            # half the groups one by one, the rest as one batch on the other slot
+            ng = coeffs.shape[0]
+            for g in range(ng // 2):
+                pairs, n, wide = synth.to_sparse(coeffs[g])
+                ctx.submit_group_sparse(g, pairs, n, wide, slot=0)
+                ctx.slot_wait(0)
+            ids, runs, ns, wides = [], [], [], []
+            for g in range(ng // 2, ng):
+                pairs, n, wide = synth.to_sparse(coeffs[g])
+                ids.append(g); runs.append(pairs); ns.append(n)
+                if len(wide):
+                    wide = wide.copy()
+                    wide[:, 0] += np.uint32(g * 3 * 65536)
+                    wides.append(wide)
+            if ids:
+                ctx.submit_groups_sparse(np.array(ids, np.uint32), np.concatenate(runs), np.concatenate(ns),
+                                         np.concatenate(wides) if wides else None, slot=1)
+                ctx.slot_wait(1)
+        else:
+            for g in range(coeffs.shape[0]):
+                ctx.submit_group(g, coeffs[g], slot=g % 2)
+            ctx.slot_wait(0); ctx.slot_wait(1)
+        ctx.frame_run()
+        ctx.sync()
+        outs.append(ctx.read_planes())
+    for a, b in zip(outs[0], outs[1]):
+        assert bit_equal(a, b), diff_report(a, b)
+
+
+def test_sparse_submit_matches_dense_submit(ctx):
+    from jxl_rs_amd import synth
+    wl = synth.make_vardct(520, 300, mix=synth.MIX_ALL, seed=11, epf_iters=2)
+    _sparse_frame_equals_dense(ctx, wl)
+
+
+def test_sparse_submit_wide_values_and_empty_groups(ctx):
+    """values outside i16 travel in the wide list; an all-zero group is a valid (empty) submission"""
+    from jxl_rs_amd import synth
+    wl = synth.make_vardct(512, 512, mix=synth.MIX_D1, seed=12, epf_iters=1)
+
+    def mutate(c):
+        c[0, 1, 5] = 40000
+        c[0, 0, 77] = -70000
+        c[1, 2, 65535] = 32768
+        c[1, 1, 0] = -32769
+        c[2, :, :] = 0
+    _sparse_frame_equals_dense(ctx, wl, mutate)
+
+
+def test_sparse_duplicates_accumulate(ctx):
+    """duplicate positions add up with wrapping i32 `+=` (multi-pass accumulation, group.rs:572)"""
+    from jxl_rs_amd import synth
+    wl = synth.make_vardct(256, 256, mix=synth.MIX_DCT8, seed=13, epf_iters=0, gab=False)
+    params = synth.apply_opts(ctx.default_params(256, 256), wl)
+    outs = []
+    for split in (False, True):
+        ctx.frame_begin(params)
+        ctx.set_dequant_tables(wl.tables)
+        ctx.set_lf_quantized(*wl.lf_q)
+        ctx.set_hf_meta(wl.transform_map, wl.raw_quant, wl.epf_map, wl.ytox, wl.ytob)
+        if not split:
+            pairs, n, wide = synth.to_sparse(wl.coeffs[0])
+            ctx.submit_group_sparse(0, pairs, n, wide)
+        else:
+            # every coefficient v sent as (v - 3) and (+3): two passes over the same positions
+            a = wl.coeffs[0].copy()
+            nz = a != 0
+            first = np.where(nz, a - 3, 0)
+            second = np.where(nz, 3, 0)
+            p1, n1, _ = synth.to_sparse(first)
+            p2, n2, _ = synth.to_sparse(second)
+            # positions whose first part became zero vanish from p1; that is fine (0 + 3)
+            runs, ns = [], []
+            o1 = np.concatenate([[0], np.cumsum(n1.astype(np.int64))]); o2 = np.concatenate([[0], np.cumsum(n2.astype(np.int64))])
+            for c in range(3):
+                runs += [p1[o1[c]:o1[c + 1]], p2[o2[c]:o2[c + 1]]]
+                ns.append(int(n1[c] + n2[c]))
+            ctx.submit_group_sparse(0, np.concatenate(runs), np.array(ns, np.uint32), None)
+        ctx.slot_wait(0)
+        ctx.frame_run()
+        ctx.sync()
+        outs.append(ctx.read_planes())
+    for a, b in zip(outs[0], outs[1]):
+        assert bit_equal(a, b), diff_report(a, b)
+
+
+def test_sparse_submit_argument_errors(ctx):
+    from jxl_rs_amd import synth
+    from jxl_rs_amd.lib import JxlHipError
+    wl = synth.make_vardct(256, 256, mix=synth.MIX_DCT8, seed=14, epf_iters=0, gab=False)
+    ctx.frame_begin(synth.apply_opts(ctx.default_params(256, 256), wl))
+    pairs, n, wide = synth.to_sparse(wl.coeffs[0])
+    with pytest.raises(JxlHipError):
+        ctx.submit_group_sparse(5, pairs, n, wide)          # group out of range
+    with pytest.raises(JxlHipError):
+        ctx.submit_group_sparse(0, pairs, n, wide, flags=0)  # partial render: unsupported
+    with pytest.raises(JxlHipError):
+        ctx.submit_group_sparse(0, pairs, n, np.array([[3 * 65536, 1]], np.uint32))  # wide pos out of range
