@@ -228,6 +228,33 @@ def main():
             roofline["copy_ceiling_GBs"] = round(copy_gbs, 1)
             roofline["frac_of_copy_ceiling"] = round(roofline["achieved"] / copy_gbs, 4)
 
+    # ---- CPU baseline: the oracle (C port of the reference path) on all host cores, bounded crop
+    cpu = None
+    if rank == 0 and not args.no_cpu:
+        from oracle.oracle import Oracle
+        o = Oracle(fused=True)
+        cs = min(args.cpu_sample, size)
+        cwl = synth.make_vardct(cs, cs, mix=synth.MIX_D1, seed=args.seed, unique_groups=24, epf_iters=2)
+        p = o.default_params(cs, cs)
+        lf = o.dequant_lf(p, *cwl.lf_q)
+        cores = os.cpu_count() or 1
+        o.vardct_frame(p, cwl.coeffs, cwl.transform_map, cwl.raw_quant, cwl.epf_map, cwl.ytox, cwl.ytob, lf,
+                       cwl.tables, num_threads=cores)  # warm-up
+        reps, t0 = 0, time.perf_counter()
+        while True:
+            o.vardct_frame(p, cwl.coeffs, cwl.transform_map, cwl.raw_quant, cwl.epf_map, cwl.ytox, cwl.ytob, lf,
+                           cwl.tables, num_threads=cores)
+            reps += 1
+            el = time.perf_counter() - t0
+            if el > 10.0 or reps >= 20:
+                break
+        cpu = {"value": round(cs * cs * reps / 1e6 / el, 2), "unit": "MP/s", "cores": cores, "kind": "port",
+               "sample": f"{reps} reps of a {cs}x{cs} crop-sized frame of the same synthetic workload "
+                         f"(same type mix / filters), C oracle -O3 x86-64-v3, pthreads over groups and row bands"}
+
+    for c in ctxs:
+        c.close()
+    ctxs = []
     # ---- end-to-end legs: coefficients start in pinned HOST memory every frame.  Reported
     # beside `value`, never as `value`.  Two transports: the reference's dense i32 slabs
     # (jxlh_submit_group) and (position, value) pairs (jxlh_submit_groups_sparse).
@@ -235,7 +262,8 @@ def main():
     if rank == 0 and not args.no_e2e and torch.cuda.is_available():
         e2e = {}
         ng = wl.coeffs.shape[0]
-        ectx = [jxl_rs_amd.Context(local_rank, n_slots=4) for _ in range(2)]
+        nslots = 2
+        ectx = [jxl_rs_amd.Context(local_rank, n_slots=nslots) for _ in range(2)]
         for c in ectx:
             c.frame_begin(synth.apply_opts(c.default_params(size, size), wl))
             c.set_dequant_tables(wl.tables)
@@ -259,7 +287,6 @@ def main():
         pin_d, pin_d_addr = ectx[0].alloc_pinned(wl.coeffs.nbytes)
         pin_d.view(np.int32)[:] = wl.coeffs.reshape(-1)
         ids = np.arange(ng, dtype=np.uint32)
-        nslots = 4
         per = (ng + nslots - 1) // nslots
 
         def submit_sparse(c):
@@ -292,34 +319,10 @@ def main():
             e2e[name] = {"value": round(size * size * frames / 1e6 / el, 1), "unit": "MP/s",
                          "ms_per_frame": round(el * 1e3 / frames, 3), "h2d_MB_per_frame": round(nbytes / 1e6, 1),
                          "frames": frames}
-        e2e["note"] = ("pinned host coefficients -> H2D on 4 slot streams -> (sparse: device zero-fill + scatter) -> "
+        e2e["note"] = ("pinned host coefficients -> H2D on 2 slot streams -> (sparse: device zero-fill + scatter) -> "
                        "K0b/K3/K1/filters, 2 frames in flight; planes stay on the device")
         for c in ectx:
             c.close()
-
-    # ---- CPU baseline: the oracle (C port of the reference path) on all host cores, bounded crop
-    cpu = None
-    if rank == 0 and not args.no_cpu:
-        from oracle.oracle import Oracle
-        o = Oracle(fused=True)
-        cs = min(args.cpu_sample, size)
-        cwl = synth.make_vardct(cs, cs, mix=synth.MIX_D1, seed=args.seed, unique_groups=24, epf_iters=2)
-        p = o.default_params(cs, cs)
-        lf = o.dequant_lf(p, *cwl.lf_q)
-        cores = os.cpu_count() or 1
-        o.vardct_frame(p, cwl.coeffs, cwl.transform_map, cwl.raw_quant, cwl.epf_map, cwl.ytox, cwl.ytob, lf,
-                       cwl.tables, num_threads=cores)  # warm-up
-        reps, t0 = 0, time.perf_counter()
-        while True:
-            o.vardct_frame(p, cwl.coeffs, cwl.transform_map, cwl.raw_quant, cwl.epf_map, cwl.ytox, cwl.ytob, lf,
-                           cwl.tables, num_threads=cores)
-            reps += 1
-            el = time.perf_counter() - t0
-            if el > 10.0 or reps >= 20:
-                break
-        cpu = {"value": round(cs * cs * reps / 1e6 / el, 2), "unit": "MP/s", "cores": cores, "kind": "port",
-               "sample": f"{reps} reps of a {cs}x{cs} crop-sized frame of the same synthetic workload "
-                         f"(same type mix / filters), C oracle -O3 x86-64-v3, pthreads over groups and row bands"}
 
     if rank == 0:
         out = {
@@ -332,14 +335,12 @@ def main():
                                    f"Gaborish, EPF iters=2), inputs HBM-resident", "groups": int(wl.coeffs.shape[0]),
                        "sharding": ("group-row bands + RCCL all-gather" if (args.strong and world > 1)
                                     else "independent frames per GPU, no collective"),
-                       "frames_in_flight_per_gpu": len(ctxs), "epf_population": args.epf},
+                       "frames_in_flight_per_gpu": max(1, args.inflight), "epf_population": args.epf},
             "hip_event_ms_per_step_rank0": round(ev_ms / args.steps, 4),
             "setup": {"host_generate_s": round(gen_s, 2), "h2d_coeffs_s": round(h2d_s, 2)},
             "roofline": roofline, "cpu_baseline": cpu, "e2e_pcie_inclusive": e2e,
         }
         print(json.dumps(out))
-    for c in ctxs:
-        c.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -250,11 +250,10 @@ jxlh_status jxlh_ctx_create(int32_t device_ordinal, int32_t n_slots, jxlh_ctx** 
     delete ctx;
     return JXLH_ERR_DEVICE;
   }
-  ctx->k1s_ok = true;
-  for (int i = 0; i < 3; i++)
-    ctx->k1s_ok = ctx->k1s_ok && hipStreamCreateWithFlags(&ctx->k1s.aux[i], hipStreamNonBlocking) == hipSuccess;
-  for (int i = 0; i < 4; i++)
-    ctx->k1s_ok = ctx->k1s_ok && hipEventCreateWithFlags(&ctx->k1s.ev[i], hipEventDisableTiming) == hipSuccess;
+  // The forked K1 class kernels (K1Streams) measured no gain and every extra stream competes for
+  // the few hardware queues the runtime multiplexes streams onto (false dependencies between a
+  // context's uploads and another context's kernels): the aux streams are not created.
+  ctx->k1s_ok = false;
   ctx->slots.resize(n_slots);
   for (auto& s : ctx->slots) {
     if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess ||

@@ -149,6 +149,12 @@ void jxlo_vardct_frame(const JxloFrameParams* p, const int32_t* coeffs /* ngroup
                        float* const lf[3], const float* const tables[17], float* const planes[3],
                        float* const tmp[3], size_t stride, int num_threads);
 
+/* ---- sparse coefficient transport: the dense slab a stream of `coeffs[c][pos] += v` updates describes
+ * (group.rs:557-572).  pairs: little-endian {u16 pos; i16 val}, n[0] of X then n[1] of Y then n[2] of B;
+ * wide: n_wide x {u32 channel*65536+pos; i32 val} */
+void jxlo_expand_sparse(const uint32_t* pairs, const uint32_t n[3], const uint32_t* wide, uint32_t n_wide,
+                        int32_t* slab);
+
 /* ---- Modular inverse transforms (wrapping i32) ---- */
 /* rct.rs:14-157; planes are permuted by swapping contents so that the caller's
  * pointers keep their meaning (out[perm] = in) */

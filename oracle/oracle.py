@@ -67,6 +67,9 @@ class Oracle:
         assert bool(L.jxlo_is_fused()) == fused
         fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int32)
         dp = C.POINTER(C.c_double)
+        L.jxlo_expand_sparse.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                         C.c_uint32, C.POINTER(C.c_int32)]
+        L.jxlo_expand_sparse.restype = None
         L.jxlo_idct1d.argtypes = [fp, C.c_int, C.c_int]
         L.jxlo_rdct1d.argtypes = [fp, C.c_int, C.c_int]
         L.jxlo_idct2d.argtypes = [fp, C.c_int, C.c_int]
@@ -323,6 +326,16 @@ class Oracle:
                                    self._p3(lf), self._p3(tables), self._p3(planes), self._p3(tmp),
                                    stride, num_threads)
         return planes, lf
+
+    # ---- sparse coefficient transport ----
+    def expand_sparse(self, pairs, n, wide=None):
+        pairs = np.ascontiguousarray(pairs, dtype=np.uint32)
+        n = np.ascontiguousarray(n, dtype=np.uint32)
+        wide = np.zeros((0, 2), np.uint32) if wide is None else np.ascontiguousarray(wide, dtype=np.uint32)
+        slab = np.zeros((3, 65536), dtype=np.int32)
+        self.lib.jxlo_expand_sparse(_ptr(pairs, C.c_uint32), _ptr(n, C.c_uint32), _ptr(wide, C.c_uint32),
+                                    len(wide), _ptr(slab, C.c_int32))
+        return slab
 
     # ---- modular ----
     def rct(self, planes, op, perm):

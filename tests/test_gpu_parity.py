@@ -387,3 +387,34 @@ def test_sparse_submit_argument_errors(ctx):
         ctx.submit_group_sparse(0, pairs, n, wide, flags=0)  # partial render: unsupported
     with pytest.raises(JxlHipError):
         ctx.submit_group_sparse(0, pairs, n, np.array([[3 * 65536, 1]], np.uint32))  # wide pos out of range
+
+
+def test_sparse_expansion_matches_oracle_slab(ctx, oracle):
+    """reads the device coefficient store back after the zero-fill + scatter kernel and compares it
+    with the oracle's expansion (wide values, duplicates, an untouched group stays as submitted)"""
+    import ctypes as C
+    from jxl_rs_amd import synth
+    wl = synth.make_vardct(512, 256, mix=synth.MIX_D1, seed=15, epf_iters=0, gab=False)
+    ctx.frame_begin(synth.apply_opts(ctx.default_params(512, 256), wl))
+    ctx.set_dequant_tables(wl.tables)
+    ctx.set_lf_quantized(*wl.lf_q)
+    ctx.set_hf_meta(wl.transform_map, wl.raw_quant, wl.epf_map, wl.ytox, wl.ytob)
+    slab = wl.coeffs[1].copy()
+    slab[0, 3] = 123456
+    slab[2, 65535] = -40000
+    pairs, n, wide = synth.to_sparse(slab)
+    dup = np.array([7 | (5 << 16), 7 | (0xFFFE << 16)], dtype=np.uint32)  # pos 7: +5, -2 in channel X
+    pairs = np.concatenate([dup, pairs]); n = n.copy(); n[0] += 2
+    ctx.submit_group(0, wl.coeffs[0])                 # dense
+    ctx.submit_group_sparse(1, pairs, n, wide)        # sparse
+    ctx.slot_wait(0)
+    ctx.frame_run()
+    ctx.sync()
+    ptr, count = ctx.coeff_buffer()
+    got = np.zeros(count, dtype=np.int32)
+    hip = C.CDLL("libamdhip64.so")
+    assert hip.hipMemcpy(C.c_void_p(got.ctypes.data), C.c_void_p(ptr), C.c_size_t(got.nbytes), C.c_int(2)) == 0
+    got = got.reshape(2, 3, 65536)
+    assert np.array_equal(got[0], wl.coeffs[0])
+    assert np.array_equal(got[1], oracle.expand_sparse(pairs, n, wide))
+    assert got[1][0, 7] == slab[0, 7] + 3

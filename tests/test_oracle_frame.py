@@ -159,3 +159,24 @@ def test_palette_value_classes(oracle):
     assert (out[:, 6] == 0).all()
     assert abs(out[0, 7]) == 4
     assert (out[:, 8] == -out[:, 9] ).all() or True
+
+
+def test_sparse_transport_round_trip(oracle_any):
+    """to_sparse (host packing) followed by the oracle's zero + `+=` expansion (group.rs:557-572)
+    reproduces the dense slab, including values outside i16 and wrapping duplicate accumulation."""
+    from jxl_rs_amd import synth
+    wl = synth.make_vardct(256, 256, mix=synth.MIX_ALL, seed=21, epf_iters=0)
+    slab = wl.coeffs[0].copy()
+    slab[0, 9] = 40000
+    slab[2, 65535] = -32769
+    slab[1, 0] = 32767
+    pairs, n, wide = synth.to_sparse(slab)
+    assert len(wide) == 2 and int(n.sum()) == int((slab != 0).sum()) - 2
+    assert np.array_equal(oracle_any.expand_sparse(pairs, n, wide), slab)
+    # duplicates accumulate with wrapping adds
+    dup = np.array([5 | (0x7FFF << 16)] * 3, dtype=np.uint32)            # 3 x (pos 5, +32767) in channel X
+    widew = np.array([[5, 0x7FFFFFFF], [5, 1]], dtype=np.uint32)          # + i32::MAX + 1 -> wraps
+    out = oracle_any.expand_sparse(dup, np.array([3, 0, 0], np.uint32), widew)
+    expect = np.int64(3 * 32767 + 0x7FFFFFFF + 1)
+    expect = ((expect + 2**31) % 2**32) - 2**31
+    assert out[0, 5] == expect and np.count_nonzero(out) == 1

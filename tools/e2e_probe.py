@@ -76,3 +76,23 @@ for i in range(N):
 for cc in cs:
     cc.sync()
 print("pipelined 2 contexts:", (time.perf_counter() - t0) / N * 1e3, "ms/frame")
+# ---- does a large second pinned allocation change the picture? (bench.py holds the dense slabs too)
+big, big_addr = c.alloc_pinned(wl.coeffs.nbytes)
+big.view(np.int32)[:] = wl.coeffs.reshape(-1)
+t0 = time.perf_counter()
+for i in range(N):
+    cc = cs[i % 2]
+    cc.sync(); submit_to(cc); cc.frame_run()
+for cc in cs:
+    cc.sync()
+print("pipelined, after 805 MB pinned alloc:", (time.perf_counter() - t0) / N * 1e3, "ms/frame")
+import torch
+a_t = torch.empty(size * size * 3, dtype=torch.float32, device="cuda").normal_(); b_t = torch.empty_like(a_t)
+b_t.copy_(a_t); torch.cuda.synchronize(); del a_t, b_t
+t0 = time.perf_counter()
+for i in range(N):
+    cc = cs[i % 2]
+    cc.sync(); submit_to(cc); cc.frame_run()
+for cc in cs:
+    cc.sync()
+print("pipelined, after torch alloc/free:", (time.perf_counter() - t0) / N * 1e3, "ms/frame")
