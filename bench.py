@@ -55,6 +55,8 @@ def main():
                     help="EPF sigma population: spec = SURVEY 8(d) draws (raw_quant U[2,16], sharpness U{0..7}: 93%% of "
                          "blocks fall below MIN_SIGMA and pass through); active = every block filtered "
                          "(sharpness 7); passthrough = none")
+    ap.add_argument("--epf-iters", type=int, default=2, choices=[0, 1, 2, 3],
+                    help="EPF iterations (config 3: 2; config 2: 0; 3 adds EPF0 and uses the per-stage filter kernels)")
     ap.add_argument("--mix", default="d1", choices=["d1", "dct8", "all"],
                     help="transform-type mix of the synthetic frame (d1 = BASELINE config 3)")
     args = ap.parse_args()
@@ -81,7 +83,7 @@ def main():
     t0 = time.time()
     mix = {"d1": synth.MIX_D1, "dct8": synth.MIX_DCT8, "all": synth.MIX_ALL}[args.mix]
     wl = synth.make_vardct(size, size, mix=mix, seed=args.seed + rank, unique_groups=24,
-                           epf_iters=2, gab=True, lf_smoothing=True)
+                           epf_iters=args.epf_iters, gab=True, lf_smoothing=True)
     gen_s = time.time() - t0
     if args.epf == "active":
         wl.epf_map[:] = 7
@@ -234,7 +236,7 @@ def main():
         from oracle.oracle import Oracle
         o = Oracle(fused=True)
         cs = min(args.cpu_sample, size)
-        cwl = synth.make_vardct(cs, cs, mix=synth.MIX_D1, seed=args.seed, unique_groups=24, epf_iters=2)
+        cwl = synth.make_vardct(cs, cs, mix=mix, seed=args.seed, unique_groups=24, epf_iters=args.epf_iters)
         p = o.default_params(cs, cs)
         lf = o.dequant_lf(p, *cwl.lf_q)
         cores = os.cpu_count() or 1
@@ -331,8 +333,9 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "strong" if (args.strong and world > 1) else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{size}x{size} VarDCT d1 full pipeline (DCT8..32 mix, CfL, LF smoothing, "
-                                   f"Gaborish, EPF iters=2), inputs HBM-resident", "groups": int(wl.coeffs.shape[0]),
+            "config": {"workload": f"{size}x{size} VarDCT {args.mix} mix full pipeline (CfL, LF smoothing, "
+                                   f"Gaborish, EPF iters={args.epf_iters}), inputs HBM-resident",
+                       "groups": int(wl.coeffs.shape[0]),
                        "sharding": ("group-row bands + RCCL all-gather" if (args.strong and world > 1)
                                     else "independent frames per GPU, no collective"),
                        "frames_in_flight_per_gpu": max(1, args.inflight), "epf_population": args.epf},
