@@ -406,11 +406,24 @@ __global__ __launch_bounds__(kThreads) void k1_dct32(const FrameDev f, const Wor
 }
 
 // family D: the nine 8x8 special transform types (IDENTITY, DCT2X2, DCT4X4, DCT4X8, DCT8X4, AFV0-3).
-// Work items of different types share one list; each lane transforms its own block.
-__global__ __launch_bounds__(kThreads) void k1_special(const FrameDev f, const WorkLists wl) {
-  __shared__ float s_buf[kWaves * 2 * kSpecNB * kSpecPitch];
-  __shared__ BlockInfo s_binfo[kWaves][kSpecNB];
-  __shared__ int s_type[kWaves][kSpecNB];
+// Each lane transforms its own block, so a wavefront must hold blocks of ONE code path or the
+// nine paths serialise.  The special work list is in raster order (mixed types): a wave takes a
+// (chunk of 256 items, type bin) pair, compacts the chunk's items of its bin through a ballot, and
+// runs them in batches of kSpecNB blocks -- every batch is uniform in type (the four AFV kinds
+// share one path that differs only in two flip flags).
+constexpr int kSpecWaves = 2;
+constexpr int kSpecThreads = kSpecWaves * 64;
+constexpr int kSpecChunk = 256;
+constexpr int kSpecBins = 6;
+__device__ __forceinline__ int special_bin(int type) {
+  return type == 1 ? 0 : type == 2 ? 1 : type == 3 ? 2 : type == 12 ? 3 : type == 13 ? 4 : 5;
+}
+
+__global__ __launch_bounds__(kSpecThreads) void k1_special(const FrameDev f, const WorkLists wl) {
+  __shared__ float s_buf[kSpecWaves * 2 * kSpecNB * kSpecPitch];
+  __shared__ BlockInfo s_binfo[kSpecWaves][kSpecNB];
+  __shared__ int s_type[kSpecWaves][kSpecNB];
+  __shared__ int s_idx[kSpecWaves][kSpecChunk];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const WorkItem* __restrict__ items = wl.items[kClsSpecial];
   const int count = wl.counts[kClsSpecial];
@@ -418,74 +431,90 @@ __global__ __launch_bounds__(kThreads) void k1_special(const FrameDev f, const W
   float* tout = tin + kSpecNB * kSpecPitch;
   BlockInfo* binfo = s_binfo[wave];
   int* btype = s_type[wave];
-  const int nbatches = (count + kSpecNB - 1) / kSpecNB;
+  int* mine = s_idx[wave];
+  const int npairs = ((count + kSpecChunk - 1) / kSpecChunk) * kSpecBins;
   constexpr int NCH = kSpecNB * 64 / 256;
-  for (int batch = blockIdx.x * kWaves + wave; batch < nbatches; batch += gridDim.x * kWaves) {
-    const int nb = min(kSpecNB, count - batch * kSpecNB);
-    if (lane < nb) {
-      const WorkItem it = items[batch * kSpecNB + lane];
-      decode_item(f, it, &binfo[lane]);
-      btype[lane] = (int)(it.packed >> 20) & 31;
+  for (int pair = blockIdx.x * kSpecWaves + wave; pair < npairs; pair += gridDim.x * kSpecWaves) {
+    const int chunk = pair / kSpecBins, bin = pair % kSpecBins;
+    // ---- this wave's items of the chunk: the ones whose type falls in `bin`
+    int nmine = 0;
+#pragma unroll
+    for (int i = 0; i < kSpecChunk / 64; i++) {
+      const int idx = chunk * kSpecChunk + i * 64 + lane;
+      const bool m = idx < count && special_bin((int)(items[idx].packed >> 20) & 31) == bin;
+      const unsigned long long mask = __ballot(m);
+      if (m) mine[nmine + __popcll(mask & ((1ull << lane) - 1ull))] = idx;
+      nmine += __popcll(mask);
     }
     wave_sync();
-    float dy[4 * NCH];
-    auto run_channel = [&](auto ch_tag) {
-      constexpr int CH = decltype(ch_tag)::value;
-#pragma unroll
-      for (int j = 0; j < NCH; j++) {
-        const int fl = (j * 64 + lane) * 4;
-        const int b = fl / 64, k = fl % 64;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        float d4[4] = {dy[j * 4], dy[j * 4 + 1], dy[j * 4 + 2], dy[j * 4 + 3]};
-        if (b < nb) {
-          const BlockInfo bi = binfo[b];
-          const int qt = quant_table_for_type(btype[b]);
-          const float* tab = f.tables + f.table_offset[qt] + CH * 64;
-          const int4 qv = *reinterpret_cast<const int4*>(f.coeffs + bi.coef_off + CH * kGroupArea + k);
-          const float4 tv = *reinterpret_cast<const float4*>(tab + k);
-          v = dequant4<CH>(f, qv, tv, bi, d4);
-        }
-        if constexpr (CH == 1) {
-          dy[j * 4] = d4[0];
-          dy[j * 4 + 1] = d4[1];
-          dy[j * 4 + 2] = d4[2];
-          dy[j * 4 + 3] = d4[3];
-        }
-        float* dst = tin + b * kSpecPitch + k;
-        dst[0] = v.x;
-        dst[1] = v.y;
-        dst[2] = v.z;
-        dst[3] = v.w;
-      }
-      wave_sync();
+    for (int b0 = 0; b0 < nmine; b0 += kSpecNB) {
+      const int nb = min(kSpecNB, nmine - b0);
       if (lane < nb) {
-        float* c = tin + lane * kSpecPitch;
-        c[0] = f.lf[CH][binfo[lane].lf_off];  // transform_buffer[0] = lf[0]
-        special_8x8(btype[lane], c, tout + lane * kSpecPitch);
+        const WorkItem it = items[mine[b0 + lane]];
+        decode_item(f, it, &binfo[lane]);
+        btype[lane] = (int)(it.packed >> 20) & 31;
       }
       wave_sync();
-      float* __restrict__ plane = f.planes[CH];
+      float dy[4 * NCH];
+      auto run_channel = [&](auto ch_tag) {
+        constexpr int CH = decltype(ch_tag)::value;
 #pragma unroll
-      for (int j = 0; j < NCH; j++) {
-        const int fl = (j * 64 + lane) * 4;
-        const int b = fl / 64, p = fl % 64;
-        if (b < nb) {
-          if (f.tiled) {  // memory order inside the block is x*8 + y
-            const int x = p / 8, y0 = p % 8;
-            const float* src = tout + b * kSpecPitch + y0 * 8 + x;
-            *reinterpret_cast<float4*>(plane + binfo[b].px_off + p) = make_float4(src[0], src[8], src[16], src[24]);
-          } else {
-            const float* src = tout + b * kSpecPitch + p;
-            float* dst = plane + binfo[b].px_off + (p / 8) * (int)f.plane_stride + (p % 8);
-            *reinterpret_cast<float4*>(dst) = make_float4(src[0], src[1], src[2], src[3]);
+        for (int j = 0; j < NCH; j++) {
+          const int fl = (j * 64 + lane) * 4;
+          const int b = fl / 64, k = fl % 64;
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          float d4[4] = {dy[j * 4], dy[j * 4 + 1], dy[j * 4 + 2], dy[j * 4 + 3]};
+          if (b < nb) {
+            const BlockInfo bi = binfo[b];
+            const int qt = quant_table_for_type(btype[b]);
+            const float* tab = f.tables + f.table_offset[qt] + CH * 64;
+            const int4 qv = *reinterpret_cast<const int4*>(f.coeffs + bi.coef_off + CH * kGroupArea + k);
+            const float4 tv = *reinterpret_cast<const float4*>(tab + k);
+            v = dequant4<CH>(f, qv, tv, bi, d4);
+          }
+          if constexpr (CH == 1) {
+            dy[j * 4] = d4[0];
+            dy[j * 4 + 1] = d4[1];
+            dy[j * 4 + 2] = d4[2];
+            dy[j * 4 + 3] = d4[3];
+          }
+          float* dst = tin + b * kSpecPitch + k;
+          dst[0] = v.x;
+          dst[1] = v.y;
+          dst[2] = v.z;
+          dst[3] = v.w;
+        }
+        wave_sync();
+        if (lane < nb) {
+          float* c = tin + lane * kSpecPitch;
+          c[0] = f.lf[CH][binfo[lane].lf_off];  // transform_buffer[0] = lf[0]
+          special_8x8(btype[lane], c, tout + lane * kSpecPitch);
+        }
+        wave_sync();
+        float* __restrict__ plane = f.planes[CH];
+#pragma unroll
+        for (int j = 0; j < NCH; j++) {
+          const int fl = (j * 64 + lane) * 4;
+          const int b = fl / 64, p = fl % 64;
+          if (b < nb) {
+            if (f.tiled) {  // memory order inside the block is x*8 + y
+              const int x = p / 8, y0 = p % 8;
+              const float* src = tout + b * kSpecPitch + y0 * 8 + x;
+              *reinterpret_cast<float4*>(plane + binfo[b].px_off + p) = make_float4(src[0], src[8], src[16], src[24]);
+            } else {
+              const float* src = tout + b * kSpecPitch + p;
+              float* dst = plane + binfo[b].px_off + (p / 8) * (int)f.plane_stride + (p % 8);
+              *reinterpret_cast<float4*>(dst) = make_float4(src[0], src[1], src[2], src[3]);
+            }
           }
         }
-      }
-      wave_sync();
-    };
-    run_channel(std::integral_constant<int, 1>{});
-    run_channel(std::integral_constant<int, 0>{});
-    run_channel(std::integral_constant<int, 2>{});
+        wave_sync();
+      };
+      run_channel(std::integral_constant<int, 1>{});
+      run_channel(std::integral_constant<int, 0>{});
+      run_channel(std::integral_constant<int, 2>{});
+    }
+    wave_sync();  // `mine` is rewritten by the next pair
   }
 }
 
@@ -565,7 +594,8 @@ void launch_vardct_groups(hipStream_t s, const K1Streams* aux, const FrameDev& f
   hipLaunchKernelGGL(k1_dct8, dim3(grid_for(nblk, kWaves * S8x8::NB * 2, 4096)), dim3(kThreads), 0, s, f, wl);
   hipLaunchKernelGGL(k1_dct16, dim3(grid_for(nblk / 2, kWaves * 8 * 2, 2048)), dim3(kThreads), 0, s16, f, wl);
   hipLaunchKernelGGL(k1_dct32, dim3(grid_for(nblk / 4, kWaves * 4 * 2, 2048)), dim3(kThreads), 0, s32, f, wl);
-  hipLaunchKernelGGL(k1_special, dim3(grid_for(nblk, kWaves * kSpecNB * 4, 1024)), dim3(kThreads), 0, smisc, f, wl);
+  hipLaunchKernelGGL(k1_special, dim3(grid_for((long)(nblk / kSpecChunk + 1) * kSpecBins, kSpecWaves, 2048)),
+                     dim3(kSpecThreads), 0, smisc, f, wl);
   hipLaunchKernelGGL(k1_large, dim3(grid_for(nblk / 32, 1, 1024)), dim3(kLargeThreads), 0, smisc, f, wl);
   if (aux) {  // join
     for (int i = 0; i < 3; i++) {

@@ -195,7 +195,7 @@ __device__ __forceinline__ void idct_batch(float* __restrict__ buf, int nb, int 
 // transform.rs:14-32, :295-374, :510-662.  These 4-wide paths are unfused in the
 // reference's x86 build (idct2d.rs:348-366) and plain scalar code otherwise.
 constexpr int kSpecPitch = 65;  // odd: lane b walks its own block conflict-free
-constexpr int kSpecNB = 16;     // blocks per batch (in + out tiles fit one wave buffer)
+constexpr int kSpecNB = 32;     // blocks per batch: in + out tiles of one wave = 16.6 KB of LDS
 
 __constant__ float kAfvBasisDev[256] = {
 #include "afv_basis.inc"

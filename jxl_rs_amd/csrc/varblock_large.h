@@ -150,6 +150,21 @@ __device__ __forceinline__ float adjust_quant_bias_s(int q, float bias_c, float 
   return (q > -2 && q < 2) ? quant * bias_c : adjusted;
 }
 
+// idx -> (x, y) inside a W x H pixel region (W = 1 << wlog, both multiples of 8) such that
+// consecutive threads touch consecutive memory: raster planes are x-major, the 8x8-tiled layout
+// stores a block as x*8 + y (see FrameDev::tiled), so there the walk goes down the 8 rows of a
+// block column first.
+__device__ __forceinline__ void region_xy(bool tiled, int wlog, int idx, int& x, int& y) {
+  if (tiled) {
+    const int j = idx & 63, blk = idx >> 6;
+    x = ((blk & ((1 << (wlog - 3)) - 1)) << 3) + (j >> 3);
+    y = ((blk >> (wlog - 3)) << 3) + (j & 7);
+  } else {
+    x = idx & ((1 << wlog) - 1);
+    y = idx >> wlog;
+  }
+}
+
 // One channel of one large varblock.  coef(k) returns the dequantised coefficient at stored
 // index k; lf points at the cy x cx LF patch (row pitch lf_stride); plane at the top-left
 // output pixel (addressing given by `lay`).  lds: >= 2*(kLargeSlab + 256) + 1024 floats.
@@ -189,8 +204,10 @@ __device__ void large_varblock_channel(int type, CoefFn coef, const float* __res
       __syncthreads();
       float* res = lds_idct_dyn(C, bufA, bufB, LV, Lp, tid);
       // park tmp[x][v] at pixel (row v, col x) of the output rectangle
+      const int clog = 31 - __clz(C);
       for (int idx = tid; idx < C * LV; idx += kLargeThreads) {
-        const int x = idx % C, line = idx / C;
+        int x, line;
+        region_xy(lay.tiled, clog, idx, x, line);
         plane[lay.at(x, v0 + line)] = res[x * Lp + line];
       }
       __syncthreads();
@@ -203,14 +220,17 @@ __device__ void large_varblock_channel(int type, CoefFn coef, const float* __res
     const int LX = min(C, kLargeSlab / R);
     const int Lp = LX + 1;
     for (int x0 = 0; x0 < C; x0 += LX) {
+      const int xlog = 31 - __clz(LX);
       for (int idx = tid; idx < R * LX; idx += kLargeThreads) {
-        const int line = idx % LX, v = idx / LX;
+        int line, v;
+        region_xy(lay.tiled, xlog, idx, line, v);
         bufA[v * Lp + line] = plane[lay.at(x0 + line, v)];
       }
       __syncthreads();
       float* res = lds_idct_dyn(R, bufA, bufB, LX, Lp, tid);
       for (int idx = tid; idx < R * LX; idx += kLargeThreads) {
-        const int line = idx % LX, y = idx / LX;
+        int line, y;
+        region_xy(lay.tiled, xlog, idx, line, y);
         plane[lay.at(x0 + line, y)] = res[y * Lp + line];
       }
       __syncthreads();
