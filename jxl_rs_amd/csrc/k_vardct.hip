@@ -409,17 +409,17 @@ __global__ __launch_bounds__(kThreads) void k1_dct32(const FrameDev f, const Wor
 // Each lane transforms its own block, so a wavefront must hold blocks of ONE code path or the
 // nine paths serialise.  The special work list is in raster order (mixed types): a wave takes a
 // (chunk of 256 items, type bin) pair, compacts the chunk's items of its bin through a ballot, and
-// runs them in batches of kSpecNB blocks -- every batch is uniform in type (the four AFV kinds
-// share one path that differs only in two flip flags).
+// runs them in batches of kSpecNB blocks -- every batch is uniform in type, so the lane can hold
+// its block in registers and run the fully unrolled transform of that type.
 constexpr int kSpecWaves = 2;
 constexpr int kSpecThreads = kSpecWaves * 64;
 constexpr int kSpecChunk = 256;
-constexpr int kSpecBins = 6;
-__device__ __forceinline__ int special_bin(int type) {
-  return type == 1 ? 0 : type == 2 ? 1 : type == 3 ? 2 : type == 12 ? 3 : type == 13 ? 4 : 5;
+constexpr int kSpecBins = 9;
+__device__ __forceinline__ int special_bin(int type) {  // 1, 2, 3, 12, 13, 14, 15, 16, 17 -> 0..8
+  return type <= 3 ? type - 1 : type - 9;
 }
 
-__global__ __launch_bounds__(kSpecThreads) void k1_special(const FrameDev f, const WorkLists wl) {
+__global__ __launch_bounds__(kSpecThreads, 2) void k1_special(const FrameDev f, const WorkLists wl) {
   __shared__ float s_buf[kSpecWaves * 2 * kSpecNB * kSpecPitch];
   __shared__ BlockInfo s_binfo[kSpecWaves][kSpecNB];
   __shared__ int s_type[kSpecWaves][kSpecNB];
@@ -488,7 +488,18 @@ __global__ __launch_bounds__(kSpecThreads) void k1_special(const FrameDev f, con
         if (lane < nb) {
           float* c = tin + lane * kSpecPitch;
           c[0] = f.lf[CH][binfo[lane].lf_off];  // transform_buffer[0] = lf[0]
-          special_8x8(btype[lane], c, tout + lane * kSpecPitch);
+          float* o = tout + lane * kSpecPitch;
+          switch (bin) {  // wave-uniform
+            case 0: special_8x8_regs<1>(c, o); break;
+            case 1: special_8x8_regs<2>(c, o); break;
+            case 2: special_8x8_regs<3>(c, o); break;
+            case 3: special_8x8_regs<12>(c, o); break;
+            case 4: special_8x8_regs<13>(c, o); break;
+            case 5: special_8x8_regs<14>(c, o); break;
+            case 6: special_8x8_regs<15>(c, o); break;
+            case 7: special_8x8_regs<16>(c, o); break;
+            default: special_8x8_regs<17>(c, o); break;
+          }
         }
         wave_sync();
         float* __restrict__ plane = f.planes[CH];

@@ -247,9 +247,12 @@ __device__ __forceinline__ void idct2d_small(float (&d)[R * C]) {
   }
 }
 
-__device__ __forceinline__ void idct2_top_block(int s, const float* in, float* out) {
-  const int num = s / 2;
+template <int S>
+__device__ __forceinline__ void idct2_top_block(const float* in, float* out) {
+  constexpr int num = S / 2;
+#pragma unroll
   for (int y = 0; y < num; y++) {
+#pragma unroll
     for (int x = 0; x < num; x++) {
       const float c00 = in[y * 8 + x];
       const float c01 = in[y * 8 + num + x];
@@ -263,160 +266,185 @@ __device__ __forceinline__ void idct2_top_block(int s, const float* in, float* o
   }
 }
 
-// type in {1,2,3,12,13,14..17}; c = this block's 64 coefficients (c[0] already = lf),
-// o = this block's 64 output pixels.  c may be clobbered.
-__device__ inline void special_8x8(int type, float* c, float* o) {
-  switch (type) {
-    case 1: {  // IDENTITY (Hornuss)
-      const float b00 = c[0], b01 = c[1], b10 = c[8], b11 = c[9];
-      const float dcs[4] = {b00 + b01 + b10 + b11, b00 + b01 - b10 - b11, b00 - b01 + b10 - b11,
-                            b00 - b01 - b10 + b11};
-      for (int y = 0; y < 2; y++) {
-        for (int x = 0; x < 2; x++) {
-          float residual_sum = 0.0f;
-          for (int iy = 0; iy < 4; iy++)
-            for (int ix = 0; ix < 4; ix++) {
-              if (ix == 0 && iy == 0) continue;
-              residual_sum += c[(y + iy * 2) * 8 + x + ix * 2];
-            }
-          const float pivot = dcs[y * 2 + x] - residual_sum * (1.0f / 16.0f);
-          for (int iy = 0; iy < 4; iy++)
-            for (int ix = 0; ix < 4; ix++) {
-              if (ix == 1 && iy == 1) continue;
-              o[(y * 4 + iy) * 8 + x * 4 + ix] = c[(y + iy * 2) * 8 + x + ix * 2] + pivot;
-            }
-          o[(4 * y + 1) * 8 + 4 * x + 1] = pivot;
-          o[y * 4 * 8 + x * 4] = c[(y + 2) * 8 + x + 2] + pivot;
-        }
-      }
-      return;
-    }
-    case 2: {  // DCT2X2: three Hadamard levels, ping-pong between the tiles
-      idct2_top_block(2, c, o);
-      // levels read the full previous buffer outside the top block too: copy it over
-      for (int i = 0; i < 64; i++) {
-        const int y = i / 8, x = i % 8;
-        if (y >= 2 || x >= 2) o[i] = c[i];
-      }
-      idct2_top_block(4, o, c);
-      for (int i = 0; i < 64; i++) {
-        const int y = i / 8, x = i % 8;
-        if (y >= 4 || x >= 4) c[i] = o[i];
-      }
-      idct2_top_block(8, c, o);
-      return;
-    }
-    case 3: {  // DCT4X4
-      const float b00 = c[0], b01 = c[1], b10 = c[8], b11 = c[9];
-      const float dcs[4] = {b00 + b01 + b10 + b11, b00 + b01 - b10 - b11, b00 - b01 + b10 - b11,
-                            b00 - b01 - b10 + b11};
+// TYPE in {1,2,3,12,13,14..17}; c = this block's 64 coefficients (c[0] already = lf),
+// o = this block's 64 output pixels.  c may be clobbered.  Every index is a compile-time
+// constant after unrolling, so c/o may be register arrays (k1_special) as well as LDS rows.
+template <int TYPE>
+__device__ __forceinline__ void special_8x8_t(float* __restrict__ c, float* __restrict__ o) {
+  if constexpr (TYPE == 1) {  // IDENTITY (Hornuss)
+    const float b00 = c[0], b01 = c[1], b10 = c[8], b11 = c[9];
+    const float dcs[4] = {b00 + b01 + b10 + b11, b00 + b01 - b10 - b11, b00 - b01 + b10 - b11,
+                          b00 - b01 - b10 + b11};
 #pragma unroll
-      for (int y = 0; y < 2; y++)
-#pragma unroll
-        for (int x = 0; x < 2; x++) {
-          float blk[16];
-#pragma unroll
-          for (int iy = 0; iy < 4; iy++)
-#pragma unroll
-            for (int ix = 0; ix < 4; ix++)
-              blk[iy * 4 + ix] = (ix == 0 && iy == 0) ? dcs[y * 2 + x] : c[(y + iy * 2) * 8 + x + ix * 2];
-          idct2d_small<4, 4>(blk);
-#pragma unroll
-          for (int iy = 0; iy < 4; iy++)
-#pragma unroll
-            for (int ix = 0; ix < 4; ix++) o[(y * 4 + iy) * 8 + x * 4 + ix] = blk[iy * 4 + ix];
-        }
-      return;
-    }
-    case 13: {  // DCT8X4
-      const float dcs[2] = {c[0] + c[8], c[0] - c[8]};
+    for (int y = 0; y < 2; y++) {
 #pragma unroll
       for (int x = 0; x < 2; x++) {
-        float blk[32];
+        float residual_sum = 0.0f;
 #pragma unroll
         for (int iy = 0; iy < 4; iy++)
 #pragma unroll
-          for (int ix = 0; ix < 8; ix++)
-            blk[iy * 8 + ix] = (ix == 0 && iy == 0) ? dcs[x] : c[(x + iy * 2) * 8 + ix];
-        idct2d_small<8, 4>(blk);
+          for (int ix = 0; ix < 4; ix++) {
+            if (ix == 0 && iy == 0) continue;
+            residual_sum += c[(y + iy * 2) * 8 + x + ix * 2];
+          }
+        const float pivot = dcs[y * 2 + x] - residual_sum * (1.0f / 16.0f);
 #pragma unroll
-        for (int iy = 0; iy < 8; iy++)
+        for (int iy = 0; iy < 4; iy++)
 #pragma unroll
-          for (int ix = 0; ix < 4; ix++) o[iy * 8 + x * 4 + ix] = blk[iy * 4 + ix];
+          for (int ix = 0; ix < 4; ix++) {
+            if (ix == 1 && iy == 1) continue;
+            o[(y * 4 + iy) * 8 + x * 4 + ix] = c[(y + iy * 2) * 8 + x + ix * 2] + pivot;
+          }
+        o[(4 * y + 1) * 8 + 4 * x + 1] = pivot;
+        o[y * 4 * 8 + x * 4] = c[(y + 2) * 8 + x + 2] + pivot;
       }
-      return;
     }
-    case 12: {  // DCT4X8
-      const float dcs[2] = {c[0] + c[8], c[0] - c[8]};
+  } else if constexpr (TYPE == 2) {  // DCT2X2: three Hadamard levels, ping-pong between the tiles
+    idct2_top_block<2>(c, o);
+    // levels read the full previous buffer outside the top block too: copy it over
 #pragma unroll
-      for (int y = 0; y < 2; y++) {
-        float blk[32];
-#pragma unroll
-        for (int iy = 0; iy < 4; iy++)
-#pragma unroll
-          for (int ix = 0; ix < 8; ix++)
-            blk[iy * 8 + ix] = (ix == 0 && iy == 0) ? dcs[y] : c[(y + iy * 2) * 8 + ix];
-        idct2d_small<4, 8>(blk);
-#pragma unroll
-        for (int iy = 0; iy < 4; iy++)
-#pragma unroll
-          for (int ix = 0; ix < 8; ix++) o[(y * 4 + iy) * 8 + ix] = blk[iy * 8 + ix];
-      }
-      return;
+    for (int i = 0; i < 64; i++) {
+      const int y = i / 8, x = i % 8;
+      if (y >= 2 || x >= 2) o[i] = c[i];
     }
-    default: {  // AFV0..3
-      const int kind = type - 14;
-      const int afv_x = kind & 1, afv_y = kind / 2;
-      const float b00 = c[0], b01 = c[1], b10 = c[8];
-      const float dcs[3] = {(b00 + b10 + b01) * 4.0f, b00 + b10 - b01, b00 - b10};
-      {
-        float coeff[16];
+    idct2_top_block<4>(o, c);
 #pragma unroll
-        for (int iy = 0; iy < 4; iy++)
+    for (int i = 0; i < 64; i++) {
+      const int y = i / 8, x = i % 8;
+      if (y >= 4 || x >= 4) c[i] = o[i];
+    }
+    idct2_top_block<8>(c, o);
+  } else if constexpr (TYPE == 3) {  // DCT4X4
+    const float b00 = c[0], b01 = c[1], b10 = c[8], b11 = c[9];
+    const float dcs[4] = {b00 + b01 + b10 + b11, b00 + b01 - b10 - b11, b00 - b01 + b10 - b11,
+                          b00 - b01 - b10 + b11};
 #pragma unroll
-          for (int ix = 0; ix < 4; ix++)
-            coeff[iy * 4 + ix] = (ix == 0 && iy == 0) ? dcs[0] : c[iy * 2 * 8 + ix * 2];
-        for (int i = 0; i < 16; i++) {
-          float pixel = 0.0f;
+    for (int y = 0; y < 2; y++)
 #pragma unroll
-          for (int j = 0; j < 16; j++) pixel += coeff[j] * kAfvBasisDev[j * 16 + i];
-          const int iy = i / 4, ix = i % 4;
-          const int py = afv_y == 1 ? 3 - iy : iy;
-          const int px = afv_x == 1 ? 3 - ix : ix;
-          // pixels[(iy' + afv_y*4)*8 + afv_x*4 + ix'] = block[by*4 + bx] with (by,bx) flipped:
-          // block index i=(iy,ix) lands at iy' = flip(iy), ix' = flip(ix) (the flip is an involution)
-          o[(py + afv_y * 4) * 8 + afv_x * 4 + px] = pixel;
-        }
-      }
-      {
+      for (int x = 0; x < 2; x++) {
         float blk[16];
 #pragma unroll
         for (int iy = 0; iy < 4; iy++)
 #pragma unroll
           for (int ix = 0; ix < 4; ix++)
-            blk[iy * 4 + ix] = (ix == 0 && iy == 0) ? dcs[1] : c[iy * 2 * 8 + ix * 2 + 1];
+            blk[iy * 4 + ix] = (ix == 0 && iy == 0) ? dcs[y * 2 + x] : c[(y + iy * 2) * 8 + x + ix * 2];
         idct2d_small<4, 4>(blk);
 #pragma unroll
         for (int iy = 0; iy < 4; iy++)
 #pragma unroll
-          for (int ix = 0; ix < 4; ix++) o[(iy + afv_y * 4) * 8 + (1 - afv_x) * 4 + ix] = blk[iy * 4 + ix];
+          for (int ix = 0; ix < 4; ix++) o[(y * 4 + iy) * 8 + x * 4 + ix] = blk[iy * 4 + ix];
       }
-      {
-        float blk[32];
+  } else if constexpr (TYPE == 13) {  // DCT8X4
+    const float dcs[2] = {c[0] + c[8], c[0] - c[8]};
 #pragma unroll
-        for (int iy = 0; iy < 4; iy++)
+    for (int x = 0; x < 2; x++) {
+      float blk[32];
 #pragma unroll
-          for (int ix = 0; ix < 8; ix++)
-            blk[iy * 8 + ix] = (ix == 0 && iy == 0) ? dcs[2] : c[(1 + iy * 2) * 8 + ix];
-        idct2d_small<4, 8>(blk);
+      for (int iy = 0; iy < 4; iy++)
 #pragma unroll
-        for (int iy = 0; iy < 4; iy++)
+        for (int ix = 0; ix < 8; ix++)
+          blk[iy * 8 + ix] = (ix == 0 && iy == 0) ? dcs[x] : c[(x + iy * 2) * 8 + ix];
+      idct2d_small<8, 4>(blk);
 #pragma unroll
-          for (int ix = 0; ix < 8; ix++) o[(iy + (1 - afv_y) * 4) * 8 + ix] = blk[iy * 8 + ix];
+      for (int iy = 0; iy < 8; iy++)
+#pragma unroll
+        for (int ix = 0; ix < 4; ix++) o[iy * 8 + x * 4 + ix] = blk[iy * 4 + ix];
+    }
+  } else if constexpr (TYPE == 12) {  // DCT4X8
+    const float dcs[2] = {c[0] + c[8], c[0] - c[8]};
+#pragma unroll
+    for (int y = 0; y < 2; y++) {
+      float blk[32];
+#pragma unroll
+      for (int iy = 0; iy < 4; iy++)
+#pragma unroll
+        for (int ix = 0; ix < 8; ix++)
+          blk[iy * 8 + ix] = (ix == 0 && iy == 0) ? dcs[y] : c[(y + iy * 2) * 8 + ix];
+      idct2d_small<4, 8>(blk);
+#pragma unroll
+      for (int iy = 0; iy < 4; iy++)
+#pragma unroll
+        for (int ix = 0; ix < 8; ix++) o[(y * 4 + iy) * 8 + ix] = blk[iy * 8 + ix];
+    }
+  } else {  // AFV0..3
+    static_assert(TYPE >= 14 && TYPE <= 17, "special transform type");
+    constexpr int kind = TYPE - 14;
+    constexpr int afv_x = kind & 1, afv_y = kind / 2;
+    const float b00 = c[0], b01 = c[1], b10 = c[8];
+    const float dcs[3] = {(b00 + b10 + b01) * 4.0f, b00 + b10 - b01, b00 - b10};
+    {
+      float coeff[16];
+#pragma unroll
+      for (int iy = 0; iy < 4; iy++)
+#pragma unroll
+        for (int ix = 0; ix < 4; ix++)
+          coeff[iy * 4 + ix] = (ix == 0 && iy == 0) ? dcs[0] : c[iy * 2 * 8 + ix * 2];
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        float pixel = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 16; j++) pixel += coeff[j] * kAfvBasisDev[j * 16 + i];
+        const int iy = i / 4, ix = i % 4;
+        const int py = afv_y == 1 ? 3 - iy : iy;
+        const int px = afv_x == 1 ? 3 - ix : ix;
+        // pixels[(iy' + afv_y*4)*8 + afv_x*4 + ix'] = block[by*4 + bx] with (by,bx) flipped:
+        // block index i=(iy,ix) lands at iy' = flip(iy), ix' = flip(ix) (the flip is an involution)
+        o[(py + afv_y * 4) * 8 + afv_x * 4 + px] = pixel;
       }
-      return;
+    }
+    {
+      float blk[16];
+#pragma unroll
+      for (int iy = 0; iy < 4; iy++)
+#pragma unroll
+        for (int ix = 0; ix < 4; ix++)
+          blk[iy * 4 + ix] = (ix == 0 && iy == 0) ? dcs[1] : c[iy * 2 * 8 + ix * 2 + 1];
+      idct2d_small<4, 4>(blk);
+#pragma unroll
+      for (int iy = 0; iy < 4; iy++)
+#pragma unroll
+        for (int ix = 0; ix < 4; ix++) o[(iy + afv_y * 4) * 8 + (1 - afv_x) * 4 + ix] = blk[iy * 4 + ix];
+    }
+    {
+      float blk[32];
+#pragma unroll
+      for (int iy = 0; iy < 4; iy++)
+#pragma unroll
+        for (int ix = 0; ix < 8; ix++)
+          blk[iy * 8 + ix] = (ix == 0 && iy == 0) ? dcs[2] : c[(1 + iy * 2) * 8 + ix];
+      idct2d_small<4, 8>(blk);
+#pragma unroll
+      for (int iy = 0; iy < 4; iy++)
+#pragma unroll
+        for (int ix = 0; ix < 8; ix++) o[(iy + (1 - afv_y) * 4) * 8 + ix] = blk[iy * 8 + ix];
     }
   }
+}
+
+// Runtime-type front end on memory-resident blocks (stage hook, generic callers).
+__device__ inline void special_8x8(int type, float* c, float* o) {
+  switch (type) {
+    case 1: special_8x8_t<1>(c, o); return;
+    case 2: special_8x8_t<2>(c, o); return;
+    case 3: special_8x8_t<3>(c, o); return;
+    case 12: special_8x8_t<12>(c, o); return;
+    case 13: special_8x8_t<13>(c, o); return;
+    case 14: special_8x8_t<14>(c, o); return;
+    case 15: special_8x8_t<15>(c, o); return;
+    case 16: special_8x8_t<16>(c, o); return;
+    default: special_8x8_t<17>(c, o); return;
+  }
+}
+
+// The same with the block held in registers between an LDS row read and an LDS row write.
+template <int TYPE>
+__device__ __forceinline__ void special_8x8_regs(const float* __restrict__ c_row, float* __restrict__ o_row) {
+  float c[64], o[64];
+#pragma unroll
+  for (int i = 0; i < 64; i++) c[i] = c_row[i];
+  special_8x8_t<TYPE>(c, o);
+#pragma unroll
+  for (int i = 0; i < 64; i++) o_row[i] = o[i];
 }
 
 }  // namespace jxlh
