@@ -688,7 +688,7 @@ jxlh_status jxlh_frame_run(jxlh_ctx* ctx, uint32_t group_row0, uint32_t group_ro
   const int gr0 = halo_px > 0 && group_row0 > 0 ? (int)group_row0 - 1 : (int)group_row0;
   const int gr1 = halo_px > 0 && group_row1 < (uint32_t)f.ygroups ? (int)group_row1 + 1 : (int)group_row1;
   // K1 writes the 8x8-tiled layout whenever the fused filter kernel is its only consumer
-  const bool will_fuse = !(p.flags & JXLH_FRAME_UNFUSED_FILTERS) && f.epf_iters < 3 && (f.gab || f.epf_iters > 0);
+  const bool will_fuse = !(p.flags & JXLH_FRAME_UNFUSED_FILTERS) && (f.gab || f.epf_iters > 0);
   f.tiled = will_fuse ? 1 : 0;
   {
     ScopedKernelTimer t(ctx, "k1_vardct");
@@ -705,15 +705,18 @@ jxlh_status jxlh_frame_run(jxlh_ctx* ctx, uint32_t group_row0, uint32_t group_ro
   if (f.epf_iters >= 2) { stages[ns] = 2; borders[ns++] = 1; }
   float* cur[3] = {f.planes[0], f.planes[1], f.planes[2]};
   float* oth[3] = {f.tmp[0], f.tmp[1], f.tmp[2]};
-  if (!(p.flags & JXLH_FRAME_UNFUSED_FILTERS) && ns > 0 && f.epf_iters < 3) {
-    // production path: the whole stage list in one pass over HBM
+  if (!(p.flags & JXLH_FRAME_UNFUSED_FILTERS) && ns > 0) {
+    // production path: the whole stage list in one pass over HBM (two for epf_iters == 3)
     ScopedKernelTimer t(ctx, "k23_fused_filters");
-    if (launch_fused_filters(ctx->stream, f, y_lo, y_hi)) {
+    const int where = launch_fused_filters(ctx->stream, f, y_lo, y_hi);
+    if (where == 1) {
       for (int c = 0; c < 3; c++) {
         cur[c] = f.tmp[c];
         oth[c] = f.planes[c];
       }
       ns = 0;
+    } else if (where == 2) {
+      ns = 0;  // result back in f.planes
     }
   }
   for (int s = 0; s < ns; s++) {

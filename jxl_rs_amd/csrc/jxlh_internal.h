@@ -141,7 +141,7 @@ struct EpfArgs {
 void launch_epf(hipStream_t s, int stage, const EpfArgs& a, int y0, int y1);
 // Gaborish/EPF1/EPF2 of the frame's stage list in one LDS-tiled pass, planes -> tmp, output rows [y0, y1).
 // Returns false when the stage list is not covered (EPF0, i.e. epf_iters == 3, or no stage at all).
-bool launch_fused_filters(hipStream_t s, const FrameDev& f, int y0, int y1);
+int launch_fused_filters(hipStream_t s, const FrameDev& f, int y0, int y1);
 // sparse coefficient transport (k_coeffs.hip): one descriptor per submitted group
 struct SparseGroup {
   uint32_t group;   // group id

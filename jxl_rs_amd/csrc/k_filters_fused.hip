@@ -75,7 +75,7 @@ struct FusedArgs {
   int y0, y1;  // output rows [y0, y1) (band sharding); tiles start at y0
   float gab_k[3][3];
   float scale[3];
-  float sm1, bsm1, sm2, bsm2;
+  float sm0, bsm0, sm1, bsm1, sm2, bsm2;
   int tiled_in, xblocks;  // input layout (see FrameDev::tiled)
 };
 
@@ -133,6 +133,18 @@ __device__ __forceinline__ void load8(const float* __restrict__ strip, float (&v
 __device__ __forceinline__ void load4(const float* __restrict__ strip, float (&v)[4]) {
   const float4 c = lds_load4(strip);
   v[0] = c.x; v[1] = c.y; v[2] = c.z; v[3] = c.w;
+}
+
+// 10 consecutive values: v[0..2] = cols bx0-3..-1, v[3..6] = strip, v[7..9] = cols bx0+4..+6
+__device__ __forceinline__ void load10(const float* __restrict__ strip, float (&v)[10]) {
+  const float4 c = lds_load4(strip);
+  v[0] = dpp_from_left(c.y);
+  v[1] = dpp_from_left(c.z);
+  v[2] = dpp_from_left(c.w);
+  v[3] = c.x; v[4] = c.y; v[5] = c.z; v[6] = c.w;
+  v[7] = dpp_from_right(c.x);
+  v[8] = dpp_from_right(c.y);
+  v[9] = dpp_from_right(c.z);
 }
 
 #define FAD(a, b) __builtin_fabsf((a) - (b))
@@ -434,6 +446,120 @@ __device__ __forceinline__ void epf2_strip(const float* __restrict__ p0, int fx0
   for (int c = 0; c < 3; c++) emit(c, make_float4(o[c][0], o[c][1], o[c][2], o[c][3]));
 }
 
+// ---- EPF0 on one strip (epf0.rs:87-210): 12 neighbours in a radius-2 diamond, each compared
+// over a 5-pixel plus.  Always the last stage of its kernel (7 rows x 10 columns of context make
+// it the register-heaviest stage; its output goes straight to HBM).  P(cx, cy) below is the
+// reference's 7x7 window with the pixel at (3, 3); the sums keep its term order.
+template <class Emit>
+__device__ __forceinline__ void epf0_strip(const float* __restrict__ p0, int fx0, int fy, float sigma,
+                                           const FusedArgs& a, Emit&& emit) {
+  float sads[4][12];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int k = 0; k < 12; k++) sads[i][k] = 0.0f;
+#pragma unroll 1
+  for (int c = 0; c < 3; c++) {
+    const float* p = p0 + c * kPlane;
+    const float scale = a.scale[c];
+    // window rows y-3 .. y+3; index = column - (bx0 - 3)
+    float R0[10], R1[10], R2[10], R3[10], R4[10], R5[10], R6[10];
+    {
+      float t4[4], t8[8];
+      load4(p - 3 * kBW, t4);
+#pragma unroll
+      for (int j = 0; j < 4; j++) R0[3 + j] = t4[j];
+      load4(p + 3 * kBW, t4);
+#pragma unroll
+      for (int j = 0; j < 4; j++) R6[3 + j] = t4[j];
+      load8(p - 2 * kBW, t8);
+#pragma unroll
+      for (int j = 0; j < 8; j++) R1[1 + j] = t8[j];
+      load8(p - kBW, t8);
+#pragma unroll
+      for (int j = 0; j < 8; j++) R2[1 + j] = t8[j];
+      load8(p + kBW, t8);
+#pragma unroll
+      for (int j = 0; j < 8; j++) R4[1 + j] = t8[j];
+      load8(p + 2 * kBW, t8);
+#pragma unroll
+      for (int j = 0; j < 8; j++) R5[1 + j] = t8[j];
+      load10(p, R3);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+#define P(cx, cy) R##cy[(cx) + i]
+      const float p30 = P(3, 0), p21 = P(2, 1), p31 = P(3, 1), p41 = P(4, 1), p12 = P(1, 2), p22 = P(2, 2),
+                  p32 = P(3, 2), p42 = P(4, 2), p52 = P(5, 2), p03 = P(0, 3), p13 = P(1, 3), p23 = P(2, 3),
+                  p33 = P(3, 3), p43 = P(4, 3), p53 = P(5, 3), p63 = P(6, 3), p14 = P(1, 4), p24 = P(2, 4),
+                  p34 = P(3, 4), p44 = P(4, 4), p54 = P(5, 4), p25 = P(2, 5), p35 = P(3, 5), p45 = P(4, 5),
+                  p36 = P(3, 6);
+#undef P
+      const float d32_30 = FAD(p32, p30), d32_21 = FAD(p32, p21), d32_31 = FAD(p32, p31), d32_41 = FAD(p32, p41),
+                  d32_12 = FAD(p32, p12), d32_22 = FAD(p32, p22), d32_42 = FAD(p32, p42), d32_52 = FAD(p32, p52),
+                  d32_23 = FAD(p32, p23), d32_34 = FAD(p32, p34), d32_43 = FAD(p32, p43), d32_33 = FAD(p32, p33),
+                  d23_21 = FAD(p23, p21), d23_12 = FAD(p23, p12), d23_22 = FAD(p23, p22), d23_03 = FAD(p23, p03),
+                  d23_13 = FAD(p23, p13), d23_33 = FAD(p23, p33), d23_43 = FAD(p23, p43), d23_14 = FAD(p23, p14),
+                  d23_24 = FAD(p23, p24), d23_34 = FAD(p23, p34), d23_25 = FAD(p23, p25), d33_31 = FAD(p33, p31),
+                  d33_22 = FAD(p33, p22), d33_42 = FAD(p33, p42), d33_13 = FAD(p33, p13), d33_43 = FAD(p33, p43),
+                  d33_53 = FAD(p33, p53), d33_24 = FAD(p33, p24), d33_34 = FAD(p33, p34), d33_44 = FAD(p33, p44),
+                  d33_35 = FAD(p33, p35), d43_41 = FAD(p43, p41), d43_42 = FAD(p43, p42), d43_52 = FAD(p43, p52),
+                  d43_53 = FAD(p43, p53), d43_63 = FAD(p43, p63), d43_34 = FAD(p43, p34), d43_44 = FAD(p43, p44),
+                  d43_54 = FAD(p43, p54), d43_45 = FAD(p43, p45), d34_14 = FAD(p34, p14), d34_24 = FAD(p34, p24),
+                  d34_44 = FAD(p34, p44), d34_54 = FAD(p34, p54), d34_25 = FAD(p34, p25), d34_35 = FAD(p34, p35),
+                  d34_45 = FAD(p34, p45), d34_36 = FAD(p34, p36);
+      sads[i][0] = __builtin_fmaf(scale, d32_30 + d23_21 + d33_31 + d43_41 + d32_34, sads[i][0]);
+      sads[i][1] = __builtin_fmaf(scale, d32_21 + d23_12 + d33_22 + d32_43 + d23_34, sads[i][1]);
+      sads[i][2] = __builtin_fmaf(scale, d32_31 + d23_22 + d32_33 + d43_42 + d33_34, sads[i][2]);
+      sads[i][3] = __builtin_fmaf(scale, d32_41 + d32_23 + d33_42 + d43_52 + d43_34, sads[i][3]);
+      sads[i][4] = __builtin_fmaf(scale, d32_12 + d23_03 + d33_13 + d23_43 + d34_14, sads[i][4]);
+      sads[i][5] = __builtin_fmaf(scale, d32_22 + d23_13 + d23_33 + d33_43 + d34_24, sads[i][5]);
+      sads[i][6] = __builtin_fmaf(scale, d32_42 + d23_33 + d33_43 + d43_53 + d34_44, sads[i][6]);
+      sads[i][7] = __builtin_fmaf(scale, d32_52 + d23_43 + d33_53 + d43_63 + d34_54, sads[i][7]);
+      sads[i][8] = __builtin_fmaf(scale, d32_23 + d23_14 + d33_24 + d43_34 + d34_25, sads[i][8]);
+      sads[i][9] = __builtin_fmaf(scale, d32_33 + d23_24 + d33_34 + d43_44 + d34_35, sads[i][9]);
+      sads[i][10] = __builtin_fmaf(scale, d32_43 + d23_34 + d33_44 + d43_54 + d34_45, sads[i][10]);
+      sads[i][11] = __builtin_fmaf(scale, d32_34 + d23_25 + d33_35 + d43_45 + d34_36, sads[i][11]);
+    }
+  }
+  const bool pass = sigma < kMinSigma;
+  float is[4], inv_w[4];
+  strip_inv_sigma(sigma, fx0, fy, a.sm0, a.bsm0, is);
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    float wsum = 1.0f;
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+      sads[i][k] = fmaxf(__builtin_fmaf(sads[i][k], is[i], 1.0f), 0.0f);
+      wsum += sads[i][k];
+    }
+    inv_w[i] = recip_weight_sum(wsum);
+  }
+#pragma unroll 1
+  for (int c = 0; c < 3; c++) {
+    const float* p = p0 + c * kPlane;
+    float A[4], B[8], C[8], D[8], E[4];  // rows y-2 .. y+2; 8-wide rows hold cols x-2 .. x+5
+    load4(p - 2 * kBW, A);
+    load8(p - kBW, B);
+    load8(p, C);
+    load8(p + kBW, D);
+    load4(p + 2 * kBW, E);
+    float o[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int j = i + 2;
+      // neighbours 0..11: (0,-2) (-1,-1) (0,-1) (1,-1) (-2,0) (-1,0) (1,0) (2,0) (-1,1) (0,1) (1,1) (0,2)
+      const float n[12] = {A[i], B[j - 1], B[j], B[j + 1], C[j - 2], C[j - 1], C[j + 1], C[j + 2],
+                           D[j - 1], D[j], D[j + 1], E[i]};
+      float acc = C[j];
+#pragma unroll
+      for (int k = 11; k >= 0; k--) acc = __builtin_fmaf(n[k], sads[i][k], acc);
+      o[i] = pass ? C[j] : acc * inv_w[i];
+    }
+    emit(c, make_float4(o[0], o[1], o[2], o[3]));
+  }
+}
+
 // Overwrites out-of-frame positions of a stage's output region [B-m, B+T+m) with the values
 // at their mirrored in-frame coordinates.  Only called by tiles that touch the frame border.
 __device__ __forceinline__ void mirror_fill(float* __restrict__ buf, int m, int tx0, int ty0, int w, int h, int tid) {
@@ -449,8 +575,8 @@ __device__ __forceinline__ void mirror_fill(float* __restrict__ buf, int m, int 
   }
 }
 
-template <bool GAB, bool E1, bool E2>
-__global__ __launch_bounds__(kT, JXLH_FUSED_WAVES_PER_EU) void k23_fused_filters(const FusedArgs a) {
+template <bool GAB, bool E0, bool E1, bool E2>
+__global__ __launch_bounds__(kT, E0 ? 4 : JXLH_FUSED_WAVES_PER_EU) void k23_fused_filters(const FusedArgs a) {
   __shared__ __attribute__((aligned(16))) float s_buf[3 * kPlane];
   // 1/sigma of the 8x8 blocks this tile touches (block columns/rows relative to the tile's first block)
   __shared__ float s_sigma[kSigH * kSigW];
@@ -469,11 +595,12 @@ __global__ __launch_bounds__(kT, JXLH_FUSED_WAVES_PER_EU) void k23_fused_filters
   if (tile_y >= tiles_y) return;
   const int tx0 = tile_x * kTW, ty0 = a.y0 + tile_y * kTH;
   const bool edge = tx0 - kB < 0 || ty0 - kB < 0 || tx0 + kTW + kB > a.w || ty0 + kTH + kB > a.h;
-  constexpr int kBorder = (GAB ? 1 : 0) + (E1 ? 2 : 0) + (E2 ? 1 : 0);
+  constexpr int kBorder = (GAB ? 1 : 0) + (E0 ? 3 : 0) + (E1 ? 2 : 0) + (E2 ? 1 : 0);
   static_assert(kBorder >= 1 && kBorder <= kB, "at least one stage");
+  static_assert(!(E0 && (E1 || E2)), "EPF0 closes its kernel; EPF1/EPF2 follow in a second launch");
 
   const int sbx0 = max(tx0 - kB, 0) >> 3, sby0 = max(ty0 - kB, 0) >> 3;
-  if constexpr (E1 || E2) {
+  if constexpr (E0 || E1 || E2) {
     if (tid < kSigH * kSigW) {
       const int sx = min(sbx0 + tid % kSigW, (a.w - 1) >> 3), sy = min(sby0 + tid / kSigW, (a.h - 1) >> 3);
       s_sigma[tid] = at_bytes<float>(a.inv_sigma, 4u * ((uint32_t)sy * a.sigma_stride + (uint32_t)sx));
@@ -553,7 +680,8 @@ __global__ __launch_bounds__(kT, JXLH_FUSED_WAVES_PER_EU) void k23_fused_filters
     // the previous stage, where it would sit in registers the 80-VGPR budget does not have.
     int tid = tid_kernel;
     asm volatile("" : "+v"(tid));
-    if constexpr (STAGE == 2 && last && JXLH_E2_STRIPS) {
+    static_assert(STAGE != 3 || last, "EPF0 runs as the last stage");
+    if constexpr ((STAGE == 2 && last && JXLH_E2_STRIPS) || STAGE == 3) {
       constexpr int ns = rows * kStrips;
 #pragma unroll 1
       for (int t0 = 0; t0 < ns; t0 += kT) {
@@ -572,6 +700,8 @@ __global__ __launch_bounds__(kT, JXLH_FUSED_WAVES_PER_EU) void k23_fused_filters
         if (__all(sigma < kMinSigma)) {
 #pragma unroll
           for (int c = 0; c < 3; c++) put(c, lds_load4(p + c * kPlane));
+        } else if constexpr (STAGE == 3) {
+          epf0_strip(p, fx0, fy, sigma, a, put);
         } else {
           epf2_strip(p, fx0, fy, sigma, a, put);
         }
@@ -655,15 +785,16 @@ __global__ __launch_bounds__(kT, JXLH_FUSED_WAVES_PER_EU) void k23_fused_filters
   constexpr int kMg = kBorder - (GAB ? 1 : 0);      // margin after Gaborish
   constexpr int kMe1 = kMg - (E1 ? 2 : 0);          // after EPF1
   if constexpr (GAB) run_stage(std::integral_constant<int, 0>{}, std::integral_constant<int, kMg>{});
+  if constexpr (E0) run_stage(std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{});
   if constexpr (E1) run_stage(std::integral_constant<int, 1>{}, std::integral_constant<int, kMe1>{});
   if constexpr (E2) run_stage(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{});
 }
 
-template <bool GAB, bool E1, bool E2>
+template <bool GAB, bool E0, bool E1, bool E2>
 void launch_variant(hipStream_t s, const FusedArgs& a) {
   const int tiles_x = (a.w + kTW - 1) / kTW, tiles_y = (a.y1 - a.y0 + kTH - 1) / kTH;
   const dim3 grid(tiles_x * ((tiles_y + 7) / 8) * 8);
-  hipLaunchKernelGGL((k23_fused_filters<GAB, E1, E2>), grid, dim3(kT), 0, s, a);
+  hipLaunchKernelGGL((k23_fused_filters<GAB, E0, E1, E2>), grid, dim3(kT), 0, s, a);
 }
 
 __global__ void k_selftest_recip(uint32_t lo_bits, uint32_t hi_bits, unsigned long long* mismatches) {
@@ -684,13 +815,13 @@ void launch_selftest_recip(hipStream_t s, uint32_t lo_bits, uint32_t hi_bits, un
   hipLaunchKernelGGL(k_selftest_recip, dim3(2048), dim3(256), 0, s, lo_bits, hi_bits, mismatches);
 }
 
-// Runs the frame's stage list (gab?, epf1?, epf2?) fused; planes -> tmp.  Returns false if the
-// combination is not covered (epf_iters == 3 or nothing to do).
-bool launch_fused_filters(hipStream_t s, const FrameDev& f, int y0, int y1) {
-  if (f.epf_iters >= 3) return false;
-  const bool gab = f.gab != 0, e1 = f.epf_iters >= 1, e2 = f.epf_iters >= 2;
-  if (!gab && !e1 && !e2) return false;
-  if (y1 <= y0) return true;
+// Runs the frame's stage list fused.  Returns 0 if there is nothing to do, 1 if the result is in
+// f.tmp (one pass: gab?, epf1?, epf2?), 2 if it is in f.planes (epf_iters == 3: Gaborish + EPF0 go
+// planes -> tmp, EPF1 + EPF2 come back tmp -> planes, both raster).
+int launch_fused_filters(hipStream_t s, const FrameDev& f, int y0, int y1) {
+  const bool gab = f.gab != 0, e0 = f.epf_iters >= 3, e1 = f.epf_iters >= 1, e2 = f.epf_iters >= 2;
+  if (!gab && !e1 && !e2) return 0;
+  if (y1 <= y0) return e0 ? 2 : 1;
   FusedArgs a;
   for (int c = 0; c < 3; c++) {
     a.in[c] = f.planes[c];
@@ -705,18 +836,37 @@ bool launch_fused_filters(hipStream_t s, const FrameDev& f, int y0, int y1) {
   a.h = f.ysize;
   a.y0 = y0;
   a.y1 = y1;
+  a.sm0 = f.epf_sm[0];
+  a.bsm0 = f.epf_bsm[0];
   a.sm1 = f.epf_sm[1];
   a.bsm1 = f.epf_bsm[1];
   a.sm2 = f.epf_sm[2];
   a.bsm2 = f.epf_bsm[2];
   a.tiled_in = f.tiled;
   a.xblocks = f.xblocks;
-  if (gab && e1 && e2) launch_variant<true, true, true>(s, a);
-  else if (gab && e1) launch_variant<true, true, false>(s, a);
-  else if (gab) launch_variant<true, false, false>(s, a);
-  else if (e1 && e2) launch_variant<false, true, true>(s, a);
-  else launch_variant<false, true, false>(s, a);
-  return true;
+  if (e0) {
+    // first pass over the band widened by the second pass's 3-pixel border (kept 4-aligned for
+    // the tiled staging path)
+    a.y0 = max(0, y0 - 4);
+    a.y1 = min(f.ysize, y1 + 3);
+    if (gab) launch_variant<true, true, false, false>(s, a);
+    else launch_variant<false, true, false, false>(s, a);
+    for (int c = 0; c < 3; c++) {
+      a.in[c] = f.tmp[c];
+      a.out[c] = f.planes[c];
+    }
+    a.tiled_in = 0;
+    a.y0 = y0;
+    a.y1 = y1;
+    launch_variant<false, false, true, true>(s, a);
+    return 2;
+  }
+  if (gab && e1 && e2) launch_variant<true, false, true, true>(s, a);
+  else if (gab && e1) launch_variant<true, false, true, false>(s, a);
+  else if (gab) launch_variant<true, false, false, false>(s, a);
+  else if (e1 && e2) launch_variant<false, false, true, true>(s, a);
+  else launch_variant<false, false, true, false>(s, a);
+  return 1;
 }
 
 }  // namespace jxlh

@@ -108,6 +108,11 @@ FRAME_CASES = [
     (333, 77, "MIX_D1", dict(epf_iters=1, gab=True, lf_smoothing=True)),       # Gaborish + EPF1
     (66, 34, "MIX_D1", dict(epf_iters=2, gab=True, lf_smoothing=True)),        # frame edge inside a filter tile
     (3, 2, "MIX_DCT8", dict(epf_iters=2, gab=True, lf_smoothing=True)),        # frame smaller than every halo
+    # epf_iters == 3: Gaborish + EPF0 kernel followed by the EPF1 + EPF2 kernel on the fused path
+    (333, 77, "MIX_D1", dict(epf_iters=3, gab=False, lf_smoothing=True)),
+    (66, 34, "MIX_D1", dict(epf_iters=3, gab=True, lf_smoothing=True)),
+    (9, 9, "MIX_D1", dict(epf_iters=3, gab=True, lf_smoothing=True)),
+    (1024, 768, "MIX_D1", dict(epf_iters=3, gab=True, lf_smoothing=True)),
 ]
 
 
@@ -150,11 +155,12 @@ def test_vardct_frame_vs_unfused_oracle_within_tolerance(ctx, oracle_unfused):
         assert err.max() < 2e-5, f"plane {c}: max abs err {err.max()}"
 
 
-def test_band_runs_equal_whole_frame(ctx, oracle):
+@pytest.mark.parametrize("epf_iters", [2, 3])
+def test_band_runs_equal_whole_frame(ctx, oracle, epf_iters):
     """jxlh_frame_run(row0, row1): a band of group rows (multi-GPU sharding unit) produces exactly
     the rows the whole-frame run produces -- halo group rows are recomputed, nothing is exchanged."""
     from jxl_rs_amd import synth
-    wl = synth.make_vardct(520, 700, mix=synth.MIX_D1, seed=31, epf_iters=2)
+    wl = synth.make_vardct(520, 700, mix=synth.MIX_D1, seed=31, epf_iters=epf_iters)
     want, _ = run_oracle_frame(oracle, wl)
     for flags in (0, 1):
         upload_frame(ctx, wl, flags=flags)
