@@ -208,6 +208,27 @@ jxlh_status jxlh_kernel_timing_get(jxlh_ctx* ctx, int32_t i, const char** name, 
                                    int32_t* launches);
 jxlh_status jxlh_kernel_timing_reset(jxlh_ctx* ctx);
 
+/* ---------------------------------------------------------------- 8-bit sRGB output
+ * The stages the reference runs after EPF for an XYB-encoded frame saved as 8-bit sRGB -- XybStage
+ * (render/stages/xyb.rs:208-240), FromLinearStage with the sRGB curve (color/tf.rs:13-44),
+ * ConvertF32ToU8Stage incl. its dither (render/stages/convert.rs:570-606), chained as in
+ * frame/render.rs:757-762, :118 -- in one pass over the finished planes, written interleaved
+ * (channels = 3: RGB, 4: RGBA with A = 255) for frame rows [y0, y1).  `out` points at row y0 and may be
+ * host or device memory; for host memory the call returns after the copy has completed.
+ * The parameters are the reference's XybParams::new(opsin, intensity_target) (xyb.rs:147-163):
+ * inverse matrix, cbrt(biases), biases * intensity_scale, intensity_scale = 255 / intensity_target.
+ * Frames whose output colour space is not sRGB/D65 with the sRGB transfer function, or that need
+ * upsampling / blending / extra channels, keep the reference's CPU stages (JXLH_ERR_UNSUPPORTED is the
+ * caller's decision: this entry point does what it says). */
+typedef struct jxlh_xyb_params {
+  float opsin_inverse_matrix[9];
+  float bias_cbrt[3];
+  float scaled_bias[3];
+  float intensity_scale;
+} jxlh_xyb_params;
+jxlh_status jxlh_frame_read_rgb8(jxlh_ctx* ctx, const jxlh_xyb_params* p, uint32_t channels, uint32_t y0,
+                                 uint32_t y1, void* out, size_t bytes_per_row);
+
 /* ---------------------------------------------------------------- stage-level hooks */
 /* Whole-image single stages with the pipeline's mirror edge semantics; the analogue of
  * make_and_run_simple_pipeline (jxl/src/render/test.rs:83-179).  Planes: w x h f32, row stride

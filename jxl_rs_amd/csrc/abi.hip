@@ -63,6 +63,7 @@ struct jxlh_ctx {
   DevBuf<uint8_t> transform_map, epf_map;
   DevBuf<int8_t> ytox, ytob;
   DevBuf<int> error_flag;
+  DevBuf<uint8_t> rgb8;  // jxlh_frame_read_rgb8 staging for host destinations
   int* host_flag = nullptr;  // pinned
   DevBuf<uint8_t> worklist;
   float* result[3] = {nullptr, nullptr, nullptr};
@@ -164,6 +165,8 @@ void drain_timers(jxlh_ctx* ctx) {
 size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
 
 // plane -> device 2-D copy helper (pointers may be host or device)
+bool is_device_ptr(const void* p);  // defined with the stage hooks below
+
 jxlh_status copy2d(jxlh_ctx* ctx, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width_bytes,
                    size_t height, hipStream_t s) {
   if (width_bytes == 0 || height == 0) return JXLH_OK;
@@ -295,6 +298,7 @@ void jxlh_ctx_destroy(jxlh_ctx* ctx) {
   release(ctx->ytox);
   release(ctx->ytob);
   release(ctx->error_flag);
+  release(ctx->rgb8);
   if (ctx->host_flag) (void)hipHostFree(ctx->host_flag);
   release(ctx->worklist);
   for (auto& b : ctx->hook_f) release(b);
@@ -768,6 +772,44 @@ jxlh_status jxlh_ctx_sync(jxlh_ctx* ctx) {
     if (*ctx->host_flag != 0) return (jxlh_status)*ctx->host_flag;
     return JXLH_OK;
   }
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return JXLH_OK;
+}
+
+jxlh_status jxlh_frame_read_rgb8(jxlh_ctx* ctx, const jxlh_xyb_params* p, uint32_t channels, uint32_t y0,
+                                 uint32_t y1, void* out, size_t bytes_per_row) {
+  if (!ctx || !p || !out || (channels != 3 && channels != 4)) return JXLH_ERR_INVALID_ARGUMENT;
+  if (!ctx->in_frame || !ctx->result[0]) return JXLH_ERR_BAD_STATE;
+  const FrameDev& f = ctx->fd;
+  if (y1 > (uint32_t)f.ysize) y1 = (uint32_t)f.ysize;
+  if (y0 >= y1 || bytes_per_row < (size_t)f.xsize * channels) return JXLH_ERR_INVALID_ARGUMENT;
+  XybParamsDev d;
+  for (int i = 0; i < 9; i++) d.mat[i] = p->opsin_inverse_matrix[i];
+  for (int i = 0; i < 3; i++) {
+    d.bias_cbrt[i] = p->bias_cbrt[i];
+    d.scaled_bias[i] = p->scaled_bias[i];
+  }
+  d.intensity_scale = p->intensity_scale;
+  const int rows = (int)(y1 - y0);
+  const float* planes[3] = {ctx->result[0], ctx->result[1], ctx->result[2]};
+  if (is_device_ptr(out)) {
+    ScopedKernelTimer t(ctx, "k_xyb_to_rgb8");
+    launch_xyb_to_rgb8(ctx->stream, planes, f.plane_stride, f.xsize, (int)y0, rows, d, (int)channels,
+                       static_cast<uint8_t*>(out), bytes_per_row);
+    HIPCHK(ctx, hipGetLastError());
+    return JXLH_OK;
+  }
+  const size_t tight = ((size_t)f.xsize * channels + 3) & ~(size_t)3;
+  if (jxlh_status st = ensure(ctx, ctx->rgb8, tight * (size_t)rows)) return st;
+  {
+    ScopedKernelTimer t(ctx, "k_xyb_to_rgb8");
+    launch_xyb_to_rgb8(ctx->stream, planes, f.plane_stride, f.xsize, (int)y0, rows, d, (int)channels, ctx->rgb8.p,
+                       tight);
+  }
+  HIPCHK(ctx, hipGetLastError());
+  if (jxlh_status st = copy2d(ctx, out, bytes_per_row, ctx->rgb8.p, tight, (size_t)f.xsize * channels, (size_t)rows,
+                              ctx->stream))
+    return st;
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return JXLH_OK;
 }

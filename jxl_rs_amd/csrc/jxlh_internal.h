@@ -142,6 +142,13 @@ void launch_epf(hipStream_t s, int stage, const EpfArgs& a, int y0, int y1);
 // Gaborish/EPF1/EPF2 of the frame's stage list in one LDS-tiled pass, planes -> tmp, output rows [y0, y1).
 // Returns false when the stage list is not covered (EPF0, i.e. epf_iters == 3, or no stage at all).
 int launch_fused_filters(hipStream_t s, const FrameDev& f, int y0, int y1);
+// output stages (k_output.hip): XybParams of the reference (xyb.rs:147-163), same field order as
+// jxlh_xyb_params
+struct XybParamsDev {
+  float mat[9], bias_cbrt[3], scaled_bias[3], intensity_scale;
+};
+void launch_xyb_to_rgb8(hipStream_t s, const float* const planes[3], size_t stride, int w, int y0, int rows,
+                        const XybParamsDev& p, int channels, uint8_t* out, size_t out_stride);
 // sparse coefficient transport (k_coeffs.hip): one descriptor per submitted group
 struct SparseGroup {
   uint32_t group;   // group id

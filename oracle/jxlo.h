@@ -149,6 +149,22 @@ void jxlo_vardct_frame(const JxloFrameParams* p, const int32_t* coeffs /* ngroup
                        float* const lf[3], const float* const tables[17], float* const planes[3],
                        float* const tmp[3], size_t stride, int num_threads);
 
+/* ---- output stages for an XYB frame shown as 8-bit sRGB (xyb.rs, color/tf.rs, convert.rs) ---- */
+typedef struct {
+  float mat[9];         /* opsin inverse matrix */
+  float bias_cbrt[3];   /* cbrt(opsin_biases) */
+  float scaled_bias[3]; /* opsin_biases * intensity_scale */
+  float intensity_scale; /* 255 / intensity_target */
+} JxloXybParams;
+void jxlo_xyb_params(const float inverse_matrix[9], const float opsin_biases[3], float intensity_target,
+                     JxloXybParams* out);
+void jxlo_xyb_to_linear(const JxloXybParams* p, float* row_x, float* row_y, float* row_b, size_t n);
+float jxlo_linear_to_srgb1(float x);
+void jxlo_linear_to_srgb(float* v, size_t n);
+uint8_t jxlo_f32_to_u8(float v, size_t x, size_t y, int channel, int bit_depth);
+void jxlo_xyb_to_rgb8(const JxloXybParams* p, const float* px, const float* py, const float* pb, size_t w, size_t h,
+                      size_t stride, uint8_t* out, size_t out_stride_bytes, int out_channels);
+
 /* ---- sparse coefficient transport: the dense slab a stream of `coeffs[c][pos] += v` updates describes
  * (group.rs:557-572).  pairs: little-endian {u16 pos; i16 val}, n[0] of X then n[1] of Y then n[2] of B;
  * wide: n_wide x {u32 channel*65536+pos; i32 val} */

@@ -67,6 +67,17 @@ class Oracle:
         assert bool(L.jxlo_is_fused()) == fused
         fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int32)
         dp = C.POINTER(C.c_double)
+        L.jxlo_xyb_params.argtypes = [fp, fp, C.c_float, fp]
+        L.jxlo_xyb_params.restype = None
+        L.jxlo_xyb_to_linear.argtypes = [fp, fp, fp, fp, C.c_size_t]
+        L.jxlo_xyb_to_linear.restype = None
+        L.jxlo_linear_to_srgb.argtypes = [fp, C.c_size_t]
+        L.jxlo_linear_to_srgb.restype = None
+        L.jxlo_f32_to_u8.argtypes = [C.c_float, C.c_size_t, C.c_size_t, C.c_int, C.c_int]
+        L.jxlo_f32_to_u8.restype = C.c_uint8
+        L.jxlo_xyb_to_rgb8.argtypes = [fp, fp, fp, fp, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(C.c_uint8),
+                                       C.c_size_t, C.c_int]
+        L.jxlo_xyb_to_rgb8.restype = None
         L.jxlo_expand_sparse.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                          C.c_uint32, C.POINTER(C.c_int32)]
         L.jxlo_expand_sparse.restype = None
@@ -326,6 +337,39 @@ class Oracle:
                                    self._p3(lf), self._p3(tables), self._p3(planes), self._p3(tmp),
                                    stride, num_threads)
         return planes, lf
+
+    # ---- output stages (XYB -> linear -> sRGB -> u8) ----
+    def xyb_params(self, inverse_matrix, opsin_biases, intensity_target=255.0):
+        m = np.ascontiguousarray(inverse_matrix, dtype=np.float32)
+        b = np.ascontiguousarray(opsin_biases, dtype=np.float32)
+        out = np.zeros(16, dtype=np.float32)   # JxloXybParams: mat[9], bias_cbrt[3], scaled_bias[3], intensity_scale
+        self.lib.jxlo_xyb_params(_ptr(m, C.c_float), _ptr(b, C.c_float), C.c_float(intensity_target),
+                                 _ptr(out, C.c_float))
+        return out
+
+    def xyb_to_linear(self, params, x, y, b):
+        rows = [np.ascontiguousarray(a, dtype=np.float32).copy().reshape(-1) for a in (x, y, b)]
+        p = np.ascontiguousarray(params, dtype=np.float32)
+        self.lib.jxlo_xyb_to_linear(_ptr(p, C.c_float), _ptr(rows[0], C.c_float), _ptr(rows[1], C.c_float),
+                                    _ptr(rows[2], C.c_float), rows[0].size)
+        return rows
+
+    def linear_to_srgb(self, v):
+        v = np.ascontiguousarray(v, dtype=np.float32).copy()
+        self.lib.jxlo_linear_to_srgb(_ptr(v.reshape(-1), C.c_float), v.size)
+        return v
+
+    def f32_to_u8(self, v, x, y, channel, bit_depth=8):
+        return int(self.lib.jxlo_f32_to_u8(C.c_float(v), x, y, channel, bit_depth))
+
+    def xyb_to_rgb8(self, params, planes, w, h, channels=3):
+        pl = [np.ascontiguousarray(a, dtype=np.float32) for a in planes]
+        stride = pl[0].shape[1]
+        p = np.ascontiguousarray(params, dtype=np.float32)
+        out = np.zeros((h, w, channels), dtype=np.uint8)
+        self.lib.jxlo_xyb_to_rgb8(_ptr(p, C.c_float), _ptr(pl[0], C.c_float), _ptr(pl[1], C.c_float),
+                                  _ptr(pl[2], C.c_float), w, h, stride, _ptr(out, C.c_uint8), w * channels, channels)
+        return out
 
     # ---- sparse coefficient transport ----
     def expand_sparse(self, pairs, n, wide=None):

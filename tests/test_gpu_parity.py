@@ -424,3 +424,50 @@ def test_sparse_expansion_matches_oracle_slab(ctx, oracle):
     assert np.array_equal(got[0], wl.coeffs[0])
     assert np.array_equal(got[1], oracle.expand_sparse(pairs, n, wide))
     assert got[1][0, 7] == slab[0, 7] + 3
+
+
+# ---------------------------------------------------------------- 8-bit sRGB output stage
+def _default_xyb_params(oracle, kat, intensity_target=255.0):
+    k = kat["output_stage"]
+    return oracle.xyb_params(k["opsin_inverse_matrix"], [k["opsin_bias"]] * 3, intensity_target)
+
+
+@pytest.mark.parametrize("size,channels,intensity", [((520, 300), 3, 255.0), ((333, 77), 4, 255.0),
+                                                     ((66, 34), 3, 400.0), ((9, 9), 4, 255.0)])
+def test_rgb8_output_bit_exact(ctx, oracle, kat, size, channels, intensity):
+    """XybStage + sRGB FromLinearStage + ConvertF32ToU8Stage in one device pass == the oracle's
+    restatement of the three stages applied to the oracle's planes, byte for byte"""
+    from jxl_rs_amd import synth
+    w, h = size
+    wl = synth.make_vardct(w, h, mix=synth.MIX_D1, seed=w * 7 + h, epf_iters=2)
+    want_planes, _ = run_oracle_frame(oracle, wl)
+    params = _default_xyb_params(oracle, kat, intensity)
+    want = oracle.xyb_to_rgb8(params, want_planes, w, h, channels)
+    upload_frame(ctx, wl)
+    ctx.frame_run()
+    ctx.sync()
+    got = ctx.read_rgb8(params, channels)
+    assert got.shape == want.shape
+    bad = np.argwhere(got != want)
+    assert bad.size == 0, f"{len(bad)} differing bytes, first at {bad[0]}: got {got[tuple(bad[0])]} want {want[tuple(bad[0])]}"
+    # a band of rows equals the same rows of the whole image (dither is position dependent)
+    y0, y1 = h // 3, max(h // 3 + 1, (2 * h) // 3)
+    band = ctx.read_rgb8(params, channels, y0, y1)
+    assert np.array_equal(band, want[y0:y1])
+    assert len(np.unique(want)) > 16, "test image should exercise many code values"
+
+
+def test_rgb8_output_argument_errors(ctx, oracle, kat):
+    from jxl_rs_amd import synth
+    from jxl_rs_amd.lib import JxlHipError
+    wl = synth.make_vardct(64, 64, mix=synth.MIX_DCT8, seed=3, epf_iters=0, gab=False)
+    upload_frame(ctx, wl)
+    params = _default_xyb_params(oracle, kat)
+    with pytest.raises(JxlHipError):
+        ctx.read_rgb8(params, 3)          # no frame has been run yet
+    ctx.frame_run()
+    ctx.sync()
+    with pytest.raises(JxlHipError):
+        ctx.read_rgb8(params, 2)          # channels must be 3 or 4
+    with pytest.raises(JxlHipError):
+        ctx.read_rgb8(params, 3, 10, 10)  # empty row range

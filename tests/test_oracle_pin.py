@@ -147,3 +147,40 @@ def test_squeeze_tendency_simd_form_equals_scalar_definition(oracle):
         v = rng.integers(-scale, scale + 1, size=(20000, 3))
         for a, b, c in v:
             assert L.jxlo_smooth_tendency_i32(int(a), int(b), int(c)) == L.jxlo_smooth_tendency(int(a), int(b), int(c))
+
+
+# ---------------------------------------------------------------- output stages (XYB -> sRGB u8)
+def test_xyb_stage_srgb_primaries_known_answer(oracle_any, kat):
+    """xyb.rs:289-312: three XYB pixels that are the sRGB primaries at intensity 255"""
+    k = kat["output_stage"]
+    p = oracle_any.xyb_params(k["opsin_inverse_matrix"], [k["opsin_bias"]] * 3, k["intensity_target"])
+    x, y, b = (np.array(r, dtype=np.float32) for r in k["srgb_primaries_input_xyb"])
+    r, g, bb = oracle_any.xyb_to_linear(p, x, y, b)
+    want = np.array(k["srgb_primaries_output_rgb"], dtype=np.float32)   # rows: R, G, B planes
+    for got, w in zip((r, g, bb), want):
+        assert np.abs(got - w).max() < k["srgb_primaries_tol"], (got, w)
+
+
+def test_srgb_transfer_matches_pow_definition(oracle_any, kat):
+    """tf.rs:601-611: the rational-polynomial sRGB curve vs the pow() definition, tol 1e-6; also odd symmetry"""
+    k = kat["output_stage"]
+    rng = np.random.default_rng(5)
+    v = np.concatenate([rng.uniform(0, 1, 20000), rng.uniform(0, 0.004, 2000), [0.0, 0.0031308, 1.0]]).astype(np.float32)
+    got = oracle_any.linear_to_srgb(v)
+    a = v.astype(np.float64)
+    naive = np.where(a <= 0.0031308, a * 12.92, 1.055 * a ** (1 / 2.4) - 0.055)
+    assert np.abs(got - naive).max() < k["srgb_tf_vs_pow_tol"] * 2   # naive here is f64; the reference compares f32 pow
+    assert np.array_equal(oracle_any.linear_to_srgb(-v), -got)
+
+
+def test_u8_conversion_dither_properties(oracle_any):
+    """convert.rs:14-18: the dither table averages 0 and stays inside (-0.49219, 0.49219), so an exact
+    code value k/255 converts to k for every position and channel; out-of-range input clamps"""
+    for (x, y, c) in [(0, 0, 0), (31, 5, 1), (32, 40, 2), (1000, 999, 1)]:
+        for k in (0, 1, 127, 128, 254, 255):
+            assert oracle_any.f32_to_u8(k / 255.0, x, y, c) == k
+        assert oracle_any.f32_to_u8(-3.0, x, y, c) == 0
+        assert oracle_any.f32_to_u8(7.0, x, y, c) == 255
+    # a mid-grey half-step flips with the dither: both neighbours occur over a 32x32 period
+    vals = {oracle_any.f32_to_u8(100.5 / 255.0, x, y, 0) for x in range(32) for y in range(32)}
+    assert vals == {100, 101}
