@@ -321,8 +321,42 @@ def main():
             e2e[name] = {"value": round(size * size * frames / 1e6 / el, 1), "unit": "MP/s",
                          "ms_per_frame": round(el * 1e3 / frames, 3), "h2d_MB_per_frame": round(nbytes / 1e6, 1),
                          "frames": frames}
+        # full decode-to-host: sparse pairs in, interleaved 8-bit sRGB out (jxlh_frame_read_rgb8) into
+        # pinned host memory; frame i's download overlaps frame i+1's upload and kernels
+        kk = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_kat.json")))["output_stage"]
+        bias = np.float32(kk["opsin_bias"])
+        xyb_params = np.concatenate([np.asarray(kk["opsin_inverse_matrix"], np.float32),
+                                     np.full(3, np.cbrt(bias), np.float32), np.full(3, bias, np.float32),
+                                     np.ones(1, np.float32)])
+        rgb_bytes = size * size * 3
+        pin_o = [ectx[i].alloc_pinned(rgb_bytes) for i in range(2)]
+        import ctypes as C
+
+        def read_rgb(i):
+            c = ectx[i]
+            c._chk(c.L.jxlh_frame_read_rgb8(c._ctx, xyb_params.ctypes.data_as(C.c_void_p), 3, 0, size,
+                                            C.c_void_p(pin_o[i][1]), size * 3), "frame_read_rgb8")
+
+        frames = 12
+        for i in range(2):
+            submit_sparse(ectx[i]); ectx[i].frame_run()
+        for i in range(2):
+            read_rgb(i)
+        t0 = time.perf_counter()
+        submit_sparse(ectx[0]); ectx[0].frame_run()
+        for i in range(1, frames):
+            c = ectx[i % 2]
+            submit_sparse(c); c.frame_run()
+            read_rgb((i - 1) % 2)          # blocks on frame i-1 while frame i uploads and computes
+        read_rgb((frames - 1) % 2)
+        el = time.perf_counter() - t0
+        e2e["sparse_pairs_to_host_rgb8"] = {"value": round(size * size * frames / 1e6 / el, 1), "unit": "MP/s",
+                                            "ms_per_frame": round(el * 1e3 / frames, 3),
+                                            "h2d_MB_per_frame": round(total * 4 / 1e6, 1),
+                                            "d2h_MB_per_frame": round(rgb_bytes / 1e6, 1), "frames": frames}
         e2e["note"] = ("pinned host coefficients -> H2D on 2 slot streams -> (sparse: device zero-fill + scatter) -> "
-                       "K0b/K3/K1/filters, 2 frames in flight; planes stay on the device")
+                       "K0b/K3/K1/filters, 2 frames in flight; planes stay on the device except in *_to_host_rgb8, which adds "
+                       "the XYB->sRGB->u8 pass and the D2H of the interleaved image")
         for c in ectx:
             c.close()
 

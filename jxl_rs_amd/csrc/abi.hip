@@ -170,6 +170,10 @@ bool is_device_ptr(const void* p);  // defined with the stage hooks below
 jxlh_status copy2d(jxlh_ctx* ctx, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width_bytes,
                    size_t height, hipStream_t s) {
   if (width_bytes == 0 || height == 0) return JXLH_OK;
+  if (dpitch == width_bytes && spitch == width_bytes) {  // contiguous on both sides: one linear copy
+    HIPCHK(ctx, hipMemcpyAsync(dst, src, width_bytes * height, hipMemcpyDefault, s));
+    return JXLH_OK;
+  }
   HIPCHK(ctx, hipMemcpy2DAsync(dst, dpitch, src, spitch, width_bytes, height, hipMemcpyDefault, s));
   return JXLH_OK;
 }
@@ -799,6 +803,8 @@ jxlh_status jxlh_frame_read_rgb8(jxlh_ctx* ctx, const jxlh_xyb_params* p, uint32
     HIPCHK(ctx, hipGetLastError());
     return JXLH_OK;
   }
+  // staging rows are dword aligned; when the caller's rows are tight and already aligned the D2H
+  // is one linear copy, otherwise a 2-D copy of exactly the pixel bytes (row padding is never written)
   const size_t tight = ((size_t)f.xsize * channels + 3) & ~(size_t)3;
   if (jxlh_status st = ensure(ctx, ctx->rgb8, tight * (size_t)rows)) return st;
   {
@@ -807,8 +813,8 @@ jxlh_status jxlh_frame_read_rgb8(jxlh_ctx* ctx, const jxlh_xyb_params* p, uint32
                        tight);
   }
   HIPCHK(ctx, hipGetLastError());
-  if (jxlh_status st = copy2d(ctx, out, bytes_per_row, ctx->rgb8.p, tight, (size_t)f.xsize * channels, (size_t)rows,
-                              ctx->stream))
+  const size_t row_bytes = (size_t)f.xsize * channels;
+  if (jxlh_status st = copy2d(ctx, out, bytes_per_row, ctx->rgb8.p, tight, row_bytes, (size_t)rows, ctx->stream))
     return st;
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return JXLH_OK;
