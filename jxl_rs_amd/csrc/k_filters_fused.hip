@@ -31,7 +31,8 @@
 // the reference's pipeline would hand it.
 //
 // Stage subsets (gab on/off, epf_iters 0..2) are compile-time variants of the same kernel;
-// epf_iters == 3 (EPF0, 7-pixel halo) uses the per-stage kernels of k_filters.hip.
+// epf_iters == 3 runs as two launches: Gaborish + EPF0 (EPF0 always closes its kernel: its 7x10
+// register window leaves no room to hold outputs across an in-place barrier), then EPF1 + EPF2.
 #include "jxlh_internal.h"
 
 #ifndef JXLH_FUSED_TH
