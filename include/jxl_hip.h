@@ -90,6 +90,8 @@ typedef struct {
 
 enum {
   JXLH_FRAME_UNFUSED_FILTERS = 1u << 0, /* run Gaborish/EPF as one kernel per stage (debug/parity) */
+  JXLH_FRAME_EXPAND_SPARSE = 1u << 1,   /* always expand sparse submissions into dense slabs before the
+                                           transforms instead of letting them read the pairs (debug/parity) */
 };
 
 /* Header defaults of the reference (RestorationFilter / ColorCorrelationParams /
@@ -153,9 +155,11 @@ enum { JXLH_GROUP_COMPLETE = 1u << 0 /* set_buffer_for_group(.., complete = true
  *   pairs   n[0] pairs of channel X, then n[1] of Y, then n[2] of B, contiguous; pos = index inside
  *           the channel's 65536-entry slab (the same index space as the dense form)
  *   wide    values that do not fit i16 (the reference stores i32), pos = channel * 65536 + index
- * Duplicate positions accumulate with wrapping i32 adds (multi-pass accumulation).  The device
- * zero-fills the group's slab and scatters the pairs when the frame is run; everything downstream
- * is identical to the dense path.  Asynchronous like jxlh_submit_group (H2D on the slot's stream;
+ * Duplicate positions accumulate with wrapping i32 adds (multi-pass accumulation: put all passes'
+ * updates of a group in ONE list -- a group may be submitted sparse once between two jxlh_frame_run
+ * calls, JXLH_ERR_BAD_STATE otherwise).  When every group of the frame arrives this way the transforms
+ * read the pairs directly (bucketed per varblock on the device); otherwise the device zero-fills the
+ * groups' slabs and scatters the pairs.  Results are identical to the dense path bit for bit.  Asynchronous like jxlh_submit_group (H2D on the slot's stream;
  * pinned host memory from jxlh_alloc_pinned overlaps with compute). */
 typedef struct jxlh_coeff16 {
   uint16_t pos;

@@ -81,6 +81,16 @@ struct jxlh_ctx {
   size_t sp_used = 0;
   hipEvent_t sp_expanded = nullptr;
   bool sp_expanded_valid = false;
+  // K1 reading the pairs directly: the frame's pairs bucketed by varblock slot + slot tables.  Valid
+  // while every group of the frame has been submitted sparse (once) and nothing was resubmitted.
+  DevBuf<uint32_t> sp_sorted, sp_slot_start;
+  DevBuf<uint8_t> group_dense;
+  // Epochs: the submissions between two jxlh_frame_run calls.  touched[g]: 0 not resubmitted (keeps its
+  // content), 1 dense slab, 2 pairs.  sp_sorted_valid: before this epoch every group's content lived in
+  // the bucketed form (and only there).
+  std::vector<uint8_t> touched, flag_upload;
+  bool epoch_dirty = false;
+  bool sp_sorted_valid = false;
   // profiling
   bool timing = false;
   std::vector<KernelTime> ktimes;
@@ -294,6 +304,9 @@ void jxlh_ctx_destroy(jxlh_ctx* ctx) {
   release(ctx->sp_pairs);
   release(ctx->sp_groups_dev);
   release(ctx->sp_wide_dev);
+  release(ctx->sp_sorted);
+  release(ctx->sp_slot_start);
+  release(ctx->group_dense);
   if (ctx->sp_expanded) (void)hipEventDestroy(ctx->sp_expanded);
   release(ctx->raw_quant);
   release(ctx->lfq);
@@ -357,6 +370,9 @@ jxlh_status jxlh_frame_begin(jxlh_ctx* ctx, const jxlh_frame_params* p) {
     ctx->sp_pending.clear();
     ctx->sp_wide.clear();
     ctx->sp_used = 0;
+    ctx->touched.assign(ctx->ngroups, 0);
+    ctx->epoch_dirty = false;
+    ctx->sp_sorted_valid = false;
   }
   const size_t nblocks = (size_t)f.xblocks * f.yblocks;
   const size_t ncmap = (size_t)f.cmap_stride * ((f.yblocks + 7) / 8);
@@ -540,6 +556,11 @@ jxlh_status jxlh_submit_group(jxlh_ctx* ctx, int32_t slot, uint32_t group_id, co
   if (group_id >= ctx->ngroups) return JXLH_ERR_INVALID_ARGUMENT;
   if (!(flags & JXLH_GROUP_COMPLETE)) return JXLH_ERR_UNSUPPORTED;  // progressive partial renders stay on the CPU path
   Slot& s = ctx->slots[slot];
+  {
+    std::lock_guard<std::mutex> lock(ctx->sp_mutex);
+    ctx->touched[group_id] = 1;
+    ctx->epoch_dirty = true;
+  }
   int32_t* dst = ctx->coeffs.p + (size_t)group_id * 3 * kGroupArea;
   if (dst != coeffs) {
     HIPCHK(ctx, hipMemcpyAsync(dst, coeffs, (size_t)3 * kGroupArea * sizeof(int32_t), hipMemcpyDefault, s.stream));
@@ -574,6 +595,8 @@ jxlh_status jxlh_submit_groups_sparse(jxlh_ctx* ctx, int32_t slot, uint32_t coun
     if (jxlh_status st = ensure(ctx, ctx->sp_pairs, capacity)) return st;
     if (!ctx->sp_expanded) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->sp_expanded, hipEventDisableTiming));
     if (ctx->sp_used + total > capacity) return JXLH_ERR_INVALID_ARGUMENT;  // more pairs than coefficients
+    for (uint32_t i = 0; i < count; i++)  // one sparse submission per group between two runs (its list may
+      if (ctx->touched[group_ids[i]] == 2) return JXLH_ERR_BAD_STATE;  // hold several passes' updates)
     offset = ctx->sp_used;
     ctx->sp_used += total;
     size_t o = offset;
@@ -586,7 +609,9 @@ jxlh_status jxlh_submit_groups_sparse(jxlh_ctx* ctx, int32_t slot, uint32_t coun
         o += g.n[c];
       }
       ctx->sp_pending.push_back(g);
+      ctx->touched[g.group] = 2;
     }
+    ctx->epoch_dirty = true;
     for (uint32_t i = 0; i < n_wide; i++) ctx->sp_wide.push_back(make_uint2(wide[i].pos, (uint32_t)wide[i].val));
   }
   // the pair buffer is recycled per frame: the previous frame's expansion must have read it
@@ -641,10 +666,14 @@ jxlh_status jxlh_frame_run(jxlh_ctx* ctx, uint32_t group_row0, uint32_t group_ro
   for (auto& s : ctx->slots) {
     if (s.used) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, s.done, 0));
   }
-  // ---- sparse coefficient transport: zero-fill + scatter the pairs submitted since the last run
+  // ---- sparse coefficient transport.  Preferred: K1 reads the pairs itself (bucketed by varblock slot
+  // first) -- possible when every group arrived as pairs in this epoch and no value needed the wide
+  // list.  Otherwise everything ends up in the dense slabs: groups whose content so far lived only in
+  // the bucketed form are expanded from it, this epoch's pairs are zero-filled + scattered.
+  bool sparse_k1 = false;
   {
     std::lock_guard<std::mutex> lock(ctx->sp_mutex);
-    if (!ctx->sp_pending.empty() || !ctx->sp_wide.empty()) {
+    if (ctx->epoch_dirty) {
       ctx->sp_upload.swap(ctx->sp_pending);  // stays alive until the next run: the H2D copies read it
       ctx->sp_wide_upload.swap(ctx->sp_wide);
       ctx->sp_pending.clear();
@@ -652,21 +681,53 @@ jxlh_status jxlh_frame_run(jxlh_ctx* ctx, uint32_t group_row0, uint32_t group_ro
       const size_t ng = ctx->sp_upload.size(), nw = ctx->sp_wide_upload.size();
       if (jxlh_status st = ensure(ctx, ctx->sp_groups_dev, ng)) return st;
       if (jxlh_status st = ensure(ctx, ctx->sp_wide_dev, nw)) return st;
+      if (jxlh_status st = ensure(ctx, ctx->group_dense, ctx->ngroups)) return st;
       if (ng)
         HIPCHK(ctx, hipMemcpyAsync(ctx->sp_groups_dev.p, ctx->sp_upload.data(), ng * sizeof(SparseGroup),
                                    hipMemcpyHostToDevice, ctx->stream));
       if (nw)
         HIPCHK(ctx, hipMemcpyAsync(ctx->sp_wide_dev.p, ctx->sp_wide_upload.data(), nw * sizeof(uint2),
                                    hipMemcpyHostToDevice, ctx->stream));
-      {
-        ScopedKernelTimer t(ctx, "k_expand_sparse");
-        launch_expand_sparse(ctx->stream, ctx->coeffs.p, ctx->sp_pairs.p, ctx->sp_groups_dev.p, (int)ng,
-                             ctx->sp_wide_dev.p, (uint32_t)nw);
+      bool all_pairs = nw == 0 && ng == ctx->ngroups && !(p.flags & JXLH_FRAME_EXPAND_SPARSE);
+      for (size_t g = 0; all_pairs && g < ctx->ngroups; g++) all_pairs = ctx->touched[g] == 2;
+      if (ctx->sp_sorted_valid && !all_pairs) {
+        // leaving the bucketed form: groups not resubmitted now need their dense slab
+        ctx->flag_upload.assign(ctx->ngroups, 0);
+        bool any = false;
+        for (size_t g = 0; g < ctx->ngroups; g++) any |= (ctx->flag_upload[g] = ctx->touched[g] == 0) != 0;
+        if (any) {
+          HIPCHK(ctx, hipMemcpyAsync(ctx->group_dense.p, ctx->flag_upload.data(), ctx->ngroups, hipMemcpyHostToDevice,
+                                     ctx->stream));
+          ScopedKernelTimer t(ctx, "k_expand_sparse");
+          launch_expand_sorted(ctx->stream, ctx->coeffs.p, ctx->sp_sorted.p, ctx->sp_slot_start.p, ctx->group_dense.p,
+                               (int)ctx->ngroups);
+        }
       }
-      HIPCHK(ctx, hipEventRecord(ctx->sp_expanded, ctx->stream));
-      ctx->sp_expanded_valid = true;
+      if (all_pairs) {
+        const size_t capacity = ctx->ngroups * 3 * (size_t)kGroupArea;
+        if (jxlh_status st = ensure(ctx, ctx->sp_sorted, capacity)) return st;
+        if (jxlh_status st = ensure(ctx, ctx->sp_slot_start, ctx->ngroups * 3 * (size_t)kSlotTable)) return st;
+        ScopedKernelTimer t(ctx, "k_sort_sparse");
+        launch_sort_sparse(ctx->stream, ctx->sp_pairs.p, ctx->sp_groups_dev.p, (int)ng, ctx->sp_sorted.p,
+                           ctx->sp_slot_start.p);
+        ctx->sp_sorted_valid = true;
+      } else {
+        if (ng || nw) {
+          ScopedKernelTimer t(ctx, "k_expand_sparse");
+          launch_expand_sparse(ctx->stream, ctx->coeffs.p, ctx->sp_pairs.p, ctx->sp_groups_dev.p, (int)ng,
+                               ctx->sp_wide_dev.p, (uint32_t)nw, nullptr);
+        }
+        ctx->sp_sorted_valid = false;
+      }
       ctx->sp_used = 0;
+      ctx->touched.assign(ctx->ngroups, 0);
+      ctx->epoch_dirty = false;
+      if (ctx->sp_expanded) {  // the pair buffer has been consumed (bucketed or expanded)
+        HIPCHK(ctx, hipEventRecord(ctx->sp_expanded, ctx->stream));
+        ctx->sp_expanded_valid = true;
+      }
     }
+    sparse_k1 = ctx->sp_sorted_valid;
   }
   // ---- K0b: Frame::finalize_lf (frame/mod.rs:360-378)
   const bool smooth = p.do_lf_smoothing && f.xblocks > 2 && f.yblocks > 2;  // adaptive_lf_smoothing.rs:51-53
@@ -701,7 +762,12 @@ jxlh_status jxlh_frame_run(jxlh_ctx* ctx, uint32_t group_row0, uint32_t group_ro
   {
     ScopedKernelTimer t(ctx, "k1_vardct");
     // forked class kernels measured no gain on the d1 mix (event overhead ~ tail savings): run in order
-    launch_vardct_groups(ctx->stream, nullptr, f, gr0, gr1, ctx->worklist.p, ctx->error_flag.p);
+    f.sp_sorted = sparse_k1 ? ctx->sp_sorted.p : nullptr;
+    f.sp_slot_start = sparse_k1 ? ctx->sp_slot_start.p : nullptr;
+    f.group_dense = sparse_k1 ? ctx->group_dense.p : nullptr;
+    if (sparse_k1) HIPCHK(ctx, hipMemsetAsync(ctx->group_dense.p, 0, ctx->ngroups, ctx->stream));
+    launch_vardct_groups(ctx->stream, nullptr, f, gr0, gr1, ctx->worklist.p, ctx->error_flag.p,
+                         sparse_k1 ? ctx->coeffs.p : nullptr);
   }
   // ---- stage list of frame/render.rs:569-622
   const int y_lo = (int)group_row0 * kGroupDim;

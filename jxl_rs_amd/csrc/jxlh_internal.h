@@ -86,7 +86,16 @@ struct FrameDev {
   // varblock then completes whole 256-byte chunks instead of sharing 128-byte lines with its
   // neighbours, and an IDCT lane (which owns a pixel column) stores 32 contiguous bytes.
   int tiled;
+  // Sparse coefficient input (null = K1 reads the dense slabs in `coeffs`).  sp_sorted: the frame's
+  // {u16 pos; i16 val} pairs, bucketed by 64-coefficient slot inside every (group, channel) run;
+  // sp_slot_start[(group*3 + c) * kSlotTable + s] = index of the first pair of slot s, entry
+  // [.. + 1024] = end of the run.  group_dense[g] != 0 (set by k1_scan): the group holds varblocks of
+  // the special / large classes, whose kernels read a dense slab (expanded for just those groups).
+  const uint32_t* sp_sorted;
+  const uint32_t* sp_slot_start;
+  uint8_t* group_dense;
 };
+constexpr int kSlotTable = 1025;  // 1024 slots of 64 coefficients per (group, channel) + end marker
 
 // pixel (x, y) relative to a varblock's top-left pixel, for either layout:
 //   addr = base + xoff(x) + (y >> 3) * ystep_blk + (y & 7) * ystep8
@@ -125,8 +134,9 @@ struct K1Streams {
   hipStream_t aux[3];
   hipEvent_t ev[4];
 };
+// dense_coeffs: writable alias of f.coeffs, used in sparse mode to expand the groups k1_scan flags
 void launch_vardct_groups(hipStream_t s, const K1Streams* aux, const FrameDev& f, int group_row0, int group_row1,
-                          void* worklist_mem, int* error_flag);
+                          void* worklist_mem, int* error_flag, int32_t* dense_coeffs);
 void launch_gaborish(hipStream_t s, const float* in, float* out, int w, int h, size_t stride, float k0, float k1,
                      float k2, int y0, int y1);
 struct EpfArgs {
@@ -155,8 +165,15 @@ struct SparseGroup {
   uint32_t offset;  // index of the group's first pair in the pair buffer (X pairs, then Y, then B)
   uint32_t n[3];    // pairs per channel
 };
+// only_flagged (nullable): expand a group only if only_flagged[group] != 0
 void launch_expand_sparse(hipStream_t s, int32_t* coeffs, const uint32_t* pairs, const SparseGroup* groups,
-                          int n_groups, const uint2* wide, uint32_t n_wide);
+                          int n_groups, const uint2* wide, uint32_t n_wide, const uint8_t* only_flagged);
+// dense slabs of the groups with flags[g] != 0 from the bucketed pairs (all groups of the frame)
+void launch_expand_sorted(hipStream_t s, int32_t* coeffs, const uint32_t* sorted, const uint32_t* slot_start,
+                          const uint8_t* flags, int n_groups);
+// counting sort of every (group, channel) run by slot (pos >> 6) + the slot start table
+void launch_sort_sparse(hipStream_t s, const uint32_t* pairs, const SparseGroup* groups, int n_groups,
+                        uint32_t* sorted, uint32_t* slot_start);
 // counts floats with bit patterns in [lo_bits, hi_bits) whose fast reciprocal differs from 1.0f / w
 void launch_selftest_recip(hipStream_t s, uint32_t lo_bits, uint32_t hi_bits, unsigned long long* mismatches);
 void launch_transform_to_pixels(hipStream_t s, int type, uint32_t n, const float* coeffs, const float* lf,

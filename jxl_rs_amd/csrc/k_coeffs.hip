@@ -22,10 +22,12 @@ constexpr int kQuarter = kGroupArea / 4;  // 16384 coefficients = 64 KB of LDS
 
 __global__ __launch_bounds__(kExpandThreads) void k_expand_sparse(int32_t* __restrict__ coeffs,
                                                                   const uint32_t* __restrict__ pairs,
-                                                                  const SparseGroup* __restrict__ groups) {
+                                                                  const SparseGroup* __restrict__ groups,
+                                                                  const uint8_t* __restrict__ only_flagged) {
   __shared__ __attribute__((aligned(16))) int32_t s_q[kQuarter];
   const int q = blockIdx.x & 3, c = (blockIdx.x >> 2) % 3, tid = threadIdx.x;
   const SparseGroup sg = groups[blockIdx.x / 12];
+  if (only_flagged && !only_flagged[sg.group]) return;  // K1 reads this group's pairs directly
   int4* s4 = reinterpret_cast<int4*>(s_q);
 #pragma unroll
   for (int i = 0; i < kQuarter / 4 / kExpandThreads; i++) s4[i * kExpandThreads + tid] = make_int4(0, 0, 0, 0);
@@ -54,6 +56,74 @@ __global__ __launch_bounds__(kExpandThreads) void k_expand_sparse(int32_t* __res
   for (int i = 0; i < kQuarter / 4 / kExpandThreads; i++) d4[i * kExpandThreads + tid] = s4[i * kExpandThreads + tid];
 }
 
+// Buckets one (group, channel) run of pairs by 64-coefficient slot (= the unit varblock
+// coefficient offsets are counted in, group.rs:612): sorted[] receives the run reordered so that
+// a varblock's pairs are contiguous, slot_start[] the first index of every slot.  The order of
+// pairs inside a slot is arbitrary (K1 adds them up before dequantising).
+__global__ __launch_bounds__(kExpandThreads) void k_sort_sparse(const uint32_t* __restrict__ pairs,
+                                                                const SparseGroup* __restrict__ groups,
+                                                                uint32_t* __restrict__ sorted,
+                                                                uint32_t* __restrict__ slot_start) {
+  __shared__ uint32_t s_count[1024], s_cursor[1024], s_wsum[kExpandThreads / 64];
+  const SparseGroup sg = groups[blockIdx.x / 3];
+  const int c = blockIdx.x % 3, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t n = sg.n[c];
+  const uint32_t first = sg.offset + (c > 0 ? sg.n[0] : 0u) + (c > 1 ? sg.n[1] : 0u);
+  const uint32_t* __restrict__ src = pairs + first;
+  s_count[tid] = 0;
+  __syncthreads();
+  for (uint32_t i = tid; i < n; i += kExpandThreads) atomicAdd(&s_count[(src[i] & 0xffffu) >> 6], 1u);
+  __syncthreads();
+  // exclusive scan of the 1024 counts (one per thread)
+  const uint32_t mine = s_count[tid];
+  uint32_t incl = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t v = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += v;
+  }
+  if (lane == 63) s_wsum[wave] = incl;
+  __syncthreads();
+  uint32_t base = 0;
+  for (int w = 0; w < wave; w++) base += s_wsum[w];
+  const uint32_t excl = base + incl - mine;
+  s_cursor[tid] = excl;
+  uint32_t* table = slot_start + ((size_t)sg.group * 3 + c) * kSlotTable;
+  table[tid] = first + excl;
+  if (tid == 0) table[1024] = first + n;
+  __syncthreads();
+  for (uint32_t i = tid; i < n; i += kExpandThreads) {
+    const uint32_t p = src[i];
+    const uint32_t at = atomicAdd(&s_cursor[(p & 0xffffu) >> 6], 1u);
+    sorted[first + at] = p;
+  }
+}
+
+// Dense slab of a group from its bucketed pairs (no descriptors needed: the slot table delimits every
+// quarter of every (group, channel) run).  flags: expand group g only if flags[g] != 0.
+__global__ __launch_bounds__(kExpandThreads) void k_expand_sorted(int32_t* __restrict__ coeffs,
+                                                                  const uint32_t* __restrict__ sorted,
+                                                                  const uint32_t* __restrict__ slot_start,
+                                                                  const uint8_t* __restrict__ flags) {
+  __shared__ __attribute__((aligned(16))) int32_t s_q[kQuarter];
+  const int q = blockIdx.x & 3, c = (blockIdx.x >> 2) % 3, group = blockIdx.x / 12, tid = threadIdx.x;
+  if (!flags[group]) return;
+  int4* s4 = reinterpret_cast<int4*>(s_q);
+#pragma unroll
+  for (int i = 0; i < kQuarter / 4 / kExpandThreads; i++) s4[i * kExpandThreads + tid] = make_int4(0, 0, 0, 0);
+  __syncthreads();
+  const uint32_t* table = slot_start + ((size_t)group * 3 + c) * kSlotTable + q * (kQuarter / 64);
+  const uint32_t i0 = table[0], i1 = table[kQuarter / 64];
+  for (uint32_t i = i0 + tid; i < i1; i += kExpandThreads) {
+    const uint32_t p = sorted[i];
+    atomicAdd(&s_q[p & (kQuarter - 1)], (int32_t)(int16_t)(p >> 16));
+  }
+  __syncthreads();
+  int4* d4 = reinterpret_cast<int4*>(coeffs + ((size_t)group * 3 + c) * kGroupArea + q * kQuarter);
+#pragma unroll
+  for (int i = 0; i < kQuarter / 4 / kExpandThreads; i++) d4[i * kExpandThreads + tid] = s4[i * kExpandThreads + tid];
+}
+
 // values outside i16: pos = (group * 3 + channel) * 65536 + position
 __global__ void k_expand_wide(int32_t* __restrict__ coeffs, const uint2* __restrict__ wide, uint32_t n) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -62,10 +132,25 @@ __global__ void k_expand_wide(int32_t* __restrict__ coeffs, const uint2* __restr
 
 }  // namespace
 
-void launch_expand_sparse(hipStream_t s, int32_t* coeffs, const uint32_t* pairs, const SparseGroup* groups,
-                          int n_groups, const uint2* wide, uint32_t n_wide) {
+void launch_sort_sparse(hipStream_t s, const uint32_t* pairs, const SparseGroup* groups, int n_groups,
+                        uint32_t* sorted, uint32_t* slot_start) {
   if (n_groups > 0)
-    hipLaunchKernelGGL(k_expand_sparse, dim3(n_groups * 12), dim3(kExpandThreads), 0, s, coeffs, pairs, groups);
+    hipLaunchKernelGGL(k_sort_sparse, dim3(n_groups * 3), dim3(kExpandThreads), 0, s, pairs, groups, sorted,
+                       slot_start);
+}
+
+void launch_expand_sorted(hipStream_t s, int32_t* coeffs, const uint32_t* sorted, const uint32_t* slot_start,
+                          const uint8_t* flags, int n_groups) {
+  if (n_groups > 0)
+    hipLaunchKernelGGL(k_expand_sorted, dim3(n_groups * 12), dim3(kExpandThreads), 0, s, coeffs, sorted, slot_start,
+                       flags);
+}
+
+void launch_expand_sparse(hipStream_t s, int32_t* coeffs, const uint32_t* pairs, const SparseGroup* groups,
+                          int n_groups, const uint2* wide, uint32_t n_wide, const uint8_t* only_flagged) {
+  if (n_groups > 0)
+    hipLaunchKernelGGL(k_expand_sparse, dim3(n_groups * 12), dim3(kExpandThreads), 0, s, coeffs, pairs, groups,
+                       only_flagged);
   if (n_wide > 0)
     hipLaunchKernelGGL(k_expand_wide, dim3((n_wide + 255) / 256), dim3(256), 0, s, coeffs, wide, n_wide);
 }

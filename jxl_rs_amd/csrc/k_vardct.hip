@@ -69,6 +69,8 @@ struct BlockInfo {
   int px_off;    // y*stride + x of the top-left pixel
   int lf_off;    // by*xblocks + bx of the top-left block
   float sdy, x_cc, b_cc;
+  int slot_base;  // sparse input: index of the varblock's first slot in sp_slot_start (channel X)
+  int first_pos;  // position of the varblock's first coefficient inside the channel slab
 };
 
 }  // namespace
@@ -177,6 +179,7 @@ __global__ __launch_bounds__(kThreads) void k1_scan(const FrameDev f, const Work
   }
   __syncthreads();
   if (tid < kNumClasses) s_base[tid] = s_count[tid] > 0 ? atomicAdd(&wl.counts[tid], s_count[tid]) : 0;
+  if (tid == 0 && f.group_dense) f.group_dense[group] = (s_count[kClsSpecial] | s_count[kClsLarge]) != 0;
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < 4; i++) {
@@ -203,6 +206,8 @@ __device__ __forceinline__ void decode_item(const FrameDev& f, const WorkItem& i
   const int g = (int)it.group;
   const int gbx = (g % f.xgroups) * kGroupBlocks + bx, gby = (g / f.xgroups) * kGroupBlocks + by;
   bi->coef_off = g * 3 * kGroupArea + off64 * 64;  // < 2^31: jxlh_frame_begin bounds the frame
+  bi->slot_base = g * 3 * kSlotTable + off64;
+  bi->first_pos = off64 * 64;
   bi->px_off = block_px_offset(f, gbx, gby);
   bi->lf_off = gby * f.xblocks + gbx;
   bi->sdy = it.sdy;
@@ -260,7 +265,47 @@ __device__ __forceinline__ void stage4(float* __restrict__ buf, int b, int k, fl
 
 // All batches of one DCT shape assigned to this wave.  PREFETCH: issue the coefficient
 // loads of all three channels before touching any (small shapes; 3*E/4 int4 in flight per lane).
-template <class S, bool PREFETCH>
+// Sparse input: builds the integer coefficients of one channel of the batch in the wave's tile
+// (zero, then ds_add of the varblocks' pairs: duplicates from several passes add up before
+// dequantisation, like `coeffs[i] += v` in the dense slab).  64 / NB lanes per varblock walk its
+// pair range; the layout is the M layout, so the dequantisation pass converts in place.
+template <class S>
+__device__ __forceinline__ void sparse_stage_channel(const FrameDev& f, int ch, float* __restrict__ buf,
+                                                     const BlockInfo* __restrict__ binfo, int nb, int lane) {
+  int* ibuf = reinterpret_cast<int*>(buf);
+  constexpr int kWords = S::NB * S::SM;
+  if constexpr (kWords % 4 == 0) {
+    for (int i = lane * 4; i < kWords; i += 256) *reinterpret_cast<int4*>(ibuf + i) = make_int4(0, 0, 0, 0);
+  } else {
+    for (int i = lane; i < kWords; i += 64) ibuf[i] = 0;
+  }
+  wave_sync();
+  constexpr int LPB = 64 / S::NB;
+  const int b = lane / LPB, j = lane % LPB;
+  if (b < nb) {
+    const int base = binfo[b].slot_base + ch * kSlotTable;
+    const uint32_t i0 = f.sp_slot_start[base], i1 = f.sp_slot_start[base + S::N / 64];
+    const int first_pos = binfo[b].first_pos;
+    for (uint32_t i = i0 + j; i < i1; i += LPB) {
+      const uint32_t p = f.sp_sorted[i];
+      atomicAdd(&ibuf[m_addr<S>(b, (int)(p & 0xffffu) - first_pos)], (int)(int16_t)(p >> 16));
+    }
+  }
+  wave_sync();
+}
+
+template <class S>
+__device__ __forceinline__ int4 tile_q4(const float* __restrict__ buf, int b, int k) {
+  const int* ibuf = reinterpret_cast<const int*>(buf);
+  if constexpr (S::kWide) {
+    return make_int4(ibuf[m_addr<S>(b, k)], ibuf[m_addr<S>(b, k + 1)], ibuf[m_addr<S>(b, k + 2)],
+                     ibuf[m_addr<S>(b, k + 3)]);
+  } else {
+    return *reinterpret_cast<const int4*>(ibuf + m_addr<S>(b, k));
+  }
+}
+
+template <class S, bool PREFETCH, bool SPARSE>
 __device__ __forceinline__ void run_dct_class(const FrameDev& f, const WorkItem* __restrict__ items, int count, int type,
                                               float* __restrict__ buf, BlockInfo* __restrict__ binfo, int gwave,
                                               int nwaves, int lane) {
@@ -286,7 +331,7 @@ __device__ __forceinline__ void run_dct_class(const FrameDev& f, const WorkItem*
     }
     wave_sync();
     int4 qv[PREFETCH ? 3 : 1][NCH];
-    if constexpr (PREFETCH) {
+    if constexpr (PREFETCH && !SPARSE) {
 #pragma unroll
       for (int c = 0; c < 3; c++)
 #pragma unroll
@@ -300,6 +345,7 @@ __device__ __forceinline__ void run_dct_class(const FrameDev& f, const WorkItem*
     float dy[S::E];
     auto run_channel = [&](auto ch_tag) {
       constexpr int CH = decltype(ch_tag)::value;
+      if constexpr (SPARSE) sparse_stage_channel<S>(f, CH, buf, binfo, nb, lane);
 #pragma unroll
       for (int j = 0; j < NCH; j++) {
         const int fl = (j * 64 + lane) * 4;
@@ -310,7 +356,11 @@ __device__ __forceinline__ void run_dct_class(const FrameDev& f, const WorkItem*
           const BlockInfo bi = binfo[b];
           int4 qq;
           float4 tt;
-          if constexpr (PREFETCH) {
+          if constexpr (SPARSE) {
+            qq = tile_q4<S>(buf, b, k);  // converted in place: this lane alone touches (b, k..k+3)
+            if constexpr (PREFETCH) tt = tw[CH][j];
+            else tt = *reinterpret_cast<const float4*>(table + CH * tsize + k);
+          } else if constexpr (PREFETCH) {
             qq = qv[CH][j];
             tt = tw[CH][j];
           } else {
@@ -368,40 +418,49 @@ constexpr int kTileC = cmax(cmax(cmax(S32x8::kTile, S8x32::kTile), cmax(S32x16::
                             S32x32::kTile);                                       // 2624
 
 // family A: DCT 8x8 -- the dominant transform
+template <bool SPARSE>
 __global__ __launch_bounds__(kThreads) void k1_dct8(const FrameDev f, const WorkLists wl) {
   __shared__ __attribute__((aligned(16))) float s_buf[kWaves * kTileA];
   __shared__ BlockInfo s_binfo[kWaves][S8x8::NB];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  run_dct_class<S8x8, true>(f, wl.items[kClsDct8], wl.counts[kClsDct8], 0, s_buf + wave * kTileA, s_binfo[wave],
+  run_dct_class<S8x8, true, SPARSE>(f, wl.items[kClsDct8], wl.counts[kClsDct8], 0, s_buf + wave * kTileA, s_binfo[wave],
                             blockIdx.x * kWaves + wave, gridDim.x * kWaves, lane);
 }
 
 // family B: 16x8, 8x16, 16x16
-__global__ __launch_bounds__(kThreads) void k1_dct16(const FrameDev f, const WorkLists wl) {
+#ifndef JXLH_DCT16_WPE
+#define JXLH_DCT16_WPE 1
+#endif
+#ifndef JXLH_DCT32_WPE
+#define JXLH_DCT32_WPE 1
+#endif
+template <bool SPARSE>
+__global__ __launch_bounds__(kThreads, JXLH_DCT16_WPE) void k1_dct16(const FrameDev f, const WorkLists wl) {
   __shared__ __attribute__((aligned(16))) float s_buf[kWaves * kTileB];
   __shared__ BlockInfo s_binfo[kWaves][8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float* buf = s_buf + wave * kTileB;
   const int gw = blockIdx.x * kWaves + wave, nw = gridDim.x * kWaves;
-  run_dct_class<S16x8, true>(f, wl.items[kClsDct16x8], wl.counts[kClsDct16x8], 6, buf, s_binfo[wave], gw, nw, lane);
-  run_dct_class<S8x16, true>(f, wl.items[kClsDct8x16], wl.counts[kClsDct8x16], 7, buf, s_binfo[wave], gw, nw, lane);
-  run_dct_class<S16x16, true>(f, wl.items[kClsDct16x16], wl.counts[kClsDct16x16], 4, buf, s_binfo[wave], gw, nw, lane);
+  run_dct_class<S16x8, true, SPARSE>(f, wl.items[kClsDct16x8], wl.counts[kClsDct16x8], 6, buf, s_binfo[wave], gw, nw, lane);
+  run_dct_class<S8x16, true, SPARSE>(f, wl.items[kClsDct8x16], wl.counts[kClsDct8x16], 7, buf, s_binfo[wave], gw, nw, lane);
+  run_dct_class<S16x16, true, SPARSE>(f, wl.items[kClsDct16x16], wl.counts[kClsDct16x16], 4, buf, s_binfo[wave], gw, nw, lane);
 }
 
 // family C: everything with a 32-point side
-__global__ __launch_bounds__(kThreads) void k1_dct32(const FrameDev f, const WorkLists wl) {
+template <bool SPARSE>
+__global__ __launch_bounds__(kThreads, JXLH_DCT32_WPE) void k1_dct32(const FrameDev f, const WorkLists wl) {
   __shared__ __attribute__((aligned(16))) float s_buf[kWaves * kTileC];
   __shared__ BlockInfo s_binfo[kWaves][8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float* buf = s_buf + wave * kTileC;
   const int gw = blockIdx.x * kWaves + wave, nw = gridDim.x * kWaves;
-  run_dct_class<S32x8, false>(f, wl.items[kClsDct32x8], wl.counts[kClsDct32x8], 8, buf, s_binfo[wave], gw, nw, lane);
-  run_dct_class<S8x32, false>(f, wl.items[kClsDct8x32], wl.counts[kClsDct8x32], 9, buf, s_binfo[wave], gw, nw, lane);
-  run_dct_class<S32x16, false>(f, wl.items[kClsDct32x16], wl.counts[kClsDct32x16], 10, buf, s_binfo[wave], gw, nw,
+  run_dct_class<S32x8, false, SPARSE>(f, wl.items[kClsDct32x8], wl.counts[kClsDct32x8], 8, buf, s_binfo[wave], gw, nw, lane);
+  run_dct_class<S8x32, false, SPARSE>(f, wl.items[kClsDct8x32], wl.counts[kClsDct8x32], 9, buf, s_binfo[wave], gw, nw, lane);
+  run_dct_class<S32x16, false, SPARSE>(f, wl.items[kClsDct32x16], wl.counts[kClsDct32x16], 10, buf, s_binfo[wave], gw, nw,
                                lane);
-  run_dct_class<S16x32, false>(f, wl.items[kClsDct16x32], wl.counts[kClsDct16x32], 11, buf, s_binfo[wave], gw, nw,
+  run_dct_class<S16x32, false, SPARSE>(f, wl.items[kClsDct16x32], wl.counts[kClsDct16x32], 11, buf, s_binfo[wave], gw, nw,
                                lane);
-  run_dct_class<S32x32, false>(f, wl.items[kClsDct32x32], wl.counts[kClsDct32x32], 5, buf, s_binfo[wave], gw, nw,
+  run_dct_class<S32x32, false, SPARSE>(f, wl.items[kClsDct32x32], wl.counts[kClsDct32x32], 5, buf, s_binfo[wave], gw, nw,
                                lane);
 }
 
@@ -574,7 +633,7 @@ size_t vardct_worklist_bytes(const FrameDev& f) {
 }
 
 void launch_vardct_groups(hipStream_t s, const K1Streams* aux, const FrameDev& f, int group_row0, int group_row1,
-                          void* worklist_mem, int* error_flag) {
+                          void* worklist_mem, int* error_flag, int32_t* dense_coeffs) {
   const int ngroups = (group_row1 - group_row0) * f.xgroups;
   if (ngroups <= 0) return;
   // carve the work-list memory: [counts (256 B)] [class 0 items] [class 1 items] ...
@@ -602,9 +661,22 @@ void launch_vardct_groups(hipStream_t s, const K1Streams* aux, const FrameDev& f
     s32 = aux->aux[1];
     smisc = aux->aux[2];
   }
-  hipLaunchKernelGGL(k1_dct8, dim3(grid_for(nblk, kWaves * S8x8::NB * 2, 4096)), dim3(kThreads), 0, s, f, wl);
-  hipLaunchKernelGGL(k1_dct16, dim3(grid_for(nblk / 2, kWaves * 8 * 2, 2048)), dim3(kThreads), 0, s16, f, wl);
-  hipLaunchKernelGGL(k1_dct32, dim3(grid_for(nblk / 4, kWaves * 4 * 2, 2048)), dim3(kThreads), 0, s32, f, wl);
+  const bool sparse = f.sp_sorted != nullptr;
+  if (sparse && dense_coeffs) {
+    // groups that hold special / large varblocks (flagged by k1_scan) still get a dense slab
+    launch_expand_sorted(s, dense_coeffs, f.sp_sorted, f.sp_slot_start, f.group_dense, f.xgroups * f.ygroups);
+  }
+  const dim3 g8(grid_for(nblk, kWaves * S8x8::NB * 2, 4096)), g16(grid_for(nblk / 2, kWaves * 8 * 2, 2048)),
+      g32(grid_for(nblk / 4, kWaves * 4 * 2, 2048));
+  if (sparse) {
+    hipLaunchKernelGGL(k1_dct8<true>, g8, dim3(kThreads), 0, s, f, wl);
+    hipLaunchKernelGGL(k1_dct16<true>, g16, dim3(kThreads), 0, s16, f, wl);
+    hipLaunchKernelGGL(k1_dct32<true>, g32, dim3(kThreads), 0, s32, f, wl);
+  } else {
+    hipLaunchKernelGGL(k1_dct8<false>, g8, dim3(kThreads), 0, s, f, wl);
+    hipLaunchKernelGGL(k1_dct16<false>, g16, dim3(kThreads), 0, s16, f, wl);
+    hipLaunchKernelGGL(k1_dct32<false>, g32, dim3(kThreads), 0, s32, f, wl);
+  }
   hipLaunchKernelGGL(k1_special, dim3(grid_for((long)(nblk / kSpecChunk + 1) * kSpecBins, kSpecWaves, 2048)),
                      dim3(kSpecThreads), 0, smisc, f, wl);
   hipLaunchKernelGGL(k1_large, dim3(grid_for(nblk / 32, 1, 1024)), dim3(kLargeThreads), 0, smisc, f, wl);

@@ -281,7 +281,7 @@ def test_epf_fast_reciprocal_is_ieee_exact_on_weight_range():
 
 
 # ---------------------------------------------------------------- sparse coefficient transport
-def _sparse_frame_equals_dense(ctx, wl, mutate=None):
+def _sparse_frame_equals_dense(ctx, wl, mutate=None, frame_flags=0):
     """Runs the frame twice -- dense submit vs sparse submit -- and checks identical planes."""
     from jxl_rs_amd import synth
     coeffs = wl.coeffs.copy()
@@ -290,6 +290,7 @@ def _sparse_frame_equals_dense(ctx, wl, mutate=None):
     outs = []
     for sparse in (False, True):
         params = synth.apply_opts(ctx.default_params(wl.xsize, wl.ysize), wl)
+        params.flags = frame_flags
         ctx.frame_begin(params)
         ctx.set_dequant_tables(wl.tables)
         ctx.set_lf_quantized(*wl.lf_q)
@@ -324,10 +325,45 @@ def _sparse_frame_equals_dense(ctx, wl, mutate=None):
         assert bit_equal(a, b), diff_report(a, b)
 
 
-def test_sparse_submit_matches_dense_submit(ctx):
+@pytest.mark.parametrize("frame_flags", [0, 2], ids=["k1-reads-pairs", "expand-to-dense"])
+@pytest.mark.parametrize("mix,size", [("MIX_ALL", (520, 300)), ("MIX_D1", (1024, 768)), ("MIX_DCT8", (256, 256))])
+def test_sparse_submit_matches_dense_submit(ctx, mix, size, frame_flags):
+    """every group submitted as pairs: the transforms read the bucketed pairs directly (groups with
+    special / large varblocks are expanded on the side); JXLH_FRAME_EXPAND_SPARSE forces the dense slabs"""
     from jxl_rs_amd import synth
-    wl = synth.make_vardct(520, 300, mix=synth.MIX_ALL, seed=11, epf_iters=2)
-    _sparse_frame_equals_dense(ctx, wl)
+    wl = synth.make_vardct(size[0], size[1], mix=getattr(synth, mix), seed=11, epf_iters=2)
+    _sparse_frame_equals_dense(ctx, wl, frame_flags=frame_flags)
+
+
+def test_sparse_k1_rerun_and_resubmit(ctx, oracle):
+    """a frame submitted as pairs can be run again (bands) without resubmitting, and resubmitting one
+    group densely afterwards falls back to the slabs -- both still equal the oracle"""
+    from jxl_rs_amd import synth
+    wl = synth.make_vardct(520, 700, mix=synth.MIX_D1, seed=41, epf_iters=2)
+    want, _ = run_oracle_frame(oracle, wl)
+    params = synth.apply_opts(ctx.default_params(wl.xsize, wl.ysize), wl)
+    ctx.frame_begin(params)
+    ctx.set_dequant_tables(wl.tables)
+    ctx.set_lf_quantized(*wl.lf_q)
+    ctx.set_hf_meta(wl.transform_map, wl.raw_quant, wl.epf_map, wl.ytox, wl.ytob)
+    for g in range(wl.coeffs.shape[0]):
+        pairs, n, wide = synth.to_sparse(wl.coeffs[g])
+        ctx.submit_group_sparse(g, pairs, n, wide)
+    ctx.slot_wait(0)
+    for row0, row1 in ((0, 3), (1, 2), (0, 3)):
+        ctx.frame_run(row0, row1)
+        ctx.sync()
+        got = ctx.read_planes()
+        y0, y1 = row0 * 256, min(row1 * 256, wl.ysize)
+        for c in range(3):
+            assert bit_equal(got[c][y0:y1], want[c][y0:y1]), (row0, row1, c)
+    ctx.submit_group(2, wl.coeffs[2])   # same content, dense: the frame is no longer pairs-only
+    ctx.slot_wait(0)
+    ctx.frame_run()
+    ctx.sync()
+    got = ctx.read_planes()
+    for c in range(3):
+        assert bit_equal(got[c], want[c]), diff_report(got[c], want[c])
 
 
 def test_sparse_submit_wide_values_and_empty_groups(ctx):
