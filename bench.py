@@ -302,6 +302,25 @@ def main():
             for g in range(ng):
                 c.submit_group(g, pin_d_addr + g * slab, slot=g % nslots)
 
+        # the same frame resident in HBM as pairs instead of dense slabs (K1 reads the bucketed pairs):
+        # what the reconstruction kernels cost in the sparse-transport deployment, without PCIe
+        for c in ectx:
+            submit_sparse(c); c.frame_run()
+        for c in ectx:
+            c.sync()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            ectx[i % 2].frame_run()
+        for c in ectx:
+            c.sync()
+        el = time.perf_counter() - t0
+        e2e["sparse_resident_no_pcie"] = {"value": round(size * size * args.steps / 1e6 / el, 1), "unit": "MP/s",
+                                          "ms_per_frame": round(el * 1e3 / args.steps, 4), "frames": args.steps}
+        for c in ectx:   # new epoch for the PCIe legs
+            c.frame_begin(synth.apply_opts(c.default_params(size, size), wl))
+            c.set_dequant_tables(wl.tables)
+            c.set_lf_quantized(*wl.lf_q)
+            c.set_hf_meta(wl.transform_map, wl.raw_quant, wl.epf_map, wl.ytox, wl.ytob)
         for name, submit in (("sparse_pairs", submit_sparse), ("dense_i32", submit_dense)):
             frames = 12 if name == "sparse_pairs" else 6
             for i in range(2):

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Frame submitted once as sparse pairs, then re-run N times (K1 reads the bucketed pairs): for
+kernel traces of the sparse-input transforms."""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np
+import jxl_rs_amd
+from jxl_rs_amd import synth
+size = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+wl = synth.make_vardct(size, size, mix=synth.MIX_D1, seed=3, unique_groups=24, epf_iters=2)
+ng = wl.coeffs.shape[0]
+c = jxl_rs_amd.Context(0, n_slots=1)
+c.frame_begin(synth.apply_opts(c.default_params(size, size), wl))
+c.set_dequant_tables(wl.tables); c.set_lf_quantized(*wl.lf_q)
+c.set_hf_meta(wl.transform_map, wl.raw_quant, wl.epf_map, wl.ytox, wl.ytob)
+cache, runs, ns = {}, [], []
+for g in range(ng):
+    k = g % 24
+    if k not in cache:
+        cache[k] = synth.to_sparse(wl.coeffs[g])
+    runs.append(cache[k][0]); ns.append(cache[k][1])
+c.submit_groups_sparse(np.arange(ng, dtype=np.uint32), np.concatenate(runs), np.concatenate(ns), None)
+c.slot_wait(0)
+for _ in range(3):
+    c.frame_run()
+c.sync()
+t0 = time.perf_counter()
+N = 10
+for _ in range(N):
+    c.frame_run()
+c.sync()
+print("sparse-resident ms/frame:", (time.perf_counter() - t0) / N * 1e3)
