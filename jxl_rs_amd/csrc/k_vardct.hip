@@ -340,10 +340,14 @@ __device__ __forceinline__ int4 tile_q4(const float* __restrict__ buf, int b, in
   }
 }
 
+// gwave: this wave's index among the nwaves of the grid, rotated by the caller so that the classes one
+// kernel handles start on different waves (batch b of a class goes to wave (rotation + b) % nwaves);
+// without it every class would pile its batches on the low-numbered waves.  Returns the number of
+// batches of the class (the next class's rotation).
 template <class S, bool PREFETCH, bool SPARSE>
-__device__ __forceinline__ void run_dct_class(const FrameDev& f, const WorkItem* __restrict__ items, int count, int type,
-                                              float* __restrict__ buf, BlockInfo* __restrict__ binfo_base, int gwave,
-                                              int nwaves, int lane) {
+__device__ __forceinline__ int run_dct_class(const FrameDev& f, const WorkItem* __restrict__ items, int count, int type,
+                                             float* __restrict__ buf, BlockInfo* __restrict__ binfo_base, int gwave,
+                                             int nwaves, int lane) {
   constexpr int NCH = S::E / 4;  // 16-byte chunks per lane per channel
   const int q = quant_table_for_type(type);
   const float* __restrict__ table = f.tables + f.table_offset[q];
@@ -441,6 +445,13 @@ __device__ __forceinline__ void run_dct_class(const FrameDev& f, const WorkItem*
     run_channel(std::integral_constant<int, 0>{});
     run_channel(std::integral_constant<int, 2>{});
   }
+  return nbatches;
+}
+
+// wave index rotated by the batches the previous classes of the kernel occupy
+__device__ __forceinline__ int rotate_wave(int gw, int used, int nw) {
+  const int r = (gw - used % nw) % nw;
+  return r < 0 ? r + nw : r;
 }
 
 using S8x8 = Shape<8, 8>;
@@ -482,9 +493,12 @@ __global__ __launch_bounds__(kThreads, JXLH_DCT16_WPE) void k1_dct16(const Frame
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float* buf = s_buf + wave * kTileB;
   const int gw = blockIdx.x * kWaves + wave, nw = gridDim.x * kWaves;
-  run_dct_class<S16x8, true, SPARSE>(f, wl.items[kClsDct16x8], wl.counts[kClsDct16x8], 6, buf, s_binfo[wave], gw, nw, lane);
-  run_dct_class<S8x16, true, SPARSE>(f, wl.items[kClsDct8x16], wl.counts[kClsDct8x16], 7, buf, s_binfo[wave], gw, nw, lane);
-  run_dct_class<S16x16, true, SPARSE>(f, wl.items[kClsDct16x16], wl.counts[kClsDct16x16], 4, buf, s_binfo[wave], gw, nw, lane);
+  int used = run_dct_class<S16x8, true, SPARSE>(f, wl.items[kClsDct16x8], wl.counts[kClsDct16x8], 6, buf,
+                                                s_binfo[wave], gw, nw, lane);
+  used += run_dct_class<S8x16, true, SPARSE>(f, wl.items[kClsDct8x16], wl.counts[kClsDct8x16], 7, buf, s_binfo[wave],
+                                             rotate_wave(gw, used, nw), nw, lane);
+  run_dct_class<S16x16, true, SPARSE>(f, wl.items[kClsDct16x16], wl.counts[kClsDct16x16], 4, buf, s_binfo[wave],
+                                      rotate_wave(gw, used, nw), nw, lane);
 }
 
 // family C: everything with a 32-point side
@@ -495,14 +509,16 @@ __global__ __launch_bounds__(kThreads, JXLH_DCT32_WPE) void k1_dct32(const Frame
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float* buf = s_buf + wave * kTileC;
   const int gw = blockIdx.x * kWaves + wave, nw = gridDim.x * kWaves;
-  run_dct_class<S32x8, false, SPARSE>(f, wl.items[kClsDct32x8], wl.counts[kClsDct32x8], 8, buf, s_binfo[wave], gw, nw, lane);
-  run_dct_class<S8x32, false, SPARSE>(f, wl.items[kClsDct8x32], wl.counts[kClsDct8x32], 9, buf, s_binfo[wave], gw, nw, lane);
-  run_dct_class<S32x16, false, SPARSE>(f, wl.items[kClsDct32x16], wl.counts[kClsDct32x16], 10, buf, s_binfo[wave], gw, nw,
-                               lane);
-  run_dct_class<S16x32, false, SPARSE>(f, wl.items[kClsDct16x32], wl.counts[kClsDct16x32], 11, buf, s_binfo[wave], gw, nw,
-                               lane);
-  run_dct_class<S32x32, false, SPARSE>(f, wl.items[kClsDct32x32], wl.counts[kClsDct32x32], 5, buf, s_binfo[wave], gw, nw,
-                               lane);
+  int used = run_dct_class<S32x8, false, SPARSE>(f, wl.items[kClsDct32x8], wl.counts[kClsDct32x8], 8, buf,
+                                                 s_binfo[wave], gw, nw, lane);
+  used += run_dct_class<S8x32, false, SPARSE>(f, wl.items[kClsDct8x32], wl.counts[kClsDct8x32], 9, buf, s_binfo[wave],
+                                              rotate_wave(gw, used, nw), nw, lane);
+  used += run_dct_class<S32x16, false, SPARSE>(f, wl.items[kClsDct32x16], wl.counts[kClsDct32x16], 10, buf,
+                                               s_binfo[wave], rotate_wave(gw, used, nw), nw, lane);
+  used += run_dct_class<S16x32, false, SPARSE>(f, wl.items[kClsDct16x32], wl.counts[kClsDct16x32], 11, buf,
+                                               s_binfo[wave], rotate_wave(gw, used, nw), nw, lane);
+  run_dct_class<S32x32, false, SPARSE>(f, wl.items[kClsDct32x32], wl.counts[kClsDct32x32], 5, buf, s_binfo[wave],
+                                       rotate_wave(gw, used, nw), nw, lane);
 }
 
 // family D: the nine 8x8 special transform types (IDENTITY, DCT2X2, DCT4X4, DCT4X8, DCT8X4, AFV0-3).
