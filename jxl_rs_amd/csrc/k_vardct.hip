@@ -723,8 +723,17 @@ void launch_vardct_groups(hipStream_t s, const K1Streams* aux, const FrameDev& f
     // groups that hold special / large varblocks (flagged by k1_scan) still get a dense slab
     launch_expand_sorted(s, dense_coeffs, f.sp_sorted, f.sp_slot_start, f.group_dense, f.xgroups * f.ygroups);
   }
-  const dim3 g8(grid_for(nblk, kWaves * S8x8::NB * 2, 4096)), g16(grid_for(nblk / 2, kWaves * 8 * 2, 2048)),
-      g32(grid_for(nblk / 4, kWaves * 4 * 2, 2048));
+#ifndef JXLH_DCT8_GRID
+#define JXLH_DCT8_GRID 4096
+#endif
+#ifndef JXLH_DCT16_GRID
+#define JXLH_DCT16_GRID 2048
+#endif
+#ifndef JXLH_DCT32_GRID
+#define JXLH_DCT32_GRID 2048
+#endif
+  const dim3 g8(grid_for(nblk, kWaves * S8x8::NB * 2, JXLH_DCT8_GRID)), g16(grid_for(nblk / 2, kWaves * 8 * 2, JXLH_DCT16_GRID)),
+      g32(grid_for(nblk / 4, kWaves * 4 * 2, JXLH_DCT32_GRID));
   if (sparse) {
     hipLaunchKernelGGL(k1_dct8<true>, g8, dim3(kThreads), 0, s, f, wl);
     hipLaunchKernelGGL(k1_dct16<true>, g16, dim3(kThreads), 0, s16, f, wl);
