@@ -645,13 +645,17 @@ __global__ __launch_bounds__(kSpecThreads, 2) void k1_special(const FrameDev f, 
   }
 }
 
-// family E: DCT64X64 .. DCT256X256, one varblock per workgroup at a time
+// family E: DCT64X64 .. DCT256X256.  Work unit = one CHANNEL of one varblock (the channels only meet
+// in the chroma-from-luma FMA, whose Y term the X / B dequantisers recompute from the Y coefficients):
+// a 256x256 varblock keeps a workgroup busy for ~50 us per channel, so the finer unit triples the
+// parallelism and cuts the kernel's tail.
 __global__ __launch_bounds__(kLargeThreads) void k1_large(const FrameDev f, const WorkLists wl) {
   __shared__ float s_lds[2 * (kLargeSlab + 256) + 1024];
   const int count = wl.counts[kClsLarge];
   const int tid = threadIdx.x;
   const float b0 = f.quant_biases[0], b1 = f.quant_biases[1], b2 = f.quant_biases[2], b3 = f.quant_biases[3];
-  for (int e = blockIdx.x; e < count; e += gridDim.x) {
+  for (int u = blockIdx.x; u < count * 3; u += gridDim.x) {
+    const int e = u / 3, ch = u % 3;
     const WorkItem it = wl.items[kClsLarge][e];
     BlockInfo bi;
     decode_item(f, it, &bi);
@@ -666,16 +670,20 @@ __global__ __launch_bounds__(kLargeThreads) void k1_large(const FrameDev f, cons
     const float x_cc = bi.x_cc, b_cc = bi.b_cc;
     auto deq_y = [&](int k) { return adjust_quant_bias(qy[k], b1, b3) * (table[tsize + k] * sdy); };
     const PixLayout lay = pix_layout(f);
-    large_varblock_channel(type, deq_y, f.lf[1] + bi.lf_off, f.xblocks, f.planes[1] + bi.px_off, lay, s_lds, tid);
-    large_varblock_channel(
-        type, [&](int k) { return __builtin_fmaf(x_cc, deq_y(k), adjust_quant_bias(qx[k], b0, b3) * (table[k] * sdx)); },
-        f.lf[0] + bi.lf_off, f.xblocks, f.planes[0] + bi.px_off, lay, s_lds, tid);
-    large_varblock_channel(
-        type,
-        [&](int k) {
-          return __builtin_fmaf(b_cc, deq_y(k), adjust_quant_bias(qb[k], b2, b3) * (table[2 * tsize + k] * sdb));
-        },
-        f.lf[2] + bi.lf_off, f.xblocks, f.planes[2] + bi.px_off, lay, s_lds, tid);
+    if (ch == 1) {
+      large_varblock_channel(type, deq_y, f.lf[1] + bi.lf_off, f.xblocks, f.planes[1] + bi.px_off, lay, s_lds, tid);
+    } else if (ch == 0) {
+      large_varblock_channel(
+          type, [&](int k) { return __builtin_fmaf(x_cc, deq_y(k), adjust_quant_bias(qx[k], b0, b3) * (table[k] * sdx)); },
+          f.lf[0] + bi.lf_off, f.xblocks, f.planes[0] + bi.px_off, lay, s_lds, tid);
+    } else {
+      large_varblock_channel(
+          type,
+          [&](int k) {
+            return __builtin_fmaf(b_cc, deq_y(k), adjust_quant_bias(qb[k], b2, b3) * (table[2 * tsize + k] * sdb));
+          },
+          f.lf[2] + bi.lf_off, f.xblocks, f.planes[2] + bi.px_off, lay, s_lds, tid);
+    }
   }
 }
 
@@ -745,7 +753,7 @@ void launch_vardct_groups(hipStream_t s, const K1Streams* aux, const FrameDev& f
   }
   hipLaunchKernelGGL(k1_special, dim3(grid_for((long)(nblk / kSpecChunk + 1) * kSpecBins, kSpecWaves, 2048)),
                      dim3(kSpecThreads), 0, smisc, f, wl);
-  hipLaunchKernelGGL(k1_large, dim3(grid_for(nblk / 32, 1, 1024)), dim3(kLargeThreads), 0, smisc, f, wl);
+  hipLaunchKernelGGL(k1_large, dim3(grid_for(3L * (nblk / 32), 1, 2048)), dim3(kLargeThreads), 0, smisc, f, wl);
   if (aux) {  // join
     for (int i = 0; i < 3; i++) {
       (void)hipEventRecord(aux->ev[1 + i], aux->aux[i]);
