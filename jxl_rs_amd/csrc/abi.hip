@@ -48,8 +48,6 @@ struct jxlh_ctx {
   hipStream_t stream = nullptr;
   std::vector<Slot> slots;
   hipEvent_t t0 = nullptr, t1 = nullptr;
-  K1Streams k1s{};
-  bool k1s_ok = false;
   std::string last_error;
   // frame state
   bool in_frame = false;
@@ -267,10 +265,6 @@ jxlh_status jxlh_ctx_create(int32_t device_ordinal, int32_t n_slots, jxlh_ctx** 
     delete ctx;
     return JXLH_ERR_DEVICE;
   }
-  // The forked K1 class kernels (K1Streams) measured no gain and every extra stream competes for
-  // the few hardware queues the runtime multiplexes streams onto (false dependencies between a
-  // context's uploads and another context's kernels): the aux streams are not created.
-  ctx->k1s_ok = false;
   ctx->slots.resize(n_slots);
   for (auto& s : ctx->slots) {
     if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess ||
@@ -320,10 +314,6 @@ void jxlh_ctx_destroy(jxlh_ctx* ctx) {
   release(ctx->worklist);
   for (auto& b : ctx->hook_f) release(b);
   for (auto& b : ctx->hook_i) release(b);
-  for (int i = 0; i < 3; i++)
-    if (ctx->k1s.aux[i]) (void)hipStreamDestroy(ctx->k1s.aux[i]);
-  for (int i = 0; i < 4; i++)
-    if (ctx->k1s.ev[i]) (void)hipEventDestroy(ctx->k1s.ev[i]);
   if (ctx->t0) (void)hipEventDestroy(ctx->t0);
   if (ctx->t1) (void)hipEventDestroy(ctx->t1);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -761,12 +751,11 @@ jxlh_status jxlh_frame_run(jxlh_ctx* ctx, uint32_t group_row0, uint32_t group_ro
   f.tiled = will_fuse ? 1 : 0;
   {
     ScopedKernelTimer t(ctx, "k1_vardct");
-    // forked class kernels measured no gain on the d1 mix (event overhead ~ tail savings): run in order
     f.sp_sorted = sparse_k1 ? ctx->sp_sorted.p : nullptr;
     f.sp_slot_start = sparse_k1 ? ctx->sp_slot_start.p : nullptr;
     f.group_dense = sparse_k1 ? ctx->group_dense.p : nullptr;
     if (sparse_k1) HIPCHK(ctx, hipMemsetAsync(ctx->group_dense.p, 0, ctx->ngroups, ctx->stream));
-    launch_vardct_groups(ctx->stream, nullptr, f, gr0, gr1, ctx->worklist.p, ctx->error_flag.p,
+    launch_vardct_groups(ctx->stream, f, gr0, gr1, ctx->worklist.p, ctx->error_flag.p,
                          sparse_k1 ? ctx->coeffs.p : nullptr);
   }
   // ---- stage list of frame/render.rs:569-622

@@ -128,14 +128,8 @@ void launch_sigma_map(hipStream_t s, const FrameDev& f, float epf_quant_mul, con
 // K1: work-list scan + per-class kernels over group rows [group_row0, group_row1).
 // worklist_mem: device scratch of vardct_worklist_bytes(f) bytes.
 size_t vardct_worklist_bytes(const FrameDev& f);
-// The class kernels are independent of each other: when `aux` is given (3 extra streams + 4 events),
-// they run concurrently and rejoin `s` before returning, so their tails overlap.
-struct K1Streams {
-  hipStream_t aux[3];
-  hipEvent_t ev[4];
-};
 // dense_coeffs: writable alias of f.coeffs, used in sparse mode to expand the groups k1_scan flags
-void launch_vardct_groups(hipStream_t s, const K1Streams* aux, const FrameDev& f, int group_row0, int group_row1,
+void launch_vardct_groups(hipStream_t s, const FrameDev& f, int group_row0, int group_row1,
                           void* worklist_mem, int* error_flag, int32_t* dense_coeffs);
 void launch_gaborish(hipStream_t s, const float* in, float* out, int w, int h, size_t stride, float k0, float k1,
                      float k2, int y0, int y1);

@@ -480,14 +480,8 @@ __global__ __launch_bounds__(kThreads) void k1_dct8(const FrameDev f, const Work
 }
 
 // family B: 16x8, 8x16, 16x16
-#ifndef JXLH_DCT16_WPE
-#define JXLH_DCT16_WPE 1
-#endif
-#ifndef JXLH_DCT32_WPE
-#define JXLH_DCT32_WPE 1
-#endif
 template <bool SPARSE>
-__global__ __launch_bounds__(kThreads, JXLH_DCT16_WPE) void k1_dct16(const FrameDev f, const WorkLists wl) {
+__global__ __launch_bounds__(kThreads) void k1_dct16(const FrameDev f, const WorkLists wl) {
   __shared__ __attribute__((aligned(16))) float s_buf[kWaves * kTileB];
   __shared__ BlockInfo s_binfo[kWaves][8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -503,7 +497,7 @@ __global__ __launch_bounds__(kThreads, JXLH_DCT16_WPE) void k1_dct16(const Frame
 
 // family C: everything with a 32-point side
 template <bool SPARSE>
-__global__ __launch_bounds__(kThreads, JXLH_DCT32_WPE) void k1_dct32(const FrameDev f, const WorkLists wl) {
+__global__ __launch_bounds__(kThreads) void k1_dct32(const FrameDev f, const WorkLists wl) {
   __shared__ __attribute__((aligned(16))) float s_buf[kWaves * kTileC];
   __shared__ BlockInfo s_binfo[kWaves][8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -697,7 +691,7 @@ size_t vardct_worklist_bytes(const FrameDev& f) {
   return items * sizeof(WorkItem) + 256;
 }
 
-void launch_vardct_groups(hipStream_t s, const K1Streams* aux, const FrameDev& f, int group_row0, int group_row1,
+void launch_vardct_groups(hipStream_t s, const FrameDev& f, int group_row0, int group_row1,
                           void* worklist_mem, int* error_flag, int32_t* dense_coeffs) {
   const int ngroups = (group_row1 - group_row0) * f.xgroups;
   if (ngroups <= 0) return;
@@ -718,48 +712,28 @@ void launch_vardct_groups(hipStream_t s, const K1Streams* aux, const FrameDev& f
     long g = (work_items + items_per_wg - 1) / items_per_wg;
     return (int)(g < 1 ? 1 : (g > cap ? cap : g));
   };
-  hipStream_t s16 = s, s32 = s, smisc = s;
-  if (aux) {  // fork
-    (void)hipEventRecord(aux->ev[0], s);
-    for (int i = 0; i < 3; i++) (void)hipStreamWaitEvent(aux->aux[i], aux->ev[0], 0);
-    s16 = aux->aux[0];
-    s32 = aux->aux[1];
-    smisc = aux->aux[2];
-  }
+  // one stream: forking the class kernels onto side streams measured no gain on the d1 mix (event
+  // overhead ~ tail savings) and extra streams compete for the runtime's few hardware queues
   const bool sparse = f.sp_sorted != nullptr;
   if (sparse && dense_coeffs) {
     // groups that hold special / large varblocks (flagged by k1_scan) still get a dense slab
     launch_expand_sorted(s, dense_coeffs, f.sp_sorted, f.sp_slot_start, f.group_dense, f.xgroups * f.ygroups);
   }
-#ifndef JXLH_DCT8_GRID
-#define JXLH_DCT8_GRID 4096
-#endif
-#ifndef JXLH_DCT16_GRID
-#define JXLH_DCT16_GRID 2048
-#endif
-#ifndef JXLH_DCT32_GRID
-#define JXLH_DCT32_GRID 2048
-#endif
-  const dim3 g8(grid_for(nblk, kWaves * S8x8::NB * 2, JXLH_DCT8_GRID)), g16(grid_for(nblk / 2, kWaves * 8 * 2, JXLH_DCT16_GRID)),
-      g32(grid_for(nblk / 4, kWaves * 4 * 2, JXLH_DCT32_GRID));
+  // caps measured flat between 768 and 8192 workgroups at 8K (tools/bench_variants.sh)
+  const dim3 g8(grid_for(nblk, kWaves * S8x8::NB * 2, 4096)), g16(grid_for(nblk / 2, kWaves * 8 * 2, 2048)),
+      g32(grid_for(nblk / 4, kWaves * 4 * 2, 2048));
   if (sparse) {
     hipLaunchKernelGGL(k1_dct8<true>, g8, dim3(kThreads), 0, s, f, wl);
-    hipLaunchKernelGGL(k1_dct16<true>, g16, dim3(kThreads), 0, s16, f, wl);
-    hipLaunchKernelGGL(k1_dct32<true>, g32, dim3(kThreads), 0, s32, f, wl);
+    hipLaunchKernelGGL(k1_dct16<true>, g16, dim3(kThreads), 0, s, f, wl);
+    hipLaunchKernelGGL(k1_dct32<true>, g32, dim3(kThreads), 0, s, f, wl);
   } else {
     hipLaunchKernelGGL(k1_dct8<false>, g8, dim3(kThreads), 0, s, f, wl);
-    hipLaunchKernelGGL(k1_dct16<false>, g16, dim3(kThreads), 0, s16, f, wl);
-    hipLaunchKernelGGL(k1_dct32<false>, g32, dim3(kThreads), 0, s32, f, wl);
+    hipLaunchKernelGGL(k1_dct16<false>, g16, dim3(kThreads), 0, s, f, wl);
+    hipLaunchKernelGGL(k1_dct32<false>, g32, dim3(kThreads), 0, s, f, wl);
   }
   hipLaunchKernelGGL(k1_special, dim3(grid_for((long)(nblk / kSpecChunk + 1) * kSpecBins, kSpecWaves, 2048)),
-                     dim3(kSpecThreads), 0, smisc, f, wl);
-  hipLaunchKernelGGL(k1_large, dim3(grid_for(3L * (nblk / 32), 1, 2048)), dim3(kLargeThreads), 0, smisc, f, wl);
-  if (aux) {  // join
-    for (int i = 0; i < 3; i++) {
-      (void)hipEventRecord(aux->ev[1 + i], aux->aux[i]);
-      (void)hipStreamWaitEvent(s, aux->ev[1 + i], 0);
-    }
-  }
+                     dim3(kSpecThreads), 0, s, f, wl);
+  hipLaunchKernelGGL(k1_large, dim3(grid_for(3L * (nblk / 32), 1, 2048)), dim3(kLargeThreads), 0, s, f, wl);
 }
 
 }  // namespace jxlh
