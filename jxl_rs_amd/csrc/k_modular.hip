@@ -119,9 +119,23 @@ __device__ __forceinline__ int32_t palette_value(const int32_t* __restrict__ pal
   return palette[(size_t)c * pstride + i];
 }
 
-__global__ void k5_palette(const int32_t* __restrict__ index, size_t n, const int32_t* __restrict__ palette,
-                           int num_colors, size_t pstride, int nb_channels, int bit_depth,
-                           int32_t* __restrict__ out) {
+// LDS_PAL: the explicit palette (num_colors x nb_channels entries, <= kPalLdsEntries) is staged in LDS
+// once per workgroup (persistent grid), so the per-pixel gathers never leave the CU.
+constexpr int kPalLdsEntries = 12288;  // 48 KB
+template <bool LDS_PAL>
+__global__ __launch_bounds__(256) void k5_palette(const int32_t* __restrict__ index, size_t n,
+                                                  const int32_t* __restrict__ palette_g, int num_colors, size_t pstride_g,
+                                                  int nb_channels, int bit_depth, int32_t* __restrict__ out) {
+  __shared__ int32_t s_pal[LDS_PAL ? kPalLdsEntries : 1];
+  const int32_t* palette = palette_g;
+  size_t pstride = pstride_g;
+  if constexpr (LDS_PAL) {
+    for (int i = threadIdx.x; i < num_colors * nb_channels; i += 256)
+      s_pal[i] = palette_g[(size_t)(i / num_colors) * pstride_g + (i % num_colors)];
+    __syncthreads();
+    palette = s_pal;
+    pstride = (size_t)num_colors;
+  }
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   const size_t nvec = n / 4;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
@@ -306,9 +320,16 @@ void launch_rct(hipStream_t s, int32_t* p0, int32_t* p1, int32_t* p2, size_t n, 
 void launch_palette(hipStream_t s, const int32_t* index, size_t n, const int32_t* palette, int num_colors,
                     size_t palette_stride, int nb_channels, int bit_depth, int32_t* out) {
   if (n == 0) return;
-  const unsigned grid = (unsigned)min((size_t)8192, (n + 255) / 256);
-  hipLaunchKernelGGL(k5_palette, dim3(grid), dim3(256), 0, s, index, n, palette, num_colors, palette_stride,
-                     nb_channels, bit_depth, out);
+  if (num_colors > 0 && (size_t)num_colors * nb_channels <= (size_t)kPalLdsEntries) {
+    // persistent grid (the palette is staged once per workgroup): 3 workgroups of 48 KB LDS per CU
+    const unsigned grid = (unsigned)min((size_t)768, (n / 4 + 255) / 256 + 1);
+    hipLaunchKernelGGL(k5_palette<true>, dim3(grid), dim3(256), 0, s, index, n, palette, num_colors, palette_stride,
+                       nb_channels, bit_depth, out);
+  } else {
+    const unsigned grid = (unsigned)min((size_t)8192, (n + 255) / 256);
+    hipLaunchKernelGGL(k5_palette<false>, dim3(grid), dim3(256), 0, s, index, n, palette, num_colors, palette_stride,
+                       nb_channels, bit_depth, out);
+  }
 }
 
 void launch_unsqueeze(hipStream_t s, int horizontal, int n_planes, const int32_t* const avg[], size_t avg_stride,

@@ -230,6 +230,15 @@ def test_palette_bit_exact(ctx, oracle, bit_depth):
     assert np.array_equal(got1[0], want[0])
 
 
+@pytest.mark.parametrize("ncol", [1, 4096, 5000])
+def test_palette_sizes_lds_and_global_paths(ctx, oracle, ncol):
+    """up to 12288 palette entries are staged in LDS; larger palettes are gathered from global memory"""
+    rng = np.random.default_rng(ncol)
+    pal = rng.integers(0, 256, size=(3, ncol)).astype(np.int32)
+    idx = rng.integers(-20, ncol + 64 + 130, size=(129, 515)).astype(np.int32)
+    assert np.array_equal(ctx.palette(idx, pal, ncol, 3, 8), oracle.palette(idx, pal, ncol, 3, 8))
+
+
 @pytest.mark.parametrize("shape", [(1, 1), (1, 2), (2, 1), (5, 9), (64, 64), (67, 129), (300, 255)])
 def test_unsqueeze_bit_exact_and_round_trip(ctx, oracle, shape):
     h, w = shape
