@@ -161,22 +161,28 @@ __global__ __launch_bounds__(256) void k5_palette(const int32_t* __restrict__ in
   }
 }
 
-// smooth_tendency_impl (squeeze.rs:107-141), a = prev, b = avg, c = next_avg
+// smooth_tendency_impl (squeeze.rs:107-141), a = prev, b = avg, c = next_avg.
+// The reference clamps with two parity tricks:
+//     if (x > 2|a-b| + (x & 1)) x = 2|a-b| + 1;      if (x + (x & 1) > 2|b-c|) x = 2|b-c|;
+// Both bounds are even, so whatever the parity of x they reduce to x = min(x, 2|a-b| + 1) and
+// x = min(x, 2|b-c|) (x even: x > t <=> x >= t + 2; x odd: x > t + 1 <=> x >= t + 3; x == t + 1 is a
+// fixed point) -- also for wrapped operands, since t + 1 and x + 1 cannot overflow (t is even, x is a
+// quarter of a 31-bit sum).  That turns eight dependent compare/select operations of the serial chain
+// into one v_min3_i32; the sign is applied as (x ^ s) - s.
 __device__ __forceinline__ int32_t smooth_tendency(int32_t a, int32_t b, int32_t c) {
   const int32_t a_b = wsub(a, b), b_c = wsub(b, c), a_c = wsub(a, c);
-  const int32_t abs_a_b = a_b < 0 ? wsub(0, a_b) : a_b;
-  const int32_t abs_b_c = b_c < 0 ? wsub(0, b_c) : b_c;
-  const int32_t abs_a_c = a_c < 0 ? wsub(0, a_c) : a_c;
-  const bool non_monotonic = (a_b ^ b_c) < 0;
-  const bool skip = (b_c != 0) && (a_b != 0) && non_monotonic;
+  const int32_t abs_a_b = max(a_b, wsub(0, a_b));
+  const int32_t abs_b_c = max(b_c, wsub(0, b_c));
+  const int32_t abs_a_c = max(a_c, wsub(0, a_c));
+  const bool skip = (b_c != 0) && (a_b != 0) && ((a_b ^ b_c) < 0);
   const int32_t abs_a_b_3 = __mulhi(abs_a_b, 0x55555556);
   int32_t x = wadd(wadd(2, abs_a_c), abs_a_b_3) >> 2;
-  const int32_t two_ab = (int32_t)((uint32_t)abs_a_b << 1);
-  if (x > wadd(two_ab, x & 1)) x = wadd(two_ab, 1);
-  const int32_t two_bc = (int32_t)((uint32_t)abs_b_c << 1);
-  if (wadd(x, x & 1) > two_bc) x = two_bc;
+  const int32_t t1 = (int32_t)(((uint32_t)abs_a_b << 1) + 1u);
+  const int32_t u = (int32_t)((uint32_t)abs_b_c << 1);
+  x = min(min(x, t1), u);
   if (skip) x = 0;
-  return a_c < 0 ? wsub(0, x) : x;
+  const int32_t sgn = a_c >> 31;
+  return wsub(x ^ sgn, sgn);
 }
 
 // unsqueeze_impl (squeeze.rs:171-185)

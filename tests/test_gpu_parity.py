@@ -258,6 +258,22 @@ def test_unsqueeze_bit_exact_and_round_trip(ctx, oracle, shape):
     assert np.array_equal(ctx.unsqueeze(True, avg, res, w, h), oracle.unsqueeze_h(avg, res, w))
 
 
+@pytest.mark.parametrize("scale", [2**15, 2**24, 2**28])
+def test_unsqueeze_large_magnitudes(ctx, oracle, scale):
+    """the device folds the reference's two parity clamps into min() operations (k_modular.hip); checked here
+    on large-magnitude data inside the range where the reference's i64 scalar definition and its wrapping
+    i32 SIMD form agree (tests/test_oracle_pin.py proves the min() identity on the full i32 range)"""
+    rng = np.random.default_rng(scale % 1000)
+    h, w = 37, 130
+    avg = rng.integers(-scale, scale, size=(h, (w + 1) // 2), dtype=np.int64).astype(np.int32)
+    res = rng.integers(-scale, scale, size=(h, w // 2), dtype=np.int64).astype(np.int32)
+    avg[2::5, 1:] = avg[2::5, :-1]   # equal neighbours: zero differences
+    assert np.array_equal(ctx.unsqueeze(True, avg, res, w, h), oracle.unsqueeze_h(avg, res, w))
+    a2 = rng.integers(-scale, scale, size=((h + 1) // 2, w), dtype=np.int64).astype(np.int32)
+    r2 = rng.integers(-scale, scale, size=(h // 2, w), dtype=np.int64).astype(np.int32)
+    assert np.array_equal(ctx.unsqueeze(False, a2, r2, w, h), oracle.unsqueeze_v(a2, r2, h))
+
+
 def test_modular_chain_config4_style(ctx, oracle):
     """Default squeeze chain + YCoCg RCT + palette on a mid-size image, bit-exact end to end."""
     from jxl_rs_amd import synth

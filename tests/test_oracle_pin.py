@@ -184,3 +184,35 @@ def test_u8_conversion_dither_properties(oracle_any):
     # a mid-grey half-step flips with the dither: both neighbours occur over a 32x32 period
     vals = {oracle_any.f32_to_u8(100.5 / 255.0, x, y, 0) for x in range(32) for y in range(32)}
     assert vals == {100, 101}
+
+
+def test_tendency_clamps_equal_min_form_on_full_i32_range(oracle_any):
+    """The device kernel (k_modular.hip) computes the reference's SIMD tendency (squeeze.rs:107-141) with its
+    two parity clamps folded into x = min(x, 2|a-b|+1, 2|b-c|) and the sign applied as (x ^ s) - s.  Proved
+    here against the oracle's line-by-line restatement, including wrapping extremes."""
+    L = oracle_any.lib
+    rng = np.random.default_rng(9)
+
+    def wrap(x):
+        return (x + 2**31) % 2**32 - 2**31
+
+    def min_form(a, b, c):
+        a_b, b_c, a_c = wrap(a - b), wrap(b - c), wrap(a - c)
+        ab = wrap(-a_b) if a_b < 0 else a_b
+        bc = wrap(-b_c) if b_c < 0 else b_c
+        ac = wrap(-a_c) if a_c < 0 else a_c
+        skip = b_c != 0 and a_b != 0 and (a_b ^ b_c) < 0
+        x = wrap(wrap(2 + ac) + ((ab * 0x55555556) >> 32)) >> 2
+        x = min(x, wrap((ab << 1) + 1), wrap(bc << 1))
+        if skip:
+            x = 0
+        s = a_c >> 31
+        return wrap((x ^ s) - s)
+
+    special = [-2**31, -2**31 + 1, -2**30, -1, 0, 1, 2, 3, 2**30, 2**31 - 2, 2**31 - 1]
+    triples = [(a, b, c) for a in special for b in special for c in special]
+    for scale in (2**8, 2**20, 2**31 - 1):
+        arr = rng.integers(-scale, scale, size=(3000, 3), dtype=np.int64)
+        triples += [tuple(int(v) for v in t) for t in arr]
+    for a, b, c in triples:
+        assert min_form(a, b, c) == L.jxlo_smooth_tendency_i32(a, b, c), (a, b, c)
