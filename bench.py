@@ -232,7 +232,7 @@ def main():
 
     # ---- CPU baseline: the oracle (C port of the reference path) on all host cores, bounded crop
     cpu = None
-    if rank == 0 and not args.no_cpu:
+    if rank == 0 and n_gpus == 1 and not args.no_cpu:  # reported baseline: single-GPU runs only
         from oracle.oracle import Oracle
         o = Oracle(fused=True)
         cs = min(args.cpu_sample, size)
@@ -261,7 +261,7 @@ def main():
     # beside `value`, never as `value`.  Two transports: the reference's dense i32 slabs
     # (jxlh_submit_group) and (position, value) pairs (jxlh_submit_groups_sparse).
     e2e = None
-    if rank == 0 and not args.no_e2e and torch.cuda.is_available():
+    if rank == 0 and n_gpus == 1 and not args.no_e2e and torch.cuda.is_available():
         e2e = {}
         ng = wl.coeffs.shape[0]
         nslots = 2
