@@ -92,6 +92,8 @@ def main():
         wl.epf_map[:] = 0
     ctxs = []
     h2d_s = 0.0
+    if args.strong and world > 1:
+        args.inflight = 1  # the band gather reads the planes of the context that just ran
     for _ in range(max(1, args.inflight)):
         c = jxl_rs_amd.Context(local_rank, n_slots=1)
         params = synth.apply_opts(c.default_params(size, size), wl)

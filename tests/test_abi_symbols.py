@@ -70,3 +70,30 @@ def test_product_package_does_not_import_the_oracle():
                 txt = open(os.path.join(dirpath, fn), errors="ignore").read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "libjxlo" not in txt, fn
                 assert "jxlo_" not in txt, fn
+
+
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """include/jxl_hip.h is a C ABI: it compiles as strict C99 and a C program links against
+    libjxl_hip.so using nothing but the header (no GPU needed for the calls made here)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no C compiler")
+    src = tmp_path / "abi_check.c"
+    src.write_text(
+        '#include <stdio.h>\n#include "jxl_hip.h"\n'
+        "int main(void) {\n"
+        "  jxlh_frame_params p;\n"
+        "  if (jxlh_default_frame_params(&p, 300, 200) != JXLH_OK) return 1;\n"
+        "  if (p.xsize != 300 || p.ysize != 200 || p.epf_iters != 2) return 2;\n"
+        "  if (jxlh_covered_blocks_x(5) != 4 || jxlh_covered_blocks_y(26) != 16) return 3;\n"
+        "  if (jxlh_frame_run(NULL, 0, 1) != JXLH_ERR_INVALID_ARGUMENT) return 4;\n"
+        "  if (sizeof(jxlh_coeff16) != 4 || sizeof(jxlh_coeff32) != 8 || sizeof(jxlh_xyb_params) != 64) return 5;\n"
+        '  printf("abi %u\\n", jxlh_abi_version());\n'
+        "  return 0;\n}\n")
+    exe = tmp_path / "abi_check"
+    libdir = os.path.join(ROOT, "jxl_rs_amd")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    str(src), "-o", str(exe), "-L", libdir, "-ljxl_hip", "-Wl,-rpath," + libdir], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    assert out.startswith("abi ")
