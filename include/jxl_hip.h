@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define JXLH_ABI_VERSION 1
+#define JXLH_ABI_VERSION 2
 #define JXLH_NUM_TRANSFORMS 27   /* HfTransformType::CARDINALITY, transform_map.rs:59-61 */
 #define JXLH_NUM_QUANT_TABLES 17 /* NUM_QUANT_TABLES, quantizer.rs:11 */
 #define JXLH_GROUP_DIM 256       /* GROUP_DIM, jxl/src/lib.rs:24-26 */
@@ -67,6 +67,12 @@ typedef struct {
  *   color_factor .. ytob_lf  ColorCorrelationParams (frame/color_correlation_map.rs:21-94)
  *   gab .. epf_border_sad_mul RestorationFilter (headers/frame_header.rs:146-233)
  *   do_lf_smoothing ........ FrameHeader::should_do_adaptive_lf_smoothing (:496-500)
+ *   hshift, vshift ......... per-channel chroma subsampling shifts of the frame (frame/group.rs:443-452,
+ *                           X, Y, B order).  Only 4:4:4 (all zero) runs on the device: subsampled frames are
+ *                           JPEG recompressions, limited to 8x8 transforms (frame/modular/mod.rs:1058-1060),
+ *                           and jxlh_frame_begin answers JXLH_ERR_UNSUPPORTED so the caller keeps its CPU path
+ *   epf_sigma_for_modular .. RestorationFilter field used when EPF runs on a Modular frame
+ *                           (features/epf.rs:81-84); carried for completeness, VarDCT frames ignore it
  */
 typedef struct {
   uint32_t abi_version; /* JXLH_ABI_VERSION */
@@ -86,6 +92,8 @@ typedef struct {
   float epf_quant_mul, epf_pass0_sigma_scale, epf_pass2_sigma_scale, epf_border_sad_mul;
   uint32_t do_lf_smoothing;
   uint32_t flags; /* JXLH_FRAME_* */
+  uint32_t hshift[3], vshift[3];
+  float epf_sigma_for_modular;
 } jxlh_frame_params;
 
 enum {

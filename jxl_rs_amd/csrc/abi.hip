@@ -247,6 +247,7 @@ jxlh_status jxlh_default_frame_params(jxlh_frame_params* p, uint32_t xsize, uint
   p->epf_pass2_sigma_scale = 6.5f;
   p->epf_border_sad_mul = 2.0f / 3.0f;
   p->do_lf_smoothing = 1;
+  p->epf_sigma_for_modular = 1.0f;  // RestorationFilter default (headers/frame_header.rs:229-231)
   return JXLH_OK;
 }
 
@@ -337,6 +338,8 @@ jxlh_status jxlh_frame_begin(jxlh_ctx* ctx, const jxlh_frame_params* p) {
   if (p->xsize == 0 || p->ysize == 0 || p->xsize > (1u << 20) || p->ysize > (1u << 20) || p->global_scale == 0 ||
       p->quant_lf == 0 || p->color_factor == 0 || p->epf_iters > 3)
     return JXLH_ERR_INVALID_ARGUMENT;
+  for (int c = 0; c < 3; c++)  // 4:2:0 / 4:2:2 JPEG recompressions stay on the caller's CPU path
+    if (p->hshift[c] != 0 || p->vshift[c] != 0) return JXLH_ERR_UNSUPPORTED;
   HIPCHK(ctx, hipSetDevice(ctx->device));
   ctx->params = *p;
   FrameDev& f = ctx->fd;

@@ -63,6 +63,8 @@ class FrameParams(C.Structure):
         ("epf_pass2_sigma_scale", C.c_float), ("epf_border_sad_mul", C.c_float),
         ("do_lf_smoothing", C.c_uint32),
         ("flags", C.c_uint32),
+        ("hshift", C.c_uint32 * 3), ("vshift", C.c_uint32 * 3),
+        ("epf_sigma_for_modular", C.c_float),
     ]
 
 

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
 def test_abi_version_and_tables():
     from jxl_rs_amd import lib, synth
     L = lib.load()
-    assert L.jxlh_abi_version() == 1
+    assert L.jxlh_abi_version() == 2
     for t in range(27):
         assert L.jxlh_covered_blocks_x(t) == synth.COVERED_X[t]
         assert L.jxlh_covered_blocks_y(t) == synth.COVERED_Y[t]
@@ -97,3 +97,17 @@ def test_header_is_plain_c_and_links_from_c(tmp_path):
                     str(src), "-o", str(exe), "-L", libdir, "-ljxl_hip", "-Wl,-rpath," + libdir], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
     assert out.startswith("abi ")
+
+
+def test_chroma_subsampled_frames_are_declined():
+    """4:2:0 / 4:2:2 frames (JPEG recompression) are outside the device path: frame_begin must say so
+    (the caller keeps the CPU pipeline) rather than mis-decode.  No GPU work is reached before the check."""
+    from jxl_rs_amd import lib
+    L = lib.load()
+    p = lib.FrameParams()
+    L.jxlh_default_frame_params(C.byref(p), 64, 64)
+    assert list(p.hshift) == [0, 0, 0] and list(p.vshift) == [0, 0, 0]
+    p.hshift[0] = 1
+    p.vshift[2] = 1
+    # (the JXLH_ERR_UNSUPPORTED answer itself needs a context: tests/test_gpu_parity.py)
+    assert L.jxlh_frame_begin(None, C.byref(p)) == lib.ERR_INVALID_ARGUMENT

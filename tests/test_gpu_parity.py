@@ -186,6 +186,17 @@ def test_invalid_transform_id_is_reported(ctx):
     assert e.value.status == lib.ERR_INVALID_TRANSFORM
 
 
+def test_chroma_subsampled_frame_is_unsupported(ctx):
+    """4:2:0 / 4:2:2 (JPEG recompression) frames keep the reference's CPU path: JXLH_ERR_UNSUPPORTED"""
+    from jxl_rs_amd import lib, JxlHipError
+    p = ctx.default_params(64, 64)
+    p.hshift[0] = 1
+    p.hshift[2] = 1
+    with pytest.raises(JxlHipError) as e:
+        ctx.frame_begin(p)
+    assert e.value.status == lib.ERR_UNSUPPORTED
+
+
 def test_call_order_errors(ctx):
     from jxl_rs_amd import lib, Context
     c2 = Context(0, 1)
