@@ -1,0 +1,97 @@
+"""Randomised differential test: frames of random (ragged) sizes, transform mixes, stage lists and
+HEADER PARAMETERS (quantiser, chroma-from-luma, Gaborish weights, every EPF knob) through the C ABI
+vs the CPU oracle, bit for bit.  The fixed parity cases use the reference's header defaults; this one
+walks the parameter space the reference's FrameHeader / RestorationFilter / ColorCorrelationParams
+can express (headers/frame_header.rs:146-233, frame/color_correlation_map.rs:21-94)."""
+import numpy as np
+import pytest
+
+from helpers import bit_equal, diff_report, run_gpu_frame, run_oracle_frame
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from jxl_rs_amd import Context
+    c = Context(0, n_slots=1)
+    yield c
+    c.close()
+
+
+def _random_case(rng):
+    from jxl_rs_amd import synth
+    w = int(rng.choice([rng.integers(1, 40), rng.integers(40, 300), rng.integers(300, 700)]))
+    h = int(rng.choice([rng.integers(1, 40), rng.integers(40, 300), rng.integers(300, 700)]))
+    mix = [synth.MIX_DCT8, synth.MIX_D1, synth.MIX_ALL][int(rng.integers(0, 3))]
+    opts = dict(epf_iters=int(rng.integers(0, 4)), gab=bool(rng.integers(0, 2)), lf_smoothing=bool(rng.integers(0, 2)))
+    over = {}
+    if rng.random() < 0.8:
+        over["global_scale"] = int(rng.integers(2000, 60000))
+        over["quant_lf"] = int(rng.integers(1, 200))
+        over["x_qm_scale"] = int(rng.integers(0, 8))
+        over["b_qm_scale"] = int(rng.integers(0, 8))
+        over["color_factor"] = int(rng.integers(1, 200))
+        over["base_correlation_x"] = float(np.float32(rng.uniform(-1, 1)))
+        over["base_correlation_b"] = float(np.float32(rng.uniform(0, 2)))
+        over["epf_quant_mul"] = float(np.float32(rng.uniform(0.1, 1.5)))
+        over["epf_pass0_sigma_scale"] = float(np.float32(rng.uniform(0.3, 2)))
+        over["epf_pass2_sigma_scale"] = float(np.float32(rng.uniform(1, 10)))
+        over["epf_border_sad_mul"] = float(np.float32(rng.uniform(0.2, 1.2)))
+    arrays = {}
+    if rng.random() < 0.7:
+        arrays["gab_w1"] = rng.uniform(0.0, 0.3, 3).astype(np.float32)
+        arrays["gab_w2"] = rng.uniform(0.0, 0.15, 3).astype(np.float32)
+        arrays["epf_channel_scale"] = rng.uniform(1.0, 60.0, 3).astype(np.float32)
+        arrays["epf_sharp_lut"] = np.sort(rng.uniform(0.0, 1.5, 8)).astype(np.float32)
+        arrays["quant_biases"] = np.concatenate([rng.uniform(0.85, 1.0, 3), rng.uniform(0.05, 0.3, 1)]).astype(np.float32)
+        arrays["lf_quant_factors"] = (1.0 / rng.uniform(100, 8000, 3)).astype(np.float32)
+    return w, h, mix, opts, over, arrays
+
+
+class _Setter(dict):
+    """kwargs for helpers.*_params_from: scalars via setattr, arrays element-wise"""
+
+
+def _apply_arrays(p, arrays):
+    for name, vals in arrays.items():
+        field = getattr(p, name)
+        for i, v in enumerate(vals):
+            field[i] = float(v)
+
+
+@pytest.mark.parametrize("seed", range(64))
+def test_random_frames_and_header_parameters_bit_exact(ctx, oracle, seed):
+    from jxl_rs_amd import synth
+    import helpers
+    rng = np.random.default_rng(1000 + seed)
+    w, h, mix, opts, over, arrays = _random_case(rng)
+    wl = synth.make_vardct(w, h, mix=mix, seed=seed, **opts)
+    # oracle
+    po = helpers.oracle_params_from(oracle, wl, **over)
+    _apply_arrays(po, arrays)
+    lf = oracle.dequant_lf(po, *wl.lf_q)
+    planes, lf_sm = oracle.vardct_frame(po, wl.coeffs, wl.transform_map, wl.raw_quant, wl.epf_map, wl.ytox, wl.ytob,
+                                        lf, wl.tables, num_threads=8)
+    want = [pl[:h, :w] for pl in planes]
+    # device (both submission forms alternate)
+    pg = helpers.gpu_params_from(ctx, wl, **over)
+    _apply_arrays(pg, arrays)
+    ctx.frame_begin(pg)
+    ctx.set_dequant_tables(wl.tables)
+    ctx.set_lf_quantized(*wl.lf_q)
+    ctx.set_hf_meta(wl.transform_map, wl.raw_quant, wl.epf_map, wl.ytox, wl.ytob)
+    for g in range(wl.coeffs.shape[0]):
+        if seed % 2:
+            ctx.submit_group_sparse(g, *synth.to_sparse(wl.coeffs[g]))
+        else:
+            ctx.submit_group(g, wl.coeffs[g])
+    ctx.slot_wait(0)
+    ctx.frame_run()
+    ctx.sync()
+    got = ctx.read_planes()
+    got_lf = ctx.read_lf()
+    desc = f"{w}x{h} {opts} {sorted(over)} {sorted(arrays)}"
+    for c in range(3):
+        assert bit_equal(got_lf[c], lf_sm[c]), f"LF ch{c} {desc}: {diff_report(got_lf[c], lf_sm[c])}"
+        assert bit_equal(got[c], want[c]), f"plane {c} {desc}: {diff_report(got[c], want[c])}"
