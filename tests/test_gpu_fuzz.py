@@ -61,7 +61,7 @@ def _apply_arrays(p, arrays):
 
 
 @pytest.mark.parametrize("seed", range(64))
-def test_random_frames_and_header_parameters_bit_exact(ctx, oracle, seed):
+def test_random_frames_and_header_parameters_bit_exact(ctx, oracle, kat, seed):
     from jxl_rs_amd import synth
     import helpers
     rng = np.random.default_rng(1000 + seed)
@@ -95,3 +95,11 @@ def test_random_frames_and_header_parameters_bit_exact(ctx, oracle, seed):
     for c in range(3):
         assert bit_equal(got_lf[c], lf_sm[c]), f"LF ch{c} {desc}: {diff_report(got_lf[c], lf_sm[c])}"
         assert bit_equal(got[c], want[c]), f"plane {c} {desc}: {diff_report(got[c], want[c])}"
+    # 8-bit sRGB output with a random opsin matrix / bias / intensity target (XybParams, xyb.rs:147-163)
+    k = kat["output_stage"]
+    mat = (np.asarray(k["opsin_inverse_matrix"]) * rng.uniform(0.8, 1.2, 9)).astype(np.float32)
+    bias = (np.full(3, k["opsin_bias"]) * rng.uniform(0.5, 1.5, 3)).astype(np.float32)
+    xp = oracle.xyb_params(mat, bias, float(rng.choice([80.0, 255.0, 1000.0, 4000.0])))
+    channels = 3 + seed % 2
+    want8 = oracle.xyb_to_rgb8(xp, [np.ascontiguousarray(p) for p in want], w, h, channels)
+    assert np.array_equal(ctx.read_rgb8(xp, channels), want8), f"rgb8 {desc}"
