@@ -240,6 +240,10 @@ typedef struct jxlh_xyb_params {
 } jxlh_xyb_params;
 jxlh_status jxlh_frame_read_rgb8(jxlh_ctx* ctx, const jxlh_xyb_params* p, uint32_t channels, uint32_t y0,
                                  uint32_t y1, void* out, size_t bytes_per_row);
+/* The same with ConvertF32ToU16Stage at 16 bits (render/stages/convert.rs:743-761: clamp to [0,1], x65535,
+ * round to nearest even, no dither): native-endian u16 samples, interleaved. */
+jxlh_status jxlh_frame_read_rgb16(jxlh_ctx* ctx, const jxlh_xyb_params* p, uint32_t channels, uint32_t y0,
+                                  uint32_t y1, void* out, size_t bytes_per_row);
 
 /* ---------------------------------------------------------------- stage-level hooks */
 /* Whole-image single stages with the pipeline's mirror edge semantics; the analogue of

@@ -878,6 +878,45 @@ jxlh_status jxlh_frame_read_rgb8(jxlh_ctx* ctx, const jxlh_xyb_params* p, uint32
   return JXLH_OK;
 }
 
+jxlh_status jxlh_frame_read_rgb16(jxlh_ctx* ctx, const jxlh_xyb_params* p, uint32_t channels, uint32_t y0,
+                                  uint32_t y1, void* out, size_t bytes_per_row) {
+  if (!ctx || !p || !out || (channels != 3 && channels != 4)) return JXLH_ERR_INVALID_ARGUMENT;
+  if (!ctx->in_frame || !ctx->result[0]) return JXLH_ERR_BAD_STATE;
+  const FrameDev& f = ctx->fd;
+  if (y1 > (uint32_t)f.ysize) y1 = (uint32_t)f.ysize;
+  const size_t row_bytes = (size_t)f.xsize * channels * sizeof(uint16_t);
+  if (y0 >= y1 || bytes_per_row < row_bytes || bytes_per_row % sizeof(uint16_t) != 0 ||
+      reinterpret_cast<uintptr_t>(out) % sizeof(uint16_t) != 0)
+    return JXLH_ERR_INVALID_ARGUMENT;
+  XybParamsDev d;
+  for (int i = 0; i < 9; i++) d.mat[i] = p->opsin_inverse_matrix[i];
+  for (int i = 0; i < 3; i++) {
+    d.bias_cbrt[i] = p->bias_cbrt[i];
+    d.scaled_bias[i] = p->scaled_bias[i];
+  }
+  d.intensity_scale = p->intensity_scale;
+  const int rows = (int)(y1 - y0);
+  const float* planes[3] = {ctx->result[0], ctx->result[1], ctx->result[2]};
+  if (is_device_ptr(out)) {
+    ScopedKernelTimer t(ctx, "k_xyb_to_rgb16");
+    launch_xyb_to_rgb16(ctx->stream, planes, f.plane_stride, f.xsize, (int)y0, rows, d, (int)channels,
+                        static_cast<uint16_t*>(out), bytes_per_row / sizeof(uint16_t));
+    HIPCHK(ctx, hipGetLastError());
+    return JXLH_OK;
+  }
+  if (jxlh_status st = ensure(ctx, ctx->rgb8, row_bytes * (size_t)rows)) return st;
+  {
+    ScopedKernelTimer t(ctx, "k_xyb_to_rgb16");
+    launch_xyb_to_rgb16(ctx->stream, planes, f.plane_stride, f.xsize, (int)y0, rows, d, (int)channels,
+                        reinterpret_cast<uint16_t*>(ctx->rgb8.p), (size_t)f.xsize * channels);
+  }
+  HIPCHK(ctx, hipGetLastError());
+  if (jxlh_status st = copy2d(ctx, out, bytes_per_row, ctx->rgb8.p, row_bytes, row_bytes, (size_t)rows, ctx->stream))
+    return st;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return JXLH_OK;
+}
+
 jxlh_status jxlh_frame_read_planes(jxlh_ctx* ctx, const jxlh_plane out[3]) {
   if (!ctx || !out) return JXLH_ERR_INVALID_ARGUMENT;
   if (!ctx->in_frame || !ctx->result[0]) return JXLH_ERR_BAD_STATE;

@@ -153,6 +153,8 @@ struct XybParamsDev {
 };
 void launch_xyb_to_rgb8(hipStream_t s, const float* const planes[3], size_t stride, int w, int y0, int rows,
                         const XybParamsDev& p, int channels, uint8_t* out, size_t out_stride);
+void launch_xyb_to_rgb16(hipStream_t s, const float* const planes[3], size_t stride, int w, int y0, int rows,
+                         const XybParamsDev& p, int channels, uint16_t* out, size_t out_stride_elems);
 // sparse coefficient transport (k_coeffs.hip): one descriptor per submitted group
 struct SparseGroup {
   uint32_t group;   // group id

@@ -44,6 +44,45 @@ __device__ __forceinline__ uint32_t to_u8(float v, const float* __restrict__ dit
   return (uint32_t)__builtin_rintf(clamped);
 }
 
+__device__ __forceinline__ uint32_t to_u16(float v) {  // f32_to_u16_simd (convert.rs:743-761), 16-bit
+  float clamped = v > 0.0f ? v : 0.0f;
+  clamped = clamped < 1.0f ? clamped : 1.0f;
+  return (uint32_t)__builtin_rintf(clamped * 65535.0f);
+}
+
+// one thread = 4 consecutive pixels of one row; 16-bit samples (no dither), little endian
+template <int CH>
+__global__ __launch_bounds__(kOutThreads) void k_xyb_to_rgb16(const float* __restrict__ px, const float* __restrict__ py,
+                                                              const float* __restrict__ pb, uint32_t stride, int w,
+                                                              int y0, int rows, const XybParamsDev p,
+                                                              uint16_t* __restrict__ out, size_t out_stride_elems) {
+  const int x4 = (blockIdx.x * kOutThreads + threadIdx.x) * 4;
+  const int r = blockIdx.y;
+  if (x4 >= w || r >= rows) return;
+  const size_t in = (size_t)(y0 + r) * stride + x4;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    if (x4 + i >= w) break;
+    const float vx = px[in + i], vy = py[in + i], vb = pb[in + i];
+    float l = vy + vx - p.bias_cbrt[0];
+    float m = vy - vx - p.bias_cbrt[1];
+    float s = vb - p.bias_cbrt[2];
+    const float l2 = l * l, m2 = m * m, s2 = s * s;
+    const float sl = l * p.intensity_scale, sm = m * p.intensity_scale, ss = s * p.intensity_scale;
+    l = __builtin_fmaf(l2, sl, p.scaled_bias[0]);
+    m = __builtin_fmaf(m2, sm, p.scaled_bias[1]);
+    s = __builtin_fmaf(s2, ss, p.scaled_bias[2]);
+    const float rr = __builtin_fmaf(p.mat[0], l, __builtin_fmaf(p.mat[1], m, p.mat[2] * s));
+    const float gg = __builtin_fmaf(p.mat[3], l, __builtin_fmaf(p.mat[4], m, p.mat[5] * s));
+    const float bb = __builtin_fmaf(p.mat[6], l, __builtin_fmaf(p.mat[7], m, p.mat[8] * s));
+    uint16_t* o = out + (size_t)r * out_stride_elems + (size_t)(x4 + i) * CH;
+    o[0] = (uint16_t)to_u16(linear_to_srgb(rr));
+    o[1] = (uint16_t)to_u16(linear_to_srgb(gg));
+    o[2] = (uint16_t)to_u16(linear_to_srgb(bb));
+    if constexpr (CH == 4) o[3] = 65535;
+  }
+}
+
 // one thread = 4 consecutive pixels of one row
 template <int CH>
 __global__ __launch_bounds__(kOutThreads) void k_xyb_to_rgb8(const float* __restrict__ px, const float* __restrict__ py,
@@ -130,6 +169,18 @@ void launch_xyb_to_rgb8(hipStream_t s, const float* const planes[3], size_t stri
   else
     hipLaunchKernelGGL(k_xyb_to_rgb8<4>, grid, dim3(kOutThreads), 0, s, planes[0], planes[1], planes[2],
                        (uint32_t)stride, w, y0, rows, p, out, out_stride, aligned);
+}
+
+void launch_xyb_to_rgb16(hipStream_t s, const float* const planes[3], size_t stride, int w, int y0, int rows,
+                         const XybParamsDev& p, int channels, uint16_t* out, size_t out_stride_elems) {
+  if (w <= 0 || rows <= 0) return;
+  const dim3 grid((unsigned)(((w + 3) / 4 + kOutThreads - 1) / kOutThreads), (unsigned)rows);
+  if (channels == 3)
+    hipLaunchKernelGGL(k_xyb_to_rgb16<3>, grid, dim3(kOutThreads), 0, s, planes[0], planes[1], planes[2],
+                       (uint32_t)stride, w, y0, rows, p, out, out_stride_elems);
+  else
+    hipLaunchKernelGGL(k_xyb_to_rgb16<4>, grid, dim3(kOutThreads), 0, s, planes[0], planes[1], planes[2],
+                       (uint32_t)stride, w, y0, rows, p, out, out_stride_elems);
 }
 
 }  // namespace jxlh

@@ -33,7 +33,7 @@ ABI_SYMBOLS = [
     "jxlh_alloc_pinned", "jxlh_free_pinned", "jxlh_frame_begin", "jxlh_frame_set_dequant_tables",
     "jxlh_frame_set_lf_quantized", "jxlh_frame_set_lf", "jxlh_frame_set_hf_meta", "jxlh_submit_group",
     "jxlh_submit_group_sparse", "jxlh_submit_groups_sparse", "jxlh_slot_wait", "jxlh_frame_coeff_buffer", "jxlh_frame_run", "jxlh_ctx_sync", "jxlh_frame_read_planes",
-    "jxlh_frame_device_planes", "jxlh_frame_read_lf", "jxlh_frame_read_rgb8", "jxlh_timer_start", "jxlh_timer_stop",
+    "jxlh_frame_device_planes", "jxlh_frame_read_lf", "jxlh_frame_read_rgb8", "jxlh_frame_read_rgb16", "jxlh_timer_start", "jxlh_timer_stop",
     "jxlh_kernel_timing_enable", "jxlh_kernel_timing_get", "jxlh_kernel_timing_reset", "jxlh_selftest_recip",
     "jxlh_stage_gaborish",
     "jxlh_stage_epf", "jxlh_stage_lf_smooth", "jxlh_stage_transform_to_pixels", "jxlh_rct", "jxlh_palette",
@@ -99,6 +99,7 @@ def load():
     L.jxlh_free_pinned.argtypes = [vp, vp]
     L.jxlh_frame_begin.argtypes = [vp, C.POINTER(FrameParams)]
     L.jxlh_frame_read_rgb8.argtypes = [vp, vp, u32, u32, u32, vp, sz]
+    L.jxlh_frame_read_rgb16.argtypes = [vp, vp, u32, u32, u32, vp, sz]
     L.jxlh_selftest_recip.argtypes = [vp, u32, u32, C.POINTER(C.c_uint64)]
     L.jxlh_frame_set_dequant_tables.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
     L.jxlh_frame_set_lf_quantized.argtypes = [vp, u32, u32, u32, u32, vp, vp, vp, sz, u32]
@@ -288,6 +289,16 @@ class Context:
         arr = np.zeros((y1 - y0, self.params.xsize, channels), dtype=np.uint8)
         self._chk(self.L.jxlh_frame_read_rgb8(self._ctx, _addr(pr), channels, y0, y1, _addr(arr),
                                               self.params.xsize * channels), "frame_read_rgb8")
+        return arr
+
+    def read_rgb16(self, xyb_params, channels=3, y0=0, y1=None):
+        """16-bit interleaved sRGB of rows [y0, y1) (jxlh_frame_read_rgb16) as a uint16 array."""
+        pr = np.ascontiguousarray(xyb_params, dtype=np.float32)
+        assert pr.size == 16
+        y1 = self.params.ysize if y1 is None else y1
+        arr = np.zeros((y1 - y0, self.params.xsize, channels), dtype=np.uint16)
+        self._chk(self.L.jxlh_frame_read_rgb16(self._ctx, _addr(pr), channels, y0, y1, _addr(arr),
+                                               self.params.xsize * channels * 2), "frame_read_rgb16")
         return arr
 
     def device_planes(self):

@@ -162,6 +162,9 @@ void jxlo_xyb_to_linear(const JxloXybParams* p, float* row_x, float* row_y, floa
 float jxlo_linear_to_srgb1(float x);
 void jxlo_linear_to_srgb(float* v, size_t n);
 uint8_t jxlo_f32_to_u8(float v, size_t x, size_t y, int channel, int bit_depth);
+uint16_t jxlo_f32_to_u16(float v, int bit_depth);
+void jxlo_xyb_to_rgb16(const JxloXybParams* p, const float* px, const float* py, const float* pb, size_t w, size_t h,
+                       size_t stride, uint16_t* out, size_t out_stride_elems, int out_channels);
 void jxlo_xyb_to_rgb8(const JxloXybParams* p, const float* px, const float* py, const float* pb, size_t w, size_t h,
                       size_t stride, uint8_t* out, size_t out_stride_bytes, int out_channels);
 

@@ -96,6 +96,34 @@ uint8_t jxlo_f32_to_u8(float v, size_t x, size_t y, int channel, int bit_depth) 
 #endif
 }
 
+/* f32_to_u16_simd (convert.rs:743-761): clamp to [0, 1], scale, round; no dither */
+uint16_t jxlo_f32_to_u16(float v, int bit_depth) {
+  const float max = (float)((1u << bit_depth) - 1u);
+  float clamped = v > 0.0f ? v : 0.0f;
+  clamped = clamped < 1.0f ? clamped : 1.0f;
+  const float scaled = clamped * max;
+#if JXLO_FUSED
+  return (uint16_t)rintf(scaled); /* avx.rs:642 */
+#else
+  return (uint16_t)roundf(scaled); /* scalar.rs:204-206 */
+#endif
+}
+
+void jxlo_xyb_to_rgb16(const JxloXybParams* p, const float* px, const float* py, const float* pb, size_t w, size_t h,
+                       size_t stride, uint16_t* out, size_t out_stride_elems, int out_channels) {
+  for (size_t y = 0; y < h; y++) {
+    for (size_t x = 0; x < w; x++) {
+      float r = px[y * stride + x], g = py[y * stride + x], b = pb[y * stride + x];
+      jxlo_xyb_to_linear(p, &r, &g, &b, 1);
+      uint16_t* o = out + y * out_stride_elems + x * (size_t)out_channels;
+      o[0] = jxlo_f32_to_u16(jxlo_linear_to_srgb1(r), 16);
+      o[1] = jxlo_f32_to_u16(jxlo_linear_to_srgb1(g), 16);
+      o[2] = jxlo_f32_to_u16(jxlo_linear_to_srgb1(b), 16);
+      if (out_channels == 4) o[3] = 65535;
+    }
+  }
+}
+
 /* the three stages on whole planes -> interleaved 8-bit (out_channels = 3: RGB, 4: RGBA with A = 255) */
 void jxlo_xyb_to_rgb8(const JxloXybParams* p, const float* px, const float* py, const float* pb, size_t w, size_t h,
                       size_t stride, uint8_t* out, size_t out_stride_bytes, int out_channels) {

@@ -78,6 +78,11 @@ class Oracle:
         L.jxlo_xyb_to_rgb8.argtypes = [fp, fp, fp, fp, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(C.c_uint8),
                                        C.c_size_t, C.c_int]
         L.jxlo_xyb_to_rgb8.restype = None
+        L.jxlo_xyb_to_rgb16.argtypes = [fp, fp, fp, fp, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(C.c_uint16),
+                                        C.c_size_t, C.c_int]
+        L.jxlo_xyb_to_rgb16.restype = None
+        L.jxlo_f32_to_u16.argtypes = [C.c_float, C.c_int]
+        L.jxlo_f32_to_u16.restype = C.c_uint16
         L.jxlo_expand_sparse.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                          C.c_uint32, C.POINTER(C.c_int32)]
         L.jxlo_expand_sparse.restype = None
@@ -369,6 +374,15 @@ class Oracle:
         out = np.zeros((h, w, channels), dtype=np.uint8)
         self.lib.jxlo_xyb_to_rgb8(_ptr(p, C.c_float), _ptr(pl[0], C.c_float), _ptr(pl[1], C.c_float),
                                   _ptr(pl[2], C.c_float), w, h, stride, _ptr(out, C.c_uint8), w * channels, channels)
+        return out
+
+    def xyb_to_rgb16(self, params, planes, w, h, channels=3):
+        pl = [np.ascontiguousarray(a, dtype=np.float32) for a in planes]
+        stride = pl[0].shape[1]
+        p = np.ascontiguousarray(params, dtype=np.float32)
+        out = np.zeros((h, w, channels), dtype=np.uint16)
+        self.lib.jxlo_xyb_to_rgb16(_ptr(p, C.c_float), _ptr(pl[0], C.c_float), _ptr(pl[1], C.c_float),
+                                   _ptr(pl[2], C.c_float), w, h, stride, _ptr(out, C.c_uint16), w * channels, channels)
         return out
 
     # ---- sparse coefficient transport ----

@@ -527,6 +527,10 @@ def test_rgb8_output_bit_exact(ctx, oracle, kat, size, channels, intensity):
     band = ctx.read_rgb8(params, channels, y0, y1)
     assert np.array_equal(band, want[y0:y1])
     assert len(np.unique(want)) > 16, "test image should exercise many code values"
+    # 16-bit samples (ConvertF32ToU16Stage: no dither)
+    want16 = oracle.xyb_to_rgb16(params, want_planes, w, h, channels)
+    assert np.array_equal(ctx.read_rgb16(params, channels), want16)
+    assert np.array_equal(ctx.read_rgb16(params, channels, y0, y1), want16[y0:y1])
 
 
 def test_rgb8_output_argument_errors(ctx, oracle, kat):

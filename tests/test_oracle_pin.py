@@ -181,6 +181,11 @@ def test_u8_conversion_dither_properties(oracle_any):
             assert oracle_any.f32_to_u8(k / 255.0, x, y, c) == k
         assert oracle_any.f32_to_u8(-3.0, x, y, c) == 0
         assert oracle_any.f32_to_u8(7.0, x, y, c) == 255
+    # 16-bit conversion (convert.rs:743-761): clamp, scale, round; exact code values survive
+    L = oracle_any.lib
+    for k in (0, 1, 257, 32768, 65534, 65535):
+        assert L.jxlo_f32_to_u16(k / 65535.0, 16) == k
+    assert L.jxlo_f32_to_u16(-1.0, 16) == 0 and L.jxlo_f32_to_u16(3.0, 16) == 65535
     # a mid-grey half-step flips with the dither: both neighbours occur over a 32x32 period
     vals = {oracle_any.f32_to_u8(100.5 / 255.0, x, y, 0) for x in range(32) for y in range(32)}
     assert vals == {100, 101}
