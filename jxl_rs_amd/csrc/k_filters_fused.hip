@@ -44,6 +44,9 @@
 #ifndef JXLH_FUSED_WAVES_PER_EU
 #define JXLH_FUSED_WAVES_PER_EU 6
 #endif
+#ifndef JXLH_FUSED_E0_WPE
+#define JXLH_FUSED_E0_WPE 3
+#endif
 #ifndef JXLH_FAST_RECIP
 #define JXLH_FAST_RECIP 1
 #endif
@@ -577,7 +580,7 @@ __device__ __forceinline__ void mirror_fill(float* __restrict__ buf, int m, int 
 }
 
 template <bool GAB, bool E0, bool E1, bool E2>
-__global__ __launch_bounds__(kT, E0 ? 4 : JXLH_FUSED_WAVES_PER_EU) void k23_fused_filters(const FusedArgs a) {
+__global__ __launch_bounds__(kT, E0 ? JXLH_FUSED_E0_WPE : JXLH_FUSED_WAVES_PER_EU) void k23_fused_filters(const FusedArgs a) {
   __shared__ __attribute__((aligned(16))) float s_buf[3 * kPlane];
   // 1/sigma of the 8x8 blocks this tile touches (block columns/rows relative to the tile's first block)
   __shared__ float s_sigma[kSigH * kSigW];
