@@ -203,9 +203,11 @@ def main():
             algo_bytes = ALGO_BYTES_PER_PX[dom] * size * size
             ach = algo_bytes / (cand[dom]["ms_per_step"] * 1e-3) / 1e9
             traffic = None
-            for k, v in pmc.items():
-                if k.startswith(dom) and isinstance(v, dict):
-                    traffic = int(v["hbm_bytes"])
+            # "k1_vardct" is the scan + class kernels: their PMC entries are k1_scan, k1_dct8, ...
+            prefix = "k1_" if dom == "k1_vardct" else dom
+            parts = [int(v["hbm_bytes"]) for k, v in pmc.items() if k.startswith(prefix) and isinstance(v, dict)]
+            if parts:
+                traffic = sum(parts)
             roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                         "traffic_source": pmc.get("_file"),

@@ -731,7 +731,9 @@ void launch_vardct_groups(hipStream_t s, const FrameDev& f, int group_row0, int 
     hipLaunchKernelGGL(k1_dct16<false>, g16, dim3(kThreads), 0, s, f, wl);
     hipLaunchKernelGGL(k1_dct32<false>, g32, dim3(kThreads), 0, s, f, wl);
   }
-  hipLaunchKernelGGL(k1_special, dim3(grid_for((long)(nblk / kSpecChunk + 1) * kSpecBins, kSpecWaves, 2048)),
+  // 4 of these workgroups fit a CU (37 KB LDS, 255 VGPRs): 1024 is the resident capacity, a larger grid
+  // only queues -- and an empty special list (the d1 mix) pays for every launched workgroup
+  hipLaunchKernelGGL(k1_special, dim3(grid_for((long)(nblk / kSpecChunk + 1) * kSpecBins, kSpecWaves, 1024)),
                      dim3(kSpecThreads), 0, s, f, wl);
   hipLaunchKernelGGL(k1_large, dim3(grid_for(3L * (nblk / 32), 1, 2048)), dim3(kLargeThreads), 0, s, f, wl);
 }
