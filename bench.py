@@ -268,8 +268,10 @@ def main():
     if rank == 0 and n_gpus == 1 and not args.no_e2e and torch.cuda.is_available():
         e2e = {}
         ng = wl.coeffs.shape[0]
-        nslots = 2
-        ectx = [jxl_rs_amd.Context(local_rank, n_slots=nslots) for _ in range(2)]
+        nslots = int(os.environ.get('JXLH_BENCH_SLOTS', '2'))
+        NE = 2  # frames in flight in the PCIe legs (3 contexts measured slower: their 9 streams alias on the
+        #         runtime's few hardware queues and serialise)
+        ectx = [jxl_rs_amd.Context(local_rank, n_slots=nslots) for _ in range(NE)]
         for c in ectx:
             c.frame_begin(synth.apply_opts(c.default_params(size, size), wl))
             c.set_dequant_tables(wl.tables)
@@ -314,7 +316,7 @@ def main():
             c.sync()
         t0 = time.perf_counter()
         for i in range(args.steps):
-            ectx[i % 2].frame_run()
+            ectx[i % NE].frame_run()
         for c in ectx:
             c.sync()
         el = time.perf_counter() - t0
@@ -327,13 +329,13 @@ def main():
             c.set_hf_meta(wl.transform_map, wl.raw_quant, wl.epf_map, wl.ytox, wl.ytob)
         for name, submit in (("sparse_pairs", submit_sparse), ("dense_i32", submit_dense)):
             frames = 12 if name == "sparse_pairs" else 6
-            for i in range(2):
+            for i in range(NE):
                 submit(ectx[i]); ectx[i].frame_run()
             for c in ectx:
                 c.sync()
             t0 = time.perf_counter()
             for i in range(frames):
-                c = ectx[i % 2]
+                c = ectx[i % NE]
                 c.sync()          # the context's previous frame is finished: its buffers can be refilled
                 submit(c)
                 c.frame_run()
@@ -352,7 +354,7 @@ def main():
                                      np.full(3, np.cbrt(bias), np.float32), np.full(3, bias, np.float32),
                                      np.ones(1, np.float32)])
         rgb_bytes = size * size * 3
-        pin_o = [ectx[i].alloc_pinned(rgb_bytes) for i in range(2)]
+        pin_o = [ectx[i].alloc_pinned(rgb_bytes) for i in range(NE)]
         import ctypes as C
 
         def read_rgb(i):
@@ -361,17 +363,19 @@ def main():
                                             C.c_void_p(pin_o[i][1]), size * 3), "frame_read_rgb8")
 
         frames = 12
-        for i in range(2):
+        for i in range(NE):
             submit_sparse(ectx[i]); ectx[i].frame_run()
-        for i in range(2):
+        for i in range(NE):
             read_rgb(i)
         t0 = time.perf_counter()
         submit_sparse(ectx[0]); ectx[0].frame_run()
         for i in range(1, frames):
-            c = ectx[i % 2]
+            c = ectx[i % NE]
             submit_sparse(c); c.frame_run()
-            read_rgb((i - 1) % 2)          # blocks on frame i-1 while frame i uploads and computes
-        read_rgb((frames - 1) % 2)
+            if i >= NE - 1:
+                read_rgb((i - (NE - 1)) % NE)   # blocks on the oldest frame while the newer ones upload and compute
+        for i in range(frames - (NE - 1), frames):
+            read_rgb(i % NE)
         el = time.perf_counter() - t0
         e2e["sparse_pairs_to_host_rgb8"] = {"value": round(size * size * frames / 1e6 / el, 1), "unit": "MP/s",
                                             "ms_per_frame": round(el * 1e3 / frames, 3),
