@@ -53,6 +53,20 @@ def main():
         out.write("\nkernel-trace stats (ns)\n")
         for row in csv.DictReader(open(stats[0])):
             out.write(f"  calls={row['Calls']:>5} avg_ns={float(row['AverageNs']):12.1f} pct={row['Percentage']:>6}  {row['Name'][:110]}\n")
+    # the HIP-event numbers bench.py printed inside that same traced process (agreement check)
+    log = os.path.join(d, "trace.log")
+    if os.path.exists(log):
+        import json
+        import re
+        m = re.search(r'\{"metric".*\}', open(log).read())
+        if m:
+            try:
+                b = json.loads(m.group(0))
+                k = b["roofline"]["all_kernels_ms_per_step"]
+                out.write("\nHIP-event timing printed by bench.py inside the kernel-trace run (same process, same launches):\n")
+                out.write("  " + "   ".join(f"{n} {v['ms_per_step']} ms" for n, v in k.items()) + f"   step {b['ms_per_step']} ms\n")
+            except Exception as e:  # noqa: BLE001 - a malformed log must not break the summary
+                out.write(f"\n(bench line in trace.log not parseable: {e})\n")
 
 
 if __name__ == "__main__":
