@@ -568,20 +568,32 @@ __global__ __launch_bounds__(kSpecThreads, 2) void k1_special(const FrameDev f, 
       float dy[4 * NCH];
       auto run_channel = [&](auto ch_tag) {
         constexpr int CH = decltype(ch_tag)::value;
+        // phase 1: every global load of the channel in flight (the LDS stores of phase 2 could alias the
+        // block infos as far as the compiler knows, which would serialise load after load)
+        int4 qv[NCH];
+        float4 tv[NCH];
+        BlockInfo bis[NCH];
+#pragma unroll
+        for (int j = 0; j < NCH; j++) {
+          const int fl = (j * 64 + lane) * 4;
+          const int b = fl / 64, k = fl % 64;
+          qv[j] = make_int4(0, 0, 0, 0);
+          tv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+          bis[j] = binfo[min(b, kSpecNB - 1)];
+          if (b < nb) {
+            const int qt = quant_table_for_type(btype[b]);
+            const float* tab = f.tables + f.table_offset[qt] + CH * 64;
+            qv[j] = *reinterpret_cast<const int4*>(f.coeffs + bis[j].coef_off + CH * kGroupArea + k);
+            tv[j] = *reinterpret_cast<const float4*>(tab + k);
+          }
+        }
 #pragma unroll
         for (int j = 0; j < NCH; j++) {
           const int fl = (j * 64 + lane) * 4;
           const int b = fl / 64, k = fl % 64;
           float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
           float d4[4] = {dy[j * 4], dy[j * 4 + 1], dy[j * 4 + 2], dy[j * 4 + 3]};
-          if (b < nb) {
-            const BlockInfo bi = binfo[b];
-            const int qt = quant_table_for_type(btype[b]);
-            const float* tab = f.tables + f.table_offset[qt] + CH * 64;
-            const int4 qv = *reinterpret_cast<const int4*>(f.coeffs + bi.coef_off + CH * kGroupArea + k);
-            const float4 tv = *reinterpret_cast<const float4*>(tab + k);
-            v = dequant4<CH>(f, qv, tv, bi, d4);
-          }
+          if (b < nb) v = dequant4<CH>(f, qv[j], tv[j], bis[j], d4);
           if constexpr (CH == 1) {
             dy[j * 4] = d4[0];
             dy[j * 4 + 1] = d4[1];
