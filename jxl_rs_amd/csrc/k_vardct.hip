@@ -542,21 +542,39 @@ __global__ __launch_bounds__(kSpecThreads, 2) void k1_special(const FrameDev f, 
   BlockInfo* binfo = s_binfo[wave];
   int* btype = s_type[wave];
   int* mine = s_idx[wave];
-  const int npairs = ((count + kSpecChunk - 1) / kSpecChunk) * kSpecBins;
+  // work unit = (chunk, type bin, channel): the channels only meet in the chroma-from-luma FMA, whose Y
+  // term the X / B units recompute from the Y coefficients -- three times the parallelism for a kernel
+  // that is bound by the latency of its serial per-unit steps
+  const int npairs = ((count + kSpecChunk - 1) / kSpecChunk) * kSpecBins * 3;
   constexpr int NCH = kSpecNB * 64 / 256;
   for (int pair = blockIdx.x * kSpecWaves + wave; pair < npairs; pair += gridDim.x * kSpecWaves) {
-    const int chunk = pair / kSpecBins, bin = pair % kSpecBins;
+    const int unit_ch = pair % 3, cb = pair / 3;
+    const int chunk = cb / kSpecBins, bin = cb % kSpecBins;
     // ---- this wave's items of the chunk: the ones whose type falls in `bin`
     int nmine = 0;
+    uint32_t packed[kSpecChunk / 64];
+#pragma unroll
+    for (int i = 0; i < kSpecChunk / 64; i++) {  // all four loads in flight before the first ballot
+      const int idx = chunk * kSpecChunk + i * 64 + lane;
+      packed[i] = items[min(idx, max(count - 1, 0))].packed;
+    }
 #pragma unroll
     for (int i = 0; i < kSpecChunk / 64; i++) {
       const int idx = chunk * kSpecChunk + i * 64 + lane;
-      const bool m = idx < count && special_bin((int)(items[idx].packed >> 20) & 31) == bin;
+      const bool m = idx < count && special_bin((int)(packed[i] >> 20) & 31) == bin;
       const unsigned long long mask = __ballot(m);
       if (m) mine[nmine + __popcll(mask & ((1ull << lane) - 1ull))] = idx;
       nmine += __popcll(mask);
     }
     wave_sync();
+    // every item of the pair has a type of this bin, and the types of a bin share one dequant table
+    // (quant_weights.rs:321-343): a wave-uniform pointer instead of a per-lane lookup in the kernel
+    // argument block (which costs two dependent memory round trips per access)
+    constexpr int kBinType[kSpecBins] = {1, 2, 3, 12, 13, 14, 15, 16, 17};
+    int bin_type = kBinType[0];
+#pragma unroll
+    for (int i = 1; i < kSpecBins; i++) bin_type = bin == i ? kBinType[i] : bin_type;
+    const float* __restrict__ bin_table = f.tables + f.table_offset[quant_table_for_type(bin_type)];
     for (int b0 = 0; b0 < nmine; b0 += kSpecNB) {
       const int nb = min(kSpecNB, nmine - b0);
       if (lane < nb) {
@@ -572,20 +590,20 @@ __global__ __launch_bounds__(kSpecThreads, 2) void k1_special(const FrameDev f, 
         // block infos as far as the compiler knows, which would serialise load after load)
         int4 qv[NCH];
         float4 tv[NCH];
-        BlockInfo bis[NCH];
+        float b_sdy[NCH], b_xcc[NCH], b_bcc[NCH];  // the fields dequant4 needs, as plain registers
+        const float lf0 = f.lf[CH][binfo[min(lane, nb - 1)].lf_off];  // in flight with the coefficient loads
 #pragma unroll
         for (int j = 0; j < NCH; j++) {
           const int fl = (j * 64 + lane) * 4;
           const int b = fl / 64, k = fl % 64;
           qv[j] = make_int4(0, 0, 0, 0);
           tv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-          bis[j] = binfo[min(b, kSpecNB - 1)];
-          if (b < nb) {
-            const int qt = quant_table_for_type(btype[b]);
-            const float* tab = f.tables + f.table_offset[qt] + CH * 64;
-            qv[j] = *reinterpret_cast<const int4*>(f.coeffs + bis[j].coef_off + CH * kGroupArea + k);
-            tv[j] = *reinterpret_cast<const float4*>(tab + k);
-          }
+          const BlockInfo* bp = &binfo[min(b, nb - 1)];  // lanes past the batch re-read its last block (discarded)
+          b_sdy[j] = bp->sdy;
+          b_xcc[j] = bp->x_cc;
+          b_bcc[j] = bp->b_cc;
+          qv[j] = *reinterpret_cast<const int4*>(f.coeffs + bp->coef_off + CH * kGroupArea + k);
+          tv[j] = *reinterpret_cast<const float4*>(bin_table + CH * 64 + k);
         }
 #pragma unroll
         for (int j = 0; j < NCH; j++) {
@@ -593,7 +611,11 @@ __global__ __launch_bounds__(kSpecThreads, 2) void k1_special(const FrameDev f, 
           const int b = fl / 64, k = fl % 64;
           float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
           float d4[4] = {dy[j * 4], dy[j * 4 + 1], dy[j * 4 + 2], dy[j * 4 + 3]};
-          if (b < nb) v = dequant4<CH>(f, qv[j], tv[j], bis[j], d4);
+          BlockInfo bi;
+          bi.sdy = b_sdy[j];
+          bi.x_cc = b_xcc[j];
+          bi.b_cc = b_bcc[j];
+          if (b < nb) v = dequant4<CH>(f, qv[j], tv[j], bi, d4);
           if constexpr (CH == 1) {
             dy[j * 4] = d4[0];
             dy[j * 4 + 1] = d4[1];
@@ -609,7 +631,7 @@ __global__ __launch_bounds__(kSpecThreads, 2) void k1_special(const FrameDev f, 
         wave_sync();
         if (lane < nb) {
           float* c = tin + lane * kSpecPitch;
-          c[0] = f.lf[CH][binfo[lane].lf_off];  // transform_buffer[0] = lf[0]
+          c[0] = lf0;  // transform_buffer[0] = lf[0]
           float* o = tout + lane * kSpecPitch;
           switch (bin) {  // wave-uniform
             case 0: special_8x8_regs<1>(c, o); break;
@@ -625,27 +647,61 @@ __global__ __launch_bounds__(kSpecThreads, 2) void k1_special(const FrameDev f, 
         }
         wave_sync();
         float* __restrict__ plane = f.planes[CH];
+        // gather first, then store: all eight stores of the lane issue back to back
+        float4 ov[NCH];
+        int oo[NCH];
 #pragma unroll
         for (int j = 0; j < NCH; j++) {
           const int fl = (j * 64 + lane) * 4;
-          const int b = fl / 64, p = fl % 64;
-          if (b < nb) {
-            if (f.tiled) {  // memory order inside the block is x*8 + y
-              const int x = p / 8, y0 = p % 8;
-              const float* src = tout + b * kSpecPitch + y0 * 8 + x;
-              *reinterpret_cast<float4*>(plane + binfo[b].px_off + p) = make_float4(src[0], src[8], src[16], src[24]);
-            } else {
-              const float* src = tout + b * kSpecPitch + p;
-              float* dst = plane + binfo[b].px_off + (p / 8) * (int)f.plane_stride + (p % 8);
-              *reinterpret_cast<float4*>(dst) = make_float4(src[0], src[1], src[2], src[3]);
-            }
+          const int b = min(fl / 64, nb - 1), p = fl % 64;
+          const int px = binfo[b].px_off;
+          if (f.tiled) {  // memory order inside the block is x*8 + y
+            const int x = p / 8, y0 = p % 8;
+            const float* src = tout + b * kSpecPitch + y0 * 8 + x;
+            ov[j] = make_float4(src[0], src[8], src[16], src[24]);
+            oo[j] = px + p;
+          } else {
+            const float* src = tout + b * kSpecPitch + p;
+            ov[j] = make_float4(src[0], src[1], src[2], src[3]);
+            oo[j] = px + (p / 8) * (int)f.plane_stride + (p % 8);
           }
+        }
+#pragma unroll
+        for (int j = 0; j < NCH; j++) {
+          const int fl = (j * 64 + lane) * 4;
+          if (fl / 64 < nb) *reinterpret_cast<float4*>(plane + oo[j]) = ov[j];
         }
         wave_sync();
       };
-      run_channel(std::integral_constant<int, 1>{});
-      run_channel(std::integral_constant<int, 0>{});
-      run_channel(std::integral_constant<int, 2>{});
+      if (unit_ch == 1) {
+        run_channel(std::integral_constant<int, 1>{});
+      } else {
+        // dequantised Y of the lane's coefficient positions (what run_channel<1> leaves in dy)
+        int4 qy[NCH];
+        float ysdy[NCH];
+#pragma unroll
+        for (int j = 0; j < NCH; j++) {  // lanes past the batch re-read its last block; their dy is unused
+          const int fl = (j * 64 + lane) * 4;
+          const BlockInfo* bp = &binfo[min(fl / 64, nb - 1)];
+          ysdy[j] = bp->sdy;
+          qy[j] = *reinterpret_cast<const int4*>(f.coeffs + bp->coef_off + kGroupArea + fl % 64);
+        }
+#pragma unroll
+        for (int j = 0; j < NCH; j++) {
+          const int k = ((j * 64 + lane) * 4) % 64;
+          float d4[4] = {0.f, 0.f, 0.f, 0.f};
+          BlockInfo bi;
+          bi.sdy = ysdy[j];
+          const float4 ty = *reinterpret_cast<const float4*>(bin_table + 64 + k);
+          (void)dequant4<1>(f, qy[j], ty, bi, d4);
+          dy[j * 4] = d4[0];
+          dy[j * 4 + 1] = d4[1];
+          dy[j * 4 + 2] = d4[2];
+          dy[j * 4 + 3] = d4[3];
+        }
+        if (unit_ch == 0) run_channel(std::integral_constant<int, 0>{});
+        else run_channel(std::integral_constant<int, 2>{});
+      }
     }
     wave_sync();  // `mine` is rewritten by the next pair
   }
@@ -745,7 +801,7 @@ void launch_vardct_groups(hipStream_t s, const FrameDev& f, int group_row0, int 
   }
   // 4 of these workgroups fit a CU (37 KB LDS, 255 VGPRs): 1024 is the resident capacity, a larger grid
   // only queues -- and an empty special list (the d1 mix) pays for every launched workgroup
-  hipLaunchKernelGGL(k1_special, dim3(grid_for((long)(nblk / kSpecChunk + 1) * kSpecBins, kSpecWaves, 1024)),
+  hipLaunchKernelGGL(k1_special, dim3(grid_for((long)(nblk / kSpecChunk + 1) * kSpecBins * 3, kSpecWaves, 1024)),
                      dim3(kSpecThreads), 0, s, f, wl);
   hipLaunchKernelGGL(k1_large, dim3(grid_for(3L * (nblk / 32), 1, 2048)), dim3(kLargeThreads), 0, s, f, wl);
 }
