@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define JXLH_ABI_VERSION 2
+#define JXLH_ABI_VERSION 3
 #define JXLH_NUM_TRANSFORMS 27   /* HfTransformType::CARDINALITY, transform_map.rs:59-61 */
 #define JXLH_NUM_QUANT_TABLES 17 /* NUM_QUANT_TABLES, quantizer.rs:11 */
 #define JXLH_GROUP_DIM 256       /* GROUP_DIM, jxl/src/lib.rs:24-26 */
@@ -42,7 +42,9 @@ enum {
   JXLH_ERR_DEVICE = -3,           /* any other HIP runtime error; see jxlh_last_error */
   JXLH_ERR_BAD_STATE = -4,        /* call order violated (e.g. submit before frame_begin) */
   JXLH_ERR_INVALID_TRANSFORM = -5,/* transform_map holds an id >= 27 (Error::InvalidVarDCTTransform) */
-  JXLH_ERR_UNSUPPORTED = -6       /* valid stream feature outside the device path (caller falls back) */
+  JXLH_ERR_UNSUPPORTED = -6,      /* valid stream feature outside the device path (caller falls back) */
+  JXLH_ERR_INVALID_BLOCK_SIZE = -7 /* a varblock larger than 8x8 in a chroma-subsampled frame
+                                      (Error::InvalidBlockSizeForChromaSubsampling, frame/modular/mod.rs:1058-1060) */
 };
 
 typedef struct jxlh_ctx jxlh_ctx;
@@ -67,10 +69,18 @@ typedef struct {
  *   color_factor .. ytob_lf  ColorCorrelationParams (frame/color_correlation_map.rs:21-94)
  *   gab .. epf_border_sad_mul RestorationFilter (headers/frame_header.rs:146-233)
  *   do_lf_smoothing ........ FrameHeader::should_do_adaptive_lf_smoothing (:496-500)
- *   hshift, vshift ......... per-channel chroma subsampling shifts of the frame (frame/group.rs:443-452,
- *                           X, Y, B order).  Only 4:4:4 (all zero) runs on the device: subsampled frames are
- *                           JPEG recompressions, limited to 8x8 transforms (frame/modular/mod.rs:1058-1060),
- *                           and jxlh_frame_begin answers JXLH_ERR_UNSUPPORTED so the caller keeps its CPU path
+ *   hshift, vshift ......... FrameHeader::hshift(c) / vshift(c) (headers/frame_header.rs:501-512), channel order
+ *                           X/Cb, Y, B/Cr, each 0 or 1: channel c holds (size >> shift) samples (4:2:0, 4:2:2,
+ *                           4:4:0 JPEG recompressions).  Such frames are limited to 8x8 transforms
+ *                           (frame/modular/mod.rs:1058-1060; JXLH_ERR_INVALID_BLOCK_SIZE otherwise), their size
+ *                           in blocks is rounded up to whole blocks of the coarsest channel
+ *                           (FrameHeader::size_blocks, :564-569), the LF samples of a sub-sampled channel
+ *                           sit in the top-left corner of each LF group's rectangle (frame/group.rs:485-504,
+ *                           modular/mod.rs:877-893) and the LF dequantisation skips chroma-from-luma.
+ *                           The transforms reconstruct every channel at its own resolution
+ *                           (frame/group.rs:223-250) and the chroma upsampling stages
+ *                           (render/stages/chroma_upsample.rs, frame/render.rs:569-576) run before Gaborish /
+ *                           EPF, so everything downstream sees full-resolution planes.
  *   epf_sigma_for_modular .. RestorationFilter field used when EPF runs on a Modular frame
  *                           (features/epf.rs:81-84); carried for completeness, VarDCT frames ignore it
  */
@@ -245,6 +255,14 @@ jxlh_status jxlh_frame_read_rgb8(jxlh_ctx* ctx, const jxlh_xyb_params* p, uint32
 jxlh_status jxlh_frame_read_rgb16(jxlh_ctx* ctx, const jxlh_xyb_params* p, uint32_t channels, uint32_t y0,
                                   uint32_t y1, void* out, size_t bytes_per_row);
 
+/* The same for a YCbCr frame (do_ycbcr, not XYB-encoded -- JPEG recompressions): YcbcrToRgbStage
+ * (render/stages/ycbcr.rs:35-78) on the planes taken as Cb, Y, Cr, then the integer conversion; no
+ * transfer-function stage (frame/render.rs:755-763). */
+jxlh_status jxlh_frame_read_ycbcr_rgb8(jxlh_ctx* ctx, uint32_t channels, uint32_t y0, uint32_t y1, void* out,
+                                       size_t bytes_per_row);
+jxlh_status jxlh_frame_read_ycbcr_rgb16(jxlh_ctx* ctx, uint32_t channels, uint32_t y0, uint32_t y1, void* out,
+                                        size_t bytes_per_row);
+
 /* ---------------------------------------------------------------- stage-level hooks */
 /* Whole-image single stages with the pipeline's mirror edge semantics; the analogue of
  * make_and_run_simple_pipeline (jxl/src/render/test.rs:83-179).  Planes: w x h f32, row stride
@@ -256,6 +274,10 @@ jxlh_status jxlh_stage_gaborish(jxlh_ctx* ctx, const float* in, float* out, uint
 jxlh_status jxlh_stage_epf(jxlh_ctx* ctx, int32_t stage, const jxlh_frame_params* p,
                            const float* const in[3], float* const out[3], uint32_t w, uint32_t h,
                            size_t stride, const float* inv_sigma, size_t sigma_stride);
+/* HorizontalChromaUpsample (horizontal != 0: out is 2w x h) or VerticalChromaUpsample (out is w x 2h) on a
+ * tight w x h plane, edges mirrored (render/stages/chroma_upsample.rs:31-63, :108-147) */
+jxlh_status jxlh_stage_chroma_upsample(jxlh_ctx* ctx, const float* in, float* out, uint32_t w, uint32_t h,
+                                       int32_t horizontal);
 /* adaptive_lf_smoothing on w x h tight planes (frame/adaptive_lf_smoothing.rs:44-125) */
 jxlh_status jxlh_stage_lf_smooth(jxlh_ctx* ctx, const jxlh_frame_params* p, const float* const in[3],
                                  float* const out[3], uint32_t w, uint32_t h);

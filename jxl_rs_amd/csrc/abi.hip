@@ -205,6 +205,7 @@ const char* jxlh_status_string(jxlh_status s) {
     case JXLH_ERR_BAD_STATE: return "call order violated";
     case JXLH_ERR_INVALID_TRANSFORM: return "invalid VarDCT transform id";
     case JXLH_ERR_UNSUPPORTED: return "unsupported on the device path";
+    case JXLH_ERR_INVALID_BLOCK_SIZE: return "varblock larger than 8x8 in a chroma-subsampled frame";
     default: return "unknown status";
   }
 }
@@ -338,16 +339,28 @@ jxlh_status jxlh_frame_begin(jxlh_ctx* ctx, const jxlh_frame_params* p) {
   if (p->xsize == 0 || p->ysize == 0 || p->xsize > (1u << 20) || p->ysize > (1u << 20) || p->global_scale == 0 ||
       p->quant_lf == 0 || p->color_factor == 0 || p->epf_iters > 3)
     return JXLH_ERR_INVALID_ARGUMENT;
-  for (int c = 0; c < 3; c++)  // 4:2:0 / 4:2:2 JPEG recompressions stay on the caller's CPU path
-    if (p->hshift[c] != 0 || p->vshift[c] != 0) return JXLH_ERR_UNSUPPORTED;
+  // chroma subsampling (JPEG recompressions): jpeg_upsampling gives shifts of 0 or 1 per axis and channel,
+  // relative to the most finely sampled channel (headers/frame_header.rs:252-253, :501-512)
+  uint32_t maxhs = 0, maxvs = 0;
+  for (int c = 0; c < 3; c++) {
+    if (p->hshift[c] > 1 || p->vshift[c] > 1) return JXLH_ERR_INVALID_ARGUMENT;
+    maxhs |= p->hshift[c];
+    maxvs |= p->vshift[c];
+  }
   HIPCHK(ctx, hipSetDevice(ctx->device));
   ctx->params = *p;
   FrameDev& f = ctx->fd;
   std::memset(&f, 0, sizeof f);
   f.xsize = (int)p->xsize;
   f.ysize = (int)p->ysize;
-  f.xblocks = (int)((p->xsize + 7) / 8);
-  f.yblocks = (int)((p->ysize + 7) / 8);
+  // FrameHeader::size_blocks (headers/frame_header.rs:564-569): whole blocks of the coarsest channel
+  f.xblocks = (int)(((p->xsize + (8u << maxhs) - 1) / (8u << maxhs)) << maxhs);
+  f.yblocks = (int)(((p->ysize + (8u << maxvs) - 1) / (8u << maxvs)) << maxvs);
+  f.subsampled = (maxhs | maxvs) != 0;
+  for (int c = 0; c < 3; c++) {
+    f.hshift[c] = (int)p->hshift[c];
+    f.vshift[c] = (int)p->vshift[c];
+  }
   f.xgroups = (int)((p->xsize + kGroupDim - 1) / kGroupDim);
   f.ygroups = (int)((p->ysize + kGroupDim - 1) / kGroupDim);
   f.cmap_stride = (f.xblocks + 7) / 8;
@@ -372,7 +385,8 @@ jxlh_status jxlh_frame_begin(jxlh_ctx* ctx, const jxlh_frame_params* p) {
   jxlh_status st;
   for (int c = 0; c < 3; c++) {
     if ((st = ensure(ctx, ctx->planes[c], plane_elems)) != JXLH_OK) return st;
-    if ((st = ensure(ctx, ctx->tmp[c], plane_elems)) != JXLH_OK) return st;
+    // + one block row: the scrap tile K1 stores the blocks a sub-sampled channel does not hold into
+    if ((st = ensure(ctx, ctx->tmp[c], plane_elems + 8 * f.plane_stride)) != JXLH_OK) return st;
     if ((st = ensure(ctx, ctx->lf_raw[c], nblocks)) != JXLH_OK) return st;
     if ((st = ensure(ctx, ctx->lf_sm[c], nblocks)) != JXLH_OK) return st;
   }
@@ -391,6 +405,7 @@ jxlh_status jxlh_frame_begin(jxlh_ctx* ctx, const jxlh_frame_params* p) {
     f.tmp[c] = ctx->tmp[c].p;
     f.lf[c] = ctx->lf_raw[c].p;
   }
+  f.scrap_off = (int)plane_elems;
   f.coeffs = ctx->coeffs.p;
   f.transform_map = ctx->transform_map.p;
   f.raw_quant = ctx->raw_quant.p;
@@ -491,9 +506,14 @@ jxlh_status jxlh_frame_set_lf_quantized(jxlh_ctx* ctx, uint32_t x0, uint32_t y0,
   const size_t off = (size_t)y0 * ctx->fd.xblocks + x0;
   {
     ScopedKernelTimer t(ctx, "k0a_dequant_lf");
-    launch_dequant_lf(ctx->stream, ctx->lfq.p, ctx->lfq.p + n, ctx->lfq.p + 2 * n, w, ctx->lf_raw[0].p + off,
-                      ctx->lf_raw[1].p + off, ctx->lf_raw[2].p + off, ctx->fd.xblocks, (int)w, (int)h, fac_x, fac_y,
-                      fac_b, cfl_x, cfl_b);
+    if (ctx->fd.subsampled)  // !is444(): no chroma-from-luma; the samples beyond (size >> shift) are don't-cares
+      launch_dequant_lf_plain(ctx->stream, ctx->lfq.p, ctx->lfq.p + n, ctx->lfq.p + 2 * n, w, ctx->lf_raw[0].p + off,
+                              ctx->lf_raw[1].p + off, ctx->lf_raw[2].p + off, ctx->fd.xblocks, (int)w, (int)h, fac_x,
+                              fac_y, fac_b);
+    else
+      launch_dequant_lf(ctx->stream, ctx->lfq.p, ctx->lfq.p + n, ctx->lfq.p + 2 * n, w, ctx->lf_raw[0].p + off,
+                        ctx->lf_raw[1].p + off, ctx->lf_raw[2].p + off, ctx->fd.xblocks, (int)w, (int)h, fac_x, fac_y,
+                        fac_b, cfl_x, cfl_b);
   }
   HIPCHK(ctx, hipGetLastError());
   // the host buffers may be reused by the caller as soon as we return
@@ -758,8 +778,26 @@ jxlh_status jxlh_frame_run(jxlh_ctx* ctx, uint32_t group_row0, uint32_t group_ro
     f.sp_slot_start = sparse_k1 ? ctx->sp_slot_start.p : nullptr;
     f.group_dense = sparse_k1 ? ctx->group_dense.p : nullptr;
     if (sparse_k1) HIPCHK(ctx, hipMemsetAsync(ctx->group_dense.p, 0, ctx->ngroups, ctx->stream));
-    launch_vardct_groups(ctx->stream, f, gr0, gr1, ctx->worklist.p, ctx->error_flag.p,
+    // a sub-sampled channel is reconstructed at its own resolution into tmp[c] ...
+    FrameDev fk = f;
+    for (int c = 0; c < 3; c++)
+      if (f.hshift[c] | f.vshift[c]) fk.planes[c] = f.tmp[c];
+    launch_vardct_groups(ctx->stream, fk, gr0, gr1, ctx->worklist.p, ctx->error_flag.p,
                          sparse_k1 ? ctx->coeffs.p : nullptr);
+  }
+  if (f.subsampled) {
+    // ... and brought to full resolution into planes[c] before any filter (frame/render.rs:569-576); rows: the
+    // K1 region (the outermost rows of a halo group row read beyond it, and nobody reads them)
+    ScopedKernelTimer t(ctx, "k_chroma_upsample");
+    const PixLayout lay = pix_layout(f);
+    for (int c = 0; c < 3; c++) {
+      const int hs = f.hshift[c], vs = f.vshift[c];
+      if (!(hs | vs)) continue;
+      const int cw = (f.xsize + (1 << hs) - 1) >> hs, ch = (f.ysize + (1 << vs) - 1) >> vs;
+      const int sy0 = (gr0 * kGroupDim) >> vs, sy1 = min(ch, (gr1 * kGroupDim) >> vs);
+      launch_chroma_upsample(ctx->stream, f.tmp[c], f.planes[c], lay, lay, hs, vs, cw, ch, sy0, sy1, f.xblocks * 8,
+                             f.yblocks * 8);
+    }
   }
   // ---- stage list of frame/render.rs:569-622
   const int y_lo = (int)group_row0 * kGroupDim;
@@ -838,20 +876,28 @@ jxlh_status jxlh_ctx_sync(jxlh_ctx* ctx) {
   return JXLH_OK;
 }
 
-jxlh_status jxlh_frame_read_rgb8(jxlh_ctx* ctx, const jxlh_xyb_params* p, uint32_t channels, uint32_t y0,
-                                 uint32_t y1, void* out, size_t bytes_per_row) {
-  if (!ctx || !p || !out || (channels != 3 && channels != 4)) return JXLH_ERR_INVALID_ARGUMENT;
+namespace {
+const XybParamsDev* xyb_params_dev(const jxlh_xyb_params* p, XybParamsDev* d) {
+  if (!p) return nullptr;
+  for (int i = 0; i < 9; i++) d->mat[i] = p->opsin_inverse_matrix[i];
+  for (int i = 0; i < 3; i++) {
+    d->bias_cbrt[i] = p->bias_cbrt[i];
+    d->scaled_bias[i] = p->scaled_bias[i];
+  }
+  d->intensity_scale = p->intensity_scale;
+  return d;
+}
+
+// p == nullptr: the frame is YCbCr (planes Cb, Y, Cr) and takes YcbcrToRgbStage instead of XybStage + sRGB curve
+jxlh_status read_rgb8(jxlh_ctx* ctx, const jxlh_xyb_params* p, uint32_t channels, uint32_t y0, uint32_t y1, void* out,
+                      size_t bytes_per_row) {
+  if (!ctx || !out || (channels != 3 && channels != 4)) return JXLH_ERR_INVALID_ARGUMENT;
   if (!ctx->in_frame || !ctx->result[0]) return JXLH_ERR_BAD_STATE;
   const FrameDev& f = ctx->fd;
   if (y1 > (uint32_t)f.ysize) y1 = (uint32_t)f.ysize;
   if (y0 >= y1 || bytes_per_row < (size_t)f.xsize * channels) return JXLH_ERR_INVALID_ARGUMENT;
-  XybParamsDev d;
-  for (int i = 0; i < 9; i++) d.mat[i] = p->opsin_inverse_matrix[i];
-  for (int i = 0; i < 3; i++) {
-    d.bias_cbrt[i] = p->bias_cbrt[i];
-    d.scaled_bias[i] = p->scaled_bias[i];
-  }
-  d.intensity_scale = p->intensity_scale;
+  XybParamsDev dv;
+  const XybParamsDev* d = xyb_params_dev(p, &dv);
   const int rows = (int)(y1 - y0);
   const float* planes[3] = {ctx->result[0], ctx->result[1], ctx->result[2]};
   if (is_device_ptr(out)) {
@@ -878,9 +924,9 @@ jxlh_status jxlh_frame_read_rgb8(jxlh_ctx* ctx, const jxlh_xyb_params* p, uint32
   return JXLH_OK;
 }
 
-jxlh_status jxlh_frame_read_rgb16(jxlh_ctx* ctx, const jxlh_xyb_params* p, uint32_t channels, uint32_t y0,
-                                  uint32_t y1, void* out, size_t bytes_per_row) {
-  if (!ctx || !p || !out || (channels != 3 && channels != 4)) return JXLH_ERR_INVALID_ARGUMENT;
+jxlh_status read_rgb16(jxlh_ctx* ctx, const jxlh_xyb_params* p, uint32_t channels, uint32_t y0, uint32_t y1, void* out,
+                       size_t bytes_per_row) {
+  if (!ctx || !out || (channels != 3 && channels != 4)) return JXLH_ERR_INVALID_ARGUMENT;
   if (!ctx->in_frame || !ctx->result[0]) return JXLH_ERR_BAD_STATE;
   const FrameDev& f = ctx->fd;
   if (y1 > (uint32_t)f.ysize) y1 = (uint32_t)f.ysize;
@@ -888,13 +934,8 @@ jxlh_status jxlh_frame_read_rgb16(jxlh_ctx* ctx, const jxlh_xyb_params* p, uint3
   if (y0 >= y1 || bytes_per_row < row_bytes || bytes_per_row % sizeof(uint16_t) != 0 ||
       reinterpret_cast<uintptr_t>(out) % sizeof(uint16_t) != 0)
     return JXLH_ERR_INVALID_ARGUMENT;
-  XybParamsDev d;
-  for (int i = 0; i < 9; i++) d.mat[i] = p->opsin_inverse_matrix[i];
-  for (int i = 0; i < 3; i++) {
-    d.bias_cbrt[i] = p->bias_cbrt[i];
-    d.scaled_bias[i] = p->scaled_bias[i];
-  }
-  d.intensity_scale = p->intensity_scale;
+  XybParamsDev dv;
+  const XybParamsDev* d = xyb_params_dev(p, &dv);
   const int rows = (int)(y1 - y0);
   const float* planes[3] = {ctx->result[0], ctx->result[1], ctx->result[2]};
   if (is_device_ptr(out)) {
@@ -915,6 +956,26 @@ jxlh_status jxlh_frame_read_rgb16(jxlh_ctx* ctx, const jxlh_xyb_params* p, uint3
     return st;
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return JXLH_OK;
+}
+}  // namespace
+
+jxlh_status jxlh_frame_read_rgb8(jxlh_ctx* ctx, const jxlh_xyb_params* p, uint32_t channels, uint32_t y0,
+                                 uint32_t y1, void* out, size_t bytes_per_row) {
+  if (!p) return JXLH_ERR_INVALID_ARGUMENT;
+  return read_rgb8(ctx, p, channels, y0, y1, out, bytes_per_row);
+}
+jxlh_status jxlh_frame_read_rgb16(jxlh_ctx* ctx, const jxlh_xyb_params* p, uint32_t channels, uint32_t y0,
+                                  uint32_t y1, void* out, size_t bytes_per_row) {
+  if (!p) return JXLH_ERR_INVALID_ARGUMENT;
+  return read_rgb16(ctx, p, channels, y0, y1, out, bytes_per_row);
+}
+jxlh_status jxlh_frame_read_ycbcr_rgb8(jxlh_ctx* ctx, uint32_t channels, uint32_t y0, uint32_t y1, void* out,
+                                       size_t bytes_per_row) {
+  return read_rgb8(ctx, nullptr, channels, y0, y1, out, bytes_per_row);
+}
+jxlh_status jxlh_frame_read_ycbcr_rgb16(jxlh_ctx* ctx, uint32_t channels, uint32_t y0, uint32_t y1, void* out,
+                                        size_t bytes_per_row) {
+  return read_rgb16(ctx, nullptr, channels, y0, y1, out, bytes_per_row);
 }
 
 jxlh_status jxlh_frame_read_planes(jxlh_ctx* ctx, const jxlh_plane out[3]) {
@@ -1114,6 +1175,28 @@ jxlh_status jxlh_stage_lf_smooth(jxlh_ctx* ctx, const jxlh_frame_params* p, cons
   for (int c = 0; c < 3; c++)
     if ((st = stage_out(ctx, out[c], dout[c], n))) return st;
   return JXLH_OK;
+}
+
+jxlh_status jxlh_stage_chroma_upsample(jxlh_ctx* ctx, const float* in, float* out, uint32_t w, uint32_t h,
+                                       int32_t horizontal) {
+  if (!ctx || !in || !out || w > (1u << 20) || h > (1u << 20)) return JXLH_ERR_INVALID_ARGUMENT;
+  if (w == 0 || h == 0) return JXLH_OK;
+  const size_t n = (size_t)w * h;
+  if (2 * n >= (1ull << 31)) return JXLH_ERR_UNSUPPORTED;
+  jxlh_status st;
+  if ((st = stage_in(ctx, ctx->hook_f[0], in, n))) return st;
+  if ((st = ensure(ctx, ctx->hook_f[1], 2 * n))) return st;
+  const int ow = horizontal ? 2 * (int)w : (int)w, oh = horizontal ? (int)h : 2 * (int)h;
+  PixLayout sl, dl;
+  sl.tiled = dl.tiled = 0;
+  sl.ystep8 = (int)w;
+  sl.ystep_blk = 8 * (int)w;
+  dl.ystep8 = ow;
+  dl.ystep_blk = 8 * ow;
+  launch_chroma_upsample(ctx->stream, ctx->hook_f[0].p, ctx->hook_f[1].p, sl, dl, horizontal ? 1 : 0, horizontal ? 0 : 1,
+                         (int)w, (int)h, 0, (int)h, ow, oh);
+  HIPCHK(ctx, hipGetLastError());
+  return stage_out(ctx, out, ctx->hook_f[1].p, 2 * n);
 }
 
 jxlh_status jxlh_stage_transform_to_pixels(jxlh_ctx* ctx, int32_t type, uint32_t n, const float* coeffs,

@@ -86,6 +86,12 @@ struct FrameDev {
   // varblock then completes whole 256-byte chunks instead of sharing 128-byte lines with its
   // neighbours, and an IDCT lane (which owns a pixel column) stores 32 contiguous bytes.
   int tiled;
+  // Chroma-subsampled frames (JPEG recompressions): channel c has (size >> shift) samples.  K1 writes such
+  // a channel at the down-sampled block positions of its plane (same stride / tiling as a full plane);
+  // blocks the channel does not hold go to the scrap tile at scrap_off (behind the plane proper).
+  int subsampled;
+  int hshift[3], vshift[3];
+  int scrap_off;
   // Sparse coefficient input (null = K1 reads the dense slabs in `coeffs`).  sp_sorted: the frame's
   // {u16 pos; i16 val} pairs, bucketed by 64-coefficient slot inside every (group, channel) run;
   // sp_slot_start[(group*3 + c) * kSlotTable + s] = index of the first pair of slot s, entry
@@ -95,6 +101,7 @@ struct FrameDev {
   const uint32_t* sp_slot_start;
   uint8_t* group_dense;
 };
+constexpr int kLfGroupBlocks = 256;  // an LF group is 2048 x 2048 pixels
 constexpr int kSlotTable = 1025;  // 1024 slots of 64 coefficients per (group, channel) + end marker
 
 // pixel (x, y) relative to a varblock's top-left pixel, for either layout:
@@ -122,6 +129,15 @@ __host__ __device__ inline int block_px_offset(const FrameDev& f, int gbx, int g
 void launch_dequant_lf(hipStream_t s, const int32_t* qy, const int32_t* qx, const int32_t* qb, size_t qstride,
                        float* ox, float* oy, float* ob, size_t ostride, int w, int h, float fac_x, float fac_y,
                        float fac_b, float cfl_x, float cfl_b);
+// dequant_lf of a chroma-subsampled frame: no chroma-from-luma, out = q * fac per channel (modular/mod.rs:877-893)
+void launch_dequant_lf_plain(hipStream_t s, const int32_t* qy, const int32_t* qx, const int32_t* qb, size_t qstride,
+                             float* ox, float* oy, float* ob, size_t ostride, int w, int h, float fac_x, float fac_y,
+                             float fac_b);
+// chroma_upsample.rs: sub-sampled channel (cw x ch samples, rows [sy0, sy1)) -> full channel, horizontal pass
+// then vertical pass fused; writes are clipped to out_w x out_h
+void launch_chroma_upsample(hipStream_t s, const float* src, float* dst, const PixLayout& slay,
+                            const PixLayout& dlay, int hshift, int vshift, int cw, int ch, int sy0, int sy1, int out_w,
+                            int out_h);
 void launch_lf_smooth(hipStream_t s, const float* const in[3], float* const out[3], int w, int h,
                       const float lf_factors[3]);
 void launch_sigma_map(hipStream_t s, const FrameDev& f, float epf_quant_mul, const float* sharp_lut);
@@ -152,9 +168,9 @@ struct XybParamsDev {
   float mat[9], bias_cbrt[3], scaled_bias[3], intensity_scale;
 };
 void launch_xyb_to_rgb8(hipStream_t s, const float* const planes[3], size_t stride, int w, int y0, int rows,
-                        const XybParamsDev& p, int channels, uint8_t* out, size_t out_stride);
+                        const XybParamsDev* p, int channels, uint8_t* out, size_t out_stride);
 void launch_xyb_to_rgb16(hipStream_t s, const float* const planes[3], size_t stride, int w, int y0, int rows,
-                         const XybParamsDev& p, int channels, uint16_t* out, size_t out_stride_elems);
+                         const XybParamsDev* p, int channels, uint16_t* out, size_t out_stride_elems);
 // sparse coefficient transport (k_coeffs.hip): one descriptor per submitted group
 struct SparseGroup {
   uint32_t group;   // group id

@@ -27,6 +27,19 @@ __global__ void k0a_dequant_lf(const int32_t* __restrict__ qy, const int32_t* __
   ob[oi] = in_y * cfl_b + in_b;
 }
 
+__global__ void k0a_dequant_lf_plain(const int32_t* __restrict__ qy, const int32_t* __restrict__ qx,
+                                     const int32_t* __restrict__ qb, size_t qstride, float* __restrict__ ox,
+                                     float* __restrict__ oy, float* __restrict__ ob, size_t ostride, int w, int h,
+                                     float fac_x, float fac_y, float fac_b) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y;
+  if (x >= w || y >= h) return;
+  const size_t qi = (size_t)y * qstride + x, oi = (size_t)y * ostride + x;
+  ox[oi] = (float)qx[qi] * fac_x;
+  oy[oi] = (float)qy[qi] * fac_y;
+  ob[oi] = (float)qb[qi] * fac_b;
+}
+
 constexpr float kWSide = 0.20345139757231578f;
 constexpr float kWCorner = 0.0334829185968739f;
 
@@ -86,6 +99,14 @@ void launch_dequant_lf(hipStream_t s, const int32_t* qy, const int32_t* qx, cons
   if (w <= 0 || h <= 0) return;
   hipLaunchKernelGGL(k0a_dequant_lf, dim3((w + 255) / 256, h), dim3(256), 0, s, qy, qx, qb, qstride, ox, oy, ob,
                      ostride, w, h, fac_x, fac_y, fac_b, cfl_x, cfl_b);
+}
+
+void launch_dequant_lf_plain(hipStream_t s, const int32_t* qy, const int32_t* qx, const int32_t* qb, size_t qstride,
+                             float* ox, float* oy, float* ob, size_t ostride, int w, int h, float fac_x, float fac_y,
+                             float fac_b) {
+  if (w <= 0 || h <= 0) return;
+  hipLaunchKernelGGL(k0a_dequant_lf_plain, dim3((w + 255) / 256, h), dim3(256), 0, s, qy, qx, qb, qstride, ox, oy, ob,
+                     ostride, w, h, fac_x, fac_y, fac_b);
 }
 
 void launch_lf_smooth(hipStream_t s, const float* const in[3], float* const out[3], int w, int h,

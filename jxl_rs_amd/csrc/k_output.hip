@@ -36,6 +36,35 @@ __device__ __forceinline__ float linear_to_srgb(float x) {
   return __builtin_copysignf(r, x);
 }
 
+// Samples of one pixel -> display-referred R, G, B in [0, 1] nominal.
+//   YCBCR = false: XybStage (xyb.rs:220-240) + the sRGB transfer function (frame/render.rs:757-762)
+//   YCBCR = true : YcbcrToRgbStage on planes ordered Cb, Y, Cr (render/stages/ycbcr.rs:35-78); such frames
+//                  are not XYB-encoded, so no transfer-function stage follows (frame/render.rs:755-763)
+template <bool YCBCR>
+__device__ __forceinline__ void to_display_rgb(const XybParamsDev& p, float c0, float c1, float c2, float& r, float& g,
+                                               float& b) {
+  if constexpr (YCBCR) {
+    constexpr float k128 = 128.0f / 255.0f, kCrToR = 1.402f, kCrToG = -0.299f * 1.402f / 0.587f,
+                    kCbToG = -0.114f * 1.772f / 0.587f, kCbToB = 1.772f;
+    const float y = c1 + k128;
+    r = __builtin_fmaf(c2, kCrToR, y);
+    g = __builtin_fmaf(c2, kCrToG, __builtin_fmaf(c0, kCbToG, y));
+    b = __builtin_fmaf(c0, kCbToB, y);
+  } else {
+    float l = c1 + c0 - p.bias_cbrt[0];
+    float m = c1 - c0 - p.bias_cbrt[1];
+    float s = c2 - p.bias_cbrt[2];
+    const float l2 = l * l, m2 = m * m, s2 = s * s;
+    const float sl = l * p.intensity_scale, sm = m * p.intensity_scale, ss = s * p.intensity_scale;
+    l = __builtin_fmaf(l2, sl, p.scaled_bias[0]);
+    m = __builtin_fmaf(m2, sm, p.scaled_bias[1]);
+    s = __builtin_fmaf(s2, ss, p.scaled_bias[2]);
+    r = linear_to_srgb(__builtin_fmaf(p.mat[0], l, __builtin_fmaf(p.mat[1], m, p.mat[2] * s)));
+    g = linear_to_srgb(__builtin_fmaf(p.mat[3], l, __builtin_fmaf(p.mat[4], m, p.mat[5] * s)));
+    b = linear_to_srgb(__builtin_fmaf(p.mat[6], l, __builtin_fmaf(p.mat[7], m, p.mat[8] * s)));
+  }
+}
+
 __device__ __forceinline__ uint32_t to_u8(float v, const float* __restrict__ dither, int x, int y, int c) {
   const float d = dither[((y + c * 13) & 31) * 32 + ((x + c * 23) & 31)];
   const float dithered = v * 255.0f + d;
@@ -51,7 +80,7 @@ __device__ __forceinline__ uint32_t to_u16(float v) {  // f32_to_u16_simd (conve
 }
 
 // one thread = 4 consecutive pixels of one row; 16-bit samples (no dither), little endian
-template <int CH>
+template <int CH, bool YCBCR>
 __global__ __launch_bounds__(kOutThreads) void k_xyb_to_rgb16(const float* __restrict__ px, const float* __restrict__ py,
                                                               const float* __restrict__ pb, uint32_t stride, int w,
                                                               int y0, int rows, const XybParamsDev p,
@@ -63,28 +92,18 @@ __global__ __launch_bounds__(kOutThreads) void k_xyb_to_rgb16(const float* __res
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     if (x4 + i >= w) break;
-    const float vx = px[in + i], vy = py[in + i], vb = pb[in + i];
-    float l = vy + vx - p.bias_cbrt[0];
-    float m = vy - vx - p.bias_cbrt[1];
-    float s = vb - p.bias_cbrt[2];
-    const float l2 = l * l, m2 = m * m, s2 = s * s;
-    const float sl = l * p.intensity_scale, sm = m * p.intensity_scale, ss = s * p.intensity_scale;
-    l = __builtin_fmaf(l2, sl, p.scaled_bias[0]);
-    m = __builtin_fmaf(m2, sm, p.scaled_bias[1]);
-    s = __builtin_fmaf(s2, ss, p.scaled_bias[2]);
-    const float rr = __builtin_fmaf(p.mat[0], l, __builtin_fmaf(p.mat[1], m, p.mat[2] * s));
-    const float gg = __builtin_fmaf(p.mat[3], l, __builtin_fmaf(p.mat[4], m, p.mat[5] * s));
-    const float bb = __builtin_fmaf(p.mat[6], l, __builtin_fmaf(p.mat[7], m, p.mat[8] * s));
+    float rr, gg, bb;
+    to_display_rgb<YCBCR>(p, px[in + i], py[in + i], pb[in + i], rr, gg, bb);
     uint16_t* o = out + (size_t)r * out_stride_elems + (size_t)(x4 + i) * CH;
-    o[0] = (uint16_t)to_u16(linear_to_srgb(rr));
-    o[1] = (uint16_t)to_u16(linear_to_srgb(gg));
-    o[2] = (uint16_t)to_u16(linear_to_srgb(bb));
+    o[0] = (uint16_t)to_u16(rr);
+    o[1] = (uint16_t)to_u16(gg);
+    o[2] = (uint16_t)to_u16(bb);
     if constexpr (CH == 4) o[3] = 65535;
   }
 }
 
 // one thread = 4 consecutive pixels of one row
-template <int CH>
+template <int CH, bool YCBCR>
 __global__ __launch_bounds__(kOutThreads) void k_xyb_to_rgb8(const float* __restrict__ px, const float* __restrict__ py,
                                                              const float* __restrict__ pb, uint32_t stride, int w,
                                                              int y0, int rows, const XybParamsDev p,
@@ -116,21 +135,11 @@ __global__ __launch_bounds__(kOutThreads) void k_xyb_to_rgb8(const float* __rest
   uint32_t q[4][3];
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    // xyb_process (xyb.rs:220-240)
-    float l = vy[i] + vx[i] - p.bias_cbrt[0];
-    float m = vy[i] - vx[i] - p.bias_cbrt[1];
-    float s = vb[i] - p.bias_cbrt[2];
-    const float l2 = l * l, m2 = m * m, s2 = s * s;
-    const float sl = l * p.intensity_scale, sm = m * p.intensity_scale, ss = s * p.intensity_scale;
-    l = __builtin_fmaf(l2, sl, p.scaled_bias[0]);
-    m = __builtin_fmaf(m2, sm, p.scaled_bias[1]);
-    s = __builtin_fmaf(s2, ss, p.scaled_bias[2]);
-    const float rr = __builtin_fmaf(p.mat[0], l, __builtin_fmaf(p.mat[1], m, p.mat[2] * s));
-    const float gg = __builtin_fmaf(p.mat[3], l, __builtin_fmaf(p.mat[4], m, p.mat[5] * s));
-    const float bb = __builtin_fmaf(p.mat[6], l, __builtin_fmaf(p.mat[7], m, p.mat[8] * s));
-    q[i][0] = to_u8(linear_to_srgb(rr), s_dither, x4 + i, y, 0);
-    q[i][1] = to_u8(linear_to_srgb(gg), s_dither, x4 + i, y, 1);
-    q[i][2] = to_u8(linear_to_srgb(bb), s_dither, x4 + i, y, 2);
+    float rr, gg, bb;
+    to_display_rgb<YCBCR>(p, vx[i], vy[i], vb[i], rr, gg, bb);
+    q[i][0] = to_u8(rr, s_dither, x4 + i, y, 0);
+    q[i][1] = to_u8(gg, s_dither, x4 + i, y, 1);
+    q[i][2] = to_u8(bb, s_dither, x4 + i, y, 2);
   }
   uint8_t* o = out + (size_t)r * out_stride + (size_t)x4 * CH;
   if (aligned && x4 + 4 <= w) {
@@ -159,28 +168,36 @@ __global__ __launch_bounds__(kOutThreads) void k_xyb_to_rgb8(const float* __rest
 }  // namespace
 
 void launch_xyb_to_rgb8(hipStream_t s, const float* const planes[3], size_t stride, int w, int y0, int rows,
-                        const XybParamsDev& p, int channels, uint8_t* out, size_t out_stride) {
+                        const XybParamsDev* p, int channels, uint8_t* out, size_t out_stride) {
   if (w <= 0 || rows <= 0) return;
   const dim3 grid((unsigned)(((w + 3) / 4 + kOutThreads - 1) / kOutThreads), (unsigned)rows);
   const int aligned = ((reinterpret_cast<uintptr_t>(out) | out_stride) & 3) == 0;
-  if (channels == 3)
-    hipLaunchKernelGGL(k_xyb_to_rgb8<3>, grid, dim3(kOutThreads), 0, s, planes[0], planes[1], planes[2],
-                       (uint32_t)stride, w, y0, rows, p, out, out_stride, aligned);
-  else
-    hipLaunchKernelGGL(k_xyb_to_rgb8<4>, grid, dim3(kOutThreads), 0, s, planes[0], planes[1], planes[2],
-                       (uint32_t)stride, w, y0, rows, p, out, out_stride, aligned);
+  const XybParamsDev q = p ? *p : XybParamsDev{};
+#define JXLH_LAUNCH8(CH, Y)                                                                                      \
+  hipLaunchKernelGGL((k_xyb_to_rgb8<CH, Y>), grid, dim3(kOutThreads), 0, s, planes[0], planes[1], planes[2],     \
+                     (uint32_t)stride, w, y0, rows, q, out, out_stride, aligned)
+  if (p) {
+    if (channels == 3) JXLH_LAUNCH8(3, false); else JXLH_LAUNCH8(4, false);
+  } else {
+    if (channels == 3) JXLH_LAUNCH8(3, true); else JXLH_LAUNCH8(4, true);
+  }
+#undef JXLH_LAUNCH8
 }
 
 void launch_xyb_to_rgb16(hipStream_t s, const float* const planes[3], size_t stride, int w, int y0, int rows,
-                         const XybParamsDev& p, int channels, uint16_t* out, size_t out_stride_elems) {
+                         const XybParamsDev* p, int channels, uint16_t* out, size_t out_stride_elems) {
   if (w <= 0 || rows <= 0) return;
   const dim3 grid((unsigned)(((w + 3) / 4 + kOutThreads - 1) / kOutThreads), (unsigned)rows);
-  if (channels == 3)
-    hipLaunchKernelGGL(k_xyb_to_rgb16<3>, grid, dim3(kOutThreads), 0, s, planes[0], planes[1], planes[2],
-                       (uint32_t)stride, w, y0, rows, p, out, out_stride_elems);
-  else
-    hipLaunchKernelGGL(k_xyb_to_rgb16<4>, grid, dim3(kOutThreads), 0, s, planes[0], planes[1], planes[2],
-                       (uint32_t)stride, w, y0, rows, p, out, out_stride_elems);
+  const XybParamsDev q = p ? *p : XybParamsDev{};
+#define JXLH_LAUNCH16(CH, Y)                                                                                     \
+  hipLaunchKernelGGL((k_xyb_to_rgb16<CH, Y>), grid, dim3(kOutThreads), 0, s, planes[0], planes[1], planes[2],    \
+                     (uint32_t)stride, w, y0, rows, q, out, out_stride_elems)
+  if (p) {
+    if (channels == 3) JXLH_LAUNCH16(3, false); else JXLH_LAUNCH16(4, false);
+  } else {
+    if (channels == 3) JXLH_LAUNCH16(3, true); else JXLH_LAUNCH16(4, true);
+  }
+#undef JXLH_LAUNCH16
 }
 
 }  // namespace jxlh

@@ -66,8 +66,9 @@ static_assert(sizeof(WorkItem) == 32, "work item layout");
 
 struct BlockInfo {
   int coef_off;  // offset of the varblock inside the frame's coefficient store (channel X)
-  int px_off;    // y*stride + x of the top-left pixel
-  int lf_off;    // by*xblocks + bx of the top-left block
+  // per channel (they differ only in chroma-subsampled frames, K1e / group.rs:223-250, :485-504):
+  int px_off[3];  // offset of the top-left pixel in the channel's plane
+  int lf_off[3];  // by*xblocks + bx of the channel's first LF sample
   float sdy, x_cc, b_cc;
   int slot_base;  // sparse input: index of the varblock's first slot in sp_slot_start (channel X)
   int first_pos;  // position of the varblock's first coefficient inside the channel slab
@@ -105,6 +106,8 @@ __global__ __launch_bounds__(kThreads) void k1_scan(const FrameDev f, const Work
     if (raw >= 128) {  // first (top-left) block of a varblock, group.rs:468-473
       if (type < JXLH_NUM_TRANSFORMS) {
         sz = covered_x(type) * covered_y(type);
+        // Error::InvalidBlockSizeForChromaSubsampling (frame/modular/mod.rs:1058-1060)
+        if (f.subsampled && sz > 1) atomicExch(error_flag, JXLH_ERR_INVALID_BLOCK_SIZE);
       } else {
         atomicExch(error_flag, JXLH_ERR_INVALID_TRANSFORM);  // Error::InvalidVarDCTTransform
       }
@@ -208,8 +211,26 @@ __device__ __forceinline__ void decode_item(const FrameDev& f, const WorkItem& i
   bi->coef_off = g * 3 * kGroupArea + off64 * 64;  // < 2^31: jxlh_frame_begin bounds the frame
   bi->slot_base = g * 3 * kSlotTable + off64;
   bi->first_pos = off64 * 64;
-  bi->px_off = block_px_offset(f, gbx, gby);
-  bi->lf_off = gby * f.xblocks + gbx;
+  if (!f.subsampled) {
+    const int px = block_px_offset(f, gbx, gby), lf = gby * f.xblocks + gbx;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      bi->px_off[c] = px;
+      bi->lf_off[c] = lf;
+    }
+  } else {
+    // A channel holds only the blocks aligned to its sampling, at the down-sampled position; its LF
+    // samples sit in the top-left corner of each LF group's rectangle.  The other blocks are still
+    // transformed (their lanes cannot be re-assigned cheaply) and stored into a scrap tile behind the plane.
+    const int lfbx = gbx & ~(kLfGroupBlocks - 1), lfby = gby & ~(kLfGroupBlocks - 1);
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const int hs = f.hshift[c], vs = f.vshift[c];
+      const bool aligned = ((gbx >> hs) << hs) == gbx && ((gby >> vs) << vs) == gby;
+      bi->px_off[c] = aligned ? block_px_offset(f, gbx >> hs, gby >> vs) : f.scrap_off;
+      bi->lf_off[c] = (lfby + ((gby - lfby) >> vs)) * f.xblocks + lfbx + ((gbx - lfbx) >> hs);
+    }
+  }
   bi->sdy = it.sdy;
   bi->x_cc = it.x_cc;
   bi->b_cc = it.b_cc;
@@ -428,9 +449,9 @@ __device__ __forceinline__ int run_dct_class(const FrameDev& f, const WorkItem* 
       const PixLayout lay = pix_layout(f);
       const int xblocks = f.xblocks;
       idct_batch<S>(
-          buf, nb, lane, [&](int b, int y, int x) { return lfp[binfo[b].lf_off + y * xblocks + x]; },
+          buf, nb, lane, [&](int b, int y, int x) { return lfp[binfo[b].lf_off[CH] + y * xblocks + x]; },
           [&](int b, int x, int yb, const float(&v)[8]) {
-            float* dst = plane + binfo[b].px_off + lay.xoff(x) + yb * lay.ystep_blk;
+            float* dst = plane + binfo[b].px_off[CH] + lay.xoff(x) + yb * lay.ystep_blk;
             if (lay.tiled) {  // the lane's 8 rows are contiguous: two 16-byte stores
               *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
               *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
@@ -591,7 +612,7 @@ __global__ __launch_bounds__(kSpecThreads, 2) void k1_special(const FrameDev f, 
         int4 qv[NCH];
         float4 tv[NCH];
         float b_sdy[NCH], b_xcc[NCH], b_bcc[NCH];  // the fields dequant4 needs, as plain registers
-        const float lf0 = f.lf[CH][binfo[min(lane, nb - 1)].lf_off];  // in flight with the coefficient loads
+        const float lf0 = f.lf[CH][binfo[min(lane, nb - 1)].lf_off[CH]];  // in flight with the coefficient loads
 #pragma unroll
         for (int j = 0; j < NCH; j++) {
           const int fl = (j * 64 + lane) * 4;
@@ -654,7 +675,7 @@ __global__ __launch_bounds__(kSpecThreads, 2) void k1_special(const FrameDev f, 
         for (int j = 0; j < NCH; j++) {
           const int fl = (j * 64 + lane) * 4;
           const int b = min(fl / 64, nb - 1), p = fl % 64;
-          const int px = binfo[b].px_off;
+          const int px = binfo[b].px_off[CH];
           if (f.tiled) {  // memory order inside the block is x*8 + y
             const int x = p / 8, y0 = p % 8;
             const float* src = tout + b * kSpecPitch + y0 * 8 + x;
@@ -733,18 +754,18 @@ __global__ __launch_bounds__(kLargeThreads) void k1_large(const FrameDev f, cons
     auto deq_y = [&](int k) { return adjust_quant_bias(qy[k], b1, b3) * (table[tsize + k] * sdy); };
     const PixLayout lay = pix_layout(f);
     if (ch == 1) {
-      large_varblock_channel(type, deq_y, f.lf[1] + bi.lf_off, f.xblocks, f.planes[1] + bi.px_off, lay, s_lds, tid);
+      large_varblock_channel(type, deq_y, f.lf[1] + bi.lf_off[1], f.xblocks, f.planes[1] + bi.px_off[1], lay, s_lds, tid);
     } else if (ch == 0) {
       large_varblock_channel(
           type, [&](int k) { return __builtin_fmaf(x_cc, deq_y(k), adjust_quant_bias(qx[k], b0, b3) * (table[k] * sdx)); },
-          f.lf[0] + bi.lf_off, f.xblocks, f.planes[0] + bi.px_off, lay, s_lds, tid);
+          f.lf[0] + bi.lf_off[0], f.xblocks, f.planes[0] + bi.px_off[0], lay, s_lds, tid);
     } else {
       large_varblock_channel(
           type,
           [&](int k) {
             return __builtin_fmaf(b_cc, deq_y(k), adjust_quant_bias(qb[k], b2, b3) * (table[2 * tsize + k] * sdb));
           },
-          f.lf[2] + bi.lf_off, f.xblocks, f.planes[2] + bi.px_off, lay, s_lds, tid);
+          f.lf[2] + bi.lf_off[2], f.xblocks, f.planes[2] + bi.px_off[2], lay, s_lds, tid);
     }
   }
 }

@@ -24,6 +24,7 @@ ERR_DEVICE = -3
 ERR_BAD_STATE = -4
 ERR_INVALID_TRANSFORM = -5
 ERR_UNSUPPORTED = -6
+ERR_INVALID_BLOCK_SIZE = -7
 FRAME_UNFUSED_FILTERS = 1
 GROUP_COMPLETE = 1
 
@@ -33,7 +34,8 @@ ABI_SYMBOLS = [
     "jxlh_alloc_pinned", "jxlh_free_pinned", "jxlh_frame_begin", "jxlh_frame_set_dequant_tables",
     "jxlh_frame_set_lf_quantized", "jxlh_frame_set_lf", "jxlh_frame_set_hf_meta", "jxlh_submit_group",
     "jxlh_submit_group_sparse", "jxlh_submit_groups_sparse", "jxlh_slot_wait", "jxlh_frame_coeff_buffer", "jxlh_frame_run", "jxlh_ctx_sync", "jxlh_frame_read_planes",
-    "jxlh_frame_device_planes", "jxlh_frame_read_lf", "jxlh_frame_read_rgb8", "jxlh_frame_read_rgb16", "jxlh_timer_start", "jxlh_timer_stop",
+    "jxlh_frame_device_planes", "jxlh_frame_read_lf", "jxlh_frame_read_rgb8", "jxlh_frame_read_rgb16",
+    "jxlh_frame_read_ycbcr_rgb8", "jxlh_frame_read_ycbcr_rgb16", "jxlh_stage_chroma_upsample", "jxlh_timer_start", "jxlh_timer_stop",
     "jxlh_kernel_timing_enable", "jxlh_kernel_timing_get", "jxlh_kernel_timing_reset", "jxlh_selftest_recip",
     "jxlh_stage_gaborish",
     "jxlh_stage_epf", "jxlh_stage_lf_smooth", "jxlh_stage_transform_to_pixels", "jxlh_rct", "jxlh_palette",
@@ -100,6 +102,9 @@ def load():
     L.jxlh_frame_begin.argtypes = [vp, C.POINTER(FrameParams)]
     L.jxlh_frame_read_rgb8.argtypes = [vp, vp, u32, u32, u32, vp, sz]
     L.jxlh_frame_read_rgb16.argtypes = [vp, vp, u32, u32, u32, vp, sz]
+    L.jxlh_frame_read_ycbcr_rgb8.argtypes = [vp, u32, u32, u32, vp, sz]
+    L.jxlh_frame_read_ycbcr_rgb16.argtypes = [vp, u32, u32, u32, vp, sz]
+    L.jxlh_stage_chroma_upsample.argtypes = [vp, vp, vp, u32, u32, i32]
     L.jxlh_selftest_recip.argtypes = [vp, u32, u32, C.POINTER(C.c_uint64)]
     L.jxlh_frame_set_dequant_tables.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
     L.jxlh_frame_set_lf_quantized.argtypes = [vp, u32, u32, u32, u32, vp, vp, vp, sz, u32]
@@ -183,8 +188,10 @@ class Context:
     # ---- frame ----
     def frame_begin(self, params):
         self.params = params
-        self.xblocks = (params.xsize + 7) // 8
-        self.yblocks = (params.ysize + 7) // 8
+        # FrameHeader::size_blocks: whole blocks of the coarsest (sub-sampled) channel
+        mh, mv = max(params.hshift), max(params.vshift)
+        self.xblocks = -(-params.xsize // (8 << mh)) << mh
+        self.yblocks = -(-params.ysize // (8 << mv)) << mv
         self._chk(self.L.jxlh_frame_begin(self._ctx, C.byref(params)), "frame_begin")
 
     def set_dequant_tables(self, tables):
@@ -301,6 +308,21 @@ class Context:
                                                self.params.xsize * channels * 2), "frame_read_rgb16")
         return arr
 
+    def read_ycbcr_rgb8(self, channels=3, y0=0, y1=None):
+        """8-bit interleaved RGB of a YCbCr frame (planes Cb, Y, Cr; jxlh_frame_read_ycbcr_rgb8)."""
+        y1 = self.params.ysize if y1 is None else y1
+        arr = np.zeros((y1 - y0, self.params.xsize, channels), dtype=np.uint8)
+        self._chk(self.L.jxlh_frame_read_ycbcr_rgb8(self._ctx, channels, y0, y1, _addr(arr),
+                                                    self.params.xsize * channels), "frame_read_ycbcr_rgb8")
+        return arr
+
+    def read_ycbcr_rgb16(self, channels=3, y0=0, y1=None):
+        y1 = self.params.ysize if y1 is None else y1
+        arr = np.zeros((y1 - y0, self.params.xsize, channels), dtype=np.uint16)
+        self._chk(self.L.jxlh_frame_read_ycbcr_rgb16(self._ctx, channels, y0, y1, _addr(arr),
+                                                     self.params.xsize * channels * 2), "frame_read_ycbcr_rgb16")
+        return arr
+
     def device_planes(self):
         ptrs = (C.c_void_p * 3)()
         stride = C.c_size_t()
@@ -379,6 +401,14 @@ class Context:
         pin = (C.c_void_p * 3)(*[a.ctypes.data for a in lf])
         pout = (C.c_void_p * 3)(*[a.ctypes.data for a in out])
         self._chk(self.L.jxlh_stage_lf_smooth(self._ctx, C.byref(params), pin, pout, w, h), "stage_lf_smooth")
+        return out
+
+    def stage_chroma_upsample(self, plane, horizontal):
+        plane = np.ascontiguousarray(plane, dtype=np.float32)
+        h, w = plane.shape
+        out = np.zeros((h, 2 * w) if horizontal else (2 * h, w), dtype=np.float32)
+        self._chk(self.L.jxlh_stage_chroma_upsample(self._ctx, _addr(plane), _addr(out), w, h, 1 if horizontal else 0),
+                  "stage_chroma_upsample")
         return out
 
     def stage_transform_to_pixels(self, ttype, coeffs, lf):

@@ -21,6 +21,8 @@ REQ_Y = [1, 1, 1, 1, 2, 4, 2, 4, 4, 1, 1, 8, 8, 16, 16, 32, 32]
 # type mixes (type id -> area weight)
 MIX_DCT8 = {0: 1.0}
 MIX_D1 = {0: 0.50, 4: 0.10, 6: 0.08, 7: 0.08, 5: 0.08, 10: 0.04, 11: 0.04, 8: 0.04, 9: 0.04}
+# every 8x8 transform: what a chroma-subsampled (JPEG-recompression) frame may hold
+MIX_8X8 = {0: 0.55, 1: 0.05, 2: 0.05, 3: 0.05, 12: 0.05, 13: 0.05, 14: 0.05, 15: 0.05, 16: 0.05, 17: 0.05}
 MIX_ALL = {0: 0.30, 4: 0.06, 6: 0.05, 7: 0.05, 5: 0.06, 10: 0.03, 11: 0.03, 8: 0.03, 9: 0.03,
            1: 0.012, 2: 0.012, 3: 0.012, 12: 0.012, 13: 0.012, 14: 0.01, 15: 0.01, 16: 0.01, 17: 0.01,
            18: 0.06, 19: 0.03, 20: 0.03, 21: 0.04, 22: 0.02, 23: 0.02, 24: 0.04, 25: 0.02, 26: 0.02}
@@ -267,12 +269,14 @@ class VarDctWorkload:
     opts: dict = field(default_factory=dict)
 
     @property
-    def xblocks(self):
-        return (self.xsize + 7) // 8
+    def xblocks(self):  # FrameHeader::size_blocks: whole blocks of the coarsest channel
+        mh = max(self.opts.get("hshift", (0, 0, 0)))
+        return -(-self.xsize // (8 << mh)) << mh
 
     @property
     def yblocks(self):
-        return (self.ysize + 7) // 8
+        mv = max(self.opts.get("vshift", (0, 0, 0)))
+        return -(-self.ysize // (8 << mv)) << mv
 
     @property
     def xgroups(self):
@@ -305,13 +309,16 @@ def _coeff_block(rng, t, n):
 
 
 def make_vardct(xsize, ysize, mix=None, seed=0, unique_groups=None, epf_iters=2, gab=True, lf_smoothing=True,
-                coeff_scale=1):
+                coeff_scale=1, hshift=(0, 0, 0), vshift=(0, 0, 0)):
     """Builds a VarDCT workload.  unique_groups: generate only that many distinct group contents
     and reuse them round-robin (host-side generation time for 8K/16K frames); group *positions*,
     maps and LF are always generated for the whole frame."""
     mix = MIX_D1 if mix is None else mix
     rng = np.random.default_rng([0x4A584C, seed, xsize, ysize])
-    xb, yb = (xsize + 7) // 8, (ysize + 7) // 8
+    mh, mv = max(hshift), max(vshift)
+    if mh or mv:
+        assert all(COVERED_X[t] == 1 and COVERED_Y[t] == 1 for t in mix), "sub-sampled frames hold 8x8 transforms only"
+    xb, yb = -(-xsize // (8 << mh)) << mh, -(-ysize // (8 << mv)) << mv
     xg, yg = (xsize + 255) // 256, (ysize + 255) // 256
     ngroups = xg * yg
     transform_map = np.zeros((yb, xb), dtype=np.uint8)
@@ -364,7 +371,8 @@ def make_vardct(xsize, ysize, mix=None, seed=0, unique_groups=None, epf_iters=2,
     qb = np.round((B - Y) / fac[2]).astype(np.int32)  # B = y*cfl_b(=1) + qb*fac
     return VarDctWorkload(xsize, ysize, transform_map, raw_quant, epf_map, ytox, ytob, [qy, qx, qb], coeffs,
                           library_dequant_tables(),
-                          dict(epf_iters=epf_iters, gab=gab, lf_smoothing=lf_smoothing, seed=seed))
+                          dict(epf_iters=epf_iters, gab=gab, lf_smoothing=lf_smoothing, seed=seed,
+                               hshift=tuple(hshift), vshift=tuple(vshift)))
 
 
 def apply_opts(params, wl):
@@ -372,6 +380,9 @@ def apply_opts(params, wl):
     params.epf_iters = wl.opts.get("epf_iters", 2)
     params.gab = 1 if wl.opts.get("gab", True) else 0
     params.do_lf_smoothing = 1 if wl.opts.get("lf_smoothing", True) else 0
+    for c in range(3):
+        params.hshift[c] = wl.opts.get("hshift", (0, 0, 0))[c]
+        params.vshift[c] = wl.opts.get("vshift", (0, 0, 0))[c]
     return params
 
 

@@ -102,6 +102,9 @@ typedef struct {
   float epf_channel_scale[3];
   float epf_quant_mul, epf_pass0_sigma_scale, epf_pass2_sigma_scale, epf_border_sad_mul;
   int32_t do_lf_smoothing;
+  /* chroma subsampling of channel c = X/Cb, Y, B/Cr (headers/frame_header.rs:501-512): the channel has
+   * (size >> shift) samples; 0 everywhere for 4:4:4 */
+  int32_t hshift[3], vshift[3];
 } JxloFrameParams;
 
 void jxlo_default_frame_params(JxloFrameParams* p, int xsize, int ysize);
@@ -112,6 +115,9 @@ void jxlo_default_frame_params(JxloFrameParams* p, int xsize, int ysize);
 void jxlo_dequant_lf(const JxloFrameParams* p, const int32_t* qy, const int32_t* qx,
                      const int32_t* qb, float mul, size_t n, float* out_x, float* out_y,
                      float* out_b);
+/* K0a, branch for subsampled frames (frame/modular/mod.rs:877-893): no chroma-from-luma, one channel,
+ * elementwise (the caller passes the channel's own quantised plane: X <- input[1], Y <- input[0]) */
+void jxlo_dequant_lf_channel(const JxloFrameParams* p, int c, const int32_t* q, float mul, size_t n, float* out);
 /* K0b adaptive_lf_smoothing (frame/adaptive_lf_smoothing.rs:44-125); planes w x h, tight */
 void jxlo_adaptive_lf_smoothing(const JxloFrameParams* p, const float* const in[3], int w, int h,
                                 float* const out[3]);
@@ -141,6 +147,15 @@ void jxlo_epf_rows(int stage, const JxloFrameParams* p, const float* const in[3]
                    size_t stride, const float* inv_sigma, size_t sigma_stride,
                    float* const out[3], int y0, int y1);
 
+/* HorizontalChromaUpsample / VerticalChromaUpsample (render/stages/chroma_upsample.rs:31-63,:108-147) on a
+ * whole channel with the pipeline's mirror at the edges of the (sub-sampled) channel
+ * (low_memory_pipeline/render_group.rs:389-476).  in: ws x hs samples; out: 2*ws x hs (h) or ws x 2*hs (v);
+ * the caller crops to the frame size. */
+void jxlo_chroma_upsample_h(const float* in, int ws, int hs, size_t in_stride, float* out, size_t out_stride);
+void jxlo_chroma_upsample_v(const float* in, int ws, int hs, size_t in_stride, float* out, size_t out_stride);
+/* YcbcrToRgbStage (render/stages/ycbcr.rs:35-78): planes in the order Cb, Y, Cr become R, G, B in place */
+void jxlo_ycbcr_to_rgb(float* cb, float* y, float* cr, size_t n);
+
 /* whole chain K0b..K3 on num_threads host threads (the cpu_baseline harness).
  * lf is smoothed in place when do_lf_smoothing.  planes/tmp: 3 planes each.  */
 void jxlo_vardct_frame(const JxloFrameParams* p, const int32_t* coeffs /* ngroups*3*65536 */,
@@ -165,6 +180,12 @@ uint8_t jxlo_f32_to_u8(float v, size_t x, size_t y, int channel, int bit_depth);
 uint16_t jxlo_f32_to_u16(float v, int bit_depth);
 void jxlo_xyb_to_rgb16(const JxloXybParams* p, const float* px, const float* py, const float* pb, size_t w, size_t h,
                        size_t stride, uint16_t* out, size_t out_stride_elems, int out_channels);
+/* a YCbCr frame (do_ycbcr, not XYB-encoded: frame/render.rs:755) shown as 8 / 16 bit: ycbcr, then the
+ * integer conversion -- no transfer function stage */
+void jxlo_ycbcr_to_rgb8(const float* pcb, const float* py, const float* pcr, size_t w, size_t h, size_t stride,
+                        uint8_t* out, size_t out_stride_bytes, int out_channels);
+void jxlo_ycbcr_to_rgb16(const float* pcb, const float* py, const float* pcr, size_t w, size_t h, size_t stride,
+                         uint16_t* out, size_t out_stride_elems, int out_channels);
 void jxlo_xyb_to_rgb8(const JxloXybParams* p, const float* px, const float* py, const float* pb, size_t w, size_t h,
                       size_t stride, uint8_t* out, size_t out_stride_bytes, int out_channels);
 

@@ -138,3 +138,48 @@ void jxlo_xyb_to_rgb8(const JxloXybParams* p, const float* px, const float* py, 
     }
   }
 }
+
+/* ---- YCbCr frames (JPEG recompression): render/stages/ycbcr.rs:35-78 ---- */
+void jxlo_ycbcr_to_rgb(float* cb, float* y, float* cr, size_t n) {
+  /* the constants are f32 literals of the products the source spells out */
+  const float c128 = 128.0f / 255.0f;
+  const float cr_to_r = 1.402f;
+  const float cr_to_g = -0.299f * 1.402f / 0.587f;
+  const float cb_to_g = -0.114f * 1.772f / 0.587f;
+  const float cb_to_b = 1.772f;
+  for (size_t i = 0; i < n; i++) {
+    const float yv = y[i] + c128, cbv = cb[i], crv = cr[i];
+    const float r = mul_add(crv, cr_to_r, yv);
+    const float g = mul_add(crv, cr_to_g, mul_add(cbv, cb_to_g, yv));
+    const float b = mul_add(cbv, cb_to_b, yv);
+    cb[i] = r; /* R -> Cb plane, G -> Y plane, B -> Cr plane (:74-77) */
+    y[i] = g;
+    cr[i] = b;
+  }
+}
+
+void jxlo_ycbcr_to_rgb8(const float* pcb, const float* py, const float* pcr, size_t w, size_t h, size_t stride,
+                        uint8_t* out, size_t out_stride_bytes, int out_channels) {
+  for (size_t y = 0; y < h; y++) {
+    for (size_t x = 0; x < w; x++) {
+      float v[3] = {pcb[y * stride + x], py[y * stride + x], pcr[y * stride + x]};
+      jxlo_ycbcr_to_rgb(&v[0], &v[1], &v[2], 1);
+      uint8_t* o = out + y * out_stride_bytes + x * (size_t)out_channels;
+      for (int c = 0; c < 3; c++) o[c] = jxlo_f32_to_u8(v[c], x, y, c, 8);
+      if (out_channels == 4) o[3] = 255;
+    }
+  }
+}
+
+void jxlo_ycbcr_to_rgb16(const float* pcb, const float* py, const float* pcr, size_t w, size_t h, size_t stride,
+                         uint16_t* out, size_t out_stride_elems, int out_channels) {
+  for (size_t y = 0; y < h; y++) {
+    for (size_t x = 0; x < w; x++) {
+      float v[3] = {pcb[y * stride + x], py[y * stride + x], pcr[y * stride + x]};
+      jxlo_ycbcr_to_rgb(&v[0], &v[1], &v[2], 1);
+      uint16_t* o = out + y * out_stride_elems + x * (size_t)out_channels;
+      for (int c = 0; c < 3; c++) o[c] = jxlo_f32_to_u16(v[c], 16);
+      if (out_channels == 4) o[3] = 65535;
+    }
+  }
+}

@@ -100,6 +100,12 @@ void jxlo_dequant_lf(const JxloFrameParams* p, const int32_t* qy, const int32_t*
   }
 }
 
+void jxlo_dequant_lf_channel(const JxloFrameParams* p, int c, const int32_t* q, float mul, size_t n, float* out) {
+  const float inv_quant_lf = (float)(1 << 16) / ((float)p->global_scale * (float)p->quant_lf);
+  const float fac = (p->lf_quant_factors[c] * inv_quant_lf) * mul; /* modular/mod.rs:884 */
+  for (size_t i = 0; i < n; i++) out[i] = (float)q[i] * fac;
+}
+
 /* ---------------- K0b ---------------- */
 static const float kWSide = 0.20345139757231578f;
 static const float kWCorner = 0.0334829185968739f;
@@ -218,16 +224,23 @@ void jxlo_decode_group(const JxloFrameParams* p, int group, const int32_t* coeff
         tb[2][k] = mul_add(b_cc, dy, db);
       }
       for (int c = 0; c < 3; c++) {
-        /* LF patch cy x cx (:227-235) */
+        /* sub-sampled channels only hold the blocks aligned to their sampling (:223-226); bx, by are
+         * group-local there, and a group is an even number of blocks */
+        const int hs = p->hshift[c], vs = p->vshift[c];
+        if ((((bx >> hs) << hs) != bx) || (((by >> vs) << vs) != by)) continue;
+        /* LF patch cy x cx (:227-235); the sub-sampled LF samples of an LF group sit in the top-left
+         * corner of the group's rectangle of the LF image (:485-504) */
+        const int lfg = p->group_dim; /* LF group = group_dim blocks (8 * group_dim pixels) */
+        const int lfbx = ((bx0 + bx) / lfg) * lfg, lfby = ((by0 + by) / lfg) * lfg;
+        const int lx = lfbx + ((bx0 + bx - lfbx) >> hs), ly = lfby + ((by0 + by - lfby) >> vs);
         for (int y = 0; y < cy; y++)
-          for (int x = 0; x < cx; x++)
-            lfbuf[y * cx + x] = lf[c][(size_t)(by0 + by + y) * mstride + (bx0 + bx + x)];
+          for (int x = 0; x < cx; x++) lfbuf[y * cx + x] = lf[c][(size_t)(ly + y) * mstride + (lx + x)];
         jxlo_transform_to_pixels(type, lfbuf, tb[c]);
-        /* copy R x C pixels into the plane (:237-250) */
+        /* copy R x C pixels into the plane at the down-sampled origin (:237-250) */
         const int R = cy * 8, C = cx * 8;
+        const size_t ox = (size_t)(((bx0 + bx) * 8) >> hs), oy = (size_t)(((by0 + by) * 8) >> vs);
         for (int y = 0; y < R; y++)
-          memcpy(planes[c] + (size_t)((by0 + by) * 8 + y) * stride + (size_t)(bx0 + bx) * 8,
-                 tb[c] + (size_t)y * C, sizeof(float) * C);
+          memcpy(planes[c] + (oy + y) * stride + ox, tb[c] + (size_t)y * C, sizeof(float) * C);
       }
       off += n;
     }
@@ -248,6 +261,30 @@ static inline int mirror(int v, int s) { /* util/mirror.rs:8-19 */
 }
 
 #define PIX(pl, x, y) ((pl)[(size_t)mirror((y), h) * stride + (size_t)mirror((x), w)])
+
+/* ---------------- chroma upsampling (render/stages/chroma_upsample.rs) ---------------- */
+void jxlo_chroma_upsample_h(const float* in, int ws, int hs, size_t in_stride, float* out, size_t out_stride) {
+  for (int y = 0; y < hs; y++) {
+    const float* r = in + (size_t)y * in_stride;
+    for (int x = 0; x < ws; x++) {
+      const float prev = r[mirror(x - 1, ws)], cur = r[x], next = r[mirror(x + 1, ws)];
+      out[(size_t)y * out_stride + 2 * x] = mul_add(prev, 0.25f, cur * 0.75f);     /* :53 */
+      out[(size_t)y * out_stride + 2 * x + 1] = mul_add(next, 0.25f, cur * 0.75f); /* :56 */
+    }
+  }
+}
+
+void jxlo_chroma_upsample_v(const float* in, int ws, int hs, size_t in_stride, float* out, size_t out_stride) {
+  for (int y = 0; y < hs; y++) {
+    const float* rp = in + (size_t)mirror(y - 1, hs) * in_stride;
+    const float* rc = in + (size_t)y * in_stride;
+    const float* rn = in + (size_t)mirror(y + 1, hs) * in_stride;
+    for (int x = 0; x < ws; x++) {
+      out[(size_t)(2 * y) * out_stride + x] = mul_add(rp[x], 0.25f, rc[x] * 0.75f);     /* :137 */
+      out[(size_t)(2 * y + 1) * out_stride + x] = mul_add(rn[x], 0.25f, rc[x] * 0.75f); /* :140 */
+    }
+  }
+}
 
 /* ---------------- K2 ---------------- */
 void jxlo_gaborish_rows(const float* in, int w, int h, size_t stride, float w1, float w2,
@@ -557,6 +594,23 @@ void jxlo_vardct_frame(const JxloFrameParams* p, const int32_t* coeffs,
   const int xg = (p->xsize + p->group_dim - 1) / p->group_dim;
   const int yg = (p->ysize + p->group_dim - 1) / p->group_dim;
   run_parallel(num_threads, xg * yg, group_job, &j);
+  /* chroma upsampling first (frame/render.rs:569-576): horizontal, then vertical, per channel; the
+   * channel's image is ceil(size / 2^shift) samples, mirrored at its own edges */
+  for (int c = 0; c < 3; c++) {
+    const int hs = p->hshift[c], vs = p->vshift[c];
+    if (!hs && !vs) continue;
+    int cw = (p->xsize + (1 << hs) - 1) >> hs, chh = (p->ysize + (1 << vs) - 1) >> vs;
+    if (hs) {
+      jxlo_chroma_upsample_h(planes[c], cw, chh, stride, tmp[c], stride);
+      cw *= 2;
+      for (int y = 0; y < chh; y++) memcpy(planes[c] + (size_t)y * stride, tmp[c] + (size_t)y * stride, sizeof(float) * cw);
+    }
+    if (vs) {
+      jxlo_chroma_upsample_v(planes[c], cw, chh, stride, tmp[c], stride);
+      chh *= 2;
+      for (int y = 0; y < chh; y++) memcpy(planes[c] + (size_t)y * stride, tmp[c] + (size_t)y * stride, sizeof(float) * cw);
+    }
+  }
   /* stage list of frame/render.rs:569-622: gaborish, epf0 (iters>=3), epf1 (>=1), epf2 (>=2);
    * result always ends in planes[] */
   float* cur[3] = {planes[0], planes[1], planes[2]};

@@ -36,6 +36,7 @@ class FrameParams(C.Structure):
         ("epf_quant_mul", C.c_float), ("epf_pass0_sigma_scale", C.c_float),
         ("epf_pass2_sigma_scale", C.c_float), ("epf_border_sad_mul", C.c_float),
         ("do_lf_smoothing", C.c_int32),
+        ("hshift", C.c_int32 * 3), ("vshift", C.c_int32 * 3),
     ]
 
 
@@ -115,6 +116,15 @@ class Oracle:
         L.jxlo_vardct_frame.argtypes = [C.POINTER(FrameParams), ip, C.POINTER(C.c_uint8), ip,
                                         C.POINTER(C.c_uint8), C.POINTER(C.c_int8), C.POINTER(C.c_int8),
                                         pf3, pf3, pf3, pf3, C.c_size_t, C.c_int]
+        L.jxlo_dequant_lf_channel.argtypes = [C.POINTER(FrameParams), C.c_int, ip, C.c_float, C.c_size_t, fp]
+        for fn in (L.jxlo_chroma_upsample_h, L.jxlo_chroma_upsample_v):
+            fn.argtypes = [fp, C.c_int, C.c_int, C.c_size_t, fp, C.c_size_t]
+            fn.restype = None
+        L.jxlo_ycbcr_to_rgb.argtypes = [fp, fp, fp, C.c_size_t]
+        L.jxlo_ycbcr_to_rgb8.argtypes = [fp, fp, fp, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(C.c_uint8),
+                                         C.c_size_t, C.c_int]
+        L.jxlo_ycbcr_to_rgb16.argtypes = [fp, fp, fp, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(C.c_uint16),
+                                          C.c_size_t, C.c_int]
         L.jxlo_rct.argtypes = [ip, ip, ip, C.c_size_t, C.c_int, C.c_int]
         L.jxlo_palette.argtypes = [ip, C.c_size_t, ip, C.c_int, C.c_size_t, C.c_int, C.c_int, ip]
         L.jxlo_unsqueeze_h.argtypes = [ip, C.c_size_t, ip, C.c_size_t, C.c_int, C.c_int, ip, C.c_size_t]
@@ -383,6 +393,40 @@ class Oracle:
         out = np.zeros((h, w, channels), dtype=np.uint16)
         self.lib.jxlo_xyb_to_rgb16(_ptr(p, C.c_float), _ptr(pl[0], C.c_float), _ptr(pl[1], C.c_float),
                                    _ptr(pl[2], C.c_float), w, h, stride, _ptr(out, C.c_uint16), w * channels, channels)
+        return out
+
+    # ---- sub-sampled (JPEG-recompression) frames ----
+    def dequant_lf_channel(self, p, c, q, mul=1.0):
+        q = np.ascontiguousarray(q, dtype=np.int32)
+        out = np.zeros(q.shape, dtype=np.float32)
+        self.lib.jxlo_dequant_lf_channel(C.byref(p), c, _ptr(q, C.c_int32), C.c_float(mul), q.size, _ptr(out, C.c_float))
+        return out
+
+    def chroma_upsample(self, plane, horizontal):
+        plane = _f32(plane)
+        hs, ws = plane.shape
+        out = np.zeros((hs, 2 * ws) if horizontal else (2 * hs, ws), dtype=np.float32)
+        fn = self.lib.jxlo_chroma_upsample_h if horizontal else self.lib.jxlo_chroma_upsample_v
+        fn(_ptr(plane, C.c_float), ws, hs, ws, _ptr(out, C.c_float), out.shape[1])
+        return out
+
+    def ycbcr_to_rgb(self, cb, y, cr):
+        a = [_f32(v).copy() for v in (cb, y, cr)]
+        self.lib.jxlo_ycbcr_to_rgb(_ptr(a[0], C.c_float), _ptr(a[1], C.c_float), _ptr(a[2], C.c_float), a[0].size)
+        return a  # R, G, B
+
+    def ycbcr_to_rgb8(self, planes, w, h, channels=3):
+        pl = [np.ascontiguousarray(a, dtype=np.float32) for a in planes]
+        out = np.zeros((h, w, channels), dtype=np.uint8)
+        self.lib.jxlo_ycbcr_to_rgb8(_ptr(pl[0], C.c_float), _ptr(pl[1], C.c_float), _ptr(pl[2], C.c_float), w, h,
+                                    pl[0].shape[1], _ptr(out, C.c_uint8), w * channels, channels)
+        return out
+
+    def ycbcr_to_rgb16(self, planes, w, h, channels=3):
+        pl = [np.ascontiguousarray(a, dtype=np.float32) for a in planes]
+        out = np.zeros((h, w, channels), dtype=np.uint16)
+        self.lib.jxlo_ycbcr_to_rgb16(_ptr(pl[0], C.c_float), _ptr(pl[1], C.c_float), _ptr(pl[2], C.c_float), w, h,
+                                     pl[0].shape[1], _ptr(out, C.c_uint16), w * channels, channels)
         return out
 
     # ---- sparse coefficient transport ----

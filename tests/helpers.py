@@ -3,11 +3,23 @@ through the HIP path (via the C ABI), and forward-squeeze for round-trip propert
 import numpy as np
 
 
+def _set_shifts(p, wl):
+    for c in range(3):
+        p.hshift[c] = wl.opts.get("hshift", (0, 0, 0))[c]
+        p.vshift[c] = wl.opts.get("vshift", (0, 0, 0))[c]
+
+
+def is_subsampled(wl):
+    return any(wl.opts.get("hshift", (0, 0, 0))) or any(wl.opts.get("vshift", (0, 0, 0)))
+
+
 def oracle_params_from(o, wl, **over):
     p = o.default_params(wl.xsize, wl.ysize)
     p.epf_iters = wl.opts.get("epf_iters", 2)
     p.gab = 1 if wl.opts.get("gab", True) else 0
     p.do_lf_smoothing = 1 if wl.opts.get("lf_smoothing", True) else 0
+    _set_shifts(p, wl)
+    p.xsize_blocks, p.ysize_blocks = wl.xblocks, wl.yblocks
     for k, v in over.items():
         setattr(p, k, v)
     return p
@@ -18,6 +30,7 @@ def gpu_params_from(ctx, wl, **over):
     p.epf_iters = wl.opts.get("epf_iters", 2)
     p.gab = 1 if wl.opts.get("gab", True) else 0
     p.do_lf_smoothing = 1 if wl.opts.get("lf_smoothing", True) else 0
+    _set_shifts(p, wl)
     for k, v in over.items():
         setattr(p, k, v)
     return p
@@ -26,7 +39,11 @@ def gpu_params_from(ctx, wl, **over):
 def run_oracle_frame(o, wl, num_threads=8, tables=None, **over):
     """Whole chain on the CPU oracle.  Returns (planes cropped to the frame, smoothed LF)."""
     p = oracle_params_from(o, wl, **over)
-    lf = o.dequant_lf(p, *wl.lf_q)
+    if is_subsampled(wl):  # no chroma-from-luma; channel c <- its own coded plane (Y, X, B order in lf_q)
+        lf = [o.dequant_lf_channel(p, 0, wl.lf_q[1]), o.dequant_lf_channel(p, 1, wl.lf_q[0]),
+              o.dequant_lf_channel(p, 2, wl.lf_q[2])]
+    else:
+        lf = o.dequant_lf(p, *wl.lf_q)
     tables = wl.tables if tables is None else tables
     planes, lf_sm = o.vardct_frame(p, wl.coeffs, wl.transform_map, wl.raw_quant, wl.epf_map, wl.ytox, wl.ytob, lf,
                                    tables, num_threads=num_threads)

@@ -186,15 +186,109 @@ def test_invalid_transform_id_is_reported(ctx):
     assert e.value.status == lib.ERR_INVALID_TRANSFORM
 
 
-def test_chroma_subsampled_frame_is_unsupported(ctx):
-    """4:2:0 / 4:2:2 (JPEG recompression) frames keep the reference's CPU path: JXLH_ERR_UNSUPPORTED"""
-    from jxl_rs_amd import lib, JxlHipError
+# ---------------------------------------------------------------- chroma-subsampled (JPEG-recompression) frames
+SUBSAMPLINGS = {
+    "420": ((1, 0, 1), (1, 0, 1)),
+    "422": ((1, 0, 1), (0, 0, 0)),
+    "440": ((0, 0, 0), (1, 0, 1)),
+    "mixed": ((1, 0, 0), (0, 0, 1)),   # Cb halved horizontally, Cr vertically
+    "luma": ((0, 1, 0), (0, 1, 0)),    # any channel may be the sub-sampled one
+}
+SUB_CASES = [
+    (64, 64, "420", dict(epf_iters=0, gab=False, lf_smoothing=False)),      # what a recompressed JPEG looks like
+    (300, 270, "420", dict(epf_iters=0, gab=False, lf_smoothing=False)),    # two group columns, ragged
+    (515, 389, "420", dict(epf_iters=2, gab=True, lf_smoothing=True)),      # filters after the upsampling (tiled K1)
+    (515, 389, "422", dict(epf_iters=0, gab=False, lf_smoothing=True)),
+    (333, 77, "440", dict(epf_iters=1, gab=True, lf_smoothing=False)),
+    (257, 263, "mixed", dict(epf_iters=3, gab=True, lf_smoothing=True)),
+    (97, 131, "luma", dict(epf_iters=2, gab=False, lf_smoothing=False)),
+    (9, 7, "420", dict(epf_iters=2, gab=True, lf_smoothing=True)),          # chroma is a single block
+    (2100, 40, "420", dict(epf_iters=0, gab=False, lf_smoothing=False)),    # crosses an LF group: corner-packed LF
+]
+
+
+@pytest.mark.parametrize("case", SUB_CASES, ids=lambda c: f"{c[0]}x{c[1]}-{c[2]}-epf{c[3]['epf_iters']}")
+def test_subsampled_frame_bit_exact(ctx, oracle, case):
+    """K1e (frame/group.rs:223-250, :443-504) + chroma upsampling (render/stages/chroma_upsample.rs) + the
+    filter chain, dense and sparse submission, fused and per-stage filters"""
+    from jxl_rs_amd import synth
+    w, h, sub, opts = case
+    hs, vs = SUBSAMPLINGS[sub]
+    wl = synth.make_vardct(w, h, mix=synth.MIX_8X8, seed=w + 3 * h, hshift=hs, vshift=vs, **opts)
+    want, want_lf = run_oracle_frame(oracle, wl)
+    for flags in (0, 1):
+        got, got_lf = run_gpu_frame(ctx, wl, flags=flags)
+        for c in range(3):
+            assert bit_equal(got_lf[c], want_lf[c]), f"flags={flags} LF ch{c}: {diff_report(got_lf[c], want_lf[c])}"
+            assert bit_equal(got[c], want[c]), f"flags={flags} plane {c}: {diff_report(got[c], want[c])}"
+    # sparse submission: the transforms read the pairs
+    p = gpu_params_from(ctx, wl)
+    ctx.frame_begin(p)
+    ctx.set_dequant_tables(wl.tables)
+    ctx.set_lf_quantized(*wl.lf_q)
+    ctx.set_hf_meta(wl.transform_map, wl.raw_quant, wl.epf_map, wl.ytox, wl.ytob)
+    for g in range(wl.coeffs.shape[0]):
+        pairs, n, wide = synth.to_sparse(wl.coeffs[g])
+        ctx.submit_group_sparse(g, pairs, n, wide)
+    ctx.slot_wait(0)
+    ctx.frame_run()
+    ctx.sync()
+    got = ctx.read_planes()
+    for c in range(3):
+        assert bit_equal(got[c], want[c]), f"sparse plane {c}: {diff_report(got[c], want[c])}"
+
+
+def test_subsampled_frame_rejects_large_varblocks(ctx):
+    """Error::InvalidBlockSizeForChromaSubsampling (frame/modular/mod.rs:1058-1060)"""
+    from jxl_rs_amd import synth, lib, JxlHipError
+    wl = synth.make_vardct(128, 128, mix=synth.MIX_D1, seed=2, epf_iters=0, gab=False)
+    wl.opts["hshift"], wl.opts["vshift"] = (1, 0, 1), (1, 0, 1)
+    upload_frame(ctx, wl)
+    ctx.frame_run()
+    with pytest.raises(JxlHipError) as e:
+        ctx.sync()
+    assert e.value.status == lib.ERR_INVALID_BLOCK_SIZE
     p = ctx.default_params(64, 64)
-    p.hshift[0] = 1
-    p.hshift[2] = 1
+    p.hshift[0] = 2
     with pytest.raises(JxlHipError) as e:
         ctx.frame_begin(p)
-    assert e.value.status == lib.ERR_UNSUPPORTED
+    assert e.value.status == lib.ERR_INVALID_ARGUMENT
+
+
+@pytest.mark.parametrize("shape", [(1, 3), (3, 1), (1, 1), (37, 53), (256, 300), (5, 1024)])
+def test_chroma_upsample_stage_bit_exact(ctx, oracle, kat, shape):
+    """HorizontalChromaUpsample / VerticalChromaUpsample hooks vs the oracle (and the reference's own vectors)"""
+    rng = np.random.default_rng(shape[0] * 1000 + shape[1])
+    plane = rng.standard_normal(shape).astype(np.float32)
+    for horizontal in (True, False):
+        got = ctx.stage_chroma_upsample(plane, horizontal)
+        assert bit_equal(got, oracle.chroma_upsample(plane, horizontal)), f"horizontal={horizontal}"
+    k = kat["chroma_upsample"]
+    assert np.array_equal(ctx.stage_chroma_upsample(np.array([k["input"]], np.float32), True)[0], np.float32(k["expected"]))
+    assert np.array_equal(ctx.stage_chroma_upsample(np.array([k["input"]], np.float32).T, False)[:, 0], np.float32(k["expected"]))
+
+
+@pytest.mark.parametrize("size,sub,channels", [((300, 270), "420", 3), ((97, 131), "422", 4), ((64, 64), "440", 3)])
+def test_ycbcr_output_bit_exact(ctx, oracle, size, sub, channels):
+    """a recompressed JPEG end to end: K1e, chroma upsampling, YcbcrToRgbStage, ConvertF32ToU8/U16"""
+    from jxl_rs_amd import synth
+    w, h = size
+    hs, vs = SUBSAMPLINGS[sub]
+    wl = synth.make_vardct(w, h, mix=synth.MIX_8X8, seed=w ^ h, epf_iters=0, gab=False, lf_smoothing=False, hshift=hs, vshift=vs)
+    wl.lf_q[0] = wl.lf_q[0] // 3   # keep Y + 128/255 inside [0, 1] so the clamps are not the whole story
+    want_planes, _ = run_oracle_frame(oracle, wl)
+    want8 = oracle.ycbcr_to_rgb8(want_planes, w, h, channels)
+    want16 = oracle.ycbcr_to_rgb16(want_planes, w, h, channels)
+    upload_frame(ctx, wl)
+    ctx.frame_run()
+    ctx.sync()
+    got8 = ctx.read_ycbcr_rgb8(channels)
+    bad = np.argwhere(got8 != want8)
+    assert bad.size == 0, f"{len(bad)} differing bytes, first at {bad[0]}"
+    assert np.array_equal(ctx.read_ycbcr_rgb16(channels), want16)
+    y0, y1 = h // 3, (2 * h) // 3
+    assert np.array_equal(ctx.read_ycbcr_rgb8(channels, y0, y1), want8[y0:y1])
+    assert len(np.unique(want8)) > 16
 
 
 def test_call_order_errors(ctx):

@@ -221,3 +221,62 @@ def test_tendency_clamps_equal_min_form_on_full_i32_range(oracle_any):
         triples += [tuple(int(v) for v in t) for t in arr]
     for a, b, c in triples:
         assert min_form(a, b, c) == L.jxlo_smooth_tendency_i32(a, b, c), (a, b, c)
+
+
+# ---------------------------------------------------------------- chroma-subsampled frames
+def test_chroma_upsample_known_answers(oracle_any, kat):
+    """the reference's own vectors, exact (render/stages/chroma_upsample.rs:200-236)"""
+    k = kat["chroma_upsample"]
+    row = np.array([k["input"]], np.float32)
+    assert np.array_equal(oracle_any.chroma_upsample(row, True)[0], np.float32(k["expected"]))
+    assert np.array_equal(oracle_any.chroma_upsample(row.T, False)[:, 0], np.float32(k["expected"]))
+    # a constant plane stays constant, a single sample is replicated (mirror on both sides)
+    assert np.array_equal(oracle_any.chroma_upsample(np.full((3, 5), 0.37, np.float32), True), np.full((3, 10), np.float32(0.37)))
+    assert np.array_equal(oracle_any.chroma_upsample(np.array([[2.5]], np.float32), False), np.full((2, 1), np.float32(2.5)))
+
+
+def test_ycbcr_stage_known_answer(oracle_any, kat):
+    """render/stages/ycbcr.rs:126-152: the three sRGB primaries"""
+    k = kat["ycbcr"]
+    rgb = oracle_any.ycbcr_to_rgb(k["cb"], k["y"], k["cr"])
+    for c in range(3):
+        assert np.max(np.abs(rgb[c] - np.float32(k["expected_rgb"][c]))) <= k["tol"]
+    # grey: Cb = Cr = 0 leaves R = G = B = Y + 128/255
+    r, g, b = oracle_any.ycbcr_to_rgb([0.0], [0.25], [0.0])
+    assert r[0] == g[0] == b[0] == np.float32(0.25) + np.float32(128.0) / np.float32(255.0)
+
+
+@pytest.mark.parametrize("sub", [((1, 0, 1), (1, 0, 1)), ((1, 0, 1), (0, 0, 0)), ((0, 0, 0), (1, 0, 1)), ((1, 0, 0), (0, 0, 1))])
+def test_subsampled_frame_is_the_444_decode_of_the_aligned_blocks(oracle, sub):
+    """Structure of K1e (frame/group.rs:223-250, :485-504): with a constant LF image, a sub-sampled channel is
+    the 4:4:4 reconstruction of the blocks aligned to its sampling, gathered and chroma-upsampled; the other
+    channels are untouched."""
+    import copy
+    from jxl_rs_amd import synth
+    from helpers import oracle_params_from, run_oracle_frame
+    hs, vs = sub
+    wl = synth.make_vardct(300, 270, mix=synth.MIX_8X8, seed=5, epf_iters=0, gab=False, lf_smoothing=False, hshift=hs, vshift=vs)
+    for i, v in enumerate((700, 3, -40)):
+        wl.lf_q[i][:] = v
+    got, _ = run_oracle_frame(oracle, wl)
+    wl0 = copy.copy(wl)
+    wl0.opts = dict(wl.opts, hshift=(0, 0, 0), vshift=(0, 0, 0))
+    p0 = oracle_params_from(oracle, wl0)
+    p0.xsize_blocks, p0.ysize_blocks = wl.xblocks, wl.yblocks
+    lf = [oracle.dequant_lf_channel(p0, 0, wl.lf_q[1]), oracle.dequant_lf_channel(p0, 1, wl.lf_q[0]),
+          oracle.dequant_lf_channel(p0, 2, wl.lf_q[2])]
+    full = [np.zeros((wl.yblocks * 8, wl.xblocks * 8), np.float32) for _ in range(3)]
+    for g in range(wl.coeffs.shape[0]):
+        oracle.decode_group(p0, g, wl.coeffs[g], wl.transform_map, wl.raw_quant, wl.ytox, wl.ytob, lf, wl.tables, full)
+    for c in range(3):
+        H, W = full[c].shape
+        b = full[c].reshape(H // 8, 8, W // 8, 8)[::1 << vs[c], :, ::1 << hs[c], :]
+        sub_plane = b.reshape(b.shape[0] * 8, b.shape[2] * 8)
+        cw, ch = -(-wl.xsize // (1 << hs[c])), -(-wl.ysize // (1 << vs[c]))
+        sub_plane = np.ascontiguousarray(sub_plane[:ch, :cw])
+        if hs[c]:
+            sub_plane = oracle.chroma_upsample(sub_plane, True)
+        if vs[c]:
+            sub_plane = oracle.chroma_upsample(sub_plane, False)
+        want = sub_plane[:wl.ysize, :wl.xsize]
+        assert np.array_equal(got[c].view(np.uint32), want.view(np.uint32)), f"channel {c}"

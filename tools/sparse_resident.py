@@ -30,3 +30,8 @@ for _ in range(N):
     c.frame_run()
 c.sync()
 print("sparse-resident ms/frame:", (time.perf_counter() - t0) / N * 1e3)
+c.kernel_timing(True)
+for _ in range(N):
+    c.frame_run()
+c.sync()
+print({k: round(v[0] / N, 4) for k, v in c.kernel_times().items()})
