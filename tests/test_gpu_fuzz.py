@@ -103,3 +103,49 @@ def test_random_frames_and_header_parameters_bit_exact(ctx, oracle, kat, seed):
     channels = 3 + seed % 2
     want8 = oracle.xyb_to_rgb8(xp, [np.ascontiguousarray(p) for p in want], w, h, channels)
     assert np.array_equal(ctx.read_rgb8(xp, channels), want8), f"rgb8 {desc}"
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_subsampled_frames_bit_exact(ctx, oracle, seed):
+    """Chroma-subsampled frames: random per-channel shifts (each 0 or 1, any channel), ragged sizes, every 8x8
+    transform, random stage lists and header parameters; ends in the YCbCr -> RGB8 output."""
+    from jxl_rs_amd import synth
+    import helpers
+    rng = np.random.default_rng(5000 + seed)
+    w, h, _, opts, over, arrays = _random_case(rng)
+    hs = tuple(int(v) for v in rng.integers(0, 2, 3))
+    vs = tuple(int(v) for v in rng.integers(0, 2, 3))
+    if not (any(hs) or any(vs)):
+        hs = (1, 0, 1)
+    wl = synth.make_vardct(w, h, mix=synth.MIX_8X8, seed=seed, hshift=hs, vshift=vs, **opts)
+    po = helpers.oracle_params_from(oracle, wl, **over)
+    _apply_arrays(po, arrays)
+    lf = [oracle.dequant_lf_channel(po, 0, wl.lf_q[1]), oracle.dequant_lf_channel(po, 1, wl.lf_q[0]),
+          oracle.dequant_lf_channel(po, 2, wl.lf_q[2])]
+    planes, lf_sm = oracle.vardct_frame(po, wl.coeffs, wl.transform_map, wl.raw_quant, wl.epf_map, wl.ytox, wl.ytob,
+                                        lf, wl.tables, num_threads=8)
+    want = [pl[:h, :w] for pl in planes]
+    pg = helpers.gpu_params_from(ctx, wl, **over)
+    _apply_arrays(pg, arrays)
+    pg.flags = seed % 3 == 2  # every third case on the one-kernel-per-stage filters
+    ctx.frame_begin(pg)
+    ctx.set_dequant_tables(wl.tables)
+    ctx.set_lf_quantized(*wl.lf_q)
+    ctx.set_hf_meta(wl.transform_map, wl.raw_quant, wl.epf_map, wl.ytox, wl.ytob)
+    for g in range(wl.coeffs.shape[0]):
+        if seed % 2:
+            ctx.submit_group_sparse(g, *synth.to_sparse(wl.coeffs[g]))
+        else:
+            ctx.submit_group(g, wl.coeffs[g])
+    ctx.slot_wait(0)
+    ctx.frame_run()
+    ctx.sync()
+    got = ctx.read_planes()
+    got_lf = ctx.read_lf()
+    desc = f"{w}x{h} h{hs} v{vs} {opts} {sorted(over)} {sorted(arrays)}"
+    for c in range(3):
+        assert bit_equal(got_lf[c], lf_sm[c]), f"LF ch{c} {desc}: {diff_report(got_lf[c], lf_sm[c])}"
+        assert bit_equal(got[c], want[c]), f"plane {c} {desc}: {diff_report(got[c], want[c])}"
+    channels = 3 + seed % 2
+    want8 = oracle.ycbcr_to_rgb8([np.ascontiguousarray(p) for p in want], w, h, channels)
+    assert np.array_equal(ctx.read_ycbcr_rgb8(channels), want8), f"rgb8 {desc}"
