@@ -81,6 +81,12 @@ typedef struct {
  *                           (frame/group.rs:223-250) and the chroma upsampling stages
  *                           (render/stages/chroma_upsample.rs, frame/render.rs:569-576) run before Gaborish /
  *                           EPF, so everything downstream sees full-resolution planes.
+ *   upsampling ............. FrameHeader::upsampling (1, 2, 4 or 8; 0 means 1).  xsize / ysize are then the CODED
+ *                           size FrameHeader::size() = ceil(size_upsampled / upsampling) (:555-561) and
+ *                           xsize_upsampled / ysize_upsampled the image size after the Upsample2x/4x/8x stages
+ *                           (0 = xsize * upsampling); the stages run on the three colour channels after the
+ *                           filters (frame/render.rs:655-671) and every jxlh_frame_read_* call then returns the
+ *                           upsampled image.  Such a frame is run whole (JXLH_ERR_UNSUPPORTED for a band).
  *   epf_sigma_for_modular .. RestorationFilter field used when EPF runs on a Modular frame
  *                           (features/epf.rs:81-84); carried for completeness, VarDCT frames ignore it
  */
@@ -104,6 +110,8 @@ typedef struct {
   uint32_t flags; /* JXLH_FRAME_* */
   uint32_t hshift[3], vshift[3];
   float epf_sigma_for_modular;
+  uint32_t upsampling;
+  uint32_t xsize_upsampled, ysize_upsampled;
 } jxlh_frame_params;
 
 enum {
@@ -133,6 +141,12 @@ jxlh_status jxlh_free_pinned(jxlh_ctx* ctx, void* p);
 /* Replaces Frame::from_header_and_toc's LF / HfMetadata allocation
  * (frame/decode.rs:172-204) + prepare_render_pipeline (frame/render.rs:907). */
 jxlh_status jxlh_frame_begin(jxlh_ctx* ctx, const jxlh_frame_params* p);
+
+/* CustomTransformData::weights2 / weights4 / weights8 (headers/transform_data.rs:337-344): 15 / 55 / 210 weights
+ * of the 2x / 4x / 8x upsampling kernels; NULL selects the codestream defaults (DEFAULT_KERN_*, :34-333).
+ * Per decoder like the reference's file header: persists across frames; callable outside a frame. */
+jxlh_status jxlh_set_upsampling_weights(jxlh_ctx* ctx, const float* weights2, const float* weights4,
+                                        const float* weights8);
 
 /* HfGlobalState::dequant_matrices (frame/quant_weights.rs:347-351): 17 tables, table t holds
  * 3 * n[t] inverse weights, channel-major (matrix(type, c), :1081-1086). */
@@ -278,6 +292,9 @@ jxlh_status jxlh_stage_epf(jxlh_ctx* ctx, int32_t stage, const jxlh_frame_params
  * tight w x h plane, edges mirrored (render/stages/chroma_upsample.rs:31-63, :108-147) */
 jxlh_status jxlh_stage_chroma_upsample(jxlh_ctx* ctx, const float* in, float* out, uint32_t w, uint32_t h,
                                        int32_t horizontal);
+/* Upsample2x / 4x / 8x (render/stages/upsample.rs) on a tight w x h plane -> (n*w) x (n*h), n = 2, 4, 8, with the
+ * weights of jxlh_set_upsampling_weights; input mirrored 2 pixels at its edges */
+jxlh_status jxlh_stage_upsample(jxlh_ctx* ctx, int32_t n, const float* in, float* out, uint32_t w, uint32_t h);
 /* adaptive_lf_smoothing on w x h tight planes (frame/adaptive_lf_smoothing.rs:44-125) */
 jxlh_status jxlh_stage_lf_smooth(jxlh_ctx* ctx, const jxlh_frame_params* p, const float* const in[3],
                                  float* const out[3], uint32_t w, uint32_t h);

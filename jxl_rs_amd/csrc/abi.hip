@@ -65,6 +65,12 @@ struct jxlh_ctx {
   int* host_flag = nullptr;  // pinned
   DevBuf<uint8_t> worklist;
   float* result[3] = {nullptr, nullptr, nullptr};
+  // geometry of `result`: the frame itself, or its upsampled image (frame_header.upsampling > 1)
+  int res_w = 0, res_h = 0;
+  size_t res_stride = 0;
+  DevBuf<float> ups[3];        // upsampled planes
+  DevBuf<float> ups_kernels;   // expanded 5x5 kernels of the frame's factor
+  std::vector<float> ups_weights[3];  // custom weights2 / weights4 / weights8 (empty = defaults)
   // stage hooks scratch
   DevBuf<float> hook_f[8];
   DevBuf<int32_t> hook_i[4];
@@ -312,6 +318,8 @@ void jxlh_ctx_destroy(jxlh_ctx* ctx) {
   release(ctx->ytob);
   release(ctx->error_flag);
   release(ctx->rgb8);
+  for (auto& b : ctx->ups) release(b);
+  release(ctx->ups_kernels);
   if (ctx->host_flag) (void)hipHostFree(ctx->host_flag);
   release(ctx->worklist);
   for (auto& b : ctx->hook_f) release(b);
@@ -341,6 +349,14 @@ jxlh_status jxlh_frame_begin(jxlh_ctx* ctx, const jxlh_frame_params* p) {
     return JXLH_ERR_INVALID_ARGUMENT;
   // chroma subsampling (JPEG recompressions): jpeg_upsampling gives shifts of 0 or 1 per axis and channel,
   // relative to the most finely sampled channel (headers/frame_header.rs:252-253, :501-512)
+  if (p->upsampling > 1 && p->upsampling != 2 && p->upsampling != 4 && p->upsampling != 8) return JXLH_ERR_INVALID_ARGUMENT;
+  if (p->upsampling > 1) {  // FrameHeader::size() = ceil(size_upsampled / upsampling) (headers/frame_header.rs:555-561)
+    const uint32_t n = p->upsampling;
+    if (p->xsize_upsampled > p->xsize * n || p->ysize_upsampled > p->ysize * n ||
+        (p->xsize_upsampled && (p->xsize_upsampled + n - 1) / n != p->xsize) ||
+        (p->ysize_upsampled && (p->ysize_upsampled + n - 1) / n != p->ysize))
+      return JXLH_ERR_INVALID_ARGUMENT;
+  }
   uint32_t maxhs = 0, maxvs = 0;
   for (int c = 0; c < 3; c++) {
     if (p->hshift[c] > 1 || p->vshift[c] > 1) return JXLH_ERR_INVALID_ARGUMENT;
@@ -446,6 +462,18 @@ jxlh_status jxlh_frame_begin(jxlh_ctx* ctx, const jxlh_frame_params* p) {
   ctx->lf_smoothed = false;
   for (auto& s : ctx->slots) s.used = false;
   for (int c = 0; c < 3; c++) ctx->result[c] = nullptr;
+  return JXLH_OK;
+}
+
+jxlh_status jxlh_set_upsampling_weights(jxlh_ctx* ctx, const float* weights2, const float* weights4,
+                                        const float* weights8) {
+  if (!ctx) return JXLH_ERR_INVALID_ARGUMENT;
+  const float* src[3] = {weights2, weights4, weights8};
+  const size_t cnt[3] = {15, 55, 210};
+  for (int i = 0; i < 3; i++) {
+    if (src[i]) ctx->ups_weights[i].assign(src[i], src[i] + cnt[i]);
+    else ctx->ups_weights[i].clear();
+  }
   return JXLH_OK;
 }
 
@@ -668,6 +696,39 @@ jxlh_status jxlh_frame_coeff_buffer(jxlh_ctx* ctx, int32_t** device_ptr, size_t*
   return JXLH_OK;
 }
 
+namespace {
+#include "upsampling_weights.inc"
+// Upsample::new (render/stages/upsample.rs:31-66): the 15 / 55 / 210 weights are the upper triangle of the
+// symmetric top-left quadrant of the (5n/2 x 2)^2 kernel image; expands to n*n kernels of 5x5 taps
+void expand_upsampling_kernels(int n, const float* weights, float* flat) {
+  const int half = n / 2, last = n - 1;
+  for (int i = 0; i < 5 * half; i++) {
+    for (int j = 0; j < 5 * half; j++) {
+      const int y = std::min(i, j), x = std::max(i, j);
+      const float wv = weights[5 * half * y - y * (y - 1) / 2 + x - y];
+      const int oy = j / 5, ox = i / 5, ky = j % 5, kx = i % 5;
+      flat[(oy * n + ox) * 25 + ky * 5 + kx] = wv;
+      flat[((last - oy) * n + ox) * 25 + (4 - ky) * 5 + kx] = wv;
+      flat[(oy * n + (last - ox)) * 25 + ky * 5 + (4 - kx)] = wv;
+      flat[((last - oy) * n + (last - ox)) * 25 + (4 - ky) * 5 + (4 - kx)] = wv;
+    }
+  }
+}
+
+jxlh_status upload_upsampling_kernels(jxlh_ctx* ctx, int n) {
+  const int slot = n == 2 ? 0 : n == 4 ? 1 : 2;
+  const float* dflt = n == 2 ? kDefaultUpsamplingWeights2 : n == 4 ? kDefaultUpsamplingWeights4 : kDefaultUpsamplingWeights8;
+  const float* w = ctx->ups_weights[slot].empty() ? dflt : ctx->ups_weights[slot].data();
+  std::vector<float> flat((size_t)n * n * 25);
+  expand_upsampling_kernels(n, w, flat.data());
+  if (jxlh_status st = ensure(ctx, ctx->ups_kernels, flat.size())) return st;
+  // pageable source: the copy is staged by the runtime before the call returns
+  HIPCHK(ctx, hipMemcpyAsync(ctx->ups_kernels.p, flat.data(), flat.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return JXLH_OK;
+}
+}  // namespace
+
 jxlh_status jxlh_frame_run(jxlh_ctx* ctx, uint32_t group_row0, uint32_t group_row1) {
   if (!ctx) return JXLH_ERR_INVALID_ARGUMENT;
   if (!ctx->in_frame || !ctx->tables_set) return JXLH_ERR_BAD_STATE;
@@ -857,6 +918,30 @@ jxlh_status jxlh_frame_run(jxlh_ctx* ctx, uint32_t group_row0, uint32_t group_ro
     }
   }
   for (int c = 0; c < 3; c++) ctx->result[c] = cur[c];
+  ctx->res_w = f.xsize;
+  ctx->res_h = f.ysize;
+  ctx->res_stride = f.plane_stride;
+  if (p.upsampling > 1) {
+    // Upsample2x/4x/8x on the three colour channels (frame/render.rs:655-671).  The 5x5 window crosses band
+    // edges, so an upsampled frame is run whole.
+    if (group_row0 != 0 || group_row1 != (uint32_t)f.ygroups) return JXLH_ERR_UNSUPPORTED;
+    const int n = (int)p.upsampling;
+    const int ow = p.xsize_upsampled ? (int)p.xsize_upsampled : f.xsize * n;
+    const int oh = p.ysize_upsampled ? (int)p.ysize_upsampled : f.ysize * n;
+    const size_t ostride = round_up((size_t)f.xsize * n, 64);
+    if (jxlh_status st = upload_upsampling_kernels(ctx, n)) return st;
+    for (int c = 0; c < 3; c++)
+      if (jxlh_status st = ensure(ctx, ctx->ups[c], ostride * (size_t)f.ysize * n)) return st;
+    ScopedKernelTimer t(ctx, "k_upsample");
+    for (int c = 0; c < 3; c++) {
+      launch_upsample(ctx->stream, n, cur[c], f.plane_stride, f.xsize, f.ysize, ctx->ups_kernels.p, ctx->ups[c].p,
+                      ostride, ow, oh);
+      ctx->result[c] = ctx->ups[c].p;
+    }
+    ctx->res_w = ow;
+    ctx->res_h = oh;
+    ctx->res_stride = ostride;
+  }
   HIPCHK(ctx, hipGetLastError());
   return JXLH_OK;
 }
@@ -893,31 +978,30 @@ jxlh_status read_rgb8(jxlh_ctx* ctx, const jxlh_xyb_params* p, uint32_t channels
                       size_t bytes_per_row) {
   if (!ctx || !out || (channels != 3 && channels != 4)) return JXLH_ERR_INVALID_ARGUMENT;
   if (!ctx->in_frame || !ctx->result[0]) return JXLH_ERR_BAD_STATE;
-  const FrameDev& f = ctx->fd;
-  if (y1 > (uint32_t)f.ysize) y1 = (uint32_t)f.ysize;
-  if (y0 >= y1 || bytes_per_row < (size_t)f.xsize * channels) return JXLH_ERR_INVALID_ARGUMENT;
+  if (y1 > (uint32_t)ctx->res_h) y1 = (uint32_t)ctx->res_h;
+  if (y0 >= y1 || bytes_per_row < (size_t)ctx->res_w * channels) return JXLH_ERR_INVALID_ARGUMENT;
   XybParamsDev dv;
   const XybParamsDev* d = xyb_params_dev(p, &dv);
   const int rows = (int)(y1 - y0);
   const float* planes[3] = {ctx->result[0], ctx->result[1], ctx->result[2]};
   if (is_device_ptr(out)) {
     ScopedKernelTimer t(ctx, "k_xyb_to_rgb8");
-    launch_xyb_to_rgb8(ctx->stream, planes, f.plane_stride, f.xsize, (int)y0, rows, d, (int)channels,
+    launch_xyb_to_rgb8(ctx->stream, planes, ctx->res_stride, ctx->res_w, (int)y0, rows, d, (int)channels,
                        static_cast<uint8_t*>(out), bytes_per_row);
     HIPCHK(ctx, hipGetLastError());
     return JXLH_OK;
   }
   // staging rows are dword aligned; when the caller's rows are tight and already aligned the D2H
   // is one linear copy, otherwise a 2-D copy of exactly the pixel bytes (row padding is never written)
-  const size_t tight = ((size_t)f.xsize * channels + 3) & ~(size_t)3;
+  const size_t tight = ((size_t)ctx->res_w * channels + 3) & ~(size_t)3;
   if (jxlh_status st = ensure(ctx, ctx->rgb8, tight * (size_t)rows)) return st;
   {
     ScopedKernelTimer t(ctx, "k_xyb_to_rgb8");
-    launch_xyb_to_rgb8(ctx->stream, planes, f.plane_stride, f.xsize, (int)y0, rows, d, (int)channels, ctx->rgb8.p,
+    launch_xyb_to_rgb8(ctx->stream, planes, ctx->res_stride, ctx->res_w, (int)y0, rows, d, (int)channels, ctx->rgb8.p,
                        tight);
   }
   HIPCHK(ctx, hipGetLastError());
-  const size_t row_bytes = (size_t)f.xsize * channels;
+  const size_t row_bytes = (size_t)ctx->res_w * channels;
   if (jxlh_status st = copy2d(ctx, out, bytes_per_row, ctx->rgb8.p, tight, row_bytes, (size_t)rows, ctx->stream))
     return st;
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -928,9 +1012,8 @@ jxlh_status read_rgb16(jxlh_ctx* ctx, const jxlh_xyb_params* p, uint32_t channel
                        size_t bytes_per_row) {
   if (!ctx || !out || (channels != 3 && channels != 4)) return JXLH_ERR_INVALID_ARGUMENT;
   if (!ctx->in_frame || !ctx->result[0]) return JXLH_ERR_BAD_STATE;
-  const FrameDev& f = ctx->fd;
-  if (y1 > (uint32_t)f.ysize) y1 = (uint32_t)f.ysize;
-  const size_t row_bytes = (size_t)f.xsize * channels * sizeof(uint16_t);
+  if (y1 > (uint32_t)ctx->res_h) y1 = (uint32_t)ctx->res_h;
+  const size_t row_bytes = (size_t)ctx->res_w * channels * sizeof(uint16_t);
   if (y0 >= y1 || bytes_per_row < row_bytes || bytes_per_row % sizeof(uint16_t) != 0 ||
       reinterpret_cast<uintptr_t>(out) % sizeof(uint16_t) != 0)
     return JXLH_ERR_INVALID_ARGUMENT;
@@ -940,7 +1023,7 @@ jxlh_status read_rgb16(jxlh_ctx* ctx, const jxlh_xyb_params* p, uint32_t channel
   const float* planes[3] = {ctx->result[0], ctx->result[1], ctx->result[2]};
   if (is_device_ptr(out)) {
     ScopedKernelTimer t(ctx, "k_xyb_to_rgb16");
-    launch_xyb_to_rgb16(ctx->stream, planes, f.plane_stride, f.xsize, (int)y0, rows, d, (int)channels,
+    launch_xyb_to_rgb16(ctx->stream, planes, ctx->res_stride, ctx->res_w, (int)y0, rows, d, (int)channels,
                         static_cast<uint16_t*>(out), bytes_per_row / sizeof(uint16_t));
     HIPCHK(ctx, hipGetLastError());
     return JXLH_OK;
@@ -948,8 +1031,8 @@ jxlh_status read_rgb16(jxlh_ctx* ctx, const jxlh_xyb_params* p, uint32_t channel
   if (jxlh_status st = ensure(ctx, ctx->rgb8, row_bytes * (size_t)rows)) return st;
   {
     ScopedKernelTimer t(ctx, "k_xyb_to_rgb16");
-    launch_xyb_to_rgb16(ctx->stream, planes, f.plane_stride, f.xsize, (int)y0, rows, d, (int)channels,
-                        reinterpret_cast<uint16_t*>(ctx->rgb8.p), (size_t)f.xsize * channels);
+    launch_xyb_to_rgb16(ctx->stream, planes, ctx->res_stride, ctx->res_w, (int)y0, rows, d, (int)channels,
+                        reinterpret_cast<uint16_t*>(ctx->rgb8.p), (size_t)ctx->res_w * channels);
   }
   HIPCHK(ctx, hipGetLastError());
   if (jxlh_status st = copy2d(ctx, out, bytes_per_row, ctx->rgb8.p, row_bytes, row_bytes, (size_t)rows, ctx->stream))
@@ -981,13 +1064,12 @@ jxlh_status jxlh_frame_read_ycbcr_rgb16(jxlh_ctx* ctx, uint32_t channels, uint32
 jxlh_status jxlh_frame_read_planes(jxlh_ctx* ctx, const jxlh_plane out[3]) {
   if (!ctx || !out) return JXLH_ERR_INVALID_ARGUMENT;
   if (!ctx->in_frame || !ctx->result[0]) return JXLH_ERR_BAD_STATE;
-  const FrameDev& f = ctx->fd;
   for (int c = 0; c < 3; c++) {
-    if (!out[c].ptr || out[c].bytes_per_row < (size_t)f.xsize * sizeof(float) || out[c].num_rows < (size_t)f.ysize ||
+    if (!out[c].ptr || out[c].bytes_per_row < (size_t)ctx->res_w * sizeof(float) || out[c].num_rows < (size_t)ctx->res_h ||
         out[c].bytes_between_rows < out[c].bytes_per_row)
       return JXLH_ERR_INVALID_ARGUMENT;
     jxlh_status st = copy2d(ctx, out[c].ptr, out[c].bytes_between_rows, ctx->result[c],
-                            f.plane_stride * sizeof(float), (size_t)f.xsize * sizeof(float), f.ysize, ctx->stream);
+                            ctx->res_stride * sizeof(float), (size_t)ctx->res_w * sizeof(float), ctx->res_h, ctx->stream);
     if (st != JXLH_OK) return st;
   }
   return jxlh_ctx_sync(ctx);
@@ -997,7 +1079,7 @@ jxlh_status jxlh_frame_device_planes(jxlh_ctx* ctx, float* planes[3], size_t* st
   if (!ctx || !planes) return JXLH_ERR_INVALID_ARGUMENT;
   if (!ctx->in_frame || !ctx->result[0]) return JXLH_ERR_BAD_STATE;
   for (int c = 0; c < 3; c++) planes[c] = ctx->result[c];
-  if (stride) *stride = ctx->fd.plane_stride;
+  if (stride) *stride = ctx->res_stride;
   return JXLH_OK;
 }
 
@@ -1197,6 +1279,22 @@ jxlh_status jxlh_stage_chroma_upsample(jxlh_ctx* ctx, const float* in, float* ou
                          (int)w, (int)h, 0, (int)h, ow, oh);
   HIPCHK(ctx, hipGetLastError());
   return stage_out(ctx, out, ctx->hook_f[1].p, 2 * n);
+}
+
+jxlh_status jxlh_stage_upsample(jxlh_ctx* ctx, int32_t n, const float* in, float* out, uint32_t w, uint32_t h) {
+  if (!ctx || !in || !out || (n != 2 && n != 4 && n != 8) || w > (1u << 20) || h > (1u << 20))
+    return JXLH_ERR_INVALID_ARGUMENT;
+  if (w == 0 || h == 0) return JXLH_OK;
+  const size_t ni = (size_t)w * h, no = ni * (size_t)n * n;
+  if (no >= (1ull << 32)) return JXLH_ERR_UNSUPPORTED;
+  jxlh_status st;
+  if ((st = stage_in(ctx, ctx->hook_f[0], in, ni))) return st;
+  if ((st = ensure(ctx, ctx->hook_f[1], no))) return st;
+  if ((st = upload_upsampling_kernels(ctx, n))) return st;
+  launch_upsample(ctx->stream, n, ctx->hook_f[0].p, w, (int)w, (int)h, ctx->ups_kernels.p, ctx->hook_f[1].p,
+                  (size_t)w * n, (int)w * n, (int)h * n);
+  HIPCHK(ctx, hipGetLastError());
+  return stage_out(ctx, out, ctx->hook_f[1].p, no);
 }
 
 jxlh_status jxlh_stage_transform_to_pixels(jxlh_ctx* ctx, int32_t type, uint32_t n, const float* coeffs,

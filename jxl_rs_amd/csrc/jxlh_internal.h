@@ -138,6 +138,9 @@ void launch_dequant_lf_plain(hipStream_t s, const int32_t* qy, const int32_t* qx
 void launch_chroma_upsample(hipStream_t s, const float* src, float* dst, const PixLayout& slay,
                             const PixLayout& dlay, int hshift, int vshift, int cw, int ch, int sy0, int sy1, int out_w,
                             int out_h);
+// upsample.rs: n = 2, 4, 8; kernels = n*n*25 expanded taps on the device; writes are clipped to out_w x out_h
+void launch_upsample(hipStream_t s, int n, const float* in, size_t in_stride, int w, int h, const float* kernels,
+                     float* out, size_t out_stride, int out_w, int out_h);
 void launch_lf_smooth(hipStream_t s, const float* const in[3], float* const out[3], int w, int h,
                       const float lf_factors[3]);
 void launch_sigma_map(hipStream_t s, const FrameDev& f, float epf_quant_mul, const float* sharp_lut);

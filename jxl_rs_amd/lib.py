@@ -35,7 +35,7 @@ ABI_SYMBOLS = [
     "jxlh_frame_set_lf_quantized", "jxlh_frame_set_lf", "jxlh_frame_set_hf_meta", "jxlh_submit_group",
     "jxlh_submit_group_sparse", "jxlh_submit_groups_sparse", "jxlh_slot_wait", "jxlh_frame_coeff_buffer", "jxlh_frame_run", "jxlh_ctx_sync", "jxlh_frame_read_planes",
     "jxlh_frame_device_planes", "jxlh_frame_read_lf", "jxlh_frame_read_rgb8", "jxlh_frame_read_rgb16",
-    "jxlh_frame_read_ycbcr_rgb8", "jxlh_frame_read_ycbcr_rgb16", "jxlh_stage_chroma_upsample", "jxlh_timer_start", "jxlh_timer_stop",
+    "jxlh_frame_read_ycbcr_rgb8", "jxlh_frame_read_ycbcr_rgb16", "jxlh_stage_chroma_upsample", "jxlh_stage_upsample", "jxlh_set_upsampling_weights", "jxlh_timer_start", "jxlh_timer_stop",
     "jxlh_kernel_timing_enable", "jxlh_kernel_timing_get", "jxlh_kernel_timing_reset", "jxlh_selftest_recip",
     "jxlh_stage_gaborish",
     "jxlh_stage_epf", "jxlh_stage_lf_smooth", "jxlh_stage_transform_to_pixels", "jxlh_rct", "jxlh_palette",
@@ -67,6 +67,8 @@ class FrameParams(C.Structure):
         ("flags", C.c_uint32),
         ("hshift", C.c_uint32 * 3), ("vshift", C.c_uint32 * 3),
         ("epf_sigma_for_modular", C.c_float),
+        ("upsampling", C.c_uint32),
+        ("xsize_upsampled", C.c_uint32), ("ysize_upsampled", C.c_uint32),
     ]
 
 
@@ -105,6 +107,8 @@ def load():
     L.jxlh_frame_read_ycbcr_rgb8.argtypes = [vp, u32, u32, u32, vp, sz]
     L.jxlh_frame_read_ycbcr_rgb16.argtypes = [vp, u32, u32, u32, vp, sz]
     L.jxlh_stage_chroma_upsample.argtypes = [vp, vp, vp, u32, u32, i32]
+    L.jxlh_stage_upsample.argtypes = [vp, i32, vp, vp, u32, u32]
+    L.jxlh_set_upsampling_weights.argtypes = [vp, vp, vp, vp]
     L.jxlh_selftest_recip.argtypes = [vp, u32, u32, C.POINTER(C.c_uint64)]
     L.jxlh_frame_set_dequant_tables.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
     L.jxlh_frame_set_lf_quantized.argtypes = [vp, u32, u32, u32, u32, vp, vp, vp, sz, u32]
@@ -276,8 +280,15 @@ class Context:
         self._chk(self.L.jxlh_ctx_sync(self._ctx), "ctx_sync")
         self._keep.clear()
 
+    @property
+    def out_size(self):
+        """(width, height) of what the jxlh_frame_read_* calls return: the frame, or its upsampled image"""
+        p = self.params
+        n = max(1, p.upsampling)
+        return (p.xsize_upsampled or p.xsize * n, p.ysize_upsampled or p.ysize * n)
+
     def read_planes(self):
-        w, h = self.params.xsize, self.params.ysize
+        w, h = self.out_size
         out = [np.zeros((h, w), dtype=np.float32) for _ in range(3)]
         planes = (Plane * 3)(*[Plane(o.ctypes.data, w * 4, h, w * 4) for o in out])
         self._chk(self.L.jxlh_frame_read_planes(self._ctx, planes), "frame_read_planes")
@@ -288,39 +299,39 @@ class Context:
         jxlh_xyb_params order.  out: optional device pointer (int) with tight rows; else a numpy array is returned."""
         pr = np.ascontiguousarray(xyb_params, dtype=np.float32)
         assert pr.size == 16
-        y1 = self.params.ysize if y1 is None else y1
+        y1 = self.out_size[1] if y1 is None else y1
         if out is not None:
             self._chk(self.L.jxlh_frame_read_rgb8(self._ctx, _addr(pr), channels, y0, y1, C.c_void_p(int(out)),
-                                                  self.params.xsize * channels), "frame_read_rgb8")
+                                                  self.out_size[0] * channels), "frame_read_rgb8")
             return None
-        arr = np.zeros((y1 - y0, self.params.xsize, channels), dtype=np.uint8)
+        arr = np.zeros((y1 - y0, self.out_size[0], channels), dtype=np.uint8)
         self._chk(self.L.jxlh_frame_read_rgb8(self._ctx, _addr(pr), channels, y0, y1, _addr(arr),
-                                              self.params.xsize * channels), "frame_read_rgb8")
+                                              self.out_size[0] * channels), "frame_read_rgb8")
         return arr
 
     def read_rgb16(self, xyb_params, channels=3, y0=0, y1=None):
         """16-bit interleaved sRGB of rows [y0, y1) (jxlh_frame_read_rgb16) as a uint16 array."""
         pr = np.ascontiguousarray(xyb_params, dtype=np.float32)
         assert pr.size == 16
-        y1 = self.params.ysize if y1 is None else y1
-        arr = np.zeros((y1 - y0, self.params.xsize, channels), dtype=np.uint16)
+        y1 = self.out_size[1] if y1 is None else y1
+        arr = np.zeros((y1 - y0, self.out_size[0], channels), dtype=np.uint16)
         self._chk(self.L.jxlh_frame_read_rgb16(self._ctx, _addr(pr), channels, y0, y1, _addr(arr),
-                                               self.params.xsize * channels * 2), "frame_read_rgb16")
+                                               self.out_size[0] * channels * 2), "frame_read_rgb16")
         return arr
 
     def read_ycbcr_rgb8(self, channels=3, y0=0, y1=None):
         """8-bit interleaved RGB of a YCbCr frame (planes Cb, Y, Cr; jxlh_frame_read_ycbcr_rgb8)."""
-        y1 = self.params.ysize if y1 is None else y1
-        arr = np.zeros((y1 - y0, self.params.xsize, channels), dtype=np.uint8)
+        y1 = self.out_size[1] if y1 is None else y1
+        arr = np.zeros((y1 - y0, self.out_size[0], channels), dtype=np.uint8)
         self._chk(self.L.jxlh_frame_read_ycbcr_rgb8(self._ctx, channels, y0, y1, _addr(arr),
-                                                    self.params.xsize * channels), "frame_read_ycbcr_rgb8")
+                                                    self.out_size[0] * channels), "frame_read_ycbcr_rgb8")
         return arr
 
     def read_ycbcr_rgb16(self, channels=3, y0=0, y1=None):
-        y1 = self.params.ysize if y1 is None else y1
-        arr = np.zeros((y1 - y0, self.params.xsize, channels), dtype=np.uint16)
+        y1 = self.out_size[1] if y1 is None else y1
+        arr = np.zeros((y1 - y0, self.out_size[0], channels), dtype=np.uint16)
         self._chk(self.L.jxlh_frame_read_ycbcr_rgb16(self._ctx, channels, y0, y1, _addr(arr),
-                                                     self.params.xsize * channels * 2), "frame_read_ycbcr_rgb16")
+                                                     self.out_size[0] * channels * 2), "frame_read_ycbcr_rgb16")
         return arr
 
     def device_planes(self):
@@ -401,6 +412,20 @@ class Context:
         pin = (C.c_void_p * 3)(*[a.ctypes.data for a in lf])
         pout = (C.c_void_p * 3)(*[a.ctypes.data for a in out])
         self._chk(self.L.jxlh_stage_lf_smooth(self._ctx, C.byref(params), pin, pout, w, h), "stage_lf_smooth")
+        return out
+
+    def set_upsampling_weights(self, w2=None, w4=None, w8=None):
+        arrs = [None if w is None else np.ascontiguousarray(w, dtype=np.float32) for w in (w2, w4, w8)]
+        for a, n in zip(arrs, (15, 55, 210)):
+            assert a is None or a.size == n
+        self._chk(self.L.jxlh_set_upsampling_weights(self._ctx, *[None if a is None else _addr(a) for a in arrs]),
+                  "set_upsampling_weights")
+
+    def stage_upsample(self, n, plane):
+        plane = np.ascontiguousarray(plane, dtype=np.float32)
+        h, w = plane.shape
+        out = np.zeros((h * n, w * n), dtype=np.float32)
+        self._chk(self.L.jxlh_stage_upsample(self._ctx, n, _addr(plane), _addr(out), w, h), "stage_upsample")
         return out
 
     def stage_chroma_upsample(self, plane, horizontal):

@@ -153,6 +153,13 @@ void jxlo_epf_rows(int stage, const JxloFrameParams* p, const float* const in[3]
  * the caller crops to the frame size. */
 void jxlo_chroma_upsample_h(const float* in, int ws, int hs, size_t in_stride, float* out, size_t out_stride);
 void jxlo_chroma_upsample_v(const float* in, int ws, int hs, size_t in_stride, float* out, size_t out_stride);
+/* Upsample<N> (render/stages/upsample.rs), N = 2, 4, 8.  weights: 15 / 55 / 210 values
+ * (CustomTransformData::weights2/4/8, headers/transform_data.rs:337-344; NULL = the defaults).
+ * jxlo_upsample_kernels expands them into the N*N kernels of 25 taps (upsample.rs:31-66), flat[(oy*N+ox)*25 + ky*5+kx];
+ * jxlo_upsample runs the stage on a w x h plane -> (N*w) x (N*h), input mirrored 2 pixels at its edges. */
+void jxlo_upsample_kernels(int n, const float* weights, float* flat);
+void jxlo_upsample(int n, const float* weights, const float* in, int w, int h, size_t in_stride, float* out,
+                   size_t out_stride);
 /* YcbcrToRgbStage (render/stages/ycbcr.rs:35-78): planes in the order Cb, Y, Cr become R, G, B in place */
 void jxlo_ycbcr_to_rgb(float* cb, float* y, float* cr, size_t n);
 

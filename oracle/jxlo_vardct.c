@@ -286,6 +286,58 @@ void jxlo_chroma_upsample_v(const float* in, int ws, int hs, size_t in_stride, f
   }
 }
 
+/* ---------------- 2x / 4x / 8x upsampling (render/stages/upsample.rs) ---------------- */
+#include "upsampling_weights.inc"
+
+void jxlo_upsample_kernels(int n, const float* weights, float* flat) {
+  if (!weights) weights = n == 2 ? kDefaultUpsamplingWeights2 : n == 4 ? kDefaultUpsamplingWeights4 : kDefaultUpsamplingWeights8;
+  const int half = n / 2;
+  /* upsample.rs:31-50: the weights are the upper triangle of the symmetric (5*half)^2 top-left quadrant */
+  for (int i = 0; i < 5 * half; i++) {
+    for (int j = 0; j < 5 * half; j++) {
+      const int y = i < j ? i : j, x = i < j ? j : i;
+      const float wv = weights[5 * half * y - y * (y - 1) / 2 + x - y];
+      const int dj = j / 5, di = i / 5, kj = j % 5, ki = i % 5, last = 2 * half - 1;
+      /* kernel[a][b][c][d] -> flat[(a*n + b)*25 + c*5 + d] */
+      flat[((dj)*n + di) * 25 + kj * 5 + ki] = wv;
+      flat[((last - dj) * n + di) * 25 + (4 - kj) * 5 + ki] = wv;
+      flat[((dj)*n + (last - di)) * 25 + kj * 5 + (4 - ki)] = wv;
+      flat[((last - dj) * n + (last - di)) * 25 + (4 - kj) * 5 + (4 - ki)] = wv;
+    }
+  }
+}
+
+void jxlo_upsample(int n, const float* weights, const float* in, int w, int h, size_t in_stride, float* out,
+                   size_t out_stride) {
+  float flat[64 * 25];
+  jxlo_upsample_kernels(n, weights, flat);
+  for (int y = 0; y < h; y++) {
+    for (int x = 0; x < w; x++) {
+      float win[25], mn, mx;
+      for (int ky = 0; ky < 5; ky++)
+        for (int kx = 0; kx < 5; kx++)
+          win[ky * 5 + kx] = in[(size_t)mirror(y - 2 + ky, h) * in_stride + (size_t)mirror(x - 2 + kx, w)];
+      mn = mx = win[0];
+      for (int t = 1; t < 25; t++) { /* compute_minmax, :115-172 */
+        mn = win[t] < mn ? win[t] : mn;
+        mx = win[t] > mx ? win[t] : mx;
+      }
+      for (int oy = 0; oy < n; oy++) {
+        for (int ox = 0; ox < n; ox++) {
+          const float* k = flat + (oy * n + ox) * 25;
+          /* kernel_conv (:175-215): three accumulators, tap t feeds accumulator t % 3 */
+          float acc[3] = {win[0] * k[0], win[1] * k[1], win[2] * k[2]};
+          for (int t = 3; t < 25; t++) acc[t % 3] = mul_add(win[t], k[t], acc[t % 3]);
+          float v = acc[0] + acc[1] + acc[2];
+          v = v > mn ? v : mn; /* .max(minval).min(maxval) */
+          v = v < mx ? v : mx;
+          out[(size_t)(y * n + oy) * out_stride + (size_t)(x * n + ox)] = v;
+        }
+      }
+    }
+  }
+}
+
 /* ---------------- K2 ---------------- */
 void jxlo_gaborish_rows(const float* in, int w, int h, size_t stride, float w1, float w2,
                         float* out, int y0, int y1) {

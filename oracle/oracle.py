@@ -120,6 +120,8 @@ class Oracle:
         for fn in (L.jxlo_chroma_upsample_h, L.jxlo_chroma_upsample_v):
             fn.argtypes = [fp, C.c_int, C.c_int, C.c_size_t, fp, C.c_size_t]
             fn.restype = None
+        L.jxlo_upsample_kernels.argtypes = [C.c_int, fp, fp]
+        L.jxlo_upsample.argtypes = [C.c_int, fp, fp, C.c_int, C.c_int, C.c_size_t, fp, C.c_size_t]
         L.jxlo_ycbcr_to_rgb.argtypes = [fp, fp, fp, C.c_size_t]
         L.jxlo_ycbcr_to_rgb8.argtypes = [fp, fp, fp, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(C.c_uint8),
                                          C.c_size_t, C.c_int]
@@ -408,6 +410,21 @@ class Oracle:
         out = np.zeros((hs, 2 * ws) if horizontal else (2 * hs, ws), dtype=np.float32)
         fn = self.lib.jxlo_chroma_upsample_h if horizontal else self.lib.jxlo_chroma_upsample_v
         fn(_ptr(plane, C.c_float), ws, hs, ws, _ptr(out, C.c_float), out.shape[1])
+        return out
+
+    def upsample_kernels(self, n, weights=None):
+        flat = np.zeros((n, n, 5, 5), dtype=np.float32)
+        wp = None if weights is None else _ptr(np.ascontiguousarray(weights, dtype=np.float32), C.c_float)
+        self.lib.jxlo_upsample_kernels(n, wp, _ptr(flat, C.c_float))
+        return flat
+
+    def upsample(self, n, plane, weights=None):
+        plane = _f32(plane)
+        h, w = plane.shape
+        out = np.zeros((h * n, w * n), dtype=np.float32)
+        wts = None if weights is None else np.ascontiguousarray(weights, dtype=np.float32)
+        self.lib.jxlo_upsample(n, None if wts is None else _ptr(wts, C.c_float), _ptr(plane, C.c_float), w, h, w,
+                               _ptr(out, C.c_float), w * n)
         return out
 
     def ycbcr_to_rgb(self, cb, y, cr):

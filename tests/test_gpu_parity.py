@@ -268,6 +268,66 @@ def test_chroma_upsample_stage_bit_exact(ctx, oracle, kat, shape):
     assert np.array_equal(ctx.stage_chroma_upsample(np.array([k["input"]], np.float32).T, False)[:, 0], np.float32(k["expected"]))
 
 
+# ---------------------------------------------------------------- 2x / 4x / 8x upsampling
+@pytest.mark.parametrize("n", [2, 4, 8])
+@pytest.mark.parametrize("shape", [(7, 7), (1, 1), (3, 70), (130, 67)])
+def test_upsample_stage_bit_exact(ctx, oracle, kat, n, shape):
+    """Upsample2x/4x/8x hook vs the oracle, default and custom weights; plus the reference's own properties
+    (render/stages/upsample.rs:516-852): a constant plane stays constant, an impulse paints the kernel"""
+    rng = np.random.default_rng(n * 100 + shape[0])
+    plane = rng.standard_normal(shape).astype(np.float32)
+    ctx.set_upsampling_weights()
+    assert bit_equal(ctx.stage_upsample(n, plane), oracle.upsample(n, plane))
+    const = np.full(shape, 0.777, np.float32)
+    assert np.max(np.abs(ctx.stage_upsample(n, const) - np.float32(0.777))) <= kat["upsampling"]["constant_tol"][str(n)]
+    # custom weights (CustomTransformData), then back to the defaults
+    cnt = {2: 15, 4: 55, 8: 210}[n]
+    w = rng.uniform(-0.1, 0.3, cnt).astype(np.float32)
+    ctx.set_upsampling_weights(**{f"w{n}": w})
+    assert bit_equal(ctx.stage_upsample(n, plane), oracle.upsample(n, plane, w))
+    ctx.set_upsampling_weights()
+    assert bit_equal(ctx.stage_upsample(n, plane), oracle.upsample(n, plane))
+
+
+@pytest.mark.parametrize("n,size,up_size", [(2, (300, 270), None), (4, (77, 33), (305, 130)), (8, (40, 40), (313, 320)),
+                                            (2, (515, 389), (1029, 777))])
+def test_upsampled_frame_bit_exact(ctx, oracle, kat, n, size, up_size):
+    """frame_header.upsampling: the stages run after the filters on the three colour channels
+    (frame/render.rs:655-671); planes and the RGB8 output come back at the upsampled size"""
+    from jxl_rs_amd import synth
+    w, h = size
+    wl = synth.make_vardct(w, h, mix=synth.MIX_D1, seed=w + h + n, epf_iters=2)
+    want, _ = run_oracle_frame(oracle, wl)
+    ow, oh = up_size if up_size else (w * n, h * n)
+    want_up = [oracle.upsample(n, np.ascontiguousarray(p))[:oh, :ow] for p in want]
+    over = dict(upsampling=n)
+    if up_size:
+        over.update(xsize_upsampled=ow, ysize_upsampled=oh)
+    upload_frame(ctx, wl, **over)
+    ctx.frame_run()
+    ctx.sync()
+    got = ctx.read_planes()
+    for c in range(3):
+        assert got[c].shape == (oh, ow)
+        assert bit_equal(got[c], want_up[c]), f"plane {c}: {diff_report(got[c], want_up[c])}"
+    params = _default_xyb_params(oracle, kat)
+    want8 = oracle.xyb_to_rgb8(params, [np.ascontiguousarray(p) for p in want_up], ow, oh, 3)
+    assert np.array_equal(ctx.read_rgb8(params, 3), want8)
+
+
+def test_upsampled_frame_argument_errors(ctx):
+    from jxl_rs_amd import synth, lib, JxlHipError
+    wl = synth.make_vardct(600, 600, mix=synth.MIX_DCT8, seed=1, epf_iters=0, gab=False)
+    for over in (dict(upsampling=3), dict(upsampling=2, xsize_upsampled=1300), dict(upsampling=4, ysize_upsampled=100)):
+        with pytest.raises(JxlHipError) as e:
+            ctx.frame_begin(gpu_params_from(ctx, wl, **over))
+        assert e.value.status == lib.ERR_INVALID_ARGUMENT
+    upload_frame(ctx, wl, upsampling=2)
+    with pytest.raises(JxlHipError) as e:
+        ctx.frame_run(0, 1)        # a band of an upsampled frame
+    assert e.value.status == lib.ERR_UNSUPPORTED
+
+
 @pytest.mark.parametrize("size,sub,channels", [((300, 270), "420", 3), ((97, 131), "422", 4), ((64, 64), "440", 3)])
 def test_ycbcr_output_bit_exact(ctx, oracle, size, sub, channels):
     """a recompressed JPEG end to end: K1e, chroma upsampling, YcbcrToRgbStage, ConvertF32ToU8/U16"""

@@ -280,3 +280,40 @@ def test_subsampled_frame_is_the_444_decode_of_the_aligned_blocks(oracle, sub):
             sub_plane = oracle.chroma_upsample(sub_plane, False)
         want = sub_plane[:wl.ysize, :wl.xsize]
         assert np.array_equal(got[c].view(np.uint32), want.view(np.uint32)), f"channel {c}"
+
+
+# ---------------------------------------------------------------- 2x / 4x / 8x upsampling
+@pytest.mark.parametrize("n", [2, 4, 8])
+def test_upsampling_matches_the_reference_tests_expectations(oracle_any, kat, n):
+    """render/stages/upsample.rs:516-852: an impulse in a 7x7 image paints the kernel -- output pixel (i, j) of
+    the 5n x 5n footprint equals weights[index_map[mapped_i][mapped_j]] clamped to [0, 1], with the reference's
+    own triangular index tables and position mapping; the n-pixel border stays zero; the response is symmetric;
+    a constant image stays constant."""
+    k = kat["upsampling"]
+    w = np.float32(k[f"weights{n}"])
+    im = np.array(k["index_maps"][str(n)])
+    img = np.zeros((7, 7), np.float32)
+    img[3, 3] = 1.0
+    out = oracle_any.upsample(n, img)
+    assert out.shape == (7 * n, 7 * n)
+    eps = k["impulse_tol"]
+    assert np.abs(out[:n]).max() <= eps and np.abs(out[-n:]).max() <= eps
+    assert np.abs(out[:, :n]).max() <= eps and np.abs(out[:, -n:]).max() <= eps
+    half = n // 2
+    for i in range(5 * n):
+        for j in range(5 * n):
+            if n == 2:  # upsample.rs:601-611
+                di, ki, dj, kj = i % 2, i // 2, j % 2, j // 2
+                mi = 4 - ki if di == 0 else ki
+                mj = 4 - kj if dj == 0 else kj
+            else:       # upsample.rs:683-693, :836-846
+                mi = (4 - i // n + (i % half) * 5) if (i % n) < half else (i // n + (half - 1 - (i % half)) * 5)
+                mj = (4 - j // n + (j % half) * 5) if (j % n) < half else (j // n + (half - 1 - (j % half)) * 5)
+            want = min(max(w[im[mi][mj]], 0.0), 1.0)
+            assert abs(out[n + i, n + j] - want) <= eps, (i, j)
+    assert np.array_equal(out, out[::-1, ::-1])
+    const = oracle_any.upsample(n, np.full((30, 17), 0.777, np.float32))
+    assert np.abs(const - np.float32(0.777)).max() <= k["constant_tol"][str(n)]
+    # the expanded kernels: every phase sums to 1 (the weights are a partition of unity)
+    kern = oracle_any.upsample_kernels(n)
+    assert np.abs(kern.reshape(n * n, 25).sum(axis=1) - 1.0).max() < 1e-5
