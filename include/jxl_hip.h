@@ -87,6 +87,12 @@ typedef struct {
  *                           (0 = xsize * upsampling); the stages run on the three colour channels after the
  *                           filters (frame/render.rs:655-671) and every jxlh_frame_read_* call then returns the
  *                           upsampled image.  Such a frame is run whole (JXLH_ERR_UNSUPPORTED for a band).
+ *   noise, noise_lut ....... FrameHeader::has_noise() (:486-488) and Noise::lut (features/noise.rs:9-20).  The frame then
+ *                           ends with the reference's noise synthesis at the result's resolution: random planes
+ *                           from Xorshift128Plus seeded per 256x256 tile with (visible_frame_index,
+ *                           nonvisible_frame_index, x0, y0) (frame/decode.rs:578-668), ConvolveNoiseStage on
+ *                           each, AddNoiseStage with ColorCorrelationParams::y_to_x_lf / y_to_b_lf
+ *                           (render/stages/noise.rs, frame/render.rs:673-683)
  *   epf_sigma_for_modular .. RestorationFilter field used when EPF runs on a Modular frame
  *                           (features/epf.rs:81-84); carried for completeness, VarDCT frames ignore it
  */
@@ -112,6 +118,9 @@ typedef struct {
   float epf_sigma_for_modular;
   uint32_t upsampling;
   uint32_t xsize_upsampled, ysize_upsampled;
+  uint32_t noise;
+  float noise_lut[8];
+  uint32_t visible_frame_index, nonvisible_frame_index;
 } jxlh_frame_params;
 
 enum {
@@ -295,6 +304,14 @@ jxlh_status jxlh_stage_chroma_upsample(jxlh_ctx* ctx, const float* in, float* ou
 /* Upsample2x / 4x / 8x (render/stages/upsample.rs) on a tight w x h plane -> (n*w) x (n*h), n = 2, 4, 8, with the
  * weights of jxlh_set_upsampling_weights; input mirrored 2 pixels at its edges */
 jxlh_status jxlh_stage_upsample(jxlh_ctx* ctx, int32_t n, const float* in, float* out, uint32_t w, uint32_t h);
+/* Noise synthesis, stage by stage (tight arrays): the three random planes of a w x h image
+ * (render_noise_for_group, frame/decode.rs:578-668); ConvolveNoiseStage (render/stages/noise.rs:32-86);
+ * AddNoiseStage on n samples with p's noise_lut and colour-correlation fields (noise.rs:140-189), in place. */
+jxlh_status jxlh_stage_noise_generate(jxlh_ctx* ctx, uint32_t visible_frame_index, uint32_t nonvisible_frame_index,
+                                      uint32_t w, uint32_t h, float* const out[3]);
+jxlh_status jxlh_stage_noise_convolve(jxlh_ctx* ctx, const float* in, float* out, uint32_t w, uint32_t h);
+jxlh_status jxlh_stage_noise_add(jxlh_ctx* ctx, const jxlh_frame_params* p, float* const planes[3],
+                                 const float* const rnd[3], size_t n);
 /* adaptive_lf_smoothing on w x h tight planes (frame/adaptive_lf_smoothing.rs:44-125) */
 jxlh_status jxlh_stage_lf_smooth(jxlh_ctx* ctx, const jxlh_frame_params* p, const float* const in[3],
                                  float* const out[3], uint32_t w, uint32_t h);

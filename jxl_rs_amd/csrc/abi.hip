@@ -68,6 +68,8 @@ struct jxlh_ctx {
   // geometry of `result`: the frame itself, or its upsampled image (frame_header.upsampling > 1)
   int res_w = 0, res_h = 0;
   size_t res_stride = 0;
+  DevBuf<float> noise[3];      // random planes of the noise synthesis
+  DevBuf<uint64_t> xs_jump;    // xorshift128+ jump matrices T^(2^j), uploaded on first use
   DevBuf<float> ups[3];        // upsampled planes
   DevBuf<float> ups_kernels;   // expanded 5x5 kernels of the frame's factor
   std::vector<float> ups_weights[3];  // custom weights2 / weights4 / weights8 (empty = defaults)
@@ -319,6 +321,8 @@ void jxlh_ctx_destroy(jxlh_ctx* ctx) {
   release(ctx->error_flag);
   release(ctx->rgb8);
   for (auto& b : ctx->ups) release(b);
+  for (auto& b : ctx->noise) release(b);
+  release(ctx->xs_jump);
   release(ctx->ups_kernels);
   if (ctx->host_flag) (void)hipHostFree(ctx->host_flag);
   release(ctx->worklist);
@@ -715,6 +719,23 @@ void expand_upsampling_kernels(int n, const float* weights, float* flat) {
   }
 }
 
+jxlh_status ensure_jump_table(jxlh_ctx* ctx) {
+  if (ctx->xs_jump.p) return JXLH_OK;
+  static uint64_t table[16][128][2];
+  static std::once_flag once;
+  std::call_once(once, [] { xorshift_jump_table(table); });
+  if (jxlh_status st = ensure(ctx, ctx->xs_jump, sizeof(table) / sizeof(uint64_t))) return st;
+  HIPCHK(ctx, hipMemcpyAsync(ctx->xs_jump.p, table, sizeof(table), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return JXLH_OK;
+}
+
+bool noise_lut_is_zero(const float lut[8]) {
+  for (int i = 0; i < 8; i++)
+    if (lut[i] != 0.0f) return false;
+  return true;
+}
+
 jxlh_status upload_upsampling_kernels(jxlh_ctx* ctx, int n) {
   const int slot = n == 2 ? 0 : n == 4 ? 1 : 2;
   const float* dflt = n == 2 ? kDefaultUpsamplingWeights2 : n == 4 ? kDefaultUpsamplingWeights4 : kDefaultUpsamplingWeights8;
@@ -941,6 +962,28 @@ jxlh_status jxlh_frame_run(jxlh_ctx* ctx, uint32_t group_row0, uint32_t group_ro
     ctx->res_w = ow;
     ctx->res_h = oh;
     ctx->res_stride = ostride;
+  }
+  if (p.noise && !noise_lut_is_zero(p.noise_lut)) {  // AddNoiseStage returns early on an all-zero LUT (noise.rs:153-155)
+    // render_noise_for_group + ConvolveNoise x3 + AddNoise (frame/decode.rs:578-668, frame/render.rs:673-683),
+    // at the resolution of the result (after upsampling).  Random planes: the 256-row tile rows that cover
+    // the band plus the convolution's 2-row border.
+    const int W = ctx->res_w, H = ctx->res_h;
+    const int ya = p.upsampling > 1 ? 0 : y_lo, yb = p.upsampling > 1 ? H : y_hi;
+    if (jxlh_status st = ensure_jump_table(ctx)) return st;
+    for (int c = 0; c < 3; c++)
+      if (jxlh_status st = ensure(ctx, ctx->noise[c], ctx->res_stride * (size_t)H)) return st;
+    float* nz[3] = {ctx->noise[0].p, ctx->noise[1].p, ctx->noise[2].p};
+    const int ty0 = max(0, ya - 2) / 256, ty1 = (min(H, yb + 2) + 255) / 256;
+    {
+      ScopedKernelTimer t(ctx, "k_noise_generate");
+      launch_noise_generate(ctx->stream, nz, ctx->res_stride, W, H, ty0, ty1, p.visible_frame_index,
+                            p.nonvisible_frame_index, ctx->xs_jump.p);
+    }
+    const float ytox = p.base_correlation_x + (float)p.ytox_lf / (float)p.color_factor;  // y_to_x_lf
+    const float ytob = p.base_correlation_b + (float)p.ytob_lf / (float)p.color_factor;
+    ScopedKernelTimer t(ctx, "k_noise_apply");
+    launch_noise_apply(ctx->stream, nz, ctx->res_stride, ctx->result, ctx->res_stride, W, H, ya, yb, p.noise_lut, ytox,
+                       ytob);
   }
   HIPCHK(ctx, hipGetLastError());
   return JXLH_OK;
@@ -1295,6 +1338,61 @@ jxlh_status jxlh_stage_upsample(jxlh_ctx* ctx, int32_t n, const float* in, float
                   (size_t)w * n, (int)w * n, (int)h * n);
   HIPCHK(ctx, hipGetLastError());
   return stage_out(ctx, out, ctx->hook_f[1].p, no);
+}
+
+jxlh_status jxlh_stage_noise_generate(jxlh_ctx* ctx, uint32_t visible_frame_index, uint32_t nonvisible_frame_index,
+                                      uint32_t w, uint32_t h, float* const out[3]) {
+  if (!ctx || !out || !out[0] || !out[1] || !out[2] || w == 0 || h == 0 || w > (1u << 20) || h > (1u << 20))
+    return JXLH_ERR_INVALID_ARGUMENT;
+  const size_t n = (size_t)w * h;
+  jxlh_status st;
+  if ((st = ensure_jump_table(ctx))) return st;
+  float* d[3];
+  for (int c = 0; c < 3; c++) {
+    if ((st = ensure(ctx, ctx->hook_f[c], n))) return st;
+    d[c] = ctx->hook_f[c].p;
+  }
+  launch_noise_generate(ctx->stream, d, w, (int)w, (int)h, 0, ((int)h + 255) / 256, visible_frame_index,
+                        nonvisible_frame_index, ctx->xs_jump.p);
+  HIPCHK(ctx, hipGetLastError());
+  for (int c = 0; c < 3; c++)
+    if ((st = stage_out(ctx, out[c], d[c], n))) return st;
+  return JXLH_OK;
+}
+
+jxlh_status jxlh_stage_noise_convolve(jxlh_ctx* ctx, const float* in, float* out, uint32_t w, uint32_t h) {
+  if (!ctx || !in || !out || w > (1u << 20) || h > (1u << 20)) return JXLH_ERR_INVALID_ARGUMENT;
+  if (w == 0 || h == 0) return JXLH_OK;
+  const size_t n = (size_t)w * h;
+  jxlh_status st;
+  if ((st = stage_in(ctx, ctx->hook_f[0], in, n))) return st;
+  if ((st = ensure(ctx, ctx->hook_f[1], n))) return st;
+  launch_noise_convolve(ctx->stream, ctx->hook_f[0].p, ctx->hook_f[1].p, (int)w, (int)h);
+  HIPCHK(ctx, hipGetLastError());
+  return stage_out(ctx, out, ctx->hook_f[1].p, n);
+}
+
+jxlh_status jxlh_stage_noise_add(jxlh_ctx* ctx, const jxlh_frame_params* p, float* const planes[3],
+                                 const float* const rnd[3], size_t n) {
+  if (!ctx || !p || !planes || !rnd || p->color_factor == 0) return JXLH_ERR_INVALID_ARGUMENT;
+  if (n == 0 || noise_lut_is_zero(p->noise_lut)) return JXLH_OK;
+  jxlh_status st;
+  float* dp[3];
+  const float* dr[3];
+  for (int c = 0; c < 3; c++) {
+    if (!planes[c] || !rnd[c]) return JXLH_ERR_INVALID_ARGUMENT;
+    if ((st = stage_in(ctx, ctx->hook_f[c], planes[c], n))) return st;
+    if ((st = stage_in(ctx, ctx->hook_f[3 + c], rnd[c], n))) return st;
+    dp[c] = ctx->hook_f[c].p;
+    dr[c] = ctx->hook_f[3 + c].p;
+  }
+  const float ytox = p->base_correlation_x + (float)p->ytox_lf / (float)p->color_factor;
+  const float ytob = p->base_correlation_b + (float)p->ytob_lf / (float)p->color_factor;
+  launch_noise_add(ctx->stream, dp, dr, n, p->noise_lut, ytox, ytob);
+  HIPCHK(ctx, hipGetLastError());
+  for (int c = 0; c < 3; c++)
+    if ((st = stage_out(ctx, planes[c], dp[c], n))) return st;
+  return JXLH_OK;
 }
 
 jxlh_status jxlh_stage_transform_to_pixels(jxlh_ctx* ctx, int32_t type, uint32_t n, const float* coeffs,

@@ -141,6 +141,15 @@ void launch_chroma_upsample(hipStream_t s, const float* src, float* dst, const P
 // upsample.rs: n = 2, 4, 8; kernels = n*n*25 expanded taps on the device; writes are clipped to out_w x out_h
 void launch_upsample(hipStream_t s, int n, const float* in, size_t in_stride, int w, int h, const float* kernels,
                      float* out, size_t out_stride, int out_w, int out_h);
+// noise synthesis (k_noise.hip)
+void xorshift_jump_table(uint64_t out[16][128][2]);
+void launch_noise_generate(hipStream_t s, float* const out[3], size_t stride, int w, int h, int tile_y0, int tile_y1,
+                           uint32_t visible, uint32_t nonvisible, const void* jump_table_dev);
+void launch_noise_apply(hipStream_t s, const float* const noise[3], size_t nstride, float* const planes[3], size_t pstride,
+                        int w, int h, int y0, int y1, const float lut[8], float ytox, float ytob);
+void launch_noise_convolve(hipStream_t s, const float* in, float* out, int w, int h);
+void launch_noise_add(hipStream_t s, float* const planes[3], const float* const rnd[3], size_t n, const float lut[8],
+                      float ytox, float ytob);
 void launch_lf_smooth(hipStream_t s, const float* const in[3], float* const out[3], int w, int h,
                       const float lf_factors[3]);
 void launch_sigma_map(hipStream_t s, const FrameDev& f, float epf_quant_mul, const float* sharp_lut);

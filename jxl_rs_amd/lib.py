@@ -35,7 +35,8 @@ ABI_SYMBOLS = [
     "jxlh_frame_set_lf_quantized", "jxlh_frame_set_lf", "jxlh_frame_set_hf_meta", "jxlh_submit_group",
     "jxlh_submit_group_sparse", "jxlh_submit_groups_sparse", "jxlh_slot_wait", "jxlh_frame_coeff_buffer", "jxlh_frame_run", "jxlh_ctx_sync", "jxlh_frame_read_planes",
     "jxlh_frame_device_planes", "jxlh_frame_read_lf", "jxlh_frame_read_rgb8", "jxlh_frame_read_rgb16",
-    "jxlh_frame_read_ycbcr_rgb8", "jxlh_frame_read_ycbcr_rgb16", "jxlh_stage_chroma_upsample", "jxlh_stage_upsample", "jxlh_set_upsampling_weights", "jxlh_timer_start", "jxlh_timer_stop",
+    "jxlh_frame_read_ycbcr_rgb8", "jxlh_frame_read_ycbcr_rgb16", "jxlh_stage_chroma_upsample", "jxlh_stage_upsample", "jxlh_set_upsampling_weights", "jxlh_stage_noise_generate",
+    "jxlh_stage_noise_convolve", "jxlh_stage_noise_add", "jxlh_timer_start", "jxlh_timer_stop",
     "jxlh_kernel_timing_enable", "jxlh_kernel_timing_get", "jxlh_kernel_timing_reset", "jxlh_selftest_recip",
     "jxlh_stage_gaborish",
     "jxlh_stage_epf", "jxlh_stage_lf_smooth", "jxlh_stage_transform_to_pixels", "jxlh_rct", "jxlh_palette",
@@ -69,6 +70,8 @@ class FrameParams(C.Structure):
         ("epf_sigma_for_modular", C.c_float),
         ("upsampling", C.c_uint32),
         ("xsize_upsampled", C.c_uint32), ("ysize_upsampled", C.c_uint32),
+        ("noise", C.c_uint32), ("noise_lut", C.c_float * 8),
+        ("visible_frame_index", C.c_uint32), ("nonvisible_frame_index", C.c_uint32),
     ]
 
 
@@ -108,6 +111,9 @@ def load():
     L.jxlh_frame_read_ycbcr_rgb16.argtypes = [vp, u32, u32, u32, vp, sz]
     L.jxlh_stage_chroma_upsample.argtypes = [vp, vp, vp, u32, u32, i32]
     L.jxlh_stage_upsample.argtypes = [vp, i32, vp, vp, u32, u32]
+    L.jxlh_stage_noise_generate.argtypes = [vp, u32, u32, u32, u32, C.POINTER(vp)]
+    L.jxlh_stage_noise_convolve.argtypes = [vp, vp, vp, u32, u32]
+    L.jxlh_stage_noise_add.argtypes = [vp, C.POINTER(FrameParams), C.POINTER(vp), C.POINTER(vp), sz]
     L.jxlh_set_upsampling_weights.argtypes = [vp, vp, vp, vp]
     L.jxlh_selftest_recip.argtypes = [vp, u32, u32, C.POINTER(C.c_uint64)]
     L.jxlh_frame_set_dequant_tables.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
@@ -427,6 +433,27 @@ class Context:
         out = np.zeros((h * n, w * n), dtype=np.float32)
         self._chk(self.L.jxlh_stage_upsample(self._ctx, n, _addr(plane), _addr(out), w, h), "stage_upsample")
         return out
+
+    def stage_noise_generate(self, visible, nonvisible, w, h):
+        out = [np.zeros((h, w), dtype=np.float32) for _ in range(3)]
+        ptrs = (C.c_void_p * 3)(*[a.ctypes.data for a in out])
+        self._chk(self.L.jxlh_stage_noise_generate(self._ctx, visible, nonvisible, w, h, ptrs), "stage_noise_generate")
+        return out
+
+    def stage_noise_convolve(self, plane):
+        plane = np.ascontiguousarray(plane, dtype=np.float32)
+        h, w = plane.shape
+        out = np.zeros_like(plane)
+        self._chk(self.L.jxlh_stage_noise_convolve(self._ctx, _addr(plane), _addr(out), w, h), "stage_noise_convolve")
+        return out
+
+    def stage_noise_add(self, params, planes, rnd):
+        pl = [np.ascontiguousarray(a, dtype=np.float32).copy() for a in planes]
+        rn = [np.ascontiguousarray(a, dtype=np.float32) for a in rnd]
+        pp = (C.c_void_p * 3)(*[a.ctypes.data for a in pl])
+        pr = (C.c_void_p * 3)(*[a.ctypes.data for a in rn])
+        self._chk(self.L.jxlh_stage_noise_add(self._ctx, C.byref(params), pp, pr, pl[0].size), "stage_noise_add")
+        return pl
 
     def stage_chroma_upsample(self, plane, horizontal):
         plane = np.ascontiguousarray(plane, dtype=np.float32)

@@ -196,6 +196,23 @@ void jxlo_ycbcr_to_rgb16(const float* pcb, const float* py, const float* pcr, si
 void jxlo_xyb_to_rgb8(const JxloXybParams* p, const float* px, const float* py, const float* pb, size_t w, size_t h,
                       size_t stride, uint8_t* out, size_t out_stride_bytes, int out_channels);
 
+/* ---- noise synthesis (util/xorshift128plus.rs, frame/decode.rs:578-668, render/stages/noise.rs, features/noise.rs) ---- */
+typedef struct {
+  uint64_t s0[8], s1[8];
+} JxloXorshift;
+void jxlo_xorshift_seed(uint64_t seed, JxloXorshift* r);
+void jxlo_xorshift_seeds(uint32_t a, uint32_t b, uint32_t c, uint32_t d, JxloXorshift* r);
+void jxlo_xorshift_fill(JxloXorshift* r, uint64_t out[8]);
+/* the three random planes (values in [1, 2)) of a w x h image, one generator per group_dim^2 tile */
+void jxlo_noise_generate(uint32_t visible_frame_index, uint32_t nonvisible_frame_index, int w, int h, int group_dim,
+                         float* const out[3], size_t stride);
+/* ConvolveNoiseStage: 5x5 high-pass, edges mirrored */
+void jxlo_noise_convolve(const float* in, int w, int h, size_t stride, float* out, size_t out_stride);
+float jxlo_noise_strength(const float lut[8], float vx);
+/* AddNoiseStage on n samples; ytox / ytob = ColorCorrelationParams::y_to_x_lf / y_to_b_lf */
+void jxlo_noise_add(const float lut[8], float ytox, float ytob, float* px, float* py, float* pb, const float* rr,
+                    const float* rg, const float* rc, size_t n);
+
 /* ---- sparse coefficient transport: the dense slab a stream of `coeffs[c][pos] += v` updates describes
  * (group.rs:557-572).  pairs: little-endian {u16 pos; i16 val}, n[0] of X then n[1] of Y then n[2] of B;
  * wide: n_wide x {u32 channel*65536+pos; i32 val} */

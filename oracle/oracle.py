@@ -122,6 +122,15 @@ class Oracle:
             fn.restype = None
         L.jxlo_upsample_kernels.argtypes = [C.c_int, fp, fp]
         L.jxlo_upsample.argtypes = [C.c_int, fp, fp, C.c_int, C.c_int, C.c_size_t, fp, C.c_size_t]
+        u64p = C.POINTER(C.c_uint64)
+        L.jxlo_xorshift_seed.argtypes = [C.c_uint64, u64p]
+        L.jxlo_xorshift_seeds.argtypes = [C.c_uint32] * 4 + [u64p]
+        L.jxlo_xorshift_fill.argtypes = [u64p, u64p]
+        L.jxlo_noise_generate.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int, pf3, C.c_size_t]
+        L.jxlo_noise_convolve.argtypes = [fp, C.c_int, C.c_int, C.c_size_t, fp, C.c_size_t]
+        L.jxlo_noise_strength.argtypes = [fp, C.c_float]
+        L.jxlo_noise_strength.restype = C.c_float
+        L.jxlo_noise_add.argtypes = [fp, C.c_float, C.c_float, fp, fp, fp, fp, fp, fp, C.c_size_t]
         L.jxlo_ycbcr_to_rgb.argtypes = [fp, fp, fp, C.c_size_t]
         L.jxlo_ycbcr_to_rgb8.argtypes = [fp, fp, fp, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(C.c_uint8),
                                          C.c_size_t, C.c_int]
@@ -426,6 +435,39 @@ class Oracle:
         self.lib.jxlo_upsample(n, None if wts is None else _ptr(wts, C.c_float), _ptr(plane, C.c_float), w, h, w,
                                _ptr(out, C.c_float), w * n)
         return out
+
+    # ---- noise synthesis ----
+    def xorshift_golden(self, seed, nvec):
+        st = np.zeros(16, dtype=np.uint64)
+        self.lib.jxlo_xorshift_seed(seed, _ptr(st, C.c_uint64))
+        out = np.zeros((nvec, 8), dtype=np.uint64)
+        for i in range(nvec):
+            self.lib.jxlo_xorshift_fill(_ptr(st, C.c_uint64), _ptr(out[i], C.c_uint64))
+        return out
+
+    def noise_generate(self, visible, nonvisible, w, h, group_dim=256):
+        out = [np.zeros((h, w), dtype=np.float32) for _ in range(3)]
+        self.lib.jxlo_noise_generate(visible, nonvisible, w, h, group_dim, self._p3(out), w)
+        return out
+
+    def noise_convolve(self, plane):
+        plane = _f32(plane)
+        h, w = plane.shape
+        out = np.zeros_like(plane)
+        self.lib.jxlo_noise_convolve(_ptr(plane, C.c_float), w, h, w, _ptr(out, C.c_float), w)
+        return out
+
+    def noise_strength(self, lut, v):
+        lut = np.ascontiguousarray(lut, dtype=np.float32)
+        return float(self.lib.jxlo_noise_strength(_ptr(lut, C.c_float), C.c_float(v)))
+
+    def noise_add(self, lut, ytox, ytob, planes, rnd):
+        lut = np.ascontiguousarray(lut, dtype=np.float32)
+        pl = [_f32(a).copy() for a in planes]
+        rn = [_f32(a) for a in rnd]
+        self.lib.jxlo_noise_add(_ptr(lut, C.c_float), C.c_float(ytox), C.c_float(ytob), *[_ptr(a, C.c_float) for a in pl],
+                                *[_ptr(a, C.c_float) for a in rn], pl[0].size)
+        return pl
 
     def ycbcr_to_rgb(self, cb, y, cr):
         a = [_f32(v).copy() for v in (cb, y, cr)]

@@ -317,3 +317,41 @@ def test_upsampling_matches_the_reference_tests_expectations(oracle_any, kat, n)
     # the expanded kernels: every phase sums to 1 (the weights are a partition of unity)
     kern = oracle_any.upsample_kernels(n)
     assert np.abs(kern.reshape(n * n, 25).sum(axis=1) - 1.0).max() < 1e-5
+
+
+# ---------------------------------------------------------------- noise synthesis
+def test_xorshift128plus_golden(oracle_any, kat):
+    """util/xorshift128plus.rs:77-735: 64 fills of 8 lanes after new_with_seed(12345), bit for bit"""
+    k = kat["noise"]
+    want = np.array([int(v, 16) for v in k["xorshift_golden"]], dtype=np.uint64).reshape(64, 8)
+    assert np.array_equal(oracle_any.xorshift_golden(k["xorshift_seed"], 64), want)
+
+
+def test_noise_stage_known_answers(oracle_any, kat):
+    """render/stages/noise.rs:205-325: ConvolveNoise on a 2x2 ramp; AddNoise against goldens generated by libjxl"""
+    k = kat["noise"]
+    conv = oracle_any.noise_convolve(np.array(k["convolve_input"], np.float32).reshape(2, 2))
+    assert np.max(np.abs(conv.ravel() - np.float32(k["convolve_expected"]))) <= k["convolve_tol"]
+    a = (np.float32(k["add_input_start"]) + np.float32(k["add_input_step"]) * np.arange(64, dtype=np.float32)).reshape(8, 8)
+    out = oracle_any.noise_add(k["add_lut"], 0.0, 1.0, [a, a, a], [a, a, a])  # ColorCorrelationParams::default()
+    for c in range(3):
+        assert np.max(np.abs(out[c].ravel() - np.float32(k["add_expected"][c]))) <= k["add_tol"]
+    # strength: piecewise linear through the LUT, clamped (features/noise.rs:21-41)
+    lut = [0.0, 0.1, 0.2, 0.4, 0.8, 1.6, 0.3, 0.5]
+    assert oracle_any.noise_strength(lut, -1.0) == 0.0
+    assert abs(oracle_any.noise_strength(lut, 0.5 / 6) - 0.05) < 1e-7
+    assert oracle_any.noise_strength(lut, 4.5 / 6) == 1.0           # (0.8 + 1.6) / 2 clamps to 1
+    assert abs(oracle_any.noise_strength(lut, 100.0) - 0.5) < 1e-7  # beyond the table: last entry
+
+
+def test_noise_generation_structure(oracle):
+    """frame/decode.rs:578-668: values in [1, 2); tiles are seeded by their corner, so a tile's content does not
+    depend on the image around it as long as its own extent is the same; the frame indices reseed everything"""
+    a = oracle.noise_generate(1, 2, 600, 300)
+    assert all(p.min() >= 1.0 and p.max() < 2.0 for p in a)
+    b = oracle.noise_generate(1, 2, 512, 256)
+    for c in range(3):
+        assert np.array_equal(a[c][:256, :512], b[c])
+    c2 = oracle.noise_generate(1, 3, 600, 300)
+    assert not np.array_equal(a[0], c2[0])
+    assert abs(float(a[0].mean()) - 1.5) < 0.01
