@@ -286,6 +286,31 @@ jxlh_status jxlh_frame_read_ycbcr_rgb8(jxlh_ctx* ctx, uint32_t channels, uint32_
 jxlh_status jxlh_frame_read_ycbcr_rgb16(jxlh_ctx* ctx, uint32_t channels, uint32_t y0, uint32_t y1, void* out,
                                         size_t bytes_per_row);
 
+/* General form of the output calls: the colour stage of the frame (frame/render.rs:755-763) -- XybStage, for an
+ * XYB-encoded frame, followed by FromLinearStage with one of the reference's transfer functions
+ * (render/stages/from_linear.rs:133-145; curves of color/tf.rs and util/fast_math.rs, evaluated operation for
+ * operation), YcbcrToRgbStage, or nothing -- then ConvertF32ToU8Stage (bits = 8) or ConvertF32ToU16Stage (16).
+ *   JXLH_TF_LINEAR  no FromLinearStage (linear output, TransferFunction::is_linear)
+ *   JXLH_TF_SRGB    linear_to_srgb_simd            JXLH_TF_BT709  linear_to_bt709_simd
+ *   JXLH_TF_PQ      linear_to_pq_simd, tf_param = intensity_target
+ *   JXLH_TF_HLG     hlg_display_to_scene + scene_to_hlg; tf_param = (1 - g) / g with the system gamma
+ *                   g = 1.2 * 1.111^log2(intensity_target / 1000) evaluated by the caller exactly as
+ *                   color/tf.rs:442-446 does (host libm), hlg_luminance_rgb = luminance_rgb
+ *   JXLH_TF_GAMMA   fast_powf_simd(|v|, tf_param), tf_param = the encoding exponent in (0, 1] */
+enum { JXLH_COLOR_XYB = 0, JXLH_COLOR_YCBCR = 1, JXLH_COLOR_NONE = 2 };
+enum { JXLH_TF_LINEAR = 0, JXLH_TF_SRGB = 1, JXLH_TF_BT709 = 2, JXLH_TF_PQ = 3, JXLH_TF_HLG = 4, JXLH_TF_GAMMA = 5 };
+typedef struct jxlh_output_desc {
+  uint32_t color;     /* JXLH_COLOR_* */
+  uint32_t transfer;  /* JXLH_TF_*, used with JXLH_COLOR_XYB */
+  jxlh_xyb_params xyb;
+  float tf_param;
+  float hlg_luminance_rgb[3];
+  uint32_t bits;      /* 8 or 16 */
+  uint32_t channels;  /* 3 or 4 (alpha = opaque) */
+} jxlh_output_desc;
+jxlh_status jxlh_frame_read_output(jxlh_ctx* ctx, const jxlh_output_desc* d, uint32_t y0, uint32_t y1, void* out,
+                                   size_t bytes_per_row);
+
 /* ---------------------------------------------------------------- stage-level hooks */
 /* Whole-image single stages with the pipeline's mirror edge semantics; the analogue of
  * make_and_run_simple_pipeline (jxl/src/render/test.rs:83-179).  Planes: w x h f32, row stride

@@ -1016,20 +1016,20 @@ const XybParamsDev* xyb_params_dev(const jxlh_xyb_params* p, XybParamsDev* d) {
   return d;
 }
 
-// p == nullptr: the frame is YCbCr (planes Cb, Y, Cr) and takes YcbcrToRgbStage instead of XybStage + sRGB curve
-jxlh_status read_rgb8(jxlh_ctx* ctx, const jxlh_xyb_params* p, uint32_t channels, uint32_t y0, uint32_t y1, void* out,
-                      size_t bytes_per_row) {
+// mode: kTfLinear..kTfGamma = XybStage (p) + that transfer function (t); kModeYcbcr; kModeNone
+jxlh_status read_rgb8(jxlh_ctx* ctx, int mode, const jxlh_xyb_params* p, const TfParamsDev& tf, uint32_t channels,
+                      uint32_t y0, uint32_t y1, void* out, size_t bytes_per_row) {
   if (!ctx || !out || (channels != 3 && channels != 4)) return JXLH_ERR_INVALID_ARGUMENT;
   if (!ctx->in_frame || !ctx->result[0]) return JXLH_ERR_BAD_STATE;
   if (y1 > (uint32_t)ctx->res_h) y1 = (uint32_t)ctx->res_h;
   if (y0 >= y1 || bytes_per_row < (size_t)ctx->res_w * channels) return JXLH_ERR_INVALID_ARGUMENT;
-  XybParamsDev dv;
-  const XybParamsDev* d = xyb_params_dev(p, &dv);
+  XybParamsDev d = {};
+  xyb_params_dev(p, &d);
   const int rows = (int)(y1 - y0);
   const float* planes[3] = {ctx->result[0], ctx->result[1], ctx->result[2]};
   if (is_device_ptr(out)) {
     ScopedKernelTimer t(ctx, "k_xyb_to_rgb8");
-    launch_xyb_to_rgb8(ctx->stream, planes, ctx->res_stride, ctx->res_w, (int)y0, rows, d, (int)channels,
+    launch_xyb_to_rgb8(ctx->stream, planes, ctx->res_stride, ctx->res_w, (int)y0, rows, mode, d, tf, (int)channels,
                        static_cast<uint8_t*>(out), bytes_per_row);
     HIPCHK(ctx, hipGetLastError());
     return JXLH_OK;
@@ -1040,7 +1040,7 @@ jxlh_status read_rgb8(jxlh_ctx* ctx, const jxlh_xyb_params* p, uint32_t channels
   if (jxlh_status st = ensure(ctx, ctx->rgb8, tight * (size_t)rows)) return st;
   {
     ScopedKernelTimer t(ctx, "k_xyb_to_rgb8");
-    launch_xyb_to_rgb8(ctx->stream, planes, ctx->res_stride, ctx->res_w, (int)y0, rows, d, (int)channels, ctx->rgb8.p,
+    launch_xyb_to_rgb8(ctx->stream, planes, ctx->res_stride, ctx->res_w, (int)y0, rows, mode, d, tf, (int)channels, ctx->rgb8.p,
                        tight);
   }
   HIPCHK(ctx, hipGetLastError());
@@ -1051,8 +1051,8 @@ jxlh_status read_rgb8(jxlh_ctx* ctx, const jxlh_xyb_params* p, uint32_t channels
   return JXLH_OK;
 }
 
-jxlh_status read_rgb16(jxlh_ctx* ctx, const jxlh_xyb_params* p, uint32_t channels, uint32_t y0, uint32_t y1, void* out,
-                       size_t bytes_per_row) {
+jxlh_status read_rgb16(jxlh_ctx* ctx, int mode, const jxlh_xyb_params* p, const TfParamsDev& tf, uint32_t channels,
+                       uint32_t y0, uint32_t y1, void* out, size_t bytes_per_row) {
   if (!ctx || !out || (channels != 3 && channels != 4)) return JXLH_ERR_INVALID_ARGUMENT;
   if (!ctx->in_frame || !ctx->result[0]) return JXLH_ERR_BAD_STATE;
   if (y1 > (uint32_t)ctx->res_h) y1 = (uint32_t)ctx->res_h;
@@ -1060,13 +1060,13 @@ jxlh_status read_rgb16(jxlh_ctx* ctx, const jxlh_xyb_params* p, uint32_t channel
   if (y0 >= y1 || bytes_per_row < row_bytes || bytes_per_row % sizeof(uint16_t) != 0 ||
       reinterpret_cast<uintptr_t>(out) % sizeof(uint16_t) != 0)
     return JXLH_ERR_INVALID_ARGUMENT;
-  XybParamsDev dv;
-  const XybParamsDev* d = xyb_params_dev(p, &dv);
+  XybParamsDev d = {};
+  xyb_params_dev(p, &d);
   const int rows = (int)(y1 - y0);
   const float* planes[3] = {ctx->result[0], ctx->result[1], ctx->result[2]};
   if (is_device_ptr(out)) {
     ScopedKernelTimer t(ctx, "k_xyb_to_rgb16");
-    launch_xyb_to_rgb16(ctx->stream, planes, ctx->res_stride, ctx->res_w, (int)y0, rows, d, (int)channels,
+    launch_xyb_to_rgb16(ctx->stream, planes, ctx->res_stride, ctx->res_w, (int)y0, rows, mode, d, tf, (int)channels,
                         static_cast<uint16_t*>(out), bytes_per_row / sizeof(uint16_t));
     HIPCHK(ctx, hipGetLastError());
     return JXLH_OK;
@@ -1074,7 +1074,7 @@ jxlh_status read_rgb16(jxlh_ctx* ctx, const jxlh_xyb_params* p, uint32_t channel
   if (jxlh_status st = ensure(ctx, ctx->rgb8, row_bytes * (size_t)rows)) return st;
   {
     ScopedKernelTimer t(ctx, "k_xyb_to_rgb16");
-    launch_xyb_to_rgb16(ctx->stream, planes, ctx->res_stride, ctx->res_w, (int)y0, rows, d, (int)channels,
+    launch_xyb_to_rgb16(ctx->stream, planes, ctx->res_stride, ctx->res_w, (int)y0, rows, mode, d, tf, (int)channels,
                         reinterpret_cast<uint16_t*>(ctx->rgb8.p), (size_t)ctx->res_w * channels);
   }
   HIPCHK(ctx, hipGetLastError());
@@ -1088,20 +1088,41 @@ jxlh_status read_rgb16(jxlh_ctx* ctx, const jxlh_xyb_params* p, uint32_t channel
 jxlh_status jxlh_frame_read_rgb8(jxlh_ctx* ctx, const jxlh_xyb_params* p, uint32_t channels, uint32_t y0,
                                  uint32_t y1, void* out, size_t bytes_per_row) {
   if (!p) return JXLH_ERR_INVALID_ARGUMENT;
-  return read_rgb8(ctx, p, channels, y0, y1, out, bytes_per_row);
+  return read_rgb8(ctx, kTfSrgb, p, TfParamsDev{}, channels, y0, y1, out, bytes_per_row);
 }
 jxlh_status jxlh_frame_read_rgb16(jxlh_ctx* ctx, const jxlh_xyb_params* p, uint32_t channels, uint32_t y0,
                                   uint32_t y1, void* out, size_t bytes_per_row) {
   if (!p) return JXLH_ERR_INVALID_ARGUMENT;
-  return read_rgb16(ctx, p, channels, y0, y1, out, bytes_per_row);
+  return read_rgb16(ctx, kTfSrgb, p, TfParamsDev{}, channels, y0, y1, out, bytes_per_row);
 }
 jxlh_status jxlh_frame_read_ycbcr_rgb8(jxlh_ctx* ctx, uint32_t channels, uint32_t y0, uint32_t y1, void* out,
                                        size_t bytes_per_row) {
-  return read_rgb8(ctx, nullptr, channels, y0, y1, out, bytes_per_row);
+  return read_rgb8(ctx, kModeYcbcr, nullptr, TfParamsDev{}, channels, y0, y1, out, bytes_per_row);
 }
 jxlh_status jxlh_frame_read_ycbcr_rgb16(jxlh_ctx* ctx, uint32_t channels, uint32_t y0, uint32_t y1, void* out,
                                         size_t bytes_per_row) {
-  return read_rgb16(ctx, nullptr, channels, y0, y1, out, bytes_per_row);
+  return read_rgb16(ctx, kModeYcbcr, nullptr, TfParamsDev{}, channels, y0, y1, out, bytes_per_row);
+}
+
+jxlh_status jxlh_frame_read_output(jxlh_ctx* ctx, const jxlh_output_desc* d, uint32_t y0, uint32_t y1, void* out,
+                                   size_t bytes_per_row) {
+  if (!ctx || !d || (d->bits != 8 && d->bits != 16)) return JXLH_ERR_INVALID_ARGUMENT;
+  int mode;
+  switch (d->color) {
+    case JXLH_COLOR_XYB:
+      if (d->transfer > JXLH_TF_GAMMA) return JXLH_ERR_INVALID_ARGUMENT;
+      mode = (int)d->transfer;  // JXLH_TF_* share the values of the internal modes
+      break;
+    case JXLH_COLOR_YCBCR: mode = kModeYcbcr; break;
+    case JXLH_COLOR_NONE: mode = kModeNone; break;
+    default: return JXLH_ERR_INVALID_ARGUMENT;
+  }
+  TfParamsDev t;
+  t.param = d->tf_param;
+  for (int i = 0; i < 3; i++) t.lum[i] = d->hlg_luminance_rgb[i];
+  const jxlh_xyb_params* xp = d->color == JXLH_COLOR_XYB ? &d->xyb : nullptr;
+  return d->bits == 8 ? read_rgb8(ctx, mode, xp, t, d->channels, y0, y1, out, bytes_per_row)
+                      : read_rgb16(ctx, mode, xp, t, d->channels, y0, y1, out, bytes_per_row);
 }
 
 jxlh_status jxlh_frame_read_planes(jxlh_ctx* ctx, const jxlh_plane out[3]) {

@@ -179,10 +179,17 @@ int launch_fused_filters(hipStream_t s, const FrameDev& f, int y0, int y1);
 struct XybParamsDev {
   float mat[9], bias_cbrt[3], scaled_bias[3], intensity_scale;
 };
-void launch_xyb_to_rgb8(hipStream_t s, const float* const planes[3], size_t stride, int w, int y0, int rows,
-                        const XybParamsDev* p, int channels, uint8_t* out, size_t out_stride);
-void launch_xyb_to_rgb16(hipStream_t s, const float* const planes[3], size_t stride, int w, int y0, int rows,
-                         const XybParamsDev* p, int channels, uint16_t* out, size_t out_stride_elems);
+// output colour handling of the read kernels: XybStage followed by one of the reference's transfer functions
+// (render/stages/from_linear.rs:133-145), or the YCbCr / identity alternatives
+enum { kTfLinear = 0, kTfSrgb = 1, kTfBt709 = 2, kTfPq = 3, kTfHlg = 4, kTfGamma = 5, kModeYcbcr = 6, kModeNone = 7 };
+struct TfParamsDev {
+  float param;   // PQ: intensity_target; HLG: OOTF exponent; gamma: exponent
+  float lum[3];  // HLG: luminance_rgb
+};
+void launch_xyb_to_rgb8(hipStream_t s, const float* const planes[3], size_t stride, int w, int y0, int rows, int mode,
+                        const XybParamsDev& q, const TfParamsDev& t, int channels, uint8_t* out, size_t out_stride);
+void launch_xyb_to_rgb16(hipStream_t s, const float* const planes[3], size_t stride, int w, int y0, int rows, int mode,
+                         const XybParamsDev& q, const TfParamsDev& t, int channels, uint16_t* out, size_t out_stride_elems);
 // sparse coefficient transport (k_coeffs.hip): one descriptor per submitted group
 struct SparseGroup {
   uint32_t group;   // group id

@@ -36,14 +36,133 @@ __device__ __forceinline__ float linear_to_srgb(float x) {
   return __builtin_copysignf(r, x);
 }
 
+#include "tf_constants.inc"
+
+// util/rational_poly.rs:20-35 (FMA Horner, the SIMD form) and :13-17 (plain mul + add, the scalar form)
+template <int NP, int NQ>
+__device__ __forceinline__ float ratpoly_fma(float x, const float (&p)[NP], const float (&q)[NQ]) {
+  float yp = p[NP - 1], yq = q[NQ - 1];
+#pragma unroll
+  for (int i = NP - 2; i >= 0; i--) yp = __builtin_fmaf(yp, x, p[i]);
+#pragma unroll
+  for (int i = NQ - 2; i >= 0; i--) yq = __builtin_fmaf(yq, x, q[i]);
+  return yp / yq;
+}
+template <int NP, int NQ>
+__device__ __forceinline__ float ratpoly_plain(float x, const float (&p)[NP], const float (&q)[NQ]) {
+  float yp = p[NP - 1], yq = q[NQ - 1];
+#pragma unroll
+  for (int i = NP - 2; i >= 0; i--) yp = yp * x + p[i];
+#pragma unroll
+  for (int i = NQ - 2; i >= 0; i--) yq = yq * x + q[i];
+  return yp / yq;
+}
+
+template <bool SIMD>
+__device__ __forceinline__ float fast_log2f_dev(float x) {  // util/fast_math.rs:127-149
+  const int32_t x_bits = __float_as_int(x);
+  const int32_t exp_bits = (int32_t)((uint32_t)x_bits - 0x3f2aaaabu);
+  const int32_t exp_shifted = exp_bits >> 23;
+  const float mantissa = __int_as_float((int32_t)((uint32_t)x_bits - ((uint32_t)exp_shifted << 23)));
+  const float m1 = mantissa - 1.0f;
+  const float poly = SIMD ? ratpoly_fma(m1, kTf_LOG2F_P, kTf_LOG2F_Q) : ratpoly_plain(m1, kTf_LOG2F_P, kTf_LOG2F_Q);
+  return poly + (float)exp_shifted;
+}
+template <bool SIMD>
+__device__ __forceinline__ float fast_pow2f_dev(float x) {  // util/fast_math.rs:79-114
+  const float x_floor = __builtin_floorf(x);
+  const float e = __int_as_float((int32_t)(((uint32_t)((int32_t)x_floor + 127)) << 23));
+  const float frac = x - x_floor;
+  float num = frac + kTf_POW2F_NUMER[0], den;
+  if constexpr (SIMD) {
+    num = __builtin_fmaf(num, frac, kTf_POW2F_NUMER[1]);
+    num = __builtin_fmaf(num, frac, kTf_POW2F_NUMER[2]);
+    num = num * e;
+    den = __builtin_fmaf(kTf_POW2F_DENOM[0], frac, kTf_POW2F_DENOM[1]);
+    den = __builtin_fmaf(den, frac, kTf_POW2F_DENOM[2]);
+    den = __builtin_fmaf(den, frac, kTf_POW2F_DENOM[3]);
+  } else {
+    num = num * frac + kTf_POW2F_NUMER[1];
+    num = num * frac + kTf_POW2F_NUMER[2];
+    num = num * e;
+    den = kTf_POW2F_DENOM[0] * frac + kTf_POW2F_DENOM[1];
+    den = den * frac + kTf_POW2F_DENOM[2];
+    den = den * frac + kTf_POW2F_DENOM[3];
+  }
+  return num / den;
+}
+template <bool SIMD>
+__device__ __forceinline__ float fast_powf_dev(float base, float e) {
+  return fast_pow2f_dev<SIMD>(fast_log2f_dev<SIMD>(base) * e);
+}
+
+__device__ __forceinline__ float linear_to_bt709(float x) {  // color/tf.rs:115-148
+  const float a = __builtin_fabsf(x);
+  const float r = (0.018f > a) ? a * 4.5f : ratpoly_fma(__builtin_sqrtf(a), kTf_BT709_P, kTf_BT709_Q);
+  return __builtin_copysignf(r, x);
+}
+__device__ __forceinline__ float linear_to_pq(float y_mult, float x) {  // color/tf.rs:288-314
+  const float a = __builtin_fabsf(x);
+  const float a_1_4 = __builtin_sqrtf(__builtin_sqrtf(a * y_mult));
+  const float y_small = ratpoly_fma(a_1_4, kTf_PQ_INV_EOTF_P_SMALL, kTf_PQ_INV_EOTF_Q_SMALL);
+  const float y_large = ratpoly_fma(a_1_4, kTf_PQ_INV_EOTF_P, kTf_PQ_INV_EOTF_Q);
+  return __builtin_copysignf((1e-4f > a) ? y_small : y_large, x);
+}
+__device__ __forceinline__ float scene_to_hlg(float x) {  // color/tf.rs:482-497
+  constexpr double kA = 0.17883277, kB = 1.0 - 4.0 * kA, kC = 0.5599107295;
+  constexpr float k = (float)(kA * 0.693147180559945309417232121458176568), hb = (float)kB, hc = (float)kC;
+  const float a = __builtin_fabsf(x);
+  const float y = (a <= 1.0f / 12.0f) ? __builtin_sqrtf(3.0f * a) : k * fast_log2f_dev<false>(12.0f * a - hb) + hc;
+  return __builtin_copysignf(y, x);
+}
+
+// FromLinearStage (render/stages/from_linear.rs:57-112) on one pixel
+template <int TF>
+__device__ __forceinline__ void from_linear(const TfParamsDev& t, float& r, float& g, float& b) {
+  if constexpr (TF == kTfSrgb) {
+    r = linear_to_srgb(r);
+    g = linear_to_srgb(g);
+    b = linear_to_srgb(b);
+  } else if constexpr (TF == kTfBt709) {
+    r = linear_to_bt709(r);
+    g = linear_to_bt709(g);
+    b = linear_to_bt709(b);
+  } else if constexpr (TF == kTfPq) {
+    const float y_mult = t.param * (1.0f / 10000.0f);
+    r = linear_to_pq(y_mult, r);
+    g = linear_to_pq(y_mult, g);
+    b = linear_to_pq(y_mult, b);
+  } else if constexpr (TF == kTfHlg) {
+    if (!(__builtin_fabsf(t.param) < 0.1f)) {  // hlg_ootf_inner (color/tf.rs:379-393), exponent from the host
+      const float mixed = __builtin_fmaf(r, t.lum[0], __builtin_fmaf(g, t.lum[1], b * t.lum[2]));
+      const float mult = fast_powf_dev<false>(mixed, t.param);
+      r *= mult;
+      g *= mult;
+      b *= mult;
+    }
+    r = scene_to_hlg(r);
+    g = scene_to_hlg(g);
+    b = scene_to_hlg(b);
+  } else if constexpr (TF == kTfGamma) {
+    r = __builtin_copysignf(fast_powf_dev<true>(__builtin_fabsf(r), t.param), r);
+    g = __builtin_copysignf(fast_powf_dev<true>(__builtin_fabsf(g), t.param), g);
+    b = __builtin_copysignf(fast_powf_dev<true>(__builtin_fabsf(b), t.param), b);
+  }
+}
+
 // Samples of one pixel -> display-referred R, G, B in [0, 1] nominal.
 //   YCBCR = false: XybStage (xyb.rs:220-240) + the sRGB transfer function (frame/render.rs:757-762)
 //   YCBCR = true : YcbcrToRgbStage on planes ordered Cb, Y, Cr (render/stages/ycbcr.rs:35-78); such frames
 //                  are not XYB-encoded, so no transfer-function stage follows (frame/render.rs:755-763)
-template <bool YCBCR>
-__device__ __forceinline__ void to_display_rgb(const XybParamsDev& p, float c0, float c1, float c2, float& r, float& g,
-                                               float& b) {
-  if constexpr (YCBCR) {
+//   MODE = kTfLinear .. kTfGamma: XybStage, then that transfer function;  kModeYcbcr;  kModeNone: planes are RGB already
+template <int MODE>
+__device__ __forceinline__ void to_display_rgb(const XybParamsDev& p, const TfParamsDev& t, float c0, float c1, float c2,
+                                               float& r, float& g, float& b) {
+  if constexpr (MODE == kModeNone) {
+    r = c0;
+    g = c1;
+    b = c2;
+  } else if constexpr (MODE == kModeYcbcr) {
     constexpr float k128 = 128.0f / 255.0f, kCrToR = 1.402f, kCrToG = -0.299f * 1.402f / 0.587f,
                     kCbToG = -0.114f * 1.772f / 0.587f, kCbToB = 1.772f;
     const float y = c1 + k128;
@@ -59,9 +178,10 @@ __device__ __forceinline__ void to_display_rgb(const XybParamsDev& p, float c0, 
     l = __builtin_fmaf(l2, sl, p.scaled_bias[0]);
     m = __builtin_fmaf(m2, sm, p.scaled_bias[1]);
     s = __builtin_fmaf(s2, ss, p.scaled_bias[2]);
-    r = linear_to_srgb(__builtin_fmaf(p.mat[0], l, __builtin_fmaf(p.mat[1], m, p.mat[2] * s)));
-    g = linear_to_srgb(__builtin_fmaf(p.mat[3], l, __builtin_fmaf(p.mat[4], m, p.mat[5] * s)));
-    b = linear_to_srgb(__builtin_fmaf(p.mat[6], l, __builtin_fmaf(p.mat[7], m, p.mat[8] * s)));
+    r = __builtin_fmaf(p.mat[0], l, __builtin_fmaf(p.mat[1], m, p.mat[2] * s));
+    g = __builtin_fmaf(p.mat[3], l, __builtin_fmaf(p.mat[4], m, p.mat[5] * s));
+    b = __builtin_fmaf(p.mat[6], l, __builtin_fmaf(p.mat[7], m, p.mat[8] * s));
+    from_linear<MODE>(t, r, g, b);
   }
 }
 
@@ -80,10 +200,10 @@ __device__ __forceinline__ uint32_t to_u16(float v) {  // f32_to_u16_simd (conve
 }
 
 // one thread = 4 consecutive pixels of one row; 16-bit samples (no dither), little endian
-template <int CH, bool YCBCR>
+template <int CH, int MODE>
 __global__ __launch_bounds__(kOutThreads) void k_xyb_to_rgb16(const float* __restrict__ px, const float* __restrict__ py,
                                                               const float* __restrict__ pb, uint32_t stride, int w,
-                                                              int y0, int rows, const XybParamsDev p,
+                                                              int y0, int rows, const XybParamsDev p, const TfParamsDev t,
                                                               uint16_t* __restrict__ out, size_t out_stride_elems) {
   const int x4 = (blockIdx.x * kOutThreads + threadIdx.x) * 4;
   const int r = blockIdx.y;
@@ -93,7 +213,7 @@ __global__ __launch_bounds__(kOutThreads) void k_xyb_to_rgb16(const float* __res
   for (int i = 0; i < 4; i++) {
     if (x4 + i >= w) break;
     float rr, gg, bb;
-    to_display_rgb<YCBCR>(p, px[in + i], py[in + i], pb[in + i], rr, gg, bb);
+    to_display_rgb<MODE>(p, t, px[in + i], py[in + i], pb[in + i], rr, gg, bb);
     uint16_t* o = out + (size_t)r * out_stride_elems + (size_t)(x4 + i) * CH;
     o[0] = (uint16_t)to_u16(rr);
     o[1] = (uint16_t)to_u16(gg);
@@ -103,10 +223,10 @@ __global__ __launch_bounds__(kOutThreads) void k_xyb_to_rgb16(const float* __res
 }
 
 // one thread = 4 consecutive pixels of one row
-template <int CH, bool YCBCR>
+template <int CH, int MODE>
 __global__ __launch_bounds__(kOutThreads) void k_xyb_to_rgb8(const float* __restrict__ px, const float* __restrict__ py,
                                                              const float* __restrict__ pb, uint32_t stride, int w,
-                                                             int y0, int rows, const XybParamsDev p,
+                                                             int y0, int rows, const XybParamsDev p, const TfParamsDev t,
                                                              uint8_t* __restrict__ out, size_t out_stride, int aligned) {
   __shared__ float s_dither[32 * 32];
   for (int i = threadIdx.x; i < 32 * 32; i += kOutThreads) s_dither[i] = kDitherDev[i];
@@ -136,7 +256,7 @@ __global__ __launch_bounds__(kOutThreads) void k_xyb_to_rgb8(const float* __rest
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     float rr, gg, bb;
-    to_display_rgb<YCBCR>(p, vx[i], vy[i], vb[i], rr, gg, bb);
+    to_display_rgb<MODE>(p, t, vx[i], vy[i], vb[i], rr, gg, bb);
     q[i][0] = to_u8(rr, s_dither, x4 + i, y, 0);
     q[i][1] = to_u8(gg, s_dither, x4 + i, y, 1);
     q[i][2] = to_u8(bb, s_dither, x4 + i, y, 2);
@@ -167,37 +287,59 @@ __global__ __launch_bounds__(kOutThreads) void k_xyb_to_rgb8(const float* __rest
 
 }  // namespace
 
-void launch_xyb_to_rgb8(hipStream_t s, const float* const planes[3], size_t stride, int w, int y0, int rows,
-                        const XybParamsDev* p, int channels, uint8_t* out, size_t out_stride) {
-  if (w <= 0 || rows <= 0) return;
+template <int MODE>
+void launch8_mode(hipStream_t s, const float* const planes[3], size_t stride, int w, int y0, int rows, const XybParamsDev& q,
+                  const TfParamsDev& t, int channels, uint8_t* out, size_t out_stride) {
   const dim3 grid((unsigned)(((w + 3) / 4 + kOutThreads - 1) / kOutThreads), (unsigned)rows);
   const int aligned = ((reinterpret_cast<uintptr_t>(out) | out_stride) & 3) == 0;
-  const XybParamsDev q = p ? *p : XybParamsDev{};
-#define JXLH_LAUNCH8(CH, Y)                                                                                      \
-  hipLaunchKernelGGL((k_xyb_to_rgb8<CH, Y>), grid, dim3(kOutThreads), 0, s, planes[0], planes[1], planes[2],     \
-                     (uint32_t)stride, w, y0, rows, q, out, out_stride, aligned)
-  if (p) {
-    if (channels == 3) JXLH_LAUNCH8(3, false); else JXLH_LAUNCH8(4, false);
-  } else {
-    if (channels == 3) JXLH_LAUNCH8(3, true); else JXLH_LAUNCH8(4, true);
-  }
-#undef JXLH_LAUNCH8
+  if (channels == 3)
+    hipLaunchKernelGGL((k_xyb_to_rgb8<3, MODE>), grid, dim3(kOutThreads), 0, s, planes[0], planes[1], planes[2],
+                       (uint32_t)stride, w, y0, rows, q, t, out, out_stride, aligned);
+  else
+    hipLaunchKernelGGL((k_xyb_to_rgb8<4, MODE>), grid, dim3(kOutThreads), 0, s, planes[0], planes[1], planes[2],
+                       (uint32_t)stride, w, y0, rows, q, t, out, out_stride, aligned);
+}
+template <int MODE>
+void launch16_mode(hipStream_t s, const float* const planes[3], size_t stride, int w, int y0, int rows,
+                   const XybParamsDev& q, const TfParamsDev& t, int channels, uint16_t* out, size_t out_stride_elems) {
+  const dim3 grid((unsigned)(((w + 3) / 4 + kOutThreads - 1) / kOutThreads), (unsigned)rows);
+  if (channels == 3)
+    hipLaunchKernelGGL((k_xyb_to_rgb16<3, MODE>), grid, dim3(kOutThreads), 0, s, planes[0], planes[1], planes[2],
+                       (uint32_t)stride, w, y0, rows, q, t, out, out_stride_elems);
+  else
+    hipLaunchKernelGGL((k_xyb_to_rgb16<4, MODE>), grid, dim3(kOutThreads), 0, s, planes[0], planes[1], planes[2],
+                       (uint32_t)stride, w, y0, rows, q, t, out, out_stride_elems);
 }
 
-void launch_xyb_to_rgb16(hipStream_t s, const float* const planes[3], size_t stride, int w, int y0, int rows,
-                         const XybParamsDev* p, int channels, uint16_t* out, size_t out_stride_elems) {
+// mode: kTfLinear..kTfGamma (XYB frame + that transfer function), kModeYcbcr, kModeNone
+void launch_xyb_to_rgb8(hipStream_t s, const float* const planes[3], size_t stride, int w, int y0, int rows, int mode,
+                        const XybParamsDev& q, const TfParamsDev& t, int channels, uint8_t* out, size_t out_stride) {
   if (w <= 0 || rows <= 0) return;
-  const dim3 grid((unsigned)(((w + 3) / 4 + kOutThreads - 1) / kOutThreads), (unsigned)rows);
-  const XybParamsDev q = p ? *p : XybParamsDev{};
-#define JXLH_LAUNCH16(CH, Y)                                                                                     \
-  hipLaunchKernelGGL((k_xyb_to_rgb16<CH, Y>), grid, dim3(kOutThreads), 0, s, planes[0], planes[1], planes[2],    \
-                     (uint32_t)stride, w, y0, rows, q, out, out_stride_elems)
-  if (p) {
-    if (channels == 3) JXLH_LAUNCH16(3, false); else JXLH_LAUNCH16(4, false);
-  } else {
-    if (channels == 3) JXLH_LAUNCH16(3, true); else JXLH_LAUNCH16(4, true);
+  switch (mode) {
+    case kTfLinear: launch8_mode<kTfLinear>(s, planes, stride, w, y0, rows, q, t, channels, out, out_stride); break;
+    case kTfSrgb: launch8_mode<kTfSrgb>(s, planes, stride, w, y0, rows, q, t, channels, out, out_stride); break;
+    case kTfBt709: launch8_mode<kTfBt709>(s, planes, stride, w, y0, rows, q, t, channels, out, out_stride); break;
+    case kTfPq: launch8_mode<kTfPq>(s, planes, stride, w, y0, rows, q, t, channels, out, out_stride); break;
+    case kTfHlg: launch8_mode<kTfHlg>(s, planes, stride, w, y0, rows, q, t, channels, out, out_stride); break;
+    case kTfGamma: launch8_mode<kTfGamma>(s, planes, stride, w, y0, rows, q, t, channels, out, out_stride); break;
+    case kModeYcbcr: launch8_mode<kModeYcbcr>(s, planes, stride, w, y0, rows, q, t, channels, out, out_stride); break;
+    default: launch8_mode<kModeNone>(s, planes, stride, w, y0, rows, q, t, channels, out, out_stride); break;
   }
-#undef JXLH_LAUNCH16
+}
+
+void launch_xyb_to_rgb16(hipStream_t s, const float* const planes[3], size_t stride, int w, int y0, int rows, int mode,
+                         const XybParamsDev& q, const TfParamsDev& t, int channels, uint16_t* out, size_t out_stride_elems) {
+  if (w <= 0 || rows <= 0) return;
+  switch (mode) {
+    case kTfLinear: launch16_mode<kTfLinear>(s, planes, stride, w, y0, rows, q, t, channels, out, out_stride_elems); break;
+    case kTfSrgb: launch16_mode<kTfSrgb>(s, planes, stride, w, y0, rows, q, t, channels, out, out_stride_elems); break;
+    case kTfBt709: launch16_mode<kTfBt709>(s, planes, stride, w, y0, rows, q, t, channels, out, out_stride_elems); break;
+    case kTfPq: launch16_mode<kTfPq>(s, planes, stride, w, y0, rows, q, t, channels, out, out_stride_elems); break;
+    case kTfHlg: launch16_mode<kTfHlg>(s, planes, stride, w, y0, rows, q, t, channels, out, out_stride_elems); break;
+    case kTfGamma: launch16_mode<kTfGamma>(s, planes, stride, w, y0, rows, q, t, channels, out, out_stride_elems); break;
+    case kModeYcbcr: launch16_mode<kModeYcbcr>(s, planes, stride, w, y0, rows, q, t, channels, out, out_stride_elems); break;
+    default: launch16_mode<kModeNone>(s, planes, stride, w, y0, rows, q, t, channels, out, out_stride_elems); break;
+  }
 }
 
 }  // namespace jxlh

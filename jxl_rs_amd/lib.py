@@ -35,7 +35,7 @@ ABI_SYMBOLS = [
     "jxlh_frame_set_lf_quantized", "jxlh_frame_set_lf", "jxlh_frame_set_hf_meta", "jxlh_submit_group",
     "jxlh_submit_group_sparse", "jxlh_submit_groups_sparse", "jxlh_slot_wait", "jxlh_frame_coeff_buffer", "jxlh_frame_run", "jxlh_ctx_sync", "jxlh_frame_read_planes",
     "jxlh_frame_device_planes", "jxlh_frame_read_lf", "jxlh_frame_read_rgb8", "jxlh_frame_read_rgb16",
-    "jxlh_frame_read_ycbcr_rgb8", "jxlh_frame_read_ycbcr_rgb16", "jxlh_stage_chroma_upsample", "jxlh_stage_upsample", "jxlh_set_upsampling_weights", "jxlh_stage_noise_generate",
+    "jxlh_frame_read_ycbcr_rgb8", "jxlh_frame_read_ycbcr_rgb16", "jxlh_frame_read_output", "jxlh_stage_chroma_upsample", "jxlh_stage_upsample", "jxlh_set_upsampling_weights", "jxlh_stage_noise_generate",
     "jxlh_stage_noise_convolve", "jxlh_stage_noise_add", "jxlh_timer_start", "jxlh_timer_stop",
     "jxlh_kernel_timing_enable", "jxlh_kernel_timing_get", "jxlh_kernel_timing_reset", "jxlh_selftest_recip",
     "jxlh_stage_gaborish",
@@ -75,6 +75,16 @@ class FrameParams(C.Structure):
     ]
 
 
+class OutputDesc(C.Structure):
+    """jxlh_output_desc."""
+    _fields_ = [("color", C.c_uint32), ("transfer", C.c_uint32), ("xyb", C.c_float * 16), ("tf_param", C.c_float),
+                ("hlg_luminance_rgb", C.c_float * 3), ("bits", C.c_uint32), ("channels", C.c_uint32)]
+
+
+COLOR_XYB, COLOR_YCBCR, COLOR_NONE = 0, 1, 2
+TF = {"linear": 0, "srgb": 1, "bt709": 2, "pq": 3, "hlg": 4, "gamma": 5}
+
+
 class Plane(C.Structure):
     """jxlh_plane == RawImageBuffer."""
     _fields_ = [("ptr", C.c_void_p), ("bytes_per_row", C.c_size_t), ("num_rows", C.c_size_t),
@@ -107,6 +117,7 @@ def load():
     L.jxlh_frame_begin.argtypes = [vp, C.POINTER(FrameParams)]
     L.jxlh_frame_read_rgb8.argtypes = [vp, vp, u32, u32, u32, vp, sz]
     L.jxlh_frame_read_rgb16.argtypes = [vp, vp, u32, u32, u32, vp, sz]
+    L.jxlh_frame_read_output.argtypes = [vp, C.POINTER(OutputDesc), u32, u32, vp, sz]
     L.jxlh_frame_read_ycbcr_rgb8.argtypes = [vp, u32, u32, u32, vp, sz]
     L.jxlh_frame_read_ycbcr_rgb16.argtypes = [vp, u32, u32, u32, vp, sz]
     L.jxlh_stage_chroma_upsample.argtypes = [vp, vp, vp, u32, u32, i32]
@@ -323,6 +334,23 @@ class Context:
         arr = np.zeros((y1 - y0, self.out_size[0], channels), dtype=np.uint16)
         self._chk(self.L.jxlh_frame_read_rgb16(self._ctx, _addr(pr), channels, y0, y1, _addr(arr),
                                                self.out_size[0] * channels * 2), "frame_read_rgb16")
+        return arr
+
+    def read_output(self, color=COLOR_XYB, transfer="srgb", xyb_params=None, tf_param=0.0, lum=(0.2627, 0.678, 0.0593),
+                    bits=8, channels=3, y0=0, y1=None):
+        """jxlh_frame_read_output: interleaved 8- or 16-bit samples after the frame's colour stage"""
+        d = OutputDesc()
+        d.color, d.transfer, d.bits, d.channels, d.tf_param = color, TF[transfer], bits, channels, tf_param
+        if xyb_params is not None:
+            for i, v in enumerate(np.asarray(xyb_params, dtype=np.float32).ravel()):
+                d.xyb[i] = float(v)
+        for i in range(3):
+            d.hlg_luminance_rgb[i] = lum[i]
+        w, h = self.out_size
+        y1 = h if y1 is None else y1
+        arr = np.zeros((y1 - y0, w, channels), dtype=np.uint8 if bits == 8 else np.uint16)
+        self._chk(self.L.jxlh_frame_read_output(self._ctx, C.byref(d), y0, y1, _addr(arr), w * channels * (bits // 8)),
+                  "frame_read_output")
         return arr
 
     def read_ycbcr_rgb8(self, channels=3, y0=0, y1=None):

@@ -187,6 +187,17 @@ uint8_t jxlo_f32_to_u8(float v, size_t x, size_t y, int channel, int bit_depth);
 uint16_t jxlo_f32_to_u16(float v, int bit_depth);
 void jxlo_xyb_to_rgb16(const JxloXybParams* p, const float* px, const float* py, const float* pb, size_t w, size_t h,
                        size_t stride, uint16_t* out, size_t out_stride_elems, int out_channels);
+/* FromLinearStage (render/stages/from_linear.rs:57-112): kind 0 none, 1 sRGB, 2 BT.709, 3 PQ (param = intensity_target),
+ * 4 HLG (param = (1 - system_gamma) / system_gamma, lum = luminance_rgb), 5 gamma (param = exponent) */
+float jxlo_fast_powf(float base, float e, int simd);
+float jxlo_linear_to_bt709_1(float x);
+float jxlo_linear_to_pq_1(float intensity_target, float x);
+float jxlo_linear_to_gamma_1(float g, float x);
+void jxlo_linear_to_hlg_1(float exponent, const float lum[3], float* r, float* g, float* b);
+void jxlo_from_linear(int kind, float param, const float lum[3], float* r, float* g, float* b, size_t n);
+void jxlo_xyb_to_rgb_tf(const JxloXybParams* p, int kind, float param, const float lum[3], const float* px, const float* py,
+                        const float* pb, size_t w, size_t h, size_t stride, int bits, void* out, size_t out_stride_elems,
+                        int out_channels);
 /* a YCbCr frame (do_ycbcr, not XYB-encoded: frame/render.rs:755) shown as 8 / 16 bit: ycbcr, then the
  * integer conversion -- no transfer function stage */
 void jxlo_ycbcr_to_rgb8(const float* pcb, const float* py, const float* pcr, size_t w, size_t h, size_t stride,

@@ -183,3 +183,132 @@ void jxlo_ycbcr_to_rgb16(const float* pcb, const float* py, const float* pcr, si
     }
   }
 }
+
+/* ---- FromLinearStage, the other transfer functions (render/stages/from_linear.rs:57-112) ----
+ * The SIMD-dispatched curves (BT.709, PQ, gamma) use mul_add (= FMA on the FMA back-ends); HLG runs through the
+ * scalar helpers: plain mul/add Horner steps (util/rational_poly.rs:13-17, fast_math.rs:80-137) and a true fused
+ * f32::mul_add in the luminance mix (color/tf.rs:385). */
+#include "tf_constants.inc"
+
+static inline float ratpoly_simd(float x, const float* p, int np, const float* q, int nq) { /* rational_poly.rs:20-35 */
+  float yp = p[np - 1], yq = q[nq - 1];
+  for (int i = np - 2; i >= 0; i--) yp = mul_add(yp, x, p[i]);
+  for (int i = nq - 2; i >= 0; i--) yq = mul_add(yq, x, q[i]);
+  return yp / yq;
+}
+static inline float ratpoly_scalar(float x, const float* p, int np, const float* q, int nq) { /* :13-17 */
+  float yp = p[np - 1], yq = q[nq - 1];
+  for (int i = np - 2; i >= 0; i--) yp = yp * x + p[i];
+  for (int i = nq - 2; i >= 0; i--) yq = yq * x + q[i];
+  return yp / yq;
+}
+static inline float bits_f(int32_t b) { float f; memcpy(&f, &b, 4); return f; }
+static inline int32_t f_bits(float f) { int32_t b; memcpy(&b, &f, 4); return b; }
+
+static inline float fast_log2f_any(float x, int simd) { /* fast_math.rs:127-149 */
+  const int32_t x_bits = f_bits(x);
+  const int32_t exp_bits = (int32_t)((uint32_t)x_bits - 0x3f2aaaabu);
+  const int32_t exp_shifted = exp_bits >> 23;
+  const float mantissa = bits_f((int32_t)((uint32_t)x_bits - ((uint32_t)exp_shifted << 23)));
+  const float exp_val = (float)exp_shifted;
+  const float m1 = mantissa - 1.0f;
+  return (simd ? ratpoly_simd(m1, kTf_LOG2F_P, 3, kTf_LOG2F_Q, 3) : ratpoly_scalar(m1, kTf_LOG2F_P, 3, kTf_LOG2F_Q, 3)) + exp_val;
+}
+static inline float fast_pow2f_any(float x, int simd) { /* fast_math.rs:79-114 */
+  const float x_floor = floorf(x);
+  const float e = bits_f((int32_t)(((uint32_t)((int32_t)x_floor + 127)) << 23));
+  const float frac = x - x_floor;
+  float num = frac + kTf_POW2F_NUMER[0];
+  float den;
+  if (simd) {
+    num = mul_add(num, frac, kTf_POW2F_NUMER[1]);
+    num = mul_add(num, frac, kTf_POW2F_NUMER[2]);
+    num = num * e;
+    den = mul_add(kTf_POW2F_DENOM[0], frac, kTf_POW2F_DENOM[1]);
+    den = mul_add(den, frac, kTf_POW2F_DENOM[2]);
+    den = mul_add(den, frac, kTf_POW2F_DENOM[3]);
+  } else {
+    num = num * frac + kTf_POW2F_NUMER[1];
+    num = num * frac + kTf_POW2F_NUMER[2];
+    num = num * e;
+    den = kTf_POW2F_DENOM[0] * frac + kTf_POW2F_DENOM[1];
+    den = den * frac + kTf_POW2F_DENOM[2];
+    den = den * frac + kTf_POW2F_DENOM[3];
+  }
+  return num / den;
+}
+float jxlo_fast_powf(float base, float e, int simd) { return fast_pow2f_any(fast_log2f_any(base, simd) * e, simd); }
+
+float jxlo_linear_to_bt709_1(float x) { /* color/tf.rs:115-148 */
+  const float a = fabsf(x);
+  const float r = (0.018f > a) ? a * 4.5f : ratpoly_simd(sqrtf(a), kTf_BT709_P, 5, kTf_BT709_Q, 5);
+  return copysignf(r, x);
+}
+float jxlo_linear_to_pq_1(float intensity_target, float x) { /* color/tf.rs:288-314 */
+  const float y_mult = intensity_target * (1.0f / 10000.0f);
+  const float a = fabsf(x);
+  const float a_1_4 = sqrtf(sqrtf(a * y_mult));
+  const float y_small = ratpoly_simd(a_1_4, kTf_PQ_INV_EOTF_P_SMALL, 5, kTf_PQ_INV_EOTF_Q_SMALL, 5);
+  const float y_large = ratpoly_simd(a_1_4, kTf_PQ_INV_EOTF_P, 5, kTf_PQ_INV_EOTF_Q, 5);
+  return copysignf((1e-4f > a) ? y_small : y_large, x);
+}
+float jxlo_linear_to_gamma_1(float g, float x) { /* from_linear.rs:99-110 */
+  return copysignf(jxlo_fast_powf(fabsf(x), g, 1), x);
+}
+/* hlg_display_to_scene + scene_to_hlg (color/tf.rs:379-393, :437-447, :482-497); exponent =
+ * (1 - system_gamma) / system_gamma, the host-side scalar tf.rs:442-446 computes from intensity_target */
+void jxlo_linear_to_hlg_1(float exponent, const float lum[3], float* r, float* g, float* b) {
+  if (!(fabsf(exponent) < 0.1f)) {
+    const float mixed = fmaf(*r, lum[0], fmaf(*g, lum[1], *b * lum[2])); /* std f32::mul_add: always fused */
+    const float mult = jxlo_fast_powf(mixed, exponent, 0);
+    *r *= mult;
+    *g *= mult;
+    *b *= mult;
+  }
+  const double HLG_A = 0.17883277, HLG_B = 1.0 - 4.0 * HLG_A, HLG_C = 0.5599107295;
+  const float k = (float)(HLG_A * 0.693147180559945309417232121458176568), hb = (float)HLG_B, hc = (float)HLG_C;
+  float* v[3] = {r, g, b};
+  for (int i = 0; i < 3; i++) {
+    const float a = fabsf(*v[i]);
+    const float y = (a <= 1.0f / 12.0f) ? sqrtf(3.0f * a) : k * fast_log2f_any(12.0f * a - hb, 0) + hc;
+    *v[i] = copysignf(y, *v[i]);
+  }
+}
+
+/* kind: 0 linear (no stage), 1 sRGB, 2 BT.709, 3 PQ (param = intensity_target), 4 HLG (param = exponent, lum),
+ * 5 gamma (param = exponent) */
+void jxlo_from_linear(int kind, float param, const float lum[3], float* r, float* g, float* b, size_t n) {
+  for (size_t i = 0; i < n; i++) {
+    switch (kind) {
+      case 1: r[i] = jxlo_linear_to_srgb1(r[i]); g[i] = jxlo_linear_to_srgb1(g[i]); b[i] = jxlo_linear_to_srgb1(b[i]); break;
+      case 2: r[i] = jxlo_linear_to_bt709_1(r[i]); g[i] = jxlo_linear_to_bt709_1(g[i]); b[i] = jxlo_linear_to_bt709_1(b[i]); break;
+      case 3: r[i] = jxlo_linear_to_pq_1(param, r[i]); g[i] = jxlo_linear_to_pq_1(param, g[i]); b[i] = jxlo_linear_to_pq_1(param, b[i]); break;
+      case 4: jxlo_linear_to_hlg_1(param, lum, &r[i], &g[i], &b[i]); break;
+      case 5: r[i] = jxlo_linear_to_gamma_1(param, r[i]); g[i] = jxlo_linear_to_gamma_1(param, g[i]); b[i] = jxlo_linear_to_gamma_1(param, b[i]); break;
+      default: break;
+    }
+  }
+}
+
+/* XybStage -> FromLinearStage(kind) -> ConvertF32ToU8 / U16, the general form of jxlo_xyb_to_rgb8/16 */
+void jxlo_xyb_to_rgb_tf(const JxloXybParams* p, int kind, float param, const float lum[3], const float* px, const float* py,
+                        const float* pb, size_t w, size_t h, size_t stride, int bits, void* out, size_t out_stride_elems,
+                        int out_channels) {
+  for (size_t y = 0; y < h; y++) {
+    for (size_t x = 0; x < w; x++) {
+      float r = px[y * stride + x], g = py[y * stride + x], b = pb[y * stride + x];
+      jxlo_xyb_to_linear(p, &r, &g, &b, 1);
+      jxlo_from_linear(kind, param, lum, &r, &g, &b, 1);
+      const float v[3] = {r, g, b};
+      if (bits == 8) {
+        uint8_t* o = (uint8_t*)out + y * out_stride_elems + x * (size_t)out_channels;
+        for (int c = 0; c < 3; c++) o[c] = jxlo_f32_to_u8(v[c], x, y, c, 8);
+        if (out_channels == 4) o[3] = 255;
+      } else {
+        uint16_t* o = (uint16_t*)out + y * out_stride_elems + x * (size_t)out_channels;
+        for (int c = 0; c < 3; c++) o[c] = jxlo_f32_to_u16(v[c], 16);
+        if (out_channels == 4) o[3] = 65535;
+      }
+    }
+  }
+}

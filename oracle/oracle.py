@@ -131,6 +131,11 @@ class Oracle:
         L.jxlo_noise_strength.argtypes = [fp, C.c_float]
         L.jxlo_noise_strength.restype = C.c_float
         L.jxlo_noise_add.argtypes = [fp, C.c_float, C.c_float, fp, fp, fp, fp, fp, fp, C.c_size_t]
+        L.jxlo_fast_powf.argtypes = [C.c_float, C.c_float, C.c_int]
+        L.jxlo_fast_powf.restype = C.c_float
+        L.jxlo_from_linear.argtypes = [C.c_int, C.c_float, fp, fp, fp, fp, C.c_size_t]
+        L.jxlo_xyb_to_rgb_tf.argtypes = [fp, C.c_int, C.c_float, fp, fp, fp, fp, C.c_size_t, C.c_size_t, C.c_size_t,
+                                         C.c_int, C.c_void_p, C.c_size_t, C.c_int]
         L.jxlo_ycbcr_to_rgb.argtypes = [fp, fp, fp, C.c_size_t]
         L.jxlo_ycbcr_to_rgb8.argtypes = [fp, fp, fp, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(C.c_uint8),
                                          C.c_size_t, C.c_int]
@@ -468,6 +473,28 @@ class Oracle:
         self.lib.jxlo_noise_add(_ptr(lut, C.c_float), C.c_float(ytox), C.c_float(ytob), *[_ptr(a, C.c_float) for a in pl],
                                 *[_ptr(a, C.c_float) for a in rn], pl[0].size)
         return pl
+
+    TF_KINDS = {"linear": 0, "srgb": 1, "bt709": 2, "pq": 3, "hlg": 4, "gamma": 5}
+
+    def from_linear(self, kind, rgb, param=0.0, lum=(0.2627, 0.678, 0.0593)):
+        a = [_f32(v).copy() for v in rgb]
+        lum = np.ascontiguousarray(lum, dtype=np.float32)
+        self.lib.jxlo_from_linear(self.TF_KINDS[kind], C.c_float(param), _ptr(lum, C.c_float),
+                                  *[_ptr(v, C.c_float) for v in a], a[0].size)
+        return a
+
+    def fast_powf(self, base, e, simd=True):
+        return float(self.lib.jxlo_fast_powf(C.c_float(base), C.c_float(e), 1 if simd else 0))
+
+    def xyb_to_rgb_tf(self, params, kind, planes, w, h, channels=3, bits=8, param=0.0, lum=(0.2627, 0.678, 0.0593)):
+        pl = [np.ascontiguousarray(a, dtype=np.float32) for a in planes]
+        p = np.ascontiguousarray(params, dtype=np.float32)
+        lum = np.ascontiguousarray(lum, dtype=np.float32)
+        out = np.zeros((h, w, channels), dtype=np.uint8 if bits == 8 else np.uint16)
+        self.lib.jxlo_xyb_to_rgb_tf(_ptr(p, C.c_float), self.TF_KINDS[kind], C.c_float(param), _ptr(lum, C.c_float),
+                                    _ptr(pl[0], C.c_float), _ptr(pl[1], C.c_float), _ptr(pl[2], C.c_float), w, h,
+                                    pl[0].shape[1], bits, out.ctypes.data, w * channels, channels)
+        return out
 
     def ycbcr_to_rgb(self, cb, y, cr):
         a = [_f32(v).copy() for v in (cb, y, cr)]

@@ -801,6 +801,35 @@ def test_rgb8_output_bit_exact(ctx, oracle, kat, size, channels, intensity):
     assert np.array_equal(ctx.read_rgb16(params, channels, y0, y1), want16[y0:y1])
 
 
+@pytest.mark.parametrize("tf,param", [("linear", 0.0), ("srgb", 0.0), ("bt709", 0.0), ("pq", 10000.0), ("pq", 4000.0),
+                                      ("hlg", -0.1667), ("hlg", 0.05), ("gamma", 0.45454545)])
+@pytest.mark.parametrize("bits,channels", [(8, 3), (16, 4)])
+def test_output_transfer_functions_bit_exact(ctx, oracle, kat, tf, param, bits, channels):
+    """XybStage + FromLinearStage(tf) + integer conversion through jxlh_frame_read_output, every transfer function
+    of render/stages/from_linear.rs:133-145, byte for byte vs the oracle"""
+    from jxl_rs_amd import synth, lib
+    w, h = 300, 140
+    wl = synth.make_vardct(w, h, mix=synth.MIX_D1, seed=11, epf_iters=1)
+    want_planes, _ = run_oracle_frame(oracle, wl)
+    params = _default_xyb_params(oracle, kat, 255.0 if tf != "pq" else param)
+    lum = (0.2627, 0.678, 0.0593)
+    want = oracle.xyb_to_rgb_tf(params, tf, want_planes, w, h, channels, bits, param, lum)
+    upload_frame(ctx, wl)
+    ctx.frame_run()
+    ctx.sync()
+    got = ctx.read_output(lib.COLOR_XYB, tf, params, param, lum, bits, channels)
+    bad = np.argwhere(got != want)
+    assert bad.size == 0, f"{len(bad)} differing samples, first at {bad[0]}: got {got[tuple(bad[0])]} want {want[tuple(bad[0])]}"
+    assert len(np.unique(want)) > 16
+    if tf == "srgb":  # the dedicated entry points are this call
+        ref = ctx.read_rgb8(params, channels) if bits == 8 else ctx.read_rgb16(params, channels)
+        assert np.array_equal(got, ref)
+    # COLOR_NONE: the planes are taken as RGB
+    raw = ctx.read_output(lib.COLOR_NONE, "linear", None, 0.0, lum, 16, 3)
+    want_raw = np.stack([np.rint(np.clip(p, 0, 1) * np.float32(65535)).astype(np.uint16) for p in want_planes], axis=-1)
+    assert np.array_equal(raw, want_raw)
+
+
 def test_rgb8_output_argument_errors(ctx, oracle, kat):
     from jxl_rs_amd import synth
     from jxl_rs_amd.lib import JxlHipError

@@ -355,3 +355,46 @@ def test_noise_generation_structure(oracle):
     c2 = oracle.noise_generate(1, 3, 600, 300)
     assert not np.array_equal(a[0], c2[0])
     assert abs(float(a[0].mean()) - 1.5) < 0.01
+
+
+# ---------------------------------------------------------------- transfer functions (FromLinearStage)
+def test_transfer_functions_against_their_definitions(oracle_any, kat):
+    """color/tf.rs:575-800 checks each approximation against the defining formula on samples in [-1, 1]; the same
+    comparisons (f64 definitions) with the reference's tolerances"""
+    tol = kat["transfer_functions"]["tolerances"]
+    x = np.linspace(-1, 1, 100001).astype(np.float32)
+    a = np.abs(x.astype(np.float64))
+    sign = np.sign(x)
+    got = oracle_any.from_linear("srgb", [x, x, x])[1]
+    assert np.abs(got - np.where(np.abs(x) <= np.float32(0.0031308), a * 12.92, 1.055 * a ** (1 / 2.4) - 0.055) * sign).max() <= tol["srgb_vs_pow"]
+    got = oracle_any.from_linear("bt709", [x, x, x])[2]
+    keep = np.abs(x) != np.float32(0.018)   # `0.018 > a` vs the definition's `a <= 0.018`: the one sample they disagree on
+    want = np.where(np.abs(x) < np.float32(0.018), a * 4.5, 1.099 * a ** 0.45 - 0.099) * sign
+    assert np.abs(got - want)[keep].max() <= tol["bt709_vs_pow"]
+    m1, m2, c1, c2, c3 = 2610 / 16384, 2523 / 4096 * 128, 3424 / 4096, 2413 / 4096 * 32, 2392 / 4096 * 32
+    for it in (9900.0, 10000.0, 10100.0):
+        got = oracle_any.from_linear("pq", [x, x, x], param=it)[0]
+        xp = (a * it / 10000.0) ** m1
+        want = ((c1 + xp * c2) / (1 + xp * c3)) ** m2 * sign
+        # the SIMD form differs from the scalar one by up to 2e-5 near zero (tf.rs:690-706); away from it both meet 8e-7
+        near0 = a < 1e-3
+        assert np.abs(got - want)[~near0].max() <= tol["pq_vs_precise"]
+        assert np.abs(got - want)[near0 & (a > 0)].max() <= tol["pq_simd_vs_scalar"]
+    got = oracle_any.from_linear("hlg", [x, x, x], param=0.0)[0]   # exponent 0: OOTF skipped (|exp| < 0.1)
+    A, C = 0.17883277, 0.5599107295
+    B = 1 - 4 * A
+    want = np.where(a <= 1 / 12, np.sqrt(3 * a), A * np.log(np.maximum(12 * a - B, 1e-30)) + C) * sign
+    assert np.abs(got - want).max() <= tol["hlg_vs_precise"]
+    xs = np.linspace(1e-3, 1, 4000).astype(np.float32)
+    for g in (0.45, 1 / 2.2, 0.9):
+        got = oracle_any.from_linear("gamma", [xs, xs, xs], param=g)[0]
+        assert np.abs(got / xs.astype(np.float64) ** g - 1).max() <= tol["powf_rel"]
+    # HLG inverse OOTF: mult = mixed^exponent on the luminance mix
+    r, g_, b = [np.float32([v]) for v in (0.4, 0.3, 0.2)]
+    lum = (0.2627, 0.678, 0.0593)
+    e = -0.1667
+    out = oracle_any.from_linear("hlg", [r, g_, b], param=e, lum=lum)
+    mixed = 0.4 * lum[0] + 0.3 * lum[1] + 0.2 * lum[2]
+    sc = [v * mixed ** e for v in (0.4, 0.3, 0.2)]
+    want = [np.sqrt(3 * v) if v <= 1 / 12 else A * np.log(12 * v - B) + C for v in sc]
+    assert max(abs(float(out[i][0]) - want[i]) for i in range(3)) < 2e-5
