@@ -849,8 +849,10 @@ jxlh_status jxlh_frame_run(jxlh_ctx* ctx, uint32_t group_row0, uint32_t group_ro
   // ---- K1 on the band plus one halo group row on each side (filters read across it)
   const int halo_px = (f.gab ? 1 : 0) + (f.epf_iters >= 3 ? 3 : 0) + (f.epf_iters >= 1 ? 2 : 0) +
                       (f.epf_iters >= 2 ? 1 : 0);
-  const int gr0 = halo_px > 0 && group_row0 > 0 ? (int)group_row0 - 1 : (int)group_row0;
-  const int gr1 = halo_px > 0 && group_row1 < (uint32_t)f.ygroups ? (int)group_row1 + 1 : (int)group_row1;
+  // (vertical chroma upsampling reads one sub-sampled row beyond the band as well)
+  const bool need_halo = halo_px > 0 || f.subsampled;
+  const int gr0 = need_halo && group_row0 > 0 ? (int)group_row0 - 1 : (int)group_row0;
+  const int gr1 = need_halo && group_row1 < (uint32_t)f.ygroups ? (int)group_row1 + 1 : (int)group_row1;
   // K1 writes the 8x8-tiled layout whenever the fused filter kernel is its only consumer
   const bool will_fuse = !(p.flags & JXLH_FRAME_UNFUSED_FILTERS) && (f.gab || f.epf_iters > 0);
   f.tiled = will_fuse ? 1 : 0;

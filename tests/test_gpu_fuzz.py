@@ -149,3 +149,80 @@ def test_random_subsampled_frames_bit_exact(ctx, oracle, seed):
     channels = 3 + seed % 2
     want8 = oracle.ycbcr_to_rgb8([np.ascontiguousarray(p) for p in want], w, h, channels)
     assert np.array_equal(ctx.read_ycbcr_rgb8(channels), want8), f"rgb8 {desc}"
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_random_feature_combinations_bit_exact(ctx, oracle, kat, seed):
+    """Everything after the transforms, combined at random: chroma subsampling or not, 2x/4x/8x upsampling with
+    default or custom weights and cropped target size, noise, whole frame or a band of group rows, and a random
+    output transfer function at 8 or 16 bits"""
+    from jxl_rs_amd import synth, lib
+    import helpers
+    rng = np.random.default_rng(9000 + seed)
+    w, h = int(rng.integers(20, 420)), int(rng.integers(20, 560))
+    sub = bool(rng.integers(0, 2))
+    hs = vs = (0, 0, 0)
+    if sub:
+        hs, vs = tuple(int(v) for v in rng.integers(0, 2, 3)), tuple(int(v) for v in rng.integers(0, 2, 3))
+        if not (any(hs) or any(vs)):
+            vs = (1, 0, 1)
+    ups = int(rng.choice([1, 1, 2, 4, 8])) if w * h < 60000 else int(rng.choice([1, 2]))
+    noise = bool(rng.integers(0, 2))
+    opts = dict(epf_iters=int(rng.integers(0, 4)), gab=bool(rng.integers(0, 2)), lf_smoothing=bool(rng.integers(0, 2)))
+    wl = synth.make_vardct(w, h, mix=synth.MIX_8X8 if sub else synth.MIX_ALL, seed=seed, hshift=hs, vshift=vs, **opts)
+    over = dict(ytox_lf=int(rng.integers(-20, 21)), ytob_lf=int(rng.integers(-20, 21)))
+    base, _ = helpers.run_oracle_frame(oracle, wl, **over)
+    ow, oh = w * ups, h * ups
+    custom = None
+    if ups > 1:
+        if rng.random() < 0.5:  # any size whose ceil division by ups is the coded size
+            ow, oh = int(rng.integers((w - 1) * ups + 1, w * ups + 1)), int(rng.integers((h - 1) * ups + 1, h * ups + 1))
+        if rng.random() < 0.5:
+            custom = rng.uniform(-0.05, 0.2, {2: 15, 4: 55, 8: 210}[ups]).astype(np.float32)
+        base = [oracle.upsample(ups, np.ascontiguousarray(p), custom)[:oh, :ow] for p in base]
+    lut = rng.uniform(0, 0.4, 8).astype(np.float32)
+    vis, nonvis = int(rng.integers(0, 100)), int(rng.integers(0, 100))
+    p = helpers.gpu_params_from(ctx, wl, upsampling=ups, xsize_upsampled=ow if ups > 1 else 0,
+                                ysize_upsampled=oh if ups > 1 else 0, noise=int(noise), visible_frame_index=vis,
+                                nonvisible_frame_index=nonvis, **over)
+    for i in range(8):
+        p.noise_lut[i] = float(lut[i])
+    if noise:
+        ytox = float(np.float32(p.base_correlation_x) + np.float32(over["ytox_lf"]) / np.float32(p.color_factor))
+        ytob = float(np.float32(p.base_correlation_b) + np.float32(over["ytob_lf"]) / np.float32(p.color_factor))
+        rnd = [oracle.noise_convolve(r) for r in oracle.noise_generate(vis, nonvis, ow, oh)]
+        base = oracle.noise_add(lut, ytox, ytob, [np.ascontiguousarray(q) for q in base], rnd)
+    ctx.set_upsampling_weights(**({f"w{ups}": custom} if custom is not None else {}))
+    ctx.frame_begin(p)
+    ctx.set_dequant_tables(wl.tables)
+    ctx.set_lf_quantized(*wl.lf_q)
+    ctx.set_hf_meta(wl.transform_map, wl.raw_quant, wl.epf_map, wl.ytox, wl.ytob)
+    for g in range(wl.coeffs.shape[0]):
+        if seed % 2:
+            ctx.submit_group_sparse(g, *synth.to_sparse(wl.coeffs[g]))
+        else:
+            ctx.submit_group(g, wl.coeffs[g])
+    ctx.slot_wait(0)
+    ygroups = (h + 255) // 256
+    band = ups == 1 and ygroups > 1 and rng.random() < 0.6
+    r0, r1 = (int(rng.integers(0, ygroups)), ygroups) if band else (0, ygroups)
+    if band:
+        r1 = int(rng.integers(r0 + 1, ygroups + 1))
+    ctx.frame_run(r0, r1)
+    ctx.sync()
+    got = ctx.read_planes()
+    y0, y1 = (r0 * 256, min(h, r1 * 256)) if band else (0, oh)
+    desc = f"{w}x{h} sub={hs}/{vs} ups={ups}->{ow}x{oh} custom={custom is not None} noise={noise} rows {y0}:{y1} {opts}"
+    for c in range(3):
+        assert bit_equal(got[c][y0:y1], base[c][y0:y1]), f"plane {c} {desc}: {diff_report(got[c][y0:y1], base[c][y0:y1])}"
+    ctx.set_upsampling_weights()
+    # output stage on the rows that were computed
+    tf = str(rng.choice(["linear", "srgb", "bt709", "pq", "hlg", "gamma"]))
+    param = {"pq": 4000.0, "hlg": -0.2, "gamma": 0.5}.get(tf, 0.0)
+    bits, channels = int(rng.choice([8, 16])), int(rng.choice([3, 4]))
+    lum = (0.2627, 0.678, 0.0593)
+    k = kat["output_stage"]
+    xp = oracle.xyb_params(k["opsin_inverse_matrix"], [k["opsin_bias"]] * 3, 255.0)
+    want = oracle.xyb_to_rgb_tf(xp, tf, [np.ascontiguousarray(q) for q in base], ow, oh, channels, bits, param, lum)
+    out = ctx.read_output(lib.COLOR_XYB, tf, xp, param, lum, bits, channels, y0, y1)
+    assert np.array_equal(out, want[y0:y1]), f"output {tf}/{bits}/{channels} {desc}"
