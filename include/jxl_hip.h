@@ -360,6 +360,13 @@ jxlh_status jxlh_rct(jxlh_ctx* ctx, int32_t* p0, int32_t* p1, int32_t* p2, size_
 jxlh_status jxlh_palette(jxlh_ctx* ctx, const int32_t* index, size_t n, const int32_t* palette,
                          int32_t num_colors, size_t palette_stride, int32_t nb_channels,
                          int32_t bit_depth, int32_t* out);
+/* do_palette_step_general with delta entries and / or a neighbour predictor (palette.rs:228-251): index is w x h,
+ * entries below num_deltas are added to Predictor::predict_one (modular/predict.rs:152-198; predictor = Predictor
+ * as u32, 6 = Weighted is JXLH_ERR_UNSUPPORTED) of the already reconstructed neighbours, palette_size =
+ * num_colors + num_deltas.  Sequential by nature: runs as a skewed wavefront, far from bandwidth bound. */
+jxlh_status jxlh_palette_delta(jxlh_ctx* ctx, const int32_t* index, uint32_t w, uint32_t h, const int32_t* palette,
+                               int32_t num_colors, int32_t num_deltas, size_t palette_stride, int32_t nb_channels,
+                               int32_t bit_depth, int32_t predictor, int32_t* out);
 /* do_hsqueeze_step / do_vsqueeze_step (squeeze.rs:456-481, :661-682), whole plane.
  * horizontal: avg is ceil(out_w/2) x h, res floor(out_w/2) x h; vertical likewise in y. */
 jxlh_status jxlh_unsqueeze(jxlh_ctx* ctx, int32_t horizontal, const int32_t* avg, size_t avg_stride,

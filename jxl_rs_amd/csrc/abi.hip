@@ -1478,6 +1478,34 @@ jxlh_status jxlh_palette(jxlh_ctx* ctx, const int32_t* index, size_t n, const in
   return stage_out(ctx, out, (const int32_t*)ctx->hook_i[2].p, n * nb_channels);
 }
 
+jxlh_status jxlh_palette_delta(jxlh_ctx* ctx, const int32_t* index, uint32_t w, uint32_t h, const int32_t* palette,
+                               int32_t num_colors, int32_t num_deltas, size_t palette_stride, int32_t nb_channels,
+                               int32_t bit_depth, int32_t predictor, int32_t* out) {
+  if (!ctx || !index || !palette || !out || num_colors < 0 || num_deltas < 0 || nb_channels < 1 || nb_channels > 64 ||
+      bit_depth < 1 || bit_depth > 24 || palette_stride < (size_t)num_colors + (size_t)num_deltas || predictor < 0 ||
+      predictor > 13 || w > (1u << 20) || h > (1u << 20))
+    return JXLH_ERR_INVALID_ARGUMENT;
+  if (predictor == 6) return JXLH_ERR_UNSUPPORTED;  // Weighted: its own stateful branch (palette.rs:200-227), host
+  if (w == 0 || h == 0) return JXLH_OK;
+  const size_t n = (size_t)w * h, pal_n = palette_stride * (size_t)nb_channels;
+  if (n * (size_t)nb_channels >= (1ull << 31)) return JXLH_ERR_UNSUPPORTED;
+  if (is_device_ptr(index) && is_device_ptr(palette) && is_device_ptr(out)) {
+    ScopedKernelTimer t(ctx, "k5_palette_delta");
+    launch_palette_delta(ctx->stream, index, (int)w, (int)h, palette, num_colors, num_deltas, palette_stride,
+                         nb_channels, bit_depth, predictor, out);
+    HIPCHK(ctx, hipGetLastError());
+    return JXLH_OK;
+  }
+  jxlh_status st;
+  if ((st = stage_in(ctx, ctx->hook_i[0], index, n))) return st;
+  if ((st = stage_in(ctx, ctx->hook_i[1], palette, pal_n ? pal_n : 1))) return st;
+  if ((st = ensure(ctx, ctx->hook_i[2], n * nb_channels))) return st;
+  launch_palette_delta(ctx->stream, ctx->hook_i[0].p, (int)w, (int)h, ctx->hook_i[1].p, num_colors, num_deltas,
+                       palette_stride, nb_channels, bit_depth, predictor, ctx->hook_i[2].p);
+  HIPCHK(ctx, hipGetLastError());
+  return stage_out(ctx, out, (const int32_t*)ctx->hook_i[2].p, n * nb_channels);
+}
+
 jxlh_status jxlh_unsqueeze(jxlh_ctx* ctx, int32_t horizontal, const int32_t* avg, size_t avg_stride,
                            const int32_t* res, size_t res_stride, uint32_t out_w, uint32_t out_h, int32_t* out,
                            size_t out_stride) {

@@ -119,6 +119,93 @@ __device__ __forceinline__ int32_t palette_value(const int32_t* __restrict__ pal
   return palette[(size_t)c * pstride + i];
 }
 
+// ---- palette step with delta entries and / or a neighbour predictor (do_palette_step_general, palette.rs:228-251)
+// Entries below num_deltas are ADDED to a prediction from already reconstructed neighbours (left, top row up to
+// x + 2, the row above that): a raster-order dependency.  Pixel (x, y) can go once (x - 1, y) and (x + 2, y - 1)
+// are done, so all pixels with the same x + 3y are independent: a workgroup takes a band of kDeltaRows rows, lane
+// l = row, and at step s lane l handles x = s - 3l (a skewed wavefront).  A row's recent outputs live in an LDS
+// ring of 8 columns (the row below reads columns x - 1 .. x + 2, the one after x; the owner is writing x + 3 / x + 6
+// at that moment), its own left / leftleft in registers; one barrier per step.  Bands run one after the other in the
+// same workgroup, the first rows of a band reading the previous band's last two rows from global memory.
+// One workgroup per channel: (w + 3 * kDeltaRows) * ceil(h / kDeltaRows) steps -- correct and on the device, not fast
+// (a cross-workgroup pipeline of the bands would cut it to w + 3h steps).
+constexpr int kDeltaRows = 1024;
+
+__device__ __forceinline__ int64_t predict_one(int predictor, int64_t left, int64_t top, int64_t toptop, int64_t topleft,
+                                               int64_t topright, int64_t leftleft, int64_t toprightright) {
+  switch (predictor) {  // Predictor::predict_one, modular/predict.rs:152-198 (i64, `/` truncates)
+    case 1: return left;
+    case 2: return top;
+    case 3: return (top + left) / 2;
+    case 4: {
+      const int64_t p = left + top - topleft;
+      const int64_t dl = p - left < 0 ? left - p : p - left, dt = p - top < 0 ? top - p : p - top;
+      return dl < dt ? left : top;
+    }
+    case 5: {
+      const int64_t mn = left < top ? left : top, mx = left < top ? top : left;
+      const int64_t grad = left + top - topleft;
+      const int64_t gmax = topleft < mn ? mx : grad;
+      return topleft > mx ? mn : gmax;
+    }
+    case 7: return topright;
+    case 8: return topleft;
+    case 9: return leftleft;
+    case 10: return (left + topleft) / 2;
+    case 11: return (top + topleft) / 2;
+    case 12: return (top + topright) / 2;
+    case 13: return (6 * top - 2 * toptop + 7 * left + leftleft + toprightright + 3 * topright + 8) / 16;
+    default: return 0;
+  }
+}
+
+__global__ __launch_bounds__(kDeltaRows) void k5_palette_delta(const int32_t* __restrict__ index, int w, int h,
+                                                               const int32_t* __restrict__ palette, int num_colors,
+                                                               int num_deltas, size_t pstride, int bit_depth,
+                                                               int predictor, int32_t* out_base) {
+  __shared__ int32_t s_ring[kDeltaRows][8];
+  const int c = blockIdx.x, l = threadIdx.x;
+  int32_t* out = out_base + (size_t)c * (size_t)w * h;  // no __restrict__: rows are read back
+  const int palette_size = num_colors + num_deltas;
+  for (int y0 = 0; y0 < h; y0 += kDeltaRows) {
+    const int rows = min(kDeltaRows, h - y0);
+    const int y = y0 + l;
+    const int32_t* __restrict__ irow = index + (size_t)min(y, h - 1) * w;
+    int32_t* orow = out + (size_t)min(y, h - 1) * w;
+    int32_t left_v = 0, leftleft_v = 0;  // out[y][x - 1], out[y][x - 2]
+    const int nsteps = w + 3 * (rows - 1);
+    for (int s = 0; s < nsteps; s++) {
+      const int x = s - 3 * l;
+      if (l < rows && x >= 0 && x < w) {
+        const int32_t idx = irow[x];
+        int32_t val = palette_value(palette, pstride, idx, c, palette_size, bit_depth);
+        if (idx < num_deltas) {
+          // row y - 1 / y - 2: the LDS ring of the lane above, or -- for the band's first rows -- global memory
+          auto T = [&](int xx) -> int32_t { return l > 0 ? s_ring[l - 1][xx & 7] : out[(size_t)(y - 1) * w + xx]; };
+          auto TT = [&](int xx) -> int32_t { return l > 1 ? s_ring[l - 2][xx & 7] : out[(size_t)(y - 2) * w + xx]; };
+          // PredictionData::get_rows, modular/predict.rs:96-128
+          const int64_t left = x > 0 ? left_v : (y > 0 ? T(0) : 0);
+          const int64_t top = y > 0 ? T(x) : left;
+          const int64_t topleft = (x > 0 && y > 0) ? T(x - 1) : left;
+          const int64_t topright = (x + 1 < w && y > 0) ? T(x + 1) : top;
+          const int64_t leftleft = x > 1 ? leftleft_v : left;
+          const int64_t toptop = y > 1 ? TT(x) : top;
+          const int64_t toprightright = (x + 2 < w && y > 0) ? T(x + 2) : topright;
+          const int64_t pred = predict_one(predictor, left, top, toptop, topleft, topright, leftleft, toprightright);
+          val = (int32_t)(uint32_t)(uint64_t)(pred + (int64_t)val);
+        }
+        orow[x] = val;
+        s_ring[l][x & 7] = val;
+        leftleft_v = left_v;
+        left_v = val;
+      }
+      __syncthreads();
+    }
+    __threadfence();  // the next band reads this band's last rows from global memory
+    __syncthreads();
+  }
+}
+
 // LDS_PAL: the explicit palette (num_colors x nb_channels entries, <= kPalLdsEntries) is staged in LDS
 // once per workgroup (persistent grid), so the per-pixel gathers never leave the CU.
 constexpr int kPalLdsEntries = 12288;  // 48 KB
@@ -336,6 +423,14 @@ void launch_palette(hipStream_t s, const int32_t* index, size_t n, const int32_t
     hipLaunchKernelGGL(k5_palette<false>, dim3(grid), dim3(256), 0, s, index, n, palette, num_colors, palette_stride,
                        nb_channels, bit_depth, out);
   }
+}
+
+void launch_palette_delta(hipStream_t s, const int32_t* index, int w, int h, const int32_t* palette, int num_colors,
+                          int num_deltas, size_t palette_stride, int nb_channels, int bit_depth, int predictor,
+                          int32_t* out) {
+  if (w <= 0 || h <= 0) return;
+  hipLaunchKernelGGL(k5_palette_delta, dim3(nb_channels), dim3(kDeltaRows), 0, s, index, w, h, palette, num_colors,
+                     num_deltas, palette_stride, bit_depth, predictor, out);
 }
 
 void launch_unsqueeze(hipStream_t s, int horizontal, int n_planes, const int32_t* const avg[], size_t avg_stride,

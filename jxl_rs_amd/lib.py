@@ -39,7 +39,7 @@ ABI_SYMBOLS = [
     "jxlh_stage_noise_convolve", "jxlh_stage_noise_add", "jxlh_timer_start", "jxlh_timer_stop",
     "jxlh_kernel_timing_enable", "jxlh_kernel_timing_get", "jxlh_kernel_timing_reset", "jxlh_selftest_recip",
     "jxlh_stage_gaborish",
-    "jxlh_stage_epf", "jxlh_stage_lf_smooth", "jxlh_stage_transform_to_pixels", "jxlh_rct", "jxlh_palette",
+    "jxlh_stage_epf", "jxlh_stage_lf_smooth", "jxlh_stage_transform_to_pixels", "jxlh_rct", "jxlh_palette", "jxlh_palette_delta",
     "jxlh_unsqueeze", "jxlh_unsqueeze_planes", "jxlh_abi_version", "jxlh_covered_blocks_x", "jxlh_covered_blocks_y",
     "jxlh_quant_table_for_type", "jxlh_quant_table_size",
 ]
@@ -152,6 +152,7 @@ def load():
     L.jxlh_stage_transform_to_pixels.argtypes = [vp, i32, u32, vp, vp, vp]
     L.jxlh_rct.argtypes = [vp, vp, vp, vp, sz, i32, i32]
     L.jxlh_palette.argtypes = [vp, vp, sz, vp, i32, sz, i32, i32, vp]
+    L.jxlh_palette_delta.argtypes = [vp, vp, u32, u32, vp, i32, i32, sz, i32, i32, i32, vp]
     L.jxlh_unsqueeze.argtypes = [vp, i32, vp, sz, vp, sz, u32, u32, vp, sz]
     L.jxlh_unsqueeze_planes.argtypes = [vp, i32, i32, C.POINTER(vp), sz, C.POINTER(vp), sz, u32, u32, C.POINTER(vp), sz]
     L.jxlh_abi_version.restype = u32
@@ -515,6 +516,16 @@ class Context:
         out = np.zeros((nb_channels,) + idx.shape, dtype=np.int32)
         self._chk(self.L.jxlh_palette(self._ctx, _addr(idx), idx.size, _addr(pal), num_colors, pal.shape[1],
                                       nb_channels, bit_depth, _addr(out)), "palette")
+        return out
+
+    def palette_delta(self, index, palette, num_colors, num_deltas, bit_depth, predictor):
+        """index [h, w]; palette [nb_channels, >= num_colors + num_deltas] -> [nb_channels, h, w] (jxlh_palette_delta)"""
+        idx = np.ascontiguousarray(index, dtype=np.int32)
+        pal = np.ascontiguousarray(palette, dtype=np.int32)
+        h, w = idx.shape
+        out = np.zeros((pal.shape[0], h, w), dtype=np.int32)
+        self._chk(self.L.jxlh_palette_delta(self._ctx, _addr(idx), w, h, _addr(pal), num_colors, num_deltas, pal.shape[1],
+                                            pal.shape[0], bit_depth, predictor, _addr(out)), "palette_delta")
         return out
 
     def unsqueeze_planes(self, horizontal, avg, res, out, out_w, out_h, avg_stride, res_stride, out_stride):

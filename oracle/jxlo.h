@@ -238,6 +238,10 @@ void jxlo_rct(int32_t* p0, int32_t* p1, int32_t* p2, size_t n, int op, int perm)
  * palette_stride; out channel c at out + c*n */
 void jxlo_palette(const int32_t* index, size_t n, const int32_t* palette, int num_colors,
                   size_t palette_stride, int nb_channels, int bit_depth, int32_t* out);
+/* do_palette_step_general with delta entries / a predictor (palette.rs:228-251); predictor = Predictor as u32
+ * (modular/predict.rs:16-31), anything but 6 (Weighted) */
+void jxlo_palette_delta(const int32_t* index, int w, int h, const int32_t* palette, int num_colors, int num_deltas,
+                        size_t palette_stride, int nb_channels, int bit_depth, int predictor, int32_t* out);
 int32_t jxlo_palette_value(const int32_t* palette, size_t palette_stride, int64_t index, int c,
                            int palette_size, int bit_depth);
 /* squeeze.rs:143-194,389-481,576-682 whole-plane (no neighbour tiles) */

@@ -105,6 +105,66 @@ void jxlo_palette(const int32_t* index, size_t n, const int32_t* palette, int nu
           jxlo_palette_value(palette, palette_stride, (int64_t)index[i], c, num_colors, bit_depth);
 }
 
+/* Predictor::predict_one without the weighted predictor (modular/predict.rs:152-198) on the neighbourhood
+ * PredictionData::get builds (:96-137), i64 arithmetic, `/` truncating like Rust's */
+static int64_t predict_one(int predictor, const int32_t* out, int w, int x, int y) {
+  const int32_t* row = out + (size_t)y * w;
+  const int32_t* row_top = out + (size_t)(y > 0 ? y - 1 : 0) * w;
+  const int32_t* row_toptop = out + (size_t)(y > 1 ? y - 2 : 0) * w;
+  const int64_t left = x > 0 ? row[x - 1] : (y > 0 ? row_top[0] : 0);
+  const int64_t top = y > 0 ? row_top[x] : left;
+  const int64_t topleft = (x > 0 && y > 0) ? row_top[x - 1] : left;
+  const int64_t topright = (x + 1 < w && y > 0) ? row_top[x + 1] : top;
+  const int64_t leftleft = x > 1 ? row[x - 2] : left;
+  const int64_t toptop = y > 1 ? row_toptop[x] : top;
+  const int64_t toprightright = (x + 2 < w && y > 0) ? row_top[x + 2] : topright;
+  switch (predictor) {
+    case 0: return 0;
+    case 1: return left;
+    case 2: return top;
+    case 3: return (top + left) / 2;
+    case 4: { /* select, :191-198 */
+      const int64_t p = left + top - topleft;
+      const int64_t dl = p - left < 0 ? left - p : p - left, dt = p - top < 0 ? top - p : p - top;
+      return dl < dt ? left : top;
+    }
+    case 5: { /* clamped_gradient, :139-146 */
+      const int64_t mn = left < top ? left : top, mx = left < top ? top : left;
+      const int64_t grad = left + top - topleft;
+      const int64_t gmax = topleft < mn ? mx : grad;
+      return topleft > mx ? mn : gmax;
+    }
+    case 7: return topright;
+    case 8: return topleft;
+    case 9: return leftleft;
+    case 10: return (left + topleft) / 2;
+    case 11: return (top + topleft) / 2;
+    case 12: return (top + topright) / 2;
+    case 13: return (6 * top - 2 * toptop + 7 * left + leftleft + toprightright + 3 * topright + 8) / 16;
+    default: return 0; /* 6 = Weighted: not restated (its own branch of the step, palette.rs:200-227) */
+  }
+}
+
+/* do_palette_step_general, the branch with delta entries and / or a predictor other than Zero and Weighted
+ * (palette.rs:228-251): raster order per channel, entries below num_deltas are added to the prediction from the
+ * already reconstructed neighbours */
+void jxlo_palette_delta(const int32_t* index, int w, int h, const int32_t* palette, int num_colors, int num_deltas,
+                        size_t palette_stride, int nb_channels, int bit_depth, int predictor, int32_t* out) {
+  const size_t n = (size_t)w * h;
+  for (int c = 0; c < nb_channels; c++) {
+    int32_t* o = out + (size_t)c * n;
+    for (int y = 0; y < h; y++) {
+      for (int x = 0; x < w; x++) {
+        const int32_t idx = index[(size_t)y * w + x];
+        const int32_t entry = jxlo_palette_value(palette, palette_stride, (int64_t)idx, c, num_colors + num_deltas, bit_depth);
+        int32_t val = entry;
+        if (idx < num_deltas) val = (int32_t)(uint32_t)(uint64_t)(predict_one(predictor, o, w, x, y) + (int64_t)entry);
+        o[(size_t)y * w + x] = val;
+      }
+    }
+  }
+}
+
 /* ---- squeeze ---- */
 int64_t jxlo_smooth_tendency(int64_t b, int64_t a, int64_t n) { /* squeeze.rs:143-168 */
   int64_t diff = 0;

@@ -143,6 +143,7 @@ class Oracle:
                                           C.c_size_t, C.c_int]
         L.jxlo_rct.argtypes = [ip, ip, ip, C.c_size_t, C.c_int, C.c_int]
         L.jxlo_palette.argtypes = [ip, C.c_size_t, ip, C.c_int, C.c_size_t, C.c_int, C.c_int, ip]
+        L.jxlo_palette_delta.argtypes = [ip, C.c_int, C.c_int, ip, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_int, ip]
         L.jxlo_unsqueeze_h.argtypes = [ip, C.c_size_t, ip, C.c_size_t, C.c_int, C.c_int, ip, C.c_size_t]
         L.jxlo_unsqueeze_v.argtypes = [ip, C.c_size_t, ip, C.c_size_t, C.c_int, C.c_int, ip, C.c_size_t]
         L.jxlo_smooth_tendency.argtypes = [C.c_int64] * 3
@@ -526,6 +527,17 @@ class Oracle:
         return slab
 
     # ---- modular ----
+    def palette_delta(self, index, palette, num_colors, num_deltas, bit_depth, predictor):
+        """index [h, w]; palette [nb_channels, num_colors + num_deltas] -> [nb_channels, h, w]"""
+        index = np.ascontiguousarray(index, dtype=np.int32)
+        palette = np.ascontiguousarray(palette, dtype=np.int32)
+        h, w = index.shape
+        nb = palette.shape[0]
+        out = np.zeros((nb, h, w), dtype=np.int32)
+        self.lib.jxlo_palette_delta(_ptr(index, C.c_int32), w, h, _ptr(palette, C.c_int32), num_colors, num_deltas,
+                                    palette.shape[1], nb, bit_depth, predictor, _ptr(out, C.c_int32))
+        return out
+
     def rct(self, planes, op, perm):
         ps = [np.ascontiguousarray(a, dtype=np.int32).copy() for a in planes]
         self.lib.jxlo_rct(_ptr(ps[0], C.c_int32), _ptr(ps[1], C.c_int32), _ptr(ps[2], C.c_int32),

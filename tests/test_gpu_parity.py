@@ -518,6 +518,36 @@ def test_palette_sizes_lds_and_global_paths(ctx, oracle, ncol):
     assert np.array_equal(ctx.palette(idx, pal, ncol, 3, 8), oracle.palette(idx, pal, ncol, 3, 8))
 
 
+@pytest.mark.parametrize("predictor", [0, 1, 2, 3, 4, 5, 7, 8, 9, 10, 11, 12, 13])
+def test_delta_palette_bit_exact(ctx, oracle, predictor):
+    """do_palette_step_general with delta entries and every neighbour predictor (palette.rs:228-251,
+    modular/predict.rs:152-198): the skewed-wavefront kernel vs the raster-order oracle, incl. implicit (negative and
+    beyond-the-palette) indices, images narrower than the dependency reach, and one taller than a row band"""
+    rng = np.random.default_rng(100 + predictor)
+    for (h, w), nb, bit_depth in (((37, 53), 3, 8), ((1, 40), 3, 8), ((50, 1), 1, 8), ((9, 2), 4, 12), ((1100, 7), 3, 8),
+                                  ((130, 300), 3, 10)):
+        num_colors, num_deltas = int(rng.integers(1, 20)), int(rng.integers(0, 8))
+        pal = rng.integers(-30, 1 << bit_depth, size=(nb, num_colors + num_deltas)).astype(np.int32)
+        pal[:, :num_deltas] = rng.integers(-12, 13, size=(nb, num_deltas))   # delta entries are small steps
+        idx = rng.integers(-8, num_colors + num_deltas + 100, size=(h, w)).astype(np.int32)
+        idx[rng.random((h, w)) < 0.5] = rng.integers(0, max(1, num_deltas + 2))   # plenty of predicted pixels
+        got = ctx.palette_delta(idx, pal, num_colors, num_deltas, bit_depth, predictor)
+        want = oracle.palette_delta(idx, pal, num_colors, num_deltas, bit_depth, predictor)
+        assert np.array_equal(got, want), f"{h}x{w} nb={nb} colors={num_colors} deltas={num_deltas}"
+    # without deltas and with the Zero predictor this is the plain gather
+    if predictor == 0:
+        pal = rng.integers(0, 256, size=(3, 16)).astype(np.int32)
+        idx = rng.integers(-4, 200, size=(20, 30)).astype(np.int32)
+        assert np.array_equal(ctx.palette_delta(idx, pal, 16, 0, 8, 0), ctx.palette(idx, pal, 16, 3, 8))
+
+
+def test_delta_palette_weighted_predictor_is_unsupported(ctx):
+    from jxl_rs_amd import lib, JxlHipError
+    with pytest.raises(JxlHipError) as e:
+        ctx.palette_delta(np.zeros((4, 4), np.int32), np.zeros((3, 4), np.int32), 2, 2, 8, 6)
+    assert e.value.status == lib.ERR_UNSUPPORTED
+
+
 @pytest.mark.parametrize("shape", [(1, 1), (1, 2), (2, 1), (5, 9), (64, 64), (67, 129), (300, 255)])
 def test_unsqueeze_bit_exact_and_round_trip(ctx, oracle, shape):
     h, w = shape
