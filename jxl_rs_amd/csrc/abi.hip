@@ -1489,10 +1489,12 @@ jxlh_status jxlh_palette_delta(jxlh_ctx* ctx, const int32_t* index, uint32_t w, 
   if (w == 0 || h == 0) return JXLH_OK;
   const size_t n = (size_t)w * h, pal_n = palette_stride * (size_t)nb_channels;
   if (n * (size_t)nb_channels >= (1ull << 31)) return JXLH_ERR_UNSUPPORTED;
+  if (jxlh_status st0 = ensure(ctx, ctx->hook_i[3], (size_t)nb_channels * palette_delta_bands((int)h))) return st0;
+  int* progress = reinterpret_cast<int*>(ctx->hook_i[3].p);
   if (is_device_ptr(index) && is_device_ptr(palette) && is_device_ptr(out)) {
     ScopedKernelTimer t(ctx, "k5_palette_delta");
     launch_palette_delta(ctx->stream, index, (int)w, (int)h, palette, num_colors, num_deltas, palette_stride,
-                         nb_channels, bit_depth, predictor, out);
+                         nb_channels, bit_depth, predictor, out, progress);
     HIPCHK(ctx, hipGetLastError());
     return JXLH_OK;
   }
@@ -1501,7 +1503,7 @@ jxlh_status jxlh_palette_delta(jxlh_ctx* ctx, const int32_t* index, uint32_t w, 
   if ((st = stage_in(ctx, ctx->hook_i[1], palette, pal_n ? pal_n : 1))) return st;
   if ((st = ensure(ctx, ctx->hook_i[2], n * nb_channels))) return st;
   launch_palette_delta(ctx->stream, ctx->hook_i[0].p, (int)w, (int)h, ctx->hook_i[1].p, num_colors, num_deltas,
-                       palette_stride, nb_channels, bit_depth, predictor, ctx->hook_i[2].p);
+                       palette_stride, nb_channels, bit_depth, predictor, ctx->hook_i[2].p, progress);
   HIPCHK(ctx, hipGetLastError());
   return stage_out(ctx, out, (const int32_t*)ctx->hook_i[2].p, n * nb_channels);
 }

@@ -214,7 +214,8 @@ void launch_palette(hipStream_t s, const int32_t* index, size_t n, const int32_t
                     size_t palette_stride, int nb_channels, int bit_depth, int32_t* out);
 void launch_palette_delta(hipStream_t s, const int32_t* index, int w, int h, const int32_t* palette, int num_colors,
                           int num_deltas, size_t palette_stride, int nb_channels, int bit_depth, int predictor,
-                          int32_t* out);
+                          int32_t* out, int* progress);
+int palette_delta_bands(int h);
 // n_planes (<= 3) planes of identical geometry in one launch (the channels of one squeeze step)
 void launch_unsqueeze(hipStream_t s, int horizontal, int n_planes, const int32_t* const avg[], size_t avg_stride,
                       const int32_t* const res[], size_t res_stride, uint32_t out_w, uint32_t out_h,

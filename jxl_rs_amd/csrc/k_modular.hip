@@ -122,14 +122,18 @@ __device__ __forceinline__ int32_t palette_value(const int32_t* __restrict__ pal
 // ---- palette step with delta entries and / or a neighbour predictor (do_palette_step_general, palette.rs:228-251)
 // Entries below num_deltas are ADDED to a prediction from already reconstructed neighbours (left, top row up to
 // x + 2, the row above that): a raster-order dependency.  Pixel (x, y) can go once (x - 1, y) and (x + 2, y - 1)
-// are done, so all pixels with the same x + 3y are independent: a workgroup takes a band of kDeltaRows rows, lane
-// l = row, and at step s lane l handles x = s - 3l (a skewed wavefront).  A row's recent outputs live in an LDS
-// ring of 8 columns (the row below reads columns x - 1 .. x + 2, the one after x; the owner is writing x + 3 / x + 6
-// at that moment), its own left / leftleft in registers; one barrier per step.  Bands run one after the other in the
-// same workgroup, the first rows of a band reading the previous band's last two rows from global memory.
-// One workgroup per channel: (w + 3 * kDeltaRows) * ceil(h / kDeltaRows) steps -- correct and on the device, not fast
-// (a cross-workgroup pipeline of the bands would cut it to w + 3h steps).
-constexpr int kDeltaRows = 1024;
+// are done, so all pixels with the same x + 3y are independent -- a wavefront of w + 3h steps:
+//  * a workgroup owns a band of kDeltaRows rows of one channel, lane l = row; at step s lane l handles x = s - 3l.
+//    A row's recent outputs live in an LDS ring of 8 columns (the row below reads columns x - 1 .. x + 2, the one
+//    after that column x, while the owner is writing x + 3 / x + 6), its own left / leftleft in registers; one
+//    LDS-only barrier per step.
+//  * bands are pipelined ACROSS workgroups: band k trails band k - 1 by 3 * kDeltaRows steps.  The producer
+//    publishes its completed step count every kDeltaPublish steps (device-scope fence, then one store); the consumer
+//    copies the next 64 columns of the two rows above it into LDS every 64 steps, after the counter says they are
+//    final, with device-coherent loads (they bypass the CU's L1, which may hold the lines from before they were
+//    written).  A waiting band only depends on bands with a lower block index, which were dispatched earlier.
+constexpr int kDeltaRows = 256;
+constexpr int kDeltaPublish = 32;
 
 __device__ __forceinline__ int64_t predict_one(int predictor, int64_t left, int64_t top, int64_t toptop, int64_t topleft,
                                                int64_t topright, int64_t leftleft, int64_t toprightright) {
@@ -162,47 +166,123 @@ __device__ __forceinline__ int64_t predict_one(int predictor, int64_t left, int6
 __global__ __launch_bounds__(kDeltaRows) void k5_palette_delta(const int32_t* __restrict__ index, int w, int h,
                                                                const int32_t* __restrict__ palette, int num_colors,
                                                                int num_deltas, size_t pstride, int bit_depth,
-                                                               int predictor, int32_t* out_base) {
+                                                               int predictor, int32_t* out_base, int* progress_base) {
   __shared__ int32_t s_ring[kDeltaRows][8];
-  const int c = blockIdx.x, l = threadIdx.x;
+  __shared__ int32_t s_above[2][128];  // rows y0 - 1 and y0 - 2 (of the previous band), a window of 128 columns
+  __shared__ int s_avail;
+  const int c = blockIdx.x, band = blockIdx.y, nbands = gridDim.y, l = threadIdx.x;
   int32_t* out = out_base + (size_t)c * (size_t)w * h;  // no __restrict__: rows are read back
+  int* progress = progress_base + (size_t)c * nbands;
   const int palette_size = num_colors + num_deltas;
-  for (int y0 = 0; y0 < h; y0 += kDeltaRows) {
-    const int rows = min(kDeltaRows, h - y0);
-    const int y = y0 + l;
-    const int32_t* __restrict__ irow = index + (size_t)min(y, h - 1) * w;
-    int32_t* orow = out + (size_t)min(y, h - 1) * w;
-    int32_t left_v = 0, leftleft_v = 0;  // out[y][x - 1], out[y][x - 2]
-    const int nsteps = w + 3 * (rows - 1);
-    for (int s = 0; s < nsteps; s++) {
-      const int x = s - 3 * l;
-      if (l < rows && x >= 0 && x < w) {
-        const int32_t idx = irow[x];
-        int32_t val = palette_value(palette, pstride, idx, c, palette_size, bit_depth);
-        if (idx < num_deltas) {
-          // row y - 1 / y - 2: the LDS ring of the lane above, or -- for the band's first rows -- global memory
-          auto T = [&](int xx) -> int32_t { return l > 0 ? s_ring[l - 1][xx & 7] : out[(size_t)(y - 1) * w + xx]; };
-          auto TT = [&](int xx) -> int32_t { return l > 1 ? s_ring[l - 2][xx & 7] : out[(size_t)(y - 2) * w + xx]; };
-          // PredictionData::get_rows, modular/predict.rs:96-128
-          const int64_t left = x > 0 ? left_v : (y > 0 ? T(0) : 0);
-          const int64_t top = y > 0 ? T(x) : left;
-          const int64_t topleft = (x > 0 && y > 0) ? T(x - 1) : left;
-          const int64_t topright = (x + 1 < w && y > 0) ? T(x + 1) : top;
-          const int64_t leftleft = x > 1 ? leftleft_v : left;
-          const int64_t toptop = y > 1 ? TT(x) : top;
-          const int64_t toprightright = (x + 2 < w && y > 0) ? T(x + 2) : topright;
-          const int64_t pred = predict_one(predictor, left, top, toptop, topleft, topright, leftleft, toprightright);
-          val = (int32_t)(uint32_t)(uint64_t)(pred + (int64_t)val);
-        }
-        orow[x] = val;
-        s_ring[l][x & 7] = val;
-        leftleft_v = left_v;
-        left_v = val;
-      }
-      __syncthreads();
+  const int y0 = band * kDeltaRows;
+  const int rows = min(kDeltaRows, h - y0);
+  const int y = y0 + l;
+  const int32_t* __restrict__ irow = index + (size_t)min(y, h - 1) * w;
+  int32_t* orow = out + (size_t)min(y, h - 1) * w;
+  int32_t left_v = 0, leftleft_v = 0;  // out[y][x - 1], out[y][x - 2]
+  // Two-stage prefetch along the row, so that neither the index load nor the palette gather it feeds sits on the
+  // per-step critical path (the step barrier waits for LDS only).  The queues are indexed by the STEP (slot s & 7 /
+  // s & 3), not by the column, so that an 8x unrolled loop addresses them with compile-time register numbers and
+  // no value in flight is ever moved: at step s a lane consumes index / entry of its column x from slot s & 7 /
+  // s & 3, refills the index slot with column x + 8 and the entry slot with column x + 4 (index from slot (s+4) & 7).
+  int32_t iq[8], eq[4];
+  {
+    const int s0 = 3 * l;  // the lane's first step
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      iq[k] = 0;
+#pragma unroll
+      for (int j = 0; j < 8; j++)
+        if (((s0 + j) & 7) == k) iq[k] = (l < rows && j < w) ? irow[j] : 0;
     }
-    __threadfence();  // the next band reads this band's last rows from global memory
-    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      eq[k] = 0;
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        if (((s0 + j) & 3) == k) {
+          int32_t ix = 0;
+#pragma unroll
+          for (int m = 0; m < 8; m++) ix = ((s0 + j) & 7) == m ? iq[m] : ix;
+          eq[k] = palette_value(palette, pstride, ix, c, palette_size, bit_depth);
+        }
+    }
+  }
+  const int nsteps = w + 3 * (rows - 1);
+  // steps the previous band (always kDeltaRows rows) takes; its last row finishes column x at step x + 3*(R-1)
+  const int prod_steps = w + 3 * (kDeltaRows - 1);
+  int avail = 0;  // completed steps of the previous band, as last observed
+  auto step = [&](const int s, auto slot_tag) {
+    constexpr int K = decltype(slot_tag)::value;
+    const int x = s - 3 * l;
+    if (l < rows && x >= 0 && x < w) {
+      const int32_t idx = iq[K];
+      int32_t val = eq[K & 3];
+      iq[K] = x + 8 < w ? irow[x + 8] : 0;
+      eq[K & 3] = palette_value(palette, pstride, iq[(K + 4) & 7], c, palette_size, bit_depth);  // column x + 4
+      if (idx < num_deltas) {
+        // row y - 1 / y - 2: the LDS ring of the lane above, or the window of the previous band's rows
+        auto T = [&](int xx) -> int32_t { return l > 0 ? s_ring[l - 1][xx & 7] : s_above[0][xx & 127]; };
+        auto TT = [&](int xx) -> int32_t {
+          return l > 1 ? s_ring[l - 2][xx & 7] : s_above[l == 1 ? 0 : 1][xx & 127];
+        };
+        // PredictionData::get_rows, modular/predict.rs:96-128
+        const int64_t left = x > 0 ? left_v : (y > 0 ? T(0) : 0);
+        const int64_t top = y > 0 ? T(x) : left;
+        const int64_t topleft = (x > 0 && y > 0) ? T(x - 1) : left;
+        const int64_t topright = (x + 1 < w && y > 0) ? T(x + 1) : top;
+        const int64_t leftleft = x > 1 ? leftleft_v : left;
+        const int64_t toptop = y > 1 ? TT(x) : top;
+        const int64_t toprightright = (x + 2 < w && y > 0) ? T(x + 2) : topright;
+        const int64_t pred = predict_one(predictor, left, top, toptop, topleft, topright, leftleft, toprightright);
+        val = (int32_t)(uint32_t)(uint64_t)(pred + (int64_t)val);
+      }
+      orow[x] = val;
+      s_ring[l][x & 7] = val;
+      leftleft_v = left_v;
+      left_v = val;
+    }
+    if (band + 1 < nbands && ((s + 1) % kDeltaPublish == 0 || s + 1 == nsteps)) {
+      __threadfence();  // this thread's stores are visible device-wide ...
+      __syncthreads();  // ... for every thread of the band
+      if (l == 0) __hip_atomic_store(&progress[band], s + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      // LDS writes of this step visible to the workgroup; global loads / stores stay in flight
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+  };
+  for (int s8 = 0; s8 < nsteps; s8 += 8) {
+    if (band > 0 && (s8 & 63) == 0) {
+      // columns this band's first rows touch during steps s8 .. s8 + 63: up to s8 + 65 -> copy [lo, hi)
+      const int lo = s8 == 0 ? 0 : s8 + 2, hi = min(w, s8 + 66);
+      if (lo < hi) {
+        const int need = min(prod_steps, (hi - 1) + 3 * (kDeltaRows - 1) + 1);
+        if (avail < need) {
+          if (l == 0) {
+            int v;
+            while ((v = __hip_atomic_load(&progress[band - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) < need)
+              __builtin_amdgcn_s_sleep(2);
+            s_avail = v;
+          }
+          __syncthreads();
+          avail = s_avail;
+        }
+        for (int t = l; t < 2 * (hi - lo); t += kDeltaRows) {
+          const int r = t & 1, col = lo + (t >> 1);
+          s_above[r][col & 127] =
+              __hip_atomic_load(&out[(size_t)(y0 - 1 - r) * w + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+      }
+    }
+    if (s8 + 0 < nsteps) step(s8 + 0, std::integral_constant<int, 0>{});
+    if (s8 + 1 < nsteps) step(s8 + 1, std::integral_constant<int, 1>{});
+    if (s8 + 2 < nsteps) step(s8 + 2, std::integral_constant<int, 2>{});
+    if (s8 + 3 < nsteps) step(s8 + 3, std::integral_constant<int, 3>{});
+    if (s8 + 4 < nsteps) step(s8 + 4, std::integral_constant<int, 4>{});
+    if (s8 + 5 < nsteps) step(s8 + 5, std::integral_constant<int, 5>{});
+    if (s8 + 6 < nsteps) step(s8 + 6, std::integral_constant<int, 6>{});
+    if (s8 + 7 < nsteps) step(s8 + 7, std::integral_constant<int, 7>{});
   }
 }
 
@@ -425,12 +505,16 @@ void launch_palette(hipStream_t s, const int32_t* index, size_t n, const int32_t
   }
 }
 
+// progress: nb_channels * palette_delta_bands(h) ints of device scratch
+int palette_delta_bands(int h) { return (h + kDeltaRows - 1) / kDeltaRows; }
 void launch_palette_delta(hipStream_t s, const int32_t* index, int w, int h, const int32_t* palette, int num_colors,
                           int num_deltas, size_t palette_stride, int nb_channels, int bit_depth, int predictor,
-                          int32_t* out) {
+                          int32_t* out, int* progress) {
   if (w <= 0 || h <= 0) return;
-  hipLaunchKernelGGL(k5_palette_delta, dim3(nb_channels), dim3(kDeltaRows), 0, s, index, w, h, palette, num_colors,
-                     num_deltas, palette_stride, bit_depth, predictor, out);
+  const int nbands = palette_delta_bands(h);
+  (void)hipMemsetAsync(progress, 0, sizeof(int) * (size_t)nb_channels * nbands, s);
+  hipLaunchKernelGGL(k5_palette_delta, dim3(nb_channels, nbands), dim3(kDeltaRows), 0, s, index, w, h, palette,
+                     num_colors, num_deltas, palette_stride, bit_depth, predictor, out, progress);
 }
 
 void launch_unsqueeze(hipStream_t s, int horizontal, int n_planes, const int32_t* const avg[], size_t avg_stride,
