@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Kernel times of a chroma-subsampled (JPEG-recompression-like) frame: 8x8 transforms only, no filters,
-YCbCr -> RGB8 output.  usage: tools/bench_jpeg420.py [size] [420|422|440]"""
+YCbCr -> RGB8 output.  usage: tools/bench_jpeg420.py [size] [420|422|440|444] [8x8|dct8]"""
 import json
 import os
 import sys
@@ -16,7 +16,8 @@ size = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 sub = sys.argv[2] if len(sys.argv) > 2 else "420"
 hs, vs = {"420": ((1, 0, 1), (1, 0, 1)), "422": ((1, 0, 1), (0, 0, 0)), "440": ((0, 0, 0), (1, 0, 1)),
           "444": ((0, 0, 0), (0, 0, 0))}[sub]
-wl = synth.make_vardct(size, size, mix=synth.MIX_8X8 if sub != "444" else synth.MIX_8X8, seed=3, unique_groups=24,
+mix = {"8x8": synth.MIX_8X8, "dct8": synth.MIX_DCT8}[sys.argv[3] if len(sys.argv) > 3 else "8x8"]
+wl = synth.make_vardct(size, size, mix=mix, seed=3, unique_groups=24,
                        epf_iters=0, gab=False, lf_smoothing=False, hshift=hs, vshift=vs)
 c = jxl_rs_amd.Context(0, n_slots=1)
 p = synth.apply_opts(c.default_params(size, size), wl)
@@ -40,5 +41,5 @@ for _ in range(N):
 c.sync()
 kt = {k: round(v[0] / N, 4) for k, v in c.kernel_times().items()}
 total = sum(kt.values())
-print(json.dumps({"workload": f"{size}x{size} {sub} 8x8 transforms, no filters, RGB8 out", "kernels_ms": kt,
+print(json.dumps({"workload": f"{size}x{size} {sub} {sys.argv[3] if len(sys.argv) > 3 else '8x8'} transforms, no filters, RGB8 out", "kernels_ms": kt,
                   "ms_per_frame": round(total, 4), "MP_per_s": round(size * size / total / 1e3, 1)}))
