@@ -365,7 +365,10 @@ __device__ __forceinline__ int4 tile_q4(const float* __restrict__ buf, int b, in
 // kernel handles start on different waves (batch b of a class goes to wave (rotation + b) % nwaves);
 // without it every class would pile its batches on the low-numbered waves.  Returns the number of
 // batches of the class (the next class's rotation).
-template <class S, bool PREFETCH, bool SPARSE>
+// SUB (chroma-subsampled frames, S8x8 only): a channel holds a block only if the block is aligned to the channel's
+// sampling (decode_item marks the others with px_off == scrap_off); their coefficients are never decoded (zeros
+// in the reference's slab, frame/group.rs:521-524), so the loads are skipped and read as zero, and nothing is stored.
+template <class S, bool PREFETCH, bool SPARSE, bool SUB = false>
 __device__ __forceinline__ int run_dct_class(const FrameDev& f, const WorkItem* __restrict__ items, int count, int type,
                                              float* __restrict__ buf, BlockInfo* __restrict__ binfo_base, int gwave,
                                              int nwaves, int lane) {
@@ -405,7 +408,8 @@ __device__ __forceinline__ int run_dct_class(const FrameDev& f, const WorkItem* 
           const int fl = (j * 64 + lane) * 4;
           const int b = fl / S::N, k = fl % S::N;
           qv[c][j] = make_int4(0, 0, 0, 0);
-          if (b < nb) qv[c][j] = *reinterpret_cast<const int4*>(f.coeffs + binfo[b].coef_off + c * kGroupArea + k);
+          if (b < nb && (!SUB || binfo[b].px_off[c] != f.scrap_off))
+            qv[c][j] = *reinterpret_cast<const int4*>(f.coeffs + binfo[b].coef_off + c * kGroupArea + k);
         }
     }
     float dy[S::E];
@@ -451,6 +455,7 @@ __device__ __forceinline__ int run_dct_class(const FrameDev& f, const WorkItem* 
       idct_batch<S>(
           buf, nb, lane, [&](int b, int y, int x) { return lfp[binfo[b].lf_off[CH] + y * xblocks + x]; },
           [&](int b, int x, int yb, const float(&v)[8]) {
+            if (SUB && binfo[b].px_off[CH] == f.scrap_off) return;
             float* dst = plane + binfo[b].px_off[CH] + lay.xoff(x) + yb * lay.ystep_blk;
             if (lay.tiled) {  // the lane's 8 rows are contiguous: two 16-byte stores
               *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
@@ -491,12 +496,12 @@ constexpr int kTileC = cmax(cmax(cmax(S32x8::kTile, S8x32::kTile), cmax(S32x16::
                             S32x32::kTile);                                       // 2624
 
 // family A: DCT 8x8 -- the dominant transform
-template <bool SPARSE>
+template <bool SPARSE, bool SUB = false>
 __global__ __launch_bounds__(kThreads) void k1_dct8(const FrameDev f, const WorkLists wl) {
   __shared__ __attribute__((aligned(16))) float s_buf[kWaves * kTileA];
   __shared__ BlockInfo s_binfo[kWaves][S8x8::NB];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  run_dct_class<S8x8, true, SPARSE>(f, wl.items[kClsDct8], wl.counts[kClsDct8], 0, s_buf + wave * kTileA, s_binfo[wave],
+  run_dct_class<S8x8, true, SPARSE, SUB>(f, wl.items[kClsDct8], wl.counts[kClsDct8], 0, s_buf + wave * kTileA, s_binfo[wave],
                             blockIdx.x * kWaves + wave, gridDim.x * kWaves, lane);
 }
 
@@ -811,7 +816,11 @@ void launch_vardct_groups(hipStream_t s, const FrameDev& f, int group_row0, int 
   // caps measured flat between 768 and 8192 workgroups at 8K (tools/bench_variants.sh)
   const dim3 g8(grid_for(nblk, kWaves * S8x8::NB * 2, 4096)), g16(grid_for(nblk / 2, kWaves * 8 * 2, 2048)),
       g32(grid_for(nblk / 4, kWaves * 4 * 2, 2048));
-  if (sparse) {
+  if (f.subsampled) {
+    if (sparse) hipLaunchKernelGGL((k1_dct8<true, true>), g8, dim3(kThreads), 0, s, f, wl);
+    else hipLaunchKernelGGL((k1_dct8<false, true>), g8, dim3(kThreads), 0, s, f, wl);
+    // the other DCT classes are empty in a sub-sampled frame (k1_scan reports larger varblocks as an error)
+  } else if (sparse) {
     hipLaunchKernelGGL(k1_dct8<true>, g8, dim3(kThreads), 0, s, f, wl);
     hipLaunchKernelGGL(k1_dct16<true>, g16, dim3(kThreads), 0, s, f, wl);
     hipLaunchKernelGGL(k1_dct32<true>, g32, dim3(kThreads), 0, s, f, wl);

@@ -350,6 +350,13 @@ def make_vardct(xsize, ysize, mix=None, seed=0, unique_groups=None, epf_iters=2,
                 n = COVERED_X[t] * COVERED_Y[t] * 64
                 for j, i in enumerate(idxs):
                     slab[:, offs[i]:offs[i] + n] = data[j]
+            if mh or mv:
+                # a decoder never writes coefficients for a channel at blocks the channel does not hold
+                # (frame/group.rs:521-524): the slab stays zero there (a group is an even number of blocks)
+                for i, (bx, by, t) in enumerate(blocks):
+                    for c in range(3):
+                        if (bx % (1 << hshift[c])) or (by % (1 << vshift[c])):
+                            slab[c, offs[i]:offs[i + 1]] = 0
             if key is not None:
                 cache[key] = (tmap, rq, slab)
         transform_map[by0:by0 + bh, bx0:bx0 + bw] = tmap
