@@ -68,6 +68,10 @@ struct jxlh_ctx {
   // geometry of `result`: the frame itself, or its upsampled image (frame_header.upsampling > 1)
   int res_w = 0, res_h = 0;
   size_t res_stride = 0;
+  // chroma-subsampled frame with nothing between the transforms and the output: the upsampling into planes[] is
+  // deferred until somebody asks for the planes (the YCbCr output calls read the sub-sampled channels directly)
+  bool chroma_lazy = false;
+  int lazy_gr0 = 0, lazy_gr1 = 0;
   DevBuf<float> noise[3];      // random planes of the noise synthesis
   DevBuf<uint64_t> xs_jump;    // xorshift128+ jump matrices T^(2^j), uploaded on first use
   DevBuf<float> ups[3];        // upsampled planes
@@ -466,6 +470,7 @@ jxlh_status jxlh_frame_begin(jxlh_ctx* ctx, const jxlh_frame_params* p) {
   ctx->lf_smoothed = false;
   for (auto& s : ctx->slots) s.used = false;
   for (int c = 0; c < 3; c++) ctx->result[c] = nullptr;
+  ctx->chroma_lazy = false;
   return JXLH_OK;
 }
 
@@ -736,6 +741,28 @@ bool noise_lut_is_zero(const float lut[8]) {
   return true;
 }
 
+// chroma upsampling of the sub-sampled channels, tmp[c] -> planes[c], over the rows K1 produced for group rows
+// [gr0, gr1) (the outermost rows of a halo group row read beyond the region, and nobody reads them)
+void run_chroma_upsample(jxlh_ctx* ctx, int gr0, int gr1) {
+  const FrameDev& f = ctx->fd;
+  ScopedKernelTimer t(ctx, "k_chroma_upsample");
+  const PixLayout lay = pix_layout(f);
+  for (int c = 0; c < 3; c++) {
+    const int hs = f.hshift[c], vs = f.vshift[c];
+    if (!(hs | vs)) continue;
+    const int cw = (f.xsize + (1 << hs) - 1) >> hs, ch = (f.ysize + (1 << vs) - 1) >> vs;
+    const int sy0 = (gr0 * kGroupDim) >> vs, sy1 = min(ch, (gr1 * kGroupDim) >> vs);
+    launch_chroma_upsample(ctx->stream, f.tmp[c], f.planes[c], lay, lay, hs, vs, cw, ch, sy0, sy1, f.xblocks * 8,
+                           f.yblocks * 8);
+  }
+}
+
+void materialise_chroma(jxlh_ctx* ctx) {
+  if (!ctx->chroma_lazy) return;
+  run_chroma_upsample(ctx, ctx->lazy_gr0, ctx->lazy_gr1);
+  ctx->chroma_lazy = false;
+}
+
 jxlh_status upload_upsampling_kernels(jxlh_ctx* ctx, int n) {
   const int slot = n == 2 ? 0 : n == 4 ? 1 : 2;
   const float* dflt = n == 2 ? kDefaultUpsamplingWeights2 : n == 4 ? kDefaultUpsamplingWeights4 : kDefaultUpsamplingWeights8;
@@ -869,19 +896,15 @@ jxlh_status jxlh_frame_run(jxlh_ctx* ctx, uint32_t group_row0, uint32_t group_ro
     launch_vardct_groups(ctx->stream, fk, gr0, gr1, ctx->worklist.p, ctx->error_flag.p,
                          sparse_k1 ? ctx->coeffs.p : nullptr);
   }
+  ctx->chroma_lazy = false;
   if (f.subsampled) {
-    // ... and brought to full resolution into planes[c] before any filter (frame/render.rs:569-576); rows: the
-    // K1 region (the outermost rows of a halo group row read beyond it, and nobody reads them)
-    ScopedKernelTimer t(ctx, "k_chroma_upsample");
-    const PixLayout lay = pix_layout(f);
-    for (int c = 0; c < 3; c++) {
-      const int hs = f.hshift[c], vs = f.vshift[c];
-      if (!(hs | vs)) continue;
-      const int cw = (f.xsize + (1 << hs) - 1) >> hs, ch = (f.ysize + (1 << vs) - 1) >> vs;
-      const int sy0 = (gr0 * kGroupDim) >> vs, sy1 = min(ch, (gr1 * kGroupDim) >> vs);
-      launch_chroma_upsample(ctx->stream, f.tmp[c], f.planes[c], lay, lay, hs, vs, cw, ch, sy0, sy1, f.xblocks * 8,
-                             f.yblocks * 8);
-    }
+    // ... and brought to full resolution into planes[c] before any filter (frame/render.rs:569-576) -- or, when no
+    // stage follows at all, only when the planes are asked for (materialise_chroma)
+    const bool stages_follow = f.gab || f.epf_iters > 0 || p.upsampling > 1 || (p.noise && !noise_lut_is_zero(p.noise_lut));
+    ctx->lazy_gr0 = gr0;
+    ctx->lazy_gr1 = gr1;
+    if (stages_follow) run_chroma_upsample(ctx, gr0, gr1);
+    else ctx->chroma_lazy = true;
   }
   // ---- stage list of frame/render.rs:569-622
   const int y_lo = (int)group_row0 * kGroupDim;
@@ -1018,6 +1041,20 @@ const XybParamsDev* xyb_params_dev(const jxlh_xyb_params* p, XybParamsDev* d) {
   return d;
 }
 
+SubPlanesDev sub_planes_dev(const jxlh_ctx* ctx) {
+  const FrameDev& f = ctx->fd;
+  SubPlanesDev sp;
+  for (int c = 0; c < 3; c++) {
+    const int hs = f.hshift[c], vs = f.vshift[c];
+    sp.p[c] = (hs | vs) ? f.tmp[c] : f.planes[c];
+    sp.hs[c] = hs;
+    sp.vs[c] = vs;
+    sp.cw[c] = (f.xsize + (1 << hs) - 1) >> hs;
+    sp.ch[c] = (f.ysize + (1 << vs) - 1) >> vs;
+  }
+  return sp;
+}
+
 // mode: kTfLinear..kTfGamma = XybStage (p) + that transfer function (t); kModeYcbcr; kModeNone
 jxlh_status read_rgb8(jxlh_ctx* ctx, int mode, const jxlh_xyb_params* p, const TfParamsDev& tf, uint32_t channels,
                       uint32_t y0, uint32_t y1, void* out, size_t bytes_per_row) {
@@ -1028,7 +1065,28 @@ jxlh_status read_rgb8(jxlh_ctx* ctx, int mode, const jxlh_xyb_params* p, const T
   XybParamsDev d = {};
   xyb_params_dev(p, &d);
   const int rows = (int)(y1 - y0);
+  const bool fused_chroma = ctx->chroma_lazy && mode == kModeYcbcr;
+  if (!fused_chroma) materialise_chroma(ctx);
   const float* planes[3] = {ctx->result[0], ctx->result[1], ctx->result[2]};
+  if (fused_chroma) {
+    const SubPlanesDev sp = sub_planes_dev(ctx);
+    const size_t tight = ((size_t)ctx->res_w * channels + 3) & ~(size_t)3;
+    const bool dev = is_device_ptr(out);
+    if (!dev)
+      if (jxlh_status st = ensure(ctx, ctx->rgb8, tight * (size_t)rows)) return st;
+    {
+      ScopedKernelTimer t(ctx, "k_ycbcr_sub_to_rgb");
+      launch_ycbcr_sub_to_rgb(ctx->stream, sp, ctx->res_stride, ctx->res_w, (int)y0, rows, (int)channels, 8,
+                              dev ? out : (void*)ctx->rgb8.p, dev ? bytes_per_row : tight);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    if (dev) return JXLH_OK;
+    if (jxlh_status st = copy2d(ctx, out, bytes_per_row, ctx->rgb8.p, tight, (size_t)ctx->res_w * channels, (size_t)rows,
+                                ctx->stream))
+      return st;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return JXLH_OK;
+  }
   if (is_device_ptr(out)) {
     ScopedKernelTimer t(ctx, "k_xyb_to_rgb8");
     launch_xyb_to_rgb8(ctx->stream, planes, ctx->res_stride, ctx->res_w, (int)y0, rows, mode, d, tf, (int)channels,
@@ -1065,7 +1123,27 @@ jxlh_status read_rgb16(jxlh_ctx* ctx, int mode, const jxlh_xyb_params* p, const 
   XybParamsDev d = {};
   xyb_params_dev(p, &d);
   const int rows = (int)(y1 - y0);
+  const bool fused_chroma = ctx->chroma_lazy && mode == kModeYcbcr;
+  if (!fused_chroma) materialise_chroma(ctx);
   const float* planes[3] = {ctx->result[0], ctx->result[1], ctx->result[2]};
+  if (fused_chroma) {
+    const SubPlanesDev sp = sub_planes_dev(ctx);
+    const bool dev = is_device_ptr(out);
+    if (!dev)
+      if (jxlh_status st = ensure(ctx, ctx->rgb8, row_bytes * (size_t)rows)) return st;
+    {
+      ScopedKernelTimer t(ctx, "k_ycbcr_sub_to_rgb");
+      launch_ycbcr_sub_to_rgb(ctx->stream, sp, ctx->res_stride, ctx->res_w, (int)y0, rows, (int)channels, 16,
+                              dev ? out : (void*)ctx->rgb8.p,
+                              dev ? bytes_per_row / sizeof(uint16_t) : (size_t)ctx->res_w * channels);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    if (dev) return JXLH_OK;
+    if (jxlh_status st = copy2d(ctx, out, bytes_per_row, ctx->rgb8.p, row_bytes, row_bytes, (size_t)rows, ctx->stream))
+      return st;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return JXLH_OK;
+  }
   if (is_device_ptr(out)) {
     ScopedKernelTimer t(ctx, "k_xyb_to_rgb16");
     launch_xyb_to_rgb16(ctx->stream, planes, ctx->res_stride, ctx->res_w, (int)y0, rows, mode, d, tf, (int)channels,
@@ -1130,6 +1208,7 @@ jxlh_status jxlh_frame_read_output(jxlh_ctx* ctx, const jxlh_output_desc* d, uin
 jxlh_status jxlh_frame_read_planes(jxlh_ctx* ctx, const jxlh_plane out[3]) {
   if (!ctx || !out) return JXLH_ERR_INVALID_ARGUMENT;
   if (!ctx->in_frame || !ctx->result[0]) return JXLH_ERR_BAD_STATE;
+  materialise_chroma(ctx);
   for (int c = 0; c < 3; c++) {
     if (!out[c].ptr || out[c].bytes_per_row < (size_t)ctx->res_w * sizeof(float) || out[c].num_rows < (size_t)ctx->res_h ||
         out[c].bytes_between_rows < out[c].bytes_per_row)
@@ -1144,6 +1223,7 @@ jxlh_status jxlh_frame_read_planes(jxlh_ctx* ctx, const jxlh_plane out[3]) {
 jxlh_status jxlh_frame_device_planes(jxlh_ctx* ctx, float* planes[3], size_t* stride) {
   if (!ctx || !planes) return JXLH_ERR_INVALID_ARGUMENT;
   if (!ctx->in_frame || !ctx->result[0]) return JXLH_ERR_BAD_STATE;
+  materialise_chroma(ctx);
   for (int c = 0; c < 3; c++) planes[c] = ctx->result[c];
   if (stride) *stride = ctx->res_stride;
   return JXLH_OK;

@@ -186,6 +186,13 @@ struct TfParamsDev {
   float param;   // PQ: intensity_target; HLG: OOTF exponent; gamma: exponent
   float lum[3];  // HLG: luminance_rgb
 };
+// K1's output of a chroma-subsampled frame: p[c] = the full plane (no shift) or the sub-sampled one (cw x ch samples)
+struct SubPlanesDev {
+  const float* p[3];
+  int hs[3], vs[3], cw[3], ch[3];
+};
+void launch_ycbcr_sub_to_rgb(hipStream_t s, const SubPlanesDev& sp, size_t stride, int w, int y0, int rows, int channels,
+                             int bits, void* out, size_t out_stride);
 void launch_xyb_to_rgb8(hipStream_t s, const float* const planes[3], size_t stride, int w, int y0, int rows, int mode,
                         const XybParamsDev& q, const TfParamsDev& t, int channels, uint8_t* out, size_t out_stride);
 void launch_xyb_to_rgb16(hipStream_t s, const float* const planes[3], size_t stride, int w, int y0, int rows, int mode,

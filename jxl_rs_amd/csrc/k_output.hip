@@ -285,7 +285,161 @@ __global__ __launch_bounds__(kOutThreads) void k_xyb_to_rgb8(const float* __rest
   }
 }
 
+// YCbCr frame with sub-sampled chroma, straight from K1's output: HorizontalChromaUpsample / VerticalChromaUpsample
+// (the arithmetic of k_chroma.hip: blend = fma(neighbour, 0.25, centre * 0.75), horizontal stage first, mirrored at the
+// edges of the sub-sampled channel) evaluated per output pixel, then YcbcrToRgbStage and the integer conversion.
+// Used when nothing sits between the transforms and the output (no filters, upsampling or noise): the full-resolution
+// chroma planes are then never written or read back.
+__device__ __forceinline__ int mirror_idx(int v, int s) {
+  while (v < 0 || v >= s) v = v < 0 ? -v - 1 : 2 * s - v - 1;
+  return v;
+}
+__device__ __forceinline__ float chroma_blend(float neighbour, float centre) {
+  return __builtin_fmaf(neighbour, 0.25f, centre * 0.75f);
+}
+
+template <int CH, bool U16>
+__global__ __launch_bounds__(kOutThreads) void k_ycbcr_sub_to_rgb(const SubPlanesDev sp, uint32_t stride, int w, int y0,
+                                                                  int rows, void* __restrict__ out, size_t out_stride,
+                                                                  int aligned) {
+  __shared__ float s_dither[32 * 32];
+  if constexpr (!U16) {
+    for (int i = threadIdx.x; i < 32 * 32; i += kOutThreads) s_dither[i] = kDitherDev[i];
+    __syncthreads();
+  }
+  const int x4 = (blockIdx.x * kOutThreads + threadIdx.x) * 4;
+  const int r = blockIdx.y;
+  if (x4 >= w || r >= rows) return;
+  const int y = y0 + r;
+  float v[3][4];
+  const bool whole = x4 + 4 <= w;
+  auto load4 = [&](const float* __restrict__ row, int x0, int n, float (&o)[4]) {  // row[x0 .. x0+3], zero past n
+    if (x0 + 4 <= n && ((reinterpret_cast<uintptr_t>(row + x0) & 15) == 0)) {
+      const float4 t = *reinterpret_cast<const float4*>(row + x0);
+      o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; i++) o[i] = x0 + i < n ? row[x0 + i] : 0.0f;
+    }
+  };
+  auto mirror1 = [](int v, int n) {  // one reflection, then clamped: exact for the +-1 / +-2 excursions used here
+    v = v < 0 ? -v - 1 : (v >= n ? 2 * n - v - 1 : v);
+    return v < 0 ? 0 : (v >= n ? n - 1 : v);
+  };
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    const float* __restrict__ p = sp.p[c];
+    const int hs = sp.hs[c], vs = sp.vs[c];
+    if (!(hs | vs)) {
+      load4(p + (size_t)y * stride, x4, w, v[c]);
+      continue;
+    }
+    const int cw = sp.cw[c], ch = sp.ch[c];
+    const int sy = y >> vs;
+    const float* __restrict__ row_c = p + (size_t)sy * stride;
+    const float* __restrict__ row_n = p + (size_t)(vs ? mirror1((y & 1) ? sy + 1 : sy - 1, ch) : sy) * stride;
+    float hc[4], hn[4];  // the horizontal stage's output at the four pixels, centre row and neighbour row
+    if (hs) {
+      // pixels x4 .. x4+3 sit on sub-samples s0, s0, s0+1, s0+1 (x4 is a multiple of 4) with horizontal neighbours
+      // s0-1, s0+1, s0, s0+2
+      const int s0 = x4 >> 1;
+      const int ia = mirror1(s0 - 1, cw), ib = min(s0, cw - 1), ic = mirror1(s0 + 1, cw), id = mirror1(s0 + 2, cw);
+      const float ca = row_c[ia], cb = row_c[ib], cc = row_c[ic], cd = row_c[id];
+      hc[0] = chroma_blend(ca, cb);
+      hc[1] = chroma_blend(cc, cb);
+      hc[2] = chroma_blend(cb, cc);
+      hc[3] = chroma_blend(cd, cc);
+      if (vs) {
+        const float na = row_n[ia], nb = row_n[ib], nc = row_n[ic], nd = row_n[id];
+        hn[0] = chroma_blend(na, nb);
+        hn[1] = chroma_blend(nc, nb);
+        hn[2] = chroma_blend(nb, nc);
+        hn[3] = chroma_blend(nd, nc);
+      }
+    } else {
+      load4(row_c, x4, w, hc);
+      load4(row_n, x4, w, hn);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) v[c][i] = vs ? chroma_blend(hn[i], hc[i]) : hc[i];
+  }
+  (void)whole;
+  uint32_t q[4][3];
+  const XybParamsDev xp = {};
+  const TfParamsDev tp = {};
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    float rr, gg, bb;
+    to_display_rgb<kModeYcbcr>(xp, tp, v[0][i], v[1][i], v[2][i], rr, gg, bb);
+    if constexpr (U16) {
+      q[i][0] = to_u16(rr);
+      q[i][1] = to_u16(gg);
+      q[i][2] = to_u16(bb);
+    } else {
+      q[i][0] = to_u8(rr, s_dither, x4 + i, y, 0);
+      q[i][1] = to_u8(gg, s_dither, x4 + i, y, 1);
+      q[i][2] = to_u8(bb, s_dither, x4 + i, y, 2);
+    }
+  }
+  if constexpr (U16) {
+    uint16_t* o = static_cast<uint16_t*>(out) + (size_t)r * out_stride + (size_t)x4 * CH;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      if (x4 + i < w) {
+        o[i * CH] = (uint16_t)q[i][0];
+        o[i * CH + 1] = (uint16_t)q[i][1];
+        o[i * CH + 2] = (uint16_t)q[i][2];
+        if constexpr (CH == 4) o[i * CH + 3] = 65535;
+      }
+  } else {
+    uint8_t* o = static_cast<uint8_t*>(out) + (size_t)r * out_stride + (size_t)x4 * CH;
+    if (aligned && x4 + 4 <= w) {
+      uint32_t* o32 = reinterpret_cast<uint32_t*>(o);
+      if constexpr (CH == 3) {
+        o32[0] = q[0][0] | (q[0][1] << 8) | (q[0][2] << 16) | (q[1][0] << 24);
+        o32[1] = q[1][1] | (q[1][2] << 8) | (q[2][0] << 16) | (q[2][1] << 24);
+        o32[2] = q[2][2] | (q[3][0] << 8) | (q[3][1] << 16) | (q[3][2] << 24);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++) o32[i] = q[i][0] | (q[i][1] << 8) | (q[i][2] << 16) | 0xff000000u;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+        if (x4 + i < w) {
+          o[i * CH] = (uint8_t)q[i][0];
+          o[i * CH + 1] = (uint8_t)q[i][1];
+          o[i * CH + 2] = (uint8_t)q[i][2];
+          if constexpr (CH == 4) o[i * CH + 3] = 255;
+        }
+    }
+  }
+}
+
 }  // namespace
+
+// out_stride: bytes (8-bit) or elements (16-bit)
+void launch_ycbcr_sub_to_rgb(hipStream_t s, const SubPlanesDev& sp, size_t stride, int w, int y0, int rows, int channels,
+                             int bits, void* out, size_t out_stride) {
+  if (w <= 0 || rows <= 0) return;
+  const dim3 grid((unsigned)(((w + 3) / 4 + kOutThreads - 1) / kOutThreads), (unsigned)rows);
+  const int aligned = ((reinterpret_cast<uintptr_t>(out) | out_stride) & 3) == 0;
+  if (bits == 8) {
+    if (channels == 3)
+      hipLaunchKernelGGL((k_ycbcr_sub_to_rgb<3, false>), grid, dim3(kOutThreads), 0, s, sp, (uint32_t)stride, w, y0, rows,
+                         out, out_stride, aligned);
+    else
+      hipLaunchKernelGGL((k_ycbcr_sub_to_rgb<4, false>), grid, dim3(kOutThreads), 0, s, sp, (uint32_t)stride, w, y0, rows,
+                         out, out_stride, aligned);
+  } else {
+    if (channels == 3)
+      hipLaunchKernelGGL((k_ycbcr_sub_to_rgb<3, true>), grid, dim3(kOutThreads), 0, s, sp, (uint32_t)stride, w, y0, rows,
+                         out, out_stride, aligned);
+    else
+      hipLaunchKernelGGL((k_ycbcr_sub_to_rgb<4, true>), grid, dim3(kOutThreads), 0, s, sp, (uint32_t)stride, w, y0, rows,
+                         out, out_stride, aligned);
+  }
+}
 
 template <int MODE>
 void launch8_mode(hipStream_t s, const float* const planes[3], size_t stride, int w, int y0, int rows, const XybParamsDev& q,
