@@ -135,7 +135,8 @@ __device__ __forceinline__ int32_t palette_value(const int32_t* __restrict__ pal
 constexpr int kDeltaRows = 256;
 constexpr int kDeltaPublish = 32;
 
-__device__ __forceinline__ int64_t predict_one(int predictor, int64_t left, int64_t top, int64_t toptop, int64_t topleft,
+template <int predictor>
+__device__ __forceinline__ int64_t predict_one(int64_t left, int64_t top, int64_t toptop, int64_t topleft,
                                                int64_t topright, int64_t leftleft, int64_t toprightright) {
   switch (predictor) {  // Predictor::predict_one, modular/predict.rs:152-198 (i64, `/` truncates)
     case 1: return left;
@@ -163,48 +164,37 @@ __device__ __forceinline__ int64_t predict_one(int predictor, int64_t left, int6
   }
 }
 
+// `out` already holds the palette entry of every pixel (the parallel gather kernel ran first): the wavefront only
+// adds the prediction where index < num_deltas.
+template <int PREDICTOR>
 __global__ __launch_bounds__(kDeltaRows) void k5_palette_delta(const int32_t* __restrict__ index, int w, int h,
-                                                               const int32_t* __restrict__ palette, int num_colors,
-                                                               int num_deltas, size_t pstride, int bit_depth,
-                                                               int predictor, int32_t* out_base, int* progress_base) {
+                                                               int num_deltas, int32_t* out_base, int* progress_base) {
   __shared__ int32_t s_ring[kDeltaRows][8];
   __shared__ int32_t s_above[2][128];  // rows y0 - 1 and y0 - 2 (of the previous band), a window of 128 columns
   __shared__ int s_avail;
   const int c = blockIdx.x, band = blockIdx.y, nbands = gridDim.y, l = threadIdx.x;
   int32_t* out = out_base + (size_t)c * (size_t)w * h;  // no __restrict__: rows are read back
   int* progress = progress_base + (size_t)c * nbands;
-  const int palette_size = num_colors + num_deltas;
   const int y0 = band * kDeltaRows;
   const int rows = min(kDeltaRows, h - y0);
   const int y = y0 + l;
   const int32_t* __restrict__ irow = index + (size_t)min(y, h - 1) * w;
   int32_t* orow = out + (size_t)min(y, h - 1) * w;
   int32_t left_v = 0, leftleft_v = 0;  // out[y][x - 1], out[y][x - 2]
-  // Two-stage prefetch along the row, so that neither the index load nor the palette gather it feeds sits on the
-  // per-step critical path (the step barrier waits for LDS only).  The queues are indexed by the STEP (slot s & 7 /
-  // s & 3), not by the column, so that an 8x unrolled loop addresses them with compile-time register numbers and
-  // no value in flight is ever moved: at step s a lane consumes index / entry of its column x from slot s & 7 /
-  // s & 3, refills the index slot with column x + 8 and the entry slot with column x + 4 (index from slot (s+4) & 7).
-  int32_t iq[8], eq[4];
+  // Index and palette entry of a lane's next 8 columns are loaded 8 steps ahead, off the per-step critical path (the
+  // step barrier waits for LDS only).  The queues are indexed by the STEP (slot s & 7), not by the column, so that
+  // the 8x unrolled loop addresses them with compile-time register numbers and no value in flight is ever moved.
+  int32_t iq[8], eq[8];
   {
     const int s0 = 3 * l;  // the lane's first step
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-      iq[k] = 0;
+      iq[k] = eq[k] = 0;
 #pragma unroll
       for (int j = 0; j < 8; j++)
-        if (((s0 + j) & 7) == k) iq[k] = (l < rows && j < w) ? irow[j] : 0;
-    }
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      eq[k] = 0;
-#pragma unroll
-      for (int j = 0; j < 4; j++)
-        if (((s0 + j) & 3) == k) {
-          int32_t ix = 0;
-#pragma unroll
-          for (int m = 0; m < 8; m++) ix = ((s0 + j) & 7) == m ? iq[m] : ix;
-          eq[k] = palette_value(palette, pstride, ix, c, palette_size, bit_depth);
+        if (((s0 + j) & 7) == k && l < rows && j < w) {
+          iq[k] = irow[j];
+          eq[k] = orow[j];
         }
     }
   }
@@ -217,9 +207,11 @@ __global__ __launch_bounds__(kDeltaRows) void k5_palette_delta(const int32_t* __
     const int x = s - 3 * l;
     if (l < rows && x >= 0 && x < w) {
       const int32_t idx = iq[K];
-      int32_t val = eq[K & 3];
-      iq[K] = x + 8 < w ? irow[x + 8] : 0;
-      eq[K & 3] = palette_value(palette, pstride, iq[(K + 4) & 7], c, palette_size, bit_depth);  // column x + 4
+      int32_t val = eq[K];
+      if (x + 8 < w) {
+        iq[K] = irow[x + 8];
+        eq[K] = orow[x + 8];
+      }
       if (idx < num_deltas) {
         // row y - 1 / y - 2: the LDS ring of the lane above, or the window of the previous band's rows
         auto T = [&](int xx) -> int32_t { return l > 0 ? s_ring[l - 1][xx & 7] : s_above[0][xx & 127]; };
@@ -234,10 +226,10 @@ __global__ __launch_bounds__(kDeltaRows) void k5_palette_delta(const int32_t* __
         const int64_t leftleft = x > 1 ? leftleft_v : left;
         const int64_t toptop = y > 1 ? TT(x) : top;
         const int64_t toprightright = (x + 2 < w && y > 0) ? T(x + 2) : topright;
-        const int64_t pred = predict_one(predictor, left, top, toptop, topleft, topright, leftleft, toprightright);
+        const int64_t pred = predict_one<PREDICTOR>(left, top, toptop, topleft, topright, leftleft, toprightright);
         val = (int32_t)(uint32_t)(uint64_t)(pred + (int64_t)val);
+        orow[x] = val;
       }
-      orow[x] = val;
       s_ring[l][x & 7] = val;
       leftleft_v = left_v;
       left_v = val;
@@ -511,10 +503,21 @@ void launch_palette_delta(hipStream_t s, const int32_t* index, int w, int h, con
                           int num_deltas, size_t palette_stride, int nb_channels, int bit_depth, int predictor,
                           int32_t* out, int* progress) {
   if (w <= 0 || h <= 0) return;
+  // every pixel's palette entry, in parallel (get_palette_value with palette_size = num_colors + num_deltas) ...
+  launch_palette(s, index, (size_t)w * h, palette, num_colors + num_deltas, palette_stride, nb_channels, bit_depth, out);
+  if (num_deltas <= 0 && predictor == 0) return;
+  // ... then the wavefront adds the predictions (entries below num_deltas, incl. the implicit negative indices)
   const int nbands = palette_delta_bands(h);
   (void)hipMemsetAsync(progress, 0, sizeof(int) * (size_t)nb_channels * nbands, s);
-  hipLaunchKernelGGL(k5_palette_delta, dim3(nb_channels, nbands), dim3(kDeltaRows), 0, s, index, w, h, palette,
-                     num_colors, num_deltas, palette_stride, bit_depth, predictor, out, progress);
+  const dim3 grid(nb_channels, nbands), block(kDeltaRows);
+#define JXLH_DELTA(P) \
+  case P: hipLaunchKernelGGL(k5_palette_delta<P>, grid, block, 0, s, index, w, h, num_deltas, out, progress); break
+  switch (predictor) {
+    JXLH_DELTA(0); JXLH_DELTA(1); JXLH_DELTA(2); JXLH_DELTA(3); JXLH_DELTA(4); JXLH_DELTA(5); JXLH_DELTA(7);
+    JXLH_DELTA(8); JXLH_DELTA(9); JXLH_DELTA(10); JXLH_DELTA(11); JXLH_DELTA(12); JXLH_DELTA(13);
+    default: break;
+  }
+#undef JXLH_DELTA
 }
 
 void launch_unsqueeze(hipStream_t s, int horizontal, int n_planes, const int32_t* const avg[], size_t avg_stride,

@@ -1,16 +1,20 @@
+#!/usr/bin/env python3
+"""Delta-palette wavefront kernel timing: usage tools/bench_delta_palette.py [WxH ...] (gradient predictor, 3 channels)"""
 import sys, os, time
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import jxl_rs_amd
 from jxl_rs_amd import lib
 c = jxl_rs_amd.Context(0, 1)
-for n in (1024, 4096, 8192):
+sizes = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]] or [(1024, 1024), (4096, 4096), (8192, 8192)]
+for w, h in sizes:
     rng = np.random.default_rng(1)
-    idx = torch.from_numpy(rng.integers(0, 40, size=(n, n)).astype(np.int32)).cuda()
+    idx = torch.from_numpy(rng.integers(0, 40, size=(h, w)).astype(np.int32)).cuda()
     pal = torch.from_numpy(rng.integers(-10, 256, size=(3, 64)).astype(np.int32)).cuda()
-    out = torch.empty((3, n, n), dtype=torch.int32, device="cuda")
+    out = torch.empty((3, h, w), dtype=torch.int32, device="cuda")
     def run():
-        c._chk(c.L.jxlh_palette_delta(c._ctx, lib._addr(idx), n, n, lib._addr(pal), 56, 8, 64, 3, 8, 5, lib._addr(out)), "pd")
+        c._chk(c.L.jxlh_palette_delta(c._ctx, lib._addr(idx), w, h, lib._addr(pal), 56, 8, 64, 3, 8, 5, lib._addr(out)), "pd")
     run(); c.sync()
     t0 = time.perf_counter(); run(); c.sync(); t = time.perf_counter() - t0
-    print(n, "delta palette gradient predictor: %.2f ms  (%.1f MP/s)" % (t * 1e3, n * n / t / 1e6))
+    steps = w + 3 * h
+    print(f"{w}x{h}: {t*1e3:.2f} ms  ({w*h/t/1e6:.1f} MP/s, {t*1e6/steps:.2f} us per wavefront step of {steps})")
