@@ -571,10 +571,17 @@ __global__ __launch_bounds__(kSpecThreads, 2) void k1_special(const FrameDev f, 
   // work unit = (chunk, type bin, channel): the channels only meet in the chroma-from-luma FMA, whose Y
   // term the X / B units recompute from the Y coefficients -- three times the parallelism for a kernel
   // that is bound by the latency of its serial per-unit steps
-  const int npairs = ((count + kSpecChunk - 1) / kSpecChunk) * kSpecBins * 3;
+  // JXLH_SPEC_SPLIT = 1 makes the channels separate work units (X / B recompute the dequantised Y): three times the
+  // parallelism, but the kernel is VALU bound on the all-types frame (profiles/r01_j_allmix16k_pmc.txt) and the two
+  // extra dequantisations cost more than the parallelism buys: 16K all types, K1 2.55 -> 2.46 ms without the split
+#ifndef JXLH_SPEC_SPLIT
+#define JXLH_SPEC_SPLIT 0
+#endif
+  constexpr int kUnitsPerBin = JXLH_SPEC_SPLIT ? 3 : 1;
+  const int npairs = ((count + kSpecChunk - 1) / kSpecChunk) * kSpecBins * kUnitsPerBin;
   constexpr int NCH = kSpecNB * 64 / 256;
   for (int pair = blockIdx.x * kSpecWaves + wave; pair < npairs; pair += gridDim.x * kSpecWaves) {
-    const int unit_ch = pair % 3, cb = pair / 3;
+    const int unit_ch = JXLH_SPEC_SPLIT ? pair % 3 : 3, cb = pair / kUnitsPerBin;
     const int chunk = cb / kSpecBins, bin = cb % kSpecBins;
     // ---- this wave's items of the chunk: the ones whose type falls in `bin`
     int nmine = 0;
@@ -699,7 +706,11 @@ __global__ __launch_bounds__(kSpecThreads, 2) void k1_special(const FrameDev f, 
         }
         wave_sync();
       };
-      if (unit_ch == 1) {
+      if (unit_ch == 3) {  // all three channels by one wave: the dequantised Y stays in registers
+        run_channel(std::integral_constant<int, 1>{});
+        run_channel(std::integral_constant<int, 0>{});
+        run_channel(std::integral_constant<int, 2>{});
+      } else if (unit_ch == 1) {
         run_channel(std::integral_constant<int, 1>{});
       } else {
         // dequantised Y of the lane's coefficient positions (what run_channel<1> leaves in dy)
