@@ -6,6 +6,7 @@ import numpy as np, torch
 import jxl_rs_amd
 from jxl_rs_amd import lib
 c = jxl_rs_amd.Context(0, 1)
+ND = int(os.environ.get("ND", "8"))
 sizes = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]] or [(1024, 1024), (4096, 4096), (8192, 8192)]
 for w, h in sizes:
     rng = np.random.default_rng(1)
@@ -13,7 +14,7 @@ for w, h in sizes:
     pal = torch.from_numpy(rng.integers(-10, 256, size=(3, 64)).astype(np.int32)).cuda()
     out = torch.empty((3, h, w), dtype=torch.int32, device="cuda")
     def run():
-        c._chk(c.L.jxlh_palette_delta(c._ctx, lib._addr(idx), w, h, lib._addr(pal), 56, 8, 64, 3, 8, 5, lib._addr(out)), "pd")
+        c._chk(c.L.jxlh_palette_delta(c._ctx, lib._addr(idx), w, h, lib._addr(pal), 64 - ND, ND, 64, 3, 8, 5, lib._addr(out)), "pd")
     run(); c.sync()
     t0 = time.perf_counter(); run(); c.sync(); t = time.perf_counter() - t0
     steps = w + 3 * h
