@@ -219,6 +219,12 @@ jxlh_status jxlh_submit_group_sparse(jxlh_ctx* ctx, int32_t slot, uint32_t group
 jxlh_status jxlh_submit_groups_sparse(jxlh_ctx* ctx, int32_t slot, uint32_t count, const uint32_t* group_ids,
                                       const jxlh_coeff16* pairs, const uint32_t* n, const jxlh_coeff32* wide,
                                       uint32_t n_wide, uint32_t flags);
+/* The same with 3 bytes per update on the bus: positions (u16) and values (i8) as two arrays in the order of the
+ * pairs above; updates whose value does not fit 8 bits go to `wide` like those that do not fit 16 above.  At d1 nearly
+ * every coefficient fits, and the host-to-device copy is what bounds the decode-to-device rate. */
+jxlh_status jxlh_submit_groups_sparse8(jxlh_ctx* ctx, int32_t slot, uint32_t count, const uint32_t* group_ids,
+                                       const uint16_t* pos, const int8_t* val, const uint32_t* n,
+                                       const jxlh_coeff32* wide, uint32_t n_wide, uint32_t flags);
 jxlh_status jxlh_slot_wait(jxlh_ctx* ctx, int32_t slot);
 
 /* Device-resident coefficient store of the current frame (ngroups * 3 * 65536 i32), for callers

@@ -26,6 +26,8 @@ struct Slot {
   hipStream_t stream = nullptr;
   hipEvent_t done = nullptr;
   bool used = false;
+  uint8_t* stage8 = nullptr;  // device staging of the 3-byte sparse form (positions | values), grown on demand
+  size_t stage8_cap = 0;
 };
 
 struct KernelTime {
@@ -299,6 +301,7 @@ void jxlh_ctx_destroy(jxlh_ctx* ctx) {
   for (auto& s : ctx->slots) {
     if (s.done) (void)hipEventDestroy(s.done);
     if (s.stream) (void)hipStreamDestroy(s.stream);
+    if (s.stage8) (void)hipFree(s.stage8);
   }
   for (int c = 0; c < 3; c++) {
     release(ctx->planes[c]);
@@ -620,54 +623,99 @@ jxlh_status jxlh_submit_group(jxlh_ctx* ctx, int32_t slot, uint32_t group_id, co
   return JXLH_OK;
 }
 
-jxlh_status jxlh_submit_groups_sparse(jxlh_ctx* ctx, int32_t slot, uint32_t count, const uint32_t* group_ids,
-                                      const jxlh_coeff16* pairs, const uint32_t* n, const jxlh_coeff32* wide,
-                                      uint32_t n_wide, uint32_t flags) {
+namespace {
+// bookkeeping shared by the sparse submission forms: validates, reserves `total` pairs in the frame's pair buffer
+// (offset returned) and records the groups / wide entries for the next jxlh_frame_run
+jxlh_status sparse_reserve(jxlh_ctx* ctx, int32_t slot, uint32_t count, const uint32_t* group_ids, const uint32_t* n,
+                           const jxlh_coeff32* wide, uint32_t n_wide, uint32_t flags, size_t* offset_out,
+                           size_t* total_out) {
   if (!ctx || slot < 0 || (size_t)slot >= ctx->slots.size() || !group_ids || !n || (n_wide && !wide))
     return JXLH_ERR_INVALID_ARGUMENT;
   if (!ctx->in_frame) return JXLH_ERR_BAD_STATE;
   if (!(flags & JXLH_GROUP_COMPLETE)) return JXLH_ERR_UNSUPPORTED;
-  if (count == 0) return JXLH_OK;
   size_t total = 0;
   for (uint32_t i = 0; i < count; i++) {
     if (group_ids[i] >= ctx->ngroups) return JXLH_ERR_INVALID_ARGUMENT;
     total += (size_t)n[3 * i] + n[3 * i + 1] + n[3 * i + 2];
   }
-  if (total && !pairs) return JXLH_ERR_INVALID_ARGUMENT;
   const size_t wide_limit = ctx->ngroups * 3 * (size_t)kGroupArea;
   for (uint32_t i = 0; i < n_wide; i++)
     if (wide[i].pos >= wide_limit) return JXLH_ERR_INVALID_ARGUMENT;
-  Slot& s = ctx->slots[slot];
-  size_t offset;
-  {
-    std::lock_guard<std::mutex> lock(ctx->sp_mutex);
-    const size_t capacity = ctx->ngroups * 3 * (size_t)kGroupArea;  // one pair per coefficient
-    if (jxlh_status st = ensure(ctx, ctx->sp_pairs, capacity)) return st;
-    if (!ctx->sp_expanded) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->sp_expanded, hipEventDisableTiming));
-    if (ctx->sp_used + total > capacity) return JXLH_ERR_INVALID_ARGUMENT;  // more pairs than coefficients
-    for (uint32_t i = 0; i < count; i++)  // one sparse submission per group between two runs (its list may
-      if (ctx->touched[group_ids[i]] == 2) return JXLH_ERR_BAD_STATE;  // hold several passes' updates)
-    offset = ctx->sp_used;
-    ctx->sp_used += total;
-    size_t o = offset;
-    for (uint32_t i = 0; i < count; i++) {
-      SparseGroup g;
-      g.group = group_ids[i];
-      g.offset = (uint32_t)o;
-      for (int c = 0; c < 3; c++) {
-        g.n[c] = n[3 * i + c];
-        o += g.n[c];
-      }
-      ctx->sp_pending.push_back(g);
-      ctx->touched[g.group] = 2;
+  std::lock_guard<std::mutex> lock(ctx->sp_mutex);
+  const size_t capacity = ctx->ngroups * 3 * (size_t)kGroupArea;  // one pair per coefficient
+  if (jxlh_status st = ensure(ctx, ctx->sp_pairs, capacity)) return st;
+  if (!ctx->sp_expanded) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->sp_expanded, hipEventDisableTiming));
+  if (ctx->sp_used + total > capacity) return JXLH_ERR_INVALID_ARGUMENT;  // more pairs than coefficients
+  for (uint32_t i = 0; i < count; i++)  // one sparse submission per group between two runs (its list may
+    if (ctx->touched[group_ids[i]] == 2) return JXLH_ERR_BAD_STATE;  // hold several passes' updates)
+  const size_t offset = ctx->sp_used;
+  ctx->sp_used += total;
+  size_t o = offset;
+  for (uint32_t i = 0; i < count; i++) {
+    SparseGroup g;
+    g.group = group_ids[i];
+    g.offset = (uint32_t)o;
+    for (int c = 0; c < 3; c++) {
+      g.n[c] = n[3 * i + c];
+      o += g.n[c];
     }
-    ctx->epoch_dirty = true;
-    for (uint32_t i = 0; i < n_wide; i++) ctx->sp_wide.push_back(make_uint2(wide[i].pos, (uint32_t)wide[i].val));
+    ctx->sp_pending.push_back(g);
+    ctx->touched[g.group] = 2;
   }
+  ctx->epoch_dirty = true;
+  for (uint32_t i = 0; i < n_wide; i++) ctx->sp_wide.push_back(make_uint2(wide[i].pos, (uint32_t)wide[i].val));
+  *offset_out = offset;
+  *total_out = total;
+  return JXLH_OK;
+}
+}  // namespace
+
+jxlh_status jxlh_submit_groups_sparse(jxlh_ctx* ctx, int32_t slot, uint32_t count, const uint32_t* group_ids,
+                                      const jxlh_coeff16* pairs, const uint32_t* n, const jxlh_coeff32* wide,
+                                      uint32_t n_wide, uint32_t flags) {
+  if (count == 0 && ctx && ctx->in_frame) return JXLH_OK;
+  size_t offset = 0, total = 0;
+  if (jxlh_status st = sparse_reserve(ctx, slot, count, group_ids, n, wide, n_wide, flags, &offset, &total)) return st;
+  if (total && !pairs) return JXLH_ERR_INVALID_ARGUMENT;
+  Slot& s = ctx->slots[slot];
   // the pair buffer is recycled per frame: the previous frame's expansion must have read it
   if (ctx->sp_expanded_valid) HIPCHK(ctx, hipStreamWaitEvent(s.stream, ctx->sp_expanded, 0));
   if (total)
     HIPCHK(ctx, hipMemcpyAsync(ctx->sp_pairs.p + offset, pairs, total * sizeof(uint32_t), hipMemcpyDefault, s.stream));
+  HIPCHK(ctx, hipEventRecord(s.done, s.stream));
+  s.used = true;
+  return JXLH_OK;
+}
+
+// 3 bytes per coefficient update on the bus: positions and values as separate arrays (u16 / i8), widened into the
+// pair buffer by a small kernel on the slot's stream
+jxlh_status jxlh_submit_groups_sparse8(jxlh_ctx* ctx, int32_t slot, uint32_t count, const uint32_t* group_ids,
+                                       const uint16_t* pos, const int8_t* val, const uint32_t* n,
+                                       const jxlh_coeff32* wide, uint32_t n_wide, uint32_t flags) {
+  if (count == 0 && ctx && ctx->in_frame) return JXLH_OK;
+  size_t offset = 0, total = 0;
+  if (jxlh_status st = sparse_reserve(ctx, slot, count, group_ids, n, wide, n_wide, flags, &offset, &total)) return st;
+  if (total && (!pos || !val)) return JXLH_ERR_INVALID_ARGUMENT;
+  Slot& s = ctx->slots[slot];
+  if (ctx->sp_expanded_valid) HIPCHK(ctx, hipStreamWaitEvent(s.stream, ctx->sp_expanded, 0));
+  if (total) {
+    // staging: [positions | values], reused by the slot (stream-ordered)
+    const size_t pos_bytes = (total * sizeof(uint16_t) + 15) & ~(size_t)15;
+    if (s.stage8_cap < pos_bytes + total) {
+      HIPCHK(ctx, hipStreamSynchronize(s.stream));  // the old staging may still be read by a queued kernel
+      if (s.stage8) (void)hipFree(s.stage8);
+      s.stage8 = nullptr;
+      s.stage8_cap = 0;
+      const size_t cap = (pos_bytes + total) * 5 / 4 + 4096;
+      if (hipMalloc(reinterpret_cast<void**>(&s.stage8), cap) != hipSuccess) return JXLH_ERR_OUT_OF_MEMORY;
+      s.stage8_cap = cap;
+    }
+    HIPCHK(ctx, hipMemcpyAsync(s.stage8, pos, total * sizeof(uint16_t), hipMemcpyDefault, s.stream));
+    HIPCHK(ctx, hipMemcpyAsync(s.stage8 + pos_bytes, val, total, hipMemcpyDefault, s.stream));
+    launch_pack_pairs8(s.stream, reinterpret_cast<const uint16_t*>(s.stage8),
+                       reinterpret_cast<const int8_t*>(s.stage8 + pos_bytes), total, ctx->sp_pairs.p + offset);
+    HIPCHK(ctx, hipGetLastError());
+  }
   HIPCHK(ctx, hipEventRecord(s.done, s.stream));
   s.used = true;
   return JXLH_OK;

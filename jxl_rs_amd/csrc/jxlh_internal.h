@@ -204,6 +204,7 @@ struct SparseGroup {
   uint32_t n[3];    // pairs per channel
 };
 // only_flagged (nullable): expand a group only if only_flagged[group] != 0
+void launch_pack_pairs8(hipStream_t s, const uint16_t* pos, const int8_t* val, size_t n, uint32_t* pairs);
 void launch_expand_sparse(hipStream_t s, int32_t* coeffs, const uint32_t* pairs, const SparseGroup* groups,
                           int n_groups, const uint2* wide, uint32_t n_wide, const uint8_t* only_flagged);
 // dense slabs of the groups with flags[g] != 0 from the bucketed pairs (all groups of the frame)

@@ -155,4 +155,27 @@ void launch_expand_sparse(hipStream_t s, int32_t* coeffs, const uint32_t* pairs,
     hipLaunchKernelGGL(k_expand_wide, dim3((n_wide + 255) / 256), dim3(256), 0, s, coeffs, wide, n_wide);
 }
 
+namespace {
+// {u16 pos} + {i8 val} -> the {u16 pos; i16 val} pair word of the sparse pipeline
+__global__ __launch_bounds__(256) void k_pack_pairs8(const uint16_t* __restrict__ pos, const int8_t* __restrict__ val,
+                                                     size_t n, uint32_t* __restrict__ pairs) {
+  const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i + 4 <= n && ((reinterpret_cast<uintptr_t>(pos + i) & 7) == 0) && ((reinterpret_cast<uintptr_t>(val + i) & 3) == 0) &&
+      ((reinterpret_cast<uintptr_t>(pairs + i) & 15) == 0)) {
+    const uint2 p = *reinterpret_cast<const uint2*>(pos + i);
+    const uint32_t v = *reinterpret_cast<const uint32_t*>(val + i);
+    auto mk = [](uint32_t ps, uint32_t vb) { return ps | ((uint32_t)(uint16_t)(int16_t)(int8_t)vb << 16); };
+    *reinterpret_cast<uint4*>(pairs + i) = make_uint4(mk(p.x & 0xffffu, v & 0xffu), mk(p.x >> 16, (v >> 8) & 0xffu),
+                                                      mk(p.y & 0xffffu, (v >> 16) & 0xffu), mk(p.y >> 16, v >> 24));
+  } else {
+    for (size_t k = i; k < n && k < i + 4; k++) pairs[k] = (uint32_t)pos[k] | ((uint32_t)(uint16_t)(int16_t)val[k] << 16);
+  }
+}
+}  // namespace
+
+void launch_pack_pairs8(hipStream_t s, const uint16_t* pos, const int8_t* val, size_t n, uint32_t* pairs) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(k_pack_pairs8, dim3((unsigned)((n / 4 + 256) / 256)), dim3(256), 0, s, pos, val, n, pairs);
+}
+
 }  // namespace jxlh

@@ -33,7 +33,7 @@ ABI_SYMBOLS = [
     "jxlh_default_frame_params", "jxlh_ctx_create", "jxlh_ctx_destroy", "jxlh_status_string", "jxlh_last_error",
     "jxlh_alloc_pinned", "jxlh_free_pinned", "jxlh_frame_begin", "jxlh_frame_set_dequant_tables",
     "jxlh_frame_set_lf_quantized", "jxlh_frame_set_lf", "jxlh_frame_set_hf_meta", "jxlh_submit_group",
-    "jxlh_submit_group_sparse", "jxlh_submit_groups_sparse", "jxlh_slot_wait", "jxlh_frame_coeff_buffer", "jxlh_frame_run", "jxlh_ctx_sync", "jxlh_frame_read_planes",
+    "jxlh_submit_group_sparse", "jxlh_submit_groups_sparse", "jxlh_submit_groups_sparse8", "jxlh_slot_wait", "jxlh_frame_coeff_buffer", "jxlh_frame_run", "jxlh_ctx_sync", "jxlh_frame_read_planes",
     "jxlh_frame_device_planes", "jxlh_frame_read_lf", "jxlh_frame_read_rgb8", "jxlh_frame_read_rgb16",
     "jxlh_frame_read_ycbcr_rgb8", "jxlh_frame_read_ycbcr_rgb16", "jxlh_frame_read_output", "jxlh_stage_chroma_upsample", "jxlh_stage_upsample", "jxlh_set_upsampling_weights", "jxlh_stage_noise_generate",
     "jxlh_stage_noise_convolve", "jxlh_stage_noise_add", "jxlh_timer_start", "jxlh_timer_stop",
@@ -135,6 +135,7 @@ def load():
     L.jxlh_slot_wait.argtypes = [vp, i32]
     L.jxlh_submit_group_sparse.argtypes = [vp, i32, u32, vp, vp, vp, u32, u32]
     L.jxlh_submit_groups_sparse.argtypes = [vp, i32, u32, vp, vp, vp, vp, u32, u32]
+    L.jxlh_submit_groups_sparse8.argtypes = [vp, i32, u32, vp, vp, vp, vp, vp, u32, u32]
     L.jxlh_frame_coeff_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
     L.jxlh_frame_run.argtypes = [vp, u32, u32]
     L.jxlh_ctx_sync.argtypes = [vp]
@@ -273,6 +274,22 @@ class Context:
         self._chk(self.L.jxlh_submit_groups_sparse(self._ctx, slot, len(group_ids), _addr(group_ids), addr, _addr(n),
                                                    None if wide is None else _addr(wide), nw, flags),
                   "submit_groups_sparse")
+
+    def submit_groups_sparse8(self, group_ids, pos, val, n, wide=None, slot=0, flags=GROUP_COMPLETE):
+        """3-byte form: pos (uint16) and val (int8) arrays, or raw host addresses (pinned memory)."""
+        group_ids = np.ascontiguousarray(group_ids, dtype=np.uint32)
+        n = np.ascontiguousarray(n, dtype=np.uint32)
+        nw = 0 if wide is None else len(wide)
+        wide = None if nw == 0 else np.ascontiguousarray(wide, dtype=np.uint32)
+        if not isinstance(pos, int):
+            pos = np.ascontiguousarray(pos, dtype=np.uint16)
+            val = np.ascontiguousarray(val, dtype=np.int8)
+        pa = pos if isinstance(pos, int) else _addr(pos)
+        va = val if isinstance(val, int) else _addr(val)
+        self._keep.append((group_ids, pos, val, n, wide))
+        self._chk(self.L.jxlh_submit_groups_sparse8(self._ctx, slot, len(group_ids), _addr(group_ids), pa, va, _addr(n),
+                                                    None if wide is None else _addr(wide), nw, flags),
+                  "submit_groups_sparse8")
 
     def alloc_pinned(self, nbytes):
         """Pinned host buffer (jxlh_alloc_pinned) as a uint8 numpy view; freed with the context."""

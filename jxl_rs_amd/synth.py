@@ -448,3 +448,23 @@ def to_sparse(group_coeffs):
     pairs = np.concatenate(runs).astype(np.uint32) if runs else np.zeros(0, np.uint32)
     widea = np.concatenate(wide).astype(np.uint32) if wide else np.zeros((0, 2), np.uint32)
     return pairs, np.asarray(n, dtype=np.uint32), widea
+
+
+def to_sparse8(group_coeffs):
+    """3-byte transport form (jxlh_submit_groups_sparse8): (pos uint16 [n0+n1+n2], val int8 [n0+n1+n2], n[3],
+    wide uint32 [k, 2] = (channel * 65536 + pos, value) for values outside i8)."""
+    g = np.asarray(group_coeffs).reshape(3, -1)
+    ps, vs, n, wide = [], [], [], []
+    for c in range(3):
+        pos = np.flatnonzero(g[c])
+        val = g[c][pos]
+        fits = (val >= -128) & (val <= 127)
+        ps.append(pos[fits].astype(np.uint16))
+        vs.append(val[fits].astype(np.int8))
+        n.append(int(fits.sum()))
+        if (~fits).any():
+            wide.append(np.stack([(c * 65536 + pos[~fits]).astype(np.uint32),
+                                  val[~fits].astype(np.int32).view(np.uint32)], axis=1))
+    widea = np.concatenate(wide).astype(np.uint32) if wide else np.zeros((0, 2), np.uint32)
+    return (np.concatenate(ps) if ps else np.zeros(0, np.uint16), np.concatenate(vs) if vs else np.zeros(0, np.int8),
+            np.asarray(n, dtype=np.uint32), widea)

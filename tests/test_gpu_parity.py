@@ -760,6 +760,42 @@ def test_sparse_duplicates_accumulate(ctx):
         assert bit_equal(a, b), diff_report(a, b)
 
 
+@pytest.mark.parametrize("mix,size,scale", [("MIX_D1", (520, 300), 1), ("MIX_ALL", (300, 270), 40)])
+def test_sparse8_submit_matches_dense_submit(ctx, oracle, mix, size, scale):
+    """jxlh_submit_groups_sparse8 (u16 positions + i8 values, larger values through the wide list) gives the frame
+    the dense submission gives, bit for bit; scale 40 pushes a good share of the values past 8 bits"""
+    from jxl_rs_amd import synth
+    w, h = size
+    wl = synth.make_vardct(w, h, mix=getattr(synth, mix), seed=w + h, epf_iters=2, coeff_scale=scale)
+    want, _ = run_gpu_frame(ctx, wl)
+    p = gpu_params_from(ctx, wl)
+    ctx.frame_begin(p)
+    ctx.set_dequant_tables(wl.tables)
+    ctx.set_lf_quantized(*wl.lf_q)
+    ctx.set_hf_meta(wl.transform_map, wl.raw_quant, wl.epf_map, wl.ytox, wl.ytob)
+    ng = wl.coeffs.shape[0]
+    parts = [synth.to_sparse8(wl.coeffs[g]) for g in range(ng)]
+    pos = np.concatenate([q[0] for q in parts])
+    val = np.concatenate([q[1] for q in parts])
+    n = np.concatenate([q[2] for q in parts])
+    wide = []
+    for g, q in enumerate(parts):   # the batched form addresses wide entries frame-wide
+        if len(q[3]):
+            e = q[3].copy()
+            e[:, 0] += np.uint32(g * 3 * 65536)
+            wide.append(e)
+    wide = np.concatenate(wide) if wide else None
+    if scale > 1:
+        assert wide is not None and len(wide) > 100
+    ctx.submit_groups_sparse8(np.arange(ng, dtype=np.uint32), pos, val, n, wide)
+    ctx.slot_wait(0)
+    ctx.frame_run()
+    ctx.sync()
+    got = ctx.read_planes()
+    for c in range(3):
+        assert bit_equal(got[c], want[c]), f"plane {c}: {diff_report(got[c], want[c])}"
+
+
 def test_sparse_submit_argument_errors(ctx):
     from jxl_rs_amd import synth
     from jxl_rs_amd.lib import JxlHipError
