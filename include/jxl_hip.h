@@ -279,6 +279,11 @@ typedef struct jxlh_xyb_params {
 } jxlh_xyb_params;
 jxlh_status jxlh_frame_read_rgb8(jxlh_ctx* ctx, const jxlh_xyb_params* p, uint32_t channels, uint32_t y0,
                                  uint32_t y1, void* out, size_t bytes_per_row);
+/* jxlh_frame_read_rgb8 without the final wait: the conversion and the copy to `out` are queued on the context's
+ * stream and the call returns; `out` (pinned host memory, or device memory) holds the image after the next
+ * jxlh_ctx_sync.  Lets the download of frame i run while the caller submits frame i + 1 to another context. */
+jxlh_status jxlh_frame_read_rgb8_async(jxlh_ctx* ctx, const jxlh_xyb_params* p, uint32_t channels, uint32_t y0,
+                                       uint32_t y1, void* out, size_t bytes_per_row);
 /* The same with ConvertF32ToU16Stage at 16 bits (render/stages/convert.rs:743-761: clamp to [0,1], x65535,
  * round to nearest even, no dither): native-endian u16 samples, interleaved. */
 jxlh_status jxlh_frame_read_rgb16(jxlh_ctx* ctx, const jxlh_xyb_params* p, uint32_t channels, uint32_t y0,

@@ -1105,7 +1105,7 @@ SubPlanesDev sub_planes_dev(const jxlh_ctx* ctx) {
 
 // mode: kTfLinear..kTfGamma = XybStage (p) + that transfer function (t); kModeYcbcr; kModeNone
 jxlh_status read_rgb8(jxlh_ctx* ctx, int mode, const jxlh_xyb_params* p, const TfParamsDev& tf, uint32_t channels,
-                      uint32_t y0, uint32_t y1, void* out, size_t bytes_per_row) {
+                      uint32_t y0, uint32_t y1, void* out, size_t bytes_per_row, bool wait = true) {
   if (!ctx || !out || (channels != 3 && channels != 4)) return JXLH_ERR_INVALID_ARGUMENT;
   if (!ctx->in_frame || !ctx->result[0]) return JXLH_ERR_BAD_STATE;
   if (y1 > (uint32_t)ctx->res_h) y1 = (uint32_t)ctx->res_h;
@@ -1132,7 +1132,7 @@ jxlh_status read_rgb8(jxlh_ctx* ctx, int mode, const jxlh_xyb_params* p, const T
     if (jxlh_status st = copy2d(ctx, out, bytes_per_row, ctx->rgb8.p, tight, (size_t)ctx->res_w * channels, (size_t)rows,
                                 ctx->stream))
       return st;
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (wait) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return JXLH_OK;
   }
   if (is_device_ptr(out)) {
@@ -1155,7 +1155,7 @@ jxlh_status read_rgb8(jxlh_ctx* ctx, int mode, const jxlh_xyb_params* p, const T
   const size_t row_bytes = (size_t)ctx->res_w * channels;
   if (jxlh_status st = copy2d(ctx, out, bytes_per_row, ctx->rgb8.p, tight, row_bytes, (size_t)rows, ctx->stream))
     return st;
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (wait) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return JXLH_OK;
 }
 
@@ -1217,6 +1217,11 @@ jxlh_status jxlh_frame_read_rgb8(jxlh_ctx* ctx, const jxlh_xyb_params* p, uint32
                                  uint32_t y1, void* out, size_t bytes_per_row) {
   if (!p) return JXLH_ERR_INVALID_ARGUMENT;
   return read_rgb8(ctx, kTfSrgb, p, TfParamsDev{}, channels, y0, y1, out, bytes_per_row);
+}
+jxlh_status jxlh_frame_read_rgb8_async(jxlh_ctx* ctx, const jxlh_xyb_params* p, uint32_t channels, uint32_t y0,
+                                       uint32_t y1, void* out, size_t bytes_per_row) {
+  if (!p) return JXLH_ERR_INVALID_ARGUMENT;
+  return read_rgb8(ctx, kTfSrgb, p, TfParamsDev{}, channels, y0, y1, out, bytes_per_row, /*wait=*/false);
 }
 jxlh_status jxlh_frame_read_rgb16(jxlh_ctx* ctx, const jxlh_xyb_params* p, uint32_t channels, uint32_t y0,
                                   uint32_t y1, void* out, size_t bytes_per_row) {
