@@ -907,9 +907,8 @@ def test_output_transfer_functions_bit_exact(ctx, oracle, kat, tf, param, bits, 
 
 def test_rgb8_async_read_equals_blocking_read(ctx, oracle, kat):
     """jxlh_frame_read_rgb8_async: same bytes as the blocking call once the context has been synchronised,
-    for pinned host memory (ABI allocation) and for device memory"""
+    into pinned host memory"""
     import ctypes as C
-    import torch
     from jxl_rs_amd import synth
     w, h = 333, 77
     wl = synth.make_vardct(w, h, mix=synth.MIX_D1, seed=5, epf_iters=2)
@@ -925,11 +924,6 @@ def test_rgb8_async_read_equals_blocking_read(ctx, oracle, kat):
              "frame_read_rgb8_async")
     ctx.sync()
     assert np.array_equal(pinned[:w * h * 3].reshape(h, w, 3), want)
-    dev = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda")
-    ctx._chk(ctx.L.jxlh_frame_read_rgb8_async(ctx._ctx, pr.ctypes.data_as(C.c_void_p), 3, 0, h, C.c_void_p(dev.data_ptr()),
-                                              w * 3), "frame_read_rgb8_async")
-    ctx.sync()
-    assert np.array_equal(dev.cpu().numpy(), want)
 
 
 def test_rgb8_output_argument_errors(ctx, oracle, kat):
