@@ -56,6 +56,29 @@ def main():
     timeit("unsqueeze_h_x3", lambda: ctx.unsqueeze_planes(True, avg3h, res3h, out3, n, n, avg_h.shape[1], res_h.shape[1], n),
            3 * 8.0 * n * n)
     timeit("unsqueeze_v_x3", lambda: ctx.unsqueeze_planes(False, avg3v, res3v, out3, n, n, n, n, n), 3 * 8.0 * n * n)
+    # ---- BASELINE config 4 as one unit: the default squeeze chain of an n x n image on three channels
+    # (modular/transforms/squeeze.rs:39-105, smallest level first), every step batched over the channels, then RCT
+    from jxl_rs_amd import synth
+    steps, (cur_w, cur_h) = synth.default_squeeze_steps(n, n)  # (horizontal, out_w, out_h) in decoder order; base size
+    cur = [torch.randint(0, 256, (cur_h, cur_w), dtype=torch.int32, device=dev, generator=g) for _ in range(3)]
+    plan = []
+    for horizontal, ow, oh in steps:
+        rw, rh = (ow // 2, oh) if horizontal else (ow, oh // 2)
+        res = [torch.randint(-8, 9, (max(rh, 1), max(rw, 1)), dtype=torch.int32, device=dev, generator=g) for _ in range(3)]
+        outs = [torch.empty((oh, ow), dtype=torch.int32, device=dev) for _ in range(3)]
+        plan.append((horizontal, ow, oh, res, outs))
+
+    def chain():
+        avg = cur
+        for horizontal, ow, oh, res, outs in plan:
+            ctx.unsqueeze_planes(horizontal, avg, res, outs, ow, oh, avg[0].shape[1], res[0].shape[1], ow)
+            avg = outs
+        ctx._chk(L.jxlh_rct(ctx._ctx, P(avg[0]), P(avg[1]), P(avg[2]), n * n, 6, 0), "rct")
+
+    samples = sum(ow * oh for _, ow, oh, _, _ in plan) * 3
+    timeit("config4_chain_squeeze_rct", chain, 8.0 * samples + 24.0 * n * n, reps=3)
+    results["config4_chain_squeeze_rct"]["steps"] = len(plan)
+    results["config4_chain_squeeze_rct"]["MP_per_s"] = round(n * n / results["config4_chain_squeeze_rct"]["ms"] / 1e3, 1)
     print(json.dumps({"size": n, "kernels": results}))
 
 
