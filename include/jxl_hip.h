@@ -378,6 +378,19 @@ jxlh_status jxlh_palette(jxlh_ctx* ctx, const int32_t* index, size_t n, const in
 jxlh_status jxlh_palette_delta(jxlh_ctx* ctx, const int32_t* index, uint32_t w, uint32_t h, const int32_t* palette,
                                int32_t num_colors, int32_t num_deltas, size_t palette_stride, int32_t nb_channels,
                                int32_t bit_depth, int32_t predictor, int32_t* out);
+/* The stages between the Modular channels and the rest of the pipeline (render/stages/convert.rs), whole planes:
+ *  - jxlh_modular_to_rgb8: ConvertI32ToU8Stage (:642-715) on three channels, interleaved -- what the pipeline builder
+ *    substitutes for ConvertModularToF32 + ConvertF32ToU8 when the output depth is a multiple of the channel depth
+ *    (render/builder.rs:152-170): multiplier = (2^8 - 1) / (2^bits - 1), max = 255; a lossless 8-bit image after
+ *    RCT / Palette / Squeeze goes straight to displayable bytes
+ *  - jxlh_modular_to_f32: ConvertModularToF32Stage for integer samples (:488-533), val * 1 / (2^bits - 1)
+ *  - jxlh_modular_xyb_to_f32: ConvertModularXYBToF32Stage (:306-343), channels in coded order Y, X, B,
+ *    quant_factors = LfQuantFactors::quant_factors (X, Y, B) */
+jxlh_status jxlh_modular_to_rgb8(jxlh_ctx* ctx, const int32_t* const planes[3], size_t stride, uint32_t w, uint32_t h,
+                                 int32_t multiplier, int32_t max, uint32_t channels, void* out, size_t bytes_per_row);
+jxlh_status jxlh_modular_to_f32(jxlh_ctx* ctx, const int32_t* in, size_t n, uint32_t bits_per_sample, float* out);
+jxlh_status jxlh_modular_xyb_to_f32(jxlh_ctx* ctx, const int32_t* y, const int32_t* x, const int32_t* b, size_t n,
+                                    const float quant_factors[3], float* ox, float* oy, float* ob);
 /* do_hsqueeze_step / do_vsqueeze_step (squeeze.rs:456-481, :661-682), whole plane.
  * horizontal: avg is ceil(out_w/2) x h, res floor(out_w/2) x h; vertical likewise in y. */
 jxlh_status jxlh_unsqueeze(jxlh_ctx* ctx, int32_t horizontal, const int32_t* avg, size_t avg_stride,

@@ -1641,6 +1641,81 @@ jxlh_status jxlh_palette_delta(jxlh_ctx* ctx, const int32_t* index, uint32_t w, 
   return stage_out(ctx, out, (const int32_t*)ctx->hook_i[2].p, n * nb_channels);
 }
 
+// ---- Modular channels -> pipeline samples (render/stages/convert.rs)
+jxlh_status jxlh_modular_to_rgb8(jxlh_ctx* ctx, const int32_t* const planes[3], size_t stride, uint32_t w, uint32_t h,
+                                 int32_t multiplier, int32_t max, uint32_t channels, void* out, size_t bytes_per_row) {
+  if (!ctx || !planes || !planes[0] || !planes[1] || !planes[2] || !out || stride < w || (channels != 3 && channels != 4) ||
+      bytes_per_row < (size_t)w * channels || max < 0 || max > 255 || w > (1u << 20) || h > (1u << 20))
+    return JXLH_ERR_INVALID_ARGUMENT;
+  if (w == 0 || h == 0) return JXLH_OK;
+  const bool dev_in = is_device_ptr(planes[0]) && is_device_ptr(planes[1]) && is_device_ptr(planes[2]);
+  const int32_t* src[3] = {planes[0], planes[1], planes[2]};
+  size_t sstride = stride;
+  jxlh_status st;
+  if (!dev_in) {
+    const size_t n = (size_t)stride * h;
+    for (int c = 0; c < 3; c++) {
+      if ((st = stage_in(ctx, ctx->hook_i[c], planes[c], n))) return st;
+      src[c] = ctx->hook_i[c].p;
+    }
+  }
+  ScopedKernelTimer t(ctx, "k_i32_to_rgb8");
+  if (is_device_ptr(out)) {
+    launch_i32_to_rgb8(ctx->stream, src, sstride, (int)w, (int)h, multiplier, max, (int)channels,
+                       static_cast<uint8_t*>(out), bytes_per_row);
+    HIPCHK(ctx, hipGetLastError());
+    return JXLH_OK;
+  }
+  const size_t tight = (size_t)w * channels;
+  if ((st = ensure(ctx, ctx->rgb8, tight * (size_t)h))) return st;
+  launch_i32_to_rgb8(ctx->stream, src, sstride, (int)w, (int)h, multiplier, max, (int)channels, ctx->rgb8.p, tight);
+  HIPCHK(ctx, hipGetLastError());
+  if ((st = copy2d(ctx, out, bytes_per_row, ctx->rgb8.p, tight, tight, (size_t)h, ctx->stream))) return st;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return JXLH_OK;
+}
+
+jxlh_status jxlh_modular_to_f32(jxlh_ctx* ctx, const int32_t* in, size_t n, uint32_t bits_per_sample, float* out) {
+  if (!ctx || !in || !out || bits_per_sample < 1 || bits_per_sample > 32) return JXLH_ERR_INVALID_ARGUMENT;
+  if (n == 0) return JXLH_OK;
+  const float scale = 1.0f / (float)((1ull << bits_per_sample) - 1);  // convert.rs:528
+  if (is_device_ptr(in) && is_device_ptr(out)) {
+    launch_modular_to_f32(ctx->stream, in, n, scale, out);
+    HIPCHK(ctx, hipGetLastError());
+    return JXLH_OK;
+  }
+  jxlh_status st;
+  if ((st = stage_in(ctx, ctx->hook_i[0], in, n))) return st;
+  if ((st = ensure(ctx, ctx->hook_f[0], n))) return st;
+  launch_modular_to_f32(ctx->stream, ctx->hook_i[0].p, n, scale, ctx->hook_f[0].p);
+  HIPCHK(ctx, hipGetLastError());
+  return stage_out(ctx, out, (const float*)ctx->hook_f[0].p, n);
+}
+
+jxlh_status jxlh_modular_xyb_to_f32(jxlh_ctx* ctx, const int32_t* y, const int32_t* x, const int32_t* b, size_t n,
+                                    const float quant_factors[3], float* ox, float* oy, float* ob) {
+  if (!ctx || !y || !x || !b || !quant_factors || !ox || !oy || !ob) return JXLH_ERR_INVALID_ARGUMENT;
+  if (n == 0) return JXLH_OK;
+  const int32_t* in[3] = {y, x, b};
+  float* outp[3] = {ox, oy, ob};
+  if (is_device_ptr(y) && is_device_ptr(x) && is_device_ptr(b) && is_device_ptr(ox) && is_device_ptr(oy) && is_device_ptr(ob)) {
+    launch_modular_xyb_to_f32(ctx->stream, y, x, b, n, quant_factors, ox, oy, ob);
+    HIPCHK(ctx, hipGetLastError());
+    return JXLH_OK;
+  }
+  jxlh_status st;
+  for (int c = 0; c < 3; c++) {
+    if ((st = stage_in(ctx, ctx->hook_i[c], in[c], n))) return st;
+    if ((st = ensure(ctx, ctx->hook_f[c], n))) return st;
+  }
+  launch_modular_xyb_to_f32(ctx->stream, ctx->hook_i[0].p, ctx->hook_i[1].p, ctx->hook_i[2].p, n, quant_factors,
+                            ctx->hook_f[0].p, ctx->hook_f[1].p, ctx->hook_f[2].p);
+  HIPCHK(ctx, hipGetLastError());
+  for (int c = 0; c < 3; c++)
+    if ((st = stage_out(ctx, outp[c], (const float*)ctx->hook_f[c].p, n))) return st;
+  return JXLH_OK;
+}
+
 jxlh_status jxlh_unsqueeze(jxlh_ctx* ctx, int32_t horizontal, const int32_t* avg, size_t avg_stride,
                            const int32_t* res, size_t res_stride, uint32_t out_w, uint32_t out_h, int32_t* out,
                            size_t out_stride) {

@@ -224,6 +224,11 @@ void launch_palette_delta(hipStream_t s, const int32_t* index, int w, int h, con
                           int num_deltas, size_t palette_stride, int nb_channels, int bit_depth, int predictor,
                           int32_t* out, int* progress);
 int palette_delta_bands(int h);
+void launch_i32_to_rgb8(hipStream_t s, const int32_t* const planes[3], size_t stride, int w, int h, int32_t mult,
+                        int32_t maxv, int channels, uint8_t* out, size_t out_stride);
+void launch_modular_to_f32(hipStream_t s, const int32_t* in, size_t n, float scale, float* out);
+void launch_modular_xyb_to_f32(hipStream_t s, const int32_t* y, const int32_t* x, const int32_t* b, size_t n,
+                               const float scale[3], float* ox, float* oy, float* ob);
 // n_planes (<= 3) planes of identical geometry in one launch (the channels of one squeeze step)
 void launch_unsqueeze(hipStream_t s, int horizontal, int n_planes, const int32_t* const avg[], size_t avg_stride,
                       const int32_t* const res[], size_t res_stride, uint32_t out_w, uint32_t out_h,

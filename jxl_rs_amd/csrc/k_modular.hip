@@ -520,6 +520,77 @@ void launch_palette_delta(hipStream_t s, const int32_t* index, int w, int h, con
 #undef JXLH_DELTA
 }
 
+namespace {
+// ConvertI32ToU8Stage x3 (render/stages/convert.rs:672-691) + interleave: 4 pixels per thread
+template <int CH>
+__global__ __launch_bounds__(256) void k_i32_to_rgb8(const int32_t* __restrict__ p0, const int32_t* __restrict__ p1,
+                                                     const int32_t* __restrict__ p2, size_t stride, int w, int h,
+                                                     int32_t mult, int32_t maxv, uint8_t* __restrict__ out,
+                                                     size_t out_stride) {
+  const int x4 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  const int y = blockIdx.y;
+  if (x4 >= w || y >= h) return;
+  const int32_t* __restrict__ pl[3] = {p0, p1, p2};
+  uint32_t q[4][3];
+#pragma unroll
+  for (int c = 0; c < 3; c++)
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int32_t v = x4 + i < w ? pl[c][(size_t)y * stride + x4 + i] : 0;
+      const int32_t scaled = (int32_t)((uint32_t)v * (uint32_t)mult);
+      const int32_t zeroclip = scaled < 0 ? 0 : scaled;
+      q[i][c] = (uint32_t)(scaled > maxv ? maxv : zeroclip) & 0xffu;
+    }
+  uint8_t* o = out + (size_t)y * out_stride + (size_t)x4 * CH;
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+    if (x4 + i < w) {
+      o[i * CH] = (uint8_t)q[i][0];
+      o[i * CH + 1] = (uint8_t)q[i][1];
+      o[i * CH + 2] = (uint8_t)q[i][2];
+      if constexpr (CH == 4) o[i * CH + 3] = 255;
+    }
+}
+
+// ConvertModularToF32Stage, integer samples (convert.rs:488-533)
+__global__ void k_modular_to_f32(const int32_t* __restrict__ in, size_t n, float scale, float* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = (float)in[i] * scale;
+}
+// ConvertModularXYBToF32Stage (convert.rs:306-343)
+__global__ void k_modular_xyb_to_f32(const int32_t* __restrict__ y, const int32_t* __restrict__ x,
+                                     const int32_t* __restrict__ b, size_t n, float sx, float sy, float sb,
+                                     float* __restrict__ ox, float* __restrict__ oy, float* __restrict__ ob) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float fy = (float)y[i];
+  ox[i] = (float)x[i] * sx;
+  oy[i] = fy * sy;
+  ob[i] = ((float)b[i] + fy) * sb;
+}
+}  // namespace
+
+void launch_i32_to_rgb8(hipStream_t s, const int32_t* const planes[3], size_t stride, int w, int h, int32_t mult,
+                        int32_t maxv, int channels, uint8_t* out, size_t out_stride) {
+  if (w <= 0 || h <= 0) return;
+  const dim3 grid(((w + 3) / 4 + 255) / 256, h);
+  if (channels == 3)
+    hipLaunchKernelGGL(k_i32_to_rgb8<3>, grid, dim3(256), 0, s, planes[0], planes[1], planes[2], stride, w, h, mult, maxv,
+                       out, out_stride);
+  else
+    hipLaunchKernelGGL(k_i32_to_rgb8<4>, grid, dim3(256), 0, s, planes[0], planes[1], planes[2], stride, w, h, mult, maxv,
+                       out, out_stride);
+}
+void launch_modular_to_f32(hipStream_t s, const int32_t* in, size_t n, float scale, float* out) {
+  if (n) hipLaunchKernelGGL(k_modular_to_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, n, scale, out);
+}
+void launch_modular_xyb_to_f32(hipStream_t s, const int32_t* y, const int32_t* x, const int32_t* b, size_t n,
+                               const float scale[3], float* ox, float* oy, float* ob) {
+  if (n)
+    hipLaunchKernelGGL(k_modular_xyb_to_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, y, x, b, n, scale[0],
+                       scale[1], scale[2], ox, oy, ob);
+}
+
 void launch_unsqueeze(hipStream_t s, int horizontal, int n_planes, const int32_t* const avg[], size_t avg_stride,
                       const int32_t* const res[], size_t res_stride, uint32_t out_w, uint32_t out_h,
                       int32_t* const out[], size_t out_stride) {

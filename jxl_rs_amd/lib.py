@@ -39,7 +39,8 @@ ABI_SYMBOLS = [
     "jxlh_stage_noise_convolve", "jxlh_stage_noise_add", "jxlh_timer_start", "jxlh_timer_stop",
     "jxlh_kernel_timing_enable", "jxlh_kernel_timing_get", "jxlh_kernel_timing_reset", "jxlh_selftest_recip",
     "jxlh_stage_gaborish",
-    "jxlh_stage_epf", "jxlh_stage_lf_smooth", "jxlh_stage_transform_to_pixels", "jxlh_rct", "jxlh_palette", "jxlh_palette_delta",
+    "jxlh_stage_epf", "jxlh_stage_lf_smooth", "jxlh_stage_transform_to_pixels", "jxlh_rct", "jxlh_palette", "jxlh_palette_delta", "jxlh_modular_to_rgb8",
+    "jxlh_modular_to_f32", "jxlh_modular_xyb_to_f32",
     "jxlh_unsqueeze", "jxlh_unsqueeze_planes", "jxlh_abi_version", "jxlh_covered_blocks_x", "jxlh_covered_blocks_y",
     "jxlh_quant_table_for_type", "jxlh_quant_table_size",
 ]
@@ -155,6 +156,9 @@ def load():
     L.jxlh_rct.argtypes = [vp, vp, vp, vp, sz, i32, i32]
     L.jxlh_palette.argtypes = [vp, vp, sz, vp, i32, sz, i32, i32, vp]
     L.jxlh_palette_delta.argtypes = [vp, vp, u32, u32, vp, i32, i32, sz, i32, i32, i32, vp]
+    L.jxlh_modular_to_rgb8.argtypes = [vp, C.POINTER(vp), sz, u32, u32, i32, i32, u32, vp, sz]
+    L.jxlh_modular_to_f32.argtypes = [vp, vp, sz, u32, vp]
+    L.jxlh_modular_xyb_to_f32.argtypes = [vp, vp, vp, vp, sz, vp, vp, vp, vp]
     L.jxlh_unsqueeze.argtypes = [vp, i32, vp, sz, vp, sz, u32, u32, vp, sz]
     L.jxlh_unsqueeze_planes.argtypes = [vp, i32, i32, C.POINTER(vp), sz, C.POINTER(vp), sz, u32, u32, C.POINTER(vp), sz]
     L.jxlh_abi_version.restype = u32
@@ -534,6 +538,29 @@ class Context:
         out = np.zeros((nb_channels,) + idx.shape, dtype=np.int32)
         self._chk(self.L.jxlh_palette(self._ctx, _addr(idx), idx.size, _addr(pal), num_colors, pal.shape[1],
                                       nb_channels, bit_depth, _addr(out)), "palette")
+        return out
+
+    def modular_to_rgb8(self, planes, multiplier, maxv, channels=3):
+        pl = [np.ascontiguousarray(a, dtype=np.int32) for a in planes]
+        h, w = pl[0].shape
+        out = np.zeros((h, w, channels), dtype=np.uint8)
+        ptrs = (C.c_void_p * 3)(*[a.ctypes.data for a in pl])
+        self._chk(self.L.jxlh_modular_to_rgb8(self._ctx, ptrs, w, w, h, multiplier, maxv, channels, _addr(out), w * channels),
+                  "modular_to_rgb8")
+        return out
+
+    def modular_to_f32(self, plane, bits):
+        a = np.ascontiguousarray(plane, dtype=np.int32)
+        out = np.zeros(a.shape, dtype=np.float32)
+        self._chk(self.L.jxlh_modular_to_f32(self._ctx, _addr(a), a.size, bits, _addr(out)), "modular_to_f32")
+        return out
+
+    def modular_xyb_to_f32(self, y, x, b, quant_factors):
+        y, x, b = [np.ascontiguousarray(v, dtype=np.int32) for v in (y, x, b)]
+        q = np.ascontiguousarray(quant_factors, dtype=np.float32)
+        out = [np.zeros(y.shape, dtype=np.float32) for _ in range(3)]
+        self._chk(self.L.jxlh_modular_xyb_to_f32(self._ctx, _addr(y), _addr(x), _addr(b), y.size, _addr(q),
+                                                 *[_addr(o) for o in out]), "modular_xyb_to_f32")
         return out
 
     def palette_delta(self, index, palette, num_colors, num_deltas, bit_depth, predictor):

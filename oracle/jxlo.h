@@ -242,6 +242,11 @@ void jxlo_palette(const int32_t* index, size_t n, const int32_t* palette, int nu
  * (modular/predict.rs:16-31), anything but 6 (Weighted) */
 void jxlo_palette_delta(const int32_t* index, int w, int h, const int32_t* palette, int num_colors, int num_deltas,
                         size_t palette_stride, int nb_channels, int bit_depth, int predictor, int32_t* out);
+/* Modular channels -> pipeline samples (render/stages/convert.rs:278-343, :488-533, :642-715) */
+void jxlo_i32_to_u8(const int32_t* in, size_t n, int32_t multiplier, int32_t max, uint8_t* out);
+void jxlo_modular_to_f32(const int32_t* in, size_t n, int bits, float* out);
+void jxlo_modular_xyb_to_f32(const int32_t* y, const int32_t* x, const int32_t* b, size_t n, const float scale[3],
+                             float* ox, float* oy, float* ob);
 int32_t jxlo_palette_value(const int32_t* palette, size_t palette_stride, int64_t index, int c,
                            int palette_size, int bit_depth);
 /* squeeze.rs:143-194,389-481,576-682 whole-plane (no neighbour tiles) */

@@ -266,3 +266,29 @@ void jxlo_unsqueeze_v(const int32_t* avg, size_t avg_stride, const int32_t* res,
   }
   if (has_tail) memcpy(out + (size_t)(2 * h) * out_stride, avg + (size_t)h * avg_stride, sizeof(int32_t) * w);
 }
+
+/* ---- the stages between Modular channels and the rest of the pipeline (render/stages/convert.rs) ---- */
+/* ConvertI32ToU8Stage (:642-715; the builder's replacement for ModularToF32 + F32ToU8 when the output depth is a
+ * multiple of the channel's, render/builder.rs:152-170): wrapping multiply, clamp to [0, max], low byte */
+void jxlo_i32_to_u8(const int32_t* in, size_t n, int32_t multiplier, int32_t max, uint8_t* out) {
+  for (size_t i = 0; i < n; i++) {
+    const int32_t scaled = (int32_t)((uint32_t)in[i] * (uint32_t)multiplier);
+    const int32_t zeroclip = scaled < 0 ? 0 : scaled;
+    const int32_t clip = scaled > max ? max : zeroclip;
+    out[i] = (uint8_t)clip;
+  }
+}
+/* ConvertModularToF32Stage, integer samples (:488-533): val * (1 / (2^bits - 1)) */
+void jxlo_modular_to_f32(const int32_t* in, size_t n, int bits, float* out) {
+  const float scale = 1.0f / (float)((1ull << bits) - 1);
+  for (size_t i = 0; i < n; i++) out[i] = (float)in[i] * scale;
+}
+/* ConvertModularXYBToF32Stage (:306-343): channels arrive as Y, X, B; B carries B - Y */
+void jxlo_modular_xyb_to_f32(const int32_t* y, const int32_t* x, const int32_t* b, size_t n, const float scale[3],
+                             float* ox, float* oy, float* ob) {
+  for (size_t i = 0; i < n; i++) {
+    ox[i] = (float)x[i] * scale[0];
+    oy[i] = (float)y[i] * scale[1];
+    ob[i] = ((float)b[i] + (float)y[i]) * scale[2];
+  }
+}

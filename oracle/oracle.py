@@ -144,6 +144,9 @@ class Oracle:
         L.jxlo_rct.argtypes = [ip, ip, ip, C.c_size_t, C.c_int, C.c_int]
         L.jxlo_palette.argtypes = [ip, C.c_size_t, ip, C.c_int, C.c_size_t, C.c_int, C.c_int, ip]
         L.jxlo_palette_delta.argtypes = [ip, C.c_int, C.c_int, ip, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_int, ip]
+        L.jxlo_i32_to_u8.argtypes = [ip, C.c_size_t, C.c_int32, C.c_int32, C.POINTER(C.c_uint8)]
+        L.jxlo_modular_to_f32.argtypes = [ip, C.c_size_t, C.c_int, fp]
+        L.jxlo_modular_xyb_to_f32.argtypes = [ip, ip, ip, C.c_size_t, fp, fp, fp, fp]
         L.jxlo_unsqueeze_h.argtypes = [ip, C.c_size_t, ip, C.c_size_t, C.c_int, C.c_int, ip, C.c_size_t]
         L.jxlo_unsqueeze_v.argtypes = [ip, C.c_size_t, ip, C.c_size_t, C.c_int, C.c_int, ip, C.c_size_t]
         L.jxlo_smooth_tendency.argtypes = [C.c_int64] * 3
@@ -537,6 +540,26 @@ class Oracle:
         self.lib.jxlo_palette_delta(_ptr(index, C.c_int32), w, h, _ptr(palette, C.c_int32), num_colors, num_deltas,
                                     palette.shape[1], nb, bit_depth, predictor, _ptr(out, C.c_int32))
         return out
+
+    def i32_to_u8(self, plane, multiplier, maxv):
+        a = np.ascontiguousarray(plane, dtype=np.int32)
+        out = np.zeros(a.shape, dtype=np.uint8)
+        self.lib.jxlo_i32_to_u8(_ptr(a, C.c_int32), a.size, multiplier, maxv, _ptr(out, C.c_uint8))
+        return out
+
+    def modular_to_f32(self, plane, bits):
+        a = np.ascontiguousarray(plane, dtype=np.int32)
+        out = np.zeros(a.shape, dtype=np.float32)
+        self.lib.jxlo_modular_to_f32(_ptr(a, C.c_int32), a.size, bits, _ptr(out, C.c_float))
+        return out
+
+    def modular_xyb_to_f32(self, y, x, b, scale):
+        y, x, b = [np.ascontiguousarray(v, dtype=np.int32) for v in (y, x, b)]
+        sc = np.ascontiguousarray(scale, dtype=np.float32)
+        out = [np.zeros(y.shape, dtype=np.float32) for _ in range(3)]
+        self.lib.jxlo_modular_xyb_to_f32(_ptr(y, C.c_int32), _ptr(x, C.c_int32), _ptr(b, C.c_int32), y.size,
+                                         _ptr(sc, C.c_float), *[_ptr(o, C.c_float) for o in out])
+        return out  # X, Y, B
 
     def rct(self, planes, op, perm):
         ps = [np.ascontiguousarray(a, dtype=np.int32).copy() for a in planes]

@@ -550,6 +550,28 @@ def test_delta_palette_bit_exact(ctx, oracle, predictor):
         assert np.array_equal(ctx.palette_delta(idx, pal, 16, 0, 8, 0), ctx.palette(idx, pal, 16, 3, 8))
 
 
+@pytest.mark.parametrize("shape", [(1, 1), (37, 53), (300, 258)])
+def test_modular_output_bridges_bit_exact(ctx, oracle, shape):
+    """ConvertI32ToU8 (interleaved), ConvertModularToF32 and ConvertModularXYBToF32 (render/stages/convert.rs)"""
+    rng = np.random.default_rng(shape[0] * 7 + shape[1])
+    planes = [rng.integers(-40, 300, size=shape).astype(np.int32) for _ in range(3)]
+    planes[0].flat[0] = 2**31 - 1   # the multiply wraps like the reference's i32 lanes
+    for bits, channels in ((8, 3), (4, 4), (2, 3), (1, 4)):
+        mult, maxv = 255 // ((1 << bits) - 1), 255
+        got = ctx.modular_to_rgb8(planes, mult, maxv, channels)
+        for c in range(3):
+            assert np.array_equal(got[..., c], oracle.i32_to_u8(planes[c], mult, maxv)), (bits, c)
+        if channels == 4:
+            assert (got[..., 3] == 255).all()
+    for bits in (1, 8, 12, 16, 24, 32):
+        assert bit_equal(ctx.modular_to_f32(planes[1], bits), oracle.modular_to_f32(planes[1], bits)), bits
+    q = np.float32([1.0 / 4096, 1.0 / 512, 1.0 / 256])
+    got = ctx.modular_xyb_to_f32(planes[0], planes[1], planes[2], q)
+    want = oracle.modular_xyb_to_f32(planes[0], planes[1], planes[2], q)
+    for c in range(3):
+        assert bit_equal(got[c], want[c]), c
+
+
 def test_delta_palette_weighted_predictor_is_unsupported(ctx):
     from jxl_rs_amd import lib, JxlHipError
     with pytest.raises(JxlHipError) as e:
