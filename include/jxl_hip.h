@@ -321,6 +321,9 @@ typedef struct jxlh_output_desc {
 } jxlh_output_desc;
 jxlh_status jxlh_frame_read_output(jxlh_ctx* ctx, const jxlh_output_desc* d, uint32_t y0, uint32_t y1, void* out,
                                    size_t bytes_per_row);
+/* without the final wait, like jxlh_frame_read_rgb8_async: `out` is valid after the next jxlh_ctx_sync */
+jxlh_status jxlh_frame_read_output_async(jxlh_ctx* ctx, const jxlh_output_desc* d, uint32_t y0, uint32_t y1, void* out,
+                                         size_t bytes_per_row);
 
 /* ---------------------------------------------------------------- stage-level hooks */
 /* Whole-image single stages with the pipeline's mirror edge semantics; the analogue of

@@ -1160,7 +1160,7 @@ jxlh_status read_rgb8(jxlh_ctx* ctx, int mode, const jxlh_xyb_params* p, const T
 }
 
 jxlh_status read_rgb16(jxlh_ctx* ctx, int mode, const jxlh_xyb_params* p, const TfParamsDev& tf, uint32_t channels,
-                       uint32_t y0, uint32_t y1, void* out, size_t bytes_per_row) {
+                       uint32_t y0, uint32_t y1, void* out, size_t bytes_per_row, bool wait = true) {
   if (!ctx || !out || (channels != 3 && channels != 4)) return JXLH_ERR_INVALID_ARGUMENT;
   if (!ctx->in_frame || !ctx->result[0]) return JXLH_ERR_BAD_STATE;
   if (y1 > (uint32_t)ctx->res_h) y1 = (uint32_t)ctx->res_h;
@@ -1189,7 +1189,7 @@ jxlh_status read_rgb16(jxlh_ctx* ctx, int mode, const jxlh_xyb_params* p, const 
     if (dev) return JXLH_OK;
     if (jxlh_status st = copy2d(ctx, out, bytes_per_row, ctx->rgb8.p, row_bytes, row_bytes, (size_t)rows, ctx->stream))
       return st;
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (wait) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return JXLH_OK;
   }
   if (is_device_ptr(out)) {
@@ -1208,7 +1208,7 @@ jxlh_status read_rgb16(jxlh_ctx* ctx, int mode, const jxlh_xyb_params* p, const 
   HIPCHK(ctx, hipGetLastError());
   if (jxlh_status st = copy2d(ctx, out, bytes_per_row, ctx->rgb8.p, row_bytes, row_bytes, (size_t)rows, ctx->stream))
     return st;
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (wait) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return JXLH_OK;
 }
 }  // namespace
@@ -1237,8 +1237,9 @@ jxlh_status jxlh_frame_read_ycbcr_rgb16(jxlh_ctx* ctx, uint32_t channels, uint32
   return read_rgb16(ctx, kModeYcbcr, nullptr, TfParamsDev{}, channels, y0, y1, out, bytes_per_row);
 }
 
-jxlh_status jxlh_frame_read_output(jxlh_ctx* ctx, const jxlh_output_desc* d, uint32_t y0, uint32_t y1, void* out,
-                                   size_t bytes_per_row) {
+namespace {
+jxlh_status read_output(jxlh_ctx* ctx, const jxlh_output_desc* d, uint32_t y0, uint32_t y1, void* out,
+                        size_t bytes_per_row, bool wait) {
   if (!ctx || !d || (d->bits != 8 && d->bits != 16)) return JXLH_ERR_INVALID_ARGUMENT;
   int mode;
   switch (d->color) {
@@ -1254,8 +1255,18 @@ jxlh_status jxlh_frame_read_output(jxlh_ctx* ctx, const jxlh_output_desc* d, uin
   t.param = d->tf_param;
   for (int i = 0; i < 3; i++) t.lum[i] = d->hlg_luminance_rgb[i];
   const jxlh_xyb_params* xp = d->color == JXLH_COLOR_XYB ? &d->xyb : nullptr;
-  return d->bits == 8 ? read_rgb8(ctx, mode, xp, t, d->channels, y0, y1, out, bytes_per_row)
-                      : read_rgb16(ctx, mode, xp, t, d->channels, y0, y1, out, bytes_per_row);
+  return d->bits == 8 ? read_rgb8(ctx, mode, xp, t, d->channels, y0, y1, out, bytes_per_row, wait)
+                      : read_rgb16(ctx, mode, xp, t, d->channels, y0, y1, out, bytes_per_row, wait);
+}
+}  // namespace
+
+jxlh_status jxlh_frame_read_output(jxlh_ctx* ctx, const jxlh_output_desc* d, uint32_t y0, uint32_t y1, void* out,
+                                   size_t bytes_per_row) {
+  return read_output(ctx, d, y0, y1, out, bytes_per_row, /*wait=*/true);
+}
+jxlh_status jxlh_frame_read_output_async(jxlh_ctx* ctx, const jxlh_output_desc* d, uint32_t y0, uint32_t y1, void* out,
+                                         size_t bytes_per_row) {
+  return read_output(ctx, d, y0, y1, out, bytes_per_row, /*wait=*/false);
 }
 
 jxlh_status jxlh_frame_read_planes(jxlh_ctx* ctx, const jxlh_plane out[3]) {

@@ -35,7 +35,7 @@ ABI_SYMBOLS = [
     "jxlh_frame_set_lf_quantized", "jxlh_frame_set_lf", "jxlh_frame_set_hf_meta", "jxlh_submit_group",
     "jxlh_submit_group_sparse", "jxlh_submit_groups_sparse", "jxlh_submit_groups_sparse8", "jxlh_slot_wait", "jxlh_frame_coeff_buffer", "jxlh_frame_run", "jxlh_ctx_sync", "jxlh_frame_read_planes",
     "jxlh_frame_device_planes", "jxlh_frame_read_lf", "jxlh_frame_read_rgb8", "jxlh_frame_read_rgb8_async", "jxlh_frame_read_rgb16",
-    "jxlh_frame_read_ycbcr_rgb8", "jxlh_frame_read_ycbcr_rgb16", "jxlh_frame_read_output", "jxlh_stage_chroma_upsample", "jxlh_stage_upsample", "jxlh_set_upsampling_weights", "jxlh_stage_noise_generate",
+    "jxlh_frame_read_ycbcr_rgb8", "jxlh_frame_read_ycbcr_rgb16", "jxlh_frame_read_output", "jxlh_frame_read_output_async", "jxlh_stage_chroma_upsample", "jxlh_stage_upsample", "jxlh_set_upsampling_weights", "jxlh_stage_noise_generate",
     "jxlh_stage_noise_convolve", "jxlh_stage_noise_add", "jxlh_timer_start", "jxlh_timer_stop",
     "jxlh_kernel_timing_enable", "jxlh_kernel_timing_get", "jxlh_kernel_timing_reset", "jxlh_selftest_recip",
     "jxlh_stage_gaborish",
@@ -120,6 +120,7 @@ def load():
     L.jxlh_frame_read_rgb16.argtypes = [vp, vp, u32, u32, u32, vp, sz]
     L.jxlh_frame_read_rgb8_async.argtypes = [vp, vp, u32, u32, u32, vp, sz]
     L.jxlh_frame_read_output.argtypes = [vp, C.POINTER(OutputDesc), u32, u32, vp, sz]
+    L.jxlh_frame_read_output_async.argtypes = [vp, C.POINTER(OutputDesc), u32, u32, vp, sz]
     L.jxlh_frame_read_ycbcr_rgb8.argtypes = [vp, u32, u32, u32, vp, sz]
     L.jxlh_frame_read_ycbcr_rgb16.argtypes = [vp, u32, u32, u32, vp, sz]
     L.jxlh_stage_chroma_upsample.argtypes = [vp, vp, vp, u32, u32, i32]

@@ -946,6 +946,18 @@ def test_rgb8_async_read_equals_blocking_read(ctx, oracle, kat):
              "frame_read_rgb8_async")
     ctx.sync()
     assert np.array_equal(pinned[:w * h * 3].reshape(h, w, 3), want)
+    # the general descriptor form, 16-bit PQ
+    from jxl_rs_amd import lib
+    want16 = ctx.read_output(lib.COLOR_XYB, "pq", params, 4000.0, bits=16, channels=3)
+    d = lib.OutputDesc()
+    d.color, d.transfer, d.bits, d.channels, d.tf_param = lib.COLOR_XYB, lib.TF["pq"], 16, 3, 4000.0
+    for i, v in enumerate(np.asarray(params, dtype=np.float32).ravel()):
+        d.xyb[i] = float(v)
+    pinned16, addr16 = ctx.alloc_pinned(w * h * 3 * 2)
+    ctx._chk(ctx.L.jxlh_frame_read_output_async(ctx._ctx, C.byref(d), 0, h, C.c_void_p(addr16), w * 3 * 2),
+             "frame_read_output_async")
+    ctx.sync()
+    assert np.array_equal(pinned16[:w * h * 6].view(np.uint16).reshape(h, w, 3), want16)
 
 
 def test_rgb8_output_argument_errors(ctx, oracle, kat):
