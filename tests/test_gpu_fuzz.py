@@ -226,3 +226,41 @@ def test_random_feature_combinations_bit_exact(ctx, oracle, kat, seed):
     want = oracle.xyb_to_rgb_tf(xp, tf, [np.ascontiguousarray(q) for q in base], ow, oh, channels, bits, param, lum)
     out = ctx.read_output(lib.COLOR_XYB, tf, xp, param, lum, bits, channels, y0, y1)
     assert np.array_equal(out, want[y0:y1]), f"output {tf}/{bits}/{channels} {desc}"
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_modular_ops_bit_exact(ctx, oracle, seed):
+    """RCT (every op and permutation), Palette (explicit, implicit and delta entries), delta Palette with a random
+    predictor, one unsqueeze step in each direction and the Modular -> RGB8 bridge on random shapes and values"""
+    rng = np.random.default_rng(7000 + seed)
+    h, w = int(rng.integers(1, 200)), int(rng.integers(1, 300))
+    lim = int(rng.choice([256, 4096, 1 << 20]))
+    planes = [rng.integers(-lim, lim, size=(h, w)).astype(np.int32) for _ in range(3)]
+    op, perm = int(rng.integers(0, 7)), int(rng.integers(0, 6))
+    got, want = ctx.rct(planes, op, perm), oracle.rct(planes, op, perm)
+    for c in range(3):
+        assert np.array_equal(got[c], want[c]), f"rct op={op} perm={perm} {h}x{w}"
+    nb, bit_depth = int(rng.integers(1, 5)), int(rng.choice([8, 10, 16]))
+    ncol = int(rng.integers(1, 300))
+    pal = rng.integers(-50, 1 << bit_depth, size=(nb, ncol)).astype(np.int32)
+    idx = rng.integers(-80, ncol + 200, size=(h, w)).astype(np.int32)
+    assert np.array_equal(ctx.palette(idx, pal, ncol, nb, bit_depth), oracle.palette(idx, pal, ncol, nb, bit_depth)), "palette"
+    nd = int(rng.integers(0, min(ncol, 9)))
+    pred = int(rng.choice([0, 1, 2, 3, 4, 5, 7, 8, 9, 10, 11, 12, 13]))
+    idx2 = idx.copy()
+    idx2[rng.random((h, w)) < 0.4] = rng.integers(0, nd + 2)
+    assert np.array_equal(ctx.palette_delta(idx2, pal, ncol - nd, nd, bit_depth, pred),
+                          oracle.palette_delta(idx2, pal, ncol - nd, nd, bit_depth, pred)), f"delta palette pred={pred} nd={nd}"
+    if w >= 2:
+        avg = rng.integers(-lim, lim, size=(h, (w + 1) // 2)).astype(np.int32)
+        res = rng.integers(-lim // 4 - 1, lim // 4 + 1, size=(h, w // 2)).astype(np.int32)
+        assert np.array_equal(ctx.unsqueeze(True, avg, res, w, h), oracle.unsqueeze_h(avg, res, w)), "unsqueeze h"
+    if h >= 2:
+        avg = rng.integers(-lim, lim, size=((h + 1) // 2, w)).astype(np.int32)
+        res = rng.integers(-lim // 4 - 1, lim // 4 + 1, size=(h // 2, w)).astype(np.int32)
+        assert np.array_equal(ctx.unsqueeze(False, avg, res, w, h), oracle.unsqueeze_v(avg, res, h)), "unsqueeze v"
+    bits = int(rng.choice([1, 2, 4, 8]))
+    mult = 255 // ((1 << bits) - 1)
+    rgb = ctx.modular_to_rgb8(planes, mult, 255, 3)
+    for c in range(3):
+        assert np.array_equal(rgb[..., c], oracle.i32_to_u8(planes[c], mult, 255))
