@@ -43,8 +43,11 @@ enum {
   JXLH_ERR_BAD_STATE = -4,        /* call order violated (e.g. submit before frame_begin) */
   JXLH_ERR_INVALID_TRANSFORM = -5,/* transform_map holds an id >= 27 (Error::InvalidVarDCTTransform) */
   JXLH_ERR_UNSUPPORTED = -6,      /* valid stream feature outside the device path (caller falls back) */
-  JXLH_ERR_INVALID_BLOCK_SIZE = -7 /* a varblock larger than 8x8 in a chroma-subsampled frame
+  JXLH_ERR_INVALID_BLOCK_SIZE = -7, /* a varblock larger than 8x8 in a chroma-subsampled frame
                                       (Error::InvalidBlockSizeForChromaSubsampling, frame/modular/mod.rs:1058-1060) */
+  JXLH_ERR_BLOCK_OUT_OF_BOUNDS = -8 /* a varblock crosses its group's or the frame's edge, or the first-block flags of
+                                       a group cover more than its 1024 blocks (Error::HFBlockOutOfBounds,
+                                       frame/modular/mod.rs:1061-1064); the offending varblocks are not reconstructed */
 };
 
 typedef struct jxlh_ctx jxlh_ctx;

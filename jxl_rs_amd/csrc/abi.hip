@@ -93,6 +93,9 @@ struct jxlh_ctx {
   size_t sp_used = 0;
   hipEvent_t sp_expanded = nullptr;
   bool sp_expanded_valid = false;
+  // recorded behind the transforms of every jxlh_frame_run: dense resubmissions wait for it
+  hipEvent_t k1_done = nullptr;
+  bool k1_done_valid = false;
   // K1 reading the pairs directly: the frame's pairs bucketed by varblock slot + slot tables.  Valid
   // while every group of the frame has been submitted sparse (once) and nothing was resubmitted.
   DevBuf<uint32_t> sp_sorted, sp_slot_start;
@@ -220,6 +223,7 @@ const char* jxlh_status_string(jxlh_status s) {
     case JXLH_ERR_INVALID_TRANSFORM: return "invalid VarDCT transform id";
     case JXLH_ERR_UNSUPPORTED: return "unsupported on the device path";
     case JXLH_ERR_INVALID_BLOCK_SIZE: return "varblock larger than 8x8 in a chroma-subsampled frame";
+    case JXLH_ERR_BLOCK_OUT_OF_BOUNDS: return "varblock crosses its group or the frame edge";
     default: return "unknown status";
   }
 }
@@ -319,6 +323,7 @@ void jxlh_ctx_destroy(jxlh_ctx* ctx) {
   release(ctx->sp_slot_start);
   release(ctx->group_dense);
   if (ctx->sp_expanded) (void)hipEventDestroy(ctx->sp_expanded);
+  if (ctx->k1_done) (void)hipEventDestroy(ctx->k1_done);
   release(ctx->raw_quant);
   release(ctx->lfq);
   release(ctx->transform_map);
@@ -427,6 +432,11 @@ jxlh_status jxlh_frame_begin(jxlh_ctx* ctx, const jxlh_frame_params* p) {
   if ((st = ensure(ctx, ctx->error_flag, 1)) != JXLH_OK) return st;
   if ((st = ensure(ctx, ctx->worklist, vardct_worklist_bytes(f))) != JXLH_OK) return st;
   HIPCHK(ctx, hipMemsetAsync(ctx->error_flag.p, 0, sizeof(int), ctx->stream));
+  // rects the caller never sets read as "not the first block of a varblock" (no work item, no stale map bytes of
+  // an earlier frame reaching K1)
+  HIPCHK(ctx, hipMemsetAsync(ctx->transform_map.p, 0, nblocks, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(ctx->raw_quant.p, 0, nblocks * sizeof(int32_t), ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(ctx->epf_map.p, 0, nblocks, ctx->stream));
   for (int c = 0; c < 3; c++) {
     f.planes[c] = ctx->planes[c].p;
     f.tmp[c] = ctx->tmp[c].p;
@@ -510,6 +520,8 @@ jxlh_status jxlh_frame_set_dequant_tables(jxlh_ctx* ctx, const float* const tabl
   }
   ctx->fd.tables = ctx->tables.p;
   ctx->tables_set = true;
+  // like the other setters: the caller's buffers may be reused (or freed) as soon as the call returns
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return JXLH_OK;
 }
 
@@ -611,10 +623,20 @@ jxlh_status jxlh_submit_group(jxlh_ctx* ctx, int32_t slot, uint32_t group_id, co
   Slot& s = ctx->slots[slot];
   {
     std::lock_guard<std::mutex> lock(ctx->sp_mutex);
+    if (ctx->touched[group_id] == 2) {
+      // submitted as pairs earlier in this epoch: the dense slab replaces that submission
+      for (size_t i = 0; i < ctx->sp_pending.size();) {
+        if (ctx->sp_pending[i].group == group_id) ctx->sp_pending.erase(ctx->sp_pending.begin() + i);
+        else i++;
+      }
+    }
     ctx->touched[group_id] = 1;
     ctx->epoch_dirty = true;
   }
   int32_t* dst = ctx->coeffs.p + (size_t)group_id * 3 * kGroupArea;
+  // the previous jxlh_frame_run's transforms may still be reading the slab (callers that use the *_async reads
+  // do not wait between frames)
+  if (ctx->k1_done_valid) HIPCHK(ctx, hipStreamWaitEvent(s.stream, ctx->k1_done, 0));
   if (dst != coeffs) {
     HIPCHK(ctx, hipMemcpyAsync(dst, coeffs, (size_t)3 * kGroupArea * sizeof(int32_t), hipMemcpyDefault, s.stream));
   }
@@ -646,8 +668,11 @@ jxlh_status sparse_reserve(jxlh_ctx* ctx, int32_t slot, uint32_t count, const ui
   if (jxlh_status st = ensure(ctx, ctx->sp_pairs, capacity)) return st;
   if (!ctx->sp_expanded) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->sp_expanded, hipEventDisableTiming));
   if (ctx->sp_used + total > capacity) return JXLH_ERR_INVALID_ARGUMENT;  // more pairs than coefficients
-  for (uint32_t i = 0; i < count; i++)  // one sparse submission per group between two runs (its list may
+  for (uint32_t i = 0; i < count; i++) {  // one sparse submission per group between two runs (its list may
     if (ctx->touched[group_ids[i]] == 2) return JXLH_ERR_BAD_STATE;  // hold several passes' updates)
+    for (uint32_t k = 0; k < i; k++)  // ... and not twice inside this batch either
+      if (group_ids[k] == group_ids[i]) return JXLH_ERR_BAD_STATE;
+  }
   const size_t offset = ctx->sp_used;
   ctx->sp_used += total;
   size_t o = offset;
@@ -944,6 +969,10 @@ jxlh_status jxlh_frame_run(jxlh_ctx* ctx, uint32_t group_row0, uint32_t group_ro
     launch_vardct_groups(ctx->stream, fk, gr0, gr1, ctx->worklist.p, ctx->error_flag.p,
                          sparse_k1 ? ctx->coeffs.p : nullptr);
   }
+  // the coefficient slabs are free again: dense resubmissions of the next frame wait for this (jxlh_submit_group)
+  if (!ctx->k1_done) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->k1_done, hipEventDisableTiming));
+  HIPCHK(ctx, hipEventRecord(ctx->k1_done, ctx->stream));
+  ctx->k1_done_valid = true;
   ctx->chroma_lazy = false;
   if (f.subsampled) {
     // ... and brought to full resolution into planes[c] before any filter (frame/render.rs:569-576) -- or, when no

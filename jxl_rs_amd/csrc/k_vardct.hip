@@ -108,6 +108,12 @@ __global__ __launch_bounds__(kThreads) void k1_scan(const FrameDev f, const Work
         sz = covered_x(type) * covered_y(type);
         // Error::InvalidBlockSizeForChromaSubsampling (frame/modular/mod.rs:1058-1060)
         if (f.subsampled && sz > 1) atomicExch(error_flag, JXLH_ERR_INVALID_BLOCK_SIZE);
+        // Error::HFBlockOutOfBounds (frame/modular/mod.rs:1061-1064): the varblock must end inside its group
+        // and inside the frame.  Such an item is dropped: its pixel stores would leave the plane.
+        if (bx + covered_x(type) > bw || by + covered_y(type) > bh) {
+          atomicExch(error_flag, JXLH_ERR_BLOCK_OUT_OF_BOUNDS);
+          sz = 0;
+        }
       } else {
         atomicExch(error_flag, JXLH_ERR_INVALID_TRANSFORM);  // Error::InvalidVarDCTTransform
       }
@@ -125,9 +131,21 @@ __global__ __launch_bounds__(kThreads) void k1_scan(const FrameDev f, const Work
   if (lane == 63) s_wave_sum[wave] = incl;
   __syncthreads();
   int off64 = incl - local;
+  int group_total = 0;
 #pragma unroll
-  for (int w = 0; w < kWaves; w++)
+  for (int w = 0; w < kWaves; w++) {
     if (w < wave) off64 += s_wave_sum[w];
+    group_total += s_wave_sum[w];
+  }
+  // first-block flags that claim more blocks than the group holds (overlapping varblocks; the reference cannot
+  // produce such a map, a caller-built one can): the 10-bit coefficient offset of the work items would overflow,
+  // K1 would read past the group's slab and the class lists (sized by area) could overflow.  Nothing of such a
+  // group is reconstructed.
+  if (group_total > bw * bh) {
+    if (tid == 0) atomicExch(error_flag, JXLH_ERR_BLOCK_OUT_OF_BOUNDS);
+#pragma unroll
+    for (int i = 0; i < 4; i++) sizes[i] = 0;
+  }
   // per-class rank of every varblock in raster order (stable: neighbouring blocks stay
   // neighbours in the lists -> contiguous coefficient reads, full-line pixel writes)
   int slot[4];

@@ -25,6 +25,7 @@ ERR_BAD_STATE = -4
 ERR_INVALID_TRANSFORM = -5
 ERR_UNSUPPORTED = -6
 ERR_INVALID_BLOCK_SIZE = -7
+ERR_BLOCK_OUT_OF_BOUNDS = -8
 FRAME_UNFUSED_FILTERS = 1
 GROUP_COMPLETE = 1
 

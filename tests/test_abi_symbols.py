@@ -99,9 +99,10 @@ def test_header_is_plain_c_and_links_from_c(tmp_path):
     assert out.startswith("abi ")
 
 
-def test_chroma_subsampled_frames_are_declined():
-    """4:2:0 / 4:2:2 frames (JPEG recompression) are outside the device path: frame_begin must say so
-    (the caller keeps the CPU pipeline) rather than mis-decode.  No GPU work is reached before the check."""
+def test_frame_begin_validates_before_touching_the_device():
+    """Chroma-subsampled frames (hshift / vshift in {0, 1}) are part of the device path (K1e); what frame_begin
+    rejects without a context is the call itself.  The shift-range check needs a context: tests/test_gpu_parity.py
+    ::test_subsampled_frame_rejects_large_varblocks."""
     from jxl_rs_amd import lib
     L = lib.load()
     p = lib.FrameParams()
@@ -109,5 +110,18 @@ def test_chroma_subsampled_frames_are_declined():
     assert list(p.hshift) == [0, 0, 0] and list(p.vshift) == [0, 0, 0]
     p.hshift[0] = 1
     p.vshift[2] = 1
-    # (the JXLH_ERR_UNSUPPORTED answer itself needs a context: tests/test_gpu_parity.py)
     assert L.jxlh_frame_begin(None, C.byref(p)) == lib.ERR_INVALID_ARGUMENT
+
+
+def test_generated_constant_tables_have_one_content():
+    """oracle/tools/extract_reference_constants.py writes every .inc twice (oracle/ for the checker, csrc/ for the
+    device library): the two copies must never drift apart, or parity tests compare different constants."""
+    a, b = os.path.join(ROOT, "oracle"), os.path.join(ROOT, "jxl_rs_amd", "csrc")
+    names = sorted(f for f in os.listdir(a) if f.endswith(".inc"))
+    assert names, "no generated tables found"
+    for f in names:
+        assert open(os.path.join(a, f), "rb").read() == open(os.path.join(b, f), "rb").read(), f
+    # and the device library's Makefile rebuilds when one of them changes
+    mk = open(os.path.join(b, "Makefile")).read()
+    for f in sorted(x for x in os.listdir(b) if x.endswith(".inc")):
+        assert f in mk, f"{f} missing from HDRS in csrc/Makefile"

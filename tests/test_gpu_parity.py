@@ -255,6 +255,74 @@ def test_subsampled_frame_rejects_large_varblocks(ctx):
     assert e.value.status == lib.ERR_INVALID_ARGUMENT
 
 
+def test_varblock_out_of_bounds_is_reported(ctx):
+    """Error::HFBlockOutOfBounds (frame/modular/mod.rs:1061-1064): a first-block flag whose varblock would cross
+    the frame / group edge is reported and not reconstructed (no out-of-plane stores)."""
+    from jxl_rs_amd import synth, lib, JxlHipError
+    wl = synth.make_vardct(300, 260, mix=synth.MIX_DCT8, seed=5, epf_iters=0, gab=False)
+    # a DCT32x32 (type 5) whose top-left block is the last block of the first group row/column: crosses the group edge
+    bad = wl.transform_map.copy()
+    bad[31, 31] = 128 | 5
+    upload_frame(ctx, wl)
+    ctx.set_hf_meta(bad, wl.raw_quant, wl.epf_map, wl.ytox, wl.ytob)
+    ctx.frame_run()
+    with pytest.raises(JxlHipError) as e:
+        ctx.sync()
+    assert e.value.status == lib.ERR_BLOCK_OUT_OF_BOUNDS
+    # crossing the frame's right edge (300 px = 38 blocks; block column 37 is the last)
+    bad = wl.transform_map.copy()
+    bad[2, 37] = 128 | 6  # DCT16X8: covered_x = 1, covered_y = 2 -> fine; 7 = DCT8X16: covered_x = 2 -> out
+    bad[3, 37] = 6
+    upload_frame(ctx, wl)
+    ctx.set_hf_meta(bad, wl.raw_quant, wl.epf_map, wl.ytox, wl.ytob)
+    ctx.frame_run()
+    ctx.sync()  # legal
+    bad[2, 37] = 128 | 7
+    bad[3, 37] = 128 | 0
+    upload_frame(ctx, wl)
+    ctx.set_hf_meta(bad, wl.raw_quant, wl.epf_map, wl.ytox, wl.ytob)
+    ctx.frame_run()
+    with pytest.raises(JxlHipError) as e:
+        ctx.sync()
+    assert e.value.status == lib.ERR_BLOCK_OUT_OF_BOUNDS
+    # a group whose first-block flags claim more than its 1024 blocks (overlapping 32x32 varblocks everywhere)
+    bad = wl.transform_map.copy()
+    bad[:28, :28] = 128 | 5
+    upload_frame(ctx, wl)
+    ctx.set_hf_meta(bad, wl.raw_quant, wl.epf_map, wl.ytox, wl.ytob)
+    ctx.frame_run()
+    with pytest.raises(JxlHipError) as e:
+        ctx.sync()
+    assert e.value.status == lib.ERR_BLOCK_OUT_OF_BOUNDS
+    # the context is still usable
+    got, _ = run_gpu_frame(ctx, wl)
+    assert np.isfinite(got[1]).all()
+
+
+def test_unset_map_rects_read_as_empty(ctx, oracle):
+    """jxlh_frame_begin clears the HfMetadata maps: a rect the caller never sets holds no varblocks, whatever an
+    earlier (larger) frame left in the buffers."""
+    from jxl_rs_amd import synth
+    big = synth.make_vardct(600, 520, mix=synth.MIX_ALL, seed=9, epf_iters=0, gab=False)
+    run_gpu_frame(ctx, big)
+    wl = synth.make_vardct(300, 260, mix=synth.MIX_D1, seed=4, epf_iters=0, gab=False, lf_smoothing=False)
+    p = gpu_params_from(ctx, wl)
+    ctx.frame_begin(p)
+    ctx.set_dequant_tables(wl.tables)
+    ctx.set_lf_quantized(*wl.lf_q)
+    # only the first group row's maps arrive
+    ctx.set_hf_meta(wl.transform_map[:32], wl.raw_quant[:32], wl.epf_map[:32], wl.ytox[:4], wl.ytob[:4])
+    for g in range(wl.coeffs.shape[0]):
+        ctx.submit_group(g, wl.coeffs[g])
+    ctx.slot_wait(0)
+    ctx.frame_run()
+    ctx.sync()  # no error: the second group row simply holds no work
+    got = ctx.read_planes()
+    want, _ = run_oracle_frame(oracle, wl)
+    for c in range(3):
+        assert bit_equal(got[c][:256], want[c][:256]), f"plane {c}"
+
+
 @pytest.mark.parametrize("shape", [(1, 3), (3, 1), (1, 1), (37, 53), (256, 300), (5, 1024)])
 def test_chroma_upsample_stage_bit_exact(ctx, oracle, kat, shape):
     """HorizontalChromaUpsample / VerticalChromaUpsample hooks vs the oracle (and the reference's own vectors)"""
