@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define JXLH_ABI_VERSION 3
+#define JXLH_ABI_VERSION 4
 #define JXLH_NUM_TRANSFORMS 27   /* HfTransformType::CARDINALITY, transform_map.rs:59-61 */
 #define JXLH_NUM_QUANT_TABLES 17 /* NUM_QUANT_TABLES, quantizer.rs:11 */
 #define JXLH_GROUP_DIM 256       /* GROUP_DIM, jxl/src/lib.rs:24-26 */
@@ -261,6 +261,10 @@ jxlh_status jxlh_kernel_timing_enable(jxlh_ctx* ctx, int32_t enable);
 jxlh_status jxlh_kernel_timing_get(jxlh_ctx* ctx, int32_t i, const char** name, float* total_ms,
                                    int32_t* launches);
 jxlh_status jxlh_kernel_timing_reset(jxlh_ctx* ctx);
+/* Device-to-device copy ceiling, measured: a float4 copy of `bytes` (src and dst buffers allocated for the call)
+ * repeated `reps` times on the context's stream; *gb_per_s = (bytes read + bytes written) / time.  The yardstick
+ * SURVEY.md 8(d) asks for next to the 8 TB/s spec peak. */
+jxlh_status jxlh_probe_copy_bandwidth(jxlh_ctx* ctx, size_t bytes, int32_t reps, float* gb_per_s);
 
 /* ---------------------------------------------------------------- 8-bit sRGB output
  * The stages the reference runs after EPF for an XYB-encoded frame saved as 8-bit sRGB -- XybStage
@@ -410,6 +414,39 @@ jxlh_status jxlh_unsqueeze_planes(jxlh_ctx* ctx, int32_t horizontal, int32_t n_p
                                   const int32_t* const avg[], size_t avg_stride, const int32_t* const res[],
                                   size_t res_stride, uint32_t out_w, uint32_t out_h, int32_t* const out[],
                                   size_t out_stride);
+
+/* ---------------------------------------------------------------- multi-GPU
+ * The reference renders a frame's groups on a pool of host threads and joins them in the pipeline's output buffers
+ * (frame/render.rs:395-479).  Here a frame is cut into contiguous bands of group rows, one per GPU ("rank"):
+ * rank r owns group rows [r * per, min((r + 1) * per, ygroups)), per = ceil(ygroups / nranks).  Each rank gets the
+ * replicated small inputs (LF, HfMetadata maps, dequant tables) and the coefficient groups of ITS band, runs the
+ * transforms on exactly that band, exchanges the one block row (8 pixel rows x 3 channels, 0.8 MB at 8K) its filters
+ * read across each band edge with the neighbour rank, filters its band, and the finished bands are all-gathered so
+ * that every rank holds the whole frame.  Frames with upsampling run whole (JXLH_ERR_UNSUPPORTED here); chroma-
+ * subsampled frames recompute the halo group row instead of exchanging it.
+ *
+ * One process per GPU (torch.distributed.run, mpirun, ...): the library owns an RCCL communicator.
+ *   rank 0: jxlh_comm_unique_id(id); the launcher broadcasts the 128 bytes; every rank: jxlh_comm_init(ctx, id, rank, n)
+ *   BEFORE its first jxlh_frame_begin (which sizes the planes for the in-place gather).  Per frame, every rank calls
+ *   jxlh_frame_run_sharded then jxlh_frame_allgather (collectives: all ranks, same order); both only enqueue work on
+ *   the context's stream (ncclSend/ncclRecv of the edge rows, ncclAllGather per plane).
+ * One process driving several GPUs (or several contexts on one GPU): jxlh_comm_init_local(peers, n) makes peers[i]
+ *   rank i, jxlh_frames_run_sharded_local / jxlh_frames_allgather_local drive all of them with direct device copies. */
+#define JXLH_COMM_ID_BYTES 128
+jxlh_status jxlh_comm_unique_id(uint8_t id[JXLH_COMM_ID_BYTES]);
+jxlh_status jxlh_comm_init(jxlh_ctx* ctx, const uint8_t id[JXLH_COMM_ID_BYTES], int32_t rank, int32_t nranks);
+jxlh_status jxlh_comm_init_local(jxlh_ctx* const peers[], int32_t nranks);
+jxlh_status jxlh_comm_destroy(jxlh_ctx* ctx);
+/* rank / nranks of the context (0 / 1 without a communicator) and, inside a frame, the band of group rows it owns;
+ * any output pointer may be NULL */
+jxlh_status jxlh_comm_band(jxlh_ctx* ctx, int32_t* rank, int32_t* nranks, uint32_t* group_row0, uint32_t* group_row1);
+jxlh_status jxlh_frame_run_sharded(jxlh_ctx* ctx);
+jxlh_status jxlh_frame_allgather(jxlh_ctx* ctx);
+jxlh_status jxlh_frames_run_sharded_local(jxlh_ctx* const peers[], int32_t nranks);
+jxlh_status jxlh_frames_allgather_local(jxlh_ctx* const peers[], int32_t nranks);
+/* In-place all-gather of a device buffer of nranks * bytes_per_rank bytes (rank r's part at r * bytes_per_rank), on the
+ * context's stream: the join of band-sharded Modular work (RCT / Palette on row bands of whole planes). */
+jxlh_status jxlh_comm_allgather(jxlh_ctx* ctx, void* buf, size_t bytes_per_rank);
 
 /* library info */
 uint32_t jxlh_abi_version(void);

@@ -6,204 +6,7 @@
 // set_lf* / set_hf_meta; decode_hf_global -> set_dequant_tables; decode_hf_group ->
 // submit_group (async H2D on the caller's slot stream, overlapping the host's entropy decode
 // of the next group); finalize_lf + render -> frame_run.
-#include <hip/hip_runtime.h>
-
-#include <cmath>
-#include <cstdio>
-#include <cstring>
-#include <mutex>
-#include <new>
-#include <string>
-#include <vector>
-
-#include "jxlh_internal.h"
-
-using namespace jxlh;
-
-namespace {
-
-struct Slot {
-  hipStream_t stream = nullptr;
-  hipEvent_t done = nullptr;
-  bool used = false;
-  uint8_t* stage8 = nullptr;  // device staging of the 3-byte sparse form (positions | values), grown on demand
-  size_t stage8_cap = 0;
-};
-
-struct KernelTime {
-  std::string name;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
-  float total_ms = 0.f;
-  int launches = 0;
-};
-
-template <class T>
-struct DevBuf {
-  T* p = nullptr;
-  size_t n = 0;  // elements
-};
-
-}  // namespace
-
-struct jxlh_ctx {
-  int device = 0;
-  hipStream_t stream = nullptr;
-  std::vector<Slot> slots;
-  hipEvent_t t0 = nullptr, t1 = nullptr;
-  std::string last_error;
-  // frame state
-  bool in_frame = false;
-  bool tables_set = false, lf_smoothed = false;
-  jxlh_frame_params params;
-  FrameDev fd;
-  size_t ngroups = 0;
-  DevBuf<float> planes[3], tmp[3], lf_raw[3], lf_sm[3], sigma, tables;
-  int table_offset[JXLH_NUM_QUANT_TABLES] = {0};
-  DevBuf<int32_t> coeffs, raw_quant, lfq;
-  DevBuf<uint8_t> transform_map, epf_map;
-  DevBuf<int8_t> ytox, ytob;
-  DevBuf<int> error_flag;
-  DevBuf<uint8_t> rgb8;  // jxlh_frame_read_rgb8 staging for host destinations
-  int* host_flag = nullptr;  // pinned
-  DevBuf<uint8_t> worklist;
-  float* result[3] = {nullptr, nullptr, nullptr};
-  // geometry of `result`: the frame itself, or its upsampled image (frame_header.upsampling > 1)
-  int res_w = 0, res_h = 0;
-  size_t res_stride = 0;
-  // chroma-subsampled frame with nothing between the transforms and the output: the upsampling into planes[] is
-  // deferred until somebody asks for the planes (the YCbCr output calls read the sub-sampled channels directly)
-  bool chroma_lazy = false;
-  int lazy_gr0 = 0, lazy_gr1 = 0;
-  DevBuf<float> noise[3];      // random planes of the noise synthesis
-  DevBuf<uint64_t> xs_jump;    // xorshift128+ jump matrices T^(2^j), uploaded on first use
-  DevBuf<float> ups[3];        // upsampled planes
-  DevBuf<float> ups_kernels;   // expanded 5x5 kernels of the frame's factor
-  std::vector<float> ups_weights[3];  // custom weights2 / weights4 / weights8 (empty = defaults)
-  // stage hooks scratch
-  DevBuf<float> hook_f[8];
-  DevBuf<int32_t> hook_i[4];
-  // sparse coefficient transport (jxlh_submit_group(s)_sparse): pairs land in sp_pairs (bump
-  // allocated, sized for a frame's worst case), are expanded by the next jxlh_frame_run
-  std::mutex sp_mutex;
-  DevBuf<uint32_t> sp_pairs;
-  DevBuf<SparseGroup> sp_groups_dev;
-  DevBuf<uint2> sp_wide_dev;
-  std::vector<SparseGroup> sp_pending, sp_upload;
-  std::vector<uint2> sp_wide, sp_wide_upload;
-  size_t sp_used = 0;
-  hipEvent_t sp_expanded = nullptr;
-  bool sp_expanded_valid = false;
-  // recorded behind the transforms of every jxlh_frame_run: dense resubmissions wait for it
-  hipEvent_t k1_done = nullptr;
-  bool k1_done_valid = false;
-  // K1 reading the pairs directly: the frame's pairs bucketed by varblock slot + slot tables.  Valid
-  // while every group of the frame has been submitted sparse (once) and nothing was resubmitted.
-  DevBuf<uint32_t> sp_sorted, sp_slot_start;
-  DevBuf<uint8_t> group_dense;
-  // Epochs: the submissions between two jxlh_frame_run calls.  touched[g]: 0 not resubmitted (keeps its
-  // content), 1 dense slab, 2 pairs.  sp_sorted_valid: before this epoch every group's content lived in
-  // the bucketed form (and only there).
-  std::vector<uint8_t> touched, flag_upload;
-  bool epoch_dirty = false;
-  bool sp_sorted_valid = false;
-  // profiling
-  bool timing = false;
-  std::vector<KernelTime> ktimes;
-};
-
-namespace {
-
-jxlh_status fail(jxlh_ctx* ctx, hipError_t e, const char* what) {
-  if (ctx) {
-    ctx->last_error = std::string(what) + ": " + hipGetErrorString(e);
-  }
-  (void)hipGetLastError();  // clear the sticky per-thread error so later checks start clean
-  return e == hipErrorOutOfMemory ? JXLH_ERR_OUT_OF_MEMORY : JXLH_ERR_DEVICE;
-}
-
-#define HIPCHK(ctx, expr)                               \
-  do {                                                  \
-    hipError_t e_ = (expr);                             \
-    if (e_ != hipSuccess) return fail(ctx, e_, #expr);  \
-  } while (0)
-
-template <class T>
-jxlh_status ensure(jxlh_ctx* ctx, DevBuf<T>& b, size_t n) {
-  if (b.n >= n && b.p) return JXLH_OK;
-  if (b.p) {
-    HIPCHK(ctx, hipFree(b.p));
-    b.p = nullptr;
-    b.n = 0;
-  }
-  if (n == 0) return JXLH_OK;
-  HIPCHK(ctx, hipMalloc(reinterpret_cast<void**>(&b.p), n * sizeof(T)));
-  b.n = n;
-  return JXLH_OK;
-}
-
-template <class T>
-void release(DevBuf<T>& b) {
-  if (b.p) (void)hipFree(b.p);
-  b.p = nullptr;
-  b.n = 0;
-}
-
-struct ScopedKernelTimer {
-  jxlh_ctx* ctx;
-  hipEvent_t a = nullptr, b = nullptr;
-  KernelTime* kt = nullptr;
-  ScopedKernelTimer(jxlh_ctx* c, const char* name) : ctx(c) {
-    if (!ctx->timing) return;
-    for (auto& k : ctx->ktimes)
-      if (k.name == name) kt = &k;
-    if (!kt) {
-      ctx->ktimes.push_back(KernelTime{name, {}, 0.f, 0});
-      kt = &ctx->ktimes.back();
-    }
-    (void)hipEventCreate(&a);
-    (void)hipEventCreate(&b);
-    (void)hipEventRecord(a, ctx->stream);
-  }
-  ~ScopedKernelTimer() {
-    if (!kt) return;
-    (void)hipEventRecord(b, ctx->stream);
-    kt->pending.emplace_back(a, b);
-  }
-};
-
-void drain_timers(jxlh_ctx* ctx) {
-  for (auto& k : ctx->ktimes) {
-    for (auto& pr : k.pending) {
-      (void)hipEventSynchronize(pr.second);
-      float ms = 0.f;
-      if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
-        k.total_ms += ms;
-        k.launches += 1;
-      }
-      (void)hipEventDestroy(pr.first);
-      (void)hipEventDestroy(pr.second);
-    }
-    k.pending.clear();
-  }
-}
-
-size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
-
-// plane -> device 2-D copy helper (pointers may be host or device)
-bool is_device_ptr(const void* p);  // defined with the stage hooks below
-
-jxlh_status copy2d(jxlh_ctx* ctx, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width_bytes,
-                   size_t height, hipStream_t s) {
-  if (width_bytes == 0 || height == 0) return JXLH_OK;
-  if (dpitch == width_bytes && spitch == width_bytes) {  // contiguous on both sides: one linear copy
-    HIPCHK(ctx, hipMemcpyAsync(dst, src, width_bytes * height, hipMemcpyDefault, s));
-    return JXLH_OK;
-  }
-  HIPCHK(ctx, hipMemcpy2DAsync(dst, dpitch, src, spitch, width_bytes, height, hipMemcpyDefault, s));
-  return JXLH_OK;
-}
-
-}  // namespace
+#include "jxlh_ctx.h"
 
 extern "C" {
 
@@ -324,6 +127,7 @@ void jxlh_ctx_destroy(jxlh_ctx* ctx) {
   release(ctx->group_dense);
   if (ctx->sp_expanded) (void)hipEventDestroy(ctx->sp_expanded);
   if (ctx->k1_done) (void)hipEventDestroy(ctx->k1_done);
+  comm_release(ctx);
   release(ctx->raw_quant);
   release(ctx->lfq);
   release(ctx->transform_map);
@@ -398,6 +202,8 @@ jxlh_status jxlh_frame_begin(jxlh_ctx* ctx, const jxlh_frame_params* p) {
   f.cmap_stride = (f.xblocks + 7) / 8;
   f.plane_stride = round_up((size_t)f.xblocks * 8, 64);
   const size_t plane_elems = f.plane_stride * (size_t)f.yblocks * 8;
+  // a sharded frame is all-gathered in place with equal counts per rank: room for nranks whole bands
+  const size_t gather_elems = (size_t)comm_nranks(ctx) * comm_rows_per_rank(ctx, f.ygroups) * kGroupDim * f.plane_stride;
   // K1 uses 32-bit pixel and coefficient offsets
   // planes are addressed with 32-bit BYTE offsets in the filter kernels, coefficients with 32-bit indices
   if (plane_elems >= (1ull << 30) || (size_t)f.xgroups * f.ygroups * 3 * kGroupArea >= (1ull << 31))
@@ -416,9 +222,9 @@ jxlh_status jxlh_frame_begin(jxlh_ctx* ctx, const jxlh_frame_params* p) {
   const size_t ncmap = (size_t)f.cmap_stride * ((f.yblocks + 7) / 8);
   jxlh_status st;
   for (int c = 0; c < 3; c++) {
-    if ((st = ensure(ctx, ctx->planes[c], plane_elems)) != JXLH_OK) return st;
+    if ((st = ensure(ctx, ctx->planes[c], std::max(plane_elems, gather_elems))) != JXLH_OK) return st;
     // + one block row: the scrap tile K1 stores the blocks a sub-sampled channel does not hold into
-    if ((st = ensure(ctx, ctx->tmp[c], plane_elems + 8 * f.plane_stride)) != JXLH_OK) return st;
+    if ((st = ensure(ctx, ctx->tmp[c], std::max(plane_elems + 8 * f.plane_stride, gather_elems))) != JXLH_OK) return st;
     if ((st = ensure(ctx, ctx->lf_raw[c], nblocks)) != JXLH_OK) return st;
     if ((st = ensure(ctx, ctx->lf_sm[c], nblocks)) != JXLH_OK) return st;
   }
@@ -850,13 +656,14 @@ jxlh_status upload_upsampling_kernels(jxlh_ctx* ctx, int n) {
 }
 }  // namespace
 
-jxlh_status jxlh_frame_run(jxlh_ctx* ctx, uint32_t group_row0, uint32_t group_row1) {
-  if (!ctx) return JXLH_ERR_INVALID_ARGUMENT;
-  if (!ctx->in_frame || !ctx->tables_set) return JXLH_ERR_BAD_STATE;
+}  // extern "C"
+
+namespace jxlh_host {
+
+// everything before K1: upload fences, sparse coefficient transport, K0b, K3 sigma
+jxlh_status run_prologue(jxlh_ctx* ctx, RunPlan* plan) {
   FrameDev& f = ctx->fd;
   const jxlh_frame_params& p = ctx->params;
-  if (group_row1 > (uint32_t)f.ygroups) group_row1 = (uint32_t)f.ygroups;
-  if (group_row0 >= group_row1) return JXLH_ERR_INVALID_ARGUMENT;
   // coefficient uploads issued on slot streams must land before K1
   for (auto& s : ctx->slots) {
     if (s.used) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, s.done, 0));
@@ -924,6 +731,7 @@ jxlh_status jxlh_frame_run(jxlh_ctx* ctx, uint32_t group_row0, uint32_t group_ro
     }
     sparse_k1 = ctx->sp_sorted_valid;
   }
+  plan->sparse_k1 = sparse_k1;
   // ---- K0b: Frame::finalize_lf (frame/mod.rs:360-378)
   const bool smooth = p.do_lf_smoothing && f.xblocks > 2 && f.yblocks > 2;  // adaptive_lf_smoothing.rs:51-53
   if (smooth) {
@@ -946,16 +754,18 @@ jxlh_status jxlh_frame_run(jxlh_ctx* ctx, uint32_t group_row0, uint32_t group_ro
     ScopedKernelTimer t(ctx, "k3_sigma_map");
     launch_sigma_map(ctx->stream, f, p.epf_quant_mul, p.epf_sharp_lut);
   }
-  // ---- K1 on the band plus one halo group row on each side (filters read across it)
-  const int halo_px = (f.gab ? 1 : 0) + (f.epf_iters >= 3 ? 3 : 0) + (f.epf_iters >= 1 ? 2 : 0) +
-                      (f.epf_iters >= 2 ? 1 : 0);
-  // (vertical chroma upsampling reads one sub-sampled row beyond the band as well)
-  const bool need_halo = halo_px > 0 || f.subsampled;
-  const int gr0 = need_halo && group_row0 > 0 ? (int)group_row0 - 1 : (int)group_row0;
-  const int gr1 = need_halo && group_row1 < (uint32_t)f.ygroups ? (int)group_row1 + 1 : (int)group_row1;
+  plan->halo_px = (f.gab ? 1 : 0) + (f.epf_iters >= 3 ? 3 : 0) + (f.epf_iters >= 1 ? 2 : 0) + (f.epf_iters >= 2 ? 1 : 0);
   // K1 writes the 8x8-tiled layout whenever the fused filter kernel is its only consumer
-  const bool will_fuse = !(p.flags & JXLH_FRAME_UNFUSED_FILTERS) && (f.gab || f.epf_iters > 0);
-  f.tiled = will_fuse ? 1 : 0;
+  plan->will_fuse = !(p.flags & JXLH_FRAME_UNFUSED_FILTERS) && (f.gab || f.epf_iters > 0);
+  f.tiled = plan->will_fuse ? 1 : 0;
+  return JXLH_OK;
+}
+
+// K1 for group rows [gr0, gr1) (+ the chroma upsampling of a sub-sampled frame)
+jxlh_status run_k1(jxlh_ctx* ctx, const RunPlan& plan, int gr0, int gr1) {
+  FrameDev& f = ctx->fd;
+  const jxlh_frame_params& p = ctx->params;
+  const bool sparse_k1 = plan.sparse_k1;
   {
     ScopedKernelTimer t(ctx, "k1_vardct");
     f.sp_sorted = sparse_k1 ? ctx->sp_sorted.p : nullptr;
@@ -983,6 +793,14 @@ jxlh_status jxlh_frame_run(jxlh_ctx* ctx, uint32_t group_row0, uint32_t group_ro
     if (stages_follow) run_chroma_upsample(ctx, gr0, gr1);
     else ctx->chroma_lazy = true;
   }
+  return JXLH_OK;
+}
+
+// the stage list on group rows [group_row0, group_row1), then upsampling and noise
+jxlh_status run_stages(jxlh_ctx* ctx, const RunPlan& plan, uint32_t group_row0, uint32_t group_row1) {
+  FrameDev& f = ctx->fd;
+  const jxlh_frame_params& p = ctx->params;
+  (void)plan;
   // ---- stage list of frame/render.rs:569-622
   const int y_lo = (int)group_row0 * kGroupDim;
   const int y_hi = min((int)group_row1 * kGroupDim, f.ysize);
@@ -1089,6 +907,26 @@ jxlh_status jxlh_frame_run(jxlh_ctx* ctx, uint32_t group_row0, uint32_t group_ro
   }
   HIPCHK(ctx, hipGetLastError());
   return JXLH_OK;
+}
+}  // namespace jxlh_host
+
+extern "C" {
+
+jxlh_status jxlh_frame_run(jxlh_ctx* ctx, uint32_t group_row0, uint32_t group_row1) {
+  if (!ctx) return JXLH_ERR_INVALID_ARGUMENT;
+  if (!ctx->in_frame || !ctx->tables_set) return JXLH_ERR_BAD_STATE;
+  FrameDev& f = ctx->fd;
+  if (group_row1 > (uint32_t)f.ygroups) group_row1 = (uint32_t)f.ygroups;
+  if (group_row0 >= group_row1) return JXLH_ERR_INVALID_ARGUMENT;
+  RunPlan plan;
+  if (jxlh_status st = run_prologue(ctx, &plan)) return st;
+  // ---- K1 on the band plus one halo group row on each side (filters read across it)
+  // (vertical chroma upsampling reads one sub-sampled row beyond the band as well)
+  const bool need_halo = plan.halo_px > 0 || f.subsampled;
+  const int gr0 = need_halo && group_row0 > 0 ? (int)group_row0 - 1 : (int)group_row0;
+  const int gr1 = need_halo && group_row1 < (uint32_t)f.ygroups ? (int)group_row1 + 1 : (int)group_row1;
+  if (jxlh_status st = run_k1(ctx, plan, gr0, gr1)) return st;
+  return run_stages(ctx, plan, group_row0, group_row1);
 }
 
 jxlh_status jxlh_ctx_sync(jxlh_ctx* ctx) {
@@ -1392,14 +1230,6 @@ jxlh_status stage_out(jxlh_ctx* ctx, T* dst, const T* src, size_t n) {
   HIPCHK(ctx, hipMemcpyAsync(dst, src, n * sizeof(T), hipMemcpyDefault, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return JXLH_OK;
-}
-bool is_device_ptr(const void* p) {
-  hipPointerAttribute_t attr;
-  if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
-    (void)hipGetLastError();
-    return false;
-  }
-  return attr.type == hipMemoryTypeDevice;
 }
 }  // namespace
 extern "C" {

@@ -1,0 +1,239 @@
+// Host-side state behind the C ABI: the context structure and the small helpers abi.hip and comm.hip share.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "jxlh_internal.h"
+
+using namespace jxlh;
+
+namespace jxlh_host {
+
+struct Slot {
+  hipStream_t stream = nullptr;
+  hipEvent_t done = nullptr;
+  bool used = false;
+  uint8_t* stage8 = nullptr;  // device staging of the 3-byte sparse form (positions | values), grown on demand
+  size_t stage8_cap = 0;
+};
+
+struct KernelTime {
+  std::string name;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+  float total_ms = 0.f;
+  int launches = 0;
+};
+
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;  // elements
+};
+
+}  // namespace jxlh_host
+using namespace jxlh_host;
+
+namespace jxlh_host {
+struct Comm;  // comm.hip
+}
+
+struct jxlh_ctx {
+  jxlh_host::Comm* comm = nullptr;  // multi-GPU: rank / transport of this context (null = single GPU)
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::vector<Slot> slots;
+  hipEvent_t t0 = nullptr, t1 = nullptr;
+  std::string last_error;
+  // frame state
+  bool in_frame = false;
+  bool tables_set = false, lf_smoothed = false;
+  jxlh_frame_params params;
+  FrameDev fd;
+  size_t ngroups = 0;
+  DevBuf<float> planes[3], tmp[3], lf_raw[3], lf_sm[3], sigma, tables;
+  int table_offset[JXLH_NUM_QUANT_TABLES] = {0};
+  DevBuf<int32_t> coeffs, raw_quant, lfq;
+  DevBuf<uint8_t> transform_map, epf_map;
+  DevBuf<int8_t> ytox, ytob;
+  DevBuf<int> error_flag;
+  DevBuf<uint8_t> rgb8;  // jxlh_frame_read_rgb8 staging for host destinations
+  int* host_flag = nullptr;  // pinned
+  DevBuf<uint8_t> worklist;
+  float* result[3] = {nullptr, nullptr, nullptr};
+  // geometry of `result`: the frame itself, or its upsampled image (frame_header.upsampling > 1)
+  int res_w = 0, res_h = 0;
+  size_t res_stride = 0;
+  // chroma-subsampled frame with nothing between the transforms and the output: the upsampling into planes[] is
+  // deferred until somebody asks for the planes (the YCbCr output calls read the sub-sampled channels directly)
+  bool chroma_lazy = false;
+  int lazy_gr0 = 0, lazy_gr1 = 0;
+  DevBuf<float> noise[3];      // random planes of the noise synthesis
+  DevBuf<uint64_t> xs_jump;    // xorshift128+ jump matrices T^(2^j), uploaded on first use
+  DevBuf<float> ups[3];        // upsampled planes
+  DevBuf<float> ups_kernels;   // expanded 5x5 kernels of the frame's factor
+  std::vector<float> ups_weights[3];  // custom weights2 / weights4 / weights8 (empty = defaults)
+  // stage hooks scratch
+  DevBuf<float> hook_f[8];
+  DevBuf<int32_t> hook_i[4];
+  // sparse coefficient transport (jxlh_submit_group(s)_sparse): pairs land in sp_pairs (bump
+  // allocated, sized for a frame's worst case), are expanded by the next jxlh_frame_run
+  std::mutex sp_mutex;
+  DevBuf<uint32_t> sp_pairs;
+  DevBuf<SparseGroup> sp_groups_dev;
+  DevBuf<uint2> sp_wide_dev;
+  std::vector<SparseGroup> sp_pending, sp_upload;
+  std::vector<uint2> sp_wide, sp_wide_upload;
+  size_t sp_used = 0;
+  hipEvent_t sp_expanded = nullptr;
+  bool sp_expanded_valid = false;
+  // recorded behind the transforms of every jxlh_frame_run: dense resubmissions wait for it
+  hipEvent_t k1_done = nullptr;
+  bool k1_done_valid = false;
+  // K1 reading the pairs directly: the frame's pairs bucketed by varblock slot + slot tables.  Valid
+  // while every group of the frame has been submitted sparse (once) and nothing was resubmitted.
+  DevBuf<uint32_t> sp_sorted, sp_slot_start;
+  DevBuf<uint8_t> group_dense;
+  // Epochs: the submissions between two jxlh_frame_run calls.  touched[g]: 0 not resubmitted (keeps its
+  // content), 1 dense slab, 2 pairs.  sp_sorted_valid: before this epoch every group's content lived in
+  // the bucketed form (and only there).
+  std::vector<uint8_t> touched, flag_upload;
+  bool epoch_dirty = false;
+  bool sp_sorted_valid = false;
+  // profiling
+  bool timing = false;
+  std::vector<KernelTime> ktimes;
+};
+
+namespace jxlh_host {
+
+inline jxlh_status fail(jxlh_ctx* ctx, hipError_t e, const char* what) {
+  if (ctx) {
+    ctx->last_error = std::string(what) + ": " + hipGetErrorString(e);
+  }
+  (void)hipGetLastError();  // clear the sticky per-thread error so later checks start clean
+  return e == hipErrorOutOfMemory ? JXLH_ERR_OUT_OF_MEMORY : JXLH_ERR_DEVICE;
+}
+
+#define HIPCHK(ctx, expr)                               \
+  do {                                                  \
+    hipError_t e_ = (expr);                             \
+    if (e_ != hipSuccess) return fail(ctx, e_, #expr);  \
+  } while (0)
+
+template <class T>
+jxlh_status ensure(jxlh_ctx* ctx, DevBuf<T>& b, size_t n) {
+  if (b.n >= n && b.p) return JXLH_OK;
+  if (b.p) {
+    HIPCHK(ctx, hipFree(b.p));
+    b.p = nullptr;
+    b.n = 0;
+  }
+  if (n == 0) return JXLH_OK;
+  HIPCHK(ctx, hipMalloc(reinterpret_cast<void**>(&b.p), n * sizeof(T)));
+  b.n = n;
+  return JXLH_OK;
+}
+
+template <class T>
+void release(DevBuf<T>& b) {
+  if (b.p) (void)hipFree(b.p);
+  b.p = nullptr;
+  b.n = 0;
+}
+
+struct ScopedKernelTimer {
+  jxlh_ctx* ctx;
+  hipEvent_t a = nullptr, b = nullptr;
+  KernelTime* kt = nullptr;
+  ScopedKernelTimer(jxlh_ctx* c, const char* name) : ctx(c) {
+    if (!ctx->timing) return;
+    for (auto& k : ctx->ktimes)
+      if (k.name == name) kt = &k;
+    if (!kt) {
+      ctx->ktimes.push_back(KernelTime{name, {}, 0.f, 0});
+      kt = &ctx->ktimes.back();
+    }
+    (void)hipEventCreate(&a);
+    (void)hipEventCreate(&b);
+    (void)hipEventRecord(a, ctx->stream);
+  }
+  ~ScopedKernelTimer() {
+    if (!kt) return;
+    (void)hipEventRecord(b, ctx->stream);
+    kt->pending.emplace_back(a, b);
+  }
+};
+
+inline void drain_timers(jxlh_ctx* ctx) {
+  for (auto& k : ctx->ktimes) {
+    for (auto& pr : k.pending) {
+      (void)hipEventSynchronize(pr.second);
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+        k.total_ms += ms;
+        k.launches += 1;
+      }
+      (void)hipEventDestroy(pr.first);
+      (void)hipEventDestroy(pr.second);
+    }
+    k.pending.clear();
+  }
+}
+
+inline size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
+
+// plane -> device 2-D copy helper (pointers may be host or device)
+inline bool is_device_ptr(const void* p) {
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return attr.type == hipMemoryTypeDevice;
+}
+
+inline jxlh_status copy2d(jxlh_ctx* ctx, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width_bytes,
+                   size_t height, hipStream_t s) {
+  if (width_bytes == 0 || height == 0) return JXLH_OK;
+  if (dpitch == width_bytes && spitch == width_bytes) {  // contiguous on both sides: one linear copy
+    HIPCHK(ctx, hipMemcpyAsync(dst, src, width_bytes * height, hipMemcpyDefault, s));
+    return JXLH_OK;
+  }
+  HIPCHK(ctx, hipMemcpy2DAsync(dst, dpitch, src, spitch, width_bytes, height, hipMemcpyDefault, s));
+  return JXLH_OK;
+}
+
+// jxlh_frame_run in three pieces (abi.hip), so that a sharded run (comm.hip) can put the halo exchange between the
+// transforms and the filters
+struct RunPlan {
+  bool sparse_k1 = false;
+  int halo_px = 0;       // rows the filters read beyond a band
+  bool will_fuse = false;
+};
+jxlh_status run_prologue(jxlh_ctx* ctx, RunPlan* plan);
+jxlh_status run_k1(jxlh_ctx* ctx, const RunPlan& plan, int gr0, int gr1);
+jxlh_status run_stages(jxlh_ctx* ctx, const RunPlan& plan, uint32_t group_row0, uint32_t group_row1);
+// Where run_stages leaves the finished planes (1 = f.tmp, 0 = f.planes): a property of the frame's stage list, so a
+// rank that filtered nothing (empty band) still knows where the gathered frame lives.
+inline int result_in_tmp(const jxlh_ctx* ctx) {
+  const FrameDev& f = ctx->fd;
+  const int ns = (f.gab ? 1 : 0) + (f.epf_iters >= 3 ? 1 : 0) + (f.epf_iters >= 1 ? 1 : 0) + (f.epf_iters >= 2 ? 1 : 0);
+  if (ns == 0) return 0;
+  if (!(ctx->params.flags & JXLH_FRAME_UNFUSED_FILTERS)) return f.epf_iters >= 3 ? 0 : 1;
+  return ns & 1;
+}
+// comm.hip
+void comm_release(jxlh_ctx* ctx);
+int comm_nranks(const jxlh_ctx* ctx);
+int comm_rows_per_rank(const jxlh_ctx* ctx, int ygroups);
+
+}  // namespace jxlh_host
+using namespace jxlh_host;

@@ -44,6 +44,9 @@ ABI_SYMBOLS = [
     "jxlh_modular_to_f32", "jxlh_modular_xyb_to_f32",
     "jxlh_unsqueeze", "jxlh_unsqueeze_planes", "jxlh_abi_version", "jxlh_covered_blocks_x", "jxlh_covered_blocks_y",
     "jxlh_quant_table_for_type", "jxlh_quant_table_size",
+    "jxlh_comm_unique_id", "jxlh_comm_init", "jxlh_comm_init_local", "jxlh_comm_destroy", "jxlh_comm_band",
+    "jxlh_frame_run_sharded", "jxlh_frame_allgather", "jxlh_frames_run_sharded_local", "jxlh_frames_allgather_local",
+    "jxlh_comm_allgather", "jxlh_probe_copy_bandwidth",
 ]
 
 
@@ -164,11 +167,55 @@ def load():
     L.jxlh_unsqueeze.argtypes = [vp, i32, vp, sz, vp, sz, u32, u32, vp, sz]
     L.jxlh_unsqueeze_planes.argtypes = [vp, i32, i32, C.POINTER(vp), sz, C.POINTER(vp), sz, u32, u32, C.POINTER(vp), sz]
     L.jxlh_abi_version.restype = u32
+    L.jxlh_comm_unique_id.argtypes = [vp]
+    L.jxlh_comm_init.argtypes = [vp, vp, i32, i32]
+    L.jxlh_comm_init_local.argtypes = [C.POINTER(vp), i32]
+    L.jxlh_comm_destroy.argtypes = [vp]
+    L.jxlh_comm_band.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(u32), C.POINTER(u32)]
+    L.jxlh_frame_run_sharded.argtypes = [vp]
+    L.jxlh_frame_allgather.argtypes = [vp]
+    L.jxlh_frames_run_sharded_local.argtypes = [C.POINTER(vp), i32]
+    L.jxlh_frames_allgather_local.argtypes = [C.POINTER(vp), i32]
+    L.jxlh_comm_allgather.argtypes = [vp, vp, sz]
+    L.jxlh_probe_copy_bandwidth.argtypes = [vp, sz, i32, fp]
     for name in ("jxlh_covered_blocks_x", "jxlh_covered_blocks_y", "jxlh_quant_table_for_type",
                  "jxlh_quant_table_size"):
         getattr(L, name).argtypes = [i32]
         getattr(L, name).restype = i32
     return L
+
+
+def comm_unique_id():
+    """128-byte RCCL id (rank 0 creates it, the launcher broadcasts it to every rank)"""
+    buf = (C.c_uint8 * 128)()
+    st = load().jxlh_comm_unique_id(buf)
+    if st != OK:
+        raise JxlHipError(st, "jxlh_comm_unique_id")
+    return bytes(buf)
+
+
+def _ctx_array(ctxs):
+    arr = (C.c_void_p * len(ctxs))(*[c._ctx for c in ctxs])
+    return arr
+
+
+def comm_init_local(ctxs):
+    """contexts of this process become ranks 0..n-1 of an in-process group (direct device copies)"""
+    st = ctxs[0].L.jxlh_comm_init_local(_ctx_array(ctxs), len(ctxs))
+    if st != OK:
+        raise JxlHipError(st, "jxlh_comm_init_local")
+
+
+def frames_run_sharded_local(ctxs):
+    st = ctxs[0].L.jxlh_frames_run_sharded_local(_ctx_array(ctxs), len(ctxs))
+    if st != OK:
+        raise JxlHipError(st, "jxlh_frames_run_sharded_local", ctxs[0].L.jxlh_last_error(ctxs[0]._ctx).decode())
+
+
+def frames_allgather_local(ctxs):
+    st = ctxs[0].L.jxlh_frames_allgather_local(_ctx_array(ctxs), len(ctxs))
+    if st != OK:
+        raise JxlHipError(st, "jxlh_frames_allgather_local", ctxs[0].L.jxlh_last_error(ctxs[0]._ctx).decode())
 
 
 def _addr(a):
@@ -321,6 +368,36 @@ class Context:
     def sync(self):
         self._chk(self.L.jxlh_ctx_sync(self._ctx), "ctx_sync")
         self._keep.clear()
+
+    def probe_copy_bandwidth(self, nbytes, reps=10):
+        """GB/s (read + written) of a float4 device-to-device copy of nbytes"""
+        v = C.c_float()
+        self._chk(self.L.jxlh_probe_copy_bandwidth(self._ctx, nbytes, reps, C.byref(v)), "probe_copy_bandwidth")
+        return v.value
+
+    # ---- multi-GPU (one process per GPU: RCCL communicator owned by the library)
+    def comm_init(self, unique_id, rank, nranks):
+        """unique_id: the 128 bytes rank 0 obtained from comm_unique_id() and the launcher distributed"""
+        buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
+        self._chk(self.L.jxlh_comm_init(self._ctx, buf, rank, nranks), "comm_init")
+
+    def comm_destroy(self):
+        self._chk(self.L.jxlh_comm_destroy(self._ctx), "comm_destroy")
+
+    def comm_band(self):
+        """(rank, nranks, group_row0, group_row1) of this context inside the current frame"""
+        r, n, a, b = C.c_int32(), C.c_int32(), C.c_uint32(), C.c_uint32()
+        self._chk(self.L.jxlh_comm_band(self._ctx, C.byref(r), C.byref(n), C.byref(a), C.byref(b)), "comm_band")
+        return r.value, n.value, a.value, b.value
+
+    def frame_run_sharded(self):
+        self._chk(self.L.jxlh_frame_run_sharded(self._ctx), "frame_run_sharded")
+
+    def frame_allgather(self):
+        self._chk(self.L.jxlh_frame_allgather(self._ctx), "frame_allgather")
+
+    def comm_allgather(self, dev_ptr, bytes_per_rank):
+        self._chk(self.L.jxlh_comm_allgather(self._ctx, _addr(dev_ptr), bytes_per_rank), "comm_allgather")
 
     @property
     def out_size(self):

@@ -1,0 +1,138 @@
+"""Multi-GPU band sharding through the C ABI on ONE GPU: the in-process transport (jxlh_comm_init_local) runs the
+same band logic as the RCCL transport -- transforms on the own band only, halo EXCHANGE of the edge block rows,
+filters, all-gather -- with several contexts standing in for the ranks.  Every rank's gathered frame must equal the
+oracle's whole frame bit for bit.  The RCCL transport itself is exercised with a one-rank communicator (what a
+single-GPU box can run); its N > 1 form runs in bench.py --gpus N."""
+import numpy as np
+import pytest
+
+from helpers import bit_equal, diff_report, gpu_params_from, run_oracle_frame
+
+pytestmark = pytest.mark.gpu
+
+
+def upload_band(ctx, wl, groups, **over):
+    """replicated small inputs + the coefficient groups in `groups` only"""
+    p = gpu_params_from(ctx, wl, **over)
+    ctx.frame_begin(p)
+    ctx.set_dequant_tables(wl.tables)
+    ctx.set_lf_quantized(*wl.lf_q)
+    ctx.set_hf_meta(wl.transform_map, wl.raw_quant, wl.epf_map, wl.ytox, wl.ytob)
+    poison = np.full(3 * 65536, 0x3FFF, dtype=np.int32)
+    for g in range(wl.coeffs.shape[0]):
+        ctx.submit_group(g, wl.coeffs[g] if g in groups else poison)
+    ctx.slot_wait(0)
+
+
+def band_groups(wl, rank, n, extra=0):
+    from jxl_rs_amd.shard import band_for_rank
+    r0, r1, _ = band_for_rank(wl.ygroups, rank, n)
+    if r0 >= r1:
+        return set()
+    r0, r1 = max(0, r0 - extra), min(wl.ygroups, r1 + extra)
+    return {gy * wl.xgroups + gx for gy in range(r0, r1) for gx in range(wl.xgroups)}
+
+
+@pytest.mark.parametrize("n", [2, 3, 6])
+@pytest.mark.parametrize("epf_iters,gab,flags", [(2, True, 0), (0, True, 0), (3, True, 0), (1, False, 0), (2, True, 1),
+                                                 (3, True, 1), (0, False, 0)])
+def test_local_sharded_frame_equals_whole(oracle, n, epf_iters, gab, flags):
+    import jxl_rs_amd
+    from jxl_rs_amd import lib, synth
+    wl = synth.make_vardct(520, 1000, mix=synth.MIX_ALL, seed=31 + n, epf_iters=epf_iters, gab=gab)
+    assert wl.ygroups == 4
+    want, _ = run_oracle_frame(oracle, wl)
+    ctxs = [jxl_rs_amd.Context(0, 1) for _ in range(n)]
+    try:
+        lib.comm_init_local(ctxs)
+        for r, c in enumerate(ctxs):
+            # the rank holds ONLY its band's coefficients (the other groups are poisoned): any recomputed halo
+            # group row would show
+            upload_band(c, wl, band_groups(wl, r, n), flags=flags)
+            assert c.comm_band()[:2] == (r, n)
+        for rep in range(2):  # a second run on the same contexts: events and buffers are reusable
+            lib.frames_run_sharded_local(ctxs)
+            lib.frames_allgather_local(ctxs)
+            for r, c in enumerate(ctxs):
+                c.sync()
+                got = c.read_planes()
+                for ch in range(3):
+                    assert bit_equal(got[ch], want[ch]), f"rank {r} plane {ch} rep {rep}: {diff_report(got[ch], want[ch])}"
+    finally:
+        for c in ctxs:
+            c.close()
+
+
+def test_local_sharded_subsampled_frame(oracle):
+    """chroma-subsampled frames keep the recomputed halo group row (their chroma upsampling reads across the band
+    edge): the rank then needs the neighbouring group rows' coefficients too"""
+    import jxl_rs_amd
+    from jxl_rs_amd import lib, synth
+    hs = vs = (1, 0, 1)
+    wl = synth.make_vardct(300, 700, mix=synth.MIX_8X8, seed=12, epf_iters=1, hshift=hs, vshift=vs)
+    want, _ = run_oracle_frame(oracle, wl)
+    ctxs = [jxl_rs_amd.Context(0, 1) for _ in range(2)]
+    try:
+        lib.comm_init_local(ctxs)
+        for r, c in enumerate(ctxs):
+            upload_band(c, wl, band_groups(wl, r, 2, extra=1))
+        lib.frames_run_sharded_local(ctxs)
+        lib.frames_allgather_local(ctxs)
+        for r, c in enumerate(ctxs):
+            c.sync()
+            got = c.read_planes()
+            for ch in range(3):
+                assert bit_equal(got[ch], want[ch]), f"rank {r} plane {ch}: {diff_report(got[ch], want[ch])}"
+    finally:
+        for c in ctxs:
+            c.close()
+
+
+def test_sharded_upsampled_frame_is_declined():
+    import jxl_rs_amd
+    from jxl_rs_amd import lib, synth, JxlHipError
+    wl = synth.make_vardct(300, 600, mix=synth.MIX_D1, seed=3, epf_iters=1)
+    ctxs = [jxl_rs_amd.Context(0, 1) for _ in range(2)]
+    try:
+        lib.comm_init_local(ctxs)
+        for c in ctxs:
+            upload_band(c, wl, set(range(wl.coeffs.shape[0])), upsampling=2)
+        with pytest.raises(JxlHipError) as e:
+            lib.frames_run_sharded_local(ctxs)
+        assert e.value.status == lib.ERR_UNSUPPORTED
+    finally:
+        for c in ctxs:
+            c.close()
+
+
+def test_rccl_transport_single_rank(oracle):
+    """the RCCL path with a one-rank communicator: librccl is found, the communicator comes up on the context's
+    device, the sharded run + in-place all-gather reproduce the whole frame"""
+    import jxl_rs_amd
+    from jxl_rs_amd import lib, synth, JxlHipError
+    wl = synth.make_vardct(520, 600, mix=synth.MIX_D1, seed=8, epf_iters=2)
+    want, _ = run_oracle_frame(oracle, wl)
+    c = jxl_rs_amd.Context(0, 1)
+    try:
+        uid = lib.comm_unique_id()
+        assert len(uid) == 128 and any(uid)
+        c.comm_init(uid, 0, 1)
+        with pytest.raises(JxlHipError):  # one communicator per context
+            c.comm_init(uid, 0, 1)
+        upload_band(c, wl, set(range(wl.coeffs.shape[0])))
+        assert c.comm_band() == (0, 1, 0, wl.ygroups)
+        c.frame_run_sharded()
+        c.frame_allgather()
+        c.sync()
+        got = c.read_planes()
+        for ch in range(3):
+            assert bit_equal(got[ch], want[ch]), f"plane {ch}: {diff_report(got[ch], want[ch])}"
+        # generic in-place gather of a device buffer (the join of band-sharded Modular work)
+        addr, n_i32 = c.coeff_buffer()
+        c.comm_allgather(addr, 4096)
+        c.sync()
+        c.comm_destroy()
+        c.frame_run()  # back to a plain single-GPU context
+        c.sync()
+    finally:
+        c.close()
