@@ -6,17 +6,21 @@ dequant+CfL+LLF+IDCT, Gaborish, EPF1, EPF2) over one synthetic 8192x8192 VarDCT 
 (BASELINE.json configs[2]) whose inputs -- 805 MB of i32 coefficients, the HfMetadata maps,
 the quantised LF, the dequant tables -- are resident in HBM before the timed region starts.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--size 8192] [--cpu-sample 2048]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--size 8192] [--cpu-sample 8192]
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): frames are independent units, so
-every rank reconstructs its own frame of the same shape with no data-path collective
-("weak" scaling; value = all ranks' pixels / max-over-ranks time).  --strong shards ONE
-frame by bands of group rows and all-gathers the finished planes over RCCL (the layout
-north_star describes); it is reported with "scaling": "strong".
+N > 1 (launched by torch.distributed.run, one rank per GPU) measures BOTH multi-GPU forms in one run:
+  * weak (the top-level `value`): frames are independent units, every rank reconstructs its own frame of the
+    same shape with no data-path collective; value = all ranks' pixels / max-over-ranks time;
+  * strong (`strong_scaling`): ONE frame cut into bands of group rows, one band per rank -- transforms on the
+    own band, halo exchange of the edge block rows (ncclSend/ncclRecv), filters, in-place ncclAllGather of
+    the finished planes so that every rank holds the whole frame (the layout north_star describes).  The
+    RCCL communicator is the library's own (jxlh_comm_init); torch.distributed only launches, broadcasts the
+    128-byte id, and does the barrier / max-over-ranks of the timing protocol.
 
-Rank 0 prints ONE JSON line: metric/value/... + "roofline" (dominant kernel, HIP-event
-timed on the kernels' own stream) + "cpu_baseline" (the CPU oracle, a C port of the
-reference, all host cores, on a bounded crop of the same workload).
+Rank 0 prints ONE JSON line: metric/value/... + "roofline" (every kernel of the chain with its own
+algorithmic bytes and fraction, HIP-event timed on the kernels' own stream; the chain against the
+fused-ideal numerator; the all-blocks-filtered EPF population next to the spec one; measured copy
+ceilings) + "cpu_baseline" (the CPU oracle, a C port of the reference, on the same frame size).
 """
 import argparse
 import json
@@ -28,6 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+FUSED_IDEAL_BYTES_PER_PX = 24.4  # compulsory traffic of the whole chain as ONE kernel
 # algorithmic (compulsory) HBM bytes per pixel of each kernel, SURVEY.md section 8(d) / DESIGN.md
 ALGO_BYTES_PER_PX = {
     "k1_vardct": 24.3,         # 12 B coeffs in + 12 B planes out + maps/LF (scan + class kernels)
@@ -43,9 +48,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=8192)
-    ap.add_argument("--cpu-sample", type=int, default=4096)
+    ap.add_argument("--cpu-sample", type=int, default=8192)
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--strong", action="store_true")
+    ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the sharded-frame (strong scaling) leg")
     ap.add_argument("--no-e2e", action="store_true",
                     help="skip the PCIe-inclusive legs (pinned host coefficients -> finished planes)")
     ap.add_argument("--seed", type=int, default=3)
@@ -92,8 +97,6 @@ def main():
         wl.epf_map[:] = 0
     ctxs = []
     h2d_s = 0.0
-    if args.strong and world > 1:
-        args.inflight = 1  # the band gather reads the planes of the context that just ran
     for _ in range(max(1, args.inflight)):
         c = jxl_rs_amd.Context(local_rank, n_slots=1)
         params = synth.apply_opts(c.default_params(size, size), wl)
@@ -111,80 +114,167 @@ def main():
     step_no = [0]
 
     ygroups = wl.ygroups
-    if args.strong and world > 1:
-        per = (ygroups + world - 1) // world
-        row0, row1 = min(rank * per, ygroups), min((rank + 1) * per, ygroups)
-    else:
-        row0, row1 = 0, ygroups
 
     def step():
-        ctxs[step_no[0] % len(ctxs)].frame_run(row0, row1)
+        ctxs[step_no[0] % len(ctxs)].frame_run(0, ygroups)
         step_no[0] += 1
 
     def sync_all():
         for c in ctxs:
             c.sync()
 
-    def gather():
-        if not (args.strong and world > 1):
-            return
-        # RCCL all-gather of the finished band (planes are device-resident; torch only wraps the
-        # pointers' contents via a staging tensor)
-        ptrs, stride = ctx.device_planes()
-        y0, y1 = row0 * 256, min(row1 * 256, size)
-        band = torch.empty((3, per * 256, size), dtype=torch.float32, device=f"cuda:{local_rank}")
-        full = torch.empty((world * 3, per * 256, size), dtype=torch.float32, device=f"cuda:{local_rank}")
-        import ctypes as C
-        hip = C.CDLL("libamdhip64.so")
-        for c in range(3):
-            hip.hipMemcpy2D(C.c_void_p(band[c].data_ptr()), C.c_size_t(size * 4),
-                            C.c_void_p(ptrs[c] + y0 * stride * 4), C.c_size_t(stride * 4),
-                            C.c_size_t(size * 4), C.c_size_t(y1 - y0), C.c_int(3))
-        dist.all_gather_into_tensor(full, band)
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
 
+    def max_over_ranks(seconds):
+        if dist is None:
+            return seconds
+        t = torch.tensor([seconds], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # ---- weak leg (N = 1: THE measurement): K steps of whole frames, one frame per rank
     for _ in range(args.warmup):
         step()
-        ctx.sync()
-        gather()
     sync_all()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize() if torch.cuda.is_available() else None
+    barrier()
     t_wall0 = time.perf_counter()
     ctx.timer_start()
     for _ in range(args.steps):
         step()
-        if args.strong and world > 1:
-            ctx.sync()
-            gather()
     ev_ms = ctx.timer_stop()
     sync_all()
-    torch.cuda.synchronize() if torch.cuda.is_available() else None
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
     wall_s = time.perf_counter() - t_wall0
-    if dist is not None:
-        dist.barrier()
-        t = torch.tensor([wall_s], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall_s = float(t.item())
+    barrier()
+    wall_s = max_over_ranks(wall_s)
     ms_per_step = wall_s * 1e3 / args.steps
-    px_per_step = size * size * (1 if (args.strong and world > 1) else n_gpus)
-    value = px_per_step / 1e6 / (ms_per_step / 1e3)
+    value = size * size * n_gpus / 1e6 / (ms_per_step / 1e3)
+
+    # ---- strong leg (N > 1): one frame sharded by bands of group rows, halo exchange + all-gather in the timed region
+    strong = None
+    if world > 1 and not args.no_strong:
+        from jxl_rs_amd import lib as jl
+        swl = wl if rank == 0 else synth.make_vardct(size, size, mix=mix, seed=args.seed, unique_groups=24,
+                                                     epf_iters=args.epf_iters, gab=True, lf_smoothing=True)
+        if args.epf == "active":
+            swl.epf_map[:] = 7
+            swl.raw_quant[:] = np.minimum(swl.raw_quant, 4)
+        elif args.epf == "passthrough":
+            swl.epf_map[:] = 0
+        box = [jl.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        sctx = jxl_rs_amd.Context(local_rank, n_slots=1)
+        sctx.comm_init(box[0], rank, world)          # before frame_begin: it sizes the planes for the gather
+        sctx.frame_begin(synth.apply_opts(sctx.default_params(size, size), swl))
+        sctx.set_dequant_tables(swl.tables)
+        sctx.set_lf_quantized(*swl.lf_q)            # LF / maps / tables are replicated (20 MB)
+        sctx.set_hf_meta(swl.transform_map, swl.raw_quant, swl.epf_map, swl.ytox, swl.ytob)
+        _, _, row0, row1 = sctx.comm_band()
+        for g in range(row0 * swl.xgroups, row1 * swl.xgroups):   # only the own band's coefficient groups
+            sctx.submit_group(g, swl.coeffs[g])
+        sctx.slot_wait(0)
+
+        def sstep():
+            sctx.frame_run_sharded()
+            sctx.frame_allgather()
+
+        for _ in range(max(1, args.warmup)):
+            sstep()
+        sctx.sync()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            sstep()
+        sctx.sync()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        s_wall = time.perf_counter() - t0
+        barrier()
+        s_wall = max_over_ranks(s_wall)
+        # without the gather: what the sharded compute alone costs (band K1 + exchange + filters)
+        for _ in range(2):
+            sctx.frame_run_sharded()
+        sctx.sync()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            sctx.frame_run_sharded()
+        sctx.sync()
+        c_wall = max_over_ranks(time.perf_counter() - t0)
+        barrier()
+        # every rank must hold the same, complete frame; rank 0 also holds the single-GPU result of this very frame
+        sstep()
+        sctx.sync()
+        got = sctx.read_planes()
+        digest = int(sum(int(np.sum(pl.view(np.uint32), dtype=np.uint64)) for pl in got) & 0x7FFFFFFFFFFFFFFF)
+        dd = torch.tensor([digest, -digest], dtype=torch.int64, device=f"cuda:{local_rank}")
+        dist.all_reduce(dd, op=dist.ReduceOp.MAX)
+        same_everywhere = int(dd[0].item()) == -int(dd[1].item())
+        matches_single = None
+        if rank == 0:
+            ctx.frame_run(0, ygroups)
+            ctx.sync()
+            ref = ctx.read_planes()
+            matches_single = all(np.array_equal(a.view(np.uint32), b.view(np.uint32)) for a, b in zip(got, ref))
+            del ref
+        del got
+        s_ms = s_wall * 1e3 / args.steps
+        strong = {"value": round(size * size / 1e6 / (s_ms / 1e3), 1), "unit": "MP/s", "ms_per_step": round(s_ms, 4),
+                  "scaling": "strong", "n_gpus": world,
+                  "ms_per_step_without_gather": round(c_wall * 1e3 / args.steps, 4),
+                  "allgather_MB_total": round(3 * size * size * 4 / 1e6, 1),
+                  "halo_exchange_KB_per_edge": round(3 * 8 * swl.xblocks * 8 * 4 / 1e3, 1),
+                  "band_group_rows_per_rank": (ygroups + world - 1) // world,
+                  "frame_identical_on_all_ranks": bool(same_everywhere),
+                  "frame_bit_equal_to_single_gpu_run": matches_single,
+                  "what": "ONE frame: per rank K1 on its band of group rows, ncclSend/ncclRecv of the edge block rows, "
+                          "fused filters on the band, in-place ncclAllGather of the 3 finished planes (library-owned "
+                          "RCCL communicator); every rank ends with the whole frame"}
+        sctx.comm_destroy()
+        sctx.close()
 
     # ---- per-kernel HIP-event timing (separate steps; not part of the timed region)
     roofline = None
-    kernels = {}
     if rank == 0:
-        ctx.kernel_timing_reset()
-        ctx.kernel_timing(True)
-        nprof = max(3, min(args.steps, 10))
-        for _ in range(nprof):
+        npx = size * size
+
+        def kernel_table():
+            ctx.kernel_timing_reset()
+            ctx.kernel_timing(True)
+            nprof = max(3, min(args.steps, 10))
+            for _ in range(nprof):
+                ctx.frame_run(0, ygroups)
+            ctx.sync()
+            kt = ctx.kernel_times()
+            ctx.kernel_timing(False)
+            out = {}
+            for name, (ms, n) in kt.items():
+                k = {"ms_per_step": round(ms / nprof, 4), "launches_per_step": n // nprof}
+                if name in ALGO_BYTES_PER_PX:  # each kernel against ITS OWN compulsory traffic
+                    ab = ALGO_BYTES_PER_PX[name] * npx
+                    k["algorithmic_bytes"] = int(ab)
+                    k["achieved_GBs"] = round(ab / (ms / nprof * 1e-3) / 1e9, 1)
+                    k["frac"] = round(k["achieved_GBs"] / HBM_PEAK_GBS, 4)
+                out[name] = k
+            return out
+
+        kernels = kernel_table()
+        # the population where EVERY 8x8 block is filtered (sharpness 7, raw_quant <= 4), same frame otherwise: the
+        # spec draws leave 93 % of the blocks below EPF's MIN_SIGMA (they pass through, like epf1.rs:72-78)
+        active = None
+        if args.epf == "spec" and args.epf_iters > 0:
+            ctx.set_hf_meta(wl.transform_map, np.minimum(wl.raw_quant, 4), np.full_like(wl.epf_map, 7), wl.ytox, wl.ytob)
+            ak = kernel_table()
+            ctx.set_hf_meta(wl.transform_map, wl.raw_quant, wl.epf_map, wl.ytox, wl.ytob)
             ctx.frame_run(0, ygroups)
-        ctx.sync()
-        kt = ctx.kernel_times()
-        ctx.kernel_timing(False)
-        for name, (ms, n) in kt.items():
-            per_step_ms = ms / nprof
-            kernels[name] = {"ms_per_step": round(per_step_ms, 4), "launches_per_step": n // nprof}
+            ctx.sync()
+            active = {k: ak[k] for k in ak if k in ALGO_BYTES_PER_PX}
+            active["sum_of_kernels_ms"] = round(sum(v["ms_per_step"] for v in ak.values()), 4)
         cand = {k: v for k, v in kernels.items() if k in ALGO_BYTES_PER_PX}
         # HBM traffic of the dominant kernel from the committed rocprofv3 --pmc passes of this same
         # command (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; tools/gpu_profile.sh, tools/pmc_summary.py).
@@ -200,63 +290,91 @@ def main():
             pmc = {}
         if cand:
             dom = max(cand, key=lambda k: cand[k]["ms_per_step"])
-            algo_bytes = ALGO_BYTES_PER_PX[dom] * size * size
-            ach = algo_bytes / (cand[dom]["ms_per_step"] * 1e-3) / 1e9
             traffic = None
             # "k1_vardct" is the scan + class kernels: their PMC entries are k1_scan, k1_dct8, ...
             prefix = "k1_" if dom == "k1_vardct" else dom
             parts = [int(v["hbm_bytes"]) for k, v in pmc.items() if k.startswith(prefix) and isinstance(v, dict)]
             if parts:
                 traffic = sum(parts)
-            roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+            chain_ms = sum(v["ms_per_step"] for v in kernels.values())
+            ideal = FUSED_IDEAL_BYTES_PER_PX * npx
+            roofline = {"kernel": dom, "bound": "hbm", "achieved": cand[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": cand[dom]["frac"], "traffic": traffic,
                         "traffic_source": pmc.get("_file"),
-                        "algorithmic_bytes_per_launch": int(algo_bytes),
-                        "avg_launch_ms": cand[dom]["ms_per_step"], "all_kernels_ms_per_step": kernels}
-
-    # ---- on-device copy ceiling: a device-to-device copy of one frame's worth of planes
-    copy_gbs = None
-    if rank == 0 and torch.cuda.is_available():
-        n = size * size * 3
-        a_t = torch.empty(n, dtype=torch.float32, device=f"cuda:{local_rank}").normal_()
-        b_t = torch.empty_like(a_t)
-        for _ in range(3):
-            b_t.copy_(a_t)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(10):
-            b_t.copy_(a_t)
-        e1.record()
-        torch.cuda.synchronize()
-        copy_gbs = 2 * n * 4 * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
-        del a_t, b_t
+                        "algorithmic_bytes_per_launch": cand[dom]["algorithmic_bytes"],
+                        "avg_launch_ms": cand[dom]["ms_per_step"], "all_kernels_ms_per_step": kernels,
+                        # the whole IDCT+EPF stage against north_star's numerator: what ONE fused kernel would move
+                        "chain_vs_fused_ideal": {
+                            "algorithmic_bytes": int(ideal), "bytes_per_px": FUSED_IDEAL_BYTES_PER_PX,
+                            "sum_of_kernels_ms": round(chain_ms, 4),
+                            "achieved_GBs": round(ideal / (chain_ms * 1e-3) / 1e9, 1),
+                            "frac": round(ideal / (chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                            "ms_per_step_pipelined": round(ms_per_step, 4),
+                            "frac_pipelined": round(ideal / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                        "epf_population_all_active": active}
+        # ---- measured copy ceilings: a float4 read+write kernel, frame-sized (one plane set in, one
+        # out: the traffic shape of K1 and of the filters) and Infinity-Cache-resident
         if roofline is not None:
-            roofline["copy_ceiling_GBs"] = round(copy_gbs, 1)
-            roofline["frac_of_copy_ceiling"] = round(roofline["achieved"] / copy_gbs, 4)
+            big = ctx.probe_copy_bandwidth(3 * npx * 4, reps=10)
+            small = ctx.probe_copy_bandwidth(64 << 20, reps=50)
+            roofline["copy_ceiling_GBs"] = round(big, 1)
+            roofline["copy_ceiling"] = {"frame_sized": {"bytes_each_way": 3 * npx * 4, "GBs": round(big, 1)},
+                                        "infinity_cache_resident": {"bytes_each_way": 64 << 20, "GBs": round(small, 1)},
+                                        "kernel": "float4 grid-stride copy (jxlh_probe_copy_bandwidth)"}
+            roofline["frac_of_copy_ceiling"] = round(roofline["achieved"] / big, 4)
 
-    # ---- CPU baseline: the oracle (C port of the reference path) on all host cores, bounded crop
+    # ---- CPU baseline: the oracle (C port of the reference path) on the same frame size
     cpu = None
     if rank == 0 and n_gpus == 1 and not args.no_cpu:  # reported baseline: single-GPU runs only
         from oracle.oracle import Oracle
         o = Oracle(fused=True)
         cs = min(args.cpu_sample, size)
-        cwl = synth.make_vardct(cs, cs, mix=mix, seed=args.seed, unique_groups=24, epf_iters=args.epf_iters)
+        cwl = wl if cs == size else synth.make_vardct(cs, cs, mix=mix, seed=args.seed, unique_groups=24,
+                                                      epf_iters=args.epf_iters)
         p = o.default_params(cs, cs)
+        p.epf_iters = args.epf_iters
         lf = o.dequant_lf(p, *cwl.lf_q)
         cores = os.cpu_count() or 1
-        o.vardct_frame(p, cwl.coeffs, cwl.transform_map, cwl.raw_quant, cwl.epf_map, cwl.ytox, cwl.ytob, lf,
-                       cwl.tables, num_threads=cores)  # warm-up
+
+        def cpu_run(c, nthreads, buffers):
+            o.vardct_frame(p, c.coeffs, c.transform_map, c.raw_quant, c.epf_map, c.ytox, c.ytob, lf, c.tables,
+                           num_threads=nthreads, buffers=buffers)
+            return o.last_buffers
+
+        bufs = cpu_run(cwl, cores, None)  # warm-up; allocates (and first-touches) the planes once
         reps, t0 = 0, time.perf_counter()
         while True:
-            o.vardct_frame(p, cwl.coeffs, cwl.transform_map, cwl.raw_quant, cwl.epf_map, cwl.ytox, cwl.ytob, lf,
-                           cwl.tables, num_threads=cores)
+            cpu_run(cwl, cores, bufs)
             reps += 1
             el = time.perf_counter() - t0
-            if el > 10.0 or reps >= 20:
+            if el > 12.0 or reps >= 20:
                 break
-        cpu = {"value": round(cs * cs * reps / 1e6 / el, 2), "unit": "MP/s", "cores": cores, "kind": "port",
-               "sample": f"{reps} reps of a {cs}x{cs} crop-sized frame of the same synthetic workload "
-                         f"(same type mix / filters), C oracle -O3 x86-64-v3, pthreads over groups and row bands"}
+        all_core = cs * cs * reps / 1e6 / el
+        # one thread, on a 2048^2 frame of the same workload (a whole 8K frame would take ~15 s per repetition)
+        s1 = min(2048, cs)
+        wl1 = synth.make_vardct(s1, s1, mix=mix, seed=args.seed, unique_groups=24, epf_iters=args.epf_iters)
+        p1 = o.default_params(s1, s1)
+        p1.epf_iters = args.epf_iters
+        lf1 = o.dequant_lf(p1, *wl1.lf_q)
+        b1 = None
+        t1 = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            o.vardct_frame(p1, wl1.coeffs, wl1.transform_map, wl1.raw_quant, wl1.epf_map, wl1.ytox, wl1.ytob, lf1,
+                           wl1.tables, num_threads=1, buffers=b1)
+            b1 = o.last_buffers
+            t1.append(time.perf_counter() - t0)
+        one = s1 * s1 / 1e6 / min(t1[1:])
+        cpu = {"value": round(all_core, 2), "unit": "MP/s", "cores": cores, "kind": "port",
+               "sample": f"{reps} reps of the same {cs}x{cs} synthetic frame the GPU ran (same type mix / filters), C oracle "
+                         f"-O3 x86-64-v3 (scalar restatement, not the reference's SIMD), pthreads over groups and row "
+                         f"bands, output planes allocated and touched before the timed region",
+               "one_thread": {"value": round(one, 2), "unit": "MP/s", "sample": f"best of 2 timed runs of a {s1}x{s1} frame"},
+               "parallel_efficiency": round(all_core / (one * cores), 3),
+               "note": "harness limits, not arithmetic, set the all-core figure: a thread pool is created per stage "
+                       "(5 per frame), adaptive LF smoothing and the sigma map run on one thread, and the oracle is "
+                       "scalar C; the reference itself (Rust, SIMD, rayon) cannot be built in this image"}
+        del bufs
 
     for c in ctxs:
         c.close()
@@ -413,14 +531,15 @@ def main():
             "metric": "megapixels/sec decoded (8K VarDCT d1 reconstruction: dequant+CfL+IDCT+LF smoothing+Gaborish+EPF)",
             "value": round(value, 1), "unit": "MP/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "strong" if (args.strong and world > 1) else "weak",
+            "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{size}x{size} VarDCT {args.mix} mix full pipeline (CfL, LF smoothing, "
                                    f"Gaborish, EPF iters={args.epf_iters}), inputs HBM-resident",
                        "groups": int(wl.coeffs.shape[0]),
-                       "sharding": ("group-row bands + RCCL all-gather" if (args.strong and world > 1)
-                                    else "independent frames per GPU, no collective"),
+                       "sharding": "independent frames per GPU, no collective (strong_scaling: one frame in bands of "
+                                   "group rows, halo exchange + RCCL all-gather)" if world > 1 else "single GPU",
                        "frames_in_flight_per_gpu": max(1, args.inflight), "epf_population": args.epf},
+            "strong_scaling": strong,
             "hip_event_ms_per_step_rank0": round(ev_ms / args.steps, 4),
             "setup": {"host_generate_s": round(gen_s, 2), "h2d_coeffs_s": round(h2d_s, 2)},
             "roofline": roofline, "cpu_baseline": cpu, "e2e_pcie_inclusive": e2e,

@@ -1,0 +1,212 @@
+//! Safe host side of the MI355X JPEG XL reconstruction path for jxl-rs.
+//!
+//! Mirrors `include/jxl_hip.hpp` (the C++ rendering of the same surface, compiled and tested in this repository by
+//! `tests/cpp/frame_parity.cc`): every method carries the name of the jxl-rs function whose work it takes over.
+//! This crate depends on nothing but `jxl_hip_sys`; the three seams where the `jxl` crate calls it are listed in
+//! INTEGRATION.md section 2.  NOT compiled in the build image of this repository (no Rust toolchain there).
+use jxl_hip_sys as sys;
+use std::ffi::CStr;
+use std::os::raw::c_void;
+
+/// `Error::Gpu(..)` payload for jxl-rs' `#[non_exhaustive] enum Error` (jxl/src/error.rs:15-17).
+#[derive(Debug, Clone, PartialEq, Eq)]
+pub enum HipError {
+    InvalidArgument,
+    OutOfMemory,
+    Device(String),
+    BadState,
+    /// -> `Error::InvalidVarDCTTransform`
+    InvalidTransform,
+    /// a valid stream feature outside the device path: the caller keeps the CPU pipeline for this frame
+    Unsupported,
+    /// -> `Error::InvalidBlockSizeForChromaSubsampling`
+    InvalidBlockSize,
+    /// -> `Error::HFBlockOutOfBounds`
+    BlockOutOfBounds,
+    Unknown(i32),
+}
+
+pub type Result<T> = std::result::Result<T, HipError>;
+
+fn check(ctx: *const sys::jxlh_ctx, st: sys::jxlh_status) -> Result<()> {
+    match st {
+        sys::JXLH_OK => Ok(()),
+        sys::JXLH_ERR_INVALID_ARGUMENT => Err(HipError::InvalidArgument),
+        sys::JXLH_ERR_OUT_OF_MEMORY => Err(HipError::OutOfMemory),
+        sys::JXLH_ERR_DEVICE => {
+            let msg = if ctx.is_null() {
+                String::new()
+            } else {
+                // SAFETY: jxlh_last_error returns a NUL-terminated string owned by the context
+                unsafe { CStr::from_ptr(sys::jxlh_last_error(ctx)) }.to_string_lossy().into_owned()
+            };
+            Err(HipError::Device(msg))
+        }
+        sys::JXLH_ERR_BAD_STATE => Err(HipError::BadState),
+        sys::JXLH_ERR_INVALID_TRANSFORM => Err(HipError::InvalidTransform),
+        sys::JXLH_ERR_UNSUPPORTED => Err(HipError::Unsupported),
+        sys::JXLH_ERR_INVALID_BLOCK_SIZE => Err(HipError::InvalidBlockSize),
+        sys::JXLH_ERR_BLOCK_OUT_OF_BOUNDS => Err(HipError::BlockOutOfBounds),
+        other => Err(HipError::Unknown(other)),
+    }
+}
+
+/// One device context (one HIP stream for the kernels + one upload stream per decoding thread).
+pub struct Context {
+    raw: *mut sys::jxlh_ctx,
+}
+// SAFETY: frame-level calls are made by one thread; jxlh_submit_group* is re-entrant per `slot`
+// (include/jxl_hip.h "Conventions"), which is how `submit_*` below are used from the runner's threads.
+unsafe impl Send for Context {}
+unsafe impl Sync for Context {}
+
+impl Context {
+    /// `n_slots` = the JxlParallelRunner's thread count (jxl/src/api/mod.rs:77-81).
+    pub fn new(device: i32, n_slots: i32) -> Result<Self> {
+        let mut raw = std::ptr::null_mut();
+        // SAFETY: out pointer is valid
+        check(std::ptr::null(), unsafe { sys::jxlh_ctx_create(device, n_slots, &mut raw) })?;
+        Ok(Self { raw })
+    }
+    pub fn raw(&self) -> *mut sys::jxlh_ctx {
+        self.raw
+    }
+    fn ok(&self, st: sys::jxlh_status) -> Result<()> {
+        check(self.raw, st)
+    }
+    pub fn default_params(xsize: u32, ysize: u32) -> sys::jxlh_frame_params {
+        // SAFETY: plain-old-data struct, fully written by the call
+        let mut p: sys::jxlh_frame_params = unsafe { std::mem::zeroed() };
+        unsafe { sys::jxlh_default_frame_params(&mut p, xsize, ysize) };
+        p
+    }
+    /// blocks until the kernels queued so far are done; reports device-side stream errors
+    pub fn sync(&self) -> Result<()> {
+        self.ok(unsafe { sys::jxlh_ctx_sync(self.raw) })
+    }
+    /// pinned host memory for coefficient slabs / pair lists (replaces `VarDctBuffers::coeffs_storage`)
+    pub fn alloc_pinned(&self, bytes: usize) -> Result<PinnedBuf<'_>> {
+        let mut p: *mut c_void = std::ptr::null_mut();
+        self.ok(unsafe { sys::jxlh_alloc_pinned(self.raw, bytes, &mut p) })?;
+        Ok(PinnedBuf { ctx: self, ptr: p, len: bytes })
+    }
+}
+
+impl Drop for Context {
+    fn drop(&mut self) {
+        // SAFETY: created by jxlh_ctx_create, destroyed once
+        unsafe { sys::jxlh_ctx_destroy(self.raw) }
+    }
+}
+
+pub struct PinnedBuf<'a> {
+    ctx: &'a Context,
+    ptr: *mut c_void,
+    len: usize,
+}
+impl PinnedBuf<'_> {
+    pub fn as_mut_slice<T: Copy>(&mut self) -> &mut [T] {
+        // SAFETY: hipHostMalloc memory is suitably aligned for any scalar; len is the allocation size
+        unsafe { std::slice::from_raw_parts_mut(self.ptr as *mut T, self.len / std::mem::size_of::<T>()) }
+    }
+    pub fn as_ptr(&self) -> *const c_void {
+        self.ptr
+    }
+}
+impl Drop for PinnedBuf<'_> {
+    fn drop(&mut self) {
+        unsafe { sys::jxlh_free_pinned(self.ctx.raw, self.ptr) };
+    }
+}
+
+/// A VarDCT frame on the device.  Call order = the reference's frame flow.
+pub struct VarDctFrame<'a> {
+    ctx: &'a Context,
+    pub xsize: u32,
+    pub ysize: u32,
+}
+
+impl<'a> VarDctFrame<'a> {
+    /// `Frame::from_header_and_toc` + `prepare_render_pipeline` (frame/decode.rs:172-204, frame/render.rs:907)
+    pub fn begin(ctx: &'a Context, p: &sys::jxlh_frame_params) -> Result<Self> {
+        ctx.ok(unsafe { sys::jxlh_frame_begin(ctx.raw, p) })?;
+        Ok(Self { ctx, xsize: p.xsize, ysize: p.ysize })
+    }
+    /// `decode_hf_global`: `DequantMatrices::matrix(table, c)` for the 17 tables (frame/quant_weights.rs:1081-1086)
+    pub fn decode_hf_global(&self, tables: &[&[f32]; 17]) -> Result<()> {
+        let ptrs: Vec<*const f32> = tables.iter().map(|t| t.as_ptr()).collect();
+        let n: Vec<usize> = tables.iter().map(|t| t.len() / 3).collect();
+        self.ctx.ok(unsafe { sys::jxlh_frame_set_dequant_tables(self.ctx.raw, ptrs.as_ptr(), n.as_ptr()) })
+    }
+    /// `decode_lf_group` -> `dequant_lf` (frame/modular/mod.rs:837-929): rect in blocks, channels in coded order Y, X, B
+    #[allow(clippy::too_many_arguments)]
+    pub fn decode_lf_group(&self, x0: u32, y0: u32, w: u32, h: u32, qy: &[i32], qx: &[i32], qb: &[i32], stride: usize,
+                           extra_precision: u32) -> Result<()> {
+        let need = (h as usize - 1) * stride + w as usize;
+        if qy.len() < need || qx.len() < need || qb.len() < need {
+            return Err(HipError::InvalidArgument);
+        }
+        self.ctx.ok(unsafe {
+            sys::jxlh_frame_set_lf_quantized(self.ctx.raw, x0, y0, w, h, qy.as_ptr(), qx.as_ptr(), qb.as_ptr(), stride,
+                                             extra_precision)
+        })
+    }
+    /// `decode_hf_metadata` (frame/modular/mod.rs:984-1081): HfMetadata maps of a rect in blocks
+    #[allow(clippy::too_many_arguments)]
+    pub fn decode_hf_metadata(&self, x0: u32, y0: u32, w: u32, h: u32, transform_map: &[u8], raw_quant: &[i32],
+                              epf_map: &[u8], map_stride: usize, ytox: &[i8], ytob: &[i8], cmap_stride: usize) -> Result<()> {
+        self.ctx.ok(unsafe {
+            sys::jxlh_frame_set_hf_meta(self.ctx.raw, x0, y0, w, h, transform_map.as_ptr(), raw_quant.as_ptr(),
+                                        epf_map.as_ptr(), map_stride, ytox.as_ptr(), ytob.as_ptr(), cmap_stride)
+        })
+    }
+    /// the `if let Some(pixels)` branch of `decode_vardct_group` (frame/group.rs:579-611): the group's dense slab,
+    /// 3 x 65536 i32 in pinned memory; asynchronous, reuse the slab after `slot_wait`.  `complete = false` is a
+    /// progressive pass whose coefficients will be added to by later passes (`set_buffer_for_group(.., complete, ..)`).
+    pub fn decode_vardct_group(&self, slot: i32, group: u32, coeffs: &[i32], complete: bool) -> Result<()> {
+        if coeffs.len() != 3 * 65536 {
+            return Err(HipError::InvalidArgument);
+        }
+        let flags = if complete { sys::JXLH_GROUP_COMPLETE } else { 0 };
+        self.ctx.ok(unsafe { sys::jxlh_submit_group(self.ctx.raw, slot, group, coeffs.as_ptr(), flags) })
+    }
+    /// the same from the entropy loop's updates (frame/group.rs:557-572 emits `(position, value)` instead of
+    /// `coeffs[position] += value`): `pairs` = X run, Y run, B run
+    pub fn decode_vardct_group_sparse(&self, slot: i32, group: u32, pairs: &[sys::jxlh_coeff16], n: [u32; 3],
+                                      wide: &[sys::jxlh_coeff32], complete: bool) -> Result<()> {
+        if pairs.len() != (n[0] + n[1] + n[2]) as usize {
+            return Err(HipError::InvalidArgument);
+        }
+        let flags = if complete { sys::JXLH_GROUP_COMPLETE } else { 0 };
+        self.ctx.ok(unsafe {
+            sys::jxlh_submit_group_sparse(self.ctx.raw, slot, group, pairs.as_ptr(), n.as_ptr(), wide.as_ptr(),
+                                          wide.len() as u32, flags)
+        })
+    }
+    pub fn slot_wait(&self, slot: i32) -> Result<()> {
+        self.ctx.ok(unsafe { sys::jxlh_slot_wait(self.ctx.raw, slot) })
+    }
+    /// `Frame::finalize_lf` + `SigmaSource::new` + the reconstruction of every submitted group + the Gaborish / EPF
+    /// stages of frame/render.rs:569-622 (and chroma upsampling / upsampling / noise when the parameters ask for them)
+    pub fn finalize_and_render(&self) -> Result<()> {
+        self.ctx.ok(unsafe { sys::jxlh_frame_run(self.ctx.raw, 0, u32::MAX) })
+    }
+    /// `mark_group_to_rerender` + re-render (render/mod.rs:143-146): after more passes arrived for `groups`
+    pub fn rerender_groups(&self, groups: &[u32]) -> Result<()> {
+        self.ctx.ok(unsafe { sys::jxlh_frame_rerender_groups(self.ctx.raw, groups.as_ptr(), groups.len() as u32) })
+    }
+    /// the save stage for planar f32 XYB output; `out[c]` = `RawImageBuffer` of channel c
+    pub fn read_planes(&self, out: &[sys::jxlh_plane; 3]) -> Result<()> {
+        self.ctx.ok(unsafe { sys::jxlh_frame_read_planes(self.ctx.raw, out.as_ptr()) })
+    }
+    /// XybStage + FromLinearStage(sRGB) + ConvertF32ToU8Stage, interleaved, rows [y0, y1)
+    pub fn read_rgb8(&self, p: &sys::jxlh_xyb_params, channels: u32, y0: u32, y1: u32, out: &mut [u8],
+                     bytes_per_row: usize) -> Result<()> {
+        if out.len() < (y1 - y0) as usize * bytes_per_row {
+            return Err(HipError::InvalidArgument);
+        }
+        self.ctx.ok(unsafe {
+            sys::jxlh_frame_read_rgb8(self.ctx.raw, p, channels, y0, y1, out.as_mut_ptr() as *mut c_void, bytes_per_row)
+        })
+    }
+}

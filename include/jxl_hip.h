@@ -42,7 +42,9 @@ enum {
   JXLH_ERR_DEVICE = -3,           /* any other HIP runtime error; see jxlh_last_error */
   JXLH_ERR_BAD_STATE = -4,        /* call order violated (e.g. submit before frame_begin) */
   JXLH_ERR_INVALID_TRANSFORM = -5,/* transform_map holds an id >= 27 (Error::InvalidVarDCTTransform) */
-  JXLH_ERR_UNSUPPORTED = -6,      /* valid stream feature outside the device path (caller falls back) */
+  JXLH_ERR_UNSUPPORTED = -6,      /* valid stream feature outside the device path (caller falls back): band or sharded
+                                     runs and group re-renders of upsampled frames, the Weighted predictor in
+                                     jxlh_palette_delta, frames beyond 2^31 coefficients */
   JXLH_ERR_INVALID_BLOCK_SIZE = -7, /* a varblock larger than 8x8 in a chroma-subsampled frame
                                       (Error::InvalidBlockSizeForChromaSubsampling, frame/modular/mod.rs:1058-1060) */
   JXLH_ERR_BLOCK_OUT_OF_BOUNDS = -8 /* a varblock crosses its group's or the frame's edge, or the first-block flags of
@@ -190,7 +192,16 @@ jxlh_status jxlh_frame_set_hf_meta(jxlh_ctx* ctx, uint32_t x0, uint32_t y0, uint
  * H2D copy on slot's stream; the slab may be reused after jxlh_slot_wait(slot). */
 jxlh_status jxlh_submit_group(jxlh_ctx* ctx, int32_t slot, uint32_t group_id, const int32_t* coeffs,
                               uint32_t flags);
-enum { JXLH_GROUP_COMPLETE = 1u << 0 /* set_buffer_for_group(.., complete = true, ..) */ };
+/* Flags of the submit calls.
+ *   JXLH_GROUP_COMPLETE    set_buffer_for_group's `complete` (render/mod.rs:128-137): this is the last time the group
+ *                          is submitted.  Without it the submission is a progressive pass: the frame can be rendered
+ *                          with what has arrived (jxlh_frame_run), and groups that receive further passes later are
+ *                          brought up to date with jxlh_frame_rerender_groups.
+ *   JXLH_GROUP_ACCUMULATE  sparse forms only: the pairs are ADDED to the group's coefficients of the earlier passes
+ *                          on the device (frame/group.rs:572 `+=` on Frame::hf_coefficients, frame/decode.rs:547-558)
+ *                          instead of replacing them.  A dense slab always replaces the group's coefficients, so a
+ *                          progressive caller that keeps dense slabs submits its accumulated slab. */
+enum { JXLH_GROUP_COMPLETE = 1u << 0, JXLH_GROUP_ACCUMULATE = 1u << 1 };
 
 /* Sparse form of jxlh_submit_group (the dense i32 slab is ~90 % zeros at d1 and
  * its PCIe transfer bounds end-to-end decode).  The entropy loop of decode_vardct_group
@@ -240,6 +251,13 @@ jxlh_status jxlh_frame_coeff_buffer(jxlh_ctx* ctx, int32_t** device_ptr, size_t*
  * of frame/render.rs:569-622 (Gaborish x3, EPF0/1/2).  group range [g0, g1) restricts K1 and the
  * filters to a band of group rows (multi-GPU sharding); pass 0, UINT32_MAX for the whole frame. */
 jxlh_status jxlh_frame_run(jxlh_ctx* ctx, uint32_t group_row0, uint32_t group_row1);
+/* mark_group_to_rerender + the re-render it triggers (render/mod.rs:143-146, callers frame/decode.rs:703-711): after
+ * a jxlh_frame_run, groups whose coefficients changed (a later progressive pass) are reconstructed again -- the
+ * transforms of exactly the listed groups, then the filters on every pixel row those groups influence (their rows
+ * widened by the stage list's border: the part of the reference's 3x3 group neighbourhood that can change).  Stage
+ * lists that overwrite the transforms' output (epf_iters == 3, per-stage kernels with an even stage count) and
+ * chroma-subsampled frames re-render the whole frame instead; upsampled frames return JXLH_ERR_UNSUPPORTED. */
+jxlh_status jxlh_frame_rerender_groups(jxlh_ctx* ctx, const uint32_t* group_ids, uint32_t count);
 /* blocks until the main stream is idle */
 jxlh_status jxlh_ctx_sync(jxlh_ctx* ctx);
 /* Copies the finished planes out (host or device destination).  Replaces the save stage for

@@ -6,6 +6,8 @@
 // set_lf* / set_hf_meta; decode_hf_global -> set_dequant_tables; decode_hf_group ->
 // submit_group (async H2D on the caller's slot stream, overlapping the host's entropy decode
 // of the next group); finalize_lf + render -> frame_run.
+#include <algorithm>
+
 #include "jxlh_ctx.h"
 
 extern "C" {
@@ -287,6 +289,7 @@ jxlh_status jxlh_frame_begin(jxlh_ctx* ctx, const jxlh_frame_params* p) {
     for (int q = 0; q < JXLH_NUM_QUANT_TABLES; q++) f.table_offset[q] = ctx->table_offset[q];
   }
   ctx->lf_smoothed = false;
+  ctx->rendered = false;
   for (auto& s : ctx->slots) s.used = false;
   for (int c = 0; c < 3; c++) ctx->result[c] = nullptr;
   ctx->chroma_lazy = false;
@@ -425,7 +428,10 @@ jxlh_status jxlh_submit_group(jxlh_ctx* ctx, int32_t slot, uint32_t group_id, co
   if (!ctx || !coeffs || slot < 0 || (size_t)slot >= ctx->slots.size()) return JXLH_ERR_INVALID_ARGUMENT;
   if (!ctx->in_frame) return JXLH_ERR_BAD_STATE;
   if (group_id >= ctx->ngroups) return JXLH_ERR_INVALID_ARGUMENT;
-  if (!(flags & JXLH_GROUP_COMPLETE)) return JXLH_ERR_UNSUPPORTED;  // progressive partial renders stay on the CPU path
+  // JXLH_GROUP_COMPLETE is the caller's bookkeeping (set_buffer_for_group's `complete`): a slab always REPLACES the
+  // group's coefficients, so a progressive decoder submits what it has accumulated so far (the reference keeps that
+  // in Frame::hf_coefficients, frame/decode.rs:547-558) and re-renders the group when a later pass changes it
+  if (flags & JXLH_GROUP_ACCUMULATE) return JXLH_ERR_INVALID_ARGUMENT;  // device-side accumulation: sparse form only
   Slot& s = ctx->slots[slot];
   {
     std::lock_guard<std::mutex> lock(ctx->sp_mutex);
@@ -460,7 +466,6 @@ jxlh_status sparse_reserve(jxlh_ctx* ctx, int32_t slot, uint32_t count, const ui
   if (!ctx || slot < 0 || (size_t)slot >= ctx->slots.size() || !group_ids || !n || (n_wide && !wide))
     return JXLH_ERR_INVALID_ARGUMENT;
   if (!ctx->in_frame) return JXLH_ERR_BAD_STATE;
-  if (!(flags & JXLH_GROUP_COMPLETE)) return JXLH_ERR_UNSUPPORTED;
   size_t total = 0;
   for (uint32_t i = 0; i < count; i++) {
     if (group_ids[i] >= ctx->ngroups) return JXLH_ERR_INVALID_ARGUMENT;
@@ -490,6 +495,7 @@ jxlh_status sparse_reserve(jxlh_ctx* ctx, int32_t slot, uint32_t count, const ui
       g.n[c] = n[3 * i + c];
       o += g.n[c];
     }
+    g.flags = (flags & JXLH_GROUP_ACCUMULATE) ? 1u : 0u;
     ctx->sp_pending.push_back(g);
     ctx->touched[g.group] = 2;
   }
@@ -692,11 +698,20 @@ jxlh_status run_prologue(jxlh_ctx* ctx, RunPlan* plan) {
                                    hipMemcpyHostToDevice, ctx->stream));
       bool all_pairs = nw == 0 && ng == ctx->ngroups && !(p.flags & JXLH_FRAME_EXPAND_SPARSE);
       for (size_t g = 0; all_pairs && g < ctx->ngroups; g++) all_pairs = ctx->touched[g] == 2;
+      // pairs that ADD to a group's earlier passes need that group's dense slab
+      std::vector<uint8_t> accum(ctx->ngroups, 0);
+      for (const SparseGroup& sg : ctx->sp_upload) {
+        if (sg.flags & 1u) {
+          accum[sg.group] = 1;
+          all_pairs = false;
+        }
+      }
       if (ctx->sp_sorted_valid && !all_pairs) {
-        // leaving the bucketed form: groups not resubmitted now need their dense slab
+        // leaving the bucketed form: groups not resubmitted now (or only added to) need their dense slab
         ctx->flag_upload.assign(ctx->ngroups, 0);
         bool any = false;
-        for (size_t g = 0; g < ctx->ngroups; g++) any |= (ctx->flag_upload[g] = ctx->touched[g] == 0) != 0;
+        for (size_t g = 0; g < ctx->ngroups; g++)
+          any |= (ctx->flag_upload[g] = (ctx->touched[g] == 0 || accum[g]) ? 1 : 0) != 0;
         if (any) {
           HIPCHK(ctx, hipMemcpyAsync(ctx->group_dense.p, ctx->flag_upload.data(), ctx->ngroups, hipMemcpyHostToDevice,
                                      ctx->stream));
@@ -798,12 +813,16 @@ jxlh_status run_k1(jxlh_ctx* ctx, const RunPlan& plan, int gr0, int gr1) {
 
 // the stage list on group rows [group_row0, group_row1), then upsampling and noise
 jxlh_status run_stages(jxlh_ctx* ctx, const RunPlan& plan, uint32_t group_row0, uint32_t group_row1) {
+  const bool whole = group_row0 == 0 && group_row1 == (uint32_t)ctx->fd.ygroups;
+  return run_stages_rows(ctx, plan, (int)group_row0 * kGroupDim, min((int)group_row1 * kGroupDim, ctx->fd.ysize), whole);
+}
+
+// ... on pixel rows [y_lo, y_hi)
+jxlh_status run_stages_rows(jxlh_ctx* ctx, const RunPlan& plan, int y_lo, int y_hi, bool whole_frame) {
   FrameDev& f = ctx->fd;
   const jxlh_frame_params& p = ctx->params;
   (void)plan;
   // ---- stage list of frame/render.rs:569-622
-  const int y_lo = (int)group_row0 * kGroupDim;
-  const int y_hi = min((int)group_row1 * kGroupDim, f.ysize);
   int stages[4], borders[4], ns = 0;
   if (f.gab) { stages[ns] = -1; borders[ns++] = 1; }
   if (f.epf_iters >= 3) { stages[ns] = 0; borders[ns++] = 3; }
@@ -865,7 +884,7 @@ jxlh_status run_stages(jxlh_ctx* ctx, const RunPlan& plan, uint32_t group_row0, 
   if (p.upsampling > 1) {
     // Upsample2x/4x/8x on the three colour channels (frame/render.rs:655-671).  The 5x5 window crosses band
     // edges, so an upsampled frame is run whole.
-    if (group_row0 != 0 || group_row1 != (uint32_t)f.ygroups) return JXLH_ERR_UNSUPPORTED;
+    if (!whole_frame) return JXLH_ERR_UNSUPPORTED;
     const int n = (int)p.upsampling;
     const int ow = p.xsize_upsampled ? (int)p.xsize_upsampled : f.xsize * n;
     const int oh = p.ysize_upsampled ? (int)p.ysize_upsampled : f.ysize * n;
@@ -926,7 +945,70 @@ jxlh_status jxlh_frame_run(jxlh_ctx* ctx, uint32_t group_row0, uint32_t group_ro
   const int gr0 = need_halo && group_row0 > 0 ? (int)group_row0 - 1 : (int)group_row0;
   const int gr1 = need_halo && group_row1 < (uint32_t)f.ygroups ? (int)group_row1 + 1 : (int)group_row1;
   if (jxlh_status st = run_k1(ctx, plan, gr0, gr1)) return st;
+  if (group_row0 == 0 && group_row1 == (uint32_t)f.ygroups) ctx->rendered = true;
   return run_stages(ctx, plan, group_row0, group_row1);
+}
+
+jxlh_status jxlh_frame_rerender_groups(jxlh_ctx* ctx, const uint32_t* group_ids, uint32_t count) {
+  if (!ctx || (count && !group_ids)) return JXLH_ERR_INVALID_ARGUMENT;
+  if (!ctx->in_frame || !ctx->tables_set) return JXLH_ERR_BAD_STATE;
+  FrameDev& f = ctx->fd;
+  for (uint32_t i = 0; i < count; i++)
+    if (group_ids[i] >= ctx->ngroups) return JXLH_ERR_INVALID_ARGUMENT;
+  if (count == 0) return JXLH_OK;
+  const jxlh_frame_params& p = ctx->params;
+  if (p.upsampling > 1) return JXLH_ERR_UNSUPPORTED;  // like a band run: the 5x5 upsampling window crosses groups
+  const int ns = (f.gab ? 1 : 0) + (f.epf_iters >= 3 ? 1 : 0) + (f.epf_iters >= 1 ? 1 : 0) + (f.epf_iters >= 2 ? 1 : 0);
+  // Re-rendering a group needs its neighbours' UNFILTERED pixels (the filters read across the group edge).  They
+  // are still in `planes` when the stage list leaves its result in `tmp` (the fused path with up to two EPF passes,
+  // or no filter at all); a stage list that ends in `planes` has overwritten them, a sub-sampled frame keeps them
+  // in another form, and a frame that was never rendered has none: those render the frame again.
+  const bool per_stage = (p.flags & JXLH_FRAME_UNFUSED_FILTERS) != 0;  // ping-pongs planes <-> tmp: kept only for one stage
+  const bool unfiltered_kept = ns == 0 || (per_stage ? ns == 1 : result_in_tmp(ctx) != 0);
+  if (!ctx->rendered || !unfiltered_kept || f.subsampled) return jxlh_frame_run(ctx, 0, UINT32_MAX);
+  RunPlan plan;
+  if (jxlh_status st = run_prologue(ctx, &plan)) return st;
+  // ---- transforms of exactly the listed groups
+  ctx->rerender_upload.assign(group_ids, group_ids + count);
+  std::sort(ctx->rerender_upload.begin(), ctx->rerender_upload.end());
+  ctx->rerender_upload.erase(std::unique(ctx->rerender_upload.begin(), ctx->rerender_upload.end()),
+                             ctx->rerender_upload.end());
+  const int n = (int)ctx->rerender_upload.size();
+  if (jxlh_status st = ensure(ctx, ctx->rerender_list, (size_t)n)) return st;
+  HIPCHK(ctx, hipMemcpyAsync(ctx->rerender_list.p, ctx->rerender_upload.data(), n * sizeof(int), hipMemcpyHostToDevice,
+                             ctx->stream));
+  {
+    ScopedKernelTimer t(ctx, "k1_vardct");
+    f.sp_sorted = plan.sparse_k1 ? ctx->sp_sorted.p : nullptr;
+    f.sp_slot_start = plan.sparse_k1 ? ctx->sp_slot_start.p : nullptr;
+    f.group_dense = plan.sparse_k1 ? ctx->group_dense.p : nullptr;
+    if (plan.sparse_k1) HIPCHK(ctx, hipMemsetAsync(ctx->group_dense.p, 0, ctx->ngroups, ctx->stream));
+    launch_vardct_groups(ctx->stream, f, 0, 0, ctx->worklist.p, ctx->error_flag.p,
+                         plan.sparse_k1 ? ctx->coeffs.p : nullptr, ctx->rerender_list.p, n);
+  }
+  if (!ctx->k1_done) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->k1_done, hipEventDisableTiming));
+  HIPCHK(ctx, hipEventRecord(ctx->k1_done, ctx->stream));
+  ctx->k1_done_valid = true;
+  // ---- the filters on every pixel row the listed groups influence: their own rows widened by the stage list's
+  // reach (mark_group_to_rerender's 3x3 neighbourhood, restricted to what can actually change), merged into bands
+  int prev_lo = -1, prev_hi = -1;
+  for (int i = 0; i <= n; i++) {
+    int lo = -1, hi = -1;
+    if (i < n) {
+      const int gy = ctx->rerender_upload[i] / f.xgroups;
+      lo = max(0, gy * kGroupDim - plan.halo_px);
+      hi = min(f.ysize, (gy + 1) * kGroupDim + plan.halo_px);
+    }
+    if (i < n && prev_hi >= lo) {
+      prev_hi = max(prev_hi, hi);
+      continue;
+    }
+    if (prev_lo >= 0)
+      if (jxlh_status st = run_stages_rows(ctx, plan, prev_lo, prev_hi, prev_lo == 0 && prev_hi == f.ysize)) return st;
+    prev_lo = lo;
+    prev_hi = hi;
+  }
+  return JXLH_OK;
 }
 
 jxlh_status jxlh_ctx_sync(jxlh_ctx* ctx) {

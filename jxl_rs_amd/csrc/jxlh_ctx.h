@@ -67,6 +67,9 @@ struct jxlh_ctx {
   DevBuf<uint8_t> rgb8;  // jxlh_frame_read_rgb8 staging for host destinations
   int* host_flag = nullptr;  // pinned
   DevBuf<uint8_t> worklist;
+  DevBuf<int> rerender_list;          // group ids of jxlh_frame_rerender_groups on the device
+  std::vector<int> rerender_upload;   // ... and their host copy (alive until the copy has run)
+  bool rendered = false;              // a full jxlh_frame_run has happened in this frame
   float* result[3] = {nullptr, nullptr, nullptr};
   // geometry of `result`: the frame itself, or its upsampled image (frame_header.upsampling > 1)
   int res_w = 0, res_h = 0;
@@ -221,6 +224,7 @@ struct RunPlan {
 jxlh_status run_prologue(jxlh_ctx* ctx, RunPlan* plan);
 jxlh_status run_k1(jxlh_ctx* ctx, const RunPlan& plan, int gr0, int gr1);
 jxlh_status run_stages(jxlh_ctx* ctx, const RunPlan& plan, uint32_t group_row0, uint32_t group_row1);
+jxlh_status run_stages_rows(jxlh_ctx* ctx, const RunPlan& plan, int y_lo, int y_hi, bool whole_frame);
 // Where run_stages leaves the finished planes (1 = f.tmp, 0 = f.planes): a property of the frame's stage list, so a
 // rank that filtered nothing (empty band) still knows where the gathered frame lives.
 inline int result_in_tmp(const jxlh_ctx* ctx) {

@@ -157,8 +157,10 @@ void launch_sigma_map(hipStream_t s, const FrameDev& f, float epf_quant_mul, con
 // worklist_mem: device scratch of vardct_worklist_bytes(f) bytes.
 size_t vardct_worklist_bytes(const FrameDev& f);
 // dense_coeffs: writable alias of f.coeffs, used in sparse mode to expand the groups k1_scan flags
+// group_list (device, n_list entries) replaces the row range by an explicit list of group ids when non-null
 void launch_vardct_groups(hipStream_t s, const FrameDev& f, int group_row0, int group_row1,
-                          void* worklist_mem, int* error_flag, int32_t* dense_coeffs);
+                          void* worklist_mem, int* error_flag, int32_t* dense_coeffs,
+                          const int* group_list = nullptr, int n_list = 0);
 void launch_gaborish(hipStream_t s, const float* in, float* out, int w, int h, size_t stride, float k0, float k1,
                      float k2, int y0, int y1);
 struct EpfArgs {
@@ -202,6 +204,7 @@ struct SparseGroup {
   uint32_t group;   // group id
   uint32_t offset;  // index of the group's first pair in the pair buffer (X pairs, then Y, then B)
   uint32_t n[3];    // pairs per channel
+  uint32_t flags;   // bit 0: add the pairs to the group's current slab instead of starting from zero
 };
 // only_flagged (nullable): expand a group only if only_flagged[group] != 0
 void launch_pack_pairs8(hipStream_t s, const uint16_t* pos, const int8_t* val, size_t n, uint32_t* pairs);

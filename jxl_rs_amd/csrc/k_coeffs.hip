@@ -29,8 +29,13 @@ __global__ __launch_bounds__(kExpandThreads) void k_expand_sparse(int32_t* __res
   const SparseGroup sg = groups[blockIdx.x / 12];
   if (only_flagged && !only_flagged[sg.group]) return;  // K1 reads this group's pairs directly
   int4* s4 = reinterpret_cast<int4*>(s_q);
+  int4* d4 = reinterpret_cast<int4*>(coeffs + ((size_t)sg.group * 3 + c) * kGroupArea + q * kQuarter);
+  // a later pass of a progressive frame adds to what the earlier passes left (frame/group.rs:572 `+=` on the
+  // frame's hf_coefficients, frame/decode.rs:547-558); a first / only submission starts from zero
+  const bool accumulate = (sg.flags & 1u) != 0;
 #pragma unroll
-  for (int i = 0; i < kQuarter / 4 / kExpandThreads; i++) s4[i * kExpandThreads + tid] = make_int4(0, 0, 0, 0);
+  for (int i = 0; i < kQuarter / 4 / kExpandThreads; i++)
+    s4[i * kExpandThreads + tid] = accumulate ? d4[i * kExpandThreads + tid] : make_int4(0, 0, 0, 0);
   __syncthreads();
   const uint32_t n = sg.n[c];
   const uint32_t first = sg.offset + (c > 0 ? sg.n[0] : 0u) + (c > 1 ? sg.n[1] : 0u);
@@ -51,7 +56,6 @@ __global__ __launch_bounds__(kExpandThreads) void k_expand_sparse(int32_t* __res
     }
   }
   __syncthreads();
-  int4* d4 = reinterpret_cast<int4*>(coeffs + ((size_t)sg.group * 3 + c) * kGroupArea + q * kQuarter);
 #pragma unroll
   for (int i = 0; i < kQuarter / 4 / kExpandThreads; i++) d4[i * kExpandThreads + tid] = s4[i * kExpandThreads + tid];
 }

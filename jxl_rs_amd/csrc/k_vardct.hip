@@ -85,11 +85,11 @@ namespace {
 
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void k1_scan(const FrameDev f, const WorkLists wl, const int group_row0,
-                                                     int* __restrict__ error_flag) {
+                                                     int* __restrict__ error_flag, const int* __restrict__ group_list) {
   __shared__ int s_wave_sum[kWaves];
   __shared__ int s_count[kNumClasses], s_base[kNumClasses];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int group = group_row0 * f.xgroups + blockIdx.x;
+  const int group = group_list ? group_list[blockIdx.x] : group_row0 * f.xgroups + blockIdx.x;
   const int bx0 = (group % f.xgroups) * kGroupBlocks, by0 = (group / f.xgroups) * kGroupBlocks;
   const int bw = min(kGroupBlocks, f.xblocks - bx0), bh = min(kGroupBlocks, f.yblocks - by0);
   if (tid < kNumClasses) s_count[tid] = 0;
@@ -815,8 +815,9 @@ size_t vardct_worklist_bytes(const FrameDev& f) {
 }
 
 void launch_vardct_groups(hipStream_t s, const FrameDev& f, int group_row0, int group_row1,
-                          void* worklist_mem, int* error_flag, int32_t* dense_coeffs) {
-  const int ngroups = (group_row1 - group_row0) * f.xgroups;
+                          void* worklist_mem, int* error_flag, int32_t* dense_coeffs, const int* group_list,
+                          int n_list) {
+  const int ngroups = group_list ? n_list : (group_row1 - group_row0) * f.xgroups;
   if (ngroups <= 0) return;
   // carve the work-list memory: [counts (256 B)] [class 0 items] [class 1 items] ...
   WorkLists wl;
@@ -828,7 +829,7 @@ void launch_vardct_groups(hipStream_t s, const FrameDev& f, int group_row0, int 
     p += (nblocks / class_min_area(c) + 1) * sizeof(WorkItem);
   }
   (void)hipMemsetAsync(wl.counts, 0, kNumClasses * sizeof(int), s);
-  hipLaunchKernelGGL(k1_scan, dim3(ngroups), dim3(kThreads), 0, s, f, wl, group_row0, error_flag);
+  hipLaunchKernelGGL(k1_scan, dim3(ngroups), dim3(kThreads), 0, s, f, wl, group_row0, error_flag, group_list);
   // grids: enough waves to fill the chip; kernels stride over their lists (counts are device-side)
   const int nblk = ngroups * kGroupBlocks * kGroupBlocks;
   auto grid_for = [](long work_items, int items_per_wg, int cap) {

@@ -28,6 +28,7 @@ ERR_INVALID_BLOCK_SIZE = -7
 ERR_BLOCK_OUT_OF_BOUNDS = -8
 FRAME_UNFUSED_FILTERS = 1
 GROUP_COMPLETE = 1
+GROUP_ACCUMULATE = 2
 
 # every symbol include/jxl_hip.h declares (checked by tests/test_abi_symbols.py)
 ABI_SYMBOLS = [
@@ -46,7 +47,7 @@ ABI_SYMBOLS = [
     "jxlh_quant_table_for_type", "jxlh_quant_table_size",
     "jxlh_comm_unique_id", "jxlh_comm_init", "jxlh_comm_init_local", "jxlh_comm_destroy", "jxlh_comm_band",
     "jxlh_frame_run_sharded", "jxlh_frame_allgather", "jxlh_frames_run_sharded_local", "jxlh_frames_allgather_local",
-    "jxlh_comm_allgather", "jxlh_probe_copy_bandwidth",
+    "jxlh_comm_allgather", "jxlh_probe_copy_bandwidth", "jxlh_frame_rerender_groups",
 ]
 
 
@@ -178,6 +179,7 @@ def load():
     L.jxlh_frames_allgather_local.argtypes = [C.POINTER(vp), i32]
     L.jxlh_comm_allgather.argtypes = [vp, vp, sz]
     L.jxlh_probe_copy_bandwidth.argtypes = [vp, sz, i32, fp]
+    L.jxlh_frame_rerender_groups.argtypes = [vp, vp, u32]
     for name in ("jxlh_covered_blocks_x", "jxlh_covered_blocks_y", "jxlh_quant_table_for_type",
                  "jxlh_quant_table_size"):
         getattr(L, name).argtypes = [i32]
@@ -364,6 +366,10 @@ class Context:
 
     def frame_run(self, group_row0=0, group_row1=0xFFFFFFFF):
         self._chk(self.L.jxlh_frame_run(self._ctx, group_row0, group_row1), "frame_run")
+
+    def rerender_groups(self, group_ids):
+        ids = np.ascontiguousarray(group_ids, dtype=np.uint32)
+        self._chk(self.L.jxlh_frame_rerender_groups(self._ctx, _addr(ids), len(ids)), "frame_rerender_groups")
 
     def sync(self):
         self._chk(self.L.jxlh_ctx_sync(self._ctx), "ctx_sync")

@@ -1,8 +1,10 @@
 """Sharding of one VarDCT frame across ranks: contiguous bands of group rows.
 
-K1 has no cross-group dependence; the filters need a 4..7 pixel halo, which the C ABI provides by
-running K1 on one extra group row on each side of the band (`jxlh_frame_run(row0, row1)`), so no
-GPU<->GPU exchange happens before the final all-gather of the finished planes."""
+K1 has no cross-group dependence; the filters need a 4..7 pixel halo.  The library (csrc/comm.hip) runs K1 on
+exactly the rank's band, exchanges one block row per band edge with the neighbour rank and all-gathers the
+finished planes (`jxlh_frame_run_sharded`, `jxlh_frame_allgather`); `jxlh_frame_run(row0, row1)` is the
+stand-alone form that recomputes a halo group row instead.  The helpers here mirror the library's partition for
+host code that distributes coefficient groups to ranks and for the CPU tests."""
 
 
 def band_for_rank(ygroups, rank, world):

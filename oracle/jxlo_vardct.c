@@ -602,7 +602,11 @@ static void stage_job(void* v, int i, int n) {
   const int h = j->p->ysize, w = j->p->xsize;
   int y0 = i * j->rows_per_job, y1 = y0 + j->rows_per_job;
   if (y1 > h) y1 = h;
-  if (j->stage < 0) {
+  if (j->stage == -2) {
+    for (int c = 0; c < 3; c++)
+      for (int y = y0; y < y1; y++)
+        memcpy(j->sout[c] + (size_t)y * j->stride, j->sin[c] + (size_t)y * j->stride, sizeof(float) * (size_t)w);
+  } else if (j->stage < 0) {
     for (int c = 0; c < 3; c++)
       jxlo_gaborish_rows(j->sin[c], w, h, j->stride, j->p->gab_w1[c], j->p->gab_w2[c], j->sout[c],
                          y0, y1);
@@ -688,9 +692,12 @@ void jxlo_vardct_frame(const JxloFrameParams* p, const int32_t* coeffs,
     }
   }
   if (cur[0] != planes[0]) {
-    for (int c = 0; c < 3; c++)
-      for (int y = 0; y < p->ysize; y++)
-        memcpy(planes[c] + (size_t)y * stride, cur[c] + (size_t)y * stride, sizeof(float) * p->xsize);
+    j.stage = -2; /* copy rows of cur back into planes, in parallel like the stages */
+    for (int c = 0; c < 3; c++) {
+      j.sin[c] = cur[c];
+      j.sout[c] = planes[c];
+    }
+    run_parallel(num_threads, njobs, stage_job, &j);
   }
   free(sigma);
 }

@@ -313,11 +313,14 @@ class Oracle:
                           sig.shape[1], self._p3(out))
         return out
 
-    def vardct_band(self, p, coeffs, transform_map, raw_quant, epf_map, ytox, ytob, lf, tables, row0, row1):
-        """Band of group rows [row0, row1) the way a rank computes it: K1 on the band plus one halo
-        group row on each side, every stage on the band's rows extended by the later stages' borders
-        (mirrors jxlh_frame_run).  lf must already be smoothed.  Returns 3 planes holding valid data
-        on the band's pixel rows."""
+    def vardct_band(self, p, coeffs, transform_map, raw_quant, epf_map, ytox, ytob, lf, tables, row0, row1,
+                    exchange=None):
+        """Band of group rows [row0, row1) the way a rank computes it.  exchange is None: K1 on the band plus
+        one halo group row on each side (mirrors jxlh_frame_run(row0, row1)).  exchange = callable(planes):
+        K1 on exactly the band; the callable then fills the block row above / below the band from the
+        neighbour ranks (mirrors jxlh_frame_run_sharded).  Every stage then runs on the band's rows extended
+        by the later stages' borders.  lf must already be smoothed.  Returns 3 planes holding valid data on
+        the band's pixel rows."""
         bw, bh = p.xsize_blocks, p.ysize_blocks
         stride = bw * 8
         xg = (p.xsize + 255) // 256
@@ -325,9 +328,11 @@ class Oracle:
         cur = [np.zeros((bh * 8, stride), dtype=np.float32) for _ in range(3)]
         oth = [np.zeros((bh * 8, stride), dtype=np.float32) for _ in range(3)]
         co = np.ascontiguousarray(coeffs, dtype=np.int32)
-        gr0, gr1 = max(row0 - 1, 0), min(row1 + 1, yg)
+        gr0, gr1 = (row0, row1) if exchange is not None else (max(row0 - 1, 0), min(row1 + 1, yg))
         for g in range(gr0 * xg, gr1 * xg):
             self.decode_group(p, g, co[g], transform_map, raw_quant, ytox, ytob, lf, tables, cur)
+        if exchange is not None:
+            exchange(cur)
         sigma = self.sigma_map(p, raw_quant, epf_map)
         stages, borders = [], []
         if p.gab:
@@ -354,12 +359,17 @@ class Oracle:
         return cur
 
     def vardct_frame(self, p, coeffs, transform_map, raw_quant, epf_map, ytox, ytob, lf, tables,
-                     num_threads=1):
-        """Runs the whole chain; returns 3 planes (padded to whole blocks)."""
+                     num_threads=1, buffers=None):
+        """Runs the whole chain; returns 3 planes (padded to whole blocks).  buffers = (planes, tmp) of an earlier
+        call are reused when given (timing loops: no allocation / first-touch page faults in the timed region)."""
         bw, bh = p.xsize_blocks, p.ysize_blocks
         stride = bw * 8
-        planes = [np.zeros((bh * 8, stride), dtype=np.float32) for _ in range(3)]
-        tmp = [np.zeros((bh * 8, stride), dtype=np.float32) for _ in range(3)]
+        if buffers is not None:
+            planes, tmp = buffers
+        else:
+            planes = [np.zeros((bh * 8, stride), dtype=np.float32) for _ in range(3)]
+            tmp = [np.zeros((bh * 8, stride), dtype=np.float32) for _ in range(3)]
+        self.last_buffers = (planes, tmp)
         lf = [_f32(a).copy() for a in lf]
         tm = np.ascontiguousarray(transform_map, dtype=np.uint8)
         rq = np.ascontiguousarray(raw_quant, dtype=np.int32)

@@ -553,7 +553,9 @@ def test_call_order_errors(ctx):
         assert c2.L.jxlh_frame_run(c2._ctx, 0, 1) == lib.ERR_BAD_STATE  # no dequant tables yet
         assert c2.L.jxlh_submit_group(c2._ctx, 5, 0, c2._ctx, 1) == lib.ERR_INVALID_ARGUMENT  # bad slot
         assert c2.L.jxlh_submit_group(c2._ctx, 0, 99, c2._ctx, 1) == lib.ERR_INVALID_ARGUMENT  # bad group
-        assert c2.L.jxlh_submit_group(c2._ctx, 0, 0, c2._ctx, 0) == lib.ERR_UNSUPPORTED  # partial render
+        # progressive passes (flags without COMPLETE) are accepted (tests/test_gpu_progressive.py); what a dense slab
+        # cannot do is accumulate on the device
+        assert c2.L.jxlh_submit_group(c2._ctx, 0, 0, c2._ctx, lib.GROUP_ACCUMULATE) == lib.ERR_INVALID_ARGUMENT
     finally:
         c2.close()
 
@@ -895,9 +897,11 @@ def test_sparse_submit_argument_errors(ctx):
     with pytest.raises(JxlHipError):
         ctx.submit_group_sparse(5, pairs, n, wide)          # group out of range
     with pytest.raises(JxlHipError):
-        ctx.submit_group_sparse(0, pairs, n, wide, flags=0)  # partial render: unsupported
-    with pytest.raises(JxlHipError):
         ctx.submit_group_sparse(0, pairs, n, np.array([[3 * 65536, 1]], np.uint32))  # wide pos out of range
+    ctx.submit_group_sparse(0, pairs, n, wide, flags=0)      # a progressive pass (tests/test_gpu_progressive.py)
+    with pytest.raises(JxlHipError):
+        ctx.submit_group_sparse(0, pairs, n, wide)           # twice in one epoch
+    ctx.slot_wait(0)
 
 
 def test_sparse_expansion_matches_oracle_slab(ctx, oracle):

@@ -1,8 +1,9 @@
-"""Multi-rank path on CPU (gloo, world_size 2): band partition of group rows, per-rank band
-computation with halo recompute, all-gather and reassembly must reproduce the whole-frame result
-bit for bit.  The compute stand-in is the oracle (HIP kernels cannot run here); the band logic is
-the one `jxlh_frame_run(row0, row1)` implements and `bench.py --strong` drives, and
-tests/test_gpu_parity.py::test_band_runs_equal_whole_frame checks the device side of it."""
+"""Multi-rank path on CPU (gloo, world_size 2 and 3): band partition of group rows, transforms on the own band,
+halo EXCHANGE of the edge block rows with the neighbour ranks (send / recv), filters on the band, all-gather and
+reassembly must reproduce the whole-frame result bit for bit.  The compute stand-in is the oracle (HIP kernels
+cannot run here); the protocol is the one `jxlh_frame_run_sharded` + `jxlh_frame_allgather` implement over RCCL
+and `bench.py --gpus N` drives; tests/test_gpu_sharding.py checks the device side of it with the in-process
+transport, tests/test_gpu_parity.py::test_band_runs_equal_whole_frame the halo-recompute form."""
 import os
 import sys
 
@@ -38,12 +39,37 @@ def _worker(rank, world, port, out_dir):
     from helpers import oracle_params_from
 
     o = Oracle(fused=True)
-    wl = synth.make_vardct(300, 700, mix=synth.MIX_D1, seed=21, epf_iters=2)  # 3 group rows -> 2 + 1
+    wl = synth.make_vardct(300, 700, mix=synth.MIX_D1, seed=21, epf_iters=2)  # 3 group rows -> 2 + 1 or 1 + 1 + 1
     p = oracle_params_from(o, wl)
     lf = o.adaptive_lf_smoothing(p, o.dequant_lf(p, *wl.lf_q))
     row0, row1, per = band_for_rank(wl.ygroups, rank, world)
-    planes = o.vardct_band(p, wl.coeffs, wl.transform_map, wl.raw_quant, wl.epf_map, wl.ytox, wl.ytob, lf,
-                           wl.tables, row0, row1)
+    # the rank holds only its own band's coefficients
+    coeffs = np.full_like(wl.coeffs, 0x3FFF)
+    coeffs[row0 * wl.xgroups:row1 * wl.xgroups] = wl.coeffs[row0 * wl.xgroups:row1 * wl.xgroups]
+
+    def exchange(planes):
+        """one block row (8 pixel rows x 3 channels) per band edge, like the grouped ncclSend / ncclRecv"""
+        reqs, recvs = [], []
+        for nb, send_rows, recv_rows in ((rank - 1, (row0 * 256, row0 * 256 + 8), (row0 * 256 - 8, row0 * 256)),
+                                         (rank + 1, (row1 * 256 - 8, row1 * 256), (row1 * 256, row1 * 256 + 8))):
+            if nb < 0 or nb >= world or row0 >= row1:
+                continue
+            n0, n1, _ = band_for_rank(wl.ygroups, nb, world)
+            if n0 >= n1:
+                continue
+            out = torch.from_numpy(np.stack([pl[send_rows[0]:send_rows[1]] for pl in planes]).copy())
+            buf = torch.zeros_like(out)
+            reqs.append(dist.isend(out, nb))
+            reqs.append(dist.irecv(buf, nb))
+            recvs.append((buf, recv_rows))
+        for r in reqs:
+            r.wait()
+        for buf, (a, b) in recvs:
+            for c in range(3):
+                planes[c][a:b] = buf[c].numpy()
+
+    planes = o.vardct_band(p, coeffs, wl.transform_map, wl.raw_quant, wl.epf_map, wl.ytox, wl.ytob, lf,
+                           wl.tables, row0, row1, exchange=exchange)
     y0, y1 = band_pixel_rows(row0, row1, wl.ysize)
     band = torch.zeros((3, per * 256, wl.xsize), dtype=torch.float32)
     for c in range(3):
@@ -56,16 +82,17 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_rank_band_sharding_reassembles_the_frame(tmp_path, oracle):
+@pytest.mark.parametrize("world", [2, 3])
+def test_band_sharding_with_halo_exchange_reassembles_the_frame(tmp_path, oracle, world):
     import torch.multiprocessing as mp
     from jxl_rs_amd import synth
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import run_oracle_frame
-    port = 29500 + os.getpid() % 2000
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    port = 29500 + (os.getpid() * 7 + world) % 2000
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     wl = synth.make_vardct(300, 700, mix=synth.MIX_D1, seed=21, epf_iters=2)
     want, _ = run_oracle_frame(oracle, wl)
-    for r in range(2):
+    for r in range(world):
         got = np.load(tmp_path / f"rank{r}.npy")
         assert got.shape == (3, 700, 300)
         for c in range(3):
