@@ -56,6 +56,15 @@
 #ifndef JXLH_E2_STRIPS
 #define JXLH_E2_STRIPS 1
 #endif
+// An EPF wavefront (128 strip rows) with at most this many active strips hands them to the compacted pass
+// (<= 64: a wavefront that compacts takes 64 strips back; 0 = only all-identity wavefronts skip work, the round-1
+// behaviour).  EPF2 as the last stage compacts wavefronts with fewer than JXLH_DENSE_ITEMS active strips of 64.
+#ifndef JXLH_SPARSE_MAX
+#define JXLH_SPARSE_MAX 64
+#endif
+#ifndef JXLH_DENSE_ITEMS
+#define JXLH_DENSE_ITEMS 40
+#endif
 
 namespace jxlh {
 namespace {
@@ -69,6 +78,8 @@ constexpr int kT = JXLH_FUSED_THREADS;
 static_assert(kStrips == 16, "lane <-> strip mapping relies on 16-lane DPP rows");
 static_assert(kTH % 4 == 0 && kT % 64 == 0, "tiled staging fetches 4-row groups");
 constexpr int kSigW = kBW / 8 + 2, kSigH = kBH / 8 + 2;
+constexpr int kDenseItems = JXLH_DENSE_ITEMS, kSparseMax = JXLH_SPARSE_MAX;
+static_assert(kSparseMax <= 64, "a compacting wavefront takes 64 strips");
 
 struct FusedArgs {
   const float* in[3];
@@ -137,6 +148,18 @@ __device__ __forceinline__ void load8(const float* __restrict__ strip, float (&v
 __device__ __forceinline__ void load4(const float* __restrict__ strip, float (&v)[4]) {
   const float4 c = lds_load4(strip);
   v[0] = c.x; v[1] = c.y; v[2] = c.z; v[3] = c.w;
+}
+
+// The same 8 values for a work item that is NOT laid out one strip per lane (compacted EPF items, see run_stage):
+// the side taps come from LDS (two 8-byte reads) instead of the neighbouring lanes.  edge_l / edge_r: the strip is
+// the first / last of its tile row; its outer taps feed only pixels nobody consumes, so they may be anything in-bounds.
+__device__ __forceinline__ void load8g(const float* __restrict__ strip, bool edge_l, bool edge_r, float (&v)[8]) {
+  const float4 c = lds_load4(strip);
+  const float2 l = *reinterpret_cast<const float2*>(__builtin_assume_aligned(strip - (edge_l ? 0 : 2), 8));
+  const float2 r = *reinterpret_cast<const float2*>(__builtin_assume_aligned(strip + (edge_r ? 2 : 4), 8));
+  v[0] = l.x; v[1] = l.y;
+  v[2] = c.x; v[3] = c.y; v[4] = c.z; v[5] = c.w;
+  v[6] = r.x; v[7] = r.y;
 }
 
 // 10 consecutive values: v[0..2] = cols bx0-3..-1, v[3..6] = strip, v[7..9] = cols bx0+4..+6
@@ -230,6 +253,7 @@ __device__ __forceinline__ void epf1_pair(const float* __restrict__ p0, Regeom&&
     wv[0][i] = wv[1][i] = wv[2][i] = 0.0f;
     wh[0][i] = wh[1][i] = 0.0f;
   }
+
   // one channel at a time (a rolled loop): unrolled, the scheduler interleaves the three
   // channels' loads and difference maps and triples the live registers
 #if JXLH_E1_ROLLED
@@ -336,6 +360,88 @@ __device__ __forceinline__ void epf1_pair(const float* __restrict__ p0, Regeom&&
   }
 }
 
+// ---- EPF1 on ONE strip (4 pixels of row fy) for compacted items: any lane, any strip, every tap from LDS.
+// Same sums as epf1_pair (five terms each: top, left, centre, right, bottom; channels accumulated with the same FMA),
+// evaluated for one row only -- half the maps, no second row to share them with.
+//   V(x', r) = |P(x',r) - P(x',r+1)|,  H(x', r) = |P(x',r) - P(x'+1,r)|
+//   SAD_N(x,y) = sum_c s_c PV_c(x, y-1),  SAD_S = sum_c s_c PV_c(x, y),  SAD_E = sum_c s_c PH_c(x, y),  SAD_W = SAD_E(x-1, y)
+template <class Emit>
+__device__ __forceinline__ void epf1_strip_g(const float* __restrict__ p0, int fx0, int fy, float sigma, bool edge_l,
+                                             bool edge_r, const FusedArgs& a, Emit&& emit) {
+  float wn[4], ws[4], we[5];  // we[k]: column x - 1 + k
+#pragma unroll
+  for (int i = 0; i < 4; i++) wn[i] = ws[i] = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 5; k++) we[k] = 0.0f;
+#pragma unroll 1
+  for (int c = 0; c < 3; c++) {
+    const float* p = p0 + c * kPlane;
+    const float scale = a.scale[c];
+    float A[4], B[8], C[8], D[8], E[4];  // rows y-2 .. y+2; 8-wide rows hold columns x-2 .. x+5
+    load4(p - 2 * kBW, A);
+    load8g(p - kBW, edge_l, edge_r, B);
+    load8g(p, edge_l, edge_r, C);
+    load8g(p + kBW, edge_l, edge_r, D);
+    load4(p + 2 * kBW, E);
+    float vm1[6], v0[6];  // V at rows y-1 and y, columns x-1 .. x+4 (index j: column x - 1 + j)
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      vm1[j] = FAD(B[j + 1], C[j + 1]);
+      v0[j] = FAD(C[j + 1], D[j + 1]);
+    }
+    float h0[7];  // H at row y, columns x-2 .. x+4 (index j: column x - 2 + j)
+#pragma unroll
+    for (int j = 0; j < 7; j++) h0[j] = FAD(C[j], C[j + 1]);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const float vm2 = FAD(A[i], B[i + 2]), vp1 = FAD(D[i + 2], E[i]);
+      const float pvn = vm2 + vm1[i] + vm1[i + 1] + vm1[i + 2] + v0[i + 1];    // PV(x+i, y-1)
+      const float pvs = vm1[i + 1] + v0[i] + v0[i + 1] + v0[i + 2] + vp1;      // PV(x+i, y)
+      wn[i] = __builtin_fmaf(pvn, scale, wn[i]);
+      ws[i] = __builtin_fmaf(pvs, scale, ws[i]);
+    }
+#pragma unroll
+    for (int k = 0; k < 5; k++) {  // PH(x - 1 + k, y)
+      const float hm1 = FAD(B[k + 1], B[k + 2]), hp1 = FAD(D[k + 1], D[k + 2]);
+      const float ph = hm1 + h0[k] + h0[k + 1] + h0[k + 2] + hp1;
+      we[k] = __builtin_fmaf(ph, scale, we[k]);
+    }
+  }
+  const bool pass = sigma < kMinSigma;
+  float is[4], wgt[4][4], inv_w[4];
+  strip_inv_sigma(sigma, fx0, fy, a.sm1, a.bsm1, is);
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const float sad[4] = {wn[i], we[i], we[i + 1], ws[i]};  // N, W, E, S (epf1.rs:96)
+    float wsum = 1.0f;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      wgt[i][k] = fmaxf(__builtin_fmaf(sad[k], is[i], 1.0f), 0.0f);
+      wsum += wgt[i][k];
+    }
+    inv_w[i] = recip_weight_sum(wsum);
+  }
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    const float* p = p0 + c * kPlane;
+    float N[4], M[8], S[4];
+    load4(p - kBW, N);
+    load8g(p, edge_l, edge_r, M);
+    load4(p + kBW, S);
+    float o[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      float acc = M[i + 2];
+      acc = __builtin_fmaf(S[i], wgt[i][3], acc);
+      acc = __builtin_fmaf(M[i + 3], wgt[i][2], acc);
+      acc = __builtin_fmaf(M[i + 1], wgt[i][1], acc);
+      acc = __builtin_fmaf(N[i], wgt[i][0], acc);
+      o[i] = pass ? M[i + 2] : acc * inv_w[i];
+    }
+    emit(c, make_float4(o[0], o[1], o[2], o[3]));
+  }
+}
+
 // ---- EPF2 on a 4x2 micro-tile (epf2.rs:84-136)
 template <class Emit>
 __device__ __forceinline__ void epf2_pair(const float* __restrict__ p0, int fx0, int fy, float sigma0, float sigma1,
@@ -408,15 +514,16 @@ __device__ __forceinline__ void epf2_pair(const float* __restrict__ p0, int fx0,
 
 // ---- EPF2 on one strip (epf2.rs:84-136): the form used when EPF2 is the last stage and
 // register pressure matters more than the shared SADs of the 4x2 form
-template <class Emit>
+template <bool GENERIC, class Emit>
 __device__ __forceinline__ void epf2_strip(const float* __restrict__ p0, int fx0, int fy, float sigma,
-                                           const FusedArgs& a, Emit&& emit) {
+                                           const FusedArgs& a, Emit&& emit, bool edge_l = false, bool edge_r = false) {
   float t[3][4], m[3][8], b[3][4];
 #pragma unroll
   for (int c = 0; c < 3; c++) {
     const float* p = p0 + c * kPlane;
     load4(p - kBW, t[c]);
-    load8(p, m[c]);
+    if constexpr (GENERIC) load8g(p, edge_l, edge_r, m[c]);
+    else load8(p, m[c]);
     load4(p + kBW, b[c]);
   }
   const bool pass = sigma < kMinSigma;
@@ -584,7 +691,14 @@ __global__ __launch_bounds__(kT, E0 ? JXLH_FUSED_E0_WPE : JXLH_FUSED_WAVES_PER_E
   __shared__ __attribute__((aligned(16))) float s_buf[3 * kPlane];
   // 1/sigma of the 8x8 blocks this tile touches (block columns/rows relative to the tile's first block)
   __shared__ float s_sigma[kSigH * kSigW];
+  // compacted EPF items of the current stage (see run_stage) and the number of wavefronts free to take them
+  __shared__ uint16_t s_list[(kTH + 2 * kB) * kStrips];
+  __shared__ int s_cnt, s_nsw;
   const int tid_kernel = threadIdx.x, tid = tid_kernel;
+  if (tid_kernel == 0) {
+    s_cnt = 0;
+    s_nsw = 0;
+  }
   // blockIdx.x enumerates tiles so that the workgroups one XCD receives (ids congruent mod 8)
   // walk along a tile row: neighbouring tiles share 128-byte output lines and halo input
   // lines, which then meet in the same (non-coherent) L2.
@@ -671,6 +785,14 @@ __global__ __launch_bounds__(kT, E0 ? JXLH_FUSED_E0_WPE : JXLH_FUSED_WAVES_PER_E
   // One stage, in place: margin = the output region's margin around the tile (the input region's
   // minus the stage's border).  Every 4x2 item of the region is computed into registers, then
   // (after a barrier: all reads done) written back over the input.
+  //
+  // EPF stages and sparse sigma maps.  A block whose sigma is below MIN_SIGMA passes through (epf1.rs:72-78), and
+  // on d1-like content most blocks do (93 % of the SURVEY population) -- yet a wavefront spans 8 blocks, so nearly
+  // half of the wavefronts would run the whole stage for a handful of live lanes.  A wavefront therefore counts
+  // its active items: none -> nothing to do (the stage is the identity in place); many (>= kDenseItems) -> the
+  // dense form (one strip per lane, side taps through DPP); few -> the active items go to a workgroup-wide list
+  // and are processed after a barrier as compacted wavefronts by the GENERIC form of the stage (side taps from
+  // LDS).  Both forms add the same terms in the same order.
   auto run_stage = [&](auto stage_tag, auto margin_tag) {
     constexpr int STAGE = decltype(stage_tag)::value;  // 0 gaborish, 1 epf1, 2 epf2
     constexpr int margin = decltype(margin_tag)::value;
@@ -687,97 +809,208 @@ __global__ __launch_bounds__(kT, E0 ? JXLH_FUSED_E0_WPE : JXLH_FUSED_WAVES_PER_E
     static_assert(STAGE != 3 || last, "EPF0 runs as the last stage");
     if constexpr ((STAGE == 2 && last && JXLH_E2_STRIPS) || STAGE == 3) {
       constexpr int ns = rows * kStrips;
+      auto strip_geom = [&](int t, int& by, int& bx0, int& fy, int& fx0, float& sigma) {
+        by = kB + t / kStrips;
+        bx0 = (t % kStrips) * 4;
+        fy = ty0 - kB + by;
+        fx0 = tx0 - kB + bx0;
+        const int sx = (min(max(fx0, 0), a.w - 1) >> 3) - sbx0, sy = (min(max(fy, 0), a.h - 1) >> 3) - sby0;
+        sigma = s_sigma[sy * kSigW + sx];
+      };
+      auto store = [&](int bx0, int fy, int fx0, int c, float4 o) {
+        if (bx0 >= kB && bx0 < kB + kTW && fy < a.y1 && fy < a.h && fx0 < a.w)
+          at_bytes<float4>(a.out[c], 4u * ((uint32_t)fy * a.stride + (uint32_t)fx0)) = o;
+      };
 #pragma unroll 1
       for (int t0 = 0; t0 < ns; t0 += kT) {
         if (t0 + (tid & ~63) >= ns) break;
         const int t = t0 + tid;
         const bool live = t < ns;
-        const int by = kB + (live ? t / kStrips : 0), bx0 = (t % kStrips) * 4;
-        const int fy = ty0 - kB + by, fx0 = tx0 - kB + bx0;
-        const int sx = (min(max(fx0, 0), a.w - 1) >> 3) - sbx0, sy = (min(max(fy, 0), a.h - 1) >> 3) - sby0;
-        const float sigma = s_sigma[sy * kSigW + sx];
+        int by, bx0, fy, fx0;
+        float sigma;
+        strip_geom(live ? t : 0, by, bx0, fy, fx0, sigma);
         const float* p = s_buf + by * kBW + bx0;
         auto put = [&](int c, float4 o) {
-          if (live && bx0 >= kB && bx0 < kB + kTW && fy < a.y1 && fy < a.h && fx0 < a.w)
-            at_bytes<float4>(a.out[c], 4u * ((uint32_t)fy * a.stride + (uint32_t)fx0)) = o;
+          if (live) store(bx0, fy, fx0, c, o);
         };
-        if (__all(sigma < kMinSigma)) {
+        const bool act = live && !(sigma < kMinSigma);
+        const int cnt = __popcll(__ballot(act));
+        if (cnt == 0) {
 #pragma unroll
           for (int c = 0; c < 3; c++) put(c, lds_load4(p + c * kPlane));
-        } else if constexpr (STAGE == 3) {
-          epf0_strip(p, fx0, fy, sigma, a, put);
+        } else if (STAGE == 3 || cnt >= kDenseItems) {
+          if constexpr (STAGE == 3) epf0_strip(p, fx0, fy, sigma, a, put);
+          else epf2_strip<false>(p, fx0, fy, sigma, a, put);
         } else {
-          epf2_strip(p, fx0, fy, sigma, a, put);
+          // few active strips: the others leave now, the active ones are queued
+          if (!act) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) put(c, lds_load4(p + c * kPlane));
+          } else {
+            s_list[atomicAdd(&s_cnt, 1)] = (uint16_t)t;
+          }
+        }
+      }
+      if constexpr (STAGE == 2) {
+        __syncthreads();
+        const int cnt = s_cnt;
+#pragma unroll 1
+        for (int i = tid; i < cnt; i += kT) {
+          const int t = s_list[i];
+          int by, bx0, fy, fx0;
+          float sigma;
+          strip_geom(t, by, bx0, fy, fx0, sigma);
+          const float* p = s_buf + by * kBW + bx0;
+          epf2_strip<true>(p, fx0, fy, sigma, a, [&](int c, float4 o) { store(bx0, fy, fx0, c, o); }, bx0 == 0,
+                           bx0 == kBW - 4);
         }
       }
       return;
     }
+    static_assert(kPasses == 1 || STAGE == 0 || last, "held registers of one pass");
+    auto geom_of = [&](int t) -> Geom {
+      Geom g;
+      g.live = t < n;
+      const int by = kB - margin + (g.live ? (t / kStrips) * 2 : 0);
+      g.bx0 = (t % kStrips) * 4;
+      g.fy = ty0 - kB + by;
+      g.fx0 = tx0 - kB + g.bx0;
+      g.p = s_buf + by * kBW + g.bx0;
+      if constexpr (STAGE != 0) {
+        const int sx = (min(max(g.fx0, 0), a.w - 1) >> 3) - sbx0;
+        const int sy0 = (min(max(g.fy, 0), a.h - 1) >> 3) - sby0, sy1 = (min(max(g.fy + 1, 0), a.h - 1) >> 3) - sby0;
+        g.sigma0 = s_sigma[sy0 * kSigW + sx];
+        g.sigma1 = s_sigma[sy1 * kSigW + sx];
+      } else {
+        g.sigma0 = g.sigma1 = 0.0f;
+      }
+      return g;
+    };
+    auto put_global = [&](const Geom& g, int r, int c, float4 o) {
+      const int fyr = g.fy + r;
+      if (g.live && g.bx0 >= kB && g.bx0 < kB + kTW && fyr < a.y1 && fyr < a.h && g.fx0 < a.w)
+        at_bytes<float4>(a.out[c], 4u * ((uint32_t)fyr * a.stride + (uint32_t)g.fx0)) = o;
+    };
     float4 held[last ? 1 : kPasses][2][3];
+    // what `held` carries (EPF stages: at most one entry per thread): -1 nothing, otherwise a 4x2 item t (dense
+    // form, both rows) or, with bit 15 set, a compacted strip entry t * 2 + r (row r only, in held[0][0])
+    int held_e = -1;
+    if constexpr (STAGE == 0) {
 #pragma unroll
-    for (int pass = 0; pass < kPasses; pass++) {
-      if (pass * kT + (tid & ~63) >= n) continue;  // wave-uniform: nothing left for this wave
+      for (int pass = 0; pass < kPasses; pass++) {
+        if (pass * kT + (tid & ~63) >= n) continue;  // wave-uniform: nothing left for this wave
+        const Geom g = geom_of(pass * kT + tid);
+        auto put_g = [&](int r, int c, float4 o) {
+          if constexpr (last) put_global(g, r, c, o);
+          else held[pass][r][c] = o;
+        };
+#pragma unroll
+        for (int c = 0; c < 3; c++) gab_pair(g.p + c * kPlane, c, a.gab_k[c][0], a.gab_k[c][1], a.gab_k[c][2], put_g);
+      }
+    } else {
+      static_assert(STAGE == 0 || kPasses == 1, "one EPF item per thread");
+      // ---- phase A: classify.  dense: this wavefront runs its own 64 items in the dense form; otherwise its
+      // active strips go to the list and the wavefront is free to take 64 compacted strips
       auto geom = [&]() -> Geom {
         int tl = tid_kernel;
         asm volatile("" : "+v"(tl));  // recomputed where needed, not kept (see epf1_pair)
-        const int t = pass * kT + tl;
-        Geom g;
-        g.live = t < n;
-        const int by = kB - margin + (g.live ? (t / kStrips) * 2 : 0);
-        g.bx0 = (t % kStrips) * 4;
-        g.fy = ty0 - kB + by;
-        g.fx0 = tx0 - kB + g.bx0;
-        g.p = s_buf + by * kBW + g.bx0;
-        if constexpr (STAGE != 0) {
-          const int sx = (min(max(g.fx0, 0), a.w - 1) >> 3) - sbx0;
-          const int sy0 = (min(max(g.fy, 0), a.h - 1) >> 3) - sby0, sy1 = (min(max(g.fy + 1, 0), a.h - 1) >> 3) - sby0;
-          g.sigma0 = s_sigma[sy0 * kSigW + sx];
-          g.sigma1 = s_sigma[sy1 * kSigW + sx];
-        } else {
-          g.sigma0 = g.sigma1 = 0.0f;
-        }
-        return g;
+        return geom_of(tl);
       };
-      auto put = [&](const Geom& g, int r, int c, float4 o) {
-        if constexpr (last) {
-          const int fyr = g.fy + r;
-          if (g.live && g.bx0 >= kB && g.bx0 < kB + kTW && fyr < a.y1 && fyr < a.h && g.fx0 < a.w)
-            at_bytes<float4>(a.out[c], 4u * ((uint32_t)fyr * a.stride + (uint32_t)g.fx0)) = o;
-        } else {
-          held[pass][r][c] = o;
-        }
-      };
-      const Geom g = geom();
-      auto put_g = [&](int r, int c, float4 o) { put(g, r, c, o); };
-      if constexpr (STAGE == 0) {
-#pragma unroll
-        for (int c = 0; c < 3; c++) gab_pair(g.p + c * kPlane, c, a.gab_k[c][0], a.gab_k[c][1], a.gab_k[c][2], put_g);
-      } else {
-        if (__all(g.sigma0 < kMinSigma && g.sigma1 < kMinSigma)) {
-          // every micro-tile of this wave is below MIN_SIGMA: the stage is the identity here
-          // (the reference takes the same shortcut per SIMD vector, epf1.rs:72-78)
-#pragma unroll
-          for (int c = 0; c < 3; c++) {
-            put_g(0, c, lds_load4(g.p + c * kPlane));
-            put_g(1, c, lds_load4(g.p + c * kPlane + kBW));
+      bool dense = false;
+      int my_slot = -1;
+      if ((tid & ~63) < n) {
+        const Geom g = geom();
+        const bool act0 = g.live && !(g.sigma0 < kMinSigma), act1 = g.live && !(g.sigma1 < kMinSigma);
+        const unsigned long long m0 = __ballot(act0), m1 = __ballot(act1);
+        const int cnt = __popcll(m0) + __popcll(m1);  // active strips of this wavefront
+        // EPF2 as an in-place stage has no compacted form: any active strip makes the wavefront dense
+        dense = STAGE == 1 ? cnt > kSparseMax : cnt > 0;
+        if (!dense) {
+          int slot = 0, base = 0;
+          if ((tid & 63) == 0) {
+            slot = atomicAdd(&s_nsw, 1);
+            if (cnt) base = atomicAdd(&s_cnt, cnt);
           }
-        } else if constexpr (STAGE == 1) {
-          epf1_pair(g.p, geom, a, put);
-        } else {
-          epf2_pair(g.p, g.fx0, g.fy, g.sigma0, g.sigma1, a, put_g);
+          my_slot = __builtin_amdgcn_readfirstlane(slot);
+          base = __builtin_amdgcn_readfirstlane(base);
+          const unsigned long long below = (1ull << (tid & 63)) - 1ull;
+          if (act0) s_list[base + __popcll(m0 & below)] = (uint16_t)(tid * 2);
+          if (act1) s_list[base + __popcll(m0) + __popcll(m1 & below)] = (uint16_t)(tid * 2 + 1);
+          // rows below MIN_SIGMA: the stage is the identity there (in place: nothing to do; as the last stage:
+          // copy out) -- the reference takes the same shortcut per SIMD vector, epf1.rs:72-78
+          if constexpr (last) {
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+              if (r ? act1 : act0) continue;
+#pragma unroll
+              for (int c = 0; c < 3; c++) put_global(g, r, c, lds_load4(g.p + c * kPlane + r * kBW));
+            }
+          }
+        }
+      }
+      __syncthreads();  // the list is complete
+      // ---- phase B: a wavefront is EITHER dense (its own items) OR takes compacted strips, so `held` has one
+      // definition per thread and no live range crosses the other form's code
+      if (dense) {
+        const Geom g = geom();
+        auto put = [&](const Geom& gg, int r, int c, float4 o) {
+          if constexpr (last) put_global(gg, r, c, o);
+          else held[0][r][c] = o;
+        };
+        if constexpr (STAGE == 1) epf1_pair(g.p, geom, a, put);
+        else epf2_pair(g.p, g.fx0, g.fy, g.sigma0, g.sigma1, a, [&](int r, int c, float4 o) { put(g, r, c, o); });
+        held_e = tid;
+      } else if constexpr (STAGE == 1) {
+        const int cnt = s_cnt;
+        const int i = my_slot >= 0 ? my_slot * 64 + (tid & 63) : cnt;
+        if (__any(i < cnt)) {
+          const bool on = i < cnt;
+          const int e = (int)s_list[min(i, cnt - 1)];
+          const Geom g = geom_of(e >> 1);
+          const int r = e & 1;
+          epf1_strip_g(g.p + r * kBW, g.fx0, g.fy + r, r ? g.sigma1 : g.sigma0, g.bx0 == 0, g.bx0 == kBW - 4, a,
+                       [&](int c, float4 o) {
+                         if constexpr (last) {
+                           if (on) put_global(g, r, c, o);
+                         } else {
+                           held[0][0][c] = o;
+                         }
+                       });
+          if (on) held_e = e | 0x8000;
         }
       }
     }
     if constexpr (!last) {
       __syncthreads();  // every read of the stage's input is done
+      if constexpr (STAGE == 0) {
 #pragma unroll
-      for (int pass = 0; pass < kPasses; pass++) {
-        const int t = pass * kT + tid;
-        if (t >= n) continue;
-        float* d = s_buf + (kB - margin + (t / kStrips) * 2) * kBW + (t % kStrips) * 4;
+        for (int pass = 0; pass < kPasses; pass++) {
+          const int t = pass * kT + tid;
+          if (t >= n) continue;
+          float* d = s_buf + (kB - margin + (t / kStrips) * 2) * kBW + (t % kStrips) * 4;
 #pragma unroll
-        for (int r = 0; r < 2; r++)
+          for (int r = 0; r < 2; r++)
 #pragma unroll
-          for (int c = 0; c < 3; c++) lds_store4(d + c * kPlane + r * kBW, held[pass][r][c]);
+            for (int c = 0; c < 3; c++) lds_store4(d + c * kPlane + r * kBW, held[pass][r][c]);
+        }
+      } else if (held_e >= 0) {
+        const bool strip = (held_e & 0x8000) != 0;
+        const int t = strip ? (held_e & 0x7fff) >> 1 : held_e, r0 = strip ? (held_e & 1) : 0;
+        if (t < n) {
+          float* d = s_buf + (kB - margin + (t / kStrips) * 2 + r0) * kBW + (t % kStrips) * 4;
+#pragma unroll
+          for (int c = 0; c < 3; c++) lds_store4(d + c * kPlane, held[0][0][c]);
+          if (!strip) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) lds_store4(d + c * kPlane + kBW, held[0][1][c]);
+          }
+        }
+      }
+      if constexpr (STAGE != 0) {
+        if (tid == 0) {
+          s_cnt = 0;
+          s_nsw = 0;
+        }
       }
       __syncthreads();
       if (edge) {
