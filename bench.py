@@ -51,6 +51,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=8192)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the sharded-frame (strong scaling) leg")
+    ap.add_argument("--no-active", action="store_true",
+                    help="skip the all-blocks-filtered EPF population (profiling runs: one population per kernel name)")
     ap.add_argument("--no-e2e", action="store_true",
                     help="skip the PCIe-inclusive legs (pinned host coefficients -> finished planes)")
     ap.add_argument("--seed", type=int, default=3)
@@ -267,7 +269,7 @@ def main():
         # the population where EVERY 8x8 block is filtered (sharpness 7, raw_quant <= 4), same frame otherwise: the
         # spec draws leave 93 % of the blocks below EPF's MIN_SIGMA (they pass through, like epf1.rs:72-78)
         active = None
-        if args.epf == "spec" and args.epf_iters > 0:
+        if args.epf == "spec" and args.epf_iters > 0 and not args.no_active:
             ctx.set_hf_meta(wl.transform_map, np.minimum(wl.raw_quant, 4), np.full_like(wl.epf_map, 7), wl.ytox, wl.ytob)
             ak = kernel_table()
             ctx.set_hf_meta(wl.transform_map, wl.raw_quant, wl.epf_map, wl.ytox, wl.ytob)

@@ -232,9 +232,30 @@ def random_group_tiling(rng, bw, bh, mix):
     prob /= prob.sum()
     tmap = np.zeros((bh, bw), dtype=np.uint8)
     covered = np.zeros((bh, bw), dtype=bool)
+    placed_at = {}
+    # The raster-order fill below almost never finds room for a 64..256-pixel varblock (it would have to start on a
+    # still-empty 8..32-block square), so those types are seeded first: per type, as many placements as its area
+    # share of the group calls for (stochastic rounding), at free positions aligned to the varblock's own size.
+    for t in sorted((t for t in types if COVERED_X[t] * COVERED_Y[t] >= 64), key=lambda t: -COVERED_X[t] * COVERED_Y[t]):
+        cx, cy = COVERED_X[t], COVERED_Y[t]
+        want = mix[t] * bw * bh / (cx * cy)
+        count = int(want) + (1 if rng.random() < want - int(want) else 0)
+        for _ in range(count):
+            free = [(x, y) for y in range(0, bh - cy + 1, cy) for x in range(0, bw - cx + 1, cx)
+                    if not covered[y:y + cy, x:x + cx].any()]
+            if not free:
+                break
+            x, y = free[int(rng.integers(len(free)))]
+            covered[y:y + cy, x:x + cx] = True
+            tmap[y:y + cy, x:x + cx] = t
+            tmap[y, x] = t | 0x80
+            placed_at[(x, y)] = t
     blocks = []
     for by in range(bh):
         for bx in range(bw):
+            if (bx, by) in placed_at:
+                blocks.append((bx, by, placed_at[(bx, by)]))
+                continue
             if covered[by, bx]:
                 continue
             order = rng.choice(len(types), size=min(4, len(types)), replace=False, p=prob)

@@ -81,3 +81,83 @@ def test_2k_default_squeeze_chain_round_trip(ctx):
     for (horizontal, ow, oh), r in zip(steps, reversed(residuals)):
         cur = ctx.unsqueeze(horizontal, cur, r, ow, oh)
     assert np.array_equal(cur, img)
+
+
+def _band_check(ctx, oracle, wl, bands, what):
+    """whole frame on the GPU; the oracle recomputes the given bands of group rows the way a rank would"""
+    got, got_lf = run_gpu_frame(ctx, wl)
+    p = oracle_params_from(oracle, wl)
+    lf = oracle.adaptive_lf_smoothing(p, oracle.dequant_lf(p, *wl.lf_q)) if p.do_lf_smoothing else oracle.dequant_lf(p, *wl.lf_q)
+    for c in range(3):
+        assert bit_equal(got_lf[c], lf[c]), f"{what}: LF ch{c}"
+    for row0, row1 in bands:
+        band = oracle.vardct_band(p, wl.coeffs, wl.transform_map, wl.raw_quant, wl.epf_map, wl.ytox, wl.ytob, lf,
+                                  wl.tables, row0, row1)
+        y0, y1 = row0 * 256, min(row1 * 256, wl.ysize)
+        for c in range(3):
+            a, b = got[c][y0:y1], band[c][y0:y1, : wl.xsize]
+            assert bit_equal(a, b), f"{what}: rows {y0}:{y1} ch{c}: {diff_report(a, b)}"
+        del band
+    return got
+
+
+def test_4k_config2_bands_vs_oracle(ctx, oracle):
+    """BASELINE configs[1]: 4096x4096 VarDCT d1 (mixed DCT8..32), IDCT + dequant + Gaborish, EPF off"""
+    from jxl_rs_amd import synth
+    wl = synth.make_vardct(4096, 4096, mix=synth.MIX_D1, seed=402, unique_groups=24, epf_iters=0, gab=True)
+    got = _band_check(ctx, oracle, wl, ((0, 1), (6, 8), (15, 16)), "config 2")
+    assert all(np.isfinite(g).all() for g in got)
+
+
+def test_4k_all_types_epf0_bands_vs_oracle(ctx, oracle):
+    """every transform type with epf_iters = 3 (Gaborish + EPF0 + EPF1 + EPF2: the two-pass fused path) at 4096^2"""
+    from jxl_rs_amd import synth
+    wl = synth.make_vardct(4096, 4096, mix=synth.MIX_ALL, seed=403, unique_groups=24, epf_iters=3, gab=True)
+    _band_check(ctx, oracle, wl, ((3, 4), (15, 16)), "all types, EPF0")
+
+
+def test_16k_config5_bands_and_determinism(ctx, oracle):
+    """BASELINE configs[4]: 16384x16384, every one of the 27 transform types incl. DCT256 and AFV0-3"""
+    from jxl_rs_amd import synth
+    wl = synth.make_vardct(16384, 16384, mix=synth.MIX_ALL, seed=1605, unique_groups=32, epf_iters=2)
+    types = set(np.unique(wl.transform_map[wl.transform_map >= 128] & 127).tolist())
+    # DCT256X256, the 128-pixel family, the 64-pixel family, every special 8x8 type incl. AFV0-3 (the generator seeds
+    # the large types per group by area share, so one of the two 128x256 orientations may be missing for a seed)
+    assert {24, 21, 18, 1, 2, 3, 12, 13, 14, 15, 16, 17} <= types and len(types) >= 25, sorted(types)
+    got = _band_check(ctx, oracle, wl, ((0, 1), (37, 38), (63, 64)), "config 5")
+    ctx.frame_run()
+    ctx.sync()
+    again = ctx.read_planes()
+    for c in range(3):
+        assert bit_equal(again[c], got[c])
+
+
+def test_8k_modular_chain_vs_oracle(ctx, oracle):
+    """BASELINE configs[3] against the ORACLE (not only a round trip): the whole default squeeze chain of an
+    8192x8192 image on three channels (residuals as in SURVEY 8(d): Laplacian(b = 3), 8-bit averages), then the
+    YCoCg RCT; and a 256-colour palette expansion of an 8192x8192 index plane."""
+    from jxl_rs_amd import synth
+    n = 8192
+    base, residuals, steps = synth.make_modular_planes(n, n, seed=84)
+    cur_g = [b.copy() for b in base]
+    cur_o = [b.copy() for b in base]
+    for (horizontal, ow, oh), res in zip(steps, residuals):
+        cur_g = [ctx.unsqueeze(horizontal, cur_g[c], res[c], ow, oh) for c in range(3)]
+        if horizontal:
+            cur_o = [oracle.unsqueeze_h(cur_o[c], res[c], ow) for c in range(3)]
+        else:
+            cur_o = [oracle.unsqueeze_v(cur_o[c], res[c], oh) for c in range(3)]
+        for c in range(3):
+            assert np.array_equal(cur_g[c], cur_o[c]), f"unsqueeze step {'h' if horizontal else 'v'} -> {ow}x{oh}, channel {c}"
+    assert cur_g[0].shape == (n, n)
+    out_g = ctx.rct(cur_g, 6, 0)
+    out_o = oracle.rct(cur_o, 6, 0)
+    for c in range(3):
+        assert np.array_equal(out_g[c], out_o[c]), f"rct channel {c}"
+    del cur_g, cur_o, out_g, out_o
+    rng = np.random.default_rng(256)
+    pal = rng.integers(0, 256, size=(3, 256)).astype(np.int32)
+    idx = rng.integers(-3, 300, size=(n, n)).astype(np.int32)  # incl. implicit entries below 0 / beyond the palette
+    got = ctx.palette(idx, pal, 256, 3, 8)
+    want = oracle.palette(idx, pal, 256, 3, 8)
+    assert np.array_equal(got, want)

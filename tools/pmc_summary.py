@@ -32,6 +32,24 @@ def main():
         for cn in sorted(acc[k]):
             v = acc[k][cn]
             out.write(f"  {cn:28s} {sum(v) / len(v):18.1f}   (n={len(v)})\n")
+    # Derived per-kernel figures.  Normalisation (MI355X_MICROARCH.md, "rocprofv3 PMC slots" / cycle constants):
+    # SQ_* cycle counters are summed over the chip and count quad-cycles for the wave-level ones; GRBM_GUI_ACTIVE is
+    # summed over the 8 XCDs.  VALU busy = SQ_ACTIVE_INST_VALU * 4 / (1024 SIMDs) / (GRBM_GUI_ACTIVE / 8): the share
+    # of the kernel's cycles in which a SIMD's vector ALU was issuing; LDS busy = SQ_LDS_IDX_ACTIVE / (256 CUs) over the
+    # same denominator; the wait shares are fractions of SQ_WAVE_CYCLES (what a resident wavefront spends parked on
+    # s_waitcnt / barriers, issue-stalled, or issuing).
+    out.write("\nderived (see the comment in tools/pmc_summary.py for the normalisation)\n")
+    for k in sorted(acc):
+        a = {cn: sum(v) / len(v) for cn, v in acc[k].items()}
+        need = ("SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY",
+                "SQ_ACTIVE_INST_ANY", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_INSTS_VALU", "SQ_WAVES")
+        if not all(n in a for n in need) or a["GRBM_GUI_ACTIVE"] == 0 or a["SQ_WAVE_CYCLES"] == 0:
+            continue
+        cyc = a["GRBM_GUI_ACTIVE"] / 8.0
+        out.write(f"  {k:44s} kernel cycles {cyc:10.0f}  VALU busy {a['SQ_ACTIVE_INST_VALU'] * 4 / 1024 / cyc:5.1%}  "
+                  f"LDS busy {a['SQ_LDS_IDX_ACTIVE'] / 256 / cyc:5.1%} (conflict cycles {a['SQ_LDS_BANK_CONFLICT'] / max(a['SQ_LDS_IDX_ACTIVE'], 1):5.1%} of them)  "
+                  f"wave cycles: parked {a['SQ_WAIT_ANY'] / a['SQ_WAVE_CYCLES']:5.1%} issue-stalled {a['SQ_WAIT_INST_ANY'] / a['SQ_WAVE_CYCLES']:5.1%} "
+                  f"issuing {a['SQ_ACTIVE_INST_ANY'] / a['SQ_WAVE_CYCLES']:5.1%}  VALU insts/wave {a['SQ_INSTS_VALU'] / max(a['SQ_WAVES'], 1):8.0f}\n")
     # HBM traffic per launch (FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE is doubled for wide
     # coalesced reads on gfx950, MI355X_MICROARCH.md section HBM)
     traffic = {}
