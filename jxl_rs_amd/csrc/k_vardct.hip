@@ -762,44 +762,70 @@ __global__ __launch_bounds__(kSpecThreads, 2) void k1_special(const FrameDev f, 
   }
 }
 
-// family E: DCT64X64 .. DCT256X256.  Work unit = one CHANNEL of one varblock (the channels only meet
-// in the chroma-from-luma FMA, whose Y term the X / B dequantisers recompute from the Y coefficients):
-// a 256x256 varblock keeps a workgroup busy for ~50 us per channel, so the finer unit triples the
-// parallelism and cuts the kernel's tail.
-__global__ __launch_bounds__(kLargeThreads) void k1_large(const FrameDev f, const WorkLists wl) {
-  __shared__ float s_lds[2 * (kLargeSlab + 256) + 1024];
+// family E: DCT64X64 .. DCT256X256.  A 256x256 varblock is 32 slab steps of 4096 samples per channel (16 per
+// separable pass) against 2 for a 64x64 one, and pass 2 needs all of pass 1: with a whole varblock-channel as the
+// work unit the kernel was as slow as its longest workgroup (3.5 ms at 16K with the 128 / 256 sizes present).  The
+// two passes are therefore separate launches over uniform SLAB units:
+//   k1_large_units   one thread per large varblock: reserves its slabs in the unit list (item | slab << 24)
+//   k1_large_pass<1> unit = (slab of lines, channel): dequantise + LLF corner + horizontal IDCT -> output rectangle
+//   k1_large_pass<2> unit = (slab of pixel columns, channel): vertical IDCT in place
+// (the varblock's own output rectangle is the inter-pass scratch; it stays in L2 / Infinity Cache between the launches)
+__global__ __launch_bounds__(256) void k1_large_units(const WorkLists wl, uint32_t* __restrict__ units) {
   const int count = wl.counts[kClsLarge];
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < count; e += gridDim.x * blockDim.x) {
+    const int type = (int)(wl.items[kClsLarge][e].packed >> 20) & 31;
+    const int n = max(1, covered_x(type) * covered_y(type) * 64 / kLargeSlab);  // 64x32 / 32x64: half a slab
+    const int base = atomicAdd(&wl.counts[kNumClasses], n);
+    for (int s = 0; s < n; s++) units[base + s] = (uint32_t)e | ((uint32_t)s << 24);
+  }
+}
+
+#ifndef JXLH_LARGE_WPE
+#define JXLH_LARGE_WPE 4
+#endif
+template <int PASS>
+__global__ __launch_bounds__(kLargeThreads, JXLH_LARGE_WPE) void k1_large_pass(const FrameDev f, const WorkLists wl,
+                                                                const uint32_t* __restrict__ units) {
+  __shared__ float s_lds[2 * (kLargeSlab + 256) + 1024];
+  const int total = wl.counts[kNumClasses] * 3;
   const int tid = threadIdx.x;
   const float b0 = f.quant_biases[0], b1 = f.quant_biases[1], b2 = f.quant_biases[2], b3 = f.quant_biases[3];
-  for (int u = blockIdx.x; u < count * 3; u += gridDim.x) {
-    const int e = u / 3, ch = u % 3;
+  for (int u = blockIdx.x; u < total; u += gridDim.x) {
+    const uint32_t unit = units[u / 3];
+    const int e = (int)(unit & 0xffffffu), slab = (int)(unit >> 24), ch = u % 3;
     const WorkItem it = wl.items[kClsLarge][e];
     BlockInfo bi;
     decode_item(f, it, &bi);
     const int type = (int)(it.packed >> 20) & 31;
-    const int q = quant_table_for_type(type);
-    const float* __restrict__ table = f.tables + f.table_offset[q];
-    const int tsize = quant_table_size(q);
-    const int32_t* __restrict__ qx = f.coeffs + bi.coef_off;
-    const int32_t* __restrict__ qy = qx + kGroupArea;
-    const int32_t* __restrict__ qb = qx + 2 * kGroupArea;
-    const float sdy = bi.sdy, sdx = bi.sdy * f.x_dm, sdb = bi.sdy * f.b_dm;
-    const float x_cc = bi.x_cc, b_cc = bi.b_cc;
-    auto deq_y = [&](int k) { return adjust_quant_bias(qy[k], b1, b3) * (table[tsize + k] * sdy); };
+    const LargeGeom g(type);
     const PixLayout lay = pix_layout(f);
-    if (ch == 1) {
-      large_varblock_channel(type, deq_y, f.lf[1] + bi.lf_off[1], f.xblocks, f.planes[1] + bi.px_off[1], lay, s_lds, tid);
-    } else if (ch == 0) {
-      large_varblock_channel(
-          type, [&](int k) { return __builtin_fmaf(x_cc, deq_y(k), adjust_quant_bias(qx[k], b0, b3) * (table[k] * sdx)); },
-          f.lf[0] + bi.lf_off[0], f.xblocks, f.planes[0] + bi.px_off[0], lay, s_lds, tid);
+    float* plane = f.planes[ch] + bi.px_off[ch];
+    if constexpr (PASS == 2) {
+      large_pass2_slab(g, slab * g.LX, plane, lay, s_lds, tid);
     } else {
-      large_varblock_channel(
-          type,
+      const int v0 = slab * g.LV;
+      float* llf = s_lds + 2 * (kLargeSlab + 256);
+      if (g.slab_needs_llf(v0)) large_llf(f.lf[ch] + bi.lf_off[ch], f.xblocks, g.cy, g.cx, s_lds, llf, tid);
+      const int q = quant_table_for_type(type);
+      const float* __restrict__ table = f.tables + f.table_offset[q];
+      const int tsize = quant_table_size(q);
+      // one dequantiser for the three channels (the channel is uniform over the workgroup): Y alone, or the
+      // channel's own coefficient plus the chroma-from-luma multiple of the dequantised Y (group.rs:100-133)
+      const int32_t* __restrict__ qy = f.coeffs + bi.coef_off + kGroupArea;
+      const int32_t* __restrict__ qc = f.coeffs + bi.coef_off + ch * kGroupArea;
+      const float* __restrict__ ty = table + tsize;
+      const float* __restrict__ tc = table + ch * tsize;
+      const float sdy = bi.sdy, sdc = ch == 0 ? bi.sdy * f.x_dm : bi.sdy * f.b_dm;
+      const float cc = ch == 0 ? bi.x_cc : bi.b_cc, bc = ch == 0 ? b0 : b2;
+      const bool luma = ch == 1;
+      large_pass1_slab(
+          g, v0,
           [&](int k) {
-            return __builtin_fmaf(b_cc, deq_y(k), adjust_quant_bias(qb[k], b2, b3) * (table[2 * tsize + k] * sdb));
+            const float y = adjust_quant_bias(qy[k], b1, b3) * (ty[k] * sdy);
+            if (luma) return y;
+            return __builtin_fmaf(cc, y, adjust_quant_bias(qc[k], bc, b3) * (tc[k] * sdc));
           },
-          f.lf[2] + bi.lf_off[2], f.xblocks, f.planes[2] + bi.px_off[2], lay, s_lds, tid);
+          llf, plane, lay, s_lds, tid);
     }
   }
 }
@@ -811,7 +837,8 @@ size_t vardct_worklist_bytes(const FrameDev& f) {
   const size_t nblocks = (size_t)f.xblocks * f.yblocks;
   size_t items = 0;
   for (int c = 0; c < kNumClasses; c++) items += nblocks / class_min_area(c) + 1;
-  return items * sizeof(WorkItem) + 256;
+  // + the slab-unit list of the large transforms (one u32 per 4096 samples of large-varblock area)
+  return items * sizeof(WorkItem) + 256 + (nblocks / 64 + 16) * sizeof(uint32_t);
 }
 
 void launch_vardct_groups(hipStream_t s, const FrameDev& f, int group_row0, int group_row1,
@@ -828,7 +855,8 @@ void launch_vardct_groups(hipStream_t s, const FrameDev& f, int group_row0, int 
     wl.items[c] = reinterpret_cast<WorkItem*>(p);
     p += (nblocks / class_min_area(c) + 1) * sizeof(WorkItem);
   }
-  (void)hipMemsetAsync(wl.counts, 0, kNumClasses * sizeof(int), s);
+  uint32_t* large_units = reinterpret_cast<uint32_t*>(p);  // behind the last class list
+  (void)hipMemsetAsync(wl.counts, 0, (kNumClasses + 1) * sizeof(int), s);  // [kNumClasses] = slab units of the large class
   hipLaunchKernelGGL(k1_scan, dim3(ngroups), dim3(kThreads), 0, s, f, wl, group_row0, error_flag, group_list);
   // grids: enough waves to fill the chip; kernels stride over their lists (counts are device-side)
   const int nblk = ngroups * kGroupBlocks * kGroupBlocks;
@@ -863,7 +891,12 @@ void launch_vardct_groups(hipStream_t s, const FrameDev& f, int group_row0, int 
   // only queues -- and an empty special list (the d1 mix) pays for every launched workgroup
   hipLaunchKernelGGL(k1_special, dim3(grid_for((long)(nblk / kSpecChunk + 1) * kSpecBins * 3, kSpecWaves, 1024)),
                      dim3(kSpecThreads), 0, s, f, wl);
-  hipLaunchKernelGGL(k1_large, dim3(grid_for(3L * (nblk / 32), 1, 2048)), dim3(kLargeThreads), 0, s, f, wl);
+  // the large class: unit list, then one launch per separable pass; 4 workgroups fit a CU (39 KB of LDS each).  All
+  // three exit at once when the class is empty (the d1 mix)
+  hipLaunchKernelGGL(k1_large_units, dim3(grid_for(nblk / 64 + 1, 256, 64)), dim3(256), 0, s, wl, large_units);
+  const dim3 glarge(grid_for(3L * (nblk / 64 + 1), 1, 2048));
+  hipLaunchKernelGGL(k1_large_pass<1>, glarge, dim3(kLargeThreads), 0, s, f, wl, large_units);
+  hipLaunchKernelGGL(k1_large_pass<2>, glarge, dim3(kLargeThreads), 0, s, f, wl, large_units);
 }
 
 }  // namespace jxlh

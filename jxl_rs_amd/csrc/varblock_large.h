@@ -19,38 +19,69 @@ namespace jxlh {
 
 constexpr int kLargeThreads = 256;
 constexpr int kLargeSlab = 4096;  // coefficients per slab
+constexpr int kSlabIters = kLargeSlab / kLargeThreads;      // samples per thread and slab
+constexpr int kPairIters = kLargeSlab / 2 / kLargeThreads;  // butterfly pairs per thread and sweep
+// Pairs (samples: twice as many) a thread has in flight at a time: every LDS / global read of a chunk is issued before
+// the first dependent operation.  The whole slab at once (8) costs registers the IDCT_32 leaves need.
+#ifndef JXLH_LARGE_CHUNK
+#define JXLH_LARGE_CHUNK 2
+#endif
+constexpr int kChunk = JXLH_LARGE_CHUNK;
+static_assert(kPairIters % kChunk == 0, "chunking");
 
-// 1-D IDCT of size N along i for L lines; data at X[i*Lp + line].  Ping-pongs between a and b
+// 1-D IDCT of size N along i for L = 1 << lL lines; data at X[i*Lp + line].  Ping-pongs between a and b
 // and returns the buffer holding the result.  All threads of the workgroup must call.
+// Every size here is a power of two: the index arithmetic is shifts and masks (with run-time divisors it was the
+// bulk of the kernel's instructions -- ten integer divisions per sample and pass).
 template <int N>
-__device__ float* lds_idct(float* __restrict__ a, float* __restrict__ b, int L, int Lp, int tid) {
+__device__ float* lds_idct(float* __restrict__ a, float* __restrict__ b, int lL, int Lp, int tid) {
   float* src = a;
   float* dst = b;
-  // down-sweep: split every length-n sub-array into even | prefix-summed odd halves
-  for (int n = N; n > 32; n >>= 1) {
-    const int h = n / 2;
-    for (int idx = tid; idx < (N / 2) * L; idx += kLargeThreads) {
-      const int line = idx % L, p = idx / L;
-      const int s = p / h, i = p % h;
-      const int base = s * n;
-      const float e = src[(base + 2 * i) * Lp + line];
-      float o = src[(base + 2 * i + 1) * Lp + line];
-      if (i > 0) {
-        o += src[(base + 2 * i - 1) * Lp + line];
-      } else {
-        o *= kSqrt2;
+  // L <= 128 divides the workgroup size, so a thread keeps ONE line through a whole sweep and walks the pairs
+  // p = p0, p0 + pstep, ...: addresses are affine in the iteration (the generic idx -> (line, pair) arithmetic was
+  // most of this kernel's ~100 vector instructions per sample and pass)
+  const int line = tid & ((1 << lL) - 1), p0 = tid >> lL, pstep = kLargeThreads >> lL;
+  constexpr int P = N / 2;  // pairs per line
+  // down-sweep: split every length-n sub-array into even | prefix-summed odd halves.  With n = 2h and p = s*h + i:
+  // source rows 2p, 2p + 1 (and 2p - 1), destination rows p + s*h and p + s*h + h
+  auto down = [&](auto n_tag) {
+    constexpr int n = decltype(n_tag)::value;
+    if constexpr (n <= N && n > 32) {
+      constexpr int h = n / 2;
+#pragma unroll 1
+      for (int c0 = 0; c0 < kPairIters; c0 += kChunk) {
+        if (p0 + c0 * pstep >= P) break;
+        float e[kChunk], o[kChunk], om[kChunk];
+#pragma unroll
+        for (int it = 0; it < kChunk; it++) {
+          const int p = p0 + (c0 + it) * pstep;
+          const bool on = p < P;
+          const float* q = src + (2 * p) * Lp + line;
+          e[it] = on ? q[0] : 0.f;
+          o[it] = on ? q[Lp] : 0.f;
+          om[it] = (on && (p & (h - 1)) != 0) ? q[-Lp] : 0.f;
+        }
+#pragma unroll
+        for (int it = 0; it < kChunk; it++) {
+          const int p = p0 + (c0 + it) * pstep;
+          if (p < P) {
+            float* d = dst + (p + (p & ~(h - 1))) * Lp + line;  // row p + s*h
+            d[0] = e[it];
+            d[h * Lp] = (p & (h - 1)) != 0 ? o[it] + om[it] : o[it] * kSqrt2;
+          }
+        }
       }
-      dst[(base + i) * Lp + line] = e;
-      dst[(base + h + i) * Lp + line] = o;
+      __syncthreads();
+      float* t = src;
+      src = dst;
+      dst = t;
     }
-    __syncthreads();
-    float* t = src;
-    src = dst;
-    dst = t;
-  }
+  };
+  down(std::integral_constant<int, 256>{});
+  down(std::integral_constant<int, 128>{});
+  down(std::integral_constant<int, 64>{});
   // leaves: register IDCT_32 per (line, leaf), in place
-  for (int idx = tid; idx < (N / 32) * L; idx += kLargeThreads) {
-    const int line = idx % L, leaf = idx / L;
+  for (int leaf = p0; leaf < N / 32; leaf += pstep) {
     float x[32];
     float* p = src + (leaf * 32) * Lp + line;
 #pragma unroll
@@ -60,20 +91,33 @@ __device__ float* lds_idct(float* __restrict__ a, float* __restrict__ b, int L, 
     for (int j = 0; j < 32; j++) p[j * Lp] = x[j];
   }
   __syncthreads();
-  // up-sweep: out[i] = e[i] + w_i o[i], out[n-1-i] = e[i] - w_i o[i]
+  // up-sweep: out[i] = e[i] + w_i o[i], out[n-1-i] = e[i] - w_i o[i]; source rows p + s*h and p + s*h + h,
+  // destination rows p + s*h and (s + 1)*n - 1 - i
   auto sweep = [&](auto n_tag) {
     constexpr int n = decltype(n_tag)::value;
     if constexpr (n <= N) {
       constexpr int h = n / 2;
-      for (int idx = tid; idx < (N / 2) * L; idx += kLargeThreads) {
-        const int line = idx % L, p = idx / L;
-        const int s = p / h, i = p % h;
-        const int base = s * n;
-        const float e = src[(base + i) * Lp + line];
-        const float o = src[(base + h + i) * Lp + line];
-        const float w = IdctW<n>::w[i];
-        dst[(base + i) * Lp + line] = __builtin_fmaf(o, w, e);
-        dst[(base + n - 1 - i) * Lp + line] = __builtin_fmaf(-o, w, e);
+#pragma unroll 1
+      for (int c0 = 0; c0 < kPairIters; c0 += kChunk) {
+        if (p0 + c0 * pstep >= P) break;
+        float e[kChunk], o[kChunk];
+#pragma unroll
+        for (int it = 0; it < kChunk; it++) {
+          const int p = p0 + (c0 + it) * pstep;
+          const float* q = src + (p + (p & ~(h - 1))) * Lp + line;
+          e[it] = p < P ? q[0] : 0.f;
+          o[it] = p < P ? q[h * Lp] : 0.f;
+        }
+#pragma unroll
+        for (int it = 0; it < kChunk; it++) {
+          const int p = p0 + (c0 + it) * pstep;
+          if (p < P) {
+            const int i = p & (h - 1), sn = 2 * (p & ~(h - 1));  // s * n
+            const float w = IdctW<n>::w[i];
+            dst[(sn + i) * Lp + line] = __builtin_fmaf(o[it], w, e[it]);
+            dst[(sn + n - 1 - i) * Lp + line] = __builtin_fmaf(-o[it], w, e[it]);
+          }
+        }
       }
       __syncthreads();
       float* t = src;
@@ -87,12 +131,12 @@ __device__ float* lds_idct(float* __restrict__ a, float* __restrict__ b, int L, 
   return src;
 }
 
-__device__ inline float* lds_idct_dyn(int n, float* a, float* b, int L, int Lp, int tid) {
+__device__ inline float* lds_idct_dyn(int n, float* a, float* b, int lL, int Lp, int tid) {
   switch (n) {
-    case 32: return lds_idct<32>(a, b, L, Lp, tid);
-    case 64: return lds_idct<64>(a, b, L, Lp, tid);
-    case 128: return lds_idct<128>(a, b, L, Lp, tid);
-    default: return lds_idct<256>(a, b, L, Lp, tid);
+    case 32: return lds_idct<32>(a, b, lL, Lp, tid);
+    case 64: return lds_idct<64>(a, b, lL, Lp, tid);
+    case 128: return lds_idct<128>(a, b, lL, Lp, tid);
+    default: return lds_idct<256>(a, b, lL, Lp, tid);
   }
 }
 
@@ -165,77 +209,140 @@ __device__ __forceinline__ void region_xy(bool tiled, int wlog, int idx, int& x,
   }
 }
 
-// One channel of one large varblock.  coef(k) returns the dequantised coefficient at stored
-// index k; lf points at the cy x cx LF patch (row pitch lf_stride); plane at the top-left
-// output pixel (addressing given by `lay`).  lds: >= 2*(kLargeSlab + 256) + 1024 floats.
+// Geometry of a large varblock's two passes: pass 1 works on slabs of LV lines (fixed v) x all C horizontal
+// frequencies, pass 2 on slabs of LX pixel columns x all R rows; a slab is kLargeSlab samples (a 64x64 varblock is
+// one slab per pass, a 256x256 one sixteen).
+struct LargeGeom {
+  int R, C, cx, cy, mn, mx, mxRC, lc, lr, lm;
+  bool wide;
+  int LV, llv, LX, xlog;
+  __device__ explicit LargeGeom(int type) {
+    cx = covered_x(type);
+    cy = covered_y(type);
+    R = cy * 8;
+    C = cx * 8;
+    wide = R < C;
+    mxRC = max(R, C);
+    mn = min(cy, cx);
+    mx = max(cy, cx);
+    lc = 31 - __clz(C);
+    lr = 31 - __clz(R);
+    lm = max(lc, lr);
+    LV = min(R, kLargeSlab / C);
+    llv = 31 - __clz(LV);
+    LX = min(C, kLargeSlab / R);
+    xlog = 31 - __clz(LX);
+  }
+  __device__ int slabs_per_pass() const { return R / LV; }  // == C / LX; 1 for the 64x32 / 32x64 half slabs
+  // does the slab of lines [v0, v0 + LV) hold coefficients the LLF-from-LF corner overwrites (transform.rs:450)?
+  __device__ bool slab_needs_llf(int v0) const { return v0 < (wide ? mn : mx); }
+};
+
+// Pass 1 of ONE slab: lines v0 .. v0 + LV of the horizontal IDCT, result parked at pixel (row v, col x) of the
+// varblock's output rectangle.  coef(k) returns the dequantised coefficient at stored index k; llf (LDS) holds the
+// mn x mx LLF corner when the slab needs it.  lds: >= 2 * (kLargeSlab + 256) floats.  All threads must call.
+// Pass 1 of ONE slab: lines v0 .. v0 + LV of the horizontal IDCT, result parked at pixel (row v, col x) of the
+// varblock's output rectangle.  coef(k) returns the dequantised coefficient at stored index k; llf (LDS) holds the
+// mn x mx LLF corner when the slab needs it.  lds: >= 2 * (kLargeSlab + 256) floats.  All threads must call.
+// (Compile-time specialisation on (transform length, lines per slab) was measured: 233-256 VGPRs with spills and
+// no faster than this run-time geometry form at 128-181 VGPRs -- profiles/r02_e_large_path.txt.)
+template <class CoefFn>
+__device__ __forceinline__ void large_pass1_slab(const LargeGeom& g, int v0, CoefFn coef, const float* __restrict__ llf,
+                                                 float* __restrict__ plane, const PixLayout lay, float* lds, int tid) {
+  float* bufA = lds;
+  float* bufB = lds + (kLargeSlab + 256);
+  const int Lp = g.LV + 1, total = g.C << g.llv;
+#pragma unroll 1
+  for (int c0 = 0; c0 < kSlabIters; c0 += 2 * kChunk) {
+    if (c0 * kLargeThreads >= total) break;  // half slabs
+    float val[2 * kChunk];
+    int at[2 * kChunk];
+#pragma unroll
+    for (int it = 0; it < 2 * kChunk; it++) {  // unrolled: the chunk's coefficient loads are all in flight together
+      const int idx = (c0 + it) * kLargeThreads + tid;
+      // wide: stored in[v*C + u], u fastest in memory; otherwise in[u*R + v], v fastest
+      const int u = g.wide ? (idx & (g.C - 1)) : (idx >> g.llv), line = g.wide ? (idx >> g.lc) : (idx & (g.LV - 1));
+      const int v = v0 + line;
+      const int k = g.wide ? (v << g.lc) + u : (u << g.lr) + v;
+      const int kr = k >> g.lm, kq = k & (g.mxRC - 1);
+      at[it] = u * Lp + line;
+      // LLF overwrites the HF-decoded corner (transform.rs:450)
+      val[it] = (kr < g.mn && kq < g.mx) ? llf[kr * g.mx + kq] : coef(k);
+    }
+#pragma unroll
+    for (int it = 0; it < 2 * kChunk; it++) bufA[at[it]] = val[it];
+  }
+  __syncthreads();
+  float* res = lds_idct_dyn(g.C, bufA, bufB, g.llv, Lp, tid);
+#pragma unroll 1
+  for (int c0 = 0; c0 < kSlabIters; c0 += 2 * kChunk) {
+    if (c0 * kLargeThreads >= total) break;
+#pragma unroll
+    for (int it = 0; it < 2 * kChunk; it++) {
+      const int idx = (c0 + it) * kLargeThreads + tid;
+      int x, line;
+      region_xy(lay.tiled, g.lc, idx, x, line);
+      plane[lay.at(x, v0 + line)] = res[x * Lp + line];
+    }
+  }
+  __syncthreads();
+}
+
+// Pass 2 of ONE slab: pixel columns x0 .. x0 + LX, vertical IDCT in place in the output rectangle.
+__device__ __forceinline__ void large_pass2_slab(const LargeGeom& g, int x0, float* __restrict__ plane,
+                                                 const PixLayout lay, float* lds, int tid) {
+  float* bufA = lds;
+  float* bufB = lds + (kLargeSlab + 256);
+  const int Lp = g.LX + 1, total = g.R << g.xlog;
+#pragma unroll 1
+  for (int c0 = 0; c0 < kSlabIters; c0 += 2 * kChunk) {
+    if (c0 * kLargeThreads >= total) break;
+    float val[2 * kChunk];
+#pragma unroll
+    for (int it = 0; it < 2 * kChunk; it++) {
+      const int idx = (c0 + it) * kLargeThreads + tid;
+      int line, v;
+      region_xy(lay.tiled, g.xlog, idx, line, v);
+      val[it] = plane[lay.at(x0 + line, v)];
+    }
+#pragma unroll
+    for (int it = 0; it < 2 * kChunk; it++) {
+      const int idx = (c0 + it) * kLargeThreads + tid;
+      int line, v;
+      region_xy(lay.tiled, g.xlog, idx, line, v);
+      bufA[v * Lp + line] = val[it];
+    }
+  }
+  __syncthreads();
+  float* res = lds_idct_dyn(g.R, bufA, bufB, g.xlog, Lp, tid);
+#pragma unroll 1
+  for (int c0 = 0; c0 < kSlabIters; c0 += 2 * kChunk) {
+    if (c0 * kLargeThreads >= total) break;
+#pragma unroll
+    for (int it = 0; it < 2 * kChunk; it++) {
+      const int idx = (c0 + it) * kLargeThreads + tid;
+      int line, y;
+      region_xy(lay.tiled, g.xlog, idx, line, y);
+      plane[lay.at(x0 + line, y)] = res[y * Lp + line];
+    }
+  }
+  __syncthreads();
+}
+
+// One channel of one large varblock, both passes by one workgroup (stage hook; the frame path runs the passes as
+// separate launches over slab units, k_vardct.hip).  lf points at the cy x cx LF patch (row pitch lf_stride); plane
+// at the top-left output pixel (addressing given by `lay`).  lds: >= 2*(kLargeSlab + 256) + 1024 floats.
 // All threads of the (256-thread) workgroup must call with identical arguments.
 template <class CoefFn>
 __device__ void large_varblock_channel(int type, CoefFn coef, const float* __restrict__ lf, int lf_stride,
                                        float* __restrict__ plane, const PixLayout lay, float* lds, int tid) {
-  const int cx = covered_x(type), cy = covered_y(type);
-  const int R = cy * 8, C = cx * 8;
-  const bool wide = R < C;
-  const int mxRC = max(R, C);
-  const int mn = min(cy, cx), mx = max(cy, cx);
-  float* bufA = lds;
-  float* bufB = lds + (kLargeSlab + 256);
+  const LargeGeom g(type);
   float* llf = lds + 2 * (kLargeSlab + 256);
-  large_llf(lf, lf_stride, cy, cx, bufA, llf, tid);
-  // ---------------- pass 1: along u (size C) for lines v
-  {
-    const int LV = min(R, kLargeSlab / C);
-    const int Lp = LV + 1;
-    for (int v0 = 0; v0 < R; v0 += LV) {
-      for (int idx = tid; idx < C * LV; idx += kLargeThreads) {
-        int u, line;
-        if (wide) {  // stored in[v*C + u]: u fastest in memory
-          u = idx % C;
-          line = idx / C;
-        } else {     // stored in[u*R + v]: v fastest
-          line = idx % LV;
-          u = idx / LV;
-        }
-        const int v = v0 + line;
-        const int k = wide ? v * C + u : u * R + v;
-        const int kr = k / mxRC, kq = k % mxRC;
-        // LLF overwrites the HF-decoded corner (transform.rs:450)
-        bufA[u * Lp + line] = (kr < mn && kq < mx) ? llf[kr * mx + kq] : coef(k);
-      }
-      __syncthreads();
-      float* res = lds_idct_dyn(C, bufA, bufB, LV, Lp, tid);
-      // park tmp[x][v] at pixel (row v, col x) of the output rectangle
-      const int clog = 31 - __clz(C);
-      for (int idx = tid; idx < C * LV; idx += kLargeThreads) {
-        int x, line;
-        region_xy(lay.tiled, clog, idx, x, line);
-        plane[lay.at(x, v0 + line)] = res[x * Lp + line];
-      }
-      __syncthreads();
-    }
-  }
+  large_llf(lf, lf_stride, g.cy, g.cx, lds, llf, tid);
+  for (int v0 = 0; v0 < g.R; v0 += g.LV) large_pass1_slab(g, v0, coef, llf, plane, lay, lds, tid);
   __threadfence_block();
   __syncthreads();
-  // ---------------- pass 2: along v (size R) for pixel columns x
-  {
-    const int LX = min(C, kLargeSlab / R);
-    const int Lp = LX + 1;
-    for (int x0 = 0; x0 < C; x0 += LX) {
-      const int xlog = 31 - __clz(LX);
-      for (int idx = tid; idx < R * LX; idx += kLargeThreads) {
-        int line, v;
-        region_xy(lay.tiled, xlog, idx, line, v);
-        bufA[v * Lp + line] = plane[lay.at(x0 + line, v)];
-      }
-      __syncthreads();
-      float* res = lds_idct_dyn(R, bufA, bufB, LX, Lp, tid);
-      for (int idx = tid; idx < R * LX; idx += kLargeThreads) {
-        int line, y;
-        region_xy(lay.tiled, xlog, idx, line, y);
-        plane[lay.at(x0 + line, y)] = res[y * Lp + line];
-      }
-      __syncthreads();
-    }
-  }
+  for (int x0 = 0; x0 < g.C; x0 += g.LX) large_pass2_slab(g, x0, plane, lay, lds, tid);
   __threadfence_block();
   __syncthreads();
 }
