@@ -51,6 +51,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=8192)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the sharded-frame (strong scaling) leg")
+    ap.add_argument("--strong-at-1", action="store_true",
+                    help="run the sharded-frame leg with a single rank too (validation of the RCCL path on a 1-GPU box; "
+                         "needs a torch.distributed.run launch)")
     ap.add_argument("--no-active", action="store_true",
                     help="skip the all-blocks-filtered EPF population (profiling runs: one population per kernel name)")
     ap.add_argument("--no-e2e", action="store_true",
@@ -159,7 +162,7 @@ def main():
 
     # ---- strong leg (N > 1): one frame sharded by bands of group rows, halo exchange + all-gather in the timed region
     strong = None
-    if world > 1 and not args.no_strong:
+    if (world > 1 or (args.strong_at_1 and dist is not None)) and not args.no_strong:
         from jxl_rs_amd import lib as jl
         swl = wl if rank == 0 else synth.make_vardct(size, size, mix=mix, seed=args.seed, unique_groups=24,
                                                      epf_iters=args.epf_iters, gab=True, lf_smoothing=True)

@@ -99,7 +99,7 @@ typedef struct {
  *                           each, AddNoiseStage with ColorCorrelationParams::y_to_x_lf / y_to_b_lf
  *                           (render/stages/noise.rs, frame/render.rs:673-683)
  *   epf_sigma_for_modular .. RestorationFilter field used when EPF runs on a Modular frame
- *                           (features/epf.rs:81-84); carried for completeness, VarDCT frames ignore it
+ *                           (features/epf.rs:81-84): jxlh_modular_frame_filters; VarDCT frames ignore it
  */
 typedef struct {
   uint32_t abi_version; /* JXLH_ABI_VERSION */
@@ -399,6 +399,11 @@ jxlh_status jxlh_rct(jxlh_ctx* ctx, int32_t* p0, int32_t* p1, int32_t* p2, size_
 jxlh_status jxlh_palette(jxlh_ctx* ctx, const int32_t* index, size_t n, const int32_t* palette,
                          int32_t num_colors, size_t palette_stride, int32_t nb_channels,
                          int32_t bit_depth, int32_t* out);
+/* The same on a run of n samples of a larger image (device pointers only): channel c of the run is written at
+ * out + c * out_channel_stride, so a rank can expand its share of the index plane straight into full-size planes. */
+jxlh_status jxlh_palette_strided(jxlh_ctx* ctx, const int32_t* index, size_t n, const int32_t* palette,
+                                 int32_t num_colors, size_t palette_stride, int32_t nb_channels, int32_t bit_depth,
+                                 int32_t* out, size_t out_channel_stride);
 /* do_palette_step_general with delta entries and / or a neighbour predictor (palette.rs:228-251): index is w x h,
  * entries below num_deltas are added to Predictor::predict_one (modular/predict.rs:152-198; predictor = Predictor
  * as u32, 6 = Weighted is JXLH_ERR_UNSUPPORTED) of the already reconstructed neighbours, palette_size =
@@ -465,6 +470,24 @@ jxlh_status jxlh_frames_allgather_local(jxlh_ctx* const peers[], int32_t nranks)
 /* In-place all-gather of a device buffer of nranks * bytes_per_rank bytes (rank r's part at r * bytes_per_rank), on the
  * context's stream: the join of band-sharded Modular work (RCT / Palette on row bands of whole planes). */
 jxlh_status jxlh_comm_allgather(jxlh_ctx* ctx, void* buf, size_t bytes_per_rank);
+/* the same for an in-process group: bufs[i] = rank i's copy of the buffer */
+jxlh_status jxlh_comm_allgather_local(jxlh_ctx* const peers[], int32_t nranks, void* const bufs[], size_t bytes_per_rank);
+/* Modular across GPUs.  RCT and the non-delta Palette are per-sample: a rank runs jxlh_rct /
+ * jxlh_palette on its contiguous share of the samples (any split the caller likes; jxl_rs_amd/shard.py uses
+ * ceil(n / nranks) rounded up to 4 samples so that every share starts 16-byte aligned) and the planes are joined with
+ * jxlh_comm_allgather.  Squeeze is NOT sharded: the recurrence along a line is a serial dependency chain, and the
+ * kernel's time is that chain's latency (one full-resolution vertical step takes 0.46 ms for one plane and for three,
+ * profiles/r02_h_modular.txt) -- giving each GPU fewer lines leaves the chain as long as it was, so N GPUs run N
+ * images (or the channels of one) as replicas instead. */
+
+/* Gaborish / EPF on a Modular frame (a lossless or lossy-modular frame whose restoration filter is on): the stage list
+ * of frame/render.rs:569-622 on three f32 planes the caller holds on the device (the output of jxlh_modular_to_f32 /
+ * jxlh_modular_xyb_to_f32), with the CONSTANT sigma of features/epf.rs:81-84 -- INV_SIGMA_NUM / epf_sigma_for_modular
+ * for every pixel -- instead of the per-block map a VarDCT frame derives from its quantisation field.  Uses gab, gab_w*,
+ * epf_iters and the epf_* fields of p; w x h samples per plane, row stride `stride` floats (a multiple of 4; planes
+ * 16-byte aligned); the result is written to out[], in[] may be overwritten (epf_iters == 3). */
+jxlh_status jxlh_modular_frame_filters(jxlh_ctx* ctx, const jxlh_frame_params* p, float* const in[3],
+                                       float* const out[3], uint32_t w, uint32_t h, size_t stride);
 
 /* library info */
 uint32_t jxlh_abi_version(void);

@@ -10,6 +10,26 @@
 
 #include "jxlh_ctx.h"
 
+namespace jxlh_host {
+// the restoration filter's header fields in the form the kernels take them
+void set_filter_params(FrameDev& f, const jxlh_frame_params& p) {
+  for (int c = 0; c < 3; c++) {  // GaborishStage::new, gaborish.rs:20-27
+    const float total = 1.0f + p.gab_w1[c] * 4.0f + p.gab_w2[c] * 4.0f;
+    f.gab_k[c][0] = 1.0f / total;
+    f.gab_k[c][1] = p.gab_w1[c] / total;
+    f.gab_k[c][2] = p.gab_w2[c] / total;
+    f.epf_channel_scale[c] = p.epf_channel_scale[c];
+  }
+  const float sigma_scale[3] = {p.epf_pass0_sigma_scale, 1.0f, p.epf_pass2_sigma_scale};  // render.rs:599-621
+  for (int s = 0; s < 3; s++) {
+    f.epf_sm[s] = sigma_scale[s] * 1.65f;  // epf1.rs:67-68
+    f.epf_bsm[s] = f.epf_sm[s] * p.epf_border_sad_mul;
+  }
+  f.epf_iters = (int)p.epf_iters;
+  f.gab = (int)p.gab;
+}
+}  // namespace jxlh_host
+
 extern "C" {
 
 uint32_t jxlh_abi_version(void) { return JXLH_ABI_VERSION; }
@@ -266,20 +286,7 @@ jxlh_status jxlh_frame_begin(jxlh_ctx* ctx, const jxlh_frame_params* p) {
   f.color_factor = (float)p->color_factor;
   f.base_x = p->base_correlation_x;
   f.base_b = p->base_correlation_b;
-  for (int c = 0; c < 3; c++) {  // GaborishStage::new, gaborish.rs:20-27
-    const float total = 1.0f + p->gab_w1[c] * 4.0f + p->gab_w2[c] * 4.0f;
-    f.gab_k[c][0] = 1.0f / total;
-    f.gab_k[c][1] = p->gab_w1[c] / total;
-    f.gab_k[c][2] = p->gab_w2[c] / total;
-    f.epf_channel_scale[c] = p->epf_channel_scale[c];
-  }
-  const float sigma_scale[3] = {p->epf_pass0_sigma_scale, 1.0f, p->epf_pass2_sigma_scale};  // render.rs:599-621
-  for (int s = 0; s < 3; s++) {
-    f.epf_sm[s] = sigma_scale[s] * 1.65f;  // epf1.rs:67-68
-    f.epf_bsm[s] = f.epf_sm[s] * p->epf_border_sad_mul;
-  }
-  f.epf_iters = (int)p->epf_iters;
-  f.gab = (int)p->gab;
+  set_filter_params(f, *p);
   ctx->in_frame = true;
   // dequant tables persist across frames until replaced (library tables are per-decoder,
   // quant_weights.rs:356-374)
@@ -1380,6 +1387,52 @@ jxlh_status jxlh_stage_epf(jxlh_ctx* ctx, int32_t stage, const jxlh_frame_params
   return JXLH_OK;
 }
 
+jxlh_status jxlh_modular_frame_filters(jxlh_ctx* ctx, const jxlh_frame_params* p, float* const in[3],
+                                       float* const out[3], uint32_t w, uint32_t h, size_t stride) {
+  if (!ctx || !p || !in || !out || stride < w || (stride & 3) || p->epf_iters > 3) return JXLH_ERR_INVALID_ARGUMENT;
+  for (int c = 0; c < 3; c++) {
+    if (!in[c] || !out[c] || in[c] == out[c] || !is_device_ptr(in[c]) || !is_device_ptr(out[c]) ||
+        (reinterpret_cast<uintptr_t>(in[c]) & 15) || (reinterpret_cast<uintptr_t>(out[c]) & 15))
+      return JXLH_ERR_INVALID_ARGUMENT;
+  }
+  if (!(p->epf_sigma_for_modular > 0.0f)) return JXLH_ERR_INVALID_ARGUMENT;
+  if (w == 0 || h == 0) return JXLH_OK;
+  FrameDev f{};
+  f.xsize = (int)w;
+  f.ysize = (int)h;
+  f.xblocks = (int)((w + 7) / 8);
+  f.yblocks = (int)((h + 7) / 8);
+  f.plane_stride = stride;
+  f.tiled = 0;
+  set_filter_params(f, *p);
+  for (int c = 0; c < 3; c++) {
+    f.planes[c] = in[c];
+    f.tmp[c] = out[c];
+  }
+  // SigmaSource::Constant (features/epf.rs:81-84): one value for every block
+  const size_t nb = (size_t)f.xblocks * f.yblocks;
+  if (jxlh_status st = ensure(ctx, ctx->hook_f[7], nb)) return st;
+  if (f.epf_iters > 0) {
+    const float sigma = kInvSigmaNum / p->epf_sigma_for_modular;
+    std::vector<float> host(nb, sigma);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->hook_f[7].p, host.data(), nb * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // `host` goes out of scope
+  }
+  f.inv_sigma = ctx->hook_f[7].p;
+  int where;
+  {
+    ScopedKernelTimer t(ctx, "k23_fused_filters");
+    where = launch_fused_filters(ctx->stream, f, 0, (int)h);
+  }
+  HIPCHK(ctx, hipGetLastError());
+  if (where != 1) {  // no stage at all, or a stage list that ends in its input planes (epf_iters == 3)
+    for (int c = 0; c < 3; c++)
+      HIPCHK(ctx, hipMemcpy2DAsync(out[c], stride * sizeof(float), in[c], stride * sizeof(float), (size_t)w * sizeof(float), h,
+                                   hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  return JXLH_OK;
+}
+
 jxlh_status jxlh_stage_lf_smooth(jxlh_ctx* ctx, const jxlh_frame_params* p, const float* const in[3],
                                  float* const out[3], uint32_t w, uint32_t h) {
   if (!ctx || !p || !in || !out || p->global_scale == 0 || p->quant_lf == 0) return JXLH_ERR_INVALID_ARGUMENT;
@@ -1561,6 +1614,21 @@ jxlh_status jxlh_palette(jxlh_ctx* ctx, const int32_t* index, size_t n, const in
                  bit_depth, ctx->hook_i[2].p);
   HIPCHK(ctx, hipGetLastError());
   return stage_out(ctx, out, (const int32_t*)ctx->hook_i[2].p, n * nb_channels);
+}
+
+jxlh_status jxlh_palette_strided(jxlh_ctx* ctx, const int32_t* index, size_t n, const int32_t* palette,
+                                 int32_t num_colors, size_t palette_stride, int32_t nb_channels, int32_t bit_depth,
+                                 int32_t* out, size_t out_channel_stride) {
+  if (!ctx || !index || !palette || !out || num_colors < 0 || nb_channels < 1 || nb_channels > 64 || bit_depth < 1 ||
+      bit_depth > 24 || palette_stride < (size_t)num_colors || out_channel_stride < n)
+    return JXLH_ERR_INVALID_ARGUMENT;
+  if (!is_device_ptr(index) || !is_device_ptr(palette) || !is_device_ptr(out)) return JXLH_ERR_INVALID_ARGUMENT;
+  if (n == 0) return JXLH_OK;
+  ScopedKernelTimer t(ctx, "k5_palette");
+  launch_palette(ctx->stream, index, n, palette, num_colors, palette_stride, nb_channels, bit_depth, out,
+                 out_channel_stride);
+  HIPCHK(ctx, hipGetLastError());
+  return JXLH_OK;
 }
 
 jxlh_status jxlh_palette_delta(jxlh_ctx* ctx, const int32_t* index, uint32_t w, uint32_t h, const int32_t* palette,

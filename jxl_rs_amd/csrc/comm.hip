@@ -336,6 +336,32 @@ jxlh_status jxlh_comm_allgather(jxlh_ctx* ctx, void* buf, size_t bytes_per_rank)
   return JXLH_OK;
 }
 
+jxlh_status jxlh_comm_allgather_local(jxlh_ctx* const peers[], int32_t n, void* const bufs[], size_t bytes_per_rank) {
+  if (!peers || !bufs || n < 1) return JXLH_ERR_INVALID_ARGUMENT;
+  for (int i = 0; i < n; i++)
+    if (!peers[i] || !bufs[i] || !peers[i]->comm || peers[i]->comm->nccl || peers[i]->comm->nranks != n ||
+        peers[i]->comm->rank != i)
+      return JXLH_ERR_BAD_STATE;
+  // every rank's part is final once its stream reaches this point ...
+  for (int i = 0; i < n; i++) {
+    HIPCHK(peers[i], hipSetDevice(peers[i]->device));
+    HIPCHK(peers[i], hipEventRecord(peers[i]->comm->done_ev, peers[i]->stream));
+  }
+  // ... and every rank pulls the other ranks' parts
+  for (int i = 0; i < n; i++) {
+    jxlh_ctx* dst = peers[i];
+    HIPCHK(dst, hipSetDevice(dst->device));
+    for (int k = 0; k < n; k++) {
+      if (k == i) continue;
+      HIPCHK(dst, hipStreamWaitEvent(dst->stream, peers[k]->comm->done_ev, 0));
+      HIPCHK(dst, hipMemcpyAsync(static_cast<char*>(bufs[i]) + (size_t)k * bytes_per_rank,
+                                 static_cast<const char*>(bufs[k]) + (size_t)k * bytes_per_rank, bytes_per_rank,
+                                 hipMemcpyDefault, dst->stream));
+    }
+  }
+  return JXLH_OK;
+}
+
 // ---- local transport -----------------------------------------------------------------------------------------
 jxlh_status jxlh_frames_run_sharded_local(jxlh_ctx* const peers[], int32_t n) {
   if (!peers || n < 1) return JXLH_ERR_INVALID_ARGUMENT;

@@ -234,6 +234,7 @@ inline int result_in_tmp(const jxlh_ctx* ctx) {
   if (!(ctx->params.flags & JXLH_FRAME_UNFUSED_FILTERS)) return f.epf_iters >= 3 ? 0 : 1;
   return ns & 1;
 }
+void set_filter_params(FrameDev& f, const jxlh_frame_params& p);
 // comm.hip
 void comm_release(jxlh_ctx* ctx);
 int comm_nranks(const jxlh_ctx* ctx);

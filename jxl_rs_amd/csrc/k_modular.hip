@@ -284,7 +284,8 @@ constexpr int kPalLdsEntries = 12288;  // 48 KB
 template <bool LDS_PAL>
 __global__ __launch_bounds__(256) void k5_palette(const int32_t* __restrict__ index, size_t n,
                                                   const int32_t* __restrict__ palette_g, int num_colors, size_t pstride_g,
-                                                  int nb_channels, int bit_depth, int32_t* __restrict__ out) {
+                                                  int nb_channels, int bit_depth, int32_t* __restrict__ out,
+                                                  size_t ostride) {
   __shared__ int32_t s_pal[LDS_PAL ? kPalLdsEntries : 1];
   const int32_t* palette = palette_g;
   size_t pstride = pstride_g;
@@ -305,10 +306,10 @@ __global__ __launch_bounds__(256) void k5_palette(const int32_t* __restrict__ in
       v.y = palette_value(palette, pstride, idx.y, c, num_colors, bit_depth);
       v.z = palette_value(palette, pstride, idx.z, c, num_colors, bit_depth);
       v.w = palette_value(palette, pstride, idx.w, c, num_colors, bit_depth);
-      if ((n & 3) == 0) {
-        reinterpret_cast<int4*>(out + (size_t)c * n)[i] = v;
+      if ((ostride & 3) == 0) {
+        reinterpret_cast<int4*>(out + (size_t)c * ostride)[i] = v;
       } else {  // channel planes are only 4-byte aligned
-        int32_t* o = out + (size_t)c * n + i * 4;
+        int32_t* o = out + (size_t)c * ostride + i * 4;
         o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
       }
     }
@@ -316,7 +317,7 @@ __global__ __launch_bounds__(256) void k5_palette(const int32_t* __restrict__ in
   for (size_t i = nvec * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const int32_t idx = index[i];
     for (int c = 0; c < nb_channels; c++)
-      out[(size_t)c * n + i] = palette_value(palette, pstride, idx, c, num_colors, bit_depth);
+      out[(size_t)c * ostride + i] = palette_value(palette, pstride, idx, c, num_colors, bit_depth);
   }
 }
 
@@ -366,6 +367,9 @@ struct SqueezePlanes {
   int32_t* out[3];
 };
 
+#ifndef JXLH_SQ_U
+#define JXLH_SQ_U 16
+#endif
 template <bool HVEC>
 __global__ __launch_bounds__(64) void k6_unsqueeze(const SqueezePlanes pl, size_t avg_lp, size_t avg_ep, size_t res_lp,
                                                    size_t res_ep, size_t out_lp, size_t out_ep, int n_lines,
@@ -383,7 +387,7 @@ __global__ __launch_bounds__(64) void k6_unsqueeze(const SqueezePlanes pl, size_
   const bool has_tail = n_out & 1;
   int32_t cur = a[0];
   int32_t prev_b = cur;  // first `prev` is avg[0] (squeeze.rs:411-414, :591-594)
-  constexpr int U = 16;
+  constexpr int U = JXLH_SQ_U;  // steps whose inputs are requested ahead (two such blocks are in flight)
   // main body: next_avg = avg[i+1] exists for i < w-1 (or i < w with a tail)
   const int n_main = has_tail ? w : w - 1;
   const int n_blocks = n_main / U;
@@ -483,17 +487,18 @@ void launch_rct(hipStream_t s, int32_t* p0, int32_t* p1, int32_t* p2, size_t n, 
 }
 
 void launch_palette(hipStream_t s, const int32_t* index, size_t n, const int32_t* palette, int num_colors,
-                    size_t palette_stride, int nb_channels, int bit_depth, int32_t* out) {
+                    size_t palette_stride, int nb_channels, int bit_depth, int32_t* out, size_t out_channel_stride) {
   if (n == 0) return;
+  const size_t ostride = out_channel_stride ? out_channel_stride : n;
   if (num_colors > 0 && (size_t)num_colors * nb_channels <= (size_t)kPalLdsEntries) {
     // persistent grid (the palette is staged once per workgroup): 3 workgroups of 48 KB LDS per CU
     const unsigned grid = (unsigned)min((size_t)768, (n / 4 + 255) / 256 + 1);
     hipLaunchKernelGGL(k5_palette<true>, dim3(grid), dim3(256), 0, s, index, n, palette, num_colors, palette_stride,
-                       nb_channels, bit_depth, out);
+                       nb_channels, bit_depth, out, ostride);
   } else {
     const unsigned grid = (unsigned)min((size_t)8192, (n + 255) / 256);
     hipLaunchKernelGGL(k5_palette<false>, dim3(grid), dim3(256), 0, s, index, n, palette, num_colors, palette_stride,
-                       nb_channels, bit_depth, out);
+                       nb_channels, bit_depth, out, ostride);
   }
 }
 

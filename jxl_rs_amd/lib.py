@@ -48,6 +48,7 @@ ABI_SYMBOLS = [
     "jxlh_comm_unique_id", "jxlh_comm_init", "jxlh_comm_init_local", "jxlh_comm_destroy", "jxlh_comm_band",
     "jxlh_frame_run_sharded", "jxlh_frame_allgather", "jxlh_frames_run_sharded_local", "jxlh_frames_allgather_local",
     "jxlh_comm_allgather", "jxlh_probe_copy_bandwidth", "jxlh_frame_rerender_groups",
+    "jxlh_comm_allgather_local", "jxlh_palette_strided", "jxlh_modular_frame_filters",
 ]
 
 
@@ -180,6 +181,9 @@ def load():
     L.jxlh_comm_allgather.argtypes = [vp, vp, sz]
     L.jxlh_probe_copy_bandwidth.argtypes = [vp, sz, i32, fp]
     L.jxlh_frame_rerender_groups.argtypes = [vp, vp, u32]
+    L.jxlh_comm_allgather_local.argtypes = [C.POINTER(vp), i32, C.POINTER(vp), sz]
+    L.jxlh_palette_strided.argtypes = [vp, vp, sz, vp, i32, sz, i32, i32, vp, sz]
+    L.jxlh_modular_frame_filters.argtypes = [vp, C.POINTER(FrameParams), C.POINTER(vp), C.POINTER(vp), u32, u32, sz]
     for name in ("jxlh_covered_blocks_x", "jxlh_covered_blocks_y", "jxlh_quant_table_for_type",
                  "jxlh_quant_table_size"):
         getattr(L, name).argtypes = [i32]
@@ -218,6 +222,14 @@ def frames_allgather_local(ctxs):
     st = ctxs[0].L.jxlh_frames_allgather_local(_ctx_array(ctxs), len(ctxs))
     if st != OK:
         raise JxlHipError(st, "jxlh_frames_allgather_local", ctxs[0].L.jxlh_last_error(ctxs[0]._ctx).decode())
+
+
+def comm_allgather_local(ctxs, bufs, bytes_per_rank):
+    """in-place all-gather of one buffer per in-process rank (bufs[i]: device pointer / tensor of rank i)"""
+    arr = (C.c_void_p * len(bufs))(*[_addr(b).value for b in bufs])
+    st = ctxs[0].L.jxlh_comm_allgather_local(_ctx_array(ctxs), len(ctxs), arr, bytes_per_rank)
+    if st != OK:
+        raise JxlHipError(st, "jxlh_comm_allgather_local")
 
 
 def _addr(a):

@@ -30,3 +30,13 @@ def assemble(gathered, ygroups, world, ysize, group_dim=256):
         if y1 > y0:
             chunks.append(gathered[r][:, : y1 - y0, :])
     return np.concatenate(chunks, axis=1) if chunks else None
+
+
+def sample_share(n, rank, world, align=4):
+    """[i0, i1) samples of a per-sample Modular transform (RCT, non-delta Palette) that `rank` runs; shares are
+    ceil(n / world) rounded up to `align` samples (16-byte aligned starts for the vectorised kernels), the count per
+    rank being what the in-place all-gather moves (the buffers must hold world * count samples)."""
+    count = -(-n // world)
+    count = -(-count // align) * align
+    i0 = min(rank * count, n)
+    return i0, min(i0 + count, n), count

@@ -146,3 +146,40 @@ def test_rerender_before_any_render_renders_the_frame(ctx, oracle):
     ctx.slot_wait(0)
     ctx.rerender_groups([0])
     check(ctx, oracle_frame(oracle, wl, wl.coeffs), "rerender as the first render")
+
+
+@pytest.mark.parametrize("epf_iters,gab", [(2, True), (1, False), (3, True), (0, True), (0, False)])
+def test_modular_frame_filters_constant_sigma(ctx, oracle, epf_iters, gab):
+    """Gaborish / EPF on a Modular frame: SigmaSource::Constant(INV_SIGMA_NUM / epf_sigma_for_modular)
+    (features/epf.rs:81-84) for every pixel, on caller-held device planes"""
+    import ctypes as C
+    from helpers import DeviceArray
+    w, h, stride = 301, 217, 304
+    rng = np.random.default_rng(5 + epf_iters)
+    planes = [np.zeros((h, stride), np.float32) for _ in range(3)]
+    for c in range(3):
+        planes[c][:, :w] = (rng.random((h, w)) * (0.1 if c == 0 else 1.0)).astype(np.float32)
+        planes[c][:, :w] += np.float32(0.2) * (np.arange(w) // 16 % 2)[None, :]  # edges for the filter to see
+    p = ctx.default_params(w, h)
+    p.epf_iters, p.gab = epf_iters, 1 if gab else 0
+    p.epf_sigma_for_modular = 0.7
+    po = oracle.default_params(w, h)
+    po.epf_iters, po.gab = epf_iters, 1 if gab else 0
+    sigma = np.full(((h + 7) // 8, (w + 7) // 8), np.float32(-1.1715728752538099024) / np.float32(0.7), dtype=np.float32)
+    cur = [pl[:, :w].copy() for pl in planes]
+    if gab:
+        cur = [oracle.gaborish(cur[c], po.gab_w1[c], po.gab_w2[c]) for c in range(3)]
+    for stage, need in ((0, 3), (1, 1), (2, 2)):
+        if epf_iters >= need:
+            cur = oracle.epf(stage, po, cur, sigma)
+    tin = [DeviceArray(pl) for pl in planes]
+    tout = [DeviceArray(nbytes=h * stride * 4) for _ in range(3)]
+    vin = (C.c_void_p * 3)(*[t.ptr for t in tin])
+    vout = (C.c_void_p * 3)(*[t.ptr for t in tout])
+    ctx._chk(ctx.L.jxlh_modular_frame_filters(ctx._ctx, C.byref(p), vin, vout, w, h, stride), "modular_frame_filters")
+    ctx.sync()
+    for c in range(3):
+        got = tout[c].download(np.float32, h * stride).reshape(h, stride)[:, :w]
+        assert bit_equal(got, cur[c]), f"channel {c}: {diff_report(got, cur[c])}"
+    for t in tin + tout:
+        t.free()

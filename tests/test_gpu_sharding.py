@@ -136,3 +136,58 @@ def test_rccl_transport_single_rank(oracle):
         c.sync()
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("n", [2, 3])
+def test_modular_rct_and_palette_band_sharded(oracle, n):
+    """RCT / non-delta Palette across ranks: every rank transforms its share of the samples, the planes are joined
+    with the in-place all-gather; every rank must end with the oracle's whole planes."""
+    import ctypes as C
+    import jxl_rs_amd
+    from helpers import DeviceArray
+    from jxl_rs_amd import lib
+    from jxl_rs_amd.shard import sample_share
+    rng = np.random.default_rng(90 + n)
+    h, w = 777, 1001
+    total = h * w
+    planes = [rng.integers(-300, 300, size=total).astype(np.int32) for _ in range(3)]
+    want = oracle.rct([p.reshape(h, w) for p in planes], 6, 3)
+    pal = rng.integers(0, 256, size=(3, 200)).astype(np.int32)
+    idx = rng.integers(-2, 260, size=total).astype(np.int32)  # incl. implicit entries on both sides
+    want_pal = oracle.palette(idx.reshape(h, w), pal, 200, 3, 8)
+    ctxs = [jxl_rs_amd.Context(0, 1) for _ in range(n)]
+    bufs = []
+    try:
+        lib.comm_init_local(ctxs)
+        _, _, count = sample_share(total, 0, n)
+        dev = [[DeviceArray(nbytes=4 * n * count) for _ in range(3)] for _ in range(n)]
+        out = [DeviceArray(nbytes=4 * 3 * n * count) for _ in range(n)]
+        t_idx, t_pal = DeviceArray(idx), DeviceArray(pal)
+        bufs = [b for row in dev for b in row] + out + [t_idx, t_pal]
+        for r, c in enumerate(ctxs):
+            i0, i1, _ = sample_share(total, r, n)
+            for ch in range(3):  # a rank holds only its share of the inputs
+                dev[r][ch].upload(planes[ch][i0:i1], 4 * i0)
+            if i1 > i0:
+                c._chk(c.L.jxlh_rct(c._ctx, C.c_void_p(dev[r][0].ptr + 4 * i0), C.c_void_p(dev[r][1].ptr + 4 * i0),
+                                    C.c_void_p(dev[r][2].ptr + 4 * i0), i1 - i0, 6, 3), "rct")
+                # palette of the share, expanded straight into the full-size planes (channel stride n * count)
+                c._chk(c.L.jxlh_palette_strided(c._ctx, C.c_void_p(t_idx.ptr + 4 * i0), i1 - i0, C.c_void_p(t_pal.ptr),
+                                                200, 200, 3, 8, C.c_void_p(out[r].ptr + 4 * i0), n * count),
+                       "palette_strided")
+        for ch in range(3):
+            lib.comm_allgather_local(ctxs, [dev[r][ch].ptr for r in range(n)], 4 * count)
+            lib.comm_allgather_local(ctxs, [out[r].ptr + 4 * ch * n * count for r in range(n)], 4 * count)
+        for c in ctxs:
+            c.sync()
+        for r in range(n):
+            for ch in range(3):
+                got = dev[r][ch].download(np.int32, total).reshape(h, w)
+                assert np.array_equal(got, want[ch]), f"rct rank {r} channel {ch}"
+                gp = out[r].download(np.int32, total, 4 * ch * n * count).reshape(h, w)
+                assert np.array_equal(gp, want_pal[ch]), f"palette rank {r} channel {ch}"
+    finally:
+        for b in bufs:
+            b.free()
+        for c in ctxs:
+            c.close()
