@@ -297,6 +297,7 @@ jxlh_status jxlh_frame_begin(jxlh_ctx* ctx, const jxlh_frame_params* p) {
   }
   ctx->lf_smoothed = false;
   ctx->rendered = false;
+  ctx->has_special = ctx->has_large = false;
   for (auto& s : ctx->slots) s.used = false;
   for (int c = 0; c < 3; c++) ctx->result[c] = nullptr;
   ctx->chroma_lazy = false;
@@ -418,6 +419,24 @@ jxlh_status jxlh_frame_set_hf_meta(jxlh_ctx* ctx, uint32_t x0, uint32_t y0, uint
   if (cmap_stride < cw) return JXLH_ERR_INVALID_ARGUMENT;
   const size_t off = (size_t)y0 * ctx->fd.xblocks + x0;
   const size_t coff = (size_t)(y0 / 8) * ctx->fd.cmap_stride + x0 / 8;
+  // which of the rarely used transform families the frame holds at all (their kernels are not even launched for a
+  // frame without them: four empty launches cost ~20 us of a 0.45 ms K1).  A map that arrives in device memory is not
+  // inspected: both families are then assumed present.
+  if (is_device_ptr(transform_map)) {
+    ctx->has_special = ctx->has_large = true;
+  } else if (!(ctx->has_special && ctx->has_large)) {
+    bool sp = false, lg = false;
+    for (uint32_t y = 0; y < h; y++) {
+      const uint8_t* row = transform_map + (size_t)y * map_stride;
+      for (uint32_t x = 0; x < w; x++) {
+        const uint8_t t = row[x] & 127;
+        lg |= t >= 18;
+        sp |= (t >= 1 && t <= 3) || (t >= 12 && t <= 17);
+      }
+    }
+    ctx->has_special |= sp;
+    ctx->has_large |= lg;
+  }
   jxlh_status st;
   if ((st = copy2d(ctx, ctx->transform_map.p + off, ctx->fd.xblocks, transform_map, map_stride, w, h, ctx->stream)))
     return st;
@@ -799,7 +818,7 @@ jxlh_status run_k1(jxlh_ctx* ctx, const RunPlan& plan, int gr0, int gr1) {
     for (int c = 0; c < 3; c++)
       if (f.hshift[c] | f.vshift[c]) fk.planes[c] = f.tmp[c];
     launch_vardct_groups(ctx->stream, fk, gr0, gr1, ctx->worklist.p, ctx->error_flag.p,
-                         sparse_k1 ? ctx->coeffs.p : nullptr);
+                         sparse_k1 ? ctx->coeffs.p : nullptr, nullptr, 0, ctx->has_special, ctx->has_large);
   }
   // the coefficient slabs are free again: dense resubmissions of the next frame wait for this (jxlh_submit_group)
   if (!ctx->k1_done) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->k1_done, hipEventDisableTiming));
@@ -991,7 +1010,8 @@ jxlh_status jxlh_frame_rerender_groups(jxlh_ctx* ctx, const uint32_t* group_ids,
     f.group_dense = plan.sparse_k1 ? ctx->group_dense.p : nullptr;
     if (plan.sparse_k1) HIPCHK(ctx, hipMemsetAsync(ctx->group_dense.p, 0, ctx->ngroups, ctx->stream));
     launch_vardct_groups(ctx->stream, f, 0, 0, ctx->worklist.p, ctx->error_flag.p,
-                         plan.sparse_k1 ? ctx->coeffs.p : nullptr, ctx->rerender_list.p, n);
+                         plan.sparse_k1 ? ctx->coeffs.p : nullptr, ctx->rerender_list.p, n, ctx->has_special,
+                         ctx->has_large);
   }
   if (!ctx->k1_done) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->k1_done, hipEventDisableTiming));
   HIPCHK(ctx, hipEventRecord(ctx->k1_done, ctx->stream));

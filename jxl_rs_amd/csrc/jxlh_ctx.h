@@ -70,6 +70,7 @@ struct jxlh_ctx {
   DevBuf<int> rerender_list;          // group ids of jxlh_frame_rerender_groups on the device
   std::vector<int> rerender_upload;   // ... and their host copy (alive until the copy has run)
   bool rendered = false;              // a full jxlh_frame_run has happened in this frame
+  bool has_special = false, has_large = false;  // transform families seen in the frame's maps (jxlh_frame_set_hf_meta)
   float* result[3] = {nullptr, nullptr, nullptr};
   // geometry of `result`: the frame itself, or its upsampled image (frame_header.upsampling > 1)
   int res_w = 0, res_h = 0;

@@ -160,7 +160,8 @@ size_t vardct_worklist_bytes(const FrameDev& f);
 // group_list (device, n_list entries) replaces the row range by an explicit list of group ids when non-null
 void launch_vardct_groups(hipStream_t s, const FrameDev& f, int group_row0, int group_row1,
                           void* worklist_mem, int* error_flag, int32_t* dense_coeffs,
-                          const int* group_list = nullptr, int n_list = 0);
+                          const int* group_list = nullptr, int n_list = 0, bool has_special = true,
+                          bool has_large = true);
 void launch_gaborish(hipStream_t s, const float* in, float* out, int w, int h, size_t stride, float k0, float k1,
                      float k2, int y0, int y1);
 struct EpfArgs {

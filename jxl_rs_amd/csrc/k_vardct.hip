@@ -843,7 +843,7 @@ size_t vardct_worklist_bytes(const FrameDev& f) {
 
 void launch_vardct_groups(hipStream_t s, const FrameDev& f, int group_row0, int group_row1,
                           void* worklist_mem, int* error_flag, int32_t* dense_coeffs, const int* group_list,
-                          int n_list) {
+                          int n_list, bool has_special, bool has_large) {
   const int ngroups = group_list ? n_list : (group_row1 - group_row0) * f.xgroups;
   if (ngroups <= 0) return;
   // carve the work-list memory: [counts (256 B)] [class 0 items] [class 1 items] ...
@@ -889,8 +889,10 @@ void launch_vardct_groups(hipStream_t s, const FrameDev& f, int group_row0, int 
   }
   // 4 of these workgroups fit a CU (37 KB LDS, 255 VGPRs): 1024 is the resident capacity, a larger grid
   // only queues -- and an empty special list (the d1 mix) pays for every launched workgroup
-  hipLaunchKernelGGL(k1_special, dim3(grid_for((long)(nblk / kSpecChunk + 1) * kSpecBins * 3, kSpecWaves, 1024)),
-                     dim3(kSpecThreads), 0, s, f, wl);
+  if (has_special)
+    hipLaunchKernelGGL(k1_special, dim3(grid_for((long)(nblk / kSpecChunk + 1) * kSpecBins * 3, kSpecWaves, 1024)),
+                       dim3(kSpecThreads), 0, s, f, wl);
+  if (!has_large) return;
   // the large class: unit list, then one launch per separable pass; 4 workgroups fit a CU (39 KB of LDS each).  All
   // three exit at once when the class is empty (the d1 mix)
   hipLaunchKernelGGL(k1_large_units, dim3(grid_for(nblk / 64 + 1, 256, 64)), dim3(256), 0, s, wl, large_units);

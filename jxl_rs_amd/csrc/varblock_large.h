@@ -21,13 +21,14 @@ constexpr int kLargeThreads = 256;
 constexpr int kLargeSlab = 4096;  // coefficients per slab
 constexpr int kSlabIters = kLargeSlab / kLargeThreads;      // samples per thread and slab
 constexpr int kPairIters = kLargeSlab / 2 / kLargeThreads;  // butterfly pairs per thread and sweep
+constexpr int kQuadIters = kLargeSlab / 4 / kLargeThreads;  // quads per thread and two-level sweep
 // Pairs (samples: twice as many) a thread has in flight at a time: every LDS / global read of a chunk is issued before
 // the first dependent operation.  The whole slab at once (8) costs registers the IDCT_32 leaves need.
 #ifndef JXLH_LARGE_CHUNK
 #define JXLH_LARGE_CHUNK 2
 #endif
 constexpr int kChunk = JXLH_LARGE_CHUNK;
-static_assert(kPairIters % kChunk == 0, "chunking");
+static_assert(kPairIters % kChunk == 0 && kQuadIters % kChunk == 0, "chunking");
 
 // 1-D IDCT of size N along i for L = 1 << lL lines; data at X[i*Lp + line].  Ping-pongs between a and b
 // and returns the buffer holding the result.  All threads of the workgroup must call.
@@ -77,9 +78,63 @@ __device__ float* lds_idct(float* __restrict__ a, float* __restrict__ b, int lL,
       dst = t;
     }
   };
-  down(std::integral_constant<int, 256>{});
-  down(std::integral_constant<int, 128>{});
-  down(std::integral_constant<int, 64>{});
+  // Two recursion levels in one LDS round trip (lengths n and n/2; q = n/4, quad j of sub-array s):
+  //   E[2j] = x[4j], E[2j+1] = x[4j+2], O'[k] = x[2k+1] + x[2k-1] (k > 0) or x[1]*sqrt2   -- level n
+  //   ee = E[2j], eo = E[2j+1] + E[2j-1] (j > 0) or E[1]*sqrt2, likewise oe / oo from O'   -- level n/2
+  // i.e. exactly the operations of the two single sweeps (the level-n sums are rounded before level n/2 adds them),
+  // with 7 reads + 4 writes per quad instead of 12 + 8, and one barrier instead of two.
+  auto down2 = [&](auto n_tag) {
+    constexpr int n = decltype(n_tag)::value, h = n / 2, q = n / 4;
+    constexpr int Q = N / 4;  // quads per line
+    const int g0 = tid >> lL, gstep = kLargeThreads >> lL;
+#pragma unroll 1
+    for (int c0 = 0; c0 < kQuadIters; c0 += kChunk) {
+      if (g0 + c0 * gstep >= Q) break;
+      float ee[kChunk], eo[kChunk], oe[kChunk], oo[kChunk];
+#pragma unroll
+      for (int it = 0; it < kChunk; it++) {
+        const int g = g0 + (c0 + it) * gstep;
+        const bool on = g < Q;
+        const int j = g & (q - 1);
+        const float* x = src + (4 * g) * Lp + line;  // row base + 4j of sub-array s: 4g = s*n + 4j
+        const bool first = j == 0;
+        const float x0 = on ? x[0] : 0.f, x1 = on ? x[Lp] : 0.f, x2 = on ? x[2 * Lp] : 0.f, x3 = on ? x[3 * Lp] : 0.f;
+        const float xm1 = (on && !first) ? x[-Lp] : 0.f, xm2 = (on && !first) ? x[-2 * Lp] : 0.f,
+                    xm3 = (on && !first) ? x[-3 * Lp] : 0.f;
+        const float o_2j = first ? x1 * kSqrt2 : x1 + xm1;   // O'[2j]
+        const float o_2j1 = x3 + x1;                          // O'[2j+1]
+        const float o_2jm1 = xm1 + xm3;                       // O'[2j-1] (j > 0)
+        ee[it] = x0;
+        eo[it] = first ? x2 * kSqrt2 : x2 + xm2;
+        oe[it] = o_2j;
+        oo[it] = first ? o_2j1 * kSqrt2 : o_2j1 + o_2jm1;
+      }
+#pragma unroll
+      for (int it = 0; it < kChunk; it++) {
+        const int g = g0 + (c0 + it) * gstep;
+        if (g < Q) {
+          const int j = g & (q - 1), base = (g & ~(q - 1)) * 4;  // s * n
+          float* d = dst + (base + j) * Lp + line;
+          d[0] = ee[it];
+          d[q * Lp] = eo[it];
+          d[h * Lp] = oe[it];
+          d[(h + q) * Lp] = oo[it];
+        }
+      }
+    }
+    __syncthreads();
+    float* t = src;
+    src = dst;
+    dst = t;
+  };
+  if constexpr (N == 256) {
+    down2(std::integral_constant<int, 256>{});
+    down(std::integral_constant<int, 64>{});
+  } else if constexpr (N == 128) {
+    down2(std::integral_constant<int, 128>{});
+  } else {
+    down(std::integral_constant<int, 64>{});
+  }
   // leaves: register IDCT_32 per (line, leaf), in place
   for (int leaf = p0; leaf < N / 32; leaf += pstep) {
     float x[32];
@@ -125,9 +180,56 @@ __device__ float* lds_idct(float* __restrict__ a, float* __restrict__ b, int lL,
       dst = t;
     }
   };
-  sweep(std::integral_constant<int, 64>{});
-  sweep(std::integral_constant<int, 128>{});
-  sweep(std::integral_constant<int, 256>{});
+  // two butterfly levels (lengths n/2 then n) in one round trip: 4 reads + 4 writes per quad instead of 8 + 8
+  auto sweep2 = [&](auto n_tag) {
+    constexpr int n = decltype(n_tag)::value, h = n / 2, q = n / 4;
+    constexpr int Q = N / 4;
+    const int g0 = tid >> lL, gstep = kLargeThreads >> lL;
+#pragma unroll 1
+    for (int c0 = 0; c0 < kQuadIters; c0 += kChunk) {
+      if (g0 + c0 * gstep >= Q) break;
+      float ee[kChunk], eo[kChunk], oe[kChunk], oo[kChunk];
+#pragma unroll
+      for (int it = 0; it < kChunk; it++) {
+        const int g = g0 + (c0 + it) * gstep;
+        const bool on = g < Q;
+        const int j = g & (q - 1), base = (g & ~(q - 1)) * 4;
+        const float* x = src + (base + j) * Lp + line;
+        ee[it] = on ? x[0] : 0.f;
+        eo[it] = on ? x[q * Lp] : 0.f;
+        oe[it] = on ? x[h * Lp] : 0.f;
+        oo[it] = on ? x[(h + q) * Lp] : 0.f;
+      }
+#pragma unroll
+      for (int it = 0; it < kChunk; it++) {
+        const int g = g0 + (c0 + it) * gstep;
+        if (g < Q) {
+          const int j = g & (q - 1), base = (g & ~(q - 1)) * 4;
+          const float wq = IdctW<h>::w[j];
+          const float e_lo = __builtin_fmaf(eo[it], wq, ee[it]), e_hi = __builtin_fmaf(-eo[it], wq, ee[it]);  // E[j], E[h-1-j]
+          const float o_lo = __builtin_fmaf(oo[it], wq, oe[it]), o_hi = __builtin_fmaf(-oo[it], wq, oe[it]);  // O[j], O[h-1-j]
+          const float w_lo = IdctW<n>::w[j], w_hi = IdctW<n>::w[h - 1 - j];
+          float* d = dst + base * Lp + line;
+          d[j * Lp] = __builtin_fmaf(o_lo, w_lo, e_lo);
+          d[(n - 1 - j) * Lp] = __builtin_fmaf(-o_lo, w_lo, e_lo);
+          d[(h - 1 - j) * Lp] = __builtin_fmaf(o_hi, w_hi, e_hi);
+          d[(h + j) * Lp] = __builtin_fmaf(-o_hi, w_hi, e_hi);
+        }
+      }
+    }
+    __syncthreads();
+    float* t = src;
+    src = dst;
+    dst = t;
+  };
+  if constexpr (N == 256) {
+    sweep(std::integral_constant<int, 64>{});
+    sweep2(std::integral_constant<int, 256>{});
+  } else if constexpr (N == 128) {
+    sweep2(std::integral_constant<int, 128>{});
+  } else {
+    sweep(std::integral_constant<int, 64>{});
+  }
   return src;
 }
 
