@@ -984,6 +984,8 @@ jxlh_status jxlh_frame_rerender_groups(jxlh_ctx* ctx, const uint32_t* group_ids,
   if (count == 0) return JXLH_OK;
   const jxlh_frame_params& p = ctx->params;
   if (p.upsampling > 1) return JXLH_ERR_UNSUPPORTED;  // like a band run: the 5x5 upsampling window crosses groups
+  // a rank of a sharded frame holds only its band: progressive re-renders run on unsharded contexts
+  if (comm_nranks(ctx) > 1) return JXLH_ERR_UNSUPPORTED;
   const int ns = (f.gab ? 1 : 0) + (f.epf_iters >= 3 ? 1 : 0) + (f.epf_iters >= 1 ? 1 : 0) + (f.epf_iters >= 2 ? 1 : 0);
   // Re-rendering a group needs its neighbours' UNFILTERED pixels (the filters read across the group edge).  They
   // are still in `planes` when the stage list leaves its result in `tmp` (the fused path with up to two EPF passes,

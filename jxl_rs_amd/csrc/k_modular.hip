@@ -49,7 +49,7 @@ __device__ __forceinline__ void rct_op(int32_t v0, int32_t v1, int32_t v2, int32
 // perm: which output plane receives w0/w1/w2 (rct.rs:132-156)
 template <int OP>
 __global__ void k4_rct(int32_t* __restrict__ p0, int32_t* __restrict__ p1, int32_t* __restrict__ p2, size_t n,
-                       int perm) {
+                       int perm, size_t nvec) {
   int32_t* o[3];
   switch (perm) {
     default:
@@ -60,7 +60,7 @@ __global__ void k4_rct(int32_t* __restrict__ p0, int32_t* __restrict__ p1, int32
     case 4: o[0] = p1; o[1] = p0; o[2] = p2; break;  // Grb
     case 5: o[0] = p2; o[1] = p1; o[2] = p0; break;  // Bgr
   }
-  const size_t nvec = n / 4;
+  // nvec = n / 4 when the three planes are 16-byte aligned (launch_rct), else 0: everything takes the scalar loop
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
     const int4 a = reinterpret_cast<const int4*>(p0)[i];
@@ -285,7 +285,7 @@ template <bool LDS_PAL>
 __global__ __launch_bounds__(256) void k5_palette(const int32_t* __restrict__ index, size_t n,
                                                   const int32_t* __restrict__ palette_g, int num_colors, size_t pstride_g,
                                                   int nb_channels, int bit_depth, int32_t* __restrict__ out,
-                                                  size_t ostride) {
+                                                  size_t ostride, size_t nvec) {
   __shared__ int32_t s_pal[LDS_PAL ? kPalLdsEntries : 1];
   const int32_t* palette = palette_g;
   size_t pstride = pstride_g;
@@ -297,7 +297,6 @@ __global__ __launch_bounds__(256) void k5_palette(const int32_t* __restrict__ in
     pstride = (size_t)num_colors;
   }
   const size_t stride = (size_t)gridDim.x * blockDim.x;
-  const size_t nvec = n / 4;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
     const int4 idx = reinterpret_cast<const int4*>(index)[i];
     for (int c = 0; c < nb_channels; c++) {
@@ -306,7 +305,7 @@ __global__ __launch_bounds__(256) void k5_palette(const int32_t* __restrict__ in
       v.y = palette_value(palette, pstride, idx.y, c, num_colors, bit_depth);
       v.z = palette_value(palette, pstride, idx.z, c, num_colors, bit_depth);
       v.w = palette_value(palette, pstride, idx.w, c, num_colors, bit_depth);
-      if ((ostride & 3) == 0) {
+      if ((ostride & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
         reinterpret_cast<int4*>(out + (size_t)c * ostride)[i] = v;
       } else {  // channel planes are only 4-byte aligned
         int32_t* o = out + (size_t)c * ostride + i * 4;
@@ -475,14 +474,17 @@ __global__ __launch_bounds__(64) void k6_unsqueeze(const SqueezePlanes pl, size_
 void launch_rct(hipStream_t s, int32_t* p0, int32_t* p1, int32_t* p2, size_t n, int op, int perm) {
   if (n == 0) return;
   const unsigned grid = (unsigned)min((size_t)8192, (n / 4 + 255) / 256 + 1);
+  // sub-ranges of planes (band-sharded runs) may start anywhere: vector accesses only for 16-byte aligned planes
+  const bool aligned = ((reinterpret_cast<uintptr_t>(p0) | reinterpret_cast<uintptr_t>(p1) | reinterpret_cast<uintptr_t>(p2)) & 15) == 0;
+  const size_t nvec = aligned ? n / 4 : 0;
   switch (op) {
-    case 0: hipLaunchKernelGGL(k4_rct<0>, dim3(grid), dim3(256), 0, s, p0, p1, p2, n, perm); break;
-    case 1: hipLaunchKernelGGL(k4_rct<1>, dim3(grid), dim3(256), 0, s, p0, p1, p2, n, perm); break;
-    case 2: hipLaunchKernelGGL(k4_rct<2>, dim3(grid), dim3(256), 0, s, p0, p1, p2, n, perm); break;
-    case 3: hipLaunchKernelGGL(k4_rct<3>, dim3(grid), dim3(256), 0, s, p0, p1, p2, n, perm); break;
-    case 4: hipLaunchKernelGGL(k4_rct<4>, dim3(grid), dim3(256), 0, s, p0, p1, p2, n, perm); break;
-    case 5: hipLaunchKernelGGL(k4_rct<5>, dim3(grid), dim3(256), 0, s, p0, p1, p2, n, perm); break;
-    default: hipLaunchKernelGGL(k4_rct<6>, dim3(grid), dim3(256), 0, s, p0, p1, p2, n, perm); break;
+    case 0: hipLaunchKernelGGL(k4_rct<0>, dim3(grid), dim3(256), 0, s, p0, p1, p2, n, perm, nvec); break;
+    case 1: hipLaunchKernelGGL(k4_rct<1>, dim3(grid), dim3(256), 0, s, p0, p1, p2, n, perm, nvec); break;
+    case 2: hipLaunchKernelGGL(k4_rct<2>, dim3(grid), dim3(256), 0, s, p0, p1, p2, n, perm, nvec); break;
+    case 3: hipLaunchKernelGGL(k4_rct<3>, dim3(grid), dim3(256), 0, s, p0, p1, p2, n, perm, nvec); break;
+    case 4: hipLaunchKernelGGL(k4_rct<4>, dim3(grid), dim3(256), 0, s, p0, p1, p2, n, perm, nvec); break;
+    case 5: hipLaunchKernelGGL(k4_rct<5>, dim3(grid), dim3(256), 0, s, p0, p1, p2, n, perm, nvec); break;
+    default: hipLaunchKernelGGL(k4_rct<6>, dim3(grid), dim3(256), 0, s, p0, p1, p2, n, perm, nvec); break;
   }
 }
 
@@ -490,15 +492,16 @@ void launch_palette(hipStream_t s, const int32_t* index, size_t n, const int32_t
                     size_t palette_stride, int nb_channels, int bit_depth, int32_t* out, size_t out_channel_stride) {
   if (n == 0) return;
   const size_t ostride = out_channel_stride ? out_channel_stride : n;
+  const size_t nvec = (reinterpret_cast<uintptr_t>(index) & 15) == 0 ? n / 4 : 0;  // int4 index loads need alignment
   if (num_colors > 0 && (size_t)num_colors * nb_channels <= (size_t)kPalLdsEntries) {
     // persistent grid (the palette is staged once per workgroup): 3 workgroups of 48 KB LDS per CU
     const unsigned grid = (unsigned)min((size_t)768, (n / 4 + 255) / 256 + 1);
     hipLaunchKernelGGL(k5_palette<true>, dim3(grid), dim3(256), 0, s, index, n, palette, num_colors, palette_stride,
-                       nb_channels, bit_depth, out, ostride);
+                       nb_channels, bit_depth, out, ostride, nvec);
   } else {
     const unsigned grid = (unsigned)min((size_t)8192, (n + 255) / 256);
     hipLaunchKernelGGL(k5_palette<false>, dim3(grid), dim3(256), 0, s, index, n, palette, num_colors, palette_stride,
-                       nb_channels, bit_depth, out, ostride);
+                       nb_channels, bit_depth, out, ostride, nvec);
   }
 }
 

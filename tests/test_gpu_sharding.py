@@ -191,3 +191,41 @@ def test_modular_rct_and_palette_band_sharded(oracle, n):
             b.free()
         for c in ctxs:
             c.close()
+
+
+def test_rct_and_palette_on_unaligned_device_subranges(oracle):
+    """a share of a plane may start at any sample: the vectorised kernels fall back to scalar accesses when a
+    device pointer is not 16-byte aligned"""
+    import ctypes as C
+    import jxl_rs_amd
+    from helpers import DeviceArray
+    rng = np.random.default_rng(7)
+    n = 10007
+    planes = [rng.integers(-1000, 1000, size=n + 3).astype(np.int32) for _ in range(3)]
+    pal = rng.integers(0, 256, size=(3, 64)).astype(np.int32)
+    idx = rng.integers(-2, 140, size=n + 3).astype(np.int32)
+    ctx = jxl_rs_amd.Context(0, 1)
+    bufs = []
+    try:
+        for off in (1, 2, 3):
+            dev = [DeviceArray(p) for p in planes]
+            t_idx, t_pal, out = DeviceArray(idx), DeviceArray(pal), DeviceArray(nbytes=4 * 3 * (n + 8))
+            bufs += dev + [t_idx, t_pal, out]
+            ctx._chk(ctx.L.jxlh_rct(ctx._ctx, C.c_void_p(dev[0].ptr + 4 * off), C.c_void_p(dev[1].ptr + 4 * off),
+                                    C.c_void_p(dev[2].ptr + 4 * off), n, 5, 1), "rct")
+            ctx._chk(ctx.L.jxlh_palette_strided(ctx._ctx, C.c_void_p(t_idx.ptr + 4 * off), n, C.c_void_p(t_pal.ptr), 64, 64, 3,
+                                                8, C.c_void_p(out.ptr + 4 * off), n + 5), "palette_strided")
+            ctx.sync()
+            want = oracle.rct([p[off:off + n].reshape(1, n) for p in planes], 5, 1)
+            for ch in range(3):
+                got = dev[ch].download(np.int32, n, 4 * off)
+                assert np.array_equal(got, want[ch].reshape(-1)), (off, ch)
+                assert np.array_equal(dev[ch].download(np.int32, off), planes[ch][:off])  # untouched before the range
+            wp = oracle.palette(idx[off:off + n].reshape(1, n), pal, 64, 3, 8)
+            for ch in range(3):
+                got = out.download(np.int32, n, 4 * (off + ch * (n + 5)))
+                assert np.array_equal(got, wp[ch].reshape(-1)), ("palette", off, ch)
+    finally:
+        for b in bufs:
+            b.free()
+        ctx.close()
