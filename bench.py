@@ -42,6 +42,26 @@ ALGO_BYTES_PER_PX = {
 }
 
 
+def usable_cores():
+    """Host cores this process may actually use: the affinity mask capped by the container's CPU quota
+    (cgroup v2 cpu.max / v1 cfs quota).  os.cpu_count() reports the machine (256 on the GPU boxes) while the
+    container is throttled to its quota (16 there): 256 threads then time-slice 16 cores' worth of CPU time."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, -(-q // per)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -343,7 +363,7 @@ def main():
         p = o.default_params(cs, cs)
         p.epf_iters = args.epf_iters
         lf = o.dequant_lf(p, *cwl.lf_q)
-        cores = os.cpu_count() or 1
+        cores = usable_cores()
 
         def cpu_run(c, nthreads, buffers):
             o.vardct_frame(p, c.coeffs, c.transform_map, c.raw_quant, c.epf_map, c.ytox, c.ytob, lf, c.tables,
@@ -380,9 +400,11 @@ def main():
                          f"bands, output planes allocated and touched before the timed region",
                "one_thread": {"value": round(one, 2), "unit": "MP/s", "sample": f"best of 2 timed runs of a {s1}x{s1} frame"},
                "parallel_efficiency": round(all_core / (one * cores), 3),
-               "note": "harness limits, not arithmetic, set the all-core figure: a thread pool is created per stage "
-                       "(5 per frame), adaptive LF smoothing and the sigma map run on one thread, and the oracle is "
-                       "scalar C; the reference itself (Rust, SIMD, rayon) cannot be built in this image"}
+               "machine_cpus": os.cpu_count(),
+               "note": "cores = the affinity mask capped by the container's cgroup CPU quota (what the process can really "
+                       "use; round 1 ran 256 threads on a 16-core quota); a thread pool is created per stage, adaptive LF "
+                       "smoothing and the sigma map run on one thread, and the oracle is scalar C -- the reference itself "
+                       "(Rust, SIMD, rayon) cannot be built in this image"}
         del bufs
 
     for c in ctxs:

@@ -76,9 +76,13 @@ struct BlockInfo {
 
 }  // namespace
 
+// every class counter on its own 128-byte line: the 1024 scan workgroups' atomics then meet on nine lines (and L2
+// channels) instead of one
+constexpr int kCountPitch = 32;
+constexpr size_t kCountBytes = (size_t)(kNumClasses + 1) * kCountPitch * sizeof(int);
 struct WorkLists {
   WorkItem* items[kNumClasses];
-  int* counts;  // kNumClasses ints, zeroed before k1_scan
+  int* counts;  // (kNumClasses + 1) counters at kCountPitch ints, zeroed before k1_scan; the last = large slab units
 };
 
 namespace {
@@ -199,7 +203,7 @@ __global__ __launch_bounds__(kThreads) void k1_scan(const FrameDev f, const Work
     }
   }
   __syncthreads();
-  if (tid < kNumClasses) s_base[tid] = s_count[tid] > 0 ? atomicAdd(&wl.counts[tid], s_count[tid]) : 0;
+  if (tid < kNumClasses) s_base[tid] = s_count[tid] > 0 ? atomicAdd(&wl.counts[(tid) * kCountPitch], s_count[tid]) : 0;
   if (tid == 0 && f.group_dense) f.group_dense[group] = (s_count[kClsSpecial] | s_count[kClsLarge]) != 0;
   __syncthreads();
 #pragma unroll
@@ -519,7 +523,7 @@ __global__ __launch_bounds__(kThreads) void k1_dct8(const FrameDev f, const Work
   __shared__ __attribute__((aligned(16))) float s_buf[kWaves * kTileA];
   __shared__ BlockInfo s_binfo[kWaves][S8x8::NB];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  run_dct_class<S8x8, true, SPARSE, SUB>(f, wl.items[kClsDct8], wl.counts[kClsDct8], 0, s_buf + wave * kTileA, s_binfo[wave],
+  run_dct_class<S8x8, true, SPARSE, SUB>(f, wl.items[kClsDct8], wl.counts[(kClsDct8) * kCountPitch], 0, s_buf + wave * kTileA, s_binfo[wave],
                             blockIdx.x * kWaves + wave, gridDim.x * kWaves, lane);
 }
 
@@ -531,11 +535,11 @@ __global__ __launch_bounds__(kThreads) void k1_dct16(const FrameDev f, const Wor
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float* buf = s_buf + wave * kTileB;
   const int gw = blockIdx.x * kWaves + wave, nw = gridDim.x * kWaves;
-  int used = run_dct_class<S16x8, true, SPARSE>(f, wl.items[kClsDct16x8], wl.counts[kClsDct16x8], 6, buf,
+  int used = run_dct_class<S16x8, true, SPARSE>(f, wl.items[kClsDct16x8], wl.counts[(kClsDct16x8) * kCountPitch], 6, buf,
                                                 s_binfo[wave], gw, nw, lane);
-  used += run_dct_class<S8x16, true, SPARSE>(f, wl.items[kClsDct8x16], wl.counts[kClsDct8x16], 7, buf, s_binfo[wave],
+  used += run_dct_class<S8x16, true, SPARSE>(f, wl.items[kClsDct8x16], wl.counts[(kClsDct8x16) * kCountPitch], 7, buf, s_binfo[wave],
                                              rotate_wave(gw, used, nw), nw, lane);
-  run_dct_class<S16x16, true, SPARSE>(f, wl.items[kClsDct16x16], wl.counts[kClsDct16x16], 4, buf, s_binfo[wave],
+  run_dct_class<S16x16, true, SPARSE>(f, wl.items[kClsDct16x16], wl.counts[(kClsDct16x16) * kCountPitch], 4, buf, s_binfo[wave],
                                       rotate_wave(gw, used, nw), nw, lane);
 }
 
@@ -547,15 +551,15 @@ __global__ __launch_bounds__(kThreads) void k1_dct32(const FrameDev f, const Wor
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float* buf = s_buf + wave * kTileC;
   const int gw = blockIdx.x * kWaves + wave, nw = gridDim.x * kWaves;
-  int used = run_dct_class<S32x8, false, SPARSE>(f, wl.items[kClsDct32x8], wl.counts[kClsDct32x8], 8, buf,
+  int used = run_dct_class<S32x8, false, SPARSE>(f, wl.items[kClsDct32x8], wl.counts[(kClsDct32x8) * kCountPitch], 8, buf,
                                                  s_binfo[wave], gw, nw, lane);
-  used += run_dct_class<S8x32, false, SPARSE>(f, wl.items[kClsDct8x32], wl.counts[kClsDct8x32], 9, buf, s_binfo[wave],
+  used += run_dct_class<S8x32, false, SPARSE>(f, wl.items[kClsDct8x32], wl.counts[(kClsDct8x32) * kCountPitch], 9, buf, s_binfo[wave],
                                               rotate_wave(gw, used, nw), nw, lane);
-  used += run_dct_class<S32x16, false, SPARSE>(f, wl.items[kClsDct32x16], wl.counts[kClsDct32x16], 10, buf,
+  used += run_dct_class<S32x16, false, SPARSE>(f, wl.items[kClsDct32x16], wl.counts[(kClsDct32x16) * kCountPitch], 10, buf,
                                                s_binfo[wave], rotate_wave(gw, used, nw), nw, lane);
-  used += run_dct_class<S16x32, false, SPARSE>(f, wl.items[kClsDct16x32], wl.counts[kClsDct16x32], 11, buf,
+  used += run_dct_class<S16x32, false, SPARSE>(f, wl.items[kClsDct16x32], wl.counts[(kClsDct16x32) * kCountPitch], 11, buf,
                                                s_binfo[wave], rotate_wave(gw, used, nw), nw, lane);
-  run_dct_class<S32x32, false, SPARSE>(f, wl.items[kClsDct32x32], wl.counts[kClsDct32x32], 5, buf, s_binfo[wave],
+  run_dct_class<S32x32, false, SPARSE>(f, wl.items[kClsDct32x32], wl.counts[(kClsDct32x32) * kCountPitch], 5, buf, s_binfo[wave],
                                        rotate_wave(gw, used, nw), nw, lane);
 }
 
@@ -580,7 +584,7 @@ __global__ __launch_bounds__(kSpecThreads, 2) void k1_special(const FrameDev f, 
   __shared__ int s_idx[kSpecWaves][kSpecChunk];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const WorkItem* __restrict__ items = wl.items[kClsSpecial];
-  const int count = wl.counts[kClsSpecial];
+  const int count = wl.counts[(kClsSpecial) * kCountPitch];
   float* tin = s_buf + wave * 2 * kSpecNB * kSpecPitch;
   float* tout = tin + kSpecNB * kSpecPitch;
   BlockInfo* binfo = s_binfo[wave];
@@ -771,11 +775,11 @@ __global__ __launch_bounds__(kSpecThreads, 2) void k1_special(const FrameDev f, 
 //   k1_large_pass<2> unit = (slab of pixel columns, channel): vertical IDCT in place
 // (the varblock's own output rectangle is the inter-pass scratch; it stays in L2 / Infinity Cache between the launches)
 __global__ __launch_bounds__(256) void k1_large_units(const WorkLists wl, uint32_t* __restrict__ units) {
-  const int count = wl.counts[kClsLarge];
+  const int count = wl.counts[(kClsLarge) * kCountPitch];
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < count; e += gridDim.x * blockDim.x) {
     const int type = (int)(wl.items[kClsLarge][e].packed >> 20) & 31;
     const int n = max(1, covered_x(type) * covered_y(type) * 64 / kLargeSlab);  // 64x32 / 32x64: half a slab
-    const int base = atomicAdd(&wl.counts[kNumClasses], n);
+    const int base = atomicAdd(&wl.counts[(kNumClasses) * kCountPitch], n);
     for (int s = 0; s < n; s++) units[base + s] = (uint32_t)e | ((uint32_t)s << 24);
   }
 }
@@ -787,7 +791,7 @@ template <int PASS>
 __global__ __launch_bounds__(kLargeThreads, JXLH_LARGE_WPE) void k1_large_pass(const FrameDev f, const WorkLists wl,
                                                                 const uint32_t* __restrict__ units) {
   __shared__ float s_lds[2 * (kLargeSlab + 256) + 1024];
-  const int total = wl.counts[kNumClasses] * 3;
+  const int total = wl.counts[(kNumClasses) * kCountPitch] * 3;
   const int tid = threadIdx.x;
   const float b0 = f.quant_biases[0], b1 = f.quant_biases[1], b2 = f.quant_biases[2], b3 = f.quant_biases[3];
   for (int u = blockIdx.x; u < total; u += gridDim.x) {
@@ -838,7 +842,7 @@ size_t vardct_worklist_bytes(const FrameDev& f) {
   size_t items = 0;
   for (int c = 0; c < kNumClasses; c++) items += nblocks / class_min_area(c) + 1;
   // + the slab-unit list of the large transforms (one u32 per 4096 samples of large-varblock area)
-  return items * sizeof(WorkItem) + 256 + (nblocks / 64 + 16) * sizeof(uint32_t);
+  return items * sizeof(WorkItem) + kCountBytes + (nblocks / 64 + 16) * sizeof(uint32_t);
 }
 
 void launch_vardct_groups(hipStream_t s, const FrameDev& f, int group_row0, int group_row1,
@@ -846,17 +850,17 @@ void launch_vardct_groups(hipStream_t s, const FrameDev& f, int group_row0, int 
                           int n_list, bool has_special, bool has_large) {
   const int ngroups = group_list ? n_list : (group_row1 - group_row0) * f.xgroups;
   if (ngroups <= 0) return;
-  // carve the work-list memory: [counts (256 B)] [class 0 items] [class 1 items] ...
+  // carve the work-list memory: [counters, one 128-byte line each] [class 0 items] [class 1 items] ...
   WorkLists wl;
   wl.counts = reinterpret_cast<int*>(worklist_mem);
-  char* p = reinterpret_cast<char*>(worklist_mem) + 256;
+  char* p = reinterpret_cast<char*>(worklist_mem) + kCountBytes;
   const size_t nblocks = (size_t)f.xblocks * f.yblocks;
   for (int c = 0; c < kNumClasses; c++) {
     wl.items[c] = reinterpret_cast<WorkItem*>(p);
     p += (nblocks / class_min_area(c) + 1) * sizeof(WorkItem);
   }
   uint32_t* large_units = reinterpret_cast<uint32_t*>(p);  // behind the last class list
-  (void)hipMemsetAsync(wl.counts, 0, (kNumClasses + 1) * sizeof(int), s);  // [kNumClasses] = slab units of the large class
+  (void)hipMemsetAsync(wl.counts, 0, kCountBytes, s);  // [kNumClasses] = slab units of the large class
   hipLaunchKernelGGL(k1_scan, dim3(ngroups), dim3(kThreads), 0, s, f, wl, group_row0, error_flag, group_list);
   // grids: enough waves to fill the chip; kernels stride over their lists (counts are device-side)
   const int nblk = ngroups * kGroupBlocks * kGroupBlocks;

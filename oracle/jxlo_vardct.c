@@ -110,18 +110,15 @@ void jxlo_dequant_lf_channel(const JxloFrameParams* p, int c, const int32_t* q, 
 static const float kWSide = 0.20345139757231578f;
 static const float kWCorner = 0.0334829185968739f;
 
-void jxlo_adaptive_lf_smoothing(const JxloFrameParams* p, const float* const in[3], int w, int h,
-                                float* const out[3]) {
+/* rows [y0, y1) of adaptive_lf_smoothing (the image must be larger than 2 x 2) */
+static void lf_smoothing_rows(const JxloFrameParams* p, const float* const in[3], int w, int h,
+                              float* const out[3], int y0, int y1) {
   const float w_center = 1.0f - 4.0f * (kWSide + kWCorner);
   /* finalize_lf (frame/mod.rs:360-369): inv_quant_lf * quant_factors[c] */
   const float inv_quant_lf = inv_global_scale(p) / (float)p->quant_lf;
   float lf_factors[3];
   for (int c = 0; c < 3; c++) lf_factors[c] = inv_quant_lf * p->lf_quant_factors[c];
-  if (h <= 2 || w <= 2) {
-    for (int c = 0; c < 3; c++) memcpy(out[c], in[c], sizeof(float) * (size_t)w * h);
-    return;
-  }
-  for (int y = 0; y < h; y++) {
+  for (int y = y0; y < y1; y++) {
     for (int x = 0; x < w; x++) {
       const size_t i = (size_t)y * w + x;
       if (y == 0 || y == h - 1 || x == 0 || x == w - 1) {
@@ -147,18 +144,31 @@ void jxlo_adaptive_lf_smoothing(const JxloFrameParams* p, const float* const in[
   }
 }
 
+void jxlo_adaptive_lf_smoothing(const JxloFrameParams* p, const float* const in[3], int w, int h,
+                                float* const out[3]) {
+  if (h <= 2 || w <= 2) {
+    for (int c = 0; c < 3; c++) memcpy(out[c], in[c], sizeof(float) * (size_t)w * h);
+    return;
+  }
+  lf_smoothing_rows(p, in, w, h, out, 0, h);
+}
+
 /* ---------------- K3 sigma ---------------- */
-void jxlo_sigma_map(const JxloFrameParams* p, const int32_t* raw_quant, const uint8_t* epf_map,
-                    float* inv_sigma) {
+static void sigma_map_range(const JxloFrameParams* p, const int32_t* raw_quant, const uint8_t* epf_map,
+                            float* inv_sigma, size_t i0, size_t i1) {
   const float kInvSigmaNum = -1.1715728752538099024f;
   const float quant_scale = 1.0f / inv_global_scale(p);
-  const size_t n = (size_t)p->xsize_blocks * p->ysize_blocks;
-  for (size_t i = 0; i < n; i++) {
+  for (size_t i = i0; i < i1; i++) {
     const float sigma_quant = p->epf_quant_mul / (quant_scale * (float)raw_quant[i] * kInvSigmaNum);
     float sigma = sigma_quant * p->epf_sharp_lut[epf_map[i]];
     sigma = sigma < -1e-4f ? sigma : -1e-4f; /* f32::min */
     inv_sigma[i] = 1.0f / sigma;
   }
+}
+
+void jxlo_sigma_map(const JxloFrameParams* p, const int32_t* raw_quant, const uint8_t* epf_map,
+                    float* inv_sigma) {
+  sigma_map_range(p, raw_quant, epf_map, inv_sigma, 0, (size_t)p->xsize_blocks * p->ysize_blocks);
 }
 
 /* ---------------- K1 ---------------- */
@@ -586,7 +596,30 @@ typedef struct {
   float* sout[3];
   const float* sigma;
   int rows_per_job;
+  /* LF smoothing / sigma jobs */
+  const float* lf_in[3];
+  float* lf_out[3];
+  const uint8_t* epf_map;
+  float* sigma_out;
 } Job;
+
+static void lf_job(void* v, int i, int n) {
+  (void)n;
+  Job* j = (Job*)v;
+  const int h = j->p->ysize_blocks, w = j->p->xsize_blocks;
+  int y0 = i * 16, y1 = y0 + 16;
+  if (y1 > h) y1 = h;
+  lf_smoothing_rows(j->p, j->lf_in, w, h, j->lf_out, y0, y1);
+}
+
+static void sigma_job(void* v, int i, int n) {
+  (void)n;
+  Job* j = (Job*)v;
+  const int h = j->p->ysize_blocks, w = j->p->xsize_blocks;
+  int y0 = i * 16, y1 = y0 + 16;
+  if (y1 > h) y1 = h;
+  sigma_map_range(j->p, j->raw_quant, j->epf_map, j->sigma_out, (size_t)y0 * w, (size_t)y1 * w);
+}
 
 static void group_job(void* v, int i, int n) {
   (void)n;
@@ -622,21 +655,28 @@ void jxlo_vardct_frame(const JxloFrameParams* p, const int32_t* coeffs,
                        float* const lf[3], const float* const tables[17], float* const planes[3],
                        float* const tmp[3], size_t stride, int num_threads) {
   const int bw = p->xsize_blocks, bh = p->ysize_blocks;
-  if (p->do_lf_smoothing) {
+  Job j;
+  memset(&j, 0, sizeof j);
+  j.p = p;
+  j.raw_quant = raw_quant;
+  j.epf_map = epf_map;
+  const int lf_jobs = (bh + 15) / 16;
+  if (p->do_lf_smoothing && bw > 2 && bh > 2) {
     float* sm[3];
-    const float* lin[3] = {lf[0], lf[1], lf[2]};
-    for (int c = 0; c < 3; c++) sm[c] = (float*)malloc(sizeof(float) * (size_t)bw * bh);
-    jxlo_adaptive_lf_smoothing(p, lin, bw, bh, sm);
+    for (int c = 0; c < 3; c++) {
+      sm[c] = (float*)malloc(sizeof(float) * (size_t)bw * bh);
+      j.lf_in[c] = lf[c];
+      j.lf_out[c] = sm[c];
+    }
+    run_parallel(num_threads, lf_jobs, lf_job, &j);
     for (int c = 0; c < 3; c++) {
       memcpy(lf[c], sm[c], sizeof(float) * (size_t)bw * bh);
       free(sm[c]);
     }
   }
   float* sigma = (float*)malloc(sizeof(float) * (size_t)bw * bh);
-  if (p->epf_iters > 0) jxlo_sigma_map(p, raw_quant, epf_map, sigma);
-  Job j;
-  memset(&j, 0, sizeof j);
-  j.p = p;
+  j.sigma_out = sigma;
+  if (p->epf_iters > 0) run_parallel(num_threads, lf_jobs, sigma_job, &j);
   j.coeffs = coeffs;
   j.transform_map = transform_map;
   j.raw_quant = raw_quant;
