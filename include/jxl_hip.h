@@ -438,6 +438,21 @@ jxlh_status jxlh_unsqueeze_planes(jxlh_ctx* ctx, int32_t horizontal, int32_t n_p
                                   size_t res_stride, uint32_t out_w, uint32_t out_h, int32_t* const out[],
                                   size_t out_stride);
 
+/* smooth_h_unsqueeze / smooth_v_unsqueeze / smooth_2d_unsqueeze (modular/transforms/squeeze.rs:1010-1105, :1120-1225,
+ * :908-1003): the step a squeeze runs while its residual channel has not arrived (DataStatus::Zero,
+ * transforms/step.rs:138-150, dispatched at :841-851) -- the progressive previews of a squeezed image.  `avg` is the
+ * WHOLE average channel (avg_w x avg_h; for JXLH_SMOOTH_2D the average of two steps back, half size in both axes);
+ * the out_w x out_h output rectangle sits at (x0, y0) of the output channel -- (0, 0) and the full size for a whole
+ * channel, a grid tile's Rect otherwise (the window reads across tile edges, columns clamp and rows mirror at the
+ * CHANNEL's borders: TiledChannelView::load_row_to_scratch, step.rs:372-420).  As in the reference, a rectangle
+ * without one complete sample pair on a doubled axis is left untouched.  Float-to-int conversion truncates after the
+ * +-0.5 (the scalar, NEON and wasm back-ends' as_i32; the x86 ones round a second time).
+ * Host or device pointers. */
+enum { JXLH_SMOOTH_H = 0, JXLH_SMOOTH_V = 1, JXLH_SMOOTH_2D = 2 };
+jxlh_status jxlh_smooth_unsqueeze(jxlh_ctx* ctx, int32_t kind, const int32_t* avg, size_t avg_stride, uint32_t avg_w,
+                                  uint32_t avg_h, uint32_t x0, uint32_t y0, int32_t* out, size_t out_stride,
+                                  uint32_t out_w, uint32_t out_h);
+
 /* ---------------------------------------------------------------- multi-GPU
  * The reference renders a frame's groups on a pool of host threads and joins them in the pipeline's output buffers
  * (frame/render.rs:395-479).  Here a frame is cut into contiguous bands of group rows, one per GPU ("rank"):

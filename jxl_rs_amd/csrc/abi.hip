@@ -1794,6 +1794,38 @@ jxlh_status jxlh_unsqueeze(jxlh_ctx* ctx, int32_t horizontal, const int32_t* avg
   return stage_out(ctx, out, (const int32_t*)ctx->hook_i[2].p, out_stride * out_h);
 }
 
+jxlh_status jxlh_smooth_unsqueeze(jxlh_ctx* ctx, int32_t kind, const int32_t* avg, size_t avg_stride, uint32_t avg_w,
+                                  uint32_t avg_h, uint32_t x0, uint32_t y0, int32_t* out, size_t out_stride,
+                                  uint32_t out_w, uint32_t out_h) {
+  if (!ctx || !avg || !out || kind < JXLH_SMOOTH_H || kind > JXLH_SMOOTH_2D || avg_w == 0 || avg_h == 0 ||
+      avg_stride < avg_w || out_stride < out_w || avg_w > (1u << 30) || avg_h > (1u << 30) || x0 > (1u << 30) ||
+      y0 > (1u << 30) || out_w > (1u << 30) || out_h > (1u << 30))
+    return JXLH_ERR_INVALID_ARGUMENT;
+  const bool fx = kind != JXLH_SMOOTH_V, fy = kind != JXLH_SMOOTH_H;
+  if ((fx ? out_w / 2 : out_w) == 0 || (fy ? out_h / 2 : out_h) == 0) return JXLH_OK; /* squeeze.rs:921-923 */
+  static const char* const kNames[3] = {"k6_smooth_unsqueeze_h", "k6_smooth_unsqueeze_v", "k6_smooth_unsqueeze_2d"};
+  if (is_device_ptr(avg) && is_device_ptr(out)) {
+    ScopedKernelTimer t(ctx, kNames[kind]);
+    launch_smooth_unsqueeze(ctx->stream, kind, avg, avg_stride, (int)avg_w, (int)avg_h, (int)x0, (int)y0, out,
+                            out_stride, (int)out_w, (int)out_h);
+    HIPCHK(ctx, hipGetLastError());
+    return JXLH_OK;
+  }
+  jxlh_status st;
+  if ((st = stage_in(ctx, ctx->hook_i[0], avg, avg_stride * avg_h))) return st;
+  if ((st = ensure(ctx, ctx->hook_i[2], out_stride * out_h))) return st;
+  launch_smooth_unsqueeze(ctx->stream, kind, ctx->hook_i[0].p, avg_stride, (int)avg_w, (int)avg_h, (int)x0, (int)y0,
+                          ctx->hook_i[2].p, out_stride, (int)out_w, (int)out_h);
+  HIPCHK(ctx, hipGetLastError());
+  /* every sample of the rectangle is written; the stride padding of a host `out` is overwritten with whatever the
+   * staging buffer held only if out_stride > out_w -- copy row by row instead */
+  if (out_stride == out_w) return stage_out(ctx, out, (const int32_t*)ctx->hook_i[2].p, out_stride * out_h);
+  HIPCHK(ctx, hipMemcpy2DAsync(out, out_stride * sizeof(int32_t), ctx->hook_i[2].p, out_stride * sizeof(int32_t),
+                               out_w * sizeof(int32_t), out_h, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return JXLH_OK;
+}
+
 jxlh_status jxlh_unsqueeze_planes(jxlh_ctx* ctx, int32_t horizontal, int32_t n_planes, const int32_t* const avg[],
                                   size_t avg_stride, const int32_t* const res[], size_t res_stride, uint32_t out_w,
                                   uint32_t out_h, int32_t* const out[], size_t out_stride) {

@@ -629,4 +629,170 @@ void launch_unsqueeze(hipStream_t s, int horizontal, int n_planes, const int32_t
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Smooth unsqueeze: what a squeeze step runs while its residual channel has not arrived (progressive previews;
+// transforms/step.rs:138-150 picks the kind, :841-851 dispatches): smooth_h / smooth_v / smooth_2d_unsqueeze
+// (squeeze.rs:908-1225).  A pure 5x5 stencil on the average channel -- unlike the regular step there is no
+// recurrence, so it is one thread per column of a 64 x 16 tile of average samples, walking four rows with a sliding window; the
+// tile's 68 x 20 window is staged through LDS once.
+// Arithmetic order is the reference's (four partial sums of <= 4 FMAs from zero, (a + b) + (c + d), +-0.5,
+// truncating convert: the scalar / NEON / wasm as_i32; the x86 back-ends' cvtps rounds a second time, see
+// DESIGN.md 4).
+struct SmTap {
+  int n;
+  float w;
+};
+#define SW2 0.62646443f
+#define SW10 0.24413736f
+#define SW18 0.06118795f
+#define SW26 -0.01328634f
+#define SW34 -0.03355509f
+#define SW50 -0.02015225f
+#define SW58 -0.01033307f
+#define SW74 -0.00056067f
+#define SV1 0.69472290f
+#define SV9 0.27861324f
+#define SV17 0.07666797f
+#define SV25 -0.00778371f
+#define SV41 -0.03143468f
+#define SV49 -0.02150597f
+#define SV65 -0.00434251f
+#define SV73 -0.00078780f
+// n < 0: the slot is empty (the 2-D kernel's third partial sum has three taps)
+__device__ static constexpr SmTap kSm2d[4][16] = {
+    {{1, SW58}, {2, SW50}, {3, SW74}, {5, SW58}, {6, SW18}, {7, SW10}, {8, SW34}, {10, SW50},
+     {11, SW10}, {12, SW2}, {13, SW26}, {-1, 0.f}, {15, SW74}, {16, SW34}, {17, SW26}, {18, SW50}},
+    {{1, SW74}, {2, SW50}, {3, SW58}, {6, SW34}, {7, SW10}, {8, SW18}, {9, SW58}, {11, SW26},
+     {12, SW2}, {13, SW10}, {14, SW50}, {-1, 0.f}, {16, SW50}, {17, SW26}, {18, SW34}, {19, SW74}},
+    {{5, SW74}, {6, SW34}, {7, SW26}, {8, SW50}, {10, SW50}, {11, SW10}, {12, SW2}, {13, SW26},
+     {15, SW58}, {16, SW18}, {17, SW10}, {-1, 0.f}, {18, SW34}, {21, SW58}, {22, SW50}, {23, SW74}},
+    {{6, SW50}, {7, SW26}, {8, SW34}, {9, SW74}, {11, SW26}, {12, SW2}, {13, SW10}, {14, SW50},
+     {16, SW34}, {17, SW10}, {18, SW18}, {-1, 0.f}, {19, SW58}, {21, SW74}, {22, SW50}, {23, SW58}}};
+__device__ static constexpr SmTap kSm1d[2][16] = {
+    {{1, SV73}, {2, SV65}, {5, SV65}, {6, SV25}, {7, SV17}, {8, SV41}, {10, SV49}, {11, SV9},
+     {12, SV1}, {13, SV25}, {15, SV65}, {16, SV25}, {17, SV17}, {18, SV41}, {21, SV73}, {22, SV65}},
+    {{2, SV65}, {3, SV73}, {6, SV41}, {7, SV17}, {8, SV25}, {9, SV65}, {11, SV25}, {12, SV1},
+     {13, SV9}, {14, SV49}, {16, SV41}, {17, SV17}, {18, SV25}, {19, SV65}, {22, SV65}, {23, SV73}}};
+
+template <bool TWO_D, int WHICH>
+__device__ __forceinline__ int32_t smooth_eval(const float (&n)[25]) {
+  float part[4];
+#pragma unroll
+  for (int g = 0; g < 4; g++) {
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      constexpr const SmTap* t = TWO_D ? kSm2d[WHICH] : kSm1d[WHICH & 1];
+      const SmTap tp = t[4 * g + k];
+      if (tp.n >= 0) acc = __fmaf_rn(n[tp.n], tp.w, acc);
+    }
+    part[g] = acc;
+  }
+  const float sum = __fadd_rn(__fadd_rn(part[0], part[1]), __fadd_rn(part[2], part[3]));
+  return (int32_t)__fadd_rn(sum, copysignf(0.5f, sum));
+}
+
+#define JXLH_SM_TX 64
+#define JXLH_SM_WAVES 4
+#define JXLH_SM_RPT 8                                 // consecutive rows one thread walks with a sliding window
+#define JXLH_SM_TY (JXLH_SM_WAVES * JXLH_SM_RPT)      // average rows per workgroup: 20 window rows for 16 (1.25x)
+// KIND 0: horizontal (out = 2 in_x), 1: vertical, 2: both.  nx x ny = average samples the rectangle covers.
+template <int KIND, bool PAIR>
+__global__ __launch_bounds__(JXLH_SM_TX* JXLH_SM_WAVES) void k6_smooth_unsqueeze(
+    const int32_t* __restrict__ in, size_t in_stride, int in_w, int in_h, int cx0, int cy0, int32_t* __restrict__ out,
+    size_t out_stride, int out_w, int out_h, int nx, int ny) {
+  __shared__ float tile[JXLH_SM_TY + 4][JXLH_SM_TX + 4 + 1];
+  const int tid = threadIdx.x;
+  const int bx = blockIdx.x * JXLH_SM_TX, by = blockIdx.y * JXLH_SM_TY;
+  // one wave per window row (row arithmetic is wave-uniform), lane = column; lanes 0..3 also fetch the 4 extra columns.
+  // rows mirror ( -1 -> 0, h -> h - 1 ), columns clamp: load_row_to_scratch, step.rs:386-416
+  const int wave = __builtin_amdgcn_readfirstlane(tid / JXLH_SM_TX), lane = tid % JXLH_SM_TX;
+  for (int r = wave; r < JXLH_SM_TY + 4; r += JXLH_SM_WAVES) {
+    int y = cy0 + by + r - 2;
+    y = in_h == 1 ? 0 : (y < 0 ? -y - 1 : (y >= in_h ? 2 * in_h - 1 - y : y));
+    y = min(max(y, 0), in_h - 1);  // only rows no live thread reads can still be outside
+    const int32_t* row = in + (size_t)y * in_stride;
+    const int x = cx0 + bx + lane - 2;
+    tile[r][lane] = (float)row[min(max(x, 0), in_w - 1)];
+    if (lane < 4) tile[r][JXLH_SM_TX + lane] = (float)row[min(max(x + JXLH_SM_TX, 0), in_w - 1)];
+  }
+  __syncthreads();
+  const int ix = bx + lane;
+  if (ix >= nx) return;
+  const bool both = 2 * ix + 1 < out_w;
+  float win[5][5];  // window rows; the first four are loaded once, then one new row per step
+#pragma unroll
+  for (int r = 0; r < 4; r++)
+#pragma unroll
+    for (int c = 0; c < 5; c++) win[r][c] = tile[wave * JXLH_SM_RPT + r][lane + c];
+#pragma unroll
+  for (int k = 0; k < JXLH_SM_RPT; k++) {
+    const int ly = wave * JXLH_SM_RPT + k, iy = by + ly;
+    if (iy >= ny) return;  // wave-uniform
+#pragma unroll
+    for (int c = 0; c < 5; c++) win[4][c] = tile[ly + 4][lane + c];
+    float n[25];
+#pragma unroll
+    for (int r = 0; r < 5; r++)
+#pragma unroll
+      for (int c = 0; c < 5; c++) n[KIND == 1 ? 5 * c + r : 5 * r + c] = win[r][c];
+    if (KIND == 2) {
+      const int32_t o00 = smooth_eval<true, 0>(n), o01 = smooth_eval<true, 1>(n);
+      const int32_t o10 = smooth_eval<true, 2>(n), o11 = smooth_eval<true, 3>(n);
+      int32_t* p0 = out + (size_t)(2 * iy) * out_stride + 2 * ix;
+      if (PAIR && both) {  // PAIR: base and stride keep every sample pair 8-byte aligned
+        *(int2*)p0 = make_int2(o00, o01);
+        if (2 * iy + 1 < out_h) *(int2*)(p0 + out_stride) = make_int2(o10, o11);
+      } else {
+        p0[0] = o00;
+        if (both) p0[1] = o01;
+        if (2 * iy + 1 < out_h) {
+          p0[out_stride] = o10;
+          if (both) p0[out_stride + 1] = o11;
+        }
+      }
+    } else if (KIND == 0) {
+      int32_t* p = out + (size_t)iy * out_stride + 2 * ix;
+      const int32_t e = smooth_eval<false, 0>(n), o = smooth_eval<false, 1>(n);
+      if (PAIR && both) {
+        *(int2*)p = make_int2(e, o);
+      } else {
+        p[0] = e;
+        if (both) p[1] = o;
+      }
+    } else {
+      int32_t* p = out + (size_t)(2 * iy) * out_stride + ix;
+      p[0] = smooth_eval<false, 0>(n);
+      if (2 * iy + 1 < out_h) p[out_stride] = smooth_eval<false, 1>(n);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+      for (int c = 0; c < 5; c++) win[r][c] = win[r + 1][c];
+  }
+}
+
+void launch_smooth_unsqueeze(hipStream_t s, int kind, const int32_t* in, size_t in_stride, int in_w, int in_h, int x0,
+                             int y0, int32_t* out, size_t out_stride, int out_w, int out_h) {
+  const bool fx = kind != 1, fy = kind != 0;
+  // the reference returns with the output untouched when the rectangle has no complete pair (squeeze.rs:921-923)
+  if ((fx ? out_w / 2 : out_w) == 0 || (fy ? out_h / 2 : out_h) == 0) return;
+  const int nx = fx ? (out_w + 1) / 2 : out_w, ny = fy ? (out_h + 1) / 2 : out_h;
+  const int cx0 = fx ? x0 / 2 : x0, cy0 = fy ? y0 / 2 : y0;
+  const dim3 grid((nx + JXLH_SM_TX - 1) / JXLH_SM_TX, (ny + JXLH_SM_TY - 1) / JXLH_SM_TY);
+  const dim3 block(JXLH_SM_TX * JXLH_SM_WAVES);
+  const bool pair = (uintptr_t)out % 8 == 0 && out_stride % 2 == 0;
+#define JXLH_SM_LAUNCH(K, P)                                                                                        \
+  hipLaunchKernelGGL((k6_smooth_unsqueeze<K, P>), grid, block, 0, s, in, in_stride, in_w, in_h, cx0, cy0, out,      \
+                     out_stride, out_w, out_h, nx, ny)
+  if (kind == 0) {
+    if (pair) JXLH_SM_LAUNCH(0, true); else JXLH_SM_LAUNCH(0, false);
+  } else if (kind == 1) {
+    JXLH_SM_LAUNCH(1, false);
+  } else {
+    if (pair) JXLH_SM_LAUNCH(2, true); else JXLH_SM_LAUNCH(2, false);
+  }
+#undef JXLH_SM_LAUNCH
+}
+
 }  // namespace jxlh

@@ -43,7 +43,7 @@ ABI_SYMBOLS = [
     "jxlh_stage_gaborish",
     "jxlh_stage_epf", "jxlh_stage_lf_smooth", "jxlh_stage_transform_to_pixels", "jxlh_rct", "jxlh_palette", "jxlh_palette_delta", "jxlh_modular_to_rgb8",
     "jxlh_modular_to_f32", "jxlh_modular_xyb_to_f32",
-    "jxlh_unsqueeze", "jxlh_unsqueeze_planes", "jxlh_abi_version", "jxlh_covered_blocks_x", "jxlh_covered_blocks_y",
+    "jxlh_unsqueeze", "jxlh_unsqueeze_planes", "jxlh_smooth_unsqueeze", "jxlh_abi_version", "jxlh_covered_blocks_x", "jxlh_covered_blocks_y",
     "jxlh_quant_table_for_type", "jxlh_quant_table_size",
     "jxlh_comm_unique_id", "jxlh_comm_init", "jxlh_comm_init_local", "jxlh_comm_destroy", "jxlh_comm_band",
     "jxlh_frame_run_sharded", "jxlh_frame_allgather", "jxlh_frames_run_sharded_local", "jxlh_frames_allgather_local",
@@ -167,6 +167,7 @@ def load():
     L.jxlh_modular_to_f32.argtypes = [vp, vp, sz, u32, vp]
     L.jxlh_modular_xyb_to_f32.argtypes = [vp, vp, vp, vp, sz, vp, vp, vp, vp]
     L.jxlh_unsqueeze.argtypes = [vp, i32, vp, sz, vp, sz, u32, u32, vp, sz]
+    L.jxlh_smooth_unsqueeze.argtypes = [vp, i32, vp, sz, u32, u32, u32, u32, vp, sz, u32, u32]
     L.jxlh_unsqueeze_planes.argtypes = [vp, i32, i32, C.POINTER(vp), sz, C.POINTER(vp), sz, u32, u32, C.POINTER(vp), sz]
     L.jxlh_abi_version.restype = u32
     L.jxlh_comm_unique_id.argtypes = [vp]
@@ -678,6 +679,22 @@ class Context:
         ov = (C.c_void_p * n)(*[_addr(a).value for a in out])
         self._chk(self.L.jxlh_unsqueeze_planes(self._ctx, 1 if horizontal else 0, n, av, avg_stride, rv, res_stride,
                                                out_w, out_h, ov, out_stride), "unsqueeze_planes")
+
+    SMOOTH_H, SMOOTH_V, SMOOTH_2D = 0, 1, 2
+
+    def smooth_unsqueeze(self, kind, avg, out_w, out_h, x0=0, y0=0, out=None):
+        """smooth_{h,v,2d}_unsqueeze (squeeze.rs:908-1225): `avg` the whole average channel, host array."""
+        avg = np.ascontiguousarray(avg, dtype=np.int32)
+        if out is None:
+            out = np.zeros((out_h, out_w), dtype=np.int32)
+        self._chk(self.L.jxlh_smooth_unsqueeze(self._ctx, kind, _addr(avg), avg.shape[1], avg.shape[1], avg.shape[0],
+                                               x0, y0, _addr(out), out.shape[1], out_w, out_h), "smooth_unsqueeze")
+        return out
+
+    def smooth_unsqueeze_dev(self, kind, avg, avg_stride, avg_w, avg_h, out, out_stride, out_w, out_h, x0=0, y0=0):
+        """Device-resident form (pointers / DeviceArray / tensors)."""
+        self._chk(self.L.jxlh_smooth_unsqueeze(self._ctx, kind, _addr(avg), avg_stride, avg_w, avg_h, x0, y0,
+                                               _addr(out), out_stride, out_w, out_h), "smooth_unsqueeze")
 
     def unsqueeze(self, horizontal, avg, res, out_w, out_h):
         avg = np.ascontiguousarray(avg, dtype=np.int32)

@@ -11,6 +11,7 @@
  * All arithmetic is wrapping i32 (jxl_simd/src/scalar.rs Wrapping<i32>); the
  * scalar squeeze definition uses i64 intermediates and truncating division.
  */
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -265,6 +266,123 @@ void jxlo_unsqueeze_v(const int32_t* avg, size_t avg_stride, const int32_t* res,
     }
   }
   if (has_tail) memcpy(out + (size_t)(2 * h) * out_stride, avg + (size_t)h * avg_stride, sizeof(int32_t) * w);
+}
+
+/* ---- smooth unsqueeze: what a squeeze step runs when its residual channel has not arrived (all-zero), i.e. the
+ * progressive previews (transforms/step.rs:138-150 picks the kind, :841-851 dispatches).  The average channel is
+ * upsampled by a 5x5 float kernel instead of the integer tendency recurrence. ---- */
+#ifndef JXLO_FUSED
+#define JXLO_FUSED 1
+#endif
+static inline float sm_mul_add(float a, float b, float c) {
+#if JXLO_FUSED
+  return fmaf(a, b, c);
+#else
+  return (a * b) + c;
+#endif
+}
+typedef struct { uint8_t n; float w; } SmTap;
+/* Four partial sums of (up to) four taps, each from zero in the listed order, joined as (a + b) + (c + d), then
+ * + copysign(0.5, sum) and a truncating convert: convolve_2d_simd squeeze.rs:686-812, convolve_1d_simd :814-888.
+ * n[k] is the 5x5 neighbourhood, k = 5 * row + col (the vertical variant transposes it, :1160-1188). */
+#define W2 0.62646443f
+#define W10 0.24413736f
+#define W18 0.06118795f
+#define W26 -0.01328634f
+#define W34 -0.03355509f
+#define W50 -0.02015225f
+#define W58 -0.01033307f
+#define W74 -0.00056067f
+static const SmTap kSm2d[4][16] = {
+    {{1, W58}, {2, W50}, {3, W74}, {5, W58}, {6, W18}, {7, W10}, {8, W34}, {10, W50}, {11, W10}, {12, W2}, {13, W26},
+     {0, 0.f}, {15, W74}, {16, W34}, {17, W26}, {18, W50}},
+    {{1, W74}, {2, W50}, {3, W58}, {6, W34}, {7, W10}, {8, W18}, {9, W58}, {11, W26}, {12, W2}, {13, W10}, {14, W50},
+     {0, 0.f}, {16, W50}, {17, W26}, {18, W34}, {19, W74}},
+    {{5, W74}, {6, W34}, {7, W26}, {8, W50}, {10, W50}, {11, W10}, {12, W2}, {13, W26}, {15, W58}, {16, W18},
+     {17, W10}, {0, 0.f}, {18, W34}, {21, W58}, {22, W50}, {23, W74}},
+    {{6, W50}, {7, W26}, {8, W34}, {9, W74}, {11, W26}, {12, W2}, {13, W10}, {14, W50}, {16, W34}, {17, W10},
+     {18, W18}, {0, 0.f}, {19, W58}, {21, W74}, {22, W50}, {23, W58}}};
+#define V1 0.69472290f
+#define V9 0.27861324f
+#define V17 0.07666797f
+#define V25 -0.00778371f
+#define V41 -0.03143468f
+#define V49 -0.02150597f
+#define V65 -0.00434251f
+#define V73 -0.00078780f
+static const SmTap kSm1d[2][16] = {
+    {{1, V73}, {2, V65}, {5, V65}, {6, V25}, {7, V17}, {8, V41}, {10, V49}, {11, V9}, {12, V1}, {13, V25}, {15, V65},
+     {16, V25}, {17, V17}, {18, V41}, {21, V73}, {22, V65}},
+    {{2, V65}, {3, V73}, {6, V41}, {7, V17}, {8, V25}, {9, V65}, {11, V25}, {12, V1}, {13, V9}, {14, V49}, {16, V41},
+     {17, V17}, {18, V25}, {19, V65}, {22, V65}, {23, V73}}};
+/* a {0, 0.f} entry marks a three-tap partial sum (the 2-D kernel's third): it is skipped, not accumulated */
+/* as_i32 differs between the reference's back-ends: scalar (`as i32`, jxl_simd/src/scalar.rs:178), NEON (vcvtq_s32_f32,
+ * aarch64/neon.rs:400) and wasm truncate -- with the +-0.5 that is round-half-away, the evident intent -- while the
+ * x86 ones use cvtps (x86_64/avx.rs:580, sse42.rs:472, avx512.rs:638), round-to-nearest-even ON TOP of the +-0.5.
+ * cvt_rne = 0 restates the former (what the product implements), 1 the x86 behaviour (kept to show the difference). */
+static int32_t sm_eval(const SmTap t[16], const float n[25], int cvt_rne) {
+  float part[4];
+  for (int g = 0; g < 4; g++) {
+    float acc = 0.f;
+    for (int k = 0; k < 4; k++) {
+      const SmTap tp = t[4 * g + k];
+      if (tp.w == 0.f) continue;
+      acc = sm_mul_add(n[tp.n], tp.w, acc);
+    }
+    part[g] = acc;
+  }
+  const float sum = (part[0] + part[1]) + (part[2] + part[3]);
+  const float biased = sum + copysignf(0.5f, sum);
+  return cvt_rne ? (int32_t)lrintf(biased) : (int32_t)biased;
+}
+void jxlo_smooth_convolve_2d(const float n[25], int cvt_rne, int32_t out[4]) {
+  for (int i = 0; i < 4; i++) out[i] = sm_eval(kSm2d[i], n, cvt_rne);
+}
+void jxlo_smooth_convolve_1d(const float n[25], int cvt_rne, int32_t out[2]) {
+  for (int i = 0; i < 2; i++) out[i] = sm_eval(kSm1d[i], n, cvt_rne);
+}
+/* TiledChannelView::load_row_to_scratch (step.rs:372-420) seen from one sample: rows mirror without repeating the
+ * edge twice ( -1 -> 0, -2 -> 1, h -> h - 1 ), columns clamp. */
+static float sm_sample(const int32_t* in, size_t stride, int w, int h, int x, int y) {
+  const int yy = h == 1 ? 0 : (y < 0 ? -y - 1 : (y >= h ? 2 * h - 1 - y : y));
+  const int xx = x < 0 ? 0 : (x >= w ? w - 1 : x);
+  return (float)in[(size_t)yy * stride + xx];
+}
+/* kind 0: smooth_h_unsqueeze (squeeze.rs:1010-1105), 1: smooth_v_unsqueeze (:1120-1225), 2: smooth_2d_unsqueeze
+ * (:908-1003).  `in` is the whole average channel (in_w x in_h); the out_w x out_h output rectangle sits at (x0, y0)
+ * of the output channel (Rect of the grid tile; (0, 0) for a whole channel). */
+void jxlo_smooth_unsqueeze(int kind, const int32_t* in, size_t in_stride, int in_w, int in_h, int x0, int y0,
+                           int32_t* out, size_t out_stride, int out_w, int out_h, int cvt_rne) {
+  const int fx = kind != 1, fy = kind != 0; /* which axes double */
+  const int in_xs = fx ? out_w / 2 : out_w, in_ys = fy ? out_h / 2 : out_h;
+  if (in_xs == 0 || in_ys == 0) return;
+  const int cx0 = fx ? x0 / 2 : x0, cy0 = fy ? y0 / 2 : y0;
+  const int ny = fy ? (out_h + 1) / 2 : out_h, nx = fx ? (out_w + 1) / 2 : out_w;
+  for (int iy = 0; iy < ny; iy++) {
+    for (int ix = 0; ix < nx; ix++) {
+      float n[25];
+      for (int r = 0; r < 5; r++)
+        for (int c = 0; c < 5; c++) {
+          const float v = sm_sample(in, in_stride, in_w, in_h, cx0 + ix + c - 2, cy0 + iy + r - 2);
+          n[kind == 1 ? 5 * c + r : 5 * r + c] = v;
+        }
+      if (kind == 2) {
+        int32_t o[4];
+        jxlo_smooth_convolve_2d(n, cvt_rne, o);
+        for (int k = 0; k < 4; k++) {
+          const int ox = 2 * ix + (k & 1), oy = 2 * iy + (k >> 1);
+          if (ox < out_w && oy < out_h) out[(size_t)oy * out_stride + ox] = o[k];
+        }
+      } else {
+        int32_t o[2];
+        jxlo_smooth_convolve_1d(n, cvt_rne, o);
+        for (int k = 0; k < 2; k++) {
+          const int ox = kind == 0 ? 2 * ix + k : ix, oy = kind == 0 ? iy : 2 * iy + k;
+          if (ox < out_w && oy < out_h) out[(size_t)oy * out_stride + ox] = o[k];
+        }
+      }
+    }
+  }
 }
 
 /* ---- the stages between Modular channels and the rest of the pipeline (render/stages/convert.rs) ---- */

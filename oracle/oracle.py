@@ -149,6 +149,12 @@ class Oracle:
         L.jxlo_modular_xyb_to_f32.argtypes = [ip, ip, ip, C.c_size_t, fp, fp, fp, fp]
         L.jxlo_unsqueeze_h.argtypes = [ip, C.c_size_t, ip, C.c_size_t, C.c_int, C.c_int, ip, C.c_size_t]
         L.jxlo_unsqueeze_v.argtypes = [ip, C.c_size_t, ip, C.c_size_t, C.c_int, C.c_int, ip, C.c_size_t]
+        L.jxlo_smooth_convolve_2d.argtypes = [fp, C.c_int, ip]
+        L.jxlo_smooth_convolve_1d.argtypes = [fp, C.c_int, ip]
+        L.jxlo_smooth_unsqueeze.argtypes = [C.c_int, ip, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, ip,
+                                            C.c_size_t, C.c_int, C.c_int, C.c_int]
+        for f in (L.jxlo_smooth_convolve_2d, L.jxlo_smooth_convolve_1d, L.jxlo_smooth_unsqueeze):
+            f.restype = None
         L.jxlo_smooth_tendency.argtypes = [C.c_int64] * 3
         L.jxlo_smooth_tendency.restype = C.c_int64
         L.jxlo_smooth_tendency_i32.argtypes = [C.c_int32] * 3
@@ -592,6 +598,24 @@ class Oracle:
         out = np.zeros((h, out_w), dtype=np.int32)
         self.lib.jxlo_unsqueeze_h(_ptr(avg, C.c_int32), avg.shape[1], _ptr(res, C.c_int32),
                                   max(res.shape[1], 1), out_w, h, _ptr(out, C.c_int32), out_w)
+        return out
+
+    SMOOTH_H, SMOOTH_V, SMOOTH_2D = 0, 1, 2
+
+    def smooth_convolve(self, n25, two_d, cvt_rne=False):
+        n = np.ascontiguousarray(n25, dtype=np.float32).reshape(25)
+        out = np.zeros(4 if two_d else 2, dtype=np.int32)
+        fn = self.lib.jxlo_smooth_convolve_2d if two_d else self.lib.jxlo_smooth_convolve_1d
+        fn(_ptr(n, C.c_float), int(cvt_rne), _ptr(out, C.c_int32))
+        return out
+
+    def smooth_unsqueeze(self, kind, avg, out_w, out_h, x0=0, y0=0, cvt_rne=False, out=None):
+        """smooth_{h,v,2d}_unsqueeze on the whole average channel `avg`; the out_w x out_h rectangle at (x0, y0)."""
+        avg = np.ascontiguousarray(avg, dtype=np.int32)
+        if out is None:
+            out = np.zeros((out_h, out_w), dtype=np.int32)
+        self.lib.jxlo_smooth_unsqueeze(kind, _ptr(avg, C.c_int32), avg.shape[1], avg.shape[1], avg.shape[0], x0, y0,
+                                       _ptr(out, C.c_int32), out.shape[1], out_w, out_h, int(cvt_rne))
         return out
 
     def unsqueeze_v(self, avg, res, out_h):

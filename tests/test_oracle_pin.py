@@ -430,3 +430,90 @@ def test_transfer_functions_against_their_definitions(oracle_any, kat):
     sc = [v * mixed ** e for v in (0.4, 0.3, 0.2)]
     want = [np.sqrt(3 * v) if v <= 1 / 12 else A * np.log(12 * v - B) + C for v in sc]
     assert max(abs(float(out[i][0]) - want[i]) for i in range(3)) < 2e-5
+
+
+# ---------------------------------------------------------------- smooth unsqueeze (progressive previews)
+# The reference's own tests of convolve_2d_simd / convolve_1d_simd (modular/transforms/squeeze.rs:1243-1319, run on
+# ScalarDescriptor -> the unfused build, truncating convert).
+def test_smooth_convolve_constant_input_is_identity(oracle_any):
+    for val in (-1000.0, -1.0, 0.0, 1.0, 42.0, 255.0, 10000.0):
+        n = np.full(25, val, dtype=np.float32)
+        assert (oracle_any.smooth_convolve(n, True) == int(val)).all(), val
+        assert (oracle_any.smooth_convolve(n, False) == int(val)).all(), val
+
+
+def test_smooth_convolve_2d_symmetry(oracle_any):
+    def imp(k):
+        n = np.zeros(25, dtype=np.float32)
+        n[k] = 10000.0
+        return oracle_any.smooth_convolve(n, True)
+    o, h, v = imp(6), imp(8), imp(16)
+    assert (o[0], o[1], o[2], o[3]) == (h[1], h[0], h[3], h[2])
+    assert (o[0], o[1], o[2], o[3]) == (v[2], v[3], v[0], v[1])
+    assert len(set(o.tolist())) > 1  # the impulse response is not flat: the checks above are not vacuous
+
+
+def test_smooth_convolve_1d_symmetry(oracle_any):
+    def imp(k):
+        n = np.zeros(25, dtype=np.float32)
+        n[k] = 10000.0
+        return oracle_any.smooth_convolve(n, False)
+    a, b = imp(7), imp(17)
+    assert (a == b).all()
+    c, d = imp(6), imp(8)
+    assert c[0] == d[1] and c[1] == d[0] and c[0] != c[1]
+
+
+def _smooth_numpy(kind, avg, out_w, out_h, x0, y0, conv):
+    """Independent restatement of the three sliding-window drivers (squeeze.rs:908-1225) on a padded copy: rows
+    mirror ('symmetric'), columns clamp ('edge'), exactly what load_row_to_scratch (step.rs:372-420) produces."""
+    fx, fy = kind != 1, kind != 0
+    if (out_w // 2 if fx else out_w) == 0 or (out_h // 2 if fy else out_h) == 0:
+        return np.zeros((out_h, out_w), dtype=np.int32)
+    P = 2 + max(avg.shape) + out_w + out_h  # generous: np.pad handles pads longer than the array for these modes
+    pad = np.pad(np.pad(avg, ((P, P), (0, 0)), mode="symmetric") if avg.shape[0] > 1
+                 else np.repeat(avg, 2 * P + 1, axis=0), ((0, 0), (P, P)), mode="edge").astype(np.float32)
+    out = np.zeros((out_h, out_w), dtype=np.int32)
+    cx0, cy0 = (x0 // 2 if fx else x0), (y0 // 2 if fy else y0)
+    for iy in range((out_h + 1) // 2 if fy else out_h):
+        for ix in range((out_w + 1) // 2 if fx else out_w):
+            win = pad[P + cy0 + iy - 2:P + cy0 + iy + 3, P + cx0 + ix - 2:P + cx0 + ix + 3]
+            o = conv((win.T if kind == 1 else win).reshape(25), kind == 2)
+            for k, val in enumerate(o):
+                ox = 2 * ix + (k & 1) if fx else ix
+                oy = (2 * iy + (k >> 1 if kind == 2 else k)) if fy else iy
+                if ox < out_w and oy < out_h:
+                    out[oy, ox] = val
+    return out
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2])
+def test_smooth_unsqueeze_window_walk_vs_padded_restatement(oracle_any, kind):
+    rng = np.random.default_rng(40 + kind)
+    fx, fy = kind != 1, kind != 0
+    for (w, h) in [(1, 1), (2, 2), (3, 1), (1, 3), (5, 4), (8, 8), (9, 7), (17, 2), (2, 13), (16, 11)]:
+        aw, ah = ((w + 1) // 2 if fx else w), ((h + 1) // 2 if fy else h)
+        avg = rng.integers(-2000, 2000, size=(ah, aw)).astype(np.int32)
+        want = _smooth_numpy(kind, avg, w, h, 0, 0, oracle_any.smooth_convolve)
+        got = oracle_any.smooth_unsqueeze(kind, avg, w, h)
+        assert (got == want).all(), (kind, w, h)
+    # a grid tile of a larger channel: the rectangle's origin moves the window, the clamps stay the channel's
+    W, H = 37, 29
+    avg = rng.integers(-2000, 2000, size=((H + 1) // 2 if fy else H, (W + 1) // 2 if fx else W)).astype(np.int32)
+    whole = oracle_any.smooth_unsqueeze(kind, avg, W, H)
+    for (x0, y0, w, h) in [(0, 0, 16, 16), (16, 0, 16, 16), (32, 16, 5, 13), (16, 16, 16, 13)]:
+        tile = oracle_any.smooth_unsqueeze(kind, avg, w, h, x0, y0)
+        assert (tile == whole[y0:y0 + h, x0:x0 + w]).all(), (kind, x0, y0)
+        assert (tile == _smooth_numpy(kind, avg, w, h, x0, y0, oracle_any.smooth_convolve)).all()
+
+
+def test_smooth_unsqueeze_x86_convert_differs_from_the_other_backends(oracle):
+    """cvtps after the +-0.5 (x86 back-ends) rounds |sum| up to the NEXT integer whenever frac(|sum|) is in (0, 0.5):
+    the back-ends disagree by one level on about half the samples; the product implements the truncating form."""
+    rng = np.random.default_rng(44)
+    avg = rng.integers(-500, 500, size=(32, 32)).astype(np.int32)
+    a = oracle.smooth_unsqueeze(2, avg, 64, 64)
+    b = oracle.smooth_unsqueeze(2, avg, 64, 64, cvt_rne=True)
+    d = np.abs(a.astype(np.int64) - b)
+    assert d.max() == 1 and 0.2 < (d != 0).mean() < 0.8
+    assert (np.abs(b) >= np.abs(a)).all()

@@ -49,6 +49,13 @@ def main():
                                                              n, n, P(out), n), "uh"), 8.0 * n * n)
     timeit("unsqueeze_v", lambda: ctx._chk(L.jxlh_unsqueeze(ctx._ctx, 0, P(avg_v), n, P(res_v), n, n, n, P(out), n), "uv"),
            8.0 * n * n)
+    # progressive previews: the smooth steps (no recurrence; read the average once, write the doubled channel)
+    avg_q = torch.randint(0, 256, (n - n // 2, n - n // 2), dtype=torch.int32, device=dev, generator=g)
+    timeit("smooth_unsqueeze_2d", lambda: ctx.smooth_unsqueeze_dev(2, avg_q, avg_q.shape[1], avg_q.shape[1],
+                                                                    avg_q.shape[0], out, n, n, n), 5.0 * n * n)
+    timeit("smooth_unsqueeze_h", lambda: ctx.smooth_unsqueeze_dev(0, avg_h, avg_h.shape[1], avg_h.shape[1], n, out, n, n, n),
+           6.0 * n * n)
+    timeit("smooth_unsqueeze_v", lambda: ctx.smooth_unsqueeze_dev(1, avg_v, n, n, avg_v.shape[0], out, n, n, n), 6.0 * n * n)
     # the three channels of a squeeze step in one launch
     avg3h = [avg_h.clone() for _ in range(3)]; res3h = [res_h.clone() for _ in range(3)]
     avg3v = [avg_v.clone() for _ in range(3)]; res3v = [res_v.clone() for _ in range(3)]
