@@ -438,6 +438,16 @@ jxlh_status jxlh_unsqueeze_planes(jxlh_ctx* ctx, int32_t horizontal, int32_t n_p
                                   size_t res_stride, uint32_t out_w, uint32_t out_h, int32_t* const out[],
                                   size_t out_stride);
 
+/* A squeeze step of three channels followed by do_rct_step (rct.rs:118-157) on the same three channels, in one pass:
+ * the shape the end of a colour image's inverse transform chain has (default_squeeze, squeeze.rs:71-105, finishes with
+ * the full-size step -- vertical for square and tall images, horizontal for wide ones; the encoder applied the RCT
+ * before the squeeze, so it is undone after it).  Equivalent to jxlh_unsqueeze_planes(horizontal, 3 planes) +
+ * jxlh_rct(out[0..2], op, perm) without the second read and write of the image.  out planes may not alias avg / res.
+ * Device pointers only. */
+jxlh_status jxlh_unsqueeze_rct(jxlh_ctx* ctx, int32_t horizontal, const int32_t* const avg[3], size_t avg_stride,
+                               const int32_t* const res[3], size_t res_stride, uint32_t out_w, uint32_t out_h,
+                               int32_t* const out[3], size_t out_stride, int32_t op, int32_t perm);
+
 /* smooth_h_unsqueeze / smooth_v_unsqueeze / smooth_2d_unsqueeze (modular/transforms/squeeze.rs:1010-1105, :1120-1225,
  * :908-1003): the step a squeeze runs while its residual channel has not arrived (DataStatus::Zero,
  * transforms/step.rs:138-150, dispatched at :841-851) -- the progressive previews of a squeezed image.  `avg` is the

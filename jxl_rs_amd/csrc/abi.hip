@@ -1794,6 +1794,43 @@ jxlh_status jxlh_unsqueeze(jxlh_ctx* ctx, int32_t horizontal, const int32_t* avg
   return stage_out(ctx, out, (const int32_t*)ctx->hook_i[2].p, out_stride * out_h);
 }
 
+jxlh_status jxlh_unsqueeze_rct(jxlh_ctx* ctx, int32_t horizontal, const int32_t* const avg[3], size_t avg_stride,
+                               const int32_t* const res[3], size_t res_stride, uint32_t out_w, uint32_t out_h,
+                               int32_t* const out[3], size_t out_stride, int32_t op, int32_t perm) {
+  if (!ctx || !avg || !res || !out || out_stride < out_w || op < 0 || op > 6 || perm < 0 || perm > 5)
+    return JXLH_ERR_INVALID_ARGUMENT;
+  if (out_w == 0 || out_h == 0) return JXLH_OK;
+  const uint32_t avg_w = horizontal ? (out_w + 1) / 2 : out_w;
+  const uint32_t res_w = horizontal ? out_w / 2 : out_w, res_h = horizontal ? out_h : out_h / 2;
+  const bool has_res = (size_t)res_w * res_h > 0;
+  if (avg_stride < avg_w || (has_res && res_stride < res_w)) return JXLH_ERR_INVALID_ARGUMENT;
+  const int32_t* rv[3];
+  for (int i = 0; i < 3; i++) {
+    if (!avg[i] || !out[i] || !is_device_ptr(avg[i]) || !is_device_ptr(out[i])) return JXLH_ERR_INVALID_ARGUMENT;
+    if (has_res && (!res[i] || !is_device_ptr(res[i]))) return JXLH_ERR_INVALID_ARGUMENT;
+    rv[i] = res[i] ? res[i] : avg[i];
+  }
+  {
+    ScopedKernelTimer t(ctx, horizontal ? "k6_unsqueeze_rct_h" : "k6_unsqueeze_rct_v");
+    if (launch_unsqueeze_rct(ctx->stream, horizontal, avg, avg_stride, rv, res_stride, out_w, out_h, out, out_stride, op,
+                             perm)) {
+      HIPCHK(ctx, hipGetLastError());
+      return JXLH_OK;
+    }
+  }
+  // planes of 2^31 samples or more: the two separate passes (the RCT row by row when the rows are padded)
+  launch_unsqueeze(ctx->stream, horizontal, 3, avg, avg_stride, rv, res_stride, out_w, out_h, out, out_stride);
+  if (out_stride == out_w) {
+    launch_rct(ctx->stream, out[0], out[1], out[2], (size_t)out_w * out_h, op, perm);
+  } else {
+    for (uint32_t y = 0; y < out_h; y++)
+      launch_rct(ctx->stream, out[0] + (size_t)y * out_stride, out[1] + (size_t)y * out_stride,
+                 out[2] + (size_t)y * out_stride, out_w, op, perm);
+  }
+  HIPCHK(ctx, hipGetLastError());
+  return JXLH_OK;
+}
+
 jxlh_status jxlh_smooth_unsqueeze(jxlh_ctx* ctx, int32_t kind, const int32_t* avg, size_t avg_stride, uint32_t avg_w,
                                   uint32_t avg_h, uint32_t x0, uint32_t y0, int32_t* out, size_t out_stride,
                                   uint32_t out_w, uint32_t out_h) {

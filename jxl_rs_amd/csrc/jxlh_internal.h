@@ -238,6 +238,10 @@ void launch_modular_xyb_to_f32(hipStream_t s, const int32_t* y, const int32_t* x
 void launch_unsqueeze(hipStream_t s, int horizontal, int n_planes, const int32_t* const avg[], size_t avg_stride,
                       const int32_t* const res[], size_t res_stride, uint32_t out_w, uint32_t out_h,
                       int32_t* const out[], size_t out_stride);
+// fused unsqueeze of three planes + inverse RCT; false = not applicable (plane too large), nothing launched
+bool launch_unsqueeze_rct(hipStream_t s, int horizontal, const int32_t* const avg[3], size_t avg_stride,
+                          const int32_t* const res[3], size_t res_stride, uint32_t out_w, uint32_t out_h,
+                          int32_t* const out[3], size_t out_stride, int op, int perm);
 // smooth_{h,v,2d}_unsqueeze on a rectangle of the output channel; `in` is the whole average channel
 void launch_smooth_unsqueeze(hipStream_t s, int kind, const int32_t* in, size_t in_stride, int in_w, int in_h, int x0,
                              int y0, int32_t* out, size_t out_stride, int out_w, int out_h);

@@ -344,14 +344,39 @@ __device__ __forceinline__ int32_t smooth_tendency(int32_t a, int32_t b, int32_t
   return wsub(x ^ sgn, sgn);
 }
 
-// unsqueeze_impl (squeeze.rs:171-185)
-__device__ __forceinline__ void unsqueeze(int32_t avg, int32_t res, int32_t next_avg, int32_t prev, int32_t& a,
-                                          int32_t& b) {
-  const int32_t diff = wadd(res, smooth_tendency(prev, avg, next_avg));
-  const int32_t sign = (int32_t)((uint32_t)diff >> 31);
-  const int32_t diff_2 = wadd(diff, sign) >> 1;
-  a = wadd(avg, diff_2);
-  b = wsub(a, diff);
+// unsqueeze_impl (squeeze.rs:171-185) around smooth_tendency, restated for the serial chain.  One wave owns a line, so
+// a step costs (instructions on the dependent path) x 8 cycles (tools/exp/valu_latency.hip: 8 cycles between dependent
+// VALU instructions of a lone wave, 5 between independent ones); the step is therefore written on the state
+//     d = prev_b - avg                      (a_b of smooth_tendency_impl)
+// with everything that does not depend on it moved off the path:
+//     b_c = avg - next, sm = sign mask of b_c, bc = |b_c|        (per step constants)
+//     e   = d with the sign of b_c applied: the tendency is non-zero only for e >= 0 (prev, avg, next monotone:
+//           a_b and b_c of one sign -- `skip` of the reference), and then |a_b| = e, |a_c| = e + bc
+//     x   = max(0, min3((e + e/3 + bc + 2) >> 2, 2e + 1, 2bc))   (e < 0 makes 2e + 1 negative: the max is the skip)
+//     diff = res + sign(b_c) * x
+//     h   = diff - trunc(diff / 2) = (diff + 1 + (diff >> 31)) >> 1
+//     b = avg - h, a = b + diff (off the path), and the next state d' = b - next = b_c - h.
+// Eleven dependent instructions instead of about twenty-four; bit-equal to the form above wherever the reference's
+// i32 SIMD arithmetic does not wrap (test_unsqueeze_large_magnitudes: +-2^28).
+__device__ __forceinline__ uint32_t xad(uint32_t a, uint32_t b, uint32_t c) { return (a ^ b) + c; }  // v_xad_u32
+__device__ __forceinline__ void unsqueeze_step(int32_t avg, int32_t res, int32_t next_avg, int32_t& d, int32_t& a,
+                                               int32_t& b) {
+  // off the dependent path
+  const int32_t b_c = wsub(avg, next_avg);
+  const uint32_t sm = (uint32_t)(b_c >> 31), nsm = (uint32_t)b_c >> 31;
+  const uint32_t bc = xad((uint32_t)b_c, sm, nsm);
+  const uint32_t k2 = bc + 2u, u = bc << 1, rs = (uint32_t)res + nsm;
+  // the chain
+  const int32_t e = (int32_t)xad((uint32_t)d, sm, nsm);
+  const int32_t e3 = __mulhi(e, 0x55555556);
+  const int32_t s = (int32_t)((uint32_t)e + (uint32_t)e3 + k2) >> 2;
+  const int32_t t1 = (int32_t)(((uint32_t)e << 1) + 1u);
+  const int32_t x = max(min(min(s, t1), (int32_t)u), 0);
+  const int32_t diff = (int32_t)xad((uint32_t)x, sm, rs);
+  const int32_t h = (int32_t)((uint32_t)diff + (uint32_t)(diff >> 31) + 1u) >> 1;
+  d = wsub(b_c, h);
+  b = wsub(avg, h);
+  a = wadd(b, diff);
 }
 
 // One lane per line; up to 3 planes (the channels of one squeeze step) per launch via blockIdx.y.
@@ -385,7 +410,7 @@ __global__ __launch_bounds__(64) void k6_unsqueeze(const SqueezePlanes pl, size_
   }
   const bool has_tail = n_out & 1;
   int32_t cur = a[0];
-  int32_t prev_b = cur;  // first `prev` is avg[0] (squeeze.rs:411-414, :591-594)
+  int32_t d = 0;  // prev - avg; the first `prev` is avg[0] itself (squeeze.rs:411-414, :591-594)
   constexpr int U = JXLH_SQ_U;  // steps whose inputs are requested ahead (two such blocks are in flight)
   // main body: next_avg = avg[i+1] exists for i < w-1 (or i < w with a tail)
   const int n_main = has_tail ? w : w - 1;
@@ -419,8 +444,7 @@ __global__ __launch_bounds__(64) void k6_unsqueeze(const SqueezePlanes pl, size_
     int32_t va[U], vb[U];
 #pragma unroll
     for (int k = 0; k < U; k++) {
-      unsqueeze(cur, xr[k], xa[k], prev_b, va[k], vb[k]);
-      prev_b = vb[k];
+      unsqueeze_step(cur, xr[k], xa[k], d, va[k], vb[k]);
       cur = xa[k];
     }
     if constexpr (HVEC) {
@@ -453,15 +477,14 @@ __global__ __launch_bounds__(64) void k6_unsqueeze(const SqueezePlanes pl, size_
   for (; i < n_main; i++) {
     const int32_t nxt = a[(size_t)(i + 1) * avg_ep];
     int32_t va, vb;
-    unsqueeze(cur, r[(size_t)i * res_ep], nxt, prev_b, va, vb);
+    unsqueeze_step(cur, r[(size_t)i * res_ep], nxt, d, va, vb);
     o[(size_t)(2 * i) * out_ep] = va;
     o[(size_t)(2 * i + 1) * out_ep] = vb;
-    prev_b = vb;
     cur = nxt;
   }
   if (!has_tail) {  // last pair: next_avg = avg itself (squeeze.rs:423-433, :608-616)
     int32_t va, vb;
-    unsqueeze(cur, r[(size_t)(w - 1) * res_ep], cur, prev_b, va, vb);
+    unsqueeze_step(cur, r[(size_t)(w - 1) * res_ep], cur, d, va, vb);
     o[(size_t)(2 * w - 2) * out_ep] = va;
     o[(size_t)(2 * w - 1) * out_ep] = vb;
   } else {  // odd size: trailing average is copied (squeeze.rs:434-437, :641-643)
@@ -599,6 +622,372 @@ void launch_modular_xyb_to_f32(hipStream_t s, const int32_t* y, const int32_t* x
                        scale[1], scale[2], ox, oy, ob);
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for the wave's outstanding global
+// stores (vmcnt(0)); in the mover / chain kernels below nothing in the workgroup ever reads those back.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// The same recurrence with the memory traffic taken off the chain wave.  In k6_unsqueeze a lane fetches and stores
+// its own line: for a horizontal step that is 64 different cache lines per memory instruction, and in both directions
+// the address arithmetic and the memory instructions sit in the one instruction stream whose length is the step time.
+// Here a workgroup is one CHAIN wave (lane = line, 64 lines) and three MOVER waves: the movers stream chunks of
+// JXLH_SQT_S steps through LDS -- coalesced along whichever axis is contiguous in memory, transposed by the LDS layout
+// for the horizontal step (the CPU does this with register transposes, squeeze.rs:249-283) -- double-buffered against
+// the chain wave, which touches only LDS: 128-bit reads / writes for the horizontal layout (line pitch = 4 mod 32
+// dwords: conflict-free), one dword per lane and step for the vertical one.
+#define JXLH_SQT_S 32                    // steps per chunk
+#define JXLH_SQT_PI (JXLH_SQT_S + 4)     // line pitch of the input tiles, horizontal layout
+#define JXLH_SQT_PO (2 * JXLH_SQT_S + 4) // ... of the output tile
+template <bool HORIZ>
+__global__ __launch_bounds__(256) void k6_unsqueeze_tiled(const SqueezePlanes pl, size_t avg_lp, size_t avg_ep,
+                                                          size_t res_lp, size_t res_ep, size_t out_lp, size_t out_ep,
+                                                          int n_lines, int n_out) {
+  constexpr int S = JXLH_SQT_S, PI = JXLH_SQT_PI, PO = JXLH_SQT_PO;
+  constexpr int IN_ELEMS = HORIZ ? 64 * PI : 64 * S, OUT_ELEMS = HORIZ ? 64 * PO : 64 * 2 * S;
+  __shared__ __attribute__((aligned(16))) int32_t s_avg[2][IN_ELEMS];
+  __shared__ __attribute__((aligned(16))) int32_t s_res[2][IN_ELEMS];
+  __shared__ __attribute__((aligned(16))) int32_t s_out[2][OUT_ELEMS];
+  const int tid = threadIdx.x;
+  const int l0 = blockIdx.x * 64;
+  const int32_t* __restrict__ ga = pl.avg[blockIdx.y];
+  const int32_t* __restrict__ gr = pl.res[blockIdx.y];
+  int32_t* __restrict__ go = pl.out[blockIdx.y];
+  const int w = n_out / 2;
+  const bool has_tail = n_out & 1;
+  const int n_main = has_tail ? w : w - 1;  // steps whose next_avg = avg[i + 1] exists
+  const int n_chunks = n_main / S;
+  const bool chain = tid < 64;
+  const int m = tid - 64;  // mover index 0..191
+
+  // movers: chunk c of the inputs (next_avg = avg[i0 + 1 + k], res[i0 + k]) -> registers -> LDS, in two halves so that
+  // all of a chunk's loads are in flight together (and the previous chunk's stores are issued under them)
+  // Offsets are 32-bit (the launcher keeps planes of 2^31 samples or more on k6_unsqueeze) and affine in the slot j.
+  // Three mover waves: with the chain wave that is one wave per SIMD, and two workgroups share a CU (a fifth wave
+  // doubles up on a SIMD and the second workgroup no longer fits: measured, 384 workgroups took two rounds).
+  constexpr int NM = 192, NIN = (64 * S + NM - 1) / NM, NOUT = (64 * 2 * S + NM - 1) / NM;
+  // horizontal: the element index is the contiguous axis (32 elements of one line per half wave);
+  // vertical: the line index is (64 lines of one element row per wave)
+  const int in_r0 = HORIZ ? m / S : m % 64, in_k0 = HORIZ ? m % S : m / 64;
+  constexpr int IN_DR = HORIZ ? NM / S : 0, IN_DK = HORIZ ? 0 : NM / 64;
+  const int out_r0 = HORIZ ? m / (2 * S) : m % 64, out_k0 = HORIZ ? m % (2 * S) : m / 64;
+  constexpr int OUT_DR = HORIZ ? NM / (2 * S) : 0, OUT_DK = HORIZ ? 0 : NM / 64;
+  const uint32_t alp = (uint32_t)avg_lp, aep = (uint32_t)avg_ep, rlp = (uint32_t)res_lp, rep = (uint32_t)res_ep;
+  const uint32_t olp = (uint32_t)out_lp, oep = (uint32_t)out_ep;
+  const uint32_t a_off0 = (uint32_t)(l0 + in_r0) * alp + (uint32_t)(1 + in_k0) * aep;
+  const uint32_t r_off0 = (uint32_t)(l0 + in_r0) * rlp + (uint32_t)in_k0 * rep;
+  const uint32_t o_off0 = (uint32_t)(l0 + out_r0) * olp + (uint32_t)out_k0 * oep;
+  const uint32_t a_dj = IN_DR * alp + IN_DK * aep, r_dj = IN_DR * rlp + IN_DK * rep, o_dj = OUT_DR * olp + OUT_DK * oep;
+  const int in_lds0 = HORIZ ? in_r0 * PI + in_k0 : in_k0 * 64 + in_r0;
+  constexpr int IN_LDS_DJ = HORIZ ? IN_DR * PI : IN_DK * 64;
+  const int out_lds0 = HORIZ ? out_r0 * PO + out_k0 : out_k0 * 64 + out_r0;
+  constexpr int OUT_LDS_DJ = HORIZ ? OUT_DR * PO : OUT_DK * 64;
+  auto fetch_chunk = [&](int c, int32_t(&va)[NIN], int32_t(&vr)[NIN]) {
+    const uint32_t ca = a_off0 + (uint32_t)(c * S) * aep, cr = r_off0 + (uint32_t)(c * S) * rep;
+#pragma unroll
+    for (int j = 0; j < NIN; j++) {
+      const bool ok = l0 + in_r0 + j * IN_DR < n_lines && m + j * NM < 64 * S;
+      va[j] = ok ? ga[ca + j * a_dj] : 0;
+      vr[j] = ok ? gr[cr + j * r_dj] : 0;
+    }
+  };
+  auto stage_chunk = [&](int c, const int32_t(&va)[NIN], const int32_t(&vr)[NIN]) {
+#pragma unroll
+    for (int j = 0; j < NIN; j++) {
+      if (m + j * NM < 64 * S) {
+        s_avg[c & 1][in_lds0 + j * IN_LDS_DJ] = va[j];
+        s_res[c & 1][in_lds0 + j * IN_LDS_DJ] = vr[j];
+      }
+    }
+  };
+  auto store_chunk = [&](int c) {
+    const int32_t* so = s_out[c & 1];
+    const uint32_t co = o_off0 + (uint32_t)(2 * c * S) * oep;
+    int32_t v[NOUT];
+#pragma unroll
+    for (int j = 0; j < NOUT; j++) v[j] = m + j * NM < 64 * 2 * S ? so[out_lds0 + j * OUT_LDS_DJ] : 0;
+#pragma unroll
+    for (int j = 0; j < NOUT; j++)
+      if (l0 + out_r0 + j * OUT_DR < n_lines && m + j * NM < 64 * 2 * S) go[co + j * o_dj] = v[j];
+  };
+
+  const int l = l0 + tid;  // chain lanes
+  int32_t cur = 0, d = 0;
+  if (chain && l < n_lines) cur = ga[(size_t)l * avg_lp];
+  // mover schedule, iteration c: stage chunk c + 1 (fetched during iteration c - 1: its latency is a whole iteration
+  // old), fetch chunk c + 2 into registers, drain the outputs of chunk c - 1
+  int32_t pa[NIN], pr[NIN];
+  if (!chain && n_chunks > 0) {
+    fetch_chunk(0, pa, pr);
+    stage_chunk(0, pa, pr);
+    if (n_chunks > 1) fetch_chunk(1, pa, pr);
+  }
+  lds_barrier();
+  for (int c = 0; c < n_chunks; c++) {
+    if (!chain) {
+      if (c + 1 < n_chunks) stage_chunk(c + 1, pa, pr);
+      if (c + 2 < n_chunks) fetch_chunk(c + 2, pa, pr);
+      if (c >= 1) store_chunk(c - 1);
+    } else {
+      const int32_t* ia = s_avg[c & 1];
+      const int32_t* ir = s_res[c & 1];
+      int32_t* oa = s_out[c & 1];
+      int32_t xa[S], xr[S];
+      if constexpr (HORIZ) {
+#pragma unroll
+        for (int j = 0; j < S / 4; j++) {
+          const int4 va = *reinterpret_cast<const int4*>(ia + tid * PI + 4 * j);
+          const int4 vr = *reinterpret_cast<const int4*>(ir + tid * PI + 4 * j);
+          xa[4 * j] = va.x; xa[4 * j + 1] = va.y; xa[4 * j + 2] = va.z; xa[4 * j + 3] = va.w;
+          xr[4 * j] = vr.x; xr[4 * j + 1] = vr.y; xr[4 * j + 2] = vr.z; xr[4 * j + 3] = vr.w;
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < S; k++) {
+          xa[k] = ia[k * 64 + tid];
+          xr[k] = ir[k * 64 + tid];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < S; k += 2) {
+        int32_t a0, b0, a1, b1;
+        unsqueeze_step(cur, xr[k], xa[k], d, a0, b0);
+        unsqueeze_step(xa[k], xr[k + 1], xa[k + 1], d, a1, b1);
+        cur = xa[k + 1];
+        if constexpr (HORIZ) {
+          *reinterpret_cast<int4*>(oa + tid * PO + 2 * k) = make_int4(a0, b0, a1, b1);
+        } else {
+          oa[(2 * k) * 64 + tid] = a0;
+          oa[(2 * k + 1) * 64 + tid] = b0;
+          oa[(2 * k + 2) * 64 + tid] = a1;
+          oa[(2 * k + 3) * 64 + tid] = b1;
+        }
+      }
+    }
+    lds_barrier();
+  }
+  if (!chain) {
+    if (n_chunks > 0) store_chunk(n_chunks - 1);
+    return;
+  }
+  if (l >= n_lines) return;
+  // what is left of the line (< S steps, the closing pair or the copied tail): the chain lane itself, as in k6_unsqueeze
+  const int32_t* __restrict__ a = ga + (size_t)l * avg_lp;
+  const int32_t* __restrict__ r = gr + (size_t)l * res_lp;
+  int32_t* __restrict__ o = go + (size_t)l * out_lp;
+  for (int i = n_chunks * S; i < n_main; i++) {
+    const int32_t nxt = a[(size_t)(i + 1) * avg_ep];
+    int32_t va, vb;
+    unsqueeze_step(cur, r[(size_t)i * res_ep], nxt, d, va, vb);
+    o[(size_t)(2 * i) * out_ep] = va;
+    o[(size_t)(2 * i + 1) * out_ep] = vb;
+    cur = nxt;
+  }
+  if (!has_tail) {
+    int32_t va, vb;
+    unsqueeze_step(cur, r[(size_t)(w - 1) * res_ep], cur, d, va, vb);
+    o[(size_t)(2 * w - 2) * out_ep] = va;
+    o[(size_t)(2 * w - 1) * out_ep] = vb;
+  } else {
+    o[(size_t)(2 * w) * out_ep] = cur;
+  }
+}
+
+// The last step of a colour image's squeeze chain is an unsqueeze of three channels at full size (vertical for square
+// and tall images, horizontal for wide ones: default_squeeze, squeeze.rs:71-105), and the transform that follows it in
+// the inverse chain is the RCT on the same three channels: a second full read and write of the image.  Fused form:
+// the chain wave's lanes are 3 planes x NL lines, so that the three channel values of every output sample meet in one
+// workgroup's LDS tile, and the movers apply rct_op while they drain it.  NL = 21 lines for the horizontal step (63
+// lanes); 16 columns for the vertical one (48 lanes), so that the per-plane row segments the movers touch are whole
+// 64-byte sectors.  The remainder of a line (what k6_unsqueeze_tiled leaves to the chain lane's own stores) goes
+// through the tile as well, as a partial chunk.
+template <bool HORIZ>
+__global__ __launch_bounds__(256) void k6_unsqueeze_rct(const SqueezePlanes pl, uint32_t avg_lp, uint32_t avg_ep,
+                                                        uint32_t res_lp, uint32_t res_ep, uint32_t out_lp,
+                                                        uint32_t out_ep, int n_lines, int n_out, int op, int perm) {
+  constexpr int S = JXLH_SQT_S, PI = JXLH_SQT_PI, PO = JXLH_SQT_PO, NL = HORIZ ? 21 : 16, NM = 192;
+  constexpr int NIN = (64 * S + NM - 1) / NM, NPIX = (NL * 2 * S + NM - 1) / NM;
+  constexpr int IN_ELEMS = HORIZ ? 64 * PI : 64 * S, OUT_ELEMS = HORIZ ? 64 * PO : 64 * 2 * S;
+  __shared__ __attribute__((aligned(16))) int32_t s_avg[2][IN_ELEMS];
+  __shared__ __attribute__((aligned(16))) int32_t s_res[2][IN_ELEMS];
+  __shared__ __attribute__((aligned(16))) int32_t s_out[2][OUT_ELEMS];
+  const int tid = threadIdx.x;
+  const int l0 = blockIdx.x * NL;
+  const int w = n_out / 2;
+  const bool has_tail = n_out & 1;
+  const int n_main = has_tail ? w : w - 1;
+  const int n_chunks = n_main / S;
+  const bool chain = tid < 64;
+  const int m = tid - 64;
+  // perm: which output plane receives w0 / w1 / w2 (as k4_rct)
+  int32_t *o0, *o1, *o2;
+  switch (perm) {
+    default:
+    case 0: o0 = pl.out[0]; o1 = pl.out[1]; o2 = pl.out[2]; break;
+    case 1: o0 = pl.out[1]; o1 = pl.out[2]; o2 = pl.out[0]; break;
+    case 2: o0 = pl.out[2]; o1 = pl.out[0]; o2 = pl.out[1]; break;
+    case 3: o0 = pl.out[0]; o1 = pl.out[2]; o2 = pl.out[1]; break;
+    case 4: o0 = pl.out[1]; o1 = pl.out[0]; o2 = pl.out[2]; break;
+    case 5: o0 = pl.out[2]; o1 = pl.out[1]; o2 = pl.out[0]; break;
+  }
+  // plane p of a channel triple as base + masked byte offsets (a select chain over three pointers is turned into a
+  // table in scratch memory by the compiler, and a scratch load in front of every global load)
+  const int64_t a_d1 = (const char*)pl.avg[1] - (const char*)pl.avg[0], a_d2 = (const char*)pl.avg[2] - (const char*)pl.avg[0];
+  const int64_t r_d1 = (const char*)pl.res[1] - (const char*)pl.res[0], r_d2 = (const char*)pl.res[2] - (const char*)pl.res[0];
+  auto plane_ptr = [](const int32_t* base, int64_t d1, int64_t d2, int p) {
+    const int64_t off = (-(int64_t)(p == 1) & d1) | (-(int64_t)(p == 2) & d2);
+    return (const int32_t*)((const char*)base + off);
+  };
+  // tile row r = plane * NL + line; rows from 3 NL on are unused
+  auto row_of = [&](int r, int& p, int& q) {
+    p = r / NL;
+    q = r - p * NL;
+    return r < 3 * NL && l0 + q < n_lines;
+  };
+  // tile position of (row r, element k): one line per row of PI / PO dwords for the horizontal step (the chain lane
+  // reads its row with 128-bit accesses), one element row of 64 lanes for the vertical one
+  auto in_idx = [](int r, int k) { return HORIZ ? r * PI + k : k * 64 + r; };
+  auto out_idx = [](int r, int k) { return HORIZ ? r * PO + k : k * 64 + r; };
+  auto fetch_chunk = [&](int c, int32_t(&va)[NIN], int32_t(&vr)[NIN]) {
+#pragma unroll
+    for (int j = 0; j < NIN; j++) {
+      const int f = m + j * NM, r = HORIZ ? f / S : f % 64, k = HORIZ ? f % S : f / 64;
+      int p, q;
+      const bool ok = row_of(r, p, q) && f < 64 * S;
+      const int32_t* ap = plane_ptr(pl.avg[0], a_d1, a_d2, p);
+      const int32_t* rp = plane_ptr(pl.res[0], r_d1, r_d2, p);
+      va[j] = ok ? ap[(uint32_t)(l0 + q) * avg_lp + (uint32_t)(c * S + 1 + k) * avg_ep] : 0;
+      vr[j] = ok ? rp[(uint32_t)(l0 + q) * res_lp + (uint32_t)(c * S + k) * res_ep] : 0;
+    }
+  };
+  auto stage_chunk = [&](int c, const int32_t(&va)[NIN], const int32_t(&vr)[NIN]) {
+#pragma unroll
+    for (int j = 0; j < NIN; j++) {
+      const int f = m + j * NM, r = HORIZ ? f / S : f % 64, k = HORIZ ? f % S : f / 64;
+      if (f < 64 * S) {
+        s_avg[c & 1][in_idx(r, k)] = va[j];
+        s_res[c & 1][in_idx(r, k)] = vr[j];
+      }
+    }
+  };
+  // drain `count` (<= 2 S) output samples per line of chunk c, through the RCT
+  auto store_chunk = [&](int c, int count) {
+    const int32_t* so = s_out[c & 1];
+#pragma unroll
+    for (int j = 0; j < NPIX; j++) {
+      const int f = m + j * NM, q = HORIZ ? f / (2 * S) : f % NL, k = HORIZ ? f % (2 * S) : f / NL;
+      if (f < NL * 2 * S && l0 + q < n_lines && k < count) {
+        const int32_t v0 = so[out_idx(q, k)], v1 = so[out_idx(NL + q, k)], v2 = so[out_idx(2 * NL + q, k)];
+        int32_t x, y, z;
+        switch (op) {
+          case 0: rct_op<0>(v0, v1, v2, x, y, z); break;
+          case 1: rct_op<1>(v0, v1, v2, x, y, z); break;
+          case 2: rct_op<2>(v0, v1, v2, x, y, z); break;
+          case 3: rct_op<3>(v0, v1, v2, x, y, z); break;
+          case 4: rct_op<4>(v0, v1, v2, x, y, z); break;
+          case 5: rct_op<5>(v0, v1, v2, x, y, z); break;
+          default: rct_op<6>(v0, v1, v2, x, y, z); break;
+        }
+        const uint32_t off = (uint32_t)(l0 + q) * out_lp + (uint32_t)(2 * c * S + k) * out_ep;
+        o0[off] = x;
+        o1[off] = y;
+        o2[off] = z;
+      }
+    }
+  };
+
+  int cp, cq;
+  const bool live = chain && row_of(tid, cp, cq);
+  const int32_t* __restrict__ a = nullptr;
+  const int32_t* __restrict__ r = nullptr;
+  int32_t cur = 0, d = 0;
+  if (live) {
+    a = plane_ptr(pl.avg[0], a_d1, a_d2, cp) + (size_t)(l0 + cq) * avg_lp;
+    r = plane_ptr(pl.res[0], r_d1, r_d2, cp) + (size_t)(l0 + cq) * res_lp;
+    cur = a[0];
+  }
+  int32_t pa[NIN], pr[NIN];
+  if (!chain && n_chunks > 0) {
+    fetch_chunk(0, pa, pr);
+    stage_chunk(0, pa, pr);
+    if (n_chunks > 1) fetch_chunk(1, pa, pr);
+  }
+  lds_barrier();
+  for (int c = 0; c < n_chunks; c++) {
+    if (!chain) {
+      if (c + 1 < n_chunks) stage_chunk(c + 1, pa, pr);
+      if (c + 2 < n_chunks) fetch_chunk(c + 2, pa, pr);
+      if (c >= 1) store_chunk(c - 1, 2 * S);
+    } else {
+      const int32_t* ia = s_avg[c & 1];
+      const int32_t* ir = s_res[c & 1];
+      int32_t* oa = s_out[c & 1];
+      int32_t xa[S], xr[S];
+      if constexpr (HORIZ) {
+#pragma unroll
+        for (int j = 0; j < S / 4; j++) {
+          const int4 va = *reinterpret_cast<const int4*>(ia + tid * PI + 4 * j);
+          const int4 vr = *reinterpret_cast<const int4*>(ir + tid * PI + 4 * j);
+          xa[4 * j] = va.x; xa[4 * j + 1] = va.y; xa[4 * j + 2] = va.z; xa[4 * j + 3] = va.w;
+          xr[4 * j] = vr.x; xr[4 * j + 1] = vr.y; xr[4 * j + 2] = vr.z; xr[4 * j + 3] = vr.w;
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < S; k++) {
+          xa[k] = ia[k * 64 + tid];
+          xr[k] = ir[k * 64 + tid];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < S; k += 2) {
+        int32_t a0, b0, a1, b1;
+        unsqueeze_step(cur, xr[k], xa[k], d, a0, b0);
+        unsqueeze_step(xa[k], xr[k + 1], xa[k + 1], d, a1, b1);
+        cur = xa[k + 1];
+        if constexpr (HORIZ) {
+          *reinterpret_cast<int4*>(oa + tid * PO + 2 * k) = make_int4(a0, b0, a1, b1);
+        } else {
+          oa[(2 * k) * 64 + tid] = a0;
+          oa[(2 * k + 1) * 64 + tid] = b0;
+          oa[(2 * k + 2) * 64 + tid] = a1;
+          oa[(2 * k + 3) * 64 + tid] = b1;
+        }
+      }
+    }
+    lds_barrier();
+  }
+  // the rest of the line as a partial chunk: the chain lanes read their own inputs (< S steps), the movers drain
+  const int rest = n_out - 2 * n_chunks * S;  // 1 .. 2 S samples
+  if (chain) {
+    if (live) {
+      int32_t* oa = s_out[n_chunks & 1];
+      const int i0 = n_chunks * S;
+      if (w == 0) {
+        oa[out_idx(tid, 0)] = cur;  // single sample (squeeze.rs:468-476, :672-675)
+      } else {
+        for (int i = i0; i < n_main; i++) {
+          const int32_t nxt = a[(size_t)(i + 1) * avg_ep];
+          int32_t va, vb;
+          unsqueeze_step(cur, r[(size_t)i * res_ep], nxt, d, va, vb);
+          oa[out_idx(tid, 2 * (i - i0))] = va;
+          oa[out_idx(tid, 2 * (i - i0) + 1)] = vb;
+          cur = nxt;
+        }
+        if (!has_tail) {
+          int32_t va, vb;
+          unsqueeze_step(cur, r[(size_t)(w - 1) * res_ep], cur, d, va, vb);
+          oa[out_idx(tid, 2 * (w - 1 - i0))] = va;
+          oa[out_idx(tid, 2 * (w - 1 - i0) + 1)] = vb;
+        } else {
+          oa[out_idx(tid, 2 * (w - i0))] = cur;
+        }
+      }
+    }
+  } else if (n_chunks > 0) {
+    store_chunk(n_chunks - 1, 2 * S);
+  }
+  lds_barrier();
+  if (!chain) store_chunk(n_chunks, rest);
+}
+
 void launch_unsqueeze(hipStream_t s, int horizontal, int n_planes, const int32_t* const avg[], size_t avg_stride,
                       const int32_t* const res[], size_t res_stride, uint32_t out_w, uint32_t out_h,
                       int32_t* const out[], size_t out_stride) {
@@ -610,6 +999,22 @@ void launch_unsqueeze(hipStream_t s, int horizontal, int n_planes, const int32_t
     pl.res[i] = res[i];
     pl.out[i] = out[i];
     aligned = aligned && ((uintptr_t)avg[i] % 16 == 0) && ((uintptr_t)res[i] % 16 == 0) && ((uintptr_t)out[i] % 16 == 0);
+  }
+  // long lines go through the mover / chain workgroups; short ones (the early levels of a squeeze chain) keep the
+  // one-wave kernel: nothing to stream, and a 256-thread workgroup would idle three waves
+  const int n_steps = (int)(horizontal ? out_w : out_h) / 2;
+  const size_t span = out_stride * (size_t)out_h;  // the largest of the three planes; the kernel's offsets are 32-bit
+  if (n_steps >= 4 * JXLH_SQT_S && span < ((size_t)1 << 31) && avg_stride * (size_t)out_h < ((size_t)1 << 31) &&
+      res_stride * (size_t)out_h < ((size_t)1 << 31)) {
+    const int n_lines = (int)(horizontal ? out_h : out_w);
+    const dim3 grid((n_lines + 63) / 64, n_planes);
+    if (horizontal)
+      hipLaunchKernelGGL(k6_unsqueeze_tiled<true>, grid, dim3(256), 0, s, pl, avg_stride, (size_t)1, res_stride,
+                         (size_t)1, out_stride, (size_t)1, n_lines, (int)out_w);
+    else
+      hipLaunchKernelGGL(k6_unsqueeze_tiled<false>, grid, dim3(256), 0, s, pl, (size_t)1, avg_stride, (size_t)1,
+                         res_stride, (size_t)1, out_stride, n_lines, (int)out_h);
+    return;
   }
   if (horizontal) {
     const int n_lines = (int)out_h;
@@ -627,6 +1032,33 @@ void launch_unsqueeze(hipStream_t s, int horizontal, int n_planes, const int32_t
     hipLaunchKernelGGL(k6_unsqueeze<false>, grid, dim3(64), 0, s, pl, (size_t)1, avg_stride, (size_t)1, res_stride,
                        (size_t)1, out_stride, n_lines, (int)out_h);
   }
+}
+
+// Unsqueeze of three channels + inverse RCT on them, one pass (planes below 2^31 samples; the caller falls back to
+// the two separate launches otherwise).
+bool launch_unsqueeze_rct(hipStream_t s, int horizontal, const int32_t* const avg[3], size_t avg_stride,
+                          const int32_t* const res[3], size_t res_stride, uint32_t out_w, uint32_t out_h,
+                          int32_t* const out[3], size_t out_stride, int op, int perm) {
+  if (out_w == 0 || out_h == 0) return true;
+  const size_t lim = (size_t)1 << 31;
+  if (out_stride * (size_t)out_h >= lim || avg_stride * (size_t)out_h >= lim || res_stride * (size_t)out_h >= lim)
+    return false;
+  SqueezePlanes pl{};
+  for (int i = 0; i < 3; i++) {
+    pl.avg[i] = avg[i];
+    pl.res[i] = res[i];
+    pl.out[i] = out[i];
+  }
+  if (horizontal) {
+    const dim3 grid((out_h + 20) / 21);
+    hipLaunchKernelGGL(k6_unsqueeze_rct<true>, grid, dim3(256), 0, s, pl, (uint32_t)avg_stride, 1u, (uint32_t)res_stride,
+                       1u, (uint32_t)out_stride, 1u, (int)out_h, (int)out_w, op, perm);
+  } else {
+    const dim3 grid((out_w + 15) / 16);
+    hipLaunchKernelGGL(k6_unsqueeze_rct<false>, grid, dim3(256), 0, s, pl, 1u, (uint32_t)avg_stride, 1u,
+                       (uint32_t)res_stride, 1u, (uint32_t)out_stride, (int)out_w, (int)out_h, op, perm);
+  }
+  return true;
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -43,7 +43,7 @@ ABI_SYMBOLS = [
     "jxlh_stage_gaborish",
     "jxlh_stage_epf", "jxlh_stage_lf_smooth", "jxlh_stage_transform_to_pixels", "jxlh_rct", "jxlh_palette", "jxlh_palette_delta", "jxlh_modular_to_rgb8",
     "jxlh_modular_to_f32", "jxlh_modular_xyb_to_f32",
-    "jxlh_unsqueeze", "jxlh_unsqueeze_planes", "jxlh_smooth_unsqueeze", "jxlh_abi_version", "jxlh_covered_blocks_x", "jxlh_covered_blocks_y",
+    "jxlh_unsqueeze", "jxlh_unsqueeze_planes", "jxlh_smooth_unsqueeze", "jxlh_unsqueeze_rct", "jxlh_abi_version", "jxlh_covered_blocks_x", "jxlh_covered_blocks_y",
     "jxlh_quant_table_for_type", "jxlh_quant_table_size",
     "jxlh_comm_unique_id", "jxlh_comm_init", "jxlh_comm_init_local", "jxlh_comm_destroy", "jxlh_comm_band",
     "jxlh_frame_run_sharded", "jxlh_frame_allgather", "jxlh_frames_run_sharded_local", "jxlh_frames_allgather_local",
@@ -167,6 +167,7 @@ def load():
     L.jxlh_modular_to_f32.argtypes = [vp, vp, sz, u32, vp]
     L.jxlh_modular_xyb_to_f32.argtypes = [vp, vp, vp, vp, sz, vp, vp, vp, vp]
     L.jxlh_unsqueeze.argtypes = [vp, i32, vp, sz, vp, sz, u32, u32, vp, sz]
+    L.jxlh_unsqueeze_rct.argtypes = [vp, i32, C.POINTER(vp), sz, C.POINTER(vp), sz, u32, u32, C.POINTER(vp), sz, i32, i32]
     L.jxlh_smooth_unsqueeze.argtypes = [vp, i32, vp, sz, u32, u32, u32, u32, vp, sz, u32, u32]
     L.jxlh_unsqueeze_planes.argtypes = [vp, i32, i32, C.POINTER(vp), sz, C.POINTER(vp), sz, u32, u32, C.POINTER(vp), sz]
     L.jxlh_abi_version.restype = u32
@@ -679,6 +680,14 @@ class Context:
         ov = (C.c_void_p * n)(*[_addr(a).value for a in out])
         self._chk(self.L.jxlh_unsqueeze_planes(self._ctx, 1 if horizontal else 0, n, av, avg_stride, rv, res_stride,
                                                out_w, out_h, ov, out_stride), "unsqueeze_planes")
+
+    def unsqueeze_rct(self, horizontal, avg, res, out, out_w, out_h, avg_stride, res_stride, out_stride, op, perm):
+        """Unsqueeze of three device-resident planes fused with the inverse RCT on them."""
+        av = (C.c_void_p * 3)(*[_addr(a).value for a in avg])
+        rv = (C.c_void_p * 3)(*[_addr(a).value for a in res])
+        ov = (C.c_void_p * 3)(*[_addr(a).value for a in out])
+        self._chk(self.L.jxlh_unsqueeze_rct(self._ctx, 1 if horizontal else 0, av, avg_stride, rv, res_stride, out_w,
+                                            out_h, ov, out_stride, op, perm), "unsqueeze_rct")
 
     SMOOTH_H, SMOOTH_V, SMOOTH_2D = 0, 1, 2
 

@@ -668,6 +668,83 @@ def test_unsqueeze_bit_exact_and_round_trip(ctx, oracle, shape):
     assert np.array_equal(ctx.unsqueeze(True, avg, res, w, h), oracle.unsqueeze_h(avg, res, w))
 
 
+@pytest.mark.parametrize("shape", [(70, 256), (70, 257), (1, 300), (129, 321), (64, 322), (200, 1031), (3, 2048)])
+def test_unsqueeze_long_lines_take_the_streamed_kernel(ctx, oracle, shape):
+    """lines of >= 128 steps run in k6_unsqueeze_tiled (mover waves stream 32-step chunks through LDS for one chain
+    wave): chunk boundaries, the scalar remainder, odd lengths, line counts that do not fill a workgroup -- in both
+    directions (the shape is transposed for the vertical step) and with strided / multi-plane device buffers."""
+    lines, n = shape
+    rng = np.random.default_rng(lines * 7 + n)
+    avg = rng.integers(-3000, 3000, size=(lines, (n + 1) // 2)).astype(np.int32)
+    res = np.round(rng.laplace(0, 40, size=(lines, n // 2))).astype(np.int32)
+    avg[::4, 1:] = avg[::4, :-1]  # runs of equal averages: zero tendencies
+    assert np.array_equal(ctx.unsqueeze(True, avg, res, n, lines), oracle.unsqueeze_h(avg, res, n))
+    at, rt = np.ascontiguousarray(avg.T), np.ascontiguousarray(res.T)
+    assert np.array_equal(ctx.unsqueeze(False, at, rt, lines, n), oracle.unsqueeze_v(at, rt, n))
+    # three planes in one launch, strides wider than the rows, sentinel-checked padding
+    from helpers import DeviceArray
+    a_stride, r_stride, o_stride = avg.shape[1] + 5, max(res.shape[1], 1) + 3, n + 9
+    planes = []
+    for c in range(3):
+        a = np.zeros((lines, a_stride), np.int32); a[:, :avg.shape[1]] = np.roll(avg, c, axis=0)
+        r = np.zeros((lines, r_stride), np.int32); r[:, :res.shape[1]] = np.roll(res, c, axis=0)
+        planes.append((a, r, DeviceArray(a), DeviceArray(r), DeviceArray(np.full((lines, o_stride), -77, np.int32))))
+    ctx.unsqueeze_planes(True, [p[2].ptr for p in planes], [p[3].ptr for p in planes], [p[4].ptr for p in planes],
+                         n, lines, a_stride, r_stride, o_stride)
+    ctx.sync()
+    for a, r, da, dr, do in planes:
+        got = do.download(np.int32, lines * o_stride).reshape(lines, o_stride)
+        assert np.array_equal(got[:, :n], oracle.unsqueeze_h(a[:, :avg.shape[1]], r[:, :res.shape[1]], n))
+        assert (got[:, n:] == -77).all()
+        da.free(); dr.free(); do.free()
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (1, 2), (3, 7), (16, 64), (21, 64), (22, 65), (50, 129), (64, 130),
+                                   (129, 321), (7, 1031)])
+@pytest.mark.parametrize("op_perm", [(6, 0), (0, 0), (1, 3), (2, 1), (3, 5), (4, 2), (5, 4), (6, 5)])
+@pytest.mark.parametrize("horizontal", [True, False])
+def test_fused_unsqueeze_and_rct(ctx, oracle, shape, op_perm, horizontal):
+    """jxlh_unsqueeze_rct == oracle unsqueeze on three planes followed by the oracle RCT: both directions, every op,
+    permutations, line counts around the 21-line / 16-column workgroups, lengths around the 32-step chunks (incl.
+    everything-in-the-remainder), strided planes with sentinel padding."""
+    from helpers import DeviceArray
+    lines, n = shape          # lines x n samples along the squeezed axis
+    op, perm = op_perm
+    rng = np.random.default_rng(lines * 13 + n + op * 7 + perm)
+    na, nr = (n + 1) // 2, n // 2
+    pad = (3, 5, 2)
+    host, dev = [], []
+    for c in range(3):
+        a = rng.integers(-3000, 3000, size=(lines, na)).astype(np.int32)
+        r = np.round(rng.laplace(0, 40, size=(lines, nr))).astype(np.int32)
+        if not horizontal:
+            a, r = np.ascontiguousarray(a.T), np.ascontiguousarray(r.T)
+        host.append((a, r))
+    ow, oh = (n, lines) if horizontal else (lines, n)
+    a_stride, r_stride, o_stride = host[0][0].shape[1] + pad[0], max(host[0][1].shape[1], 1) + pad[1], ow + pad[2]
+
+    def padded(x, stride):
+        out = np.zeros((max(x.shape[0], 1), stride), np.int32)
+        out[:x.shape[0], :x.shape[1]] = x
+        return out
+    for a, r in host:
+        dev.append((DeviceArray(padded(a, a_stride)), DeviceArray(padded(r, r_stride)),
+                    DeviceArray(np.full((oh, o_stride), -55, np.int32))))
+    ctx.unsqueeze_rct(horizontal, [d[0].ptr for d in dev], [d[1].ptr for d in dev], [d[2].ptr for d in dev], ow, oh,
+                      a_stride, r_stride, o_stride, op, perm)
+    ctx.sync()
+    unsq = [oracle.unsqueeze_h(a, r, ow) if horizontal else oracle.unsqueeze_v(a, r, oh) for a, r in host]
+    want = oracle.rct(unsq, op, perm)
+    for c in range(3):
+        got = dev[c][2].download(np.int32, oh * o_stride).reshape(oh, o_stride)
+        exp = want[c].reshape(oh, ow)
+        assert np.array_equal(got[:, :ow], exp), (c, np.argwhere(got[:, :ow] != exp)[:4])
+        assert (got[:, ow:] == -55).all()
+    for d in dev:
+        for x in d:
+            x.free()
+
+
 @pytest.mark.parametrize("scale", [2**15, 2**24, 2**28])
 def test_unsqueeze_large_magnitudes(ctx, oracle, scale):
     """the device folds the reference's two parity clamps into min() operations (k_modular.hip); checked here

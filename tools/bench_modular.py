@@ -82,9 +82,23 @@ def main():
             avg = outs
         ctx._chk(L.jxlh_rct(ctx._ctx, P(avg[0]), P(avg[1]), P(avg[2]), n * n, 6, 0), "rct")
 
+    def chain_fused():
+        avg = cur
+        for horizontal, ow, oh, res, outs in plan[:-1]:
+            ctx.unsqueeze_planes(horizontal, avg, res, outs, ow, oh, avg[0].shape[1], res[0].shape[1], ow)
+            avg = outs
+        horizontal, ow, oh, res, outs = plan[-1]
+        ctx.unsqueeze_rct(horizontal, avg, res, outs, ow, oh, avg[0].shape[1], res[0].shape[1], ow, 6, 0)
+
     samples = sum(ow * oh for _, ow, oh, _, _ in plan) * 3
     timeit("config4_chain_squeeze_rct", chain, 8.0 * samples + 24.0 * n * n, reps=3)
     results["config4_chain_squeeze_rct"]["steps"] = len(plan)
+    timeit("config4_chain_fused_last_step", chain_fused, 8.0 * samples + 0.0, reps=3)
+    last = plan[-1]
+    timeit("unsqueeze_rct_last_step_x3", lambda: ctx.unsqueeze_rct(last[0], plan[-2][4], last[3], last[4], last[1], last[2],
+                                                                    plan[-2][4][0].shape[1], last[3][0].shape[1], last[1], 6, 0),
+           3 * 8.0 * n * n)
+    results["unsqueeze_rct_last_step_x3"]["horizontal"] = bool(last[0])
     results["config4_chain_squeeze_rct"]["MP_per_s"] = round(n * n / results["config4_chain_squeeze_rct"]["ms"] / 1e3, 1)
     print(json.dumps({"size": n, "kernels": results}))
 
