@@ -799,7 +799,7 @@ __global__ __launch_bounds__(256) void k6_unsqueeze_tiled(const SqueezePlanes pl
 // lanes); 16 columns for the vertical one (48 lanes), so that the per-plane row segments the movers touch are whole
 // 64-byte sectors.  The remainder of a line (what k6_unsqueeze_tiled leaves to the chain lane's own stores) goes
 // through the tile as well, as a partial chunk.
-template <bool HORIZ>
+template <bool HORIZ, bool VEC>
 __global__ __launch_bounds__(256) void k6_unsqueeze_rct(const SqueezePlanes pl, uint32_t avg_lp, uint32_t avg_ep,
                                                         uint32_t res_lp, uint32_t res_ep, uint32_t out_lp,
                                                         uint32_t out_ep, int n_lines, int n_out, int op, int perm) {
@@ -846,7 +846,31 @@ __global__ __launch_bounds__(256) void k6_unsqueeze_rct(const SqueezePlanes pl, 
   // reads its row with 128-bit accesses), one element row of 64 lanes for the vertical one
   auto in_idx = [](int r, int k) { return HORIZ ? r * PI + k : k * 64 + r; };
   auto out_idx = [](int r, int k) { return HORIZ ? r * PO + k : k * 64 + r; };
+  // VEC (vertical step, 16-byte aligned planes, column count a multiple of 4): a mover slot is four columns of one
+  // plane's element row -- 16 row segments of 64 bytes per wave instruction instead of three (or four, when storing),
+  // which is what this step's throughput hangs on once three planes stream through every workgroup.  The register
+  // arrays then hold int4 slots: (k, plane, quad) for the inputs, (k, quad) for the outputs.
+  static_assert(!(VEC && HORIZ), "the vector movers are for the vertical step");
+  constexpr int NVIN = (S * 12 + NM - 1) / NM, NVOUT = (2 * S * 4 + NM - 1) / NM;
   auto fetch_chunk = [&](int c, int32_t(&va)[NIN], int32_t(&vr)[NIN]) {
+    if constexpr (VEC) {
+#pragma unroll
+      for (int j = 0; j < NVIN; j++) {
+        const int f = m + j * NM, k = f / 12, rem = f - k * 12, p = rem >> 2, qq = rem & 3;
+        // slots past the tile (the last j) and quads past the last column read a valid address instead of being
+        // predicated (a select between a load and a constant becomes a load through a selected POINTER, via scratch);
+        // what they fetch is never staged / never stored
+        const int kk = min(k, S - 1);
+        const uint32_t col = (uint32_t)(l0 + 4 * qq < n_lines ? l0 + 4 * qq : l0);
+        const int32_t* ap = plane_ptr(pl.avg[0], a_d1, a_d2, p);
+        const int32_t* rp = plane_ptr(pl.res[0], r_d1, r_d2, p);
+        const int4 xa = *reinterpret_cast<const int4*>(ap + (uint32_t)(c * S + 1 + kk) * avg_ep + col);
+        const int4 xr = *reinterpret_cast<const int4*>(rp + (uint32_t)(c * S + kk) * res_ep + col);
+        va[4 * j] = xa.x; va[4 * j + 1] = xa.y; va[4 * j + 2] = xa.z; va[4 * j + 3] = xa.w;
+        vr[4 * j] = xr.x; vr[4 * j + 1] = xr.y; vr[4 * j + 2] = xr.z; vr[4 * j + 3] = xr.w;
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < NIN; j++) {
       const int f = m + j * NM, r = HORIZ ? f / S : f % 64, k = HORIZ ? f % S : f / 64;
@@ -859,6 +883,18 @@ __global__ __launch_bounds__(256) void k6_unsqueeze_rct(const SqueezePlanes pl, 
     }
   };
   auto stage_chunk = [&](int c, const int32_t(&va)[NIN], const int32_t(&vr)[NIN]) {
+    if constexpr (VEC) {
+#pragma unroll
+      for (int j = 0; j < NVIN; j++) {
+        const int f = m + j * NM, k = f / 12, rem = f - k * 12, p = rem >> 2, qq = rem & 3;
+        if (f < S * 12) {
+          const int idx = k * 64 + p * NL + 4 * qq;
+          *reinterpret_cast<int4*>(&s_avg[c & 1][idx]) = make_int4(va[4 * j], va[4 * j + 1], va[4 * j + 2], va[4 * j + 3]);
+          *reinterpret_cast<int4*>(&s_res[c & 1][idx]) = make_int4(vr[4 * j], vr[4 * j + 1], vr[4 * j + 2], vr[4 * j + 3]);
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < NIN; j++) {
       const int f = m + j * NM, r = HORIZ ? f / S : f % 64, k = HORIZ ? f % S : f / 64;
@@ -869,8 +905,41 @@ __global__ __launch_bounds__(256) void k6_unsqueeze_rct(const SqueezePlanes pl, 
     }
   };
   // drain `count` (<= 2 S) output samples per line of chunk c, through the RCT
+  auto rct4 = [&](const int4& v0, const int4& v1, const int4& v2, int4& x, int4& y, int4& z) {
+    switch (op) {
+#define JXLH_RCT4(OP)                          \
+  case OP:                                     \
+    rct_op<OP>(v0.x, v1.x, v2.x, x.x, y.x, z.x); \
+    rct_op<OP>(v0.y, v1.y, v2.y, x.y, y.y, z.y); \
+    rct_op<OP>(v0.z, v1.z, v2.z, x.z, y.z, z.z); \
+    rct_op<OP>(v0.w, v1.w, v2.w, x.w, y.w, z.w); \
+    break;
+      JXLH_RCT4(0) JXLH_RCT4(1) JXLH_RCT4(2) JXLH_RCT4(3) JXLH_RCT4(4) JXLH_RCT4(5)
+      default:
+      JXLH_RCT4(6)
+#undef JXLH_RCT4
+    }
+  };
   auto store_chunk = [&](int c, int count) {
     const int32_t* so = s_out[c & 1];
+    if constexpr (VEC) {
+#pragma unroll
+      for (int j = 0; j < NVOUT; j++) {
+        const int f = m + j * NM, k = f >> 2, qq = f & 3;
+        if (f < 2 * S * 4 && l0 + 4 * qq < n_lines && k < count) {
+          const int4 v0 = *reinterpret_cast<const int4*>(so + k * 64 + 4 * qq);
+          const int4 v1 = *reinterpret_cast<const int4*>(so + k * 64 + NL + 4 * qq);
+          const int4 v2 = *reinterpret_cast<const int4*>(so + k * 64 + 2 * NL + 4 * qq);
+          int4 x, y, z;
+          rct4(v0, v1, v2, x, y, z);
+          const uint32_t off = (uint32_t)(2 * c * S + k) * out_ep + (uint32_t)(l0 + 4 * qq);
+          *reinterpret_cast<int4*>(o0 + off) = x;
+          *reinterpret_cast<int4*>(o1 + off) = y;
+          *reinterpret_cast<int4*>(o2 + off) = z;
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < NPIX; j++) {
       const int f = m + j * NM, q = HORIZ ? f / (2 * S) : f % NL, k = HORIZ ? f % (2 * S) : f / NL;
@@ -1051,12 +1120,19 @@ bool launch_unsqueeze_rct(hipStream_t s, int horizontal, const int32_t* const av
   }
   if (horizontal) {
     const dim3 grid((out_h + 20) / 21);
-    hipLaunchKernelGGL(k6_unsqueeze_rct<true>, grid, dim3(256), 0, s, pl, (uint32_t)avg_stride, 1u, (uint32_t)res_stride,
+    hipLaunchKernelGGL((k6_unsqueeze_rct<true, false>), grid, dim3(256), 0, s, pl, (uint32_t)avg_stride, 1u, (uint32_t)res_stride,
                        1u, (uint32_t)out_stride, 1u, (int)out_h, (int)out_w, op, perm);
   } else {
     const dim3 grid((out_w + 15) / 16);
-    hipLaunchKernelGGL(k6_unsqueeze_rct<false>, grid, dim3(256), 0, s, pl, 1u, (uint32_t)avg_stride, 1u,
-                       (uint32_t)res_stride, 1u, (uint32_t)out_stride, (int)out_w, (int)out_h, op, perm);
+    bool vec = out_w % 4 == 0 && avg_stride % 4 == 0 && res_stride % 4 == 0 && out_stride % 4 == 0;
+    for (int i = 0; i < 3; i++)
+      vec = vec && ((uintptr_t)avg[i] % 16 == 0) && ((uintptr_t)res[i] % 16 == 0) && ((uintptr_t)out[i] % 16 == 0);
+    if (vec)
+      hipLaunchKernelGGL((k6_unsqueeze_rct<false, true>), grid, dim3(256), 0, s, pl, 1u, (uint32_t)avg_stride, 1u,
+                         (uint32_t)res_stride, 1u, (uint32_t)out_stride, (int)out_w, (int)out_h, op, perm);
+    else
+      hipLaunchKernelGGL((k6_unsqueeze_rct<false, false>), grid, dim3(256), 0, s, pl, 1u, (uint32_t)avg_stride, 1u,
+                         (uint32_t)res_stride, 1u, (uint32_t)out_stride, (int)out_w, (int)out_h, op, perm);
   }
   return true;
 }

@@ -699,11 +699,11 @@ def test_unsqueeze_long_lines_take_the_streamed_kernel(ctx, oracle, shape):
         da.free(); dr.free(); do.free()
 
 
-@pytest.mark.parametrize("shape", [(1, 1), (1, 2), (3, 7), (16, 64), (21, 64), (22, 65), (50, 129), (64, 130),
-                                   (129, 321), (7, 1031)])
+@pytest.mark.parametrize("shape", [(1, 1), (1, 2), (3, 7), (4, 70), (16, 64), (21, 64), (22, 65), (32, 200), (50, 129),
+                                   (64, 130), (100, 257), (129, 321), (7, 1031)])
 @pytest.mark.parametrize("op_perm", [(6, 0), (0, 0), (1, 3), (2, 1), (3, 5), (4, 2), (5, 4), (6, 5)])
-@pytest.mark.parametrize("horizontal", [True, False])
-def test_fused_unsqueeze_and_rct(ctx, oracle, shape, op_perm, horizontal):
+@pytest.mark.parametrize("horizontal,pad", [(True, (3, 5, 2)), (False, (3, 5, 2)), (False, (4, 8, 0))])
+def test_fused_unsqueeze_and_rct(ctx, oracle, shape, op_perm, horizontal, pad):
     """jxlh_unsqueeze_rct == oracle unsqueeze on three planes followed by the oracle RCT: both directions, every op,
     permutations, line counts around the 21-line / 16-column workgroups, lengths around the 32-step chunks (incl.
     everything-in-the-remainder), strided planes with sentinel padding."""
@@ -712,8 +712,7 @@ def test_fused_unsqueeze_and_rct(ctx, oracle, shape, op_perm, horizontal):
     op, perm = op_perm
     rng = np.random.default_rng(lines * 13 + n + op * 7 + perm)
     na, nr = (n + 1) // 2, n // 2
-    pad = (3, 5, 2)
-    host, dev = [], []
+    host, dev = [], []   # pad (4, 8, 0): 16-byte aligned rows -> the vector movers when the column count allows
     for c in range(3):
         a = rng.integers(-3000, 3000, size=(lines, na)).astype(np.int32)
         r = np.round(rng.laplace(0, 40, size=(lines, nr))).astype(np.int32)
@@ -722,6 +721,8 @@ def test_fused_unsqueeze_and_rct(ctx, oracle, shape, op_perm, horizontal):
         host.append((a, r))
     ow, oh = (n, lines) if horizontal else (lines, n)
     a_stride, r_stride, o_stride = host[0][0].shape[1] + pad[0], max(host[0][1].shape[1], 1) + pad[1], ow + pad[2]
+    if pad[2] == 0:  # keep the strides multiples of four wherever the widths are
+        a_stride, r_stride = (a_stride + 3) // 4 * 4, (r_stride + 3) // 4 * 4
 
     def padded(x, stride):
         out = np.zeros((max(x.shape[0], 1), stride), np.int32)
