@@ -804,7 +804,7 @@ __global__ __launch_bounds__(256) void k6_unsqueeze_rct(const SqueezePlanes pl, 
                                                         uint32_t res_lp, uint32_t res_ep, uint32_t out_lp,
                                                         uint32_t out_ep, int n_lines, int n_out, int op, int perm) {
   constexpr int S = JXLH_SQT_S, PI = JXLH_SQT_PI, PO = JXLH_SQT_PO, NL = HORIZ ? 21 : 16, NM = 192;
-  constexpr int NIN = (64 * S + NM - 1) / NM, NPIX = (NL * 2 * S + NM - 1) / NM;
+  constexpr int NIN = VEC ? 4 * ((S * 12 + 63) / 64) : (64 * S + NM - 1) / NM, NPIX = (NL * 2 * S + NM - 1) / NM;
   constexpr int IN_ELEMS = HORIZ ? 64 * PI : 64 * S, OUT_ELEMS = HORIZ ? 64 * PO : 64 * 2 * S;
   __shared__ __attribute__((aligned(16))) int32_t s_avg[2][IN_ELEMS];
   __shared__ __attribute__((aligned(16))) int32_t s_res[2][IN_ELEMS];
@@ -816,7 +816,12 @@ __global__ __launch_bounds__(256) void k6_unsqueeze_rct(const SqueezePlanes pl, 
   const int n_main = has_tail ? w : w - 1;
   const int n_chunks = n_main / S;
   const bool chain = tid < 64;
-  const int m = tid - 64;
+  // Mover roles.  The scalar movers (m = 0..191) both load and store.  The vector movers are split, wave 1 loading and
+  // waves 2..3 storing: a wave with loads and stores outstanding waits for the stores' acknowledgements whenever it
+  // needs a loaded value (one in-order vmcnt), which with a handful of wide instructions per chunk is all it does.
+  const bool loader = VEC ? (tid >= 64 && tid < 128) : !chain, storer = VEC ? tid >= 128 : !chain;
+  const int m = VEC ? (tid < 128 ? tid - 64 : tid - 128) : tid - 64;
+  constexpr int NML = VEC ? 64 : 192, NMS = VEC ? 128 : 192;
   // perm: which output plane receives w0 / w1 / w2 (as k4_rct)
   int32_t *o0, *o1, *o2;
   switch (perm) {
@@ -851,12 +856,12 @@ __global__ __launch_bounds__(256) void k6_unsqueeze_rct(const SqueezePlanes pl, 
   // which is what this step's throughput hangs on once three planes stream through every workgroup.  The register
   // arrays then hold int4 slots: (k, plane, quad) for the inputs, (k, quad) for the outputs.
   static_assert(!(VEC && HORIZ), "the vector movers are for the vertical step");
-  constexpr int NVIN = (S * 12 + NM - 1) / NM, NVOUT = (2 * S * 4 + NM - 1) / NM;
+  constexpr int NVIN = (S * 12 + NML - 1) / NML, NVOUT = (2 * S * 4 + NMS - 1) / NMS;
   auto fetch_chunk = [&](int c, int32_t(&va)[NIN], int32_t(&vr)[NIN]) {
     if constexpr (VEC) {
 #pragma unroll
       for (int j = 0; j < NVIN; j++) {
-        const int f = m + j * NM, k = f / 12, rem = f - k * 12, p = rem >> 2, qq = rem & 3;
+        const int f = m + j * NML, k = f / 12, rem = f - k * 12, p = rem >> 2, qq = rem & 3;
         // slots past the tile (the last j) and quads past the last column read a valid address instead of being
         // predicated (a select between a load and a constant becomes a load through a selected POINTER, via scratch);
         // what they fetch is never staged / never stored
@@ -886,7 +891,7 @@ __global__ __launch_bounds__(256) void k6_unsqueeze_rct(const SqueezePlanes pl, 
     if constexpr (VEC) {
 #pragma unroll
       for (int j = 0; j < NVIN; j++) {
-        const int f = m + j * NM, k = f / 12, rem = f - k * 12, p = rem >> 2, qq = rem & 3;
+        const int f = m + j * NML, k = f / 12, rem = f - k * 12, p = rem >> 2, qq = rem & 3;
         if (f < S * 12) {
           const int idx = k * 64 + p * NL + 4 * qq;
           *reinterpret_cast<int4*>(&s_avg[c & 1][idx]) = make_int4(va[4 * j], va[4 * j + 1], va[4 * j + 2], va[4 * j + 3]);
@@ -925,7 +930,7 @@ __global__ __launch_bounds__(256) void k6_unsqueeze_rct(const SqueezePlanes pl, 
     if constexpr (VEC) {
 #pragma unroll
       for (int j = 0; j < NVOUT; j++) {
-        const int f = m + j * NM, k = f >> 2, qq = f & 3;
+        const int f = m + j * NMS, k = f >> 2, qq = f & 3;
         if (f < 2 * S * 4 && l0 + 4 * qq < n_lines && k < count) {
           const int4 v0 = *reinterpret_cast<const int4*>(so + k * 64 + 4 * qq);
           const int4 v1 = *reinterpret_cast<const int4*>(so + k * 64 + NL + 4 * qq);
@@ -974,7 +979,7 @@ __global__ __launch_bounds__(256) void k6_unsqueeze_rct(const SqueezePlanes pl, 
     cur = a[0];
   }
   int32_t pa[NIN], pr[NIN];
-  if (!chain && n_chunks > 0) {
+  if (loader && n_chunks > 0) {
     fetch_chunk(0, pa, pr);
     stage_chunk(0, pa, pr);
     if (n_chunks > 1) fetch_chunk(1, pa, pr);
@@ -982,9 +987,9 @@ __global__ __launch_bounds__(256) void k6_unsqueeze_rct(const SqueezePlanes pl, 
   lds_barrier();
   for (int c = 0; c < n_chunks; c++) {
     if (!chain) {
-      if (c + 1 < n_chunks) stage_chunk(c + 1, pa, pr);
-      if (c + 2 < n_chunks) fetch_chunk(c + 2, pa, pr);
-      if (c >= 1) store_chunk(c - 1, 2 * S);
+      if (loader && c + 1 < n_chunks) stage_chunk(c + 1, pa, pr);
+      if (loader && c + 2 < n_chunks) fetch_chunk(c + 2, pa, pr);
+      if (storer && c >= 1) store_chunk(c - 1, 2 * S);
     } else {
       const int32_t* ia = s_avg[c & 1];
       const int32_t* ir = s_res[c & 1];
@@ -1050,11 +1055,11 @@ __global__ __launch_bounds__(256) void k6_unsqueeze_rct(const SqueezePlanes pl, 
         }
       }
     }
-  } else if (n_chunks > 0) {
+  } else if (storer && n_chunks > 0) {
     store_chunk(n_chunks - 1, 2 * S);
   }
   lds_barrier();
-  if (!chain) store_chunk(n_chunks, rest);
+  if (storer) store_chunk(n_chunks, rest);
 }
 
 void launch_unsqueeze(hipStream_t s, int horizontal, int n_planes, const int32_t* const avg[], size_t avg_stride,
