@@ -43,8 +43,8 @@ enum {
   JXLH_ERR_BAD_STATE = -4,        /* call order violated (e.g. submit before frame_begin) */
   JXLH_ERR_INVALID_TRANSFORM = -5,/* transform_map holds an id >= 27 (Error::InvalidVarDCTTransform) */
   JXLH_ERR_UNSUPPORTED = -6,      /* valid stream feature outside the device path (caller falls back): band or sharded
-                                     runs and group re-renders of upsampled frames, the Weighted predictor in
-                                     jxlh_palette_delta, frames beyond 2^31 coefficients */
+                                     runs and group re-renders of upsampled frames, frames beyond 2^31 coefficients,
+                                     predictor 6 in jxlh_palette_delta (use jxlh_palette_delta_wp) */
   JXLH_ERR_INVALID_BLOCK_SIZE = -7, /* a varblock larger than 8x8 in a chroma-subsampled frame
                                       (Error::InvalidBlockSizeForChromaSubsampling, frame/modular/mod.rs:1058-1060) */
   JXLH_ERR_BLOCK_OUT_OF_BOUNDS = -8 /* a varblock crosses its group's or the frame's edge, or the first-block flags of
@@ -406,11 +406,21 @@ jxlh_status jxlh_palette_strided(jxlh_ctx* ctx, const int32_t* index, size_t n, 
                                  int32_t* out, size_t out_channel_stride);
 /* do_palette_step_general with delta entries and / or a neighbour predictor (palette.rs:228-251): index is w x h,
  * entries below num_deltas are added to Predictor::predict_one (modular/predict.rs:152-198; predictor = Predictor
- * as u32, 6 = Weighted is JXLH_ERR_UNSUPPORTED) of the already reconstructed neighbours, palette_size =
+ * as u32; 6 = Weighted needs its header: jxlh_palette_delta_wp, JXLH_ERR_UNSUPPORTED here) of the already
+ * reconstructed neighbours, palette_size =
  * num_colors + num_deltas.  Sequential by nature: runs as a skewed wavefront, far from bandwidth bound. */
 jxlh_status jxlh_palette_delta(jxlh_ctx* ctx, const int32_t* index, uint32_t w, uint32_t h, const int32_t* palette,
                                int32_t num_colors, int32_t num_deltas, size_t palette_stride, int32_t nb_channels,
                                int32_t bit_depth, int32_t predictor, int32_t* out);
+/* The same step with Predictor::Weighted (palette.rs:200-227): every pixel runs the self-correcting predictor
+ * (WeightedPredictorState, modular/predict.rs:221-519) and updates its error state, delta entries are added to its
+ * prediction.  wp = the group's WeightedHeader (headers/modular.rs:16-66; 5-bit p*, 4-bit w*). */
+typedef struct jxlh_wp_header {
+  uint32_t p1c, p2c, p3ca, p3cb, p3cc, p3cd, p3ce, w0, w1, w2, w3;
+} jxlh_wp_header;
+jxlh_status jxlh_palette_delta_wp(jxlh_ctx* ctx, const int32_t* index, uint32_t w, uint32_t h, const int32_t* palette,
+                                  int32_t num_colors, int32_t num_deltas, size_t palette_stride, int32_t nb_channels,
+                                  int32_t bit_depth, const jxlh_wp_header* wp, int32_t* out);
 /* The stages between the Modular channels and the rest of the pipeline (render/stages/convert.rs), whole planes:
  *  - jxlh_modular_to_rgb8: ConvertI32ToU8Stage (:642-715) on three channels, interleaved -- what the pipeline builder
  *    substitutes for ConvertModularToF32 + ConvertF32ToU8 when the output depth is a multiple of the channel depth

@@ -1758,6 +1758,43 @@ jxlh_status jxlh_modular_xyb_to_f32(jxlh_ctx* ctx, const int32_t* y, const int32
   return JXLH_OK;
 }
 
+jxlh_status jxlh_palette_delta_wp(jxlh_ctx* ctx, const int32_t* index, uint32_t w, uint32_t h, const int32_t* palette,
+                                  int32_t num_colors, int32_t num_deltas, size_t palette_stride, int32_t nb_channels,
+                                  int32_t bit_depth, const jxlh_wp_header* wp, int32_t* out) {
+  if (!ctx || !index || !palette || !out || !wp || num_colors < 0 || num_deltas < 0 || nb_channels < 1 ||
+      nb_channels > 64 || bit_depth < 1 || bit_depth > 24 ||
+      palette_stride < (size_t)num_colors + (size_t)num_deltas || w > (1u << 20) || h > (1u << 20))
+    return JXLH_ERR_INVALID_ARGUMENT;
+  const uint32_t header[11] = {wp->p1c, wp->p2c, wp->p3ca, wp->p3cb, wp->p3cc, wp->p3cd, wp->p3ce,
+                               wp->w0,  wp->w1,  wp->w2,   wp->w3};
+  for (int i = 0; i < 11; i++)
+    if (header[i] >= (i < 7 ? 32u : 16u)) return JXLH_ERR_INVALID_ARGUMENT;  // Bits(5) / Bits(4) fields
+  if (w == 0 || h == 0) return JXLH_OK;
+  const size_t n = (size_t)w * h, pal_n = palette_stride * (size_t)nb_channels;
+  if (n * (size_t)nb_channels >= (1ull << 31)) return JXLH_ERR_UNSUPPORTED;
+  const size_t nbands = (size_t)palette_delta_bands((int)h);
+  // progress counters, then the band-edge rows of predictor state (5 rows of w per channel and band)
+  const size_t n_prog = (size_t)nb_channels * nbands, n_rows = n_prog * 5 * (size_t)w;
+  if (jxlh_status st0 = ensure(ctx, ctx->hook_i[3], n_prog + n_rows)) return st0;
+  int* progress = reinterpret_cast<int*>(ctx->hook_i[3].p);
+  int32_t* wp_rows = ctx->hook_i[3].p + n_prog;
+  if (is_device_ptr(index) && is_device_ptr(palette) && is_device_ptr(out)) {
+    ScopedKernelTimer t(ctx, "k5_palette_wp");
+    launch_palette_wp(ctx->stream, index, (int)w, (int)h, palette, num_colors, num_deltas, palette_stride, nb_channels,
+                      bit_depth, header, out, progress, wp_rows);
+    HIPCHK(ctx, hipGetLastError());
+    return JXLH_OK;
+  }
+  jxlh_status st;
+  if ((st = stage_in(ctx, ctx->hook_i[0], index, n))) return st;
+  if ((st = stage_in(ctx, ctx->hook_i[1], palette, pal_n ? pal_n : 1))) return st;
+  if ((st = ensure(ctx, ctx->hook_i[2], n * nb_channels))) return st;
+  launch_palette_wp(ctx->stream, ctx->hook_i[0].p, (int)w, (int)h, ctx->hook_i[1].p, num_colors, num_deltas,
+                    palette_stride, nb_channels, bit_depth, header, ctx->hook_i[2].p, progress, wp_rows);
+  HIPCHK(ctx, hipGetLastError());
+  return stage_out(ctx, out, (const int32_t*)ctx->hook_i[2].p, n * nb_channels);
+}
+
 jxlh_status jxlh_unsqueeze(jxlh_ctx* ctx, int32_t horizontal, const int32_t* avg, size_t avg_stride,
                            const int32_t* res, size_t res_stride, uint32_t out_w, uint32_t out_h, int32_t* out,
                            size_t out_stride) {

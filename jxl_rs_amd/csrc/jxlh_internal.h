@@ -229,6 +229,9 @@ void launch_palette_delta(hipStream_t s, const int32_t* index, int w, int h, con
                           int num_deltas, size_t palette_stride, int nb_channels, int bit_depth, int predictor,
                           int32_t* out, int* progress);
 int palette_delta_bands(int h);
+void launch_palette_wp(hipStream_t s, const int32_t* index, int w, int h, const int32_t* palette, int num_colors,
+                       int num_deltas, size_t palette_stride, int nb_channels, int bit_depth, const uint32_t header[11],
+                       int32_t* out, int* progress, int32_t* wp_rows);
 void launch_i32_to_rgb8(hipStream_t s, const int32_t* const planes[3], size_t stride, int w, int h, int32_t mult,
                         int32_t maxv, int channels, uint8_t* out, size_t out_stride);
 void launch_modular_to_f32(hipStream_t s, const int32_t* in, size_t n, float scale, float* out);

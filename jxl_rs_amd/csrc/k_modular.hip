@@ -278,6 +278,206 @@ __global__ __launch_bounds__(kDeltaRows) void k5_palette_delta(const int32_t* __
   }
 }
 
+// ---- the same step with Predictor::Weighted (do_palette_step_general, palette.rs:200-227): EVERY pixel runs the
+// self-correcting predictor (WeightedPredictorState::predict_and_property + update_errors, modular/predict.rs:312-517),
+// delta entries are added to its prediction.  The predictor's state is, per pixel, the signed error TE of the final
+// prediction and the four sub-predictors' absolute errors E[4]; pixel (x, y) reads TE / E of (x - 1 .. x + 1, y - 1)
+// and of (x - 1, y), (x - 2, y).  The reference keeps two rows of them and ADDS E(x, y) into the previous row's slot
+// x + 1 (:508-515), so that the "north" sum of the next pixel already contains its west neighbour's errors; here every
+// row keeps its own E in the LDS ring next to its outputs and the lane adds its own E(x - 1, y) / E(x - 2, y) from
+// registers: err_n = E(x, y-1) + E(x-1, y), err_nw = E(x-1, y-1) + E(x-2, y), err_ne = E(x+1, y-1), with the
+// reference's edge rules (pos_nw = max(x-1, 0), pos_ne = min(x+1, w-1) index the SAME summed slots).  Same wavefront
+// as k5_palette_delta (x + 3y), same band pipeline; a band's last row also publishes its TE / E row for the band below.
+struct WpParams {
+  uint32_t w[4];
+  int32_t p1c, p2c, p3c[5];
+};
+__constant__ uint32_t kWpDivLookup[64] = {  // (1 << 24) / (i + 1), predict.rs:206-213
+    16777216, 8388608, 5592405, 4194304, 3355443, 2796202, 2396745, 2097152, 1864135, 1677721, 1525201, 1398101,
+    1290555,  1198372, 1118481, 1048576, 986895,  932067,  883011,  838860,  798915,  762600,  729444,  699050,
+    671088,   645277,  621378,  599186,  578524,  559240,  541200,  524288,  508400,  493447,  479349,  466033,
+    453438,   441505,  430185,  419430,  409200,  399457,  390167,  381300,  372827,  364722,  356962,  349525,
+    342392,   335544,  328965,  322638,  316551,  310689,  305040,  299593,  294337,  289262,  284359,  279620,
+    275036,   270600,  266305,  262144};
+
+// wp_rows: per channel and band, five rows of w ints (TE, E0..E3 of the band's last row)
+__global__ __launch_bounds__(kDeltaRows) void k5_palette_wp(const int32_t* __restrict__ index, int w, int h,
+                                                            int num_deltas, int32_t* out_base, int* progress_base,
+                                                            int32_t* wp_rows_base, const WpParams P) {
+  __shared__ int32_t s_ring[kDeltaRows][8];
+  __shared__ int32_t s_te[kDeltaRows][8];
+  __shared__ uint32_t s_e[4][kDeltaRows][8];
+  __shared__ int32_t s_above[2][128];  // out rows y0 - 1 and y0 - 2 (of the previous band), a window of 128 columns
+  __shared__ int32_t s_above_te[128];  // TE and E of row y0 - 1
+  __shared__ uint32_t s_above_e[4][128];
+  __shared__ int s_avail;
+  const int c = blockIdx.x, band = blockIdx.y, nbands = gridDim.y, l = threadIdx.x;
+  int32_t* out = out_base + (size_t)c * (size_t)w * h;
+  int* progress = progress_base + (size_t)c * nbands;
+  int32_t* wp_mine = wp_rows_base + ((size_t)c * nbands + band) * 5 * (size_t)w;        // written by the last row
+  const int32_t* wp_prev = wp_rows_base + ((size_t)c * nbands + band - 1) * 5 * (size_t)w;  // read when band > 0
+  const int y0 = band * kDeltaRows;
+  const int rows = min(kDeltaRows, h - y0);
+  const int y = y0 + l;
+  const bool publishes_rows = band + 1 < nbands && l == rows - 1;
+  const int32_t* __restrict__ irow = index + (size_t)min(y, h - 1) * w;
+  int32_t* orow = out + (size_t)min(y, h - 1) * w;
+  int32_t left_v = 0, te1 = 0;       // out[y][x - 1], TE(x - 1, y)
+  uint32_t e1[4] = {0, 0, 0, 0}, e2[4] = {0, 0, 0, 0};  // E(x - 1, y), E(x - 2, y)
+  int32_t iq[8], eq[8];
+  {
+    const int s0 = 3 * l;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      iq[k] = eq[k] = 0;
+#pragma unroll
+      for (int j = 0; j < 8; j++)
+        if (((s0 + j) & 7) == k && l < rows && j < w) {
+          iq[k] = irow[j];
+          eq[k] = orow[j];
+        }
+    }
+  }
+  const int nsteps = w + 3 * (rows - 1);
+  const int prod_steps = w + 3 * (kDeltaRows - 1);
+  int avail = 0;
+  auto step = [&](const int s, auto slot_tag) {
+    constexpr int K = decltype(slot_tag)::value;
+    const int x = s - 3 * l;
+    if (l < rows && x >= 0 && x < w) {
+      const int32_t idx = iq[K];
+      const int32_t entry = eq[K];
+      if (x + 8 < w) {
+        iq[K] = irow[x + 8];
+        eq[K] = orow[x + 8];
+      }
+      auto T = [&](int xx) -> int32_t { return l > 0 ? s_ring[l - 1][xx & 7] : s_above[0][xx & 127]; };
+      auto TT = [&](int xx) -> int32_t { return l > 1 ? s_ring[l - 2][xx & 7] : s_above[l == 1 ? 0 : 1][xx & 127]; };
+      auto TEa = [&](int xx) -> int64_t {
+        return y > 0 ? (int64_t)(l > 0 ? s_te[l - 1][xx & 7] : s_above_te[xx & 127]) : 0;
+      };
+      auto Ea = [&](int k, int xx) -> uint32_t {
+        return y > 0 ? (l > 0 ? s_e[k][l - 1][xx & 7] : s_above_e[k][xx & 127]) : 0u;
+      };
+      // PredictionData::get_rows, modular/predict.rs:96-128
+      const int32_t left = x > 0 ? left_v : (y > 0 ? T(0) : 0);
+      const int32_t top = y > 0 ? T(x) : left;
+      const int32_t topleft = (x > 0 && y > 0) ? T(x - 1) : left;
+      const int32_t topright = (x + 1 < w && y > 0) ? T(x + 1) : top;
+      const int32_t toptop = y > 1 ? TT(x) : top;
+      const int pos_ne = x + 1 < w ? x + 1 : x, pos_nw = x > 0 ? x - 1 : 0;
+      // weights from the error sums (:340-377)
+      uint32_t wk[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint32_t en = Ea(k, x) + (x > 0 ? e1[k] : 0u);
+        const uint32_t ene = pos_ne == x ? en : Ea(k, x + 1);
+        const uint32_t enw = pos_nw == x ? en : Ea(k, x - 1) + (x > 1 ? e2[k] : 0u);
+        const uint32_t err = en + ene + enw;
+        int shift = 63 - __clzll((unsigned long long)err + 1ull) - 5;
+        shift = shift < 0 ? 0 : shift;
+        wk[k] = 4u + ((P.w[k] * kWpDivLookup[err >> shift]) >> shift);
+      }
+      const int64_t te_w = x > 0 ? (int64_t)te1 : 0, te_n = TEa(x), te_nw = TEa(pos_nw), te_ne = TEa(pos_ne);
+      const int64_t sum_wn = te_n + te_w;
+      const int64_t n = (int64_t)top << 3, wv = (int64_t)left << 3, ne = (int64_t)topright << 3;
+      const int64_t nw = (int64_t)topleft << 3, nn = (int64_t)toptop << 3;
+      int64_t pk[4];
+      pk[0] = wv + ne - n;
+      pk[1] = n - (((sum_wn + te_ne) * (int64_t)P.p1c) >> 5);
+      pk[2] = wv - (((sum_wn + te_nw) * (int64_t)P.p2c) >> 5);
+      pk[3] = n - ((te_nw * (int64_t)P.p3c[0] + te_n * (int64_t)P.p3c[1] + te_ne * (int64_t)P.p3c[2] +
+                    (nn - n) * (int64_t)P.p3c[3] + (nw - wv) * (int64_t)P.p3c[4]) >> 5);
+      const int log_weight = 63 - __clzll((unsigned long long)wk[0] + wk[1] + wk[2] + wk[3]);
+      const int64_t w0s = (int64_t)(wk[0] >> (log_weight - 4)), w1s = (int64_t)(wk[1] >> (log_weight - 4));
+      const int64_t w2s = (int64_t)(wk[2] >> (log_weight - 4)), w3s = (int64_t)(wk[3] >> (log_weight - 4));
+      const int64_t weight_sum = w0s + w1s + w2s + w3s;
+      const int64_t sum = (weight_sum >> 1) - 1 + w0s * pk[0] + w1s * pk[1] + w2s * pk[2] + w3s * pk[3];
+      int64_t pred = (sum * (int64_t)kWpDivLookup[weight_sum - 1]) >> 24;
+      if (((te_n ^ te_w) | (te_n ^ te_nw)) <= 0) {
+        const int64_t mx = max(wv, max(ne, n)), mn = min(wv, min(ne, n));
+        pred = max(mn, min(mx, pred));
+      }
+      const int64_t wp_pred = (pred + 3) >> 3;
+      int32_t val = entry;
+      if (idx < num_deltas) {
+        val = (int32_t)(uint32_t)(uint64_t)(wp_pred + (int64_t)entry);
+        orow[x] = val;
+      }
+      // update_errors (:472-517)
+      const int64_t v = (int64_t)val << 3;
+      const int32_t te = (int32_t)(pred - v);
+      uint32_t e[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int64_t dd = pk[k] - v;
+        e[k] = (uint32_t)(((dd < 0 ? -dd : dd) + 3) >> 3);
+      }
+      s_ring[l][x & 7] = val;
+      s_te[l][x & 7] = te;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        s_e[k][l][x & 7] = e[k];
+        e2[k] = e1[k];
+        e1[k] = e[k];
+      }
+      if (publishes_rows) {
+        wp_mine[x] = te;
+#pragma unroll
+        for (int k = 0; k < 4; k++) wp_mine[(size_t)(1 + k) * w + x] = (int32_t)e[k];
+      }
+      te1 = te;
+      left_v = val;
+    }
+    if (band + 1 < nbands && ((s + 1) % kDeltaPublish == 0 || s + 1 == nsteps)) {
+      __threadfence();
+      __syncthreads();
+      if (l == 0) __hip_atomic_store(&progress[band], s + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+  };
+  for (int s8 = 0; s8 < nsteps; s8 += 8) {
+    if (band > 0 && (s8 & 63) == 0) {
+      const int lo = s8 == 0 ? 0 : s8 + 2, hi = min(w, s8 + 66);
+      if (lo < hi) {
+        const int need = min(prod_steps, (hi - 1) + 3 * (kDeltaRows - 1) + 1);
+        if (avail < need) {
+          if (l == 0) {
+            int v;
+            while ((v = __hip_atomic_load(&progress[band - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) < need)
+              __builtin_amdgcn_s_sleep(2);
+            s_avail = v;
+          }
+          __syncthreads();
+          avail = s_avail;
+        }
+        // 2 output rows + TE + 4 E rows of the columns [lo, hi), device-coherent loads
+        for (int t = l; t < 7 * (hi - lo); t += kDeltaRows) {
+          const int r = t % 7, col = lo + t / 7;
+          if (r < 2) {
+            s_above[r][col & 127] =
+                __hip_atomic_load(&out[(size_t)(y0 - 1 - r) * w + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          } else {
+            const int32_t vv = __hip_atomic_load(&wp_prev[(size_t)(r - 2) * w + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (r == 2) s_above_te[col & 127] = vv;
+            else s_above_e[r - 3][col & 127] = (uint32_t)vv;
+          }
+        }
+        __syncthreads();
+      }
+    }
+    if (s8 + 0 < nsteps) step(s8 + 0, std::integral_constant<int, 0>{});
+    if (s8 + 1 < nsteps) step(s8 + 1, std::integral_constant<int, 1>{});
+    if (s8 + 2 < nsteps) step(s8 + 2, std::integral_constant<int, 2>{});
+    if (s8 + 3 < nsteps) step(s8 + 3, std::integral_constant<int, 3>{});
+    if (s8 + 4 < nsteps) step(s8 + 4, std::integral_constant<int, 4>{});
+    if (s8 + 5 < nsteps) step(s8 + 5, std::integral_constant<int, 5>{});
+    if (s8 + 6 < nsteps) step(s8 + 6, std::integral_constant<int, 6>{});
+    if (s8 + 7 < nsteps) step(s8 + 7, std::integral_constant<int, 7>{});
+  }
+}
+
 // LDS_PAL: the explicit palette (num_colors x nb_channels entries, <= kPalLdsEntries) is staged in LDS
 // once per workgroup (persistent grid), so the per-pixel gathers never leave the CU.
 constexpr int kPalLdsEntries = 12288;  // 48 KB
@@ -530,6 +730,23 @@ void launch_palette(hipStream_t s, const int32_t* index, size_t n, const int32_t
 
 // progress: nb_channels * palette_delta_bands(h) ints of device scratch
 int palette_delta_bands(int h) { return (h + kDeltaRows - 1) / kDeltaRows; }
+// Weighted predictor: header = p1c, p2c, p3ca..p3ce, w0..w3; wp_rows: nb_channels * bands * 5 * w ints of scratch
+void launch_palette_wp(hipStream_t s, const int32_t* index, int w, int h, const int32_t* palette, int num_colors,
+                       int num_deltas, size_t palette_stride, int nb_channels, int bit_depth, const uint32_t header[11],
+                       int32_t* out, int* progress, int32_t* wp_rows) {
+  if (w <= 0 || h <= 0) return;
+  launch_palette(s, index, (size_t)w * h, palette, num_colors + num_deltas, palette_stride, nb_channels, bit_depth, out);
+  const int nbands = palette_delta_bands(h);
+  (void)hipMemsetAsync(progress, 0, sizeof(int) * (size_t)nb_channels * nbands, s);
+  WpParams P;
+  P.p1c = (int32_t)header[0];
+  P.p2c = (int32_t)header[1];
+  for (int i = 0; i < 5; i++) P.p3c[i] = (int32_t)header[2 + i];
+  for (int i = 0; i < 4; i++) P.w[i] = header[7 + i];
+  hipLaunchKernelGGL(k5_palette_wp, dim3(nb_channels, nbands), dim3(kDeltaRows), 0, s, index, w, h, num_deltas, out,
+                     progress, wp_rows, P);
+}
+
 void launch_palette_delta(hipStream_t s, const int32_t* index, int w, int h, const int32_t* palette, int num_colors,
                           int num_deltas, size_t palette_stride, int nb_channels, int bit_depth, int predictor,
                           int32_t* out, int* progress) {

@@ -43,7 +43,7 @@ ABI_SYMBOLS = [
     "jxlh_stage_gaborish",
     "jxlh_stage_epf", "jxlh_stage_lf_smooth", "jxlh_stage_transform_to_pixels", "jxlh_rct", "jxlh_palette", "jxlh_palette_delta", "jxlh_modular_to_rgb8",
     "jxlh_modular_to_f32", "jxlh_modular_xyb_to_f32",
-    "jxlh_unsqueeze", "jxlh_unsqueeze_planes", "jxlh_smooth_unsqueeze", "jxlh_unsqueeze_rct", "jxlh_abi_version", "jxlh_covered_blocks_x", "jxlh_covered_blocks_y",
+    "jxlh_unsqueeze", "jxlh_unsqueeze_planes", "jxlh_smooth_unsqueeze", "jxlh_unsqueeze_rct", "jxlh_palette_delta_wp", "jxlh_abi_version", "jxlh_covered_blocks_x", "jxlh_covered_blocks_y",
     "jxlh_quant_table_for_type", "jxlh_quant_table_size",
     "jxlh_comm_unique_id", "jxlh_comm_init", "jxlh_comm_init_local", "jxlh_comm_destroy", "jxlh_comm_band",
     "jxlh_frame_run_sharded", "jxlh_frame_allgather", "jxlh_frames_run_sharded_local", "jxlh_frames_allgather_local",
@@ -163,6 +163,7 @@ def load():
     L.jxlh_rct.argtypes = [vp, vp, vp, vp, sz, i32, i32]
     L.jxlh_palette.argtypes = [vp, vp, sz, vp, i32, sz, i32, i32, vp]
     L.jxlh_palette_delta.argtypes = [vp, vp, u32, u32, vp, i32, i32, sz, i32, i32, i32, vp]
+    L.jxlh_palette_delta_wp.argtypes = [vp, vp, u32, u32, vp, i32, i32, sz, i32, i32, vp, vp]
     L.jxlh_modular_to_rgb8.argtypes = [vp, C.POINTER(vp), sz, u32, u32, i32, i32, u32, vp, sz]
     L.jxlh_modular_to_f32.argtypes = [vp, vp, sz, u32, vp]
     L.jxlh_modular_xyb_to_f32.argtypes = [vp, vp, vp, vp, sz, vp, vp, vp, vp]
@@ -670,6 +671,19 @@ class Context:
         out = np.zeros((pal.shape[0], h, w), dtype=np.int32)
         self._chk(self.L.jxlh_palette_delta(self._ctx, _addr(idx), w, h, _addr(pal), num_colors, num_deltas, pal.shape[1],
                                             pal.shape[0], bit_depth, predictor, _addr(out)), "palette_delta")
+        return out
+
+    def palette_delta_wp(self, index, palette, num_colors, num_deltas, bit_depth, wp_header):
+        """The Weighted-predictor branch of the palette step; wp_header = (p1c, p2c, p3ca..p3ce, w0..w3)."""
+        idx = np.ascontiguousarray(index, dtype=np.int32)
+        pal = np.ascontiguousarray(palette, dtype=np.int32)
+        hdr = np.ascontiguousarray(wp_header, dtype=np.uint32)
+        assert hdr.size == 11
+        h, w = idx.shape
+        out = np.zeros((pal.shape[0], h, w), dtype=np.int32)
+        self._chk(self.L.jxlh_palette_delta_wp(self._ctx, _addr(idx), w, h, _addr(pal), num_colors, num_deltas,
+                                               pal.shape[1], pal.shape[0], bit_depth, _addr(hdr), _addr(out)),
+                  "palette_delta_wp")
         return out
 
     def unsqueeze_planes(self, horizontal, avg, res, out, out_w, out_h, avg_stride, res_stride, out_stride):

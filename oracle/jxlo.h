@@ -242,6 +242,14 @@ void jxlo_palette(const int32_t* index, size_t n, const int32_t* palette, int nu
  * (modular/predict.rs:16-31), anything but 6 (Weighted) */
 void jxlo_palette_delta(const int32_t* index, int w, int h, const int32_t* palette, int num_colors, int num_deltas,
                         size_t palette_stride, int nb_channels, int bit_depth, int predictor, int32_t* out);
+typedef struct jxlo_wp_state jxlo_wp_state;
+jxlo_wp_state* jxlo_wp_new(const uint32_t header[11], int xsize);
+void jxlo_wp_free(jxlo_wp_state* s);
+int64_t jxlo_wp_predict(jxlo_wp_state* s, int x, int y, const int32_t neighbours[5], int32_t* property);
+void jxlo_wp_update(jxlo_wp_state* s, int32_t correct_val, int x, int y);
+void jxlo_palette_delta_wp(const int32_t* index, int w, int h, const int32_t* palette, int num_colors, int num_deltas,
+                           size_t palette_stride, int nb_channels, int bit_depth, const uint32_t wp_header[11],
+                           int32_t* out);
 /* Modular channels -> pipeline samples (render/stages/convert.rs:278-343, :488-533, :642-715) */
 void jxlo_i32_to_u8(const int32_t* in, size_t n, int32_t multiplier, int32_t max, uint8_t* out);
 void jxlo_modular_to_f32(const int32_t* in, size_t n, int bits, float* out);

@@ -166,6 +166,143 @@ void jxlo_palette_delta(const int32_t* index, int w, int h, const int32_t* palet
   }
 }
 
+/* ---- the self-correcting ("Weighted") predictor, modular/predict.rs:201-519 ----
+ * State per channel: two rows of the four sub-predictors' error sums (pred_errors_buffer) and of the final
+ * prediction's signed error (error), double-buffered by row parity; error[half + 0] stays 0 and position x lives at
+ * error[half + x + 1].  The interface keeps the reference's two calls: predict (predict_and_property, :312-470) and
+ * update (update_errors, :472-517). */
+#define WP_EXTRA_BITS 3
+#define WP_ROUND (((1 << WP_EXTRA_BITS) >> 1) - 1)
+static const uint32_t kWpDivLookup[64] = { /* (1 << 24) / (i + 1), :206-213 */
+    16777216, 8388608, 5592405, 4194304, 3355443, 2796202, 2396745, 2097152, 1864135, 1677721, 1525201, 1398101,
+    1290555,  1198372, 1118481, 1048576, 986895,  932067,  883011,  838860,  798915,  762600,  729444,  699050,
+    671088,   645277,  621378,  599186,  578524,  559240,  541200,  524288,  508400,  493447,  479349,  466033,
+    453438,   441505,  430185,  419430,  409200,  399457,  390167,  381300,  372827,  364722,  356962,  349525,
+    342392,   335544,  328965,  322638,  316551,  310689,  305040,  299593,  294337,  289262,  284359,  279620,
+    275036,   270600,  266305,  262144};
+struct jxlo_wp_state {
+  int xsize;
+  uint32_t (*pe)[4]; /* pred_errors_buffer, 2 * (xsize + 1) entries */
+  int32_t* error;    /* 2 * (xsize + 1) entries */
+  int64_t prediction[4];
+  int64_t pred;
+  uint8_t w[4], p1c, p2c, p3c[5];
+};
+static int wp_ilog2_u64(uint64_t v) { return 63 - __builtin_clzll(v); }
+/* header: p1c, p2c, p3ca..p3ce, w0..w3 (headers/modular.rs:16-66) */
+jxlo_wp_state* jxlo_wp_new(const uint32_t header[11], int xsize) {
+  jxlo_wp_state* s = (jxlo_wp_state*)calloc(1, sizeof(*s));
+  s->xsize = xsize;
+  s->pe = calloc((size_t)2 * (xsize + 1), sizeof(*s->pe));
+  s->error = calloc((size_t)2 * (xsize + 1), sizeof(int32_t));
+  s->p1c = (uint8_t)header[0];
+  s->p2c = (uint8_t)header[1];
+  for (int i = 0; i < 5; i++) s->p3c[i] = (uint8_t)header[2 + i];
+  for (int i = 0; i < 4; i++) s->w[i] = (uint8_t)header[7 + i];
+  return s;
+}
+void jxlo_wp_free(jxlo_wp_state* s) {
+  if (!s) return;
+  free(s->pe);
+  free(s->error);
+  free(s);
+}
+static inline int64_t wp_abs(int64_t v) { return v < 0 ? -v : v; }
+/* neighbours = top, left, topright, topleft, toptop (PredictionData); returns the prediction, *property = the
+ * largest-magnitude neighbouring error */
+int64_t jxlo_wp_predict(jxlo_wp_state* s, int x, int y, const int32_t nb[5], int32_t* property) {
+  const int half = s->xsize + 1;
+  const int cur_row = (y & 1) ? 0 : half, prev_row = (y & 1) ? half : 0;
+  const int pos_ne = x + 1 < s->xsize ? x + 1 : x;
+  const int pos_nw = x > 0 ? x - 1 : 0;
+  const uint32_t* err_n = s->pe[prev_row + x];
+  const uint32_t* err_ne = s->pe[prev_row + pos_ne];
+  const uint32_t* err_nw = s->pe[prev_row + pos_nw];
+  uint32_t wk[4];
+  for (int k = 0; k < 4; k++) {
+    const uint32_t err = err_n[k] + err_ne[k] + err_nw[k]; /* wrapping */
+    int shift = wp_ilog2_u64((uint64_t)err + 1) - 5;
+    if (shift < 0) shift = 0;
+    const uint32_t div = kWpDivLookup[err >> shift];
+    wk[k] = 4u + (((uint32_t)s->w[k] * div) >> shift);
+  }
+  const int64_t te_w = s->error[cur_row + x];
+  const int64_t te_n = s->error[prev_row + 1 + x];
+  const int64_t te_nw = s->error[prev_row + 1 + pos_nw];
+  const int64_t sum_wn = te_n + te_w;
+  const int64_t te_ne = s->error[prev_row + 1 + pos_ne];
+  int64_t p = te_w;
+  if (wp_abs(te_n) > wp_abs(p)) p = te_n;
+  if (wp_abs(te_nw) > wp_abs(p)) p = te_nw;
+  if (wp_abs(te_ne) > wp_abs(p)) p = te_ne;
+  const int64_t n = (int64_t)nb[0] << WP_EXTRA_BITS, w = (int64_t)nb[1] << WP_EXTRA_BITS;
+  const int64_t ne = (int64_t)nb[2] << WP_EXTRA_BITS, nw = (int64_t)nb[3] << WP_EXTRA_BITS;
+  const int64_t nn = (int64_t)nb[4] << WP_EXTRA_BITS;
+  const int64_t p0 = w + ne - n;
+  const int64_t p1 = n - (((sum_wn + te_ne) * (int64_t)s->p1c) >> 5);
+  const int64_t p2 = w - (((sum_wn + te_nw) * (int64_t)s->p2c) >> 5);
+  const int64_t p3 = n - ((te_nw * (int64_t)s->p3c[0] + te_n * (int64_t)s->p3c[1] + te_ne * (int64_t)s->p3c[2] +
+                           (nn - n) * (int64_t)s->p3c[3] + (nw - w) * (int64_t)s->p3c[4]) >> 5);
+  const int log_weight = wp_ilog2_u64((uint64_t)wk[0] + wk[1] + wk[2] + wk[3]);
+  const int64_t w0s = (int64_t)wk[0] >> (log_weight - 4), w1s = (int64_t)wk[1] >> (log_weight - 4);
+  const int64_t w2s = (int64_t)wk[2] >> (log_weight - 4), w3s = (int64_t)wk[3] >> (log_weight - 4);
+  const int64_t weight_sum = w0s + w1s + w2s + w3s;
+  const int64_t sum = (weight_sum >> 1) - 1 + w0s * p0 + w1s * p1 + w2s * p2 + w3s * p3;
+  int64_t pred = (sum * (int64_t)kWpDivLookup[weight_sum - 1]) >> 24;
+  if (((te_n ^ te_w) | (te_n ^ te_nw)) <= 0) {
+    const int64_t mx = w > (ne > n ? ne : n) ? w : (ne > n ? ne : n);
+    const int64_t mn = w < (ne < n ? ne : n) ? w : (ne < n ? ne : n);
+    const int64_t lo = mx < pred ? mx : pred;
+    pred = mn > lo ? mn : lo;
+  }
+  s->prediction[0] = p0; s->prediction[1] = p1; s->prediction[2] = p2; s->prediction[3] = p3;
+  s->pred = pred;
+  if (property) *property = (int32_t)p;
+  return (pred + WP_ROUND) >> WP_EXTRA_BITS;
+}
+void jxlo_wp_update(jxlo_wp_state* s, int32_t correct_val, int x, int y) {
+  const int half = s->xsize + 1;
+  const int cur_row = (y & 1) ? 0 : half, prev_row = (y & 1) ? half : 0;
+  const int64_t val = (int64_t)correct_val << WP_EXTRA_BITS;
+  s->error[cur_row + x + 1] = (int32_t)(s->pred - val);
+  uint32_t e[4];
+  for (int k = 0; k < 4; k++) e[k] = (uint32_t)((wp_abs(s->prediction[k] - val) + WP_ROUND) >> WP_EXTRA_BITS);
+  for (int k = 0; k < 4; k++) s->pe[cur_row + x][k] = e[k];
+  for (int k = 0; k < 4; k++) s->pe[prev_row + x + 1][k] += e[k];
+}
+/* do_palette_step_general, predictor == Weighted branch (palette.rs:200-227): every pixel runs the predictor and
+ * updates its errors, delta entries (index < num_deltas) are added to the prediction */
+void jxlo_palette_delta_wp(const int32_t* index, int w, int h, const int32_t* palette, int num_colors, int num_deltas,
+                           size_t palette_stride, int nb_channels, int bit_depth, const uint32_t wp_header[11],
+                           int32_t* out) {
+  const size_t n = (size_t)w * h;
+  for (int c = 0; c < nb_channels; c++) {
+    int32_t* o = out + (size_t)c * n;
+    jxlo_wp_state* st = jxlo_wp_new(wp_header, w);
+    for (int y = 0; y < h; y++) {
+      for (int x = 0; x < w; x++) {
+        const int32_t idx = index[(size_t)y * w + x];
+        const int32_t entry = jxlo_palette_value(palette, palette_stride, (int64_t)idx, c, num_colors + num_deltas, bit_depth);
+        /* PredictionData::get (predict.rs:96-128) */
+        const int32_t* row = o + (size_t)y * w;
+        const int32_t* row_top = o + (size_t)(y > 0 ? y - 1 : 0) * w;
+        const int32_t* row_toptop = o + (size_t)(y > 1 ? y - 2 : 0) * w;
+        const int32_t left = x > 0 ? row[x - 1] : (y > 0 ? row_top[0] : 0);
+        const int32_t top = y > 0 ? row_top[x] : left;
+        const int32_t topleft = (x > 0 && y > 0) ? row_top[x - 1] : left;
+        const int32_t topright = (x + 1 < w && y > 0) ? row_top[x + 1] : top;
+        const int32_t toptop = y > 1 ? row_toptop[x] : top;
+        const int32_t nb[5] = {top, left, topright, topleft, toptop};
+        const int64_t pred = jxlo_wp_predict(st, x, y, nb, NULL);
+        const int32_t val = idx < num_deltas ? (int32_t)(uint32_t)(uint64_t)(pred + (int64_t)entry) : entry;
+        o[(size_t)y * w + x] = val;
+        jxlo_wp_update(st, val, x, y);
+      }
+    }
+    jxlo_wp_free(st);
+  }
+}
+
 /* ---- squeeze ---- */
 int64_t jxlo_smooth_tendency(int64_t b, int64_t a, int64_t n) { /* squeeze.rs:143-168 */
   int64_t diff = 0;

@@ -147,6 +147,18 @@ class Oracle:
         L.jxlo_i32_to_u8.argtypes = [ip, C.c_size_t, C.c_int32, C.c_int32, C.POINTER(C.c_uint8)]
         L.jxlo_modular_to_f32.argtypes = [ip, C.c_size_t, C.c_int, fp]
         L.jxlo_modular_xyb_to_f32.argtypes = [ip, ip, ip, C.c_size_t, fp, fp, fp, fp]
+        u32p = C.POINTER(C.c_uint32)
+        L.jxlo_wp_new.argtypes = [u32p, C.c_int]
+        L.jxlo_wp_new.restype = C.c_void_p
+        L.jxlo_wp_free.argtypes = [C.c_void_p]
+        L.jxlo_wp_free.restype = None
+        L.jxlo_wp_predict.argtypes = [C.c_void_p, C.c_int, C.c_int, ip, ip]
+        L.jxlo_wp_predict.restype = C.c_int64
+        L.jxlo_wp_update.argtypes = [C.c_void_p, C.c_int32, C.c_int, C.c_int]
+        L.jxlo_wp_update.restype = None
+        L.jxlo_palette_delta_wp.argtypes = [ip, C.c_int, C.c_int, ip, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int,
+                                            u32p, ip]
+        L.jxlo_palette_delta_wp.restype = None
         L.jxlo_unsqueeze_h.argtypes = [ip, C.c_size_t, ip, C.c_size_t, C.c_int, C.c_int, ip, C.c_size_t]
         L.jxlo_unsqueeze_v.argtypes = [ip, C.c_size_t, ip, C.c_size_t, C.c_int, C.c_int, ip, C.c_size_t]
         L.jxlo_smooth_convolve_2d.argtypes = [fp, C.c_int, ip]
@@ -589,6 +601,17 @@ class Oracle:
         out = np.zeros((nb_channels,) + idx.shape, dtype=np.int32)
         self.lib.jxlo_palette(_ptr(idx, C.c_int32), idx.size, _ptr(pal, C.c_int32), num_colors,
                               pal.shape[1], nb_channels, bit_depth, _ptr(out, C.c_int32))
+        return out
+
+    def palette_delta_wp(self, index, palette, num_colors, num_deltas, nb_channels, bit_depth, wp_header):
+        """wp_header: (p1c, p2c, p3ca, p3cb, p3cc, p3cd, p3ce, w0, w1, w2, w3)"""
+        idx = np.ascontiguousarray(index, dtype=np.int32)
+        pal = np.ascontiguousarray(palette, dtype=np.int32)
+        hdr = np.ascontiguousarray(wp_header, dtype=np.uint32)
+        h, w = idx.shape
+        out = np.zeros((nb_channels, h, w), dtype=np.int32)
+        self.lib.jxlo_palette_delta_wp(_ptr(idx, C.c_int32), w, h, _ptr(pal, C.c_int32), num_colors, num_deltas,
+                                       pal.shape[1], nb_channels, bit_depth, _ptr(hdr, C.c_uint32), _ptr(out, C.c_int32))
         return out
 
     def unsqueeze_h(self, avg, res, out_w):

@@ -642,11 +642,67 @@ def test_modular_output_bridges_bit_exact(ctx, oracle, shape):
         assert bit_equal(got[c], want[c]), c
 
 
-def test_delta_palette_weighted_predictor_is_unsupported(ctx):
+def test_delta_palette_weighted_predictor_needs_its_header(ctx):
+    """predictor 6 through jxlh_palette_delta has no WeightedHeader to run with: the caller is pointed at
+    jxlh_palette_delta_wp; header fields outside their bit widths are rejected there"""
     from jxl_rs_amd import lib, JxlHipError
     with pytest.raises(JxlHipError) as e:
         ctx.palette_delta(np.zeros((4, 4), np.int32), np.zeros((3, 4), np.int32), 2, 2, 8, 6)
     assert e.value.status == lib.ERR_UNSUPPORTED
+    with pytest.raises(JxlHipError) as e:
+        ctx.palette_delta_wp(np.zeros((4, 4), np.int32), np.zeros((3, 4), np.int32), 2, 2, 8,
+                             (32, 10, 7, 7, 7, 0, 0, 13, 12, 12, 12))
+    assert e.value.status == lib.ERR_INVALID_ARGUMENT
+
+
+WP_DEFAULT = (16, 10, 7, 7, 7, 0, 0, 13, 12, 12, 12)   # WeightedHeader defaults, headers/modular.rs:16-66
+
+
+@pytest.mark.parametrize("hdr", [WP_DEFAULT, (31, 0, 5, 19, 7, 3, 30, 15, 0, 1, 9), (0, 31, 31, 0, 0, 31, 1, 0, 15, 15, 0)])
+def test_delta_palette_weighted_predictor_bit_exact(ctx, oracle, hdr):
+    """do_palette_step_general, Predictor::Weighted (palette.rs:200-227): the wavefront kernel carries the predictor's
+    error state in LDS rings / registers instead of the reference's two summed rows; bit-exact against the oracle
+    (pinned on the reference's libjxl golden), incl. images narrower than the reach, one row / one column, more than
+    one 256-row band (band-edge state goes through global scratch) and smooth content where the predictor locks on"""
+    rng = np.random.default_rng(sum(hdr))
+    for (h, w), nb, bit_depth in (((37, 53), 3, 8), ((1, 40), 3, 8), ((50, 1), 1, 8), ((9, 2), 2, 12), ((1100, 7), 3, 8),
+                                  ((130, 300), 3, 10), ((530, 70), 1, 8), ((257, 3), 2, 8)):
+        num_colors, num_deltas = int(rng.integers(1, 20)), int(rng.integers(0, 8))
+        pal = rng.integers(-30, 1 << bit_depth, size=(nb, num_colors + num_deltas)).astype(np.int32)
+        pal[:, :num_deltas] = rng.integers(-12, 13, size=(nb, num_deltas))
+        idx = rng.integers(-8, num_colors + num_deltas + 100, size=(h, w)).astype(np.int32)
+        idx[rng.random((h, w)) < 0.6] = rng.integers(0, max(1, num_deltas + 2))
+        got = ctx.palette_delta_wp(idx, pal, num_colors, num_deltas, bit_depth, hdr)
+        want = oracle.palette_delta_wp(idx, pal, num_colors, num_deltas, nb, bit_depth, hdr)
+        assert np.array_equal(got, want), (f"{h}x{w} nb={nb} colors={num_colors} deltas={num_deltas}",
+                                           np.argwhere(got != want)[:4])
+    # a smooth ramp coded as "delta 0 everywhere after a seed": the predictor extrapolates, errors stay small
+    h, w = 300, 200
+    idx = np.zeros((h, w), np.int32)
+    idx[0, :] = 1 + (np.arange(w) % 5)
+    idx[:, 0] = 1 + (np.arange(h) % 5)
+    pal = np.array([[0, 10, 12, 15, 19, 24]], np.int32)
+    got = ctx.palette_delta_wp(idx, pal, 5, 1, 8, hdr)
+    assert np.array_equal(got, oracle.palette_delta_wp(idx, pal, 5, 1, 1, 8, hdr))
+
+
+def test_delta_palette_weighted_predictor_device_pointers(ctx, oracle):
+    from helpers import DeviceArray
+    rng = np.random.default_rng(9)
+    h, w, nb = 300, 129, 3
+    pal = rng.integers(0, 256, size=(nb, 12)).astype(np.int32)
+    pal[:, :4] = rng.integers(-9, 10, size=(nb, 4))
+    idx = rng.integers(0, 12, size=(h, w)).astype(np.int32)
+    d_idx, d_pal, d_out = DeviceArray(idx), DeviceArray(pal), DeviceArray(nbytes=nb * h * w * 4)
+    hdr = np.array(WP_DEFAULT, np.uint32)
+    from jxl_rs_amd import lib
+    ctx._chk(ctx.L.jxlh_palette_delta_wp(ctx._ctx, lib._addr(d_idx.ptr), w, h, lib._addr(d_pal.ptr), 8, 4, 12, nb, 8,
+                                         lib._addr(hdr), lib._addr(d_out.ptr)), "palette_delta_wp")
+    ctx.sync()
+    got = d_out.download(np.int32, nb * h * w).reshape(nb, h, w)
+    assert np.array_equal(got, oracle.palette_delta_wp(idx, pal, 8, 4, nb, 8, WP_DEFAULT))
+    for d in (d_idx, d_pal, d_out):
+        d.free()
 
 
 @pytest.mark.parametrize("shape", [(1, 1), (1, 2), (2, 1), (5, 9), (64, 64), (67, 129), (300, 255)])

@@ -517,3 +517,51 @@ def test_smooth_unsqueeze_x86_convert_differs_from_the_other_backends(oracle):
     d = np.abs(a.astype(np.int64) - b)
     assert d.max() == 1 and 0.2 < (d != 0).mean() < 0.8
     assert (np.abs(b) >= np.abs(a)).all()
+
+
+# ---------------------------------------------------------------- the self-correcting ("Weighted") predictor
+def test_weighted_predictor_libjxl_golden(oracle):
+    """predict_and_update_errors (modular/predict.rs:561-592): an LCG drives header, positions, neighbours and the
+    corrected values; the four expected (prediction, property) pairs were generated with libjxl's predictor."""
+    import ctypes as C
+
+    class Lcg:
+        def __init__(self):
+            self.out = 1
+
+        def next(self):
+            self.out = self.out * 48271 % 0x7FFFFFFF
+            return self.out
+    rng = Lcg()
+    header = [rng.next() % 32 for _ in range(7)] + [rng.next() % 16 for _ in range(4)]  # p1c p2c p3ca..e, w0..w3
+    L = oracle.lib
+    hdr = (C.c_uint32 * 11)(*header)
+    xsize = ysize = 8
+    st = L.jxlo_wp_new(hdr, xsize)
+    got = []
+    for _ in range(4):
+        x, y = rng.next() % xsize, rng.next() % ysize
+        top, left, topright, topleft, toptop = [rng.next() % 256 for _ in range(5)]
+        nb = (C.c_int32 * 5)(top, left, topright, topleft, toptop)
+        prop = C.c_int32()
+        pred = L.jxlo_wp_predict(st, x, y, nb, C.byref(prop))
+        L.jxlo_wp_update(st, rng.next() % 256, x, y)
+        got.append((pred, prop.value))
+    L.jxlo_wp_free(st)
+    assert got == [(135, 0), (110, -60), (165, 0), (153, -60)]
+
+
+def test_weighted_predictor_reproduces_flat_and_ramp_images(oracle):
+    """Sanity on whole images through the palette step: with every index a delta entry of value 0 the output is the
+    predictor's own extrapolation -- a constant image stays constant, and the first pixel is 0 + entry."""
+    w, h = 19, 11
+    pal = np.zeros((1, 1), np.int32)           # one delta entry: 0
+    idx = np.zeros((h, w), np.int32)
+    hdr = (16, 10, 7, 7, 7, 0, 0, 13, 12, 12, 12)  # the header's defaults (headers/modular.rs:16-66)
+    out = oracle.palette_delta_wp(idx, pal, 0, 1, 1, 8, hdr)
+    assert (out == 0).all()
+    pal2 = np.array([[0, 37]], np.int32)       # entry 1 is a colour: absolute 37
+    idx2 = np.zeros((h, w), np.int32)
+    idx2[0, 0] = 1
+    out2 = oracle.palette_delta_wp(idx2, pal2, 1, 1, 1, 8, hdr)
+    assert out2[0, 0, 0] == 37 and (out2[0, 0, 1:] == 37).all()  # West-like extrapolation along the first row

@@ -19,3 +19,9 @@ for w, h in sizes:
     t0 = time.perf_counter(); run(); c.sync(); t = time.perf_counter() - t0
     steps = w + 3 * h
     print(f"{w}x{h}: {t*1e3:.2f} ms  ({w*h/t/1e6:.1f} MP/s, {t*1e6/steps:.2f} us per wavefront step of {steps})")
+    hdr = np.array((16, 10, 7, 7, 7, 0, 0, 13, 12, 12, 12), np.uint32)   # Weighted predictor, default header
+    def run_wp():
+        c._chk(c.L.jxlh_palette_delta_wp(c._ctx, lib._addr(idx), w, h, lib._addr(pal), 64 - ND, ND, 64, 3, 8, lib._addr(hdr), lib._addr(out)), "wp")
+    run_wp(); c.sync()
+    t0 = time.perf_counter(); run_wp(); c.sync(); t = time.perf_counter() - t0
+    print(f"{w}x{h} weighted: {t*1e3:.2f} ms  ({w*h/t/1e6:.1f} MP/s, {t*1e6/steps:.2f} us per wavefront step)")
