@@ -134,6 +134,7 @@ __device__ __forceinline__ int32_t palette_value(const int32_t* __restrict__ pal
 //    written).  A waiting band only depends on bands with a lower block index, which were dispatched earlier.
 constexpr int kDeltaRows = 256;
 constexpr int kDeltaPublish = 32;
+constexpr int kDeltaQueue = 8;  // steps a lane's index / entry loads run ahead (8 or 16)
 
 template <int predictor>
 __device__ __forceinline__ int64_t predict_one(int64_t left, int64_t top, int64_t toptop, int64_t topleft,
@@ -184,15 +185,16 @@ __global__ __launch_bounds__(kDeltaRows) void k5_palette_delta(const int32_t* __
   // Index and palette entry of a lane's next 8 columns are loaded 8 steps ahead, off the per-step critical path (the
   // step barrier waits for LDS only).  The queues are indexed by the STEP (slot s & 7), not by the column, so that
   // the 8x unrolled loop addresses them with compile-time register numbers and no value in flight is ever moved.
-  int32_t iq[8], eq[8];
+  constexpr int Q = kDeltaQueue;
+  int32_t iq[Q], eq[Q];
   {
     const int s0 = 3 * l;  // the lane's first step
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
+    for (int k = 0; k < Q; k++) {
       iq[k] = eq[k] = 0;
 #pragma unroll
-      for (int j = 0; j < 8; j++)
-        if (((s0 + j) & 7) == k && l < rows && j < w) {
+      for (int j = 0; j < Q; j++)
+        if (((s0 + j) & (Q - 1)) == k && l < rows && j < w) {
           iq[k] = irow[j];
           eq[k] = orow[j];
         }
@@ -208,9 +210,9 @@ __global__ __launch_bounds__(kDeltaRows) void k5_palette_delta(const int32_t* __
     if (l < rows && x >= 0 && x < w) {
       const int32_t idx = iq[K];
       int32_t val = eq[K];
-      if (x + 8 < w) {
-        iq[K] = irow[x + 8];
-        eq[K] = orow[x + 8];
+      if (x + Q < w) {
+        iq[K] = irow[x + Q];
+        eq[K] = orow[x + Q];
       }
       if (idx < num_deltas) {
         // row y - 1 / y - 2: the LDS ring of the lane above, or the window of the previous band's rows
@@ -243,7 +245,7 @@ __global__ __launch_bounds__(kDeltaRows) void k5_palette_delta(const int32_t* __
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
   };
-  for (int s8 = 0; s8 < nsteps; s8 += 8) {
+  for (int s8 = 0; s8 < nsteps; s8 += Q) {
     if (band > 0 && (s8 & 63) == 0) {
       // columns this band's first rows touch during steps s8 .. s8 + 63: up to s8 + 65 -> copy [lo, hi)
       const int lo = s8 == 0 ? 0 : s8 + 2, hi = min(w, s8 + 66);
@@ -267,14 +269,11 @@ __global__ __launch_bounds__(kDeltaRows) void k5_palette_delta(const int32_t* __
         __syncthreads();
       }
     }
-    if (s8 + 0 < nsteps) step(s8 + 0, std::integral_constant<int, 0>{});
-    if (s8 + 1 < nsteps) step(s8 + 1, std::integral_constant<int, 1>{});
-    if (s8 + 2 < nsteps) step(s8 + 2, std::integral_constant<int, 2>{});
-    if (s8 + 3 < nsteps) step(s8 + 3, std::integral_constant<int, 3>{});
-    if (s8 + 4 < nsteps) step(s8 + 4, std::integral_constant<int, 4>{});
-    if (s8 + 5 < nsteps) step(s8 + 5, std::integral_constant<int, 5>{});
-    if (s8 + 6 < nsteps) step(s8 + 6, std::integral_constant<int, 6>{});
-    if (s8 + 7 < nsteps) step(s8 + 7, std::integral_constant<int, 7>{});
+#define JXLH_DSTEP(I) \
+  if (Q > I && s8 + I < nsteps) step(s8 + I, std::integral_constant<int, (I) & (Q - 1)>{});
+    JXLH_DSTEP(0) JXLH_DSTEP(1) JXLH_DSTEP(2) JXLH_DSTEP(3) JXLH_DSTEP(4) JXLH_DSTEP(5) JXLH_DSTEP(6) JXLH_DSTEP(7)
+    JXLH_DSTEP(8) JXLH_DSTEP(9) JXLH_DSTEP(10) JXLH_DSTEP(11) JXLH_DSTEP(12) JXLH_DSTEP(13) JXLH_DSTEP(14) JXLH_DSTEP(15)
+#undef JXLH_DSTEP
   }
 }
 
