@@ -167,10 +167,26 @@ __device__ __forceinline__ int64_t predict_one(int64_t left, int64_t top, int64_
 
 // `out` already holds the palette entry of every pixel (the parallel gather kernel ran first): the wavefront only
 // adds the prediction where index < num_deltas.
+//
+// Global memory is touched in CHUNKS of kDeltaChunk steps, never inside a step.  A wave with loads and stores both
+// outstanding has to drain everything (one in-order vmcnt, vmcnt(0)) whenever it needs a loaded value, so a per-step
+// "load the column 8 steps ahead, store this column" costs a full memory round trip per step, prefetch or not --
+// that, not the prediction, was the 0.7-1.6 us step of the first version.  Per chunk a lane now: stores the outputs of
+// the previous chunk (LDS -> global), moves the next chunk's index / entry values from registers to LDS (they were
+// requested a whole chunk ago) and requests the chunk after that.  Steps read and write LDS only (lane-private rows of
+// 33 dwords: conflict-free).  Progress is published one chunk late, right before a chunk's stores are issued, when
+// the previous chunk's stores have long been acknowledged: the fence is free.
+constexpr int kDeltaChunk = 32;
+static_assert(kDeltaPublish == kDeltaChunk, "progress is published per chunk");
+
 template <int PREDICTOR>
 __global__ __launch_bounds__(kDeltaRows) void k5_palette_delta(const int32_t* __restrict__ index, int w, int h,
                                                                int num_deltas, int32_t* out_base, int* progress_base) {
-  __shared__ int32_t s_ring[kDeltaRows][8];
+  constexpr int C = kDeltaChunk;
+  // rows 0 / 1 of the ring are the two rows ABOVE the band (y0 - 2, y0 - 1), fed from s_above one step ahead by lane
+  // 0, so that every lane reads its neighbours the same way, unconditionally and in one batch; lane l owns row l + 2
+  __shared__ int32_t s_ring[kDeltaRows + 2][9];
+  __shared__ int32_t s_idx[kDeltaRows][C + 1], s_ent[kDeltaRows][C + 1], s_outc[kDeltaRows][C + 1];
   __shared__ int32_t s_above[2][128];  // rows y0 - 1 and y0 - 2 (of the previous band), a window of 128 columns
   __shared__ int s_avail;
   const int c = blockIdx.x, band = blockIdx.y, nbands = gridDim.y, l = threadIdx.x;
@@ -179,76 +195,56 @@ __global__ __launch_bounds__(kDeltaRows) void k5_palette_delta(const int32_t* __
   const int y0 = band * kDeltaRows;
   const int rows = min(kDeltaRows, h - y0);
   const int y = y0 + l;
-  const int32_t* __restrict__ irow = index + (size_t)min(y, h - 1) * w;
-  int32_t* orow = out + (size_t)min(y, h - 1) * w;
+  const bool live = l < rows;
   int32_t left_v = 0, leftleft_v = 0;  // out[y][x - 1], out[y][x - 2]
-  // Index and palette entry of a lane's next 8 columns are loaded 8 steps ahead, off the per-step critical path (the
-  // step barrier waits for LDS only).  The queues are indexed by the STEP (slot s & 7), not by the column, so that
-  // the 8x unrolled loop addresses them with compile-time register numbers and no value in flight is ever moved.
-  constexpr int Q = kDeltaQueue;
-  int32_t iq[Q], eq[Q];
-  {
-    const int s0 = 3 * l;  // the lane's first step
-#pragma unroll
-    for (int k = 0; k < Q; k++) {
-      iq[k] = eq[k] = 0;
-#pragma unroll
-      for (int j = 0; j < Q; j++)
-        if (((s0 + j) & (Q - 1)) == k && l < rows && j < w) {
-          iq[k] = irow[j];
-          eq[k] = orow[j];
-        }
-    }
-  }
   const int nsteps = w + 3 * (rows - 1);
+  const int nchunks = (nsteps + C - 1) / C;
   // steps the previous band (always kDeltaRows rows) takes; its last row finishes column x at step x + 3*(R-1)
   const int prod_steps = w + 3 * (kDeltaRows - 1);
-  int avail = 0;  // completed steps of the previous band, as last observed
-  auto step = [&](const int s, auto slot_tag) {
-    constexpr int K = decltype(slot_tag)::value;
-    const int x = s - 3 * l;
-    if (l < rows && x >= 0 && x < w) {
-      const int32_t idx = iq[K];
-      int32_t val = eq[K];
-      if (x + Q < w) {
-        iq[K] = irow[x + Q];
-        eq[K] = orow[x + Q];
-      }
-      if (idx < num_deltas) {
-        // row y - 1 / y - 2: the LDS ring of the lane above, or the window of the previous band's rows
-        auto T = [&](int xx) -> int32_t { return l > 0 ? s_ring[l - 1][xx & 7] : s_above[0][xx & 127]; };
-        auto TT = [&](int xx) -> int32_t {
-          return l > 1 ? s_ring[l - 2][xx & 7] : s_above[l == 1 ? 0 : 1][xx & 127];
-        };
-        // PredictionData::get_rows, modular/predict.rs:96-128
-        const int64_t left = x > 0 ? left_v : (y > 0 ? T(0) : 0);
-        const int64_t top = y > 0 ? T(x) : left;
-        const int64_t topleft = (x > 0 && y > 0) ? T(x - 1) : left;
-        const int64_t topright = (x + 1 < w && y > 0) ? T(x + 1) : top;
-        const int64_t leftleft = x > 1 ? leftleft_v : left;
-        const int64_t toptop = y > 1 ? TT(x) : top;
-        const int64_t toprightright = (x + 2 < w && y > 0) ? T(x + 2) : topright;
-        const int64_t pred = predict_one<PREDICTOR>(left, top, toptop, topleft, topright, leftleft, toprightright);
-        val = (int32_t)(uint32_t)(uint64_t)(pred + (int64_t)val);
-        orow[x] = val;
-      }
-      s_ring[l][x & 7] = val;
-      leftleft_v = left_v;
-      left_v = val;
-    }
-    if (band + 1 < nbands && ((s + 1) % kDeltaPublish == 0 || s + 1 == nsteps)) {
-      __threadfence();  // this thread's stores are visible device-wide ...
-      __syncthreads();  // ... for every thread of the band
-      if (l == 0) __hip_atomic_store(&progress[band], s + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      // LDS writes of this step visible to the workgroup; global loads / stores stay in flight
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  int avail = 0;  // completed (and stored) steps of the previous band, as last observed
+  // Chunk k of row r = columns [k C - 3 r, k C - 3 r + C): 32 contiguous samples.  The chunk is moved TRANSPOSED:
+  // thread t handles column t % 32 of rows t / 32 + 8 i, so that a wave instruction touches two 128-byte row segments
+  // (a lane fetching its own row's samples costs the texture path one cache-line request per lane: ~0.25 us per
+  // instruction, which was the whole step time); the LDS tiles turn rows back into lanes.  Columns outside the row
+  // read the nearest valid one, rows below the image read its last row; neither is ever used.
+  static_assert(C == 32 && kDeltaRows == 256, "the mover mapping below assumes 32-column chunks and 256-row bands");
+  constexpr int NI = 32;  // rows per thread and chunk
+  const int mcol = l & 31, mrow0 = l >> 5;
+  int32_t nq_i[NI], nq_e[NI];  // the chunk after the current one, in flight
+  auto fetch = [&](int k) {
+#pragma unroll
+    for (int i = 0; i < NI; i++) {
+      const int r = mrow0 + 8 * i;
+      const int xi = min(max(k * C - 3 * r + mcol, 0), w - 1);
+      const size_t off = (size_t)min(y0 + r, h - 1) * w + xi;
+      nq_i[i] = index[off];
+      nq_e[i] = out[off];
     }
   };
-  for (int s8 = 0; s8 < nsteps; s8 += Q) {
-    if (band > 0 && (s8 & 63) == 0) {
-      // columns this band's first rows touch during steps s8 .. s8 + 63: up to s8 + 65 -> copy [lo, hi)
-      const int lo = s8 == 0 ? 0 : s8 + 2, hi = min(w, s8 + 66);
+  auto stage = [&]() {
+#pragma unroll
+    for (int i = 0; i < NI; i++) {
+      s_idx[mrow0 + 8 * i][mcol] = nq_i[i];
+      s_ent[mrow0 + 8 * i][mcol] = nq_e[i];
+    }
+  };
+  auto flush = [&](int k) {
+#pragma unroll
+    for (int i = 0; i < NI; i++) {
+      const int r = mrow0 + 8 * i;
+      const int x = k * C - 3 * r + mcol;
+      if (r < rows && x >= 0 && x < w) out[(size_t)(y0 + r) * w + x] = s_outc[r][mcol];
+    }
+  };
+  fetch(0);
+  stage();
+  if (nchunks > 1) fetch(1);
+  __syncthreads();
+  for (int k = 0; k < nchunks; k++) {
+    const int s0 = k * C;
+    if (band > 0 && (s0 & 63) == 0) {
+      // columns this band's first rows touch during steps s0 .. s0 + 63: up to s0 + 66 -> copy [lo, hi)
+      const int lo = s0 == 0 ? 0 : s0 + 3, hi = min(w, s0 + 67);  // lane 0 copies column s + 3 during step s
       if (lo < hi) {
         const int need = min(prod_steps, (hi - 1) + 3 * (kDeltaRows - 1) + 1);
         if (avail < need) {
@@ -269,11 +265,60 @@ __global__ __launch_bounds__(kDeltaRows) void k5_palette_delta(const int32_t* __
         __syncthreads();
       }
     }
-#define JXLH_DSTEP(I) \
-  if (Q > I && s8 + I < nsteps) step(s8 + I, std::integral_constant<int, (I) & (Q - 1)>{});
-    JXLH_DSTEP(0) JXLH_DSTEP(1) JXLH_DSTEP(2) JXLH_DSTEP(3) JXLH_DSTEP(4) JXLH_DSTEP(5) JXLH_DSTEP(6) JXLH_DSTEP(7)
-    JXLH_DSTEP(8) JXLH_DSTEP(9) JXLH_DSTEP(10) JXLH_DSTEP(11) JXLH_DSTEP(12) JXLH_DSTEP(13) JXLH_DSTEP(14) JXLH_DSTEP(15)
-#undef JXLH_DSTEP
+    if (band > 0 && s0 == 0) {  // the ring's view of the rows above, for step 0: columns 0..2 / column 0
+      if (l < 3) s_ring[1][l] = s_above[0][l];
+      if (l == 0) s_ring[0][0] = s_above[1][0];
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    const int send = min(C, nsteps - s0);
+    for (int j = 0; j < send; j++) {
+      const int s = s0 + j;
+      const int x = s - 3 * l;
+      // one batch of LDS reads, no branches: values that do not exist (first rows / columns) are read from valid
+      // addresses and discarded by the selects below
+      const int32_t idx = s_idx[l][j];
+      const int32_t ent = s_ent[l][j];
+      const int32_t t_m1 = s_ring[l + 1][(x - 1) & 7], t_0 = s_ring[l + 1][x & 7], t_p1 = s_ring[l + 1][(x + 1) & 7];
+      const int32_t t_p2 = s_ring[l + 1][(x + 2) & 7], tt_0 = s_ring[l][x & 7];
+      const bool active = live && x >= 0 && x < w;
+      // PredictionData::get_rows, modular/predict.rs:96-128
+      const int64_t left = x > 0 ? left_v : (y > 0 ? t_0 : 0);
+      const int64_t top = y > 0 ? t_0 : left;
+      const int64_t topleft = (x > 0 && y > 0) ? t_m1 : left;
+      const int64_t topright = (x + 1 < w && y > 0) ? t_p1 : top;
+      const int64_t leftleft = x > 1 ? leftleft_v : left;
+      const int64_t toptop = y > 1 ? tt_0 : top;
+      const int64_t toprightright = (x + 2 < w && y > 0) ? t_p2 : topright;
+      const int64_t pred = predict_one<PREDICTOR>(left, top, toptop, topleft, topright, leftleft, toprightright);
+      const int32_t val = idx < num_deltas ? (int32_t)(uint32_t)(uint64_t)(pred + (int64_t)ent) : ent;
+      if (active) {
+        s_outc[l][j] = val;
+        s_ring[l + 2][x & 7] = val;
+        leftleft_v = left_v;
+        left_v = val;
+      }
+      if (band > 0 && l == 0) {  // the rows above, one step ahead (columns past the row's end are never selected)
+        s_ring[1][(s + 3) & 7] = s_above[0][(s + 3) & 127];
+        s_ring[0][(s + 1) & 7] = s_above[1][(s + 1) & 127];
+      }
+      // LDS writes of this step visible to the workgroup
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    // chunk boundary: what chunk k - 1 stored a whole chunk ago is what the band below may now read
+    if (band + 1 < nbands && k > 0) {
+      __threadfence();
+      __syncthreads();
+      if (l == 0) __hip_atomic_store(&progress[band], s0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    flush(k);
+    if (k + 1 < nchunks) stage();  // chunk k + 1 (every lane is past its last read of chunk k: the step barriers)
+    if (k + 2 < nchunks) fetch(k + 2);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the staged chunk is visible; loads stay in flight
+  }
+  if (band + 1 < nbands) {
+    __threadfence();
+    __syncthreads();
+    if (l == 0) __hip_atomic_store(&progress[band], nsteps, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
