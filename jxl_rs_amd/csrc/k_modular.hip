@@ -233,7 +233,12 @@ __global__ __launch_bounds__(kDeltaRows) void k5_palette_delta(const int32_t* __
     for (int i = 0; i < NI; i++) {
       const int r = mrow0 + 8 * i;
       const int x = k * C - 3 * r + mcol;
-      if (r < rows && x >= 0 && x < w) out[(size_t)(y0 + r) * w + x] = s_outc[r][mcol];
+      // agent-scope (write-through) stores: the band below reads these rows from another XCD, whose L2 is not
+      // coherent with this one's.  With plain stores every publish needs a release fence = a write-back of this
+      // XCD's whole L2 (measured ~10 us per chunk, 60 % of a band's time); written through, "visible to the
+      // agent" is simply "acknowledged", which the publish below waits for with vmcnt(0).
+      if (r < rows && x >= 0 && x < w)
+        __hip_atomic_store(&out[(size_t)(y0 + r) * w + x], s_outc[r][mcol], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   };
   fetch(0);
@@ -306,9 +311,9 @@ __global__ __launch_bounds__(kDeltaRows) void k5_palette_delta(const int32_t* __
     }
     // chunk boundary: what chunk k - 1 stored a whole chunk ago is what the band below may now read
     if (band + 1 < nbands && k > 0) {
-      __threadfence();
-      __syncthreads();
-      if (l == 0) __hip_atomic_store(&progress[band], s0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's write-through stores of chunk k - 1 have landed
+      __syncthreads();                                  // ... and every other thread's
+      if (l == 0) __hip_atomic_store(&progress[band], s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     flush(k);
     if (k + 1 < nchunks) stage();  // chunk k + 1 (every lane is past its last read of chunk k: the step barriers)
@@ -316,9 +321,9 @@ __global__ __launch_bounds__(kDeltaRows) void k5_palette_delta(const int32_t* __
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the staged chunk is visible; loads stay in flight
   }
   if (band + 1 < nbands) {
-    __threadfence();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (l == 0) __hip_atomic_store(&progress[band], nsteps, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (l == 0) __hip_atomic_store(&progress[band], nsteps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 

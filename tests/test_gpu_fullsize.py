@@ -161,3 +161,25 @@ def test_8k_modular_chain_vs_oracle(ctx, oracle):
     got = ctx.palette(idx, pal, 256, 3, 8)
     want = oracle.palette(idx, pal, 256, 3, 8)
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("weighted", [False, True])
+def test_delta_palette_many_bands_bit_exact(ctx, oracle, weighted):
+    """2048 x 3072 x 3 channels: twelve 256-row bands per channel pipelined across workgroups (progress counters,
+    write-through stores, the rows above a band read from another XCD) -- the whole image against the raster-order
+    oracle, for the gradient predictor and for the Weighted one (whose band-edge state rows travel the same way)."""
+    rng = np.random.default_rng(77 + weighted)
+    h, w, nb = 3072, 2048, 3
+    num_colors, num_deltas = 40, 8
+    pal = rng.integers(0, 256, size=(nb, num_colors + num_deltas)).astype(np.int32)
+    pal[:, :num_deltas] = rng.integers(-6, 7, size=(nb, num_deltas))
+    idx = rng.integers(0, num_colors + num_deltas, size=(h, w)).astype(np.int32)
+    idx[rng.random((h, w)) < 0.5] = rng.integers(0, num_deltas)
+    if weighted:
+        hdr = (16, 10, 7, 7, 7, 0, 0, 13, 12, 12, 12)
+        got = ctx.palette_delta_wp(idx, pal, num_colors, num_deltas, 8, hdr)
+        want = oracle.palette_delta_wp(idx, pal, num_colors, num_deltas, nb, 8, hdr)
+    else:
+        got = ctx.palette_delta(idx, pal, num_colors, num_deltas, 8, 5)
+        want = oracle.palette_delta(idx, pal, num_colors, num_deltas, 8, 5)
+    assert np.array_equal(got, want), np.argwhere(got != want)[:5]
