@@ -134,7 +134,6 @@ __device__ __forceinline__ int32_t palette_value(const int32_t* __restrict__ pal
 //    written).  A waiting band only depends on bands with a lower block index, which were dispatched earlier.
 constexpr int kDeltaRows = 256;
 constexpr int kDeltaPublish = 32;
-constexpr int kDeltaQueue = 8;  // steps a lane's index / entry loads run ahead (8 or 16)
 
 template <int predictor>
 __device__ __forceinline__ int64_t predict_one(int64_t left, int64_t top, int64_t toptop, int64_t topleft,
@@ -349,13 +348,20 @@ __constant__ uint32_t kWpDivLookup[64] = {  // (1 << 24) / (i + 1), predict.rs:2
     342392,   335544,  328965,  322638,  316551,  310689,  305040,  299593,  294337,  289262,  284359,  279620,
     275036,   270600,  266305,  262144};
 
-// wp_rows: per channel and band, five rows of w ints (TE, E0..E3 of the band's last row)
+// wp_rows: per channel and band, five rows of w ints (TE, E0..E3 of the band's last row).
+// Memory movement as in k5_palette_delta: chunks of 32 steps moved as coalesced row segments through LDS, neighbour and
+// state reads in one unconditional batch (the rows above the band are fed into ring rows 0 / 1 one step ahead by lane
+// 0), outputs and the published state row written through at agent scope.
 __global__ __launch_bounds__(kDeltaRows) void k5_palette_wp(const int32_t* __restrict__ index, int w, int h,
                                                             int num_deltas, int32_t* out_base, int* progress_base,
                                                             int32_t* wp_rows_base, const WpParams P) {
-  __shared__ int32_t s_ring[kDeltaRows][8];
-  __shared__ int32_t s_te[kDeltaRows][8];
-  __shared__ uint32_t s_e[4][kDeltaRows][8];
+  constexpr int C = kDeltaChunk;
+  // ring row 0 / 1 = rows y0 - 2 / y0 - 1, lane l owns row l + 2 (s_te / s_e: row 1 = y0 - 1, lane l owns row l + 2)
+  __shared__ int32_t s_ring[kDeltaRows + 2][9];
+  __shared__ int32_t s_te[kDeltaRows + 2][9];
+  __shared__ uint32_t s_e[4][kDeltaRows + 2][9];
+  __shared__ int32_t s_idx[kDeltaRows][C + 1], s_ent[kDeltaRows][C + 1], s_outc[kDeltaRows][C + 1];
+  __shared__ int32_t s_state[5][C];    // TE, E0..E3 of the band's last row for the current chunk
   __shared__ int32_t s_above[2][128];  // out rows y0 - 1 and y0 - 2 (of the previous band), a window of 128 columns
   __shared__ int32_t s_above_te[128];  // TE and E of row y0 - 1
   __shared__ uint32_t s_above_e[4][128];
@@ -363,132 +369,62 @@ __global__ __launch_bounds__(kDeltaRows) void k5_palette_wp(const int32_t* __res
   const int c = blockIdx.x, band = blockIdx.y, nbands = gridDim.y, l = threadIdx.x;
   int32_t* out = out_base + (size_t)c * (size_t)w * h;
   int* progress = progress_base + (size_t)c * nbands;
-  int32_t* wp_mine = wp_rows_base + ((size_t)c * nbands + band) * 5 * (size_t)w;        // written by the last row
+  int32_t* wp_mine = wp_rows_base + ((size_t)c * nbands + band) * 5 * (size_t)w;        // written for the band below
   const int32_t* wp_prev = wp_rows_base + ((size_t)c * nbands + band - 1) * 5 * (size_t)w;  // read when band > 0
   const int y0 = band * kDeltaRows;
   const int rows = min(kDeltaRows, h - y0);
   const int y = y0 + l;
-  const bool publishes_rows = band + 1 < nbands && l == rows - 1;
-  const int32_t* __restrict__ irow = index + (size_t)min(y, h - 1) * w;
-  int32_t* orow = out + (size_t)min(y, h - 1) * w;
-  int32_t left_v = 0, te1 = 0;       // out[y][x - 1], TE(x - 1, y)
+  const bool live = l < rows;
+  const bool publishes = band + 1 < nbands;  // then rows == kDeltaRows and the last row is lane kDeltaRows - 1
+  int32_t left_v = 0, te1 = 0;              // out[y][x - 1], TE(x - 1, y)
   uint32_t e1[4] = {0, 0, 0, 0}, e2[4] = {0, 0, 0, 0};  // E(x - 1, y), E(x - 2, y)
-  int32_t iq[8], eq[8];
-  {
-    const int s0 = 3 * l;
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-      iq[k] = eq[k] = 0;
-#pragma unroll
-      for (int j = 0; j < 8; j++)
-        if (((s0 + j) & 7) == k && l < rows && j < w) {
-          iq[k] = irow[j];
-          eq[k] = orow[j];
-        }
-    }
-  }
   const int nsteps = w + 3 * (rows - 1);
+  const int nchunks = (nsteps + C - 1) / C;
   const int prod_steps = w + 3 * (kDeltaRows - 1);
   int avail = 0;
-  auto step = [&](const int s, auto slot_tag) {
-    constexpr int K = decltype(slot_tag)::value;
-    const int x = s - 3 * l;
-    if (l < rows && x >= 0 && x < w) {
-      const int32_t idx = iq[K];
-      const int32_t entry = eq[K];
-      if (x + 8 < w) {
-        iq[K] = irow[x + 8];
-        eq[K] = orow[x + 8];
-      }
-      auto T = [&](int xx) -> int32_t { return l > 0 ? s_ring[l - 1][xx & 7] : s_above[0][xx & 127]; };
-      auto TT = [&](int xx) -> int32_t { return l > 1 ? s_ring[l - 2][xx & 7] : s_above[l == 1 ? 0 : 1][xx & 127]; };
-      auto TEa = [&](int xx) -> int64_t {
-        return y > 0 ? (int64_t)(l > 0 ? s_te[l - 1][xx & 7] : s_above_te[xx & 127]) : 0;
-      };
-      auto Ea = [&](int k, int xx) -> uint32_t {
-        return y > 0 ? (l > 0 ? s_e[k][l - 1][xx & 7] : s_above_e[k][xx & 127]) : 0u;
-      };
-      // PredictionData::get_rows, modular/predict.rs:96-128
-      const int32_t left = x > 0 ? left_v : (y > 0 ? T(0) : 0);
-      const int32_t top = y > 0 ? T(x) : left;
-      const int32_t topleft = (x > 0 && y > 0) ? T(x - 1) : left;
-      const int32_t topright = (x + 1 < w && y > 0) ? T(x + 1) : top;
-      const int32_t toptop = y > 1 ? TT(x) : top;
-      const int pos_ne = x + 1 < w ? x + 1 : x, pos_nw = x > 0 ? x - 1 : 0;
-      // weights from the error sums (:340-377)
-      uint32_t wk[4];
+  static_assert(C == 32 && kDeltaRows == 256, "the mover mapping below assumes 32-column chunks and 256-row bands");
+  constexpr int NI = 32;
+  const int mcol = l & 31, mrow0 = l >> 5;
+  int32_t nq_i[NI], nq_e[NI];
+  auto fetch = [&](int k) {
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const uint32_t en = Ea(k, x) + (x > 0 ? e1[k] : 0u);
-        const uint32_t ene = pos_ne == x ? en : Ea(k, x + 1);
-        const uint32_t enw = pos_nw == x ? en : Ea(k, x - 1) + (x > 1 ? e2[k] : 0u);
-        const uint32_t err = en + ene + enw;
-        int shift = 63 - __clzll((unsigned long long)err + 1ull) - 5;
-        shift = shift < 0 ? 0 : shift;
-        wk[k] = 4u + ((P.w[k] * kWpDivLookup[err >> shift]) >> shift);
-      }
-      const int64_t te_w = x > 0 ? (int64_t)te1 : 0, te_n = TEa(x), te_nw = TEa(pos_nw), te_ne = TEa(pos_ne);
-      const int64_t sum_wn = te_n + te_w;
-      const int64_t n = (int64_t)top << 3, wv = (int64_t)left << 3, ne = (int64_t)topright << 3;
-      const int64_t nw = (int64_t)topleft << 3, nn = (int64_t)toptop << 3;
-      int64_t pk[4];
-      pk[0] = wv + ne - n;
-      pk[1] = n - (((sum_wn + te_ne) * (int64_t)P.p1c) >> 5);
-      pk[2] = wv - (((sum_wn + te_nw) * (int64_t)P.p2c) >> 5);
-      pk[3] = n - ((te_nw * (int64_t)P.p3c[0] + te_n * (int64_t)P.p3c[1] + te_ne * (int64_t)P.p3c[2] +
-                    (nn - n) * (int64_t)P.p3c[3] + (nw - wv) * (int64_t)P.p3c[4]) >> 5);
-      const int log_weight = 63 - __clzll((unsigned long long)wk[0] + wk[1] + wk[2] + wk[3]);
-      const int64_t w0s = (int64_t)(wk[0] >> (log_weight - 4)), w1s = (int64_t)(wk[1] >> (log_weight - 4));
-      const int64_t w2s = (int64_t)(wk[2] >> (log_weight - 4)), w3s = (int64_t)(wk[3] >> (log_weight - 4));
-      const int64_t weight_sum = w0s + w1s + w2s + w3s;
-      const int64_t sum = (weight_sum >> 1) - 1 + w0s * pk[0] + w1s * pk[1] + w2s * pk[2] + w3s * pk[3];
-      int64_t pred = (sum * (int64_t)kWpDivLookup[weight_sum - 1]) >> 24;
-      if (((te_n ^ te_w) | (te_n ^ te_nw)) <= 0) {
-        const int64_t mx = max(wv, max(ne, n)), mn = min(wv, min(ne, n));
-        pred = max(mn, min(mx, pred));
-      }
-      const int64_t wp_pred = (pred + 3) >> 3;
-      int32_t val = entry;
-      if (idx < num_deltas) {
-        val = (int32_t)(uint32_t)(uint64_t)(wp_pred + (int64_t)entry);
-        orow[x] = val;
-      }
-      // update_errors (:472-517)
-      const int64_t v = (int64_t)val << 3;
-      const int32_t te = (int32_t)(pred - v);
-      uint32_t e[4];
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const int64_t dd = pk[k] - v;
-        e[k] = (uint32_t)(((dd < 0 ? -dd : dd) + 3) >> 3);
-      }
-      s_ring[l][x & 7] = val;
-      s_te[l][x & 7] = te;
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        s_e[k][l][x & 7] = e[k];
-        e2[k] = e1[k];
-        e1[k] = e[k];
-      }
-      if (publishes_rows) {
-        wp_mine[x] = te;
-#pragma unroll
-        for (int k = 0; k < 4; k++) wp_mine[(size_t)(1 + k) * w + x] = (int32_t)e[k];
-      }
-      te1 = te;
-      left_v = val;
-    }
-    if (band + 1 < nbands && ((s + 1) % kDeltaPublish == 0 || s + 1 == nsteps)) {
-      __threadfence();
-      __syncthreads();
-      if (l == 0) __hip_atomic_store(&progress[band], s + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    for (int i = 0; i < NI; i++) {
+      const int r = mrow0 + 8 * i;
+      const int xi = min(max(k * C - 3 * r + mcol, 0), w - 1);
+      const size_t off = (size_t)min(y0 + r, h - 1) * w + xi;
+      nq_i[i] = index[off];
+      nq_e[i] = out[off];
     }
   };
-  for (int s8 = 0; s8 < nsteps; s8 += 8) {
-    if (band > 0 && (s8 & 63) == 0) {
-      const int lo = s8 == 0 ? 0 : s8 + 2, hi = min(w, s8 + 66);
+  auto stage = [&]() {
+#pragma unroll
+    for (int i = 0; i < NI; i++) {
+      s_idx[mrow0 + 8 * i][mcol] = nq_i[i];
+      s_ent[mrow0 + 8 * i][mcol] = nq_e[i];
+    }
+  };
+  auto flush = [&](int k) {
+#pragma unroll
+    for (int i = 0; i < NI; i++) {
+      const int r = mrow0 + 8 * i;
+      const int x = k * C - 3 * r + mcol;
+      if (r < rows && x >= 0 && x < w)
+        __hip_atomic_store(&out[(size_t)(y0 + r) * w + x], s_outc[r][mcol], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (publishes && l < 5 * C) {  // the last row's predictor state of this chunk: 5 rows x 32 columns
+      const int q = l >> 5, x = k * C - 3 * (kDeltaRows - 1) + mcol;
+      if (x >= 0 && x < w)
+        __hip_atomic_store(&wp_mine[(size_t)q * w + x], s_state[q][mcol], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+  fetch(0);
+  stage();
+  if (nchunks > 1) fetch(1);
+  __syncthreads();
+  for (int k = 0; k < nchunks; k++) {
+    const int s0 = k * C;
+    if (band > 0 && (s0 & 63) == 0) {
+      const int lo = s0 == 0 ? 0 : s0 + 3, hi = min(w, s0 + 67);  // lane 0 copies column s + 3 during step s
       if (lo < hi) {
         const int need = min(prod_steps, (hi - 1) + 3 * (kDeltaRows - 1) + 1);
         if (avail < need) {
@@ -516,14 +452,130 @@ __global__ __launch_bounds__(kDeltaRows) void k5_palette_wp(const int32_t* __res
         __syncthreads();
       }
     }
-    if (s8 + 0 < nsteps) step(s8 + 0, std::integral_constant<int, 0>{});
-    if (s8 + 1 < nsteps) step(s8 + 1, std::integral_constant<int, 1>{});
-    if (s8 + 2 < nsteps) step(s8 + 2, std::integral_constant<int, 2>{});
-    if (s8 + 3 < nsteps) step(s8 + 3, std::integral_constant<int, 3>{});
-    if (s8 + 4 < nsteps) step(s8 + 4, std::integral_constant<int, 4>{});
-    if (s8 + 5 < nsteps) step(s8 + 5, std::integral_constant<int, 5>{});
-    if (s8 + 6 < nsteps) step(s8 + 6, std::integral_constant<int, 6>{});
-    if (s8 + 7 < nsteps) step(s8 + 7, std::integral_constant<int, 7>{});
+    if (band > 0 && s0 == 0) {  // the rings' view of the row(s) above, for step 0: columns 0..2 / column 0
+      if (l < 3) {
+        s_ring[1][l] = s_above[0][l];
+        s_te[1][l] = s_above_te[l];
+#pragma unroll
+        for (int q = 0; q < 4; q++) s_e[q][1][l] = s_above_e[q][l];
+      }
+      if (l == 0) s_ring[0][0] = s_above[1][0];
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    const int send = min(C, nsteps - s0);
+    for (int j = 0; j < send; j++) {
+      const int s = s0 + j;
+      const int x = s - 3 * l;
+      const bool active = live && x >= 0 && x < w;
+      // one batch of LDS reads; what does not exist is read from valid addresses and discarded by the selects
+      const int32_t idx = s_idx[l][j];
+      const int32_t entry = s_ent[l][j];
+      const int cm = (x - 1) & 7, c0 = x & 7, cp = (x + 1) & 7;
+      const int32_t t_m1 = s_ring[l + 1][cm], t_0 = s_ring[l + 1][c0], t_p1 = s_ring[l + 1][cp], tt_0 = s_ring[l][c0];
+      const int32_t ta_m1 = s_te[l + 1][cm], ta_0 = s_te[l + 1][c0], ta_p1 = s_te[l + 1][cp];
+      uint32_t ea_m1[4], ea_0[4], ea_p1[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        ea_m1[q] = s_e[q][l + 1][cm];
+        ea_0[q] = s_e[q][l + 1][c0];
+        ea_p1[q] = s_e[q][l + 1][cp];
+      }
+      const bool has_top = y > 0;
+      // PredictionData::get_rows, modular/predict.rs:96-128
+      const int32_t left = x > 0 ? left_v : (has_top ? t_0 : 0);
+      const int32_t top = has_top ? t_0 : left;
+      const int32_t topleft = (x > 0 && has_top) ? t_m1 : left;
+      const int32_t topright = (x + 1 < w && has_top) ? t_p1 : top;
+      const int32_t toptop = y > 1 ? tt_0 : top;
+      const bool at_right = !(x + 1 < w), at_left = !(x > 0);  // pos_ne == x, pos_nw == x
+      // weights from the error sums (:340-377)
+      uint32_t wk[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const uint32_t en = (has_top ? ea_0[q] : 0u) + (x > 0 ? e1[q] : 0u);
+        const uint32_t ene = at_right ? en : (has_top ? ea_p1[q] : 0u);
+        const uint32_t enw = at_left ? en : (has_top ? ea_m1[q] : 0u) + (x > 1 ? e2[q] : 0u);
+        const uint32_t err = en + ene + enw;
+        int shift = 63 - __clzll((unsigned long long)err + 1ull) - 5;
+        shift = shift < 0 ? 0 : shift;
+        wk[q] = 4u + ((P.w[q] * kWpDivLookup[err >> shift]) >> shift);
+      }
+      const int64_t te_w = x > 0 ? (int64_t)te1 : 0;
+      const int64_t te_n = has_top ? (int64_t)ta_0 : 0;
+      const int64_t te_nw = has_top ? (int64_t)(at_left ? ta_0 : ta_m1) : 0;
+      const int64_t te_ne = has_top ? (int64_t)(at_right ? ta_0 : ta_p1) : 0;
+      const int64_t sum_wn = te_n + te_w;
+      const int64_t n = (int64_t)top << 3, wv = (int64_t)left << 3, ne = (int64_t)topright << 3;
+      const int64_t nw = (int64_t)topleft << 3, nn = (int64_t)toptop << 3;
+      int64_t pk[4];
+      pk[0] = wv + ne - n;
+      pk[1] = n - (((sum_wn + te_ne) * (int64_t)P.p1c) >> 5);
+      pk[2] = wv - (((sum_wn + te_nw) * (int64_t)P.p2c) >> 5);
+      pk[3] = n - ((te_nw * (int64_t)P.p3c[0] + te_n * (int64_t)P.p3c[1] + te_ne * (int64_t)P.p3c[2] +
+                    (nn - n) * (int64_t)P.p3c[3] + (nw - wv) * (int64_t)P.p3c[4]) >> 5);
+      const int log_weight = 63 - __clzll((unsigned long long)wk[0] + wk[1] + wk[2] + wk[3]);
+      const int64_t w0s = (int64_t)(wk[0] >> (log_weight - 4)), w1s = (int64_t)(wk[1] >> (log_weight - 4));
+      const int64_t w2s = (int64_t)(wk[2] >> (log_weight - 4)), w3s = (int64_t)(wk[3] >> (log_weight - 4));
+      const int64_t weight_sum = w0s + w1s + w2s + w3s;
+      const int64_t sum = (weight_sum >> 1) - 1 + w0s * pk[0] + w1s * pk[1] + w2s * pk[2] + w3s * pk[3];
+      int64_t pred = (sum * (int64_t)kWpDivLookup[(weight_sum - 1) & 63]) >> 24;
+      if (((te_n ^ te_w) | (te_n ^ te_nw)) <= 0) {
+        const int64_t mx = max(wv, max(ne, n)), mn = min(wv, min(ne, n));
+        pred = max(mn, min(mx, pred));
+      }
+      const int64_t wp_pred = (pred + 3) >> 3;
+      const int32_t val = idx < num_deltas ? (int32_t)(uint32_t)(uint64_t)(wp_pred + (int64_t)entry) : entry;
+      // update_errors (:472-517)
+      const int64_t v = (int64_t)val << 3;
+      const int32_t te = (int32_t)(pred - v);
+      uint32_t e[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int64_t dd = pk[q] - v;
+        e[q] = (uint32_t)(((dd < 0 ? -dd : dd) + 3) >> 3);
+      }
+      if (active) {
+        s_outc[l][j] = val;
+        s_ring[l + 2][c0] = val;
+        s_te[l + 2][c0] = te;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          s_e[q][l + 2][c0] = e[q];
+          e2[q] = e1[q];
+          e1[q] = e[q];
+        }
+        if (publishes && l == kDeltaRows - 1) {
+          s_state[0][j] = te;
+#pragma unroll
+          for (int q = 0; q < 4; q++) s_state[1 + q][j] = (int32_t)e[q];
+        }
+        te1 = te;
+        left_v = val;
+      }
+      if (band > 0 && l == 0) {  // the rows above, one step ahead (columns past the row's end are never selected)
+        const int ca = (s + 3) & 127, cr = (s + 3) & 7;
+        s_ring[1][cr] = s_above[0][ca];
+        s_te[1][cr] = s_above_te[ca];
+#pragma unroll
+        for (int q = 0; q < 4; q++) s_e[q][1][cr] = s_above_e[q][ca];
+        s_ring[0][(s + 1) & 7] = s_above[1][(s + 1) & 127];
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    if (publishes && k > 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's write-through stores of chunk k - 1 have landed
+      __syncthreads();
+      if (l == 0) __hip_atomic_store(&progress[band], s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    flush(k);
+    if (k + 1 < nchunks) stage();
+    if (k + 2 < nchunks) fetch(k + 2);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+  if (publishes) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (l == 0) __hip_atomic_store(&progress[band], nsteps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
