@@ -12,6 +12,7 @@ for cfg in "c2:--size 4096 --epf-iters 0" "c5:--size 16384 --mix all" "c5e3:--si
   timeout 600 python bench.py $args --no-cpu --no-e2e --no-active > gpurun_out/${TAG}_cfg_$name.json 2> gpurun_out/${TAG}_cfg_$name.err
 done
 timeout 600 python tools/bench_modular.py > gpurun_out/${TAG}_modular.json 2> gpurun_out/${TAG}_modular.err
+timeout 300 python tools/bench_delta_palette.py 1024x1024 8192x8192 > gpurun_out/${TAG}_delta_palette.txt 2>/dev/null
 python - <<PY
 import json,glob
 for f in sorted(glob.glob("gpurun_out/${TAG}_*.json")):
