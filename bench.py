@@ -194,16 +194,27 @@ def main():
                 swl.epf_map[:] = 0
             box = [jl.comm_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(box, src=0)
-            sctx = jxl_rs_amd.Context(local_rank, n_slots=1)
-            sctx.comm_init(box[0], rank, world)          # before frame_begin: it sizes the planes for the gather
-            sctx.frame_begin(synth.apply_opts(sctx.default_params(size, size), swl))
-            sctx.set_dequant_tables(swl.tables)
-            sctx.set_lf_quantized(*swl.lf_q)            # LF / maps / tables are replicated (20 MB)
-            sctx.set_hf_meta(swl.transform_map, swl.raw_quant, swl.epf_map, swl.ytox, swl.ytob)
-            _, _, row0, row1 = sctx.comm_band()
-            for g in range(row0 * swl.xgroups, row1 * swl.xgroups):   # only the own band's coefficient groups
-                sctx.submit_group(g, swl.coeffs[g])
-            sctx.slot_wait(0)
+            setup_error = None
+            try:
+                sctx = jxl_rs_amd.Context(local_rank, n_slots=1)
+                sctx.comm_init(box[0], rank, world)      # before frame_begin: it sizes the planes for the gather
+                sctx.frame_begin(synth.apply_opts(sctx.default_params(size, size), swl))
+                sctx.set_dequant_tables(swl.tables)
+                sctx.set_lf_quantized(*swl.lf_q)        # LF / maps / tables are replicated (20 MB)
+                sctx.set_hf_meta(swl.transform_map, swl.raw_quant, swl.epf_map, swl.ytox, swl.ytob)
+                _, _, row0, row1 = sctx.comm_band()
+                for g in range(row0 * swl.xgroups, row1 * swl.xgroups):   # only the own band's coefficient groups
+                    sctx.submit_group(g, swl.coeffs[g])
+                sctx.slot_wait(0)
+            except Exception as e:
+                setup_error = f"{type(e).__name__}: {e}"
+            # all ranks take the sharded leg or none does: a rank that failed to set up must not leave the others
+            # waiting in a collective
+            okf = torch.tensor([0 if setup_error else 1], dtype=torch.int32,
+                               device=f"cuda:{local_rank}" if torch.cuda.is_available() else "cpu")
+            dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+            if int(okf.item()) == 0:
+                raise RuntimeError(setup_error or "another rank failed to set up the sharded frame")
 
             def sstep():
                 sctx.frame_run_sharded()
