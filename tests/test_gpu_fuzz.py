@@ -231,7 +231,8 @@ def test_random_feature_combinations_bit_exact(ctx, oracle, kat, seed):
 @pytest.mark.parametrize("seed", range(24))
 def test_random_modular_ops_bit_exact(ctx, oracle, seed):
     """RCT (every op and permutation), Palette (explicit, implicit and delta entries), delta Palette with a random
-    predictor, one unsqueeze step in each direction and the Modular -> RGB8 bridge on random shapes and values"""
+    predictor and with the Weighted one, one unsqueeze step in each direction, the smooth unsqueeze kinds on a tile
+    and the Modular -> RGB8 bridge on random shapes and values"""
     rng = np.random.default_rng(7000 + seed)
     h, w = int(rng.integers(1, 200)), int(rng.integers(1, 300))
     lim = int(rng.choice([256, 4096, 1 << 20]))
@@ -259,6 +260,19 @@ def test_random_modular_ops_bit_exact(ctx, oracle, seed):
         avg = rng.integers(-lim, lim, size=((h + 1) // 2, w)).astype(np.int32)
         res = rng.integers(-lim // 4 - 1, lim // 4 + 1, size=(h // 2, w)).astype(np.int32)
         assert np.array_equal(ctx.unsqueeze(False, avg, res, w, h), oracle.unsqueeze_v(avg, res, h)), "unsqueeze v"
+    # the Weighted-predictor branch of the palette step, random header
+    hdr = [int(v) for v in rng.integers(0, 32, size=7)] + [int(v) for v in rng.integers(0, 16, size=4)]
+    assert np.array_equal(ctx.palette_delta_wp(idx2, pal, ncol - nd, nd, bit_depth, hdr),
+                          oracle.palette_delta_wp(idx2, pal, ncol - nd, nd, nb, bit_depth, hdr)), f"wp palette {hdr}"
+    # smooth (progressive-preview) unsqueeze, the three kinds, on a tile of the channel
+    for kind in (0, 1, 2):
+        ah, aw = ((h + 1) // 2 if kind != 0 else h), ((w + 1) // 2 if kind != 1 else w)
+        avg = rng.integers(-lim, lim, size=(ah, aw)).astype(np.int32)
+        x0 = 2 * int(rng.integers(0, max(1, w // 4)))
+        y0 = 2 * int(rng.integers(0, max(1, h // 4)))
+        tw, th = w - x0, h - y0
+        assert np.array_equal(ctx.smooth_unsqueeze(kind, avg, tw, th, x0, y0),
+                              oracle.smooth_unsqueeze(kind, avg, tw, th, x0, y0)), f"smooth unsqueeze kind={kind}"
     bits = int(rng.choice([1, 2, 4, 8]))
     mult = 255 // ((1 << bits) - 1)
     rgb = ctx.modular_to_rgb8(planes, mult, 255, 3)
