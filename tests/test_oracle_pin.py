@@ -565,3 +565,53 @@ def test_weighted_predictor_reproduces_flat_and_ramp_images(oracle):
     idx2[0, 0] = 1
     out2 = oracle.palette_delta_wp(idx2, pal2, 1, 1, 1, 8, hdr)
     assert out2[0, 0, 0] == 37 and (out2[0, 0, 1:] == 37).all()  # West-like extrapolation along the first row
+
+
+# ---------------------------------------------------------------- the unsqueeze step as the device computes it
+def _unsqueeze_step_d_state(avg, res, nx, d):
+    """numpy transcription of unsqueeze_step (jxl_rs_amd/csrc/k_modular.hip): the recurrence on d = prev - avg with the
+    sign of avg - next applied up front; wrapping i32 arithmetic as on the device"""
+    i32, u32 = np.int32, np.uint32
+    with np.errstate(over="ignore"):
+        b_c = (avg.astype(u32) - nx.astype(u32)).astype(i32)
+        sm = (b_c >> 31).astype(u32)
+        nsm = b_c.astype(u32) >> u32(31)
+        bc = (b_c.astype(u32) ^ sm) + nsm
+        k2, u, rs = bc + u32(2), bc << u32(1), res.astype(u32) + nsm
+        e = ((d.astype(u32) ^ sm) + nsm).astype(i32)
+        e3 = ((e.astype(np.int64) * 0x55555556) >> 32).astype(i32)
+        s = (e.astype(u32) + e3.astype(u32) + k2).astype(i32) >> 2
+        t1 = ((e.astype(u32) << u32(1)) + u32(1)).astype(i32)
+        x = np.maximum(np.minimum(np.minimum(s, t1), u.astype(i32)), 0)
+        diff = ((x.astype(u32) ^ sm) + rs).astype(i32)
+        h = (diff.astype(u32) + (diff >> 31).astype(u32) + u32(1)).astype(i32) >> 1
+        d2 = (b_c.astype(u32) - h.astype(u32)).astype(i32)
+        b = (avg.astype(u32) - h.astype(u32)).astype(i32)
+        a = (b.astype(u32) + diff.astype(u32)).astype(i32)
+    return a, b, d2
+
+
+@pytest.mark.parametrize("bits", [3, 9, 17, 24, 28])
+def test_unsqueeze_d_state_restatement_equals_the_reference_forms(oracle, bits):
+    """The device runs the squeeze recurrence in a restated form with half the dependent instructions.  It must equal
+    the reference's scalar i64 definition (= the oracle) wherever the reference is well defined, i.e. wherever its own
+    i32 SIMD form and its i64 scalar form agree: step operands below 2^29 (beyond that the two reference forms differ
+    from EACH OTHER on ~10 % of random inputs at 2^30 and ~40 % at 2^31, so there is nothing to be equal to).  Whole
+    lines are driven with inputs up to 2^28: the outputs of a step can exceed its inputs."""
+    rng = np.random.default_rng(bits)
+    lim = 1 << bits
+    h, w = 64, 257
+    avg = rng.integers(-lim, lim, size=(h, (w + 1) // 2), dtype=np.int64).astype(np.int32)
+    res = rng.integers(-lim, lim, size=(h, w // 2), dtype=np.int64).astype(np.int32)
+    avg[1::3, 1:] = avg[1::3, :-1] + rng.integers(-3, 4, size=avg[1::3, 1:].shape)  # near-flat runs: small tendencies
+    res[::2] = rng.integers(-4, 5, size=res[::2].shape)
+    out = np.zeros((h, w), np.int32)
+    d = np.zeros(h, np.int32)
+    nr = w // 2
+    for x in range(nr):
+        cur = avg[:, x]
+        nx = avg[:, x + 1] if x + 1 < avg.shape[1] else cur
+        a, b, d = _unsqueeze_step_d_state(cur, res[:, x], nx, d)
+        out[:, 2 * x], out[:, 2 * x + 1] = a, b
+    out[:, w - 1] = avg[:, nr]
+    assert np.array_equal(out, oracle.unsqueeze_h(avg, res, w))
