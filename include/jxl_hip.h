@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define JXLH_ABI_VERSION 4
+#define JXLH_ABI_VERSION 5
 #define JXLH_NUM_TRANSFORMS 27   /* HfTransformType::CARDINALITY, transform_map.rs:59-61 */
 #define JXLH_NUM_QUANT_TABLES 17 /* NUM_QUANT_TABLES, quantizer.rs:11 */
 #define JXLH_GROUP_DIM 256       /* GROUP_DIM, jxl/src/lib.rs:24-26 */

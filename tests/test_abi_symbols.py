@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
 def test_abi_version_and_tables():
     from jxl_rs_amd import lib, synth
     L = lib.load()
-    assert L.jxlh_abi_version() == 4
+    assert L.jxlh_abi_version() == 5
     for t in range(27):
         assert L.jxlh_covered_blocks_x(t) == synth.COVERED_X[t]
         assert L.jxlh_covered_blocks_y(t) == synth.COVERED_Y[t]
