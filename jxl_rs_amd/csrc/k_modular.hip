@@ -366,7 +366,11 @@ __global__ __launch_bounds__(kDeltaRows) void k5_palette_wp(const int32_t* __res
   __shared__ int32_t s_above_te[128];  // TE and E of row y0 - 1
   __shared__ uint32_t s_above_e[4][128];
   __shared__ int s_avail;
+  // the division table in LDS: from constant memory each lookup is a global load on the step's dependent path (two
+  // rounds per step, ~0.4 us each -- most of what this kernel's step cost over k5_palette_delta's)
+  __shared__ uint32_t s_div[64];
   const int c = blockIdx.x, band = blockIdx.y, nbands = gridDim.y, l = threadIdx.x;
+  if (l < 64) s_div[l] = kWpDivLookup[l];
   int32_t* out = out_base + (size_t)c * (size_t)w * h;
   int* progress = progress_base + (size_t)c * nbands;
   int32_t* wp_mine = wp_rows_base + ((size_t)c * nbands + band) * 5 * (size_t)w;        // written for the band below
@@ -498,7 +502,7 @@ __global__ __launch_bounds__(kDeltaRows) void k5_palette_wp(const int32_t* __res
         const uint32_t err = en + ene + enw;
         int shift = 63 - __clzll((unsigned long long)err + 1ull) - 5;
         shift = shift < 0 ? 0 : shift;
-        wk[q] = 4u + ((P.w[q] * kWpDivLookup[err >> shift]) >> shift);
+        wk[q] = 4u + ((P.w[q] * s_div[err >> shift]) >> shift);
       }
       const int64_t te_w = x > 0 ? (int64_t)te1 : 0;
       const int64_t te_n = has_top ? (int64_t)ta_0 : 0;
@@ -518,7 +522,7 @@ __global__ __launch_bounds__(kDeltaRows) void k5_palette_wp(const int32_t* __res
       const int64_t w2s = (int64_t)(wk[2] >> (log_weight - 4)), w3s = (int64_t)(wk[3] >> (log_weight - 4));
       const int64_t weight_sum = w0s + w1s + w2s + w3s;
       const int64_t sum = (weight_sum >> 1) - 1 + w0s * pk[0] + w1s * pk[1] + w2s * pk[2] + w3s * pk[3];
-      int64_t pred = (sum * (int64_t)kWpDivLookup[(weight_sum - 1) & 63]) >> 24;
+      int64_t pred = (sum * (int64_t)s_div[(weight_sum - 1) & 63]) >> 24;
       if (((te_n ^ te_w) | (te_n ^ te_nw)) <= 0) {
         const int64_t mx = max(wv, max(ne, n)), mn = min(wv, min(ne, n));
         pred = max(mn, min(mx, pred));
