@@ -978,6 +978,7 @@ __global__ __launch_bounds__(256) void k6_unsqueeze_tiled(const SqueezePlanes pl
   const int n_main = has_tail ? w : w - 1;  // steps whose next_avg = avg[i + 1] exists
   const int n_chunks = n_main / S;
   const bool chain = tid < 64;
+  if (chain) __builtin_amdgcn_s_setprio(3);  // the step time IS this wave's issue latency
   const int m = tid - 64;  // mover index 0..191
 
   // movers: chunk c of the inputs (next_avg = avg[i0 + 1 + k], res[i0 + k]) -> registers -> LDS, in two halves so that
@@ -1138,6 +1139,7 @@ __global__ __launch_bounds__(256) void k6_unsqueeze_rct(const SqueezePlanes pl, 
   const int n_main = has_tail ? w : w - 1;
   const int n_chunks = n_main / S;
   const bool chain = tid < 64;
+  if (chain) __builtin_amdgcn_s_setprio(3);  // the step time IS this wave's issue latency
   // Mover roles.  The scalar movers (m = 0..191) both load and store.  The vector movers are split, wave 1 loading and
   // waves 2..3 storing: a wave with loads and stores outstanding waits for the stores' acknowledgements whenever it
   // needs a loaded value (one in-order vmcnt), which with a handful of wide instructions per chunk is all it does.
