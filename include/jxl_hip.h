@@ -435,7 +435,8 @@ jxlh_status jxlh_modular_to_f32(jxlh_ctx* ctx, const int32_t* in, size_t n, uint
 jxlh_status jxlh_modular_xyb_to_f32(jxlh_ctx* ctx, const int32_t* y, const int32_t* x, const int32_t* b, size_t n,
                                     const float quant_factors[3], float* ox, float* oy, float* ob);
 /* do_hsqueeze_step / do_vsqueeze_step (squeeze.rs:456-481, :661-682), whole plane.
- * horizontal: avg is ceil(out_w/2) x h, res floor(out_w/2) x h; vertical likewise in y. */
+ * horizontal: avg is ceil(out_w/2) x h, res floor(out_w/2) x h; vertical likewise in y.  `out` may not overlap `avg` or
+ * `res` (lines are streamed: inputs are read ahead of the outputs being written). */
 jxlh_status jxlh_unsqueeze(jxlh_ctx* ctx, int32_t horizontal, const int32_t* avg, size_t avg_stride,
                            const int32_t* res, size_t res_stride, uint32_t out_w, uint32_t out_h,
                            int32_t* out, size_t out_stride);
