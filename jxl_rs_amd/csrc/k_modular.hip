@@ -1122,13 +1122,19 @@ __global__ __launch_bounds__(256) void k6_unsqueeze_tiled(const SqueezePlanes pl
 // lanes); 16 columns for the vertical one (48 lanes), so that the per-plane row segments the movers touch are whole
 // 64-byte sectors.  The remainder of a line (what k6_unsqueeze_tiled leaves to the chain lane's own stores) goes
 // through the tile as well, as a partial chunk.
-template <bool HORIZ, bool VEC>
-__global__ __launch_bounds__(256) void k6_unsqueeze_rct(const SqueezePlanes pl, uint32_t avg_lp, uint32_t avg_ep,
+// NCW = chain waves: 2 widens the vertical tile to 32 columns per plane (96 chain lanes in two waves), so that the
+// movers touch whole 128-byte lines of every plane row; vector movers only.
+template <bool HORIZ, bool VEC, int NCW = 1>
+__global__ __launch_bounds__(64 * (3 * NCW + 1)) void k6_unsqueeze_rct(const SqueezePlanes pl, uint32_t avg_lp, uint32_t avg_ep,
                                                         uint32_t res_lp, uint32_t res_ep, uint32_t out_lp,
                                                         uint32_t out_ep, int n_lines, int n_out, int op, int perm) {
-  constexpr int S = JXLH_SQT_S, PI = JXLH_SQT_PI, PO = JXLH_SQT_PO, NL = HORIZ ? 21 : 16, NM = 192;
-  constexpr int NIN = VEC ? 4 * ((S * 12 + 63) / 64) : (64 * S + NM - 1) / NM, NPIX = (NL * 2 * S + NM - 1) / NM;
-  constexpr int IN_ELEMS = HORIZ ? 64 * PI : 64 * S, OUT_ELEMS = HORIZ ? 64 * PO : 64 * 2 * S;
+  static_assert(NCW == 1 || (VEC && !HORIZ), "two chain waves: vertical step with the vector movers");
+  constexpr int S = JXLH_SQT_S, PI = JXLH_SQT_PI, PO = JXLH_SQT_PO, NL = HORIZ ? 21 : 16 * NCW, NM = 192;
+  constexpr int RP = 64 * NCW;   // tile rows (= chain lanes) of the vertical layout
+  constexpr int QN = NL / 4;     // 4-column quads per plane row (vector movers)
+  constexpr int NLW = NCW;       // loader waves of the vector movers (the wide tile has twice the slots)
+  constexpr int NIN = VEC ? 4 * ((S * 3 * QN + 64 * NLW - 1) / (64 * NLW)) : (64 * S + NM - 1) / NM, NPIX = (NL * 2 * S + NM - 1) / NM;
+  constexpr int IN_ELEMS = HORIZ ? 64 * PI : RP * S, OUT_ELEMS = HORIZ ? 64 * PO : RP * 2 * S;
   __shared__ __attribute__((aligned(16))) int32_t s_avg[2][IN_ELEMS];
   __shared__ __attribute__((aligned(16))) int32_t s_res[2][IN_ELEMS];
   __shared__ __attribute__((aligned(16))) int32_t s_out[2][OUT_ELEMS];
@@ -1138,14 +1144,15 @@ __global__ __launch_bounds__(256) void k6_unsqueeze_rct(const SqueezePlanes pl, 
   const bool has_tail = n_out & 1;
   const int n_main = has_tail ? w : w - 1;
   const int n_chunks = n_main / S;
-  const bool chain = tid < 64;
+  const bool chain = tid < 64 * NCW;
   if (chain) __builtin_amdgcn_s_setprio(3);  // the step time IS this wave's issue latency
-  // Mover roles.  The scalar movers (m = 0..191) both load and store.  The vector movers are split, wave 1 loading and
-  // waves 2..3 storing: a wave with loads and stores outstanding waits for the stores' acknowledgements whenever it
+  // Mover roles.  The scalar movers (m = 0..191) both load and store.  The vector movers are split, NCW waves loading
+  // and NCW + 1 waves storing: a wave with loads and stores outstanding waits for the stores' acknowledgements whenever it
   // needs a loaded value (one in-order vmcnt), which with a handful of wide instructions per chunk is all it does.
-  const bool loader = VEC ? (tid >= 64 && tid < 128) : !chain, storer = VEC ? tid >= 128 : !chain;
-  const int m = VEC ? (tid < 128 ? tid - 64 : tid - 128) : tid - 64;
-  constexpr int NML = VEC ? 64 : 192, NMS = VEC ? 128 : 192;
+  constexpr int MB = 64 * NCW;  // first mover thread
+  const bool loader = VEC ? (tid >= MB && tid < MB + 64 * NLW) : !chain, storer = VEC ? tid >= MB + 64 * NLW : !chain;
+  const int m = VEC ? (tid < MB + 64 * NLW ? tid - MB : tid - MB - 64 * NLW) : tid - 64;
+  constexpr int NML = VEC ? 64 * NLW : 192, NMS = VEC ? 64 * (NCW + 1) : 192;  // storer waves: 2 (3 for the wide tile)
   // perm: which output plane receives w0 / w1 / w2 (as k4_rct)
   int32_t *o0, *o1, *o2;
   switch (perm) {
@@ -1173,19 +1180,19 @@ __global__ __launch_bounds__(256) void k6_unsqueeze_rct(const SqueezePlanes pl, 
   };
   // tile position of (row r, element k): one line per row of PI / PO dwords for the horizontal step (the chain lane
   // reads its row with 128-bit accesses), one element row of 64 lanes for the vertical one
-  auto in_idx = [](int r, int k) { return HORIZ ? r * PI + k : k * 64 + r; };
-  auto out_idx = [](int r, int k) { return HORIZ ? r * PO + k : k * 64 + r; };
+  auto in_idx = [](int r, int k) { return HORIZ ? r * PI + k : k * RP + r; };
+  auto out_idx = [](int r, int k) { return HORIZ ? r * PO + k : k * RP + r; };
   // VEC (vertical step, 16-byte aligned planes, column count a multiple of 4): a mover slot is four columns of one
   // plane's element row -- 16 row segments of 64 bytes per wave instruction instead of three (or four, when storing),
   // which is what this step's throughput hangs on once three planes stream through every workgroup.  The register
   // arrays then hold int4 slots: (k, plane, quad) for the inputs, (k, quad) for the outputs.
   static_assert(!(VEC && HORIZ), "the vector movers are for the vertical step");
-  constexpr int NVIN = (S * 12 + NML - 1) / NML, NVOUT = (2 * S * 4 + NMS - 1) / NMS;
+  constexpr int NVIN = (S * 3 * QN + NML - 1) / NML, NVOUT = (2 * S * QN + NMS - 1) / NMS;
   auto fetch_chunk = [&](int c, int32_t(&va)[NIN], int32_t(&vr)[NIN]) {
     if constexpr (VEC) {
 #pragma unroll
       for (int j = 0; j < NVIN; j++) {
-        const int f = m + j * NML, k = f / 12, rem = f - k * 12, p = rem >> 2, qq = rem & 3;
+        const int f = m + j * NML, k = f / (3 * QN), rem = f - k * (3 * QN), p = rem / QN, qq = rem % QN;
         // slots past the tile (the last j) and quads past the last column read a valid address instead of being
         // predicated (a select between a load and a constant becomes a load through a selected POINTER, via scratch);
         // what they fetch is never staged / never stored
@@ -1215,9 +1222,9 @@ __global__ __launch_bounds__(256) void k6_unsqueeze_rct(const SqueezePlanes pl, 
     if constexpr (VEC) {
 #pragma unroll
       for (int j = 0; j < NVIN; j++) {
-        const int f = m + j * NML, k = f / 12, rem = f - k * 12, p = rem >> 2, qq = rem & 3;
-        if (f < S * 12) {
-          const int idx = k * 64 + p * NL + 4 * qq;
+        const int f = m + j * NML, k = f / (3 * QN), rem = f - k * (3 * QN), p = rem / QN, qq = rem % QN;
+        if (f < S * 3 * QN) {
+          const int idx = k * RP + p * NL + 4 * qq;
           *reinterpret_cast<int4*>(&s_avg[c & 1][idx]) = make_int4(va[4 * j], va[4 * j + 1], va[4 * j + 2], va[4 * j + 3]);
           *reinterpret_cast<int4*>(&s_res[c & 1][idx]) = make_int4(vr[4 * j], vr[4 * j + 1], vr[4 * j + 2], vr[4 * j + 3]);
         }
@@ -1254,11 +1261,11 @@ __global__ __launch_bounds__(256) void k6_unsqueeze_rct(const SqueezePlanes pl, 
     if constexpr (VEC) {
 #pragma unroll
       for (int j = 0; j < NVOUT; j++) {
-        const int f = m + j * NMS, k = f >> 2, qq = f & 3;
-        if (f < 2 * S * 4 && l0 + 4 * qq < n_lines && k < count) {
-          const int4 v0 = *reinterpret_cast<const int4*>(so + k * 64 + 4 * qq);
-          const int4 v1 = *reinterpret_cast<const int4*>(so + k * 64 + NL + 4 * qq);
-          const int4 v2 = *reinterpret_cast<const int4*>(so + k * 64 + 2 * NL + 4 * qq);
+        const int f = m + j * NMS, k = f / QN, qq = f % QN;
+        if (f < 2 * S * QN && l0 + 4 * qq < n_lines && k < count) {
+          const int4 v0 = *reinterpret_cast<const int4*>(so + k * RP + 4 * qq);
+          const int4 v1 = *reinterpret_cast<const int4*>(so + k * RP + NL + 4 * qq);
+          const int4 v2 = *reinterpret_cast<const int4*>(so + k * RP + 2 * NL + 4 * qq);
           int4 x, y, z;
           rct4(v0, v1, v2, x, y, z);
           const uint32_t off = (uint32_t)(2 * c * S + k) * out_ep + (uint32_t)(l0 + 4 * qq);
@@ -1330,8 +1337,8 @@ __global__ __launch_bounds__(256) void k6_unsqueeze_rct(const SqueezePlanes pl, 
       } else {
 #pragma unroll
         for (int k = 0; k < S; k++) {
-          xa[k] = ia[k * 64 + tid];
-          xr[k] = ir[k * 64 + tid];
+          xa[k] = ia[k * RP + tid];
+          xr[k] = ir[k * RP + tid];
         }
       }
 #pragma unroll
@@ -1343,10 +1350,10 @@ __global__ __launch_bounds__(256) void k6_unsqueeze_rct(const SqueezePlanes pl, 
         if constexpr (HORIZ) {
           *reinterpret_cast<int4*>(oa + tid * PO + 2 * k) = make_int4(a0, b0, a1, b1);
         } else {
-          oa[(2 * k) * 64 + tid] = a0;
-          oa[(2 * k + 1) * 64 + tid] = b0;
-          oa[(2 * k + 2) * 64 + tid] = a1;
-          oa[(2 * k + 3) * 64 + tid] = b1;
+          oa[(2 * k) * RP + tid] = a0;
+          oa[(2 * k + 1) * RP + tid] = b0;
+          oa[(2 * k + 2) * RP + tid] = a1;
+          oa[(2 * k + 3) * RP + tid] = b1;
         }
       }
     }
@@ -1456,7 +1463,12 @@ bool launch_unsqueeze_rct(hipStream_t s, int horizontal, const int32_t* const av
     bool vec = out_w % 4 == 0 && avg_stride % 4 == 0 && res_stride % 4 == 0 && out_stride % 4 == 0;
     for (int i = 0; i < 3; i++)
       vec = vec && ((uintptr_t)avg[i] % 16 == 0) && ((uintptr_t)res[i] % 16 == 0) && ((uintptr_t)out[i] % 16 == 0);
-    if (vec)
+    if (vec && out_w >= 4096 && out_w % 32 == 0) {
+      // wide planes: 32 columns per plane and workgroup (whole 128-byte lines), one workgroup per CU is enough
+      hipLaunchKernelGGL((k6_unsqueeze_rct<false, true, 2>), dim3((out_w + 31) / 32), dim3(448), 0, s, pl, 1u,
+                         (uint32_t)avg_stride, 1u, (uint32_t)res_stride, 1u, (uint32_t)out_stride, (int)out_w,
+                         (int)out_h, op, perm);
+    } else if (vec)
       hipLaunchKernelGGL((k6_unsqueeze_rct<false, true>), grid, dim3(256), 0, s, pl, 1u, (uint32_t)avg_stride, 1u,
                          (uint32_t)res_stride, 1u, (uint32_t)out_stride, (int)out_w, (int)out_h, op, perm);
     else

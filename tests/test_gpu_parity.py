@@ -756,7 +756,7 @@ def test_unsqueeze_long_lines_take_the_streamed_kernel(ctx, oracle, shape):
 
 
 @pytest.mark.parametrize("shape", [(1, 1), (1, 2), (3, 7), (4, 70), (16, 64), (21, 64), (22, 65), (32, 200), (50, 129),
-                                   (64, 130), (100, 257), (129, 321), (7, 1031)])
+                                   (64, 130), (100, 257), (129, 321), (7, 1031), (4096, 70), (4128, 33)])
 @pytest.mark.parametrize("op_perm", [(6, 0), (0, 0), (1, 3), (2, 1), (3, 5), (4, 2), (5, 4), (6, 5)])
 @pytest.mark.parametrize("horizontal,pad", [(True, (3, 5, 2)), (False, (3, 5, 2)), (False, (4, 8, 0))])
 def test_fused_unsqueeze_and_rct(ctx, oracle, shape, op_perm, horizontal, pad):
