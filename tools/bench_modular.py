@@ -99,6 +99,24 @@ def main():
                                                                     plan[-2][4][0].shape[1], last[3][0].shape[1], last[1], 6, 0),
            3 * 8.0 * n * n)
     results["unsqueeze_rct_last_step_x3"]["horizontal"] = bool(last[0])
+    # per-level times of the chain (each step alone, its inputs from the previous level's outputs)
+    levels = []
+    avg = cur
+    for i, (horizontal, ow, oh, res, outs) in enumerate(plan):
+        a_in = avg
+        fused = i == len(plan) - 1
+        if fused:
+            fn = lambda: ctx.unsqueeze_rct(horizontal, a_in, res, outs, ow, oh, a_in[0].shape[1], res[0].shape[1], ow, 6, 0)
+        else:
+            fn = lambda: ctx.unsqueeze_planes(horizontal, a_in, res, outs, ow, oh, a_in[0].shape[1], res[0].shape[1], ow)
+        fn(); ctx.sync()
+        ctx.timer_start()
+        for _ in range(3):
+            fn()
+        levels.append({"step": ("h" if horizontal else "v") + ("+rct" if fused else ""), "out": [ow, oh],
+                       "ms": round(ctx.timer_stop() / 3, 4)})
+        avg = outs
+    results["config4_levels"] = levels
     results["config4_chain_squeeze_rct"]["MP_per_s"] = round(n * n / results["config4_chain_squeeze_rct"]["ms"] / 1e3, 1)
     print(json.dumps({"size": n, "kernels": results}))
 
