@@ -449,6 +449,21 @@ jxlh_status jxlh_unsqueeze_planes(jxlh_ctx* ctx, int32_t horizontal, int32_t n_p
                                   size_t res_stride, uint32_t out_w, uint32_t out_h, int32_t* const out[],
                                   size_t out_stride);
 
+/* Several consecutive squeeze steps in one call: level i takes the previous level's output (the base planes for
+ * level 0) as its averages and levels[i].res as its residuals; only the last level's planes are written.  The first
+ * levels of a chain are tiny (default_squeeze, squeeze.rs:71-105, starts from <= 8 x 8): as separate launches they cost
+ * ~10 us each whatever their size, so up to 16 levels whose planes stay within 128 x 128 run as ONE launch with the
+ * planes in LDS; anything else is run level by level through context scratch (same result).  Device pointers only. */
+typedef struct jxlh_squeeze_level {
+  int32_t horizontal;
+  uint32_t out_w, out_h;
+  const int32_t* res[3]; /* floor(out_w/2) x out_h (horizontal) or out_w x floor(out_h/2); unused planes NULL */
+  size_t res_stride;
+} jxlh_squeeze_level;
+jxlh_status jxlh_unsqueeze_levels(jxlh_ctx* ctx, int32_t n_planes, int32_t n_levels, const jxlh_squeeze_level* levels,
+                                  const int32_t* const base[], size_t base_stride, uint32_t base_w, uint32_t base_h,
+                                  int32_t* const out[], size_t out_stride);
+
 /* A squeeze step of three channels followed by do_rct_step (rct.rs:118-157) on the same three channels, in one pass:
  * the shape the end of a colour image's inverse transform chain has (default_squeeze, squeeze.rs:71-105, finishes with
  * the full-size step -- vertical for square and tall images, horizontal for wide ones; the encoder applied the RCT

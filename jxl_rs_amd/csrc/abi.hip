@@ -1831,6 +1831,77 @@ jxlh_status jxlh_unsqueeze(jxlh_ctx* ctx, int32_t horizontal, const int32_t* avg
   return stage_out(ctx, out, (const int32_t*)ctx->hook_i[2].p, out_stride * out_h);
 }
 
+jxlh_status jxlh_unsqueeze_levels(jxlh_ctx* ctx, int32_t n_planes, int32_t n_levels, const jxlh_squeeze_level* levels,
+                                  const int32_t* const base[], size_t base_stride, uint32_t base_w, uint32_t base_h,
+                                  int32_t* const out[], size_t out_stride) {
+  if (!ctx || !levels || !base || !out || n_planes < 1 || n_planes > 3 || n_levels < 1 || n_levels > 64 || base_w == 0 ||
+      base_h == 0 || base_stride < base_w)
+    return JXLH_ERR_INVALID_ARGUMENT;
+  // geometry: every level doubles (up to the odd sample) the axis it squeezes
+  uint32_t cw = base_w, ch = base_h;
+  size_t max_plane = (size_t)base_w * base_h;
+  for (int i = 0; i < n_levels; i++) {
+    const jxlh_squeeze_level& lv = levels[i];
+    if (lv.out_w == 0 || lv.out_h == 0 || lv.out_w > (1u << 20) || lv.out_h > (1u << 20)) return JXLH_ERR_INVALID_ARGUMENT;
+    const uint32_t aw = lv.horizontal ? (lv.out_w + 1) / 2 : lv.out_w, ah = lv.horizontal ? lv.out_h : (lv.out_h + 1) / 2;
+    if (aw != cw || ah != ch) return JXLH_ERR_INVALID_ARGUMENT;
+    const uint32_t rw = lv.horizontal ? lv.out_w / 2 : lv.out_w, rh = lv.horizontal ? lv.out_h : lv.out_h / 2;
+    for (int p = 0; p < n_planes; p++)
+      if ((size_t)rw * rh > 0 && (!lv.res[p] || !is_device_ptr(lv.res[p]) || lv.res_stride < rw))
+        return JXLH_ERR_INVALID_ARGUMENT;
+    cw = lv.out_w;
+    ch = lv.out_h;
+    max_plane = std::max(max_plane, (size_t)cw * ch);
+  }
+  if (out_stride < cw) return JXLH_ERR_INVALID_ARGUMENT;
+  for (int p = 0; p < n_planes; p++)
+    if (!base[p] || !out[p] || !is_device_ptr(base[p]) || !is_device_ptr(out[p])) return JXLH_ERR_INVALID_ARGUMENT;
+  if (n_levels <= 16) {
+    int hz[16];
+    uint32_t ow[16], oh[16];
+    size_t rs[16];
+    const int32_t* rp[16 * 3];
+    for (int i = 0; i < n_levels; i++) {
+      hz[i] = levels[i].horizontal ? 1 : 0;
+      ow[i] = levels[i].out_w;
+      oh[i] = levels[i].out_h;
+      rs[i] = levels[i].res_stride;
+      for (int p = 0; p < 3; p++) rp[i * 3 + p] = p < n_planes && levels[i].res[p] ? levels[i].res[p] : base[0];
+    }
+    ScopedKernelTimer t(ctx, "k6_unsqueeze_levels");
+    if (launch_unsqueeze_levels(ctx->stream, n_planes, n_levels, hz, ow, oh, rp, rs, base, base_stride, base_w, base_h,
+                                out, out_stride)) {
+      HIPCHK(ctx, hipGetLastError());
+      return JXLH_OK;
+    }
+  }
+  // level by level, intermediate planes in context scratch (two sets of n_planes planes, swapped per level)
+  jxlh_status st;
+  if ((st = ensure(ctx, ctx->hook_i[0], max_plane * n_planes))) return st;
+  if ((st = ensure(ctx, ctx->hook_i[1], max_plane * n_planes))) return st;
+  const int32_t* cur[3];
+  size_t cur_stride = base_stride;
+  for (int p = 0; p < n_planes; p++) cur[p] = base[p];
+  ScopedKernelTimer t(ctx, "k6_unsqueeze_levels_stepwise");
+  for (int i = 0; i < n_levels; i++) {
+    const jxlh_squeeze_level& lv = levels[i];
+    const bool last = i == n_levels - 1;
+    int32_t* dst[3];
+    const int32_t* rv[3];
+    const size_t dst_stride = last ? out_stride : lv.out_w;
+    for (int p = 0; p < n_planes; p++) {
+      dst[p] = last ? out[p] : ctx->hook_i[i & 1].p + (size_t)p * max_plane;
+      rv[p] = lv.res[p] ? lv.res[p] : cur[p];
+    }
+    launch_unsqueeze(ctx->stream, lv.horizontal ? 1 : 0, n_planes, cur, cur_stride, rv, lv.res_stride, lv.out_w, lv.out_h,
+                     dst, dst_stride);
+    for (int p = 0; p < n_planes; p++) cur[p] = dst[p];
+    cur_stride = dst_stride;
+  }
+  HIPCHK(ctx, hipGetLastError());
+  return JXLH_OK;
+}
+
 jxlh_status jxlh_unsqueeze_rct(jxlh_ctx* ctx, int32_t horizontal, const int32_t* const avg[3], size_t avg_stride,
                                const int32_t* const res[3], size_t res_stride, uint32_t out_w, uint32_t out_h,
                                int32_t* const out[3], size_t out_stride, int32_t op, int32_t perm) {

@@ -245,6 +245,12 @@ void launch_unsqueeze(hipStream_t s, int horizontal, int n_planes, const int32_t
 bool launch_unsqueeze_rct(hipStream_t s, int horizontal, const int32_t* const avg[3], size_t avg_stride,
                           const int32_t* const res[3], size_t res_stride, uint32_t out_w, uint32_t out_h,
                           int32_t* const out[3], size_t out_stride, int op, int perm);
+// several consecutive squeeze steps of small planes (all sides <= 128) in one launch; res[i * 3 + p] = residual plane
+// of level i, plane p.  false = the chain does not qualify, nothing launched
+bool launch_unsqueeze_levels(hipStream_t s, int n_planes, int n_levels, const int* horizontal, const uint32_t* out_w,
+                             const uint32_t* out_h, const int32_t* const* res, const size_t* res_stride,
+                             const int32_t* const base[], size_t base_stride, uint32_t base_w, uint32_t base_h,
+                             int32_t* const out[], size_t out_stride);
 // smooth_{h,v,2d}_unsqueeze on a rectangle of the output channel; `in` is the whole average channel
 void launch_smooth_unsqueeze(hipStream_t s, int kind, const int32_t* in, size_t in_stride, int in_w, int in_h, int x0,
                              int y0, int32_t* out, size_t out_stride, int out_w, int out_h);

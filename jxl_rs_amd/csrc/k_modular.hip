@@ -1478,6 +1478,184 @@ bool launch_unsqueeze_rct(hipStream_t s, int horizontal, const int32_t* const av
   return true;
 }
 
+// The first levels of a squeeze chain are tiny (8x8 -> 16x8 -> 16x16 -> ... ) and each one, as its own launch, costs
+// ~10 us however few steps it has: the eight levels up to 128 x 128 of the default chain took 83 us for 240 steps.
+// Here one workgroup per plane walks ALL of them: the running average plane lives in LDS (two buffers swapped per
+// level), a level's residual plane is staged through LDS with coalesced loads, lanes = lines, and only the last level
+// is written out.
+#define JXLH_SQL_MAX 128                 // largest plane side handled in LDS
+#define JXLH_SQL_LEVELS 16
+struct SqueezeLevels {
+  int n_levels;
+  int base_w, base_h;
+  uint32_t base_stride, out_stride;
+  const int32_t* base[3];
+  int32_t* out[3];
+  struct {
+    int horizontal, out_w, out_h;
+    uint32_t res_stride;
+    const int32_t* res[3];
+  } lv[JXLH_SQL_LEVELS];
+};
+__global__ __launch_bounds__(256) void k6_unsqueeze_levels(const SqueezeLevels L) {
+  // Two plane buffers, swapped per level.  A level's output is twice its input, so only the buffer the LAST level
+  // writes has to hold a full 128 x 128 plane; the other one (and the residual tile) hold half planes.  Row pitch =
+  // width | 1 (odd: lane = row and lane = column are both conflict-free).
+  constexpr int kFull = JXLH_SQL_MAX * (JXLH_SQL_MAX + 1), kHalf = JXLH_SQL_MAX * (JXLH_SQL_MAX / 2 + 1);
+  __shared__ int32_t s_big[kFull], s_half[kHalf], s_r[kHalf];
+  const int tid = threadIdx.x, pl = blockIdx.x;
+  // level i reads buf[(i + off) & 1] and writes the other one; the last level must write s_big (index 0)
+  const int off = L.n_levels & 1;
+  auto buf = [&](int k) { return (k & 1) ? s_half : s_big; };
+  int cw = L.base_w, ch = L.base_h;
+  // plane <-> thread mapping without divisions: tx = tid % TW, TW = the power of two >= the plane's width, 256 / TW
+  // rows per pass (uniform per level); at most 64 passes for a 128-row plane
+  auto tile_log2 = [](int width) { return width <= 1 ? 0 : 32 - __builtin_clz((unsigned)(width - 1)); };
+  {
+    int32_t* b0 = buf(off);
+    const int pc = cw | 1, lg = tile_log2(cw), tx = tid & ((1 << lg) - 1), ty = tid >> lg, rpp = 256 >> lg;
+    for (int y = ty; y < ch; y += rpp)
+      if (tx < cw) b0[y * pc + tx] = L.base[pl][(size_t)y * L.base_stride + tx];
+  }
+  // a level's residuals are fetched into registers (coalesced, <= 33 per thread) while the PREVIOUS level's recurrence
+  // runs, and dropped into the LDS tile at the level's start: the global round trip is off the serial path
+  constexpr int kResPasses = 64;
+  int32_t rq[kResPasses];
+  auto fetch_res = [&](int lv) {
+    const int horizontal = L.lv[lv].horizontal, ow = L.lv[lv].out_w, oh = L.lv[lv].out_h;
+    const int rw = horizontal ? ow / 2 : ow, rh = horizontal ? oh : oh / 2;
+    const int32_t* __restrict__ res = L.lv[lv].res[pl];
+    const uint32_t rstride = L.lv[lv].res_stride;
+    const int lg = tile_log2(rw), tx = tid & ((1 << lg) - 1), ty = tid >> lg, rpp = 256 >> lg;
+    const int txc = min(tx, max(rw - 1, 0));
+#pragma unroll
+    for (int j = 0; j < kResPasses; j++) {
+      const int y = ty + j * rpp;
+      if (j * rpp >= rh) break;  // uniform
+      rq[j] = res[(size_t)min(y, rh - 1) * rstride + txc];  // past the plane: a valid sample, never staged
+    }
+  };
+  fetch_res(0);
+  for (int lv = 0; lv < L.n_levels; lv++) {
+    const int horizontal = L.lv[lv].horizontal, ow = L.lv[lv].out_w, oh = L.lv[lv].out_h;
+    const int rw = horizontal ? ow / 2 : ow, rh = horizontal ? oh : oh / 2;
+    const int pc = cw | 1, po = ow | 1, pr = rw | 1;
+    {
+      const int lg = tile_log2(rw), tx = tid & ((1 << lg) - 1), ty = tid >> lg, rpp = 256 >> lg;
+#pragma unroll
+      for (int j = 0; j < kResPasses; j++) {
+        const int y = ty + j * rpp;
+        if (j * rpp >= rh) break;  // uniform
+        if (tx < rw && y < rh) s_r[y * pr + tx] = rq[j];
+      }
+    }
+    __syncthreads();
+    if (lv + 1 < L.n_levels) fetch_res(lv + 1);
+    const int32_t* cur_buf = buf(lv + off);
+    int32_t* nxt_buf = buf(lv + off + 1);
+    const int n_lines = horizontal ? oh : ow, n_out = horizontal ? ow : oh;
+    if (tid < n_lines) {
+      // element i of line `tid`: horizontal = row tid, vertical = column tid
+      const int32_t* a = cur_buf + (horizontal ? tid * pc : tid);
+      const int32_t* r = s_r + (horizontal ? tid * pr : tid);
+      int32_t* o = nxt_buf + (horizontal ? tid * po : tid);
+      const int aep = horizontal ? 1 : pc, rep = horizontal ? 1 : pr, oep = horizontal ? 1 : po;
+      const int w = n_out / 2;
+      if (w == 0) {
+        o[0] = a[0];
+      } else {
+        const bool has_tail = n_out & 1;
+        const int n_main = has_tail ? w : w - 1;
+        int32_t c0 = a[0], d = 0;
+        int i = 0;
+        for (; i + 4 <= n_main; i += 4) {  // operands of four steps in one LDS round trip
+          int32_t nx[4], rr[4], va[4], vb[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            nx[k] = a[(i + k + 1) * aep];
+            rr[k] = r[(i + k) * rep];
+          }
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            unsqueeze_step(c0, rr[k], nx[k], d, va[k], vb[k]);
+            c0 = nx[k];
+          }
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            o[(2 * (i + k)) * oep] = va[k];
+            o[(2 * (i + k) + 1) * oep] = vb[k];
+          }
+        }
+        for (; i < n_main; i++) {
+          const int32_t nx = a[(i + 1) * aep];
+          int32_t va, vb;
+          unsqueeze_step(c0, r[i * rep], nx, d, va, vb);
+          o[(2 * i) * oep] = va;
+          o[(2 * i + 1) * oep] = vb;
+          c0 = nx;
+        }
+        if (!has_tail) {
+          int32_t va, vb;
+          unsqueeze_step(c0, r[(w - 1) * rep], c0, d, va, vb);
+          o[(2 * w - 2) * oep] = va;
+          o[(2 * w - 1) * oep] = vb;
+        } else {
+          o[(2 * w) * oep] = c0;
+        }
+      }
+    }
+    __syncthreads();
+    cw = ow;
+    ch = oh;
+  }
+  {
+    const int32_t* fin = buf(L.n_levels + off);  // = s_big
+    const int pc = cw | 1, lg = tile_log2(cw), tx = tid & ((1 << lg) - 1), ty = tid >> lg, rpp = 256 >> lg;
+    for (int y = ty; y < ch; y += rpp)
+      if (tx < cw) L.out[pl][(size_t)y * L.out_stride + tx] = fin[y * pc + tx];
+  }
+}
+
+// n_levels <= 16 levels, every plane side <= 128: one launch.  Returns false when the chain does not qualify.
+bool launch_unsqueeze_levels(hipStream_t s, int n_planes, int n_levels, const int* horizontal, const uint32_t* out_w,
+                             const uint32_t* out_h, const int32_t* const* res, const size_t* res_stride,
+                             const int32_t* const base[], size_t base_stride, uint32_t base_w, uint32_t base_h,
+                             int32_t* const out[], size_t out_stride) {
+  if (n_levels < 1 || n_levels > JXLH_SQL_LEVELS || n_planes < 1 || n_planes > 3) return false;
+  if (base_w == 0 || base_h == 0 || base_w > JXLH_SQL_MAX || base_h > JXLH_SQL_MAX) return false;
+  SqueezeLevels L{};
+  L.n_levels = n_levels;
+  L.base_w = (int)base_w;
+  L.base_h = (int)base_h;
+  L.base_stride = (uint32_t)base_stride;
+  L.out_stride = (uint32_t)out_stride;
+  for (int p = 0; p < n_planes; p++) {
+    L.base[p] = base[p];
+    L.out[p] = out[p];
+  }
+  for (int i = 0; i < n_levels; i++) {
+    if (out_w[i] == 0 || out_h[i] == 0 || out_w[i] > JXLH_SQL_MAX || out_h[i] > JXLH_SQL_MAX) return false;
+    L.lv[i].horizontal = horizontal[i];
+    L.lv[i].out_w = (int)out_w[i];
+    L.lv[i].out_h = (int)out_h[i];
+    L.lv[i].res_stride = (uint32_t)res_stride[i];
+    for (int p = 0; p < n_planes; p++) L.lv[i].res[p] = res[i * 3 + p];
+  }
+  // every plane written to the half-size buffer (the base when n_levels is odd, and every second level counted from
+  // the end) must fit it: rows * (width | 1) <= 128 * 65
+  const size_t half_cap = (size_t)JXLH_SQL_MAX * (JXLH_SQL_MAX / 2 + 1);
+  auto fits_half = [&](uint32_t pw, uint32_t ph) { return (size_t)ph * (pw | 1u) <= half_cap; };
+  if ((n_levels & 1) && !fits_half(base_w, base_h)) return false;
+  for (int i = n_levels - 2; i >= 0; i -= 2)
+    if (!fits_half(out_w[i], out_h[i])) return false;
+  for (int i = 0; i < n_levels; i++) {  // the residual tile has the same capacity
+    const uint32_t rw = horizontal[i] ? out_w[i] / 2 : out_w[i], rh = horizontal[i] ? out_h[i] : out_h[i] / 2;
+    if (rw && rh && !fits_half(rw, rh)) return false;
+  }
+  hipLaunchKernelGGL(k6_unsqueeze_levels, dim3(n_planes), dim3(256), 0, s, L);
+  return true;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Smooth unsqueeze: what a squeeze step runs while its residual channel has not arrived (progressive previews;
 // transforms/step.rs:138-150 picks the kind, :841-851 dispatches): smooth_h / smooth_v / smooth_2d_unsqueeze

@@ -43,7 +43,7 @@ ABI_SYMBOLS = [
     "jxlh_stage_gaborish",
     "jxlh_stage_epf", "jxlh_stage_lf_smooth", "jxlh_stage_transform_to_pixels", "jxlh_rct", "jxlh_palette", "jxlh_palette_delta", "jxlh_modular_to_rgb8",
     "jxlh_modular_to_f32", "jxlh_modular_xyb_to_f32",
-    "jxlh_unsqueeze", "jxlh_unsqueeze_planes", "jxlh_smooth_unsqueeze", "jxlh_unsqueeze_rct", "jxlh_palette_delta_wp", "jxlh_abi_version", "jxlh_covered_blocks_x", "jxlh_covered_blocks_y",
+    "jxlh_unsqueeze", "jxlh_unsqueeze_planes", "jxlh_smooth_unsqueeze", "jxlh_unsqueeze_rct", "jxlh_palette_delta_wp", "jxlh_unsqueeze_levels", "jxlh_abi_version", "jxlh_covered_blocks_x", "jxlh_covered_blocks_y",
     "jxlh_quant_table_for_type", "jxlh_quant_table_size",
     "jxlh_comm_unique_id", "jxlh_comm_init", "jxlh_comm_init_local", "jxlh_comm_destroy", "jxlh_comm_band",
     "jxlh_frame_run_sharded", "jxlh_frame_allgather", "jxlh_frames_run_sharded_local", "jxlh_frames_allgather_local",
@@ -163,6 +163,7 @@ def load():
     L.jxlh_rct.argtypes = [vp, vp, vp, vp, sz, i32, i32]
     L.jxlh_palette.argtypes = [vp, vp, sz, vp, i32, sz, i32, i32, vp]
     L.jxlh_palette_delta.argtypes = [vp, vp, u32, u32, vp, i32, i32, sz, i32, i32, i32, vp]
+    L.jxlh_unsqueeze_levels.argtypes = [vp, i32, i32, vp, C.POINTER(vp), sz, u32, u32, C.POINTER(vp), sz]
     L.jxlh_palette_delta_wp.argtypes = [vp, vp, u32, u32, vp, i32, i32, sz, i32, i32, vp, vp]
     L.jxlh_modular_to_rgb8.argtypes = [vp, C.POINTER(vp), sz, u32, u32, i32, i32, u32, vp, sz]
     L.jxlh_modular_to_f32.argtypes = [vp, vp, sz, u32, vp]
@@ -242,6 +243,11 @@ def _addr(a):
     if hasattr(a, "data_ptr"):  # torch tensor (device memory plumbing only)
         return C.c_void_p(a.data_ptr())
     return C.c_void_p(a.ctypes.data)
+
+
+class SqueezeLevel(C.Structure):  # jxlh_squeeze_level
+    _fields_ = [("horizontal", C.c_int32), ("out_w", C.c_uint32), ("out_h", C.c_uint32), ("res", C.c_void_p * 3),
+                ("res_stride", C.c_size_t)]
 
 
 class Context:
@@ -694,6 +700,22 @@ class Context:
         ov = (C.c_void_p * n)(*[_addr(a).value for a in out])
         self._chk(self.L.jxlh_unsqueeze_planes(self._ctx, 1 if horizontal else 0, n, av, avg_stride, rv, res_stride,
                                                out_w, out_h, ov, out_stride), "unsqueeze_planes")
+
+    def unsqueeze_levels(self, levels, base, base_stride, base_w, base_h, out, out_stride):
+        """Several squeeze steps in one call (device-resident): levels = [(horizontal, out_w, out_h, [res planes],
+        res_stride)], base / out = lists of n_planes device pointers."""
+        n_planes = len(base)
+        arr = (SqueezeLevel * len(levels))()
+        for i, (hz, ow, oh, res, rstride) in enumerate(levels):
+            arr[i].horizontal = 1 if hz else 0
+            arr[i].out_w, arr[i].out_h = ow, oh
+            for p in range(3):
+                arr[i].res[p] = _addr(res[p]).value if p < n_planes and res[p] is not None else None
+            arr[i].res_stride = rstride
+        bv = (C.c_void_p * n_planes)(*[_addr(a).value for a in base])
+        ov = (C.c_void_p * n_planes)(*[_addr(a).value for a in out])
+        self._chk(self.L.jxlh_unsqueeze_levels(self._ctx, n_planes, len(levels), C.cast(arr, C.c_void_p), bv, base_stride,
+                                               base_w, base_h, ov, out_stride), "unsqueeze_levels")
 
     def unsqueeze_rct(self, horizontal, avg, res, out, out_w, out_h, avg_stride, res_stride, out_stride, op, perm):
         """Unsqueeze of three device-resident planes fused with the inverse RCT on them."""

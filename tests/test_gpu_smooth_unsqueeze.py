@@ -125,3 +125,56 @@ def test_progressive_preview_of_a_squeezed_channel(ctx, oracle):
     assert np.array_equal(prev1d, oracle.smooth_unsqueeze(H, a1_back, n, n))
     assert np.abs(prev1d - img).mean() < np.abs(prev2d - img).mean()
     assert np.array_equal(ctx.unsqueeze(True, a1_back, r1, n, n), img)
+
+
+# ---------------------------------------------------------------- several squeeze levels in one call
+@pytest.mark.parametrize("size", [(9, 13), (16, 8), (100, 77), (128, 128), (64, 128), (127, 65), (300, 200), (1000, 130)])
+@pytest.mark.parametrize("nchan", [1, 3])
+def test_unsqueeze_levels_equals_the_steps_one_by_one(ctx, oracle, size, nchan):
+    """jxlh_unsqueeze_levels on the default squeeze chain of a w x h image (squeeze.rs:71-105): planes up to 128 x 128
+    run as one launch with the planes in LDS, larger chains level by level through scratch -- either way the result
+    is the oracle's step-by-step one.  Residual planes have padded strides."""
+    from jxl_rs_amd import synth
+    w, h = size
+    base, residuals, steps = synth.make_modular_planes(w, h, seed=w * 131 + h, nchan=nchan)
+    bh, bw = base[0].shape
+    want = [b.copy() for b in base]
+    for (horizontal, ow, oh), res in zip(steps, residuals):
+        want = [oracle.unsqueeze_h(want[c], res[c], ow) if horizontal else oracle.unsqueeze_v(want[c], res[c], oh)
+                for c in range(nchan)]
+    if not steps:
+        pytest.skip("no squeeze level at this size")
+    dev_base = [DeviceArray(b) for b in base]
+    levels, keep = [], []
+    for (horizontal, ow, oh), res in zip(steps, residuals):
+        rstride = max(res[0].shape[1], 1) + 3
+        planes = []
+        for c in range(nchan):
+            padded = np.zeros((max(res[c].shape[0], 1), rstride), np.int32)
+            padded[:res[c].shape[0], :res[c].shape[1]] = res[c]
+            d = DeviceArray(padded)
+            keep.append(d)
+            planes.append(d.ptr)
+        levels.append((horizontal, ow, oh, planes + [None] * (3 - nchan), rstride))
+    o_stride = w + 5
+    dev_out = [DeviceArray(np.full((h, o_stride), -9, np.int32)) for _ in range(nchan)]
+    ctx.unsqueeze_levels(levels, [d.ptr for d in dev_base], bw, bw, bh, [d.ptr for d in dev_out], o_stride)
+    ctx.sync()
+    for c in range(nchan):
+        got = dev_out[c].download(np.int32, h * o_stride).reshape(h, o_stride)
+        assert np.array_equal(got[:, :w], want[c]), (c, np.argwhere(got[:, :w] != want[c])[:4])
+        assert (got[:, w:] == -9).all()
+    for d in dev_base + dev_out + keep:
+        d.free()
+
+
+def test_unsqueeze_levels_rejects_inconsistent_geometry(ctx):
+    from jxl_rs_amd import lib, JxlHipError
+    base = DeviceArray(np.zeros((8, 8), np.int32))
+    res = DeviceArray(np.zeros((8, 8), np.int32))
+    out = DeviceArray(np.zeros((8, 32), np.int32))
+    with pytest.raises(JxlHipError) as e:   # 8 x 8 averages cannot produce a 32-wide level
+        ctx.unsqueeze_levels([(True, 32, 8, [res.ptr, None, None], 8)], [base.ptr], 8, 8, 8, [out.ptr], 32)
+    assert e.value.status == lib.ERR_INVALID_ARGUMENT
+    for d in (base, res, out):
+        d.free()

@@ -90,10 +90,34 @@ def main():
         horizontal, ow, oh, res, outs = plan[-1]
         ctx.unsqueeze_rct(horizontal, avg, res, outs, ow, oh, avg[0].shape[1], res[0].shape[1], ow, 6, 0)
 
+    n_small = sum(1 for _, ow, oh, _, _ in plan if ow <= 128 and oh <= 128)   # the levels that fit one LDS launch
+
+    def chain_levels():
+        small = [(hz, ow, oh, res, res[0].shape[1]) for hz, ow, oh, res, _ in plan[:n_small]]
+        ctx.unsqueeze_levels(small, cur, cur_w, cur_w, cur_h, plan[n_small - 1][4], plan[n_small - 1][1])
+        avg = plan[n_small - 1][4]
+        for horizontal, ow, oh, res, outs in plan[n_small:-1]:
+            ctx.unsqueeze_planes(horizontal, avg, res, outs, ow, oh, avg[0].shape[1], res[0].shape[1], ow)
+            avg = outs
+        horizontal, ow, oh, res, outs = plan[-1]
+        ctx.unsqueeze_rct(horizontal, avg, res, outs, ow, oh, avg[0].shape[1], res[0].shape[1], ow, 6, 0)
+
     samples = sum(ow * oh for _, ow, oh, _, _ in plan) * 3
     timeit("config4_chain_squeeze_rct", chain, 8.0 * samples + 24.0 * n * n, reps=3)
     results["config4_chain_squeeze_rct"]["steps"] = len(plan)
     timeit("config4_chain_fused_last_step", chain_fused, 8.0 * samples + 0.0, reps=3)
+    small = [(hz, ow, oh, res, res[0].shape[1]) for hz, ow, oh, res, _ in plan[:n_small]]
+    timeit("config4_small_levels_one_launch", lambda: ctx.unsqueeze_levels(small, cur, cur_w, cur_w, cur_h, plan[n_small - 1][4],
+                                                                             plan[n_small - 1][1]), 1.0, reps=5)
+
+    def small_stepwise():
+        avg = cur
+        for horizontal, ow, oh, res, outs in plan[:n_small]:
+            ctx.unsqueeze_planes(horizontal, avg, res, outs, ow, oh, avg[0].shape[1], res[0].shape[1], ow)
+            avg = outs
+    timeit("config4_small_levels_stepwise", small_stepwise, 1.0, reps=5)
+    timeit("config4_chain_levels_fused_last_step", chain_levels, 8.0 * samples + 0.0, reps=3)
+    results["config4_chain_levels_fused_last_step"]["levels_in_one_launch"] = n_small
     last = plan[-1]
     timeit("unsqueeze_rct_last_step_x3", lambda: ctx.unsqueeze_rct(last[0], plan[-2][4], last[3], last[4], last[1], last[2],
                                                                     plan[-2][4][0].shape[1], last[3][0].shape[1], last[1], 6, 0),
