@@ -1524,10 +1524,11 @@ __global__ __launch_bounds__(256) void k6_unsqueeze_levels(const SqueezeLevels L
   auto fetch_res = [&](int lv) {
     const int horizontal = L.lv[lv].horizontal, ow = L.lv[lv].out_w, oh = L.lv[lv].out_h;
     const int rw = horizontal ? ow / 2 : ow, rh = horizontal ? oh : oh / 2;
+    if (rw == 0 || rh == 0) return;  // a one-sample axis has no residuals (and no plane to read)
     const int32_t* __restrict__ res = L.lv[lv].res[pl];
     const uint32_t rstride = L.lv[lv].res_stride;
     const int lg = tile_log2(rw), tx = tid & ((1 << lg) - 1), ty = tid >> lg, rpp = 256 >> lg;
-    const int txc = min(tx, max(rw - 1, 0));
+    const int txc = min(tx, rw - 1);
 #pragma unroll
     for (int j = 0; j < kResPasses; j++) {
       const int y = ty + j * rpp;

@@ -128,7 +128,8 @@ def test_progressive_preview_of_a_squeezed_channel(ctx, oracle):
 
 
 # ---------------------------------------------------------------- several squeeze levels in one call
-@pytest.mark.parametrize("size", [(9, 13), (16, 8), (100, 77), (128, 128), (64, 128), (127, 65), (300, 200), (1000, 130)])
+@pytest.mark.parametrize("size", [(9, 13), (16, 8), (100, 77), (128, 128), (64, 128), (127, 65), (300, 200), (1000, 130), (1, 40),
+                                  (33, 1)])
 @pytest.mark.parametrize("nchan", [1, 3])
 def test_unsqueeze_levels_equals_the_steps_one_by_one(ctx, oracle, size, nchan):
     """jxlh_unsqueeze_levels on the default squeeze chain of a w x h image (squeeze.rs:71-105): planes up to 128 x 128
