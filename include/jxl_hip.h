@@ -496,8 +496,11 @@ jxlh_status jxlh_smooth_unsqueeze(jxlh_ctx* ctx, int32_t kind, const int32_t* av
  * replicated small inputs (LF, HfMetadata maps, dequant tables) and the coefficient groups of ITS band, runs the
  * transforms on exactly that band, exchanges the one block row (8 pixel rows x 3 channels, 0.8 MB at 8K) its filters
  * read across each band edge with the neighbour rank, filters its band, and the finished bands are all-gathered so
- * that every rank holds the whole frame.  Frames with upsampling run whole (JXLH_ERR_UNSUPPORTED here); chroma-
- * subsampled frames recompute the halo group row instead of exchanging it.
+ * that every rank holds the whole frame.  Frames with upsampling run whole (JXLH_ERR_UNSUPPORTED here).
+ * Chroma-subsampled frames recompute the halo group row instead of exchanging it (their chroma upsampling reads
+ * across the band edge in the sub-sampled domain): for such a frame a rank must ALSO be given the coefficient
+ * groups of the one group row above and the one below its band, [r * per - 1, (r + 1) * per + 1) clipped to the
+ * frame; and its chroma is brought to full resolution before the gather even when no filter stage follows.
  *
  * One process per GPU (torch.distributed.run, mpirun, ...): the library owns an RCCL communicator.
  *   rank 0: jxlh_comm_unique_id(id); the launcher broadcasts the 128 bytes; every rank: jxlh_comm_init(ctx, id, rank, n)

@@ -831,7 +831,9 @@ jxlh_status run_k1(jxlh_ctx* ctx, const RunPlan& plan, int gr0, int gr1) {
     const bool stages_follow = f.gab || f.epf_iters > 0 || p.upsampling > 1 || (p.noise && !noise_lut_is_zero(p.noise_lut));
     ctx->lazy_gr0 = gr0;
     ctx->lazy_gr1 = gr1;
-    if (stages_follow) run_chroma_upsample(ctx, gr0, gr1);
+    // A sharded frame gathers planes[c] band by band (jxlh_frame_allgather): the full-resolution chroma must exist
+    // on every rank before the gather, and a deferred upsampling would cover only this rank's band afterwards.
+    if (stages_follow || jxlh_host::comm_nranks(ctx) > 1) run_chroma_upsample(ctx, gr0, gr1);
     else ctx->chroma_lazy = true;
   }
   return JXLH_OK;
@@ -993,7 +995,10 @@ jxlh_status jxlh_frame_rerender_groups(jxlh_ctx* ctx, const uint32_t* group_ids,
   // in another form, and a frame that was never rendered has none: those render the frame again.
   const bool per_stage = (p.flags & JXLH_FRAME_UNFUSED_FILTERS) != 0;  // ping-pongs planes <-> tmp: kept only for one stage
   const bool unfiltered_kept = ns == 0 || (per_stage ? ns == 1 : result_in_tmp(ctx) != 0);
-  if (!ctx->rendered || !unfiltered_kept || f.subsampled) return jxlh_frame_run(ctx, 0, UINT32_MAX);
+  // Noise is added IN PLACE to the result planes.  Without a filter stage the result lives in `planes`, the planes K1
+  // writes: the groups that are not re-transformed would receive their noise a second time.
+  const bool noise_in_place = ns == 0 && p.noise && !noise_lut_is_zero(p.noise_lut);
+  if (!ctx->rendered || !unfiltered_kept || f.subsampled || noise_in_place) return jxlh_frame_run(ctx, 0, UINT32_MAX);
   RunPlan plan;
   if (jxlh_status st = run_prologue(ctx, &plan)) return st;
   // ---- transforms of exactly the listed groups
@@ -1795,15 +1800,20 @@ jxlh_status jxlh_palette_delta_wp(jxlh_ctx* ctx, const int32_t* index, uint32_t 
   return stage_out(ctx, out, (const int32_t*)ctx->hook_i[2].p, n * nb_channels);
 }
 
+// dimension bound of the squeeze entry points (the kernels take `int` line counts / lengths)
+static constexpr uint32_t kMaxModularDim = 1u << 20;
+
 jxlh_status jxlh_unsqueeze(jxlh_ctx* ctx, int32_t horizontal, const int32_t* avg, size_t avg_stride,
                            const int32_t* res, size_t res_stride, uint32_t out_w, uint32_t out_h, int32_t* out,
                            size_t out_stride) {
   if (!ctx || !avg || !out || out_stride < out_w) return JXLH_ERR_INVALID_ARGUMENT;
   if (out_w == 0 || out_h == 0) return JXLH_OK;
+  if (out_w > kMaxModularDim || out_h > kMaxModularDim) return JXLH_ERR_UNSUPPORTED;
   const uint32_t avg_w = horizontal ? (out_w + 1) / 2 : out_w, avg_h = horizontal ? out_h : (out_h + 1) / 2;
   const uint32_t res_w = horizontal ? out_w / 2 : out_w, res_h = horizontal ? out_h : out_h / 2;
-  if (avg_stride < avg_w || (res_w * res_h > 0 && (!res || res_stride < res_w))) return JXLH_ERR_INVALID_ARGUMENT;
-  if (is_device_ptr(avg) && is_device_ptr(out) && (res_w * res_h == 0 || is_device_ptr(res))) {
+  const bool has_res = (size_t)res_w * res_h > 0;
+  if (avg_stride < avg_w || (has_res && (!res || res_stride < res_w))) return JXLH_ERR_INVALID_ARGUMENT;
+  if (is_device_ptr(avg) && is_device_ptr(out) && (!has_res || is_device_ptr(res))) {
     ScopedKernelTimer t(ctx, horizontal ? "k6_unsqueeze_h" : "k6_unsqueeze_v");
     const int32_t* av[1] = {avg};
     const int32_t* rv[1] = {res ? res : avg};
@@ -1814,7 +1824,7 @@ jxlh_status jxlh_unsqueeze(jxlh_ctx* ctx, int32_t horizontal, const int32_t* avg
   }
   jxlh_status st;
   if ((st = stage_in(ctx, ctx->hook_i[0], avg, avg_stride * avg_h))) return st;
-  const size_t res_n = (res_w * res_h > 0) ? res_stride * res_h : 0;
+  const size_t res_n = has_res ? res_stride * res_h : 0;
   if (res_n) {
     if ((st = stage_in(ctx, ctx->hook_i[1], res, res_n))) return st;
   } else if ((st = ensure(ctx, ctx->hook_i[1], 1))) {
@@ -1977,14 +1987,16 @@ jxlh_status jxlh_unsqueeze_planes(jxlh_ctx* ctx, int32_t horizontal, int32_t n_p
   if (!ctx || !avg || !res || !out || n_planes < 1 || n_planes > 3 || out_stride < out_w)
     return JXLH_ERR_INVALID_ARGUMENT;
   if (out_w == 0 || out_h == 0) return JXLH_OK;
+  if (out_w > kMaxModularDim || out_h > kMaxModularDim) return JXLH_ERR_UNSUPPORTED;
   const uint32_t avg_w = horizontal ? (out_w + 1) / 2 : out_w;
   const uint32_t res_w = horizontal ? out_w / 2 : out_w, res_h = horizontal ? out_h : out_h / 2;
-  if (avg_stride < avg_w || (res_w * res_h > 0 && res_stride < res_w)) return JXLH_ERR_INVALID_ARGUMENT;
+  const bool has_res = (size_t)res_w * res_h > 0;
+  if (avg_stride < avg_w || (has_res && res_stride < res_w)) return JXLH_ERR_INVALID_ARGUMENT;
   const int32_t* rv[3];
   for (int i = 0; i < n_planes; i++) {
     if (!avg[i] || !out[i] || !is_device_ptr(avg[i]) || !is_device_ptr(out[i])) return JXLH_ERR_INVALID_ARGUMENT;
     rv[i] = res[i] ? res[i] : avg[i];
-    if (res_w * res_h > 0 && (!res[i] || !is_device_ptr(res[i]))) return JXLH_ERR_INVALID_ARGUMENT;
+    if (has_res && (!res[i] || !is_device_ptr(res[i]))) return JXLH_ERR_INVALID_ARGUMENT;
   }
   ScopedKernelTimer t(ctx, horizontal ? "k6_unsqueeze_h" : "k6_unsqueeze_v");
   launch_unsqueeze(ctx->stream, horizontal, n_planes, avg, avg_stride, rv, res_stride, out_w, out_h, out, out_stride);

@@ -780,6 +780,7 @@ __global__ __launch_bounds__(256) void k1_large_units(const WorkLists wl, uint32
     const int type = (int)(wl.items[kClsLarge][e].packed >> 20) & 31;
     const int n = max(1, covered_x(type) * covered_y(type) * 64 / kLargeSlab);  // 64x32 / 32x64: half a slab
     const int base = atomicAdd(&wl.counts[(kNumClasses) * kCountPitch], n);
+    // capacity = nblocks / 32 + 16 >= the units any valid map can need (k1_scan drops overlapping varblocks)
     for (int s = 0; s < n; s++) units[base + s] = (uint32_t)e | ((uint32_t)s << 24);
   }
 }
@@ -837,12 +838,15 @@ __global__ __launch_bounds__(kLargeThreads, JXLH_LARGE_WPE) void k1_large_pass(c
 }  // namespace
 
 // ---- host side -----------------------------------------------------------------------------
+static size_t large_unit_capacity(size_t nblocks) { return nblocks / 32 + 16; }
+
 size_t vardct_worklist_bytes(const FrameDev& f) {
   const size_t nblocks = (size_t)f.xblocks * f.yblocks;
   size_t items = 0;
   for (int c = 0; c < kNumClasses; c++) items += nblocks / class_min_area(c) + 1;
-  // + the slab-unit list of the large transforms (one u32 per 4096 samples of large-varblock area)
-  return items * sizeof(WorkItem) + kCountBytes + (nblocks / 64 + 16) * sizeof(uint32_t);
+  // + the slab-unit list of the large transforms: one u32 per 4096 samples of large-varblock area, but a 64x32 /
+  // 32x64 varblock (32 blocks, half a slab) still takes a whole unit -> worst case one unit per 32 blocks
+  return items * sizeof(WorkItem) + kCountBytes + large_unit_capacity(nblocks) * sizeof(uint32_t);
 }
 
 void launch_vardct_groups(hipStream_t s, const FrameDev& f, int group_row0, int group_row1,
@@ -900,7 +904,7 @@ void launch_vardct_groups(hipStream_t s, const FrameDev& f, int group_row0, int 
   // the large class: unit list, then one launch per separable pass; 4 workgroups fit a CU (39 KB of LDS each).  All
   // three exit at once when the class is empty (the d1 mix)
   hipLaunchKernelGGL(k1_large_units, dim3(grid_for(nblk / 64 + 1, 256, 64)), dim3(256), 0, s, wl, large_units);
-  const dim3 glarge(grid_for(3L * (nblk / 64 + 1), 1, 2048));
+  const dim3 glarge(grid_for(3L * (nblk / 32 + 1), 1, 2048));
   hipLaunchKernelGGL(k1_large_pass<1>, glarge, dim3(kLargeThreads), 0, s, f, wl, large_units);
   hipLaunchKernelGGL(k1_large_pass<2>, glarge, dim3(kLargeThreads), 0, s, f, wl, large_units);
 }

@@ -131,6 +131,21 @@ def test_vardct_frame_bit_exact(ctx, oracle, case):
             assert bit_equal(got[c], want[c]), f"flags={flags} plane {c}: {diff_report(got[c], want[c])}"
 
 
+@pytest.mark.parametrize("ttype", [18, 19, 20, 21, 24])
+def test_uniform_large_varblock_frame(ctx, oracle, ttype):
+    """a frame tiled by ONE large type.  DCT64X32 / DCT32X64 varblocks cover 32 blocks but still take a whole slab
+    unit each: a frame of nothing else needs nblocks / 32 units, the worst case the unit list is sized for
+    (round 2 sized it for nblocks / 64 and wrote past the work-list allocation)"""
+    from jxl_rs_amd import synth
+    wl = synth.make_vardct(512, 768, mix={ttype: 1.0}, seed=100 + ttype, epf_iters=1, gab=True)
+    first = wl.transform_map[wl.transform_map >= 128] & 127
+    assert (first == ttype).all() and first.size == 64 * 96 // (synth.COVERED_X[ttype] * synth.COVERED_Y[ttype])
+    want, _ = run_oracle_frame(oracle, wl)
+    got, _ = run_gpu_frame(ctx, wl)
+    for c in range(3):
+        assert bit_equal(got[c], want[c]), f"type {ttype} plane {c}: {diff_report(got[c], want[c])}"
+
+
 def test_vardct_frame_prefilter_planes_and_determinism(ctx, oracle):
     """K1 alone (no filters) vs jxlo_decode_group, and run-to-run bit-identical output
     (result independent of launch geometry / scheduling)."""
@@ -800,6 +815,25 @@ def test_fused_unsqueeze_and_rct(ctx, oracle, shape, op_perm, horizontal, pad):
     for d in dev:
         for x in d:
             x.free()
+
+
+def test_unsqueeze_rejects_dimensions_whose_product_wraps(ctx):
+    """65536 x 65536: `res_w * res_h` used to be formed in 32 bits, wrapped to 0 and skipped the null / stride /
+    device-pointer checks on the residual plane"""
+    import ctypes as C
+    from jxl_rs_amd import lib
+    one = np.zeros((1, 1), dtype=np.int32)
+    p = one.ctypes.data_as(C.c_void_p)
+    for hz in (0, 1):
+        st = ctx.L.jxlh_unsqueeze(ctx._ctx, hz, p, 1 << 20, None, 0, 65536, 65536 * 2, p, 1 << 20)
+        assert st in (lib.ERR_UNSUPPORTED, lib.ERR_INVALID_ARGUMENT), st
+        pv = (C.c_void_p * 1)(p.value)
+        nv = (C.c_void_p * 1)(None)
+        st = ctx.L.jxlh_unsqueeze_planes(ctx._ctx, hz, 1, pv, 1 << 20, nv, 0, 65536, 65536 * 2, pv, 1 << 20)
+        assert st in (lib.ERR_UNSUPPORTED, lib.ERR_INVALID_ARGUMENT), st
+    # inside the dimension bound the residual plane is still checked
+    st = ctx.L.jxlh_unsqueeze(ctx._ctx, 1, p, 1 << 19, None, 0, 1 << 20, 1 << 12, p, 1 << 20)
+    assert st == lib.ERR_INVALID_ARGUMENT
 
 
 @pytest.mark.parametrize("scale", [2**15, 2**24, 2**28])

@@ -50,7 +50,8 @@ def check(ctx, want, what):
 
 
 CASES = [dict(epf_iters=2, gab=True), dict(epf_iters=0, gab=False), dict(epf_iters=3, gab=True),
-         dict(epf_iters=1, gab=True, flags=1), dict(epf_iters=2, gab=True, flags=1), dict(epf_iters=2, gab=True, noise=True)]
+         dict(epf_iters=1, gab=True, flags=1), dict(epf_iters=2, gab=True, flags=1), dict(epf_iters=2, gab=True, noise=True),
+         dict(epf_iters=0, gab=False, noise=True)]  # noise is added in place to the planes K1 writes
 
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))

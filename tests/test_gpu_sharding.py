@@ -88,6 +88,34 @@ def test_local_sharded_subsampled_frame(oracle):
             c.close()
 
 
+def test_local_sharded_subsampled_frame_without_stages(oracle):
+    """the JPEG-recompression case: 4:2:0, no Gaborish / EPF / noise / upsampling.  A single-GPU run defers the chroma
+    upsampling until the planes are asked for; a sharded run must upsample before the all-gather, or every rank ends
+    up with stale chroma outside its own band (both the plane read and the fused YCbCr -> RGB8 read)"""
+    import jxl_rs_amd
+    from jxl_rs_amd import lib, synth
+    hs = vs = (1, 0, 1)
+    wl = synth.make_vardct(300, 700, mix=synth.MIX_8X8, seed=13, epf_iters=0, gab=False, hshift=hs, vshift=vs)
+    want, _ = run_oracle_frame(oracle, wl)
+    want_rgb = oracle.ycbcr_to_rgb8(want, wl.xsize, wl.ysize, 3)
+    ctxs = [jxl_rs_amd.Context(0, 1) for _ in range(2)]
+    try:
+        lib.comm_init_local(ctxs)
+        for r, c in enumerate(ctxs):
+            upload_band(c, wl, band_groups(wl, r, 2, extra=1))
+        lib.frames_run_sharded_local(ctxs)
+        lib.frames_allgather_local(ctxs)
+        for r, c in enumerate(ctxs):
+            c.sync()
+            assert np.array_equal(c.read_ycbcr_rgb8(3), want_rgb), f"rank {r}: YCbCr RGB8 read differs"
+            got = c.read_planes()
+            for ch in range(3):
+                assert bit_equal(got[ch], want[ch]), f"rank {r} plane {ch}: {diff_report(got[ch], want[ch])}"
+    finally:
+        for c in ctxs:
+            c.close()
+
+
 def test_sharded_upsampled_frame_is_declined():
     import jxl_rs_amd
     from jxl_rs_amd import lib, synth, JxlHipError
