@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define JXLH_ABI_VERSION 5
+#define JXLH_ABI_VERSION 6
 #define JXLH_NUM_TRANSFORMS 27   /* HfTransformType::CARDINALITY, transform_map.rs:59-61 */
 #define JXLH_NUM_QUANT_TABLES 17 /* NUM_QUANT_TABLES, quantizer.rs:11 */
 #define JXLH_GROUP_DIM 256       /* GROUP_DIM, jxl/src/lib.rs:24-26 */
@@ -268,22 +268,6 @@ jxlh_status jxlh_frame_device_planes(jxlh_ctx* ctx, float* planes[3], size_t* st
 /* smoothed LF image as used by K1 (tests) */
 jxlh_status jxlh_frame_read_lf(jxlh_ctx* ctx, float* x, float* y, float* b, size_t stride);
 
-/* ---------------------------------------------------------------- timing / profiling */
-/* HIP-event timing on the stream the kernels are launched on. */
-jxlh_status jxlh_timer_start(jxlh_ctx* ctx);
-jxlh_status jxlh_timer_stop(jxlh_ctx* ctx, float* elapsed_ms);
-/* per-kernel event pairs; accumulates while enabled */
-jxlh_status jxlh_kernel_timing_enable(jxlh_ctx* ctx, int32_t enable);
-/* i-th kernel that ran while timing was enabled: name, total ms, launches. Returns
- * JXLH_ERR_INVALID_ARGUMENT past the end. */
-jxlh_status jxlh_kernel_timing_get(jxlh_ctx* ctx, int32_t i, const char** name, float* total_ms,
-                                   int32_t* launches);
-jxlh_status jxlh_kernel_timing_reset(jxlh_ctx* ctx);
-/* Device-to-device copy ceiling, measured: a float4 copy of `bytes` (src and dst buffers allocated for the call)
- * repeated `reps` times on the context's stream; *gb_per_s = (bytes read + bytes written) / time.  The yardstick
- * SURVEY.md 8(d) asks for next to the 8 TB/s spec peak. */
-jxlh_status jxlh_probe_copy_bandwidth(jxlh_ctx* ctx, size_t bytes, int32_t reps, float* gb_per_s);
-
 /* ---------------------------------------------------------------- 8-bit sRGB output
  * The stages the reference runs after EPF for an XYB-encoded frame saved as 8-bit sRGB -- XybStage
  * (render/stages/xyb.rs:208-240), FromLinearStage with the sRGB curve (color/tf.rs:13-44),
@@ -383,12 +367,6 @@ jxlh_status jxlh_stage_lf_smooth(jxlh_ctx* ctx, const jxlh_frame_params* p, cons
  * coeffs n * cx*cy*64 dequantised coefficients, lf n * cx*cy samples, pixels n * (cy*8)*(cx*8). */
 jxlh_status jxlh_stage_transform_to_pixels(jxlh_ctx* ctx, int32_t type, uint32_t n, const float* coeffs,
                                            const float* lf, float* pixels);
-
-/* Device self-test of the EPF weight normalisation: the filters compute 1/(1 + sum of weights)
- * (epf0.rs:208, epf1.rs:140, epf2.rs:130 divide) with rcp + two FMA refinement steps.  Counts the
- * floats whose bit pattern lies in [lo_bits, hi_bits) for which that differs from the IEEE
- * quotient 1.0f / w; the filters rely on 0 mismatches over [1.0f, 16.0f). */
-jxlh_status jxlh_selftest_recip(jxlh_ctx* ctx, uint32_t lo_bits, uint32_t hi_bits, uint64_t* mismatches);
 
 /* ---------------------------------------------------------------- Modular (wrapping i32) */
 /* do_rct_step (modular/transforms/rct.rs:118-157) on whole planes of n samples, in place. */

@@ -1,0 +1,43 @@
+/*
+ * jxl_hip_dev.h -- developer / bench instruments of libjxl_hip.so.
+ *
+ * NOT part of the drop-in boundary: a decoder binds include/jxl_hip.h only (tools/gen_rust_binding.py generates the
+ * Rust -sys crate from that header alone).  These entry points exist for bench.py, the profiling tools and the GPU
+ * tests: HIP-event timers on the stream the kernels run on, per-kernel timing, a measured copy ceiling and a device
+ * self-test.  They are exported by the same library and follow the same conventions (status codes, no exceptions).
+ */
+#ifndef JXL_HIP_DEV_H_
+#define JXL_HIP_DEV_H_
+
+#include "jxl_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* HIP-event timing on the stream the kernels are launched on. */
+jxlh_status jxlh_timer_start(jxlh_ctx* ctx);
+jxlh_status jxlh_timer_stop(jxlh_ctx* ctx, float* elapsed_ms);
+/* per-kernel event pairs; accumulates while enabled */
+jxlh_status jxlh_kernel_timing_enable(jxlh_ctx* ctx, int32_t enable);
+/* i-th kernel that ran while timing was enabled: name, total ms, launches. Returns
+ * JXLH_ERR_INVALID_ARGUMENT past the end. */
+jxlh_status jxlh_kernel_timing_get(jxlh_ctx* ctx, int32_t i, const char** name, float* total_ms,
+                                   int32_t* launches);
+jxlh_status jxlh_kernel_timing_reset(jxlh_ctx* ctx);
+/* Device-to-device copy ceiling, measured: a float4 copy of `bytes` (src and dst buffers allocated for the call)
+ * repeated `reps` times on the context's stream; *gb_per_s = (bytes read + bytes written) / time.  The yardstick
+ * SURVEY.md 8(d) asks for next to the 8 TB/s spec peak. */
+jxlh_status jxlh_probe_copy_bandwidth(jxlh_ctx* ctx, size_t bytes, int32_t reps, float* gb_per_s);
+
+
+/* Device self-test of the EPF weight normalisation: the filters compute 1/(1 + sum of weights)
+ * (epf0.rs:208, epf1.rs:140, epf2.rs:130 divide) with rcp + two FMA refinement steps.  Counts the
+ * floats whose bit pattern lies in [lo_bits, hi_bits) for which that differs from the IEEE
+ * quotient 1.0f / w; the filters rely on 0 mismatches over [1.0f, 16.0f). */
+jxlh_status jxlh_selftest_recip(jxlh_ctx* ctx, uint32_t lo_bits, uint32_t hi_bits, uint64_t* mismatches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JXL_HIP_DEV_H_ */

@@ -1,0 +1,175 @@
+// C ABI, coefficient transport: dense group slabs (jxlh_submit_group) and the sparse (position, value) forms
+//  -- asynchronous H2D on the caller's slot stream, multi-pass accumulation.
+#include <algorithm>
+
+#include "jxlh_ctx.h"
+
+extern "C" {
+
+jxlh_status jxlh_submit_group(jxlh_ctx* ctx, int32_t slot, uint32_t group_id, const int32_t* coeffs, uint32_t flags) {
+  if (!ctx || !coeffs || slot < 0 || (size_t)slot >= ctx->slots.size()) return JXLH_ERR_INVALID_ARGUMENT;
+  if (!ctx->in_frame) return JXLH_ERR_BAD_STATE;
+  if (group_id >= ctx->ngroups) return JXLH_ERR_INVALID_ARGUMENT;
+  // JXLH_GROUP_COMPLETE is the caller's bookkeeping (set_buffer_for_group's `complete`): a slab always REPLACES the
+  // group's coefficients, so a progressive decoder submits what it has accumulated so far (the reference keeps that
+  // in Frame::hf_coefficients, frame/decode.rs:547-558) and re-renders the group when a later pass changes it
+  if (flags & JXLH_GROUP_ACCUMULATE) return JXLH_ERR_INVALID_ARGUMENT;  // device-side accumulation: sparse form only
+  Slot& s = ctx->slots[slot];
+  {
+    std::lock_guard<std::mutex> lock(ctx->sp_mutex);
+    if (ctx->touched[group_id] == 2) {
+      // submitted as pairs earlier in this epoch: the dense slab replaces that submission
+      for (size_t i = 0; i < ctx->sp_pending.size();) {
+        if (ctx->sp_pending[i].group == group_id) ctx->sp_pending.erase(ctx->sp_pending.begin() + i);
+        else i++;
+      }
+    }
+    ctx->touched[group_id] = 1;
+    ctx->epoch_dirty = true;
+  }
+  int32_t* dst = ctx->coeffs.p + (size_t)group_id * 3 * kGroupArea;
+  // the previous jxlh_frame_run's transforms may still be reading the slab (callers that use the *_async reads
+  // do not wait between frames)
+  if (ctx->k1_done_valid) HIPCHK(ctx, hipStreamWaitEvent(s.stream, ctx->k1_done, 0));
+  if (dst != coeffs) {
+    HIPCHK(ctx, hipMemcpyAsync(dst, coeffs, (size_t)3 * kGroupArea * sizeof(int32_t), hipMemcpyDefault, s.stream));
+  }
+  HIPCHK(ctx, hipEventRecord(s.done, s.stream));
+  s.used = true;
+  return JXLH_OK;
+}
+
+namespace {
+// bookkeeping shared by the sparse submission forms: validates, reserves `total` pairs in the frame's pair buffer
+// (offset returned) and records the groups / wide entries for the next jxlh_frame_run
+jxlh_status sparse_reserve(jxlh_ctx* ctx, int32_t slot, uint32_t count, const uint32_t* group_ids, const uint32_t* n,
+                           const jxlh_coeff32* wide, uint32_t n_wide, uint32_t flags, size_t* offset_out,
+                           size_t* total_out) {
+  if (!ctx || slot < 0 || (size_t)slot >= ctx->slots.size() || !group_ids || !n || (n_wide && !wide))
+    return JXLH_ERR_INVALID_ARGUMENT;
+  if (!ctx->in_frame) return JXLH_ERR_BAD_STATE;
+  size_t total = 0;
+  for (uint32_t i = 0; i < count; i++) {
+    if (group_ids[i] >= ctx->ngroups) return JXLH_ERR_INVALID_ARGUMENT;
+    total += (size_t)n[3 * i] + n[3 * i + 1] + n[3 * i + 2];
+  }
+  const size_t wide_limit = ctx->ngroups * 3 * (size_t)kGroupArea;
+  for (uint32_t i = 0; i < n_wide; i++)
+    if (wide[i].pos >= wide_limit) return JXLH_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lock(ctx->sp_mutex);
+  const size_t capacity = ctx->ngroups * 3 * (size_t)kGroupArea;  // one pair per coefficient
+  if (jxlh_status st = ensure(ctx, ctx->sp_pairs, capacity)) return st;
+  if (!ctx->sp_expanded) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->sp_expanded, hipEventDisableTiming));
+  if (ctx->sp_used + total > capacity) return JXLH_ERR_INVALID_ARGUMENT;  // more pairs than coefficients
+  for (uint32_t i = 0; i < count; i++) {  // one sparse submission per group between two runs (its list may
+    if (ctx->touched[group_ids[i]] == 2) return JXLH_ERR_BAD_STATE;  // hold several passes' updates)
+    for (uint32_t k = 0; k < i; k++)  // ... and not twice inside this batch either
+      if (group_ids[k] == group_ids[i]) return JXLH_ERR_BAD_STATE;
+  }
+  const size_t offset = ctx->sp_used;
+  ctx->sp_used += total;
+  size_t o = offset;
+  for (uint32_t i = 0; i < count; i++) {
+    SparseGroup g;
+    g.group = group_ids[i];
+    g.offset = (uint32_t)o;
+    for (int c = 0; c < 3; c++) {
+      g.n[c] = n[3 * i + c];
+      o += g.n[c];
+    }
+    g.flags = (flags & JXLH_GROUP_ACCUMULATE) ? 1u : 0u;
+    ctx->sp_pending.push_back(g);
+    ctx->touched[g.group] = 2;
+  }
+  ctx->epoch_dirty = true;
+  for (uint32_t i = 0; i < n_wide; i++) ctx->sp_wide.push_back(make_uint2(wide[i].pos, (uint32_t)wide[i].val));
+  *offset_out = offset;
+  *total_out = total;
+  return JXLH_OK;
+}
+}  // namespace
+
+jxlh_status jxlh_submit_groups_sparse(jxlh_ctx* ctx, int32_t slot, uint32_t count, const uint32_t* group_ids,
+                                      const jxlh_coeff16* pairs, const uint32_t* n, const jxlh_coeff32* wide,
+                                      uint32_t n_wide, uint32_t flags) {
+  if (count == 0 && ctx && ctx->in_frame) return JXLH_OK;
+  size_t offset = 0, total = 0;
+  if (jxlh_status st = sparse_reserve(ctx, slot, count, group_ids, n, wide, n_wide, flags, &offset, &total)) return st;
+  if (total && !pairs) return JXLH_ERR_INVALID_ARGUMENT;
+  Slot& s = ctx->slots[slot];
+  // the pair buffer is recycled per frame: the previous frame's expansion must have read it
+  if (ctx->sp_expanded_valid) HIPCHK(ctx, hipStreamWaitEvent(s.stream, ctx->sp_expanded, 0));
+  if (total)
+    HIPCHK(ctx, hipMemcpyAsync(ctx->sp_pairs.p + offset, pairs, total * sizeof(uint32_t), hipMemcpyDefault, s.stream));
+  HIPCHK(ctx, hipEventRecord(s.done, s.stream));
+  s.used = true;
+  return JXLH_OK;
+}
+
+// 3 bytes per coefficient update on the bus: positions and values as separate arrays (u16 / i8), widened into the
+// pair buffer by a small kernel on the slot's stream
+jxlh_status jxlh_submit_groups_sparse8(jxlh_ctx* ctx, int32_t slot, uint32_t count, const uint32_t* group_ids,
+                                       const uint16_t* pos, const int8_t* val, const uint32_t* n,
+                                       const jxlh_coeff32* wide, uint32_t n_wide, uint32_t flags) {
+  if (count == 0 && ctx && ctx->in_frame) return JXLH_OK;
+  size_t offset = 0, total = 0;
+  if (jxlh_status st = sparse_reserve(ctx, slot, count, group_ids, n, wide, n_wide, flags, &offset, &total)) return st;
+  if (total && (!pos || !val)) return JXLH_ERR_INVALID_ARGUMENT;
+  Slot& s = ctx->slots[slot];
+  if (ctx->sp_expanded_valid) HIPCHK(ctx, hipStreamWaitEvent(s.stream, ctx->sp_expanded, 0));
+  if (total) {
+    // staging: [positions | values], reused by the slot (stream-ordered)
+    const size_t pos_bytes = (total * sizeof(uint16_t) + 15) & ~(size_t)15;
+    if (s.stage8_cap < pos_bytes + total) {
+      HIPCHK(ctx, hipStreamSynchronize(s.stream));  // the old staging may still be read by a queued kernel
+      if (s.stage8) (void)hipFree(s.stage8);
+      s.stage8 = nullptr;
+      s.stage8_cap = 0;
+      const size_t cap = (pos_bytes + total) * 5 / 4 + 4096;
+      if (hipMalloc(reinterpret_cast<void**>(&s.stage8), cap) != hipSuccess) return JXLH_ERR_OUT_OF_MEMORY;
+      s.stage8_cap = cap;
+    }
+    HIPCHK(ctx, hipMemcpyAsync(s.stage8, pos, total * sizeof(uint16_t), hipMemcpyDefault, s.stream));
+    HIPCHK(ctx, hipMemcpyAsync(s.stage8 + pos_bytes, val, total, hipMemcpyDefault, s.stream));
+    launch_pack_pairs8(s.stream, reinterpret_cast<const uint16_t*>(s.stage8),
+                       reinterpret_cast<const int8_t*>(s.stage8 + pos_bytes), total, ctx->sp_pairs.p + offset);
+    HIPCHK(ctx, hipGetLastError());
+  }
+  HIPCHK(ctx, hipEventRecord(s.done, s.stream));
+  s.used = true;
+  return JXLH_OK;
+}
+
+jxlh_status jxlh_submit_group_sparse(jxlh_ctx* ctx, int32_t slot, uint32_t group_id, const jxlh_coeff16* pairs,
+                                     const uint32_t n[3], const jxlh_coeff32* wide, uint32_t n_wide,
+                                     uint32_t flags) {
+  if (!ctx || !n) return JXLH_ERR_INVALID_ARGUMENT;
+  if (group_id >= ctx->ngroups) return JXLH_ERR_INVALID_ARGUMENT;
+  // the single-group form addresses wide entries relative to the group
+  std::vector<jxlh_coeff32> w;
+  if (n_wide) {
+    if (!wide) return JXLH_ERR_INVALID_ARGUMENT;
+    w.assign(wide, wide + n_wide);
+    for (auto& e : w) {
+      if (e.pos >= 3u * kGroupArea) return JXLH_ERR_INVALID_ARGUMENT;
+      e.pos += group_id * 3u * kGroupArea;
+    }
+  }
+  return jxlh_submit_groups_sparse(ctx, slot, 1, &group_id, pairs, n, w.data(), n_wide, flags);
+}
+
+jxlh_status jxlh_slot_wait(jxlh_ctx* ctx, int32_t slot) {
+  if (!ctx || slot < 0 || (size_t)slot >= ctx->slots.size()) return JXLH_ERR_INVALID_ARGUMENT;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->slots[slot].stream));
+  return JXLH_OK;
+}
+
+jxlh_status jxlh_frame_coeff_buffer(jxlh_ctx* ctx, int32_t** device_ptr, size_t* n_int32) {
+  if (!ctx || !device_ptr) return JXLH_ERR_INVALID_ARGUMENT;
+  if (!ctx->in_frame) return JXLH_ERR_BAD_STATE;
+  *device_ptr = ctx->coeffs.p;
+  if (n_int32) *n_int32 = ctx->ngroups * 3 * kGroupArea;
+  return JXLH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,64 @@
+// Developer / bench instruments declared in include/jxl_hip_dev.h (NOT part of the product ABI in jxl_hip.h, not bound
+// by the generated Rust -sys crate): HIP-event timers on the kernels' own stream, per-kernel timing, the exhaustive
+// reciprocal self-test.  (jxlh_probe_copy_bandwidth lives next to its kernel in k_probe.hip.)
+#include <algorithm>
+
+#include "jxlh_ctx.h"
+#include "../../include/jxl_hip_dev.h"
+
+extern "C" {
+
+// ---------------------------------------------------------------- timing
+jxlh_status jxlh_timer_start(jxlh_ctx* ctx) {
+  if (!ctx) return JXLH_ERR_INVALID_ARGUMENT;
+  HIPCHK(ctx, hipEventRecord(ctx->t0, ctx->stream));
+  return JXLH_OK;
+}
+
+jxlh_status jxlh_timer_stop(jxlh_ctx* ctx, float* elapsed_ms) {
+  if (!ctx || !elapsed_ms) return JXLH_ERR_INVALID_ARGUMENT;
+  HIPCHK(ctx, hipEventRecord(ctx->t1, ctx->stream));
+  HIPCHK(ctx, hipEventSynchronize(ctx->t1));
+  HIPCHK(ctx, hipEventElapsedTime(elapsed_ms, ctx->t0, ctx->t1));
+  return JXLH_OK;
+}
+
+jxlh_status jxlh_kernel_timing_enable(jxlh_ctx* ctx, int32_t enable) {
+  if (!ctx) return JXLH_ERR_INVALID_ARGUMENT;
+  ctx->timing = enable != 0;
+  return JXLH_OK;
+}
+
+jxlh_status jxlh_kernel_timing_get(jxlh_ctx* ctx, int32_t i, const char** name, float* total_ms, int32_t* launches) {
+  if (!ctx || i < 0) return JXLH_ERR_INVALID_ARGUMENT;
+  drain_timers(ctx);
+  if ((size_t)i >= ctx->ktimes.size()) return JXLH_ERR_INVALID_ARGUMENT;
+  if (name) *name = ctx->ktimes[i].name.c_str();
+  if (total_ms) *total_ms = ctx->ktimes[i].total_ms;
+  if (launches) *launches = ctx->ktimes[i].launches;
+  return JXLH_OK;
+}
+
+jxlh_status jxlh_kernel_timing_reset(jxlh_ctx* ctx) {
+  if (!ctx) return JXLH_ERR_INVALID_ARGUMENT;
+  drain_timers(ctx);
+  ctx->ktimes.clear();
+  return JXLH_OK;
+}
+
+jxlh_status jxlh_selftest_recip(jxlh_ctx* ctx, uint32_t lo_bits, uint32_t hi_bits, uint64_t* mismatches) {
+  if (!ctx || !mismatches || hi_bits < lo_bits) return JXLH_ERR_INVALID_ARGUMENT;
+  jxlh_status st;
+  if ((st = ensure(ctx, ctx->hook_i[0], 2))) return st;
+  unsigned long long* d = reinterpret_cast<unsigned long long*>(ctx->hook_i[0].p);
+  HIPCHK(ctx, hipMemsetAsync(d, 0, sizeof(unsigned long long), ctx->stream));
+  launch_selftest_recip(ctx->stream, lo_bits, hi_bits, d);
+  HIPCHK(ctx, hipGetLastError());
+  unsigned long long host = 0;
+  HIPCHK(ctx, hipMemcpyAsync(&host, d, sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  *mismatches = host;
+  return JXLH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,896 @@
+// C ABI of the MI355X JPEG XL reconstruction path (include/jxl_hip.h): context, device
+// memory, streams, uploads and kernel sequencing.  No compute happens on the host here and
+// there is no CPU fallback: every entry point either launches HIP kernels or fails.
+//
+// Sequencing mirrors the reference's frame flow: decode_lf_group ->
+// set_lf* / set_hf_meta; decode_hf_global -> set_dequant_tables; decode_hf_group ->
+// submit_group (async H2D on the caller's slot stream, overlapping the host's entropy decode
+// of the next group); finalize_lf + render -> frame_run.
+#include <algorithm>
+
+#include "jxlh_ctx.h"
+
+namespace jxlh_host {
+// the restoration filter's header fields in the form the kernels take them
+void set_filter_params(FrameDev& f, const jxlh_frame_params& p) {
+  for (int c = 0; c < 3; c++) {  // GaborishStage::new, gaborish.rs:20-27
+    const float total = 1.0f + p.gab_w1[c] * 4.0f + p.gab_w2[c] * 4.0f;
+    f.gab_k[c][0] = 1.0f / total;
+    f.gab_k[c][1] = p.gab_w1[c] / total;
+    f.gab_k[c][2] = p.gab_w2[c] / total;
+    f.epf_channel_scale[c] = p.epf_channel_scale[c];
+  }
+  const float sigma_scale[3] = {p.epf_pass0_sigma_scale, 1.0f, p.epf_pass2_sigma_scale};  // render.rs:599-621
+  for (int s = 0; s < 3; s++) {
+    f.epf_sm[s] = sigma_scale[s] * 1.65f;  // epf1.rs:67-68
+    f.epf_bsm[s] = f.epf_sm[s] * p.epf_border_sad_mul;
+  }
+  f.epf_iters = (int)p.epf_iters;
+  f.gab = (int)p.gab;
+}
+}  // namespace jxlh_host
+
+extern "C" {
+
+uint32_t jxlh_abi_version(void) { return JXLH_ABI_VERSION; }
+int32_t jxlh_covered_blocks_x(int32_t t) { return (t >= 0 && t < 27) ? covered_x(t) : -1; }
+int32_t jxlh_covered_blocks_y(int32_t t) { return (t >= 0 && t < 27) ? covered_y(t) : -1; }
+int32_t jxlh_quant_table_for_type(int32_t t) { return (t >= 0 && t < 27) ? quant_table_for_type(t) : -1; }
+int32_t jxlh_quant_table_size(int32_t q) { return (q >= 0 && q < 17) ? quant_table_size(q) : -1; }
+
+const char* jxlh_status_string(jxlh_status s) {
+  switch (s) {
+    case JXLH_OK: return "ok";
+    case JXLH_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case JXLH_ERR_OUT_OF_MEMORY: return "out of device memory";
+    case JXLH_ERR_DEVICE: return "HIP runtime error";
+    case JXLH_ERR_BAD_STATE: return "call order violated";
+    case JXLH_ERR_INVALID_TRANSFORM: return "invalid VarDCT transform id";
+    case JXLH_ERR_UNSUPPORTED: return "unsupported on the device path";
+    case JXLH_ERR_INVALID_BLOCK_SIZE: return "varblock larger than 8x8 in a chroma-subsampled frame";
+    case JXLH_ERR_BLOCK_OUT_OF_BOUNDS: return "varblock crosses its group or the frame edge";
+    default: return "unknown status";
+  }
+}
+
+const char* jxlh_last_error(const jxlh_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+jxlh_status jxlh_default_frame_params(jxlh_frame_params* p, uint32_t xsize, uint32_t ysize) {
+  if (!p) return JXLH_ERR_INVALID_ARGUMENT;
+  std::memset(p, 0, sizeof *p);
+  p->abi_version = JXLH_ABI_VERSION;
+  p->xsize = xsize;
+  p->ysize = ysize;
+  p->global_scale = 21845;  // not a header default; a typical d1 value
+  p->quant_lf = 16;         // QuantizerParams::read default branch (quantizer.rs:67)
+  p->lf_quant_factors[0] = 1.0f / 4096.0f;  // quant_weights.rs:24-30
+  p->lf_quant_factors[1] = 1.0f / 512.0f;
+  p->lf_quant_factors[2] = 1.0f / 256.0f;
+  p->quant_biases[0] = 1.0f - 0.05465007330715401f;  // headers/transform_data.rs:30-31
+  p->quant_biases[1] = 1.0f - 0.07005449891748593f;
+  p->quant_biases[2] = 1.0f - 0.049935103337343655f;
+  p->quant_biases[3] = 0.145f;
+  p->x_qm_scale = 3;  // frame_header.rs:308-315
+  p->b_qm_scale = 2;
+  p->color_factor = 84;  // color_correlation_map.rs:18, :31-40
+  p->base_correlation_x = 0.0f;
+  p->base_correlation_b = 1.0f;
+  p->gab = 1;  // frame_header.rs:150-177
+  for (int c = 0; c < 3; c++) {
+    p->gab_w1[c] = 0.115169525f;
+    p->gab_w2[c] = 0.061248592f;
+  }
+  p->epf_iters = 2;
+  for (int i = 0; i < 8; i++) p->epf_sharp_lut[i] = (float)i / 7.0f;
+  p->epf_sharp_lut[7] = 1.0f;
+  p->epf_channel_scale[0] = 40.0f;
+  p->epf_channel_scale[1] = 5.0f;
+  p->epf_channel_scale[2] = 3.5f;
+  p->epf_quant_mul = 0.46f;
+  p->epf_pass0_sigma_scale = 0.9f;
+  p->epf_pass2_sigma_scale = 6.5f;
+  p->epf_border_sad_mul = 2.0f / 3.0f;
+  p->do_lf_smoothing = 1;
+  p->epf_sigma_for_modular = 1.0f;  // RestorationFilter default (headers/frame_header.rs:229-231)
+  return JXLH_OK;
+}
+
+jxlh_status jxlh_ctx_create(int32_t device_ordinal, int32_t n_slots, jxlh_ctx** out) {
+  if (!out || n_slots < 1 || n_slots > 1024) return JXLH_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device_ordinal < 0 || device_ordinal >= ndev)
+    return JXLH_ERR_DEVICE;
+  jxlh_ctx* ctx = new (std::nothrow) jxlh_ctx();
+  if (!ctx) return JXLH_ERR_OUT_OF_MEMORY;
+  ctx->device = device_ordinal;
+  if (hipSetDevice(device_ordinal) != hipSuccess ||
+      hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreate(&ctx->t0) != hipSuccess || hipEventCreate(&ctx->t1) != hipSuccess) {
+    delete ctx;
+    return JXLH_ERR_DEVICE;
+  }
+  ctx->slots.resize(n_slots);
+  for (auto& s : ctx->slots) {
+    if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess) {
+      jxlh_ctx_destroy(ctx);
+      return JXLH_ERR_DEVICE;
+    }
+  }
+  *out = ctx;
+  return JXLH_OK;
+}
+
+void jxlh_ctx_destroy(jxlh_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipDeviceSynchronize();
+  drain_timers(ctx);
+  for (auto& s : ctx->slots) {
+    if (s.done) (void)hipEventDestroy(s.done);
+    if (s.stream) (void)hipStreamDestroy(s.stream);
+    if (s.stage8) (void)hipFree(s.stage8);
+  }
+  for (int c = 0; c < 3; c++) {
+    release(ctx->planes[c]);
+    release(ctx->tmp[c]);
+    release(ctx->lf_raw[c]);
+    release(ctx->lf_sm[c]);
+  }
+  release(ctx->sigma);
+  release(ctx->tables);
+  release(ctx->coeffs);
+  release(ctx->sp_pairs);
+  release(ctx->sp_groups_dev);
+  release(ctx->sp_wide_dev);
+  release(ctx->sp_sorted);
+  release(ctx->sp_slot_start);
+  release(ctx->group_dense);
+  if (ctx->sp_expanded) (void)hipEventDestroy(ctx->sp_expanded);
+  if (ctx->k1_done) (void)hipEventDestroy(ctx->k1_done);
+  comm_release(ctx);
+  release(ctx->raw_quant);
+  release(ctx->lfq);
+  release(ctx->transform_map);
+  release(ctx->epf_map);
+  release(ctx->ytox);
+  release(ctx->ytob);
+  release(ctx->error_flag);
+  release(ctx->rgb8);
+  for (auto& b : ctx->ups) release(b);
+  for (auto& b : ctx->noise) release(b);
+  release(ctx->xs_jump);
+  release(ctx->ups_kernels);
+  if (ctx->host_flag) (void)hipHostFree(ctx->host_flag);
+  release(ctx->worklist);
+  for (auto& b : ctx->hook_f) release(b);
+  for (auto& b : ctx->hook_i) release(b);
+  if (ctx->t0) (void)hipEventDestroy(ctx->t0);
+  if (ctx->t1) (void)hipEventDestroy(ctx->t1);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+jxlh_status jxlh_alloc_pinned(jxlh_ctx* ctx, size_t bytes, void** out) {
+  if (!ctx || !out) return JXLH_ERR_INVALID_ARGUMENT;
+  HIPCHK(ctx, hipHostMalloc(out, bytes, hipHostMallocDefault));
+  return JXLH_OK;
+}
+
+jxlh_status jxlh_free_pinned(jxlh_ctx* ctx, void* p) {
+  if (!ctx) return JXLH_ERR_INVALID_ARGUMENT;
+  if (p) HIPCHK(ctx, hipHostFree(p));
+  return JXLH_OK;
+}
+
+jxlh_status jxlh_frame_begin(jxlh_ctx* ctx, const jxlh_frame_params* p) {
+  if (!ctx || !p || p->abi_version != JXLH_ABI_VERSION) return JXLH_ERR_INVALID_ARGUMENT;
+  if (p->xsize == 0 || p->ysize == 0 || p->xsize > (1u << 20) || p->ysize > (1u << 20) || p->global_scale == 0 ||
+      p->quant_lf == 0 || p->color_factor == 0 || p->epf_iters > 3)
+    return JXLH_ERR_INVALID_ARGUMENT;
+  // chroma subsampling (JPEG recompressions): jpeg_upsampling gives shifts of 0 or 1 per axis and channel,
+  // relative to the most finely sampled channel (headers/frame_header.rs:252-253, :501-512)
+  if (p->upsampling > 1 && p->upsampling != 2 && p->upsampling != 4 && p->upsampling != 8) return JXLH_ERR_INVALID_ARGUMENT;
+  if (p->upsampling > 1) {  // FrameHeader::size() = ceil(size_upsampled / upsampling) (headers/frame_header.rs:555-561)
+    const uint32_t n = p->upsampling;
+    if (p->xsize_upsampled > p->xsize * n || p->ysize_upsampled > p->ysize * n ||
+        (p->xsize_upsampled && (p->xsize_upsampled + n - 1) / n != p->xsize) ||
+        (p->ysize_upsampled && (p->ysize_upsampled + n - 1) / n != p->ysize))
+      return JXLH_ERR_INVALID_ARGUMENT;
+  }
+  uint32_t maxhs = 0, maxvs = 0;
+  for (int c = 0; c < 3; c++) {
+    if (p->hshift[c] > 1 || p->vshift[c] > 1) return JXLH_ERR_INVALID_ARGUMENT;
+    maxhs |= p->hshift[c];
+    maxvs |= p->vshift[c];
+  }
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  ctx->params = *p;
+  FrameDev& f = ctx->fd;
+  std::memset(&f, 0, sizeof f);
+  f.xsize = (int)p->xsize;
+  f.ysize = (int)p->ysize;
+  // FrameHeader::size_blocks (headers/frame_header.rs:564-569): whole blocks of the coarsest channel
+  f.xblocks = (int)(((p->xsize + (8u << maxhs) - 1) / (8u << maxhs)) << maxhs);
+  f.yblocks = (int)(((p->ysize + (8u << maxvs) - 1) / (8u << maxvs)) << maxvs);
+  f.subsampled = (maxhs | maxvs) != 0;
+  for (int c = 0; c < 3; c++) {
+    f.hshift[c] = (int)p->hshift[c];
+    f.vshift[c] = (int)p->vshift[c];
+  }
+  f.xgroups = (int)((p->xsize + kGroupDim - 1) / kGroupDim);
+  f.ygroups = (int)((p->ysize + kGroupDim - 1) / kGroupDim);
+  f.cmap_stride = (f.xblocks + 7) / 8;
+  f.plane_stride = round_up((size_t)f.xblocks * 8, 64);
+  const size_t plane_elems = f.plane_stride * (size_t)f.yblocks * 8;
+  // a sharded frame is all-gathered in place with equal counts per rank: room for nranks whole bands
+  const size_t gather_elems = (size_t)comm_nranks(ctx) * comm_rows_per_rank(ctx, f.ygroups) * kGroupDim * f.plane_stride;
+  // K1 uses 32-bit pixel and coefficient offsets
+  // planes are addressed with 32-bit BYTE offsets in the filter kernels, coefficients with 32-bit indices
+  if (plane_elems >= (1ull << 30) || (size_t)f.xgroups * f.ygroups * 3 * kGroupArea >= (1ull << 31))
+    return JXLH_ERR_UNSUPPORTED;
+  ctx->ngroups = (size_t)f.xgroups * f.ygroups;
+  {
+    std::lock_guard<std::mutex> lock(ctx->sp_mutex);
+    ctx->sp_pending.clear();
+    ctx->sp_wide.clear();
+    ctx->sp_used = 0;
+    ctx->touched.assign(ctx->ngroups, 0);
+    ctx->epoch_dirty = false;
+    ctx->sp_sorted_valid = false;
+  }
+  const size_t nblocks = (size_t)f.xblocks * f.yblocks;
+  const size_t ncmap = (size_t)f.cmap_stride * ((f.yblocks + 7) / 8);
+  jxlh_status st;
+  for (int c = 0; c < 3; c++) {
+    if ((st = ensure(ctx, ctx->planes[c], std::max(plane_elems, gather_elems))) != JXLH_OK) return st;
+    // + one block row: the scrap tile K1 stores the blocks a sub-sampled channel does not hold into
+    if ((st = ensure(ctx, ctx->tmp[c], std::max(plane_elems + 8 * f.plane_stride, gather_elems))) != JXLH_OK) return st;
+    if ((st = ensure(ctx, ctx->lf_raw[c], nblocks)) != JXLH_OK) return st;
+    if ((st = ensure(ctx, ctx->lf_sm[c], nblocks)) != JXLH_OK) return st;
+  }
+  if ((st = ensure(ctx, ctx->sigma, nblocks)) != JXLH_OK) return st;
+  if ((st = ensure(ctx, ctx->coeffs, ctx->ngroups * 3 * kGroupArea)) != JXLH_OK) return st;
+  if ((st = ensure(ctx, ctx->raw_quant, nblocks)) != JXLH_OK) return st;
+  if ((st = ensure(ctx, ctx->transform_map, nblocks)) != JXLH_OK) return st;
+  if ((st = ensure(ctx, ctx->epf_map, nblocks)) != JXLH_OK) return st;
+  if ((st = ensure(ctx, ctx->ytox, ncmap)) != JXLH_OK) return st;
+  if ((st = ensure(ctx, ctx->ytob, ncmap)) != JXLH_OK) return st;
+  if ((st = ensure(ctx, ctx->error_flag, 1)) != JXLH_OK) return st;
+  if ((st = ensure(ctx, ctx->worklist, vardct_worklist_bytes(f))) != JXLH_OK) return st;
+  HIPCHK(ctx, hipMemsetAsync(ctx->error_flag.p, 0, sizeof(int), ctx->stream));
+  // rects the caller never sets read as "not the first block of a varblock" (no work item, no stale map bytes of
+  // an earlier frame reaching K1)
+  HIPCHK(ctx, hipMemsetAsync(ctx->transform_map.p, 0, nblocks, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(ctx->raw_quant.p, 0, nblocks * sizeof(int32_t), ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(ctx->epf_map.p, 0, nblocks, ctx->stream));
+  for (int c = 0; c < 3; c++) {
+    f.planes[c] = ctx->planes[c].p;
+    f.tmp[c] = ctx->tmp[c].p;
+    f.lf[c] = ctx->lf_raw[c].p;
+  }
+  f.scrap_off = (int)plane_elems;
+  f.coeffs = ctx->coeffs.p;
+  f.transform_map = ctx->transform_map.p;
+  f.raw_quant = ctx->raw_quant.p;
+  f.epf_map = ctx->epf_map.p;
+  f.ytox = ctx->ytox.p;
+  f.ytob = ctx->ytob.p;
+  f.inv_sigma = ctx->sigma.p;
+  // scalars, evaluated like the reference does on the host
+  f.inv_global_scale = (float)(1 << 16) / (float)p->global_scale;        // quantizer.rs:79-81
+  f.x_dm = powf(1.0f / 1.25f, (float)p->x_qm_scale - 2.0f);              // group.rs:395
+  f.b_dm = powf(1.0f / 1.25f, (float)p->b_qm_scale - 2.0f);              // group.rs:396
+  for (int i = 0; i < 4; i++) f.quant_biases[i] = p->quant_biases[i];
+  f.color_factor = (float)p->color_factor;
+  f.base_x = p->base_correlation_x;
+  f.base_b = p->base_correlation_b;
+  set_filter_params(f, *p);
+  ctx->in_frame = true;
+  // dequant tables persist across frames until replaced (library tables are per-decoder,
+  // quant_weights.rs:356-374)
+  ctx->tables_set = ctx->tables.p != nullptr && ctx->tables_set;
+  if (ctx->tables_set) {
+    f.tables = ctx->tables.p;
+    for (int q = 0; q < JXLH_NUM_QUANT_TABLES; q++) f.table_offset[q] = ctx->table_offset[q];
+  }
+  ctx->lf_smoothed = false;
+  ctx->rendered = false;
+  ctx->has_special = ctx->has_large = false;
+  for (auto& s : ctx->slots) s.used = false;
+  for (int c = 0; c < 3; c++) ctx->result[c] = nullptr;
+  ctx->chroma_lazy = false;
+  return JXLH_OK;
+}
+
+jxlh_status jxlh_set_upsampling_weights(jxlh_ctx* ctx, const float* weights2, const float* weights4,
+                                        const float* weights8) {
+  if (!ctx) return JXLH_ERR_INVALID_ARGUMENT;
+  const float* src[3] = {weights2, weights4, weights8};
+  const size_t cnt[3] = {15, 55, 210};
+  for (int i = 0; i < 3; i++) {
+    if (src[i]) ctx->ups_weights[i].assign(src[i], src[i] + cnt[i]);
+    else ctx->ups_weights[i].clear();
+  }
+  return JXLH_OK;
+}
+
+jxlh_status jxlh_frame_set_dequant_tables(jxlh_ctx* ctx, const float* const tables[JXLH_NUM_QUANT_TABLES],
+                                          const size_t n[JXLH_NUM_QUANT_TABLES]) {
+  if (!ctx || !tables || !n) return JXLH_ERR_INVALID_ARGUMENT;
+  if (!ctx->in_frame) return JXLH_ERR_BAD_STATE;
+  size_t total = 0;
+  for (int q = 0; q < JXLH_NUM_QUANT_TABLES; q++) {
+    if (!tables[q] || n[q] != (size_t)quant_table_size(q)) return JXLH_ERR_INVALID_ARGUMENT;
+    total += 3 * n[q];
+  }
+  jxlh_status st = ensure(ctx, ctx->tables, total);
+  if (st != JXLH_OK) return st;
+  size_t off = 0;
+  for (int q = 0; q < JXLH_NUM_QUANT_TABLES; q++) {
+    ctx->fd.table_offset[q] = (int)off;
+    ctx->table_offset[q] = (int)off;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->tables.p + off, tables[q], 3 * n[q] * sizeof(float), hipMemcpyDefault,
+                               ctx->stream));
+    off += 3 * n[q];
+  }
+  ctx->fd.tables = ctx->tables.p;
+  ctx->tables_set = true;
+  // like the other setters: the caller's buffers may be reused (or freed) as soon as the call returns
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return JXLH_OK;
+}
+
+static bool rect_ok(const jxlh_ctx* ctx, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h) {
+  return (uint64_t)x0 + w <= (uint64_t)ctx->fd.xblocks && (uint64_t)y0 + h <= (uint64_t)ctx->fd.yblocks;
+}
+
+jxlh_status jxlh_frame_set_lf_quantized(jxlh_ctx* ctx, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
+                                        const int32_t* qy, const int32_t* qx, const int32_t* qb, size_t stride,
+                                        uint32_t extra_precision) {
+  if (!ctx || !qy || !qx || !qb || stride < w || extra_precision > 3) return JXLH_ERR_INVALID_ARGUMENT;
+  if (!ctx->in_frame) return JXLH_ERR_BAD_STATE;
+  if (!rect_ok(ctx, x0, y0, w, h)) return JXLH_ERR_INVALID_ARGUMENT;
+  if (w == 0 || h == 0) return JXLH_OK;
+  const size_t n = (size_t)w * h;
+  jxlh_status st = ensure(ctx, ctx->lfq, 3 * n);
+  if (st != JXLH_OK) return st;
+  // the scratch is reused by the next call: order uploads and kernel on the main stream
+  const int32_t* src[3] = {qy, qx, qb};
+  for (int c = 0; c < 3; c++) {
+    st = copy2d(ctx, ctx->lfq.p + c * n, w * sizeof(int32_t), src[c], stride * sizeof(int32_t), w * sizeof(int32_t), h,
+                ctx->stream);
+    if (st != JXLH_OK) return st;
+  }
+  const jxlh_frame_params& p = ctx->params;
+  // dequant_lf, modular/mod.rs:849-879
+  const float inv_quant_lf = (float)(1 << 16) / ((float)p.global_scale * (float)p.quant_lf);
+  const float mul = 1.0f / (float)(1u << extra_precision);
+  const float fac_x = (p.lf_quant_factors[0] * inv_quant_lf) * mul;
+  const float fac_y = (p.lf_quant_factors[1] * inv_quant_lf) * mul;
+  const float fac_b = (p.lf_quant_factors[2] * inv_quant_lf) * mul;
+  const float cfl_x = p.base_correlation_x + (float)p.ytox_lf / (float)p.color_factor;
+  const float cfl_b = p.base_correlation_b + (float)p.ytob_lf / (float)p.color_factor;
+  const size_t off = (size_t)y0 * ctx->fd.xblocks + x0;
+  {
+    ScopedKernelTimer t(ctx, "k0a_dequant_lf");
+    if (ctx->fd.subsampled)  // !is444(): no chroma-from-luma; the samples beyond (size >> shift) are don't-cares
+      launch_dequant_lf_plain(ctx->stream, ctx->lfq.p, ctx->lfq.p + n, ctx->lfq.p + 2 * n, w, ctx->lf_raw[0].p + off,
+                              ctx->lf_raw[1].p + off, ctx->lf_raw[2].p + off, ctx->fd.xblocks, (int)w, (int)h, fac_x,
+                              fac_y, fac_b);
+    else
+      launch_dequant_lf(ctx->stream, ctx->lfq.p, ctx->lfq.p + n, ctx->lfq.p + 2 * n, w, ctx->lf_raw[0].p + off,
+                        ctx->lf_raw[1].p + off, ctx->lf_raw[2].p + off, ctx->fd.xblocks, (int)w, (int)h, fac_x, fac_y,
+                        fac_b, cfl_x, cfl_b);
+  }
+  HIPCHK(ctx, hipGetLastError());
+  // the host buffers may be reused by the caller as soon as we return
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->lf_smoothed = false;
+  return JXLH_OK;
+}
+
+jxlh_status jxlh_frame_set_lf(jxlh_ctx* ctx, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, const float* x,
+                              const float* y, const float* b, size_t stride) {
+  if (!ctx || !x || !y || !b || stride < w) return JXLH_ERR_INVALID_ARGUMENT;
+  if (!ctx->in_frame) return JXLH_ERR_BAD_STATE;
+  if (!rect_ok(ctx, x0, y0, w, h)) return JXLH_ERR_INVALID_ARGUMENT;
+  const float* src[3] = {x, y, b};
+  const size_t off = (size_t)y0 * ctx->fd.xblocks + x0;
+  for (int c = 0; c < 3; c++) {
+    jxlh_status st = copy2d(ctx, ctx->lf_raw[c].p + off, ctx->fd.xblocks * sizeof(float), src[c],
+                            stride * sizeof(float), w * sizeof(float), h, ctx->stream);
+    if (st != JXLH_OK) return st;
+  }
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->lf_smoothed = false;
+  return JXLH_OK;
+}
+
+jxlh_status jxlh_frame_set_hf_meta(jxlh_ctx* ctx, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
+                                   const uint8_t* transform_map, const int32_t* raw_quant, const uint8_t* epf_map,
+                                   size_t map_stride, const int8_t* ytox, const int8_t* ytob, size_t cmap_stride) {
+  if (!ctx || !transform_map || !raw_quant || !epf_map || !ytox || !ytob || map_stride < w)
+    return JXLH_ERR_INVALID_ARGUMENT;
+  if (!ctx->in_frame) return JXLH_ERR_BAD_STATE;
+  if (!rect_ok(ctx, x0, y0, w, h) || (x0 % 8) || (y0 % 8)) return JXLH_ERR_INVALID_ARGUMENT;
+  const size_t cw = (w + 7) / 8, ch = (h + 7) / 8;
+  if (cmap_stride < cw) return JXLH_ERR_INVALID_ARGUMENT;
+  const size_t off = (size_t)y0 * ctx->fd.xblocks + x0;
+  const size_t coff = (size_t)(y0 / 8) * ctx->fd.cmap_stride + x0 / 8;
+  // which of the rarely used transform families the frame holds at all (their kernels are not even launched for a
+  // frame without them: four empty launches cost ~20 us of a 0.45 ms K1).  A map that arrives in device memory is not
+  // inspected: both families are then assumed present.
+  if (is_device_ptr(transform_map)) {
+    ctx->has_special = ctx->has_large = true;
+  } else if (!(ctx->has_special && ctx->has_large)) {
+    bool sp = false, lg = false;
+    for (uint32_t y = 0; y < h; y++) {
+      const uint8_t* row = transform_map + (size_t)y * map_stride;
+      for (uint32_t x = 0; x < w; x++) {
+        const uint8_t t = row[x] & 127;
+        lg |= t >= 18;
+        sp |= (t >= 1 && t <= 3) || (t >= 12 && t <= 17);
+      }
+    }
+    ctx->has_special |= sp;
+    ctx->has_large |= lg;
+  }
+  jxlh_status st;
+  if ((st = copy2d(ctx, ctx->transform_map.p + off, ctx->fd.xblocks, transform_map, map_stride, w, h, ctx->stream)))
+    return st;
+  if ((st = copy2d(ctx, ctx->epf_map.p + off, ctx->fd.xblocks, epf_map, map_stride, w, h, ctx->stream))) return st;
+  if ((st = copy2d(ctx, ctx->raw_quant.p + off, ctx->fd.xblocks * sizeof(int32_t), raw_quant,
+                   map_stride * sizeof(int32_t), w * sizeof(int32_t), h, ctx->stream)))
+    return st;
+  if ((st = copy2d(ctx, ctx->ytox.p + coff, ctx->fd.cmap_stride, ytox, cmap_stride, cw, ch, ctx->stream))) return st;
+  if ((st = copy2d(ctx, ctx->ytob.p + coff, ctx->fd.cmap_stride, ytob, cmap_stride, cw, ch, ctx->stream))) return st;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return JXLH_OK;
+}
+
+}  // extern "C"
+
+namespace jxlh_host {
+namespace {
+#include "upsampling_weights.inc"
+// Upsample::new (render/stages/upsample.rs:31-66): the 15 / 55 / 210 weights are the upper triangle of the
+// symmetric top-left quadrant of the (5n/2 x 2)^2 kernel image; expands to n*n kernels of 5x5 taps
+void expand_upsampling_kernels(int n, const float* weights, float* flat) {
+  const int half = n / 2, last = n - 1;
+  for (int i = 0; i < 5 * half; i++) {
+    for (int j = 0; j < 5 * half; j++) {
+      const int y = std::min(i, j), x = std::max(i, j);
+      const float wv = weights[5 * half * y - y * (y - 1) / 2 + x - y];
+      const int oy = j / 5, ox = i / 5, ky = j % 5, kx = i % 5;
+      flat[(oy * n + ox) * 25 + ky * 5 + kx] = wv;
+      flat[((last - oy) * n + ox) * 25 + (4 - ky) * 5 + kx] = wv;
+      flat[(oy * n + (last - ox)) * 25 + ky * 5 + (4 - kx)] = wv;
+      flat[((last - oy) * n + (last - ox)) * 25 + (4 - ky) * 5 + (4 - kx)] = wv;
+    }
+  }
+}
+}  // namespace
+
+jxlh_status ensure_jump_table(jxlh_ctx* ctx) {
+  if (ctx->xs_jump.p) return JXLH_OK;
+  static uint64_t table[16][128][2];
+  static std::once_flag once;
+  std::call_once(once, [] { xorshift_jump_table(table); });
+  if (jxlh_status st = ensure(ctx, ctx->xs_jump, sizeof(table) / sizeof(uint64_t))) return st;
+  HIPCHK(ctx, hipMemcpyAsync(ctx->xs_jump.p, table, sizeof(table), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return JXLH_OK;
+}
+
+bool noise_lut_is_zero(const float lut[8]) {
+  for (int i = 0; i < 8; i++)
+    if (lut[i] != 0.0f) return false;
+  return true;
+}
+
+// chroma upsampling of the sub-sampled channels, tmp[c] -> planes[c], over the rows K1 produced for group rows
+// [gr0, gr1) (the outermost rows of a halo group row read beyond the region, and nobody reads them)
+void run_chroma_upsample(jxlh_ctx* ctx, int gr0, int gr1) {
+  const FrameDev& f = ctx->fd;
+  ScopedKernelTimer t(ctx, "k_chroma_upsample");
+  const PixLayout lay = pix_layout(f);
+  for (int c = 0; c < 3; c++) {
+    const int hs = f.hshift[c], vs = f.vshift[c];
+    if (!(hs | vs)) continue;
+    const int cw = (f.xsize + (1 << hs) - 1) >> hs, ch = (f.ysize + (1 << vs) - 1) >> vs;
+    const int sy0 = (gr0 * kGroupDim) >> vs, sy1 = min(ch, (gr1 * kGroupDim) >> vs);
+    launch_chroma_upsample(ctx->stream, f.tmp[c], f.planes[c], lay, lay, hs, vs, cw, ch, sy0, sy1, f.xblocks * 8,
+                           f.yblocks * 8);
+  }
+}
+
+void materialise_chroma(jxlh_ctx* ctx) {
+  if (!ctx->chroma_lazy) return;
+  run_chroma_upsample(ctx, ctx->lazy_gr0, ctx->lazy_gr1);
+  ctx->chroma_lazy = false;
+}
+
+jxlh_status upload_upsampling_kernels(jxlh_ctx* ctx, int n) {
+  const int slot = n == 2 ? 0 : n == 4 ? 1 : 2;
+  const float* dflt = n == 2 ? kDefaultUpsamplingWeights2 : n == 4 ? kDefaultUpsamplingWeights4 : kDefaultUpsamplingWeights8;
+  const float* w = ctx->ups_weights[slot].empty() ? dflt : ctx->ups_weights[slot].data();
+  std::vector<float> flat((size_t)n * n * 25);
+  expand_upsampling_kernels(n, w, flat.data());
+  if (jxlh_status st = ensure(ctx, ctx->ups_kernels, flat.size())) return st;
+  // pageable source: the copy is staged by the runtime before the call returns
+  HIPCHK(ctx, hipMemcpyAsync(ctx->ups_kernels.p, flat.data(), flat.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return JXLH_OK;
+}
+
+// everything before K1: upload fences, sparse coefficient transport, K0b, K3 sigma
+jxlh_status run_prologue(jxlh_ctx* ctx, RunPlan* plan) {
+  FrameDev& f = ctx->fd;
+  const jxlh_frame_params& p = ctx->params;
+  // coefficient uploads issued on slot streams must land before K1
+  for (auto& s : ctx->slots) {
+    if (s.used) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, s.done, 0));
+  }
+  // ---- sparse coefficient transport.  Preferred: K1 reads the pairs itself (bucketed by varblock slot
+  // first) -- possible when every group arrived as pairs in this epoch and no value needed the wide
+  // list.  Otherwise everything ends up in the dense slabs: groups whose content so far lived only in
+  // the bucketed form are expanded from it, this epoch's pairs are zero-filled + scattered.
+  bool sparse_k1 = false;
+  {
+    std::lock_guard<std::mutex> lock(ctx->sp_mutex);
+    if (ctx->epoch_dirty) {
+      ctx->sp_upload.swap(ctx->sp_pending);  // stays alive until the next run: the H2D copies read it
+      ctx->sp_wide_upload.swap(ctx->sp_wide);
+      ctx->sp_pending.clear();
+      ctx->sp_wide.clear();
+      const size_t ng = ctx->sp_upload.size(), nw = ctx->sp_wide_upload.size();
+      if (jxlh_status st = ensure(ctx, ctx->sp_groups_dev, ng)) return st;
+      if (jxlh_status st = ensure(ctx, ctx->sp_wide_dev, nw)) return st;
+      if (jxlh_status st = ensure(ctx, ctx->group_dense, ctx->ngroups)) return st;
+      if (ng)
+        HIPCHK(ctx, hipMemcpyAsync(ctx->sp_groups_dev.p, ctx->sp_upload.data(), ng * sizeof(SparseGroup),
+                                   hipMemcpyHostToDevice, ctx->stream));
+      if (nw)
+        HIPCHK(ctx, hipMemcpyAsync(ctx->sp_wide_dev.p, ctx->sp_wide_upload.data(), nw * sizeof(uint2),
+                                   hipMemcpyHostToDevice, ctx->stream));
+      bool all_pairs = nw == 0 && ng == ctx->ngroups && !(p.flags & JXLH_FRAME_EXPAND_SPARSE);
+      for (size_t g = 0; all_pairs && g < ctx->ngroups; g++) all_pairs = ctx->touched[g] == 2;
+      // pairs that ADD to a group's earlier passes need that group's dense slab
+      std::vector<uint8_t> accum(ctx->ngroups, 0);
+      for (const SparseGroup& sg : ctx->sp_upload) {
+        if (sg.flags & 1u) {
+          accum[sg.group] = 1;
+          all_pairs = false;
+        }
+      }
+      if (ctx->sp_sorted_valid && !all_pairs) {
+        // leaving the bucketed form: groups not resubmitted now (or only added to) need their dense slab
+        ctx->flag_upload.assign(ctx->ngroups, 0);
+        bool any = false;
+        for (size_t g = 0; g < ctx->ngroups; g++)
+          any |= (ctx->flag_upload[g] = (ctx->touched[g] == 0 || accum[g]) ? 1 : 0) != 0;
+        if (any) {
+          HIPCHK(ctx, hipMemcpyAsync(ctx->group_dense.p, ctx->flag_upload.data(), ctx->ngroups, hipMemcpyHostToDevice,
+                                     ctx->stream));
+          ScopedKernelTimer t(ctx, "k_expand_sparse");
+          launch_expand_sorted(ctx->stream, ctx->coeffs.p, ctx->sp_sorted.p, ctx->sp_slot_start.p, ctx->group_dense.p,
+                               (int)ctx->ngroups);
+        }
+      }
+      if (all_pairs) {
+        const size_t capacity = ctx->ngroups * 3 * (size_t)kGroupArea;
+        if (jxlh_status st = ensure(ctx, ctx->sp_sorted, capacity)) return st;
+        if (jxlh_status st = ensure(ctx, ctx->sp_slot_start, ctx->ngroups * 3 * (size_t)kSlotTable)) return st;
+        ScopedKernelTimer t(ctx, "k_sort_sparse");
+        launch_sort_sparse(ctx->stream, ctx->sp_pairs.p, ctx->sp_groups_dev.p, (int)ng, ctx->sp_sorted.p,
+                           ctx->sp_slot_start.p);
+        ctx->sp_sorted_valid = true;
+      } else {
+        if (ng || nw) {
+          ScopedKernelTimer t(ctx, "k_expand_sparse");
+          launch_expand_sparse(ctx->stream, ctx->coeffs.p, ctx->sp_pairs.p, ctx->sp_groups_dev.p, (int)ng,
+                               ctx->sp_wide_dev.p, (uint32_t)nw, nullptr);
+        }
+        ctx->sp_sorted_valid = false;
+      }
+      ctx->sp_used = 0;
+      ctx->touched.assign(ctx->ngroups, 0);
+      ctx->epoch_dirty = false;
+      if (ctx->sp_expanded) {  // the pair buffer has been consumed (bucketed or expanded)
+        HIPCHK(ctx, hipEventRecord(ctx->sp_expanded, ctx->stream));
+        ctx->sp_expanded_valid = true;
+      }
+    }
+    sparse_k1 = ctx->sp_sorted_valid;
+  }
+  plan->sparse_k1 = sparse_k1;
+  // ---- K0b: Frame::finalize_lf (frame/mod.rs:360-378)
+  const bool smooth = p.do_lf_smoothing && f.xblocks > 2 && f.yblocks > 2;  // adaptive_lf_smoothing.rs:51-53
+  if (smooth) {
+    {  // out of place (raw -> smoothed), so re-running a frame repeats the full work
+      const float inv_quant_lf = f.inv_global_scale / (float)p.quant_lf;  // quantizer.rs:82-84
+      const float lf_factors[3] = {inv_quant_lf * p.lf_quant_factors[0], inv_quant_lf * p.lf_quant_factors[1],
+                                   inv_quant_lf * p.lf_quant_factors[2]};
+      const float* in[3] = {ctx->lf_raw[0].p, ctx->lf_raw[1].p, ctx->lf_raw[2].p};
+      float* out[3] = {ctx->lf_sm[0].p, ctx->lf_sm[1].p, ctx->lf_sm[2].p};
+      ScopedKernelTimer t(ctx, "k0b_lf_smooth");
+      launch_lf_smooth(ctx->stream, in, out, f.xblocks, f.yblocks, lf_factors);
+      ctx->lf_smoothed = true;
+    }
+    for (int c = 0; c < 3; c++) f.lf[c] = ctx->lf_sm[c].p;
+  } else {
+    for (int c = 0; c < 3; c++) f.lf[c] = ctx->lf_raw[c].p;
+  }
+  // ---- K3 sigma: SigmaSource::new (features/epf.rs:35-87)
+  if (f.epf_iters > 0) {
+    ScopedKernelTimer t(ctx, "k3_sigma_map");
+    launch_sigma_map(ctx->stream, f, p.epf_quant_mul, p.epf_sharp_lut);
+  }
+  plan->halo_px = (f.gab ? 1 : 0) + (f.epf_iters >= 3 ? 3 : 0) + (f.epf_iters >= 1 ? 2 : 0) + (f.epf_iters >= 2 ? 1 : 0);
+  // K1 writes the 8x8-tiled layout whenever the fused filter kernel is its only consumer
+  plan->will_fuse = !(p.flags & JXLH_FRAME_UNFUSED_FILTERS) && (f.gab || f.epf_iters > 0);
+  f.tiled = plan->will_fuse ? 1 : 0;
+  return JXLH_OK;
+}
+
+// K1 for group rows [gr0, gr1) (+ the chroma upsampling of a sub-sampled frame)
+jxlh_status run_k1(jxlh_ctx* ctx, const RunPlan& plan, int gr0, int gr1) {
+  FrameDev& f = ctx->fd;
+  const jxlh_frame_params& p = ctx->params;
+  const bool sparse_k1 = plan.sparse_k1;
+  {
+    ScopedKernelTimer t(ctx, "k1_vardct");
+    f.sp_sorted = sparse_k1 ? ctx->sp_sorted.p : nullptr;
+    f.sp_slot_start = sparse_k1 ? ctx->sp_slot_start.p : nullptr;
+    f.group_dense = sparse_k1 ? ctx->group_dense.p : nullptr;
+    if (sparse_k1) HIPCHK(ctx, hipMemsetAsync(ctx->group_dense.p, 0, ctx->ngroups, ctx->stream));
+    // a sub-sampled channel is reconstructed at its own resolution into tmp[c] ...
+    FrameDev fk = f;
+    for (int c = 0; c < 3; c++)
+      if (f.hshift[c] | f.vshift[c]) fk.planes[c] = f.tmp[c];
+    launch_vardct_groups(ctx->stream, fk, gr0, gr1, ctx->worklist.p, ctx->error_flag.p,
+                         sparse_k1 ? ctx->coeffs.p : nullptr, nullptr, 0, ctx->has_special, ctx->has_large);
+  }
+  // the coefficient slabs are free again: dense resubmissions of the next frame wait for this (jxlh_submit_group)
+  if (!ctx->k1_done) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->k1_done, hipEventDisableTiming));
+  HIPCHK(ctx, hipEventRecord(ctx->k1_done, ctx->stream));
+  ctx->k1_done_valid = true;
+  ctx->chroma_lazy = false;
+  if (f.subsampled) {
+    // ... and brought to full resolution into planes[c] before any filter (frame/render.rs:569-576) -- or, when no
+    // stage follows at all, only when the planes are asked for (materialise_chroma)
+    const bool stages_follow = f.gab || f.epf_iters > 0 || p.upsampling > 1 || (p.noise && !noise_lut_is_zero(p.noise_lut));
+    ctx->lazy_gr0 = gr0;
+    ctx->lazy_gr1 = gr1;
+    // A sharded frame gathers planes[c] band by band (jxlh_frame_allgather): the full-resolution chroma must exist
+    // on every rank before the gather, and a deferred upsampling would cover only this rank's band afterwards.
+    if (stages_follow || jxlh_host::comm_nranks(ctx) > 1) run_chroma_upsample(ctx, gr0, gr1);
+    else ctx->chroma_lazy = true;
+  }
+  return JXLH_OK;
+}
+
+// the stage list on group rows [group_row0, group_row1), then upsampling and noise
+jxlh_status run_stages(jxlh_ctx* ctx, const RunPlan& plan, uint32_t group_row0, uint32_t group_row1) {
+  const bool whole = group_row0 == 0 && group_row1 == (uint32_t)ctx->fd.ygroups;
+  return run_stages_rows(ctx, plan, (int)group_row0 * kGroupDim, min((int)group_row1 * kGroupDim, ctx->fd.ysize), whole);
+}
+
+// ... on pixel rows [y_lo, y_hi)
+jxlh_status run_stages_rows(jxlh_ctx* ctx, const RunPlan& plan, int y_lo, int y_hi, bool whole_frame) {
+  FrameDev& f = ctx->fd;
+  const jxlh_frame_params& p = ctx->params;
+  (void)plan;
+  // ---- stage list of frame/render.rs:569-622
+  int stages[4], borders[4], ns = 0;
+  if (f.gab) { stages[ns] = -1; borders[ns++] = 1; }
+  if (f.epf_iters >= 3) { stages[ns] = 0; borders[ns++] = 3; }
+  if (f.epf_iters >= 1) { stages[ns] = 1; borders[ns++] = 2; }
+  if (f.epf_iters >= 2) { stages[ns] = 2; borders[ns++] = 1; }
+  float* cur[3] = {f.planes[0], f.planes[1], f.planes[2]};
+  float* oth[3] = {f.tmp[0], f.tmp[1], f.tmp[2]};
+  if (!(p.flags & JXLH_FRAME_UNFUSED_FILTERS) && ns > 0) {
+    // production path: the whole stage list in one pass over HBM (two for epf_iters == 3)
+    ScopedKernelTimer t(ctx, "k23_fused_filters");
+    const int where = launch_fused_filters(ctx->stream, f, y_lo, y_hi);
+    if (where == 1) {
+      for (int c = 0; c < 3; c++) {
+        cur[c] = f.tmp[c];
+        oth[c] = f.planes[c];
+      }
+      ns = 0;
+    } else if (where == 2) {
+      ns = 0;  // result back in f.planes
+    }
+  }
+  for (int s = 0; s < ns; s++) {
+    int later = 0;
+    for (int k = s + 1; k < ns; k++) later += borders[k];
+    const int y0 = max(0, y_lo - later), y1 = min(f.ysize, y_hi + later);
+    if (stages[s] < 0) {
+      ScopedKernelTimer t(ctx, "k2_gaborish");
+      for (int c = 0; c < 3; c++)
+        launch_gaborish(ctx->stream, cur[c], oth[c], f.xsize, f.ysize, f.plane_stride, f.gab_k[c][0], f.gab_k[c][1],
+                        f.gab_k[c][2], y0, y1);
+    } else {
+      EpfArgs a;
+      for (int c = 0; c < 3; c++) {
+        a.in[c] = cur[c];
+        a.out[c] = oth[c];
+        a.scale[c] = f.epf_channel_scale[c];
+      }
+      a.inv_sigma = f.inv_sigma;
+      a.stride = f.plane_stride;
+      a.sigma_stride = (size_t)f.xblocks;
+      a.w = f.xsize;
+      a.h = f.ysize;
+      a.sm = f.epf_sm[stages[s]];
+      a.bsm = f.epf_bsm[stages[s]];
+      static const char* names[3] = {"k3a_epf0", "k3b_epf1", "k3c_epf2"};
+      ScopedKernelTimer t(ctx, names[stages[s]]);
+      launch_epf(ctx->stream, stages[s], a, y0, y1);
+    }
+    for (int c = 0; c < 3; c++) {
+      float* t = cur[c];
+      cur[c] = oth[c];
+      oth[c] = t;
+    }
+  }
+  for (int c = 0; c < 3; c++) ctx->result[c] = cur[c];
+  ctx->res_w = f.xsize;
+  ctx->res_h = f.ysize;
+  ctx->res_stride = f.plane_stride;
+  if (p.upsampling > 1) {
+    // Upsample2x/4x/8x on the three colour channels (frame/render.rs:655-671).  The 5x5 window crosses band
+    // edges, so an upsampled frame is run whole.
+    if (!whole_frame) return JXLH_ERR_UNSUPPORTED;
+    const int n = (int)p.upsampling;
+    const int ow = p.xsize_upsampled ? (int)p.xsize_upsampled : f.xsize * n;
+    const int oh = p.ysize_upsampled ? (int)p.ysize_upsampled : f.ysize * n;
+    const size_t ostride = round_up((size_t)f.xsize * n, 64);
+    if (jxlh_status st = upload_upsampling_kernels(ctx, n)) return st;
+    for (int c = 0; c < 3; c++)
+      if (jxlh_status st = ensure(ctx, ctx->ups[c], ostride * (size_t)f.ysize * n)) return st;
+    ScopedKernelTimer t(ctx, "k_upsample");
+    for (int c = 0; c < 3; c++) {
+      launch_upsample(ctx->stream, n, cur[c], f.plane_stride, f.xsize, f.ysize, ctx->ups_kernels.p, ctx->ups[c].p,
+                      ostride, ow, oh);
+      ctx->result[c] = ctx->ups[c].p;
+    }
+    ctx->res_w = ow;
+    ctx->res_h = oh;
+    ctx->res_stride = ostride;
+  }
+  if (p.noise && !noise_lut_is_zero(p.noise_lut)) {  // AddNoiseStage returns early on an all-zero LUT (noise.rs:153-155)
+    // render_noise_for_group + ConvolveNoise x3 + AddNoise (frame/decode.rs:578-668, frame/render.rs:673-683),
+    // at the resolution of the result (after upsampling).  Random planes: the 256-row tile rows that cover
+    // the band plus the convolution's 2-row border.
+    const int W = ctx->res_w, H = ctx->res_h;
+    const int ya = p.upsampling > 1 ? 0 : y_lo, yb = p.upsampling > 1 ? H : y_hi;
+    if (jxlh_status st = ensure_jump_table(ctx)) return st;
+    for (int c = 0; c < 3; c++)
+      if (jxlh_status st = ensure(ctx, ctx->noise[c], ctx->res_stride * (size_t)H)) return st;
+    float* nz[3] = {ctx->noise[0].p, ctx->noise[1].p, ctx->noise[2].p};
+    const int ty0 = max(0, ya - 2) / 256, ty1 = (min(H, yb + 2) + 255) / 256;
+    {
+      ScopedKernelTimer t(ctx, "k_noise_generate");
+      launch_noise_generate(ctx->stream, nz, ctx->res_stride, W, H, ty0, ty1, p.visible_frame_index,
+                            p.nonvisible_frame_index, ctx->xs_jump.p);
+    }
+    const float ytox = p.base_correlation_x + (float)p.ytox_lf / (float)p.color_factor;  // y_to_x_lf
+    const float ytob = p.base_correlation_b + (float)p.ytob_lf / (float)p.color_factor;
+    ScopedKernelTimer t(ctx, "k_noise_apply");
+    launch_noise_apply(ctx->stream, nz, ctx->res_stride, ctx->result, ctx->res_stride, W, H, ya, yb, p.noise_lut, ytox,
+                       ytob);
+  }
+  HIPCHK(ctx, hipGetLastError());
+  return JXLH_OK;
+}
+}  // namespace jxlh_host
+
+extern "C" {
+
+jxlh_status jxlh_frame_run(jxlh_ctx* ctx, uint32_t group_row0, uint32_t group_row1) {
+  if (!ctx) return JXLH_ERR_INVALID_ARGUMENT;
+  if (!ctx->in_frame || !ctx->tables_set) return JXLH_ERR_BAD_STATE;
+  FrameDev& f = ctx->fd;
+  if (group_row1 > (uint32_t)f.ygroups) group_row1 = (uint32_t)f.ygroups;
+  if (group_row0 >= group_row1) return JXLH_ERR_INVALID_ARGUMENT;
+  RunPlan plan;
+  if (jxlh_status st = run_prologue(ctx, &plan)) return st;
+  // ---- K1 on the band plus one halo group row on each side (filters read across it)
+  // (vertical chroma upsampling reads one sub-sampled row beyond the band as well)
+  const bool need_halo = plan.halo_px > 0 || f.subsampled;
+  const int gr0 = need_halo && group_row0 > 0 ? (int)group_row0 - 1 : (int)group_row0;
+  const int gr1 = need_halo && group_row1 < (uint32_t)f.ygroups ? (int)group_row1 + 1 : (int)group_row1;
+  if (jxlh_status st = run_k1(ctx, plan, gr0, gr1)) return st;
+  if (group_row0 == 0 && group_row1 == (uint32_t)f.ygroups) ctx->rendered = true;
+  return run_stages(ctx, plan, group_row0, group_row1);
+}
+
+jxlh_status jxlh_frame_rerender_groups(jxlh_ctx* ctx, const uint32_t* group_ids, uint32_t count) {
+  if (!ctx || (count && !group_ids)) return JXLH_ERR_INVALID_ARGUMENT;
+  if (!ctx->in_frame || !ctx->tables_set) return JXLH_ERR_BAD_STATE;
+  FrameDev& f = ctx->fd;
+  for (uint32_t i = 0; i < count; i++)
+    if (group_ids[i] >= ctx->ngroups) return JXLH_ERR_INVALID_ARGUMENT;
+  if (count == 0) return JXLH_OK;
+  const jxlh_frame_params& p = ctx->params;
+  if (p.upsampling > 1) return JXLH_ERR_UNSUPPORTED;  // like a band run: the 5x5 upsampling window crosses groups
+  // a rank of a sharded frame holds only its band: progressive re-renders run on unsharded contexts
+  if (comm_nranks(ctx) > 1) return JXLH_ERR_UNSUPPORTED;
+  const int ns = (f.gab ? 1 : 0) + (f.epf_iters >= 3 ? 1 : 0) + (f.epf_iters >= 1 ? 1 : 0) + (f.epf_iters >= 2 ? 1 : 0);
+  // Re-rendering a group needs its neighbours' UNFILTERED pixels (the filters read across the group edge).  They
+  // are still in `planes` when the stage list leaves its result in `tmp` (the fused path with up to two EPF passes,
+  // or no filter at all); a stage list that ends in `planes` has overwritten them, a sub-sampled frame keeps them
+  // in another form, and a frame that was never rendered has none: those render the frame again.
+  const bool per_stage = (p.flags & JXLH_FRAME_UNFUSED_FILTERS) != 0;  // ping-pongs planes <-> tmp: kept only for one stage
+  const bool unfiltered_kept = ns == 0 || (per_stage ? ns == 1 : result_in_tmp(ctx) != 0);
+  // Noise is added IN PLACE to the result planes.  Without a filter stage the result lives in `planes`, the planes K1
+  // writes: the groups that are not re-transformed would receive their noise a second time.
+  const bool noise_in_place = ns == 0 && p.noise && !noise_lut_is_zero(p.noise_lut);
+  if (!ctx->rendered || !unfiltered_kept || f.subsampled || noise_in_place) return jxlh_frame_run(ctx, 0, UINT32_MAX);
+  RunPlan plan;
+  if (jxlh_status st = run_prologue(ctx, &plan)) return st;
+  // ---- transforms of exactly the listed groups
+  ctx->rerender_upload.assign(group_ids, group_ids + count);
+  std::sort(ctx->rerender_upload.begin(), ctx->rerender_upload.end());
+  ctx->rerender_upload.erase(std::unique(ctx->rerender_upload.begin(), ctx->rerender_upload.end()),
+                             ctx->rerender_upload.end());
+  const int n = (int)ctx->rerender_upload.size();
+  if (jxlh_status st = ensure(ctx, ctx->rerender_list, (size_t)n)) return st;
+  HIPCHK(ctx, hipMemcpyAsync(ctx->rerender_list.p, ctx->rerender_upload.data(), n * sizeof(int), hipMemcpyHostToDevice,
+                             ctx->stream));
+  {
+    ScopedKernelTimer t(ctx, "k1_vardct");
+    f.sp_sorted = plan.sparse_k1 ? ctx->sp_sorted.p : nullptr;
+    f.sp_slot_start = plan.sparse_k1 ? ctx->sp_slot_start.p : nullptr;
+    f.group_dense = plan.sparse_k1 ? ctx->group_dense.p : nullptr;
+    if (plan.sparse_k1) HIPCHK(ctx, hipMemsetAsync(ctx->group_dense.p, 0, ctx->ngroups, ctx->stream));
+    launch_vardct_groups(ctx->stream, f, 0, 0, ctx->worklist.p, ctx->error_flag.p,
+                         plan.sparse_k1 ? ctx->coeffs.p : nullptr, ctx->rerender_list.p, n, ctx->has_special,
+                         ctx->has_large);
+  }
+  if (!ctx->k1_done) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->k1_done, hipEventDisableTiming));
+  HIPCHK(ctx, hipEventRecord(ctx->k1_done, ctx->stream));
+  ctx->k1_done_valid = true;
+  // ---- the filters on every pixel row the listed groups influence: their own rows widened by the stage list's
+  // reach (mark_group_to_rerender's 3x3 neighbourhood, restricted to what can actually change), merged into bands
+  int prev_lo = -1, prev_hi = -1;
+  for (int i = 0; i <= n; i++) {
+    int lo = -1, hi = -1;
+    if (i < n) {
+      const int gy = ctx->rerender_upload[i] / f.xgroups;
+      lo = max(0, gy * kGroupDim - plan.halo_px);
+      hi = min(f.ysize, (gy + 1) * kGroupDim + plan.halo_px);
+    }
+    if (i < n && prev_hi >= lo) {
+      prev_hi = max(prev_hi, hi);
+      continue;
+    }
+    if (prev_lo >= 0)
+      if (jxlh_status st = run_stages_rows(ctx, plan, prev_lo, prev_hi, prev_lo == 0 && prev_hi == f.ysize)) return st;
+    prev_lo = lo;
+    prev_hi = hi;
+  }
+  return JXLH_OK;
+}
+
+jxlh_status jxlh_ctx_sync(jxlh_ctx* ctx) {
+  if (!ctx) return JXLH_ERR_INVALID_ARGUMENT;
+  if (ctx->in_frame && ctx->error_flag.p) {
+    // read the flag on the context's own stream into pinned memory: a synchronous hipMemcpy would
+    // go through the null stream and serialise against other contexts' work
+    if (!ctx->host_flag) HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->host_flag), sizeof(int), hipHostMallocDefault));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->host_flag, ctx->error_flag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (*ctx->host_flag != 0) return (jxlh_status)*ctx->host_flag;
+    return JXLH_OK;
+  }
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return JXLH_OK;
+}
+
+}  // extern "C"

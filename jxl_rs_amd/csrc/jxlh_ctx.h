@@ -236,6 +236,26 @@ inline int result_in_tmp(const jxlh_ctx* ctx) {
   return ns & 1;
 }
 void set_filter_params(FrameDev& f, const jxlh_frame_params& p);
+// abi_frame.hip: pieces of the frame pipeline the read-out and stage-hook entry points share
+bool noise_lut_is_zero(const float lut[8]);
+void materialise_chroma(jxlh_ctx* ctx);          // deferred chroma upsampling of a sub-sampled frame, if still pending
+jxlh_status ensure_jump_table(jxlh_ctx* ctx);    // xorshift128+ jump matrices of the noise generator
+jxlh_status upload_upsampling_kernels(jxlh_ctx* ctx, int n);
+
+// host or device source -> context-owned device scratch / back, on the main stream (stage hooks, Modular entry points)
+template <class T>
+jxlh_status stage_in(jxlh_ctx* ctx, DevBuf<T>& b, const T* src, size_t n) {
+  jxlh_status st = ensure(ctx, b, n);
+  if (st != JXLH_OK) return st;
+  HIPCHK(ctx, hipMemcpyAsync(b.p, src, n * sizeof(T), hipMemcpyDefault, ctx->stream));
+  return JXLH_OK;
+}
+template <class T>
+jxlh_status stage_out(jxlh_ctx* ctx, T* dst, const T* src, size_t n) {
+  HIPCHK(ctx, hipMemcpyAsync(dst, src, n * sizeof(T), hipMemcpyDefault, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return JXLH_OK;
+}
 // comm.hip
 void comm_release(jxlh_ctx* ctx);
 int comm_nranks(const jxlh_ctx* ctx);

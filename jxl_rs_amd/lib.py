@@ -35,20 +35,25 @@ ABI_SYMBOLS = [
     "jxlh_default_frame_params", "jxlh_ctx_create", "jxlh_ctx_destroy", "jxlh_status_string", "jxlh_last_error",
     "jxlh_alloc_pinned", "jxlh_free_pinned", "jxlh_frame_begin", "jxlh_frame_set_dequant_tables",
     "jxlh_frame_set_lf_quantized", "jxlh_frame_set_lf", "jxlh_frame_set_hf_meta", "jxlh_submit_group",
-    "jxlh_submit_group_sparse", "jxlh_submit_groups_sparse", "jxlh_submit_groups_sparse8", "jxlh_slot_wait", "jxlh_frame_coeff_buffer", "jxlh_frame_run", "jxlh_ctx_sync", "jxlh_frame_read_planes",
-    "jxlh_frame_device_planes", "jxlh_frame_read_lf", "jxlh_frame_read_rgb8", "jxlh_frame_read_rgb8_async", "jxlh_frame_read_rgb16",
-    "jxlh_frame_read_ycbcr_rgb8", "jxlh_frame_read_ycbcr_rgb16", "jxlh_frame_read_output", "jxlh_frame_read_output_async", "jxlh_stage_chroma_upsample", "jxlh_stage_upsample", "jxlh_set_upsampling_weights", "jxlh_stage_noise_generate",
-    "jxlh_stage_noise_convolve", "jxlh_stage_noise_add", "jxlh_timer_start", "jxlh_timer_stop",
-    "jxlh_kernel_timing_enable", "jxlh_kernel_timing_get", "jxlh_kernel_timing_reset", "jxlh_selftest_recip",
-    "jxlh_stage_gaborish",
-    "jxlh_stage_epf", "jxlh_stage_lf_smooth", "jxlh_stage_transform_to_pixels", "jxlh_rct", "jxlh_palette", "jxlh_palette_delta", "jxlh_modular_to_rgb8",
-    "jxlh_modular_to_f32", "jxlh_modular_xyb_to_f32",
-    "jxlh_unsqueeze", "jxlh_unsqueeze_planes", "jxlh_smooth_unsqueeze", "jxlh_unsqueeze_rct", "jxlh_palette_delta_wp", "jxlh_unsqueeze_levels", "jxlh_abi_version", "jxlh_covered_blocks_x", "jxlh_covered_blocks_y",
-    "jxlh_quant_table_for_type", "jxlh_quant_table_size",
-    "jxlh_comm_unique_id", "jxlh_comm_init", "jxlh_comm_init_local", "jxlh_comm_destroy", "jxlh_comm_band",
-    "jxlh_frame_run_sharded", "jxlh_frame_allgather", "jxlh_frames_run_sharded_local", "jxlh_frames_allgather_local",
-    "jxlh_comm_allgather", "jxlh_probe_copy_bandwidth", "jxlh_frame_rerender_groups",
-    "jxlh_comm_allgather_local", "jxlh_palette_strided", "jxlh_modular_frame_filters",
+    "jxlh_submit_group_sparse", "jxlh_submit_groups_sparse", "jxlh_submit_groups_sparse8", "jxlh_slot_wait",
+    "jxlh_frame_coeff_buffer", "jxlh_frame_run", "jxlh_ctx_sync", "jxlh_frame_read_planes",
+    "jxlh_frame_device_planes", "jxlh_frame_read_lf", "jxlh_frame_read_rgb8", "jxlh_frame_read_rgb8_async",
+    "jxlh_frame_read_rgb16", "jxlh_frame_read_ycbcr_rgb8", "jxlh_frame_read_ycbcr_rgb16", "jxlh_frame_read_output",
+    "jxlh_frame_read_output_async", "jxlh_stage_chroma_upsample", "jxlh_stage_upsample",
+    "jxlh_set_upsampling_weights", "jxlh_stage_noise_generate", "jxlh_stage_noise_convolve", "jxlh_stage_noise_add",
+    "jxlh_stage_gaborish", "jxlh_stage_epf", "jxlh_stage_lf_smooth", "jxlh_stage_transform_to_pixels", "jxlh_rct",
+    "jxlh_palette", "jxlh_palette_delta", "jxlh_modular_to_rgb8", "jxlh_modular_to_f32", "jxlh_modular_xyb_to_f32",
+    "jxlh_unsqueeze", "jxlh_unsqueeze_planes", "jxlh_smooth_unsqueeze", "jxlh_unsqueeze_rct", "jxlh_palette_delta_wp",
+    "jxlh_unsqueeze_levels", "jxlh_abi_version", "jxlh_covered_blocks_x", "jxlh_covered_blocks_y",
+    "jxlh_quant_table_for_type", "jxlh_quant_table_size", "jxlh_comm_unique_id", "jxlh_comm_init",
+    "jxlh_comm_init_local", "jxlh_comm_destroy", "jxlh_comm_band", "jxlh_frame_run_sharded", "jxlh_frame_allgather",
+    "jxlh_frames_run_sharded_local", "jxlh_frames_allgather_local", "jxlh_comm_allgather",
+    "jxlh_frame_rerender_groups", "jxlh_comm_allgather_local", "jxlh_palette_strided", "jxlh_modular_frame_filters",
+]
+# developer / bench instruments: include/jxl_hip_dev.h (same library, not part of the drop-in boundary)
+DEV_SYMBOLS = [
+    "jxlh_timer_start", "jxlh_timer_stop", "jxlh_kernel_timing_enable", "jxlh_kernel_timing_get",
+    "jxlh_kernel_timing_reset", "jxlh_selftest_recip", "jxlh_probe_copy_bandwidth",
 ]
 
 

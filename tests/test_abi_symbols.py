@@ -10,8 +10,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def header_symbols():
-    src = open(os.path.join(ROOT, "include", "jxl_hip.h")).read()
+def header_symbols(name="jxl_hip.h"):
+    src = open(os.path.join(ROOT, "include", name)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(jxlh_[a-z0-9_]+)\s*\(", src)))
 
@@ -26,10 +26,22 @@ def test_library_exports_every_declared_symbol():
     assert sorted(lib.ABI_SYMBOLS) == declared
 
 
+def test_dev_header_is_separate_from_the_product_abi():
+    """timers / probes / self-tests live in include/jxl_hip_dev.h: exported by the library, declared nowhere in the
+    product header (so the generated Rust -sys crate does not bind them)"""
+    from jxl_rs_amd import lib
+    L = lib.load()
+    dev = [n for n in header_symbols("jxl_hip_dev.h")]
+    assert sorted(lib.DEV_SYMBOLS) == dev and dev
+    for name in dev:
+        assert hasattr(L, name), name
+    assert not set(dev) & set(header_symbols())
+
+
 def test_abi_version_and_tables():
     from jxl_rs_amd import lib, synth
     L = lib.load()
-    assert L.jxlh_abi_version() == 5
+    assert L.jxlh_abi_version() == 6
     for t in range(27):
         assert L.jxlh_covered_blocks_x(t) == synth.COVERED_X[t]
         assert L.jxlh_covered_blocks_y(t) == synth.COVERED_Y[t]
