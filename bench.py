@@ -42,6 +42,174 @@ ALGO_BYTES_PER_PX = {
 }
 
 
+def resolve_traffic(dominant, root=ROOT):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same command
+    (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; tools/gpu_profile.sh, tools/pmc_summary.py).  PMC needs its own
+    profiler run, so the value is the latest committed measurement THAT HOLDS THE DOMINANT KERNEL'S ENTRIES (other
+    profiles -- the Modular kernels, secondary configs -- have their own r*_traffic.json files), not live.
+    Returns (bytes or None, file or None)."""
+    import glob
+    # "k1_vardct" is the scan + class kernels: their PMC entries are k1_scan, k1_dct8, ...
+    prefix = "k1_" if dominant == "k1_vardct" else dominant
+    for path in sorted(glob.glob(os.path.join(root, "profiles", "r*_traffic.json")), reverse=True):
+        try:
+            pmc = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if pmc.get("_workload", "8192 d1") != "8192 d1":
+            continue
+        parts = [int(v["hbm_bytes"]) for k, v in pmc.items() if k.startswith(prefix) and isinstance(v, dict)]
+        if parts:
+            return sum(parts), os.path.relpath(path, root)
+    return None, None
+
+
+def time_vardct_config(jxl_rs_amd, synth, np, device, size, mix, epf_iters, seed, steps, warmup=2, extra_epf=None):
+    """One secondary VarDCT configuration, ONE frame in flight, inputs HBM-resident: wall-clock step time (sync on both
+    sides) + the per-kernel HIP-event table with every kernel against its own algorithmic bytes.  extra_epf: also
+    time the same frame with that epf_iters (new frame epoch, coefficients re-submitted)."""
+    t0 = time.time()
+    wl = synth.make_vardct(size, size, mix=mix, seed=seed, unique_groups=24 if size <= 8192 else 32,
+                           epf_iters=epf_iters, gab=True, lf_smoothing=True)
+    gen_s = time.time() - t0
+    ctx = jxl_rs_amd.Context(device, n_slots=1)
+    npx = size * size
+
+    def measure(iters):
+        wl.opts["epf_iters"] = iters
+        ctx.frame_begin(synth.apply_opts(ctx.default_params(size, size), wl))
+        ctx.set_dequant_tables(wl.tables)
+        ctx.set_lf_quantized(*wl.lf_q)
+        ctx.set_hf_meta(wl.transform_map, wl.raw_quant, wl.epf_map, wl.ytox, wl.ytob)
+        for g in range(wl.coeffs.shape[0]):
+            ctx.submit_group(g, wl.coeffs[g])
+        ctx.slot_wait(0)
+        for _ in range(warmup):
+            ctx.frame_run()
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ctx.frame_run()
+        ctx.sync()
+        ms = (time.perf_counter() - t0) * 1e3 / steps
+        ctx.kernel_timing_reset()
+        ctx.kernel_timing(True)
+        nprof = max(2, min(steps, 5))
+        for _ in range(nprof):
+            ctx.frame_run()
+        ctx.sync()
+        kt = ctx.kernel_times()
+        ctx.kernel_timing(False)
+        kernels = {}
+        for name, (kms, n) in kt.items():
+            k = {"ms_per_step": round(kms / nprof, 4), "launches_per_step": n // nprof}
+            if name in ALGO_BYTES_PER_PX:
+                ab = ALGO_BYTES_PER_PX[name] * npx
+                k["algorithmic_bytes"] = int(ab)
+                k["achieved_GBs"] = round(ab / (kms / nprof * 1e-3) / 1e9, 1)
+                k["frac"] = round(k["achieved_GBs"] / HBM_PEAK_GBS, 4)
+            kernels[name] = k
+        chain_ms = sum(v["ms_per_step"] for v in kernels.values())
+        ideal = (24.3 if iters == 0 else FUSED_IDEAL_BYTES_PER_PX) * npx
+        return {"epf_iters": iters, "ms_per_step": round(ms, 4), "value": round(npx / 1e6 / (ms / 1e3), 1), "unit": "MP/s",
+                "steps": steps, "frames_in_flight": 1, "kernels": kernels, "sum_of_kernels_ms": round(chain_ms, 4),
+                "chain_vs_fused_ideal": {"algorithmic_bytes": int(ideal),
+                                         "frac": round(ideal / (chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
+
+    types = sorted(set(np.unique(wl.transform_map[wl.transform_map >= 128] & 127).tolist()))
+    out = {"workload": f"{size}x{size} VarDCT, {len(types)} transform types present, CfL, LF smoothing, Gaborish, "
+                       f"EPF iters={epf_iters}, inputs HBM-resident", "transform_types": types,
+           "host_generate_s": round(gen_s, 2)}
+    out.update(measure(epf_iters))
+    if extra_epf is not None:
+        out[f"epf_iters_{extra_epf}"] = measure(extra_epf)
+    ctx.close()
+    return out
+
+
+def time_modular_config(jxl_rs_amd, np, device, size, steps, cores, cpu=True):
+    """BASELINE configs[3]: the default squeeze chain of a size x size image on three channels + YCoCg RCT (one
+    jxlh_unsqueeze_chain call, the sequence tests/test_gpu_fullsize.py holds to the oracle at this size), and the
+    256-colour palette expansion.  Fractions: the chain against SURVEY 8(d)'s 16 B per final sample (and against what
+    its levels really write, 8 B per written sample); the palette against 16 B/px."""
+    from jxl_rs_amd.modular import ModularChain
+    from jxl_rs_amd.lib import DeviceArray
+    ctx = jxl_rs_amd.Context(device, n_slots=1)
+    t0 = time.time()
+    ch = ModularChain(ctx, size, size, seed=84)
+    gen_s = time.time() - t0
+    npx = size * size
+
+    def timed(fn, reps):
+        fn()
+        ctx.sync()
+        ctx.timer_start()
+        for _ in range(reps):
+            fn()
+        return ctx.timer_stop() / reps
+
+    chain_ms = timed(ch.run_chain, steps)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ch.run_chain()
+    ctx.sync()
+    wall_ms = (time.perf_counter() - t0) * 1e3 / steps
+    ctx.kernel_timing_reset()
+    ctx.kernel_timing(True)
+    ch.run_chain()
+    ctx.sync()
+    ctx.kernel_timing(False)
+    rng = np.random.default_rng(256)
+    pal = rng.integers(0, 256, size=(3, 256)).astype(np.int32)
+    idx = rng.integers(0, 256, size=(size, size)).astype(np.int32)
+    d_idx, d_pal, d_out = DeviceArray(idx), DeviceArray(pal), DeviceArray(nbytes=3 * npx * 4)
+    pal_ms = timed(lambda: ctx._chk(ctx.L.jxlh_palette(ctx._ctx, d_idx.ptr, npx, d_pal.ptr, 256, 256, 3, 8, d_out.ptr),
+                                    "palette"), steps)
+    rct_ms = timed(lambda: ctx._chk(ctx.L.jxlh_rct(ctx._ctx, ch.d_out[0].ptr, ch.d_out[1].ptr, ch.d_out[2].ptr, npx, 6, 0),
+                                    "rct"), steps)
+    final = 16.0 * 3 * npx
+    out = {"workload": f"{size}x{size} x 3 ch i32 Modular: default squeeze chain ({len(ch.steps)} steps) + YCoCg RCT "
+                       f"(one jxlh_unsqueeze_chain call), 256-colour palette; device-resident",
+           "dtype": "i32", "host_generate_s": round(gen_s, 2),
+           "chain": {"ms": round(chain_ms, 4), "wall_ms": round(wall_ms, 4), "value": round(npx / 1e6 / (chain_ms / 1e3), 1),
+                     "unit": "MP/s", "algorithmic_bytes": int(final), "bytes_per_final_sample": 16,
+                     "achieved_GBs": round(final / (chain_ms * 1e-3) / 1e9, 1),
+                     "frac": round(final / (chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                     "bytes_written_levels": int(8.0 * ch.samples_written),
+                     "dependent_steps_on_the_longest_line": int(sum(ow if hz else oh for hz, ow, oh in ch.steps) // 2)},
+           "palette": {"ms": round(pal_ms, 4), "algorithmic_bytes": int(16.0 * npx),
+                       "frac": round(16.0 * npx / (pal_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+           "rct_alone": {"ms": round(rct_ms, 4), "algorithmic_bytes": int(24.0 * npx),
+                         "frac": round(24.0 * npx / (rct_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+           "pmc_file": "profiles/r02_n_modular_pmc.txt"}
+    if cpu:
+        # the oracle's step-by-step chain + RCT on the same planes, one thread per channel (ctypes releases the GIL)
+        from concurrent.futures import ThreadPoolExecutor
+        from oracle.oracle import Oracle
+        o = Oracle(fused=True)
+
+        def one(c):
+            cur = ch.base[c]
+            for (hz, ow, oh), res in zip(ch.steps, ch.residuals):
+                cur = o.unsqueeze_h(cur, res[c], ow) if hz else o.unsqueeze_v(cur, res[c], oh)
+            return cur
+
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(3) as ex:
+            planes = list(ex.map(one, range(3)))
+        o.rct(planes, 6, 0)
+        el = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(npx / 1e6 / el, 2), "unit": "MP/s", "cores": 3, "kind": "port",
+                               "sample": f"one {size}x{size} x 3 chain + RCT on the C oracle, one thread per channel "
+                                         f"(the recurrence is serial along a line; scalar C, not the reference's SIMD)",
+                               "seconds": round(el, 3)}
+    for d in (d_idx, d_pal, d_out):
+        d.free()
+    ch.free()
+    ctx.close()
+    return out
+
+
 def usable_cores():
     """Host cores this process may actually use: the affinity mask capped by the container's CPU quota
     (cgroup v2 cpu.max / v1 cfs quota).  os.cpu_count() reports the machine (256 on the GPU boxes) while the
@@ -78,6 +246,8 @@ def main():
                     help="skip the all-blocks-filtered EPF population (profiling runs: one population per kernel name)")
     ap.add_argument("--no-e2e", action="store_true",
                     help="skip the PCIe-inclusive legs (pinned host coefficients -> finished planes)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the `secondary` block (BASELINE configs 2, 4 and 5, one frame in flight each)")
     ap.add_argument("--seed", type=int, default=3)
     ap.add_argument("--inflight", type=int, default=2,
                     help="frames in flight per GPU (contexts with their own stream and buffers, used round-robin)")
@@ -316,31 +486,16 @@ def main():
             active = {k: ak[k] for k in ak if k in ALGO_BYTES_PER_PX}
             active["sum_of_kernels_ms"] = round(sum(v["ms_per_step"] for v in ak.values()), 4)
         cand = {k: v for k, v in kernels.items() if k in ALGO_BYTES_PER_PX}
-        # HBM traffic of the dominant kernel from the committed rocprofv3 --pmc passes of this same
-        # command (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; tools/gpu_profile.sh, tools/pmc_summary.py).
-        # PMC needs its own profiler run, so the value is the latest committed measurement, not live.
-        pmc = {}
-        try:
-            import glob
-            files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
-            if files and size == 8192 and args.mix == "d1":
-                pmc = json.load(open(files[-1]))
-                pmc["_file"] = os.path.relpath(files[-1], ROOT)
-        except Exception:
-            pmc = {}
         if cand:
             dom = max(cand, key=lambda k: cand[k]["ms_per_step"])
-            traffic = None
-            # "k1_vardct" is the scan + class kernels: their PMC entries are k1_scan, k1_dct8, ...
-            prefix = "k1_" if dom == "k1_vardct" else dom
-            parts = [int(v["hbm_bytes"]) for k, v in pmc.items() if k.startswith(prefix) and isinstance(v, dict)]
-            if parts:
-                traffic = sum(parts)
+            traffic, traffic_file = (None, None)
+            if size == 8192 and args.mix == "d1":
+                traffic, traffic_file = resolve_traffic(dom)
             chain_ms = sum(v["ms_per_step"] for v in kernels.values())
             ideal = FUSED_IDEAL_BYTES_PER_PX * npx
             roofline = {"kernel": dom, "bound": "hbm", "achieved": cand[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": cand[dom]["frac"], "traffic": traffic,
-                        "traffic_source": pmc.get("_file"),
+                        "traffic_source": traffic_file,
                         "algorithmic_bytes_per_launch": cand[dom]["algorithmic_bytes"],
                         "avg_launch_ms": cand[dom]["ms_per_step"], "all_kernels_ms_per_step": kernels,
                         # the whole IDCT+EPF stage against north_star's numerator: what ONE fused kernel would move
@@ -568,6 +723,25 @@ def main():
         for c in ectx:
             c.close()
 
+    # ---- the other BASELINE configurations, driver-visible: config 2 (4096^2, EPF off), config 4 (Modular 8192^2),
+    # config 5 (16384^2, all 27 types; + epf_iters = 3).  Not `value`: one frame in flight each, a few steps.
+    secondary = None
+    if rank == 0 and n_gpus == 1 and not args.no_secondary and torch.cuda.is_available():
+        secondary = {}
+        for key, fn in (
+                ("config2_4096_d1_epf0", lambda: time_vardct_config(jxl_rs_amd, synth, np, local_rank, 4096, synth.MIX_D1, 0,
+                                                                    args.seed, steps=10)),
+                ("config4_modular_8192", lambda: time_modular_config(jxl_rs_amd, np, local_rank, 8192, steps=5,
+                                                                     cores=usable_cores(), cpu=not args.no_cpu)),
+                ("config5_16384_all_types", lambda: time_vardct_config(jxl_rs_amd, synth, np, local_rank, 16384,
+                                                                       synth.MIX_ALL, 2, args.seed, steps=5, extra_epf=3))):
+            t0 = time.time()
+            try:
+                secondary[key] = fn()
+            except Exception as e:  # the headline line must survive a failing secondary leg
+                secondary[key] = {"error": f"{type(e).__name__}: {e}"}
+            secondary[key]["leg_wall_s"] = round(time.time() - t0, 1)
+
     if rank == 0:
         out = {
             "metric": "megapixels/sec decoded (8K VarDCT d1 reconstruction: dequant+CfL+IDCT+LF smoothing+Gaborish+EPF)",
@@ -584,7 +758,7 @@ def main():
             "strong_scaling": strong,
             "hip_event_ms_per_step_rank0": round(ev_ms / args.steps, 4),
             "setup": {"host_generate_s": round(gen_s, 2), "h2d_coeffs_s": round(h2d_s, 2)},
-            "roofline": roofline, "cpu_baseline": cpu, "e2e_pcie_inclusive": e2e,
+            "roofline": roofline, "cpu_baseline": cpu, "e2e_pcie_inclusive": e2e, "secondary": secondary,
         }
         print(json.dumps(out))
     if dist is not None:

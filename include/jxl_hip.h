@@ -442,6 +442,17 @@ jxlh_status jxlh_unsqueeze_levels(jxlh_ctx* ctx, int32_t n_planes, int32_t n_lev
                                   const int32_t* const base[], size_t base_stride, uint32_t base_w, uint32_t base_h,
                                   int32_t* const out[], size_t out_stride);
 
+/* The inverse of a WHOLE squeeze transform in one call: jxlh_unsqueeze_levels' level list (smallest level first, the
+ * order the decoder applies the steps of default_squeeze / an explicit SqueezeParams list in, squeeze.rs:39-105,
+ * transforms/apply.rs), optionally followed by the RCT that comes next in the transform list (rct_op 0..6 and
+ * rct_perm 0..5 as in jxlh_rct, n_planes == 3; rct_op < 0: none) -- the last, full-resolution step and the RCT are
+ * then one pass over the planes.  The library picks the launch per level (LDS-resident first levels, streamed middle
+ * levels, fused last level); intermediate planes live in context scratch.  Device pointers only; `out` may not alias
+ * the base or residual planes. */
+jxlh_status jxlh_unsqueeze_chain(jxlh_ctx* ctx, int32_t n_planes, int32_t n_levels, const jxlh_squeeze_level* levels,
+                                 const int32_t* const base[], size_t base_stride, uint32_t base_w, uint32_t base_h,
+                                 int32_t* const out[], size_t out_stride, int32_t rct_op, int32_t rct_perm);
+
 /* A squeeze step of three channels followed by do_rct_step (rct.rs:118-157) on the same three channels, in one pass:
  * the shape the end of a colour image's inverse transform chain has (default_squeeze, squeeze.rs:71-105, finishes with
  * the full-size step -- vertical for square and tall images, horizontal for wide ones; the encoder applied the RCT

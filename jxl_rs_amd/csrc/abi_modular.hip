@@ -321,6 +321,116 @@ jxlh_status jxlh_unsqueeze_levels(jxlh_ctx* ctx, int32_t n_planes, int32_t n_lev
   return JXLH_OK;
 }
 
+// The inverse of a whole squeeze transform as one call (+ the RCT that follows it in the transform list).
+jxlh_status jxlh_unsqueeze_chain(jxlh_ctx* ctx, int32_t n_planes, int32_t n_levels, const jxlh_squeeze_level* levels,
+                                 const int32_t* const base[], size_t base_stride, uint32_t base_w, uint32_t base_h,
+                                 int32_t* const out[], size_t out_stride, int32_t rct_op, int32_t rct_perm) {
+  if (!ctx || !levels || !base || !out || n_planes < 1 || n_planes > 3 || n_levels < 1 || n_levels > 64 || base_w == 0 ||
+      base_h == 0 || base_stride < base_w)
+    return JXLH_ERR_INVALID_ARGUMENT;
+  const bool with_rct = rct_op >= 0;
+  if (with_rct && (n_planes != 3 || rct_op > 6 || rct_perm < 0 || rct_perm > 5)) return JXLH_ERR_INVALID_ARGUMENT;
+  uint32_t cw = base_w, ch = base_h;
+  size_t max_plane = (size_t)base_w * base_h;
+  for (int i = 0; i < n_levels; i++) {
+    const jxlh_squeeze_level& lv = levels[i];
+    if (lv.out_w == 0 || lv.out_h == 0 || lv.out_w > kMaxModularDim || lv.out_h > kMaxModularDim)
+      return JXLH_ERR_INVALID_ARGUMENT;
+    const uint32_t aw = lv.horizontal ? (lv.out_w + 1) / 2 : lv.out_w, ah = lv.horizontal ? lv.out_h : (lv.out_h + 1) / 2;
+    if (aw != cw || ah != ch) return JXLH_ERR_INVALID_ARGUMENT;
+    const uint32_t rw = lv.horizontal ? lv.out_w / 2 : lv.out_w, rh = lv.horizontal ? lv.out_h : lv.out_h / 2;
+    for (int p = 0; p < n_planes; p++)
+      if ((size_t)rw * rh > 0 && (!lv.res[p] || !is_device_ptr(lv.res[p]) || lv.res_stride < rw))
+        return JXLH_ERR_INVALID_ARGUMENT;
+    cw = lv.out_w;
+    ch = lv.out_h;
+    if (i < n_levels - 1) max_plane = std::max(max_plane, (size_t)cw * ch);
+  }
+  if (out_stride < cw) return JXLH_ERR_INVALID_ARGUMENT;
+  for (int p = 0; p < n_planes; p++)
+    if (!base[p] || !out[p] || !is_device_ptr(base[p]) || !is_device_ptr(out[p])) return JXLH_ERR_INVALID_ARGUMENT;
+  // intermediate planes: two sets of n_planes planes in context scratch, swapped per level (the largest intermediate
+  // level is half the output)
+  jxlh_status st;
+  if ((st = ensure(ctx, ctx->hook_i[0], max_plane * n_planes))) return st;
+  if ((st = ensure(ctx, ctx->hook_i[1], max_plane * n_planes))) return st;
+  ScopedKernelTimer t(ctx, "k6_unsqueeze_chain");
+  const int32_t* cur[3];
+  size_t cur_stride = base_stride;
+  for (int p = 0; p < n_planes; p++) cur[p] = base[p];
+  int flip = 0;
+  auto dst_of = [&](int i, int32_t* dst[3], size_t* stride) {
+    const bool last = i == n_levels - 1;
+    for (int p = 0; p < n_planes; p++) dst[p] = last ? out[p] : ctx->hook_i[flip].p + (size_t)p * max_plane;
+    *stride = last ? out_stride : levels[i].out_w;
+    if (!last) flip ^= 1;
+  };
+  int i = 0;
+  // ---- the first levels, while the planes fit LDS: one launch (the chain starts from <= 8 x 8)
+  {
+    int n_small = 0;
+    while (n_small < n_levels - (with_rct ? 1 : 0) && n_small < JXLH_SQL_LEVELS && levels[n_small].out_w <= JXLH_SQL_MAX &&
+           levels[n_small].out_h <= JXLH_SQL_MAX)
+      n_small++;
+    while (n_small >= 2) {
+      int hz[JXLH_SQL_LEVELS];
+      uint32_t ow[JXLH_SQL_LEVELS], oh[JXLH_SQL_LEVELS];
+      size_t rs[JXLH_SQL_LEVELS];
+      const int32_t* rp[JXLH_SQL_LEVELS * 3];
+      for (int k = 0; k < n_small; k++) {
+        hz[k] = levels[k].horizontal ? 1 : 0;
+        ow[k] = levels[k].out_w;
+        oh[k] = levels[k].out_h;
+        rs[k] = levels[k].res_stride;
+        for (int p = 0; p < 3; p++) rp[k * 3 + p] = p < n_planes && levels[k].res[p] ? levels[k].res[p] : base[0];
+      }
+      int32_t* dst[3];
+      size_t dst_stride;
+      const int save = flip;
+      dst_of(n_small - 1, dst, &dst_stride);
+      if (launch_unsqueeze_levels(ctx->stream, n_planes, n_small, hz, ow, oh, rp, rs, base, base_stride, base_w, base_h, dst,
+                                  dst_stride)) {
+        for (int p = 0; p < n_planes; p++) cur[p] = dst[p];
+        cur_stride = dst_stride;
+        i = n_small;
+        break;
+      }
+      flip = save;
+      n_small--;  // a level that does not fit the kernel's half-size buffer: try a shorter prefix
+    }
+  }
+  // ---- the remaining levels, one launch each over the three planes; the last one fused with the RCT
+  for (; i < n_levels; i++) {
+    const jxlh_squeeze_level& lv = levels[i];
+    const bool last = i == n_levels - 1;
+    int32_t* dst[3];
+    size_t dst_stride;
+    dst_of(i, dst, &dst_stride);
+    const int32_t* rv[3];
+    for (int p = 0; p < n_planes; p++) rv[p] = lv.res[p] ? lv.res[p] : cur[p];
+    bool fused = false;
+    if (last && with_rct)
+      fused = launch_unsqueeze_rct(ctx->stream, lv.horizontal ? 1 : 0, cur, cur_stride, rv, lv.res_stride, lv.out_w, lv.out_h,
+                                   dst, dst_stride, rct_op, rct_perm);
+    if (!fused)
+      launch_unsqueeze(ctx->stream, lv.horizontal ? 1 : 0, n_planes, cur, cur_stride, rv, lv.res_stride, lv.out_w, lv.out_h,
+                       dst, dst_stride);
+    if (last && with_rct && !fused) {
+      if (dst_stride == lv.out_w) {
+        launch_rct(ctx->stream, dst[0], dst[1], dst[2], (size_t)lv.out_w * lv.out_h, rct_op, rct_perm);
+      } else {
+        for (uint32_t y = 0; y < lv.out_h; y++)
+          launch_rct(ctx->stream, dst[0] + (size_t)y * dst_stride, dst[1] + (size_t)y * dst_stride,
+                     dst[2] + (size_t)y * dst_stride, lv.out_w, rct_op, rct_perm);
+      }
+    }
+    for (int p = 0; p < n_planes; p++) cur[p] = dst[p];
+    cur_stride = dst_stride;
+  }
+  HIPCHK(ctx, hipGetLastError());
+  return JXLH_OK;
+}
+
 jxlh_status jxlh_unsqueeze_rct(jxlh_ctx* ctx, int32_t horizontal, const int32_t* const avg[3], size_t avg_stride,
                                const int32_t* const res[3], size_t res_stride, uint32_t out_w, uint32_t out_h,
                                int32_t* const out[3], size_t out_stride, int32_t op, int32_t perm) {

@@ -247,6 +247,8 @@ bool launch_unsqueeze_rct(hipStream_t s, int horizontal, const int32_t* const av
                           int32_t* const out[3], size_t out_stride, int op, int perm);
 // several consecutive squeeze steps of small planes (all sides <= 128) in one launch; res[i * 3 + p] = residual plane
 // of level i, plane p.  false = the chain does not qualify, nothing launched
+#define JXLH_SQL_MAX 128     // k6_unsqueeze_levels: largest plane side handled in LDS
+#define JXLH_SQL_LEVELS 16  // ... and the most levels one launch takes
 bool launch_unsqueeze_levels(hipStream_t s, int n_planes, int n_levels, const int* horizontal, const uint32_t* out_w,
                              const uint32_t* out_h, const int32_t* const* res, const size_t* res_stride,
                              const int32_t* const base[], size_t base_stride, uint32_t base_w, uint32_t base_h,

@@ -650,7 +650,7 @@ __device__ __forceinline__ int32_t smooth_tendency(int32_t a, int32_t b, int32_t
 }
 
 // unsqueeze_impl (squeeze.rs:171-185) around smooth_tendency, restated for the serial chain.  One wave owns a line, so
-// a step costs (instructions on the dependent path) x 8 cycles (tools/exp/valu_latency.hip: 8 cycles between dependent
+// a step costs (instructions on the dependent path) x 8 cycles (tools/valu_latency.hip: 8 cycles between dependent
 // VALU instructions of a lone wave, 5 between independent ones); the step is therefore written on the state
 //     d = prev_b - avg                      (a_b of smooth_tendency_impl)
 // with everything that does not depend on it moved off the path:
@@ -1483,8 +1483,6 @@ bool launch_unsqueeze_rct(hipStream_t s, int horizontal, const int32_t* const av
 // Here one workgroup per plane walks ALL of them: the running average plane lives in LDS (two buffers swapped per
 // level), a level's residual plane is staged through LDS with coalesced loads, lanes = lines, and only the last level
 // is written out.
-#define JXLH_SQL_MAX 128                 // largest plane side handled in LDS
-#define JXLH_SQL_LEVELS 16
 struct SqueezeLevels {
   int n_levels;
   int base_w, base_h;

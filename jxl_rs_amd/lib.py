@@ -44,7 +44,7 @@ ABI_SYMBOLS = [
     "jxlh_stage_gaborish", "jxlh_stage_epf", "jxlh_stage_lf_smooth", "jxlh_stage_transform_to_pixels", "jxlh_rct",
     "jxlh_palette", "jxlh_palette_delta", "jxlh_modular_to_rgb8", "jxlh_modular_to_f32", "jxlh_modular_xyb_to_f32",
     "jxlh_unsqueeze", "jxlh_unsqueeze_planes", "jxlh_smooth_unsqueeze", "jxlh_unsqueeze_rct", "jxlh_palette_delta_wp",
-    "jxlh_unsqueeze_levels", "jxlh_abi_version", "jxlh_covered_blocks_x", "jxlh_covered_blocks_y",
+    "jxlh_unsqueeze_levels", "jxlh_unsqueeze_chain", "jxlh_abi_version", "jxlh_covered_blocks_x", "jxlh_covered_blocks_y",
     "jxlh_quant_table_for_type", "jxlh_quant_table_size", "jxlh_comm_unique_id", "jxlh_comm_init",
     "jxlh_comm_init_local", "jxlh_comm_destroy", "jxlh_comm_band", "jxlh_frame_run_sharded", "jxlh_frame_allgather",
     "jxlh_frames_run_sharded_local", "jxlh_frames_allgather_local", "jxlh_comm_allgather",
@@ -169,6 +169,7 @@ def load():
     L.jxlh_palette.argtypes = [vp, vp, sz, vp, i32, sz, i32, i32, vp]
     L.jxlh_palette_delta.argtypes = [vp, vp, u32, u32, vp, i32, i32, sz, i32, i32, i32, vp]
     L.jxlh_unsqueeze_levels.argtypes = [vp, i32, i32, vp, C.POINTER(vp), sz, u32, u32, C.POINTER(vp), sz]
+    L.jxlh_unsqueeze_chain.argtypes = [vp, i32, i32, vp, C.POINTER(vp), sz, u32, u32, C.POINTER(vp), sz, i32, i32]
     L.jxlh_palette_delta_wp.argtypes = [vp, vp, u32, u32, vp, i32, i32, sz, i32, i32, vp, vp]
     L.jxlh_modular_to_rgb8.argtypes = [vp, C.POINTER(vp), sz, u32, u32, i32, i32, u32, vp, sz]
     L.jxlh_modular_to_f32.argtypes = [vp, vp, sz, u32, vp]
@@ -247,7 +248,53 @@ def _addr(a):
         return C.c_void_p(int(a))
     if hasattr(a, "data_ptr"):  # torch tensor (device memory plumbing only)
         return C.c_void_p(a.data_ptr())
+    if isinstance(a, DeviceArray):
+        return C.c_void_p(a.ptr)
     return C.c_void_p(a.ctypes.data)
+
+
+class DeviceArray:
+    """A device buffer for harness code (tests, bench) that hands DEVICE pointers to the C ABI.  Allocated through the
+    HIP runtime the library itself is linked against (ctypes on the already-loaded libamdhip64), not through torch: a second HIP
+    runtime in the process (torch bundles its own) does not see the GPU once the first one holds it."""
+    _hip = None
+
+    @classmethod
+    def hip(cls):
+        if cls._hip is None:
+            import ctypes as C
+            cls._hip = C.CDLL("libamdhip64.so")
+            cls._hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+            cls._hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+            cls._hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+            cls._hip.hipFree.argtypes = [C.c_void_p]
+        return cls._hip
+
+    def __init__(self, array=None, nbytes=None):
+        import ctypes as C
+        self.nbytes = array.nbytes if array is not None else nbytes
+        p = C.c_void_p()
+        assert self.hip().hipMalloc(C.byref(p), max(self.nbytes, 16)) == 0
+        self.ptr = p.value
+        if array is not None:
+            a = np.ascontiguousarray(array)
+            assert self.hip().hipMemcpy(self.ptr, a.ctypes.data, a.nbytes, 1) == 0  # hipMemcpyHostToDevice
+        else:
+            assert self.hip().hipMemset(self.ptr, 0, self.nbytes) == 0
+
+    def upload(self, array, byte_offset=0):
+        a = np.ascontiguousarray(array)
+        assert self.hip().hipMemcpy(self.ptr + byte_offset, a.ctypes.data, a.nbytes, 1) == 0
+
+    def download(self, dtype, count, byte_offset=0):
+        out = np.empty(count, dtype=dtype)
+        assert self.hip().hipMemcpy(out.ctypes.data, self.ptr + byte_offset, out.nbytes, 2) == 0  # DeviceToHost
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.hip().hipFree(self.ptr)
+            self.ptr = 0
 
 
 class SqueezeLevel(C.Structure):  # jxlh_squeeze_level
@@ -721,6 +768,23 @@ class Context:
         ov = (C.c_void_p * n_planes)(*[_addr(a).value for a in out])
         self._chk(self.L.jxlh_unsqueeze_levels(self._ctx, n_planes, len(levels), C.cast(arr, C.c_void_p), bv, base_stride,
                                                base_w, base_h, ov, out_stride), "unsqueeze_levels")
+
+    def unsqueeze_chain(self, levels, base, base_stride, base_w, base_h, out, out_stride, rct=None):
+        """The inverse of a whole squeeze transform (+ the RCT after it, rct = (op, perm)) in one call; arguments as
+        unsqueeze_levels."""
+        n_planes = len(base)
+        arr = (SqueezeLevel * len(levels))()
+        for i, (hz, ow, oh, res, rstride) in enumerate(levels):
+            arr[i].horizontal = 1 if hz else 0
+            arr[i].out_w, arr[i].out_h = ow, oh
+            for p in range(3):
+                arr[i].res[p] = _addr(res[p]).value if p < n_planes and res[p] is not None else None
+            arr[i].res_stride = rstride
+        bv = (C.c_void_p * n_planes)(*[_addr(a).value for a in base])
+        ov = (C.c_void_p * n_planes)(*[_addr(a).value for a in out])
+        op, perm = rct if rct is not None else (-1, 0)
+        self._chk(self.L.jxlh_unsqueeze_chain(self._ctx, n_planes, len(levels), C.cast(arr, C.c_void_p), bv, base_stride,
+                                              base_w, base_h, ov, out_stride, op, perm), "unsqueeze_chain")
 
     def unsqueeze_rct(self, horizontal, avg, res, out, out_w, out_h, avg_stride, res_stride, out_stride, op, perm):
         """Unsqueeze of three device-resident planes fused with the inverse RCT on them."""

@@ -132,45 +132,4 @@ def forward_squeeze_v(img):
     return np.ascontiguousarray(a.T), np.ascontiguousarray(r.T)
 
 
-class DeviceArray:
-    """A device buffer for tests that hand DEVICE pointers to the C ABI.  Allocated through the HIP runtime the
-    library itself is linked against (ctypes on the already-loaded libamdhip64), not through torch: a second HIP
-    runtime in the process (torch bundles its own) does not see the GPU once the first one holds it."""
-    _hip = None
-
-    @classmethod
-    def hip(cls):
-        if cls._hip is None:
-            import ctypes as C
-            cls._hip = C.CDLL("libamdhip64.so")
-            cls._hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
-            cls._hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-            cls._hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
-            cls._hip.hipFree.argtypes = [C.c_void_p]
-        return cls._hip
-
-    def __init__(self, array=None, nbytes=None):
-        import ctypes as C
-        self.nbytes = array.nbytes if array is not None else nbytes
-        p = C.c_void_p()
-        assert self.hip().hipMalloc(C.byref(p), max(self.nbytes, 16)) == 0
-        self.ptr = p.value
-        if array is not None:
-            a = np.ascontiguousarray(array)
-            assert self.hip().hipMemcpy(self.ptr, a.ctypes.data, a.nbytes, 1) == 0  # hipMemcpyHostToDevice
-        else:
-            assert self.hip().hipMemset(self.ptr, 0, self.nbytes) == 0
-
-    def upload(self, array, byte_offset=0):
-        a = np.ascontiguousarray(array)
-        assert self.hip().hipMemcpy(self.ptr + byte_offset, a.ctypes.data, a.nbytes, 1) == 0
-
-    def download(self, dtype, count, byte_offset=0):
-        out = np.empty(count, dtype=dtype)
-        assert self.hip().hipMemcpy(out.ctypes.data, self.ptr + byte_offset, out.nbytes, 2) == 0  # DeviceToHost
-        return out
-
-    def free(self):
-        if self.ptr:
-            self.hip().hipFree(self.ptr)
-            self.ptr = 0
+from jxl_rs_amd.lib import DeviceArray  # noqa: E402,F401  (device buffers for tests that hand DEVICE pointers to the C ABI)

@@ -1,14 +1,34 @@
-"""GPU tests at BASELINE.json's full sizes, through size-independent checks the oracle can afford:
-* 8192x8192 VarDCT d1 full pipeline: one band of group rows (picked by seed) recomputed by the
-  oracle exactly the way a rank would (K1 on band + halo group rows, every stage on the band's rows)
-  must equal the same rows of the GPU's whole-frame output bit for bit; plus run-to-run identity.
+"""GPU tests at BASELINE.json's full sizes:
+* VarDCT at 4096^2 / 8192^2 / 16384^2: the WHOLE frame against the oracle's whole frame, bit for bit (the C oracle
+  does an 8K frame in well under a second on the box's cores), plus a band recomputed the way a rank would and
+  run-to-run identity.
 * 8192x8192 Modular: encode -> decode round trips (forward squeeze / forward YCoCg are independent
   numpy code), i.e. losslessness at full size, for one horizontal and one vertical full-resolution
   unsqueeze step and the RCT."""
 import numpy as np
 import pytest
 
-from helpers import (bit_equal, diff_report, forward_squeeze_h, forward_squeeze_v, oracle_params_from, run_gpu_frame)
+import os
+
+from helpers import (bit_equal, diff_report, forward_squeeze_h, forward_squeeze_v, oracle_params_from, run_gpu_frame,
+                     run_oracle_frame)
+
+ORACLE_THREADS = max(1, min(32, len(os.sched_getaffinity(0))))
+
+
+def _whole_frame_check(ctx, oracle, wl, what):
+    """the GPU's whole frame == the oracle's whole frame, every pixel of every plane (and the smoothed LF)"""
+    got, got_lf = run_gpu_frame(ctx, wl)
+    want, want_lf = run_oracle_frame(oracle, wl, num_threads=ORACLE_THREADS)
+    for c in range(3):
+        assert bit_equal(got_lf[c], want_lf[c]), f"{what}: LF ch{c}"
+    for c in range(3):
+        assert got[c].shape == want[c].shape == (wl.ysize, wl.xsize)
+        if not bit_equal(got[c], want[c]):
+            bad = np.argwhere(got[c].view(np.uint32) != want[c].view(np.uint32))
+            raise AssertionError(f"{what}: plane {c}: {len(bad)} of {got[c].size} differ, first {bad[:5].tolist()}")
+    assert all(np.isfinite(g).all() for g in got)
+    return got
 
 pytestmark = pytest.mark.gpu
 
@@ -21,16 +41,14 @@ def ctx():
     c.close()
 
 
-def test_8k_vardct_band_parity_and_determinism(ctx, oracle):
+def test_8k_vardct_whole_frame_band_and_determinism(ctx, oracle):
     from jxl_rs_amd import synth
     wl = synth.make_vardct(8192, 8192, mix=synth.MIX_D1, seed=77, unique_groups=16, epf_iters=2)
-    got, got_lf = run_gpu_frame(ctx, wl)
+    got = _whole_frame_check(ctx, oracle, wl, "config 3 (8192^2 d1, EPF x2)")
     p = oracle_params_from(oracle, wl)
     lf = oracle.adaptive_lf_smoothing(p, oracle.dequant_lf(p, *wl.lf_q))
-    for c in range(3):
-        assert bit_equal(got_lf[c], lf[c]), f"LF ch{c}"
-    row = 13  # one interior band; plus the bottom edge band
-    for row0, row1 in ((row, row + 1), (31, 32)):
+    # ... and one interior band the way a rank computes it (K1 on band + halo group rows, stages on the band's rows)
+    for row0, row1 in ((13, 14),):
         band = oracle.vardct_band(p, wl.coeffs, wl.transform_map, wl.raw_quant, wl.epf_map, wl.ytox, wl.ytob, lf,
                                   wl.tables, row0, row1)
         y0, y1 = row0 * 256, min(row1 * 256, wl.ysize)
@@ -42,7 +60,6 @@ def test_8k_vardct_band_parity_and_determinism(ctx, oracle):
     again = ctx.read_planes()
     for c in range(3):
         assert bit_equal(again[c], got[c])
-    assert all(np.isfinite(g).all() for g in got)
 
 
 def test_8k_modular_round_trips(ctx, oracle):
@@ -83,40 +100,21 @@ def test_2k_default_squeeze_chain_round_trip(ctx):
     assert np.array_equal(cur, img)
 
 
-def _band_check(ctx, oracle, wl, bands, what):
-    """whole frame on the GPU; the oracle recomputes the given bands of group rows the way a rank would"""
-    got, got_lf = run_gpu_frame(ctx, wl)
-    p = oracle_params_from(oracle, wl)
-    lf = oracle.adaptive_lf_smoothing(p, oracle.dequant_lf(p, *wl.lf_q)) if p.do_lf_smoothing else oracle.dequant_lf(p, *wl.lf_q)
-    for c in range(3):
-        assert bit_equal(got_lf[c], lf[c]), f"{what}: LF ch{c}"
-    for row0, row1 in bands:
-        band = oracle.vardct_band(p, wl.coeffs, wl.transform_map, wl.raw_quant, wl.epf_map, wl.ytox, wl.ytob, lf,
-                                  wl.tables, row0, row1)
-        y0, y1 = row0 * 256, min(row1 * 256, wl.ysize)
-        for c in range(3):
-            a, b = got[c][y0:y1], band[c][y0:y1, : wl.xsize]
-            assert bit_equal(a, b), f"{what}: rows {y0}:{y1} ch{c}: {diff_report(a, b)}"
-        del band
-    return got
-
-
-def test_4k_config2_bands_vs_oracle(ctx, oracle):
+def test_4k_config2_whole_frame_vs_oracle(ctx, oracle):
     """BASELINE configs[1]: 4096x4096 VarDCT d1 (mixed DCT8..32), IDCT + dequant + Gaborish, EPF off"""
     from jxl_rs_amd import synth
     wl = synth.make_vardct(4096, 4096, mix=synth.MIX_D1, seed=402, unique_groups=24, epf_iters=0, gab=True)
-    got = _band_check(ctx, oracle, wl, ((0, 1), (6, 8), (15, 16)), "config 2")
-    assert all(np.isfinite(g).all() for g in got)
+    _whole_frame_check(ctx, oracle, wl, "config 2 (4096^2, EPF off)")
 
 
-def test_4k_all_types_epf0_bands_vs_oracle(ctx, oracle):
+def test_4k_all_types_epf0_whole_frame_vs_oracle(ctx, oracle):
     """every transform type with epf_iters = 3 (Gaborish + EPF0 + EPF1 + EPF2: the two-pass fused path) at 4096^2"""
     from jxl_rs_amd import synth
     wl = synth.make_vardct(4096, 4096, mix=synth.MIX_ALL, seed=403, unique_groups=24, epf_iters=3, gab=True)
-    _band_check(ctx, oracle, wl, ((3, 4), (15, 16)), "all types, EPF0")
+    _whole_frame_check(ctx, oracle, wl, "4096^2 all types, epf_iters = 3")
 
 
-def test_16k_config5_bands_and_determinism(ctx, oracle):
+def test_16k_config5_whole_frame_and_determinism(ctx, oracle):
     """BASELINE configs[4]: 16384x16384, every one of the 27 transform types incl. DCT256 and AFV0-3"""
     from jxl_rs_amd import synth
     wl = synth.make_vardct(16384, 16384, mix=synth.MIX_ALL, seed=1605, unique_groups=32, epf_iters=2)
@@ -124,7 +122,7 @@ def test_16k_config5_bands_and_determinism(ctx, oracle):
     # DCT256X256, the 128-pixel family, the 64-pixel family, every special 8x8 type incl. AFV0-3 (the generator seeds
     # the large types per group by area share, so one of the two 128x256 orientations may be missing for a seed)
     assert {24, 21, 18, 1, 2, 3, 12, 13, 14, 15, 16, 17} <= types and len(types) >= 25, sorted(types)
-    got = _band_check(ctx, oracle, wl, ((0, 1), (37, 38), (63, 64)), "config 5")
+    got = _whole_frame_check(ctx, oracle, wl, "config 5 (16384^2, all 27 types)")
     ctx.frame_run()
     ctx.sync()
     again = ctx.read_planes()
@@ -161,6 +159,28 @@ def test_8k_modular_chain_vs_oracle(ctx, oracle):
     got = ctx.palette(idx, pal, 256, 3, 8)
     want = oracle.palette(idx, pal, 256, 3, 8)
     assert np.array_equal(got, want)
+
+
+def test_8k_modular_timed_sequence_vs_oracle(ctx, oracle):
+    """BASELINE configs[3], the EXACT device-resident call bench.py times (jxl_rs_amd.modular.ModularChain.run_chain:
+    one jxlh_unsqueeze_chain -- first levels in one LDS launch, streamed middle levels over three planes, last level
+    fused with the YCoCg RCT) at 8192 x 8192 against the oracle's step-by-step chain + RCT, then the palette."""
+    from jxl_rs_amd.modular import ModularChain
+    n = 8192
+    ch = ModularChain(ctx, n, n, seed=84)
+    try:
+        ch.run_chain()
+        got = ch.result()
+        want = ch.oracle_result(oracle)
+        for c in range(3):
+            assert np.array_equal(got[c], want[c]), f"channel {c}: first mismatches {np.argwhere(got[c] != want[c])[:5]}"
+        del want
+        ch.run_chain()
+        again = ch.result()
+        for c in range(3):
+            assert np.array_equal(again[c], got[c]), "run-to-run"
+    finally:
+        ch.free()
 
 
 @pytest.mark.parametrize("weighted", [False, True])

@@ -852,6 +852,54 @@ def test_unsqueeze_large_magnitudes(ctx, oracle, scale):
     assert np.array_equal(ctx.unsqueeze(False, a2, r2, w, h), oracle.unsqueeze_v(a2, r2, h))
 
 
+@pytest.mark.parametrize("size", [(700, 500), (257, 129), (9, 300), (1031, 17), (16, 16), (130, 2000)])
+@pytest.mark.parametrize("rct", [None, (6, 0), (3, 4)])
+def test_unsqueeze_chain_one_call(ctx, oracle, size, rct):
+    """jxlh_unsqueeze_chain: the whole default squeeze chain of three channels (+ the RCT after it) in one call"""
+    from jxl_rs_amd.modular import ModularChain
+    w, h = size
+    ch = ModularChain(ctx, w, h, seed=w + 3 * h, rct=rct)
+    try:
+        ch.run_chain()
+        got = ch.result()
+        want = ch.oracle_result(oracle)
+        for c in range(3):
+            assert np.array_equal(got[c], want[c]), (size, rct, c, np.argwhere(got[c] != want[c])[:5])
+    finally:
+        ch.free()
+
+
+def test_unsqueeze_chain_single_plane_strided_and_errors(ctx, oracle):
+    from jxl_rs_amd import lib, synth
+    from helpers import DeviceArray
+    w, h = 333, 210
+    base, residuals, steps = synth.make_modular_planes(w, h, seed=9, nchan=1)
+    want = base[0]
+    for (hz, ow, oh), res in zip(steps, residuals):
+        want = oracle.unsqueeze_h(want, res[0], ow) if hz else oracle.unsqueeze_v(want, res[0], oh)
+    d_base = DeviceArray(base[0])
+    d_res = [DeviceArray(r[0]) if r[0].size else None for r in residuals]
+    stride = w + 5
+    d_out = DeviceArray(np.full((h, stride), -9, np.int32))
+    levels = [(hz, ow, oh, [d.ptr if d else None], max(r[0].shape[1], 1))
+              for (hz, ow, oh), r, d in zip(steps, residuals, d_res)]
+    ctx.unsqueeze_chain(levels, [d_base.ptr], base[0].shape[1], base[0].shape[1], base[0].shape[0], [d_out.ptr], stride)
+    ctx.sync()
+    got = d_out.download(np.int32, h * stride).reshape(h, stride)
+    assert np.array_equal(got[:, :w], want) and (got[:, w:] == -9).all()
+    # an RCT needs three planes; level geometry must chain
+    with pytest.raises(lib.JxlHipError) as e:
+        ctx.unsqueeze_chain(levels, [d_base.ptr], base[0].shape[1], base[0].shape[1], base[0].shape[0], [d_out.ptr], stride,
+                            rct=(6, 0))
+    assert e.value.status == lib.ERR_INVALID_ARGUMENT
+    bad = list(levels)
+    bad[1] = (bad[1][0], bad[1][1] + 2, bad[1][2], bad[1][3], bad[1][4])
+    with pytest.raises(lib.JxlHipError):
+        ctx.unsqueeze_chain(bad, [d_base.ptr], base[0].shape[1], base[0].shape[1], base[0].shape[0], [d_out.ptr], stride)
+    for d in [d_base, d_out] + [d for d in d_res if d]:
+        d.free()
+
+
 def test_modular_chain_config4_style(ctx, oracle):
     """Default squeeze chain + YCoCg RCT + palette on a mid-size image, bit-exact end to end."""
     from jxl_rs_amd import synth
