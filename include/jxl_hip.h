@@ -412,6 +412,13 @@ jxlh_status jxlh_modular_to_rgb8(jxlh_ctx* ctx, const int32_t* const planes[3], 
 jxlh_status jxlh_modular_to_f32(jxlh_ctx* ctx, const int32_t* in, size_t n, uint32_t bits_per_sample, float* out);
 jxlh_status jxlh_modular_xyb_to_f32(jxlh_ctx* ctx, const int32_t* y, const int32_t* x, const int32_t* b, size_t n,
                                     const float quant_factors[3], float* ox, float* oy, float* ob);
+/* SAMPLE RANGE of every squeeze entry point below (jxlh_unsqueeze*, jxlh_unsqueeze_chain): averages, residuals and
+ * reconstructed samples in [-2^28, 2^28).  Inside it the result equals BOTH forms the reference holds -- the i64
+ * `unsqueeze_scalar` (squeeze.rs:187-194) and the wrapping-i32 `unsqueeze_impl` / `smooth_tendency_impl` of its SIMD
+ * back-ends (squeeze.rs:107-185) -- bit for bit.  From about 2^29 on those two forms give DIFFERENT results for the
+ * same input (which one a sample gets depends on its place in the back-end's tiling), so the reference defines no
+ * value there; the device then computes a third wrapping-i32 form, deterministic but equal to neither.  8..24-bit
+ * images, also after an RCT, are far inside the range (tests/test_oracle_pin.py pins the bound on all three forms). */
 /* do_hsqueeze_step / do_vsqueeze_step (squeeze.rs:456-481, :661-682), whole plane.
  * horizontal: avg is ceil(out_w/2) x h, res floor(out_w/2) x h; vertical likewise in y.  `out` may not overlap `avg` or
  * `res` (lines are streamed: inputs are read ahead of the outputs being written). */
@@ -470,10 +477,14 @@ jxlh_status jxlh_unsqueeze_rct(jxlh_ctx* ctx, int32_t horizontal, const int32_t*
  * the out_w x out_h output rectangle sits at (x0, y0) of the output channel -- (0, 0) and the full size for a whole
  * channel, a grid tile's Rect otherwise (the window reads across tile edges, columns clamp and rows mirror at the
  * CHANNEL's borders: TiledChannelView::load_row_to_scratch, step.rs:372-420).  As in the reference, a rectangle
- * without one complete sample pair on a doubled axis is left untouched.  Float-to-int conversion truncates after the
- * +-0.5 (the scalar, NEON and wasm back-ends' as_i32; the x86 ones round a second time).
- * Host or device pointers. */
-enum { JXLH_SMOOTH_H = 0, JXLH_SMOOTH_V = 1, JXLH_SMOOTH_2D = 2 };
+ * without one complete sample pair on a doubled axis is left untouched.
+ * Float-to-int conversion: the reference's `as_i32` differs between its SIMD back-ends -- truncation on the scalar,
+ * NEON and wasm ones (jxl_simd/src/scalar.rs:178, aarch64/neon.rs:400, wasm32/simd128.rs:371), round-to-nearest-even
+ * (cvtps2dq) on the x86 ones (x86_64/avx.rs:580, sse42.rs:472, avx512.rs:638), both applied after the +-0.5
+ * (squeeze.rs:807-810, :882-883); the two differ by one on about half the samples.  The caller says which reference
+ * build it stands in for: plain kind = truncation (an aarch64 / scalar reference), kind | JXLH_SMOOTH_CVT_NEAREST_EVEN
+ * = an x86 reference.  Host or device pointers. */
+enum { JXLH_SMOOTH_H = 0, JXLH_SMOOTH_V = 1, JXLH_SMOOTH_2D = 2, JXLH_SMOOTH_CVT_NEAREST_EVEN = 0x100 };
 jxlh_status jxlh_smooth_unsqueeze(jxlh_ctx* ctx, int32_t kind, const int32_t* avg, size_t avg_stride, uint32_t avg_w,
                                   uint32_t avg_h, uint32_t x0, uint32_t y0, int32_t* out, size_t out_stride,
                                   uint32_t out_w, uint32_t out_h);

@@ -471,6 +471,9 @@ jxlh_status jxlh_unsqueeze_rct(jxlh_ctx* ctx, int32_t horizontal, const int32_t*
 jxlh_status jxlh_smooth_unsqueeze(jxlh_ctx* ctx, int32_t kind, const int32_t* avg, size_t avg_stride, uint32_t avg_w,
                                   uint32_t avg_h, uint32_t x0, uint32_t y0, int32_t* out, size_t out_stride,
                                   uint32_t out_w, uint32_t out_h) {
+  // the float -> int conversion of the reference's build target rides in the kind argument
+  const bool cvt_rne = kind >= 0 && (kind & JXLH_SMOOTH_CVT_NEAREST_EVEN) != 0;
+  if (kind >= 0) kind &= ~JXLH_SMOOTH_CVT_NEAREST_EVEN;
   if (!ctx || !avg || !out || kind < JXLH_SMOOTH_H || kind > JXLH_SMOOTH_2D || avg_w == 0 || avg_h == 0 ||
       avg_stride < avg_w || out_stride < out_w || avg_w > (1u << 30) || avg_h > (1u << 30) || x0 > (1u << 30) ||
       y0 > (1u << 30) || out_w > (1u << 30) || out_h > (1u << 30))
@@ -481,7 +484,7 @@ jxlh_status jxlh_smooth_unsqueeze(jxlh_ctx* ctx, int32_t kind, const int32_t* av
   if (is_device_ptr(avg) && is_device_ptr(out)) {
     ScopedKernelTimer t(ctx, kNames[kind]);
     launch_smooth_unsqueeze(ctx->stream, kind, avg, avg_stride, (int)avg_w, (int)avg_h, (int)x0, (int)y0, out,
-                            out_stride, (int)out_w, (int)out_h);
+                            out_stride, (int)out_w, (int)out_h, cvt_rne);
     HIPCHK(ctx, hipGetLastError());
     return JXLH_OK;
   }
@@ -489,7 +492,7 @@ jxlh_status jxlh_smooth_unsqueeze(jxlh_ctx* ctx, int32_t kind, const int32_t* av
   if ((st = stage_in(ctx, ctx->hook_i[0], avg, avg_stride * avg_h))) return st;
   if ((st = ensure(ctx, ctx->hook_i[2], out_stride * out_h))) return st;
   launch_smooth_unsqueeze(ctx->stream, kind, ctx->hook_i[0].p, avg_stride, (int)avg_w, (int)avg_h, (int)x0, (int)y0,
-                          ctx->hook_i[2].p, out_stride, (int)out_w, (int)out_h);
+                          ctx->hook_i[2].p, out_stride, (int)out_w, (int)out_h, cvt_rne);
   HIPCHK(ctx, hipGetLastError());
   /* every sample of the rectangle is written; the stride padding of a host `out` is overwritten with whatever the
    * staging buffer held only if out_stride > out_w -- copy row by row instead */

@@ -255,6 +255,6 @@ bool launch_unsqueeze_levels(hipStream_t s, int n_planes, int n_levels, const in
                              int32_t* const out[], size_t out_stride);
 // smooth_{h,v,2d}_unsqueeze on a rectangle of the output channel; `in` is the whole average channel
 void launch_smooth_unsqueeze(hipStream_t s, int kind, const int32_t* in, size_t in_stride, int in_w, int in_h, int x0,
-                             int y0, int32_t* out, size_t out_stride, int out_w, int out_h);
+                             int y0, int32_t* out, size_t out_stride, int out_w, int out_h, bool cvt_rne);
 
 }  // namespace jxlh

@@ -1700,7 +1700,9 @@ __device__ static constexpr SmTap kSm1d[2][16] = {
     {{2, SV65}, {3, SV73}, {6, SV41}, {7, SV17}, {8, SV25}, {9, SV65}, {11, SV25}, {12, SV1},
      {13, SV9}, {14, SV49}, {16, SV41}, {17, SV17}, {18, SV25}, {19, SV65}, {22, SV65}, {23, SV73}}};
 
-template <bool TWO_D, int WHICH>
+// RNE: the x86 back-ends' as_i32 (cvtps2dq: round to nearest even, jxl_simd/src/x86_64/avx.rs:580) instead of the
+// truncation of the scalar / NEON / wasm ones (scalar.rs:178): what a reference build running on an x86 host produces
+template <bool TWO_D, int WHICH, bool RNE>
 __device__ __forceinline__ int32_t smooth_eval(const float (&n)[25]) {
   float part[4];
 #pragma unroll
@@ -1715,7 +1717,8 @@ __device__ __forceinline__ int32_t smooth_eval(const float (&n)[25]) {
     part[g] = acc;
   }
   const float sum = __fadd_rn(__fadd_rn(part[0], part[1]), __fadd_rn(part[2], part[3]));
-  return (int32_t)__fadd_rn(sum, copysignf(0.5f, sum));
+  const float biased = __fadd_rn(sum, copysignf(0.5f, sum));
+  return RNE ? (int32_t)rintf(biased) : (int32_t)biased;
 }
 
 #define JXLH_SM_TX 64
@@ -1723,7 +1726,7 @@ __device__ __forceinline__ int32_t smooth_eval(const float (&n)[25]) {
 #define JXLH_SM_RPT 8                                 // consecutive rows one thread walks with a sliding window
 #define JXLH_SM_TY (JXLH_SM_WAVES * JXLH_SM_RPT)      // average rows per workgroup: 20 window rows for 16 (1.25x)
 // KIND 0: horizontal (out = 2 in_x), 1: vertical, 2: both.  nx x ny = average samples the rectangle covers.
-template <int KIND, bool PAIR>
+template <int KIND, bool PAIR, bool RNE>
 __global__ __launch_bounds__(JXLH_SM_TX* JXLH_SM_WAVES) void k6_smooth_unsqueeze(
     const int32_t* __restrict__ in, size_t in_stride, int in_w, int in_h, int cx0, int cy0, int32_t* __restrict__ out,
     size_t out_stride, int out_w, int out_h, int nx, int ny) {
@@ -1763,8 +1766,8 @@ __global__ __launch_bounds__(JXLH_SM_TX* JXLH_SM_WAVES) void k6_smooth_unsqueeze
 #pragma unroll
       for (int c = 0; c < 5; c++) n[KIND == 1 ? 5 * c + r : 5 * r + c] = win[r][c];
     if (KIND == 2) {
-      const int32_t o00 = smooth_eval<true, 0>(n), o01 = smooth_eval<true, 1>(n);
-      const int32_t o10 = smooth_eval<true, 2>(n), o11 = smooth_eval<true, 3>(n);
+      const int32_t o00 = smooth_eval<true, 0, RNE>(n), o01 = smooth_eval<true, 1, RNE>(n);
+      const int32_t o10 = smooth_eval<true, 2, RNE>(n), o11 = smooth_eval<true, 3, RNE>(n);
       int32_t* p0 = out + (size_t)(2 * iy) * out_stride + 2 * ix;
       if (PAIR && both) {  // PAIR: base and stride keep every sample pair 8-byte aligned
         *(int2*)p0 = make_int2(o00, o01);
@@ -1779,7 +1782,7 @@ __global__ __launch_bounds__(JXLH_SM_TX* JXLH_SM_WAVES) void k6_smooth_unsqueeze
       }
     } else if (KIND == 0) {
       int32_t* p = out + (size_t)iy * out_stride + 2 * ix;
-      const int32_t e = smooth_eval<false, 0>(n), o = smooth_eval<false, 1>(n);
+      const int32_t e = smooth_eval<false, 0, RNE>(n), o = smooth_eval<false, 1, RNE>(n);
       if (PAIR && both) {
         *(int2*)p = make_int2(e, o);
       } else {
@@ -1788,8 +1791,8 @@ __global__ __launch_bounds__(JXLH_SM_TX* JXLH_SM_WAVES) void k6_smooth_unsqueeze
       }
     } else {
       int32_t* p = out + (size_t)(2 * iy) * out_stride + ix;
-      p[0] = smooth_eval<false, 0>(n);
-      if (2 * iy + 1 < out_h) p[out_stride] = smooth_eval<false, 1>(n);
+      p[0] = smooth_eval<false, 0, RNE>(n);
+      if (2 * iy + 1 < out_h) p[out_stride] = smooth_eval<false, 1, RNE>(n);
     }
 #pragma unroll
     for (int r = 0; r < 4; r++)
@@ -1799,7 +1802,7 @@ __global__ __launch_bounds__(JXLH_SM_TX* JXLH_SM_WAVES) void k6_smooth_unsqueeze
 }
 
 void launch_smooth_unsqueeze(hipStream_t s, int kind, const int32_t* in, size_t in_stride, int in_w, int in_h, int x0,
-                             int y0, int32_t* out, size_t out_stride, int out_w, int out_h) {
+                             int y0, int32_t* out, size_t out_stride, int out_w, int out_h, bool cvt_rne) {
   const bool fx = kind != 1, fy = kind != 0;
   // the reference returns with the output untouched when the rectangle has no complete pair (squeeze.rs:921-923)
   if ((fx ? out_w / 2 : out_w) == 0 || (fy ? out_h / 2 : out_h) == 0) return;
@@ -1808,9 +1811,14 @@ void launch_smooth_unsqueeze(hipStream_t s, int kind, const int32_t* in, size_t 
   const dim3 grid((nx + JXLH_SM_TX - 1) / JXLH_SM_TX, (ny + JXLH_SM_TY - 1) / JXLH_SM_TY);
   const dim3 block(JXLH_SM_TX * JXLH_SM_WAVES);
   const bool pair = (uintptr_t)out % 8 == 0 && out_stride % 2 == 0;
-#define JXLH_SM_LAUNCH(K, P)                                                                                        \
-  hipLaunchKernelGGL((k6_smooth_unsqueeze<K, P>), grid, block, 0, s, in, in_stride, in_w, in_h, cx0, cy0, out,      \
+#define JXLH_SM_LAUNCH1(K, P, R)                                                                                    \
+  hipLaunchKernelGGL((k6_smooth_unsqueeze<K, P, R>), grid, block, 0, s, in, in_stride, in_w, in_h, cx0, cy0, out,   \
                      out_stride, out_w, out_h, nx, ny)
+#define JXLH_SM_LAUNCH(K, P)                  \
+  do {                                        \
+    if (cvt_rne) JXLH_SM_LAUNCH1(K, P, true); \
+    else JXLH_SM_LAUNCH1(K, P, false);        \
+  } while (0)
   if (kind == 0) {
     if (pair) JXLH_SM_LAUNCH(0, true); else JXLH_SM_LAUNCH(0, false);
   } else if (kind == 1) {
@@ -1819,6 +1827,7 @@ void launch_smooth_unsqueeze(hipStream_t s, int kind, const int32_t* in, size_t 
     if (pair) JXLH_SM_LAUNCH(2, true); else JXLH_SM_LAUNCH(2, false);
   }
 #undef JXLH_SM_LAUNCH
+#undef JXLH_SM_LAUNCH1
 }
 
 }  // namespace jxlh

@@ -795,9 +795,11 @@ class Context:
                                             out_h, ov, out_stride, op, perm), "unsqueeze_rct")
 
     SMOOTH_H, SMOOTH_V, SMOOTH_2D = 0, 1, 2
+    SMOOTH_CVT_NEAREST_EVEN = 0x100  # the x86 back-ends' as_i32 (cvtps2dq) instead of truncation
 
-    def smooth_unsqueeze(self, kind, avg, out_w, out_h, x0=0, y0=0, out=None):
+    def smooth_unsqueeze(self, kind, avg, out_w, out_h, x0=0, y0=0, out=None, cvt_rne=False):
         """smooth_{h,v,2d}_unsqueeze (squeeze.rs:908-1225): `avg` the whole average channel, host array."""
+        kind |= self.SMOOTH_CVT_NEAREST_EVEN if cvt_rne else 0
         avg = np.ascontiguousarray(avg, dtype=np.int32)
         if out is None:
             out = np.zeros((out_h, out_w), dtype=np.int32)

@@ -266,6 +266,11 @@ void jxlo_smooth_convolve_2d(const float n[25], int cvt_rne, int32_t out[4]);
 void jxlo_smooth_convolve_1d(const float n[25], int cvt_rne, int32_t out[2]);
 void jxlo_smooth_unsqueeze(int kind, const int32_t* in, size_t in_stride, int in_w, int in_h, int x0, int y0,
                            int32_t* out, size_t out_stride, int out_w, int out_h, int cvt_rne);
+/* every step in the SIMD back-ends' wrapping i32 form (unsqueeze_impl + smooth_tendency_impl, squeeze.rs:107-185) */
+void jxlo_unsqueeze_h_simd(const int32_t* avg, size_t avg_stride, const int32_t* res, size_t res_stride,
+                           int out_w, int h, int32_t* out, size_t out_stride);
+void jxlo_unsqueeze_v_simd(const int32_t* avg, size_t avg_stride, const int32_t* res, size_t res_stride,
+                           int w, int out_h, int32_t* out, size_t out_stride);
 int64_t jxlo_smooth_tendency(int64_t b, int64_t a, int64_t n);
 int32_t jxlo_smooth_tendency_i32(int32_t a, int32_t b, int32_t c); /* SIMD formulation */
 

@@ -348,8 +348,23 @@ static inline void unsqueeze(int32_t avg, int32_t res, int32_t next_avg, int32_t
   *b = (int32_t)bb;
 }
 
-void jxlo_unsqueeze_h(const int32_t* avg, size_t avg_stride, const int32_t* res, size_t res_stride,
-                      int out_w, int h, int32_t* out, size_t out_stride) {
+/* unsqueeze_impl (squeeze.rs:171-185): the 32-bit form the SIMD back-ends run on all but the remainder columns /
+ * rows (hsqueeze_impl :197-290, vsqueeze_impl :483-574) -- Wrapping<i32> lanes, tendency from smooth_tendency_impl,
+ * diff / 2 as (diff + sign bit) >> 1.  Equal to the scalar definition wherever nothing wraps; beyond that the
+ * reference's two forms give different answers for the same input. */
+static inline void unsqueeze_simd(int32_t avg, int32_t res, int32_t next_avg, int32_t prev, int32_t* a, int32_t* b) {
+  const int32_t tendency = jxlo_smooth_tendency_i32(prev, avg, next_avg);
+  const int32_t diff = wadd(res, tendency);
+  const int32_t sign = (int32_t)((uint32_t)diff >> 31);
+  const int32_t diff_2 = sar(wadd(diff, sign), 1);
+  *a = wadd(avg, diff_2);
+  *b = wsub(*a, diff);
+}
+#define unsqueeze_any(avg, res, next, prev, a, b) \
+  (simd ? unsqueeze_simd(avg, res, next, prev, a, b) : unsqueeze(avg, res, next, prev, a, b))
+
+static void unsqueeze_h_impl(const int32_t* avg, size_t avg_stride, const int32_t* res, size_t res_stride,
+                             int out_w, int h, int32_t* out, size_t out_stride, int simd) {
   const int w = out_w / 2; /* residual width; avg width = out_w - w */
   if (out_w == 0 || h == 0) return;
   if (w == 0) { /* do_hsqueeze_step :468-476 */
@@ -365,14 +380,14 @@ void jxlo_unsqueeze_h(const int32_t* avg, size_t avg_stride, const int32_t* res,
     const int x_end = has_tail ? w : w - 1;
     for (int x = 0; x < x_end; x++) {
       int32_t a, b;
-      unsqueeze(ar[x], rr[x], ar[x + 1], prev_b, &a, &b);
+      unsqueeze_any(ar[x], rr[x], ar[x + 1], prev_b, &a, &b);
       o[2 * x] = a;
       o[2 * x + 1] = b;
       prev_b = b;
     }
     if (!has_tail) {
       int32_t a, b;
-      unsqueeze(ar[w - 1], rr[w - 1], ar[w - 1], prev_b, &a, &b);
+      unsqueeze_any(ar[w - 1], rr[w - 1], ar[w - 1], prev_b, &a, &b);
       o[2 * w - 2] = a;
       o[2 * w - 1] = b;
     } else {
@@ -381,8 +396,8 @@ void jxlo_unsqueeze_h(const int32_t* avg, size_t avg_stride, const int32_t* res,
   }
 }
 
-void jxlo_unsqueeze_v(const int32_t* avg, size_t avg_stride, const int32_t* res, size_t res_stride,
-                      int w, int out_h, int32_t* out, size_t out_stride) {
+static void unsqueeze_v_impl(const int32_t* avg, size_t avg_stride, const int32_t* res, size_t res_stride,
+                             int w, int out_h, int32_t* out, size_t out_stride, int simd) {
   const int h = out_h / 2;
   if (out_h == 0 || w == 0) return;
   if (h == 0) { /* do_vsqueeze_step :672-675 */
@@ -397,12 +412,31 @@ void jxlo_unsqueeze_v(const int32_t* avg, size_t avg_stride, const int32_t* res,
     const int32_t* pb = y == 0 ? ar : out + (size_t)(2 * y - 1) * out_stride;
     for (int x = 0; x < w; x++) {
       int32_t a, b;
-      unsqueeze(ar[x], rr[x], an[x], pb[x], &a, &b);
+      unsqueeze_any(ar[x], rr[x], an[x], pb[x], &a, &b);
       out[(size_t)(2 * y) * out_stride + x] = a;
       out[(size_t)(2 * y + 1) * out_stride + x] = b;
     }
   }
   if (has_tail) memcpy(out + (size_t)(2 * h) * out_stride, avg + (size_t)h * avg_stride, sizeof(int32_t) * w);
+}
+
+void jxlo_unsqueeze_h(const int32_t* avg, size_t avg_stride, const int32_t* res, size_t res_stride,
+                      int out_w, int h, int32_t* out, size_t out_stride) {
+  unsqueeze_h_impl(avg, avg_stride, res, res_stride, out_w, h, out, out_stride, 0);
+}
+void jxlo_unsqueeze_v(const int32_t* avg, size_t avg_stride, const int32_t* res, size_t res_stride,
+                      int w, int out_h, int32_t* out, size_t out_stride) {
+  unsqueeze_v_impl(avg, avg_stride, res, res_stride, w, out_h, out, out_stride, 0);
+}
+/* the same drivers with EVERY step in the SIMD back-ends' wrapping 32-bit form (a reference build runs it on the bulk
+ * of a plane and the scalar form on the remainder columns / rows; the two agree for samples below 2^28) */
+void jxlo_unsqueeze_h_simd(const int32_t* avg, size_t avg_stride, const int32_t* res, size_t res_stride,
+                           int out_w, int h, int32_t* out, size_t out_stride) {
+  unsqueeze_h_impl(avg, avg_stride, res, res_stride, out_w, h, out, out_stride, 1);
+}
+void jxlo_unsqueeze_v_simd(const int32_t* avg, size_t avg_stride, const int32_t* res, size_t res_stride,
+                           int w, int out_h, int32_t* out, size_t out_stride) {
+  unsqueeze_v_impl(avg, avg_stride, res, res_stride, w, out_h, out, out_stride, 1);
 }
 
 /* ---- smooth unsqueeze: what a squeeze step runs when its residual channel has not arrived (all-zero), i.e. the

@@ -161,6 +161,8 @@ class Oracle:
         L.jxlo_palette_delta_wp.restype = None
         L.jxlo_unsqueeze_h.argtypes = [ip, C.c_size_t, ip, C.c_size_t, C.c_int, C.c_int, ip, C.c_size_t]
         L.jxlo_unsqueeze_v.argtypes = [ip, C.c_size_t, ip, C.c_size_t, C.c_int, C.c_int, ip, C.c_size_t]
+        L.jxlo_unsqueeze_h_simd.argtypes = L.jxlo_unsqueeze_h.argtypes
+        L.jxlo_unsqueeze_v_simd.argtypes = L.jxlo_unsqueeze_v.argtypes
         L.jxlo_smooth_convolve_2d.argtypes = [fp, C.c_int, ip]
         L.jxlo_smooth_convolve_1d.argtypes = [fp, C.c_int, ip]
         L.jxlo_smooth_unsqueeze.argtypes = [C.c_int, ip, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, ip,
@@ -614,12 +616,13 @@ class Oracle:
                                        pal.shape[1], nb_channels, bit_depth, _ptr(hdr, C.c_uint32), _ptr(out, C.c_int32))
         return out
 
-    def unsqueeze_h(self, avg, res, out_w):
+    def unsqueeze_h(self, avg, res, out_w, simd_form=False):
+        """simd_form: every step in the SIMD back-ends' wrapping i32 form instead of the scalar i64 definition"""
         avg = np.ascontiguousarray(avg, dtype=np.int32)
         res = np.ascontiguousarray(res, dtype=np.int32)
         h = avg.shape[0]
         out = np.zeros((h, out_w), dtype=np.int32)
-        self.lib.jxlo_unsqueeze_h(_ptr(avg, C.c_int32), avg.shape[1], _ptr(res, C.c_int32),
+        (self.lib.jxlo_unsqueeze_h_simd if simd_form else self.lib.jxlo_unsqueeze_h)(_ptr(avg, C.c_int32), avg.shape[1], _ptr(res, C.c_int32),
                                   max(res.shape[1], 1), out_w, h, _ptr(out, C.c_int32), out_w)
         return out
 
@@ -641,11 +644,11 @@ class Oracle:
                                        _ptr(out, C.c_int32), out.shape[1], out_w, out_h, int(cvt_rne))
         return out
 
-    def unsqueeze_v(self, avg, res, out_h):
+    def unsqueeze_v(self, avg, res, out_h, simd_form=False):
         avg = np.ascontiguousarray(avg, dtype=np.int32)
         res = np.ascontiguousarray(res, dtype=np.int32)
         w = avg.shape[1]
         out = np.zeros((out_h, w), dtype=np.int32)
-        self.lib.jxlo_unsqueeze_v(_ptr(avg, C.c_int32), w, _ptr(res, C.c_int32), w, w, out_h,
+        (self.lib.jxlo_unsqueeze_v_simd if simd_form else self.lib.jxlo_unsqueeze_v)(_ptr(avg, C.c_int32), w, _ptr(res, C.c_int32), w, w, out_h,
                                   _ptr(out, C.c_int32), w)
         return out

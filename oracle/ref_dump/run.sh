@@ -8,6 +8,9 @@ command -v cargo >/dev/null || { echo "cargo not found: the reference cannot be 
 WORK="$ROOT/oracle/_ref/jxl-rs"
 rm -rf "$WORK" && mkdir -p "$WORK"
 cp -r "$REF"/. "$WORK"/
+# functions that need a decoded frame around them are instrumented in the scratch copy (anchors verified first)
+python3 "$HERE/instrument.py" --check "$WORK"
+python3 "$HERE/instrument.py" "$WORK"
 # the .vec writer becomes a crate-level test module ...
 cat "$HERE/vec_io.rs" >> "$WORK/jxl/src/lib.rs"
 # ... and each dump module is appended to the file named in its first line

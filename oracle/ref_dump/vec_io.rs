@@ -29,4 +29,46 @@ mod ref_dump_io {
             f.write_all(&v.to_le_bytes()).unwrap();
         }
     }
+
+    // ---- helpers of the instrumented dumps (oracle/ref_dump/instrument.py): a name prefix per decoded file, and a
+    // once-per-(prefix, site) latch so that only the first call of an instrumented function writes its vectors
+    static PREFIX: std::sync::Mutex<String> = std::sync::Mutex::new(String::new());
+    static DONE: std::sync::Mutex<Vec<String>> = std::sync::Mutex::new(Vec::new());
+
+    pub fn set_prefix(p: &str) {
+        *PREFIX.lock().unwrap() = p.to_string();
+    }
+
+    pub fn name(site: &str) -> String {
+        format!("{}_{}", PREFIX.lock().unwrap(), site)
+    }
+
+    pub fn once(site: &str) -> bool {
+        if dir().is_none() || PREFIX.lock().unwrap().is_empty() {
+            return false;
+        }
+        let key = name(site);
+        let mut done = DONE.lock().unwrap();
+        if done.contains(&key) {
+            return false;
+        }
+        done.push(key);
+        true
+    }
+
+    pub fn flat_f32(i: &crate::image::Image<f32>) -> Vec<f32> {
+        (0..i.size().1).flat_map(|y| i.row(y).to_vec()).collect()
+    }
+
+    pub fn flat_i32(i: &crate::image::Image<i32>) -> Vec<i32> {
+        (0..i.size().1).flat_map(|y| i.row(y).to_vec()).collect()
+    }
+
+    pub fn flat_u8(i: &crate::image::Image<u8>) -> Vec<i32> {
+        (0..i.size().1).flat_map(|y| i.row(y).iter().map(|v| *v as i32).collect::<Vec<_>>()).collect()
+    }
+
+    pub fn flat_i8(i: &crate::image::Image<i8>) -> Vec<i32> {
+        (0..i.size().1).flat_map(|y| i.row(y).iter().map(|v| *v as i32).collect::<Vec<_>>()).collect()
+    }
 }

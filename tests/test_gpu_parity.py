@@ -836,7 +836,7 @@ def test_unsqueeze_rejects_dimensions_whose_product_wraps(ctx):
     assert st == lib.ERR_INVALID_ARGUMENT
 
 
-@pytest.mark.parametrize("scale", [2**15, 2**24, 2**28])
+@pytest.mark.parametrize("scale", [2**15, 2**24, 2**27, 2**28])
 def test_unsqueeze_large_magnitudes(ctx, oracle, scale):
     """the device folds the reference's two parity clamps into min() operations (k_modular.hip); checked here
     on large-magnitude data inside the range where the reference's i64 scalar definition and its wrapping
@@ -846,10 +846,14 @@ def test_unsqueeze_large_magnitudes(ctx, oracle, scale):
     avg = rng.integers(-scale, scale, size=(h, (w + 1) // 2), dtype=np.int64).astype(np.int32)
     res = rng.integers(-scale, scale, size=(h, w // 2), dtype=np.int64).astype(np.int32)
     avg[2::5, 1:] = avg[2::5, :-1]   # equal neighbours: zero differences
-    assert np.array_equal(ctx.unsqueeze(True, avg, res, w, h), oracle.unsqueeze_h(avg, res, w))
+    got = ctx.unsqueeze(True, avg, res, w, h)
+    assert np.array_equal(got, oracle.unsqueeze_h(avg, res, w))
+    assert np.array_equal(got, oracle.unsqueeze_h(avg, res, w, simd_form=True))  # the reference's wrapping i32 SIMD form
     a2 = rng.integers(-scale, scale, size=((h + 1) // 2, w), dtype=np.int64).astype(np.int32)
     r2 = rng.integers(-scale, scale, size=(h // 2, w), dtype=np.int64).astype(np.int32)
-    assert np.array_equal(ctx.unsqueeze(False, a2, r2, w, h), oracle.unsqueeze_v(a2, r2, h))
+    got = ctx.unsqueeze(False, a2, r2, w, h)
+    assert np.array_equal(got, oracle.unsqueeze_v(a2, r2, h))
+    assert np.array_equal(got, oracle.unsqueeze_v(a2, r2, h, simd_form=True))
 
 
 @pytest.mark.parametrize("size", [(700, 500), (257, 129), (9, 300), (1031, 17), (16, 16), (130, 2000)])

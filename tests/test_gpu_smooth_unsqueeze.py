@@ -105,6 +105,38 @@ def test_constant_and_impulse_known_answers(ctx):
     assert up[8, 8] == up[9, 9] == up[8, 9] == up[9, 8] and up[8, 8] > 6000
 
 
+@pytest.mark.parametrize("kind", [H, V, D2])
+def test_rounding_mode_of_the_reference_build(ctx, oracle, kind):
+    """`as_i32` is truncation on the reference's scalar / NEON / wasm back-ends and cvtps2dq (round to nearest even) on
+    its x86 ones (jxl_simd/src/x86_64/avx.rs:580 vs scalar.rs:178): the caller picks the build it stands in for with
+    JXLH_SMOOTH_CVT_NEAREST_EVEN.  Both modes against the oracle's two modes, whole channels and an offset tile, host
+    and device pointers; and the two modes really differ (by at most one)."""
+    w, h = 173, 97
+    ih, iw = avg_shape(kind, w, h)
+    avg = np.random.default_rng(21 + kind).integers(-4000, 4000, size=(ih, iw)).astype(np.int32)
+    trunc = ctx.smooth_unsqueeze(kind, avg, w, h)
+    rne = ctx.smooth_unsqueeze(kind, avg, w, h, cvt_rne=True)
+    assert np.array_equal(trunc, oracle.smooth_unsqueeze(kind, avg, w, h, cvt_rne=False))
+    assert np.array_equal(rne, oracle.smooth_unsqueeze(kind, avg, w, h, cvt_rne=True))
+    d = np.abs(rne.astype(np.int64) - trunc)
+    assert d.max() == 1 and 0.2 < (d != 0).mean() < 0.8
+    # a grid tile at an offset, device-resident, x86 mode
+    x0, y0, tw, th = 64, 32, 60, 50
+    want = oracle.smooth_unsqueeze(kind, avg, tw, th, x0=x0, y0=y0, cvt_rne=True)
+    d_avg, d_out = DeviceArray(avg), DeviceArray(nbytes=tw * th * 4)
+    ctx.smooth_unsqueeze_dev(kind | ctx.SMOOTH_CVT_NEAREST_EVEN, d_avg.ptr, iw, iw, ih, d_out.ptr, tw, tw, th, x0=x0, y0=y0)
+    ctx.sync()
+    assert np.array_equal(d_out.download(np.int32, tw * th).reshape(th, tw), want)
+    assert np.array_equal(want, rne[y0:y0 + th, x0:x0 + tw])
+    for buf in (d_avg, d_out):
+        buf.free()
+    # a stray flag bit is still an invalid kind
+    from jxl_rs_amd import lib, JxlHipError
+    with pytest.raises(JxlHipError) as e:
+        ctx.smooth_unsqueeze(kind | 0x200, avg, w, h)
+    assert e.value.status == lib.ERR_INVALID_ARGUMENT
+
+
 def test_progressive_preview_of_a_squeezed_channel(ctx, oracle):
     """The use this exists for: a channel squeezed h then v whose two finest residuals have not arrived.  The
     reference upsamples the quarter-size average with the 2-D kernel for the final (horizontal) step

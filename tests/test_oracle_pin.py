@@ -615,3 +615,47 @@ def test_unsqueeze_d_state_restatement_equals_the_reference_forms(oracle, bits):
         out[:, 2 * x], out[:, 2 * x + 1] = a, b
     out[:, w - 1] = avg[:, nr]
     assert np.array_equal(out, oracle.unsqueeze_h(avg, res, w))
+
+
+def _device_form_h(avg, res, w):
+    """a whole horizontal step with the device's restated recurrence (numpy transcription above)"""
+    h = avg.shape[0]
+    out, d, nr = np.zeros((h, w), np.int32), np.zeros(h, np.int32), w // 2
+    for x in range(nr):
+        cur = avg[:, x]
+        nx = avg[:, x + 1] if x + 1 < avg.shape[1] else cur
+        a, b, d = _unsqueeze_step_d_state(cur, res[:, x], nx, d)
+        out[:, 2 * x], out[:, 2 * x + 1] = a, b
+    if w & 1:
+        out[:, w - 1] = avg[:, nr]
+    return out
+
+
+def test_squeeze_forms_agree_up_to_2_28_and_the_reference_splits_beyond(oracle):
+    """The input bound include/jxl_hip.h documents for the squeeze entry points.  The reference holds TWO forms of the
+    step -- `unsqueeze_scalar` on i64 (squeeze.rs:187-194) for remainder columns / rows and the wrapping i32
+    `unsqueeze_impl` + `smooth_tendency_impl` (squeeze.rs:107-185) for everything its SIMD back-end covers.  Both are
+    restated in the oracle.  For samples in [-2^28, 2^28) the two agree with each other and with the device's form on
+    every sample; from 2^29 on the reference's own forms give different results for the same input (which one a
+    sample gets depends on its position inside the SIMD tiling), so there is no reference value to equal."""
+    h, w = 128, 257
+    for bits in (8, 20, 27, 28):
+        rng = np.random.default_rng(100 + bits)
+        lim = 1 << bits
+        avg = rng.integers(-lim, lim, size=(h, (w + 1) // 2), dtype=np.int64).astype(np.int32)
+        res = rng.integers(-lim, lim, size=(h, w // 2), dtype=np.int64).astype(np.int32)
+        sc = oracle.unsqueeze_h(avg, res, w)
+        si = oracle.unsqueeze_h(avg, res, w, simd_form=True)
+        assert np.array_equal(sc, si), bits
+        assert np.array_equal(_device_form_h(avg, res, w), sc), bits
+        a2 = np.ascontiguousarray(avg.T)
+        r2 = np.ascontiguousarray(res.T)
+        assert np.array_equal(oracle.unsqueeze_v(a2, r2, w), sc.T)
+        assert np.array_equal(oracle.unsqueeze_v(a2, r2, w, simd_form=True), sc.T)
+    for bits, least in ((30, 0.05), (31, 0.3)):
+        rng = np.random.default_rng(100 + bits)
+        lim = 1 << bits
+        avg = rng.integers(-lim, lim, size=(h, (w + 1) // 2), dtype=np.int64).astype(np.int32)
+        res = rng.integers(-lim, lim, size=(h, w // 2), dtype=np.int64).astype(np.int32)
+        split = np.mean(oracle.unsqueeze_h(avg, res, w) != oracle.unsqueeze_h(avg, res, w, simd_form=True))
+        assert split > least, (bits, split)
