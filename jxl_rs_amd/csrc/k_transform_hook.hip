@@ -70,7 +70,7 @@ __global__ __launch_bounds__(64) void k_t2p_special(int type, uint32_t n, const 
 __global__ __launch_bounds__(kLargeThreads) void k_t2p_large(int type, uint32_t n, const float* __restrict__ coeffs,
                                                              const float* __restrict__ lf,
                                                              float* __restrict__ pixels) {
-  __shared__ float lds[2 * (kLargeSlab + 256) + 1024];
+  __shared__ __attribute__((aligned(16))) float lds[kLargeWaves * kLargeTile + 2048];
   const int cx = covered_x(type), cy = covered_y(type);
   const size_t N = (size_t)cx * cy * 64;
   for (uint32_t blk = blockIdx.x; blk < n; blk += gridDim.x) {

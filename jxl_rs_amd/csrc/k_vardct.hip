@@ -25,66 +25,9 @@
 // work items); arithmetic is f32 in the reference's operation order (bit-exact vs the FMA
 // build of the oracle).  Output is independent of the order in which work items land in
 // the lists (each varblock is independent).
-#include "varblock_core.h"
-#include "varblock_large.h"
+#include "k_vardct_common.h"
 
 namespace jxlh {
-namespace {
-
-constexpr int kWaves = 4;
-constexpr int kThreads = kWaves * 64;
-
-// class ids of the work lists
-enum : int {
-  kClsDct8 = 0, kClsDct16x8, kClsDct8x16, kClsDct16x16, kClsDct32x8, kClsDct8x32, kClsDct32x16, kClsDct16x32,
-  kClsDct32x32, kClsSpecial, kClsLarge, kNumClasses
-};
-
-__host__ __device__ constexpr int class_of_type(int t) {
-  constexpr int lut[27] = {kClsDct8,    kClsSpecial, kClsSpecial, kClsSpecial,  kClsDct16x16, kClsDct32x32, kClsDct16x8,
-                           kClsDct8x16, kClsDct32x8, kClsDct8x32, kClsDct32x16, kClsDct16x32, kClsSpecial,  kClsSpecial,
-                           kClsSpecial, kClsSpecial, kClsSpecial, kClsSpecial,  kClsLarge,    kClsLarge,    kClsLarge,
-                           kClsLarge,   kClsLarge,   kClsLarge,   kClsLarge,    kClsLarge,    kClsLarge};
-  return lut[t];
-}
-// worst-case number of varblocks of a class per 8x8 block of frame area, as a divisor
-__host__ __device__ constexpr int class_min_area(int c) {
-  constexpr int lut[kNumClasses] = {1, 2, 2, 4, 4, 4, 8, 8, 16, 1, 32};
-  return lut[c];
-}
-
-// 32-byte work item
-struct __attribute__((aligned(16))) WorkItem {
-  uint32_t packed;  // bx | by << 5 | off64 << 10 | type << 20   (bx, by in blocks inside the group)
-  uint32_t group;
-  float sdy;        // inv_global_scale / raw_quant          (group.rs:153)
-  float x_cc;       // base_x + ytox / color_factor          (color_correlation_map.rs:76-78)
-  float b_cc;
-  uint32_t pad[3];
-};
-static_assert(sizeof(WorkItem) == 32, "work item layout");
-
-struct BlockInfo {
-  int coef_off;  // offset of the varblock inside the frame's coefficient store (channel X)
-  // per channel (they differ only in chroma-subsampled frames, K1e / group.rs:223-250, :485-504):
-  int px_off[3];  // offset of the top-left pixel in the channel's plane
-  int lf_off[3];  // by*xblocks + bx of the channel's first LF sample
-  float sdy, x_cc, b_cc;
-  int slot_base;  // sparse input: index of the varblock's first slot in sp_slot_start (channel X)
-  int first_pos;  // position of the varblock's first coefficient inside the channel slab
-};
-
-}  // namespace
-
-// every class counter on its own 128-byte line: the 1024 scan workgroups' atomics then meet on nine lines (and L2
-// channels) instead of one
-constexpr int kCountPitch = 32;
-constexpr size_t kCountBytes = (size_t)(kNumClasses + 1) * kCountPitch * sizeof(int);
-struct WorkLists {
-  WorkItem* items[kNumClasses];
-  int* counts;  // (kNumClasses + 1) counters at kCountPitch ints, zeroed before k1_scan; the last = large slab units
-};
-
 namespace {
 
 // ------------------------------------------------------------------------------------------
@@ -224,45 +167,6 @@ __global__ __launch_bounds__(kThreads) void k1_scan(const FrameDev f, const Work
     }
     off64 += sizes[i];
   }
-}
-
-__device__ __forceinline__ void decode_item(const FrameDev& f, const WorkItem& it, BlockInfo* bi) {
-  const int bx = it.packed & 31, by = (it.packed >> 5) & 31, off64 = (it.packed >> 10) & 1023;
-  const int g = (int)it.group;
-  const int gbx = (g % f.xgroups) * kGroupBlocks + bx, gby = (g / f.xgroups) * kGroupBlocks + by;
-  bi->coef_off = g * 3 * kGroupArea + off64 * 64;  // < 2^31: jxlh_frame_begin bounds the frame
-  bi->slot_base = g * 3 * kSlotTable + off64;
-  bi->first_pos = off64 * 64;
-  if (!f.subsampled) {
-    const int px = block_px_offset(f, gbx, gby), lf = gby * f.xblocks + gbx;
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-      bi->px_off[c] = px;
-      bi->lf_off[c] = lf;
-    }
-  } else {
-    // A channel holds only the blocks aligned to its sampling, at the down-sampled position; its LF
-    // samples sit in the top-left corner of each LF group's rectangle.  The other blocks are still
-    // transformed (their lanes cannot be re-assigned cheaply) and stored into a scrap tile behind the plane.
-    const int lfbx = gbx & ~(kLfGroupBlocks - 1), lfby = gby & ~(kLfGroupBlocks - 1);
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-      const int hs = f.hshift[c], vs = f.vshift[c];
-      const bool aligned = ((gbx >> hs) << hs) == gbx && ((gby >> vs) << vs) == gby;
-      bi->px_off[c] = aligned ? block_px_offset(f, gbx >> hs, gby >> vs) : f.scrap_off;
-      bi->lf_off[c] = (lfby + ((gby - lfby) >> vs)) * f.xblocks + lfbx + ((gbx - lfbx) >> hs);
-    }
-  }
-  bi->sdy = it.sdy;
-  bi->x_cc = it.x_cc;
-  bi->b_cc = it.b_cc;
-}
-
-// group.rs:85-96
-__device__ __forceinline__ float adjust_quant_bias(int q, float bias_c, float bias3) {
-  const float quant = (float)q;
-  const float adjusted = quant - bias3 / quant;
-  return (q > -2 && q < 2) ? quant * bias_c : adjusted;
 }
 
 // Dequantise four consecutive coefficients of channel CH (0 = X, 1 = Y, 2 = B); dy = the
@@ -766,79 +670,13 @@ __global__ __launch_bounds__(kSpecThreads, 2) void k1_special(const FrameDev f, 
   }
 }
 
-// family E: DCT64X64 .. DCT256X256.  A 256x256 varblock is 32 slab steps of 4096 samples per channel (16 per
-// separable pass) against 2 for a 64x64 one, and pass 2 needs all of pass 1: with a whole varblock-channel as the
-// work unit the kernel was as slow as its longest workgroup (3.5 ms at 16K with the 128 / 256 sizes present).  The
-// two passes are therefore separate launches over uniform SLAB units:
-//   k1_large_units   one thread per large varblock: reserves its slabs in the unit list (item | slab << 24)
-//   k1_large_pass<1> unit = (slab of lines, channel): dequantise + LLF corner + horizontal IDCT -> output rectangle
-//   k1_large_pass<2> unit = (slab of pixel columns, channel): vertical IDCT in place
-// (the varblock's own output rectangle is the inter-pass scratch; it stays in L2 / Infinity Cache between the launches)
-__global__ __launch_bounds__(256) void k1_large_units(const WorkLists wl, uint32_t* __restrict__ units) {
-  const int count = wl.counts[(kClsLarge) * kCountPitch];
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < count; e += gridDim.x * blockDim.x) {
-    const int type = (int)(wl.items[kClsLarge][e].packed >> 20) & 31;
-    const int n = max(1, covered_x(type) * covered_y(type) * 64 / kLargeSlab);  // 64x32 / 32x64: half a slab
-    const int base = atomicAdd(&wl.counts[(kNumClasses) * kCountPitch], n);
-    // capacity = nblocks / 32 + 16 >= the units any valid map can need (k1_scan drops overlapping varblocks)
-    for (int s = 0; s < n; s++) units[base + s] = (uint32_t)e | ((uint32_t)s << 24);
-  }
-}
-
-#ifndef JXLH_LARGE_WPE
-#define JXLH_LARGE_WPE 4
-#endif
-template <int PASS>
-__global__ __launch_bounds__(kLargeThreads, JXLH_LARGE_WPE) void k1_large_pass(const FrameDev f, const WorkLists wl,
-                                                                const uint32_t* __restrict__ units) {
-  __shared__ float s_lds[2 * (kLargeSlab + 256) + 1024];
-  const int total = wl.counts[(kNumClasses) * kCountPitch] * 3;
-  const int tid = threadIdx.x;
-  const float b0 = f.quant_biases[0], b1 = f.quant_biases[1], b2 = f.quant_biases[2], b3 = f.quant_biases[3];
-  for (int u = blockIdx.x; u < total; u += gridDim.x) {
-    const uint32_t unit = units[u / 3];
-    const int e = (int)(unit & 0xffffffu), slab = (int)(unit >> 24), ch = u % 3;
-    const WorkItem it = wl.items[kClsLarge][e];
-    BlockInfo bi;
-    decode_item(f, it, &bi);
-    const int type = (int)(it.packed >> 20) & 31;
-    const LargeGeom g(type);
-    const PixLayout lay = pix_layout(f);
-    float* plane = f.planes[ch] + bi.px_off[ch];
-    if constexpr (PASS == 2) {
-      large_pass2_slab(g, slab * g.LX, plane, lay, s_lds, tid);
-    } else {
-      const int v0 = slab * g.LV;
-      float* llf = s_lds + 2 * (kLargeSlab + 256);
-      if (g.slab_needs_llf(v0)) large_llf(f.lf[ch] + bi.lf_off[ch], f.xblocks, g.cy, g.cx, s_lds, llf, tid);
-      const int q = quant_table_for_type(type);
-      const float* __restrict__ table = f.tables + f.table_offset[q];
-      const int tsize = quant_table_size(q);
-      // one dequantiser for the three channels (the channel is uniform over the workgroup): Y alone, or the
-      // channel's own coefficient plus the chroma-from-luma multiple of the dequantised Y (group.rs:100-133)
-      const int32_t* __restrict__ qy = f.coeffs + bi.coef_off + kGroupArea;
-      const int32_t* __restrict__ qc = f.coeffs + bi.coef_off + ch * kGroupArea;
-      const float* __restrict__ ty = table + tsize;
-      const float* __restrict__ tc = table + ch * tsize;
-      const float sdy = bi.sdy, sdc = ch == 0 ? bi.sdy * f.x_dm : bi.sdy * f.b_dm;
-      const float cc = ch == 0 ? bi.x_cc : bi.b_cc, bc = ch == 0 ? b0 : b2;
-      const bool luma = ch == 1;
-      large_pass1_slab(
-          g, v0,
-          [&](int k) {
-            const float y = adjust_quant_bias(qy[k], b1, b3) * (ty[k] * sdy);
-            if (luma) return y;
-            return __builtin_fmaf(cc, y, adjust_quant_bias(qc[k], bc, b3) * (tc[k] * sdc));
-          },
-          llf, plane, lay, s_lds, tid);
-    }
-  }
-}
-
 }  // namespace
 
 // ---- host side -----------------------------------------------------------------------------
 static size_t large_unit_capacity(size_t nblocks) { return nblocks / 32 + 16; }
+// k_vardct_large.hip
+void launch_vardct_large(hipStream_t s, const FrameDev& f, const WorkLists& wl, int nblk, uint32_t* large_units,
+                         size_t unit_capacity, size_t nblocks);
 
 size_t vardct_worklist_bytes(const FrameDev& f) {
   const size_t nblocks = (size_t)f.xblocks * f.yblocks;
@@ -846,7 +684,9 @@ size_t vardct_worklist_bytes(const FrameDev& f) {
   for (int c = 0; c < kNumClasses; c++) items += nblocks / class_min_area(c) + 1;
   // + the slab-unit list of the large transforms: one u32 per 4096 samples of large-varblock area, but a 64x32 /
   // 32x64 varblock (32 blocks, half a slab) still takes a whole unit -> worst case one unit per 32 blocks
-  return items * sizeof(WorkItem) + kCountBytes + large_unit_capacity(nblocks) * sizeof(uint32_t);
+  // + the LLF planes of the large transforms (3 x nblocks floats, k1_large_llf)
+  return items * sizeof(WorkItem) + kCountBytes + large_unit_capacity(nblocks) * sizeof(uint32_t) + 64 +
+         3 * nblocks * sizeof(float);
 }
 
 void launch_vardct_groups(hipStream_t s, const FrameDev& f, int group_row0, int group_row1,
@@ -900,13 +740,7 @@ void launch_vardct_groups(hipStream_t s, const FrameDev& f, int group_row0, int 
   if (has_special)
     hipLaunchKernelGGL(k1_special, dim3(grid_for((long)(nblk / kSpecChunk + 1) * kSpecBins * 3, kSpecWaves, 1024)),
                        dim3(kSpecThreads), 0, s, f, wl);
-  if (!has_large) return;
-  // the large class: unit list, then one launch per separable pass; 4 workgroups fit a CU (39 KB of LDS each).  All
-  // three exit at once when the class is empty (the d1 mix)
-  hipLaunchKernelGGL(k1_large_units, dim3(grid_for(nblk / 64 + 1, 256, 64)), dim3(256), 0, s, wl, large_units);
-  const dim3 glarge(grid_for(3L * (nblk / 32 + 1), 1, 2048));
-  hipLaunchKernelGGL(k1_large_pass<1>, glarge, dim3(kLargeThreads), 0, s, f, wl, large_units);
-  hipLaunchKernelGGL(k1_large_pass<2>, glarge, dim3(kLargeThreads), 0, s, f, wl, large_units);
+  if (has_large) launch_vardct_large(s, f, wl, nblk, large_units, large_unit_capacity(nblocks), nblocks);
 }
 
 }  // namespace jxlh

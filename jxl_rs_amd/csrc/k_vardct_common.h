@@ -1,0 +1,99 @@
+// Shared by the K1 translation units (k_vardct.hip: scan + DCT8..32 classes + special transforms; k_vardct_large.hip:
+// the 64..256 transforms): the work-list types k1_scan writes and the per-item decoding.
+#pragma once
+#include "varblock_core.h"
+
+namespace jxlh {
+
+constexpr int kWaves = 4;
+constexpr int kThreads = kWaves * 64;
+
+// class ids of the work lists
+enum : int {
+  kClsDct8 = 0, kClsDct16x8, kClsDct8x16, kClsDct16x16, kClsDct32x8, kClsDct8x32, kClsDct32x16, kClsDct16x32,
+  kClsDct32x32, kClsSpecial, kClsLarge, kNumClasses
+};
+
+__host__ __device__ constexpr int class_of_type(int t) {
+  constexpr int lut[27] = {kClsDct8,    kClsSpecial, kClsSpecial, kClsSpecial,  kClsDct16x16, kClsDct32x32, kClsDct16x8,
+                           kClsDct8x16, kClsDct32x8, kClsDct8x32, kClsDct32x16, kClsDct16x32, kClsSpecial,  kClsSpecial,
+                           kClsSpecial, kClsSpecial, kClsSpecial, kClsSpecial,  kClsLarge,    kClsLarge,    kClsLarge,
+                           kClsLarge,   kClsLarge,   kClsLarge,   kClsLarge,    kClsLarge,    kClsLarge};
+  return lut[t];
+}
+// worst-case number of varblocks of a class per 8x8 block of frame area, as a divisor
+__host__ __device__ constexpr int class_min_area(int c) {
+  constexpr int lut[kNumClasses] = {1, 2, 2, 4, 4, 4, 8, 8, 16, 1, 32};
+  return lut[c];
+}
+
+// 32-byte work item
+struct __attribute__((aligned(16))) WorkItem {
+  uint32_t packed;  // bx | by << 5 | off64 << 10 | type << 20   (bx, by in blocks inside the group)
+  uint32_t group;
+  float sdy;        // inv_global_scale / raw_quant          (group.rs:153)
+  float x_cc;       // base_x + ytox / color_factor          (color_correlation_map.rs:76-78)
+  float b_cc;
+  uint32_t pad[3];
+};
+static_assert(sizeof(WorkItem) == 32, "work item layout");
+
+struct BlockInfo {
+  int coef_off;  // offset of the varblock inside the frame's coefficient store (channel X)
+  // per channel (they differ only in chroma-subsampled frames, K1e / group.rs:223-250, :485-504):
+  int px_off[3];  // offset of the top-left pixel in the channel's plane
+  int lf_off[3];  // by*xblocks + bx of the channel's first LF sample
+  float sdy, x_cc, b_cc;
+  int slot_base;  // sparse input: index of the varblock's first slot in sp_slot_start (channel X)
+  int first_pos;  // position of the varblock's first coefficient inside the channel slab
+};
+
+// every class counter on its own 128-byte line: the 1024 scan workgroups' atomics then meet on nine lines (and L2
+// channels) instead of one
+constexpr int kCountPitch = 32;
+constexpr size_t kCountBytes = (size_t)(kNumClasses + 1) * kCountPitch * sizeof(int);
+struct WorkLists {
+  WorkItem* items[kNumClasses];
+  int* counts;  // (kNumClasses + 1) counters at kCountPitch ints, zeroed before k1_scan; the last = large slab units
+};
+
+__device__ __forceinline__ void decode_item(const FrameDev& f, const WorkItem& it, BlockInfo* bi) {
+  const int bx = it.packed & 31, by = (it.packed >> 5) & 31, off64 = (it.packed >> 10) & 1023;
+  const int g = (int)it.group;
+  const int gbx = (g % f.xgroups) * kGroupBlocks + bx, gby = (g / f.xgroups) * kGroupBlocks + by;
+  bi->coef_off = g * 3 * kGroupArea + off64 * 64;  // < 2^31: jxlh_frame_begin bounds the frame
+  bi->slot_base = g * 3 * kSlotTable + off64;
+  bi->first_pos = off64 * 64;
+  if (!f.subsampled) {
+    const int px = block_px_offset(f, gbx, gby), lf = gby * f.xblocks + gbx;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      bi->px_off[c] = px;
+      bi->lf_off[c] = lf;
+    }
+  } else {
+    // A channel holds only the blocks aligned to its sampling, at the down-sampled position; its LF
+    // samples sit in the top-left corner of each LF group's rectangle.  The other blocks are still
+    // transformed (their lanes cannot be re-assigned cheaply) and stored into a scrap tile behind the plane.
+    const int lfbx = gbx & ~(kLfGroupBlocks - 1), lfby = gby & ~(kLfGroupBlocks - 1);
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const int hs = f.hshift[c], vs = f.vshift[c];
+      const bool aligned = ((gbx >> hs) << hs) == gbx && ((gby >> vs) << vs) == gby;
+      bi->px_off[c] = aligned ? block_px_offset(f, gbx >> hs, gby >> vs) : f.scrap_off;
+      bi->lf_off[c] = (lfby + ((gby - lfby) >> vs)) * f.xblocks + lfbx + ((gbx - lfbx) >> hs);
+    }
+  }
+  bi->sdy = it.sdy;
+  bi->x_cc = it.x_cc;
+  bi->b_cc = it.b_cc;
+}
+
+// group.rs:85-96
+__device__ __forceinline__ float adjust_quant_bias(int q, float bias_c, float bias3) {
+  const float quant = (float)q;
+  const float adjusted = quant - bias3 / quant;
+  return (q > -2 && q < 2) ? quant * bias_c : adjusted;
+}
+
+}  // namespace jxlh

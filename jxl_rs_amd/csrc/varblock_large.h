@@ -1,249 +1,166 @@
-// Workgroup-cooperative path for the large transforms (DCT64X64 ... DCT256X256,
-// transform types 18..26).  Semantics: transform.rs:447-509 (reinterpreting_dct2d_{cy}_{cx}
-// then idct2d_R_C), idct_large.rs:251-310 (recursive 1-D IDCT) and :387-501 (2-D drivers).
+// Wave-level path for the large transforms (DCT64X64 ... DCT256X256 and the 64x32 / 32x64 pair, transform types
+// 18..26).  Semantics: transform.rs:447-509 (reinterpreting_dct2d_{cy}_{cx} then idct2d_R_C), idct_large.rs:251-310
+// (recursive 1-D IDCT) and :387-501 (2-D drivers).
 //
-// A 256x256 varblock is 256 KiB per channel -- more than the CU's 160 KiB of LDS -- so the
-// two separable passes run slab by slab:
-//   pass 1  slab of LV lines (fixed v) x all C horizontal frequencies in LDS, 1-D IDCT_C along
-//           u as log2(C/32) decimation sweeps + one register IDCT_32 per (line, leaf) + the
-//           butterfly sweeps back up; result parked in the varblock's own output rectangle
-//   pass 2  slab of LX pixel columns x all R rows from that rectangle, IDCT_R along v, in place
-// The sweeps are elementwise over (pair, line) with `line` the fastest LDS index, so every
-// ds access of a wave is contiguous.  The operation order equals the reference recursion
-// (even half first, o[i] += o[i-1] on the *unmodified* odd inputs, w_i butterflies), so
-// results are bit-identical to the oracle's FMA build.
+// A 256x256 varblock is 256 KiB per channel -- more than a CU's LDS -- so the two separable passes run slab by slab,
+// a slab being 4096 samples = what ONE WAVEFRONT holds as 64 registers per lane:
+//   pass 1  slab = LV lines (fixed v) x all C horizontal frequencies; 1-D IDCT_C along u; result parked in the
+//           varblock's own output rectangle (it stays in L2 / Infinity Cache until pass 2)
+//   pass 2  slab = LX pixel columns x all R rows from that rectangle; IDCT_R along v; in place
+// Round 3 rewrite (profiles/r03_d_large_path.txt).  Round 2 ran the 1-D transforms as LDS sweeps of a 256-thread
+// workgroup: ~13 LDS accesses and 7 barriers per sample and pass, ~100 vector instructions per sample.  Now the
+// recursion idct_N = butterfly(idct_{N/2}(even), idct_{N/2}(prefix-summed odd)) is cut at length 64:
+//   * a lane owns one LEAF of one line: a length-64 sub-transform whose inputs it gathers straight from the staged
+//     line -- the decimation levels above the leaf are index arithmetic plus the odd halves' neighbour sums
+//     (EE[j] = t[4j], EO[j] = t[4j+2] + t[4j-2], OE[j] = t[4j+1] + t[4j-1], OO[j] = (t[4j+3] + t[4j+1]) + (t[4j-1] +
+//     t[4j-3]) for N = 256, the first element of an odd half times sqrt 2 instead) -- and transforms it in registers
+//     (idct1d<64>, the same code the 8..32 sizes use);
+//   * the N / 64 leaves of a line sit in adjacent lanes, so the butterflies back up (out[i] = e[i] + w_i o[i],
+//     out[n-1-i] = e[i] - w_i o[i]) are lane exchanges inside a quad (DPP quad_perm), no memory;
+//   * one LDS tile per wave (the staged lines; results written back in place for the coalesced store), only
+//     wave-scope synchronisation: 1 LDS write + ~2.3 reads + 1 write + 1 read per sample and pass, no barrier.
+// The operation order equals the reference recursion (even half first, o[i] += o[i-1] on the *unmodified* odd inputs,
+// level-n sums rounded before level n/2 adds them, w_i butterflies with FMA), so results are bit-identical to the
+// oracle's FMA build.
 #pragma once
 #include "varblock_core.h"
 
 namespace jxlh {
 
-constexpr int kLargeThreads = 256;
-constexpr int kLargeSlab = 4096;  // coefficients per slab
-constexpr int kSlabIters = kLargeSlab / kLargeThreads;      // samples per thread and slab
-constexpr int kPairIters = kLargeSlab / 2 / kLargeThreads;  // butterfly pairs per thread and sweep
-constexpr int kQuadIters = kLargeSlab / 4 / kLargeThreads;  // quads per thread and two-level sweep
-// Pairs (samples: twice as many) a thread has in flight at a time: every LDS / global read of a chunk is issued before
-// the first dependent operation.  The whole slab at once (8) costs registers the IDCT_32 leaves need.
-#ifndef JXLH_LARGE_CHUNK
-#define JXLH_LARGE_CHUNK 2
-#endif
-constexpr int kChunk = JXLH_LARGE_CHUNK;
-static_assert(kPairIters % kChunk == 0 && kQuadIters % kChunk == 0, "chunking");
+constexpr int kLargeThreads = 256;                 // 4 independent waves per workgroup
+constexpr int kLargeWaves = kLargeThreads / 64;
+constexpr int kLargeSlab = 4096;                   // samples per slab = per wave
+constexpr int kLargeTile = 64 * 65;                // floats of LDS per wave: lines x (N + N/64) for every N >= 64
 
-// 1-D IDCT of size N along i for L = 1 << lL lines; data at X[i*Lp + line].  Ping-pongs between a and b
-// and returns the buffer holding the result.  All threads of the workgroup must call.
-// Every size here is a power of two: the index arithmetic is shifts and masks (with run-time divisors it was the
-// bulk of the kernel's instructions -- ten integer divisions per sample and pass).
-template <int N>
-__device__ float* lds_idct(float* __restrict__ a, float* __restrict__ b, int lL, int Lp, int tid) {
-  float* src = a;
-  float* dst = b;
-  // L <= 128 divides the workgroup size, so a thread keeps ONE line through a whole sweep and walks the pairs
-  // p = p0, p0 + pstep, ...: addresses are affine in the iteration (the generic idx -> (line, pair) arithmetic was
-  // most of this kernel's ~100 vector instructions per sample and pass)
-  const int line = tid & ((1 << lL) - 1), p0 = tid >> lL, pstep = kLargeThreads >> lL;
-  constexpr int P = N / 2;  // pairs per line
-  // down-sweep: split every length-n sub-array into even | prefix-summed odd halves.  With n = 2h and p = s*h + i:
-  // source rows 2p, 2p + 1 (and 2p - 1), destination rows p + s*h and p + s*h + h
-  auto down = [&](auto n_tag) {
-    constexpr int n = decltype(n_tag)::value;
-    if constexpr (n <= N && n > 32) {
-      constexpr int h = n / 2;
-#pragma unroll 1
-      for (int c0 = 0; c0 < kPairIters; c0 += kChunk) {
-        if (p0 + c0 * pstep >= P) break;
-        float e[kChunk], o[kChunk], om[kChunk];
-#pragma unroll
-        for (int it = 0; it < kChunk; it++) {
-          const int p = p0 + (c0 + it) * pstep;
-          const bool on = p < P;
-          const float* q = src + (2 * p) * Lp + line;
-          e[it] = on ? q[0] : 0.f;
-          o[it] = on ? q[Lp] : 0.f;
-          om[it] = (on && (p & (h - 1)) != 0) ? q[-Lp] : 0.f;
-        }
-#pragma unroll
-        for (int it = 0; it < kChunk; it++) {
-          const int p = p0 + (c0 + it) * pstep;
-          if (p < P) {
-            float* d = dst + (p + (p & ~(h - 1))) * Lp + line;  // row p + s*h
-            d[0] = e[it];
-            d[h * Lp] = (p & (h - 1)) != 0 ? o[it] + om[it] : o[it] * kSqrt2;
-          }
-        }
-      }
-      __syncthreads();
-      float* t = src;
-      src = dst;
-      dst = t;
-    }
-  };
-  // Two recursion levels in one LDS round trip (lengths n and n/2; q = n/4, quad j of sub-array s):
-  //   E[2j] = x[4j], E[2j+1] = x[4j+2], O'[k] = x[2k+1] + x[2k-1] (k > 0) or x[1]*sqrt2   -- level n
-  //   ee = E[2j], eo = E[2j+1] + E[2j-1] (j > 0) or E[1]*sqrt2, likewise oe / oo from O'   -- level n/2
-  // i.e. exactly the operations of the two single sweeps (the level-n sums are rounded before level n/2 adds them),
-  // with 7 reads + 4 writes per quad instead of 12 + 8, and one barrier instead of two.
-  auto down2 = [&](auto n_tag) {
-    constexpr int n = decltype(n_tag)::value, h = n / 2, q = n / 4;
-    constexpr int Q = N / 4;  // quads per line
-    const int g0 = tid >> lL, gstep = kLargeThreads >> lL;
-#pragma unroll 1
-    for (int c0 = 0; c0 < kQuadIters; c0 += kChunk) {
-      if (g0 + c0 * gstep >= Q) break;
-      float ee[kChunk], eo[kChunk], oe[kChunk], oo[kChunk];
-#pragma unroll
-      for (int it = 0; it < kChunk; it++) {
-        const int g = g0 + (c0 + it) * gstep;
-        const bool on = g < Q;
-        const int j = g & (q - 1);
-        const float* x = src + (4 * g) * Lp + line;  // row base + 4j of sub-array s: 4g = s*n + 4j
-        const bool first = j == 0;
-        const float x0 = on ? x[0] : 0.f, x1 = on ? x[Lp] : 0.f, x2 = on ? x[2 * Lp] : 0.f, x3 = on ? x[3 * Lp] : 0.f;
-        const float xm1 = (on && !first) ? x[-Lp] : 0.f, xm2 = (on && !first) ? x[-2 * Lp] : 0.f,
-                    xm3 = (on && !first) ? x[-3 * Lp] : 0.f;
-        const float o_2j = first ? x1 * kSqrt2 : x1 + xm1;   // O'[2j]
-        const float o_2j1 = x3 + x1;                          // O'[2j+1]
-        const float o_2jm1 = xm1 + xm3;                       // O'[2j-1] (j > 0)
-        ee[it] = x0;
-        eo[it] = first ? x2 * kSqrt2 : x2 + xm2;
-        oe[it] = o_2j;
-        oo[it] = first ? o_2j1 * kSqrt2 : o_2j1 + o_2jm1;
-      }
-#pragma unroll
-      for (int it = 0; it < kChunk; it++) {
-        const int g = g0 + (c0 + it) * gstep;
-        if (g < Q) {
-          const int j = g & (q - 1), base = (g & ~(q - 1)) * 4;  // s * n
-          float* d = dst + (base + j) * Lp + line;
-          d[0] = ee[it];
-          d[q * Lp] = eo[it];
-          d[h * Lp] = oe[it];
-          d[(h + q) * Lp] = oo[it];
-        }
-      }
-    }
-    __syncthreads();
-    float* t = src;
-    src = dst;
-    dst = t;
-  };
-  if constexpr (N == 256) {
-    down2(std::integral_constant<int, 256>{});
-    down(std::integral_constant<int, 64>{});
-  } else if constexpr (N == 128) {
-    down2(std::integral_constant<int, 128>{});
-  } else {
-    down(std::integral_constant<int, 64>{});
-  }
-  // leaves: register IDCT_32 per (line, leaf), in place
-  for (int leaf = p0; leaf < N / 32; leaf += pstep) {
-    float x[32];
-    float* p = src + (leaf * 32) * Lp + line;
-#pragma unroll
-    for (int j = 0; j < 32; j++) x[j] = p[j * Lp];
-    idct1d<32, true>(x);
-#pragma unroll
-    for (int j = 0; j < 32; j++) p[j * Lp] = x[j];
-  }
-  __syncthreads();
-  // up-sweep: out[i] = e[i] + w_i o[i], out[n-1-i] = e[i] - w_i o[i]; source rows p + s*h and p + s*h + h,
-  // destination rows p + s*h and (s + 1)*n - 1 - i
-  auto sweep = [&](auto n_tag) {
-    constexpr int n = decltype(n_tag)::value;
-    if constexpr (n <= N) {
-      constexpr int h = n / 2;
-#pragma unroll 1
-      for (int c0 = 0; c0 < kPairIters; c0 += kChunk) {
-        if (p0 + c0 * pstep >= P) break;
-        float e[kChunk], o[kChunk];
-#pragma unroll
-        for (int it = 0; it < kChunk; it++) {
-          const int p = p0 + (c0 + it) * pstep;
-          const float* q = src + (p + (p & ~(h - 1))) * Lp + line;
-          e[it] = p < P ? q[0] : 0.f;
-          o[it] = p < P ? q[h * Lp] : 0.f;
-        }
-#pragma unroll
-        for (int it = 0; it < kChunk; it++) {
-          const int p = p0 + (c0 + it) * pstep;
-          if (p < P) {
-            const int i = p & (h - 1), sn = 2 * (p & ~(h - 1));  // s * n
-            const float w = IdctW<n>::w[i];
-            dst[(sn + i) * Lp + line] = __builtin_fmaf(o[it], w, e[it]);
-            dst[(sn + n - 1 - i) * Lp + line] = __builtin_fmaf(-o[it], w, e[it]);
-          }
-        }
-      }
-      __syncthreads();
-      float* t = src;
-      src = dst;
-      dst = t;
-    }
-  };
-  // two butterfly levels (lengths n/2 then n) in one round trip: 4 reads + 4 writes per quad instead of 8 + 8
-  auto sweep2 = [&](auto n_tag) {
-    constexpr int n = decltype(n_tag)::value, h = n / 2, q = n / 4;
-    constexpr int Q = N / 4;
-    const int g0 = tid >> lL, gstep = kLargeThreads >> lL;
-#pragma unroll 1
-    for (int c0 = 0; c0 < kQuadIters; c0 += kChunk) {
-      if (g0 + c0 * gstep >= Q) break;
-      float ee[kChunk], eo[kChunk], oe[kChunk], oo[kChunk];
-#pragma unroll
-      for (int it = 0; it < kChunk; it++) {
-        const int g = g0 + (c0 + it) * gstep;
-        const bool on = g < Q;
-        const int j = g & (q - 1), base = (g & ~(q - 1)) * 4;
-        const float* x = src + (base + j) * Lp + line;
-        ee[it] = on ? x[0] : 0.f;
-        eo[it] = on ? x[q * Lp] : 0.f;
-        oe[it] = on ? x[h * Lp] : 0.f;
-        oo[it] = on ? x[(h + q) * Lp] : 0.f;
-      }
-#pragma unroll
-      for (int it = 0; it < kChunk; it++) {
-        const int g = g0 + (c0 + it) * gstep;
-        if (g < Q) {
-          const int j = g & (q - 1), base = (g & ~(q - 1)) * 4;
-          const float wq = IdctW<h>::w[j];
-          const float e_lo = __builtin_fmaf(eo[it], wq, ee[it]), e_hi = __builtin_fmaf(-eo[it], wq, ee[it]);  // E[j], E[h-1-j]
-          const float o_lo = __builtin_fmaf(oo[it], wq, oe[it]), o_hi = __builtin_fmaf(-oo[it], wq, oe[it]);  // O[j], O[h-1-j]
-          const float w_lo = IdctW<n>::w[j], w_hi = IdctW<n>::w[h - 1 - j];
-          float* d = dst + base * Lp + line;
-          d[j * Lp] = __builtin_fmaf(o_lo, w_lo, e_lo);
-          d[(n - 1 - j) * Lp] = __builtin_fmaf(-o_lo, w_lo, e_lo);
-          d[(h - 1 - j) * Lp] = __builtin_fmaf(o_hi, w_hi, e_hi);
-          d[(h + j) * Lp] = __builtin_fmaf(-o_hi, w_hi, e_hi);
-        }
-      }
-    }
-    __syncthreads();
-    float* t = src;
-    src = dst;
-    dst = t;
-  };
-  if constexpr (N == 256) {
-    sweep(std::integral_constant<int, 64>{});
-    sweep2(std::integral_constant<int, 256>{});
-  } else if constexpr (N == 128) {
-    sweep2(std::integral_constant<int, 128>{});
-  } else {
-    sweep(std::integral_constant<int, 64>{});
-  }
-  return src;
+__device__ __forceinline__ float dpp_xor1(float v) {  // value of lane ^ 1
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float dpp_xor2(float v) {  // value of lane ^ 2
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
 }
 
-__device__ inline float* lds_idct_dyn(int n, float* a, float* b, int lL, int Lp, int tid) {
+// line pitch of the tile for transform length N (floats): N + N/64 (>= 64), N + 1 (32).  With K = N/64 lanes per
+// line the 32 lanes of a ds_read_b32 group (32/K lines x K leaves, leaf offsets distinct mod K) hit 32 banks.
+__host__ __device__ constexpr int large_pitch(int n) { return n >= 64 ? n + n / 64 : n + 1; }
+// where sample x of a transformed line sits: every run of 64 results is shifted by one word, so that the K leaves of
+// a line (which write x = base_leaf + r, base_leaf a multiple of 64, in the same instruction) use different banks
+__host__ __device__ constexpr int large_pos(int x) { return x + (x >> 6); }
+
+// One butterfly level across lane pairs.  in: x[r] = this lane's half-transform H_b[r] (b = 0: the even half E, b = 1:
+// the odd half O, `odd` says which this lane holds), partner(v) = the other half's lane.  With W = IdctW<2*64*...>:
+//   lane E keeps out[i]       = E[i] + w_i O[i]                     at register i
+//   lane O keeps out[n-1-i]   = E[i] - w_i O[i]  (n - 1 - i = n/2 + (63 - i) relative to its run)  at register 63 - i
+// so both lanes end with 64 results in ascending order.  woff: the pair's first weight index (lane dependent for the
+// second level of N = 256, where the two pairs of a quad cover i in [0, 64) and [64, 128)).
+template <int WN, class Partner>
+__device__ __forceinline__ void leaf_butterfly(float (&x)[64], bool odd, bool whi, Partner partner) {
+  // in place, registers r and 63 - r together (each is the other's source in the odd lane): two temporaries live
+#pragma unroll
+  for (int r = 0; r < 32; r++) {
+    constexpr int kHalf = WN / 2;
+    const int m = 63 - r;
+    float w_r = IdctW<WN>::w[r], w_m = IdctW<WN>::w[m];
+    if constexpr (WN == 256) {  // the quad's second pair works on i in [64, 128)
+      w_r = whi ? IdctW<WN>::w[(64 + r) % kHalf] : w_r;
+      w_m = whi ? IdctW<WN>::w[(64 + m) % kHalf] : w_m;
+    }
+    const float xr = x[r], xm = x[m];
+    const float oth_r = partner(xr), oth_m = partner(xm);
+    // lane E: out[i] = e + w o with e = own, o = partner's, i = its register; lane O: register t receives
+    // out[n - 1 - (63 - t)] = e - w o computed from source index 63 - t (e = partner's, o = own)
+    const float lo_r = __builtin_fmaf(oth_r, w_r, xr), lo_m = __builtin_fmaf(oth_m, w_m, xm);
+    const float hi_r = __builtin_fmaf(-xm, w_m, oth_m), hi_m = __builtin_fmaf(-xr, w_r, oth_r);
+    x[r] = odd ? hi_r : lo_r;
+    x[m] = odd ? hi_m : lo_m;
+  }
+}
+
+// 1-D IDCT of length N of the lines staged in `tile` (line l at tile + l * large_pitch(N), natural order), all 64
+// lanes: lane = line * K + leaf.  Results replace the lines in place, sample x at large_pos(x).  Lines the caller did
+// not stage compute on whatever the tile holds (the caller does not store them).
+template <int N>
+__device__ __forceinline__ void wave_idct_lines(float* __restrict__ tile, int lane) {
+  constexpr int P = large_pitch(N);
+  if constexpr (N == 32) {
+    float x[32];
+    float* t = tile + lane * P;
+#pragma unroll
+    for (int j = 0; j < 32; j++) x[j] = t[j];
+    idct1d<32, true>(x);
+    wave_sync();
+#pragma unroll
+    for (int j = 0; j < 32; j++) t[j] = x[j];
+  } else {
+    constexpr int K = N / 64;
+    const int leaf = lane & (K - 1), line = lane / K;
+    float* t = tile + line * P;
+    float x[64];
+    if constexpr (K == 1) {
+#pragma unroll
+      for (int j = 0; j < 64; j++) x[j] = t[j];
+    } else if constexpr (K == 2) {
+      // E[j] = t[2j];  O'[j] = t[2j+1] + t[2j-1], O'[0] = t[1] * sqrt2      (idct_large.rs:284-296)
+      const bool odd = leaf != 0;
+      const float* p = t + leaf;
+#pragma unroll
+      for (int j = 0; j < 64; j++) {
+        const float a = p[2 * j];
+        const float b = t[j ? 2 * j - 1 : 1];
+        x[j] = odd ? (j ? a + b : a * kSqrt2) : a;
+      }
+    } else {
+      // two decimation levels at once (see the header comment); leaf = 2 * (odd at length 256) + (odd at length 128)
+      const bool o128 = (leaf & 1) != 0, o256 = (leaf & 2) != 0;
+      const int c0 = o256 ? (o128 ? 3 : 1) : (o128 ? 2 : 0);  // EE 0, EO 2, OE 1, OO 3
+      const int c1 = o256 ? -1 : -2;                          // EO: t[4j-2]; OE, OO: t[4j-1]
+      const float* p0 = t + c0;
+      const float* p1 = t + c1;
+      const bool single = leaf == 0, quad = leaf == 3;
+#pragma unroll
+      for (int j = 0; j < 64; j++) {
+        const float a = p0[4 * j];  // EE t[4j], EO t[4j+2], OE t[4j+1], OO t[4j+3]
+        if (j == 0) {
+          const float b = t[1];     // OO: (t[3] + t[1]) * sqrt2
+          x[0] = single ? a : (quad ? (a + b) * kSqrt2 : a * kSqrt2);
+        } else {
+          const float b = p1[4 * j];      // EO t[4j-2], OE / OO t[4j-1]
+          const float c = t[4 * j + 1];   // OO only
+          const float d = t[4 * j - 3];   // OO only
+          x[j] = single ? a : (quad ? (a + c) + (b + d) : a + b);
+        }
+      }
+    }
+    idct1d<64, true>(x);
+    int base = 0;
+    if constexpr (K == 2) {
+      leaf_butterfly<128>(x, leaf != 0, false, dpp_xor1);
+      base = leaf * 64;
+    } else if constexpr (K == 4) {
+      leaf_butterfly<128>(x, (leaf & 1) != 0, false, dpp_xor1);
+      // now: lanes with leaf bit 0 clear hold H[0..64), set hold H[64..128), H = E (bit 1 clear) or O (bit 1 set)
+      leaf_butterfly<256>(x, (leaf & 2) != 0, (leaf & 1) != 0, dpp_xor2);
+      // EE: out[0..64)  EO: out[64..128)  OE: out[192..256)  OO: out[128..192)
+      base = leaf == 0 ? 0 : leaf == 1 ? 64 : leaf == 2 ? 192 : 128;
+    }
+    wave_sync();  // every lane has its inputs in registers before any result lands on top of them
+    float* d = t + large_pos(base);
+#pragma unroll
+    for (int r = 0; r < 64; r++) d[r] = x[r];
+  }
+  wave_sync();
+}
+
+__device__ __forceinline__ void wave_idct_lines_dyn(int n, float* tile, int lane) {
   switch (n) {
-    case 32: return lds_idct<32>(a, b, lL, Lp, tid);
-    case 64: return lds_idct<64>(a, b, lL, Lp, tid);
-    case 128: return lds_idct<128>(a, b, lL, Lp, tid);
-    default: return lds_idct<256>(a, b, lL, Lp, tid);
+    case 32: wave_idct_lines<32>(tile, lane); break;
+    case 64: wave_idct_lines<64>(tile, lane); break;
+    case 128: wave_idct_lines<128>(tile, lane); break;
+    default: wave_idct_lines<256>(tile, lane); break;
   }
 }
 
 // One line (n samples at stride `st`) through the reinterpreting DCT, n in {4,8,16,32}.
-__device__ inline void rdct_line(float* p, int n, int st, bool fused) {
+__device__ __forceinline__ void rdct_line(float* p, int n, int st, bool fused) {
   auto run = [&](auto n_tag, auto f_tag) {
     constexpr int NN = decltype(n_tag)::value;
     constexpr bool FF = decltype(f_tag)::value;
@@ -264,56 +181,36 @@ __device__ inline void rdct_line(float* p, int n, int st, bool fused) {
   }
 }
 
-// LLF-from-LF for a cy x cx patch (4..32 each) -> llf[r*mx + q], mn x mx.  scratch >= cy*cx.
-__device__ inline void large_llf(const float* __restrict__ lf, int lf_stride, int cy, int cx, float* scratch,
-                                 float* __restrict__ llf, int tid) {
+// LLF-from-LF of a cy x cx patch (4..32 each) by ONE wave: out[r * mx + q], mn x mx.  scratch: >= cy * cx floats of
+// LDS; `out` may be LDS or global memory.
+__device__ __forceinline__ void wave_large_llf(const float* __restrict__ lf, int lf_stride, int cy, int cx, float* scratch,
+                                      float* __restrict__ out, int lane) {
   const bool fused = min(cy, cx) > 4;  // reinterpreting_dct2d.rs:584-600
-  for (int i = tid; i < cy * cx; i += kLargeThreads) scratch[i] = lf[(i / cx) * lf_stride + (i % cx)];
-  __syncthreads();
+  for (int i = lane; i < cy * cx; i += 64) scratch[i] = lf[(i / cx) * lf_stride + (i % cx)];
+  wave_sync();
   if (cy < cx) {
-    if (tid < cy) rdct_line(scratch + tid * cx, cx, 1, fused);
-    __syncthreads();
-    if (tid < cx) rdct_line(scratch + tid, cy, cx, fused);
-    __syncthreads();
-    for (int i = tid; i < cy * cx; i += kLargeThreads) llf[i] = scratch[i];
+    if (lane < cy) rdct_line(scratch + lane * cx, cx, 1, fused);
+    wave_sync();
+    if (lane < cx) rdct_line(scratch + lane, cy, cx, fused);
+    wave_sync();
+    for (int i = lane; i < cy * cx; i += 64) out[i] = scratch[i];
   } else {
-    if (tid < cx) rdct_line(scratch + tid, cy, cx, fused);   // vertical, per column
-    __syncthreads();
-    if (tid < cy) rdct_line(scratch + tid * cx, cx, 1, fused);  // then along x, per row v
-    __syncthreads();
-    // transposed output: llf[u*cy + v] = scratch[v*cx + u]
-    for (int i = tid; i < cy * cx; i += kLargeThreads) {
+    if (lane < cx) rdct_line(scratch + lane, cy, cx, fused);   // vertical, per column
+    wave_sync();
+    if (lane < cy) rdct_line(scratch + lane * cx, cx, 1, fused);  // then along x, per row v
+    wave_sync();
+    // transposed output: out[u * cy + v] = scratch[v * cx + u]
+    for (int i = lane; i < cy * cx; i += 64) {
       const int u = i / cy, v = i % cy;
-      llf[i] = scratch[v * cx + u];
+      out[i] = scratch[v * cx + u];
     }
   }
-  __syncthreads();
-}
-
-__device__ __forceinline__ float adjust_quant_bias_s(int q, float bias_c, float bias3) {  // group.rs:85-96
-  const float quant = (float)q;
-  const float adjusted = quant - bias3 / quant;
-  return (q > -2 && q < 2) ? quant * bias_c : adjusted;
-}
-
-// idx -> (x, y) inside a W x H pixel region (W = 1 << wlog, both multiples of 8) such that
-// consecutive threads touch consecutive memory: raster planes are x-major, the 8x8-tiled layout
-// stores a block as x*8 + y (see FrameDev::tiled), so there the walk goes down the 8 rows of a
-// block column first.
-__device__ __forceinline__ void region_xy(bool tiled, int wlog, int idx, int& x, int& y) {
-  if (tiled) {
-    const int j = idx & 63, blk = idx >> 6;
-    x = ((blk & ((1 << (wlog - 3)) - 1)) << 3) + (j >> 3);
-    y = ((blk >> (wlog - 3)) << 3) + (j & 7);
-  } else {
-    x = idx & ((1 << wlog) - 1);
-    y = idx >> wlog;
-  }
+  wave_sync();
 }
 
 // Geometry of a large varblock's two passes: pass 1 works on slabs of LV lines (fixed v) x all C horizontal
-// frequencies, pass 2 on slabs of LX pixel columns x all R rows; a slab is kLargeSlab samples (a 64x64 varblock is
-// one slab per pass, a 256x256 one sixteen).
+// frequencies, pass 2 on slabs of LX pixel columns x all R rows; a slab is kLargeSlab samples (a 64x64 varblock is one
+// slab per pass, a 256x256 one sixteen; 64x32 / 32x64 are half a slab).
 struct LargeGeom {
   int R, C, cx, cy, mn, mx, mxRC, lc, lr, lm;
   bool wide;
@@ -340,111 +237,160 @@ struct LargeGeom {
   __device__ bool slab_needs_llf(int v0) const { return v0 < (wide ? mn : mx); }
 };
 
-// Pass 1 of ONE slab: lines v0 .. v0 + LV of the horizontal IDCT, result parked at pixel (row v, col x) of the
-// varblock's output rectangle.  coef(k) returns the dequantised coefficient at stored index k; llf (LDS) holds the
-// mn x mx LLF corner when the slab needs it.  lds: >= 2 * (kLargeSlab + 256) floats.  All threads must call.
-// Pass 1 of ONE slab: lines v0 .. v0 + LV of the horizontal IDCT, result parked at pixel (row v, col x) of the
-// varblock's output rectangle.  coef(k) returns the dequantised coefficient at stored index k; llf (LDS) holds the
-// mn x mx LLF corner when the slab needs it.  lds: >= 2 * (kLargeSlab + 256) floats.  All threads must call.
-// (Compile-time specialisation on (transform length, lines per slab) was measured: 233-256 VGPRs with spills and
-// no faster than this run-time geometry form at 128-181 VGPRs -- profiles/r02_e_large_path.txt.)
-template <class CoefFn>
-__device__ __forceinline__ void large_pass1_slab(const LargeGeom& g, int v0, CoefFn coef, const float* __restrict__ llf,
-                                                 float* __restrict__ plane, const PixLayout lay, float* lds, int tid) {
-  float* bufA = lds;
-  float* bufB = lds + (kLargeSlab + 256);
-  const int Lp = g.LV + 1, total = g.C << g.llv;
-#pragma unroll 1
-  for (int c0 = 0; c0 < kSlabIters; c0 += 2 * kChunk) {
-    if (c0 * kLargeThreads >= total) break;  // half slabs
-    float val[2 * kChunk];
-    int at[2 * kChunk];
+// ---- tile <-> pixel rectangle (rows y0 .. y0 + nrows, columns x0 .. x0 + ncols of the varblock's rectangle, both
+// multiples of 8).  ROWS_ARE_LINES: the tile's lines are pixel rows (pass 1: line = v, sample = x), otherwise pixel
+// columns (pass 2: line = x, sample = y).  POS: the tile holds transformed lines (sample s at large_pos(s)).
+template <bool ROWS_ARE_LINES, bool POS>
+__device__ __forceinline__ int tile_at(int P, int x, int y) {
+  const int line = ROWS_ARE_LINES ? y : x, s = ROWS_ARE_LINES ? x : y;
+  return line * P + (POS ? large_pos(s) : s);
+}
+
+template <bool ROWS_ARE_LINES>
+__device__ __forceinline__ void wave_tile_store(const float* __restrict__ tile, int P, float* __restrict__ plane,
+                                                const PixLayout lay, int x0, int y0, int ncols, int nrows, int lane) {
+  if (lay.tiled) {
+    // a 16-byte piece = 4 rows of one pixel column of an 8x8 block (memory order inside a block: x * 8 + y)
+    const int nbx = ncols >> 3, total = (ncols * nrows) >> 2;
+    for (int f = lane; f < total; f += 64) {
+      const int blk = f >> 4, x = (f & 15) >> 1, yq = f & 1;
+      const int bx = blk % nbx, by = blk / nbx;
+      const int col = bx * 8 + x, row = by * 8 + yq * 4;
+      float4 v;
+      v.x = tile[tile_at<ROWS_ARE_LINES, true>(P, col, row)];
+      v.y = tile[tile_at<ROWS_ARE_LINES, true>(P, col, row + 1)];
+      v.z = tile[tile_at<ROWS_ARE_LINES, true>(P, col, row + 2)];
+      v.w = tile[tile_at<ROWS_ARE_LINES, true>(P, col, row + 3)];
+      *reinterpret_cast<float4*>(plane + lay.at(x0 + col, y0 + row)) = v;
+    }
+  } else {
+    const int total = ncols * nrows;
+    for (int f = lane; f < total; f += 64) {
+      const int col = f % ncols, row = f / ncols;
+      plane[lay.at(x0 + col, y0 + row)] = tile[tile_at<ROWS_ARE_LINES, true>(P, col, row)];
+    }
+  }
+}
+
+// pass-2 staging: pixel columns x0 .. x0 + ncols, all nrows rows -> tile lines = columns, natural order
+__device__ __forceinline__ void wave_tile_load_columns(float* __restrict__ tile, int P, const float* __restrict__ plane,
+                                                       const PixLayout lay, int x0, int ncols, int nrows, int lane) {
+  if (lay.tiled) {
+    const int nbx = ncols >> 3, total = (ncols * nrows) >> 2;
+    for (int f0 = 0; f0 < total; f0 += 4 * 64) {  // four 16-byte loads in flight per lane
+      float4 v[4];
 #pragma unroll
-    for (int it = 0; it < 2 * kChunk; it++) {  // unrolled: the chunk's coefficient loads are all in flight together
-      const int idx = (c0 + it) * kLargeThreads + tid;
+      for (int k = 0; k < 4; k++) {
+        const int f = f0 + k * 64 + lane;
+        const int blk = f >> 4, x = (f & 15) >> 1, yq = f & 1;
+        const int bx = blk % nbx, by = blk / nbx;
+        v[k] = f < total ? *reinterpret_cast<const float4*>(plane + lay.at(x0 + bx * 8 + x, by * 8 + yq * 4))
+                         : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int f = f0 + k * 64 + lane;
+        if (f < total) {
+          const int blk = f >> 4, x = (f & 15) >> 1, yq = f & 1;
+          const int bx = blk % nbx, by = blk / nbx;
+          float* d = tile + (bx * 8 + x) * P + by * 8 + yq * 4;
+          d[0] = v[k].x;
+          d[1] = v[k].y;
+          d[2] = v[k].z;
+          d[3] = v[k].w;
+        }
+      }
+    }
+  } else {
+    const int total = ncols * nrows;
+    for (int f = lane; f < total; f += 64) {
+      const int col = f % ncols, row = f / ncols;
+      tile[col * P + row] = plane[lay.at(x0 + col, row)];
+    }
+  }
+}
+
+// Pass 1 of ONE slab by ONE wave: lines v0 .. v0 + LV of the horizontal IDCT, result parked at pixel (row v, col x) of
+// the varblock's output rectangle.  coef4(k) returns the four dequantised coefficients at stored indices k .. k + 3
+// (k a multiple of 4); llf_at(i) the LLF corner value i = kr * mx + kq (only called where the corner applies).
+// tile: kLargeTile floats of LDS owned by this wave.
+template <class Coef4, class LlfAt>
+__device__ __forceinline__ void wave_large_pass1(const LargeGeom& g, int v0, Coef4 coef4, LlfAt llf_at,
+                                                 float* __restrict__ plane, const PixLayout lay, float* tile, int lane) {
+  const int P = large_pitch(g.C), total4 = (g.C << g.llv) >> 2;
+  const bool corner = g.slab_needs_llf(v0);
+#pragma unroll 1
+  for (int f0 = 0; f0 < total4; f0 += 4 * 64) {
+    float4 val[4];
+    int at[4], step[4];
+#pragma unroll
+    for (int it = 0; it < 4; it++) {  // unrolled: the chunk's coefficient loads are all in flight together
+      const int idx = (f0 + it * 64 + lane) * 4;
       // wide: stored in[v*C + u], u fastest in memory; otherwise in[u*R + v], v fastest
       const int u = g.wide ? (idx & (g.C - 1)) : (idx >> g.llv), line = g.wide ? (idx >> g.lc) : (idx & (g.LV - 1));
       const int v = v0 + line;
       const int k = g.wide ? (v << g.lc) + u : (u << g.lr) + v;
-      const int kr = k >> g.lm, kq = k & (g.mxRC - 1);
-      at[it] = u * Lp + line;
-      // LLF overwrites the HF-decoded corner (transform.rs:450)
-      val[it] = (kr < g.mn && kq < g.mx) ? llf[kr * g.mx + kq] : coef(k);
+      at[it] = line * P + u;
+      step[it] = g.wide ? 1 : P;  // the four values: consecutive u (wide) or consecutive lines
+      float4 c = coef4(k);
+      if (corner) {  // LLF overwrites the HF-decoded corner (transform.rs:450)
+        const int kr = k >> g.lm, kq = k & (g.mxRC - 1);
+        if (kr < g.mn && kq < g.mx) {
+          c.x = llf_at(kr * g.mx + kq);
+          if (kq + 1 < g.mx) c.y = llf_at(kr * g.mx + kq + 1);
+          if (kq + 2 < g.mx) c.z = llf_at(kr * g.mx + kq + 2);
+          if (kq + 3 < g.mx) c.w = llf_at(kr * g.mx + kq + 3);
+        }
+      }
+      val[it] = c;
     }
 #pragma unroll
-    for (int it = 0; it < 2 * kChunk; it++) bufA[at[it]] = val[it];
-  }
-  __syncthreads();
-  float* res = lds_idct_dyn(g.C, bufA, bufB, g.llv, Lp, tid);
-#pragma unroll 1
-  for (int c0 = 0; c0 < kSlabIters; c0 += 2 * kChunk) {
-    if (c0 * kLargeThreads >= total) break;
-#pragma unroll
-    for (int it = 0; it < 2 * kChunk; it++) {
-      const int idx = (c0 + it) * kLargeThreads + tid;
-      int x, line;
-      region_xy(lay.tiled, g.lc, idx, x, line);
-      plane[lay.at(x, v0 + line)] = res[x * Lp + line];
+    for (int it = 0; it < 4; it++) {
+      if (f0 + it * 64 + lane < total4) {
+        float* d = tile + at[it];
+        d[0] = val[it].x;
+        d[step[it]] = val[it].y;
+        d[2 * step[it]] = val[it].z;
+        d[3 * step[it]] = val[it].w;
+      }
     }
   }
-  __syncthreads();
+  wave_sync();
+  wave_idct_lines_dyn(g.C, tile, lane);
+  wave_tile_store<true>(tile, P, plane, lay, 0, v0, g.C, g.LV, lane);
+  wave_sync();
 }
 
-// Pass 2 of ONE slab: pixel columns x0 .. x0 + LX, vertical IDCT in place in the output rectangle.
-__device__ __forceinline__ void large_pass2_slab(const LargeGeom& g, int x0, float* __restrict__ plane,
-                                                 const PixLayout lay, float* lds, int tid) {
-  float* bufA = lds;
-  float* bufB = lds + (kLargeSlab + 256);
-  const int Lp = g.LX + 1, total = g.R << g.xlog;
-#pragma unroll 1
-  for (int c0 = 0; c0 < kSlabIters; c0 += 2 * kChunk) {
-    if (c0 * kLargeThreads >= total) break;
-    float val[2 * kChunk];
-#pragma unroll
-    for (int it = 0; it < 2 * kChunk; it++) {
-      const int idx = (c0 + it) * kLargeThreads + tid;
-      int line, v;
-      region_xy(lay.tiled, g.xlog, idx, line, v);
-      val[it] = plane[lay.at(x0 + line, v)];
-    }
-#pragma unroll
-    for (int it = 0; it < 2 * kChunk; it++) {
-      const int idx = (c0 + it) * kLargeThreads + tid;
-      int line, v;
-      region_xy(lay.tiled, g.xlog, idx, line, v);
-      bufA[v * Lp + line] = val[it];
-    }
-  }
-  __syncthreads();
-  float* res = lds_idct_dyn(g.R, bufA, bufB, g.xlog, Lp, tid);
-#pragma unroll 1
-  for (int c0 = 0; c0 < kSlabIters; c0 += 2 * kChunk) {
-    if (c0 * kLargeThreads >= total) break;
-#pragma unroll
-    for (int it = 0; it < 2 * kChunk; it++) {
-      const int idx = (c0 + it) * kLargeThreads + tid;
-      int line, y;
-      region_xy(lay.tiled, g.xlog, idx, line, y);
-      plane[lay.at(x0 + line, y)] = res[y * Lp + line];
-    }
-  }
-  __syncthreads();
+// Pass 2 of ONE slab by ONE wave: pixel columns x0 .. x0 + LX, vertical IDCT in place in the output rectangle.
+__device__ __forceinline__ void wave_large_pass2(const LargeGeom& g, int x0, float* __restrict__ plane,
+                                                 const PixLayout lay, float* tile, int lane) {
+  const int P = large_pitch(g.R);
+  wave_tile_load_columns(tile, P, plane, lay, x0, g.LX, g.R, lane);
+  wave_sync();
+  wave_idct_lines_dyn(g.R, tile, lane);
+  wave_tile_store<false>(tile, P, plane, lay, x0, 0, g.LX, g.R, lane);
+  wave_sync();
 }
 
-// One channel of one large varblock, both passes by one workgroup (stage hook; the frame path runs the passes as
-// separate launches over slab units, k_vardct.hip).  lf points at the cy x cx LF patch (row pitch lf_stride); plane
-// at the top-left output pixel (addressing given by `lay`).  lds: >= 2*(kLargeSlab + 256) + 1024 floats.
-// All threads of the (256-thread) workgroup must call with identical arguments.
+// One channel of one large varblock, both passes by one 256-thread workgroup (stage hook; the frame path runs the
+// passes as separate launches over slab units, k_vardct.hip).  lf points at the cy x cx LF patch (row pitch
+// lf_stride); plane at the top-left output pixel (addressing given by `lay`).  lds: kLargeWaves * kLargeTile + 2048
+// floats.  coef(k): the dequantised coefficient at stored index k.  All threads must call with identical arguments.
 template <class CoefFn>
 __device__ void large_varblock_channel(int type, CoefFn coef, const float* __restrict__ lf, int lf_stride,
                                        float* __restrict__ plane, const PixLayout lay, float* lds, int tid) {
   const LargeGeom g(type);
-  float* llf = lds + 2 * (kLargeSlab + 256);
-  large_llf(lf, lf_stride, g.cy, g.cx, lds, llf, tid);
-  for (int v0 = 0; v0 < g.R; v0 += g.LV) large_pass1_slab(g, v0, coef, llf, plane, lay, lds, tid);
+  const int wave = tid >> 6, lane = tid & 63;
+  float* tile = lds + wave * kLargeTile;
+  float* llf = lds + kLargeWaves * kLargeTile;  // 1024 floats of result + 1024 of scratch
+  if (wave == 0) wave_large_llf(lf, lf_stride, g.cy, g.cx, llf + 1024, llf, lane);
+  __syncthreads();
+  auto coef4 = [&](int k) { return make_float4(coef(k), coef(k + 1), coef(k + 2), coef(k + 3)); };
+  for (int s = wave; s < g.slabs_per_pass(); s += kLargeWaves)
+    wave_large_pass1(g, s * g.LV, coef4, [&](int i) { return llf[i]; }, plane, lay, tile, lane);
   __threadfence_block();
   __syncthreads();
-  for (int x0 = 0; x0 < g.C; x0 += g.LX) large_pass2_slab(g, x0, plane, lay, lds, tid);
+  for (int s = wave; s < g.slabs_per_pass(); s += kLargeWaves) wave_large_pass2(g, s * g.LX, plane, lay, tile, lane);
   __threadfence_block();
   __syncthreads();
 }
