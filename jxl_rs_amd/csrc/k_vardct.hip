@@ -468,52 +468,53 @@ __global__ __launch_bounds__(kThreads) void k1_dct32(const FrameDev f, const Wor
 }
 
 // family D: the nine 8x8 special transform types (IDENTITY, DCT2X2, DCT4X4, DCT4X8, DCT8X4, AFV0-3).
-// Each lane transforms its own block, so a wavefront must hold blocks of ONE code path or the
-// nine paths serialise.  The special work list is in raster order (mixed types): a wave takes a
-// (chunk of 256 items, type bin) pair, compacts the chunk's items of its bin through a ballot, and
-// runs them in batches of kSpecNB blocks -- every batch is uniform in type, so the lane can hold
-// its block in registers and run the fully unrolled transform of that type.
+// Each lane transforms one block of one channel with the block's 64 coefficients in registers, so a wavefront must
+// hold blocks of ONE code path or the nine paths serialise.  The special work list is in raster order (mixed types): a
+// wave takes a (chunk of 512 items, type bin) pair, compacts the chunk's items of its bin through a ballot, and runs
+// them in batches of kSpecBlk = 21 blocks.  Round 3: the three channels of a batch are transformed TOGETHER -- lane =
+// (channel, block), 63 of 64 lanes busy in one pass of the (long, fully unrolled) per-type code -- where round 2 ran the
+// transform once per channel on 32 lanes; the tile is in place (a lane reads its row into registers, writes the
+// pixels over it) and the dequantised Y a batch's X / B rows need stays in 24 registers.  16K all types: 394 -> see
+// profiles/r03_d_large_path.txt.
 constexpr int kSpecWaves = 2;
 constexpr int kSpecThreads = kSpecWaves * 64;
-constexpr int kSpecChunk = 256;
+constexpr int kSpecChunk = 512;
 constexpr int kSpecBins = 9;
+constexpr int kSpecBlk = 21;                       // blocks per batch: 3 x 21 = 63 transform lanes
+constexpr int kSpecIters = (kSpecBlk * 16 + 63) / 64;  // 16-byte groups of one channel of a batch, per lane
 __device__ __forceinline__ int special_bin(int type) {  // 1, 2, 3, 12, 13, 14, 15, 16, 17 -> 0..8
   return type <= 3 ? type - 1 : type - 9;
 }
 
-__global__ __launch_bounds__(kSpecThreads, 2) void k1_special(const FrameDev f, const WorkLists wl) {
-  __shared__ float s_buf[kSpecWaves * 2 * kSpecNB * kSpecPitch];
-  __shared__ BlockInfo s_binfo[kSpecWaves][kSpecNB];
-  __shared__ int s_type[kSpecWaves][kSpecNB];
+// one lane: its block's 64 coefficients into registers, pixels written over them
+template <int TYPE>
+__device__ __forceinline__ void special_8x8_inplace(float* __restrict__ row) {
+  float c[64], o[64];
+#pragma unroll
+  for (int i = 0; i < 64; i++) c[i] = row[i];
+  special_8x8_t<TYPE>(c, o);
+#pragma unroll
+  for (int i = 0; i < 64; i++) row[i] = o[i];
+}
+
+__global__ __launch_bounds__(kSpecThreads) void k1_special(const FrameDev f, const WorkLists wl) {
+  __shared__ float s_tile[kSpecWaves][64 * kSpecPitch];
+  __shared__ BlockInfo s_binfo[kSpecWaves][kSpecBlk];
   __shared__ int s_idx[kSpecWaves][kSpecChunk];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const WorkItem* __restrict__ items = wl.items[kClsSpecial];
   const int count = wl.counts[(kClsSpecial) * kCountPitch];
-  float* tin = s_buf + wave * 2 * kSpecNB * kSpecPitch;
-  float* tout = tin + kSpecNB * kSpecPitch;
+  float* tile = s_tile[wave];
   BlockInfo* binfo = s_binfo[wave];
-  int* btype = s_type[wave];
   int* mine = s_idx[wave];
-  // work unit = (chunk, type bin, channel): the channels only meet in the chroma-from-luma FMA, whose Y
-  // term the X / B units recompute from the Y coefficients -- three times the parallelism for a kernel
-  // that is bound by the latency of its serial per-unit steps
-  // JXLH_SPEC_SPLIT = 1 makes the channels separate work units (X / B recompute the dequantised Y): three times the
-  // parallelism, but the kernel is VALU bound on the all-types frame (profiles/r01_j_allmix16k_pmc.txt) and the two
-  // extra dequantisations cost more than the parallelism buys: 16K all types, K1 2.55 -> 2.46 ms without the split
-#ifndef JXLH_SPEC_SPLIT
-#define JXLH_SPEC_SPLIT 0
-#endif
-  constexpr int kUnitsPerBin = JXLH_SPEC_SPLIT ? 3 : 1;
-  const int npairs = ((count + kSpecChunk - 1) / kSpecChunk) * kSpecBins * kUnitsPerBin;
-  constexpr int NCH = kSpecNB * 64 / 256;
+  const int npairs = ((count + kSpecChunk - 1) / kSpecChunk) * kSpecBins;
   for (int pair = blockIdx.x * kSpecWaves + wave; pair < npairs; pair += gridDim.x * kSpecWaves) {
-    const int unit_ch = JXLH_SPEC_SPLIT ? pair % 3 : 3, cb = pair / kUnitsPerBin;
-    const int chunk = cb / kSpecBins, bin = cb % kSpecBins;
+    const int chunk = pair / kSpecBins, bin = pair % kSpecBins;
     // ---- this wave's items of the chunk: the ones whose type falls in `bin`
     int nmine = 0;
     uint32_t packed[kSpecChunk / 64];
 #pragma unroll
-    for (int i = 0; i < kSpecChunk / 64; i++) {  // all four loads in flight before the first ballot
+    for (int i = 0; i < kSpecChunk / 64; i++) {  // all loads in flight before the first ballot
       const int idx = chunk * kSpecChunk + i * 64 + lane;
       packed[i] = items[min(idx, max(count - 1, 0))].packed;
     }
@@ -527,144 +528,110 @@ __global__ __launch_bounds__(kSpecThreads, 2) void k1_special(const FrameDev f, 
     }
     wave_sync();
     // every item of the pair has a type of this bin, and the types of a bin share one dequant table
-    // (quant_weights.rs:321-343): a wave-uniform pointer instead of a per-lane lookup in the kernel
-    // argument block (which costs two dependent memory round trips per access)
+    // (quant_weights.rs:321-343): a wave-uniform pointer instead of a per-lane lookup
     constexpr int kBinType[kSpecBins] = {1, 2, 3, 12, 13, 14, 15, 16, 17};
     int bin_type = kBinType[0];
 #pragma unroll
     for (int i = 1; i < kSpecBins; i++) bin_type = bin == i ? kBinType[i] : bin_type;
     const float* __restrict__ bin_table = f.tables + f.table_offset[quant_table_for_type(bin_type)];
-    for (int b0 = 0; b0 < nmine; b0 += kSpecNB) {
-      const int nb = min(kSpecNB, nmine - b0);
+    const int k0 = (lane & 15) * 4;  // the four coefficient positions this lane stages, in every block it touches
+    for (int b0 = 0; b0 < nmine; b0 += kSpecBlk) {
+      const int nb = min(kSpecBlk, nmine - b0);
       if (lane < nb) {
         const WorkItem it = items[mine[b0 + lane]];
         decode_item(f, it, &binfo[lane]);
-        btype[lane] = (int)(it.packed >> 20) & 31;
       }
       wave_sync();
-      float dy[4 * NCH];
-      auto run_channel = [&](auto ch_tag) {
+      // ---- stage the three channels: row = ch * kSpecBlk + block, reference order Y, X, B (group.rs:223)
+      float dy[4 * kSpecIters];
+      auto stage_channel = [&](auto ch_tag) {
         constexpr int CH = decltype(ch_tag)::value;
-        // phase 1: every global load of the channel in flight (the LDS stores of phase 2 could alias the
-        // block infos as far as the compiler knows, which would serialise load after load)
-        int4 qv[NCH];
-        float4 tv[NCH];
-        float b_sdy[NCH], b_xcc[NCH], b_bcc[NCH];  // the fields dequant4 needs, as plain registers
-        const float lf0 = f.lf[CH][binfo[min(lane, nb - 1)].lf_off[CH]];  // in flight with the coefficient loads
+        const float4 tv = *reinterpret_cast<const float4*>(bin_table + CH * 64 + k0);
+        int4 qv[kSpecIters];
+        float b_sdy[kSpecIters], b_xcc[kSpecIters], b_bcc[kSpecIters];
 #pragma unroll
-        for (int j = 0; j < NCH; j++) {
-          const int fl = (j * 64 + lane) * 4;
-          const int b = fl / 64, k = fl % 64;
-          qv[j] = make_int4(0, 0, 0, 0);
-          tv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-          const BlockInfo* bp = &binfo[min(b, nb - 1)];  // lanes past the batch re-read its last block (discarded)
+        for (int j = 0; j < kSpecIters; j++) {  // every global load of the channel in flight first
+          const int b = min(j * 4 + (lane >> 4), nb - 1);  // lanes past the batch re-read its last block (discarded)
+          const BlockInfo* bp = &binfo[b];
           b_sdy[j] = bp->sdy;
           b_xcc[j] = bp->x_cc;
           b_bcc[j] = bp->b_cc;
-          qv[j] = *reinterpret_cast<const int4*>(f.coeffs + bp->coef_off + CH * kGroupArea + k);
-          tv[j] = *reinterpret_cast<const float4*>(bin_table + CH * 64 + k);
+          qv[j] = *reinterpret_cast<const int4*>(f.coeffs + bp->coef_off + CH * kGroupArea + k0);
         }
 #pragma unroll
-        for (int j = 0; j < NCH; j++) {
-          const int fl = (j * 64 + lane) * 4;
-          const int b = fl / 64, k = fl % 64;
-          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < kSpecIters; j++) {
+          const int b = j * 4 + (lane >> 4);
           float d4[4] = {dy[j * 4], dy[j * 4 + 1], dy[j * 4 + 2], dy[j * 4 + 3]};
           BlockInfo bi;
           bi.sdy = b_sdy[j];
           bi.x_cc = b_xcc[j];
           bi.b_cc = b_bcc[j];
-          if (b < nb) v = dequant4<CH>(f, qv[j], tv[j], bi, d4);
+          const float4 v = dequant4<CH>(f, qv[j], tv, bi, d4);
           if constexpr (CH == 1) {
             dy[j * 4] = d4[0];
             dy[j * 4 + 1] = d4[1];
             dy[j * 4 + 2] = d4[2];
             dy[j * 4 + 3] = d4[3];
           }
-          float* dst = tin + b * kSpecPitch + k;
-          dst[0] = v.x;
-          dst[1] = v.y;
-          dst[2] = v.z;
-          dst[3] = v.w;
-        }
-        wave_sync();
-        if (lane < nb) {
-          float* c = tin + lane * kSpecPitch;
-          c[0] = lf0;  // transform_buffer[0] = lf[0]
-          float* o = tout + lane * kSpecPitch;
-          switch (bin) {  // wave-uniform
-            case 0: special_8x8_regs<1>(c, o); break;
-            case 1: special_8x8_regs<2>(c, o); break;
-            case 2: special_8x8_regs<3>(c, o); break;
-            case 3: special_8x8_regs<12>(c, o); break;
-            case 4: special_8x8_regs<13>(c, o); break;
-            case 5: special_8x8_regs<14>(c, o); break;
-            case 6: special_8x8_regs<15>(c, o); break;
-            case 7: special_8x8_regs<16>(c, o); break;
-            default: special_8x8_regs<17>(c, o); break;
+          if (b < nb) {
+            float* dst = tile + (CH * kSpecBlk + b) * kSpecPitch + k0;
+            dst[0] = v.x;
+            dst[1] = v.y;
+            dst[2] = v.z;
+            dst[3] = v.w;
           }
         }
-        wave_sync();
-        float* __restrict__ plane = f.planes[CH];
-        // gather first, then store: all eight stores of the lane issue back to back
-        float4 ov[NCH];
-        int oo[NCH];
+      };
+      stage_channel(std::integral_constant<int, 1>{});
+      stage_channel(std::integral_constant<int, 0>{});
+      stage_channel(std::integral_constant<int, 2>{});
+      // ---- transform: lane = (channel, block); transform_buffer[0] = lf[0] first
+      const int tch = lane / kSpecBlk, tb = lane % kSpecBlk;
+      const bool on = tch < 3 && tb < nb;
+      const float lf0 = f.lf[min(tch, 2)][binfo[min(tb, nb - 1)].lf_off[min(tch, 2)]];
+      wave_sync();
+      if (on) {
+        float* row = tile + lane * kSpecPitch;  // lane == tch * kSpecBlk + tb
+        row[0] = lf0;
+        switch (bin) {  // wave-uniform
+          case 0: special_8x8_inplace<1>(row); break;
+          case 1: special_8x8_inplace<2>(row); break;
+          case 2: special_8x8_inplace<3>(row); break;
+          case 3: special_8x8_inplace<12>(row); break;
+          case 4: special_8x8_inplace<13>(row); break;
+          case 5: special_8x8_inplace<14>(row); break;
+          case 6: special_8x8_inplace<15>(row); break;
+          case 7: special_8x8_inplace<16>(row); break;
+          default: special_8x8_inplace<17>(row); break;
+        }
+      }
+      wave_sync();
+      // ---- store: gather first, then store: all stores of the lane issue back to back
 #pragma unroll
-        for (int j = 0; j < NCH; j++) {
-          const int fl = (j * 64 + lane) * 4;
-          const int b = min(fl / 64, nb - 1), p = fl % 64;
-          const int px = binfo[b].px_off[CH];
+      for (int ch = 0; ch < 3; ch++) {
+        float* __restrict__ plane = f.planes[ch];
+        float4 ov[kSpecIters];
+        int oo[kSpecIters];
+#pragma unroll
+        for (int j = 0; j < kSpecIters; j++) {
+          const int b = min(j * 4 + (lane >> 4), nb - 1), p = k0;
+          const int px = binfo[b].px_off[ch];
+          const float* r = tile + (ch * kSpecBlk + b) * kSpecPitch;
           if (f.tiled) {  // memory order inside the block is x*8 + y
             const int x = p / 8, y0 = p % 8;
-            const float* src = tout + b * kSpecPitch + y0 * 8 + x;
+            const float* src = r + y0 * 8 + x;
             ov[j] = make_float4(src[0], src[8], src[16], src[24]);
             oo[j] = px + p;
           } else {
-            const float* src = tout + b * kSpecPitch + p;
-            ov[j] = make_float4(src[0], src[1], src[2], src[3]);
+            ov[j] = make_float4(r[p], r[p + 1], r[p + 2], r[p + 3]);
             oo[j] = px + (p / 8) * (int)f.plane_stride + (p % 8);
           }
         }
 #pragma unroll
-        for (int j = 0; j < NCH; j++) {
-          const int fl = (j * 64 + lane) * 4;
-          if (fl / 64 < nb) *reinterpret_cast<float4*>(plane + oo[j]) = ov[j];
-        }
-        wave_sync();
-      };
-      if (unit_ch == 3) {  // all three channels by one wave: the dequantised Y stays in registers
-        run_channel(std::integral_constant<int, 1>{});
-        run_channel(std::integral_constant<int, 0>{});
-        run_channel(std::integral_constant<int, 2>{});
-      } else if (unit_ch == 1) {
-        run_channel(std::integral_constant<int, 1>{});
-      } else {
-        // dequantised Y of the lane's coefficient positions (what run_channel<1> leaves in dy)
-        int4 qy[NCH];
-        float ysdy[NCH];
-#pragma unroll
-        for (int j = 0; j < NCH; j++) {  // lanes past the batch re-read its last block; their dy is unused
-          const int fl = (j * 64 + lane) * 4;
-          const BlockInfo* bp = &binfo[min(fl / 64, nb - 1)];
-          ysdy[j] = bp->sdy;
-          qy[j] = *reinterpret_cast<const int4*>(f.coeffs + bp->coef_off + kGroupArea + fl % 64);
-        }
-#pragma unroll
-        for (int j = 0; j < NCH; j++) {
-          const int k = ((j * 64 + lane) * 4) % 64;
-          float d4[4] = {0.f, 0.f, 0.f, 0.f};
-          BlockInfo bi;
-          bi.sdy = ysdy[j];
-          const float4 ty = *reinterpret_cast<const float4*>(bin_table + 64 + k);
-          (void)dequant4<1>(f, qy[j], ty, bi, d4);
-          dy[j * 4] = d4[0];
-          dy[j * 4 + 1] = d4[1];
-          dy[j * 4 + 2] = d4[2];
-          dy[j * 4 + 3] = d4[3];
-        }
-        if (unit_ch == 0) run_channel(std::integral_constant<int, 0>{});
-        else run_channel(std::integral_constant<int, 2>{});
+        for (int j = 0; j < kSpecIters; j++)
+          if (j * 4 + (lane >> 4) < nb) *reinterpret_cast<float4*>(plane + oo[j]) = ov[j];
       }
+      wave_sync();
     }
     wave_sync();  // `mine` is rewritten by the next pair
   }
@@ -735,10 +702,9 @@ void launch_vardct_groups(hipStream_t s, const FrameDev& f, int group_row0, int 
     hipLaunchKernelGGL(k1_dct16<false>, g16, dim3(kThreads), 0, s, f, wl);
     hipLaunchKernelGGL(k1_dct32<false>, g32, dim3(kThreads), 0, s, f, wl);
   }
-  // 4 of these workgroups fit a CU (37 KB LDS, 255 VGPRs): 1024 is the resident capacity, a larger grid
-  // only queues -- and an empty special list (the d1 mix) pays for every launched workgroup
+  // an empty special list (the d1 mix) pays for every launched workgroup: the grid follows the list's worst case
   if (has_special)
-    hipLaunchKernelGGL(k1_special, dim3(grid_for((long)(nblk / kSpecChunk + 1) * kSpecBins * 3, kSpecWaves, 1024)),
+    hipLaunchKernelGGL(k1_special, dim3(grid_for((long)(nblk / kSpecChunk + 1) * kSpecBins, kSpecWaves, 2048)),
                        dim3(kSpecThreads), 0, s, f, wl);
   if (has_large) launch_vardct_large(s, f, wl, nblk, large_units, large_unit_capacity(nblocks), nblocks);
 }

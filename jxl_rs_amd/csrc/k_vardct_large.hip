@@ -96,19 +96,31 @@ __global__ __launch_bounds__(kLargeThreads) void k1_large_pass(const FrameDev f,
             const float4 wy = *reinterpret_cast<const float4*>(ty + k);
             const int vy[4] = {iy.x, iy.y, iy.z, iy.w};
             const float fy[4] = {wy.x, wy.y, wy.z, wy.w};
-            float r[4];
-            if (luma) {
-#pragma unroll
-              for (int i = 0; i < 4; i++) r[i] = adjust_quant_bias(vy[i], b1, b3) * (fy[i] * sdy);
-            } else {
+            int vc[4] = {0, 0, 0, 0};
+            float fc[4] = {0.f, 0.f, 0.f, 0.f};
+            if (!luma) {
               const int4 ic = *reinterpret_cast<const int4*>(qc + k);
               const float4 wc = *reinterpret_cast<const float4*>(tc + k);
-              const int vc[4] = {ic.x, ic.y, ic.z, ic.w};
-              const float fc[4] = {wc.x, wc.y, wc.z, wc.w};
+              vc[0] = ic.x; vc[1] = ic.y; vc[2] = ic.z; vc[3] = ic.w;
+              fc[0] = wc.x; fc[1] = wc.y; fc[2] = wc.z; fc[3] = wc.w;
+            }
+            // adjust_quant_bias divides only for |q| >= 2 (group.rs:91-95); most slabs of a large varblock hold
+            // nothing but 0 / +-1 (high frequencies): a wavefront without a larger value skips the divisions
+            bool big = false;
+#pragma unroll
+            for (int i = 0; i < 4; i++) big |= (unsigned)(vy[i] + 1) > 2u || (unsigned)(vc[i] + 1) > 2u;
+            float r[4];
+            if (__builtin_amdgcn_ballot_w64(big) != 0) {
 #pragma unroll
               for (int i = 0; i < 4; i++) {
                 const float y = adjust_quant_bias(vy[i], b1, b3) * (fy[i] * sdy);
-                r[i] = __builtin_fmaf(cc, y, adjust_quant_bias(vc[i], bc, b3) * (fc[i] * sdc));
+                r[i] = luma ? y : __builtin_fmaf(cc, y, adjust_quant_bias(vc[i], bc, b3) * (fc[i] * sdc));
+              }
+            } else {
+#pragma unroll
+              for (int i = 0; i < 4; i++) {
+                const float y = ((float)vy[i] * b1) * (fy[i] * sdy);
+                r[i] = luma ? y : __builtin_fmaf(cc, y, ((float)vc[i] * bc) * (fc[i] * sdc));
               }
             }
             return make_float4(r[0], r[1], r[2], r[3]);
