@@ -47,6 +47,9 @@
 #ifndef JXLH_FUSED_E0_WPE
 #define JXLH_FUSED_E0_WPE 3
 #endif
+#ifndef JXLH_FUSED_E0_THREADS
+#define JXLH_FUSED_E0_THREADS 256
+#endif
 #ifndef JXLH_FAST_RECIP
 #define JXLH_FAST_RECIP 1
 #endif
@@ -65,6 +68,9 @@
 #ifndef JXLH_DENSE_ITEMS
 #define JXLH_DENSE_ITEMS 40
 #endif
+#ifndef JXLH_DENSE_ITEMS0  // the same threshold for EPF0 as the last stage of its kernel
+#define JXLH_DENSE_ITEMS0 40
+#endif
 
 namespace jxlh {
 namespace {
@@ -74,11 +80,11 @@ constexpr int kBW = kTW + 2 * kB;  // 64 floats = 16 strips = one DPP row of lan
 constexpr int kBH = kTH + 2 * kB;
 constexpr int kStrips = kBW / 4;   // 16
 constexpr int kPlane = kBW * kBH;  // floats per channel
-constexpr int kT = JXLH_FUSED_THREADS;
+constexpr int kThreadsDefault = JXLH_FUSED_THREADS;
 static_assert(kStrips == 16, "lane <-> strip mapping relies on 16-lane DPP rows");
-static_assert(kTH % 4 == 0 && kT % 64 == 0, "tiled staging fetches 4-row groups");
+static_assert(kTH % 4 == 0 && kThreadsDefault % 64 == 0, "tiled staging fetches 4-row groups");
 constexpr int kSigW = kBW / 8 + 2, kSigH = kBH / 8 + 2;
-constexpr int kDenseItems = JXLH_DENSE_ITEMS, kSparseMax = JXLH_SPARSE_MAX;
+constexpr int kDenseItems = JXLH_DENSE_ITEMS, kDenseItems0 = JXLH_DENSE_ITEMS0, kSparseMax = JXLH_SPARSE_MAX;
 static_assert(kSparseMax <= 64, "a compacting wavefront takes 64 strips");
 
 struct FusedArgs {
@@ -172,6 +178,17 @@ __device__ __forceinline__ void load10(const float* __restrict__ strip, float (&
   v[7] = dpp_from_right(c.x);
   v[8] = dpp_from_right(c.y);
   v[9] = dpp_from_right(c.z);
+}
+
+// ... and for a work item that is not laid out one strip per lane (see load8g): the side taps from the neighbouring
+// strips' 16-byte words
+__device__ __forceinline__ void load10g(const float* __restrict__ strip, bool edge_l, bool edge_r, float (&v)[10]) {
+  const float4 c = lds_load4(strip);
+  const float4 l = lds_load4(strip - (edge_l ? 0 : 4));
+  const float4 r = lds_load4(strip + (edge_r ? 0 : 4));
+  v[0] = l.y; v[1] = l.z; v[2] = l.w;
+  v[3] = c.x; v[4] = c.y; v[5] = c.z; v[6] = c.w;
+  v[7] = r.x; v[8] = r.y; v[9] = r.z;
 }
 
 #define FAD(a, b) __builtin_fabsf((a) - (b))
@@ -561,9 +578,13 @@ __device__ __forceinline__ void epf2_strip(const float* __restrict__ p0, int fx0
 // over a 5-pixel plus.  Always the last stage of its kernel (7 rows x 10 columns of context make
 // it the register-heaviest stage; its output goes straight to HBM).  P(cx, cy) below is the
 // reference's 7x7 window with the pixel at (3, 3); the sums keep its term order.
-template <class Emit>
+template <bool GENERIC, class Emit>
 __device__ __forceinline__ void epf0_strip(const float* __restrict__ p0, int fx0, int fy, float sigma,
-                                           const FusedArgs& a, Emit&& emit) {
+                                           const FusedArgs& a, Emit&& emit, bool edge_l = false, bool edge_r = false) {
+  auto ld8 = [&](const float* q, float (&v)[8]) {
+    if constexpr (GENERIC) load8g(q, edge_l, edge_r, v);
+    else load8(q, v);
+  };
   float sads[4][12];
 #pragma unroll
   for (int i = 0; i < 4; i++)
@@ -583,19 +604,20 @@ __device__ __forceinline__ void epf0_strip(const float* __restrict__ p0, int fx0
       load4(p + 3 * kBW, t4);
 #pragma unroll
       for (int j = 0; j < 4; j++) R6[3 + j] = t4[j];
-      load8(p - 2 * kBW, t8);
+      ld8(p - 2 * kBW, t8);
 #pragma unroll
       for (int j = 0; j < 8; j++) R1[1 + j] = t8[j];
-      load8(p - kBW, t8);
+      ld8(p - kBW, t8);
 #pragma unroll
       for (int j = 0; j < 8; j++) R2[1 + j] = t8[j];
-      load8(p + kBW, t8);
+      ld8(p + kBW, t8);
 #pragma unroll
       for (int j = 0; j < 8; j++) R4[1 + j] = t8[j];
-      load8(p + 2 * kBW, t8);
+      ld8(p + 2 * kBW, t8);
 #pragma unroll
       for (int j = 0; j < 8; j++) R5[1 + j] = t8[j];
-      load10(p, R3);
+      if constexpr (GENERIC) load10g(p, edge_l, edge_r, R3);
+      else load10(p, R3);
     }
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -651,9 +673,9 @@ __device__ __forceinline__ void epf0_strip(const float* __restrict__ p0, int fx0
     const float* p = p0 + c * kPlane;
     float A[4], B[8], C[8], D[8], E[4];  // rows y-2 .. y+2; 8-wide rows hold cols x-2 .. x+5
     load4(p - 2 * kBW, A);
-    load8(p - kBW, B);
-    load8(p, C);
-    load8(p + kBW, D);
+    ld8(p - kBW, B);
+    ld8(p, C);
+    ld8(p + kBW, D);
     load4(p + 2 * kBW, E);
     float o[4];
 #pragma unroll
@@ -673,6 +695,7 @@ __device__ __forceinline__ void epf0_strip(const float* __restrict__ p0, int fx0
 
 // Overwrites out-of-frame positions of a stage's output region [B-m, B+T+m) with the values
 // at their mirrored in-frame coordinates.  Only called by tiles that touch the frame border.
+template <int kT>
 __device__ __forceinline__ void mirror_fill(float* __restrict__ buf, int m, int tx0, int ty0, int w, int h, int tid) {
   const int rw = kTW + 2 * m, rh = kTH + 2 * m;
   for (int idx = tid; idx < rw * rh; idx += kT) {
@@ -686,8 +709,15 @@ __device__ __forceinline__ void mirror_fill(float* __restrict__ buf, int m, int 
   }
 }
 
+// Threads per workgroup: 512 (three workgroups of 80 VGPRs per CU), except the EPF0 variants: their 147 VGPRs allow three
+// wavefronts per SIMD, i.e. ONE 512-thread workgroup per CU with every barrier and the staging loads exposed; as
+// 256-thread workgroups three fit (LDS 51 KB each) and overlap each other: 16K epf_iters = 3, 2.97 -> see profiles/r03_g.
+template <bool E0>
+constexpr int fused_threads() { return E0 ? JXLH_FUSED_E0_THREADS : kThreadsDefault; }
+
 template <bool GAB, bool E0, bool E1, bool E2>
-__global__ __launch_bounds__(kT, E0 ? JXLH_FUSED_E0_WPE : JXLH_FUSED_WAVES_PER_EU) void k23_fused_filters(const FusedArgs a) {
+__global__ __launch_bounds__(fused_threads<E0>(), E0 ? JXLH_FUSED_E0_WPE : JXLH_FUSED_WAVES_PER_EU) void k23_fused_filters(const FusedArgs a) {
+  constexpr int kT = fused_threads<E0>();
   __shared__ __attribute__((aligned(16))) float s_buf[3 * kPlane];
   // 1/sigma of the 8x8 blocks this tile touches (block columns/rows relative to the tile's first block)
   __shared__ float s_sigma[kSigH * kSigW];
@@ -838,8 +868,8 @@ __global__ __launch_bounds__(kT, E0 ? JXLH_FUSED_E0_WPE : JXLH_FUSED_WAVES_PER_E
         if (cnt == 0) {
 #pragma unroll
           for (int c = 0; c < 3; c++) put(c, lds_load4(p + c * kPlane));
-        } else if (STAGE == 3 || cnt >= kDenseItems) {
-          if constexpr (STAGE == 3) epf0_strip(p, fx0, fy, sigma, a, put);
+        } else if (cnt >= (STAGE == 3 ? kDenseItems0 : kDenseItems)) {
+          if constexpr (STAGE == 3) epf0_strip<false>(p, fx0, fy, sigma, a, put);
           else epf2_strip<false>(p, fx0, fy, sigma, a, put);
         } else {
           // few active strips: the others leave now, the active ones are queued
@@ -851,18 +881,24 @@ __global__ __launch_bounds__(kT, E0 ? JXLH_FUSED_E0_WPE : JXLH_FUSED_WAVES_PER_E
           }
         }
       }
-      if constexpr (STAGE == 2) {
+      {
         __syncthreads();
         const int cnt = s_cnt;
 #pragma unroll 1
-        for (int i = tid; i < cnt; i += kT) {
-          const int t = s_list[i];
+        for (int i0 = 0; i0 < cnt; i0 += kT) {
+          if (i0 + (tid & ~63) >= cnt) break;  // wave-uniform
+          const int i = i0 + tid;
+          const bool on = i < cnt;
+          const int t = s_list[min(i, cnt - 1)];
           int by, bx0, fy, fx0;
           float sigma;
           strip_geom(t, by, bx0, fy, fx0, sigma);
           const float* p = s_buf + by * kBW + bx0;
-          epf2_strip<true>(p, fx0, fy, sigma, a, [&](int c, float4 o) { store(bx0, fy, fx0, c, o); }, bx0 == 0,
-                           bx0 == kBW - 4);
+          auto put = [&](int c, float4 o) {
+            if (on) store(bx0, fy, fx0, c, o);
+          };
+          if constexpr (STAGE == 3) epf0_strip<true>(p, fx0, fy, sigma, a, put, bx0 == 0, bx0 == kBW - 4);
+          else epf2_strip<true>(p, fx0, fy, sigma, a, put, bx0 == 0, bx0 == kBW - 4);
         }
       }
       return;
@@ -908,7 +944,7 @@ __global__ __launch_bounds__(kT, E0 ? JXLH_FUSED_E0_WPE : JXLH_FUSED_WAVES_PER_E
         for (int c = 0; c < 3; c++) gab_pair(g.p + c * kPlane, c, a.gab_k[c][0], a.gab_k[c][1], a.gab_k[c][2], put_g);
       }
     } else {
-      static_assert(STAGE == 0 || kPasses == 1, "one EPF item per thread");
+      static_assert(STAGE == 0 || STAGE == 3 || kPasses == 1, "one EPF item per thread (EPF0 returned above)");
       // ---- phase A: classify.  dense: this wavefront runs its own 64 items in the dense form; otherwise its
       // active strips go to the list and the wavefront is free to take 64 compacted strips
       auto geom = [&]() -> Geom {
@@ -1014,7 +1050,7 @@ __global__ __launch_bounds__(kT, E0 ? JXLH_FUSED_E0_WPE : JXLH_FUSED_WAVES_PER_E
       }
       __syncthreads();
       if (edge) {
-        mirror_fill(s_buf, margin, tx0, ty0, a.w, a.h, tid);
+        mirror_fill<kT>(s_buf, margin, tx0, ty0, a.w, a.h, tid);
         __syncthreads();
       }
     }
@@ -1031,7 +1067,7 @@ template <bool GAB, bool E0, bool E1, bool E2>
 void launch_variant(hipStream_t s, const FusedArgs& a) {
   const int tiles_x = (a.w + kTW - 1) / kTW, tiles_y = (a.y1 - a.y0 + kTH - 1) / kTH;
   const dim3 grid(tiles_x * ((tiles_y + 7) / 8) * 8);
-  hipLaunchKernelGGL((k23_fused_filters<GAB, E0, E1, E2>), grid, dim3(kT), 0, s, a);
+  hipLaunchKernelGGL((k23_fused_filters<GAB, E0, E1, E2>), grid, dim3(fused_threads<E0>()), 0, s, a);
 }
 
 __global__ void k_selftest_recip(uint32_t lo_bits, uint32_t hi_bits, unsigned long long* mismatches) {
