@@ -437,6 +437,7 @@ def main():
                       "allgather_MB_total": round(3 * size * size * 4 / 1e6, 1),
                       "halo_exchange_KB_per_edge": round(3 * 8 * swl.xblocks * 8 * 4 / 1e3, 1),
                       "band_group_rows_per_rank": (ygroups + world - 1) // world,
+                      "rccl_ranks_in_communicator": int(sctx.comm_band()[1]),
                       "frame_identical_on_all_ranks": bool(same_everywhere),
                       "frame_bit_equal_to_single_gpu_run": matches_single,
                       "what": "ONE frame: per rank K1 on its band of group rows, ncclSend/ncclRecv of the edge block rows, "
@@ -447,6 +448,54 @@ def main():
             sctx.close()
         except Exception as e:  # the weak line must survive a failure of the sharded leg
             strong = {"error": f"{type(e).__name__}: {e}"}
+
+    # ---- Modular across GPUs (BASELINE configs[3]: "Squeeze + RCT + Palette, 1 -> 8 GPU group shard + RCCL
+    # all-gather"): the squeeze chain replicated on every rank (its recurrence is serial along whole lines), the RCT
+    # and the palette expansion on the rank's own sample share, six in-place all-gathers over the library's communicator
+    strong_modular = None
+    if (world > 1 or (args.strong_at_1 and dist is not None)) and not args.no_strong:
+        try:
+            from jxl_rs_amd import lib as jl
+            from jxl_rs_amd.modular import ModularChain
+            box = [jl.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            mctx = jxl_rs_amd.Context(local_rank, n_slots=1)
+            mctx.comm_init(box[0], rank, world)
+            msize = 8192
+            mch = ModularChain(mctx, msize, msize, seed=84, world=world)
+
+            def mstep():
+                mch.run_pipeline_rccl(rank)
+
+            for _ in range(2):
+                mstep()
+            mctx.sync()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(max(3, args.steps // 2)):
+                mstep()
+            mctx.sync()
+            m_wall = max_over_ranks(time.perf_counter() - t0)
+            barrier()
+            # every rank must hold the same planes
+            planes, pal = mch.pipeline_result()
+            digest = int(sum(int(np.sum(pl.view(np.uint32), dtype=np.uint64)) for pl in planes + pal) & 0x7FFFFFFFFFFFFFFF)
+            dd = torch.tensor([digest, -digest], dtype=torch.int64, device=f"cuda:{local_rank}")
+            dist.all_reduce(dd, op=dist.ReduceOp.MAX)
+            m_ms = m_wall * 1e3 / max(3, args.steps // 2)
+            strong_modular = {"value": round(msize * msize / 1e6 / (m_ms / 1e3), 1), "unit": "MP/s", "ms_per_step": round(m_ms, 4),
+                              "scaling": "strong", "n_gpus": world, "rccl_ranks_in_communicator": world,
+                              "planes_identical_on_all_ranks": int(dd[0].item()) == -int(dd[1].item()),
+                              "allgather_MB_total": round(6 * msize * msize * 4 / 1e6, 1),
+                              "what": f"{msize}x{msize} x 3 ch: default squeeze chain replicated per rank, YCoCg RCT and 256-colour "
+                                      "palette on the rank's sample share, six in-place ncclAllGather (library-owned communicator)"}
+            del planes, pal
+            barrier()
+            mch.free()
+            mctx.comm_destroy()
+            mctx.close()
+        except Exception as e:
+            strong_modular = {"error": f"{type(e).__name__}: {e}"}
 
     # ---- per-kernel HIP-event timing (separate steps; not part of the timed region)
     roofline = None
@@ -755,7 +804,7 @@ def main():
                        "sharding": "independent frames per GPU, no collective (strong_scaling: one frame in bands of "
                                    "group rows, halo exchange + RCCL all-gather)" if world > 1 else "single GPU",
                        "frames_in_flight_per_gpu": max(1, args.inflight), "epf_population": args.epf},
-            "strong_scaling": strong,
+            "strong_scaling": strong, "strong_scaling_modular": strong_modular,
             "hip_event_ms_per_step_rank0": round(ev_ms / args.steps, 4),
             "setup": {"host_generate_s": round(gen_s, 2), "h2d_coeffs_s": round(h2d_s, 2)},
             "roofline": roofline, "cpu_baseline": cpu, "e2e_pcie_inclusive": e2e, "secondary": secondary,

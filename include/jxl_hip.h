@@ -508,7 +508,13 @@ jxlh_status jxlh_smooth_unsqueeze(jxlh_ctx* ctx, int32_t kind, const int32_t* av
  *   jxlh_frame_run_sharded then jxlh_frame_allgather (collectives: all ranks, same order); both only enqueue work on
  *   the context's stream (ncclSend/ncclRecv of the edge rows, ncclAllGather per plane).
  * One process driving several GPUs (or several contexts on one GPU): jxlh_comm_init_local(peers, n) makes peers[i]
- *   rank i, jxlh_frames_run_sharded_local / jxlh_frames_allgather_local drive all of them with direct device copies. */
+ *   rank i, jxlh_frames_run_sharded_local / jxlh_frames_allgather_local drive all of them with direct device copies.
+ *
+ * A collective whose peer never arrives (a rank that died, calls in a different order) would park the stream for
+ * ever: jxlh_ctx_sync of a context with an RCCL communicator of more than one rank therefore waits with a deadline
+ * (JXLH_COMM_TIMEOUT_S, default 120; <= 0: none) and polls ncclCommGetAsyncError; on expiry it returns JXLH_ERR_DEVICE
+ * and jxlh_last_error names the rank, the world size and the last collective enqueued (e.g. "halo exchange ... with
+ * rank 3"). */
 #define JXLH_COMM_ID_BYTES 128
 jxlh_status jxlh_comm_unique_id(uint8_t id[JXLH_COMM_ID_BYTES]);
 jxlh_status jxlh_comm_init(jxlh_ctx* ctx, const uint8_t id[JXLH_COMM_ID_BYTES], int32_t rank, int32_t nranks);

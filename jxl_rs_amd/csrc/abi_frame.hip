@@ -885,12 +885,11 @@ jxlh_status jxlh_ctx_sync(jxlh_ctx* ctx) {
     // go through the null stream and serialise against other contexts' work
     if (!ctx->host_flag) HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->host_flag), sizeof(int), hipHostMallocDefault));
     HIPCHK(ctx, hipMemcpyAsync(ctx->host_flag, ctx->error_flag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (jxlh_status st = comm_wait_stream(ctx)) return st;
     if (*ctx->host_flag != 0) return (jxlh_status)*ctx->host_flag;
     return JXLH_OK;
   }
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  return JXLH_OK;
+  return comm_wait_stream(ctx);
 }
 
 }  // extern "C"

@@ -14,6 +14,10 @@
 //   local  the peers are contexts of ONE process (several GPUs driven by one decoder process, or -- for tests --
 //          several contexts on one GPU): direct device-to-device copies ordered by events.
 #include <dlfcn.h>
+
+#include <chrono>
+#include <cstdlib>
+#include <thread>
 #include <rccl/rccl.h>  // types and enums only: every function is resolved at run time
 
 #include "jxlh_ctx.h"
@@ -31,6 +35,7 @@ struct RcclApi {
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t*) = nullptr;  // optional
 };
 
 static RcclApi* rccl_api(std::string* err) {
@@ -71,6 +76,7 @@ static RcclApi* rccl_api(std::string* err) {
     dlclose(h);
     return nullptr;
   }
+  api.CommGetAsyncError = reinterpret_cast<decltype(api.CommGetAsyncError)>(dlsym(h, "ncclCommGetAsyncError"));
   api.handle = h;
   return &api;
 }
@@ -84,6 +90,9 @@ struct Comm {
   hipEvent_t pulled_ev = nullptr;     // local: this rank has copied its neighbours' edge rows (they may overwrite them)
   hipEvent_t gathered_ev = nullptr;   // local: this rank has copied the other bands (their owners may start the next frame)
   bool gathered_valid = false;
+  // what was enqueued last on the stream through this communicator: named when a wait times out (comm_wait_stream)
+  std::string last_op;
+  double timeout_s = 120.0;           // JXLH_COMM_TIMEOUT_S; <= 0 waits forever
 };
 
 static jxlh_status nccl_fail(jxlh_ctx* ctx, const RcclApi* api, ncclResult_t r, const char* what) {
@@ -109,6 +118,43 @@ void comm_release(jxlh_ctx* ctx) {
   if (c->gathered_ev) (void)hipEventDestroy(c->gathered_ev);
   delete c;
   ctx->comm = nullptr;
+}
+
+// Waits for the context's stream like hipStreamSynchronize, but with a deadline when the stream may hold collectives
+// of an RCCL communicator with other ranks: a peer that never arrives (crashed rank, mismatched call order, a link
+// that went away) would otherwise park this process in the driver for ever.  On expiry -- or when RCCL reports an
+// asynchronous error -- the call returns JXLH_ERR_DEVICE and jxlh_last_error names rank, world size and the last
+// collective that was enqueued; the stream is left as it is (the caller tears the job down).
+jxlh_status comm_wait_stream(jxlh_ctx* ctx) {
+  Comm* c = ctx->comm;
+  if (!c || !c->nccl || c->nranks <= 1 || c->timeout_s <= 0.0) {
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return JXLH_OK;
+  }
+  RcclApi* api = rccl_api(nullptr);
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spins = 0;; spins++) {
+    const hipError_t q = hipStreamQuery(ctx->stream);
+    if (q == hipSuccess) return JXLH_OK;
+    if (q != hipErrorNotReady) return fail(ctx, q, "hipStreamQuery");
+    (void)hipGetLastError();
+    if (api && api->CommGetAsyncError) {
+      ncclResult_t ar = ncclSuccess;
+      if (api->CommGetAsyncError(c->nccl, &ar) == ncclSuccess && ar != ncclSuccess && ar != ncclInProgress) {
+        ctx->last_error = "rank " + std::to_string(c->rank) + " of " + std::to_string(c->nranks) + ": RCCL asynchronous error (" +
+                          (api->GetErrorString ? api->GetErrorString(ar) : "?") + ") after: " + c->last_op;
+        return JXLH_ERR_DEVICE;
+      }
+    }
+    const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (el > c->timeout_s) {
+      ctx->last_error = "rank " + std::to_string(c->rank) + " of " + std::to_string(c->nranks) + ": the stream did not finish within " +
+                        std::to_string((int)c->timeout_s) + " s (JXLH_COMM_TIMEOUT_S); last collective enqueued: " +
+                        (c->last_op.empty() ? std::string("none") : c->last_op);
+      return JXLH_ERR_DEVICE;
+    }
+    if (spins > 2000) std::this_thread::sleep_for(std::chrono::microseconds(spins > 20000 ? 1000 : 50));
+  }
 }
 
 int comm_nranks(const jxlh_ctx* ctx) { return ctx->comm ? ctx->comm->nranks : 1; }
@@ -186,6 +232,7 @@ jxlh_status jxlh_comm_init(jxlh_ctx* ctx, const uint8_t id[JXLH_COMM_ID_BYTES], 
   if (!c) return JXLH_ERR_OUT_OF_MEMORY;
   c->rank = rank;
   c->nranks = nranks;
+  if (const char* e = getenv("JXLH_COMM_TIMEOUT_S")) c->timeout_s = atof(e);
   ncclUniqueId u;
   std::memcpy(u.internal, id, JXLH_COMM_ID_BYTES);
   const ncclResult_t r = api->CommInitRank(&c->nccl, nranks, u, rank);
@@ -281,6 +328,8 @@ jxlh_status jxlh_frame_run_sharded(jxlh_ctx* ctx) {
       has_dn = dn0 < dn1;
     }
     if (has_up || has_dn) {
+      c->last_op = std::string("halo exchange of the band edges (ncclSend/ncclRecv with rank") + (has_up ? " " + std::to_string(c->rank - 1) : "") +
+                   (has_dn ? " " + std::to_string(c->rank + 1) : "") + ", group rows " + std::to_string(r0) + ".." + std::to_string(r1) + ")";
       NCCLCHK(ctx, api, api->GroupStart());
       for (int ch = 0; ch < 3; ch++) {
         size_t off, cnt;
@@ -318,6 +367,7 @@ jxlh_status jxlh_frame_allgather(jxlh_ctx* ctx) {
   ctx->res_h = f.ysize;
   ctx->res_stride = f.plane_stride;
   const size_t count = (size_t)comm_rows_per_rank(ctx, f.ygroups) * kGroupDim * f.plane_stride;
+  c->last_op = "ncclAllGather of the finished planes (" + std::to_string(count * 4) + " bytes per rank and plane)";
   NCCLCHK(ctx, api, api->GroupStart());
   for (int ch = 0; ch < 3; ch++)
     NCCLCHK(ctx, api, api->AllGather(res[ch] + (size_t)c->rank * count, res[ch], count, ncclFloat32, c->nccl, ctx->stream));
@@ -331,6 +381,7 @@ jxlh_status jxlh_comm_allgather(jxlh_ctx* ctx, void* buf, size_t bytes_per_rank)
   HIPCHK(ctx, hipSetDevice(ctx->device));
   Comm* c = ctx->comm;
   RcclApi* api = rccl_api(nullptr);
+  c->last_op = "jxlh_comm_allgather (" + std::to_string(bytes_per_rank) + " bytes per rank)";
   NCCLCHK(ctx, api, api->AllGather(static_cast<char*>(buf) + (size_t)c->rank * bytes_per_rank, buf, bytes_per_rank,
                                    ncclUint8, c->nccl, ctx->stream));
   return JXLH_OK;

@@ -259,6 +259,7 @@ jxlh_status stage_out(jxlh_ctx* ctx, T* dst, const T* src, size_t n) {
 // comm.hip
 void comm_release(jxlh_ctx* ctx);
 int comm_nranks(const jxlh_ctx* ctx);
+jxlh_status comm_wait_stream(jxlh_ctx* ctx);  // hipStreamSynchronize with a deadline while collectives may be queued
 int comm_rows_per_rank(const jxlh_ctx* ctx, int ygroups);
 
 }  // namespace jxlh_host

@@ -221,6 +221,57 @@ def test_modular_rct_and_palette_band_sharded(oracle, n):
             c.close()
 
 
+@pytest.mark.parametrize("n,size", [(2, (700, 500)), (3, (257, 331)), (2, (2048, 1024))])
+def test_modular_config4_pipeline_sharded(oracle, n, size):
+    """BASELINE configs[3] as ONE multi-rank pipeline (in-process ranks): replicated squeeze chain -> RCT on the own
+    sample share -> palette on the own share -> in-place all-gathers; every rank must end with the oracle's whole
+    planes (chain + RCT) and whole palette expansion"""
+    import jxl_rs_amd
+    from jxl_rs_amd import lib, synth
+    from jxl_rs_amd.modular import ModularChain, run_pipeline_local
+    w, h = size
+    planes = synth.make_modular_planes(w, h, seed=40 + n)
+    ctxs = [jxl_rs_amd.Context(0, 1) for _ in range(n)]
+    chains = []
+    try:
+        lib.comm_init_local(ctxs)
+        chains = [ModularChain(c, w, h, planes=planes, world=n) for c in ctxs]
+        run_pipeline_local(chains, ctxs)
+        want_planes, want_pal = chains[0].oracle_pipeline_result(oracle)
+        for r, ch in enumerate(chains):
+            got_planes, got_pal = ch.pipeline_result()
+            for c in range(3):
+                assert np.array_equal(got_planes[c], want_planes[c]), f"rank {r}: chain + RCT channel {c}"
+                assert np.array_equal(got_pal[c], want_pal[c]), f"rank {r}: palette channel {c}"
+    finally:
+        for ch in chains:
+            ch.free()
+        for c in ctxs:
+            c.close()
+
+
+def test_modular_config4_pipeline_rccl_single_rank(oracle):
+    """the same pipeline over the library's RCCL communicator with one rank (what a 1-GPU box can run)"""
+    import jxl_rs_amd
+    from jxl_rs_amd import lib
+    from jxl_rs_amd.modular import ModularChain
+    c = jxl_rs_amd.Context(0, 1)
+    ch = None
+    try:
+        c.comm_init(lib.comm_unique_id(), 0, 1)
+        ch = ModularChain(c, 515, 260, seed=5, world=1)
+        ch.run_pipeline_rccl(0)
+        want_planes, want_pal = ch.oracle_pipeline_result(oracle)
+        got_planes, got_pal = ch.pipeline_result()
+        for k in range(3):
+            assert np.array_equal(got_planes[k], want_planes[k]) and np.array_equal(got_pal[k], want_pal[k]), k
+        c.comm_destroy()
+    finally:
+        if ch is not None:
+            ch.free()
+        c.close()
+
+
 def test_rct_and_palette_on_unaligned_device_subranges(oracle):
     """a share of a plane may start at any sample: the vectorised kernels fall back to scalar accesses when a
     device pointer is not 16-byte aligned"""

@@ -97,3 +97,69 @@ def test_band_sharding_with_halo_exchange_reassembles_the_frame(tmp_path, oracle
         assert got.shape == (3, 700, 300)
         for c in range(3):
             assert np.array_equal(got[c].view(np.uint32), want[c].view(np.uint32)), (r, c)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# BASELINE configs[3] across ranks: replicated squeeze chain -> RCT and palette on the own sample share -> all-gather.
+# The protocol jxl_rs_amd.modular.ModularChain.run_pipeline_rccl runs over the library's RCCL communicator (and
+# tests/test_gpu_sharding.py::test_modular_config4_pipeline_sharded over the in-process transport), with the oracle as
+# the compute stand-in and gloo as the transport.
+def _modular_worker(rank, world, port, out_dir):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from jxl_rs_amd import synth
+    from jxl_rs_amd.shard import sample_share
+    from oracle.oracle import Oracle
+    o = Oracle(fused=True)
+    w, h = 301, 207
+    base, residuals, steps = synth.make_modular_planes(w, h, seed=77)
+    cur = [b.copy() for b in base]
+    for (hz, ow, oh), res in zip(steps, residuals):     # the recurrence is serial along a line: every rank runs it
+        cur = [o.unsqueeze_h(cur[c], res[c], ow) if hz else o.unsqueeze_v(cur[c], res[c], oh) for c in range(3)]
+    n = w * h
+    i0, i1, count = sample_share(n, rank, world)
+    flat = [np.zeros(world * count, np.int32) for _ in range(3)]
+    share = o.rct([cur[c].reshape(-1)[i0:i1].reshape(1, -1) for c in range(3)], 6, 0) if i1 > i0 else None
+    rng = np.random.default_rng(256)
+    idx = rng.integers(-3, 300, size=n).astype(np.int32)
+    pal = rng.integers(0, 256, size=(3, 256)).astype(np.int32)
+    pshare = o.palette(idx[i0:i1].reshape(1, -1), pal, 256, 3, 8) if i1 > i0 else None
+    out = {}
+    for name, sh in (("rct", share), ("pal", pshare)):
+        for c in range(3):
+            mine = torch.zeros(count, dtype=torch.int32)
+            if sh is not None:
+                mine[: i1 - i0] = torch.from_numpy(np.asarray(sh[c]).reshape(-1).copy())
+            full = torch.zeros(world * count, dtype=torch.int32)
+            dist.all_gather_into_tensor(full, mine)
+            out[f"{name}{c}"] = full.numpy()[:n].reshape(h, w)
+    np.savez(os.path.join(out_dir, f"modular_rank{rank}.npz"), **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_modular_pipeline_shares_reassemble(tmp_path, oracle, world):
+    import torch.multiprocessing as mp
+    from jxl_rs_amd import synth
+    port = 31500 + (os.getpid() * 5 + world) % 2000
+    mp.spawn(_modular_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    w, h = 301, 207
+    base, residuals, steps = synth.make_modular_planes(w, h, seed=77)
+    cur = [b.copy() for b in base]
+    for (hz, ow, oh), res in zip(steps, residuals):
+        cur = [oracle.unsqueeze_h(cur[c], res[c], ow) if hz else oracle.unsqueeze_v(cur[c], res[c], oh) for c in range(3)]
+    want = oracle.rct(cur, 6, 0)
+    rng = np.random.default_rng(256)
+    idx = rng.integers(-3, 300, size=w * h).astype(np.int32)
+    pal = rng.integers(0, 256, size=(3, 256)).astype(np.int32)
+    want_pal = oracle.palette(idx.reshape(h, w), pal, 256, 3, 8)
+    for r in range(world):
+        got = np.load(tmp_path / f"modular_rank{r}.npz")
+        for c in range(3):
+            assert np.array_equal(got[f"rct{c}"], want[c]), (r, c)
+            assert np.array_equal(got[f"pal{c}"], want_pal[c]), (r, c)
