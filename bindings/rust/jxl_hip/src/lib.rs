@@ -142,6 +142,9 @@ impl<'a> VarDctFrame<'a> {
     #[allow(clippy::too_many_arguments)]
     pub fn decode_lf_group(&self, x0: u32, y0: u32, w: u32, h: u32, qy: &[i32], qx: &[i32], qb: &[i32], stride: usize,
                            extra_precision: u32) -> Result<()> {
+        if w == 0 || h == 0 || stride < w as usize {
+            return Err(HipError::InvalidArgument);
+        }
         let need = (h as usize - 1) * stride + w as usize;
         if qy.len() < need || qx.len() < need || qb.len() < need {
             return Err(HipError::InvalidArgument);
@@ -155,6 +158,16 @@ impl<'a> VarDctFrame<'a> {
     #[allow(clippy::too_many_arguments)]
     pub fn decode_hf_metadata(&self, x0: u32, y0: u32, w: u32, h: u32, transform_map: &[u8], raw_quant: &[i32],
                               epf_map: &[u8], map_stride: usize, ytox: &[i8], ytob: &[i8], cmap_stride: usize) -> Result<()> {
+        // the C side reads h rows of w entries at map_stride, and one colour-tile entry per 8 x 8 blocks
+        if w == 0 || h == 0 || map_stride < w as usize || cmap_stride < (w as usize).div_ceil(8) {
+            return Err(HipError::InvalidArgument);
+        }
+        let need = (h as usize - 1) * map_stride + w as usize;
+        let cneed = ((h as usize).div_ceil(8) - 1) * cmap_stride + (w as usize).div_ceil(8);
+        if transform_map.len() < need || raw_quant.len() < need || epf_map.len() < need || ytox.len() < cneed
+            || ytob.len() < cneed {
+            return Err(HipError::InvalidArgument);
+        }
         self.ctx.ok(unsafe {
             sys::jxlh_frame_set_hf_meta(self.ctx.raw, x0, y0, w, h, transform_map.as_ptr(), raw_quant.as_ptr(),
                                         epf_map.as_ptr(), map_stride, ytox.as_ptr(), ytob.as_ptr(), cmap_stride)
@@ -163,25 +176,31 @@ impl<'a> VarDctFrame<'a> {
     /// the `if let Some(pixels)` branch of `decode_vardct_group` (frame/group.rs:579-611): the group's dense slab,
     /// 3 x 65536 i32 in pinned memory; asynchronous, reuse the slab after `slot_wait`.  `complete = false` is a
     /// progressive pass whose coefficients will be added to by later passes (`set_buffer_for_group(.., complete, ..)`).
-    pub fn decode_vardct_group(&self, slot: i32, group: u32, coeffs: &[i32], complete: bool) -> Result<()> {
+    ///
+    /// # Safety
+    /// The copy is asynchronous: `coeffs` must stay alive and unmodified until `slot_wait(slot)` has returned (the
+    /// borrow this call holds ends when it returns, the device still reads the slab).
+    pub unsafe fn decode_vardct_group(&self, slot: i32, group: u32, coeffs: &[i32], complete: bool) -> Result<()> {
         if coeffs.len() != 3 * 65536 {
             return Err(HipError::InvalidArgument);
         }
         let flags = if complete { sys::JXLH_GROUP_COMPLETE } else { 0 };
-        self.ctx.ok(unsafe { sys::jxlh_submit_group(self.ctx.raw, slot, group, coeffs.as_ptr(), flags) })
+        self.ctx.ok(sys::jxlh_submit_group(self.ctx.raw, slot, group, coeffs.as_ptr(), flags))
     }
     /// the same from the entropy loop's updates (frame/group.rs:557-572 emits `(position, value)` instead of
     /// `coeffs[position] += value`): `pairs` = X run, Y run, B run
-    pub fn decode_vardct_group_sparse(&self, slot: i32, group: u32, pairs: &[sys::jxlh_coeff16], n: [u32; 3],
+    ///
+    /// # Safety
+    /// Asynchronous like `decode_vardct_group`: `pairs` and `wide` must stay alive and unmodified until
+    /// `slot_wait(slot)` has returned.
+    pub unsafe fn decode_vardct_group_sparse(&self, slot: i32, group: u32, pairs: &[sys::jxlh_coeff16], n: [u32; 3],
                                       wide: &[sys::jxlh_coeff32], complete: bool) -> Result<()> {
         if pairs.len() != (n[0] + n[1] + n[2]) as usize {
             return Err(HipError::InvalidArgument);
         }
         let flags = if complete { sys::JXLH_GROUP_COMPLETE } else { 0 };
-        self.ctx.ok(unsafe {
-            sys::jxlh_submit_group_sparse(self.ctx.raw, slot, group, pairs.as_ptr(), n.as_ptr(), wide.as_ptr(),
-                                          wide.len() as u32, flags)
-        })
+        self.ctx.ok(sys::jxlh_submit_group_sparse(self.ctx.raw, slot, group, pairs.as_ptr(), n.as_ptr(), wide.as_ptr(),
+                                                  wide.len() as u32, flags))
     }
     pub fn slot_wait(&self, slot: i32) -> Result<()> {
         self.ctx.ok(unsafe { sys::jxlh_slot_wait(self.ctx.raw, slot) })
@@ -196,13 +215,18 @@ impl<'a> VarDctFrame<'a> {
         self.ctx.ok(unsafe { sys::jxlh_frame_rerender_groups(self.ctx.raw, groups.as_ptr(), groups.len() as u32) })
     }
     /// the save stage for planar f32 XYB output; `out[c]` = `RawImageBuffer` of channel c
-    pub fn read_planes(&self, out: &[sys::jxlh_plane; 3]) -> Result<()> {
-        self.ctx.ok(unsafe { sys::jxlh_frame_read_planes(self.ctx.raw, out.as_ptr()) })
+    ///
+    /// # Safety
+    /// Every `out[c]` must describe writable memory (host or device) of `num_rows` rows of `bytes_per_row` bytes at
+    /// `bytes_between_rows`: the descriptors carry raw pointers the compiler cannot check.
+    pub unsafe fn read_planes(&self, out: &[sys::jxlh_plane; 3]) -> Result<()> {
+        self.ctx.ok(sys::jxlh_frame_read_planes(self.ctx.raw, out.as_ptr()))
     }
     /// XybStage + FromLinearStage(sRGB) + ConvertF32ToU8Stage, interleaved, rows [y0, y1)
     pub fn read_rgb8(&self, p: &sys::jxlh_xyb_params, channels: u32, y0: u32, y1: u32, out: &mut [u8],
                      bytes_per_row: usize) -> Result<()> {
-        if out.len() < (y1 - y0) as usize * bytes_per_row {
+        let rows = y1.checked_sub(y0).ok_or(HipError::InvalidArgument)? as usize;
+        if out.len() < rows * bytes_per_row {
             return Err(HipError::InvalidArgument);
         }
         self.ctx.ok(unsafe {
