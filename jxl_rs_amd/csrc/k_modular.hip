@@ -973,10 +973,16 @@ __global__ __launch_bounds__(256) void k6_unsqueeze_tiled(const SqueezePlanes pl
   const int32_t* __restrict__ ga = pl.avg[blockIdx.y];
   const int32_t* __restrict__ gr = pl.res[blockIdx.y];
   int32_t* __restrict__ go = pl.out[blockIdx.y];
+  // w steps produce 2 w samples; an odd line ends with a copied sample.  EVERY step runs through the chunk pipeline
+  // (round 2 left the last n % S steps and the closing pair to the chain lane's own global loads: with power-of-two
+  // planes that is 31 steps per level whose memory latency sat in the dependent instruction stream, ~10 us per level):
+  // the step without a following average (even lines: next_avg = avg itself, squeeze.rs:423-430) is staged with the
+  // average index clamped to the last one, and the last chunk may be partial.
   const int w = n_out / 2;
   const bool has_tail = n_out & 1;
-  const int n_main = has_tail ? w : w - 1;  // steps whose next_avg = avg[i + 1] exists
-  const int n_chunks = n_main / S;
+  const int n_avg = n_out - w;
+  const int n_chunks = (n_out + 2 * S - 1) / (2 * S);   // chunks of 2 S output samples; the last may hold fewer steps
+  auto steps_of = [&](int c) { return max(0, min(S, w - c * S)); };
   const bool chain = tid < 64;
   if (chain) __builtin_amdgcn_s_setprio(3);  // the step time IS this wave's issue latency
   const int m = tid - 64;  // mover index 0..191
@@ -1004,12 +1010,23 @@ __global__ __launch_bounds__(256) void k6_unsqueeze_tiled(const SqueezePlanes pl
   const int out_lds0 = HORIZ ? out_r0 * PO + out_k0 : out_k0 * 64 + out_r0;
   constexpr int OUT_LDS_DJ = HORIZ ? OUT_DR * PO : OUT_DK * 64;
   auto fetch_chunk = [&](int c, int32_t(&va)[NIN], int32_t(&vr)[NIN]) {
-    const uint32_t ca = a_off0 + (uint32_t)(c * S) * aep, cr = r_off0 + (uint32_t)(c * S) * rep;
+    if (c * S + S <= w - 1) {  // every next average and residual of the chunk exists: affine offsets
+      const uint32_t ca = a_off0 + (uint32_t)(c * S) * aep, cr = r_off0 + (uint32_t)(c * S) * rep;
 #pragma unroll
-    for (int j = 0; j < NIN; j++) {
-      const bool ok = l0 + in_r0 + j * IN_DR < n_lines && m + j * NM < 64 * S;
-      va[j] = ok ? ga[ca + j * a_dj] : 0;
-      vr[j] = ok ? gr[cr + j * r_dj] : 0;
+      for (int j = 0; j < NIN; j++) {
+        const bool ok = l0 + in_r0 + j * IN_DR < n_lines && m + j * NM < 64 * S;
+        va[j] = ok ? ga[ca + j * a_dj] : 0;
+        vr[j] = ok ? gr[cr + j * r_dj] : 0;
+      }
+    } else {  // the line's end: clamp the element indices (next_avg of the last step = the last average)
+#pragma unroll
+      for (int j = 0; j < NIN; j++) {
+        const int row = in_r0 + j * IN_DR, k = in_k0 + j * IN_DK;
+        const bool ok = l0 + row < n_lines && m + j * NM < 64 * S && c * S + k < w;
+        const int ia = min(c * S + 1 + k, n_avg - 1), ir = min(c * S + k, max(w - 1, 0));
+        va[j] = ok ? ga[(uint32_t)(l0 + row) * alp + (uint32_t)ia * aep] : 0;
+        vr[j] = ok ? gr[(uint32_t)(l0 + row) * rlp + (uint32_t)ir * rep] : 0;
+      }
     }
   };
   auto stage_chunk = [&](int c, const int32_t(&va)[NIN], const int32_t(&vr)[NIN]) {
@@ -1024,12 +1041,14 @@ __global__ __launch_bounds__(256) void k6_unsqueeze_tiled(const SqueezePlanes pl
   auto store_chunk = [&](int c) {
     const int32_t* so = s_out[c & 1];
     const uint32_t co = o_off0 + (uint32_t)(2 * c * S) * oep;
+    const int count = min(2 * S, n_out - 2 * c * S);  // samples of the chunk (the last one may be partial)
     int32_t v[NOUT];
 #pragma unroll
     for (int j = 0; j < NOUT; j++) v[j] = m + j * NM < 64 * 2 * S ? so[out_lds0 + j * OUT_LDS_DJ] : 0;
 #pragma unroll
     for (int j = 0; j < NOUT; j++)
-      if (l0 + out_r0 + j * OUT_DR < n_lines && m + j * NM < 64 * 2 * S) go[co + j * o_dj] = v[j];
+      if (l0 + out_r0 + j * OUT_DR < n_lines && m + j * NM < 64 * 2 * S && out_k0 + j * OUT_DK < count)
+        go[co + j * o_dj] = v[j];
   };
 
   const int l = l0 + tid;  // chain lanes
@@ -1038,80 +1057,78 @@ __global__ __launch_bounds__(256) void k6_unsqueeze_tiled(const SqueezePlanes pl
   // mover schedule, iteration c: stage chunk c + 1 (fetched during iteration c - 1: its latency is a whole iteration
   // old), fetch chunk c + 2 into registers, drain the outputs of chunk c - 1
   int32_t pa[NIN], pr[NIN];
-  if (!chain && n_chunks > 0) {
+  if (!chain && steps_of(0) > 0) {
     fetch_chunk(0, pa, pr);
     stage_chunk(0, pa, pr);
-    if (n_chunks > 1) fetch_chunk(1, pa, pr);
+    if (steps_of(1) > 0) fetch_chunk(1, pa, pr);
   }
   lds_barrier();
   for (int c = 0; c < n_chunks; c++) {
     if (!chain) {
-      if (c + 1 < n_chunks) stage_chunk(c + 1, pa, pr);
-      if (c + 2 < n_chunks) fetch_chunk(c + 2, pa, pr);
+      if (steps_of(c + 1) > 0) stage_chunk(c + 1, pa, pr);
+      if (steps_of(c + 2) > 0) fetch_chunk(c + 2, pa, pr);
       if (c >= 1) store_chunk(c - 1);
     } else {
       const int32_t* ia = s_avg[c & 1];
       const int32_t* ir = s_res[c & 1];
       int32_t* oa = s_out[c & 1];
-      int32_t xa[S], xr[S];
-      if constexpr (HORIZ) {
-#pragma unroll
-        for (int j = 0; j < S / 4; j++) {
-          const int4 va = *reinterpret_cast<const int4*>(ia + tid * PI + 4 * j);
-          const int4 vr = *reinterpret_cast<const int4*>(ir + tid * PI + 4 * j);
-          xa[4 * j] = va.x; xa[4 * j + 1] = va.y; xa[4 * j + 2] = va.z; xa[4 * j + 3] = va.w;
-          xr[4 * j] = vr.x; xr[4 * j + 1] = vr.y; xr[4 * j + 2] = vr.z; xr[4 * j + 3] = vr.w;
-        }
-      } else {
-#pragma unroll
-        for (int k = 0; k < S; k++) {
-          xa[k] = ia[k * 64 + tid];
-          xr[k] = ir[k * 64 + tid];
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < S; k += 2) {
-        int32_t a0, b0, a1, b1;
-        unsqueeze_step(cur, xr[k], xa[k], d, a0, b0);
-        unsqueeze_step(xa[k], xr[k + 1], xa[k + 1], d, a1, b1);
-        cur = xa[k + 1];
+      const int sc = steps_of(c);
+      if (sc == S) {
+        int32_t xa[S], xr[S];
         if constexpr (HORIZ) {
-          *reinterpret_cast<int4*>(oa + tid * PO + 2 * k) = make_int4(a0, b0, a1, b1);
+#pragma unroll
+          for (int j = 0; j < S / 4; j++) {
+            const int4 va = *reinterpret_cast<const int4*>(ia + tid * PI + 4 * j);
+            const int4 vr = *reinterpret_cast<const int4*>(ir + tid * PI + 4 * j);
+            xa[4 * j] = va.x; xa[4 * j + 1] = va.y; xa[4 * j + 2] = va.z; xa[4 * j + 3] = va.w;
+            xr[4 * j] = vr.x; xr[4 * j + 1] = vr.y; xr[4 * j + 2] = vr.z; xr[4 * j + 3] = vr.w;
+          }
         } else {
-          oa[(2 * k) * 64 + tid] = a0;
-          oa[(2 * k + 1) * 64 + tid] = b0;
-          oa[(2 * k + 2) * 64 + tid] = a1;
-          oa[(2 * k + 3) * 64 + tid] = b1;
+#pragma unroll
+          for (int k = 0; k < S; k++) {
+            xa[k] = ia[k * 64 + tid];
+            xr[k] = ir[k * 64 + tid];
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < S; k += 2) {
+          int32_t a0, b0, a1, b1;
+          unsqueeze_step(cur, xr[k], xa[k], d, a0, b0);
+          unsqueeze_step(xa[k], xr[k + 1], xa[k + 1], d, a1, b1);
+          cur = xa[k + 1];
+          if constexpr (HORIZ) {
+            *reinterpret_cast<int4*>(oa + tid * PO + 2 * k) = make_int4(a0, b0, a1, b1);
+          } else {
+            oa[(2 * k) * 64 + tid] = a0;
+            oa[(2 * k + 1) * 64 + tid] = b0;
+            oa[(2 * k + 2) * 64 + tid] = a1;
+            oa[(2 * k + 3) * 64 + tid] = b1;
+          }
+        }
+      } else {  // the line's last chunk: fewer steps, one by one; an odd line's copied sample behind them
+        for (int k = 0; k < sc; k++) {
+          const int32_t nxt = HORIZ ? ia[tid * PI + k] : ia[k * 64 + tid];
+          const int32_t rs = HORIZ ? ir[tid * PI + k] : ir[k * 64 + tid];
+          int32_t va, vb;
+          unsqueeze_step(cur, rs, nxt, d, va, vb);
+          cur = nxt;
+          if constexpr (HORIZ) {
+            oa[tid * PO + 2 * k] = va;
+            oa[tid * PO + 2 * k + 1] = vb;
+          } else {
+            oa[(2 * k) * 64 + tid] = va;
+            oa[(2 * k + 1) * 64 + tid] = vb;
+          }
+        }
+        if (has_tail) {  // n_out odd: sample 2 w = avg[w] (squeeze.rs:434-437), always in the last chunk
+          if constexpr (HORIZ) oa[tid * PO + 2 * sc] = cur;
+          else oa[(2 * sc) * 64 + tid] = cur;
         }
       }
     }
     lds_barrier();
   }
-  if (!chain) {
-    if (n_chunks > 0) store_chunk(n_chunks - 1);
-    return;
-  }
-  if (l >= n_lines) return;
-  // what is left of the line (< S steps, the closing pair or the copied tail): the chain lane itself, as in k6_unsqueeze
-  const int32_t* __restrict__ a = ga + (size_t)l * avg_lp;
-  const int32_t* __restrict__ r = gr + (size_t)l * res_lp;
-  int32_t* __restrict__ o = go + (size_t)l * out_lp;
-  for (int i = n_chunks * S; i < n_main; i++) {
-    const int32_t nxt = a[(size_t)(i + 1) * avg_ep];
-    int32_t va, vb;
-    unsqueeze_step(cur, r[(size_t)i * res_ep], nxt, d, va, vb);
-    o[(size_t)(2 * i) * out_ep] = va;
-    o[(size_t)(2 * i + 1) * out_ep] = vb;
-    cur = nxt;
-  }
-  if (!has_tail) {
-    int32_t va, vb;
-    unsqueeze_step(cur, r[(size_t)(w - 1) * res_ep], cur, d, va, vb);
-    o[(size_t)(2 * w - 2) * out_ep] = va;
-    o[(size_t)(2 * w - 1) * out_ep] = vb;
-  } else {
-    o[(size_t)(2 * w) * out_ep] = cur;
-  }
+  if (!chain && n_chunks > 0) store_chunk(n_chunks - 1);
 }
 
 // The last step of a colour image's squeeze chain is an unsqueeze of three channels at full size (vertical for square
@@ -1140,10 +1157,12 @@ __global__ __launch_bounds__(64 * (3 * NCW + 1)) void k6_unsqueeze_rct(const Squ
   __shared__ __attribute__((aligned(16))) int32_t s_out[2][OUT_ELEMS];
   const int tid = threadIdx.x;
   const int l0 = blockIdx.x * NL;
+  // every step through the chunk pipeline, the last chunk possibly partial (see k6_unsqueeze_tiled)
   const int w = n_out / 2;
   const bool has_tail = n_out & 1;
-  const int n_main = has_tail ? w : w - 1;
-  const int n_chunks = n_main / S;
+  const int n_avg = n_out - w;
+  const int n_chunks = (n_out + 2 * S - 1) / (2 * S);
+  auto steps_of = [&](int c) { return max(0, min(S, w - c * S)); };
   const bool chain = tid < 64 * NCW;
   if (chain) __builtin_amdgcn_s_setprio(3);  // the step time IS this wave's issue latency
   // Mover roles.  The scalar movers (m = 0..191) both load and store.  The vector movers are split, NCW waves loading
@@ -1200,8 +1219,11 @@ __global__ __launch_bounds__(64 * (3 * NCW + 1)) void k6_unsqueeze_rct(const Squ
         const uint32_t col = (uint32_t)(l0 + 4 * qq < n_lines ? l0 + 4 * qq : l0);
         const int32_t* ap = plane_ptr(pl.avg[0], a_d1, a_d2, p);
         const int32_t* rp = plane_ptr(pl.res[0], r_d1, r_d2, p);
-        const int4 xa = *reinterpret_cast<const int4*>(ap + (uint32_t)(c * S + 1 + kk) * avg_ep + col);
-        const int4 xr = *reinterpret_cast<const int4*>(rp + (uint32_t)(c * S + kk) * res_ep + col);
+        // the line's end: next_avg of the last step of an even line is the last average itself (index clamped);
+        // steps past the line fetch valid rows that are never used
+        const int ia = min(c * S + 1 + kk, n_avg - 1), ir = min(c * S + kk, max(w - 1, 0));
+        const int4 xa = *reinterpret_cast<const int4*>(ap + (uint32_t)ia * avg_ep + col);
+        const int4 xr = *reinterpret_cast<const int4*>(rp + (uint32_t)ir * res_ep + col);
         va[4 * j] = xa.x; va[4 * j + 1] = xa.y; va[4 * j + 2] = xa.z; va[4 * j + 3] = xa.w;
         vr[4 * j] = xr.x; vr[4 * j + 1] = xr.y; vr[4 * j + 2] = xr.z; vr[4 * j + 3] = xr.w;
       }
@@ -1211,11 +1233,12 @@ __global__ __launch_bounds__(64 * (3 * NCW + 1)) void k6_unsqueeze_rct(const Squ
     for (int j = 0; j < NIN; j++) {
       const int f = m + j * NM, r = HORIZ ? f / S : f % 64, k = HORIZ ? f % S : f / 64;
       int p, q;
-      const bool ok = row_of(r, p, q) && f < 64 * S;
+      const bool ok = row_of(r, p, q) && f < 64 * S && c * S + k < w;
       const int32_t* ap = plane_ptr(pl.avg[0], a_d1, a_d2, p);
       const int32_t* rp = plane_ptr(pl.res[0], r_d1, r_d2, p);
-      va[j] = ok ? ap[(uint32_t)(l0 + q) * avg_lp + (uint32_t)(c * S + 1 + k) * avg_ep] : 0;
-      vr[j] = ok ? rp[(uint32_t)(l0 + q) * res_lp + (uint32_t)(c * S + k) * res_ep] : 0;
+      const int ia = min(c * S + 1 + k, n_avg - 1), ir = min(c * S + k, max(w - 1, 0));
+      va[j] = ok ? ap[(uint32_t)(l0 + q) * avg_lp + (uint32_t)ia * avg_ep] : 0;
+      vr[j] = ok ? rp[(uint32_t)(l0 + q) * res_lp + (uint32_t)ir * res_ep] : 0;
     }
   };
   auto stage_chunk = [&](int c, const int32_t(&va)[NIN], const int32_t(&vr)[NIN]) {
@@ -1301,96 +1324,73 @@ __global__ __launch_bounds__(64 * (3 * NCW + 1)) void k6_unsqueeze_rct(const Squ
 
   int cp, cq;
   const bool live = chain && row_of(tid, cp, cq);
-  const int32_t* __restrict__ a = nullptr;
-  const int32_t* __restrict__ r = nullptr;
   int32_t cur = 0, d = 0;
-  if (live) {
-    a = plane_ptr(pl.avg[0], a_d1, a_d2, cp) + (size_t)(l0 + cq) * avg_lp;
-    r = plane_ptr(pl.res[0], r_d1, r_d2, cp) + (size_t)(l0 + cq) * res_lp;
-    cur = a[0];
-  }
+  if (live) cur = (plane_ptr(pl.avg[0], a_d1, a_d2, cp) + (size_t)(l0 + cq) * avg_lp)[0];
+  auto count_of = [&](int c) { return min(2 * S, n_out - 2 * c * S); };
   int32_t pa[NIN], pr[NIN];
-  if (loader && n_chunks > 0) {
+  if (loader && steps_of(0) > 0) {
     fetch_chunk(0, pa, pr);
     stage_chunk(0, pa, pr);
-    if (n_chunks > 1) fetch_chunk(1, pa, pr);
+    if (steps_of(1) > 0) fetch_chunk(1, pa, pr);
   }
   lds_barrier();
   for (int c = 0; c < n_chunks; c++) {
     if (!chain) {
-      if (loader && c + 1 < n_chunks) stage_chunk(c + 1, pa, pr);
-      if (loader && c + 2 < n_chunks) fetch_chunk(c + 2, pa, pr);
-      if (storer && c >= 1) store_chunk(c - 1, 2 * S);
+      if (loader && steps_of(c + 1) > 0) stage_chunk(c + 1, pa, pr);
+      if (loader && steps_of(c + 2) > 0) fetch_chunk(c + 2, pa, pr);
+      if (storer && c >= 1) store_chunk(c - 1, count_of(c - 1));
     } else {
       const int32_t* ia = s_avg[c & 1];
       const int32_t* ir = s_res[c & 1];
       int32_t* oa = s_out[c & 1];
-      int32_t xa[S], xr[S];
-      if constexpr (HORIZ) {
-#pragma unroll
-        for (int j = 0; j < S / 4; j++) {
-          const int4 va = *reinterpret_cast<const int4*>(ia + tid * PI + 4 * j);
-          const int4 vr = *reinterpret_cast<const int4*>(ir + tid * PI + 4 * j);
-          xa[4 * j] = va.x; xa[4 * j + 1] = va.y; xa[4 * j + 2] = va.z; xa[4 * j + 3] = va.w;
-          xr[4 * j] = vr.x; xr[4 * j + 1] = vr.y; xr[4 * j + 2] = vr.z; xr[4 * j + 3] = vr.w;
-        }
-      } else {
-#pragma unroll
-        for (int k = 0; k < S; k++) {
-          xa[k] = ia[k * RP + tid];
-          xr[k] = ir[k * RP + tid];
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < S; k += 2) {
-        int32_t a0, b0, a1, b1;
-        unsqueeze_step(cur, xr[k], xa[k], d, a0, b0);
-        unsqueeze_step(xa[k], xr[k + 1], xa[k + 1], d, a1, b1);
-        cur = xa[k + 1];
+      const int sc = steps_of(c);
+      if (sc == S) {
+        int32_t xa[S], xr[S];
         if constexpr (HORIZ) {
-          *reinterpret_cast<int4*>(oa + tid * PO + 2 * k) = make_int4(a0, b0, a1, b1);
+#pragma unroll
+          for (int j = 0; j < S / 4; j++) {
+            const int4 va = *reinterpret_cast<const int4*>(ia + tid * PI + 4 * j);
+            const int4 vr = *reinterpret_cast<const int4*>(ir + tid * PI + 4 * j);
+            xa[4 * j] = va.x; xa[4 * j + 1] = va.y; xa[4 * j + 2] = va.z; xa[4 * j + 3] = va.w;
+            xr[4 * j] = vr.x; xr[4 * j + 1] = vr.y; xr[4 * j + 2] = vr.z; xr[4 * j + 3] = vr.w;
+          }
         } else {
-          oa[(2 * k) * RP + tid] = a0;
-          oa[(2 * k + 1) * RP + tid] = b0;
-          oa[(2 * k + 2) * RP + tid] = a1;
-          oa[(2 * k + 3) * RP + tid] = b1;
+#pragma unroll
+          for (int k = 0; k < S; k++) {
+            xa[k] = ia[k * RP + tid];
+            xr[k] = ir[k * RP + tid];
+          }
         }
+#pragma unroll
+        for (int k = 0; k < S; k += 2) {
+          int32_t a0, b0, a1, b1;
+          unsqueeze_step(cur, xr[k], xa[k], d, a0, b0);
+          unsqueeze_step(xa[k], xr[k + 1], xa[k + 1], d, a1, b1);
+          cur = xa[k + 1];
+          if constexpr (HORIZ) {
+            *reinterpret_cast<int4*>(oa + tid * PO + 2 * k) = make_int4(a0, b0, a1, b1);
+          } else {
+            oa[(2 * k) * RP + tid] = a0;
+            oa[(2 * k + 1) * RP + tid] = b0;
+            oa[(2 * k + 2) * RP + tid] = a1;
+            oa[(2 * k + 3) * RP + tid] = b1;
+          }
+        }
+      } else if (live) {  // the line's last chunk: fewer steps, one by one; an odd line's copied sample behind them
+        for (int k = 0; k < sc; k++) {
+          const int32_t nxt = ia[in_idx(tid, k)], rs = ir[in_idx(tid, k)];
+          int32_t va, vb;
+          unsqueeze_step(cur, rs, nxt, d, va, vb);
+          cur = nxt;
+          oa[out_idx(tid, 2 * k)] = va;
+          oa[out_idx(tid, 2 * k + 1)] = vb;
+        }
+        if (has_tail) oa[out_idx(tid, 2 * sc)] = cur;  // sample 2 w = avg[w] (squeeze.rs:434-437, :468-476)
       }
     }
     lds_barrier();
   }
-  // the rest of the line as a partial chunk: the chain lanes read their own inputs (< S steps), the movers drain
-  const int rest = n_out - 2 * n_chunks * S;  // 1 .. 2 S samples
-  if (chain) {
-    if (live) {
-      int32_t* oa = s_out[n_chunks & 1];
-      const int i0 = n_chunks * S;
-      if (w == 0) {
-        oa[out_idx(tid, 0)] = cur;  // single sample (squeeze.rs:468-476, :672-675)
-      } else {
-        for (int i = i0; i < n_main; i++) {
-          const int32_t nxt = a[(size_t)(i + 1) * avg_ep];
-          int32_t va, vb;
-          unsqueeze_step(cur, r[(size_t)i * res_ep], nxt, d, va, vb);
-          oa[out_idx(tid, 2 * (i - i0))] = va;
-          oa[out_idx(tid, 2 * (i - i0) + 1)] = vb;
-          cur = nxt;
-        }
-        if (!has_tail) {
-          int32_t va, vb;
-          unsqueeze_step(cur, r[(size_t)(w - 1) * res_ep], cur, d, va, vb);
-          oa[out_idx(tid, 2 * (w - 1 - i0))] = va;
-          oa[out_idx(tid, 2 * (w - 1 - i0) + 1)] = vb;
-        } else {
-          oa[out_idx(tid, 2 * (w - i0))] = cur;
-        }
-      }
-    }
-  } else if (storer && n_chunks > 0) {
-    store_chunk(n_chunks - 1, 2 * S);
-  }
-  lds_barrier();
-  if (storer) store_chunk(n_chunks, rest);
+  if (storer && n_chunks > 0) store_chunk(n_chunks - 1, count_of(n_chunks - 1));
 }
 
 void launch_unsqueeze(hipStream_t s, int horizontal, int n_planes, const int32_t* const avg[], size_t avg_stride,
