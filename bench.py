@@ -181,7 +181,7 @@ def time_modular_config(jxl_rs_amd, np, device, size, steps, cores, cpu=True):
                        "frac": round(16.0 * npx / (pal_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
            "rct_alone": {"ms": round(rct_ms, 4), "algorithmic_bytes": int(24.0 * npx),
                          "frac": round(24.0 * npx / (rct_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
-           "pmc_file": "profiles/r02_n_modular_pmc.txt"}
+           "pmc_file": "profiles/r03_m_modular_pmc.txt"}
     if cpu:
         # the oracle's step-by-step chain + RCT on the same planes, one thread per channel (ctypes releases the GIL)
         from concurrent.futures import ThreadPoolExecutor
