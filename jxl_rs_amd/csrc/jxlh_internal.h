@@ -7,6 +7,29 @@
 #include "../../include/jxl_hip.h"
 
 namespace jxlh {
+// 16-byte global accesses with a selectable cache policy (NT = streamed once: `nt` loads / stores)
+typedef int jxlh_i32x4 __attribute__((ext_vector_type(4)));
+typedef float jxlh_f32x4 __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ int4 gload_i4(const int* p) {
+  const jxlh_i32x4* q = reinterpret_cast<const jxlh_i32x4*>(p);
+  const jxlh_i32x4 v = NT ? __builtin_nontemporal_load(q) : *q;
+  return make_int4(v.x, v.y, v.z, v.w);
+}
+template <bool NT>
+__device__ __forceinline__ float4 gload_f4(const float* p) {
+  const jxlh_f32x4* q = reinterpret_cast<const jxlh_f32x4*>(p);
+  const jxlh_f32x4 v = NT ? __builtin_nontemporal_load(q) : *q;
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+template <bool NT>
+__device__ __forceinline__ void gstore_f4(float* p, float4 o) {
+  jxlh_f32x4 v = {o.x, o.y, o.z, o.w};
+  jxlh_f32x4* q = reinterpret_cast<jxlh_f32x4*>(p);
+  if (NT) __builtin_nontemporal_store(v, q);
+  else *q = v;
+}
+
 
 constexpr int kBlockDim = 8;
 constexpr int kGroupDim = 256;

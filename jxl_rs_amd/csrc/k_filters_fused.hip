@@ -72,6 +72,12 @@
 #define JXLH_DENSE_ITEMS0 40
 #endif
 
+#ifndef JXLH_NT_FLOAD
+#define JXLH_NT_FLOAD false
+#endif
+#ifndef JXLH_NT_FSTORE
+#define JXLH_NT_FSTORE false
+#endif
 namespace jxlh {
 namespace {
 
@@ -777,7 +783,7 @@ __global__ __launch_bounds__(fused_threads<E0>(), E0 ? JXLH_FUSED_E0_WPE : JXLH_
         const uint32_t off = in_offset(a, tx0 - kB + bx, ty0 - kB + by);
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-          const float4 v = at_bytes<float4>(a.in[c], off);
+          const float4 v = gload_f4<JXLH_NT_FLOAD>(&at_bytes<float>(a.in[c], off));
           float* d = s_buf + c * kPlane + by * kBW + bx;
           d[0] = v.x;
           d[kBW] = v.y;
@@ -791,7 +797,7 @@ __global__ __launch_bounds__(fused_threads<E0>(), E0 ? JXLH_FUSED_E0_WPE : JXLH_
         const uint32_t off = in_offset(a, tx0 - kB + bx0, ty0 - kB + by);
 #pragma unroll
         for (int c = 0; c < 3; c++)
-          lds_store4(s_buf + c * kPlane + by * kBW + bx0, at_bytes<float4>(a.in[c], off));
+          lds_store4(s_buf + c * kPlane + by * kBW + bx0, gload_f4<JXLH_NT_FLOAD>(&at_bytes<float>(a.in[c], off)));
       }
     } else {
       for (int idx = tid; idx < kStrips * rows; idx += kT) {
@@ -849,7 +855,7 @@ __global__ __launch_bounds__(fused_threads<E0>(), E0 ? JXLH_FUSED_E0_WPE : JXLH_
       };
       auto store = [&](int bx0, int fy, int fx0, int c, float4 o) {
         if (bx0 >= kB && bx0 < kB + kTW && fy < a.y1 && fy < a.h && fx0 < a.w)
-          at_bytes<float4>(a.out[c], 4u * ((uint32_t)fy * a.stride + (uint32_t)fx0)) = o;
+          gstore_f4<JXLH_NT_FSTORE>(&at_bytes<float>(a.out[c], 4u * ((uint32_t)fy * a.stride + (uint32_t)fx0)), o);
       };
 #pragma unroll 1
       for (int t0 = 0; t0 < ns; t0 += kT) {
@@ -925,7 +931,7 @@ __global__ __launch_bounds__(fused_threads<E0>(), E0 ? JXLH_FUSED_E0_WPE : JXLH_
     auto put_global = [&](const Geom& g, int r, int c, float4 o) {
       const int fyr = g.fy + r;
       if (g.live && g.bx0 >= kB && g.bx0 < kB + kTW && fyr < a.y1 && fyr < a.h && g.fx0 < a.w)
-        at_bytes<float4>(a.out[c], 4u * ((uint32_t)fyr * a.stride + (uint32_t)g.fx0)) = o;
+        gstore_f4<JXLH_NT_FSTORE>(&at_bytes<float>(a.out[c], 4u * ((uint32_t)fyr * a.stride + (uint32_t)g.fx0)), o);
     };
     float4 held[last ? 1 : kPasses][2][3];
     // what `held` carries (EPF stages: at most one entry per thread): -1 nothing, otherwise a 4x2 item t (dense

@@ -25,39 +25,73 @@
 // work items); arithmetic is f32 in the reference's operation order (bit-exact vs the FMA
 // build of the oracle).  Output is independent of the order in which work items land in
 // the lists (each varblock is independent).
+#include <algorithm>
+
 #include "k_vardct_common.h"
 
+// Cache policy of K1's two streams (round 3, profiles/r03_n_k1_policy.txt): the coefficient slabs are read exactly once
+// and the pixels are next touched by another kernel after 0.8 GB of other traffic -- `nt` on both keeps them from
+// displacing each other in L2: K1 0.448 -> 0.430 ms, pipelined step 0.824 -> 0.806 ms (alternating runs, one box).
+// (`nt` on the filter kernel's loads / stores measured 10-40 % SLOWER: its halo rows are re-read by the neighbour tile.)
+#ifndef JXLH_NT_COEF
+#define JXLH_NT_COEF true
+#endif
+#ifndef JXLH_NT_K1_STORE
+#define JXLH_NT_K1_STORE true
+#endif
 namespace jxlh {
 namespace {
 
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void k1_scan(const FrameDev f, const WorkLists wl, const int group_row0,
-                                                     int* __restrict__ error_flag, const int* __restrict__ group_list) {
-  __shared__ int s_wave_sum[kWaves];
-  __shared__ int s_count[kNumClasses], s_base[kNumClasses];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int group = group_list ? group_list[blockIdx.x] : group_row0 * f.xgroups + blockIdx.x;
+// One workgroup scans kScanGroups groups (one 256-thread quarter each).  Its duration is the serial head of K1 and is
+// one latency chain -- map bytes -> two block scans -> a returning global atomic per class -> item stores -- so (round 3)
+// every global input is requested up front, the type tables are register immediates, two classes share a 32-bit scan
+// word, and the quarters pool their counts: 256 workgroups' atomics meet on a class counter instead of 1024 (same-
+// address atomics serialise at ~12 ns each: 13 of the former 36 us).
+constexpr int kScanGroups = 4;
+constexpr int kScanThreads = kScanGroups * kThreads;
+__global__ __launch_bounds__(kScanThreads) void k1_scan(const FrameDev f, const WorkLists wl, const int group_row0,
+                                                         int* __restrict__ error_flag,
+                                                         const int* __restrict__ group_list, const int ngroups) {
+  constexpr int kPairs = (kNumClasses + 1) / 2;
+  __shared__ int s_wave_sum[kScanGroups][kWaves];
+  __shared__ uint32_t s_wcls[kScanGroups][kWaves][kPairs];
+  __shared__ int s_count[kScanGroups][kNumClasses], s_base[kScanGroups][kNumClasses];
+  const int sub = threadIdx.x / kThreads, tid = threadIdx.x % kThreads, lane = tid & 63, wave = tid >> 6;
+  const int gi = blockIdx.x * kScanGroups + sub;
+  const bool live = gi < ngroups;  // a dead quarter walks through the barriers with an empty group
+  const int group = !live ? 0 : group_list ? group_list[gi] : group_row0 * f.xgroups + gi;
   const int bx0 = (group % f.xgroups) * kGroupBlocks, by0 = (group / f.xgroups) * kGroupBlocks;
-  const int bw = min(kGroupBlocks, f.xblocks - bx0), bh = min(kGroupBlocks, f.yblocks - by0);
-  if (tid < kNumClasses) s_count[tid] = 0;
+  const int bw = live ? min(kGroupBlocks, f.xblocks - bx0) : 0, bh = live ? min(kGroupBlocks, f.yblocks - by0) : 0;
   // 4 consecutive blocks of the 32x32 raster per thread
-  int sizes[4], types[4], local = 0;
+  int sizes[4], types[4], rq4[4], local = 0;
   const int by = tid >> 3, bx4 = (tid & 7) * 4;
+  const int gby = min(by0 + by, f.yblocks - 1);
+  uint8_t raw4[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const size_t at = (size_t)gby * f.xblocks + min(bx0 + bx4 + i, f.xblocks - 1);
+    raw4[i] = f.transform_map[at];
+    rq4[i] = f.raw_quant[at];
+  }
+  // the four blocks of a thread share one colour tile (8 blocks wide, bx4 % 4 == 0)
+  const int ci = (gby / kColorTileBlocks) * f.cmap_stride + min(bx0 + bx4, f.xblocks - 1) / kColorTileBlocks;
+  const uint32_t cc = (uint32_t)(uint8_t)f.ytox[ci] | (uint32_t)(uint8_t)f.ytob[ci] << 8;
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     const int bx = bx4 + i;
-    uint8_t raw = 0;
-    if (bx < bw && by < bh) raw = f.transform_map[(size_t)(by0 + by) * f.xblocks + bx0 + bx];
+    const uint8_t raw = (bx < bw && by < bh) ? raw4[i] : 0;
     const int type = raw & 127;
     int sz = 0;
     if (raw >= 128) {  // first (top-left) block of a varblock, group.rs:468-473
       if (type < JXLH_NUM_TRANSFORMS) {
-        sz = covered_x(type) * covered_y(type);
+        const int cx = 1 << log2_covered_x_reg(type), cy = 1 << log2_covered_y_reg(type);
+        sz = cx * cy;
         // Error::InvalidBlockSizeForChromaSubsampling (frame/modular/mod.rs:1058-1060)
         if (f.subsampled && sz > 1) atomicExch(error_flag, JXLH_ERR_INVALID_BLOCK_SIZE);
         // Error::HFBlockOutOfBounds (frame/modular/mod.rs:1061-1064): the varblock must end inside its group
         // and inside the frame.  Such an item is dropped: its pixel stores would leave the plane.
-        if (bx + covered_x(type) > bw || by + covered_y(type) > bh) {
+        if (bx + cx > bw || by + cy > bh) {
           atomicExch(error_flag, JXLH_ERR_BLOCK_OUT_OF_BOUNDS);
           sz = 0;
         }
@@ -69,101 +103,104 @@ __global__ __launch_bounds__(kThreads) void k1_scan(const FrameDev f, const Work
     types[i] = type;
     local += sz;
   }
+  // coefficient offsets (in 64-coefficient slots): prefix sum of the covered areas in raster order (group.rs:612)
   int incl = local;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
     const int n = __shfl_up(incl, d, 64);
     if (lane >= d) incl += n;
   }
-  if (lane == 63) s_wave_sum[wave] = incl;
+  if (lane == 63) s_wave_sum[sub][wave] = incl;
+  // per-class rank of every varblock in raster order (stable: neighbouring blocks stay neighbours in the lists ->
+  // contiguous coefficient reads, full-line pixel writes).  Two classes share a 32-bit word, 16 bits each (a group
+  // holds at most 1024 varblocks).
+  int slot[4], cls4[4];
+  uint32_t mine[kPairs], excl[kPairs];
+#pragma unroll
+  for (int w = 0; w < kPairs; w++) mine[w] = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int cls = sizes[i] > 0 ? class_of_type_reg(types[i]) : -1;
+    cls4[i] = cls;
+    slot[i] = 0;
+    const int sh = (cls & 1) * 16;
+#pragma unroll
+    for (int w = 0; w < kPairs; w++) {
+      if ((cls >> 1) == w) {  // cls = -1 matches no pair
+        slot[i] = (int)((mine[w] >> sh) & 0xffffu);
+        mine[w] += 1u << sh;
+      }
+    }
+  }
+#pragma unroll
+  for (int w = 0; w < kPairs; w++) {
+    uint32_t inc = mine[w];
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t n = (uint32_t)__shfl_up((int)inc, d, 64);
+      if (lane >= d) inc += n;
+    }
+    excl[w] = inc - mine[w];
+    if (lane == 63) s_wcls[sub][wave][w] = inc;
+  }
   __syncthreads();
   int off64 = incl - local;
   int group_total = 0;
 #pragma unroll
-  for (int w = 0; w < kWaves; w++) {
-    if (w < wave) off64 += s_wave_sum[w];
-    group_total += s_wave_sum[w];
+  for (int v = 0; v < kWaves; v++) {
+    if (v < wave) off64 += s_wave_sum[sub][v];
+    group_total += s_wave_sum[sub][v];
   }
   // first-block flags that claim more blocks than the group holds (overlapping varblocks; the reference cannot
   // produce such a map, a caller-built one can): the 10-bit coefficient offset of the work items would overflow,
   // K1 would read past the group's slab and the class lists (sized by area) could overflow.  Nothing of such a
   // group is reconstructed.
-  if (group_total > bw * bh) {
-    if (tid == 0) atomicExch(error_flag, JXLH_ERR_BLOCK_OUT_OF_BOUNDS);
+  const bool bad_group = group_total > bw * bh;
+  if (bad_group && tid == 0) atomicExch(error_flag, JXLH_ERR_BLOCK_OUT_OF_BOUNDS);
 #pragma unroll
-    for (int i = 0; i < 4; i++) sizes[i] = 0;
-  }
-  // per-class rank of every varblock in raster order (stable: neighbouring blocks stay
-  // neighbours in the lists -> contiguous coefficient reads, full-line pixel writes)
-  int slot[4];
-  {
-    int mine[kNumClasses];
+  for (int w = 0; w < kPairs; w++) {
+    uint32_t woff = 0, total = 0;
 #pragma unroll
-    for (int c = 0; c < kNumClasses; c++) mine[c] = 0;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const int cls = sizes[i] > 0 ? class_of_type(types[i]) : -1;
-      slot[i] = 0;
-#pragma unroll
-      for (int c = 0; c < kNumClasses; c++) {
-        if (cls == c) {
-          slot[i] = mine[c];
-          mine[c]++;
-        }
-      }
+    for (int v = 0; v < kWaves; v++) {
+      if (v < wave) woff += s_wcls[sub][v][w];
+      total += s_wcls[sub][v][w];
     }
-    __shared__ int s_wcls[kWaves][kNumClasses];
-    int excl[kNumClasses];
-#pragma unroll
-    for (int c = 0; c < kNumClasses; c++) {
-      int inc = mine[c];
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const int n = __shfl_up(inc, d, 64);
-        if (lane >= d) inc += n;
-      }
-      excl[c] = inc - mine[c];
-      if (lane == 63) s_wcls[wave][c] = inc;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < kNumClasses; c++) {
-      int woff = 0, total = 0;
-#pragma unroll
-      for (int w = 0; w < kWaves; w++) {
-        if (w < wave) woff += s_wcls[w][c];
-        total += s_wcls[w][c];
-      }
-      excl[c] += woff;
-      if (tid == c) s_count[c] = total;
-    }
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const int cls = sizes[i] > 0 ? class_of_type(types[i]) : -1;
-#pragma unroll
-      for (int c = 0; c < kNumClasses; c++)
-        if (cls == c) slot[i] += excl[c];
-    }
+    excl[w] += woff;
+    if ((tid >> 1) == w && tid < kNumClasses)
+      s_count[sub][tid] = bad_group ? 0 : (int)((total >> ((tid & 1) * 16)) & 0xffffu);
   }
   __syncthreads();
-  if (tid < kNumClasses) s_base[tid] = s_count[tid] > 0 ? atomicAdd(&wl.counts[(tid) * kCountPitch], s_count[tid]) : 0;
-  if (tid == 0 && f.group_dense) f.group_dense[group] = (s_count[kClsSpecial] | s_count[kClsLarge]) != 0;
+  // one atomic per class for the whole workgroup; the quarters take consecutive ranges in group order
+  if (threadIdx.x < kNumClasses) {
+    const int c = threadIdx.x;
+    int total = 0;
+#pragma unroll
+    for (int q = 0; q < kScanGroups; q++) total += s_count[q][c];
+    int base = total > 0 ? atomicAdd(&wl.counts[c * kCountPitch], total) : 0;
+#pragma unroll
+    for (int q = 0; q < kScanGroups; q++) {
+      s_base[q][c] = base;
+      base += s_count[q][c];
+    }
+  }
+  if (live && tid == 0 && f.group_dense) f.group_dense[group] = (s_count[sub][kClsSpecial] | s_count[sub][kClsLarge]) != 0;
   __syncthreads();
+  if (bad_group) return;
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     if (sizes[i] > 0) {
-      const int gbx = bx0 + bx4 + i, gby = by0 + by;
-      const int rq = f.raw_quant[(size_t)gby * f.xblocks + gbx];
-      const int ci = (gby / kColorTileBlocks) * f.cmap_stride + gbx / kColorTileBlocks;
       WorkItem it;
       it.packed = (uint32_t)(bx4 + i) | ((uint32_t)by << 5) | ((uint32_t)off64 << 10) | ((uint32_t)types[i] << 20);
       it.group = (uint32_t)group;
-      it.sdy = f.inv_global_scale / (float)(uint32_t)rq;
-      it.x_cc = f.base_x + (float)f.ytox[ci] / f.color_factor;
-      it.b_cc = f.base_b + (float)f.ytob[ci] / f.color_factor;
-      it.pad[0] = it.pad[1] = it.pad[2] = 0;
-      const int cls = class_of_type(types[i]);
-      wl.items[cls][s_base[cls] + slot[i]] = it;
+      it.raw_quant = rq4[i];
+      it.cc = cc;
+      const int cls = cls4[i];
+      const int sh = (cls & 1) * 16;
+      int rank = slot[i];
+#pragma unroll
+      for (int w = 0; w < kPairs; w++)
+        if ((cls >> 1) == w) rank += (int)((excl[w] >> sh) & 0xffffu);
+      wl.items[cls][s_base[sub][cls] + rank] = it;
     }
     off64 += sizes[i];
   }
@@ -335,7 +372,7 @@ __device__ __forceinline__ int run_dct_class(const FrameDev& f, const WorkItem* 
           const int b = fl / S::N, k = fl % S::N;
           qv[c][j] = make_int4(0, 0, 0, 0);
           if (b < nb && (!SUB || binfo[b].px_off[c] != f.scrap_off))
-            qv[c][j] = *reinterpret_cast<const int4*>(f.coeffs + binfo[b].coef_off + c * kGroupArea + k);
+            qv[c][j] = gload_i4<JXLH_NT_COEF>(f.coeffs + binfo[b].coef_off + c * kGroupArea + k);
         }
     }
     float dy[S::E];
@@ -360,7 +397,7 @@ __device__ __forceinline__ int run_dct_class(const FrameDev& f, const WorkItem* 
             qq = qv[CH][j];
             tt = tw[CH][j];
           } else {
-            qq = *reinterpret_cast<const int4*>(f.coeffs + bi.coef_off + CH * kGroupArea + k);
+            qq = gload_i4<JXLH_NT_COEF>(f.coeffs + bi.coef_off + CH * kGroupArea + k);
             tt = *reinterpret_cast<const float4*>(table + CH * tsize + k);
           }
           v = dequant4<CH>(f, qq, tt, bi, d4);
@@ -384,8 +421,8 @@ __device__ __forceinline__ int run_dct_class(const FrameDev& f, const WorkItem* 
             if (SUB && binfo[b].px_off[CH] == f.scrap_off) return;
             float* dst = plane + binfo[b].px_off[CH] + lay.xoff(x) + yb * lay.ystep_blk;
             if (lay.tiled) {  // the lane's 8 rows are contiguous: two 16-byte stores
-              *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-              *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+              gstore_f4<JXLH_NT_K1_STORE>(dst, make_float4(v[0], v[1], v[2], v[3]));
+              gstore_f4<JXLH_NT_K1_STORE>(dst + 4, make_float4(v[4], v[5], v[6], v[7]));
             } else {
 #pragma unroll
               for (int i = 0; i < 8; i++) dst[i * lay.ystep8] = v[i];
@@ -422,8 +459,13 @@ constexpr int kTileC = cmax(cmax(cmax(S32x8::kTile, S8x32::kTile), cmax(S32x16::
                             S32x32::kTile);                                       // 2624
 
 // family A: DCT 8x8 -- the dominant transform
+#ifndef JXLH_OCC_DCT8
+#define JXLH_OCC_DCT8
+#define JXLH_OCC_DCT16
+#define JXLH_OCC_DCT32
+#endif
 template <bool SPARSE, bool SUB = false>
-__global__ __launch_bounds__(kThreads) void k1_dct8(const FrameDev f, const WorkLists wl) {
+__global__ __launch_bounds__(kThreads) JXLH_OCC_DCT8 void k1_dct8(const FrameDev f, const WorkLists wl) {
   __shared__ __attribute__((aligned(16))) float s_buf[kWaves * kTileA];
   __shared__ BlockInfo s_binfo[kWaves][S8x8::NB];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -433,7 +475,7 @@ __global__ __launch_bounds__(kThreads) void k1_dct8(const FrameDev f, const Work
 
 // family B: 16x8, 8x16, 16x16
 template <bool SPARSE>
-__global__ __launch_bounds__(kThreads) void k1_dct16(const FrameDev f, const WorkLists wl) {
+__global__ __launch_bounds__(kThreads) JXLH_OCC_DCT16 void k1_dct16(const FrameDev f, const WorkLists wl) {
   __shared__ __attribute__((aligned(16))) float s_buf[kWaves * kTileB];
   __shared__ BlockInfo s_binfo[kWaves][8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -449,7 +491,7 @@ __global__ __launch_bounds__(kThreads) void k1_dct16(const FrameDev f, const Wor
 
 // family C: everything with a 32-point side
 template <bool SPARSE>
-__global__ __launch_bounds__(kThreads) void k1_dct32(const FrameDev f, const WorkLists wl) {
+__global__ __launch_bounds__(kThreads) JXLH_OCC_DCT32 void k1_dct32(const FrameDev f, const WorkLists wl) {
   __shared__ __attribute__((aligned(16))) float s_buf[kWaves * kTileC];
   __shared__ BlockInfo s_binfo[kWaves][8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -465,6 +507,35 @@ __global__ __launch_bounds__(kThreads) void k1_dct32(const FrameDev f, const Wor
                                                s_binfo[wave], rotate_wave(gw, used, nw), nw, lane);
   run_dct_class<S32x32, false, SPARSE>(f, wl.items[kClsDct32x32], wl.counts[(kClsDct32x32) * kCountPitch], 5, buf, s_binfo[wave],
                                        rotate_wave(gw, used, nw), nw, lane);
+}
+
+// families B + C in ONE launch (round 3): both run at three waves per SIMD (145 / 168 VGPRs), so merging them costs no
+// occupancy and removes a kernel boundary -- one fill / drain less in K1's serial sequence -- while the eight class
+// lists spread over one grid (rotated start waves as inside each family)
+template <bool SPARSE>
+__global__ __launch_bounds__(kThreads, 3) void k1_dct16_32(const FrameDev f, const WorkLists wl) {
+  __shared__ __attribute__((aligned(16))) float s_buf[kWaves * kTileC];
+  __shared__ BlockInfo s_binfo[kWaves][8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* buf = s_buf + wave * kTileC;
+  const int gw = blockIdx.x * kWaves + wave, nw = gridDim.x * kWaves;
+  // the long batches (32-point sides) first: the tail of the launch is then made of the short ones
+  int used = run_dct_class<S32x32, false, SPARSE>(f, wl.items[kClsDct32x32], wl.counts[(kClsDct32x32) * kCountPitch], 5, buf,
+                                                  s_binfo[wave], gw, nw, lane);
+  used += run_dct_class<S32x16, false, SPARSE>(f, wl.items[kClsDct32x16], wl.counts[(kClsDct32x16) * kCountPitch], 10, buf,
+                                               s_binfo[wave], rotate_wave(gw, used, nw), nw, lane);
+  used += run_dct_class<S16x32, false, SPARSE>(f, wl.items[kClsDct16x32], wl.counts[(kClsDct16x32) * kCountPitch], 11, buf,
+                                               s_binfo[wave], rotate_wave(gw, used, nw), nw, lane);
+  used += run_dct_class<S32x8, false, SPARSE>(f, wl.items[kClsDct32x8], wl.counts[(kClsDct32x8) * kCountPitch], 8, buf,
+                                              s_binfo[wave], rotate_wave(gw, used, nw), nw, lane);
+  used += run_dct_class<S8x32, false, SPARSE>(f, wl.items[kClsDct8x32], wl.counts[(kClsDct8x32) * kCountPitch], 9, buf, s_binfo[wave],
+                                              rotate_wave(gw, used, nw), nw, lane);
+  used += run_dct_class<S16x16, true, SPARSE>(f, wl.items[kClsDct16x16], wl.counts[(kClsDct16x16) * kCountPitch], 4, buf, s_binfo[wave],
+                                              rotate_wave(gw, used, nw), nw, lane);
+  used += run_dct_class<S16x8, true, SPARSE>(f, wl.items[kClsDct16x8], wl.counts[(kClsDct16x8) * kCountPitch], 6, buf,
+                                             s_binfo[wave], rotate_wave(gw, used, nw), nw, lane);
+  run_dct_class<S8x16, true, SPARSE>(f, wl.items[kClsDct8x16], wl.counts[(kClsDct8x16) * kCountPitch], 7, buf, s_binfo[wave],
+                                     rotate_wave(gw, used, nw), nw, lane);
 }
 
 // family D: the nine 8x8 special transform types (IDENTITY, DCT2X2, DCT4X4, DCT4X8, DCT8X4, AFV0-3).
@@ -556,7 +627,7 @@ __global__ __launch_bounds__(kSpecThreads) void k1_special(const FrameDev f, con
           b_sdy[j] = bp->sdy;
           b_xcc[j] = bp->x_cc;
           b_bcc[j] = bp->b_cc;
-          qv[j] = *reinterpret_cast<const int4*>(f.coeffs + bp->coef_off + CH * kGroupArea + k0);
+          qv[j] = gload_i4<JXLH_NT_COEF>(f.coeffs + bp->coef_off + CH * kGroupArea + k0);
         }
 #pragma unroll
         for (int j = 0; j < kSpecIters; j++) {
@@ -672,7 +743,8 @@ void launch_vardct_groups(hipStream_t s, const FrameDev& f, int group_row0, int 
   }
   uint32_t* large_units = reinterpret_cast<uint32_t*>(p);  // behind the last class list
   (void)hipMemsetAsync(wl.counts, 0, kCountBytes, s);  // [kNumClasses] = slab units of the large class
-  hipLaunchKernelGGL(k1_scan, dim3(ngroups), dim3(kThreads), 0, s, f, wl, group_row0, error_flag, group_list);
+  hipLaunchKernelGGL(k1_scan, dim3((ngroups + kScanGroups - 1) / kScanGroups), dim3(kScanThreads), 0, s, f, wl, group_row0,
+                     error_flag, group_list, ngroups);
   // grids: enough waves to fill the chip; kernels stride over their lists (counts are device-side)
   const int nblk = ngroups * kGroupBlocks * kGroupBlocks;
   auto grid_for = [](long work_items, int items_per_wg, int cap) {
@@ -693,6 +765,18 @@ void launch_vardct_groups(hipStream_t s, const FrameDev& f, int group_row0, int 
     if (sparse) hipLaunchKernelGGL((k1_dct8<true, true>), g8, dim3(kThreads), 0, s, f, wl);
     else hipLaunchKernelGGL((k1_dct8<false, true>), g8, dim3(kThreads), 0, s, f, wl);
     // the other DCT classes are empty in a sub-sampled frame (k1_scan reports larger varblocks as an error)
+#ifndef JXLH_K1_MERGED
+#define JXLH_K1_MERGED 1
+#endif
+  } else if (JXLH_K1_MERGED) {
+    const dim3 g1632(std::min(4096u, g16.x + g32.x));
+    if (sparse) {
+      hipLaunchKernelGGL(k1_dct8<true>, g8, dim3(kThreads), 0, s, f, wl);
+      hipLaunchKernelGGL(k1_dct16_32<true>, g1632, dim3(kThreads), 0, s, f, wl);
+    } else {
+      hipLaunchKernelGGL(k1_dct8<false>, g8, dim3(kThreads), 0, s, f, wl);
+      hipLaunchKernelGGL(k1_dct16_32<false>, g1632, dim3(kThreads), 0, s, f, wl);
+    }
   } else if (sparse) {
     hipLaunchKernelGGL(k1_dct8<true>, g8, dim3(kThreads), 0, s, f, wl);
     hipLaunchKernelGGL(k1_dct16<true>, g16, dim3(kThreads), 0, s, f, wl);

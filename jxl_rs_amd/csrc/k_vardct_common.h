@@ -21,22 +21,45 @@ __host__ __device__ constexpr int class_of_type(int t) {
                            kClsLarge,   kClsLarge,   kClsLarge,   kClsLarge,    kClsLarge,    kClsLarge};
   return lut[t];
 }
+// The same tables as 4-bit fields of two 64-bit immediates: a lane that looks a table up by a type it has just
+// loaded gets shifts instead of a second, dependent memory access (k1_scan's duration is one latency chain).
+template <class F>
+constexpr uint64_t pack_lut4(F f, int t0) {
+  uint64_t v = 0;
+  for (int t = t0; t < t0 + 16 && t < JXLH_NUM_TRANSFORMS; t++) v |= (uint64_t)f(t) << (4 * (t - t0));
+  return v;
+}
+constexpr int clog2(int v) { return v <= 1 ? 0 : 1 + clog2(v >> 1); }
+constexpr int log2_covered_x(int t) { return clog2(covered_x(t)); }
+constexpr int log2_covered_y(int t) { return clog2(covered_y(t)); }
+__device__ __forceinline__ int lut4(uint64_t lo, uint64_t hi, int t) {
+  return (int)(((t < 16 ? lo : hi) >> (4 * (t & 15))) & 15u);
+}
+__device__ __forceinline__ int class_of_type_reg(int t) {
+  return lut4(pack_lut4(class_of_type, 0), pack_lut4(class_of_type, 16), t);
+}
+__device__ __forceinline__ int log2_covered_x_reg(int t) {
+  return lut4(pack_lut4(log2_covered_x, 0), pack_lut4(log2_covered_x, 16), t);
+}
+__device__ __forceinline__ int log2_covered_y_reg(int t) {
+  return lut4(pack_lut4(log2_covered_y, 0), pack_lut4(log2_covered_y, 16), t);
+}
 // worst-case number of varblocks of a class per 8x8 block of frame area, as a divisor
 __host__ __device__ constexpr int class_min_area(int c) {
   constexpr int lut[kNumClasses] = {1, 2, 2, 4, 4, 4, 8, 8, 16, 1, 32};
   return lut[c];
 }
 
-// 32-byte work item
+// 16-byte work item: what k1_scan knows about a varblock, raw -- the class kernels derive the dequantisation scale and the
+// colour-correlation factors when they decode an item (a few divisions on a handful of lanes per batch), and the
+// scan, whose duration is the serial head of K1, writes half the bytes of round 2's 32-byte form.
 struct __attribute__((aligned(16))) WorkItem {
   uint32_t packed;  // bx | by << 5 | off64 << 10 | type << 20   (bx, by in blocks inside the group)
   uint32_t group;
-  float sdy;        // inv_global_scale / raw_quant          (group.rs:153)
-  float x_cc;       // base_x + ytox / color_factor          (color_correlation_map.rs:76-78)
-  float b_cc;
-  uint32_t pad[3];
+  int32_t raw_quant;  // HfMetadata::raw_quant_map at the varblock's first block
+  uint32_t cc;        // (uint8_t)ytox | (uint8_t)ytob << 8 of the block's colour tile
 };
-static_assert(sizeof(WorkItem) == 32, "work item layout");
+static_assert(sizeof(WorkItem) == 16, "work item layout");
 
 struct BlockInfo {
   int coef_off;  // offset of the varblock inside the frame's coefficient store (channel X)
@@ -84,9 +107,9 @@ __device__ __forceinline__ void decode_item(const FrameDev& f, const WorkItem& i
       bi->lf_off[c] = (lfby + ((gby - lfby) >> vs)) * f.xblocks + lfbx + ((gbx - lfbx) >> hs);
     }
   }
-  bi->sdy = it.sdy;
-  bi->x_cc = it.x_cc;
-  bi->b_cc = it.b_cc;
+  bi->sdy = f.inv_global_scale / (float)(uint32_t)it.raw_quant;               // group.rs:153
+  bi->x_cc = f.base_x + (float)(int8_t)(it.cc & 0xffu) / f.color_factor;        // color_correlation_map.rs:76-78
+  bi->b_cc = f.base_b + (float)(int8_t)((it.cc >> 8) & 0xffu) / f.color_factor;
 }
 
 // group.rs:85-96
