@@ -454,18 +454,12 @@ using S32x16 = Shape<32, 16>;
 using S16x32 = Shape<16, 32>;
 
 constexpr int kTileA = S8x8::kTile;                                               // 832 words
-constexpr int kTileB = cmax(cmax(S16x8::kTile, S8x16::kTile), S16x16::kTile);     // 1600
 constexpr int kTileC = cmax(cmax(cmax(S32x8::kTile, S8x32::kTile), cmax(S32x16::kTile, S16x32::kTile)),
                             S32x32::kTile);                                       // 2624
 
 // family A: DCT 8x8 -- the dominant transform
-#ifndef JXLH_OCC_DCT8
-#define JXLH_OCC_DCT8
-#define JXLH_OCC_DCT16
-#define JXLH_OCC_DCT32
-#endif
 template <bool SPARSE, bool SUB = false>
-__global__ __launch_bounds__(kThreads) JXLH_OCC_DCT8 void k1_dct8(const FrameDev f, const WorkLists wl) {
+__global__ __launch_bounds__(kThreads) void k1_dct8(const FrameDev f, const WorkLists wl) {
   __shared__ __attribute__((aligned(16))) float s_buf[kWaves * kTileA];
   __shared__ BlockInfo s_binfo[kWaves][S8x8::NB];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -473,45 +467,12 @@ __global__ __launch_bounds__(kThreads) JXLH_OCC_DCT8 void k1_dct8(const FrameDev
                             blockIdx.x * kWaves + wave, gridDim.x * kWaves, lane);
 }
 
-// family B: 16x8, 8x16, 16x16
-template <bool SPARSE>
-__global__ __launch_bounds__(kThreads) JXLH_OCC_DCT16 void k1_dct16(const FrameDev f, const WorkLists wl) {
-  __shared__ __attribute__((aligned(16))) float s_buf[kWaves * kTileB];
-  __shared__ BlockInfo s_binfo[kWaves][8];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float* buf = s_buf + wave * kTileB;
-  const int gw = blockIdx.x * kWaves + wave, nw = gridDim.x * kWaves;
-  int used = run_dct_class<S16x8, true, SPARSE>(f, wl.items[kClsDct16x8], wl.counts[(kClsDct16x8) * kCountPitch], 6, buf,
-                                                s_binfo[wave], gw, nw, lane);
-  used += run_dct_class<S8x16, true, SPARSE>(f, wl.items[kClsDct8x16], wl.counts[(kClsDct8x16) * kCountPitch], 7, buf, s_binfo[wave],
-                                             rotate_wave(gw, used, nw), nw, lane);
-  run_dct_class<S16x16, true, SPARSE>(f, wl.items[kClsDct16x16], wl.counts[(kClsDct16x16) * kCountPitch], 4, buf, s_binfo[wave],
-                                      rotate_wave(gw, used, nw), nw, lane);
-}
-
-// family C: everything with a 32-point side
-template <bool SPARSE>
-__global__ __launch_bounds__(kThreads) JXLH_OCC_DCT32 void k1_dct32(const FrameDev f, const WorkLists wl) {
-  __shared__ __attribute__((aligned(16))) float s_buf[kWaves * kTileC];
-  __shared__ BlockInfo s_binfo[kWaves][8];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float* buf = s_buf + wave * kTileC;
-  const int gw = blockIdx.x * kWaves + wave, nw = gridDim.x * kWaves;
-  int used = run_dct_class<S32x8, false, SPARSE>(f, wl.items[kClsDct32x8], wl.counts[(kClsDct32x8) * kCountPitch], 8, buf,
-                                                 s_binfo[wave], gw, nw, lane);
-  used += run_dct_class<S8x32, false, SPARSE>(f, wl.items[kClsDct8x32], wl.counts[(kClsDct8x32) * kCountPitch], 9, buf, s_binfo[wave],
-                                              rotate_wave(gw, used, nw), nw, lane);
-  used += run_dct_class<S32x16, false, SPARSE>(f, wl.items[kClsDct32x16], wl.counts[(kClsDct32x16) * kCountPitch], 10, buf,
-                                               s_binfo[wave], rotate_wave(gw, used, nw), nw, lane);
-  used += run_dct_class<S16x32, false, SPARSE>(f, wl.items[kClsDct16x32], wl.counts[(kClsDct16x32) * kCountPitch], 11, buf,
-                                               s_binfo[wave], rotate_wave(gw, used, nw), nw, lane);
-  run_dct_class<S32x32, false, SPARSE>(f, wl.items[kClsDct32x32], wl.counts[(kClsDct32x32) * kCountPitch], 5, buf, s_binfo[wave],
-                                       rotate_wave(gw, used, nw), nw, lane);
-}
-
-// families B + C in ONE launch (round 3): both run at three waves per SIMD (145 / 168 VGPRs), so merging them costs no
-// occupancy and removes a kernel boundary -- one fill / drain less in K1's serial sequence -- while the eight class
-// lists spread over one grid (rotated start waves as inside each family)
+// families B (16x8, 8x16, 16x16) + C (everything with a 32-point side) in ONE launch (round 3): as two kernels both
+// ran at three waves per SIMD (145 / 168 VGPRs), so merging them costs no occupancy and removes a kernel boundary -- one
+// fill / drain less in K1's serial sequence -- while the eight class lists spread over one grid (rotated start waves).
+// Occupancy is not what limits these classes' batches anyway: at two waves per SIMD the 32-point family runs 24 %
+// slower, the 16-point one 8 %, and DCT8 is flat between 3 and 5 (profiles/r03_n_k1.txt); requesting the LF samples
+// of a batch ahead of the coefficients (through an LDS scratch) measured flat as well
 template <bool SPARSE>
 __global__ __launch_bounds__(kThreads, 3) void k1_dct16_32(const FrameDev f, const WorkLists wl) {
   __shared__ __attribute__((aligned(16))) float s_buf[kWaves * kTileC];
@@ -765,10 +726,7 @@ void launch_vardct_groups(hipStream_t s, const FrameDev& f, int group_row0, int 
     if (sparse) hipLaunchKernelGGL((k1_dct8<true, true>), g8, dim3(kThreads), 0, s, f, wl);
     else hipLaunchKernelGGL((k1_dct8<false, true>), g8, dim3(kThreads), 0, s, f, wl);
     // the other DCT classes are empty in a sub-sampled frame (k1_scan reports larger varblocks as an error)
-#ifndef JXLH_K1_MERGED
-#define JXLH_K1_MERGED 1
-#endif
-  } else if (JXLH_K1_MERGED) {
+  } else {
     const dim3 g1632(std::min(4096u, g16.x + g32.x));
     if (sparse) {
       hipLaunchKernelGGL(k1_dct8<true>, g8, dim3(kThreads), 0, s, f, wl);
@@ -777,14 +735,6 @@ void launch_vardct_groups(hipStream_t s, const FrameDev& f, int group_row0, int 
       hipLaunchKernelGGL(k1_dct8<false>, g8, dim3(kThreads), 0, s, f, wl);
       hipLaunchKernelGGL(k1_dct16_32<false>, g1632, dim3(kThreads), 0, s, f, wl);
     }
-  } else if (sparse) {
-    hipLaunchKernelGGL(k1_dct8<true>, g8, dim3(kThreads), 0, s, f, wl);
-    hipLaunchKernelGGL(k1_dct16<true>, g16, dim3(kThreads), 0, s, f, wl);
-    hipLaunchKernelGGL(k1_dct32<true>, g32, dim3(kThreads), 0, s, f, wl);
-  } else {
-    hipLaunchKernelGGL(k1_dct8<false>, g8, dim3(kThreads), 0, s, f, wl);
-    hipLaunchKernelGGL(k1_dct16<false>, g16, dim3(kThreads), 0, s, f, wl);
-    hipLaunchKernelGGL(k1_dct32<false>, g32, dim3(kThreads), 0, s, f, wl);
   }
   // an empty special list (the d1 mix) pays for every launched workgroup: the grid follows the list's worst case
   if (has_special)
