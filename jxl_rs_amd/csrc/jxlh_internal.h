@@ -103,11 +103,15 @@ struct FrameDev {
   float epf_sm[3], epf_bsm[3];    // per pass: sigma_scale*1.65 and *border_sad_mul
   int epf_iters;
   int gab;
-  // Layout of planes[] as written by K1: 0 = raster (row pitch plane_stride); 1 = 8x8-tiled,
-  // column-major inside the block: pixel (x, y) of block (bx, by) lives at
-  // (by*xblocks + bx)*64 + (x&7)*8 + (y&7).  Used between K1 and the fused filter kernel: every
-  // varblock then completes whole 256-byte chunks instead of sharing 128-byte lines with its
-  // neighbours, and an IDCT lane (which owns a pixel column) stores 32 contiguous bytes.
+  // Layout of planes[] as written by K1: 0 = raster (row pitch plane_stride); 1 = 8x8-tiled: block (bx, by) is the
+  // 256-byte chunk (by*xblocks + bx)*64, and inside it pixel (x, y) lives at (y & 4)*8 + (x & 7)*4 + (y & 3) -- the
+  // rows 0-3 of the eight columns (128 bytes), then the rows 4-7.  Used between K1 and the fused filter kernel: a
+  // varblock completes whole 256-byte chunks instead of sharing 128-byte lines with its neighbours; an IDCT lane
+  // (which owns a pixel column) stores two 16-byte pieces and the eight lanes of a block fill a 128-byte line per
+  // store instruction; the filter's staging lane fetches 4 rows of a column (16 bytes), and both of its halos are
+  // whole sectors: the 4 rows above / below a tile are one 128-byte half of each block, the 4 columns beside it 64
+  // bytes of each half.  (Round 2's x*8 + y order made the row halo half of every 32-byte sector it touched and
+  // K1's lanes write 32-byte pieces: K1 -5 %, filters -3 %, pipelined step -3.6 % with this order.)
   int tiled;
   // Chroma-subsampled frames (JPEG recompressions): channel c has (size >> shift) samples.  K1 writes such
   // a channel at the down-sampled block positions of its plane (same stride / tiling as a full plane);
@@ -128,13 +132,16 @@ constexpr int kLfGroupBlocks = 256;  // an LF group is 2048 x 2048 pixels
 constexpr int kSlotTable = 1025;  // 1024 slots of 64 coefficients per (group, channel) + end marker
 
 // pixel (x, y) relative to a varblock's top-left pixel, for either layout:
-//   addr = base + xoff(x) + (y >> 3) * ystep_blk + (y & 7) * ystep8
+//   addr = base + at(x, y)
 struct PixLayout {
-  int ystep8;     // raster: plane_stride      tiled: 1
+  int ystep8;     // raster: plane_stride      tiled: unused (see at())
   int ystep_blk;  // raster: 8 * plane_stride  tiled: xblocks * 64
   int tiled;
-  __host__ __device__ int xoff(int x) const { return tiled ? ((x >> 3) * 64 + (x & 7) * 8) : x; }
-  __host__ __device__ int at(int x, int y) const { return xoff(x) + (y >> 3) * ystep_blk + (y & 7) * ystep8; }
+  // tiled: inside a block the rows 0-3 of all eight columns, then the rows 4-7: (y & 4) * 8 + (x & 7) * 4 + (y & 3)
+  __host__ __device__ int xoff(int x) const { return tiled ? ((x >> 3) * 64 + (x & 7) * 4) : x; }
+  __host__ __device__ int at(int x, int y) const {
+    return xoff(x) + (y >> 3) * ystep_blk + (tiled ? (y & 4) * 8 + (y & 3) : (y & 7) * ystep8);
+  }
 };
 __host__ __device__ inline PixLayout pix_layout(const FrameDev& f) {
   PixLayout l;

@@ -110,7 +110,8 @@ struct FusedArgs {
 // pointer the access becomes "SGPR base + 32-bit VGPR offset" instead of a 64-bit address pair
 // per lane and channel (the kernel is register-bound at 80 VGPRs).
 __device__ __forceinline__ uint32_t in_offset(const FusedArgs& a, int fx, int fy) {
-  return 4u * (a.tiled_in ? ((uint32_t)((fy >> 3) * a.xblocks + (fx >> 3)) * 64u + (uint32_t)((fx & 7) * 8 + (fy & 7)))
+  return 4u * (a.tiled_in ? ((uint32_t)((fy >> 3) * a.xblocks + (fx >> 3)) * 64u +
+                             (uint32_t)((fy & 4) * 8 + (fx & 7) * 4 + (fy & 3)))
                           : ((uint32_t)fy * a.stride + (uint32_t)fx));
 }
 template <class T>
@@ -765,9 +766,10 @@ __global__ __launch_bounds__(fused_threads<E0>(), E0 ? JXLH_FUSED_E0_WPE : JXLH_
     constexpr int m = kBorder;
     constexpr int rows = kTH + 2 * m;
     if (!edge && a.tiled_in) {
-      // interior tile, 8x8-tiled column-major input: a lane fetches 4 rows of one pixel column
-      // (16 contiguous bytes); a wave covers 32 columns x 8 rows = four whole 256-byte blocks
-      // per channel, and scatters into the raster LDS tile with conflict-free ds_write_b32.
+      // interior tile, 8x8-tiled input (FrameDev::tiled): a lane fetches 4 rows of one pixel column
+      // (16 contiguous bytes); the 32 lanes of a half-wave read the same 4-row half of four blocks
+      // (4 x 128 contiguous bytes), the two halves together four whole 256-byte blocks per channel;
+      // the values scatter into the raster LDS tile with conflict-free ds_write_b32.
       constexpr int yg0 = (kB - m) / 4, ygn = (rows + 2 * ((kB - m) % 4) + 3) / 4;  // 4-row groups touched
       constexpr int items = kBW * ((ygn + 1) / 2) * 2;
 #pragma unroll

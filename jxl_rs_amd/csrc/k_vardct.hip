@@ -420,9 +420,9 @@ __device__ __forceinline__ int run_dct_class(const FrameDev& f, const WorkItem* 
           [&](int b, int x, int yb, const float(&v)[8]) {
             if (SUB && binfo[b].px_off[CH] == f.scrap_off) return;
             float* dst = plane + binfo[b].px_off[CH] + lay.xoff(x) + yb * lay.ystep_blk;
-            if (lay.tiled) {  // the lane's 8 rows are contiguous: two 16-byte stores
+            if (lay.tiled) {  // rows 0-3 and rows 4-7 of the lane's column: two 16-byte stores, 128 bytes apart
               gstore_f4<JXLH_NT_K1_STORE>(dst, make_float4(v[0], v[1], v[2], v[3]));
-              gstore_f4<JXLH_NT_K1_STORE>(dst + 4, make_float4(v[4], v[5], v[6], v[7]));
+              gstore_f4<JXLH_NT_K1_STORE>(dst + 32, make_float4(v[4], v[5], v[6], v[7]));
             } else {
 #pragma unroll
               for (int i = 0; i < 8; i++) dst[i * lay.ystep8] = v[i];
@@ -649,8 +649,8 @@ __global__ __launch_bounds__(kSpecThreads) void k1_special(const FrameDev f, con
           const int b = min(j * 4 + (lane >> 4), nb - 1), p = k0;
           const int px = binfo[b].px_off[ch];
           const float* r = tile + (ch * kSpecBlk + b) * kSpecPitch;
-          if (f.tiled) {  // memory order inside the block is x*8 + y
-            const int x = p / 8, y0 = p % 8;
+          if (f.tiled) {  // memory order inside the block is (y & 4) * 8 + x * 4 + (y & 3)
+            const int x = (p & 31) >> 2, y0 = (p >> 5) * 4;
             const float* src = r + y0 * 8 + x;
             ov[j] = make_float4(src[0], src[8], src[16], src[24]);
             oo[j] = px + p;
