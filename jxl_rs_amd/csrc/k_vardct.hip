@@ -715,7 +715,7 @@ void launch_vardct_groups(hipStream_t s, const FrameDev& f, int group_row0, int 
   // one stream: forking the class kernels onto side streams measured no gain on the d1 mix (event
   // overhead ~ tail savings) and extra streams compete for the runtime's few hardware queues
   const bool sparse = f.sp_sorted != nullptr;
-  if (sparse && dense_coeffs) {
+  if (sparse && dense_coeffs && (has_special || has_large)) {
     // groups that hold special / large varblocks (flagged by k1_scan) still get a dense slab
     launch_expand_sorted(s, dense_coeffs, f.sp_sorted, f.sp_slot_start, f.group_dense, f.xgroups * f.ygroups);
   }
