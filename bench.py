@@ -564,7 +564,7 @@ def main():
             roofline["copy_ceiling_GBs"] = round(big, 1)
             roofline["copy_ceiling"] = {"frame_sized": {"bytes_each_way": 3 * npx * 4, "GBs": round(big, 1)},
                                         "infinity_cache_resident": {"bytes_each_way": 64 << 20, "GBs": round(small, 1)},
-                                        "kernel": "float4 grid-stride copy (jxlh_probe_copy_bandwidth)"}
+                                        "kernel": "float4 grid-stride copy, the better of plain and nt accesses (jxlh_probe_copy_bandwidth)"}
             roofline["frac_of_copy_ceiling"] = round(roofline["achieved"] / big, 4)
 
     # ---- CPU baseline: the oracle (C port of the reference path) on the same frame size

@@ -26,8 +26,9 @@ jxlh_status jxlh_kernel_timing_get(jxlh_ctx* ctx, int32_t i, const char** name, 
                                    int32_t* launches);
 jxlh_status jxlh_kernel_timing_reset(jxlh_ctx* ctx);
 /* Device-to-device copy ceiling, measured: a float4 copy of `bytes` (src and dst buffers allocated for the call)
- * repeated `reps` times on the context's stream; *gb_per_s = (bytes read + bytes written) / time.  The yardstick
- * SURVEY.md 8(d) asks for next to the 8 TB/s spec peak. */
+ * repeated `reps` times on the context's stream, once with plain and once with non-temporal accesses;
+ * *gb_per_s = (bytes read + bytes written) / time of the faster policy.  The yardstick SURVEY.md 8(d) asks for next
+ * to the 8 TB/s spec peak. */
 jxlh_status jxlh_probe_copy_bandwidth(jxlh_ctx* ctx, size_t bytes, int32_t reps, float* gb_per_s);
 
 
