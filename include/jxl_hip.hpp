@@ -33,7 +33,7 @@ class Error : public std::runtime_error {  // -> Error::Gpu(code) on the Rust si
 
 class Context {
  public:
-  explicit Context(int device = 0, int n_slots = 1) {
+  explicit Context(int device = 0, int n_slots = 1) : n_slots_(n_slots) {
     const jxlh_status st = jxlh_ctx_create(device, n_slots, &c_);
     if (st != JXLH_OK) throw Error(st, "jxlh_ctx_create", "");
   }
@@ -41,6 +41,7 @@ class Context {
   Context(const Context&) = delete;
   Context& operator=(const Context&) = delete;
   jxlh_ctx* raw() const { return c_; }
+  int n_slots() const { return n_slots_; }
   void check(jxlh_status st, const char* where) const {
     if (st != JXLH_OK) throw Error(st, where, jxlh_last_error(c_));
   }
@@ -54,6 +55,7 @@ class Context {
 
  private:
   jxlh_ctx* c_ = nullptr;
+  int n_slots_ = 1;
 };
 
 // One VarDCT frame on the device: the order of calls is the order of Frame's sections in the codestream.

@@ -1,0 +1,259 @@
+// The C++ mirror of the reference's stage traits + RenderPipelineBuilder (include/jxl_hip_pipeline.hpp) from compiled
+// code.  Built and run by tests/test_cpp_host.py.
+//   pipeline_builder host           the lowering of stage lists onto jxlh_frame_params / jxlh_output_desc and the
+//                                   rejection of lists outside the device path -- pure host logic, no GPU
+//   pipeline_builder gpu W H ITERS  a frame assembled exactly as Frame::build_render_pipeline assembles it
+//                                   (frame/render.rs:526-790), decoded through GpuRenderPipeline in two passes
+//                                   (incomplete groups, then complete + mark_group_to_rerender), against the oracle
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <string>
+
+#include "jxl_hip_pipeline.hpp"
+#include "synth_frame.hpp"
+
+using namespace jxlh;
+
+namespace {
+int g_failed = 0;
+void expect(bool ok, const char* what) {
+  if (!ok) {
+    g_failed++;
+    fprintf(stderr, "FAILED: %s\n", what);
+  }
+}
+// the status build() / lower() fails with, or JXLH_OK
+jxlh_status status_of(const std::function<void()>& f, std::string* msg = nullptr) {
+  try {
+    f();
+  } catch (const Error& e) {
+    if (msg) *msg = e.what();
+    return e.status;
+  }
+  return JXLH_OK;
+}
+
+// RestorationFilter defaults as jxlh_default_frame_params holds them
+struct Rf {
+  float gab_w1[3], gab_w2[3], pass0, pass2, border_sad_mul;
+  std::array<float, 3> channel_scale;
+};
+Rf rf_of(const jxlh_frame_params& p) {
+  Rf r;
+  for (int c = 0; c < 3; c++) {
+    r.gab_w1[c] = p.gab_w1[c];
+    r.gab_w2[c] = p.gab_w2[c];
+    r.channel_scale[c] = p.epf_channel_scale[c];
+  }
+  r.pass0 = p.epf_pass0_sigma_scale;
+  r.pass2 = p.epf_pass2_sigma_scale;
+  r.border_sad_mul = p.epf_border_sad_mul;
+  return r;
+}
+
+// the filter part of Frame::build_render_pipeline (frame/render.rs:578-622)
+RenderPipelineBuilder add_filters(RenderPipelineBuilder b, const Rf& rf, bool gab, int epf_iters) {
+  if (gab) {
+    b = std::move(b)
+            .add_inout_stage(GaborishStage{0, rf.gab_w1[0], rf.gab_w2[0]})
+            .add_inout_stage(GaborishStage{1, rf.gab_w1[1], rf.gab_w2[1]})
+            .add_inout_stage(GaborishStage{2, rf.gab_w1[2], rf.gab_w2[2]});
+  }
+  if (epf_iters >= 3) b = std::move(b).add_inout_stage(Epf0Stage{rf.pass0, rf.border_sad_mul, rf.channel_scale});
+  if (epf_iters >= 1) b = std::move(b).add_inout_stage(Epf1Stage{1.0f, rf.border_sad_mul, rf.channel_scale});
+  if (epf_iters >= 2) b = std::move(b).add_inout_stage(Epf2Stage{rf.pass2, rf.border_sad_mul, rf.channel_scale});
+  return b;
+}
+
+jxlh_xyb_params some_xyb() {
+  jxlh_xyb_params x{};
+  for (int i = 0; i < 9; i++) x.opsin_inverse_matrix[i] = (i % 4 == 0) ? 1.0f : 0.01f * (float)i;
+  for (int i = 0; i < 3; i++) {
+    x.bias_cbrt[i] = -0.15f;
+    x.scaled_bias[i] = -0.0038f;
+  }
+  x.intensity_scale = 1.0f;
+  return x;
+}
+
+int host_checks() {
+  const jxlh_frame_params base = VarDctFrame::default_params(1000, 700);
+  const Rf rf = rf_of(base);
+  // ---- 1. the common VarDCT list: Gaborish x3, EPF1, EPF2, XYB, sRGB, U8 x3, save RGBA
+  {
+    auto b = add_filters(RenderPipelineBuilder(3, {1000, 700}, 0, 8, base), rf, true, 2);
+    b = std::move(b)
+            .add_inplace_stage(XybStage{0, some_xyb()})
+            .add_inplace_stage(FromLinearStage{0, JXLH_TF_SRGB, 0.0f, {0.f, 0.f, 0.f}})
+            .add_inout_stage(ConvertF32ToU8Stage{0, 8})
+            .add_inout_stage(ConvertF32ToU8Stage{1, 8})
+            .add_inout_stage(ConvertF32ToU8Stage{2, 8})
+            .add_save_stage({0, 1, 2}, 0, 4, 8);
+    const LoweredPipeline lp = b.lower();
+    expect(lp.frame.gab == 1 && lp.frame.epf_iters == 2 && lp.frame.upsampling == 1 && lp.frame.noise == 0, "list 1: stage-derived fields");
+    expect(lp.frame.gab_w1[1] == rf.gab_w1[1] && lp.frame.epf_pass2_sigma_scale == rf.pass2, "list 1: weights carried over");
+    // jxl/src/render/mod.rs:28-36: Gaborish 1 + EPF1 2 + EPF2 1
+    expect(lp.input_border.x == 4 && lp.input_border.y == 4, "list 1: accumulated border is 4");
+    expect(lp.has_output && lp.output.color == JXLH_COLOR_XYB && lp.output.transfer == JXLH_TF_SRGB && lp.output.bits == 8 &&
+               lp.output.channels == 4,
+           "list 1: output descriptor");
+    expect(lp.stages.size() == 11 && lp.stages[0] == "Gaborish filter for channel 0", "list 1: Display strings");
+  }
+  // ---- 2. epf_iters = 3, planar f32 save: border 1 + 3 + 2 + 1
+  {
+    auto b = add_filters(RenderPipelineBuilder(3, {1000, 700}, 0, 8, base), rf, true, 3);
+    const LoweredPipeline lp = std::move(b).add_save_stage({0, 1, 2}, 0, 3, 32).lower();
+    expect(lp.frame.epf_iters == 3 && lp.input_border.x == 7 && !lp.has_output, "list 2: three EPF passes");
+  }
+  // ---- 3. a JPEG recompression: 4:2:0 chroma, no filters, YCbCr, U8, RGB
+  {
+    auto b = RenderPipelineBuilder(3, {1000, 700}, 0, 8, base)
+                 .add_inout_stage(HorizontalChromaUpsample{0})
+                 .add_inout_stage(VerticalChromaUpsample{0})
+                 .add_inout_stage(HorizontalChromaUpsample{2})
+                 .add_inout_stage(VerticalChromaUpsample{2})
+                 .add_inplace_stage(YcbcrToRgbStage{0})
+                 .add_inout_stage(ConvertF32ToU8Stage{0, 8})
+                 .add_inout_stage(ConvertF32ToU8Stage{1, 8})
+                 .add_inout_stage(ConvertF32ToU8Stage{2, 8})
+                 .add_save_stage({0, 1, 2}, 0, 3, 8);
+    const LoweredPipeline lp = b.lower();
+    expect(lp.frame.hshift[0] == 1 && lp.frame.vshift[0] == 1 && lp.frame.hshift[1] == 0 && lp.frame.hshift[2] == 1 &&
+               lp.frame.gab == 0 && lp.frame.epf_iters == 0,
+           "list 3: chroma shifts");
+    expect(lp.output.color == JXLH_COLOR_YCBCR && lp.output.channels == 3, "list 3: YCbCr output");
+  }
+  // ---- 4. 2x frame upsampling + noise: size is size_upsampled, three noise temporaries behind the image channels
+  {
+    jxlh_frame_params small = VarDctFrame::default_params(500, 350);
+    auto b = add_filters(RenderPipelineBuilder(6, {1000, 700}, 1, 8, small), rf_of(small), true, 1);
+    std::array<float, 8> lut{0.1f, 0.2f, 0.3f, 0.4f, 0.5f, 0.6f, 0.7f, 0.8f};
+    b = std::move(b)
+            .add_inout_stage(Upsample2x{nullptr, 0})
+            .add_inout_stage(Upsample2x{nullptr, 1})
+            .add_inout_stage(Upsample2x{nullptr, 2})
+            .add_inout_stage(ConvolveNoiseStage{3})
+            .add_inout_stage(ConvolveNoiseStage{4})
+            .add_inout_stage(ConvolveNoiseStage{5})
+            .add_inplace_stage(AddNoiseStage{lut, 3, -2, 3})
+            .add_save_stage({0, 1, 2}, 0, 3, 32);
+    const LoweredPipeline lp = b.lower();
+    expect(lp.frame.upsampling == 2 && lp.frame.xsize_upsampled == 1000 && lp.frame.ysize_upsampled == 700, "list 4: upsampling");
+    expect(lp.frame.noise == 1 && lp.frame.noise_lut[7] == 0.8f && lp.frame.ytox_lf == 3 && lp.frame.ytob_lf == -2, "list 4: noise");
+    expect(lp.input_border.x == 3, "list 4: border counts the stages before the upsampling");
+  }
+  // ---- 5. lists outside the device path
+  std::string msg;
+  expect(status_of([&] { (void)add_filters(RenderPipelineBuilder(3, {1000, 700}, 0, 8, base), rf, true, 2)
+                                   .add_inplace_stage(CpuOnlyStage{"patches"}).add_save_stage({0, 1, 2}, 0, 3, 32).lower(); },
+                   &msg) == JXLH_ERR_UNSUPPORTED && msg.find("patches") != std::string::npos,
+         "patches stage is rejected by name");
+  expect(status_of([&] { (void)RenderPipelineBuilder(3, {1000, 700}, 0, 8, base)
+                                   .add_inout_stage(Epf1Stage{1.0f, rf.border_sad_mul, rf.channel_scale})
+                                   .add_inout_stage(GaborishStage{0, 0.1f, 0.05f}).add_inout_stage(GaborishStage{1, 0.1f, 0.05f})
+                                   .add_inout_stage(GaborishStage{2, 0.1f, 0.05f}).add_save_stage({0, 1, 2}, 0, 3, 32).lower(); }) ==
+             JXLH_ERR_UNSUPPORTED,
+         "EPF before Gaborish is not the reference's order");
+  expect(status_of([&] { (void)RenderPipelineBuilder(3, {1000, 700}, 0, 8, base)
+                                   .add_inout_stage(GaborishStage{0, 0.1f, 0.05f}).add_inout_stage(GaborishStage{1, 0.1f, 0.05f})
+                                   .add_save_stage({0, 1, 2}, 0, 3, 32).lower(); }) == JXLH_ERR_INVALID_ARGUMENT,
+         "Gaborish on two channels");
+  expect(status_of([&] { (void)RenderPipelineBuilder(3, {1000, 700}, 0, 8, base)
+                                   .add_inout_stage(Epf2Stage{rf.pass2, rf.border_sad_mul, rf.channel_scale})
+                                   .add_save_stage({0, 1, 2}, 0, 3, 32).lower(); }) == JXLH_ERR_UNSUPPORTED,
+         "EPF2 without EPF1");
+  expect(status_of([&] { (void)RenderPipelineBuilder(3, {1000, 700}, 0, 8, base)
+                                   .add_inout_stage(Epf1Stage{0.5f, rf.border_sad_mul, rf.channel_scale})
+                                   .add_save_stage({0, 1, 2}, 0, 3, 32).lower(); }) == JXLH_ERR_UNSUPPORTED,
+         "EPF1 sigma scale is 1 in the reference's list");
+  expect(status_of([&] { (void)RenderPipelineBuilder(3, {1000, 700}, 1, 8, base)
+                                   .add_inout_stage(Upsample4x{nullptr, 0}).add_inout_stage(Upsample4x{nullptr, 1})
+                                   .add_inout_stage(Upsample4x{nullptr, 2}).add_save_stage({0, 1, 2}, 0, 3, 32).lower(); }) ==
+             JXLH_ERR_INVALID_ARGUMENT,
+         "4x stages with a downsampling shift of 1");
+  expect(status_of([&] { (void)RenderPipelineBuilder(4, {1000, 700}, 0, 8, base)
+                                   .add_inout_stage(Upsample2x{nullptr, 3}).add_save_stage({0, 1, 2}, 0, 3, 32).lower(); }) ==
+             JXLH_ERR_UNSUPPORTED,
+         "extra-channel upsampling stays on the CPU pipeline");
+  expect(status_of([&] { (void)add_filters(RenderPipelineBuilder(3, {1000, 700}, 0, 8, base), rf, true, 2).lower(); }) ==
+             JXLH_ERR_INVALID_ARGUMENT,
+         "a pipeline without save stage");
+  expect(status_of([&] { (void)RenderPipelineBuilder(3, {1000, 700}, 0, 8, base)
+                                   .add_inplace_stage(FromLinearStage{0, JXLH_TF_PQ, 10000.f, {0.f, 0.f, 0.f}})
+                                   .add_save_stage({0, 1, 2}, 0, 3, 32).lower(); }) == JXLH_ERR_UNSUPPORTED,
+         "transfer function without XybStage");
+  expect(status_of([&] { (void)RenderPipelineBuilder(3, {1000, 700}, 0, 8, base)
+                                   .add_inplace_stage(XybStage{0, some_xyb()})
+                                   .add_inout_stage(ConvertF32ToU16Stage{0, 16}).add_inout_stage(ConvertF32ToU16Stage{1, 16})
+                                   .add_inout_stage(ConvertF32ToU16Stage{2, 16}).add_save_stage({0, 1, 2}, 0, 3, 8).lower(); }) ==
+             JXLH_ERR_INVALID_ARGUMENT,
+         "save format and conversion disagree");
+  expect(status_of([&] { (void)RenderPipelineBuilder(3, {999, 700}, 0, 8, base).add_save_stage({0, 1, 2}, 0, 3, 32).lower(); }) ==
+             JXLH_ERR_INVALID_ARGUMENT,
+         "pipeline size and frame size disagree");
+  // BORDER / SHIFT constants are the reference's
+  static_assert(GaborishStage::BORDER.x == 1 && Epf0Stage::BORDER.x == 3 && Epf1Stage::BORDER.y == 2 && Epf2Stage::BORDER.x == 1);
+  static_assert(Upsample8x::SHIFT.x == 3 && Upsample2x::BORDER.x == 2 && HorizontalChromaUpsample::SHIFT.x == 1 &&
+                HorizontalChromaUpsample::SHIFT.y == 0 && VerticalChromaUpsample::BORDER.y == 1 && ConvolveNoiseStage::BORDER.x == 2);
+  printf("host checks: %s\n", g_failed ? "FAILED" : "ok");
+  return g_failed ? 1 : 0;
+}
+
+int gpu_frame(int w, int h, int epf_iters) {
+  synth::Frame F;
+  if (!synth::make(w, h, epf_iters, &F)) return 2;
+  try {
+    Context ctx(0, 2);
+    jxlh_frame_params base = VarDctFrame::default_params((uint32_t)w, (uint32_t)h);
+    auto b = add_filters(RenderPipelineBuilder(3, {(size_t)w, (size_t)h}, 0, 8, base), rf_of(base), true, epf_iters);
+    auto pipe = std::move(b).add_save_stage({0, 1, 2}, 0, 3, 32).build(ctx);
+    expect((int)pipe->lowered().frame.epf_iters == epf_iters, "built pipeline carries the stage list");
+    VarDctFrame& frame = pipe->frame();
+    frame.decode_hf_global(F.tables);
+    frame.decode_lf_group(0, 0, (uint32_t)F.xb, (uint32_t)F.yb, F.qy.data(), F.qx.data(), F.qb.data(), (size_t)F.xb);
+    frame.decode_hf_metadata(0, 0, (uint32_t)F.xb, (uint32_t)F.yb, F.tmap.data(), F.rq.data(), F.epf.data(), (size_t)F.xb,
+                             F.ytox.data(), F.ytob.data(), (size_t)F.cw);
+    // pass 1: every group handed over, the odd ones with zeroed coefficients and `complete = false`
+    std::vector<int32_t> zeros((size_t)3 * 65536, 0);
+    for (int g = 0; g < F.ngroups; g++)
+      pipe->set_buffer_for_group((uint32_t)g, g % 2 == 0, g % 2 ? zeros.data() : &F.coeffs[(size_t)g * 3 * 65536], g % 2);
+    pipe->do_render();
+    // pass 2: the odd groups arrive complete and are marked for re-rendering (render/mod.rs:146)
+    for (int g = 1; g < F.ngroups; g += 2) {
+      pipe->set_buffer_for_group((uint32_t)g, true, &F.coeffs[(size_t)g * 3 * 65536], g % 2);
+      pipe->mark_group_to_rerender((uint32_t)g);
+    }
+    pipe->do_render();
+    ctx.sync();
+    pipe->check_buffer_sizes((size_t)w * sizeof(float), (size_t)h);
+    std::vector<float> out[3];
+    for (auto& o : out) o.resize((size_t)w * h);
+    pipe->save_planes(out[0].data(), out[1].data(), out[2].data());
+    size_t bad = 0;
+    for (int c = 0; c < 3; c++)
+      for (int y = 0; y < h; y++)
+        if (memcmp(&out[c][(size_t)y * w], &F.pl[c][(size_t)y * F.stride], sizeof(float) * w) != 0) bad++;
+    bool threw = false;
+    try {
+      pipe->check_buffer_sizes((size_t)w * sizeof(float) - 1, (size_t)h);
+    } catch (const Error& e) {
+      threw = e.status == JXLH_ERR_INVALID_ARGUMENT;
+    }
+    printf("%dx%d epf_iters=%d groups=%d through RenderPipelineBuilder, two passes: %zu differing rows, error path %s\n", w, h,
+           epf_iters, F.ngroups, bad, threw ? "ok" : "MISSING");
+    return (bad == 0 && threw && !g_failed) ? 0 : 1;
+  } catch (const std::exception& e) {
+    fprintf(stderr, "device path failed: %s\n", e.what());
+    return 3;
+  }
+}
+}  // namespace
+
+int main(int argc, char** argv) {
+  if (argc < 2 || !strcmp(argv[1], "host")) return host_checks();
+  if (!strcmp(argv[1], "gpu") && argc >= 5) return gpu_frame(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]));
+  fprintf(stderr, "usage: pipeline_builder host | gpu W H EPF_ITERS\n");
+  return 2;
+}
