@@ -3,12 +3,19 @@ HEADER PARAMETERS (quantiser, chroma-from-luma, Gaborish weights, every EPF knob
 vs the CPU oracle, bit for bit.  The fixed parity cases use the reference's header defaults; this one
 walks the parameter space the reference's FrameHeader / RestorationFilter / ColorCorrelationParams
 can express (headers/frame_header.rs:146-233, frame/color_correlation_map.rs:21-94)."""
+import os
+
 import numpy as np
 import pytest
 
 from helpers import bit_equal, diff_report, run_gpu_frame, run_oracle_frame
 
 pytestmark = pytest.mark.gpu
+
+# soak runs (tools/soak_vardct.sh): JXLH_FUZZ_OFFSET shifts every seed, JXLH_FUZZ_SCALE multiplies the frame sizes
+# (more groups per frame: 4-group scan workgroups with dead quarters, several group rows)
+FUZZ_OFFSET = int(os.environ.get("JXLH_FUZZ_OFFSET", "0"))
+FUZZ_SCALE = int(os.environ.get("JXLH_FUZZ_SCALE", "1"))
 
 
 @pytest.fixture(scope="module")
@@ -21,8 +28,8 @@ def ctx():
 
 def _random_case(rng):
     from jxl_rs_amd import synth
-    w = int(rng.choice([rng.integers(1, 40), rng.integers(40, 300), rng.integers(300, 700)]))
-    h = int(rng.choice([rng.integers(1, 40), rng.integers(40, 300), rng.integers(300, 700)]))
+    w = int(rng.choice([rng.integers(1, 40), rng.integers(40, 300), rng.integers(300, 700)])) * FUZZ_SCALE
+    h = int(rng.choice([rng.integers(1, 40), rng.integers(40, 300), rng.integers(300, 700)])) * FUZZ_SCALE
     mix = [synth.MIX_DCT8, synth.MIX_D1, synth.MIX_ALL][int(rng.integers(0, 3))]
     opts = dict(epf_iters=int(rng.integers(0, 4)), gab=bool(rng.integers(0, 2)), lf_smoothing=bool(rng.integers(0, 2)))
     over = {}
@@ -64,9 +71,9 @@ def _apply_arrays(p, arrays):
 def test_random_frames_and_header_parameters_bit_exact(ctx, oracle, kat, seed):
     from jxl_rs_amd import synth
     import helpers
-    rng = np.random.default_rng(1000 + seed)
+    rng = np.random.default_rng(1000 + seed + FUZZ_OFFSET)
     w, h, mix, opts, over, arrays = _random_case(rng)
-    wl = synth.make_vardct(w, h, mix=mix, seed=seed, **opts)
+    wl = synth.make_vardct(w, h, mix=mix, seed=seed + FUZZ_OFFSET, **opts)
     # oracle
     po = helpers.oracle_params_from(oracle, wl, **over)
     _apply_arrays(po, arrays)
@@ -111,7 +118,7 @@ def test_random_subsampled_frames_bit_exact(ctx, oracle, seed):
     transform, random stage lists and header parameters; ends in the YCbCr -> RGB8 output."""
     from jxl_rs_amd import synth
     import helpers
-    rng = np.random.default_rng(5000 + seed)
+    rng = np.random.default_rng(5000 + seed + FUZZ_OFFSET)
     w, h, _, opts, over, arrays = _random_case(rng)
     hs = tuple(int(v) for v in rng.integers(0, 2, 3))
     vs = tuple(int(v) for v in rng.integers(0, 2, 3))
