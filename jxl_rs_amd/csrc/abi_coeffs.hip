@@ -7,6 +7,7 @@
 extern "C" {
 
 jxlh_status jxlh_submit_group(jxlh_ctx* ctx, int32_t slot, uint32_t group_id, const int32_t* coeffs, uint32_t flags) {
+  JXLH_ON_DEVICE(ctx);
   if (!ctx || !coeffs || slot < 0 || (size_t)slot >= ctx->slots.size()) return JXLH_ERR_INVALID_ARGUMENT;
   if (!ctx->in_frame) return JXLH_ERR_BAD_STATE;
   if (group_id >= ctx->ngroups) return JXLH_ERR_INVALID_ARGUMENT;
@@ -92,6 +93,7 @@ jxlh_status sparse_reserve(jxlh_ctx* ctx, int32_t slot, uint32_t count, const ui
 jxlh_status jxlh_submit_groups_sparse(jxlh_ctx* ctx, int32_t slot, uint32_t count, const uint32_t* group_ids,
                                       const jxlh_coeff16* pairs, const uint32_t* n, const jxlh_coeff32* wide,
                                       uint32_t n_wide, uint32_t flags) {
+  JXLH_ON_DEVICE(ctx);
   if (count == 0 && ctx && ctx->in_frame) return JXLH_OK;
   size_t offset = 0, total = 0;
   if (jxlh_status st = sparse_reserve(ctx, slot, count, group_ids, n, wide, n_wide, flags, &offset, &total)) return st;
@@ -111,6 +113,7 @@ jxlh_status jxlh_submit_groups_sparse(jxlh_ctx* ctx, int32_t slot, uint32_t coun
 jxlh_status jxlh_submit_groups_sparse8(jxlh_ctx* ctx, int32_t slot, uint32_t count, const uint32_t* group_ids,
                                        const uint16_t* pos, const int8_t* val, const uint32_t* n,
                                        const jxlh_coeff32* wide, uint32_t n_wide, uint32_t flags) {
+  JXLH_ON_DEVICE(ctx);
   if (count == 0 && ctx && ctx->in_frame) return JXLH_OK;
   size_t offset = 0, total = 0;
   if (jxlh_status st = sparse_reserve(ctx, slot, count, group_ids, n, wide, n_wide, flags, &offset, &total)) return st;
@@ -143,6 +146,7 @@ jxlh_status jxlh_submit_groups_sparse8(jxlh_ctx* ctx, int32_t slot, uint32_t cou
 jxlh_status jxlh_submit_group_sparse(jxlh_ctx* ctx, int32_t slot, uint32_t group_id, const jxlh_coeff16* pairs,
                                      const uint32_t n[3], const jxlh_coeff32* wide, uint32_t n_wide,
                                      uint32_t flags) {
+  JXLH_ON_DEVICE(ctx);
   if (!ctx || !n) return JXLH_ERR_INVALID_ARGUMENT;
   if (group_id >= ctx->ngroups) return JXLH_ERR_INVALID_ARGUMENT;
   // the single-group form addresses wide entries relative to the group
@@ -159,12 +163,14 @@ jxlh_status jxlh_submit_group_sparse(jxlh_ctx* ctx, int32_t slot, uint32_t group
 }
 
 jxlh_status jxlh_slot_wait(jxlh_ctx* ctx, int32_t slot) {
+  JXLH_ON_DEVICE(ctx);
   if (!ctx || slot < 0 || (size_t)slot >= ctx->slots.size()) return JXLH_ERR_INVALID_ARGUMENT;
   HIPCHK(ctx, hipStreamSynchronize(ctx->slots[slot].stream));
   return JXLH_OK;
 }
 
 jxlh_status jxlh_frame_coeff_buffer(jxlh_ctx* ctx, int32_t** device_ptr, size_t* n_int32) {
+  JXLH_ON_DEVICE(ctx);
   if (!ctx || !device_ptr) return JXLH_ERR_INVALID_ARGUMENT;
   if (!ctx->in_frame) return JXLH_ERR_BAD_STATE;
   *device_ptr = ctx->coeffs.p;

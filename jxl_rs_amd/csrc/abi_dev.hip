@@ -10,12 +10,14 @@ extern "C" {
 
 // ---------------------------------------------------------------- timing
 jxlh_status jxlh_timer_start(jxlh_ctx* ctx) {
+  JXLH_ON_DEVICE(ctx);
   if (!ctx) return JXLH_ERR_INVALID_ARGUMENT;
   HIPCHK(ctx, hipEventRecord(ctx->t0, ctx->stream));
   return JXLH_OK;
 }
 
 jxlh_status jxlh_timer_stop(jxlh_ctx* ctx, float* elapsed_ms) {
+  JXLH_ON_DEVICE(ctx);
   if (!ctx || !elapsed_ms) return JXLH_ERR_INVALID_ARGUMENT;
   HIPCHK(ctx, hipEventRecord(ctx->t1, ctx->stream));
   HIPCHK(ctx, hipEventSynchronize(ctx->t1));
@@ -24,12 +26,14 @@ jxlh_status jxlh_timer_stop(jxlh_ctx* ctx, float* elapsed_ms) {
 }
 
 jxlh_status jxlh_kernel_timing_enable(jxlh_ctx* ctx, int32_t enable) {
+  JXLH_ON_DEVICE(ctx);
   if (!ctx) return JXLH_ERR_INVALID_ARGUMENT;
   ctx->timing = enable != 0;
   return JXLH_OK;
 }
 
 jxlh_status jxlh_kernel_timing_get(jxlh_ctx* ctx, int32_t i, const char** name, float* total_ms, int32_t* launches) {
+  JXLH_ON_DEVICE(ctx);
   if (!ctx || i < 0) return JXLH_ERR_INVALID_ARGUMENT;
   drain_timers(ctx);
   if ((size_t)i >= ctx->ktimes.size()) return JXLH_ERR_INVALID_ARGUMENT;
@@ -40,6 +44,7 @@ jxlh_status jxlh_kernel_timing_get(jxlh_ctx* ctx, int32_t i, const char** name, 
 }
 
 jxlh_status jxlh_kernel_timing_reset(jxlh_ctx* ctx) {
+  JXLH_ON_DEVICE(ctx);
   if (!ctx) return JXLH_ERR_INVALID_ARGUMENT;
   drain_timers(ctx);
   ctx->ktimes.clear();
@@ -47,6 +52,7 @@ jxlh_status jxlh_kernel_timing_reset(jxlh_ctx* ctx) {
 }
 
 jxlh_status jxlh_selftest_recip(jxlh_ctx* ctx, uint32_t lo_bits, uint32_t hi_bits, uint64_t* mismatches) {
+  JXLH_ON_DEVICE(ctx);
   if (!ctx || !mismatches || hi_bits < lo_bits) return JXLH_ERR_INVALID_ARGUMENT;
   jxlh_status st;
   if ((st = ensure(ctx, ctx->hook_i[0], 2))) return st;

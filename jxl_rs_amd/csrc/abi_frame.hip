@@ -173,18 +173,21 @@ void jxlh_ctx_destroy(jxlh_ctx* ctx) {
 }
 
 jxlh_status jxlh_alloc_pinned(jxlh_ctx* ctx, size_t bytes, void** out) {
+  JXLH_ON_DEVICE(ctx);
   if (!ctx || !out) return JXLH_ERR_INVALID_ARGUMENT;
   HIPCHK(ctx, hipHostMalloc(out, bytes, hipHostMallocDefault));
   return JXLH_OK;
 }
 
 jxlh_status jxlh_free_pinned(jxlh_ctx* ctx, void* p) {
+  JXLH_ON_DEVICE(ctx);
   if (!ctx) return JXLH_ERR_INVALID_ARGUMENT;
   if (p) HIPCHK(ctx, hipHostFree(p));
   return JXLH_OK;
 }
 
 jxlh_status jxlh_frame_begin(jxlh_ctx* ctx, const jxlh_frame_params* p) {
+  JXLH_ON_DEVICE(ctx);
   if (!ctx || !p || p->abi_version != JXLH_ABI_VERSION) return JXLH_ERR_INVALID_ARGUMENT;
   if (p->xsize == 0 || p->ysize == 0 || p->xsize > (1u << 20) || p->ysize > (1u << 20) || p->global_scale == 0 ||
       p->quant_lf == 0 || p->color_factor == 0 || p->epf_iters > 3)
@@ -306,6 +309,7 @@ jxlh_status jxlh_frame_begin(jxlh_ctx* ctx, const jxlh_frame_params* p) {
 
 jxlh_status jxlh_set_upsampling_weights(jxlh_ctx* ctx, const float* weights2, const float* weights4,
                                         const float* weights8) {
+  JXLH_ON_DEVICE(ctx);
   if (!ctx) return JXLH_ERR_INVALID_ARGUMENT;
   const float* src[3] = {weights2, weights4, weights8};
   const size_t cnt[3] = {15, 55, 210};
@@ -318,6 +322,7 @@ jxlh_status jxlh_set_upsampling_weights(jxlh_ctx* ctx, const float* weights2, co
 
 jxlh_status jxlh_frame_set_dequant_tables(jxlh_ctx* ctx, const float* const tables[JXLH_NUM_QUANT_TABLES],
                                           const size_t n[JXLH_NUM_QUANT_TABLES]) {
+  JXLH_ON_DEVICE(ctx);
   if (!ctx || !tables || !n) return JXLH_ERR_INVALID_ARGUMENT;
   if (!ctx->in_frame) return JXLH_ERR_BAD_STATE;
   size_t total = 0;
@@ -349,6 +354,7 @@ static bool rect_ok(const jxlh_ctx* ctx, uint32_t x0, uint32_t y0, uint32_t w, u
 jxlh_status jxlh_frame_set_lf_quantized(jxlh_ctx* ctx, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
                                         const int32_t* qy, const int32_t* qx, const int32_t* qb, size_t stride,
                                         uint32_t extra_precision) {
+  JXLH_ON_DEVICE(ctx);
   if (!ctx || !qy || !qx || !qb || stride < w || extra_precision > 3) return JXLH_ERR_INVALID_ARGUMENT;
   if (!ctx->in_frame) return JXLH_ERR_BAD_STATE;
   if (!rect_ok(ctx, x0, y0, w, h)) return JXLH_ERR_INVALID_ARGUMENT;
@@ -393,6 +399,7 @@ jxlh_status jxlh_frame_set_lf_quantized(jxlh_ctx* ctx, uint32_t x0, uint32_t y0,
 
 jxlh_status jxlh_frame_set_lf(jxlh_ctx* ctx, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, const float* x,
                               const float* y, const float* b, size_t stride) {
+  JXLH_ON_DEVICE(ctx);
   if (!ctx || !x || !y || !b || stride < w) return JXLH_ERR_INVALID_ARGUMENT;
   if (!ctx->in_frame) return JXLH_ERR_BAD_STATE;
   if (!rect_ok(ctx, x0, y0, w, h)) return JXLH_ERR_INVALID_ARGUMENT;
@@ -411,6 +418,7 @@ jxlh_status jxlh_frame_set_lf(jxlh_ctx* ctx, uint32_t x0, uint32_t y0, uint32_t 
 jxlh_status jxlh_frame_set_hf_meta(jxlh_ctx* ctx, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
                                    const uint8_t* transform_map, const int32_t* raw_quant, const uint8_t* epf_map,
                                    size_t map_stride, const int8_t* ytox, const int8_t* ytob, size_t cmap_stride) {
+  JXLH_ON_DEVICE(ctx);
   if (!ctx || !transform_map || !raw_quant || !epf_map || !ytox || !ytob || map_stride < w)
     return JXLH_ERR_INVALID_ARGUMENT;
   if (!ctx->in_frame) return JXLH_ERR_BAD_STATE;
@@ -793,6 +801,7 @@ jxlh_status run_stages_rows(jxlh_ctx* ctx, const RunPlan& plan, int y_lo, int y_
 extern "C" {
 
 jxlh_status jxlh_frame_run(jxlh_ctx* ctx, uint32_t group_row0, uint32_t group_row1) {
+  JXLH_ON_DEVICE(ctx);
   if (!ctx) return JXLH_ERR_INVALID_ARGUMENT;
   if (!ctx->in_frame || !ctx->tables_set) return JXLH_ERR_BAD_STATE;
   FrameDev& f = ctx->fd;
@@ -811,6 +820,7 @@ jxlh_status jxlh_frame_run(jxlh_ctx* ctx, uint32_t group_row0, uint32_t group_ro
 }
 
 jxlh_status jxlh_frame_rerender_groups(jxlh_ctx* ctx, const uint32_t* group_ids, uint32_t count) {
+  JXLH_ON_DEVICE(ctx);
   if (!ctx || (count && !group_ids)) return JXLH_ERR_INVALID_ARGUMENT;
   if (!ctx->in_frame || !ctx->tables_set) return JXLH_ERR_BAD_STATE;
   FrameDev& f = ctx->fd;
@@ -879,6 +889,7 @@ jxlh_status jxlh_frame_rerender_groups(jxlh_ctx* ctx, const uint32_t* group_ids,
 }
 
 jxlh_status jxlh_ctx_sync(jxlh_ctx* ctx) {
+  JXLH_ON_DEVICE(ctx);
   if (!ctx) return JXLH_ERR_INVALID_ARGUMENT;
   if (ctx->in_frame && ctx->error_flag.p) {
     // read the flag on the context's own stream into pinned memory: a synchronous hipMemcpy would

@@ -10,6 +10,7 @@ extern "C" {
 // In-place / out-of-place on the caller's buffers when they are device pointers; host
 // pointers are staged through context scratch.
 jxlh_status jxlh_rct(jxlh_ctx* ctx, int32_t* p0, int32_t* p1, int32_t* p2, size_t n, int32_t op, int32_t perm) {
+  JXLH_ON_DEVICE(ctx);
   if (!ctx || !p0 || !p1 || !p2 || op < 0 || op > 6 || perm < 0 || perm > 5) return JXLH_ERR_INVALID_ARGUMENT;
   if (n == 0) return JXLH_OK;
   if (is_device_ptr(p0) && is_device_ptr(p1) && is_device_ptr(p2)) {
@@ -31,6 +32,7 @@ jxlh_status jxlh_rct(jxlh_ctx* ctx, int32_t* p0, int32_t* p1, int32_t* p2, size_
 
 jxlh_status jxlh_palette(jxlh_ctx* ctx, const int32_t* index, size_t n, const int32_t* palette, int32_t num_colors,
                          size_t palette_stride, int32_t nb_channels, int32_t bit_depth, int32_t* out) {
+  JXLH_ON_DEVICE(ctx);
   if (!ctx || !index || !palette || !out || num_colors < 0 || nb_channels < 1 || nb_channels > 64 || bit_depth < 1 ||
       bit_depth > 24 || palette_stride < (size_t)num_colors)
     return JXLH_ERR_INVALID_ARGUMENT;
@@ -55,6 +57,7 @@ jxlh_status jxlh_palette(jxlh_ctx* ctx, const int32_t* index, size_t n, const in
 jxlh_status jxlh_palette_strided(jxlh_ctx* ctx, const int32_t* index, size_t n, const int32_t* palette,
                                  int32_t num_colors, size_t palette_stride, int32_t nb_channels, int32_t bit_depth,
                                  int32_t* out, size_t out_channel_stride) {
+  JXLH_ON_DEVICE(ctx);
   if (!ctx || !index || !palette || !out || num_colors < 0 || nb_channels < 1 || nb_channels > 64 || bit_depth < 1 ||
       bit_depth > 24 || palette_stride < (size_t)num_colors || out_channel_stride < n)
     return JXLH_ERR_INVALID_ARGUMENT;
@@ -70,6 +73,7 @@ jxlh_status jxlh_palette_strided(jxlh_ctx* ctx, const int32_t* index, size_t n, 
 jxlh_status jxlh_palette_delta(jxlh_ctx* ctx, const int32_t* index, uint32_t w, uint32_t h, const int32_t* palette,
                                int32_t num_colors, int32_t num_deltas, size_t palette_stride, int32_t nb_channels,
                                int32_t bit_depth, int32_t predictor, int32_t* out) {
+  JXLH_ON_DEVICE(ctx);
   if (!ctx || !index || !palette || !out || num_colors < 0 || num_deltas < 0 || nb_channels < 1 || nb_channels > 64 ||
       bit_depth < 1 || bit_depth > 24 || palette_stride < (size_t)num_colors + (size_t)num_deltas || predictor < 0 ||
       predictor > 13 || w > (1u << 20) || h > (1u << 20))
@@ -100,6 +104,7 @@ jxlh_status jxlh_palette_delta(jxlh_ctx* ctx, const int32_t* index, uint32_t w, 
 // ---- Modular channels -> pipeline samples (render/stages/convert.rs)
 jxlh_status jxlh_modular_to_rgb8(jxlh_ctx* ctx, const int32_t* const planes[3], size_t stride, uint32_t w, uint32_t h,
                                  int32_t multiplier, int32_t max, uint32_t channels, void* out, size_t bytes_per_row) {
+  JXLH_ON_DEVICE(ctx);
   if (!ctx || !planes || !planes[0] || !planes[1] || !planes[2] || !out || stride < w || (channels != 3 && channels != 4) ||
       bytes_per_row < (size_t)w * channels || max < 0 || max > 255 || w > (1u << 20) || h > (1u << 20))
     return JXLH_ERR_INVALID_ARGUMENT;
@@ -132,6 +137,7 @@ jxlh_status jxlh_modular_to_rgb8(jxlh_ctx* ctx, const int32_t* const planes[3], 
 }
 
 jxlh_status jxlh_modular_to_f32(jxlh_ctx* ctx, const int32_t* in, size_t n, uint32_t bits_per_sample, float* out) {
+  JXLH_ON_DEVICE(ctx);
   if (!ctx || !in || !out || bits_per_sample < 1 || bits_per_sample > 32) return JXLH_ERR_INVALID_ARGUMENT;
   if (n == 0) return JXLH_OK;
   const float scale = 1.0f / (float)((1ull << bits_per_sample) - 1);  // convert.rs:528
@@ -150,6 +156,7 @@ jxlh_status jxlh_modular_to_f32(jxlh_ctx* ctx, const int32_t* in, size_t n, uint
 
 jxlh_status jxlh_modular_xyb_to_f32(jxlh_ctx* ctx, const int32_t* y, const int32_t* x, const int32_t* b, size_t n,
                                     const float quant_factors[3], float* ox, float* oy, float* ob) {
+  JXLH_ON_DEVICE(ctx);
   if (!ctx || !y || !x || !b || !quant_factors || !ox || !oy || !ob) return JXLH_ERR_INVALID_ARGUMENT;
   if (n == 0) return JXLH_OK;
   const int32_t* in[3] = {y, x, b};
@@ -175,6 +182,7 @@ jxlh_status jxlh_modular_xyb_to_f32(jxlh_ctx* ctx, const int32_t* y, const int32
 jxlh_status jxlh_palette_delta_wp(jxlh_ctx* ctx, const int32_t* index, uint32_t w, uint32_t h, const int32_t* palette,
                                   int32_t num_colors, int32_t num_deltas, size_t palette_stride, int32_t nb_channels,
                                   int32_t bit_depth, const jxlh_wp_header* wp, int32_t* out) {
+  JXLH_ON_DEVICE(ctx);
   if (!ctx || !index || !palette || !out || !wp || num_colors < 0 || num_deltas < 0 || nb_channels < 1 ||
       nb_channels > 64 || bit_depth < 1 || bit_depth > 24 ||
       palette_stride < (size_t)num_colors + (size_t)num_deltas || w > (1u << 20) || h > (1u << 20))
@@ -215,6 +223,7 @@ static constexpr uint32_t kMaxModularDim = 1u << 20;
 jxlh_status jxlh_unsqueeze(jxlh_ctx* ctx, int32_t horizontal, const int32_t* avg, size_t avg_stride,
                            const int32_t* res, size_t res_stride, uint32_t out_w, uint32_t out_h, int32_t* out,
                            size_t out_stride) {
+  JXLH_ON_DEVICE(ctx);
   if (!ctx || !avg || !out || out_stride < out_w) return JXLH_ERR_INVALID_ARGUMENT;
   if (out_w == 0 || out_h == 0) return JXLH_OK;
   if (out_w > kMaxModularDim || out_h > kMaxModularDim) return JXLH_ERR_UNSUPPORTED;
@@ -253,6 +262,7 @@ jxlh_status jxlh_unsqueeze(jxlh_ctx* ctx, int32_t horizontal, const int32_t* avg
 jxlh_status jxlh_unsqueeze_levels(jxlh_ctx* ctx, int32_t n_planes, int32_t n_levels, const jxlh_squeeze_level* levels,
                                   const int32_t* const base[], size_t base_stride, uint32_t base_w, uint32_t base_h,
                                   int32_t* const out[], size_t out_stride) {
+  JXLH_ON_DEVICE(ctx);
   if (!ctx || !levels || !base || !out || n_planes < 1 || n_planes > 3 || n_levels < 1 || n_levels > 64 || base_w == 0 ||
       base_h == 0 || base_stride < base_w)
     return JXLH_ERR_INVALID_ARGUMENT;
@@ -325,6 +335,7 @@ jxlh_status jxlh_unsqueeze_levels(jxlh_ctx* ctx, int32_t n_planes, int32_t n_lev
 jxlh_status jxlh_unsqueeze_chain(jxlh_ctx* ctx, int32_t n_planes, int32_t n_levels, const jxlh_squeeze_level* levels,
                                  const int32_t* const base[], size_t base_stride, uint32_t base_w, uint32_t base_h,
                                  int32_t* const out[], size_t out_stride, int32_t rct_op, int32_t rct_perm) {
+  JXLH_ON_DEVICE(ctx);
   if (!ctx || !levels || !base || !out || n_planes < 1 || n_planes > 3 || n_levels < 1 || n_levels > 64 || base_w == 0 ||
       base_h == 0 || base_stride < base_w)
     return JXLH_ERR_INVALID_ARGUMENT;
@@ -434,6 +445,7 @@ jxlh_status jxlh_unsqueeze_chain(jxlh_ctx* ctx, int32_t n_planes, int32_t n_leve
 jxlh_status jxlh_unsqueeze_rct(jxlh_ctx* ctx, int32_t horizontal, const int32_t* const avg[3], size_t avg_stride,
                                const int32_t* const res[3], size_t res_stride, uint32_t out_w, uint32_t out_h,
                                int32_t* const out[3], size_t out_stride, int32_t op, int32_t perm) {
+  JXLH_ON_DEVICE(ctx);
   if (!ctx || !avg || !res || !out || out_stride < out_w || op < 0 || op > 6 || perm < 0 || perm > 5)
     return JXLH_ERR_INVALID_ARGUMENT;
   if (out_w == 0 || out_h == 0) return JXLH_OK;
@@ -471,6 +483,7 @@ jxlh_status jxlh_unsqueeze_rct(jxlh_ctx* ctx, int32_t horizontal, const int32_t*
 jxlh_status jxlh_smooth_unsqueeze(jxlh_ctx* ctx, int32_t kind, const int32_t* avg, size_t avg_stride, uint32_t avg_w,
                                   uint32_t avg_h, uint32_t x0, uint32_t y0, int32_t* out, size_t out_stride,
                                   uint32_t out_w, uint32_t out_h) {
+  JXLH_ON_DEVICE(ctx);
   // the float -> int conversion of the reference's build target rides in the kind argument
   const bool cvt_rne = kind >= 0 && (kind & JXLH_SMOOTH_CVT_NEAREST_EVEN) != 0;
   if (kind >= 0) kind &= ~JXLH_SMOOTH_CVT_NEAREST_EVEN;
@@ -506,6 +519,7 @@ jxlh_status jxlh_smooth_unsqueeze(jxlh_ctx* ctx, int32_t kind, const int32_t* av
 jxlh_status jxlh_unsqueeze_planes(jxlh_ctx* ctx, int32_t horizontal, int32_t n_planes, const int32_t* const avg[],
                                   size_t avg_stride, const int32_t* const res[], size_t res_stride, uint32_t out_w,
                                   uint32_t out_h, int32_t* const out[], size_t out_stride) {
+  JXLH_ON_DEVICE(ctx);
   if (!ctx || !avg || !res || !out || n_planes < 1 || n_planes > 3 || out_stride < out_w)
     return JXLH_ERR_INVALID_ARGUMENT;
   if (out_w == 0 || out_h == 0) return JXLH_OK;

@@ -144,25 +144,30 @@ jxlh_status read_rgb16(jxlh_ctx* ctx, int mode, const jxlh_xyb_params* p, const 
 
 jxlh_status jxlh_frame_read_rgb8(jxlh_ctx* ctx, const jxlh_xyb_params* p, uint32_t channels, uint32_t y0,
                                  uint32_t y1, void* out, size_t bytes_per_row) {
+  JXLH_ON_DEVICE(ctx);
   if (!p) return JXLH_ERR_INVALID_ARGUMENT;
   return read_rgb8(ctx, kTfSrgb, p, TfParamsDev{}, channels, y0, y1, out, bytes_per_row);
 }
 jxlh_status jxlh_frame_read_rgb8_async(jxlh_ctx* ctx, const jxlh_xyb_params* p, uint32_t channels, uint32_t y0,
                                        uint32_t y1, void* out, size_t bytes_per_row) {
+  JXLH_ON_DEVICE(ctx);
   if (!p) return JXLH_ERR_INVALID_ARGUMENT;
   return read_rgb8(ctx, kTfSrgb, p, TfParamsDev{}, channels, y0, y1, out, bytes_per_row, /*wait=*/false);
 }
 jxlh_status jxlh_frame_read_rgb16(jxlh_ctx* ctx, const jxlh_xyb_params* p, uint32_t channels, uint32_t y0,
                                   uint32_t y1, void* out, size_t bytes_per_row) {
+  JXLH_ON_DEVICE(ctx);
   if (!p) return JXLH_ERR_INVALID_ARGUMENT;
   return read_rgb16(ctx, kTfSrgb, p, TfParamsDev{}, channels, y0, y1, out, bytes_per_row);
 }
 jxlh_status jxlh_frame_read_ycbcr_rgb8(jxlh_ctx* ctx, uint32_t channels, uint32_t y0, uint32_t y1, void* out,
                                        size_t bytes_per_row) {
+  JXLH_ON_DEVICE(ctx);
   return read_rgb8(ctx, kModeYcbcr, nullptr, TfParamsDev{}, channels, y0, y1, out, bytes_per_row);
 }
 jxlh_status jxlh_frame_read_ycbcr_rgb16(jxlh_ctx* ctx, uint32_t channels, uint32_t y0, uint32_t y1, void* out,
                                         size_t bytes_per_row) {
+  JXLH_ON_DEVICE(ctx);
   return read_rgb16(ctx, kModeYcbcr, nullptr, TfParamsDev{}, channels, y0, y1, out, bytes_per_row);
 }
 
@@ -191,14 +196,17 @@ jxlh_status read_output(jxlh_ctx* ctx, const jxlh_output_desc* d, uint32_t y0, u
 
 jxlh_status jxlh_frame_read_output(jxlh_ctx* ctx, const jxlh_output_desc* d, uint32_t y0, uint32_t y1, void* out,
                                    size_t bytes_per_row) {
+  JXLH_ON_DEVICE(ctx);
   return read_output(ctx, d, y0, y1, out, bytes_per_row, /*wait=*/true);
 }
 jxlh_status jxlh_frame_read_output_async(jxlh_ctx* ctx, const jxlh_output_desc* d, uint32_t y0, uint32_t y1, void* out,
                                          size_t bytes_per_row) {
+  JXLH_ON_DEVICE(ctx);
   return read_output(ctx, d, y0, y1, out, bytes_per_row, /*wait=*/false);
 }
 
 jxlh_status jxlh_frame_read_planes(jxlh_ctx* ctx, const jxlh_plane out[3]) {
+  JXLH_ON_DEVICE(ctx);
   if (!ctx || !out) return JXLH_ERR_INVALID_ARGUMENT;
   if (!ctx->in_frame || !ctx->result[0]) return JXLH_ERR_BAD_STATE;
   materialise_chroma(ctx);
@@ -214,6 +222,7 @@ jxlh_status jxlh_frame_read_planes(jxlh_ctx* ctx, const jxlh_plane out[3]) {
 }
 
 jxlh_status jxlh_frame_device_planes(jxlh_ctx* ctx, float* planes[3], size_t* stride) {
+  JXLH_ON_DEVICE(ctx);
   if (!ctx || !planes) return JXLH_ERR_INVALID_ARGUMENT;
   if (!ctx->in_frame || !ctx->result[0]) return JXLH_ERR_BAD_STATE;
   materialise_chroma(ctx);
@@ -223,6 +232,7 @@ jxlh_status jxlh_frame_device_planes(jxlh_ctx* ctx, float* planes[3], size_t* st
 }
 
 jxlh_status jxlh_frame_read_lf(jxlh_ctx* ctx, float* x, float* y, float* b, size_t stride) {
+  JXLH_ON_DEVICE(ctx);
   if (!ctx || !x || !y || !b) return JXLH_ERR_INVALID_ARGUMENT;
   if (!ctx->in_frame) return JXLH_ERR_BAD_STATE;
   const FrameDev& f = ctx->fd;

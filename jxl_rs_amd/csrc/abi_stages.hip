@@ -9,6 +9,7 @@ extern "C" {
 
 jxlh_status jxlh_stage_gaborish(jxlh_ctx* ctx, const float* in, float* out, uint32_t w, uint32_t h, size_t stride,
                                 float w1, float w2) {
+  JXLH_ON_DEVICE(ctx);
   if (!ctx || !in || !out || stride < w) return JXLH_ERR_INVALID_ARGUMENT;
   if (w == 0 || h == 0) return JXLH_OK;
   const size_t n = stride * h;
@@ -25,6 +26,7 @@ jxlh_status jxlh_stage_gaborish(jxlh_ctx* ctx, const float* in, float* out, uint
 jxlh_status jxlh_stage_epf(jxlh_ctx* ctx, int32_t stage, const jxlh_frame_params* p, const float* const in[3],
                            float* const out[3], uint32_t w, uint32_t h, size_t stride, const float* inv_sigma,
                            size_t sigma_stride) {
+  JXLH_ON_DEVICE(ctx);
   if (!ctx || !p || !in || !out || !inv_sigma || stage < 0 || stage > 2 || stride < w || sigma_stride < (w + 7) / 8)
     return JXLH_ERR_INVALID_ARGUMENT;
   if (w == 0 || h == 0) return JXLH_OK;
@@ -58,6 +60,7 @@ jxlh_status jxlh_stage_epf(jxlh_ctx* ctx, int32_t stage, const jxlh_frame_params
 
 jxlh_status jxlh_modular_frame_filters(jxlh_ctx* ctx, const jxlh_frame_params* p, float* const in[3],
                                        float* const out[3], uint32_t w, uint32_t h, size_t stride) {
+  JXLH_ON_DEVICE(ctx);
   if (!ctx || !p || !in || !out || stride < w || (stride & 3) || p->epf_iters > 3) return JXLH_ERR_INVALID_ARGUMENT;
   for (int c = 0; c < 3; c++) {
     if (!in[c] || !out[c] || in[c] == out[c] || !is_device_ptr(in[c]) || !is_device_ptr(out[c]) ||
@@ -104,6 +107,7 @@ jxlh_status jxlh_modular_frame_filters(jxlh_ctx* ctx, const jxlh_frame_params* p
 
 jxlh_status jxlh_stage_lf_smooth(jxlh_ctx* ctx, const jxlh_frame_params* p, const float* const in[3],
                                  float* const out[3], uint32_t w, uint32_t h) {
+  JXLH_ON_DEVICE(ctx);
   if (!ctx || !p || !in || !out || p->global_scale == 0 || p->quant_lf == 0) return JXLH_ERR_INVALID_ARGUMENT;
   if (w == 0 || h == 0) return JXLH_OK;
   const size_t n = (size_t)w * h;
@@ -134,6 +138,7 @@ jxlh_status jxlh_stage_lf_smooth(jxlh_ctx* ctx, const jxlh_frame_params* p, cons
 
 jxlh_status jxlh_stage_chroma_upsample(jxlh_ctx* ctx, const float* in, float* out, uint32_t w, uint32_t h,
                                        int32_t horizontal) {
+  JXLH_ON_DEVICE(ctx);
   if (!ctx || !in || !out || w > (1u << 20) || h > (1u << 20)) return JXLH_ERR_INVALID_ARGUMENT;
   if (w == 0 || h == 0) return JXLH_OK;
   const size_t n = (size_t)w * h;
@@ -155,6 +160,7 @@ jxlh_status jxlh_stage_chroma_upsample(jxlh_ctx* ctx, const float* in, float* ou
 }
 
 jxlh_status jxlh_stage_upsample(jxlh_ctx* ctx, int32_t n, const float* in, float* out, uint32_t w, uint32_t h) {
+  JXLH_ON_DEVICE(ctx);
   if (!ctx || !in || !out || (n != 2 && n != 4 && n != 8) || w > (1u << 20) || h > (1u << 20))
     return JXLH_ERR_INVALID_ARGUMENT;
   if (w == 0 || h == 0) return JXLH_OK;
@@ -172,6 +178,7 @@ jxlh_status jxlh_stage_upsample(jxlh_ctx* ctx, int32_t n, const float* in, float
 
 jxlh_status jxlh_stage_noise_generate(jxlh_ctx* ctx, uint32_t visible_frame_index, uint32_t nonvisible_frame_index,
                                       uint32_t w, uint32_t h, float* const out[3]) {
+  JXLH_ON_DEVICE(ctx);
   if (!ctx || !out || !out[0] || !out[1] || !out[2] || w == 0 || h == 0 || w > (1u << 20) || h > (1u << 20))
     return JXLH_ERR_INVALID_ARGUMENT;
   const size_t n = (size_t)w * h;
@@ -191,6 +198,7 @@ jxlh_status jxlh_stage_noise_generate(jxlh_ctx* ctx, uint32_t visible_frame_inde
 }
 
 jxlh_status jxlh_stage_noise_convolve(jxlh_ctx* ctx, const float* in, float* out, uint32_t w, uint32_t h) {
+  JXLH_ON_DEVICE(ctx);
   if (!ctx || !in || !out || w > (1u << 20) || h > (1u << 20)) return JXLH_ERR_INVALID_ARGUMENT;
   if (w == 0 || h == 0) return JXLH_OK;
   const size_t n = (size_t)w * h;
@@ -204,6 +212,7 @@ jxlh_status jxlh_stage_noise_convolve(jxlh_ctx* ctx, const float* in, float* out
 
 jxlh_status jxlh_stage_noise_add(jxlh_ctx* ctx, const jxlh_frame_params* p, float* const planes[3],
                                  const float* const rnd[3], size_t n) {
+  JXLH_ON_DEVICE(ctx);
   if (!ctx || !p || !planes || !rnd || p->color_factor == 0) return JXLH_ERR_INVALID_ARGUMENT;
   if (n == 0 || noise_lut_is_zero(p->noise_lut)) return JXLH_OK;
   jxlh_status st;
@@ -227,6 +236,7 @@ jxlh_status jxlh_stage_noise_add(jxlh_ctx* ctx, const jxlh_frame_params* p, floa
 
 jxlh_status jxlh_stage_transform_to_pixels(jxlh_ctx* ctx, int32_t type, uint32_t n, const float* coeffs,
                                            const float* lf, float* pixels) {
+  JXLH_ON_DEVICE(ctx);
   if (!ctx || type < 0 || type >= JXLH_NUM_TRANSFORMS || !coeffs || !lf || !pixels) return JXLH_ERR_INVALID_ARGUMENT;
   if (n == 0) return JXLH_OK;
   const size_t nb = (size_t)covered_x(type) * covered_y(type);

@@ -219,6 +219,7 @@ jxlh_status jxlh_comm_unique_id(uint8_t id[JXLH_COMM_ID_BYTES]) {
 }
 
 jxlh_status jxlh_comm_init(jxlh_ctx* ctx, const uint8_t id[JXLH_COMM_ID_BYTES], int32_t rank, int32_t nranks) {
+  JXLH_ON_DEVICE(ctx);
   if (!ctx || !id || nranks < 1 || rank < 0 || rank >= nranks) return JXLH_ERR_INVALID_ARGUMENT;
   if (ctx->comm || ctx->in_frame) return JXLH_ERR_BAD_STATE;  // before the first jxlh_frame_begin: it sizes the planes
   std::string err;
@@ -280,6 +281,7 @@ jxlh_status jxlh_comm_init_local(jxlh_ctx* const peers[], int32_t nranks) {
 }
 
 jxlh_status jxlh_comm_destroy(jxlh_ctx* ctx) {
+  JXLH_ON_DEVICE(ctx);
   if (!ctx) return JXLH_ERR_INVALID_ARGUMENT;
   if (!ctx->comm) return JXLH_OK;
   HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -289,6 +291,7 @@ jxlh_status jxlh_comm_destroy(jxlh_ctx* ctx) {
 }
 
 jxlh_status jxlh_comm_band(jxlh_ctx* ctx, int32_t* rank, int32_t* nranks, uint32_t* group_row0, uint32_t* group_row1) {
+  JXLH_ON_DEVICE(ctx);
   if (!ctx) return JXLH_ERR_INVALID_ARGUMENT;
   const int n = ctx->comm ? ctx->comm->nranks : 1, r = ctx->comm ? ctx->comm->rank : 0;
   if (rank) *rank = r;
@@ -305,6 +308,7 @@ jxlh_status jxlh_comm_band(jxlh_ctx* ctx, int32_t* rank, int32_t* nranks, uint32
 
 // ---- RCCL transport ------------------------------------------------------------------------------------------
 jxlh_status jxlh_frame_run_sharded(jxlh_ctx* ctx) {
+  JXLH_ON_DEVICE(ctx);
   if (!ctx) return JXLH_ERR_INVALID_ARGUMENT;
   if (!ctx->comm || !ctx->comm->nccl) return JXLH_ERR_BAD_STATE;
   HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -354,6 +358,7 @@ jxlh_status jxlh_frame_run_sharded(jxlh_ctx* ctx) {
 }
 
 jxlh_status jxlh_frame_allgather(jxlh_ctx* ctx) {
+  JXLH_ON_DEVICE(ctx);
   if (!ctx) return JXLH_ERR_INVALID_ARGUMENT;
   if (!ctx->comm || !ctx->comm->nccl || !ctx->in_frame) return JXLH_ERR_BAD_STATE;
   HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -376,6 +381,7 @@ jxlh_status jxlh_frame_allgather(jxlh_ctx* ctx) {
 }
 
 jxlh_status jxlh_comm_allgather(jxlh_ctx* ctx, void* buf, size_t bytes_per_rank) {
+  JXLH_ON_DEVICE(ctx);
   if (!ctx || !buf) return JXLH_ERR_INVALID_ARGUMENT;
   if (!ctx->comm || !ctx->comm->nccl) return JXLH_ERR_BAD_STATE;
   HIPCHK(ctx, hipSetDevice(ctx->device));

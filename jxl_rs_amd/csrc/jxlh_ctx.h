@@ -15,6 +15,14 @@
 
 using namespace jxlh;
 
+// Every entry point that takes a context makes the context's device the calling thread's current device first: the
+// ABI promises one submitting thread per slot plus whoever runs / reads the frame, and HIP's current device is
+// per-thread state (a fresh thread sits on device 0).  hipSetDevice on the device already current costs ~70 ns.
+#define JXLH_ON_DEVICE(ctx)                        \
+  do {                                             \
+    if ((ctx) != nullptr) (void)hipSetDevice((ctx)->device); \
+  } while (0)
+
 namespace jxlh_host {
 
 struct Slot {

@@ -311,7 +311,7 @@ class Context:
         st = self.L.jxlh_ctx_create(device, n_slots, C.byref(self._ctx))
         if st != OK:
             raise JxlHipError(st, "jxlh_ctx_create", self.L.jxlh_status_string(st).decode())
-        self._keep = []
+        self._keep = {}  # slot -> host arrays an asynchronous H2D copy of that slot may still read
 
     def close(self):
         if self._ctx:
@@ -377,7 +377,7 @@ class Context:
         if isinstance(coeffs, np.ndarray):
             coeffs = np.ascontiguousarray(coeffs, dtype=np.int32)
             assert coeffs.size == 3 * 65536
-            self._keep.append(coeffs)  # async H2D: keep alive until the slot is waited on
+            self._keep.setdefault(slot, []).append(coeffs)  # async H2D: keep alive until the slot is waited on
         self._chk(self.L.jxlh_submit_group(self._ctx, slot, group_id, _addr(coeffs), flags), "submit_group")
 
     def submit_group_sparse(self, group_id, pairs, n, wide=None, slot=0, flags=GROUP_COMPLETE):
@@ -387,7 +387,7 @@ class Context:
         n = np.ascontiguousarray(n, dtype=np.uint32)
         nw = 0 if wide is None else len(wide)
         wide = None if nw == 0 else np.ascontiguousarray(wide, dtype=np.uint32)
-        self._keep.append((pairs, n, wide))
+        self._keep.setdefault(slot, []).append((pairs, n, wide))
         self._chk(self.L.jxlh_submit_group_sparse(self._ctx, slot, group_id, _addr(pairs) if pairs.size else None,
                                                   _addr(n), None if wide is None else _addr(wide), nw, flags),
                   "submit_group_sparse")
@@ -399,7 +399,7 @@ class Context:
         nw = 0 if wide is None else len(wide)
         wide = None if nw == 0 else np.ascontiguousarray(wide, dtype=np.uint32)
         addr = pairs if isinstance(pairs, int) else _addr(np.ascontiguousarray(pairs, dtype=np.uint32))
-        self._keep.append((group_ids, pairs, n, wide))
+        self._keep.setdefault(slot, []).append((group_ids, pairs, n, wide))
         self._chk(self.L.jxlh_submit_groups_sparse(self._ctx, slot, len(group_ids), _addr(group_ids), addr, _addr(n),
                                                    None if wide is None else _addr(wide), nw, flags),
                   "submit_groups_sparse")
@@ -415,7 +415,7 @@ class Context:
             val = np.ascontiguousarray(val, dtype=np.int8)
         pa = pos if isinstance(pos, int) else _addr(pos)
         va = val if isinstance(val, int) else _addr(val)
-        self._keep.append((group_ids, pos, val, n, wide))
+        self._keep.setdefault(slot, []).append((group_ids, pos, val, n, wide))
         self._chk(self.L.jxlh_submit_groups_sparse8(self._ctx, slot, len(group_ids), _addr(group_ids), pa, va, _addr(n),
                                                     None if wide is None else _addr(wide), nw, flags),
                   "submit_groups_sparse8")
@@ -430,7 +430,7 @@ class Context:
 
     def slot_wait(self, slot=0):
         self._chk(self.L.jxlh_slot_wait(self._ctx, slot), "slot_wait")
-        self._keep.clear()
+        self._keep.pop(slot, None)
 
     def coeff_buffer(self):
         p, n = C.c_void_p(), C.c_size_t()

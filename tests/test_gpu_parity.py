@@ -1266,3 +1266,71 @@ def test_rgb8_output_argument_errors(ctx, oracle, kat):
         ctx.read_rgb8(params, 2)          # channels must be 3 or 4
     with pytest.raises(JxlHipError):
         ctx.read_rgb8(params, 3, 10, 10)  # empty row range
+
+
+@pytest.mark.parametrize("form", ["dense", "sparse", "mixed"])
+def test_concurrent_submission_from_host_threads(oracle, form):
+    """jxlh_ctx_create's n_slots = the number of host threads that call jxlh_submit_group* concurrently (the
+    JxlParallelRunner's threads, jxl/src/api/mod.rs:77-81): six threads, one slot each, submit the groups of a frame at
+    the same time (ctypes releases the GIL for the duration of a call), a seventh thread runs and reads the frame.  HIP's
+    current device is per-thread state: every entry point selects the context's device itself."""
+    import threading
+
+    import helpers
+    from jxl_rs_amd import Context, synth
+    wl = synth.make_vardct(1500, 1100, mix=synth.MIX_ALL, seed=77, epf_iters=2)
+    want, want_lf = helpers.run_oracle_frame(oracle, wl)
+    nthreads = 6
+    ctx = Context(0, n_slots=nthreads)
+    try:
+        for rep in range(3):  # epochs: the bookkeeping of one frame must not leak into the next
+            p = helpers.gpu_params_from(ctx, wl)
+            ctx.frame_begin(p)
+            ctx.set_dequant_tables(wl.tables)
+            ctx.set_lf_quantized(*wl.lf_q)
+            ctx.set_hf_meta(wl.transform_map, wl.raw_quant, wl.epf_map, wl.ytox, wl.ytob)
+            ng = wl.coeffs.shape[0]
+            sparse = {g: synth.to_sparse(wl.coeffs[g]) for g in range(ng)} if form != "dense" else {}
+            errors = []
+            start = threading.Barrier(nthreads)
+
+            def worker(t):
+                try:
+                    start.wait()
+                    for g in range(t, ng, nthreads):
+                        use_sparse = form == "sparse" or (form == "mixed" and (g + rep) % 2 == 0)
+                        if use_sparse:
+                            ctx.submit_group_sparse(g, *sparse[g], slot=t)
+                        else:
+                            ctx.submit_group(g, wl.coeffs[g], slot=t)
+                    ctx.slot_wait(t)
+                except Exception as e:  # noqa: BLE001 - reported by the main thread
+                    errors.append(f"thread {t}: {type(e).__name__}: {e}")
+
+            ths = [threading.Thread(target=worker, args=(t,)) for t in range(nthreads)]
+            for th in ths:
+                th.start()
+            for th in ths:
+                th.join()
+            assert not errors, errors
+            out = {}
+
+            def runner():
+                try:
+                    ctx.frame_run()
+                    ctx.sync()
+                    out["planes"] = ctx.read_planes()
+                    out["lf"] = ctx.read_lf()
+                except Exception as e:  # noqa: BLE001
+                    errors.append(f"runner: {type(e).__name__}: {e}")
+
+            th = threading.Thread(target=runner)
+            th.start()
+            th.join()
+            assert not errors, errors
+            for c in range(3):
+                assert helpers.bit_equal(out["lf"][c], want_lf[c]), f"{form} rep {rep} LF {c}"
+                assert helpers.bit_equal(out["planes"][c], want[c]), \
+                    f"{form} rep {rep} plane {c}: {helpers.diff_report(out['planes'][c], want[c])}"
+    finally:
+        ctx.close()
