@@ -14,9 +14,11 @@
  *     device (HIP) pointer -- uploads/downloads use hipMemcpyDefault
  *   - plane descriptor == RawImageBuffer / JxlOutputBuffer::new_from_ptr
  *     (jxl/src/image/internal.rs:15-31, image/output_buffer.rs:32-52)
- *   - frame-level calls are single-threaded; jxlh_submit_group is re-entrant per
- *     `slot` (one HIP stream + one pinned staging slab per slot, mirroring
- *     PerThreadStorage, jxl/src/util/per_thread_storage.rs:13-60)
+ *   - frame-level calls are single-threaded (any ONE thread at a time, not necessarily the
+ *     same one); the jxlh_submit_group* calls are re-entrant per `slot` (one HIP stream + one
+ *     pinned staging slab per slot, mirroring PerThreadStorage,
+ *     jxl/src/util/per_thread_storage.rs:13-60).  Every entry point makes the context's device
+ *     the calling thread's current HIP device, so pool threads need no device set-up
  *   - channel order is X, Y, B everywhere (pipeline channels 0, 1, 2)
  */
 #ifndef JXL_HIP_H_
