@@ -241,9 +241,50 @@ int gpu_frame(int w, int h, int epf_iters) {
     } catch (const Error& e) {
       threw = e.status == JXLH_ERR_INVALID_ARGUMENT;
     }
-    printf("%dx%d epf_iters=%d groups=%d through RenderPipelineBuilder, two passes: %zu differing rows, error path %s\n", w, h,
-           epf_iters, F.ngroups, bad, threw ? "ok" : "MISSING");
-    return (bad == 0 && threw && !g_failed) ? 0 : 1;
+    // the same frame with the colour tail of frame/render.rs:755-790 in the stage list: XybStage, FromLinearStage (sRGB),
+    // three ConvertF32ToU8Stage, save as RGBA -- against the oracle's output stage on the oracle's planes
+    size_t bad8 = 0;
+    {
+      JxloXybParams ox;
+      const float mat[9] = {11.031566901960783f, -9.866943921568629f, -0.16462299647058826f, -3.254147380392157f,
+                            4.418770392156863f, -0.16462299647058826f, -3.6588512862745097f, 2.7129230470588235f,
+                            1.9459282392156863f};
+      const float bias[3] = {-0.0037930732552754493f, -0.0037930732552754493f, -0.0037930732552754493f};
+      jxlo_xyb_params(mat, bias, 255.0f, &ox);
+      jxlh_xyb_params gx;
+      memcpy(gx.opsin_inverse_matrix, ox.mat, sizeof(ox.mat));
+      memcpy(gx.bias_cbrt, ox.bias_cbrt, sizeof(ox.bias_cbrt));
+      memcpy(gx.scaled_bias, ox.scaled_bias, sizeof(ox.scaled_bias));
+      gx.intensity_scale = ox.intensity_scale;
+      Context ctx2(0, 1);
+      auto b2 = add_filters(RenderPipelineBuilder(3, {(size_t)w, (size_t)h}, 0, 8, base), rf_of(base), true, epf_iters);
+      auto pipe2 = std::move(b2)
+                       .add_inplace_stage(XybStage{0, gx})
+                       .add_inplace_stage(FromLinearStage{0, JXLH_TF_SRGB, 0.0f, {0.f, 0.f, 0.f}})
+                       .add_inout_stage(ConvertF32ToU8Stage{0, 8})
+                       .add_inout_stage(ConvertF32ToU8Stage{1, 8})
+                       .add_inout_stage(ConvertF32ToU8Stage{2, 8})
+                       .add_save_stage({0, 1, 2}, 0, 4, 8)
+                       .build(ctx2);
+      VarDctFrame& f2 = pipe2->frame();
+      f2.decode_hf_global(F.tables);
+      f2.decode_lf_group(0, 0, (uint32_t)F.xb, (uint32_t)F.yb, F.qy.data(), F.qx.data(), F.qb.data(), (size_t)F.xb);
+      f2.decode_hf_metadata(0, 0, (uint32_t)F.xb, (uint32_t)F.yb, F.tmap.data(), F.rq.data(), F.epf.data(), (size_t)F.xb,
+                            F.ytox.data(), F.ytob.data(), (size_t)F.cw);
+      for (int g = 0; g < F.ngroups; g++) pipe2->set_buffer_for_group((uint32_t)g, true, &F.coeffs[(size_t)g * 3 * 65536]);
+      pipe2->do_render();
+      std::vector<uint8_t> got((size_t)w * h * 4), want((size_t)w * h * 4);
+      pipe2->check_buffer_sizes((size_t)w * 4, (size_t)h);
+      pipe2->save(got.data());
+      jxlo_xyb_to_rgb8(&ox, F.pl[0].data(), F.pl[1].data(), F.pl[2].data(), (size_t)w, (size_t)h, F.stride, want.data(),
+                       (size_t)w * 4, 4);
+      for (int y = 0; y < h; y++)
+        if (memcmp(&got[(size_t)y * w * 4], &want[(size_t)y * w * 4], (size_t)w * 4) != 0) bad8++;
+    }
+    printf("%dx%d epf_iters=%d groups=%d through RenderPipelineBuilder, two passes: %zu differing rows, RGBA8 tail: %zu differing "
+           "rows, error path %s\n",
+           w, h, epf_iters, F.ngroups, bad, bad8, threw ? "ok" : "MISSING");
+    return (bad == 0 && bad8 == 0 && threw && !g_failed) ? 0 : 1;
   } catch (const std::exception& e) {
     fprintf(stderr, "device path failed: %s\n", e.what());
     return 3;

@@ -56,4 +56,5 @@ def test_pipeline_builder_frame_two_passes(tmp_path, args):
     exe = _build(tmp_path, "pipeline_builder")
     r = subprocess.run([exe, "gpu", *args], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
-    assert "0 differing rows" in r.stdout and "error path ok" in r.stdout
+    assert "two passes: 0 differing rows" in r.stdout and "RGBA8 tail: 0 differing rows" in r.stdout \
+        and "error path ok" in r.stdout
