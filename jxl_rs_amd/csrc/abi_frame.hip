@@ -262,6 +262,7 @@ jxlh_status jxlh_frame_begin(jxlh_ctx* ctx, const jxlh_frame_params* p) {
   if ((st = ensure(ctx, ctx->ytob, ncmap)) != JXLH_OK) return st;
   if ((st = ensure(ctx, ctx->error_flag, 1)) != JXLH_OK) return st;
   if ((st = ensure(ctx, ctx->worklist, vardct_worklist_bytes(f))) != JXLH_OK) return st;
+  vardct_worklist_reset(ctx->stream, ctx->worklist.p, &ctx->k1_launches);
   HIPCHK(ctx, hipMemsetAsync(ctx->error_flag.p, 0, sizeof(int), ctx->stream));
   // rects the caller never sets read as "not the first block of a varblock" (no work item, no stale map bytes of
   // an earlier frame reaching K1)
@@ -658,7 +659,7 @@ jxlh_status run_k1(jxlh_ctx* ctx, const RunPlan& plan, int gr0, int gr1) {
     FrameDev fk = f;
     for (int c = 0; c < 3; c++)
       if (f.hshift[c] | f.vshift[c]) fk.planes[c] = f.tmp[c];
-    launch_vardct_groups(ctx->stream, fk, gr0, gr1, ctx->worklist.p, ctx->error_flag.p,
+    launch_vardct_groups(ctx->stream, fk, gr0, gr1, ctx->worklist.p, &ctx->k1_launches, ctx->error_flag.p,
                          sparse_k1 ? ctx->coeffs.p : nullptr, nullptr, 0, ctx->has_special, ctx->has_large);
   }
   // the coefficient slabs are free again: dense resubmissions of the next frame wait for this (jxlh_submit_group)
@@ -859,7 +860,7 @@ jxlh_status jxlh_frame_rerender_groups(jxlh_ctx* ctx, const uint32_t* group_ids,
     f.sp_slot_start = plan.sparse_k1 ? ctx->sp_slot_start.p : nullptr;
     f.group_dense = plan.sparse_k1 ? ctx->group_dense.p : nullptr;
     if (plan.sparse_k1) HIPCHK(ctx, hipMemsetAsync(ctx->group_dense.p, 0, ctx->ngroups, ctx->stream));
-    launch_vardct_groups(ctx->stream, f, 0, 0, ctx->worklist.p, ctx->error_flag.p,
+    launch_vardct_groups(ctx->stream, f, 0, 0, ctx->worklist.p, &ctx->k1_launches, ctx->error_flag.p,
                          plan.sparse_k1 ? ctx->coeffs.p : nullptr, ctx->rerender_list.p, n, ctx->has_special,
                          ctx->has_large);
   }

@@ -109,6 +109,7 @@ struct jxlh_ctx {
   // recorded behind the transforms of every jxlh_frame_run: dense resubmissions wait for it
   hipEvent_t k1_done = nullptr;
   bool k1_done_valid = false;
+  uint32_t k1_launches = 0;  // parity selects the work-list counter set (vardct_worklist_reset / launch_vardct_groups)
   // K1 reading the pairs directly: the frame's pairs bucketed by varblock slot + slot tables.  Valid
   // while every group of the frame has been submitted sparse (once) and nothing was resubmitted.
   DevBuf<uint32_t> sp_sorted, sp_slot_start;

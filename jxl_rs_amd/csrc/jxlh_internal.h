@@ -184,12 +184,16 @@ void launch_lf_smooth(hipStream_t s, const float* const in[3], float* const out[
                       const float lf_factors[3]);
 void launch_sigma_map(hipStream_t s, const FrameDev& f, float epf_quant_mul, const float* sharp_lut);
 // K1: work-list scan + per-class kernels over group rows [group_row0, group_row1).
-// worklist_mem: device scratch of vardct_worklist_bytes(f) bytes.
+// worklist_mem: device scratch of vardct_worklist_bytes(f) bytes.  It opens with TWO sets of class counters, both
+// zeroed by vardct_worklist_reset() when a frame begins: launch n counts in set n & 1 and its scan kernel clears the
+// other set for launch n + 1 (whose last readers, the kernels of launch n - 1, are behind it in stream order) -- no
+// memset launch inside K1's serial sequence.  *launch_parity is the caller's per-context launch counter.
 size_t vardct_worklist_bytes(const FrameDev& f);
+void vardct_worklist_reset(hipStream_t s, void* worklist_mem, uint32_t* launch_parity);
 // dense_coeffs: writable alias of f.coeffs, used in sparse mode to expand the groups k1_scan flags
 // group_list (device, n_list entries) replaces the row range by an explicit list of group ids when non-null
 void launch_vardct_groups(hipStream_t s, const FrameDev& f, int group_row0, int group_row1,
-                          void* worklist_mem, int* error_flag, int32_t* dense_coeffs,
+                          void* worklist_mem, uint32_t* launch_parity, int* error_flag, int32_t* dense_coeffs,
                           const int* group_list = nullptr, int n_list = 0, bool has_special = true,
                           bool has_large = true);
 void launch_gaborish(hipStream_t s, const float* in, float* out, int w, int h, size_t stride, float k0, float k1,

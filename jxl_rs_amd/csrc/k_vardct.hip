@@ -52,11 +52,14 @@ constexpr int kScanGroups = 4;
 constexpr int kScanThreads = kScanGroups * kThreads;
 __global__ __launch_bounds__(kScanThreads) void k1_scan(const FrameDev f, const WorkLists wl, const int group_row0,
                                                          int* __restrict__ error_flag,
-                                                         const int* __restrict__ group_list, const int ngroups) {
+                                                         const int* __restrict__ group_list, const int ngroups,
+                                                         int* __restrict__ next_counts) {
   constexpr int kPairs = (kNumClasses + 1) / 2;
   __shared__ int s_wave_sum[kScanGroups][kWaves];
   __shared__ uint32_t s_wcls[kScanGroups][kWaves][kPairs];
   __shared__ int s_count[kScanGroups][kNumClasses], s_base[kScanGroups][kNumClasses];
+  // the counters of the NEXT launch (the other set: its last readers finished before this kernel started)
+  if (blockIdx.x == 0 && threadIdx.x <= kNumClasses) next_counts[threadIdx.x * kCountPitch] = 0;
   const int sub = threadIdx.x / kThreads, tid = threadIdx.x % kThreads, lane = tid & 63, wave = tid >> 6;
   const int gi = blockIdx.x * kScanGroups + sub;
   const bool live = gi < ngroups;  // a dead quarter walks through the barriers with an empty group
@@ -684,28 +687,34 @@ size_t vardct_worklist_bytes(const FrameDev& f) {
   // + the slab-unit list of the large transforms: one u32 per 4096 samples of large-varblock area, but a 64x32 /
   // 32x64 varblock (32 blocks, half a slab) still takes a whole unit -> worst case one unit per 32 blocks
   // + the LLF planes of the large transforms (3 x nblocks floats, k1_large_llf)
-  return items * sizeof(WorkItem) + kCountBytes + large_unit_capacity(nblocks) * sizeof(uint32_t) + 64 +
+  return items * sizeof(WorkItem) + 2 * kCountBytes + large_unit_capacity(nblocks) * sizeof(uint32_t) + 64 +
          3 * nblocks * sizeof(float);
 }
 
+void vardct_worklist_reset(hipStream_t s, void* worklist_mem, uint32_t* launch_parity) {
+  (void)hipMemsetAsync(worklist_mem, 0, 2 * kCountBytes, s);
+  *launch_parity = 0;
+}
+
 void launch_vardct_groups(hipStream_t s, const FrameDev& f, int group_row0, int group_row1,
-                          void* worklist_mem, int* error_flag, int32_t* dense_coeffs, const int* group_list,
-                          int n_list, bool has_special, bool has_large) {
+                          void* worklist_mem, uint32_t* launch_parity, int* error_flag, int32_t* dense_coeffs,
+                          const int* group_list, int n_list, bool has_special, bool has_large) {
   const int ngroups = group_list ? n_list : (group_row1 - group_row0) * f.xgroups;
   if (ngroups <= 0) return;
-  // carve the work-list memory: [counters, one 128-byte line each] [class 0 items] [class 1 items] ...
+  // carve the work-list memory: [two sets of counters, one 128-byte line each] [class 0 items] [class 1 items] ...
   WorkLists wl;
-  wl.counts = reinterpret_cast<int*>(worklist_mem);
-  char* p = reinterpret_cast<char*>(worklist_mem) + kCountBytes;
+  const uint32_t set = (*launch_parity)++ & 1u;
+  wl.counts = reinterpret_cast<int*>(reinterpret_cast<char*>(worklist_mem) + set * kCountBytes);
+  int* next_counts = reinterpret_cast<int*>(reinterpret_cast<char*>(worklist_mem) + (set ^ 1u) * kCountBytes);
+  char* p = reinterpret_cast<char*>(worklist_mem) + 2 * kCountBytes;
   const size_t nblocks = (size_t)f.xblocks * f.yblocks;
   for (int c = 0; c < kNumClasses; c++) {
     wl.items[c] = reinterpret_cast<WorkItem*>(p);
     p += (nblocks / class_min_area(c) + 1) * sizeof(WorkItem);
   }
   uint32_t* large_units = reinterpret_cast<uint32_t*>(p);  // behind the last class list
-  (void)hipMemsetAsync(wl.counts, 0, kCountBytes, s);  // [kNumClasses] = slab units of the large class
   hipLaunchKernelGGL(k1_scan, dim3((ngroups + kScanGroups - 1) / kScanGroups), dim3(kScanThreads), 0, s, f, wl, group_row0,
-                     error_flag, group_list, ngroups);
+                     error_flag, group_list, ngroups, next_counts);
   // grids: enough waves to fill the chip; kernels stride over their lists (counts are device-side)
   const int nblk = ngroups * kGroupBlocks * kGroupBlocks;
   auto grid_for = [](long work_items, int items_per_wg, int cap) {
