@@ -45,19 +45,20 @@ __global__ void probe(int* out, long long* cyc, int y) {
   if (threadIdx.x == 0) cyc[0] = t1 - t0;
 }
 template <int CHAINS, int OP>
-void run(const char* name, int* out, long long* cyc) {
+void run(const char* name, int* out, long long* cyc, int lanes = 64) {
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
-  probe<CHAINS, OP><<<1, 64>>>(out, cyc, 3);
+  probe<CHAINS, OP><<<1, lanes>>>(out, cyc, 3);
   hipDeviceSynchronize();
   hipEventRecord(e0);
-  probe<CHAINS, OP><<<1, 64>>>(out, cyc, 3);
+  probe<CHAINS, OP><<<1, lanes>>>(out, cyc, 3);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
   long long c; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
   const int per = (OP == 3) ? 2 : 1;
   const double n = (double)ITER * (REP / CHAINS) * CHAINS * per;
+  if (lanes != 64) printf("[%2d active lanes] ", lanes);
   printf("%-28s chains=%d  %.2f ns/instr  (%.2f counter ticks/instr, kernel %.3f ms)\n", name, CHAINS, ms * 1e6 / n, c / n, ms);
 }
 int main() {
@@ -69,5 +70,10 @@ int main() {
   run<1, 3>("v_cmp+v_cndmask", out, cyc); run<2, 3>("v_cmp+v_cndmask", out, cyc);
   run<1, 4>("v_mul_hi_u32_u24", out, cyc); run<2, 4>("v_mul_hi_u32_u24", out, cyc);
   run<1, 5>("v_mul_f32", out, cyc); run<4, 5>("v_mul_f32", out, cyc);
+  // does a wave with fewer active lanes issue faster?  (EXEC = the low 32 / 16 lanes: a block of 32 / 16 threads)
+  for (int lanes : {32, 16}) {
+    run<1, 0>("v_add_u32", out, cyc, lanes); run<4, 0>("v_add_u32", out, cyc, lanes);
+    run<1, 1>("v_mul_hi_i32", out, cyc, lanes); run<1, 2>("v_min3_i32", out, cyc, lanes);
+  }
   return 0;
 }
