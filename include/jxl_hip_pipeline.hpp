@@ -137,6 +137,22 @@ struct ConvertF32ToU16Stage {  // convert.rs:724, :767-768
   }
   bool uses_channel(int c) const { return c == channel; }
 };
+struct ConvertModularToF32Stage {  // convert.rs:351, :512-513 (bit_depth: integer samples of that many bits)
+  int channel;
+  uint8_t bit_depth;
+  static constexpr Border BORDER{0, 0}, SHIFT{0, 0};
+  std::string display() const {
+    return "convert modular data to F32 in channel " + std::to_string(channel) + " with bit depth " + std::to_string(bit_depth);
+  }
+  bool uses_channel(int c) const { return c == channel; }
+};
+struct ConvertModularXYBToF32Stage {  // convert.rs:284, :309-310; quant_factors = LfQuantFactors::quant_factors (X, Y, B)
+  int first_channel;
+  std::array<float, 3> quant_factors;
+  static constexpr Border BORDER{0, 0}, SHIFT{0, 0};
+  std::string display() const { return "convert modular xyb data to F32 in channels 0..3"; }
+  bool uses_channel(int c) const { return c >= first_channel && c < first_channel + 3; }
+};
 // A stage of the reference this path does not run on the device (patches, splines, blending, extend, spot colour,
 // premultiplied alpha, extra-channel conversions ...): adding one makes build() fail with JXLH_ERR_UNSUPPORTED.
 struct CpuOnlyStage {
@@ -158,7 +174,7 @@ struct SaveStage {
   }
 };
 
-using Stage = std::variant<HorizontalChromaUpsample, VerticalChromaUpsample, GaborishStage, Epf0Stage, Epf1Stage, Epf2Stage,
+using Stage = std::variant<ConvertModularToF32Stage, ConvertModularXYBToF32Stage, HorizontalChromaUpsample, VerticalChromaUpsample, GaborishStage, Epf0Stage, Epf1Stage, Epf2Stage,
                            Upsample2x, Upsample4x, Upsample8x, ConvolveNoiseStage, AddNoiseStage, XybStage, YcbcrToRgbStage,
                            FromLinearStage, ConvertF32ToU8Stage, ConvertF32ToU16Stage, CpuOnlyStage, SaveStage>;
 
@@ -173,6 +189,11 @@ struct LoweredPipeline {
   bool has_output = false;     // a colour / conversion tail was given: read through jxlh_frame_read_output
   jxlh_output_desc output{};
   const float* upsampling_weights = nullptr;
+  // Modular frames (Encoding::Modular: the list opens with the Modular -> f32 conversions, frame/render.rs:553-567)
+  enum class Modular { kNone, kToF32, kXybToF32, kI32ToU8 } modular = Modular::kNone;
+  uint32_t modular_bits = 0;                       // kToF32: bits per integer sample
+  std::array<float, 3> modular_quant_factors{};    // kXybToF32
+  int32_t i32_to_u8_multiplier = 0, i32_to_u8_max = 0;  // kI32ToU8: ConvertI32ToU8Stage::new(c, mult, max), builder.rs:152-170
   Border input_border{0, 0};   // accumulated BORDER of the in-out stages before any upsampling, in input pixels
   std::vector<std::string> stages;  // Display strings, in order (diagnostics; what `info!("adding stage")` logs)
 };
@@ -215,6 +236,8 @@ class RenderPipelineBuilder {
   LoweredPipeline lower() const;
   // builder.rs:120: returns the pipeline (here: begins the frame on the context with the lowered parameters)
   std::unique_ptr<GpuRenderPipeline> build(Context& ctx) &&;
+  // the same for a Modular frame's list (it opens with ConvertModularToF32Stage x3 or ConvertModularXYBToF32Stage)
+  std::unique_ptr<class GpuModularPipeline> build_modular(Context& ctx) &&;
 
  private:
   [[noreturn]] static void fail(jxlh_status st, const std::string& what) { throw Error(st, "RenderPipelineBuilder::build", what); }
@@ -239,14 +262,14 @@ inline LoweredPipeline RenderPipelineBuilder::lower() const {
   p.noise = 0;
   for (int c = 0; c < 3; c++) p.hshift[c] = p.vshift[c] = 0;
   // The reference's order (frame/render.rs:568-790) as phases; a stage may only appear in a phase >= the current one.
-  enum Phase { kChroma, kGab, kEpf0, kEpf1, kEpf2, kUpsample, kNoiseConvolve, kNoiseAdd, kColour, kTransfer, kConvert, kSave, kDone };
-  int phase = kChroma;
+  enum Phase { kModular, kChroma, kGab, kEpf0, kEpf1, kEpf2, kUpsample, kNoiseConvolve, kNoiseAdd, kColour, kTransfer, kConvert, kSave, kDone };
+  int phase = kModular;
   auto enter = [&](int ph, const Stage& s) {
     if (ph < phase) fail(JXLH_ERR_UNSUPPORTED, "stage '" + stage_display(s) + "' out of the order of Frame::build_render_pipeline");
     phase = ph;
   };
   bool gab_seen[3] = {false, false, false};
-  int ups_seen = 0, ups_factor = 0, conv_seen = 0, convert_seen = 0;
+  int ups_seen = 0, ups_factor = 0, conv_seen = 0, convert_seen = 0, modular_seen = 0;
   uint32_t convert_bits = 0;
   bool have_colour = false, have_tf = false, have_save = false, pre_upsample = true, epf1_seen = false, epf2_seen = false;
   Border border{0, 0};
@@ -264,6 +287,21 @@ inline LoweredPipeline RenderPipelineBuilder::lower() const {
     lp.stages.push_back(stage_display(s));
     if (const auto* st = std::get_if<CpuOnlyStage>(&s)) {
       fail(JXLH_ERR_UNSUPPORTED, "stage '" + st->name + "' is not part of the device path");
+    } else if (const auto* m = std::get_if<ConvertModularToF32Stage>(&s)) {
+      enter(kModular, s);
+      if (m->channel != modular_seen || m->channel > 2 || lp.modular == LoweredPipeline::Modular::kXybToF32)
+        fail(m->channel > 2 ? JXLH_ERR_UNSUPPORTED : JXLH_ERR_INVALID_ARGUMENT, "Modular -> f32 conversion: channels 0, 1, 2 in order (extra channels stay on the CPU pipeline)");
+      if (modular_seen && m->bit_depth != lp.modular_bits) fail(JXLH_ERR_UNSUPPORTED, "colour channels of different bit depths");
+      if (m->bit_depth < 1 || m->bit_depth > 31) fail(JXLH_ERR_INVALID_ARGUMENT, "bit depth");
+      lp.modular = LoweredPipeline::Modular::kToF32;
+      lp.modular_bits = m->bit_depth;
+      modular_seen++;
+    } else if (const auto* mx = std::get_if<ConvertModularXYBToF32Stage>(&s)) {
+      enter(kModular, s);
+      if (mx->first_channel != 0 || lp.modular != LoweredPipeline::Modular::kNone) fail(JXLH_ERR_INVALID_ARGUMENT, "one XYB conversion on channels 0..2");
+      lp.modular = LoweredPipeline::Modular::kXybToF32;
+      lp.modular_quant_factors = mx->quant_factors;
+      modular_seen = 3;
     } else if (const auto* h = std::get_if<HorizontalChromaUpsample>(&s)) {
       enter(kChroma, s);
       if (h->channel < 0 || h->channel > 2) fail(JXLH_ERR_INVALID_ARGUMENT, "chroma upsampling of a non-colour channel");
@@ -383,6 +421,28 @@ inline LoweredPipeline RenderPipelineBuilder::lower() const {
     }
   }
   // consistency of the whole list
+  if (lp.modular == LoweredPipeline::Modular::kToF32 && modular_seen != 3) fail(JXLH_ERR_INVALID_ARGUMENT, "Modular -> f32 conversion on some channels only");
+  if (lp.modular != LoweredPipeline::Modular::kNone) {
+    // what this path runs for a Modular frame: the conversion, Gaborish / EPF with the constant sigma of
+    // features/epf.rs:81-84 (jxlh_modular_frame_filters), then either the planes themselves or -- the builder's special
+    // case -- straight to bytes
+    if (p.upsampling != 1 || p.noise || p.hshift[0] | p.hshift[1] | p.hshift[2] | p.vshift[0] | p.vshift[1] | p.vshift[2])
+      fail(JXLH_ERR_UNSUPPORTED, "upsampling / noise / chroma subsampling on a Modular frame");
+    const bool untouched = !p.gab && p.epf_iters == 0 && !have_colour && !have_tf;
+    if (convert_seen == 3) {
+      // builder.rs:152-170: ConvertModularToF32(c, d) whose next use is ConvertF32ToU8(c, b) with b % d == 0 becomes
+      // ConvertI32ToU8Stage(c, ((1 << b) - 1) / ((1 << d) - 1), (1 << b) - 1) and the second stage disappears
+      if (lp.modular == LoweredPipeline::Modular::kToF32 && untouched && convert_bits == 8 && 8 % lp.modular_bits == 0) {
+        lp.modular = LoweredPipeline::Modular::kI32ToU8;
+        lp.i32_to_u8_multiplier = 255 / ((1 << lp.modular_bits) - 1);
+        lp.i32_to_u8_max = 255;
+      } else {
+        fail(JXLH_ERR_UNSUPPORTED, "integer output of a Modular frame other than the I32 -> U8 special case");
+      }
+    } else if (have_colour || have_tf) {
+      fail(JXLH_ERR_UNSUPPORTED, "colour stages on a Modular frame");
+    }
+  }
   if (p.gab && !(gab_seen[0] && gab_seen[1] && gab_seen[2])) fail(JXLH_ERR_INVALID_ARGUMENT, "Gaborish on some channels only");
   if (p.epf_iters == 3 && !(epf1_seen && epf2_seen)) fail(JXLH_ERR_UNSUPPORTED, "EPF0 without EPF1 and EPF2 (epf_iters >= 3 runs all three)");
   if (ups_seen != 0 && ups_seen != 3) fail(JXLH_ERR_INVALID_ARGUMENT, "frame upsampling on some channels only");
@@ -465,8 +525,57 @@ class GpuRenderPipeline {
   bool dirty_ = false, dirty_first_ = true;
 };
 
+// A Modular frame's stage list on the device: the samples come out of the Modular inverse transforms (jxlh_rct,
+// jxlh_palette*, jxlh_unsqueeze_chain) as three i32 planes, host or device memory.
+class GpuModularPipeline {
+ public:
+  GpuModularPipeline(Context& ctx, LoweredPipeline lp) : ctx_(ctx), lp_(std::move(lp)) {
+    if (lp_.modular == LoweredPipeline::Modular::kNone)
+      throw Error(JXLH_ERR_INVALID_ARGUMENT, "GpuModularPipeline", "the stage list holds no Modular conversion");
+  }
+  const LoweredPipeline& lowered() const { return lp_; }
+  // ConvertI32ToU8Stage: interleaved bytes (3 or 4 per pixel) in one pass
+  void render_u8(const int32_t* const planes[3], size_t stride, void* out, size_t bytes_per_row) {
+    if (lp_.modular != LoweredPipeline::Modular::kI32ToU8)
+      throw Error(JXLH_ERR_INVALID_ARGUMENT, "GpuModularPipeline::render_u8", "not the I32 -> U8 special case");
+    ctx_.check(jxlh_modular_to_rgb8(ctx_.raw(), planes, stride, lp_.frame.xsize, lp_.frame.ysize, lp_.i32_to_u8_multiplier,
+                                    lp_.i32_to_u8_max, lp_.output.channels, out, bytes_per_row),
+               "jxlh_modular_to_rgb8");
+  }
+  // conversion to f32 and, if the list holds them, Gaborish / EPF with the frame's constant sigma
+  // (jxlh_modular_frame_filters: device planes, 16-byte aligned, row stride a multiple of 4 floats, tmp != out).
+  // in[] in coded order for an XYB frame (Y, X, B); the result (X, Y, B) lands in out[]; tmp[] is only used when the
+  // list holds filters.  Planes are tight: stride = xsize, which must then be a multiple of 4.
+  void render_f32(const int32_t* const in[3], float* const tmp[3], float* const out[3]) {
+    const size_t w = lp_.frame.xsize, h = lp_.frame.ysize, n = w * h;
+    const bool filters = lp_.frame.gab || lp_.frame.epf_iters;
+    float* const* dst = filters ? tmp : out;
+    if (lp_.modular == LoweredPipeline::Modular::kXybToF32) {
+      ctx_.check(jxlh_modular_xyb_to_f32(ctx_.raw(), in[0], in[1], in[2], n, lp_.modular_quant_factors.data(), dst[0], dst[1], dst[2]),
+                 "jxlh_modular_xyb_to_f32");
+    } else if (lp_.modular == LoweredPipeline::Modular::kToF32) {
+      for (int c = 0; c < 3; c++)
+        ctx_.check(jxlh_modular_to_f32(ctx_.raw(), in[c], n, lp_.modular_bits, dst[c]), "jxlh_modular_to_f32");
+    } else {
+      throw Error(JXLH_ERR_INVALID_ARGUMENT, "GpuModularPipeline::render_f32", "the list lowers to the I32 -> U8 special case");
+    }
+    if (filters) {
+      if (w % 4) throw Error(JXLH_ERR_UNSUPPORTED, "GpuModularPipeline::render_f32", "filters need a row length that is a multiple of 4 samples");
+      ctx_.check(jxlh_modular_frame_filters(ctx_.raw(), &lp_.frame, tmp, out, (uint32_t)w, (uint32_t)h, w), "jxlh_modular_frame_filters");
+    }
+  }
+
+ private:
+  Context& ctx_;
+  LoweredPipeline lp_;
+};
+
 inline std::unique_ptr<GpuRenderPipeline> RenderPipelineBuilder::build(Context& ctx) && {
   return std::make_unique<GpuRenderPipeline>(ctx, lower());
+}
+
+inline std::unique_ptr<GpuModularPipeline> RenderPipelineBuilder::build_modular(Context& ctx) && {
+  return std::make_unique<GpuModularPipeline>(ctx, lower());
 }
 
 }  // namespace jxlh

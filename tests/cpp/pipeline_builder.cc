@@ -2,6 +2,7 @@
 // code.  Built and run by tests/test_cpp_host.py.
 //   pipeline_builder host           the lowering of stage lists onto jxlh_frame_params / jxlh_output_desc and the
 //                                   rejection of lists outside the device path -- pure host logic, no GPU
+//   pipeline_builder modular W H    Modular stage lists: the builder's I32 -> U8 special case, the f32 conversion, f32 + filters
 //   pipeline_builder gpu W H ITERS  a frame assembled exactly as Frame::build_render_pipeline assembles it
 //                                   (frame/render.rs:526-790), decoded through GpuRenderPipeline in two passes
 //                                   (incomplete groups, then complete + mark_group_to_rerender), against the oracle
@@ -10,6 +11,8 @@
 #include <cstring>
 #include <functional>
 #include <string>
+
+#include <hip/hip_runtime_api.h>
 
 #include "jxl_hip_pipeline.hpp"
 #include "synth_frame.hpp"
@@ -193,6 +196,46 @@ int host_checks() {
   expect(status_of([&] { (void)RenderPipelineBuilder(3, {999, 700}, 0, 8, base).add_save_stage({0, 1, 2}, 0, 3, 32).lower(); }) ==
              JXLH_ERR_INVALID_ARGUMENT,
          "pipeline size and frame size disagree");
+  // ---- 6. Modular frames: the builder's special case (builder.rs:152-170) and the f32 route
+  {
+    auto list = [&](uint8_t depth, uint8_t out_bits) {
+      auto b = RenderPipelineBuilder(3, {1000, 700}, 0, 8, base)
+                   .add_inout_stage(ConvertModularToF32Stage{0, depth})
+                   .add_inout_stage(ConvertModularToF32Stage{1, depth})
+                   .add_inout_stage(ConvertModularToF32Stage{2, depth});
+      if (out_bits == 8)
+        return std::move(b).add_inout_stage(ConvertF32ToU8Stage{0, 8}).add_inout_stage(ConvertF32ToU8Stage{1, 8})
+            .add_inout_stage(ConvertF32ToU8Stage{2, 8}).add_save_stage({0, 1, 2}, 0, 3, 8).lower();
+      return std::move(b).add_save_stage({0, 1, 2}, 0, 3, 32).lower();
+    };
+    const LoweredPipeline a = list(8, 8), b4 = list(4, 8), f = list(12, 32);
+    expect(a.modular == LoweredPipeline::Modular::kI32ToU8 && a.i32_to_u8_multiplier == 1 && a.i32_to_u8_max == 255, "8-bit Modular -> U8: multiplier 1");
+    expect(b4.modular == LoweredPipeline::Modular::kI32ToU8 && b4.i32_to_u8_multiplier == 17, "4-bit Modular -> U8: multiplier 255 / 15");
+    expect(f.modular == LoweredPipeline::Modular::kToF32 && f.modular_bits == 12 && !f.has_output, "12-bit Modular -> f32 planes");
+    expect(status_of([&] { (void)list(5, 8); }) == JXLH_ERR_UNSUPPORTED, "8 % 5 != 0: no special case, integer output stays on the CPU pipeline");
+    jxlh_frame_params pm = base;
+    pm.epf_sigma_for_modular = 1.5f;
+    auto withf = add_filters(RenderPipelineBuilder(3, {1000, 700}, 0, 8, pm)
+                                 .add_inout_stage(ConvertModularXYBToF32Stage{0, {0.01f, 0.02f, 0.03f}}),
+                             rf, true, 1);
+    const LoweredPipeline x = std::move(withf).add_save_stage({0, 1, 2}, 0, 3, 32).lower();
+    expect(x.modular == LoweredPipeline::Modular::kXybToF32 && x.frame.gab == 1 && x.frame.epf_iters == 1 &&
+               x.modular_quant_factors[2] == 0.03f && x.input_border.x == 3,
+           "lossy Modular (XYB) with Gaborish + EPF1");
+    expect(status_of([&] { (void)RenderPipelineBuilder(3, {1000, 700}, 0, 8, base)
+                                     .add_inout_stage(ConvertModularToF32Stage{0, 8}).add_inout_stage(ConvertModularToF32Stage{1, 8})
+                                     .add_save_stage({0, 1, 2}, 0, 3, 32).lower(); }) == JXLH_ERR_INVALID_ARGUMENT,
+           "Modular conversion on two channels");
+    expect(status_of([&] { (void)RenderPipelineBuilder(4, {1000, 700}, 0, 8, base)
+                                     .add_inout_stage(ConvertModularToF32Stage{3, 8}).add_save_stage({0, 1, 2}, 0, 3, 32).lower(); }) ==
+               JXLH_ERR_UNSUPPORTED,
+           "extra-channel conversion stays on the CPU pipeline");
+    expect(status_of([&] { (void)RenderPipelineBuilder(3, {1000, 700}, 0, 8, base)
+                                     .add_inout_stage(ConvertModularToF32Stage{0, 8}).add_inout_stage(ConvertModularToF32Stage{1, 8})
+                                     .add_inout_stage(ConvertModularToF32Stage{2, 8}).add_inplace_stage(XybStage{0, some_xyb()})
+                                     .add_save_stage({0, 1, 2}, 0, 3, 32).lower(); }) == JXLH_ERR_UNSUPPORTED,
+           "colour stages behind a Modular conversion");
+  }
   // BORDER / SHIFT constants are the reference's
   static_assert(GaborishStage::BORDER.x == 1 && Epf0Stage::BORDER.x == 3 && Epf1Stage::BORDER.y == 2 && Epf2Stage::BORDER.x == 1);
   static_assert(Upsample8x::SHIFT.x == 3 && Upsample2x::BORDER.x == 2 && HorizontalChromaUpsample::SHIFT.x == 1 &&
@@ -290,11 +333,100 @@ int gpu_frame(int w, int h, int epf_iters) {
     return 3;
   }
 }
+// Modular lists on the device: the I32 -> U8 special case against jxlo_i32_to_u8, the f32 conversion against
+// jxlo_modular_to_f32, and the f32 route with Gaborish + EPF1 (constant sigma) run end to end on device planes
+int gpu_modular(int w, int h) {
+  try {
+    Context ctx(0, 1);
+    const jxlh_frame_params base = VarDctFrame::default_params((uint32_t)w, (uint32_t)h);
+    synth::Rng rng{77u + (uint64_t)w * 131 + (uint64_t)h};
+    const size_t n = (size_t)w * h;
+    std::vector<int32_t> pl[3];
+    for (auto& p : pl) {
+      p.resize(n);
+      for (auto& v : p) v = rng.range(-3, 40);  // 5-bit samples with a few out-of-range ones (the stage clamps)
+    }
+    const int32_t* in[3] = {pl[0].data(), pl[1].data(), pl[2].data()};
+    // (a) 4-bit... use 5 bits -> no special case; 4-bit: multiplier 17
+    auto pa = RenderPipelineBuilder(3, {(size_t)w, (size_t)h}, 0, 8, base)
+                  .add_inout_stage(ConvertModularToF32Stage{0, 4}).add_inout_stage(ConvertModularToF32Stage{1, 4})
+                  .add_inout_stage(ConvertModularToF32Stage{2, 4}).add_inout_stage(ConvertF32ToU8Stage{0, 8})
+                  .add_inout_stage(ConvertF32ToU8Stage{1, 8}).add_inout_stage(ConvertF32ToU8Stage{2, 8})
+                  .add_save_stage({0, 1, 2}, 0, 3, 8).build_modular(ctx);
+    std::vector<uint8_t> got(n * 3), want(n * 3), ch(n);
+    pa->render_u8(in, (size_t)w, got.data(), (size_t)w * 3);
+    for (int c = 0; c < 3; c++) {
+      jxlo_i32_to_u8(pl[c].data(), n, 17, 255, ch.data());
+      for (size_t i = 0; i < n; i++) want[i * 3 + c] = ch[i];
+    }
+    const bool u8_ok = got == want;
+    // (b) 12-bit samples to f32 planes
+    auto pb = RenderPipelineBuilder(3, {(size_t)w, (size_t)h}, 0, 8, base)
+                  .add_inout_stage(ConvertModularToF32Stage{0, 12}).add_inout_stage(ConvertModularToF32Stage{1, 12})
+                  .add_inout_stage(ConvertModularToF32Stage{2, 12}).add_save_stage({0, 1, 2}, 0, 3, 32).build_modular(ctx);
+    std::vector<float> f[3], fw(n);
+    float* fo[3];
+    for (int c = 0; c < 3; c++) {
+      f[c].resize(n);
+      fo[c] = f[c].data();
+    }
+    pb->render_f32(in, fo, fo);
+    ctx.sync();
+    bool f32_ok = true;
+    for (int c = 0; c < 3; c++) {
+      jxlo_modular_to_f32(pl[c].data(), n, 12, fw.data());
+      f32_ok = f32_ok && memcmp(fw.data(), f[c].data(), n * sizeof(float)) == 0;
+    }
+    // (c) the f32 route with Gaborish + EPF1 on device planes: equal to the two ABI calls made by hand
+    bool filt_ok = true;
+    if (w % 4 == 0) {
+      jxlh_frame_params pm = base;
+      pm.epf_sigma_for_modular = 1.25f;
+      auto pc = add_filters(RenderPipelineBuilder(3, {(size_t)w, (size_t)h}, 0, 8, pm)
+                                .add_inout_stage(ConvertModularToF32Stage{0, 8}).add_inout_stage(ConvertModularToF32Stage{1, 8})
+                                .add_inout_stage(ConvertModularToF32Stage{2, 8}),
+                            rf_of(pm), true, 1);
+      auto pipe = std::move(pc).add_save_stage({0, 1, 2}, 0, 3, 32).build_modular(ctx);
+      float *dt[3], *dout[3], *dref_in[3], *dref_out[3];
+      int32_t* din[3];
+      for (int c = 0; c < 3; c++) {
+        if (hipMalloc((void**)&dt[c], n * 4) || hipMalloc((void**)&dout[c], n * 4) || hipMalloc((void**)&dref_in[c], n * 4) ||
+            hipMalloc((void**)&dref_out[c], n * 4) || hipMalloc((void**)&din[c], n * 4))
+          return fprintf(stderr, "hipMalloc failed\n"), 3;
+        if (hipMemcpy(din[c], pl[c].data(), n * 4, hipMemcpyHostToDevice)) return 3;
+      }
+      const int32_t* cin[3] = {din[0], din[1], din[2]};
+      pipe->render_f32(cin, dt, dout);
+      for (int c = 0; c < 3; c++) ctx.check(jxlh_modular_to_f32(ctx.raw(), din[c], n, 8, dref_in[c]), "to_f32");
+      jxlh_frame_params pl2 = pipe->lowered().frame;
+      ctx.check(jxlh_modular_frame_filters(ctx.raw(), &pl2, dref_in, dref_out, (uint32_t)w, (uint32_t)h, (size_t)w), "filters");
+      ctx.sync();
+      std::vector<float> a(n), b(n);
+      size_t changed = 0;
+      for (int c = 0; c < 3; c++) {
+        if (hipMemcpy(a.data(), dout[c], n * 4, hipMemcpyDeviceToHost) || hipMemcpy(b.data(), dref_out[c], n * 4, hipMemcpyDeviceToHost))
+          return 3;
+        filt_ok = filt_ok && memcmp(a.data(), b.data(), n * 4) == 0;
+        jxlo_modular_to_f32(pl[c].data(), n, 8, fw.data());
+        for (size_t i = 0; i < n; i++) changed += a[i] != fw[i];
+        (void)hipFree(dt[c]); (void)hipFree(dout[c]); (void)hipFree(dref_in[c]); (void)hipFree(dref_out[c]); (void)hipFree(din[c]);
+      }
+      filt_ok = filt_ok && changed > n / 2;  // the filters really ran
+    }
+    printf("%dx%d Modular lists: I32->U8 %s, to f32 %s, f32 + filters %s\n", w, h, u8_ok ? "ok" : "DIFFERS", f32_ok ? "ok" : "DIFFERS",
+           filt_ok ? "ok" : "DIFFERS");
+    return (u8_ok && f32_ok && filt_ok) ? 0 : 1;
+  } catch (const std::exception& e) {
+    fprintf(stderr, "device path failed: %s\n", e.what());
+    return 3;
+  }
+}
 }  // namespace
 
 int main(int argc, char** argv) {
   if (argc < 2 || !strcmp(argv[1], "host")) return host_checks();
   if (!strcmp(argv[1], "gpu") && argc >= 5) return gpu_frame(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]));
+  if (!strcmp(argv[1], "modular") && argc >= 4) return gpu_modular(atoi(argv[2]), atoi(argv[3]));
   fprintf(stderr, "usage: pipeline_builder host | gpu W H EPF_ITERS\n");
   return 2;
 }

@@ -15,7 +15,8 @@ CPP = os.path.join(ROOT, "tests", "cpp")
 def _build(tmp_path, name="frame_parity"):
     subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "-s"], check=True)
     exe = os.path.join(str(tmp_path), name)
-    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "oracle"),
+    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I", "/opt/rocm/include",
+           "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "oracle"),
            "-I", CPP, os.path.join(CPP, name + ".cc"),
            "-o", exe, "-L", os.path.join(ROOT, "jxl_rs_amd"), "-ljxl_hip", "-L", os.path.join(ROOT, "oracle"),
            "-l:libjxlo_fused.so", "-Wl,-rpath," + os.path.join(ROOT, "jxl_rs_amd"), "-Wl,-rpath," + os.path.join(ROOT, "oracle"),
@@ -58,3 +59,14 @@ def test_pipeline_builder_frame_two_passes(tmp_path, args):
     assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
     assert "two passes: 0 differing rows" in r.stdout and "RGBA8 tail: 0 differing rows" in r.stdout \
         and "error path ok" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("args", [("256", "200"), ("131", "77")])
+def test_pipeline_builder_modular_lists(tmp_path, args):
+    """Modular stage lists through the builder mirror: the I32 -> U8 special case (render/builder.rs:152-170) byte-exact
+    against the oracle, the f32 conversion bit-exact, the f32 + Gaborish + EPF1 route equal to the ABI calls made by hand"""
+    exe = _build(tmp_path, "pipeline_builder")
+    r = subprocess.run([exe, "modular", *args], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+    assert "I32->U8 ok" in r.stdout and "to f32 ok" in r.stdout and "f32 + filters ok" in r.stdout
