@@ -90,19 +90,9 @@ class ModularChain:
         pal = [self.d_pout.download(np.int32, n, 4 * ch * self.padded).reshape(self.h, self.w) for ch in range(3)]
         return planes, pal
 
-    def oracle_pipeline_result(self, oracle):
-        idx, pal = self.palette
-        return self.oracle_result(oracle), list(oracle.palette(idx, pal, pal.shape[1], 3, 8))
-
     def result(self):
         self.ctx.sync()
         return [d.download(np.int32, self.w * self.h).reshape(self.h, self.w) for d in self.d_out]
-
-    def oracle_result(self, oracle):
-        cur = [b.copy() for b in self.base]
-        for (hz, ow, oh), res in zip(self.steps, self.residuals):
-            cur = [oracle.unsqueeze_h(cur[c], res[c], ow) if hz else oracle.unsqueeze_v(cur[c], res[c], oh) for c in range(3)]
-        return oracle.rct(cur, *self.rct) if self.rct is not None else cur
 
     def free(self):
         for d in self.d_base + self.d_out + [d for lvl in self.d_res for d in lvl if d is not None]:

@@ -6,7 +6,7 @@ tests/test_golden_frames.py checks that the oracle still reproduces them (CPU) a
 same digests (GPU), so neither side can drift unnoticed, together or alone.  `inputs` is the digest of the generated
 workload itself, so a failure tells a changed generator from a changed reconstruction.
 
-usage: python tools/gen_frame_digests.py [--check]      (--check: compare instead of writing)"""
+usage: python tests/gen_frame_digests.py [--check]      (--check: compare instead of writing)"""
 import hashlib
 import json
 import os
@@ -66,7 +66,7 @@ def modular_case(oracle, name, w, h, seed, rct):
 def generate():
     from oracle.oracle import Oracle
     oracle = Oracle(fused=True)
-    doc = {"_what": "SHA-256 of dtype + shape + bytes of the oracle's (FMA build) outputs; tools/gen_frame_digests.py",
+    doc = {"_what": "SHA-256 of dtype + shape + bytes of the oracle's (FMA build) outputs; tests/gen_frame_digests.py",
            "vardct": {}, "modular": {}}
     for name, w, h, mix, seed, opts in VARDCT_CASES:
         doc["vardct"][name] = vardct_case(oracle, name, w, h, mix, seed, opts)[3]

@@ -133,3 +133,18 @@ def forward_squeeze_v(img):
 
 
 from jxl_rs_amd.lib import DeviceArray  # noqa: E402,F401  (device buffers for tests that hand DEVICE pointers to the C ABI)
+
+
+# ---- Modular chain (jxl_rs_amd.modular.ModularChain): what the oracle makes of the same planes ----
+def modular_chain_oracle(chain, oracle):
+    """the chain's levels one by one on the CPU oracle, then the RCT"""
+    cur = [b.copy() for b in chain.base]
+    for (hz, ow, oh), res in zip(chain.steps, chain.residuals):
+        cur = [oracle.unsqueeze_h(cur[c], res[c], ow) if hz else oracle.unsqueeze_v(cur[c], res[c], oh) for c in range(3)]
+    return oracle.rct(cur, *chain.rct) if chain.rct is not None else cur
+
+
+def modular_pipeline_oracle(chain, oracle):
+    """chain + RCT and the palette expansion of BASELINE configs[3]"""
+    idx, pal = chain.palette
+    return modular_chain_oracle(chain, oracle), list(oracle.palette(idx, pal, pal.shape[1], 3, 8))

@@ -2,13 +2,14 @@
 RCT in both directions and tile widths, and whole default chains through jxlh_unsqueeze_levels + steps -- every result
 compared with the oracle."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import jxl_rs_amd
 from jxl_rs_amd import synth
 from oracle.oracle import Oracle
-from helpers import DeviceArray
+from jxl_rs_amd.lib import DeviceArray
 o = Oracle(fused=True)
 ctx = jxl_rs_amd.Context(0, 1)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 40

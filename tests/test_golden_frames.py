@@ -1,4 +1,4 @@
-"""Committed golden fixtures (tests/golden/frame_digests.json, written by tools/gen_frame_digests.py): SHA-256 digests
+"""Committed golden fixtures (tests/golden/frame_digests.json, written by tests/gen_frame_digests.py): SHA-256 digests
 of the oracle's output for seeded whole frames and Modular chains.  The CPU test holds the oracle to them, the GPU
 tests hold the device path to the SAME digests through the C ABI -- neither side can drift, alone or together."""
 import json
@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import gen_frame_digests as gfd  # noqa: E402
 
 with open(gfd.OUT) as f:

@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 from helpers import bit_equal, diff_report, gpu_params_from, run_oracle_frame
+import helpers
 
 pytestmark = pytest.mark.gpu
 
@@ -237,7 +238,7 @@ def test_modular_config4_pipeline_sharded(oracle, n, size):
         lib.comm_init_local(ctxs)
         chains = [ModularChain(c, w, h, planes=planes, world=n) for c in ctxs]
         run_pipeline_local(chains, ctxs)
-        want_planes, want_pal = chains[0].oracle_pipeline_result(oracle)
+        want_planes, want_pal = helpers.modular_pipeline_oracle(chains[0], oracle)
         for r, ch in enumerate(chains):
             got_planes, got_pal = ch.pipeline_result()
             for c in range(3):
@@ -261,7 +262,7 @@ def test_modular_config4_pipeline_rccl_single_rank(oracle):
         c.comm_init(lib.comm_unique_id(), 0, 1)
         ch = ModularChain(c, 515, 260, seed=5, world=1)
         ch.run_pipeline_rccl(0)
-        want_planes, want_pal = ch.oracle_pipeline_result(oracle)
+        want_planes, want_pal = helpers.modular_pipeline_oracle(ch, oracle)
         got_planes, got_pal = ch.pipeline_result()
         for k in range(3):
             assert np.array_equal(got_planes[k], want_planes[k]) and np.array_equal(got_pal[k], want_pal[k]), k
