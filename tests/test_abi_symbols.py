@@ -82,6 +82,27 @@ def test_product_package_does_not_import_the_oracle():
                 txt = open(os.path.join(dirpath, fn), errors="ignore").read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "libjxlo" not in txt, fn
                 assert "jxlo_" not in txt, fn
+                # ... nor take an oracle object and call into it (round 3: ModularChain's oracle comparisons moved to
+                # tests/helpers.py)
+                assert "oracle." not in txt and "(oracle" not in txt and ", oracle" not in txt, fn
+
+
+def test_only_tests_smoke_and_the_cpu_baseline_touch_the_oracle():
+    """tools/, include/ and bindings/ never import, link or run anything under oracle/; bench.py and
+    __graft_entry__.py do so only in their declared places (the cpu_baseline legs, smoke())."""
+    import re
+    for sub in ("tools", "include", "bindings"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, sub)):
+            for fn in files:
+                txt = open(os.path.join(dirpath, fn), errors="ignore").read()
+                assert not re.search(r"import oracle|from oracle|libjxlo|jxlo_", txt), os.path.join(sub, fn)
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    uses = [m.start() for m in re.finditer(r"from oracle\.oracle import Oracle", bench)]
+    assert len(uses) == 2, "bench.py: one import per CPU-baseline leg (VarDCT, Modular)"
+    for pos in uses:
+        assert "cpu" in bench[max(0, pos - 1500):pos].lower(), "oracle import outside a cpu_baseline leg"
+    entry = open(os.path.join(ROOT, "__graft_entry__.py")).read()
+    assert entry.count("from oracle.oracle import Oracle") == 1 and entry.index("from oracle.oracle import Oracle") > entry.index("def smoke")
 
 
 def test_header_is_plain_c_and_links_from_c(tmp_path):
