@@ -132,573 +132,7 @@ __device__ __forceinline__ float dpp_from_right(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x101, 0xf, 0xf, true));
 }
 
-// LDS tiles are 16-byte aligned and every strip starts on a 4-float boundary; say so, or the
-// compiler splits the access into ds_read2_b32 pairs (bank conflicts).
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float4 lds_load4(const float* p) {
-  f32x4 v = *reinterpret_cast<const f32x4*>(__builtin_assume_aligned(p, 16));
-  // keep the 128-bit load whole: without this the optimiser scalarises it and the backend
-  // re-pairs the pieces as ds_read2_b32 {0,3},{1,2} -> 4-way bank conflicts
-  asm volatile("" : "+v"(v));
-  return make_float4(v.x, v.y, v.z, v.w);
-}
-__device__ __forceinline__ void lds_store4(float* p, float4 v) {
-  *reinterpret_cast<float4*>(__builtin_assume_aligned(p, 16)) = v;
-}
-
-// 8 consecutive values of a tile row around a strip: v[0..1] = cols bx0-2,-1; v[2..5] = strip;
-// v[6..7] = cols bx0+4,+5.  Lane l of a 16-lane row holds strip l of one tile row, so the
-// neighbours are the adjacent lanes' strip registers (unused taps are dead code).  Must be
-// called by all 64 lanes.
-__device__ __forceinline__ void load8(const float* __restrict__ strip, float (&v)[8]) {
-  const float4 c = lds_load4(strip);
-  v[0] = dpp_from_left(c.z);
-  v[1] = dpp_from_left(c.w);
-  v[2] = c.x; v[3] = c.y; v[4] = c.z; v[5] = c.w;
-  v[6] = dpp_from_right(c.x);
-  v[7] = dpp_from_right(c.y);
-}
-__device__ __forceinline__ void load4(const float* __restrict__ strip, float (&v)[4]) {
-  const float4 c = lds_load4(strip);
-  v[0] = c.x; v[1] = c.y; v[2] = c.z; v[3] = c.w;
-}
-
-// The same 8 values for a work item that is NOT laid out one strip per lane (compacted EPF items, see run_stage):
-// the side taps come from LDS (two 8-byte reads) instead of the neighbouring lanes.  edge_l / edge_r: the strip is
-// the first / last of its tile row; its outer taps feed only pixels nobody consumes, so they may be anything in-bounds.
-__device__ __forceinline__ void load8g(const float* __restrict__ strip, bool edge_l, bool edge_r, float (&v)[8]) {
-  const float4 c = lds_load4(strip);
-  const float2 l = *reinterpret_cast<const float2*>(__builtin_assume_aligned(strip - (edge_l ? 0 : 2), 8));
-  const float2 r = *reinterpret_cast<const float2*>(__builtin_assume_aligned(strip + (edge_r ? 2 : 4), 8));
-  v[0] = l.x; v[1] = l.y;
-  v[2] = c.x; v[3] = c.y; v[4] = c.z; v[5] = c.w;
-  v[6] = r.x; v[7] = r.y;
-}
-
-// 10 consecutive values: v[0..2] = cols bx0-3..-1, v[3..6] = strip, v[7..9] = cols bx0+4..+6
-__device__ __forceinline__ void load10(const float* __restrict__ strip, float (&v)[10]) {
-  const float4 c = lds_load4(strip);
-  v[0] = dpp_from_left(c.y);
-  v[1] = dpp_from_left(c.z);
-  v[2] = dpp_from_left(c.w);
-  v[3] = c.x; v[4] = c.y; v[5] = c.z; v[6] = c.w;
-  v[7] = dpp_from_right(c.x);
-  v[8] = dpp_from_right(c.y);
-  v[9] = dpp_from_right(c.z);
-}
-
-// ... and for a work item that is not laid out one strip per lane (see load8g): the side taps from the neighbouring
-// strips' 16-byte words
-__device__ __forceinline__ void load10g(const float* __restrict__ strip, bool edge_l, bool edge_r, float (&v)[10]) {
-  const float4 c = lds_load4(strip);
-  const float4 l = lds_load4(strip - (edge_l ? 0 : 4));
-  const float4 r = lds_load4(strip + (edge_r ? 0 : 4));
-  v[0] = l.y; v[1] = l.z; v[2] = l.w;
-  v[3] = c.x; v[4] = c.y; v[5] = c.z; v[6] = c.w;
-  v[7] = r.x; v[8] = r.y; v[9] = r.z;
-}
-
-#define FAD(a, b) __builtin_fabsf((a) - (b))
-
-// Correctly rounded 1/w for w in [1, 16) (1 + up to 12 weights in [0,1]); equals the IEEE
-// quotient 1.0f / w bit for bit on that range -- jxlh_selftest_recip checks every float.
-__device__ __forceinline__ float recip_weight_sum(float w) {
-#if JXLH_FAST_RECIP
-  float r = __builtin_amdgcn_rcpf(w);
-  float e = __builtin_fmaf(-w, r, 1.0f);
-  r = __builtin_fmaf(e, r, r);
-  e = __builtin_fmaf(-w, r, 1.0f);
-  return __builtin_fmaf(e, r, r);
-#else
-  return 1.0f / w;
-#endif
-}
-
-// sigma * sad_mul for the four pixels of a strip in frame row fy (common.rs:31-41): the border
-// multiplier applies to the first/last row and column of every 8x8 block.  fx0 % 4 == 0, so only
-// pixel 0 (fx0 % 8 == 0) or pixel 3 (fx0 % 8 == 4) can sit on a block's border column.
-__device__ __forceinline__ void strip_inv_sigma(float sigma, int fx0, int fy, float sm, float bsm, float (&is)[4]) {
-  const int ym = fy & 7;
-  const bool rowb = ym == 0 || ym == 7;
-  const float inner = sigma * sm, border = sigma * bsm;
-  const float mid = rowb ? border : inner;
-  const bool left = (fx0 & 4) == 0;
-  is[0] = left ? border : mid;
-  is[1] = mid;
-  is[2] = mid;
-  is[3] = left ? mid : border;
-}
-
-
-// Where a work item sits: strip pointer in the LDS tile (plane 0, first row), frame coordinates
-// of its first pixel, 1/sigma of the block(s) its row(s) fall in.
-struct Geom {
-  const float* p;
-  int bx0, fx0, fy;
-  bool live;
-  float sigma0, sigma1;
-};
-
-// ---- Gaborish on a 4x2 micro-tile of one channel (gaborish.rs:83-85); p = strip in the first row
-template <class Emit>
-__device__ __forceinline__ void gab_pair(const float* __restrict__ p, int c, float k0, float k1, float k2,
-                                         Emit&& emit) {
-  float t[8], m0[8], m1[8], b[8];  // rows y-1 .. y+2
-  load8(p - kBW, t);
-  load8(p, m0);
-  load8(p + kBW, m1);
-  load8(p + 2 * kBW, b);
-  float o0[4], o1[4];
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const int j = i + 2;
-    float sum = m0[j] * k0;
-    sum = __builtin_fmaf(k1, t[j] + m0[j - 1] + m1[j] + m0[j + 1], sum);
-    sum = __builtin_fmaf(k2, t[j - 1] + t[j + 1] + m1[j - 1] + m1[j + 1], sum);
-    o0[i] = sum;
-    sum = m1[j] * k0;
-    sum = __builtin_fmaf(k1, m0[j] + m1[j - 1] + b[j] + m1[j + 1], sum);
-    sum = __builtin_fmaf(k2, m0[j - 1] + m0[j + 1] + b[j - 1] + b[j + 1], sum);
-    o1[i] = sum;
-  }
-  emit(0, c, make_float4(o0[0], o0[1], o0[2], o0[3]));
-  emit(1, c, make_float4(o1[0], o1[1], o1[2], o1[3]));
-}
-
-// ---- EPF1 on a 4x2 micro-tile, all three channels (epf1.rs:84-146).
-// p0 = the strip in the first row (plane 0); emit(geom, r, c, strip).  regeom() recomputes the
-// item's Geom from the thread id: cheaper than carrying seven registers across the map phase.
-template <class Regeom, class Emit>
-__device__ __forceinline__ void epf1_pair(const float* __restrict__ p0, Regeom&& regeom, const FusedArgs& a,
-                                          Emit&& emit) {
-  float wv[3][4], wh[2][4];  // scaled plus-sums of V at rows y-1, y, y+1 and of H at rows y, y+1
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    wv[0][i] = wv[1][i] = wv[2][i] = 0.0f;
-    wh[0][i] = wh[1][i] = 0.0f;
-  }
-
-  // one channel at a time (a rolled loop): unrolled, the scheduler interleaves the three
-  // channels' loads and difference maps and triples the live registers
-#if JXLH_E1_ROLLED
-#pragma unroll 1
-#else
-#pragma unroll
-#endif
-  for (int c = 0; c < 3; c++) {
-    const float* p = p0 + c * kPlane;
-    const float scale = a.scale[c];
-    // rows y-2 .. y+3 stream through; V(x', r) = |P(x',r) - P(x',r+1)| and H(x', r) = |P(x',r) - P(x'+1,r)|
-    // are kept for x' = x-1 .. x+4 (index j = x'-x+1) on the rows whose plus-sums need the side taps
-    float A[4], B[8], C[8], D[8], E[8], F[4];
-    float vm2[4], vm1[6], v0[6], vp1[6], vp2[4];
-    float hm1[4], h0[6], hp1[6], hp2[4];
-    load4(p - 2 * kBW, A);
-    load8(p - kBW, B);
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      vm2[i] = FAD(A[i], B[i + 2]);
-      hm1[i] = FAD(B[i + 2], B[i + 3]);
-    }
-    load8(p, C);
-#pragma unroll
-    for (int j = 0; j < 6; j++) {
-      vm1[j] = FAD(B[j + 1], C[j + 1]);
-      h0[j] = FAD(C[j + 1], C[j + 2]);
-    }
-    load8(p + kBW, D);
-#pragma unroll
-    for (int j = 0; j < 6; j++) {
-      v0[j] = FAD(C[j + 1], D[j + 1]);
-      hp1[j] = FAD(D[j + 1], D[j + 2]);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      // order of the five terms == epf1.rs:116-119 (top, left, centre, right, bottom)
-      const float pv0 = vm2[i] + vm1[i] + vm1[i + 1] + vm1[i + 2] + v0[i + 1];
-      const float ph0 = hm1[i] + h0[i] + h0[i + 1] + h0[i + 2] + hp1[i + 1];
-      wv[0][i] = __builtin_fmaf(pv0, scale, wv[0][i]);
-      wh[0][i] = __builtin_fmaf(ph0, scale, wh[0][i]);
-    }
-    load8(p + 2 * kBW, E);
-#pragma unroll
-    for (int j = 0; j < 6; j++) vp1[j] = FAD(D[j + 1], E[j + 1]);
-#pragma unroll
-    for (int i = 0; i < 4; i++) hp2[i] = FAD(E[i + 2], E[i + 3]);
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const float pv1 = vm1[i + 1] + v0[i] + v0[i + 1] + v0[i + 2] + vp1[i + 1];
-      const float ph1 = h0[i + 1] + hp1[i] + hp1[i + 1] + hp1[i + 2] + hp2[i];
-      wv[1][i] = __builtin_fmaf(pv1, scale, wv[1][i]);
-      wh[1][i] = __builtin_fmaf(ph1, scale, wh[1][i]);
-    }
-    load4(p + 3 * kBW, F);
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      vp2[i] = FAD(E[i + 2], F[i]);
-      const float pv2 = v0[i + 1] + vp1[i] + vp1[i + 1] + vp1[i + 2] + vp2[i];
-      wv[2][i] = __builtin_fmaf(pv2, scale, wv[2][i]);
-    }
-  }
-  const Geom g = regeom();
-  const int fx0 = g.fx0, fy = g.fy;
-  p0 = g.p;
-  // per row: the weights of its 4 pixels (neighbours N, W, E, S, epf1.rs:96), then the channels
-#pragma unroll
-  for (int r = 0; r < 2; r++) {
-    const float sigma = r ? g.sigma1 : g.sigma0;
-    const bool pass = sigma < kMinSigma;
-    float is[4], wgt[4][4], inv_w[4];
-    strip_inv_sigma(sigma, fx0, fy + r, a.sm1, a.bsm1, is);
-    const float from_left = dpp_from_left(wh[r][3]);  // SAD_E of the pixel left of the strip
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const float sad[4] = {wv[r][i], i ? wh[r][i - 1] : from_left, wh[r][i], wv[r + 1][i]};
-      float wsum = 1.0f;
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        wgt[i][k] = fmaxf(__builtin_fmaf(sad[k], is[i], 1.0f), 0.0f);
-        wsum += wgt[i][k];
-      }
-      inv_w[i] = recip_weight_sum(wsum);
-    }
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-      const float* p = p0 + c * kPlane + r * kBW;
-      float N[4], M[8], S[4];
-      load4(p - kBW, N);
-      load8(p, M);
-      load4(p + kBW, S);
-      float o[4];
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        float acc = M[i + 2];
-        acc = __builtin_fmaf(S[i], wgt[i][3], acc);
-        acc = __builtin_fmaf(M[i + 3], wgt[i][2], acc);
-        acc = __builtin_fmaf(M[i + 1], wgt[i][1], acc);
-        acc = __builtin_fmaf(N[i], wgt[i][0], acc);
-        o[i] = pass ? M[i + 2] : acc * inv_w[i];
-      }
-      emit(g, r, c, make_float4(o[0], o[1], o[2], o[3]));
-    }
-  }
-}
-
-// ---- EPF1 on ONE strip (4 pixels of row fy) for compacted items: any lane, any strip, every tap from LDS.
-// Same sums as epf1_pair (five terms each: top, left, centre, right, bottom; channels accumulated with the same FMA),
-// evaluated for one row only -- half the maps, no second row to share them with.
-//   V(x', r) = |P(x',r) - P(x',r+1)|,  H(x', r) = |P(x',r) - P(x'+1,r)|
-//   SAD_N(x,y) = sum_c s_c PV_c(x, y-1),  SAD_S = sum_c s_c PV_c(x, y),  SAD_E = sum_c s_c PH_c(x, y),  SAD_W = SAD_E(x-1, y)
-template <class Emit>
-__device__ __forceinline__ void epf1_strip_g(const float* __restrict__ p0, int fx0, int fy, float sigma, bool edge_l,
-                                             bool edge_r, const FusedArgs& a, Emit&& emit) {
-  float wn[4], ws[4], we[5];  // we[k]: column x - 1 + k
-#pragma unroll
-  for (int i = 0; i < 4; i++) wn[i] = ws[i] = 0.0f;
-#pragma unroll
-  for (int k = 0; k < 5; k++) we[k] = 0.0f;
-#pragma unroll 1
-  for (int c = 0; c < 3; c++) {
-    const float* p = p0 + c * kPlane;
-    const float scale = a.scale[c];
-    float A[4], B[8], C[8], D[8], E[4];  // rows y-2 .. y+2; 8-wide rows hold columns x-2 .. x+5
-    load4(p - 2 * kBW, A);
-    load8g(p - kBW, edge_l, edge_r, B);
-    load8g(p, edge_l, edge_r, C);
-    load8g(p + kBW, edge_l, edge_r, D);
-    load4(p + 2 * kBW, E);
-    float vm1[6], v0[6];  // V at rows y-1 and y, columns x-1 .. x+4 (index j: column x - 1 + j)
-#pragma unroll
-    for (int j = 0; j < 6; j++) {
-      vm1[j] = FAD(B[j + 1], C[j + 1]);
-      v0[j] = FAD(C[j + 1], D[j + 1]);
-    }
-    float h0[7];  // H at row y, columns x-2 .. x+4 (index j: column x - 2 + j)
-#pragma unroll
-    for (int j = 0; j < 7; j++) h0[j] = FAD(C[j], C[j + 1]);
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const float vm2 = FAD(A[i], B[i + 2]), vp1 = FAD(D[i + 2], E[i]);
-      const float pvn = vm2 + vm1[i] + vm1[i + 1] + vm1[i + 2] + v0[i + 1];    // PV(x+i, y-1)
-      const float pvs = vm1[i + 1] + v0[i] + v0[i + 1] + v0[i + 2] + vp1;      // PV(x+i, y)
-      wn[i] = __builtin_fmaf(pvn, scale, wn[i]);
-      ws[i] = __builtin_fmaf(pvs, scale, ws[i]);
-    }
-#pragma unroll
-    for (int k = 0; k < 5; k++) {  // PH(x - 1 + k, y)
-      const float hm1 = FAD(B[k + 1], B[k + 2]), hp1 = FAD(D[k + 1], D[k + 2]);
-      const float ph = hm1 + h0[k] + h0[k + 1] + h0[k + 2] + hp1;
-      we[k] = __builtin_fmaf(ph, scale, we[k]);
-    }
-  }
-  const bool pass = sigma < kMinSigma;
-  float is[4], wgt[4][4], inv_w[4];
-  strip_inv_sigma(sigma, fx0, fy, a.sm1, a.bsm1, is);
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const float sad[4] = {wn[i], we[i], we[i + 1], ws[i]};  // N, W, E, S (epf1.rs:96)
-    float wsum = 1.0f;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      wgt[i][k] = fmaxf(__builtin_fmaf(sad[k], is[i], 1.0f), 0.0f);
-      wsum += wgt[i][k];
-    }
-    inv_w[i] = recip_weight_sum(wsum);
-  }
-#pragma unroll
-  for (int c = 0; c < 3; c++) {
-    const float* p = p0 + c * kPlane;
-    float N[4], M[8], S[4];
-    load4(p - kBW, N);
-    load8g(p, edge_l, edge_r, M);
-    load4(p + kBW, S);
-    float o[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      float acc = M[i + 2];
-      acc = __builtin_fmaf(S[i], wgt[i][3], acc);
-      acc = __builtin_fmaf(M[i + 3], wgt[i][2], acc);
-      acc = __builtin_fmaf(M[i + 1], wgt[i][1], acc);
-      acc = __builtin_fmaf(N[i], wgt[i][0], acc);
-      o[i] = pass ? M[i + 2] : acc * inv_w[i];
-    }
-    emit(c, make_float4(o[0], o[1], o[2], o[3]));
-  }
-}
-
-// ---- EPF2 on a 4x2 micro-tile (epf2.rs:84-136)
-template <class Emit>
-__device__ __forceinline__ void epf2_pair(const float* __restrict__ p0, int fx0, int fy, float sigma0, float sigma1,
-                                          const FusedArgs& a, Emit&& emit) {
-  float T[3][4], M0[3][8], M1[3][8], Bt[3][4];  // rows y-1, y, y+1, y+2
-#pragma unroll
-  for (int c = 0; c < 3; c++) {
-    const float* p = p0 + c * kPlane;
-    load4(p - kBW, T[c]);
-    load8(p, M0[c]);
-    load8(p + kBW, M1[c]);
-    load4(p + 2 * kBW, Bt[c]);
-  }
-  const float s0 = a.scale[0], s1 = a.scale[1], s2 = a.scale[2];
-  // the SAD of epf2.rs:103-109 between two pixels (symmetric in its arguments)
-  auto sad3 = [&](float ax, float ay, float ab, float bx, float by, float bb) {
-    return __builtin_fmaf(FAD(ax, bx), s0, __builtin_fmaf(FAD(ay, by), s1, FAD(ab, bb) * s2));
-  };
-  float dv[3][4];  // between rows (y-1,y), (y,y+1), (y+1,y+2)
-  float dh[2][4];  // between columns x+i and x+i+1, rows y and y+1
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const int j = i + 2;
-    dv[0][i] = sad3(T[0][i], T[1][i], T[2][i], M0[0][j], M0[1][j], M0[2][j]);
-    dv[1][i] = sad3(M1[0][j], M1[1][j], M1[2][j], M0[0][j], M0[1][j], M0[2][j]);
-    dv[2][i] = sad3(Bt[0][i], Bt[1][i], Bt[2][i], M1[0][j], M1[1][j], M1[2][j]);
-    dh[0][i] = sad3(M0[0][j + 1], M0[1][j + 1], M0[2][j + 1], M0[0][j], M0[1][j], M0[2][j]);
-    dh[1][i] = sad3(M1[0][j + 1], M1[1][j + 1], M1[2][j + 1], M1[0][j], M1[1][j], M1[2][j]);
-  }
-  // per row: the four weights of each pixel, then the channels.  The outer rows (y-1, y+2) are
-  // only needed once more, as N / S neighbours: re-read them instead of holding 24 registers.
-#pragma unroll
-  for (int r = 0; r < 2; r++) {
-    const float sigma = r ? sigma1 : sigma0;
-    const bool pass = sigma < kMinSigma;
-    float is[4], wgt[4][4], inv_w[4];
-    strip_inv_sigma(sigma, fx0, fy + r, a.sm2, a.bsm2, is);
-    const float from_left = dpp_from_left(dh[r][3]);
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      // neighbour order N, W, E, S (epf2.rs:95)
-      const float sad[4] = {dv[r][i], i ? dh[r][i - 1] : from_left, dh[r][i], dv[r + 1][i]};
-      float wacc = 1.0f;
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        wgt[i][k] = fmaxf(__builtin_fmaf(sad[k], is[i], 1.0f), 0.0f);
-        wacc += wgt[i][k];
-      }
-      inv_w[i] = recip_weight_sum(wacc);
-    }
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-      const float(&M)[8] = r ? M1[c] : M0[c];
-      float outer[4];
-      load4(p0 + c * kPlane + (r ? 2 : -1) * kBW, outer);
-      float o[4];
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const int j = i + 2;
-        const float n[4] = {r ? M0[c][j] : outer[i], M[j - 1], M[j + 1], r ? outer[i] : M1[c][j]};
-        float acc = M[j];
-#pragma unroll
-        for (int k = 0; k < 4; k++) acc = __builtin_fmaf(wgt[i][k], n[k], acc);
-        o[i] = pass ? M[j] : acc * inv_w[i];
-      }
-      emit(r, c, make_float4(o[0], o[1], o[2], o[3]));
-    }
-  }
-}
-
-// ---- EPF2 on one strip (epf2.rs:84-136): the form used when EPF2 is the last stage and
-// register pressure matters more than the shared SADs of the 4x2 form
-template <bool GENERIC, class Emit>
-__device__ __forceinline__ void epf2_strip(const float* __restrict__ p0, int fx0, int fy, float sigma,
-                                           const FusedArgs& a, Emit&& emit, bool edge_l = false, bool edge_r = false) {
-  float t[3][4], m[3][8], b[3][4];
-#pragma unroll
-  for (int c = 0; c < 3; c++) {
-    const float* p = p0 + c * kPlane;
-    load4(p - kBW, t[c]);
-    if constexpr (GENERIC) load8g(p, edge_l, edge_r, m[c]);
-    else load8(p, m[c]);
-    load4(p + kBW, b[c]);
-  }
-  const bool pass = sigma < kMinSigma;
-  float is[4];
-  strip_inv_sigma(sigma, fx0, fy, a.sm2, a.bsm2, is);
-  float o[3][4];
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const float xc = m[0][i + 2], yc = m[1][i + 2], bc = m[2][i + 2];
-    float wacc = 1.0f, xa = xc, ya = yc, ba = bc;
-    // neighbour order N, W, E, S (epf2.rs:95)
-    const float nx[4] = {t[0][i], m[0][i + 1], m[0][i + 3], b[0][i]};
-    const float ny[4] = {t[1][i], m[1][i + 1], m[1][i + 3], b[1][i]};
-    const float nb[4] = {t[2][i], m[2][i + 1], m[2][i + 3], b[2][i]};
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const float sad = __builtin_fmaf(FAD(nx[k], xc), a.scale[0],
-                                       __builtin_fmaf(FAD(ny[k], yc), a.scale[1], FAD(nb[k], bc) * a.scale[2]));
-      const float wgt = fmaxf(__builtin_fmaf(sad, is[i], 1.0f), 0.0f);
-      wacc += wgt;
-      xa = __builtin_fmaf(wgt, nx[k], xa);
-      ya = __builtin_fmaf(wgt, ny[k], ya);
-      ba = __builtin_fmaf(wgt, nb[k], ba);
-    }
-    const float inv_w = recip_weight_sum(wacc);
-    o[0][i] = pass ? xc : xa * inv_w;
-    o[1][i] = pass ? yc : ya * inv_w;
-    o[2][i] = pass ? bc : ba * inv_w;
-  }
-#pragma unroll
-  for (int c = 0; c < 3; c++) emit(c, make_float4(o[c][0], o[c][1], o[c][2], o[c][3]));
-}
-
-// ---- EPF0 on one strip (epf0.rs:87-210): 12 neighbours in a radius-2 diamond, each compared
-// over a 5-pixel plus.  Always the last stage of its kernel (7 rows x 10 columns of context make
-// it the register-heaviest stage; its output goes straight to HBM).  P(cx, cy) below is the
-// reference's 7x7 window with the pixel at (3, 3); the sums keep its term order.
-template <bool GENERIC, class Emit>
-__device__ __forceinline__ void epf0_strip(const float* __restrict__ p0, int fx0, int fy, float sigma,
-                                           const FusedArgs& a, Emit&& emit, bool edge_l = false, bool edge_r = false) {
-  auto ld8 = [&](const float* q, float (&v)[8]) {
-    if constexpr (GENERIC) load8g(q, edge_l, edge_r, v);
-    else load8(q, v);
-  };
-  float sads[4][12];
-#pragma unroll
-  for (int i = 0; i < 4; i++)
-#pragma unroll
-    for (int k = 0; k < 12; k++) sads[i][k] = 0.0f;
-#pragma unroll 1
-  for (int c = 0; c < 3; c++) {
-    const float* p = p0 + c * kPlane;
-    const float scale = a.scale[c];
-    // window rows y-3 .. y+3; index = column - (bx0 - 3)
-    float R0[10], R1[10], R2[10], R3[10], R4[10], R5[10], R6[10];
-    {
-      float t4[4], t8[8];
-      load4(p - 3 * kBW, t4);
-#pragma unroll
-      for (int j = 0; j < 4; j++) R0[3 + j] = t4[j];
-      load4(p + 3 * kBW, t4);
-#pragma unroll
-      for (int j = 0; j < 4; j++) R6[3 + j] = t4[j];
-      ld8(p - 2 * kBW, t8);
-#pragma unroll
-      for (int j = 0; j < 8; j++) R1[1 + j] = t8[j];
-      ld8(p - kBW, t8);
-#pragma unroll
-      for (int j = 0; j < 8; j++) R2[1 + j] = t8[j];
-      ld8(p + kBW, t8);
-#pragma unroll
-      for (int j = 0; j < 8; j++) R4[1 + j] = t8[j];
-      ld8(p + 2 * kBW, t8);
-#pragma unroll
-      for (int j = 0; j < 8; j++) R5[1 + j] = t8[j];
-      if constexpr (GENERIC) load10g(p, edge_l, edge_r, R3);
-      else load10(p, R3);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-#define P(cx, cy) R##cy[(cx) + i]
-      const float p30 = P(3, 0), p21 = P(2, 1), p31 = P(3, 1), p41 = P(4, 1), p12 = P(1, 2), p22 = P(2, 2),
-                  p32 = P(3, 2), p42 = P(4, 2), p52 = P(5, 2), p03 = P(0, 3), p13 = P(1, 3), p23 = P(2, 3),
-                  p33 = P(3, 3), p43 = P(4, 3), p53 = P(5, 3), p63 = P(6, 3), p14 = P(1, 4), p24 = P(2, 4),
-                  p34 = P(3, 4), p44 = P(4, 4), p54 = P(5, 4), p25 = P(2, 5), p35 = P(3, 5), p45 = P(4, 5),
-                  p36 = P(3, 6);
-#undef P
-      const float d32_30 = FAD(p32, p30), d32_21 = FAD(p32, p21), d32_31 = FAD(p32, p31), d32_41 = FAD(p32, p41),
-                  d32_12 = FAD(p32, p12), d32_22 = FAD(p32, p22), d32_42 = FAD(p32, p42), d32_52 = FAD(p32, p52),
-                  d32_23 = FAD(p32, p23), d32_34 = FAD(p32, p34), d32_43 = FAD(p32, p43), d32_33 = FAD(p32, p33),
-                  d23_21 = FAD(p23, p21), d23_12 = FAD(p23, p12), d23_22 = FAD(p23, p22), d23_03 = FAD(p23, p03),
-                  d23_13 = FAD(p23, p13), d23_33 = FAD(p23, p33), d23_43 = FAD(p23, p43), d23_14 = FAD(p23, p14),
-                  d23_24 = FAD(p23, p24), d23_34 = FAD(p23, p34), d23_25 = FAD(p23, p25), d33_31 = FAD(p33, p31),
-                  d33_22 = FAD(p33, p22), d33_42 = FAD(p33, p42), d33_13 = FAD(p33, p13), d33_43 = FAD(p33, p43),
-                  d33_53 = FAD(p33, p53), d33_24 = FAD(p33, p24), d33_34 = FAD(p33, p34), d33_44 = FAD(p33, p44),
-                  d33_35 = FAD(p33, p35), d43_41 = FAD(p43, p41), d43_42 = FAD(p43, p42), d43_52 = FAD(p43, p52),
-                  d43_53 = FAD(p43, p53), d43_63 = FAD(p43, p63), d43_34 = FAD(p43, p34), d43_44 = FAD(p43, p44),
-                  d43_54 = FAD(p43, p54), d43_45 = FAD(p43, p45), d34_14 = FAD(p34, p14), d34_24 = FAD(p34, p24),
-                  d34_44 = FAD(p34, p44), d34_54 = FAD(p34, p54), d34_25 = FAD(p34, p25), d34_35 = FAD(p34, p35),
-                  d34_45 = FAD(p34, p45), d34_36 = FAD(p34, p36);
-      sads[i][0] = __builtin_fmaf(scale, d32_30 + d23_21 + d33_31 + d43_41 + d32_34, sads[i][0]);
-      sads[i][1] = __builtin_fmaf(scale, d32_21 + d23_12 + d33_22 + d32_43 + d23_34, sads[i][1]);
-      sads[i][2] = __builtin_fmaf(scale, d32_31 + d23_22 + d32_33 + d43_42 + d33_34, sads[i][2]);
-      sads[i][3] = __builtin_fmaf(scale, d32_41 + d32_23 + d33_42 + d43_52 + d43_34, sads[i][3]);
-      sads[i][4] = __builtin_fmaf(scale, d32_12 + d23_03 + d33_13 + d23_43 + d34_14, sads[i][4]);
-      sads[i][5] = __builtin_fmaf(scale, d32_22 + d23_13 + d23_33 + d33_43 + d34_24, sads[i][5]);
-      sads[i][6] = __builtin_fmaf(scale, d32_42 + d23_33 + d33_43 + d43_53 + d34_44, sads[i][6]);
-      sads[i][7] = __builtin_fmaf(scale, d32_52 + d23_43 + d33_53 + d43_63 + d34_54, sads[i][7]);
-      sads[i][8] = __builtin_fmaf(scale, d32_23 + d23_14 + d33_24 + d43_34 + d34_25, sads[i][8]);
-      sads[i][9] = __builtin_fmaf(scale, d32_33 + d23_24 + d33_34 + d43_44 + d34_35, sads[i][9]);
-      sads[i][10] = __builtin_fmaf(scale, d32_43 + d23_34 + d33_44 + d43_54 + d34_45, sads[i][10]);
-      sads[i][11] = __builtin_fmaf(scale, d32_34 + d23_25 + d33_35 + d43_45 + d34_36, sads[i][11]);
-    }
-  }
-  const bool pass = sigma < kMinSigma;
-  float is[4], inv_w[4];
-  strip_inv_sigma(sigma, fx0, fy, a.sm0, a.bsm0, is);
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    float wsum = 1.0f;
-#pragma unroll
-    for (int k = 0; k < 12; k++) {
-      sads[i][k] = fmaxf(__builtin_fmaf(sads[i][k], is[i], 1.0f), 0.0f);
-      wsum += sads[i][k];
-    }
-    inv_w[i] = recip_weight_sum(wsum);
-  }
-#pragma unroll 1
-  for (int c = 0; c < 3; c++) {
-    const float* p = p0 + c * kPlane;
-    float A[4], B[8], C[8], D[8], E[4];  // rows y-2 .. y+2; 8-wide rows hold cols x-2 .. x+5
-    load4(p - 2 * kBW, A);
-    ld8(p - kBW, B);
-    ld8(p, C);
-    ld8(p + kBW, D);
-    load4(p + 2 * kBW, E);
-    float o[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const int j = i + 2;
-      // neighbours 0..11: (0,-2) (-1,-1) (0,-1) (1,-1) (-2,0) (-1,0) (1,0) (2,0) (-1,1) (0,1) (1,1) (0,2)
-      const float n[12] = {A[i], B[j - 1], B[j], B[j + 1], C[j - 2], C[j - 1], C[j + 1], C[j + 2],
-                           D[j - 1], D[j], D[j + 1], E[i]};
-      float acc = C[j];
-#pragma unroll
-      for (int k = 11; k >= 0; k--) acc = __builtin_fmaf(n[k], sads[i][k], acc);
-      o[i] = pass ? C[j] : acc * inv_w[i];
-    }
-    emit(c, make_float4(o[0], o[1], o[2], o[3]));
-  }
-}
+#include "filters_core.inc"
 
 // Overwrites out-of-frame positions of a stage's output region [B-m, B+T+m) with the values
 // at their mirrored in-frame coordinates.  Only called by tiles that touch the frame border.
