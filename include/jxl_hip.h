@@ -134,6 +134,8 @@ enum {
   JXLH_FRAME_UNFUSED_FILTERS = 1u << 0, /* run Gaborish/EPF as one kernel per stage (debug/parity) */
   JXLH_FRAME_EXPAND_SPARSE = 1u << 1,   /* always expand sparse submissions into dense slabs before the
                                            transforms instead of letting them read the pairs (debug/parity) */
+  JXLH_FRAME_NO_STRIP = 1u << 2,        /* whole-frame runs take the two-kernel path (transforms -> planes -> fused
+                                           filters) instead of the single strip kernel (debug/parity/A-B timing) */
 };
 
 /* Header defaults of the reference (RestorationFilter / ColorCorrelationParams /

@@ -32,6 +32,12 @@ jxlh_status jxlh_kernel_timing_reset(jxlh_ctx* ctx);
 jxlh_status jxlh_probe_copy_bandwidth(jxlh_ctx* ctx, size_t bytes, int32_t reps, float* gb_per_s);
 
 
+/* Which path the last jxlh_frame_run of the current frame took: *strip = 1 if the single strip kernel (k123_strip)
+ * produced the result; *tiles = 64x64 tiles of the frame, *tiles_by_class_kernels = how many of them were left to the
+ * transform class kernels (varblocks that leave their tile, special / large transforms) and only loaded by the strip
+ * kernel.  All 0 for the two-kernel path.  Synchronises the context's stream. */
+jxlh_status jxlh_frame_path(jxlh_ctx* ctx, int32_t* strip, int32_t* tiles, int32_t* tiles_by_class_kernels);
+
 /* Device self-test of the EPF weight normalisation: the filters compute 1/(1 + sum of weights)
  * (epf0.rs:208, epf1.rs:140, epf2.rs:130 divide) with rcp + two FMA refinement steps.  Counts the
  * floats whose bit pattern lies in [lo_bits, hi_bits) for which that differs from the IEEE

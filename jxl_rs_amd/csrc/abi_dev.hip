@@ -51,6 +51,23 @@ jxlh_status jxlh_kernel_timing_reset(jxlh_ctx* ctx) {
   return JXLH_OK;
 }
 
+jxlh_status jxlh_frame_path(jxlh_ctx* ctx, int32_t* strip, int32_t* tiles, int32_t* tiles_by_class_kernels) {
+  JXLH_ON_DEVICE(ctx);
+  if (!ctx) return JXLH_ERR_INVALID_ARGUMENT;
+  if (strip) *strip = ctx->strip_ran ? 1 : 0;
+  int32_t n = 0, k = 0;
+  if (ctx->strip_ran && ctx->strip_mode.p) {
+    n = (int32_t)(strip_strips(ctx->fd) * strip_tile_rows(ctx->fd));
+    std::vector<uint8_t> m((size_t)n);
+    HIPCHK(ctx, hipMemcpyAsync(m.data(), ctx->strip_mode.p, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (uint8_t v : m) k += v != 0;
+  }
+  if (tiles) *tiles = n;
+  if (tiles_by_class_kernels) *tiles_by_class_kernels = k;
+  return JXLH_OK;
+}
+
 jxlh_status jxlh_selftest_recip(jxlh_ctx* ctx, uint32_t lo_bits, uint32_t hi_bits, uint64_t* mismatches) {
   JXLH_ON_DEVICE(ctx);
   if (!ctx || !mismatches || hi_bits < lo_bits) return JXLH_ERR_INVALID_ARGUMENT;

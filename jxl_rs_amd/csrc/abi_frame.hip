@@ -164,6 +164,10 @@ void jxlh_ctx_destroy(jxlh_ctx* ctx) {
   release(ctx->ups_kernels);
   if (ctx->host_flag) (void)hipHostFree(ctx->host_flag);
   release(ctx->worklist);
+  release(ctx->strip_desc);
+  release(ctx->strip_mode);
+  release(ctx->strip_xchg);
+  release(ctx->strip_flags);
   for (auto& b : ctx->hook_f) release(b);
   for (auto& b : ctx->hook_i) release(b);
   if (ctx->t0) (void)hipEventDestroy(ctx->t0);
@@ -302,6 +306,8 @@ jxlh_status jxlh_frame_begin(jxlh_ctx* ctx, const jxlh_frame_params* p) {
   ctx->lf_smoothed = false;
   ctx->rendered = false;
   ctx->has_special = ctx->has_large = false;
+  ctx->strip_all_closed = true;
+  ctx->strip_ran = false;
   for (auto& s : ctx->slots) s.used = false;
   for (int c = 0; c < 3; c++) ctx->result[c] = nullptr;
   ctx->chroma_lazy = false;
@@ -431,6 +437,25 @@ jxlh_status jxlh_frame_set_hf_meta(jxlh_ctx* ctx, uint32_t x0, uint32_t y0, uint
   // which of the rarely used transform families the frame holds at all (their kernels are not even launched for a
   // frame without them: four empty launches cost ~20 us of a 0.45 ms K1).  A map that arrives in device memory is not
   // inspected: both families are then assumed present.
+  if (is_device_ptr(transform_map)) {
+    ctx->strip_all_closed = false;
+  } else if (ctx->strip_all_closed) {
+    // is every varblock a DCT with sides <= 32 inside its 64x64 tile?  (rects start on tile boundaries: x0, y0 % 8 == 0)
+    bool closed = true;
+    for (uint32_t y = 0; y < h && closed; y++) {
+      const uint8_t* row = transform_map + (size_t)y * map_stride;
+      for (uint32_t x = 0; x < w; x++) {
+        if (row[x] < 128) continue;
+        const int t = row[x] & 127;
+        if (t >= JXLH_NUM_TRANSFORMS || t == 1 || t == 2 || t == 3 || t >= 12 ||
+            (x & 7) + (uint32_t)covered_x(t) > 8 || (y & 7) + (uint32_t)covered_y(t) > 8) {
+          closed = false;
+          break;
+        }
+      }
+    }
+    ctx->strip_all_closed = closed;
+  }
   if (is_device_ptr(transform_map)) {
     ctx->has_special = ctx->has_large = true;
   } else if (!(ctx->has_special && ctx->has_large)) {
@@ -564,7 +589,7 @@ jxlh_status run_prologue(jxlh_ctx* ctx, RunPlan* plan) {
       if (nw)
         HIPCHK(ctx, hipMemcpyAsync(ctx->sp_wide_dev.p, ctx->sp_wide_upload.data(), nw * sizeof(uint2),
                                    hipMemcpyHostToDevice, ctx->stream));
-      bool all_pairs = nw == 0 && ng == ctx->ngroups && !(p.flags & JXLH_FRAME_EXPAND_SPARSE);
+      bool all_pairs = nw == 0 && ng == ctx->ngroups && !(p.flags & JXLH_FRAME_EXPAND_SPARSE) && !plan->want_strip;
       for (size_t g = 0; all_pairs && g < ctx->ngroups; g++) all_pairs = ctx->touched[g] == 2;
       // pairs that ADD to a group's earlier passes need that group's dense slab
       std::vector<uint8_t> accum(ctx->ngroups, 0);
@@ -641,6 +666,7 @@ jxlh_status run_prologue(jxlh_ctx* ctx, RunPlan* plan) {
   // K1 writes the 8x8-tiled layout whenever the fused filter kernel is its only consumer
   plan->will_fuse = !(p.flags & JXLH_FRAME_UNFUSED_FILTERS) && (f.gab || f.epf_iters > 0);
   f.tiled = plan->will_fuse ? 1 : 0;
+  plan->want_strip = plan->want_strip && !sparse_k1;
   return JXLH_OK;
 }
 
@@ -679,6 +705,82 @@ jxlh_status run_k1(jxlh_ctx* ctx, const RunPlan& plan, int gr0, int gr1) {
     else ctx->chroma_lazy = true;
   }
   return JXLH_OK;
+}
+
+// Whole-frame runs of a 4:4:4 frame with Gaborish and / or EPF1 (+ EPF2) go through the strip kernel (k_strip.hip)
+bool strip_eligible(const jxlh_ctx* ctx) {
+  const FrameDev& f = ctx->fd;
+  const jxlh_frame_params& p = ctx->params;
+  static const bool off = [] {
+    const char* e = getenv("JXLH_NO_STRIP");
+    return e && *e && *e != '0';
+  }();
+  return !off && !(p.flags & (JXLH_FRAME_UNFUSED_FILTERS | JXLH_FRAME_NO_STRIP)) && !f.subsampled && f.epf_iters <= 2 &&
+         (f.gab || f.epf_iters >= 1) && comm_nranks(ctx) <= 1;
+}
+
+// transforms + stage list of the whole frame in the strip kernel; tiles it cannot take (k1_scan decides) go through
+// K1's class kernels first
+jxlh_status run_strip(jxlh_ctx* ctx, const RunPlan& plan) {
+  FrameDev& f = ctx->fd;
+  (void)plan;
+  if (!ctx->cu_count) {
+    hipDeviceProp_t prop;
+    HIPCHK(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    ctx->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  const int strips = strip_strips(f), tile_rows = strip_tile_rows(f);
+  // two workgroups per CU; a band is at least 4 tile rows (two extra transforms per band and strip)
+  int bands = (2 * ctx->cu_count + strips / 2) / strips;
+  bands = std::max(1, std::min(bands, std::max(1, tile_rows / 4)));
+  static const int forced_bands = [] {
+    const char* e = getenv("JXLH_STRIP_BANDS");
+    return e ? atoi(e) : 0;
+  }();
+  if (forced_bands > 0) bands = std::min(forced_bands, tile_rows);
+  const size_t nblocks = (size_t)f.xblocks * f.yblocks;
+  const bool fresh = ctx->strip_desc.n < nblocks;
+  if (jxlh_status st = ensure(ctx, ctx->strip_desc, nblocks)) return st;
+  if (jxlh_status st = ensure(ctx, ctx->strip_mode, (size_t)strips * tile_rows)) return st;
+  if (jxlh_status st = ensure(ctx, ctx->strip_xchg, strip_xchg_floats(f))) return st;
+  if (jxlh_status st = ensure(ctx, ctx->strip_flags, strip_flag_ints(f, bands))) return st;
+  // blocks no varblock covers (rects never set, broken maps) keep an invalid descriptor
+  if (fresh) HIPCHK(ctx, hipMemsetAsync(ctx->strip_desc.p, 0, nblocks * sizeof(uint2), ctx->stream));
+  f.strip_desc = ctx->strip_desc.p;
+  f.strip_mode = ctx->strip_mode.p;
+  f.strip_flags = ctx->strip_flags.p;
+  f.strip_nflags = (int)strip_flag_ints(f, bands);
+  f.strips = strips;
+  f.tile_rows = tile_rows;
+  f.strip_all_closed = ctx->strip_all_closed ? 1 : 0;
+  f.tiled = 1;
+  f.sp_sorted = nullptr;
+  f.sp_slot_start = nullptr;
+  f.group_dense = nullptr;
+  {
+    ScopedKernelTimer t(ctx, "k1_vardct");
+    launch_vardct_groups(ctx->stream, f, 0, f.ygroups, ctx->worklist.p, &ctx->k1_launches, ctx->error_flag.p, nullptr,
+                         nullptr, 0, ctx->has_special, ctx->has_large);
+  }
+  {
+    ScopedKernelTimer t(ctx, "k123_strip");
+    static const float deadline_s = [] {
+      const char* e = getenv("JXLH_STRIP_DEADLINE_S");
+      return e ? (float)atof(e) : 4.0f;
+    }();
+    launch_strip(ctx->stream, f, f.strip_desc, f.strip_mode, ctx->strip_xchg.p, ctx->strip_flags.p, bands,
+                 ctx->error_flag.p, deadline_s);
+  }
+  f.strip_desc = nullptr;  // band runs / re-renders of this frame take the two-kernel path
+  f.strip_mode = nullptr;
+  if (!ctx->k1_done) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->k1_done, hipEventDisableTiming));
+  HIPCHK(ctx, hipEventRecord(ctx->k1_done, ctx->stream));
+  ctx->k1_done_valid = true;
+  ctx->chroma_lazy = false;
+  ctx->rendered = true;
+  ctx->strip_ran = true;
+  // upsampling / noise behind the stage list: the strip kernel leaves the filtered planes in f.tmp
+  return run_post_stages(ctx, f.tmp, 0, f.ysize, true);
 }
 
 // the stage list on group rows [group_row0, group_row1), then upsampling and noise
@@ -747,6 +849,13 @@ jxlh_status run_stages_rows(jxlh_ctx* ctx, const RunPlan& plan, int y_lo, int y_
       oth[c] = t;
     }
   }
+  return run_post_stages(ctx, cur, y_lo, y_hi, whole_frame);
+}
+
+// what follows the filters: upsampling and noise on the finished planes `cur` (rows [y_lo, y_hi))
+jxlh_status run_post_stages(jxlh_ctx* ctx, float* const cur[3], int y_lo, int y_hi, bool whole_frame) {
+  FrameDev& f = ctx->fd;
+  const jxlh_frame_params& p = ctx->params;
   for (int c = 0; c < 3; c++) ctx->result[c] = cur[c];
   ctx->res_w = f.xsize;
   ctx->res_h = f.ysize;
@@ -809,7 +918,11 @@ jxlh_status jxlh_frame_run(jxlh_ctx* ctx, uint32_t group_row0, uint32_t group_ro
   if (group_row1 > (uint32_t)f.ygroups) group_row1 = (uint32_t)f.ygroups;
   if (group_row0 >= group_row1) return JXLH_ERR_INVALID_ARGUMENT;
   RunPlan plan;
+  const bool whole = group_row0 == 0 && group_row1 == (uint32_t)f.ygroups;
+  plan.want_strip = whole && strip_eligible(ctx);
   if (jxlh_status st = run_prologue(ctx, &plan)) return st;
+  ctx->strip_ran = false;
+  if (plan.want_strip) return run_strip(ctx, plan);
   // ---- K1 on the band plus one halo group row on each side (filters read across it)
   // (vertical chroma upsampling reads one sub-sampled row beyond the band as well)
   const bool need_halo = plan.halo_px > 0 || f.subsampled;
@@ -838,7 +951,7 @@ jxlh_status jxlh_frame_rerender_groups(jxlh_ctx* ctx, const uint32_t* group_ids,
   // or no filter at all); a stage list that ends in `planes` has overwritten them, a sub-sampled frame keeps them
   // in another form, and a frame that was never rendered has none: those render the frame again.
   const bool per_stage = (p.flags & JXLH_FRAME_UNFUSED_FILTERS) != 0;  // ping-pongs planes <-> tmp: kept only for one stage
-  const bool unfiltered_kept = ns == 0 || (per_stage ? ns == 1 : result_in_tmp(ctx) != 0);
+  const bool unfiltered_kept = !ctx->strip_ran && (ns == 0 || (per_stage ? ns == 1 : result_in_tmp(ctx) != 0));
   // Noise is added IN PLACE to the result planes.  Without a filter stage the result lives in `planes`, the planes K1
   // writes: the groups that are not re-transformed would receive their noise a second time.
   const bool noise_in_place = ns == 0 && p.noise && !noise_lut_is_zero(p.noise_lut);

@@ -120,6 +120,16 @@ struct jxlh_ctx {
   std::vector<uint8_t> touched, flag_upload;
   bool epoch_dirty = false;
   bool sp_sorted_valid = false;
+  // strip path (k_strip.hip): block descriptors / tile modes written by k1_scan, the strips' edge-column exchange
+  // buffer, progress flags + ticket.  strip_all_closed: every rect of the transform map came from host memory and
+  // every varblock in it is a small DCT inside its 64x64 tile (jxlh_frame_set_hf_meta); strip_ran: the last
+  // jxlh_frame_run went through the strip kernel (`planes` then hold no unfiltered pixels).
+  DevBuf<uint2> strip_desc;
+  DevBuf<uint8_t> strip_mode;
+  DevBuf<float> strip_xchg;
+  DevBuf<int> strip_flags;
+  bool strip_all_closed = true, strip_ran = false;
+  int cu_count = 0;
   // profiling
   bool timing = false;
   std::vector<KernelTime> ktimes;
@@ -230,11 +240,15 @@ struct RunPlan {
   bool sparse_k1 = false;
   int halo_px = 0;       // rows the filters read beyond a band
   bool will_fuse = false;
+  bool want_strip = false;  // in: the caller would run the strip kernel (dense slabs needed); out: it will
 };
 jxlh_status run_prologue(jxlh_ctx* ctx, RunPlan* plan);
 jxlh_status run_k1(jxlh_ctx* ctx, const RunPlan& plan, int gr0, int gr1);
 jxlh_status run_stages(jxlh_ctx* ctx, const RunPlan& plan, uint32_t group_row0, uint32_t group_row1);
 jxlh_status run_stages_rows(jxlh_ctx* ctx, const RunPlan& plan, int y_lo, int y_hi, bool whole_frame);
+jxlh_status run_post_stages(jxlh_ctx* ctx, float* const cur[3], int y_lo, int y_hi, bool whole_frame);
+bool strip_eligible(const jxlh_ctx* ctx);
+jxlh_status run_strip(jxlh_ctx* ctx, const RunPlan& plan);
 // Where run_stages leaves the finished planes (1 = f.tmp, 0 = f.planes): a property of the frame's stage list, so a
 // rank that filtered nothing (empty band) still knows where the gathered frame lives.
 inline int result_in_tmp(const jxlh_ctx* ctx) {

@@ -127,6 +127,16 @@ struct FrameDev {
   const uint32_t* sp_sorted;
   const uint32_t* sp_slot_start;
   uint8_t* group_dense;
+  // Strip path (k_strip.hip; null = the frame runs K1 -> planes -> filters): written by k1_scan<STRIP> -- per block a
+  // descriptor {type | dx << 5 | dy << 7 | off64 << 9 | 1 << 31, raw_quant of its varblock}, per 64x64 tile who
+  // reconstructs it (0 = the strip kernel, 1 = K1's class kernels); the scan also clears the strip kernel's progress
+  // flags.  strip_all_closed: the host inspected the whole transform map and every tile is the strip kernel's.
+  uint2* strip_desc;
+  uint8_t* strip_mode;
+  int* strip_flags;
+  int strip_nflags;
+  int strips, tile_rows;
+  int strip_all_closed;
 };
 constexpr int kLfGroupBlocks = 256;  // an LF group is 2048 x 2048 pixels
 constexpr int kSlotTable = 1025;  // 1024 slots of 64 coefficients per (group, channel) + end marker
@@ -196,6 +206,14 @@ void launch_vardct_groups(hipStream_t s, const FrameDev& f, int group_row0, int 
                           void* worklist_mem, uint32_t* launch_parity, int* error_flag, int32_t* dense_coeffs,
                           const int* group_list = nullptr, int n_list = 0, bool has_special = true,
                           bool has_large = true);
+// k_strip.hip: dequantisation + IDCT + the frame's filter stages in one persistent kernel, result in f.tmp (raster).
+// Runs behind launch_vardct_groups on a FrameDev with the strip_* members set.  false = stage list not covered.
+int strip_tile_rows(const FrameDev& f);
+int strip_strips(const FrameDev& f);
+size_t strip_xchg_floats(const FrameDev& f);
+size_t strip_flag_ints(const FrameDev& f, int bands);
+bool launch_strip(hipStream_t s, const FrameDev& f, const uint2* desc, const uint8_t* tile_mode, float* xchg, int* flags,
+                  int bands, int* error_flag, float deadline_s);
 void launch_gaborish(hipStream_t s, const float* in, float* out, int w, int h, size_t stride, float k0, float k1,
                      float k2, int y0, int y1);
 struct EpfArgs {

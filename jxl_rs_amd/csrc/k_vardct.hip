@@ -50,6 +50,11 @@ namespace {
 // address atomics serialise at ~12 ns each: 13 of the former 36 us).
 constexpr int kScanGroups = 4;
 constexpr int kScanThreads = kScanGroups * kThreads;
+// STRIP (the frame runs through k123_strip, k_strip.hip): the scan also decides per 64x64 tile who reconstructs it -- the
+// strip kernel, iff every varblock touching the tile lies inside it and is a DCT with sides <= 32 -- writes a descriptor
+// per block of those tiles ({type | dx << 5 | dy << 7 | off64 << 9 | 1 << 31, raw_quant of the varblock}: everything the
+// strip kernel needs to find a block's varblock and its coefficients) and appends work items for the OTHER tiles only.
+template <bool STRIP>
 __global__ __launch_bounds__(kScanThreads) void k1_scan(const FrameDev f, const WorkLists wl, const int group_row0,
                                                          int* __restrict__ error_flag,
                                                          const int* __restrict__ group_list, const int ngroups,
@@ -58,6 +63,14 @@ __global__ __launch_bounds__(kScanThreads) void k1_scan(const FrameDev f, const 
   __shared__ int s_wave_sum[kScanGroups][kWaves];
   __shared__ uint32_t s_wcls[kScanGroups][kWaves][kPairs];
   __shared__ int s_count[kScanGroups][kNumClasses], s_base[kScanGroups][kNumClasses];
+  __shared__ int s_tmode[kScanGroups][16];  // STRIP: != 0 = a tile of the group (4 x 4 of them) the class kernels keep
+  if constexpr (STRIP) {
+    if (threadIdx.x < kScanGroups * 16) s_tmode[threadIdx.x / 16][threadIdx.x % 16] = 0;
+    // progress flags + ticket counter of the strip kernel that follows
+    if (blockIdx.x == 0)
+      for (int i = threadIdx.x; i < f.strip_nflags; i += kScanThreads) f.strip_flags[i] = 0;
+    __syncthreads();
+  }
   // the counters of the NEXT launch (the other set: its last readers finished before this kernel started)
   if (blockIdx.x == 0 && threadIdx.x <= kNumClasses) next_counts[threadIdx.x * kCountPitch] = 0;
   const int sub = threadIdx.x / kThreads, tid = threadIdx.x % kThreads, lane = tid & 63, wave = tid >> 6;
@@ -98,8 +111,21 @@ __global__ __launch_bounds__(kScanThreads) void k1_scan(const FrameDev f, const 
           atomicExch(error_flag, JXLH_ERR_BLOCK_OUT_OF_BOUNDS);
           sz = 0;
         }
+        if constexpr (STRIP) {
+          // tiles this varblock keeps away from the strip kernel: all it touches if it is not a small DCT or leaves
+          // its tile; every tile of the group if the map is broken
+          const bool closed = (bx & 7) + cx <= 8 && (by & 7) + cy <= 8 && class_of_type_reg(type) < kClsSpecial;
+          if (sz == 0 || f.subsampled) {
+            for (int k = 0; k < 16; k++) atomicOr(&s_tmode[sub][k], 1);
+          } else if (!closed) {
+            for (int ty = by >> 3; ty <= (by + cy - 1) >> 3; ty++)
+              for (int tx = bx >> 3; tx <= (bx + cx - 1) >> 3; tx++) atomicOr(&s_tmode[sub][ty * 4 + tx], 1);
+          }
+        }
       } else {
         atomicExch(error_flag, JXLH_ERR_INVALID_TRANSFORM);  // Error::InvalidVarDCTTransform
+        if constexpr (STRIP)
+          for (int k = 0; k < 16; k++) atomicOr(&s_tmode[sub][k], 1);
       }
     }
     sizes[i] = sz;
@@ -118,12 +144,17 @@ __global__ __launch_bounds__(kScanThreads) void k1_scan(const FrameDev f, const 
   // contiguous coefficient reads, full-line pixel writes).  Two classes share a 32-bit word, 16 bits each (a group
   // holds at most 1024 varblocks).
   int slot[4], cls4[4];
+  bool strip_tile = false;  // the thread's four blocks share a tile
+  if constexpr (STRIP) {
+    __syncthreads();
+    strip_tile = s_tmode[sub][(by >> 3) * 4 + (bx4 >> 3)] == 0;
+  }
   uint32_t mine[kPairs], excl[kPairs];
 #pragma unroll
   for (int w = 0; w < kPairs; w++) mine[w] = 0;
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    const int cls = sizes[i] > 0 ? class_of_type_reg(types[i]) : -1;
+    const int cls = sizes[i] > 0 && !strip_tile ? class_of_type_reg(types[i]) : -1;
     cls4[i] = cls;
     slot[i] = 0;
     const int sh = (cls & 1) * 16;
@@ -187,6 +218,12 @@ __global__ __launch_bounds__(kScanThreads) void k1_scan(const FrameDev f, const 
     }
   }
   if (live && tid == 0 && f.group_dense) f.group_dense[group] = (s_count[sub][kClsSpecial] | s_count[sub][kClsLarge]) != 0;
+  if constexpr (STRIP) {
+    if (live && tid < 16) {
+      const int gtx = (group % f.xgroups) * 4 + (tid & 3), gty = (group / f.xgroups) * 4 + (tid >> 2);
+      if (gtx < f.strips && gty < f.tile_rows) f.strip_mode[gty * f.strips + gtx] = (bad_group || s_tmode[sub][tid]) ? 1 : 0;
+    }
+  }
   __syncthreads();
   if (bad_group) return;
 #pragma unroll
@@ -198,44 +235,27 @@ __global__ __launch_bounds__(kScanThreads) void k1_scan(const FrameDev f, const 
       it.raw_quant = rq4[i];
       it.cc = cc;
       const int cls = cls4[i];
-      const int sh = (cls & 1) * 16;
-      int rank = slot[i];
+      if (cls >= 0) {
+        const int sh = (cls & 1) * 16;
+        int rank = slot[i];
 #pragma unroll
-      for (int w = 0; w < kPairs; w++)
-        if ((cls >> 1) == w) rank += (int)((excl[w] >> sh) & 0xffffu);
-      wl.items[cls][s_base[sub][cls] + rank] = it;
+        for (int w = 0; w < kPairs; w++)
+          if ((cls >> 1) == w) rank += (int)((excl[w] >> sh) & 0xffffu);
+        wl.items[cls][s_base[sub][cls] + rank] = it;
+      }
+      if constexpr (STRIP) {
+        if (strip_tile) {
+          const int cx = 1 << log2_covered_x_reg(types[i]), cy = 1 << log2_covered_y_reg(types[i]);
+          const uint32_t d0 = (uint32_t)types[i] | ((uint32_t)off64 << 9) | (1u << 31);
+          for (int dy = 0; dy < cy; dy++)
+            for (int dx = 0; dx < cx; dx++)
+              f.strip_desc[(size_t)(by0 + by + dy) * f.xblocks + bx0 + bx4 + i + dx] =
+                  make_uint2(d0 | ((uint32_t)dx << 5) | ((uint32_t)dy << 7), (uint32_t)rq4[i]);
+        }
+      }
     }
     off64 += sizes[i];
   }
-}
-
-// Dequantise four consecutive coefficients of channel CH (0 = X, 1 = Y, 2 = B); dy = the
-// dequantised Y at the same positions (in for X/B, out for Y).  dequant_lane, group.rs:100-133.
-template <int CH>
-__device__ __forceinline__ float4 dequant4(const FrameDev& f, const int4 q, const float4 t, const BlockInfo& bi,
-                                           float (&dy)[4]) {
-  const float bias3 = f.quant_biases[3];
-  const float bias = f.quant_biases[CH];
-  float sd = bi.sdy;
-  if constexpr (CH == 0) sd = bi.sdy * f.x_dm;
-  if constexpr (CH == 2) sd = bi.sdy * f.b_dm;
-  const int qq[4] = {q.x, q.y, q.z, q.w};
-  const float tt[4] = {t.x, t.y, t.z, t.w};
-  float r[4];
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const float mul = tt[i] * sd;
-    const float v = adjust_quant_bias(qq[i], bias, bias3) * mul;
-    if constexpr (CH == 1) {
-      dy[i] = v;
-      r[i] = v;
-    } else if constexpr (CH == 0) {
-      r[i] = __builtin_fmaf(bi.x_cc, dy[i], v);
-    } else {
-      r[i] = __builtin_fmaf(bi.b_cc, dy[i], v);
-    }
-  }
-  return make_float4(r[0], r[1], r[2], r[3]);
 }
 
 template <class S>
@@ -713,8 +733,13 @@ void launch_vardct_groups(hipStream_t s, const FrameDev& f, int group_row0, int 
     p += (nblocks / class_min_area(c) + 1) * sizeof(WorkItem);
   }
   uint32_t* large_units = reinterpret_cast<uint32_t*>(p);  // behind the last class list
-  hipLaunchKernelGGL(k1_scan, dim3((ngroups + kScanGroups - 1) / kScanGroups), dim3(kScanThreads), 0, s, f, wl, group_row0,
-                     error_flag, group_list, ngroups, next_counts);
+  if (f.strip_desc)
+    hipLaunchKernelGGL(k1_scan<true>, dim3((ngroups + kScanGroups - 1) / kScanGroups), dim3(kScanThreads), 0, s, f, wl,
+                       group_row0, error_flag, group_list, ngroups, next_counts);
+  else
+    hipLaunchKernelGGL(k1_scan<false>, dim3((ngroups + kScanGroups - 1) / kScanGroups), dim3(kScanThreads), 0, s, f, wl,
+                       group_row0, error_flag, group_list, ngroups, next_counts);
+  if (f.strip_desc && f.strip_all_closed) return;  // the host saw the whole map: no tile is left to the class kernels
   // grids: enough waves to fill the chip; kernels stride over their lists (counts are device-side)
   const int nblk = ngroups * kGroupBlocks * kGroupBlocks;
   auto grid_for = [](long work_items, int items_per_wg, int cap) {

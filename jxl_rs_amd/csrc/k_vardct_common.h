@@ -119,4 +119,33 @@ __device__ __forceinline__ float adjust_quant_bias(int q, float bias_c, float bi
   return (q > -2 && q < 2) ? quant * bias_c : adjusted;
 }
 
+// Dequantise four consecutive coefficients of channel CH (0 = X, 1 = Y, 2 = B); dy = the
+// dequantised Y at the same positions (in for X/B, out for Y).  dequant_lane, group.rs:100-133.
+template <int CH>
+__device__ __forceinline__ float4 dequant4(const FrameDev& f, const int4 q, const float4 t, const BlockInfo& bi,
+                                           float (&dy)[4]) {
+  const float bias3 = f.quant_biases[3];
+  const float bias = f.quant_biases[CH];
+  float sd = bi.sdy;
+  if constexpr (CH == 0) sd = bi.sdy * f.x_dm;
+  if constexpr (CH == 2) sd = bi.sdy * f.b_dm;
+  const int qq[4] = {q.x, q.y, q.z, q.w};
+  const float tt[4] = {t.x, t.y, t.z, t.w};
+  float r[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const float mul = tt[i] * sd;
+    const float v = adjust_quant_bias(qq[i], bias, bias3) * mul;
+    if constexpr (CH == 1) {
+      dy[i] = v;
+      r[i] = v;
+    } else if constexpr (CH == 0) {
+      r[i] = __builtin_fmaf(bi.x_cc, dy[i], v);
+    } else {
+      r[i] = __builtin_fmaf(bi.b_cc, dy[i], v);
+    }
+  }
+  return make_float4(r[0], r[1], r[2], r[3]);
+}
+
 }  // namespace jxlh

@@ -27,6 +27,8 @@ ERR_UNSUPPORTED = -6
 ERR_INVALID_BLOCK_SIZE = -7
 ERR_BLOCK_OUT_OF_BOUNDS = -8
 FRAME_UNFUSED_FILTERS = 1
+FRAME_EXPAND_SPARSE = 2
+FRAME_NO_STRIP = 4
 GROUP_COMPLETE = 1
 GROUP_ACCUMULATE = 2
 
@@ -53,7 +55,7 @@ ABI_SYMBOLS = [
 # developer / bench instruments: include/jxl_hip_dev.h (same library, not part of the drop-in boundary)
 DEV_SYMBOLS = [
     "jxlh_timer_start", "jxlh_timer_stop", "jxlh_kernel_timing_enable", "jxlh_kernel_timing_get",
-    "jxlh_kernel_timing_reset", "jxlh_selftest_recip", "jxlh_probe_copy_bandwidth",
+    "jxlh_kernel_timing_reset", "jxlh_selftest_recip", "jxlh_probe_copy_bandwidth", "jxlh_frame_path",
 ]
 
 
@@ -190,6 +192,7 @@ def load():
     L.jxlh_frames_allgather_local.argtypes = [C.POINTER(vp), i32]
     L.jxlh_comm_allgather.argtypes = [vp, vp, sz]
     L.jxlh_probe_copy_bandwidth.argtypes = [vp, sz, i32, fp]
+    L.jxlh_frame_path.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     L.jxlh_frame_rerender_groups.argtypes = [vp, vp, u32]
     L.jxlh_comm_allgather_local.argtypes = [C.POINTER(vp), i32, C.POINTER(vp), sz]
     L.jxlh_palette_strided.argtypes = [vp, vp, sz, vp, i32, sz, i32, i32, vp, sz]
@@ -453,6 +456,12 @@ class Context:
         v = C.c_float()
         self._chk(self.L.jxlh_probe_copy_bandwidth(self._ctx, nbytes, reps, C.byref(v)), "probe_copy_bandwidth")
         return v.value
+
+    def frame_path(self):
+        """(strip kernel ran, 64x64 tiles of the frame, tiles left to the transform class kernels) of the last frame_run"""
+        a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+        self._chk(self.L.jxlh_frame_path(self._ctx, C.byref(a), C.byref(b), C.byref(c)), "frame_path")
+        return bool(a.value), int(b.value), int(c.value)
 
     # ---- multi-GPU (one process per GPU: RCCL communicator owned by the library)
     def comm_init(self, unique_id, rank, nranks):

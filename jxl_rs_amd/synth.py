@@ -220,11 +220,14 @@ def library_dequant_tables():
 
 
 # ----------------------------------------------------------------------------------------
-def random_group_tiling(rng, bw, bh, mix):
+def random_group_tiling(rng, bw, bh, mix, aligned=False):
     """Random valid varblock tiling of a bw x bh (blocks) group.  Returns the u8 transform map
     (bit 7 = top-left block, frame/group.rs:468-473) and the varblock list (bx, by, type) in
     raster order of the top-left block.  Varblocks never leave the group
-    (frame/modular/mod.rs:1061-1064) but are otherwise unaligned, as the format allows."""
+    (frame/modular/mod.rs:1061-1064).  aligned=False: otherwise unaligned, as the format allows.
+    aligned=True: every varblock starts on a multiple of its own size in each direction -- the law SURVEY.md section
+    8(d) gives for the synthetic inputs, and what libjxl's encoder emits (its AC-strategy search merges blocks inside
+    64x64 tiles at positions aligned to the merged size)."""
     types = list(mix.keys())
     area = np.array([COVERED_X[t] * COVERED_Y[t] for t in types], dtype=np.float64)
     # area weights -> pick probability per placement
@@ -236,7 +239,32 @@ def random_group_tiling(rng, bw, bh, mix):
     # The raster-order fill below almost never finds room for a 64..256-pixel varblock (it would have to start on a
     # still-empty 8..32-block square), so those types are seeded first: per type, as many placements as its area
     # share of the group calls for (stochastic rounding), at free positions aligned to the varblock's own size.
-    for t in sorted((t for t in types if COVERED_X[t] * COVERED_Y[t] >= 64), key=lambda t: -COVERED_X[t] * COVERED_Y[t]):
+    if aligned:
+        # every multi-block type is seeded, largest first, at random free positions aligned to its own size, as many
+        # as its area share calls for; the raster fill below then only adds 8x8 types.  (Filling in raster order with
+        # the alignment as an extra condition starves the large shapes: 81 % DCT8 instead of the mix's 50 %.)
+        for t in sorted((t for t in types if COVERED_X[t] * COVERED_Y[t] > 1), key=lambda t: (-COVERED_X[t] * COVERED_Y[t], t)):
+            cx, cy = COVERED_X[t], COVERED_Y[t]
+            want = mix[t] / sum(mix.values()) * bw * bh / (cx * cy)
+            count = int(want) + (1 if rng.random() < want - int(want) else 0)
+            cand = [(x, y) for y in range(0, bh - cy + 1, cy) for x in range(0, bw - cx + 1, cx)]
+            for i in rng.permutation(len(cand)):
+                if count <= 0:
+                    break
+                x, y = cand[int(i)]
+                if covered[y:y + cy, x:x + cx].any():
+                    continue
+                covered[y:y + cy, x:x + cx] = True
+                tmap[y:y + cy, x:x + cx] = t
+                tmap[y, x] = t | 0x80
+                placed_at[(x, y)] = t
+                count -= 1
+        small = [t for t in types if COVERED_X[t] * COVERED_Y[t] == 1]
+        if small:
+            types = small
+            prob = np.array([mix[t] for t in types], dtype=np.float64)
+            prob /= prob.sum()
+    for t in sorted((t for t in types if COVERED_X[t] * COVERED_Y[t] >= 64 and not aligned), key=lambda t: -COVERED_X[t] * COVERED_Y[t]):
         cx, cy = COVERED_X[t], COVERED_Y[t]
         want = mix[t] * bw * bh / (cx * cy)
         count = int(want) + (1 if rng.random() < want - int(want) else 0)
@@ -263,6 +291,8 @@ def random_group_tiling(rng, bw, bh, mix):
             for oi in order:
                 t = types[oi]
                 cx, cy = COVERED_X[t], COVERED_Y[t]
+                if aligned and (bx % cx or by % cy):
+                    continue
                 if bx + cx <= bw and by + cy <= bh and not covered[by:by + cy, bx:bx + cx].any():
                     placed = True
                     break
@@ -330,7 +360,7 @@ def _coeff_block(rng, t, n):
 
 
 def make_vardct(xsize, ysize, mix=None, seed=0, unique_groups=None, epf_iters=2, gab=True, lf_smoothing=True,
-                coeff_scale=1, hshift=(0, 0, 0), vshift=(0, 0, 0)):
+                coeff_scale=1, hshift=(0, 0, 0), vshift=(0, 0, 0), aligned=False):
     """Builds a VarDCT workload.  unique_groups: generate only that many distinct group contents
     and reuse them round-robin (host-side generation time for 8K/16K frames); group *positions*,
     maps and LF are always generated for the whole frame."""
@@ -356,7 +386,7 @@ def make_vardct(xsize, ysize, mix=None, seed=0, unique_groups=None, epf_iters=2,
         if key is not None and key in cache:
             tmap, rq, slab = cache[key]
         else:
-            tmap, blocks = random_group_tiling(rng, bw, bh, mix)
+            tmap, blocks = random_group_tiling(rng, bw, bh, mix, aligned)
             rq = np.zeros((bh, bw), dtype=np.int32)
             slab = np.zeros((3, 65536), dtype=np.int32)
             # coefficients: varblocks back to back in raster order of their top-left block
@@ -400,7 +430,7 @@ def make_vardct(xsize, ysize, mix=None, seed=0, unique_groups=None, epf_iters=2,
     return VarDctWorkload(xsize, ysize, transform_map, raw_quant, epf_map, ytox, ytob, [qy, qx, qb], coeffs,
                           library_dequant_tables(),
                           dict(epf_iters=epf_iters, gab=gab, lf_smoothing=lf_smoothing, seed=seed,
-                               hshift=tuple(hshift), vshift=tuple(vshift)))
+                               hshift=tuple(hshift), vshift=tuple(vshift), aligned=bool(aligned)))
 
 
 def apply_opts(params, wl):
