@@ -440,7 +440,8 @@ jxlh_status jxlh_frame_set_hf_meta(jxlh_ctx* ctx, uint32_t x0, uint32_t y0, uint
   if (is_device_ptr(transform_map)) {
     ctx->strip_all_closed = false;
   } else if (ctx->strip_all_closed) {
-    // is every varblock a DCT with sides <= 32 inside its 64x64 tile?  (rects start on tile boundaries: x0, y0 % 8 == 0)
+    // is every varblock a DCT with sides <= 32 inside one 32x32 quadrant of its 64x64 tile?  (rects start on tile
+    // boundaries: x0, y0 % 8 == 0)
     bool closed = true;
     for (uint32_t y = 0; y < h && closed; y++) {
       const uint8_t* row = transform_map + (size_t)y * map_stride;
@@ -448,7 +449,7 @@ jxlh_status jxlh_frame_set_hf_meta(jxlh_ctx* ctx, uint32_t x0, uint32_t y0, uint
         if (row[x] < 128) continue;
         const int t = row[x] & 127;
         if (t >= JXLH_NUM_TRANSFORMS || t == 1 || t == 2 || t == 3 || t >= 12 ||
-            (x & 7) + (uint32_t)covered_x(t) > 8 || (y & 7) + (uint32_t)covered_y(t) > 8) {
+            (x & 3) + (uint32_t)covered_x(t) > 4 || (y & 3) + (uint32_t)covered_y(t) > 4) {
           closed = false;
           break;
         }

@@ -48,7 +48,7 @@
 #include "k_vardct_common.h"
 
 #ifndef JXLH_STRIP_WAVES
-#define JXLH_STRIP_WAVES 11
+#define JXLH_STRIP_WAVES 12
 #endif
 #ifndef JXLH_STRIP_WPE
 #define JXLH_STRIP_WPE 6
@@ -66,6 +66,24 @@
 #define JXLH_DENSE_ITEMS 40
 #endif
 
+#ifdef JXLH_STRIP_PROF
+// development variant (tools/build_variant.sh ... -DJXLH_STRIP_PROF): thread 0 of every workgroup accumulates the
+// s_memrealtime ticks (10 ns) it spends between the phase marks; read with jxlh_strip_prof_read
+__device__ unsigned long long g_strip_prof[16];
+#define PROF_MARK(i)                                          \
+  do {                                                        \
+    if (tid_kernel == 0) {                                    \
+      const unsigned long long now_ = now_ticks();            \
+      s_prof[i] += now_ - s_prof_t;                           \
+      s_prof_t = now_;                                        \
+    }                                                         \
+  } while (0)
+#else
+#define PROF_MARK(i) \
+  do {               \
+  } while (0)
+#endif
+
 namespace jxlh {
 namespace {
 
@@ -81,6 +99,7 @@ constexpr int kSigW = kBW / 8 + 2, kSigH = kBH / 8 + 2;
 constexpr int kDenseItems = JXLH_DENSE_ITEMS, kSparseMax = JXLH_SPARSE_MAX;
 static_assert(kCarry == 2 * kB, "the carry is the filter halo above the output tile plus the rows the output lags");
 static_assert(kNW * kUse >= ((kTH + 6) / 2) * kStrips, "one pass per in-place stage");
+static_assert(kNW >= 12, "one wavefront per (quadrant, channel) in the transform phase");
 
 struct FusedArgs {  // what filters_core.inc and the stage driver read (same names as k23_fused_filters' argument)
   float* out[3];
@@ -143,7 +162,8 @@ __device__ __forceinline__ void mirror_fill(float* __restrict__ buf, int m, int 
 __device__ __forceinline__ unsigned long long now_ticks() { return __builtin_amdgcn_s_memrealtime(); }
 
 // a block's descriptor, validated: whatever stale or hostile bits it holds, the varblock it describes lies inside the
-// tile, is one of the nine DCT shapes with sides <= 32 and its coefficients inside the group's slab
+// 32x32 quadrant of the tile its block is in, is one of the nine DCT shapes with sides <= 32 and its coefficients
+// inside the group's slab
 struct Blk {
   bool on;
   int type, dx, dy, lcx, lcy, off64;
@@ -158,8 +178,8 @@ __device__ __forceinline__ Blk decode_desc(uint32_t d, int bx, int by) {
   b.lcx = known ? log2_covered_x_reg(b.type) : 0;
   b.lcy = known ? log2_covered_y_reg(b.type) : 0;
   const int cx = 1 << b.lcx, cy = 1 << b.lcy;
-  b.on = known && b.dx < cx && b.dy < cy && b.dx <= bx && b.dy <= by && bx - b.dx + cx <= 8 && by - b.dy + cy <= 8 &&
-         b.off64 + cx * cy <= 1024;
+  b.on = known && b.dx < cx && b.dy < cy && b.dx <= (bx & 3) && b.dy <= (by & 3) && (bx & 3) - b.dx + cx <= 4 &&
+         (by & 3) - b.dy + cy <= 4 && b.off64 + cx * cy <= 1024;
   return b;
 }
 
@@ -214,25 +234,31 @@ __global__ __launch_bounds__(kNT, JXLH_STRIP_WPE) void k123_strip(const FrameDev
   __shared__ __attribute__((aligned(16))) float s_save[3 * kCarry * kBW];
   __shared__ float s_sigma[kSigH * kSigW];
   __shared__ uint16_t s_list[kBH * kStrips];
-  __shared__ uint16_t s_task[2][896];  // pass 1 / pass 2 tasks by length class: [0, 512) 8, [512, 768) 16, [768, 896) 32
+  __shared__ uint8_t s_wtask[12][448];  // per wavefront: pass 1 / pass 2 tasks of its quadrant by length class
   __shared__ uint32_t s_desc[64];
   __shared__ float s_sdy[64];
-  __shared__ int s_ntask[2][3];
-  __shared__ int s_cnt, s_nsw, s_ticket, s_abort;
+  __shared__ float s_lf[192];  // the tile's LF samples: [channel][block row][block column]
+  __shared__ int s_cnt, s_nsw, s_ticket, s_abort, s_pub;
+#ifdef JXLH_STRIP_PROF
+  __shared__ unsigned long long s_prof[16], s_prof_t;
+  if (threadIdx.x == 0) {
+    for (int i = 0; i < 16; i++) s_prof[i] = 0;
+    s_prof_t = now_ticks();
+  }
+#endif
   const FusedArgs& a = sa.fa;
-  const int tid_kernel = threadIdx.x, tid = tid_kernel;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int tid_kernel = threadIdx.x;
   constexpr int kBorder = (GAB ? 1 : 0) + (E1 ? 2 : 0) + (E2 ? 1 : 0);
   static_assert(kBorder >= 1 && kBorder <= kB, "at least one stage");
 
-  if (tid == 0) {
+  if (tid_kernel == 0) {
     s_ticket = atomicAdd(&sa.flags[sa.bands * sa.strips], 1);
     s_cnt = 0;
     s_nsw = 0;
     s_abort = 0;
   }
   __syncthreads();
-  const int ticket = s_ticket;
+  const int ticket = __builtin_amdgcn_readfirstlane(s_ticket);  // uniform: everything derived from it lives in SGPRs
   const int band = ticket / sa.strips, strip = ticket % sa.strips;
   if (band >= sa.bands) return;
   const int tr0 = (int)((long)band * sa.tile_rows / sa.bands), tr1 = (int)((long)(band + 1) * sa.tile_rows / sa.bands);
@@ -244,181 +270,203 @@ __global__ __launch_bounds__(kNT, JXLH_STRIP_WPE) void k123_strip(const FrameDev
   int* my_flag = sa.flags + band * sa.strips + strip;
   const int gx = strip / 4;  // group column (256 = 4 tiles)
 
+  // What a step's transform phase needs from global memory before it can address anything -- the tile's mode, its 64
+  // block descriptors, its 3 x 64 LF samples -- is fetched one step ahead into registers (threads 0..191).
+  uint2 nx_desc = make_uint2(0u, 1u);
+  float nx_lf = 0.0f;
+  int nx_mode = 1;
+  auto prefetch_meta = [&](int tt, int tid) {
+    if (tt >= sa.tile_rows || tt > t_end) return;
+    nx_mode = sa.tile_mode[tt * sa.strips + strip];
+    if (tid < 192) {
+      const int bi = tid & 63, gbx = strip * 8 + (bi & 7), gby = tt * 8 + (bi >> 3);
+      const bool in = gbx < f.xblocks && gby < f.yblocks;
+      const size_t at = (size_t)gby * f.xblocks + gbx;
+      if (tid < 64) nx_desc = in ? sa.desc[at] : make_uint2(0u, 1u);
+      nx_lf = in ? f.lf[tid >> 6][at] : 0.0f;
+    }
+  };
+  prefetch_meta(t_begin, tid_kernel);
+
   for (int t = t_begin; t <= t_end; t++) {
+    // Opaque copy of the thread id, per step: what a phase derives from it (addresses, lane masks, task geometry) is
+    // then computed where it is used instead of being hoisted out of the step loop, where it would sit in (spilled)
+    // registers for the whole kernel.
+    int tid = tid_kernel;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = tid >> 6;
     const bool has_tile = t < sa.tile_rows;
     const int ty0 = t * kTH - kB;  // frame row of window row kB (the filters' output tile starts there)
     const int seq = t - t_begin + 1;
     if (has_tile) {
-      const int mode = sa.tile_mode[t * sa.strips + strip];
-      if (mode == 0) {
-        // ---- (1a) the tile's block descriptors; task lists of the two IDCT passes
-        if (tid < 64) {
-          const int bx = tid & 7, by = tid >> 3;
-          const int gbx = strip * 8 + bx, gby = t * 8 + by;
-          uint2 d = make_uint2(0u, 1u);
-          if (gbx < f.xblocks && gby < f.yblocks) d = sa.desc[(size_t)gby * f.xblocks + gbx];
-          s_desc[tid] = d.x;
-          s_sdy[tid] = f.inv_global_scale / (float)(uint32_t)d.y;  // group.rs:153
-        }
-        if (tid < 6) s_ntask[tid / 3][tid % 3] = 0;
-        __syncthreads();
-        if (wave < 8) {
-          // pass 1 candidates: (row y of block row `wave`, block column): a task iff the block is the leftmost of its
-          // varblock; pass 2: (column x of block column `wave`, block row): iff it is the topmost
+      const int mode = nx_mode;
+      if (tid < 64) {
+        s_desc[tid] = nx_desc.x;
+        s_sdy[tid] = f.inv_global_scale / (float)(uint32_t)nx_desc.y;  // group.rs:153
+      }
+      if (tid < 192) s_lf[tid] = nx_lf;
+      if (tid == 0) s_pub = 0;
+      __syncthreads();
+      prefetch_meta(t + 1, tid);
+      PROF_MARK(0);
+      // Everything up to the filters is WAVE-LOCAL: wavefront (q, c) = (quadrant of the tile, channel) takes its 16
+      // blocks' worth of one channel from coefficients to pixels, publishes the 4 edge columns of its 32 rows and
+      // fetches the neighbour strip's 4 columns beside them -- only wave-scope synchronisation, so the twelve
+      // wavefronts (and the other workgroup of the CU) overlap each other's memory latencies the way K1's batches do.
+      // (k1_scan hands a tile to this kernel only if every varblock lies inside one 32x32 quadrant.)
+      const int q = wave / 3, ch = wave % 3;
+      const int qbx = (q & 1) * 4, qby = (q >> 1) * 4;  // the quadrant's first block inside the tile
+      if (mode == 0 && wave < 12) {
+        uint8_t* wl = s_wtask[wave];
+        // ---- (1a) this wavefront's tasks of the two IDCT passes, by length: [0, 128) 8, [128, 192) 16, [192, 224) 32
+        // pass 1 candidates: (row y of the quadrant, block column): a task iff the block is the leftmost of its
+        // varblock; pass 2: (column x, block row): iff it is the topmost
+        int n1[3] = {0, 0, 0}, n2[3] = {0, 0, 0};
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
           {
-            const int bxc = lane & 7, y = wave * 8 + (lane >> 3);
-            const Blk b = decode_desc(s_desc[wave * 8 + bxc], bxc, wave);
+            const int cand = r * 64 + lane, y = cand >> 2, bxc = cand & 3;
+            const Blk b = decode_desc(s_desc[(qby + (y >> 3)) * 8 + qbx + bxc], qbx + bxc, qby + (y >> 3));
             const bool act = b.on && b.dx == 0;
 #pragma unroll
             for (int k = 0; k < 3; k++) {
               const unsigned long long m = __ballot(act && b.lcx == k);
-              if (m) {
-                int base = 0;
-                if (lane == 0) base = atomicAdd(&s_ntask[0][k], __popcll(m));
-                base = __builtin_amdgcn_readfirstlane(base);
-                if (act && b.lcx == k)
-                  s_task[0][(k == 0 ? 0 : k == 1 ? 512 : 768) + base + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(y << 3 | bxc);
-              }
+              if (act && b.lcx == k) wl[(k == 0 ? 0 : k == 1 ? 128 : 192) + n1[k] + __popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)cand;
+              n1[k] += __popcll(m);
             }
           }
           {
-            const int byc = lane >> 3, x = wave * 8 + (lane & 7);
-            const Blk b = decode_desc(s_desc[byc * 8 + wave], wave, byc);
+            const int cand = r * 64 + lane, x = cand & 31, byc = cand >> 5;
+            const Blk b = decode_desc(s_desc[(qby + byc) * 8 + qbx + (x >> 3)], qbx + (x >> 3), qby + byc);
             const bool act = b.on && b.dy == 0;
 #pragma unroll
             for (int k = 0; k < 3; k++) {
               const unsigned long long m = __ballot(act && b.lcy == k);
-              if (m) {
-                int base = 0;
-                if (lane == 0) base = atomicAdd(&s_ntask[1][k], __popcll(m));
-                base = __builtin_amdgcn_readfirstlane(base);
-                if (act && b.lcy == k)
-                  s_task[1][(k == 0 ? 0 : k == 1 ? 512 : 768) + base + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(x << 3 | byc);
-              }
+              if (act && b.lcy == k) wl[224 + (k == 0 ? 0 : k == 1 ? 128 : 192) + n2[k] + __popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)cand;
+              n2[k] += __popcll(m);
             }
           }
         }
-        // ---- (1b) dequantisation + chroma-from-luma straight into the window (dequant_block, group.rs:137-177): a thread
-        // takes 4 consecutive stored coefficients of all three channels; chunk = 16 threads per 8x8 block of area
+        PROF_MARK(1);
+        // ---- (1c) LLF-from-LF (one lane per varblock) over the lowest frequencies; the dequantisation below skips
+        // that corner, which the LLF overwrites in the reference (transform.rs:450)
+        if (lane < 16) {
+          const int bx = qbx + (lane & 3), by = qby + (lane >> 2);
+          const Blk b = decode_desc(s_desc[by * 8 + bx], bx, by);
+          if (b.on && b.dx == 0 && b.dy == 0) {
+            const float* lf = s_lf + ch * 64 + by * 8 + bx;
+            float* org = s_buf + ch * kPlane + (kCarry + 8 * by) * kBW + kB + 8 * bx;
+            switch (b.type) {
+              case 0: org[0] = lf[0]; break;
+              case 4: llf_to_window<2, 2>(lf, 8, org); break;
+              case 5: llf_to_window<4, 4>(lf, 8, org); break;
+              case 6: llf_to_window<2, 1>(lf, 8, org); break;
+              case 7: llf_to_window<1, 2>(lf, 8, org); break;
+              case 8: llf_to_window<4, 1>(lf, 8, org); break;
+              case 9: llf_to_window<1, 4>(lf, 8, org); break;
+              case 10: llf_to_window<4, 2>(lf, 8, org); break;
+              default: llf_to_window<2, 4>(lf, 8, org); break;  // 11
+            }
+          }
+        }
+        // ---- (1b) dequantisation + chroma-from-luma straight into the window (dequant_block, group.rs:137-177): a lane
+        // takes 4 consecutive stored coefficients; the X / B wavefronts dequantise the Y values they need themselves
         {
           const int g = (t / 4) * f.xgroups + gx;
           const int cti = t * f.cmap_stride + strip;  // the tile IS a colour tile (64 x 64)
-          const float x_cc = f.base_x + (float)f.ytox[cti] / f.color_factor;  // color_correlation_map.rs:76-78
-          const float b_cc = f.base_b + (float)f.ytob[cti] / f.color_factor;
-          constexpr int kIters = (1024 + kNT - 1) / kNT;
-          int4 q[kIters][3];
-          float4 tw[kIters][3];
-          int woff[kIters], wstep[kIters];
-          float sdy[kIters];
-          bool on[kIters];
+          BlockInfo bi;
+          bi.x_cc = f.base_x + (float)f.ytox[cti] / f.color_factor;  // color_correlation_map.rs:76-78
+          bi.b_cc = f.base_b + (float)f.ytob[cti] / f.color_factor;
 #pragma unroll
-          for (int it = 0; it < kIters; it++) {
-            const int idx = it * kNT + tid;
-            const int bi = (idx >> 4) & 63, qd = idx & 15;
-            const int bx = bi & 7, by = bi >> 3;
-            const Blk b = decode_desc(s_desc[bi], bx, by);
-            on[it] = idx < 1024 && b.on;
-            const int cx = 1 << b.lcx;
-            const int k = 64 * (b.dy * cx + b.dx) + 4 * qd;  // index inside the varblock's stored coefficients
-            const int lr = 3 + b.lcy, lc = 3 + b.lcx;        // log2 of R, C
-            const bool wide = lr < lc;
-            // stored in[u * R + v] for R >= C, in[v * C + u] for the wide shapes (tests.rs:119-132)
-            const int u = wide ? (k & ((1 << lc) - 1)) : (k >> lr), v = wide ? (k >> lc) : (k & ((1 << lr) - 1));
-            woff[it] = (kCarry + 8 * (by - b.dy) + v) * kBW + kB + 8 * (bx - b.dx) + u;
-            wstep[it] = wide ? 1 : kBW;
-            sdy[it] = s_sdy[bi];
-            const int qt = on[it] ? quant_table_for_type(b.type) : 0;
-            const int tsize = quant_table_size(qt);
-            const float* tb = f.tables + f.table_offset[qt] + k;
-            const int* cf = f.coeffs + ((size_t)g * 3 * kGroupArea + b.off64 * 64 + k);
+          for (int half = 0; half < 2; half++) {
+            int4 qo[2], qy[2];
+            float4 to[2], ty[2];
+            int woff[2], skip[2];
+            float sdy[2];
 #pragma unroll
-            for (int c = 0; c < 3; c++) {
-              q[it][c] = make_int4(0, 0, 0, 0);
-              tw[it][c] = make_float4(0.f, 0.f, 0.f, 0.f);
-              if (on[it]) {
-                q[it][c] = gload_i4<true>(cf + c * kGroupArea);
-                tw[it][c] = *reinterpret_cast<const float4*>(tb + c * tsize);
+            for (int it = 0; it < 2; it++) {
+              const int idx = (half * 2 + it) * 64 + lane;  // 16 blocks x 16 chunks
+              const int bq = idx >> 4, qd = idx & 15;
+              const int bx = qbx + (bq & 3), by = qby + (bq >> 2);
+              const Blk b = decode_desc(s_desc[by * 8 + bx], bx, by);
+              const int k = ((b.dy << b.lcx) + b.dx) * 64 + 4 * qd;  // index inside the varblock's stored coefficients
+              const int lr = 3 + b.lcy, lc = 3 + b.lcx;              // log2 of R, C
+              const bool wide = lr < lc;
+              // stored in[u * R + v] for R >= C, in[v * C + u] for the wide shapes (tests.rs:119-132)
+              const int u = wide ? (k & ((1 << lc) - 1)) : (k >> lr), v = wide ? (k >> lc) : (k & ((1 << lr) - 1));
+              // woff < 0: nothing to do; bit 30: the four values go down a column (stride kBW) instead of along a row
+              woff[it] = !b.on ? -1 : (((kCarry + 8 * (by - b.dy) + v) * kBW + kB + 8 * (bx - b.dx) + u) | (wide ? 0 : 1 << 30));
+              // leading elements inside the LLF corner (u < cx, v < cy): written by the LLF lanes instead
+              skip[it] = wide ? ((u == 0 && v < (1 << b.lcy)) ? (1 << b.lcx) : 0) : ((v == 0 && u < (1 << b.lcx)) ? (1 << b.lcy) : 0);
+              sdy[it] = s_sdy[by * 8 + bx];
+              const int qt = b.on ? quant_table_for_type(b.type) : 0;
+              const int tsize = quant_table_size(qt);
+              const float* tb = f.tables + f.table_offset[qt] + k;
+              const int* cf = f.coeffs + ((size_t)g * 3 * kGroupArea + b.off64 * 64 + k);
+              qo[it] = qy[it] = make_int4(0, 0, 0, 0);
+              to[it] = ty[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+              if (b.on) {
+                qy[it] = gload_i4<true>(cf + kGroupArea);
+                ty[it] = *reinterpret_cast<const float4*>(tb + tsize);
+                if (ch != 1) {
+                  qo[it] = gload_i4<true>(cf + ch * kGroupArea);
+                  to[it] = *reinterpret_cast<const float4*>(tb + ch * tsize);
+                }
               }
             }
-          }
 #pragma unroll
-          for (int it = 0; it < kIters; it++) {
-            if (!on[it]) continue;
-            BlockInfo bi;
-            bi.sdy = sdy[it];
-            bi.x_cc = x_cc;
-            bi.b_cc = b_cc;
-            float dy[4];
-            const float4 vy = dequant4<1>(f, q[it][1], tw[it][1], bi, dy);  // channel order of the reference: Y, X, B
-            const float4 vx = dequant4<0>(f, q[it][0], tw[it][0], bi, dy);
-            const float4 vb = dequant4<2>(f, q[it][2], tw[it][2], bi, dy);
-            float* d = s_buf + woff[it];
-            const int st = wstep[it];
-            const float4 vv[3] = {vx, vy, vb};
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-              float* dc = d + c * kPlane;
-              if (st == 1) {
-                lds_store4(dc, vv[c]);
+            for (int it = 0; it < 2; it++) {
+              if (woff[it] < 0) continue;
+              bi.sdy = sdy[it];
+              float dy[4];
+              float4 vv = dequant4<1>(f, qy[it], ty[it], bi, dy);
+              if (ch == 0) vv = dequant4<0>(f, qo[it], to[it], bi, dy);
+              else if (ch == 2) vv = dequant4<2>(f, qo[it], to[it], bi, dy);
+              float* dc = s_buf + ch * kPlane + (woff[it] & 0xffffff);
+              const bool col = (woff[it] >> 30) != 0;
+              const int sk = skip[it];
+              if (!col && sk == 0) {
+                lds_store4(dc, vv);
               } else {
-                dc[0] = vv[c].x;
-                dc[kBW] = vv[c].y;
-                dc[2 * kBW] = vv[c].z;
-                dc[3 * kBW] = vv[c].w;
+                const int st = col ? kBW : 1;
+                if (sk < 1) dc[0] = vv.x;
+                if (sk < 2) dc[st] = vv.y;
+                if (sk < 3) dc[2 * st] = vv.z;
+                if (sk < 4) dc[3 * st] = vv.w;
               }
             }
           }
         }
-        __syncthreads();
-        // ---- (1c) LLF-from-LF over the lowest frequencies: one lane per varblock and channel
-        if (tid < 192) {
-          const int c = tid >> 6, bi = tid & 63, bx = bi & 7, by = bi >> 3;
-          const Blk b = decode_desc(s_desc[bi], bx, by);
-          if (b.on && b.dx == 0 && b.dy == 0) {
-            const float* lf = f.lf[c] + (size_t)(t * 8 + by) * f.xblocks + strip * 8 + bx;
-            float* org = s_buf + c * kPlane + (kCarry + 8 * by) * kBW + kB + 8 * bx;
-            switch (b.type) {
-              case 0: org[0] = lf[0]; break;
-              case 4: llf_to_window<2, 2>(lf, f.xblocks, org); break;
-              case 5: llf_to_window<4, 4>(lf, f.xblocks, org); break;
-              case 6: llf_to_window<2, 1>(lf, f.xblocks, org); break;
-              case 7: llf_to_window<1, 2>(lf, f.xblocks, org); break;
-              case 8: llf_to_window<4, 1>(lf, f.xblocks, org); break;
-              case 9: llf_to_window<1, 4>(lf, f.xblocks, org); break;
-              case 10: llf_to_window<4, 2>(lf, f.xblocks, org); break;
-              default: llf_to_window<2, 4>(lf, f.xblocks, org); break;  // 11
-            }
-          }
-        }
-        __syncthreads();
-        // ---- (1d) pass 1 (along u: window rows), (1e) pass 2 (along v: window columns); idct2d.rs:111-131 order.
-        // Batches of 64 tasks of one length, the long ones first; task = (channel, list entry).
+        wave_sync();
+        PROF_MARK(2);
+        // ---- (1d) pass 1 (along u: window rows), (1e) pass 2 (along v: window columns); idct2d.rs:111-131 order
+        float* qorg = s_buf + ch * kPlane + (kCarry + 8 * qby) * kBW + kB + 8 * qbx;
 #pragma unroll
         for (int pass = 0; pass < 2; pass++) {
-          const int n8 = s_ntask[pass][0] * 3, n16 = s_ntask[pass][1] * 3, n32 = s_ntask[pass][2] * 3;
-          const int b32 = (n32 + 63) >> 6, b16 = (n16 + 63) >> 6, b8 = (n8 + 63) >> 6;
-          for (int bt = wave; bt < b32 + b16 + b8; bt += kNW) {
-            const int cls = bt < b32 ? 2 : bt < b32 + b16 ? 1 : 0;  // wave-uniform
-            const int i = (bt - (cls == 2 ? 0 : cls == 1 ? b32 : b32 + b16)) * 64 + lane;
-            const int n = cls == 2 ? n32 : cls == 1 ? n16 : n8, per = n / 3;
-            if (i < n) {
-              const int c = i / per, e = s_task[pass][(cls == 0 ? 0 : cls == 1 ? 512 : 768) + i % per];
-              float* p = s_buf + c * kPlane + kCarry * kBW + kB +
-                         (pass == 0 ? (e >> 3) * kBW + (e & 7) * 8 : (e & 7) * 8 * kBW + (e >> 3));
-              if (pass == 0) {
-                if (cls == 2) idct_line<32, 1>(p);
-                else if (cls == 1) idct_line<16, 1>(p);
-                else idct_line<8, 1>(p);
-              } else {
-                if (cls == 2) idct_line<32, kBW>(p);
-                else if (cls == 1) idct_line<16, kBW>(p);
-                else idct_line<8, kBW>(p);
+#pragma unroll
+          for (int k = 2; k >= 0; k--) {  // the long transforms first
+            const int n = pass ? n2[k] : n1[k];
+            for (int i0 = 0; i0 < n; i0 += 64) {
+              if (i0 + lane < n) {
+                const int e = wl[pass * 224 + (k == 0 ? 0 : k == 1 ? 128 : 192) + i0 + lane];
+                if (pass == 0) {
+                  float* p = qorg + (e >> 2) * kBW + (e & 3) * 8;
+                  if (k == 2) idct_line<32, 1>(p);
+                  else if (k == 1) idct_line<16, 1>(p);
+                  else idct_line<8, 1>(p);
+                } else {
+                  float* p = qorg + (e >> 5) * 8 * kBW + (e & 31);
+                  if (k == 2) idct_line<32, kBW>(p);
+                  else if (k == 1) idct_line<16, kBW>(p);
+                  else idct_line<8, kBW>(p);
+                }
               }
             }
           }
-          __syncthreads();
+          wave_sync();
+          PROF_MARK(3 + pass);
         }
-      } else {
+      } else if (mode != 0) {
         // ---- (1') a tile K1's class kernels reconstructed: 8x8-tiled planes -> window (a lane fetches 4 rows of a column)
         for (int idx = tid; idx < 1024; idx += kNT) {
           const int col = idx & 63, yg = idx >> 6;
@@ -435,33 +483,33 @@ __global__ __launch_bounds__(kNT, JXLH_STRIP_WPE) void k123_strip(const FrameDev
             d[3 * kBW] = v.w;
           }
         }
-        __syncthreads();
+        __syncthreads();  // a wavefront publishes rows other wavefronts loaded
       }
-      // ---- (2) publish the tile's left / right 4 columns: written through at agent scope (the neighbour runs on another
-      // XCD, whose L2 is not coherent with this one's), acknowledged (vmcnt) before the flag goes up
-      if (sa.strips > 1) {
-        if (tid < 384) {
-          const int c = tid >> 7, side = (tid >> 6) & 1, row = tid & 63;
-          const float4 v = lds_load4(s_buf + c * kPlane + (kCarry + row) * kBW + (side ? kTW : kB));
+      // ---- (2) publish the 4 edge columns of this wavefront's 32 rows: written through at agent scope (the neighbour
+      // runs on another XCD, whose L2 is not coherent with this one's), acknowledged (vmcnt) before the count goes up;
+      // the last of the twelve raises the strip's progress flag.  (3) then the neighbour's columns beside them.
+      if (sa.strips > 1 && wave < 12) {
+        const int side = q & 1, row = (q >> 1) * 32 + (lane & 31);
+        if (lane < 32) {
+          const float4 v = lds_load4(s_buf + ch * kPlane + (kCarry + row) * kBW + (side ? kTW : kB));
           unsigned long long* dst = reinterpret_cast<unsigned long long*>(
-              sa.xchg + ((((size_t)c * 2 + side) * sa.strips + strip) * sa.xchg_rows + (size_t)t * kTH + row) * 4);
+              sa.xchg + ((((size_t)ch * 2 + side) * sa.strips + strip) * sa.xchg_rows + (size_t)t * kTH + row) * 4);
           const unsigned long long lo = (unsigned long long)__float_as_uint(v.x) | (unsigned long long)__float_as_uint(v.y) << 32;
           const unsigned long long hi = (unsigned long long)__float_as_uint(v.z) | (unsigned long long)__float_as_uint(v.w) << 32;
           __hip_atomic_store(dst, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           __hip_atomic_store(dst + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this thread's stores are acknowledged
-        __syncthreads();
-        if (tid == 0) __hip_atomic_store(my_flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // ---- (3) the neighbours' columns of the same step
-        if (lane == 0 && wave < 2) {
-          const int nb = strip + (wave ? 1 : -1);
-          if (nb >= 0 && nb < sa.strips) {
+        __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wavefront's stores are acknowledged
+        if (lane == 0 && atomicAdd(&s_pub, 1) == 11) __hip_atomic_store(my_flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        PROF_MARK(5);
+        const int nb = strip + (side ? 1 : -1);
+        if (nb >= 0 && nb < sa.strips) {
+          if (lane == 0) {
             const int* fl = sa.flags + band * sa.strips + nb;
             const unsigned long long t0 = now_ticks();
             int spins = 0;
             while (__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < seq) {
-              __builtin_amdgcn_s_sleep(4);
+              __builtin_amdgcn_s_sleep(2);
               if ((++spins & 255) == 0 && now_ticks() - t0 > sa.deadline_ticks) {
                 atomicExch(sa.error_flag, JXLH_ERR_DEVICE);
                 s_abort = 1;
@@ -469,29 +517,28 @@ __global__ __launch_bounds__(kNT, JXLH_STRIP_WPE) void k123_strip(const FrameDev
               }
             }
           }
-        }
-        __syncthreads();
-        if (s_abort) {
-          // let the rest of the band fall through as well: every later step reads as published
-          if (tid == 0) __hip_atomic_store(my_flag, 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          return;
-        }
-        if (tid < 384) {
-          const int c = tid >> 7, side = (tid >> 6) & 1, row = tid & 63;  // side 0 = my left halo = the left strip's right columns
-          const int nb = strip + (side ? 1 : -1);
-          if (nb >= 0 && nb < sa.strips) {
+          PROF_MARK(6);
+          // (lane 0's loop ends before the wavefront goes on: the other lanes wait at the reconvergence point)
+          if (lane < 32) {
             const unsigned long long* src = reinterpret_cast<const unsigned long long*>(
-                sa.xchg + ((((size_t)c * 2 + (1 - side)) * sa.strips + nb) * sa.xchg_rows + (size_t)t * kTH + row) * 4);
+                sa.xchg + ((((size_t)ch * 2 + (1 - side)) * sa.strips + nb) * sa.xchg_rows + (size_t)t * kTH + row) * 4);
             const unsigned long long lo = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned long long hi = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            lds_store4(s_buf + c * kPlane + (kCarry + row) * kBW + (side ? kB + kTW : 0),
+            lds_store4(s_buf + ch * kPlane + (kCarry + row) * kBW + (side ? kB + kTW : 0),
                        make_float4(__uint_as_float((uint32_t)lo), __uint_as_float((uint32_t)(lo >> 32)),
                                    __uint_as_float((uint32_t)hi), __uint_as_float((uint32_t)(hi >> 32))));
           }
         }
+        PROF_MARK(7);
       }
     }
     __syncthreads();
+    PROF_MARK(8);
+    if (s_abort) {
+      // a neighbour never showed up (deadline): let the rest of the band fall through as well
+      if (tid == 0) __hip_atomic_store(my_flag, 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
     // ---- (4) the next step's carry: the last 8 rows of the window as they are now (the stages work in place)
     if (t < t_end) {
       for (int i = tid; i < 3 * kCarry * kStrips; i += kNT) {
@@ -514,6 +561,7 @@ __global__ __launch_bounds__(kNT, JXLH_STRIP_WPE) void k123_strip(const FrameDev
         mirror_fill(s_buf, kBorder, tx0, ty0, a.w, a.h, tid);
       }
       __syncthreads();
+      PROF_MARK(9);
 
       auto run_stage = [&](auto stage_tag, auto margin_tag) {
         constexpr int STAGE = decltype(stage_tag)::value;  // 0 gaborish, 1 epf1, 2 epf2
@@ -729,11 +777,14 @@ __global__ __launch_bounds__(kNT, JXLH_STRIP_WPE) void k123_strip(const FrameDev
       constexpr int kMg = kBorder - (GAB ? 1 : 0);
       constexpr int kMe1 = kMg - (E1 ? 2 : 0);
       if constexpr (GAB) run_stage(std::integral_constant<int, 0>{}, std::integral_constant<int, kMg>{});
+      PROF_MARK(10);
       if constexpr (E1) run_stage(std::integral_constant<int, 1>{}, std::integral_constant<int, kMe1>{});
+      PROF_MARK(11);
       if constexpr (E2) run_stage(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{});
     }
     // ---- (6) the carry moves up
     __syncthreads();
+    PROF_MARK(12);
     if (tid == 0) {
       s_cnt = 0;
       s_nsw = 0;
@@ -744,7 +795,12 @@ __global__ __launch_bounds__(kNT, JXLH_STRIP_WPE) void k123_strip(const FrameDev
         lds_store4(s_buf + c * kPlane + r * kBW + s4, lds_load4(s_save + (c * kCarry + r) * kBW + s4));
       }
     }
+    PROF_MARK(13);
   }
+#ifdef JXLH_STRIP_PROF
+  if (tid_kernel == 0)
+    for (int i = 0; i < 16; i++) atomicAdd(&g_strip_prof[i], s_prof[i]);
+#endif
 }
 
 template <bool GAB, bool E1, bool E2>
@@ -805,3 +861,14 @@ bool launch_strip(hipStream_t s, const FrameDev& f, const uint2* desc, const uin
 }
 
 }  // namespace jxlh
+
+#ifdef JXLH_STRIP_PROF
+extern "C" int jxlh_strip_prof_read(unsigned long long* out, int reset) {
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_strip_prof), sizeof(g_strip_prof)) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_strip_prof), z, sizeof z) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif

@@ -51,7 +51,8 @@ namespace {
 constexpr int kScanGroups = 4;
 constexpr int kScanThreads = kScanGroups * kThreads;
 // STRIP (the frame runs through k123_strip, k_strip.hip): the scan also decides per 64x64 tile who reconstructs it -- the
-// strip kernel, iff every varblock touching the tile lies inside it and is a DCT with sides <= 32 -- writes a descriptor
+// strip kernel, iff every varblock touching the tile lies inside one 32x32 quadrant of it and is a DCT with sides <= 32
+// (what aligning every varblock to its own size gives) -- writes a descriptor
 // per block of those tiles ({type | dx << 5 | dy << 7 | off64 << 9 | 1 << 31, raw_quant of the varblock}: everything the
 // strip kernel needs to find a block's varblock and its coefficients) and appends work items for the OTHER tiles only.
 template <bool STRIP>
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(kScanThreads) void k1_scan(const FrameDev f, const 
         if constexpr (STRIP) {
           // tiles this varblock keeps away from the strip kernel: all it touches if it is not a small DCT or leaves
           // its tile; every tile of the group if the map is broken
-          const bool closed = (bx & 7) + cx <= 8 && (by & 7) + cy <= 8 && class_of_type_reg(type) < kClsSpecial;
+          const bool closed = (bx & 3) + cx <= 4 && (by & 3) + cy <= 4 && class_of_type_reg(type) < kClsSpecial;
           if (sz == 0 || f.subsampled) {
             for (int k = 0; k < 16; k++) atomicOr(&s_tmode[sub][k], 1);
           } else if (!closed) {
