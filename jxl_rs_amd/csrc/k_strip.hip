@@ -53,6 +53,11 @@
 #ifndef JXLH_STRIP_WPE
 #define JXLH_STRIP_WPE 6
 #endif
+// development only: -DJXLH_STRIP_ABLATE=<bits> removes phases (wrong pixels) to attribute time: 1 Gaborish, 2 EPF1, 4 EPF2,
+// 8 dequantisation, 16 IDCT passes, 32 exchange, 64 task lists + LLF, 128 save / restore of the carry
+#ifndef JXLH_STRIP_ABLATE
+#define JXLH_STRIP_ABLATE 0
+#endif
 #ifndef JXLH_FAST_RECIP
 #define JXLH_FAST_RECIP 1
 #endif
@@ -69,7 +74,8 @@
 #ifdef JXLH_STRIP_PROF
 // development variant (tools/build_variant.sh ... -DJXLH_STRIP_PROF): thread 0 of every workgroup accumulates the
 // s_memrealtime ticks (10 ns) it spends between the phase marks; read with jxlh_strip_prof_read
-__device__ unsigned long long g_strip_prof[16];
+__device__ unsigned long long g_strip_end[2048];  // per ticket: end tick, then XCC id / CU id
+__device__ unsigned long long g_strip_prof[20];  // [16] min start, [17] max start, [18] min end, [19] max end
 #define PROF_MARK(i)                                          \
   do {                                                        \
     if (tid_kernel == 0) {                                    \
@@ -121,7 +127,11 @@ struct StripArgs {
   int strips, tile_rows, bands;
   int xchg_rows;
   unsigned long long deadline_ticks;  // s_memrealtime ticks (100 MHz) a wait may last
+  int skew_ticks;                     // the second half of the bands starts this much later (see launch_strip)
 };
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
 
 template <class T>
 __device__ __forceinline__ T& at_bytes(float* base, uint32_t byte_off) {
@@ -146,16 +156,29 @@ __device__ __forceinline__ float dpp_from_right(float v) {
 
 // Overwrites out-of-frame positions of a region [kB - m, kB + T + m) of the window with the values at their mirrored
 // in-frame coordinates (jxl/src/render/simple_pipeline/run_stage.rs:129-146: every stage sees ITS input mirrored).
+// Visits only the out-of-frame columns (all region rows) and the out-of-frame rows (all region columns): a strip on
+// the left / right frame edge fills 4 columns per stage, not the window.
 __device__ __forceinline__ void mirror_fill(float* __restrict__ buf, int m, int tx0, int ty0, int w, int h, int tid) {
-  const int rw = kTW + 2 * m, rh = kTH + 2 * m;
-  for (int idx = tid; idx < rw * rh; idx += kNT) {
-    const int bx = kB - m + idx % rw, by = kB - m + idx / rw;
-    const int fx = tx0 - kB + bx, fy = ty0 - kB + by;
-    if (fx >= 0 && fx < w && fy >= 0 && fy < h) continue;
-    const int sx = mirror(fx, w) - (tx0 - kB), sy = mirror(fy, h) - (ty0 - kB);
-    if (sx < 0 || sx >= kBW || sy < 0 || sy >= kBH) continue;  // outside this window: never consumed
+  const int r0 = kB - m, rw = kTW + 2 * m, rh = kTH + 2 * m;  // region origin (both axes) and size
+  const int wx0 = tx0 - kB, wy0 = ty0 - kB;                   // frame coordinates of window (0, 0)
+  auto fill = [&](int bx, int by) {
+    const int fx = wx0 + bx, fy = wy0 + by;
+    if (fx >= 0 && fx < w && fy >= 0 && fy < h) return;
+    const int sx = mirror(fx, w) - wx0, sy = mirror(fy, h) - wy0;
+    if (sx < 0 || sx >= kBW || sy < 0 || sy >= kBH) return;  // outside this window: never consumed
 #pragma unroll
     for (int c = 0; c < 3; c++) buf[c * kPlane + by * kBW + bx] = buf[c * kPlane + sy * kBW + sx];
+  };
+  // out-of-frame columns: [r0, r0 + nl) on the left, [r0 + rw - nr, r0 + rw) on the right
+  const int nl = min(rw, max(0, -(wx0 + r0))), nr = min(rw - nl, max(0, wx0 + r0 + rw - w));
+  for (int idx = tid; idx < (nl + nr) * rh; idx += kNT) {
+    const int j = idx % (nl + nr), by = r0 + idx / (nl + nr);
+    fill(j < nl ? r0 + j : r0 + rw - nr + (j - nl), by);
+  }
+  const int nt = min(rh, max(0, -(wy0 + r0))), nbm = min(rh - nt, max(0, wy0 + r0 + rh - h));
+  for (int idx = tid; idx < (nt + nbm) * rw; idx += kNT) {
+    const int j = idx / rw, bx = r0 + idx % rw;
+    fill(bx, j < nt ? r0 + j : r0 + rh - nbm + (j - nt));
   }
 }
 
@@ -181,6 +204,48 @@ __device__ __forceinline__ Blk decode_desc(uint32_t d, int bx, int by) {
   b.on = known && b.dx < cx && b.dy < cy && b.dx <= (bx & 3) && b.dy <= (by & 3) && (bx & 3) - b.dx + cx <= 4 &&
          (by & 3) - b.dy + cy <= 4 && b.off64 + cx * cy <= 1024;
   return b;
+}
+
+// dequant_lane (group.rs:100-133) for four coefficients of channel CH with adjust_quant_bias (group.rs:85-96) read from a
+// table: for |q| < kAdjN, tab[|q|] holds what the reference computes for +|q| -- 0 * bias_c, 1 * bias_c, and for
+// |q| >= 2 the device's own (float)|q| - bias3 / (float)|q| -- and the value for -|q| is its negation EXACTLY (IEEE
+// multiplication, division and subtraction are sign-symmetric; the one exception, a table entry that is a zero, is
+// detected when the table is built and disables this path).  The division and the three-way select are what made the
+// dequantisation 37 vector instructions per coefficient, on the resource that bounds this kernel; now ~9.
+constexpr int kAdjN = 128;
+template <int CH>
+__device__ __forceinline__ float4 dequant4_fast(const FrameDev& f, const int4 q, const float4 t, float sd, float cc,
+                                                const float* __restrict__ tab, bool nofast, float (&dy)[4]) {
+  const int qq[4] = {q.x, q.y, q.z, q.w};
+  const float tt[4] = {t.x, t.y, t.z, t.w};
+  int aq[4];
+  float am[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    aq[i] = qq[i] < 0 ? -qq[i] : qq[i];
+    am[i] = tab[min(aq[i], kAdjN - 1)];
+  }
+  // magnitudes the table does not hold (kAdjN is a power of two: the OR of the four is below it iff each is): rare,
+  // wave-uniform branch around the reference's own expression
+  if (__builtin_expect(nofast || __any(((uint32_t)aq[0] | (uint32_t)aq[1] | (uint32_t)aq[2] | (uint32_t)aq[3]) >= (uint32_t)kAdjN), 0)) {
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      if (nofast || aq[i] >= kAdjN) am[i] = __uint_as_float(__float_as_uint(adjust_quant_bias(qq[i], f.quant_biases[CH], f.quant_biases[3])) ^ ((uint32_t)qq[i] & 0x80000000u));
+  }
+  float r[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const float adj = __uint_as_float(__float_as_uint(am[i]) ^ ((uint32_t)qq[i] & 0x80000000u));
+    const float mul = tt[i] * sd;
+    const float v = adj * mul;
+    if constexpr (CH == 1) {
+      dy[i] = v;
+      r[i] = v;
+    } else {
+      r[i] = __builtin_fmaf(cc, dy[i], v);
+    }
+  }
+  return make_float4(r[0], r[1], r[2], r[3]);
 }
 
 // one task of an IDCT pass: N floats at stride STEP (1 = a window row, 16-byte accesses; kBW = a window column)
@@ -234,16 +299,24 @@ __global__ __launch_bounds__(kNT, JXLH_STRIP_WPE) void k123_strip(const FrameDev
   __shared__ __attribute__((aligned(16))) float s_save[3 * kCarry * kBW];
   __shared__ float s_sigma[kSigH * kSigW];
   __shared__ uint16_t s_list[kBH * kStrips];
-  __shared__ uint8_t s_wtask[12][448];  // per wavefront: pass 1 / pass 2 tasks of its quadrant by length class
-  __shared__ uint32_t s_desc[64];
+  __shared__ uint8_t s_wtask[4][448];  // per quadrant: pass 1 / pass 2 tasks by length class
+  __shared__ int s_wn[4][6];           // ... and their counts
+  __shared__ uint32_t s_bk[64];        // per block of the tile, see (0)
+  __shared__ int s_bt[64], s_bc[64];
   __shared__ float s_sdy[64];
-  __shared__ float s_lf[192];  // the tile's LF samples: [channel][block row][block column]
+  __shared__ float s_adj[3][kAdjN];    // adjust_quant_bias of +i per channel, see dequant4_fast
+  __shared__ int s_nofast;
+  __shared__ int s_toff[JXLH_NUM_QUANT_TABLES];  // FrameDev::table_offset (a dynamically indexed kernel argument would live in scratch)
+  __shared__ float s_lf[2][192];  // the tile's LF samples [channel][block row][block column]; this step's / the next's
+  __shared__ uint32_t s_ndesc[64], s_nrq[64];  // the next tile's block descriptors as fetched
   __shared__ int s_cnt, s_nsw, s_ticket, s_abort, s_pub;
 #ifdef JXLH_STRIP_PROF
   __shared__ unsigned long long s_prof[16], s_prof_t;
   if (threadIdx.x == 0) {
     for (int i = 0; i < 16; i++) s_prof[i] = 0;
     s_prof_t = now_ticks();
+    atomicMin(&g_strip_prof[16], s_prof_t);
+    atomicMax(&g_strip_prof[17], s_prof_t);
   }
 #endif
   const FusedArgs& a = sa.fa;
@@ -251,7 +324,21 @@ __global__ __launch_bounds__(kNT, JXLH_STRIP_WPE) void k123_strip(const FrameDev
   constexpr int kBorder = (GAB ? 1 : 0) + (E1 ? 2 : 0) + (E2 ? 1 : 0);
   static_assert(kBorder >= 1 && kBorder <= kB, "at least one stage");
 
+  if (tid_kernel == 0) s_nofast = 0;
+  __syncthreads();
+  if (tid_kernel < kAdjN) {
+    const float quant = (float)tid_kernel;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      // adjust_quant_bias(+i): the expressions of group.rs:85-96 evaluated here, once per workgroup
+      const float v = tid_kernel < 2 ? quant * f.quant_biases[c] : quant - f.quant_biases[3] / quant;
+      s_adj[c][tid_kernel] = v;
+      if (tid_kernel >= 2 && v == 0.0f) s_nofast = 1;  // -(+0) is not what the reference gets for the negative coefficient
+    }
+  }
   if (tid_kernel == 0) {
+#pragma unroll
+    for (int i = 0; i < JXLH_NUM_QUANT_TABLES; i++) s_toff[i] = f.table_offset[i];
     s_ticket = atomicAdd(&sa.flags[sa.bands * sa.strips], 1);
     s_cnt = 0;
     s_nsw = 0;
@@ -261,6 +348,13 @@ __global__ __launch_bounds__(kNT, JXLH_STRIP_WPE) void k123_strip(const FrameDev
   const int ticket = __builtin_amdgcn_readfirstlane(s_ticket);  // uniform: everything derived from it lives in SGPRs
   const int band = ticket / sa.strips, strip = ticket % sa.strips;
   if (band >= sa.bands) return;
+  if (sa.skew_ticks > 0 && band >= (sa.bands + 1) / 2) {
+    // The two workgroups of a CU were dispatched half a grid apart, i.e. belong to bands b and b + bands / 2: started
+    // together they would sit in the same phase (both fetching coefficients, then both filtering) for the whole
+    // kernel; shifted by half a step one transforms while the other filters.
+    const unsigned long long t0 = now_ticks();
+    while (now_ticks() - t0 < (unsigned long long)sa.skew_ticks) __builtin_amdgcn_s_sleep(8);
+  }
   const int tr0 = (int)((long)band * sa.tile_rows / sa.bands), tr1 = (int)((long)(band + 1) * sa.tile_rows / sa.bands);
   const int t_begin = tr0 > 0 ? tr0 - 1 : 0;
   const int y_lo = tr0 * kTH, y_hi = min(tr1 * kTH, a.h);
@@ -271,19 +365,23 @@ __global__ __launch_bounds__(kNT, JXLH_STRIP_WPE) void k123_strip(const FrameDev
   const int gx = strip / 4;  // group column (256 = 4 tiles)
 
   // What a step's transform phase needs from global memory before it can address anything -- the tile's mode, its 64
-  // block descriptors, its 3 x 64 LF samples -- is fetched one step ahead into registers (threads 0..191).
-  uint2 nx_desc = make_uint2(0u, 1u);
-  float nx_lf = 0.0f;
+  // block descriptors, its 3 x 64 LF samples -- is fetched one step ahead, straight into LDS (`global_load_lds`: no
+  // register holds the value in flight, so nothing waits for it until the next step reads it).  Blocks outside the frame
+  // fetch a clamped address and are masked when decoded.
   int nx_mode = 1;
   auto prefetch_meta = [&](int tt, int tid) {
     if (tt >= sa.tile_rows || tt > t_end) return;
     nx_mode = sa.tile_mode[tt * sa.strips + strip];
     if (tid < 192) {
-      const int bi = tid & 63, gbx = strip * 8 + (bi & 7), gby = tt * 8 + (bi >> 3);
-      const bool in = gbx < f.xblocks && gby < f.yblocks;
+      const int c = __builtin_amdgcn_readfirstlane(tid >> 6);
+      const int bi = tid & 63, gbx = min(strip * 8 + (bi & 7), f.xblocks - 1), gby = min(tt * 8 + (bi >> 3), f.yblocks - 1);
       const size_t at = (size_t)gby * f.xblocks + gbx;
-      if (tid < 64) nx_desc = in ? sa.desc[at] : make_uint2(0u, 1u);
-      nx_lf = in ? f.lf[tid >> 6][at] : 0.0f;
+      if (c == 0) {
+        __builtin_amdgcn_global_load_lds((gptr_t)&sa.desc[at].x, (lptr_t)s_ndesc, 4, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)&sa.desc[at].y, (lptr_t)s_nrq, 4, 0, 0);
+      }
+      const float* lfp = c == 0 ? f.lf[0] : c == 1 ? f.lf[1] : f.lf[2];
+      __builtin_amdgcn_global_load_lds((gptr_t)(lfp + at), (lptr_t)(s_lf[(tt - t_begin) & 1] + c * 64), 4, 0, 0);
     }
   };
   prefetch_meta(t_begin, tid_kernel);
@@ -300,63 +398,80 @@ __global__ __launch_bounds__(kNT, JXLH_STRIP_WPE) void k123_strip(const FrameDev
     const int seq = t - t_begin + 1;
     if (has_tile) {
       const int mode = nx_mode;
+      // ---- (0) what the tile's 64 blocks need decoded once: where the varblock of a block starts in the window, which
+      // 64-coefficient piece of it the block stands for, its shape, its coefficients and its dequantisation weights
+      if (tid < 192) __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wavefront's prefetches have landed
       if (tid < 64) {
-        s_desc[tid] = nx_desc.x;
-        s_sdy[tid] = f.inv_global_scale / (float)(uint32_t)nx_desc.y;  // group.rs:153
+        const int bx = tid & 7, by = tid >> 3;
+        const bool in = strip * 8 + bx < f.xblocks && t * 8 + by < f.yblocks;
+        const Blk b = decode_desc(in ? s_ndesc[tid] : 0u, bx, by);
+        const int org = (kCarry + 8 * (by - b.dy)) * kBW + kB + 8 * (bx - b.dx);
+        s_bk[tid] = !b.on ? 0u
+                          : (uint32_t)org | (uint32_t)((b.dy << b.lcx) + b.dx) << 13 | (uint32_t)b.lcy << 17 |
+                                (uint32_t)b.lcx << 19 | (uint32_t)b.type << 21 | (b.dx == 0 ? 1u << 26 : 0u) |
+                                (b.dy == 0 ? 1u << 27 : 0u) | 1u << 31;
+        // quant_table_for_type for the nine small DCTs: 0, 4, 5 -> themselves; 6, 7 -> 6; 8, 9 -> 7; 10, 11 -> 8
+        s_bt[tid] = b.on ? s_toff[b.type < 6 ? b.type : 6 + ((b.type - 6) >> 1)] : 0;
+        s_bc[tid] = b.off64 * 64;
+        s_sdy[tid] = f.inv_global_scale / (float)s_nrq[tid];  // group.rs:153
       }
-      if (tid < 192) s_lf[tid] = nx_lf;
+      const float* lf_tile = s_lf[(t - t_begin) & 1];
       if (tid == 0) s_pub = 0;
       __syncthreads();
       prefetch_meta(t + 1, tid);
       PROF_MARK(0);
-      // Everything up to the filters is WAVE-LOCAL: wavefront (q, c) = (quadrant of the tile, channel) takes its 16
-      // blocks' worth of one channel from coefficients to pixels, publishes the 4 edge columns of its 32 rows and
-      // fetches the neighbour strip's 4 columns beside them -- only wave-scope synchronisation, so the twelve
-      // wavefronts (and the other workgroup of the CU) overlap each other's memory latencies the way K1's batches do.
-      // (k1_scan hands a tile to this kernel only if every varblock lies inside one 32x32 quadrant.)
+      // wavefront (q, ch) = (32x32 quadrant of the tile, channel) from the IDCT passes on (k1_scan hands a tile to this
+      // kernel only if every varblock lies inside one quadrant)
       const int q = wave / 3, ch = wave % 3;
       const int qbx = (q & 1) * 4, qby = (q >> 1) * 4;  // the quadrant's first block inside the tile
-      if (mode == 0 && wave < 12) {
-        uint8_t* wl = s_wtask[wave];
-        // ---- (1a) this wavefront's tasks of the two IDCT passes, by length: [0, 128) 8, [128, 192) 16, [192, 224) 32
-        // pass 1 candidates: (row y of the quadrant, block column): a task iff the block is the leftmost of its
-        // varblock; pass 2: (column x, block row): iff it is the topmost
-        int n1[3] = {0, 0, 0}, n2[3] = {0, 0, 0};
+      if (mode == 0) {
+        if (JXLH_STRIP_ABLATE & 64) {
+        } else if (wave < 4) {
+          // ---- (1a) wavefront w: the tasks of the two IDCT passes in quadrant w (the same for every channel), by length:
+          // [0, 128) 8, [128, 192) 16, [192, 224) 32.  pass 1 candidates: (row y of the quadrant, block column): a task
+          // iff the block is the leftmost of its varblock; pass 2: (column x, block row): iff it is the topmost
+          const int wbx = (wave & 1) * 4, wby = (wave >> 1) * 4;
+          uint8_t* wl = s_wtask[wave];
+          int n1[3] = {0, 0, 0}, n2[3] = {0, 0, 0};
 #pragma unroll
-        for (int r = 0; r < 2; r++) {
-          {
-            const int cand = r * 64 + lane, y = cand >> 2, bxc = cand & 3;
-            const Blk b = decode_desc(s_desc[(qby + (y >> 3)) * 8 + qbx + bxc], qbx + bxc, qby + (y >> 3));
-            const bool act = b.on && b.dx == 0;
+          for (int r = 0; r < 2; r++) {
+            const int cand = r * 64 + lane;
+            {
+              const int y = cand >> 2, bxc = cand & 3;
+              const uint32_t bk = s_bk[(wby + (y >> 3)) * 8 + wbx + bxc];
+              const bool act = (bk >> 26) & 1u;
+              const int lcx = (bk >> 19) & 3;
 #pragma unroll
-            for (int k = 0; k < 3; k++) {
-              const unsigned long long m = __ballot(act && b.lcx == k);
-              if (act && b.lcx == k) wl[(k == 0 ? 0 : k == 1 ? 128 : 192) + n1[k] + __popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)cand;
-              n1[k] += __popcll(m);
+              for (int k = 0; k < 3; k++) {
+                const unsigned long long m = __ballot(act && lcx == k);
+                if (act && lcx == k) wl[(k == 0 ? 0 : k == 1 ? 128 : 192) + n1[k] + __popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)cand;
+                n1[k] += __popcll(m);
+              }
+            }
+            {
+              const int x = cand & 31, byc = cand >> 5;
+              const uint32_t bk = s_bk[(wby + byc) * 8 + wbx + (x >> 3)];
+              const bool act = (bk >> 27) & 1u;
+              const int lcy = (bk >> 17) & 3;
+#pragma unroll
+              for (int k = 0; k < 3; k++) {
+                const unsigned long long m = __ballot(act && lcy == k);
+                if (act && lcy == k) wl[224 + (k == 0 ? 0 : k == 1 ? 128 : 192) + n2[k] + __popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)cand;
+                n2[k] += __popcll(m);
+              }
             }
           }
-          {
-            const int cand = r * 64 + lane, x = cand & 31, byc = cand >> 5;
-            const Blk b = decode_desc(s_desc[(qby + byc) * 8 + qbx + (x >> 3)], qbx + (x >> 3), qby + byc);
-            const bool act = b.on && b.dy == 0;
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-              const unsigned long long m = __ballot(act && b.lcy == k);
-              if (act && b.lcy == k) wl[224 + (k == 0 ? 0 : k == 1 ? 128 : 192) + n2[k] + __popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)cand;
-              n2[k] += __popcll(m);
-            }
-          }
-        }
-        PROF_MARK(1);
-        // ---- (1c) LLF-from-LF (one lane per varblock) over the lowest frequencies; the dequantisation below skips
-        // that corner, which the LLF overwrites in the reference (transform.rs:450)
-        if (lane < 16) {
-          const int bx = qbx + (lane & 3), by = qby + (lane >> 2);
-          const Blk b = decode_desc(s_desc[by * 8 + bx], bx, by);
-          if (b.on && b.dx == 0 && b.dy == 0) {
-            const float* lf = s_lf + ch * 64 + by * 8 + bx;
-            float* org = s_buf + ch * kPlane + (kCarry + 8 * by) * kBW + kB + 8 * bx;
-            switch (b.type) {
+          if (lane < 6) s_wn[wave][lane] = lane == 0 ? n1[0] : lane == 1 ? n1[1] : lane == 2 ? n1[2] : lane == 3 ? n2[0] : lane == 4 ? n2[1] : n2[2];
+        } else if (wave < 7) {
+          // ---- (1c) LLF-from-LF of channel wave - 4 (one lane per block; the first block of a varblock acts) over the
+          // lowest frequencies; the dequantisation skips that corner, which the LLF overwrites in the reference
+          // (transform.rs:450)
+          const int c = wave - 4;
+          const uint32_t bk = s_bk[lane];
+          if ((bk >> 26 & 3u) == 3u) {
+            const float* lf = lf_tile + c * 64 + lane;
+            float* org = s_buf + c * kPlane + (bk & 0x1fffu);
+            switch ((bk >> 21) & 31u) {
               case 0: org[0] = lf[0]; break;
               case 4: llf_to_window<2, 2>(lf, 8, org); break;
               case 5: llf_to_window<4, 4>(lf, 8, org); break;
@@ -369,104 +484,94 @@ __global__ __launch_bounds__(kNT, JXLH_STRIP_WPE) void k123_strip(const FrameDev
             }
           }
         }
+        PROF_MARK(1);
         // ---- (1b) dequantisation + chroma-from-luma straight into the window (dequant_block, group.rs:137-177): a lane
-        // takes 4 consecutive stored coefficients; the X / B wavefronts dequantise the Y values they need themselves
+        // takes 4 consecutive stored coefficients of the three channels; 1024 chunks, the wavefronts that built no task
+        // list and ran no LLF take a second one
         {
           const int g = (t / 4) * f.xgroups + gx;
           const int cti = t * f.cmap_stride + strip;  // the tile IS a colour tile (64 x 64)
-          BlockInfo bi;
-          bi.x_cc = f.base_x + (float)f.ytox[cti] / f.color_factor;  // color_correlation_map.rs:76-78
-          bi.b_cc = f.base_b + (float)f.ytob[cti] / f.color_factor;
+          const float x_cc = f.base_x + (float)f.ytox[cti] / f.color_factor;  // color_correlation_map.rs:76-78
+          const float b_cc = f.base_b + (float)f.ytob[cti] / f.color_factor;
+          const float sdx = f.x_dm, sdb = f.b_dm;
+#pragma unroll 1
+          for (int it = 0; it < ((JXLH_STRIP_ABLATE & 8) ? 0 : 2); it++) {
+            if (it == 1 && wave < 8) break;  // wave-uniform
+            const int idx = it == 0 ? tid : 768 + (tid - 512);
+            const int bi = (idx >> 4) & 63, qd = idx & 15;
+            const uint32_t bk = s_bk[bi];
+            if (idx >= 1024 || !(bk >> 31)) continue;
+            const int k = (int)((bk >> 13) & 15u) * 64 + 4 * qd;  // index inside the varblock's stored coefficients
+            const int lr = 3 + (int)((bk >> 17) & 3u), lc = 3 + (int)((bk >> 19) & 3u);  // log2 of R, C
+            const bool wide = lr < lc;
+            // stored in[u * R + v] for R >= C, in[v * C + u] for the wide shapes (tests.rs:119-132)
+            const int u = wide ? (k & ((1 << lc) - 1)) : (k >> lr), v = wide ? (k >> lc) : (k & ((1 << lr) - 1));
+            // leading elements inside the LLF corner (u < cx, v < cy): written by the LLF lanes instead
+            const int sk = wide ? ((u == 0 && v < (1 << (lr - 3))) ? (1 << (lc - 3)) : 0) : ((v == 0 && u < (1 << (lc - 3))) ? (1 << (lr - 3)) : 0);
+            const int tsize = 1 << (lr + lc);
+            const float* tb = f.tables + s_bt[bi] + k;
+            const int* cf = f.coeffs + ((size_t)g * 3 * kGroupArea + s_bc[bi] + k);
+            const int4 q1 = gload_i4<true>(cf + kGroupArea), q0 = gload_i4<true>(cf), q2 = gload_i4<true>(cf + 2 * kGroupArea);
+            const float4 t1 = *reinterpret_cast<const float4*>(tb + tsize), t0 = *reinterpret_cast<const float4*>(tb),
+                         t2 = *reinterpret_cast<const float4*>(tb + 2 * tsize);
+            const float sd = s_sdy[bi];
+            float dy[4];
+            const bool nofast = s_nofast != 0;
+            // channel order of the reference: Y, X, B
+            const float4 vy = dequant4_fast<1>(f, q1, t1, sd, 0.0f, s_adj[1], nofast, dy);
+            const float4 vx = dequant4_fast<0>(f, q0, t0, sd * sdx, x_cc, s_adj[0], nofast, dy);
+            const float4 vb = dequant4_fast<2>(f, q2, t2, sd * sdb, b_cc, s_adj[2], nofast, dy);
+            float* d = s_buf + (bk & 0x1fffu) + v * kBW + u;
+            const float4 vv[3] = {vx, vy, vb};
 #pragma unroll
-          for (int half = 0; half < 2; half++) {
-            int4 qo[2], qy[2];
-            float4 to[2], ty[2];
-            int woff[2], skip[2];
-            float sdy[2];
-#pragma unroll
-            for (int it = 0; it < 2; it++) {
-              const int idx = (half * 2 + it) * 64 + lane;  // 16 blocks x 16 chunks
-              const int bq = idx >> 4, qd = idx & 15;
-              const int bx = qbx + (bq & 3), by = qby + (bq >> 2);
-              const Blk b = decode_desc(s_desc[by * 8 + bx], bx, by);
-              const int k = ((b.dy << b.lcx) + b.dx) * 64 + 4 * qd;  // index inside the varblock's stored coefficients
-              const int lr = 3 + b.lcy, lc = 3 + b.lcx;              // log2 of R, C
-              const bool wide = lr < lc;
-              // stored in[u * R + v] for R >= C, in[v * C + u] for the wide shapes (tests.rs:119-132)
-              const int u = wide ? (k & ((1 << lc) - 1)) : (k >> lr), v = wide ? (k >> lc) : (k & ((1 << lr) - 1));
-              // woff < 0: nothing to do; bit 30: the four values go down a column (stride kBW) instead of along a row
-              woff[it] = !b.on ? -1 : (((kCarry + 8 * (by - b.dy) + v) * kBW + kB + 8 * (bx - b.dx) + u) | (wide ? 0 : 1 << 30));
-              // leading elements inside the LLF corner (u < cx, v < cy): written by the LLF lanes instead
-              skip[it] = wide ? ((u == 0 && v < (1 << b.lcy)) ? (1 << b.lcx) : 0) : ((v == 0 && u < (1 << b.lcx)) ? (1 << b.lcy) : 0);
-              sdy[it] = s_sdy[by * 8 + bx];
-              const int qt = b.on ? quant_table_for_type(b.type) : 0;
-              const int tsize = quant_table_size(qt);
-              const float* tb = f.tables + f.table_offset[qt] + k;
-              const int* cf = f.coeffs + ((size_t)g * 3 * kGroupArea + b.off64 * 64 + k);
-              qo[it] = qy[it] = make_int4(0, 0, 0, 0);
-              to[it] = ty[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-              if (b.on) {
-                qy[it] = gload_i4<true>(cf + kGroupArea);
-                ty[it] = *reinterpret_cast<const float4*>(tb + tsize);
-                if (ch != 1) {
-                  qo[it] = gload_i4<true>(cf + ch * kGroupArea);
-                  to[it] = *reinterpret_cast<const float4*>(tb + ch * tsize);
-                }
-              }
-            }
-#pragma unroll
-            for (int it = 0; it < 2; it++) {
-              if (woff[it] < 0) continue;
-              bi.sdy = sdy[it];
-              float dy[4];
-              float4 vv = dequant4<1>(f, qy[it], ty[it], bi, dy);
-              if (ch == 0) vv = dequant4<0>(f, qo[it], to[it], bi, dy);
-              else if (ch == 2) vv = dequant4<2>(f, qo[it], to[it], bi, dy);
-              float* dc = s_buf + ch * kPlane + (woff[it] & 0xffffff);
-              const bool col = (woff[it] >> 30) != 0;
-              const int sk = skip[it];
-              if (!col && sk == 0) {
-                lds_store4(dc, vv);
+            for (int c = 0; c < 3; c++) {
+              float* dc = d + c * kPlane;
+              if (wide && sk == 0) {
+                lds_store4(dc, vv[c]);
               } else {
-                const int st = col ? kBW : 1;
-                if (sk < 1) dc[0] = vv.x;
-                if (sk < 2) dc[st] = vv.y;
-                if (sk < 3) dc[2 * st] = vv.z;
-                if (sk < 4) dc[3 * st] = vv.w;
+                const int st = wide ? 1 : kBW;
+                if (sk < 1) dc[0] = vv[c].x;
+                if (sk < 2) dc[st] = vv[c].y;
+                if (sk < 3) dc[2 * st] = vv[c].z;
+                if (sk < 4) dc[3 * st] = vv[c].w;
               }
             }
           }
         }
-        wave_sync();
+        __syncthreads();
         PROF_MARK(2);
-        // ---- (1d) pass 1 (along u: window rows), (1e) pass 2 (along v: window columns); idct2d.rs:111-131 order
-        float* qorg = s_buf + ch * kPlane + (kCarry + 8 * qby) * kBW + kB + 8 * qbx;
+        // ---- (1d) pass 1 (along u: window rows), (1e) pass 2 (along v: window columns); idct2d.rs:111-131 order.
+        // Wave-local from here: only this wavefront touches channel ch of quadrant q.
+        {
+          const uint8_t* wl = s_wtask[q];
+          float* qorg = s_buf + ch * kPlane + (kCarry + 8 * qby) * kBW + kB + 8 * qbx;
 #pragma unroll
-        for (int pass = 0; pass < 2; pass++) {
+          for (int pass = 0; pass < 2; pass++) {
 #pragma unroll
-          for (int k = 2; k >= 0; k--) {  // the long transforms first
-            const int n = pass ? n2[k] : n1[k];
-            for (int i0 = 0; i0 < n; i0 += 64) {
-              if (i0 + lane < n) {
-                const int e = wl[pass * 224 + (k == 0 ? 0 : k == 1 ? 128 : 192) + i0 + lane];
-                if (pass == 0) {
-                  float* p = qorg + (e >> 2) * kBW + (e & 3) * 8;
-                  if (k == 2) idct_line<32, 1>(p);
-                  else if (k == 1) idct_line<16, 1>(p);
-                  else idct_line<8, 1>(p);
-                } else {
-                  float* p = qorg + (e >> 5) * 8 * kBW + (e & 31);
-                  if (k == 2) idct_line<32, kBW>(p);
-                  else if (k == 1) idct_line<16, kBW>(p);
-                  else idct_line<8, kBW>(p);
+            for (int k = 2; k >= 0; k--) {  // the long transforms first
+              const int n = (JXLH_STRIP_ABLATE & 16) ? 0 : s_wn[q][pass * 3 + k];
+              for (int i0 = 0; i0 < n; i0 += 64) {
+                if (i0 + lane < n) {
+                  const int e = wl[pass * 224 + (k == 0 ? 0 : k == 1 ? 128 : 192) + i0 + lane];
+                  if (pass == 0) {
+                    float* p = qorg + (e >> 2) * kBW + (e & 3) * 8;
+                    if (k == 2) idct_line<32, 1>(p);
+                    else if (k == 1) idct_line<16, 1>(p);
+                    else idct_line<8, 1>(p);
+                  } else {
+                    float* p = qorg + (e >> 5) * 8 * kBW + (e & 31);
+                    if (k == 2) idct_line<32, kBW>(p);
+                    else if (k == 1) idct_line<16, kBW>(p);
+                    else idct_line<8, kBW>(p);
+                  }
                 }
               }
             }
+            wave_sync();
+            PROF_MARK(3 + pass);
           }
-          wave_sync();
-          PROF_MARK(3 + pass);
         }
-      } else if (mode != 0) {
+      } else {
         // ---- (1') a tile K1's class kernels reconstructed: 8x8-tiled planes -> window (a lane fetches 4 rows of a column)
         for (int idx = tid; idx < 1024; idx += kNT) {
           const int col = idx & 63, yg = idx >> 6;
@@ -488,7 +593,7 @@ __global__ __launch_bounds__(kNT, JXLH_STRIP_WPE) void k123_strip(const FrameDev
       // ---- (2) publish the 4 edge columns of this wavefront's 32 rows: written through at agent scope (the neighbour
       // runs on another XCD, whose L2 is not coherent with this one's), acknowledged (vmcnt) before the count goes up;
       // the last of the twelve raises the strip's progress flag.  (3) then the neighbour's columns beside them.
-      if (sa.strips > 1 && wave < 12) {
+      if (sa.strips > 1 && wave < 12 && !(JXLH_STRIP_ABLATE & 32)) {
         const int side = q & 1, row = (q >> 1) * 32 + (lane & 31);
         if (lane < 32) {
           const float4 v = lds_load4(s_buf + ch * kPlane + (kCarry + row) * kBW + (side ? kTW : kB));
@@ -540,7 +645,7 @@ __global__ __launch_bounds__(kNT, JXLH_STRIP_WPE) void k123_strip(const FrameDev
       return;
     }
     // ---- (4) the next step's carry: the last 8 rows of the window as they are now (the stages work in place)
-    if (t < t_end) {
+    if (t < t_end && !(JXLH_STRIP_ABLATE & 128)) {
       for (int i = tid; i < 3 * kCarry * kStrips; i += kNT) {
         const int c = i / (kCarry * kStrips), r = (i / kStrips) % kCarry, s4 = (i % kStrips) * 4;
         lds_store4(s_save + (c * kCarry + r) * kBW + s4, lds_load4(s_buf + c * kPlane + (kBH - kCarry + r) * kBW + s4));
@@ -776,11 +881,11 @@ __global__ __launch_bounds__(kNT, JXLH_STRIP_WPE) void k123_strip(const FrameDev
       };
       constexpr int kMg = kBorder - (GAB ? 1 : 0);
       constexpr int kMe1 = kMg - (E1 ? 2 : 0);
-      if constexpr (GAB) run_stage(std::integral_constant<int, 0>{}, std::integral_constant<int, kMg>{});
+      if constexpr (GAB && !(JXLH_STRIP_ABLATE & 1)) run_stage(std::integral_constant<int, 0>{}, std::integral_constant<int, kMg>{});
       PROF_MARK(10);
-      if constexpr (E1) run_stage(std::integral_constant<int, 1>{}, std::integral_constant<int, kMe1>{});
+      if constexpr (E1 && !(JXLH_STRIP_ABLATE & 2)) run_stage(std::integral_constant<int, 1>{}, std::integral_constant<int, kMe1>{});
       PROF_MARK(11);
-      if constexpr (E2) run_stage(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{});
+      if constexpr (E2 && !(JXLH_STRIP_ABLATE & 4)) run_stage(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{});
     }
     // ---- (6) the carry moves up
     __syncthreads();
@@ -789,7 +894,7 @@ __global__ __launch_bounds__(kNT, JXLH_STRIP_WPE) void k123_strip(const FrameDev
       s_cnt = 0;
       s_nsw = 0;
     }
-    if (t < t_end) {
+    if (t < t_end && !(JXLH_STRIP_ABLATE & 128)) {
       for (int i = tid; i < 3 * kCarry * kStrips; i += kNT) {
         const int c = i / (kCarry * kStrips), r = (i / kStrips) % kCarry, s4 = (i % kStrips) * 4;
         lds_store4(s_buf + c * kPlane + r * kBW + s4, lds_load4(s_save + (c * kCarry + r) * kBW + s4));
@@ -798,8 +903,19 @@ __global__ __launch_bounds__(kNT, JXLH_STRIP_WPE) void k123_strip(const FrameDev
     PROF_MARK(13);
   }
 #ifdef JXLH_STRIP_PROF
-  if (tid_kernel == 0)
+  if (tid_kernel == 0) {
     for (int i = 0; i < 16; i++) atomicAdd(&g_strip_prof[i], s_prof[i]);
+    const unsigned long long e = now_ticks();
+    unsigned hwid, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    if (s_ticket < 1024) {
+      g_strip_end[s_ticket] = e;
+      g_strip_end[1024 + s_ticket] = (unsigned long long)hwid | (unsigned long long)xcc << 32;
+    }
+    atomicMin(&g_strip_prof[18], e);
+    atomicMax(&g_strip_prof[19], e);
+  }
 #endif
 }
 
@@ -852,6 +968,11 @@ bool launch_strip(hipStream_t s, const FrameDev& f, const uint2* desc, const uin
   sa.bands = bands;
   sa.xchg_rows = sa.tile_rows * kTH;
   sa.deadline_ticks = (unsigned long long)(deadline_s * 1.0e8);
+  static const int skew = [] {
+    const char* e = getenv("JXLH_STRIP_SKEW_US");
+    return e ? atoi(e) * 100 : 0;
+  }();
+  sa.skew_ticks = bands > 1 ? skew : 0;
   if (gab && e1 && e2) launch_variant<true, true, true>(s, f, sa);
   else if (gab && e1) launch_variant<true, true, false>(s, f, sa);
   else if (gab) launch_variant<true, false, false>(s, f, sa);
@@ -863,10 +984,14 @@ bool launch_strip(hipStream_t s, const FrameDev& f, const uint2* desc, const uin
 }  // namespace jxlh
 
 #ifdef JXLH_STRIP_PROF
+extern "C" int jxlh_strip_end_read(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_strip_end), sizeof(g_strip_end)) == hipSuccess ? 0 : -1;
+}
 extern "C" int jxlh_strip_prof_read(unsigned long long* out, int reset) {
   if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_strip_prof), sizeof(g_strip_prof)) != hipSuccess) return -1;
   if (reset) {
-    unsigned long long z[16] = {0};
+    unsigned long long z[20] = {0};
+    z[16] = z[18] = ~0ull;
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_strip_prof), z, sizeof z) != hipSuccess) return -1;
   }
   return 0;

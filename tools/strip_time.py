@@ -89,8 +89,31 @@ def main():
     L = strip[0].L
     if hasattr(L, "jxlh_strip_prof_read"):
         import ctypes as C
-        buf = (C.c_ulonglong * 16)()
+        buf = (C.c_ulonglong * 20)()
         L.jxlh_strip_prof_read(buf, 1)
+        strip[0].frame_run()
+        strip[0].sync()
+        L.jxlh_strip_prof_read(buf, 1)
+        out["one_launch_us"] = {"first_to_last_start": (buf[17] - buf[16]) / 100.0, "first_start_to_first_end": (buf[18] - buf[16]) / 100.0,
+                                "first_start_to_last_end": (buf[19] - buf[16]) / 100.0}
+        if hasattr(L, "jxlh_strip_end_read"):
+            eb = (C.c_ulonglong * 2048)()
+            L.jxlh_strip_end_read(eb)
+            t0 = buf[16]
+            ends = [(eb[i] - t0) / 100.0 for i in range(512)]
+            hw = [eb[1024 + i] for i in range(512)]
+            # HW_ID: wave 3:0, simd 5:4, pipe 7:6, cu 11:8, sh 12, se 15:13 (gfx9)
+            cu = [((h >> 8) & 15) | (((h >> 12) & 1) << 4) | (((h >> 13) & 7) << 5) | (((h >> 32) & 15) << 8) for h in hw]
+            out["band_end_us"] = [[round(min(ends[b * 128:(b + 1) * 128])), round(max(ends[b * 128:(b + 1) * 128]))] for b in range(4)]
+            out["band0_end_by_strip"] = [round(ends[i]) for i in range(0, 128, 4)]
+            out["band2_end_by_strip"] = [round(ends[256 + i]) for i in range(0, 128, 4)]
+            from collections import Counter
+            cnt = Counter(cu)
+            out["wgs_per_cu_hist"] = dict(Counter(cnt.values()))
+            out["distinct_cus"] = len(cnt)
+            solo = [ends[i] for i in range(512) if cnt[cu[i]] == 1]
+            duo = [ends[i] for i in range(512) if cnt[cu[i]] == 2]
+            out["end_us_solo_vs_duo"] = [round(sum(solo) / max(1, len(solo))), round(sum(duo) / max(1, len(duo)))]
         for _ in range(5):
             strip[0].frame_run()
         strip[0].sync()
