@@ -134,8 +134,12 @@ enum {
   JXLH_FRAME_UNFUSED_FILTERS = 1u << 0, /* run Gaborish/EPF as one kernel per stage (debug/parity) */
   JXLH_FRAME_EXPAND_SPARSE = 1u << 1,   /* always expand sparse submissions into dense slabs before the
                                            transforms instead of letting them read the pairs (debug/parity) */
-  JXLH_FRAME_NO_STRIP = 1u << 2,        /* whole-frame runs take the two-kernel path (transforms -> planes -> fused
-                                           filters) instead of the single strip kernel (debug/parity/A-B timing) */
+  JXLH_FRAME_STRIP = 1u << 2,           /* whole-frame runs go through the single strip kernel (dequantisation, IDCT and
+                                           the filter stages in one persistent launch, no intermediate planes in HBM:
+                                           2.35 GB of traffic per 8K frame instead of 3.58) instead of transforms ->
+                                           planes -> fused filters.  Bit-identical output; slower on MI355X today
+                                           (both forms are bound by instruction issue), hence
+                                           opt-in */
 };
 
 /* Header defaults of the reference (RestorationFilter / ColorCorrelationParams /

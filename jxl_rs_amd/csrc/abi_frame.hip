@@ -708,16 +708,17 @@ jxlh_status run_k1(jxlh_ctx* ctx, const RunPlan& plan, int gr0, int gr1) {
   return JXLH_OK;
 }
 
-// Whole-frame runs of a 4:4:4 frame with Gaborish and / or EPF1 (+ EPF2) go through the strip kernel (k_strip.hip)
+// Whole-frame runs of a 4:4:4 frame with Gaborish and / or EPF1 (+ EPF2) may go through the strip kernel (k_strip.hip):
+// opt-in (JXLH_FRAME_STRIP), see the flag's comment in jxl_hip.h
 bool strip_eligible(const jxlh_ctx* ctx) {
   const FrameDev& f = ctx->fd;
   const jxlh_frame_params& p = ctx->params;
-  static const bool off = [] {
-    const char* e = getenv("JXLH_NO_STRIP");
+  static const bool forced = [] {  // JXLH_STRIP=1: every eligible frame, whatever its flags say (A/B runs of whole suites)
+    const char* e = getenv("JXLH_STRIP");
     return e && *e && *e != '0';
   }();
-  return !off && !(p.flags & (JXLH_FRAME_UNFUSED_FILTERS | JXLH_FRAME_NO_STRIP)) && !f.subsampled && f.epf_iters <= 2 &&
-         (f.gab || f.epf_iters >= 1) && comm_nranks(ctx) <= 1;
+  return (forced || (p.flags & JXLH_FRAME_STRIP)) && !(p.flags & JXLH_FRAME_UNFUSED_FILTERS) && !f.subsampled &&
+         f.epf_iters <= 2 && (f.gab || f.epf_iters >= 1) && comm_nranks(ctx) <= 1;
 }
 
 // transforms + stage list of the whole frame in the strip kernel; tiles it cannot take (k1_scan decides) go through

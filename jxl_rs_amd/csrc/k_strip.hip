@@ -206,48 +206,6 @@ __device__ __forceinline__ Blk decode_desc(uint32_t d, int bx, int by) {
   return b;
 }
 
-// dequant_lane (group.rs:100-133) for four coefficients of channel CH with adjust_quant_bias (group.rs:85-96) read from a
-// table: for |q| < kAdjN, tab[|q|] holds what the reference computes for +|q| -- 0 * bias_c, 1 * bias_c, and for
-// |q| >= 2 the device's own (float)|q| - bias3 / (float)|q| -- and the value for -|q| is its negation EXACTLY (IEEE
-// multiplication, division and subtraction are sign-symmetric; the one exception, a table entry that is a zero, is
-// detected when the table is built and disables this path).  The division and the three-way select are what made the
-// dequantisation 37 vector instructions per coefficient, on the resource that bounds this kernel; now ~9.
-constexpr int kAdjN = 128;
-template <int CH>
-__device__ __forceinline__ float4 dequant4_fast(const FrameDev& f, const int4 q, const float4 t, float sd, float cc,
-                                                const float* __restrict__ tab, bool nofast, float (&dy)[4]) {
-  const int qq[4] = {q.x, q.y, q.z, q.w};
-  const float tt[4] = {t.x, t.y, t.z, t.w};
-  int aq[4];
-  float am[4];
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    aq[i] = qq[i] < 0 ? -qq[i] : qq[i];
-    am[i] = tab[min(aq[i], kAdjN - 1)];
-  }
-  // magnitudes the table does not hold (kAdjN is a power of two: the OR of the four is below it iff each is): rare,
-  // wave-uniform branch around the reference's own expression
-  if (__builtin_expect(nofast || __any(((uint32_t)aq[0] | (uint32_t)aq[1] | (uint32_t)aq[2] | (uint32_t)aq[3]) >= (uint32_t)kAdjN), 0)) {
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-      if (nofast || aq[i] >= kAdjN) am[i] = __uint_as_float(__float_as_uint(adjust_quant_bias(qq[i], f.quant_biases[CH], f.quant_biases[3])) ^ ((uint32_t)qq[i] & 0x80000000u));
-  }
-  float r[4];
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const float adj = __uint_as_float(__float_as_uint(am[i]) ^ ((uint32_t)qq[i] & 0x80000000u));
-    const float mul = tt[i] * sd;
-    const float v = adj * mul;
-    if constexpr (CH == 1) {
-      dy[i] = v;
-      r[i] = v;
-    } else {
-      r[i] = __builtin_fmaf(cc, dy[i], v);
-    }
-  }
-  return make_float4(r[0], r[1], r[2], r[3]);
-}
-
 // one task of an IDCT pass: N floats at stride STEP (1 = a window row, 16-byte accesses; kBW = a window column)
 template <int N, int STEP>
 __device__ __forceinline__ void idct_line(float* __restrict__ p) {
@@ -304,8 +262,7 @@ __global__ __launch_bounds__(kNT, JXLH_STRIP_WPE) void k123_strip(const FrameDev
   __shared__ uint32_t s_bk[64];        // per block of the tile, see (0)
   __shared__ int s_bt[64], s_bc[64];
   __shared__ float s_sdy[64];
-  __shared__ float s_adj[3][kAdjN];    // adjust_quant_bias of +i per channel, see dequant4_fast
-  __shared__ int s_nofast;
+  __shared__ AdjTable s_adj;           // adjust_quant_bias of +i per channel, see dequant4t
   __shared__ int s_toff[JXLH_NUM_QUANT_TABLES];  // FrameDev::table_offset (a dynamically indexed kernel argument would live in scratch)
   __shared__ float s_lf[2][192];  // the tile's LF samples [channel][block row][block column]; this step's / the next's
   __shared__ uint32_t s_ndesc[64], s_nrq[64];  // the next tile's block descriptors as fetched
@@ -324,18 +281,7 @@ __global__ __launch_bounds__(kNT, JXLH_STRIP_WPE) void k123_strip(const FrameDev
   constexpr int kBorder = (GAB ? 1 : 0) + (E1 ? 2 : 0) + (E2 ? 1 : 0);
   static_assert(kBorder >= 1 && kBorder <= kB, "at least one stage");
 
-  if (tid_kernel == 0) s_nofast = 0;
-  __syncthreads();
-  if (tid_kernel < kAdjN) {
-    const float quant = (float)tid_kernel;
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-      // adjust_quant_bias(+i): the expressions of group.rs:85-96 evaluated here, once per workgroup
-      const float v = tid_kernel < 2 ? quant * f.quant_biases[c] : quant - f.quant_biases[3] / quant;
-      s_adj[c][tid_kernel] = v;
-      if (tid_kernel >= 2 && v == 0.0f) s_nofast = 1;  // -(+0) is not what the reference gets for the negative coefficient
-    }
-  }
+  build_adj_table(f, &s_adj, tid_kernel, kNT);
   if (tid_kernel == 0) {
 #pragma unroll
     for (int i = 0; i < JXLH_NUM_QUANT_TABLES; i++) s_toff[i] = f.table_offset[i];
@@ -493,7 +439,6 @@ __global__ __launch_bounds__(kNT, JXLH_STRIP_WPE) void k123_strip(const FrameDev
           const int cti = t * f.cmap_stride + strip;  // the tile IS a colour tile (64 x 64)
           const float x_cc = f.base_x + (float)f.ytox[cti] / f.color_factor;  // color_correlation_map.rs:76-78
           const float b_cc = f.base_b + (float)f.ytob[cti] / f.color_factor;
-          const float sdx = f.x_dm, sdb = f.b_dm;
 #pragma unroll 1
           for (int it = 0; it < ((JXLH_STRIP_ABLATE & 8) ? 0 : 2); it++) {
             if (it == 1 && wave < 8) break;  // wave-uniform
@@ -516,11 +461,14 @@ __global__ __launch_bounds__(kNT, JXLH_STRIP_WPE) void k123_strip(const FrameDev
                          t2 = *reinterpret_cast<const float4*>(tb + 2 * tsize);
             const float sd = s_sdy[bi];
             float dy[4];
-            const bool nofast = s_nofast != 0;
+            BlockInfo binf;
+            binf.sdy = sd;
+            binf.x_cc = x_cc;
+            binf.b_cc = b_cc;
             // channel order of the reference: Y, X, B
-            const float4 vy = dequant4_fast<1>(f, q1, t1, sd, 0.0f, s_adj[1], nofast, dy);
-            const float4 vx = dequant4_fast<0>(f, q0, t0, sd * sdx, x_cc, s_adj[0], nofast, dy);
-            const float4 vb = dequant4_fast<2>(f, q2, t2, sd * sdb, b_cc, s_adj[2], nofast, dy);
+            const float4 vy = dequant4t<1>(f, q1, t1, binf, &s_adj, dy);
+            const float4 vx = dequant4t<0>(f, q0, t0, binf, &s_adj, dy);
+            const float4 vb = dequant4t<2>(f, q2, t2, binf, &s_adj, dy);
             float* d = s_buf + (bk & 0x1fffu) + v * kBW + u;
             const float4 vv[3] = {vx, vy, vb};
 #pragma unroll

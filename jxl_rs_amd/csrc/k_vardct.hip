@@ -358,7 +358,7 @@ __device__ __forceinline__ int4 tile_q4(const float* __restrict__ buf, int b, in
 template <class S, bool PREFETCH, bool SPARSE, bool SUB = false>
 __device__ __forceinline__ int run_dct_class(const FrameDev& f, const WorkItem* __restrict__ items, int count, int type,
                                              float* __restrict__ buf, BlockInfo* __restrict__ binfo_base, int gwave,
-                                             int nwaves, int lane) {
+                                             int nwaves, int lane, const AdjTable* __restrict__ adj) {
   constexpr int NCH = S::E / 4;  // 16-byte chunks per lane per channel
   const int q = quant_table_for_type(type);
   const float* __restrict__ table = f.tables + f.table_offset[q];
@@ -424,7 +424,7 @@ __device__ __forceinline__ int run_dct_class(const FrameDev& f, const WorkItem* 
             qq = gload_i4<JXLH_NT_COEF>(f.coeffs + bi.coef_off + CH * kGroupArea + k);
             tt = *reinterpret_cast<const float4*>(table + CH * tsize + k);
           }
-          v = dequant4<CH>(f, qq, tt, bi, d4);
+          v = dequant4t<CH>(f, qq, tt, bi, adj, d4);
         }
         if constexpr (CH == 1) {
           dy[j * 4] = d4[0];
@@ -486,9 +486,11 @@ template <bool SPARSE, bool SUB = false>
 __global__ __launch_bounds__(kThreads) void k1_dct8(const FrameDev f, const WorkLists wl) {
   __shared__ __attribute__((aligned(16))) float s_buf[kWaves * kTileA];
   __shared__ BlockInfo s_binfo[kWaves][S8x8::NB];
+  __shared__ AdjTable s_adj;
+  build_adj_table(f, &s_adj, threadIdx.x, kThreads);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   run_dct_class<S8x8, true, SPARSE, SUB>(f, wl.items[kClsDct8], wl.counts[(kClsDct8) * kCountPitch], 0, s_buf + wave * kTileA, s_binfo[wave],
-                            blockIdx.x * kWaves + wave, gridDim.x * kWaves, lane);
+                            blockIdx.x * kWaves + wave, gridDim.x * kWaves, lane, &s_adj);
 }
 
 // families B (16x8, 8x16, 16x16) + C (everything with a 32-point side) in ONE launch (round 3): as two kernels both
@@ -501,26 +503,28 @@ template <bool SPARSE>
 __global__ __launch_bounds__(kThreads, 3) void k1_dct16_32(const FrameDev f, const WorkLists wl) {
   __shared__ __attribute__((aligned(16))) float s_buf[kWaves * kTileC];
   __shared__ BlockInfo s_binfo[kWaves][8];
+  __shared__ AdjTable s_adj;
+  build_adj_table(f, &s_adj, threadIdx.x, kThreads);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float* buf = s_buf + wave * kTileC;
   const int gw = blockIdx.x * kWaves + wave, nw = gridDim.x * kWaves;
   // the long batches (32-point sides) first: the tail of the launch is then made of the short ones
   int used = run_dct_class<S32x32, false, SPARSE>(f, wl.items[kClsDct32x32], wl.counts[(kClsDct32x32) * kCountPitch], 5, buf,
-                                                  s_binfo[wave], gw, nw, lane);
+                                                  s_binfo[wave], gw, nw, lane, &s_adj);
   used += run_dct_class<S32x16, false, SPARSE>(f, wl.items[kClsDct32x16], wl.counts[(kClsDct32x16) * kCountPitch], 10, buf,
-                                               s_binfo[wave], rotate_wave(gw, used, nw), nw, lane);
+                                               s_binfo[wave], rotate_wave(gw, used, nw), nw, lane, &s_adj);
   used += run_dct_class<S16x32, false, SPARSE>(f, wl.items[kClsDct16x32], wl.counts[(kClsDct16x32) * kCountPitch], 11, buf,
-                                               s_binfo[wave], rotate_wave(gw, used, nw), nw, lane);
+                                               s_binfo[wave], rotate_wave(gw, used, nw), nw, lane, &s_adj);
   used += run_dct_class<S32x8, false, SPARSE>(f, wl.items[kClsDct32x8], wl.counts[(kClsDct32x8) * kCountPitch], 8, buf,
-                                              s_binfo[wave], rotate_wave(gw, used, nw), nw, lane);
+                                              s_binfo[wave], rotate_wave(gw, used, nw), nw, lane, &s_adj);
   used += run_dct_class<S8x32, false, SPARSE>(f, wl.items[kClsDct8x32], wl.counts[(kClsDct8x32) * kCountPitch], 9, buf, s_binfo[wave],
-                                              rotate_wave(gw, used, nw), nw, lane);
+                                              rotate_wave(gw, used, nw), nw, lane, &s_adj);
   used += run_dct_class<S16x16, true, SPARSE>(f, wl.items[kClsDct16x16], wl.counts[(kClsDct16x16) * kCountPitch], 4, buf, s_binfo[wave],
-                                              rotate_wave(gw, used, nw), nw, lane);
+                                              rotate_wave(gw, used, nw), nw, lane, &s_adj);
   used += run_dct_class<S16x8, true, SPARSE>(f, wl.items[kClsDct16x8], wl.counts[(kClsDct16x8) * kCountPitch], 6, buf,
-                                             s_binfo[wave], rotate_wave(gw, used, nw), nw, lane);
+                                             s_binfo[wave], rotate_wave(gw, used, nw), nw, lane, &s_adj);
   run_dct_class<S8x16, true, SPARSE>(f, wl.items[kClsDct8x16], wl.counts[(kClsDct8x16) * kCountPitch], 7, buf, s_binfo[wave],
-                                     rotate_wave(gw, used, nw), nw, lane);
+                                     rotate_wave(gw, used, nw), nw, lane, &s_adj);
 }
 
 // family D: the nine 8x8 special transform types (IDENTITY, DCT2X2, DCT4X4, DCT4X8, DCT8X4, AFV0-3).

@@ -148,4 +148,77 @@ __device__ __forceinline__ float4 dequant4(const FrameDev& f, const int4 q, cons
   return make_float4(r[0], r[1], r[2], r[3]);
 }
 
+
+// ---- adjust_quant_bias from a table (the division it holds made the dequantisation ~37 vector instructions per
+// coefficient, and the transform kernels are bound by instruction issue, not by HBM).  For |q| < kAdjN, tab[ch][|q|]
+// holds what the reference computes for +|q| (group.rs:85-96) -- 0 * bias_c, 1 * bias_c, and for |q| >= 2 the device's
+// own IEEE (float)|q| - bias3 / (float)|q| -- and the value for -|q| is its negation EXACTLY: IEEE multiplication,
+// division and subtraction are sign-symmetric.  The one exception, a table entry that is a zero (then -(+0) is not what
+// the reference gets for the negative coefficient), is detected when the table is built and turns the table off.
+// Larger magnitudes take the reference's expression behind a wave-uniform branch.
+constexpr int kAdjN = 128;
+struct AdjTable {
+  float v[3][kAdjN];
+  int nofast;
+};
+// every thread of the workgroup calls this once before its first dequantisation; ends with a workgroup barrier
+__device__ __forceinline__ void build_adj_table(const FrameDev& f, AdjTable* t, int tid, int nthreads) {
+  if (tid == 0) t->nofast = 0;
+  __syncthreads();
+  for (int i = tid; i < kAdjN; i += nthreads) {
+    const float quant = (float)i;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const float v = i < 2 ? quant * f.quant_biases[c] : quant - f.quant_biases[3] / quant;
+      t->v[c][i] = v;
+      if (i >= 2 && v == 0.0f) t->nofast = 1;
+    }
+  }
+  __syncthreads();
+}
+// dequant_lane (group.rs:100-133) for four coefficients of channel CH: same operations as dequant4, the adjusted
+// value from the table
+template <int CH>
+__device__ __forceinline__ float4 dequant4t(const FrameDev& f, const int4 q, const float4 t, const BlockInfo& bi,
+                                            const AdjTable* __restrict__ at, float (&dy)[4]) {
+  const float* __restrict__ tab = at->v[CH];
+  const bool nofast = at->nofast != 0;
+  float sd = bi.sdy;
+  if constexpr (CH == 0) sd = bi.sdy * f.x_dm;
+  if constexpr (CH == 2) sd = bi.sdy * f.b_dm;
+  const int qq[4] = {q.x, q.y, q.z, q.w};
+  const float tt[4] = {t.x, t.y, t.z, t.w};
+  int aq[4];
+  float am[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    aq[i] = qq[i] < 0 ? -qq[i] : qq[i];
+    am[i] = tab[min(aq[i], kAdjN - 1)];
+  }
+  // kAdjN is a power of two: the OR of the four magnitudes is below it iff each is
+  if (__builtin_expect(nofast || __any(((uint32_t)aq[0] | (uint32_t)aq[1] | (uint32_t)aq[2] | (uint32_t)aq[3]) >= (uint32_t)kAdjN), 0)) {
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      if (nofast || aq[i] >= kAdjN)
+        am[i] = __uint_as_float(__float_as_uint(adjust_quant_bias(qq[i], f.quant_biases[CH], f.quant_biases[3])) ^
+                                ((uint32_t)qq[i] & 0x80000000u));
+  }
+  float r[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const float adj = __uint_as_float(__float_as_uint(am[i]) ^ ((uint32_t)qq[i] & 0x80000000u));
+    const float mul = tt[i] * sd;
+    const float v = adj * mul;
+    if constexpr (CH == 1) {
+      dy[i] = v;
+      r[i] = v;
+    } else if constexpr (CH == 0) {
+      r[i] = __builtin_fmaf(bi.x_cc, dy[i], v);
+    } else {
+      r[i] = __builtin_fmaf(bi.b_cc, dy[i], v);
+    }
+  }
+  return make_float4(r[0], r[1], r[2], r[3]);
+}
+
 }  // namespace jxlh

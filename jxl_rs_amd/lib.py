@@ -28,7 +28,7 @@ ERR_INVALID_BLOCK_SIZE = -7
 ERR_BLOCK_OUT_OF_BOUNDS = -8
 FRAME_UNFUSED_FILTERS = 1
 FRAME_EXPAND_SPARSE = 2
-FRAME_NO_STRIP = 4
+FRAME_STRIP = 4
 GROUP_COMPLETE = 1
 GROUP_ACCUMULATE = 2
 

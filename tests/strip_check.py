@@ -16,7 +16,7 @@ import helpers  # noqa: E402
 def check(ctx, o, name, w, h, mix, aligned, epf, gab, seed=1, unique=None):
     wl = synth.make_vardct(w, h, mix=mix, seed=seed, unique_groups=unique, epf_iters=epf, gab=gab, aligned=aligned)
     t0 = time.time()
-    got, _ = helpers.run_gpu_frame(ctx, wl)
+    got, _ = helpers.run_gpu_frame(ctx, wl, flags=4)  # JXLH_FRAME_STRIP
     path = ctx.frame_path()
     want, _ = helpers.run_oracle_frame(o, wl, num_threads=16)
     bad = 0

@@ -74,8 +74,8 @@ def main():
         wl.epf_map[:] = 7
         wl.raw_quant[:] = np.minimum(wl.raw_quant, 4)
     out = {"size": a.size, "mix": a.mix, "aligned": not a.unaligned, "epf": a.epf, "epf_iters": a.epf_iters}
-    strip = [setup(wl, a.size, 0) for _ in range(2)]
-    two = [setup(wl, a.size, jl.FRAME_NO_STRIP) for _ in range(2)]
+    strip = [setup(wl, a.size, jl.FRAME_STRIP) for _ in range(2)]
+    two = [setup(wl, a.size, 0) for _ in range(2)]
     strip[0].frame_run()
     strip[0].sync()
     out["path"] = strip[0].frame_path()
