@@ -162,7 +162,8 @@ def time_modular_config(jxl_rs_amd, np, device, size, steps, cores, cpu=True):
     rng = np.random.default_rng(256)
     pal = rng.integers(0, 256, size=(3, 256)).astype(np.int32)
     idx = rng.integers(0, 256, size=(size, size)).astype(np.int32)
-    d_idx, d_pal, d_out = DeviceArray(idx), DeviceArray(pal), DeviceArray(nbytes=3 * npx * 4)
+    d_idx, d_pal, d_out = (DeviceArray(idx, device=device), DeviceArray(pal, device=device),
+                           DeviceArray(nbytes=3 * npx * 4, device=device))
     pal_ms = timed(lambda: ctx._chk(ctx.L.jxlh_palette(ctx._ctx, d_idx.ptr, npx, d_pal.ptr, 256, 256, 3, 8, d_out.ptr),
                                     "palette"), steps)
     rct_ms = timed(lambda: ctx._chk(ctx.L.jxlh_rct(ctx._ctx, ch.d_out[0].ptr, ch.d_out[1].ptr, ch.d_out[2].ptr, npx, 6, 0),

@@ -485,7 +485,10 @@ class GpuRenderPipeline {
   // render/mod.rs:128-136.  complete = false: a progressive pass that leaves the group open
   void set_buffer_for_group(uint32_t group_id, bool complete, const int32_t* coeffs, int slot = 0) {
     ctx_.check(jxlh_submit_group(ctx_.raw(), slot, group_id, coeffs, complete ? JXLH_GROUP_COMPLETE : 0u), "jxlh_submit_group");
-    dirty_ = true;
+    // the reference renders every group it is handed (render/mod.rs:128-136): once the frame has been rendered, a group
+    // that receives new coefficients is re-rendered whether or not the caller also marks it (duplicates are merged by
+    // jxlh_frame_rerender_groups)
+    if (!dirty_first_) rerender_.push_back(group_id);
   }
   // render/mod.rs:146
   void mark_group_to_rerender(uint32_t g) { rerender_.push_back(g); }
@@ -507,7 +510,6 @@ class GpuRenderPipeline {
       frame_.finalize_and_render();
     }
     dirty_first_ = false;
-    dirty_ = false;
     rerender_.clear();
   }
   // the save stage: interleaved integers through the colour tail, or the three f32 planes
@@ -522,7 +524,7 @@ class GpuRenderPipeline {
   LoweredPipeline lp_;
   VarDctFrame frame_;
   std::vector<uint32_t> rerender_;
-  bool dirty_ = false, dirty_first_ = true;
+  bool dirty_first_ = true;
 };
 
 // A Modular frame's stage list on the device: the samples come out of the Modular inverse transforms (jxlh_rct,

@@ -20,6 +20,7 @@ jxlh_status jxlh_timer_stop(jxlh_ctx* ctx, float* elapsed_ms) {
   JXLH_ON_DEVICE(ctx);
   if (!ctx || !elapsed_ms) return JXLH_ERR_INVALID_ARGUMENT;
   HIPCHK(ctx, hipEventRecord(ctx->t1, ctx->stream));
+  JXLH_SYNC(ctx);  // the event is the last thing on the stream; on a sharded context this wait has a deadline
   HIPCHK(ctx, hipEventSynchronize(ctx->t1));
   HIPCHK(ctx, hipEventElapsedTime(elapsed_ms, ctx->t0, ctx->t1));
   return JXLH_OK;
@@ -60,7 +61,7 @@ jxlh_status jxlh_frame_path(jxlh_ctx* ctx, int32_t* strip, int32_t* tiles, int32
     n = (int32_t)(strip_strips(ctx->fd) * strip_tile_rows(ctx->fd));
     std::vector<uint8_t> m((size_t)n);
     HIPCHK(ctx, hipMemcpyAsync(m.data(), ctx->strip_mode.p, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    JXLH_SYNC(ctx);
     for (uint8_t v : m) k += v != 0;
   }
   if (tiles) *tiles = n;
@@ -79,7 +80,7 @@ jxlh_status jxlh_selftest_recip(jxlh_ctx* ctx, uint32_t lo_bits, uint32_t hi_bit
   HIPCHK(ctx, hipGetLastError());
   unsigned long long host = 0;
   HIPCHK(ctx, hipMemcpyAsync(&host, d, sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  JXLH_SYNC(ctx);
   *mismatches = host;
   return JXLH_OK;
 }

@@ -350,7 +350,7 @@ jxlh_status jxlh_frame_set_dequant_tables(jxlh_ctx* ctx, const float* const tabl
   ctx->fd.tables = ctx->tables.p;
   ctx->tables_set = true;
   // like the other setters: the caller's buffers may be reused (or freed) as soon as the call returns
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  JXLH_SYNC(ctx);
   return JXLH_OK;
 }
 
@@ -399,7 +399,7 @@ jxlh_status jxlh_frame_set_lf_quantized(jxlh_ctx* ctx, uint32_t x0, uint32_t y0,
   }
   HIPCHK(ctx, hipGetLastError());
   // the host buffers may be reused by the caller as soon as we return
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  JXLH_SYNC(ctx);
   ctx->lf_smoothed = false;
   return JXLH_OK;
 }
@@ -417,7 +417,7 @@ jxlh_status jxlh_frame_set_lf(jxlh_ctx* ctx, uint32_t x0, uint32_t y0, uint32_t 
                             stride * sizeof(float), w * sizeof(float), h, ctx->stream);
     if (st != JXLH_OK) return st;
   }
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  JXLH_SYNC(ctx);
   ctx->lf_smoothed = false;
   return JXLH_OK;
 }
@@ -481,7 +481,7 @@ jxlh_status jxlh_frame_set_hf_meta(jxlh_ctx* ctx, uint32_t x0, uint32_t y0, uint
     return st;
   if ((st = copy2d(ctx, ctx->ytox.p + coff, ctx->fd.cmap_stride, ytox, cmap_stride, cw, ch, ctx->stream))) return st;
   if ((st = copy2d(ctx, ctx->ytob.p + coff, ctx->fd.cmap_stride, ytob, cmap_stride, cw, ch, ctx->stream))) return st;
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  JXLH_SYNC(ctx);
   return JXLH_OK;
 }
 
@@ -515,7 +515,7 @@ jxlh_status ensure_jump_table(jxlh_ctx* ctx) {
   std::call_once(once, [] { xorshift_jump_table(table); });
   if (jxlh_status st = ensure(ctx, ctx->xs_jump, sizeof(table) / sizeof(uint64_t))) return st;
   HIPCHK(ctx, hipMemcpyAsync(ctx->xs_jump.p, table, sizeof(table), hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  JXLH_SYNC(ctx);
   return JXLH_OK;
 }
 
@@ -556,7 +556,7 @@ jxlh_status upload_upsampling_kernels(jxlh_ctx* ctx, int n) {
   if (jxlh_status st = ensure(ctx, ctx->ups_kernels, flat.size())) return st;
   // pageable source: the copy is staged by the runtime before the call returns
   HIPCHK(ctx, hipMemcpyAsync(ctx->ups_kernels.p, flat.data(), flat.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  JXLH_SYNC(ctx);
   return JXLH_OK;
 }
 

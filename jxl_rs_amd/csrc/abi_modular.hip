@@ -132,7 +132,7 @@ jxlh_status jxlh_modular_to_rgb8(jxlh_ctx* ctx, const int32_t* const planes[3], 
   launch_i32_to_rgb8(ctx->stream, src, sstride, (int)w, (int)h, multiplier, max, (int)channels, ctx->rgb8.p, tight);
   HIPCHK(ctx, hipGetLastError());
   if ((st = copy2d(ctx, out, bytes_per_row, ctx->rgb8.p, tight, tight, (size_t)h, ctx->stream))) return st;
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  JXLH_SYNC(ctx);
   return JXLH_OK;
 }
 
@@ -420,7 +420,9 @@ jxlh_status jxlh_unsqueeze_chain(jxlh_ctx* ctx, int32_t n_planes, int32_t n_leve
     const int32_t* rv[3];
     for (int p = 0; p < n_planes; p++) rv[p] = lv.res[p] ? lv.res[p] : cur[p];
     bool fused = false;
-    if (last && with_rct)
+    // JXLH_SEPARATE_RCT=1 (tests): take the two-pass route that planes of 2^31 samples and more need
+    const char* sep = getenv("JXLH_SEPARATE_RCT");
+    if (last && with_rct && !(sep && *sep == '1'))
       fused = launch_unsqueeze_rct(ctx->stream, lv.horizontal ? 1 : 0, cur, cur_stride, rv, lv.res_stride, lv.out_w, lv.out_h,
                                    dst, dst_stride, rct_op, rct_perm);
     if (!fused)
@@ -430,9 +432,7 @@ jxlh_status jxlh_unsqueeze_chain(jxlh_ctx* ctx, int32_t n_planes, int32_t n_leve
       if (dst_stride == lv.out_w) {
         launch_rct(ctx->stream, dst[0], dst[1], dst[2], (size_t)lv.out_w * lv.out_h, rct_op, rct_perm);
       } else {
-        for (uint32_t y = 0; y < lv.out_h; y++)
-          launch_rct(ctx->stream, dst[0] + (size_t)y * dst_stride, dst[1] + (size_t)y * dst_stride,
-                     dst[2] + (size_t)y * dst_stride, lv.out_w, rct_op, rct_perm);
+        launch_rct_rows(ctx->stream, dst[0], dst[1], dst[2], lv.out_w, lv.out_h, dst_stride, rct_op, rct_perm);
       }
     }
     for (int p = 0; p < n_planes; p++) cur[p] = dst[p];
@@ -459,7 +459,8 @@ jxlh_status jxlh_unsqueeze_rct(jxlh_ctx* ctx, int32_t horizontal, const int32_t*
     if (has_res && (!res[i] || !is_device_ptr(res[i]))) return JXLH_ERR_INVALID_ARGUMENT;
     rv[i] = res[i] ? res[i] : avg[i];
   }
-  {
+  const char* sep = getenv("JXLH_SEPARATE_RCT");
+  if (!(sep && *sep == '1')) {
     ScopedKernelTimer t(ctx, horizontal ? "k6_unsqueeze_rct_h" : "k6_unsqueeze_rct_v");
     if (launch_unsqueeze_rct(ctx->stream, horizontal, avg, avg_stride, rv, res_stride, out_w, out_h, out, out_stride, op,
                              perm)) {
@@ -467,14 +468,12 @@ jxlh_status jxlh_unsqueeze_rct(jxlh_ctx* ctx, int32_t horizontal, const int32_t*
       return JXLH_OK;
     }
   }
-  // planes of 2^31 samples or more: the two separate passes (the RCT row by row when the rows are padded)
+  // planes of 2^31 samples or more: the two separate passes (the RCT with a row pitch when the rows are padded)
   launch_unsqueeze(ctx->stream, horizontal, 3, avg, avg_stride, rv, res_stride, out_w, out_h, out, out_stride);
   if (out_stride == out_w) {
     launch_rct(ctx->stream, out[0], out[1], out[2], (size_t)out_w * out_h, op, perm);
   } else {
-    for (uint32_t y = 0; y < out_h; y++)
-      launch_rct(ctx->stream, out[0] + (size_t)y * out_stride, out[1] + (size_t)y * out_stride,
-                 out[2] + (size_t)y * out_stride, out_w, op, perm);
+    launch_rct_rows(ctx->stream, out[0], out[1], out[2], out_w, out_h, out_stride, op, perm);
   }
   HIPCHK(ctx, hipGetLastError());
   return JXLH_OK;
@@ -512,7 +511,7 @@ jxlh_status jxlh_smooth_unsqueeze(jxlh_ctx* ctx, int32_t kind, const int32_t* av
   if (out_stride == out_w) return stage_out(ctx, out, (const int32_t*)ctx->hook_i[2].p, out_stride * out_h);
   HIPCHK(ctx, hipMemcpy2DAsync(out, out_stride * sizeof(int32_t), ctx->hook_i[2].p, out_stride * sizeof(int32_t),
                                out_w * sizeof(int32_t), out_h, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  JXLH_SYNC(ctx);
   return JXLH_OK;
 }
 

@@ -61,7 +61,7 @@ jxlh_status read_rgb8(jxlh_ctx* ctx, int mode, const jxlh_xyb_params* p, const T
     if (jxlh_status st = copy2d(ctx, out, bytes_per_row, ctx->rgb8.p, tight, (size_t)ctx->res_w * channels, (size_t)rows,
                                 ctx->stream))
       return st;
-    if (wait) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (wait) JXLH_SYNC(ctx);
     return JXLH_OK;
   }
   if (is_device_ptr(out)) {
@@ -84,7 +84,7 @@ jxlh_status read_rgb8(jxlh_ctx* ctx, int mode, const jxlh_xyb_params* p, const T
   const size_t row_bytes = (size_t)ctx->res_w * channels;
   if (jxlh_status st = copy2d(ctx, out, bytes_per_row, ctx->rgb8.p, tight, row_bytes, (size_t)rows, ctx->stream))
     return st;
-  if (wait) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (wait) JXLH_SYNC(ctx);
   return JXLH_OK;
 }
 
@@ -118,7 +118,7 @@ jxlh_status read_rgb16(jxlh_ctx* ctx, int mode, const jxlh_xyb_params* p, const 
     if (dev) return JXLH_OK;
     if (jxlh_status st = copy2d(ctx, out, bytes_per_row, ctx->rgb8.p, row_bytes, row_bytes, (size_t)rows, ctx->stream))
       return st;
-    if (wait) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (wait) JXLH_SYNC(ctx);
     return JXLH_OK;
   }
   if (is_device_ptr(out)) {
@@ -137,7 +137,7 @@ jxlh_status read_rgb16(jxlh_ctx* ctx, int mode, const jxlh_xyb_params* p, const 
   HIPCHK(ctx, hipGetLastError());
   if (jxlh_status st = copy2d(ctx, out, bytes_per_row, ctx->rgb8.p, row_bytes, row_bytes, (size_t)rows, ctx->stream))
     return st;
-  if (wait) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (wait) JXLH_SYNC(ctx);
   return JXLH_OK;
 }
 }  // namespace
@@ -243,7 +243,7 @@ jxlh_status jxlh_frame_read_lf(jxlh_ctx* ctx, float* x, float* y, float* b, size
                             f.xblocks * sizeof(float), f.yblocks, ctx->stream);
     if (st != JXLH_OK) return st;
   }
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  JXLH_SYNC(ctx);
   return JXLH_OK;
 }
 

@@ -88,7 +88,7 @@ jxlh_status jxlh_modular_frame_filters(jxlh_ctx* ctx, const jxlh_frame_params* p
     const float sigma = kInvSigmaNum / p->epf_sigma_for_modular;
     std::vector<float> host(nb, sigma);
     HIPCHK(ctx, hipMemcpyAsync(ctx->hook_f[7].p, host.data(), nb * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // `host` goes out of scope
+    JXLH_SYNC(ctx);  // `host` goes out of scope
   }
   f.inv_sigma = ctx->hook_f[7].p;
   int where;

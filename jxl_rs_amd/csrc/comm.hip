@@ -36,6 +36,7 @@ struct RcclApi {
   ncclResult_t (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t*) = nullptr;  // optional
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;                          // optional
 };
 
 static RcclApi* rccl_api(std::string* err) {
@@ -77,6 +78,7 @@ static RcclApi* rccl_api(std::string* err) {
     return nullptr;
   }
   api.CommGetAsyncError = reinterpret_cast<decltype(api.CommGetAsyncError)>(dlsym(h, "ncclCommGetAsyncError"));
+  api.CommAbort = reinterpret_cast<decltype(api.CommAbort)>(dlsym(h, "ncclCommAbort"));
   api.handle = h;
   return &api;
 }
@@ -93,6 +95,10 @@ struct Comm {
   // what was enqueued last on the stream through this communicator: named when a wait times out (comm_wait_stream)
   std::string last_op;
   double timeout_s = 120.0;           // JXLH_COMM_TIMEOUT_S; <= 0 waits forever
+  // a wait on this communicator's stream expired or RCCL reported an asynchronous error: the stream still holds the
+  // stuck collective, so the communicator is ABORTED on release (ncclCommDestroy would wait for it) and every later
+  // wait fails at once instead of sitting out another deadline
+  bool failed = false;
 };
 
 static jxlh_status nccl_fail(jxlh_ctx* ctx, const RcclApi* api, ncclResult_t r, const char* what) {
@@ -105,12 +111,27 @@ static jxlh_status nccl_fail(jxlh_ctx* ctx, const RcclApi* api, ncclResult_t r, 
     if (r_ != ncclSuccess) return nccl_fail(ctx, api, r_, #expr);   \
   } while (0)
 
+// inside ncclGroupStart ... ncclGroupEnd: an error must not leave the group open (every later RCCL call of the thread
+// would be queued into it)
+#define NCCLCHK_IN_GROUP(ctx, api, expr)                            \
+  do {                                                              \
+    ncclResult_t r_ = (expr);                                       \
+    if (r_ != ncclSuccess) {                                        \
+      (void)(api)->GroupEnd();                                      \
+      return nccl_fail(ctx, api, r_, #expr);                        \
+    }                                                               \
+  } while (0)
+
 void comm_release(jxlh_ctx* ctx) {
   Comm* c = ctx->comm;
   if (!c) return;
   (void)hipSetDevice(ctx->device);
   if (c->nccl) {
-    if (RcclApi* api = rccl_api(nullptr)) (void)api->CommDestroy(c->nccl);
+    if (RcclApi* api = rccl_api(nullptr)) {
+      // a communicator with a collective that will never complete is torn down without waiting for it
+      if (c->failed && api->CommAbort) (void)api->CommAbort(c->nccl);
+      else (void)api->CommDestroy(c->nccl);
+    }
   }
   if (c->k1_ev) (void)hipEventDestroy(c->k1_ev);
   if (c->done_ev) (void)hipEventDestroy(c->done_ev);
@@ -131,6 +152,11 @@ jxlh_status comm_wait_stream(jxlh_ctx* ctx) {
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return JXLH_OK;
   }
+  if (c->failed) {
+    ctx->last_error = "rank " + std::to_string(c->rank) + " of " + std::to_string(c->nranks) +
+                      ": the communicator failed earlier (" + c->last_op + "); destroy it (jxlh_comm_destroy / jxlh_ctx_destroy)";
+    return JXLH_ERR_DEVICE;
+  }
   RcclApi* api = rccl_api(nullptr);
   const auto t0 = std::chrono::steady_clock::now();
   for (unsigned spins = 0;; spins++) {
@@ -143,6 +169,7 @@ jxlh_status comm_wait_stream(jxlh_ctx* ctx) {
       if (api->CommGetAsyncError(c->nccl, &ar) == ncclSuccess && ar != ncclSuccess && ar != ncclInProgress) {
         ctx->last_error = "rank " + std::to_string(c->rank) + " of " + std::to_string(c->nranks) + ": RCCL asynchronous error (" +
                           (api->GetErrorString ? api->GetErrorString(ar) : "?") + ") after: " + c->last_op;
+        c->failed = true;
         return JXLH_ERR_DEVICE;
       }
     }
@@ -151,6 +178,7 @@ jxlh_status comm_wait_stream(jxlh_ctx* ctx) {
       ctx->last_error = "rank " + std::to_string(c->rank) + " of " + std::to_string(c->nranks) + ": the stream did not finish within " +
                         std::to_string((int)c->timeout_s) + " s (JXLH_COMM_TIMEOUT_S); last collective enqueued: " +
                         (c->last_op.empty() ? std::string("none") : c->last_op);
+      c->failed = true;
       return JXLH_ERR_DEVICE;
     }
     if (spins > 2000) std::this_thread::sleep_for(std::chrono::microseconds(spins > 20000 ? 1000 : 50));
@@ -339,15 +367,15 @@ jxlh_status jxlh_frame_run_sharded(jxlh_ctx* ctx) {
         size_t off, cnt;
         if (has_up) {  // my first block row goes up, the block row above my band comes down
           block_row_span(f, r0 * kGroupBlocks, &off, &cnt);
-          NCCLCHK(ctx, api, api->Send(f.planes[ch] + off, cnt, ncclFloat32, c->rank - 1, c->nccl, ctx->stream));
+          NCCLCHK_IN_GROUP(ctx, api, api->Send(f.planes[ch] + off, cnt, ncclFloat32, c->rank - 1, c->nccl, ctx->stream));
           block_row_span(f, r0 * kGroupBlocks - 1, &off, &cnt);
-          NCCLCHK(ctx, api, api->Recv(f.planes[ch] + off, cnt, ncclFloat32, c->rank - 1, c->nccl, ctx->stream));
+          NCCLCHK_IN_GROUP(ctx, api, api->Recv(f.planes[ch] + off, cnt, ncclFloat32, c->rank - 1, c->nccl, ctx->stream));
         }
         if (has_dn) {
           block_row_span(f, r1 * kGroupBlocks - 1, &off, &cnt);
-          NCCLCHK(ctx, api, api->Send(f.planes[ch] + off, cnt, ncclFloat32, c->rank + 1, c->nccl, ctx->stream));
+          NCCLCHK_IN_GROUP(ctx, api, api->Send(f.planes[ch] + off, cnt, ncclFloat32, c->rank + 1, c->nccl, ctx->stream));
           block_row_span(f, r1 * kGroupBlocks, &off, &cnt);
-          NCCLCHK(ctx, api, api->Recv(f.planes[ch] + off, cnt, ncclFloat32, c->rank + 1, c->nccl, ctx->stream));
+          NCCLCHK_IN_GROUP(ctx, api, api->Recv(f.planes[ch] + off, cnt, ncclFloat32, c->rank + 1, c->nccl, ctx->stream));
         }
       }
       NCCLCHK(ctx, api, api->GroupEnd());
@@ -375,7 +403,7 @@ jxlh_status jxlh_frame_allgather(jxlh_ctx* ctx) {
   c->last_op = "ncclAllGather of the finished planes (" + std::to_string(count * 4) + " bytes per rank and plane)";
   NCCLCHK(ctx, api, api->GroupStart());
   for (int ch = 0; ch < 3; ch++)
-    NCCLCHK(ctx, api, api->AllGather(res[ch] + (size_t)c->rank * count, res[ch], count, ncclFloat32, c->nccl, ctx->stream));
+    NCCLCHK_IN_GROUP(ctx, api, api->AllGather(res[ch] + (size_t)c->rank * count, res[ch], count, ncclFloat32, c->nccl, ctx->stream));
   NCCLCHK(ctx, api, api->GroupEnd());
   return JXLH_OK;
 }

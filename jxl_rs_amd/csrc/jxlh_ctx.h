@@ -273,16 +273,23 @@ jxlh_status stage_in(jxlh_ctx* ctx, DevBuf<T>& b, const T* src, size_t n) {
   HIPCHK(ctx, hipMemcpyAsync(b.p, src, n * sizeof(T), hipMemcpyDefault, ctx->stream));
   return JXLH_OK;
 }
-template <class T>
-jxlh_status stage_out(jxlh_ctx* ctx, T* dst, const T* src, size_t n) {
-  HIPCHK(ctx, hipMemcpyAsync(dst, src, n * sizeof(T), hipMemcpyDefault, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  return JXLH_OK;
-}
 // comm.hip
 void comm_release(jxlh_ctx* ctx);
 int comm_nranks(const jxlh_ctx* ctx);
-jxlh_status comm_wait_stream(jxlh_ctx* ctx);  // hipStreamSynchronize with a deadline while collectives may be queued
+// hipStreamSynchronize with a deadline while collectives may be queued.  EVERY blocking wait on the context's stream goes
+// through it (JXLH_SYNC): on a sharded context a stuck collective then surfaces as JXLH_ERR_DEVICE from whichever call
+// waits first -- a read-out as well as jxlh_ctx_sync -- instead of parking the process in the driver.
+jxlh_status comm_wait_stream(jxlh_ctx* ctx);
+#define JXLH_SYNC(ctx)                                        \
+  do {                                                        \
+    if (jxlh_status st_ = comm_wait_stream(ctx)) return st_;  \
+  } while (0)
+template <class T>
+jxlh_status stage_out(jxlh_ctx* ctx, T* dst, const T* src, size_t n) {
+  HIPCHK(ctx, hipMemcpyAsync(dst, src, n * sizeof(T), hipMemcpyDefault, ctx->stream));
+  JXLH_SYNC(ctx);
+  return JXLH_OK;
+}
 int comm_rows_per_rank(const jxlh_ctx* ctx, int ygroups);
 
 }  // namespace jxlh_host

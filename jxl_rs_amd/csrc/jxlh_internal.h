@@ -274,6 +274,9 @@ void launch_selftest_recip(hipStream_t s, uint32_t lo_bits, uint32_t hi_bits, un
 void launch_transform_to_pixels(hipStream_t s, int type, uint32_t n, const float* coeffs, const float* lf,
                                 float* pixels);
 void launch_rct(hipStream_t s, int32_t* p0, int32_t* p1, int32_t* p2, size_t n, int op, int perm);
+// rows of w samples at a pitch of `stride` samples, in one launch (padding untouched)
+void launch_rct_rows(hipStream_t s, int32_t* p0, int32_t* p1, int32_t* p2, uint32_t w, uint32_t h, size_t stride, int op,
+                     int perm);
 // out_channel_stride: samples between the channel planes of `out` (0 = n, contiguous planes)
 void launch_palette(hipStream_t s, const int32_t* index, size_t n, const int32_t* palette, int num_colors,
                     size_t palette_stride, int nb_channels, int bit_depth, int32_t* out, size_t out_channel_stride = 0);

@@ -85,6 +85,33 @@ __global__ void k4_rct(int32_t* __restrict__ p0, int32_t* __restrict__ p1, int32
   }
 }
 
+// the same on rows of w samples at a pitch of `stride` samples (padded planes: the padding is not touched); row y of
+// the grid's y dimension and beyond, one sample per thread along x
+template <int OP>
+__global__ void k4_rct_rows(int32_t* __restrict__ p0, int32_t* __restrict__ p1, int32_t* __restrict__ p2, uint32_t w,
+                            uint32_t h, size_t stride, int perm) {
+  int32_t* o[3];
+  switch (perm) {
+    default:
+    case 0: o[0] = p0; o[1] = p1; o[2] = p2; break;
+    case 1: o[0] = p1; o[1] = p2; o[2] = p0; break;
+    case 2: o[0] = p2; o[1] = p0; o[2] = p1; break;
+    case 3: o[0] = p0; o[1] = p2; o[2] = p1; break;
+    case 4: o[0] = p1; o[1] = p0; o[2] = p2; break;
+    case 5: o[0] = p2; o[1] = p1; o[2] = p0; break;
+  }
+  for (uint32_t y = blockIdx.y; y < h; y += gridDim.y) {
+    const size_t row = (size_t)y * stride;
+    for (uint32_t x = blockIdx.x * blockDim.x + threadIdx.x; x < w; x += gridDim.x * blockDim.x) {
+      int32_t a, b, c;
+      rct_op<OP>(p0[row + x], p1[row + x], p2[row + x], a, b, c);
+      o[0][row + x] = a;
+      o[1][row + x] = b;
+      o[2][row + x] = c;
+    }
+  }
+}
+
 __constant__ int16_t kDeltaPalette[72][3] = {
 #include "delta_palette.inc"
 };
@@ -813,6 +840,21 @@ void launch_rct(hipStream_t s, int32_t* p0, int32_t* p1, int32_t* p2, size_t n, 
     case 4: hipLaunchKernelGGL(k4_rct<4>, dim3(grid), dim3(256), 0, s, p0, p1, p2, n, perm, nvec); break;
     case 5: hipLaunchKernelGGL(k4_rct<5>, dim3(grid), dim3(256), 0, s, p0, p1, p2, n, perm, nvec); break;
     default: hipLaunchKernelGGL(k4_rct<6>, dim3(grid), dim3(256), 0, s, p0, p1, p2, n, perm, nvec); break;
+  }
+}
+
+void launch_rct_rows(hipStream_t s, int32_t* p0, int32_t* p1, int32_t* p2, uint32_t w, uint32_t h, size_t stride, int op,
+                     int perm) {
+  if (w == 0 || h == 0) return;
+  const dim3 grid(min(64u, (w + 255) / 256), min(h, 16384u));  // ONE launch whatever the row count
+  switch (op) {
+    case 0: hipLaunchKernelGGL(k4_rct_rows<0>, grid, dim3(256), 0, s, p0, p1, p2, w, h, stride, perm); break;
+    case 1: hipLaunchKernelGGL(k4_rct_rows<1>, grid, dim3(256), 0, s, p0, p1, p2, w, h, stride, perm); break;
+    case 2: hipLaunchKernelGGL(k4_rct_rows<2>, grid, dim3(256), 0, s, p0, p1, p2, w, h, stride, perm); break;
+    case 3: hipLaunchKernelGGL(k4_rct_rows<3>, grid, dim3(256), 0, s, p0, p1, p2, w, h, stride, perm); break;
+    case 4: hipLaunchKernelGGL(k4_rct_rows<4>, grid, dim3(256), 0, s, p0, p1, p2, w, h, stride, perm); break;
+    case 5: hipLaunchKernelGGL(k4_rct_rows<5>, grid, dim3(256), 0, s, p0, p1, p2, w, h, stride, perm); break;
+    default: hipLaunchKernelGGL(k4_rct_rows<6>, grid, dim3(256), 0, s, p0, p1, p2, w, h, stride, perm); break;
   }
 }
 

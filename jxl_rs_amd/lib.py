@@ -271,27 +271,39 @@ class DeviceArray:
             cls._hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
             cls._hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
             cls._hip.hipFree.argtypes = [C.c_void_p]
+            cls._hip.hipSetDevice.argtypes = [C.c_int]
         return cls._hip
 
-    def __init__(self, array=None, nbytes=None):
+    @classmethod
+    def _chk(cls, rc, what):
+        # explicit checks, not asserts: under `python -O` an assert (and the HIP call inside it) would vanish
+        if rc != 0:
+            raise JxlHipError(ERR_DEVICE, what, f"hip error {rc}")
+
+    def __init__(self, array=None, nbytes=None, device=None):
+        """device: HIP device ordinal the buffer lives on (default: the calling thread's current device -- device 0
+        unless something set another one; pass the Context's ordinal on multi-GPU hosts)"""
         import ctypes as C
         self.nbytes = array.nbytes if array is not None else nbytes
+        self.ptr = 0
+        if device is not None:
+            self._chk(self.hip().hipSetDevice(int(device)), "hipSetDevice")
         p = C.c_void_p()
-        assert self.hip().hipMalloc(C.byref(p), max(self.nbytes, 16)) == 0
+        self._chk(self.hip().hipMalloc(C.byref(p), max(self.nbytes, 16)), "hipMalloc")
         self.ptr = p.value
         if array is not None:
             a = np.ascontiguousarray(array)
-            assert self.hip().hipMemcpy(self.ptr, a.ctypes.data, a.nbytes, 1) == 0  # hipMemcpyHostToDevice
+            self._chk(self.hip().hipMemcpy(self.ptr, a.ctypes.data, a.nbytes, 1), "hipMemcpy H2D")
         else:
-            assert self.hip().hipMemset(self.ptr, 0, self.nbytes) == 0
+            self._chk(self.hip().hipMemset(self.ptr, 0, self.nbytes), "hipMemset")
 
     def upload(self, array, byte_offset=0):
         a = np.ascontiguousarray(array)
-        assert self.hip().hipMemcpy(self.ptr + byte_offset, a.ctypes.data, a.nbytes, 1) == 0
+        self._chk(self.hip().hipMemcpy(self.ptr + byte_offset, a.ctypes.data, a.nbytes, 1), "hipMemcpy H2D")
 
     def download(self, dtype, count, byte_offset=0):
         out = np.empty(count, dtype=dtype)
-        assert self.hip().hipMemcpy(out.ctypes.data, self.ptr + byte_offset, out.nbytes, 2) == 0  # DeviceToHost
+        self._chk(self.hip().hipMemcpy(out.ctypes.data, self.ptr + byte_offset, out.nbytes, 2), "hipMemcpy D2H")
         return out
 
     def free(self):
@@ -310,6 +322,7 @@ class Context:
 
     def __init__(self, device=0, n_slots=1):
         self.L = load()
+        self.device = int(device)
         self._ctx = C.c_void_p()
         st = self.L.jxlh_ctx_create(device, n_slots, C.byref(self._ctx))
         if st != OK:

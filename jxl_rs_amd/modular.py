@@ -25,9 +25,9 @@ class ModularChain:
         self.padded = self.share * world
         self.base, self.residuals, self.steps = planes if planes is not None else synth.make_modular_planes(w, h, seed=seed)
         self.base_h, self.base_w = self.base[0].shape
-        self.d_base = [DeviceArray(b) for b in self.base]
-        self.d_res = [[DeviceArray(r) if r.size else None for r in lvl] for lvl in self.residuals]
-        self.d_out = [DeviceArray(nbytes=max(w * h, self.padded) * 4) for _ in range(3)]
+        self.d_base = [DeviceArray(b, device=ctx.device) for b in self.base]
+        self.d_res = [[DeviceArray(r, device=ctx.device) if r.size else None for r in lvl] for lvl in self.residuals]
+        self.d_out = [DeviceArray(nbytes=max(w * h, self.padded) * 4, device=ctx.device) for _ in range(3)]
         self.palette = palette
         self.d_idx = self.d_pal = self.d_pout = None
         self.levels = []
@@ -53,8 +53,8 @@ class ModularChain:
             self.palette = (rng.integers(-3, 300, size=(self.h, self.w)).astype(np.int32),
                             rng.integers(0, 256, size=(3, 256)).astype(np.int32))
         idx, pal = self.palette
-        self.d_idx, self.d_pal = DeviceArray(idx), DeviceArray(pal)
-        self.d_pout = DeviceArray(nbytes=3 * self.padded * 4)
+        self.d_idx, self.d_pal = DeviceArray(idx, device=ctx.device), DeviceArray(pal, device=ctx.device)
+        self.d_pout = DeviceArray(nbytes=3 * self.padded * 4, device=ctx.device)
 
     def run_local_shares(self, rank):
         """this rank's part before the joins: replicated chain (no RCT), RCT + palette on the own sample share"""

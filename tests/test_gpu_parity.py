@@ -818,6 +818,39 @@ def test_fused_unsqueeze_and_rct(ctx, oracle, shape, op_perm, horizontal, pad):
             x.free()
 
 
+@pytest.mark.parametrize("horizontal", [True, False])
+def test_unsqueeze_rct_separate_passes_on_padded_planes(ctx, oracle, horizontal, monkeypatch):
+    """the route planes of 2^31 samples and more take (unsqueeze, then the RCT as ONE strided launch: it used to be one
+    launch per row), forced by JXLH_SEPARATE_RCT=1, on padded rows whose sentinel padding must survive"""
+    from helpers import DeviceArray
+    monkeypatch.setenv("JXLH_SEPARATE_RCT", "1")
+    lines, n, op, perm = 37, 101, 6, 1
+    rng = np.random.default_rng(99 + horizontal)
+    na, nr = (n + 1) // 2, n // 2
+    host = []
+    for c in range(3):
+        a = rng.integers(-3000, 3000, size=(lines, na)).astype(np.int32)
+        r = np.round(rng.laplace(0, 40, size=(lines, nr))).astype(np.int32)
+        if not horizontal:
+            a, r = np.ascontiguousarray(a.T), np.ascontiguousarray(r.T)
+        host.append((a, r))
+    ow, oh = (n, lines) if horizontal else (lines, n)
+    o_stride = ow + 7
+    dev = [(DeviceArray(a), DeviceArray(r), DeviceArray(np.full((oh, o_stride), -55, np.int32))) for a, r in host]
+    ctx.unsqueeze_rct(horizontal, [d[0].ptr for d in dev], [d[1].ptr for d in dev], [d[2].ptr for d in dev], ow, oh,
+                      host[0][0].shape[1], host[0][1].shape[1], o_stride, op, perm)
+    ctx.sync()
+    unsq = [oracle.unsqueeze_h(a, r, ow) if horizontal else oracle.unsqueeze_v(a, r, oh) for a, r in host]
+    want = oracle.rct(unsq, op, perm)
+    for c in range(3):
+        got = dev[c][2].download(np.int32, oh * o_stride).reshape(oh, o_stride)
+        assert np.array_equal(got[:, :ow], want[c].reshape(oh, ow)), c
+        assert (got[:, ow:] == -55).all()
+    for d in dev:
+        for x in d:
+            x.free()
+
+
 def test_unsqueeze_rejects_dimensions_whose_product_wraps(ctx):
     """65536 x 65536: `res_w * res_h` used to be formed in 32 bits, wrapped to 0 and skipped the null / stride /
     device-pointer checks on the residual plane"""
