@@ -69,8 +69,16 @@ def time_vardct_config(jxl_rs_amd, synth, np, device, size, mix, epf_iters, seed
     sides) + the per-kernel HIP-event table with every kernel against its own algorithmic bytes.  extra_epf: also
     time the same frame with that epf_iters (new frame epoch, coefficients re-submitted)."""
     t0 = time.time()
-    wl = synth.make_vardct(size, size, mix=mix, seed=seed, unique_groups=24 if size <= 8192 else 32,
-                           epf_iters=epf_iters, gab=True, lf_smoothing=True)
+    # every transform type of the mix must be in the frame (BASELINE configs[4] names DCT256X256; with 32 distinct
+    # group tilings a 4 %-of-area type can miss the draw): further seeds until it is, and say which seed it was
+    want_types = set(mix.keys())
+    for used_seed in range(seed, seed + 40):
+        wl = synth.make_vardct(size, size, mix=mix, seed=used_seed, unique_groups=24 if size <= 8192 else 32,
+                               epf_iters=epf_iters, gab=True, lf_smoothing=True)
+        have = set(np.unique(wl.transform_map[wl.transform_map >= 128] & 127).tolist())
+        if want_types <= have:
+            break
+    assert want_types <= have, f"types {sorted(want_types - have)} missing from the synthetic frame"
     gen_s = time.time() - t0
     ctx = jxl_rs_amd.Context(device, n_slots=1)
     npx = size * size
@@ -118,7 +126,7 @@ def time_vardct_config(jxl_rs_amd, synth, np, device, size, mix, epf_iters, seed
 
     types = sorted(set(np.unique(wl.transform_map[wl.transform_map >= 128] & 127).tolist()))
     out = {"workload": f"{size}x{size} VarDCT, {len(types)} transform types present, CfL, LF smoothing, Gaborish, "
-                       f"EPF iters={epf_iters}, inputs HBM-resident", "transform_types": types,
+                       f"EPF iters={epf_iters}, inputs HBM-resident", "transform_types": types, "seed": used_seed,
            "host_generate_s": round(gen_s, 2)}
     out.update(measure(epf_iters))
     if extra_epf is not None:
@@ -247,8 +255,12 @@ def main():
                     help="skip the all-blocks-filtered EPF population (profiling runs: one population per kernel name)")
     ap.add_argument("--no-e2e", action="store_true",
                     help="skip the PCIe-inclusive legs (pinned host coefficients -> finished planes)")
+    ap.add_argument("--no-strip", action="store_true", help="skip the strip-kernel A/B block (roofline.strip_kernel)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the `secondary` block (BASELINE configs 2, 4 and 5, one frame in flight each)")
+    ap.add_argument("--reps", type=int, default=5,
+                    help="repetitions of the timed region of K steps: `value` / `ms_per_step` are the MEDIAN repetition, "
+                         "min and max are reported beside it (boxes and runs differ by several per cent)")
     ap.add_argument("--seed", type=int, default=3)
     ap.add_argument("--inflight", type=int, default=2,
                     help="frames in flight per GPU (contexts with their own stream and buffers, used round-robin)")
@@ -332,23 +344,31 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    # ---- weak leg (N = 1: THE measurement): K steps of whole frames, one frame per rank
+    # ---- weak leg (N = 1: THE measurement): K steps of whole frames, one frame per rank; the timed region is
+    # repeated --reps times (barrier + synchronize on both sides of each, max over ranks of each) and the MEDIAN
+    # repetition is what `value` / `ms_per_step` report
     for _ in range(args.warmup):
         step()
     sync_all()
-    barrier()
-    t_wall0 = time.perf_counter()
-    ctx.timer_start()
-    for _ in range(args.steps):
-        step()
-    ev_ms = ctx.timer_stop()
-    sync_all()
-    if torch.cuda.is_available():
-        torch.cuda.synchronize()
-    wall_s = time.perf_counter() - t_wall0
-    barrier()
-    wall_s = max_over_ranks(wall_s)
-    ms_per_step = wall_s * 1e3 / args.steps
+    rep_ms, rep_ev = [], []
+    for _ in range(max(1, args.reps)):
+        barrier()
+        t_wall0 = time.perf_counter()
+        ctx.timer_start()
+        for _ in range(args.steps):
+            step()
+        ev = ctx.timer_stop()
+        sync_all()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        wall_s = time.perf_counter() - t_wall0
+        barrier()
+        rep_ms.append(max_over_ranks(wall_s) * 1e3 / args.steps)
+        rep_ev.append(ev)
+    order = sorted(range(len(rep_ms)), key=lambda i: rep_ms[i])
+    mid = order[(len(order) - 1) // 2]
+    ms_per_step = rep_ms[mid]
+    ev_ms = rep_ev[mid]
     value = size * size * n_gpus / 1e6 / (ms_per_step / 1e3)
 
     # ---- strong leg (N > 1): one frame sharded by bands of group rows, halo exchange + all-gather in the timed region
@@ -535,6 +555,69 @@ def main():
             ctx.sync()
             active = {k: ak[k] for k in ak if k in ALGO_BYTES_PER_PX}
             active["sum_of_kernels_ms"] = round(sum(v["ms_per_step"] for v in ak.values()), 4)
+        # ... and the population in between: a random half of the blocks filtered (real d1 content lies between the spec
+        # draw and every-block-filtered)
+        half = None
+        if args.epf == "spec" and args.epf_iters > 0 and not args.no_active:
+            pick = np.random.default_rng(args.seed + 50).random(wl.epf_map.shape) < 0.5
+            ctx.set_hf_meta(wl.transform_map, np.where(pick, np.minimum(wl.raw_quant, 4), wl.raw_quant),
+                            np.where(pick, 7, 0).astype(wl.epf_map.dtype), wl.ytox, wl.ytob)
+            hk = kernel_table()
+            ctx.set_hf_meta(wl.transform_map, wl.raw_quant, wl.epf_map, wl.ytox, wl.ytob)
+            ctx.frame_run(0, ygroups)
+            ctx.sync()
+            half = {k: hk[k] for k in hk if k in ALGO_BYTES_PER_PX}
+            half["sum_of_kernels_ms"] = round(sum(v["ms_per_step"] for v in hk.values()), 4)
+            half["blocks_filtered"] = round(float(pick.mean()), 3)
+        # ---- the strip kernel (JXLH_FRAME_STRIP, k_strip.hip): the whole chain as ONE persistent launch with no
+        # intermediate planes in HBM, on this frame (whatever its tilings let the strip kernel transform itself) and on
+        # the same workload with every varblock aligned to its own size (SURVEY 8(d)'s tiling law, what libjxl's encoder
+        # emits: every tile is the strip kernel's).  Opt-in, bit-identical, and SLOWER than the two-kernel path on MI355X
+        # today (both forms are bound by instruction issue): reported, never `value`.
+        strip = None
+        if not args.no_strip and args.epf_iters <= 2:
+            from jxl_rs_amd import lib as jl
+            strip = {}
+            for tag, swl in (("this_frame", wl), ("aligned_tilings", None)):
+                try:
+                    if swl is None:
+                        swl = synth.make_vardct(size, size, mix=mix, seed=args.seed, unique_groups=24,
+                                                epf_iters=args.epf_iters, gab=True, lf_smoothing=True, aligned=True)
+                        if args.epf == "active":
+                            swl.epf_map[:] = 7
+                            swl.raw_quant[:] = np.minimum(swl.raw_quant, 4)
+                    res = {}
+                    planes_of = {}
+                    for name, flags in (("two_kernels", 0), ("strip", jl.FRAME_STRIP)):
+                        sc = jxl_rs_amd.Context(local_rank, n_slots=1)
+                        sp = synth.apply_opts(sc.default_params(size, size), swl)
+                        sp.flags = flags
+                        sc.frame_begin(sp)
+                        sc.set_dequant_tables(swl.tables)
+                        sc.set_lf_quantized(*swl.lf_q)
+                        sc.set_hf_meta(swl.transform_map, swl.raw_quant, swl.epf_map, swl.ytox, swl.ytob)
+                        for g in range(swl.coeffs.shape[0]):
+                            sc.submit_group(g, swl.coeffs[g])
+                        sc.slot_wait(0)
+                        for _ in range(3):
+                            sc.frame_run()
+                        sc.sync()
+                        t0 = time.perf_counter()
+                        n = max(5, min(args.steps, 20))
+                        for _ in range(n):
+                            sc.frame_run()
+                        sc.sync()
+                        res[name] = {"ms_per_frame": round((time.perf_counter() - t0) * 1e3 / n, 4), "frames_in_flight": 1}
+                        if name == "strip":
+                            ran, tiles, by_class = sc.frame_path()
+                            res[name].update({"strip_kernel_ran": ran, "tiles": tiles, "tiles_left_to_class_kernels": by_class})
+                        planes_of[name] = [int(np.sum(pl.view(np.uint32), dtype=np.uint64)) for pl in sc.read_planes()]
+                        sc.close()
+                    res["bit_identical_checksums"] = planes_of["two_kernels"] == planes_of["strip"]
+                    strip[tag] = res
+                except Exception as e:
+                    strip[tag] = {"error": f"{type(e).__name__}: {e}"}
+            strip["counters"] = "profiles/r04_a_strip_pmc_aligned.txt, r04_a_strip_ablation.txt"
         cand = {k: v for k, v in kernels.items() if k in ALGO_BYTES_PER_PX}
         if cand:
             dom = max(cand, key=lambda k: cand[k]["ms_per_step"])
@@ -556,7 +639,8 @@ def main():
                             "frac": round(ideal / (chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                             "ms_per_step_pipelined": round(ms_per_step, 4),
                             "frac_pipelined": round(ideal / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
-                        "epf_population_all_active": active}
+                        "epf_population_all_active": active, "epf_population_half_active": half,
+                        "strip_kernel": strip}
         # ---- measured copy ceilings: a float4 read+write kernel, frame-sized (one plane set in, one
         # out: the traffic shape of K1 and of the filters) and Infinity-Cache-resident
         if roofline is not None:
@@ -807,6 +891,11 @@ def main():
                        "frames_in_flight_per_gpu": max(1, args.inflight), "epf_population": args.epf},
             "strong_scaling": strong, "strong_scaling_modular": strong_modular,
             "hip_event_ms_per_step_rank0": round(ev_ms / args.steps, 4),
+            "repetitions": {"n": len(rep_ms), "of_steps": args.steps, "reported": "median",
+                            "ms_per_step": [round(v, 4) for v in rep_ms], "min_ms_per_step": round(min(rep_ms), 4),
+                            "max_ms_per_step": round(max(rep_ms), 4),
+                            "value_at_min_ms": round(size * size * n_gpus / 1e6 / (min(rep_ms) / 1e3), 1),
+                            "value_at_max_ms": round(size * size * n_gpus / 1e6 / (max(rep_ms) / 1e3), 1)},
             "setup": {"host_generate_s": round(gen_s, 2), "h2d_coeffs_s": round(h2d_s, 2)},
             "roofline": roofline, "cpu_baseline": cpu, "e2e_pcie_inclusive": e2e, "secondary": secondary,
         }
