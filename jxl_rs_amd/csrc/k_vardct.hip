@@ -399,7 +399,12 @@ __device__ __forceinline__ int run_dct_class(const FrameDev& f, const WorkItem* 
             qv[c][j] = gload_i4<JXLH_NT_COEF>(f.coeffs + binfo[b].coef_off + c * kGroupArea + k);
         }
     }
-    float dy[S::E];
+    // The dequantised Y the X / B channels' chroma-from-luma needs: kept in registers across the channels -- except for
+    // the shape with 32 of them per lane (32x32, dense input), where they would sit through two 32-point IDCTs
+    // (167 VGPRs + 16 spilled + 68 bytes of scratch for that class alone): there X and B dequantise their Y values again
+    // (the coefficient read hits L2, the table-driven dequantisation is ~10 instructions per value).
+    constexpr bool kRecomputeY = !SPARSE && !PREFETCH && S::E > 16;
+    float dy[kRecomputeY ? 4 : S::E];
     auto run_channel = [&](auto ch_tag) {
       constexpr int CH = decltype(ch_tag)::value;
       if constexpr (SPARSE) sparse_stage_channel<S>(f, CH, buf, lane, sl);
@@ -408,7 +413,15 @@ __device__ __forceinline__ int run_dct_class(const FrameDev& f, const WorkItem* 
         const int fl = (j * 64 + lane) * 4;
         const int b = fl / S::N, k = fl % S::N;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        float d4[4] = {dy[j * 4], dy[j * 4 + 1], dy[j * 4 + 2], dy[j * 4 + 3]};
+        float d4[4];
+        if constexpr (kRecomputeY) {
+          d4[0] = d4[1] = d4[2] = d4[3] = 0.0f;
+        } else {
+          d4[0] = dy[j * 4];
+          d4[1] = dy[j * 4 + 1];
+          d4[2] = dy[j * 4 + 2];
+          d4[3] = dy[j * 4 + 3];
+        }
         if (b < nb) {
           const BlockInfo bi = binfo[b];
           int4 qq;
@@ -423,10 +436,15 @@ __device__ __forceinline__ int run_dct_class(const FrameDev& f, const WorkItem* 
           } else {
             qq = gload_i4<JXLH_NT_COEF>(f.coeffs + bi.coef_off + CH * kGroupArea + k);
             tt = *reinterpret_cast<const float4*>(table + CH * tsize + k);
+            if constexpr (kRecomputeY && CH != 1) {
+              const int4 qy = gload_i4<false>(f.coeffs + bi.coef_off + kGroupArea + k);
+              const float4 ty = *reinterpret_cast<const float4*>(table + tsize + k);
+              (void)dequant4t<1>(f, qy, ty, bi, adj, d4);
+            }
           }
           v = dequant4t<CH>(f, qq, tt, bi, adj, d4);
         }
-        if constexpr (CH == 1) {
+        if constexpr (CH == 1 && !kRecomputeY) {
           dy[j * 4] = d4[0];
           dy[j * 4 + 1] = d4[1];
           dy[j * 4 + 2] = d4[2];
