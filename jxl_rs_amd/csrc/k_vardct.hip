@@ -579,6 +579,8 @@ __global__ __launch_bounds__(kSpecThreads) void k1_special(const FrameDev f, con
   __shared__ float s_tile[kSpecWaves][64 * kSpecPitch];
   __shared__ BlockInfo s_binfo[kSpecWaves][kSpecBlk];
   __shared__ int s_idx[kSpecWaves][kSpecChunk];
+  __shared__ AdjTable s_adj;
+  build_adj_table(f, &s_adj, threadIdx.x, kSpecThreads);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const WorkItem* __restrict__ items = wl.items[kClsSpecial];
   const int count = wl.counts[(kClsSpecial) * kCountPitch];
@@ -644,7 +646,7 @@ __global__ __launch_bounds__(kSpecThreads) void k1_special(const FrameDev f, con
           bi.sdy = b_sdy[j];
           bi.x_cc = b_xcc[j];
           bi.b_cc = b_bcc[j];
-          const float4 v = dequant4<CH>(f, qv[j], tv, bi, d4);
+          const float4 v = dequant4t<CH>(f, qv[j], tv, bi, &s_adj, d4);
           if constexpr (CH == 1) {
             dy[j * 4] = d4[0];
             dy[j * 4 + 1] = d4[1];
