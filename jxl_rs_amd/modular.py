@@ -53,8 +53,8 @@ class ModularChain:
             self.palette = (rng.integers(-3, 300, size=(self.h, self.w)).astype(np.int32),
                             rng.integers(0, 256, size=(3, 256)).astype(np.int32))
         idx, pal = self.palette
-        self.d_idx, self.d_pal = DeviceArray(idx, device=ctx.device), DeviceArray(pal, device=ctx.device)
-        self.d_pout = DeviceArray(nbytes=3 * self.padded * 4, device=ctx.device)
+        self.d_idx, self.d_pal = DeviceArray(idx, device=self.ctx.device), DeviceArray(pal, device=self.ctx.device)
+        self.d_pout = DeviceArray(nbytes=3 * self.padded * 4, device=self.ctx.device)
 
     def run_local_shares(self, rank):
         """this rank's part before the joins: replicated chain (no RCT), RCT + palette on the own sample share"""
