@@ -247,6 +247,29 @@ jxlh_status jxlh_submit_groups_sparse(jxlh_ctx* ctx, int32_t slot, uint32_t coun
 jxlh_status jxlh_submit_groups_sparse8(jxlh_ctx* ctx, int32_t slot, uint32_t count, const uint32_t* group_ids,
                                        const uint16_t* pos, const int8_t* val, const uint32_t* n,
                                        const jxlh_coeff32* wide, uint32_t n_wide, uint32_t flags);
+/* The same with 2 bytes per update on the bus (round 4): a channel's 65536 coefficient positions are cut into 16
+ * SEGMENTS of 4096; an update is one u16 = (position inside its segment) | (value & 15) << 12 with the value in
+ * [-8, 7] (two's complement nibble), and seg_counts[(i * 3 + c) * 16 + s] says how many entries group i, channel c,
+ * segment s has; `entries` holds them in that order (group, channel, segment), any order inside a segment.  What a
+ * decoder does at `coeffs[idx] += coeff` (frame/group.rs:572): append (idx & 4095) | coeff << 12 to the bucket of
+ * idx >> 12.  Updates whose value does not fit the nibble go to the 3-byte overflow arrays pos8 / val8 (positions
+ * inside the channel slab as in jxlh_submit_groups_sparse8; n8 is count x 3, may be NULL when there is none), values
+ * beyond 8 bits to `wide`.  Every update is an addition into the group's slab, so the split changes nothing. */
+jxlh_status jxlh_submit_groups_sparse4(jxlh_ctx* ctx, int32_t slot, uint32_t count, const uint32_t* group_ids,
+                                       const uint16_t* entries, const uint16_t* seg_counts, const uint16_t* pos8,
+                                       const int8_t* val8, const uint32_t* n8, const jxlh_coeff32* wide,
+                                       uint32_t n_wide, uint32_t flags);
+/* Slot-bucketed form (round 4): 2 bytes per update AND no device-side sort.  A channel's 65536 positions are 1024
+ * SLOTS of 64 coefficients (the unit varblock coefficient offsets are counted in, frame/group.rs:612: an 8x8 block is
+ * one slot, a 16x16 varblock four); an update is one u16 = (position & 63) | (value & 1023) << 6 with the value in
+ * [-512, 511]; slot_counts[(i * 3 + c) * 1024 + s] (u8) says how many updates group i, channel c, slot s has and
+ * `entries` holds them in that order, any order inside a slot; n[3 * i + c] = the channel's total.  A decoder appends
+ * to the slot buckets of the varblock it is decoding and flushes them when the varblock ends.  When EVERY group of the
+ * frame arrives in this form, jxlh_frame_run finds the pairs already bucketed the way the transforms read them and
+ * skips the sort; values outside 10 bits go to `wide` (and take the dense route like any wide entry). */
+jxlh_status jxlh_submit_groups_slots(jxlh_ctx* ctx, int32_t slot, uint32_t count, const uint32_t* group_ids,
+                                     const uint16_t* entries, const uint8_t* slot_counts, const uint32_t* n,
+                                     const jxlh_coeff32* wide, uint32_t n_wide, uint32_t flags);
 jxlh_status jxlh_slot_wait(jxlh_ctx* ctx, int32_t slot);
 
 /* Device-resident coefficient store of the current frame (ngroups * 3 * 65536 i32), for callers

@@ -1,6 +1,7 @@
 // C ABI, coefficient transport: dense group slabs (jxlh_submit_group) and the sparse (position, value) forms
 //  -- asynchronous H2D on the caller's slot stream, multi-pass accumulation.
 #include <algorithm>
+#include <vector>
 
 #include "jxlh_ctx.h"
 
@@ -136,6 +137,137 @@ jxlh_status jxlh_submit_groups_sparse8(jxlh_ctx* ctx, int32_t slot, uint32_t cou
     HIPCHK(ctx, hipMemcpyAsync(s.stage8 + pos_bytes, val, total, hipMemcpyDefault, s.stream));
     launch_pack_pairs8(s.stream, reinterpret_cast<const uint16_t*>(s.stage8),
                        reinterpret_cast<const int8_t*>(s.stage8 + pos_bytes), total, ctx->sp_pairs.p + offset);
+    HIPCHK(ctx, hipGetLastError());
+  }
+  HIPCHK(ctx, hipEventRecord(s.done, s.stream));
+  s.used = true;
+  return JXLH_OK;
+}
+
+// 2 bytes per coefficient update on the bus: u16 entries = position inside a 4096-coefficient segment | value nibble,
+// per-segment counts, and a 3-byte overflow list for the values the nibble does not hold; widened into the pair
+// buffer by one workgroup per (group, channel) on the slot's stream
+jxlh_status jxlh_submit_groups_sparse4(jxlh_ctx* ctx, int32_t slot, uint32_t count, const uint32_t* group_ids,
+                                       const uint16_t* entries, const uint16_t* seg_counts, const uint16_t* pos8,
+                                       const int8_t* val8, const uint32_t* n8, const jxlh_coeff32* wide,
+                                       uint32_t n_wide, uint32_t flags) {
+  JXLH_ON_DEVICE(ctx);
+  if (count == 0 && ctx && ctx->in_frame) return JXLH_OK;
+  if (!ctx || !seg_counts) return JXLH_ERR_INVALID_ARGUMENT;
+  // per (group, channel): entries of the 2-byte form, overflow updates; their sum is what the pair buffer receives
+  const size_t runs = (size_t)count * 3;
+  std::vector<uint32_t> n(runs), desc(4 * runs);
+  size_t tot4 = 0, tot8 = 0;
+  for (size_t r = 0; r < runs; r++) {
+    uint32_t n4 = 0;
+    for (int sgm = 0; sgm < 16; sgm++) n4 += seg_counts[r * 16 + sgm];
+    const uint32_t no = n8 ? n8[r] : 0u;
+    if (n4 > (uint32_t)kGroupArea || no > (uint32_t)kGroupArea) return JXLH_ERR_INVALID_ARGUMENT;
+    desc[4 * r] = (uint32_t)tot4;
+    desc[4 * r + 1] = (uint32_t)tot8;
+    desc[4 * r + 2] = no;
+    n[r] = n4 + no;
+    tot4 += n4;
+    tot8 += no;
+  }
+  if ((tot4 && !entries) || (tot8 && (!pos8 || !val8))) return JXLH_ERR_INVALID_ARGUMENT;
+  size_t offset = 0, total = 0;
+  if (jxlh_status st = sparse_reserve(ctx, slot, count, group_ids, n.data(), wide, n_wide, flags, &offset, &total)) return st;
+  {
+    size_t o = 0;
+    for (size_t r = 0; r < runs; r++) {
+      desc[4 * r + 3] = (uint32_t)o;  // relative to the batch's first pair
+      o += n[r];
+    }
+  }
+  Slot& s = ctx->slots[slot];
+  if (ctx->sp_expanded_valid) HIPCHK(ctx, hipStreamWaitEvent(s.stream, ctx->sp_expanded, 0));
+  if (total) {
+    // staging: [entries | seg counts | overflow positions | overflow values | run descriptors], reused by the slot
+    auto up = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    const size_t b_ent = up(tot4 * 2), b_cnt = up(runs * 16 * 2), b_pos = up(tot8 * 2), b_val = up(tot8), b_desc = up(runs * 16);
+    const size_t need = b_ent + b_cnt + b_pos + b_val + b_desc;
+    if (s.stage8_cap < need) {
+      HIPCHK(ctx, hipStreamSynchronize(s.stream));  // the old staging may still be read by a queued kernel
+      if (s.stage8) (void)hipFree(s.stage8);
+      s.stage8 = nullptr;
+      s.stage8_cap = 0;
+      const size_t cap = need * 5 / 4 + 4096;
+      if (hipMalloc(reinterpret_cast<void**>(&s.stage8), cap) != hipSuccess) return JXLH_ERR_OUT_OF_MEMORY;
+      s.stage8_cap = cap;
+    }
+    uint8_t* d_ent = s.stage8, *d_cnt = d_ent + b_ent, *d_pos = d_cnt + b_cnt, *d_val = d_pos + b_pos, *d_desc = d_val + b_val;
+    if (tot4) HIPCHK(ctx, hipMemcpyAsync(d_ent, entries, tot4 * 2, hipMemcpyDefault, s.stream));
+    HIPCHK(ctx, hipMemcpyAsync(d_cnt, seg_counts, runs * 16 * 2, hipMemcpyDefault, s.stream));
+    if (tot8) {
+      HIPCHK(ctx, hipMemcpyAsync(d_pos, pos8, tot8 * 2, hipMemcpyDefault, s.stream));
+      HIPCHK(ctx, hipMemcpyAsync(d_val, val8, tot8, hipMemcpyDefault, s.stream));
+    }
+    // the descriptors are built here: a pageable source is staged by the runtime before the call returns
+    HIPCHK(ctx, hipMemcpyAsync(d_desc, desc.data(), runs * 16, hipMemcpyHostToDevice, s.stream));
+    launch_pack_pairs4(s.stream, reinterpret_cast<const uint16_t*>(d_ent), reinterpret_cast<const uint16_t*>(d_cnt),
+                       reinterpret_cast<const uint16_t*>(d_pos), reinterpret_cast<const int8_t*>(d_val),
+                       reinterpret_cast<const uint32_t*>(d_desc), (int)runs, ctx->sp_pairs.p + offset);
+    HIPCHK(ctx, hipGetLastError());
+  }
+  HIPCHK(ctx, hipEventRecord(s.done, s.stream));
+  s.used = true;
+  return JXLH_OK;
+}
+
+// slot-bucketed form: pair words written in slot order + the slot tables, by one workgroup per (group, channel) on the
+// slot's stream; a frame that arrives entirely in this form is not sorted (run_prologue)
+jxlh_status jxlh_submit_groups_slots(jxlh_ctx* ctx, int32_t slot, uint32_t count, const uint32_t* group_ids,
+                                     const uint16_t* entries, const uint8_t* slot_counts, const uint32_t* n,
+                                     const jxlh_coeff32* wide, uint32_t n_wide, uint32_t flags) {
+  JXLH_ON_DEVICE(ctx);
+  if (count == 0 && ctx && ctx->in_frame) return JXLH_OK;
+  if (!ctx || !slot_counts || !n) return JXLH_ERR_INVALID_ARGUMENT;
+  size_t offset = 0, total = 0;
+  if (jxlh_status st = sparse_reserve(ctx, slot, count, group_ids, n, wide, n_wide, flags, &offset, &total)) return st;
+  if (total && !entries) return JXLH_ERR_INVALID_ARGUMENT;
+  const size_t runs = (size_t)count * 3;
+  std::vector<uint32_t> desc(4 * runs);
+  {
+    size_t o = 0;
+    for (size_t r = 0; r < runs; r++) {
+      desc[4 * r] = (uint32_t)o;
+      desc[4 * r + 1] = n[r];
+      desc[4 * r + 2] = (uint32_t)(offset + o);
+      desc[4 * r + 3] = group_ids[r / 3] * 3 + (uint32_t)(r % 3);
+      o += n[r];
+    }
+  }
+  {
+    std::lock_guard<std::mutex> lock(ctx->sp_mutex);
+    if (jxlh_status st = ensure(ctx, ctx->sp_slot_start, ctx->ngroups * 3 * (size_t)kSlotTable)) return st;
+    if (ctx->bucketed.size() != ctx->ngroups) ctx->bucketed.assign(ctx->ngroups, 0);
+    for (uint32_t i = 0; i < count; i++) ctx->bucketed[group_ids[i]] = (flags & JXLH_GROUP_ACCUMULATE) ? 0 : 1;
+  }
+  Slot& s = ctx->slots[slot];
+  if (ctx->sp_expanded_valid) HIPCHK(ctx, hipStreamWaitEvent(s.stream, ctx->sp_expanded, 0));
+  // the slot tables of the previous frame may still be read by its transforms
+  if (ctx->k1_done_valid) HIPCHK(ctx, hipStreamWaitEvent(s.stream, ctx->k1_done, 0));
+  {
+    // staging: [entries | slot counts | run descriptors], reused by the slot (stream-ordered)
+    auto up = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    const size_t b_ent = up(total * 2), b_cnt = up(runs * 1024), b_desc = up(runs * 16);
+    const size_t need = b_ent + b_cnt + b_desc;
+    if (s.stage8_cap < need) {
+      HIPCHK(ctx, hipStreamSynchronize(s.stream));
+      if (s.stage8) (void)hipFree(s.stage8);
+      s.stage8 = nullptr;
+      s.stage8_cap = 0;
+      const size_t cap = need * 5 / 4 + 4096;
+      if (hipMalloc(reinterpret_cast<void**>(&s.stage8), cap) != hipSuccess) return JXLH_ERR_OUT_OF_MEMORY;
+      s.stage8_cap = cap;
+    }
+    uint8_t* d_ent = s.stage8, *d_cnt = d_ent + b_ent, *d_desc = d_cnt + b_cnt;
+    if (total) HIPCHK(ctx, hipMemcpyAsync(d_ent, entries, total * 2, hipMemcpyDefault, s.stream));
+    HIPCHK(ctx, hipMemcpyAsync(d_cnt, slot_counts, runs * 1024, hipMemcpyDefault, s.stream));
+    HIPCHK(ctx, hipMemcpyAsync(d_desc, desc.data(), runs * 16, hipMemcpyHostToDevice, s.stream));
+    launch_pack_slots(s.stream, reinterpret_cast<const uint16_t*>(d_ent), d_cnt, reinterpret_cast<const uint32_t*>(d_desc),
+                      (int)runs, ctx->sp_pairs.p, ctx->sp_slot_start.p);
     HIPCHK(ctx, hipGetLastError());
   }
   HIPCHK(ctx, hipEventRecord(s.done, s.stream));

@@ -244,6 +244,7 @@ jxlh_status jxlh_frame_begin(jxlh_ctx* ctx, const jxlh_frame_params* p) {
     ctx->sp_wide.clear();
     ctx->sp_used = 0;
     ctx->touched.assign(ctx->ngroups, 0);
+    ctx->bucketed.assign(ctx->ngroups, 0);
     ctx->epoch_dirty = false;
     ctx->sp_sorted_valid = false;
   }
@@ -614,13 +615,23 @@ jxlh_status run_prologue(jxlh_ctx* ctx, RunPlan* plan) {
                                (int)ctx->ngroups);
         }
       }
+      // every group arrived slot-bucketed (jxlh_submit_groups_slots): the pair buffer already holds what the sort would
+      // produce and the slot tables are written -- one device copy into the persistent bucketed store instead
+      bool all_bucketed = all_pairs && ctx->bucketed.size() == ctx->ngroups;
+      for (size_t g = 0; all_bucketed && g < ctx->ngroups; g++) all_bucketed = ctx->bucketed[g] != 0;
       if (all_pairs) {
         const size_t capacity = ctx->ngroups * 3 * (size_t)kGroupArea;
         if (jxlh_status st = ensure(ctx, ctx->sp_sorted, capacity)) return st;
         if (jxlh_status st = ensure(ctx, ctx->sp_slot_start, ctx->ngroups * 3 * (size_t)kSlotTable)) return st;
-        ScopedKernelTimer t(ctx, "k_sort_sparse");
-        launch_sort_sparse(ctx->stream, ctx->sp_pairs.p, ctx->sp_groups_dev.p, (int)ng, ctx->sp_sorted.p,
-                           ctx->sp_slot_start.p);
+        if (all_bucketed) {
+          ScopedKernelTimer t(ctx, "copy_bucketed_pairs");
+          HIPCHK(ctx, hipMemcpyAsync(ctx->sp_sorted.p, ctx->sp_pairs.p, ctx->sp_used * sizeof(uint32_t),
+                                     hipMemcpyDeviceToDevice, ctx->stream));
+        } else {
+          ScopedKernelTimer t(ctx, "k_sort_sparse");
+          launch_sort_sparse(ctx->stream, ctx->sp_pairs.p, ctx->sp_groups_dev.p, (int)ng, ctx->sp_sorted.p,
+                             ctx->sp_slot_start.p);
+        }
         ctx->sp_sorted_valid = true;
       } else {
         if (ng || nw) {
@@ -631,6 +642,7 @@ jxlh_status run_prologue(jxlh_ctx* ctx, RunPlan* plan) {
         ctx->sp_sorted_valid = false;
       }
       ctx->sp_used = 0;
+      ctx->bucketed.assign(ctx->ngroups, 0);
       ctx->touched.assign(ctx->ngroups, 0);
       ctx->epoch_dirty = false;
       if (ctx->sp_expanded) {  // the pair buffer has been consumed (bucketed or expanded)

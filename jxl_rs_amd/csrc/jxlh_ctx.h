@@ -118,6 +118,9 @@ struct jxlh_ctx {
   // content), 1 dense slab, 2 pairs.  sp_sorted_valid: before this epoch every group's content lived in
   // the bucketed form (and only there).
   std::vector<uint8_t> touched, flag_upload;
+  // groups submitted in the slot-bucketed form in this epoch (jxlh_submit_groups_slots): if that is every group, the
+  // pair buffer already IS the bucketed form and its slot tables are written -- no sort
+  std::vector<uint8_t> bucketed;
   bool epoch_dirty = false;
   bool sp_sorted_valid = false;
   // strip path (k_strip.hip): block descriptors / tile modes written by k1_scan, the strips' edge-column exchange

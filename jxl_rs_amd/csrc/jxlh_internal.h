@@ -261,6 +261,12 @@ struct SparseGroup {
 };
 // only_flagged (nullable): expand a group only if only_flagged[group] != 0
 void launch_pack_pairs8(hipStream_t s, const uint16_t* pos, const int8_t* val, size_t n, uint32_t* pairs);
+// the slot-bucketed form (jxlh_submit_groups_slots): pair words in slot order + the slot tables, see k_coeffs.hip
+void launch_pack_slots(hipStream_t s, const uint16_t* entries, const uint8_t* slot_counts, const uint32_t* desc, int n_runs,
+                       uint32_t* pairs, uint32_t* slot_start);
+// the 2-byte form (jxlh_submit_groups_sparse4): n_runs = groups of the batch x 3, desc = 4 words per run, see k_coeffs.hip
+void launch_pack_pairs4(hipStream_t s, const uint16_t* entries, const uint16_t* seg_counts, const uint16_t* pos8,
+                        const int8_t* val8, const uint32_t* desc, int n_runs, uint32_t* pairs);
 void launch_expand_sparse(hipStream_t s, int32_t* coeffs, const uint32_t* pairs, const SparseGroup* groups,
                           int n_groups, const uint2* wide, uint32_t n_wide, const uint8_t* only_flagged);
 // dense slabs of the groups with flags[g] != 0 from the bucketed pairs (all groups of the frame)

@@ -175,7 +175,87 @@ __global__ __launch_bounds__(256) void k_pack_pairs8(const uint16_t* __restrict_
     for (size_t k = i; k < n && k < i + 4; k++) pairs[k] = (uint32_t)pos[k] | ((uint32_t)(uint16_t)(int16_t)val[k] << 16);
   }
 }
+// the 2-byte form: one workgroup per (group of the batch, channel).  desc[4 * (3 i + c) + {0, 1, 2, 3}] = first entry of
+// the run in `entries`, first overflow update in pos8 / val8, number of overflow updates, first pair of the run in
+// `pairs`; seg_counts as in the ABI.  Output: the run's pair words, nibble entries first (segment order), then the
+// overflow updates.
+__global__ __launch_bounds__(256) void k_pack_pairs4(const uint16_t* __restrict__ entries, const uint16_t* __restrict__ seg_counts,
+                                                     const uint16_t* __restrict__ pos8, const int8_t* __restrict__ val8,
+                                                     const uint32_t* __restrict__ desc, uint32_t* __restrict__ pairs) {
+  __shared__ uint32_t s_start[17];
+  const int run = blockIdx.x;
+  if (threadIdx.x == 0) {
+    uint32_t acc = 0;
+    for (int s = 0; s < 16; s++) {
+      s_start[s] = acc;
+      acc += seg_counts[run * 16 + s];
+    }
+    s_start[16] = acc;
+  }
+  __syncthreads();
+  const uint32_t e0 = desc[4 * run], o0 = desc[4 * run + 1], no = desc[4 * run + 2], p0 = desc[4 * run + 3];
+  const uint32_t n4 = s_start[16];
+  for (uint32_t j = threadIdx.x; j < n4; j += 256) {
+    int seg = 0;  // largest s with s_start[s] <= j (a 16-way select chain on LDS broadcasts)
+#pragma unroll
+    for (int s = 1; s < 16; s++) seg += j >= s_start[s] ? 1 : 0;
+    const uint32_t e = entries[e0 + j];
+    const int32_t v = (int32_t)(e << 16) >> 28;  // sign-extended nibble
+    pairs[p0 + j] = ((uint32_t)seg << 12 | (e & 0xfffu)) | ((uint32_t)(uint16_t)(int16_t)v << 16);
+  }
+  for (uint32_t j = threadIdx.x; j < no; j += 256)
+    pairs[p0 + n4 + j] = (uint32_t)pos8[o0 + j] | ((uint32_t)(uint16_t)(int16_t)val8[o0 + j] << 16);
+}
+// the slot-bucketed form: one workgroup per (group of the batch, channel), thread = slot.  desc[4 * run + {0, 1, 2, 3}] =
+// first entry of the run in `entries`, number of entries n, first pair of the run in `pairs` (frame-wide index),
+// (group * 3 + channel).  Writes the run's pair words in slot order -- the order k_sort_sparse would produce -- and
+// its slot table, so the frame needs no sort.
+__global__ __launch_bounds__(kExpandThreads) void k_pack_slots(const uint16_t* __restrict__ entries,
+                                                              const uint8_t* __restrict__ slot_counts,
+                                                              const uint32_t* __restrict__ desc,
+                                                              uint32_t* __restrict__ pairs,
+                                                              uint32_t* __restrict__ slot_start) {
+  __shared__ uint32_t s_wsum[kExpandThreads / 64];
+  const int run = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t e0 = desc[4 * run], n = desc[4 * run + 1], first = desc[4 * run + 2], gc = desc[4 * run + 3];
+  const uint32_t mine = slot_counts[(size_t)run * 1024 + tid];
+  uint32_t incl = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t v = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += v;
+  }
+  if (lane == 63) s_wsum[wave] = incl;
+  __syncthreads();
+  uint32_t base = 0;
+  for (int w = 0; w < wave; w++) base += s_wsum[w];
+  // a count table that claims more than n entries (a caller's mistake) is cut at n: nothing outside the run is touched
+  const uint32_t excl = min(base + incl - mine, n), end = min(base + incl, n);
+  uint32_t* table = slot_start + (size_t)gc * kSlotTable;
+  table[tid] = first + excl;
+  if (tid == 0) table[1024] = first + n;
+  for (uint32_t j = excl; j < end; j++) {
+    const uint32_t e = entries[e0 + j];
+    const int32_t v = (int32_t)(e << 16) >> 22;  // sign-extended 10 bits
+    pairs[first + j] = ((uint32_t)tid << 6 | (e & 63u)) | ((uint32_t)(uint16_t)(int16_t)v << 16);
+  }
+  // entries the table does not account for (it sums to less than n) would be stale pair words: zero updates instead
+  if (tid == kExpandThreads - 1)
+    for (uint32_t j = end; j < n; j++) pairs[first + j] = (uint32_t)tid << 6;
+}
 }  // namespace
+
+void launch_pack_slots(hipStream_t s, const uint16_t* entries, const uint8_t* slot_counts, const uint32_t* desc, int n_runs,
+                       uint32_t* pairs, uint32_t* slot_start) {
+  if (n_runs <= 0) return;
+  hipLaunchKernelGGL(k_pack_slots, dim3(n_runs), dim3(kExpandThreads), 0, s, entries, slot_counts, desc, pairs, slot_start);
+}
+
+void launch_pack_pairs4(hipStream_t s, const uint16_t* entries, const uint16_t* seg_counts, const uint16_t* pos8,
+                        const int8_t* val8, const uint32_t* desc, int n_runs, uint32_t* pairs) {
+  if (n_runs <= 0) return;
+  hipLaunchKernelGGL(k_pack_pairs4, dim3(n_runs), dim3(256), 0, s, entries, seg_counts, pos8, val8, desc, pairs);
+}
 
 void launch_pack_pairs8(hipStream_t s, const uint16_t* pos, const int8_t* val, size_t n, uint32_t* pairs) {
   if (n == 0) return;

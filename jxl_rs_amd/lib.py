@@ -37,7 +37,8 @@ ABI_SYMBOLS = [
     "jxlh_default_frame_params", "jxlh_ctx_create", "jxlh_ctx_destroy", "jxlh_status_string", "jxlh_last_error",
     "jxlh_alloc_pinned", "jxlh_free_pinned", "jxlh_frame_begin", "jxlh_frame_set_dequant_tables",
     "jxlh_frame_set_lf_quantized", "jxlh_frame_set_lf", "jxlh_frame_set_hf_meta", "jxlh_submit_group",
-    "jxlh_submit_group_sparse", "jxlh_submit_groups_sparse", "jxlh_submit_groups_sparse8", "jxlh_slot_wait",
+    "jxlh_submit_group_sparse", "jxlh_submit_groups_sparse", "jxlh_submit_groups_sparse8", "jxlh_submit_groups_sparse4",
+    "jxlh_submit_groups_slots", "jxlh_slot_wait",
     "jxlh_frame_coeff_buffer", "jxlh_frame_run", "jxlh_ctx_sync", "jxlh_frame_read_planes",
     "jxlh_frame_device_planes", "jxlh_frame_read_lf", "jxlh_frame_read_rgb8", "jxlh_frame_read_rgb8_async",
     "jxlh_frame_read_rgb16", "jxlh_frame_read_ycbcr_rgb8", "jxlh_frame_read_ycbcr_rgb16", "jxlh_frame_read_output",
@@ -151,6 +152,8 @@ def load():
     L.jxlh_slot_wait.argtypes = [vp, i32]
     L.jxlh_submit_group_sparse.argtypes = [vp, i32, u32, vp, vp, vp, u32, u32]
     L.jxlh_submit_groups_sparse.argtypes = [vp, i32, u32, vp, vp, vp, vp, u32, u32]
+    L.jxlh_submit_groups_sparse4.argtypes = [vp, i32, u32, vp, vp, vp, vp, vp, vp, vp, u32, u32]
+    L.jxlh_submit_groups_slots.argtypes = [vp, i32, u32, vp, vp, vp, vp, vp, u32, u32]
     L.jxlh_submit_groups_sparse8.argtypes = [vp, i32, u32, vp, vp, vp, vp, vp, u32, u32]
     L.jxlh_frame_coeff_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
     L.jxlh_frame_run.argtypes = [vp, u32, u32]
@@ -435,6 +438,48 @@ class Context:
         self._chk(self.L.jxlh_submit_groups_sparse8(self._ctx, slot, len(group_ids), _addr(group_ids), pa, va, _addr(n),
                                                     None if wide is None else _addr(wide), nw, flags),
                   "submit_groups_sparse8")
+
+    def submit_groups_sparse4(self, group_ids, entries, seg_counts, pos8=None, val8=None, n8=None, wide=None, slot=0,
+                              flags=GROUP_COMPLETE):
+        """2-byte form (synth.to_sparse4): arrays, or raw host addresses (pinned memory) for entries / seg_counts /
+        pos8 / val8."""
+        group_ids = np.ascontiguousarray(group_ids, dtype=np.uint32)
+        nw = 0 if wide is None else len(wide)
+        wide = None if nw == 0 else np.ascontiguousarray(wide, dtype=np.uint32)
+
+        def prep(a, dt):
+            if a is None or isinstance(a, int):
+                return a, (a if a else None)
+            a = np.ascontiguousarray(a, dtype=dt)
+            return a, (_addr(a) if a.size else None)
+        entries, ea = prep(entries, np.uint16)
+        seg_counts, ca = prep(seg_counts, np.uint16)
+        pos8, pa = prep(pos8, np.uint16)
+        val8, va = prep(val8, np.int8)
+        n8 = None if n8 is None else np.ascontiguousarray(n8, dtype=np.uint32)
+        self._keep.setdefault(slot, []).append((group_ids, entries, seg_counts, pos8, val8, n8, wide))
+        self._chk(self.L.jxlh_submit_groups_sparse4(self._ctx, slot, len(group_ids), _addr(group_ids), ea, ca, pa, va,
+                                                    None if n8 is None else _addr(n8),
+                                                    None if wide is None else _addr(wide), nw, flags),
+                  "submit_groups_sparse4")
+
+    def submit_groups_slots(self, group_ids, entries, slot_counts, n, wide=None, slot=0, flags=GROUP_COMPLETE):
+        """slot-bucketed 2-byte form (synth.to_slots): arrays, or raw host addresses (pinned memory) for entries /
+        slot_counts"""
+        group_ids = np.ascontiguousarray(group_ids, dtype=np.uint32)
+        n = np.ascontiguousarray(n, dtype=np.uint32)
+        nw = 0 if wide is None else len(wide)
+        wide = None if nw == 0 else np.ascontiguousarray(wide, dtype=np.uint32)
+        if not isinstance(entries, int):
+            entries = np.ascontiguousarray(entries, dtype=np.uint16)
+        if not isinstance(slot_counts, int):
+            slot_counts = np.ascontiguousarray(slot_counts, dtype=np.uint8)
+        ea = entries if isinstance(entries, int) else (_addr(entries) if entries.size else None)
+        ca = slot_counts if isinstance(slot_counts, int) else _addr(slot_counts)
+        self._keep.setdefault(slot, []).append((group_ids, entries, slot_counts, n, wide))
+        self._chk(self.L.jxlh_submit_groups_slots(self._ctx, slot, len(group_ids), _addr(group_ids), ea, ca, _addr(n),
+                                                  None if wide is None else _addr(wide), nw, flags),
+                  "submit_groups_slots")
 
     def alloc_pinned(self, nbytes):
         """Pinned host buffer (jxlh_alloc_pinned) as a uint8 numpy view; freed with the context."""

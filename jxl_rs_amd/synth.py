@@ -519,3 +519,49 @@ def to_sparse8(group_coeffs):
     widea = np.concatenate(wide).astype(np.uint32) if wide else np.zeros((0, 2), np.uint32)
     return (np.concatenate(ps) if ps else np.zeros(0, np.uint16), np.concatenate(vs) if vs else np.zeros(0, np.int8),
             np.asarray(n, dtype=np.uint32), widea)
+
+
+def to_sparse4(group_coeffs):
+    """2-byte transport form (jxlh_submit_groups_sparse4): (entries uint16 -- (pos & 4095) | (val & 15) << 12, grouped by
+    channel and 4096-coefficient segment --, seg_counts uint16 [3, 16], pos8 uint16, val8 int8, n8 uint32 [3] -- the
+    3-byte overflow updates whose value is outside [-8, 7] --, wide uint32 [k, 2] for values outside i8)."""
+    g = np.asarray(group_coeffs).reshape(3, -1)
+    ents, counts, ps, vs, n8, wide = [], np.zeros((3, 16), np.uint16), [], [], [], []
+    for c in range(3):
+        pos = np.flatnonzero(g[c])
+        val = g[c][pos]
+        nib = (val >= -8) & (val <= 7)
+        byte = ~nib & (val >= -128) & (val <= 127)
+        big = ~nib & ~byte
+        p4, v4 = pos[nib], val[nib]
+        ents.append(((p4 & 4095) | ((v4 & 15) << 12)).astype(np.uint16))  # np.flatnonzero is sorted: segment order
+        counts[c] = np.bincount(p4 >> 12, minlength=16).astype(np.uint16)
+        ps.append(pos[byte].astype(np.uint16))
+        vs.append(val[byte].astype(np.int8))
+        n8.append(int(byte.sum()))
+        if big.any():
+            wide.append(np.stack([(c * 65536 + pos[big]).astype(np.uint32), val[big].astype(np.int32).view(np.uint32)], axis=1))
+    widea = np.concatenate(wide).astype(np.uint32) if wide else np.zeros((0, 2), np.uint32)
+    return (np.concatenate(ents), counts, np.concatenate(ps), np.concatenate(vs), np.asarray(n8, dtype=np.uint32), widea)
+
+
+def to_slots(group_coeffs):
+    """Slot-bucketed transport form (jxlh_submit_groups_slots): (entries uint16 -- (pos & 63) | (val & 1023) << 6, ordered by
+    channel and 64-coefficient slot --, slot_counts uint8 [3, 1024], n uint32 [3], wide uint32 [k, 2] for values outside
+    [-512, 511])."""
+    g = np.asarray(group_coeffs).reshape(3, -1)
+    ents, counts, n, wide = [], np.zeros((3, 1024), np.uint8), [], []
+    for c in range(3):
+        pos = np.flatnonzero(g[c])
+        val = g[c][pos]
+        fits = (val >= -512) & (val <= 511)
+        p, v = pos[fits], val[fits]
+        ents.append(((p & 63) | ((v & 1023) << 6)).astype(np.uint16))  # np.flatnonzero is sorted: slot order
+        cnt = np.bincount(p >> 6, minlength=1024)
+        assert cnt.max(initial=0) <= 255
+        counts[c] = cnt.astype(np.uint8)
+        n.append(len(p))
+        if (~fits).any():
+            wide.append(np.stack([(c * 65536 + pos[~fits]).astype(np.uint32), val[~fits].astype(np.int32).view(np.uint32)], axis=1))
+    widea = np.concatenate(wide).astype(np.uint32) if wide else np.zeros((0, 2), np.uint32)
+    return np.concatenate(ents), counts, np.asarray(n, dtype=np.uint32), widea

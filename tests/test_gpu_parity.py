@@ -1142,6 +1142,112 @@ def test_sparse8_submit_matches_dense_submit(ctx, oracle, mix, size, scale):
         assert bit_equal(got[c], want[c]), f"plane {c}: {diff_report(got[c], want[c])}"
 
 
+@pytest.mark.parametrize("mix,size,scale", [("MIX_D1", (520, 300), 1), ("MIX_D1", (1024, 512), 3), ("MIX_ALL", (300, 270), 40)])
+def test_sparse4_submit_matches_dense_submit(ctx, oracle, mix, size, scale):
+    """jxlh_submit_groups_sparse4 (2 bytes per update: 12-bit position inside a 4096-coefficient segment + value nibble,
+    per-segment counts; larger values through the 3-byte overflow arrays, the largest through the wide list) gives the
+    frame the dense submission gives, bit for bit; the scales push shares of the values into the overflow forms"""
+    from jxl_rs_amd import synth
+    w, h = size
+    wl = synth.make_vardct(w, h, mix=getattr(synth, mix), seed=w + h, epf_iters=2, coeff_scale=scale)
+    want, _ = run_gpu_frame(ctx, wl)
+    p = gpu_params_from(ctx, wl)
+    ctx.frame_begin(p)
+    ctx.set_dequant_tables(wl.tables)
+    ctx.set_lf_quantized(*wl.lf_q)
+    ctx.set_hf_meta(wl.transform_map, wl.raw_quant, wl.epf_map, wl.ytox, wl.ytob)
+    ng = wl.coeffs.shape[0]
+    parts = [synth.to_sparse4(wl.coeffs[g]) for g in range(ng)]
+    wide = []
+    for g, q in enumerate(parts):   # the batched form addresses wide entries frame-wide
+        if len(q[5]):
+            e = q[5].copy()
+            e[:, 0] += np.uint32(g * 3 * 65536)
+            wide.append(e)
+    wide = np.concatenate(wide) if wide else None
+    n8 = np.concatenate([q[4] for q in parts])
+    if scale > 1:
+        assert n8.sum() > 100
+    if scale >= 40:
+        assert wide is not None and len(wide) > 100
+    # two batches on two slots, like two decoder threads
+    half = ng // 2 if ng > 1 else ng
+    for sl, (g0, g1) in enumerate(((0, half), (half, ng))):
+        if g0 >= g1:
+            continue
+        sel = parts[g0:g1]
+        wsel = None
+        if wide is not None:
+            m = (wide[:, 0] // (3 * 65536) >= g0) & (wide[:, 0] // (3 * 65536) < g1)
+            wsel = wide[m] if m.any() else None
+        ctx.submit_groups_sparse4(np.arange(g0, g1, dtype=np.uint32), np.concatenate([q[0] for q in sel]),
+                                  np.concatenate([q[1].reshape(-1) for q in sel]), np.concatenate([q[2] for q in sel]),
+                                  np.concatenate([q[3] for q in sel]), np.concatenate([q[4] for q in sel]), wsel, slot=0)
+    ctx.slot_wait(0)
+    ctx.frame_run()
+    ctx.sync()
+    got = ctx.read_planes()
+    for c in range(3):
+        assert bit_equal(got[c], want[c]), f"plane {c}: {diff_report(got[c], want[c])}"
+
+
+@pytest.mark.parametrize("mix,size,scale,partial", [("MIX_D1", (520, 300), 1, False), ("MIX_D1", (1024, 512), 30, False),
+                                                    ("MIX_ALL", (300, 270), 200, False), ("MIX_D1", (768, 512), 1, True)])
+def test_slot_bucketed_submit_matches_dense_submit(ctx, oracle, mix, size, scale, partial):
+    """jxlh_submit_groups_slots (2 bytes per update, bucketed by 64-coefficient slot on the host: the frame is not sorted
+    on the device) gives the frame the dense submission gives, bit for bit -- with a whole frame in this form (the
+    no-sort route), with values past 10 bits in the wide list (dense route), and with only SOME groups in this form
+    and the others as plain pairs (the sort runs after all)"""
+    from jxl_rs_amd import synth
+    w, h = size
+    wl = synth.make_vardct(w, h, mix=getattr(synth, mix), seed=w + h, epf_iters=2, coeff_scale=scale)
+    want, _ = run_gpu_frame(ctx, wl)
+    p = gpu_params_from(ctx, wl)
+    ctx.frame_begin(p)
+    ctx.set_dequant_tables(wl.tables)
+    ctx.set_lf_quantized(*wl.lf_q)
+    ctx.set_hf_meta(wl.transform_map, wl.raw_quant, wl.epf_map, wl.ytox, wl.ytob)
+    ng = wl.coeffs.shape[0]
+    slotted = [g for g in range(ng) if not (partial and g % 3 == 1)]
+    parts = {g: synth.to_slots(wl.coeffs[g]) for g in slotted}
+    wide = []
+    for g, q in parts.items():   # the batched form addresses wide entries frame-wide
+        if len(q[3]):
+            e = q[3].copy()
+            e[:, 0] += np.uint32(g * 3 * 65536)
+            wide.append(e)
+    wide = np.concatenate(wide) if wide else None
+    if scale >= 200:
+        assert wide is not None and len(wide) > 50
+    ctx.kernel_timing_reset()
+    ctx.kernel_timing(True)
+    ctx.submit_groups_slots(np.asarray(slotted, dtype=np.uint32), np.concatenate([parts[g][0] for g in slotted]),
+                            np.concatenate([parts[g][1].reshape(-1) for g in slotted]),
+                            np.concatenate([parts[g][2] for g in slotted]), wide)
+    for g in range(ng):
+        if g not in parts:
+            pr, n3, wd = synth.to_sparse(wl.coeffs[g])
+            ctx.submit_group_sparse(g, pr, n3, wd)
+    ctx.slot_wait(0)
+    ctx.frame_run()
+    ctx.sync()
+    kt = ctx.kernel_times()
+    ctx.kernel_timing(False)
+    if not partial and wide is None:
+        assert "k_sort_sparse" not in kt and "copy_bucketed_pairs" in kt, sorted(kt)
+    if partial:
+        assert "k_sort_sparse" in kt, sorted(kt)
+    got = ctx.read_planes()
+    for c in range(3):
+        assert bit_equal(got[c], want[c]), f"plane {c}: {diff_report(got[c], want[c])}"
+    # the frame once more without resubmitting anything: the bucketed store persists across runs
+    ctx.frame_run()
+    ctx.sync()
+    again = ctx.read_planes()
+    for c in range(3):
+        assert bit_equal(again[c], want[c])
+
+
 def test_sparse_submit_argument_errors(ctx):
     from jxl_rs_amd import synth
     from jxl_rs_amd.lib import JxlHipError
