@@ -812,6 +812,32 @@ def main():
                     c.submit_groups_slots(ids[g0:g1], pin_se_addr + int(off_s[g0]) * 2, pin_sc_addr + g0 * 3072,
                                           ns_[3 * g0:3 * g1], None, slot=sl)
 
+        # ... and with 12-bit entries packed two per three bytes (JXLH_GROUP_ENTRIES12: values in [-32, 31])
+        from jxl_rs_amd import lib as jl_
+        c12, e12, cnt12, n12 = {}, [], [], []
+        for g in range(ng):
+            key = g % 24
+            if key not in c12 or c12[key][1] != cache[key][3]:
+                c12[key] = (synth.to_slots(wl.coeffs[cache[key][3]], True), cache[key][3])
+            q12 = c12[key][0]
+            assert len(q12[3]) == 0
+            e12.append(q12[0]); cnt12.append(q12[1].reshape(-1)); n12.append(q12[2])
+        off12 = np.concatenate([[0], np.cumsum([len(x) for x in e12])]).astype(np.int64)  # bytes
+        tot12 = int(off12[-1])
+        pin_12, pin_12_addr = ectx[0].alloc_pinned(max(4, tot12))
+        pin_12c, pin_12c_addr = ectx[0].alloc_pinned(ng * 3072)
+        pin_12[:tot12] = np.concatenate(e12)
+        pin_12c[:] = np.concatenate(cnt12)
+        n12 = np.concatenate(n12).astype(np.uint32)
+        bytes_12 = tot12 + ng * 3072
+
+        def submit_slots12(c):
+            for sl in range(nslots):
+                g0, g1 = sl * per, min(ng, (sl + 1) * per)
+                if g0 < g1:
+                    c.submit_groups_slots(ids[g0:g1], pin_12_addr + int(off12[g0]), pin_12c_addr + g0 * 3072,
+                                          n12[3 * g0:3 * g1], None, slot=sl, flags=jl_.GROUP_COMPLETE | jl_.GROUP_ENTRIES12)
+
         def submit_sparse(c):
             for sl in range(nslots):
                 g0, g1 = sl * per, min(ng, (sl + 1) * per)
@@ -850,7 +876,8 @@ def main():
             c.set_lf_quantized(*wl.lf_q)
             c.set_hf_meta(wl.transform_map, wl.raw_quant, wl.epf_map, wl.ytox, wl.ytob)
         legs = (("sparse_pairs", submit_sparse), ("sparse_pos16_val8", submit_sparse8), ("sparse_seg12_val4", submit_sparse4),
-                ("slots_pos6_val10_no_sort", submit_slots), ("dense_i32", submit_dense))
+                ("slots_pos6_val10_no_sort", submit_slots), ("slots_packed12_no_sort", submit_slots12),
+                ("dense_i32", submit_dense))
         if os.environ.get("JXLH_BENCH_E2E_ORDER") == "swap":  # leg order experiment (first-leg warm-up effects)
             legs = (legs[1], legs[0]) + legs[2:]
         for name, submit in legs:
@@ -873,7 +900,8 @@ def main():
                 c.sync()
             el = time.perf_counter() - t0
             nbytes = {"sparse_pairs": total * 4, "sparse_pos16_val8": total * 3, "sparse_seg12_val4": bytes4,
-                      "slots_pos6_val10_no_sort": bytes_slots}.get(name, wl.coeffs.nbytes)
+                      "slots_pos6_val10_no_sort": bytes_slots,
+                      "slots_packed12_no_sort": bytes_12}.get(name, wl.coeffs.nbytes)
             e2e[name] = {"value": round(size * size * frames / 1e6 / el, 1), "unit": "MP/s",
                          "ms_per_frame": round(el * 1e3 / frames, 3), "h2d_MB_per_frame": round(nbytes / 1e6, 1),
                          "frames": frames}
@@ -897,20 +925,20 @@ def main():
         for i in range(NE + 2):  # warm-up in the timed pattern
             c = ectx[i % NE]
             c.sync()
-            submit_slots(c); c.frame_run(); read_rgb(i % NE)
+            submit_slots12(c); c.frame_run(); read_rgb(i % NE)
         for c in ectx:
             c.sync()
         t0 = time.perf_counter()
         for i in range(frames):
             c = ectx[i % NE]
             c.sync()             # the context's previous frame is in host memory: its buffers can be reused
-            submit_slots(c); c.frame_run(); read_rgb(i % NE)
+            submit_slots12(c); c.frame_run(); read_rgb(i % NE)
         for c in ectx:
             c.sync()
         el = time.perf_counter() - t0
         e2e["slots_to_host_rgb8"] = {"value": round(size * size * frames / 1e6 / el, 1), "unit": "MP/s",
                                             "ms_per_frame": round(el * 1e3 / frames, 3),
-                                            "h2d_MB_per_frame": round(bytes_slots / 1e6, 1),
+                                            "h2d_MB_per_frame": round(bytes_12 / 1e6, 1),
                                             "d2h_MB_per_frame": round(rgb_bytes / 1e6, 1), "frames": frames}
         e2e["note"] = ("pinned host coefficients -> H2D on 2 slot streams -> (sparse: device zero-fill + scatter) -> "
                        "K0b/K3/K1/filters, 2 frames in flight; planes stay on the device except in *_to_host_rgb8, which adds "

@@ -208,8 +208,13 @@ jxlh_status jxlh_submit_group(jxlh_ctx* ctx, int32_t slot, uint32_t group_id, co
  *   JXLH_GROUP_ACCUMULATE  sparse forms only: the pairs are ADDED to the group's coefficients of the earlier passes
  *                          on the device (frame/group.rs:572 `+=` on Frame::hf_coefficients, frame/decode.rs:547-558)
  *                          instead of replacing them.  A dense slab always replaces the group's coefficients, so a
- *                          progressive caller that keeps dense slabs submits its accumulated slab. */
-enum { JXLH_GROUP_COMPLETE = 1u << 0, JXLH_GROUP_ACCUMULATE = 1u << 1 };
+ *                          progressive caller that keeps dense slabs submits its accumulated slab.
+ *   JXLH_GROUP_ENTRIES12   jxlh_submit_groups_slots only: the entries are 12 bits -- (position & 63) | (value & 63) << 6,
+ *                          value in [-32, 31] -- packed two per three bytes (byte 0 = e0 & 255, byte 1 = e0 >> 8 |
+ *                          (e1 & 15) << 4, byte 2 = e1 >> 4); every (group, channel) run holds an even number of them
+ *                          (an odd run is closed with a zero update, counted in its last slot), so each run starts on
+ *                          a byte.  1.5 bytes per update on the bus. */
+enum { JXLH_GROUP_COMPLETE = 1u << 0, JXLH_GROUP_ACCUMULATE = 1u << 1, JXLH_GROUP_ENTRIES12 = 1u << 2 };
 
 /* Sparse form of jxlh_submit_group (the dense i32 slab is ~90 % zeros at d1 and
  * its PCIe transfer bounds end-to-end decode).  The entropy loop of decode_vardct_group

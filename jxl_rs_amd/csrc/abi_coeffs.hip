@@ -227,6 +227,10 @@ jxlh_status jxlh_submit_groups_slots(jxlh_ctx* ctx, int32_t slot, uint32_t count
   if (jxlh_status st = sparse_reserve(ctx, slot, count, group_ids, n, wide, n_wide, flags, &offset, &total)) return st;
   if (total && !entries) return JXLH_ERR_INVALID_ARGUMENT;
   const size_t runs = (size_t)count * 3;
+  const bool e12 = (flags & JXLH_GROUP_ENTRIES12) != 0;
+  if (e12)
+    for (size_t r = 0; r < runs; r++)
+      if (n[r] & 1u) return JXLH_ERR_INVALID_ARGUMENT;  // 12-bit runs are closed to an even number of entries
   std::vector<uint32_t> desc(4 * runs);
   {
     size_t o = 0;
@@ -251,7 +255,8 @@ jxlh_status jxlh_submit_groups_slots(jxlh_ctx* ctx, int32_t slot, uint32_t count
   {
     // staging: [entries | slot counts | run descriptors], reused by the slot (stream-ordered)
     auto up = [](size_t v) { return (v + 15) & ~(size_t)15; };
-    const size_t b_ent = up(total * 2), b_cnt = up(runs * 1024), b_desc = up(runs * 16);
+    const size_t ent_bytes = e12 ? total / 2 * 3 : total * 2;
+    const size_t b_ent = up(ent_bytes), b_cnt = up(runs * 1024), b_desc = up(runs * 16);
     const size_t need = b_ent + b_cnt + b_desc;
     if (s.stage8_cap < need) {
       HIPCHK(ctx, hipStreamSynchronize(s.stream));
@@ -263,11 +268,11 @@ jxlh_status jxlh_submit_groups_slots(jxlh_ctx* ctx, int32_t slot, uint32_t count
       s.stage8_cap = cap;
     }
     uint8_t* d_ent = s.stage8, *d_cnt = d_ent + b_ent, *d_desc = d_cnt + b_cnt;
-    if (total) HIPCHK(ctx, hipMemcpyAsync(d_ent, entries, total * 2, hipMemcpyDefault, s.stream));
+    if (total) HIPCHK(ctx, hipMemcpyAsync(d_ent, entries, ent_bytes, hipMemcpyDefault, s.stream));
     HIPCHK(ctx, hipMemcpyAsync(d_cnt, slot_counts, runs * 1024, hipMemcpyDefault, s.stream));
     HIPCHK(ctx, hipMemcpyAsync(d_desc, desc.data(), runs * 16, hipMemcpyHostToDevice, s.stream));
     launch_pack_slots(s.stream, reinterpret_cast<const uint16_t*>(d_ent), d_cnt, reinterpret_cast<const uint32_t*>(d_desc),
-                      (int)runs, ctx->sp_pairs.p, ctx->sp_slot_start.p);
+                      (int)runs, ctx->sp_pairs.p, ctx->sp_slot_start.p, e12);
     HIPCHK(ctx, hipGetLastError());
   }
   HIPCHK(ctx, hipEventRecord(s.done, s.stream));

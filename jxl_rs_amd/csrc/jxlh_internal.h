@@ -263,7 +263,7 @@ struct SparseGroup {
 void launch_pack_pairs8(hipStream_t s, const uint16_t* pos, const int8_t* val, size_t n, uint32_t* pairs);
 // the slot-bucketed form (jxlh_submit_groups_slots): pair words in slot order + the slot tables, see k_coeffs.hip
 void launch_pack_slots(hipStream_t s, const uint16_t* entries, const uint8_t* slot_counts, const uint32_t* desc, int n_runs,
-                       uint32_t* pairs, uint32_t* slot_start);
+                       uint32_t* pairs, uint32_t* slot_start, bool entries12);
 // the 2-byte form (jxlh_submit_groups_sparse4): n_runs = groups of the batch x 3, desc = 4 words per run, see k_coeffs.hip
 void launch_pack_pairs4(hipStream_t s, const uint16_t* entries, const uint16_t* seg_counts, const uint16_t* pos8,
                         const int8_t* val8, const uint32_t* desc, int n_runs, uint32_t* pairs);

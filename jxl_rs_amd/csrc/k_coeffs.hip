@@ -210,6 +210,8 @@ __global__ __launch_bounds__(256) void k_pack_pairs4(const uint16_t* __restrict_
 // first entry of the run in `entries`, number of entries n, first pair of the run in `pairs` (frame-wide index),
 // (group * 3 + channel).  Writes the run's pair words in slot order -- the order k_sort_sparse would produce -- and
 // its slot table, so the frame needs no sort.
+// E12: 12-bit entries, two per three bytes (JXLH_GROUP_ENTRIES12); a run starts at byte 3 * (its first entry) / 2
+template <bool E12>
 __global__ __launch_bounds__(kExpandThreads) void k_pack_slots(const uint16_t* __restrict__ entries,
                                                               const uint8_t* __restrict__ slot_counts,
                                                               const uint32_t* __restrict__ desc,
@@ -234,9 +236,18 @@ __global__ __launch_bounds__(kExpandThreads) void k_pack_slots(const uint16_t* _
   uint32_t* table = slot_start + (size_t)gc * kSlotTable;
   table[tid] = first + excl;
   if (tid == 0) table[1024] = first + n;
+  const uint8_t* __restrict__ bytes = reinterpret_cast<const uint8_t*>(entries) + (size_t)e0 / 2 * 3;
   for (uint32_t j = excl; j < end; j++) {
-    const uint32_t e = entries[e0 + j];
-    const int32_t v = (int32_t)(e << 16) >> 22;  // sign-extended 10 bits
+    uint32_t e;
+    int32_t v;
+    if constexpr (E12) {
+      const uint8_t* b = bytes + (size_t)(j >> 1) * 3;
+      e = (j & 1u) ? ((uint32_t)b[1] >> 4 | (uint32_t)b[2] << 4) : ((uint32_t)b[0] | ((uint32_t)b[1] & 15u) << 8);
+      v = (int32_t)(e << 20) >> 26;  // sign-extended 6 bits
+    } else {
+      e = entries[e0 + j];
+      v = (int32_t)(e << 16) >> 22;  // sign-extended 10 bits
+    }
     pairs[first + j] = ((uint32_t)tid << 6 | (e & 63u)) | ((uint32_t)(uint16_t)(int16_t)v << 16);
   }
   // entries the table does not account for (it sums to less than n) would be stale pair words: zero updates instead
@@ -246,9 +257,12 @@ __global__ __launch_bounds__(kExpandThreads) void k_pack_slots(const uint16_t* _
 }  // namespace
 
 void launch_pack_slots(hipStream_t s, const uint16_t* entries, const uint8_t* slot_counts, const uint32_t* desc, int n_runs,
-                       uint32_t* pairs, uint32_t* slot_start) {
+                       uint32_t* pairs, uint32_t* slot_start, bool entries12) {
   if (n_runs <= 0) return;
-  hipLaunchKernelGGL(k_pack_slots, dim3(n_runs), dim3(kExpandThreads), 0, s, entries, slot_counts, desc, pairs, slot_start);
+  if (entries12)
+    hipLaunchKernelGGL(k_pack_slots<true>, dim3(n_runs), dim3(kExpandThreads), 0, s, entries, slot_counts, desc, pairs, slot_start);
+  else
+    hipLaunchKernelGGL(k_pack_slots<false>, dim3(n_runs), dim3(kExpandThreads), 0, s, entries, slot_counts, desc, pairs, slot_start);
 }
 
 void launch_pack_pairs4(hipStream_t s, const uint16_t* entries, const uint16_t* seg_counts, const uint16_t* pos8,

@@ -31,6 +31,7 @@ FRAME_EXPAND_SPARSE = 2
 FRAME_STRIP = 4
 GROUP_COMPLETE = 1
 GROUP_ACCUMULATE = 2
+GROUP_ENTRIES12 = 4
 
 # every symbol include/jxl_hip.h declares (checked by tests/test_abi_symbols.py)
 ABI_SYMBOLS = [
@@ -471,7 +472,7 @@ class Context:
         nw = 0 if wide is None else len(wide)
         wide = None if nw == 0 else np.ascontiguousarray(wide, dtype=np.uint32)
         if not isinstance(entries, int):
-            entries = np.ascontiguousarray(entries, dtype=np.uint16)
+            entries = np.ascontiguousarray(entries, dtype=np.uint8 if (flags & GROUP_ENTRIES12) else np.uint16)
         if not isinstance(slot_counts, int):
             slot_counts = np.ascontiguousarray(slot_counts, dtype=np.uint8)
         ea = entries if isinstance(entries, int) else (_addr(entries) if entries.size else None)

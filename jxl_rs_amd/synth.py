@@ -545,19 +545,38 @@ def to_sparse4(group_coeffs):
     return (np.concatenate(ents), counts, np.concatenate(ps), np.concatenate(vs), np.asarray(n8, dtype=np.uint32), widea)
 
 
-def to_slots(group_coeffs):
+def to_slots(group_coeffs, bits12=False):
     """Slot-bucketed transport form (jxlh_submit_groups_slots): (entries uint16 -- (pos & 63) | (val & 1023) << 6, ordered by
     channel and 64-coefficient slot --, slot_counts uint8 [3, 1024], n uint32 [3], wide uint32 [k, 2] for values outside
-    [-512, 511])."""
+    [-512, 511]).  bits12 (JXLH_GROUP_ENTRIES12): entries = uint8 bytes, 12-bit entries (value in [-32, 31]) packed two
+    per three bytes, every channel's run closed to an even count with a zero update in slot 1023."""
     g = np.asarray(group_coeffs).reshape(3, -1)
     ents, counts, n, wide = [], np.zeros((3, 1024), np.uint8), [], []
+    lo, hi, vmask = (-32, 31, 63) if bits12 else (-512, 511, 1023)
     for c in range(3):
         pos = np.flatnonzero(g[c])
         val = g[c][pos]
-        fits = (val >= -512) & (val <= 511)
+        fits = (val >= lo) & (val <= hi)
         p, v = pos[fits], val[fits]
-        ents.append(((p & 63) | ((v & 1023) << 6)).astype(np.uint16))  # np.flatnonzero is sorted: slot order
+        e = ((p & 63) | ((v & vmask) << 6)).astype(np.uint16)  # np.flatnonzero is sorted: slot order
         cnt = np.bincount(p >> 6, minlength=1024)
+        if bits12:
+            if len(e) & 1:
+                e = np.concatenate([e, np.zeros(1, np.uint16)])  # += 0 at position 0 of the last slot
+                cnt[1023] += 1
+            e0, e1 = e[0::2].astype(np.uint32), e[1::2].astype(np.uint32)
+            b = np.empty((len(e0), 3), np.uint8)
+            b[:, 0] = e0 & 255
+            b[:, 1] = (e0 >> 8) | ((e1 & 15) << 4)
+            b[:, 2] = e1 >> 4
+            ents.append(b.reshape(-1))
+            assert cnt.max(initial=0) <= 255
+            counts[c] = cnt.astype(np.uint8)
+            n.append(len(e))
+            if (~fits).any():
+                wide.append(np.stack([(c * 65536 + pos[~fits]).astype(np.uint32), val[~fits].astype(np.int32).view(np.uint32)], axis=1))
+            continue
+        ents.append(e)
         assert cnt.max(initial=0) <= 255
         counts[c] = cnt.astype(np.uint8)
         n.append(len(p))

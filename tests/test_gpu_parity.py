@@ -1191,9 +1191,10 @@ def test_sparse4_submit_matches_dense_submit(ctx, oracle, mix, size, scale):
         assert bit_equal(got[c], want[c]), f"plane {c}: {diff_report(got[c], want[c])}"
 
 
+@pytest.mark.parametrize("bits12", [False, True])
 @pytest.mark.parametrize("mix,size,scale,partial", [("MIX_D1", (520, 300), 1, False), ("MIX_D1", (1024, 512), 30, False),
                                                     ("MIX_ALL", (300, 270), 200, False), ("MIX_D1", (768, 512), 1, True)])
-def test_slot_bucketed_submit_matches_dense_submit(ctx, oracle, mix, size, scale, partial):
+def test_slot_bucketed_submit_matches_dense_submit(ctx, oracle, mix, size, scale, partial, bits12):
     """jxlh_submit_groups_slots (2 bytes per update, bucketed by 64-coefficient slot on the host: the frame is not sorted
     on the device) gives the frame the dense submission gives, bit for bit -- with a whole frame in this form (the
     no-sort route), with values past 10 bits in the wide list (dense route), and with only SOME groups in this form
@@ -1209,7 +1210,8 @@ def test_slot_bucketed_submit_matches_dense_submit(ctx, oracle, mix, size, scale
     ctx.set_hf_meta(wl.transform_map, wl.raw_quant, wl.epf_map, wl.ytox, wl.ytob)
     ng = wl.coeffs.shape[0]
     slotted = [g for g in range(ng) if not (partial and g % 3 == 1)]
-    parts = {g: synth.to_slots(wl.coeffs[g]) for g in slotted}
+    from jxl_rs_amd import lib as jl
+    parts = {g: synth.to_slots(wl.coeffs[g], bits12) for g in slotted}
     wide = []
     for g, q in parts.items():   # the batched form addresses wide entries frame-wide
         if len(q[3]):
@@ -1223,7 +1225,8 @@ def test_slot_bucketed_submit_matches_dense_submit(ctx, oracle, mix, size, scale
     ctx.kernel_timing(True)
     ctx.submit_groups_slots(np.asarray(slotted, dtype=np.uint32), np.concatenate([parts[g][0] for g in slotted]),
                             np.concatenate([parts[g][1].reshape(-1) for g in slotted]),
-                            np.concatenate([parts[g][2] for g in slotted]), wide)
+                            np.concatenate([parts[g][2] for g in slotted]), wide,
+                            flags=jl.GROUP_COMPLETE | (jl.GROUP_ENTRIES12 if bits12 else 0))
     for g in range(ng):
         if g not in parts:
             pr, n3, wd = synth.to_sparse(wl.coeffs[g])
