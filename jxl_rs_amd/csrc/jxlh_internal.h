@@ -17,6 +17,13 @@ __device__ __forceinline__ int4 gload_i4(const int* p) {
   return make_int4(v.x, v.y, v.z, v.w);
 }
 template <bool NT>
+__device__ __forceinline__ void gstore_i4(int* p, int4 o) {
+  jxlh_i32x4 v = {o.x, o.y, o.z, o.w};
+  jxlh_i32x4* q = reinterpret_cast<jxlh_i32x4*>(p);
+  if (NT) __builtin_nontemporal_store(v, q);
+  else *q = v;
+}
+template <bool NT>
 __device__ __forceinline__ float4 gload_f4(const float* p) {
   const jxlh_f32x4* q = reinterpret_cast<const jxlh_f32x4*>(p);
   const jxlh_f32x4 v = NT ? __builtin_nontemporal_load(q) : *q;

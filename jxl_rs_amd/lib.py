@@ -153,8 +153,9 @@ def load():
     L.jxlh_slot_wait.argtypes = [vp, i32]
     L.jxlh_submit_group_sparse.argtypes = [vp, i32, u32, vp, vp, vp, u32, u32]
     L.jxlh_submit_groups_sparse.argtypes = [vp, i32, u32, vp, vp, vp, vp, u32, u32]
-    L.jxlh_submit_groups_sparse4.argtypes = [vp, i32, u32, vp, vp, vp, vp, vp, vp, vp, u32, u32]
-    L.jxlh_submit_groups_slots.argtypes = [vp, i32, u32, vp, vp, vp, vp, vp, u32, u32]
+    if hasattr(L, "jxlh_submit_groups_slots"):  # absent from older builds used in A/B runs (JXLH_LIBRARY)
+        L.jxlh_submit_groups_sparse4.argtypes = [vp, i32, u32, vp, vp, vp, vp, vp, vp, vp, u32, u32]
+        L.jxlh_submit_groups_slots.argtypes = [vp, i32, u32, vp, vp, vp, vp, vp, u32, u32]
     L.jxlh_submit_groups_sparse8.argtypes = [vp, i32, u32, vp, vp, vp, vp, vp, u32, u32]
     L.jxlh_frame_coeff_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
     L.jxlh_frame_run.argtypes = [vp, u32, u32]
@@ -196,7 +197,8 @@ def load():
     L.jxlh_frames_allgather_local.argtypes = [C.POINTER(vp), i32]
     L.jxlh_comm_allgather.argtypes = [vp, vp, sz]
     L.jxlh_probe_copy_bandwidth.argtypes = [vp, sz, i32, fp]
-    L.jxlh_frame_path.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    if hasattr(L, "jxlh_frame_path"):
+        L.jxlh_frame_path.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     L.jxlh_frame_rerender_groups.argtypes = [vp, vp, u32]
     L.jxlh_comm_allgather_local.argtypes = [C.POINTER(vp), i32, C.POINTER(vp), sz]
     L.jxlh_palette_strided.argtypes = [vp, vp, sz, vp, i32, sz, i32, i32, vp, sz]
