@@ -100,5 +100,20 @@ for ne in (1, 2):
     out[f"pipelined_nosync_ms_{ne}ctx"] = round((time.perf_counter() - t0) / 12 * 1e3, 3)
     for c in cx[1:]:
         c.close()
+# deeper pipelines with ONE slot stream per context (same number of streams as 2 contexts x 2 slots)
+for ne, nsl in ((3, 1), (4, 1), (2, 1)):
+    cx = [make(nsl) for _ in range(ne)]
+    for c in cx:
+        submit(c, nsl); c.frame_run(); c.sync()
+    for i in range(ne + 4):
+        c = cx[i % ne]; c.sync(); submit(c, nsl); c.frame_run()
+    [c.sync() for c in cx]
+    t0 = time.perf_counter()
+    for i in range(12):
+        c = cx[i % ne]; c.sync(); submit(c, nsl); c.frame_run()
+    [c.sync() for c in cx]
+    out[f"pipelined_ms_{ne}ctx_{nsl}slot"] = round((time.perf_counter() - t0) / 12 * 1e3, 3)
+    for c in cx:
+        c.close()
 print(json.dumps(out))
 c0.close()
