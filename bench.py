@@ -287,7 +287,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        try:  # device_id: no guessing of the rank -> GPU mapping (a heterogeneous guess can hang the first collective)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        except TypeError:
+            dist.init_process_group("nccl", rank=rank, world_size=world)
     n_gpus = max(world, 1)
     assert n_gpus == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N"
 
