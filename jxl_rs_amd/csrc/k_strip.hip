@@ -257,8 +257,8 @@ __global__ __launch_bounds__(kNT, JXLH_STRIP_WPE) void k123_strip(const FrameDev
   __shared__ __attribute__((aligned(16))) float s_save[3 * kCarry * kBW];
   __shared__ float s_sigma[kSigH * kSigW];
   __shared__ uint16_t s_list[kBH * kStrips];
-  __shared__ uint8_t s_wtask[4][448];  // per quadrant: pass 1 / pass 2 tasks by length class
-  __shared__ int s_wn[4][6];           // ... and their counts
+  __shared__ uint16_t s_task[2][896];  // pass 1 / pass 2 tasks of the tile by length class: [0, 512) 8, [512, 768) 16, [768, 896) 32
+  __shared__ int s_ntask[2][3];        // ... and their counts
   __shared__ uint32_t s_bk[64];        // per block of the tile, see (0)
   __shared__ int s_bt[64], s_bc[64];
   __shared__ float s_sdy[64];
@@ -363,6 +363,7 @@ __global__ __launch_bounds__(kNT, JXLH_STRIP_WPE) void k123_strip(const FrameDev
       }
       const float* lf_tile = s_lf[(t - t_begin) & 1];
       if (tid == 0) s_pub = 0;
+      if (tid >= 64 && tid < 70) s_ntask[(tid - 64) / 3][(tid - 64) % 3] = 0;
       __syncthreads();
       prefetch_meta(t + 1, tid);
       PROF_MARK(0);
@@ -372,47 +373,52 @@ __global__ __launch_bounds__(kNT, JXLH_STRIP_WPE) void k123_strip(const FrameDev
       const int qbx = (q & 1) * 4, qby = (q >> 1) * 4;  // the quadrant's first block inside the tile
       if (mode == 0) {
         if (JXLH_STRIP_ABLATE & 64) {
-        } else if (wave < 4) {
-          // ---- (1a) wavefront w: the tasks of the two IDCT passes in quadrant w (the same for every channel), by length:
-          // [0, 128) 8, [128, 192) 16, [192, 224) 32.  pass 1 candidates: (row y of the quadrant, block column): a task
-          // iff the block is the leftmost of its varblock; pass 2: (column x, block row): iff it is the topmost
-          const int wbx = (wave & 1) * 4, wby = (wave >> 1) * 4;
-          uint8_t* wl = s_wtask[wave];
-          int n1[3] = {0, 0, 0}, n2[3] = {0, 0, 0};
+        } else if (wave < 8) {
+          // ---- (1a) the tasks of the two IDCT passes, tile-wide and the same for every channel, by length: [0, 512) 8,
+          // [512, 768) 16, [768, 896) 32.  Wavefront w: pass 1 candidates (row y of block row w, block column): a task
+          // iff the block is the leftmost of its varblock; pass 2 (column x of block column w, block row): iff it is
+          // the topmost.  Pooled over the whole tile and (below) the three channels, so that the rounds of the long
+          // transforms run with full lanes: per-quadrant lists left them a quarter full (99 M of the kernel's 307 M
+          // vector instructions per 8K frame were these passes).
+          {
+            const int bxc = lane & 7, y = wave * 8 + (lane >> 3);
+            const uint32_t bk = s_bk[wave * 8 + bxc];
+            const bool act = (bk >> 26) & 1u;
+            const int lcx = (bk >> 19) & 3;
 #pragma unroll
-          for (int r = 0; r < 2; r++) {
-            const int cand = r * 64 + lane;
-            {
-              const int y = cand >> 2, bxc = cand & 3;
-              const uint32_t bk = s_bk[(wby + (y >> 3)) * 8 + wbx + bxc];
-              const bool act = (bk >> 26) & 1u;
-              const int lcx = (bk >> 19) & 3;
-#pragma unroll
-              for (int k = 0; k < 3; k++) {
-                const unsigned long long m = __ballot(act && lcx == k);
-                if (act && lcx == k) wl[(k == 0 ? 0 : k == 1 ? 128 : 192) + n1[k] + __popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)cand;
-                n1[k] += __popcll(m);
-              }
-            }
-            {
-              const int x = cand & 31, byc = cand >> 5;
-              const uint32_t bk = s_bk[(wby + byc) * 8 + wbx + (x >> 3)];
-              const bool act = (bk >> 27) & 1u;
-              const int lcy = (bk >> 17) & 3;
-#pragma unroll
-              for (int k = 0; k < 3; k++) {
-                const unsigned long long m = __ballot(act && lcy == k);
-                if (act && lcy == k) wl[224 + (k == 0 ? 0 : k == 1 ? 128 : 192) + n2[k] + __popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)cand;
-                n2[k] += __popcll(m);
+            for (int k = 0; k < 3; k++) {
+              const unsigned long long m = __ballot(act && lcx == k);
+              if (m) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&s_ntask[0][k], __popcll(m));
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (act && lcx == k)
+                  s_task[0][(k == 0 ? 0 : k == 1 ? 512 : 768) + base + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(y << 3 | bxc);
               }
             }
           }
-          if (lane < 6) s_wn[wave][lane] = lane == 0 ? n1[0] : lane == 1 ? n1[1] : lane == 2 ? n1[2] : lane == 3 ? n2[0] : lane == 4 ? n2[1] : n2[2];
-        } else if (wave < 7) {
-          // ---- (1c) LLF-from-LF of channel wave - 4 (one lane per block; the first block of a varblock acts) over the
+          {
+            const int byc = lane >> 3, x = wave * 8 + (lane & 7);
+            const uint32_t bk = s_bk[byc * 8 + wave];
+            const bool act = (bk >> 27) & 1u;
+            const int lcy = (bk >> 17) & 3;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+              const unsigned long long m = __ballot(act && lcy == k);
+              if (m) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&s_ntask[1][k], __popcll(m));
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (act && lcy == k)
+                  s_task[1][(k == 0 ? 0 : k == 1 ? 512 : 768) + base + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(x << 3 | byc);
+              }
+            }
+          }
+        } else if (wave < 11) {
+          // ---- (1c) LLF-from-LF of channel wave - 8 (one lane per block; the first block of a varblock acts) over the
           // lowest frequencies; the dequantisation skips that corner, which the LLF overwrites in the reference
           // (transform.rs:450)
-          const int c = wave - 4;
+          const int c = wave - 8;
           const uint32_t bk = s_bk[lane];
           if ((bk >> 26 & 3u) == 3u) {
             const float* lf = lf_tile + c * 64 + lane;
@@ -489,35 +495,34 @@ __global__ __launch_bounds__(kNT, JXLH_STRIP_WPE) void k123_strip(const FrameDev
         __syncthreads();
         PROF_MARK(2);
         // ---- (1d) pass 1 (along u: window rows), (1e) pass 2 (along v: window columns); idct2d.rs:111-131 order.
-        // Wave-local from here: only this wavefront touches channel ch of quadrant q.
-        {
-          const uint8_t* wl = s_wtask[q];
-          float* qorg = s_buf + ch * kPlane + (kCarry + 8 * qby) * kBW + kB + 8 * qbx;
+        // Batches of 64 tasks of one length over (channel, list entry), the long ones first, batch b on wavefront b % 12.
 #pragma unroll
-          for (int pass = 0; pass < 2; pass++) {
-#pragma unroll
-            for (int k = 2; k >= 0; k--) {  // the long transforms first
-              const int n = (JXLH_STRIP_ABLATE & 16) ? 0 : s_wn[q][pass * 3 + k];
-              for (int i0 = 0; i0 < n; i0 += 64) {
-                if (i0 + lane < n) {
-                  const int e = wl[pass * 224 + (k == 0 ? 0 : k == 1 ? 128 : 192) + i0 + lane];
-                  if (pass == 0) {
-                    float* p = qorg + (e >> 2) * kBW + (e & 3) * 8;
-                    if (k == 2) idct_line<32, 1>(p);
-                    else if (k == 1) idct_line<16, 1>(p);
-                    else idct_line<8, 1>(p);
-                  } else {
-                    float* p = qorg + (e >> 5) * 8 * kBW + (e & 31);
-                    if (k == 2) idct_line<32, kBW>(p);
-                    else if (k == 1) idct_line<16, kBW>(p);
-                    else idct_line<8, kBW>(p);
-                  }
-                }
+        for (int pass = 0; pass < 2; pass++) {
+          const int m8 = s_ntask[pass][0], m16 = s_ntask[pass][1], m32 = s_ntask[pass][2];
+          const int b32 = (3 * m32 + 63) >> 6, b16 = (3 * m16 + 63) >> 6, b8 = (3 * m8 + 63) >> 6;
+          const int nb = (JXLH_STRIP_ABLATE & 16) ? 0 : b32 + b16 + b8;
+          for (int bt = wave; bt < nb; bt += kNW) {
+            const int cls = bt < b32 ? 2 : bt < b32 + b16 ? 1 : 0;  // wave-uniform
+            const int per = cls == 2 ? m32 : cls == 1 ? m16 : m8;
+            const int i = (bt - (cls == 2 ? 0 : cls == 1 ? b32 : b32 + b16)) * 64 + lane;
+            if (i < 3 * per) {
+              const int c = (i >= per ? 1 : 0) + (i >= 2 * per ? 1 : 0);
+              const int e = s_task[pass][(cls == 0 ? 0 : cls == 1 ? 512 : 768) + i - c * per];
+              float* p = s_buf + c * kPlane + kCarry * kBW + kB +
+                         (pass == 0 ? (e >> 3) * kBW + (e & 7) * 8 : (e & 7) * 8 * kBW + (e >> 3));
+              if (pass == 0) {
+                if (cls == 2) idct_line<32, 1>(p);
+                else if (cls == 1) idct_line<16, 1>(p);
+                else idct_line<8, 1>(p);
+              } else {
+                if (cls == 2) idct_line<32, kBW>(p);
+                else if (cls == 1) idct_line<16, kBW>(p);
+                else idct_line<8, kBW>(p);
               }
             }
-            wave_sync();
-            PROF_MARK(3 + pass);
           }
+          __syncthreads();
+          PROF_MARK(3 + pass);
         }
       } else {
         // ---- (1') a tile K1's class kernels reconstructed: 8x8-tiled planes -> window (a lane fetches 4 rows of a column)
