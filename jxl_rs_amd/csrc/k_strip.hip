@@ -31,11 +31,16 @@
 // tile above the band without filtering it (seed), its last step the tile below (for the 4 rows the last output rows
 // read): 2 extra transforms per band and strip instead of a dependency between bands.
 //
-// Which tiles: a tile is transformed here iff every varblock touching it lies inside it and is a DCT with sides <= 32
-// (k1_scan decides per tile and writes a descriptor per block: varblocks need not be aligned in the format, frame/
-// modular/mod.rs:1061-1064 only confines them to their group, but libjxl's encoder aligns them to their own size,
-// which closes every 64x64 tile).  Any other tile is reconstructed by K1's class kernels into `planes` as before and
-// merely LOADED into the window here, so a frame may mix both kinds freely.
+// Which tiles: a tile is transformed here iff every varblock touching it is a DCT with sides <= 32 that lies inside
+// one 32x32 quadrant of it (k1_scan decides per tile and writes a descriptor per block: varblocks need not be aligned
+// in the format, frame/modular/mod.rs:1061-1064 only confines them to their group, but libjxl's encoder aligns them to
+// their own size, which closes every quadrant).  Any other tile is reconstructed by K1's class kernels into `planes` as
+// before and merely LOADED into the window here, so a frame may mix both kinds freely.
+//
+// Status (round 4): bit-identical to the two-kernel path on every test, 2.35 GB of HBM traffic per
+// 8K frame instead of 3.58 -- and 1.0-1.14 ms against 0.74-0.80: opt-in (JXLH_FRAME_STRIP).  Both forms are bound by
+// instruction issue on MI355X; this one issues 1.3x the instructions on one critical path with two workgroups per CU
+// to hide its barriers and exchange latency.
 //
 // Synchronisation.  Workgroups take a ticket; ticket k = strip k % S of band k / S, so a workgroup's neighbours hold
 // adjacent tickets.  A workgroup publishes step q before it waits for its neighbours' step q, hence with R resident
@@ -43,7 +48,7 @@
 // worst) and ticket 0 always runs to completion when R exceeds the step count; waits are bounded by a deadline that
 // raises JXLH_ERR_DEVICE instead of hanging the device.
 //
-// Bit-exactness: every arithmetic step is the code K1 and the fused filter kernel run (dequant4, llf_from_lf,
+// Bit-exactness: every arithmetic step is the code K1 and the fused filter kernel run (dequant4t, llf_from_lf,
 // idct1d, filters_core.inc) in the same order; only where the operands live differs.
 #include "k_vardct_common.h"
 
