@@ -301,6 +301,19 @@ jxlh_status jxlh_ctx_sync(jxlh_ctx* ctx);
 jxlh_status jxlh_frame_read_planes(jxlh_ctx* ctx, const jxlh_plane out[3]);
 /* device-resident result (row stride in floats), valid until the next frame_begin */
 jxlh_status jxlh_frame_device_planes(jxlh_ctx* ctx, float* planes[3], size_t* stride);
+/* Extra channels of the frame (alpha, depth, ...: channels 3 + ec of the reference's pipeline, frame/render.rs:564-567,
+ * :624-637, :655-671).  jxlh_frame_set_extra_channel hands over Modular channel `ec` as decoded -- w x h i32 samples at
+ * row stride `stride` (host or device memory) --; the next jxlh_frame_run (whole frame) applies
+ * ConvertModularToF32Stage with the channel's bit depth (render/stages/convert.rs:488-533) and, for
+ * ec_upsampling = 2 / 4 / 8, Upsample2x / 4x / 8x with the weights of jxlh_set_upsampling_weights
+ * (render/stages/upsample.rs) -- before the colour channels' own upsampling or together with it, the result is the
+ * same per channel.  ec_upsampling counts from the channel's own resolution: w = ceil(full width / ec_upsampling).
+ * jxlh_frame_read_extra_channel copies the finished channel out: out_w x out_h f32 samples with
+ * out_w = min(w * ec_upsampling, width of the frame's result), likewise the height.  Up to JXLH_MAX_EXTRA_CHANNELS. */
+#define JXLH_MAX_EXTRA_CHANNELS 8
+jxlh_status jxlh_frame_set_extra_channel(jxlh_ctx* ctx, uint32_t ec, const int32_t* samples, size_t stride, uint32_t w,
+                                         uint32_t h, uint32_t bits_per_sample, uint32_t ec_upsampling);
+jxlh_status jxlh_frame_read_extra_channel(jxlh_ctx* ctx, uint32_t ec, const jxlh_plane* out);
 /* smoothed LF image as used by K1 (tests) */
 jxlh_status jxlh_frame_read_lf(jxlh_ctx* ctx, float* x, float* y, float* b, size_t stride);
 

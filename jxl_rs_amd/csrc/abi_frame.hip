@@ -161,9 +161,14 @@ void jxlh_ctx_destroy(jxlh_ctx* ctx) {
   for (auto& b : ctx->ups) release(b);
   for (auto& b : ctx->noise) release(b);
   release(ctx->xs_jump);
-  release(ctx->ups_kernels);
+  for (auto& b : ctx->ups_kernels_n) release(b);
   if (ctx->host_flag) (void)hipHostFree(ctx->host_flag);
   release(ctx->worklist);
+  for (auto& e : ctx->extra) {
+    release(e.raw);
+    release(e.f32);
+    release(e.out);
+  }
   release(ctx->strip_desc);
   release(ctx->strip_mode);
   release(ctx->strip_xchg);
@@ -309,6 +314,7 @@ jxlh_status jxlh_frame_begin(jxlh_ctx* ctx, const jxlh_frame_params* p) {
   ctx->has_special = ctx->has_large = false;
   ctx->strip_all_closed = true;
   ctx->strip_ran = false;
+  for (auto& e : ctx->extra) e.set = e.done = false;
   for (auto& s : ctx->slots) s.used = false;
   for (int c = 0; c < 3; c++) ctx->result[c] = nullptr;
   ctx->chroma_lazy = false;
@@ -324,6 +330,7 @@ jxlh_status jxlh_set_upsampling_weights(jxlh_ctx* ctx, const float* weights2, co
   for (int i = 0; i < 3; i++) {
     if (src[i]) ctx->ups_weights[i].assign(src[i], src[i] + cnt[i]);
     else ctx->ups_weights[i].clear();
+    ctx->ups_valid[i] = false;
   }
   return JXLH_OK;
 }
@@ -551,13 +558,18 @@ void materialise_chroma(jxlh_ctx* ctx) {
 jxlh_status upload_upsampling_kernels(jxlh_ctx* ctx, int n) {
   const int slot = n == 2 ? 0 : n == 4 ? 1 : 2;
   const float* dflt = n == 2 ? kDefaultUpsamplingWeights2 : n == 4 ? kDefaultUpsamplingWeights4 : kDefaultUpsamplingWeights8;
-  const float* w = ctx->ups_weights[slot].empty() ? dflt : ctx->ups_weights[slot].data();
-  std::vector<float> flat((size_t)n * n * 25);
-  expand_upsampling_kernels(n, w, flat.data());
-  if (jxlh_status st = ensure(ctx, ctx->ups_kernels, flat.size())) return st;
-  // pageable source: the copy is staged by the runtime before the call returns
-  HIPCHK(ctx, hipMemcpyAsync(ctx->ups_kernels.p, flat.data(), flat.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-  JXLH_SYNC(ctx);
+  if (!ctx->ups_valid[slot]) {
+    const float* w = ctx->ups_weights[slot].empty() ? dflt : ctx->ups_weights[slot].data();
+    std::vector<float> flat((size_t)n * n * 25);
+    expand_upsampling_kernels(n, w, flat.data());
+    if (jxlh_status st = ensure(ctx, ctx->ups_kernels_n[slot], flat.size())) return st;
+    // pageable source: the copy is staged by the runtime before the call returns
+    HIPCHK(ctx, hipMemcpyAsync(ctx->ups_kernels_n[slot].p, flat.data(), flat.size() * sizeof(float), hipMemcpyHostToDevice,
+                               ctx->stream));
+    JXLH_SYNC(ctx);
+    ctx->ups_valid[slot] = true;
+  }
+  ctx->ups_kernels.p = ctx->ups_kernels_n[slot].p;  // one buffer per factor: an extra channel's factor may differ from the frame's
   return JXLH_OK;
 }
 
@@ -917,7 +929,41 @@ jxlh_status run_post_stages(jxlh_ctx* ctx, float* const cur[3], int y_lo, int y_
     launch_noise_apply(ctx->stream, nz, ctx->res_stride, ctx->result, ctx->res_stride, W, H, ya, yb, p.noise_lut, ytox,
                        ytob);
   }
+  if (whole_frame)
+    if (jxlh_status st = run_extra_channels(ctx)) return st;
   HIPCHK(ctx, hipGetLastError());
+  return JXLH_OK;
+}
+
+// channels 3.. of the reference's pipeline: ConvertModularToF32Stage, then Upsample<N> by the channel's own factor
+// (frame/render.rs:564-567, :624-637 / :655-671)
+jxlh_status run_extra_channels(jxlh_ctx* ctx) {
+  for (int i = 0; i < JXLH_MAX_EXTRA_CHANNELS; i++) {
+    jxlh_ctx::ExtraChannel& e = ctx->extra[i];
+    if (!e.set) continue;
+    const size_t n = (size_t)e.w * e.h;
+    if (jxlh_status st = ensure(ctx, e.f32, n)) return st;
+    {
+      ScopedKernelTimer t(ctx, "k_modular_to_f32");
+      launch_modular_to_f32(ctx->stream, e.raw.p, n, 1.0f / (float)((1ull << e.bits) - 1), e.f32.p);
+    }
+    // the frame's result size bounds the channel's (the padding of ceil(size / factor) * factor is cut off)
+    const uint32_t full_w = (uint32_t)(ctx->res_w > 0 ? ctx->res_w : ctx->fd.xsize),
+                   full_h = (uint32_t)(ctx->res_h > 0 ? ctx->res_h : ctx->fd.ysize);
+    e.out_w = std::min(e.w * e.up, full_w);
+    e.out_h = std::min(e.h * e.up, full_h);
+    if (e.up > 1) {
+      if (jxlh_status st = upload_upsampling_kernels(ctx, (int)e.up)) return st;
+      e.out_stride = round_up((size_t)e.w * e.up, 64);
+      if (jxlh_status st = ensure(ctx, e.out, e.out_stride * (size_t)e.h * e.up)) return st;
+      ScopedKernelTimer t(ctx, "k_upsample");
+      launch_upsample(ctx->stream, (int)e.up, e.f32.p, e.w, (int)e.w, (int)e.h, ctx->ups_kernels.p, e.out.p, e.out_stride,
+                      (int)e.out_w, (int)e.out_h);
+    } else {
+      e.out_stride = e.w;
+    }
+    e.done = true;
+  }
   return JXLH_OK;
 }
 }  // namespace jxlh_host
@@ -1014,6 +1060,45 @@ jxlh_status jxlh_frame_rerender_groups(jxlh_ctx* ctx, const uint32_t* group_ids,
     prev_hi = hi;
   }
   return JXLH_OK;
+}
+
+jxlh_status jxlh_frame_set_extra_channel(jxlh_ctx* ctx, uint32_t ec, const int32_t* samples, size_t stride, uint32_t w,
+                                         uint32_t h, uint32_t bits_per_sample, uint32_t ec_upsampling) {
+  JXLH_ON_DEVICE(ctx);
+  if (!ctx || !samples || ec >= JXLH_MAX_EXTRA_CHANNELS || w == 0 || h == 0 || stride < w || bits_per_sample == 0 ||
+      bits_per_sample > 31 || (ec_upsampling != 1 && ec_upsampling != 2 && ec_upsampling != 4 && ec_upsampling != 8))
+    return JXLH_ERR_INVALID_ARGUMENT;
+  if (!ctx->in_frame) return JXLH_ERR_BAD_STATE;
+  if ((uint64_t)w * h >= (1ull << 31)) return JXLH_ERR_UNSUPPORTED;
+  jxlh_ctx::ExtraChannel& e = ctx->extra[ec];
+  if (jxlh_status st = ensure(ctx, e.raw, (size_t)w * h)) return st;
+  if (jxlh_status st = copy2d(ctx, e.raw.p, (size_t)w * sizeof(int32_t), samples, stride * sizeof(int32_t),
+                              (size_t)w * sizeof(int32_t), h, ctx->stream))
+    return st;
+  JXLH_SYNC(ctx);  // the caller's buffer may be reused as soon as the call returns
+  e.w = w;
+  e.h = h;
+  e.bits = bits_per_sample;
+  e.up = ec_upsampling;
+  e.set = true;
+  e.done = false;
+  return JXLH_OK;
+}
+
+jxlh_status jxlh_frame_read_extra_channel(jxlh_ctx* ctx, uint32_t ec, const jxlh_plane* out) {
+  JXLH_ON_DEVICE(ctx);
+  if (!ctx || !out || ec >= JXLH_MAX_EXTRA_CHANNELS) return JXLH_ERR_INVALID_ARGUMENT;
+  if (!ctx->in_frame) return JXLH_ERR_BAD_STATE;
+  const jxlh_ctx::ExtraChannel& e = ctx->extra[ec];
+  if (!e.set || !e.done) return JXLH_ERR_BAD_STATE;  // handed over but no jxlh_frame_run since
+  if (!out->ptr || out->bytes_per_row < (size_t)e.out_w * sizeof(float) || out->num_rows < e.out_h ||
+      out->bytes_between_rows < out->bytes_per_row)
+    return JXLH_ERR_INVALID_ARGUMENT;
+  const float* src = e.up > 1 ? e.out.p : e.f32.p;
+  if (jxlh_status st = copy2d(ctx, out->ptr, out->bytes_between_rows, src, e.out_stride * sizeof(float),
+                              (size_t)e.out_w * sizeof(float), e.out_h, ctx->stream))
+    return st;
+  return jxlh_ctx_sync(ctx);
 }
 
 jxlh_status jxlh_ctx_sync(jxlh_ctx* ctx) {

@@ -90,7 +90,11 @@ struct jxlh_ctx {
   DevBuf<float> noise[3];      // random planes of the noise synthesis
   DevBuf<uint64_t> xs_jump;    // xorshift128+ jump matrices T^(2^j), uploaded on first use
   DevBuf<float> ups[3];        // upsampled planes
-  DevBuf<float> ups_kernels;   // expanded 5x5 kernels of the frame's factor
+  // expanded 5x5 kernels per factor (2, 4, 8), uploaded on first use and whenever jxlh_set_upsampling_weights changes
+  // the weights; ups_kernels = the set the last upload_upsampling_kernels call selected
+  DevBuf<float> ups_kernels_n[3];
+  bool ups_valid[3] = {false, false, false};
+  struct { float* p = nullptr; } ups_kernels;
   std::vector<float> ups_weights[3];  // custom weights2 / weights4 / weights8 (empty = defaults)
   // stage hooks scratch
   DevBuf<float> hook_f[8];
@@ -123,6 +127,16 @@ struct jxlh_ctx {
   std::vector<uint8_t> bucketed;
   bool epoch_dirty = false;
   bool sp_sorted_valid = false;
+  // extra channels inside the frame path (jxlh_frame_set_extra_channel): as handed over, converted, upsampled
+  struct ExtraChannel {
+    bool set = false, done = false;
+    uint32_t w = 0, h = 0, bits = 0, up = 1;
+    uint32_t out_w = 0, out_h = 0;
+    size_t out_stride = 0;
+    DevBuf<int32_t> raw;
+    DevBuf<float> f32, out;
+  };
+  ExtraChannel extra[JXLH_MAX_EXTRA_CHANNELS];
   // strip path (k_strip.hip): block descriptors / tile modes written by k1_scan, the strips' edge-column exchange
   // buffer, progress flags + ticket.  strip_all_closed: every rect of the transform map came from host memory and
   // every varblock in it is a small DCT inside its 64x64 tile (jxlh_frame_set_hf_meta); strip_ran: the last
@@ -250,6 +264,7 @@ jxlh_status run_k1(jxlh_ctx* ctx, const RunPlan& plan, int gr0, int gr1);
 jxlh_status run_stages(jxlh_ctx* ctx, const RunPlan& plan, uint32_t group_row0, uint32_t group_row1);
 jxlh_status run_stages_rows(jxlh_ctx* ctx, const RunPlan& plan, int y_lo, int y_hi, bool whole_frame);
 jxlh_status run_post_stages(jxlh_ctx* ctx, float* const cur[3], int y_lo, int y_hi, bool whole_frame);
+jxlh_status run_extra_channels(jxlh_ctx* ctx);  // ConvertModularToF32 + Upsample of the channels handed over
 bool strip_eligible(const jxlh_ctx* ctx);
 jxlh_status run_strip(jxlh_ctx* ctx, const RunPlan& plan);
 // Where run_stages leaves the finished planes (1 = f.tmp, 0 = f.planes): a property of the frame's stage list, so a

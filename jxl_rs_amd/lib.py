@@ -41,7 +41,7 @@ ABI_SYMBOLS = [
     "jxlh_submit_group_sparse", "jxlh_submit_groups_sparse", "jxlh_submit_groups_sparse8", "jxlh_submit_groups_sparse4",
     "jxlh_submit_groups_slots", "jxlh_slot_wait",
     "jxlh_frame_coeff_buffer", "jxlh_frame_run", "jxlh_ctx_sync", "jxlh_frame_read_planes",
-    "jxlh_frame_device_planes", "jxlh_frame_read_lf", "jxlh_frame_read_rgb8", "jxlh_frame_read_rgb8_async",
+    "jxlh_frame_device_planes", "jxlh_frame_set_extra_channel", "jxlh_frame_read_extra_channel", "jxlh_frame_read_lf", "jxlh_frame_read_rgb8", "jxlh_frame_read_rgb8_async",
     "jxlh_frame_read_rgb16", "jxlh_frame_read_ycbcr_rgb8", "jxlh_frame_read_ycbcr_rgb16", "jxlh_frame_read_output",
     "jxlh_frame_read_output_async", "jxlh_stage_chroma_upsample", "jxlh_stage_upsample",
     "jxlh_set_upsampling_weights", "jxlh_stage_noise_generate", "jxlh_stage_noise_convolve", "jxlh_stage_noise_add",
@@ -197,8 +197,11 @@ def load():
     L.jxlh_frames_allgather_local.argtypes = [C.POINTER(vp), i32]
     L.jxlh_comm_allgather.argtypes = [vp, vp, sz]
     L.jxlh_probe_copy_bandwidth.argtypes = [vp, sz, i32, fp]
-    if hasattr(L, "jxlh_frame_path"):
+    if hasattr(L, "jxlh_frame_path"):  # absent from older builds used in A/B runs (JXLH_LIBRARY)
         L.jxlh_frame_path.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    if hasattr(L, "jxlh_frame_set_extra_channel"):
+        L.jxlh_frame_set_extra_channel.argtypes = [vp, u32, vp, sz, u32, u32, u32, u32]
+        L.jxlh_frame_read_extra_channel.argtypes = [vp, u32, C.POINTER(Plane)]
     L.jxlh_frame_rerender_groups.argtypes = [vp, vp, u32]
     L.jxlh_comm_allgather_local.argtypes = [C.POINTER(vp), i32, C.POINTER(vp), sz]
     L.jxlh_palette_strided.argtypes = [vp, vp, sz, vp, i32, sz, i32, i32, vp, sz]
@@ -517,6 +520,19 @@ class Context:
         v = C.c_float()
         self._chk(self.L.jxlh_probe_copy_bandwidth(self._ctx, nbytes, reps, C.byref(v)), "probe_copy_bandwidth")
         return v.value
+
+    def set_extra_channel(self, ec, samples, bits_per_sample, ec_upsampling=1):
+        """hands Modular channel 3 + ec over as decoded (i32 [h, w]); processed by the next frame_run"""
+        a = np.ascontiguousarray(samples, dtype=np.int32)
+        h, w = a.shape
+        self._chk(self.L.jxlh_frame_set_extra_channel(self._ctx, ec, _addr(a), w, w, h, bits_per_sample, ec_upsampling),
+                  "frame_set_extra_channel")
+
+    def read_extra_channel(self, ec, out_w, out_h):
+        out = np.zeros((out_h, out_w), dtype=np.float32)
+        pl = Plane(out.ctypes.data, out_w * 4, out_h, out_w * 4)
+        self._chk(self.L.jxlh_frame_read_extra_channel(self._ctx, ec, C.byref(pl)), "frame_read_extra_channel")
+        return out
 
     def frame_path(self):
         """(strip kernel ran, 64x64 tiles of the frame, tiles left to the transform class kernels) of the last frame_run"""

@@ -399,6 +399,52 @@ def test_upsampled_frame_bit_exact(ctx, oracle, kat, n, size, up_size):
     assert np.array_equal(ctx.read_rgb8(params, 3), want8)
 
 
+@pytest.mark.parametrize("n,size,up_size,strip", [(2, (300, 270), (599, 539), False), (1, (264, 200), None, False),
+                                                  (4, (77, 33), (305, 130), False), (2, (264, 200), None, True)])
+def test_extra_channels_inside_the_frame_path(ctx, oracle, n, size, up_size, strip):
+    """channels 3.. of the reference's pipeline (frame/render.rs:564-567, :624-637, :655-671): handed over as decoded
+    Modular channels, converted (ConvertModularToF32Stage with the channel's bit depth) and upsampled by their OWN
+    factor -- equal to the frame's (the late case), larger, or none -- by the same jxlh_frame_run that renders the colour
+    channels, through the two-kernel path and through the strip kernel"""
+    from jxl_rs_amd import synth, JxlHipError
+    w, h = size
+    wl = synth.make_vardct(w, h, mix=synth.MIX_D1, seed=w + h + n, epf_iters=2, aligned=True)
+    ow, oh = up_size if up_size else (w * n, h * n)
+    over = dict(upsampling=n) if n > 1 else {}
+    if up_size:
+        over.update(xsize_upsampled=ow, ysize_upsampled=oh)
+    if strip:
+        over["flags"] = 4  # JXLH_FRAME_STRIP
+    upload_frame(ctx, wl, **over)
+    rng = np.random.default_rng(w * 3 + n)
+    chans = []
+    for ec, (factor, bits) in enumerate(((max(n, 1), 8), (8, 12), (1, 16))):
+        cw, ch = -(-ow // factor), -(-oh // factor)
+        smp = rng.integers(0, 1 << bits, size=(ch, cw)).astype(np.int32)
+        ctx.set_extra_channel(ec, smp, bits, factor)
+        f32 = oracle.modular_to_f32(smp, bits)
+        want = oracle.upsample(factor, f32)[:oh, :ow] if factor > 1 else f32
+        chans.append((ec, want))
+    with pytest.raises(JxlHipError):
+        ctx.read_extra_channel(0, ow, oh)          # handed over, not rendered yet
+    ctx.frame_run()
+    ctx.sync()
+    assert ctx.frame_path()[0] == strip
+    for ec, want in chans:
+        got = ctx.read_extra_channel(ec, want.shape[1], want.shape[0])
+        assert bit_equal(got, want), f"extra channel {ec}: {diff_report(got, want)}"
+    # the colour channels are what they are without extra channels
+    want_c, _ = run_oracle_frame(oracle, wl)
+    got_c = ctx.read_planes()
+    for c in range(3):
+        ref = oracle.upsample(n, np.ascontiguousarray(want_c[c]))[:oh, :ow] if n > 1 else want_c[c]
+        assert bit_equal(got_c[c], ref)
+    with pytest.raises(JxlHipError):
+        ctx.set_extra_channel(8, np.zeros((4, 4), np.int32), 8, 1)      # index out of range
+    with pytest.raises(JxlHipError):
+        ctx.set_extra_channel(0, np.zeros((4, 4), np.int32), 8, 3)      # not a factor the format has
+
+
 def test_upsampled_frame_argument_errors(ctx):
     from jxl_rs_amd import synth, lib, JxlHipError
     wl = synth.make_vardct(600, 600, mix=synth.MIX_DCT8, seed=1, epf_iters=0, gab=False)
