@@ -189,12 +189,20 @@ struct LoweredPipeline {
   bool has_output = false;     // a colour / conversion tail was given: read through jxlh_frame_read_output
   jxlh_output_desc output{};
   const float* upsampling_weights = nullptr;
+  const float* weights_by_factor[3] = {nullptr, nullptr, nullptr};  // 2x, 4x, 8x: the frame's and the extra channels'
   // Modular frames (Encoding::Modular: the list opens with the Modular -> f32 conversions, frame/render.rs:553-567)
   enum class Modular { kNone, kToF32, kXybToF32, kI32ToU8 } modular = Modular::kNone;
   uint32_t modular_bits = 0;                       // kToF32: bits per integer sample
   std::array<float, 3> modular_quant_factors{};    // kXybToF32
   int32_t i32_to_u8_multiplier = 0, i32_to_u8_max = 0;  // kI32ToU8: ConvertI32ToU8Stage::new(c, mult, max), builder.rs:152-170
   Border input_border{0, 0};   // accumulated BORDER of the in-out stages before any upsampling, in input pixels
+  // Extra channels (pipeline channels 3..): ConvertModularToF32Stage::new(3 + ec, ec_bit_depth) (frame/render.rs:564-567)
+  // and the channel's own Upsample{2,4,8}x::new(transform_data, 3 + ec) (frame/render.rs:624-637, or with the colour
+  // channels when every ec_upsampling equals the frame's, :655-668).  bits == 0: the list does not name the channel.
+  struct Extra {
+    uint32_t bits = 0, upsampling = 1;
+  };
+  std::array<Extra, JXLH_MAX_EXTRA_CHANNELS> extra{};
   std::vector<std::string> stages;  // Display strings, in order (diagnostics; what `info!("adding stage")` logs)
 };
 
@@ -270,6 +278,7 @@ inline LoweredPipeline RenderPipelineBuilder::lower() const {
   };
   bool gab_seen[3] = {false, false, false};
   int ups_seen = 0, ups_factor = 0, conv_seen = 0, convert_seen = 0, modular_seen = 0;
+  const float*(&ec_weights)[3] = lp.weights_by_factor;  // index n >> 2: factor 2, 4, 8
   uint32_t convert_bits = 0;
   bool have_colour = false, have_tf = false, have_save = false, pre_upsample = true, epf1_seen = false, epf2_seen = false;
   Border border{0, 0};
@@ -289,10 +298,19 @@ inline LoweredPipeline RenderPipelineBuilder::lower() const {
       fail(JXLH_ERR_UNSUPPORTED, "stage '" + st->name + "' is not part of the device path");
     } else if (const auto* m = std::get_if<ConvertModularToF32Stage>(&s)) {
       enter(kModular, s);
-      if (m->channel != modular_seen || m->channel > 2 || lp.modular == LoweredPipeline::Modular::kXybToF32)
-        fail(m->channel > 2 ? JXLH_ERR_UNSUPPORTED : JXLH_ERR_INVALID_ARGUMENT, "Modular -> f32 conversion: channels 0, 1, 2 in order (extra channels stay on the CPU pipeline)");
-      if (modular_seen && m->bit_depth != lp.modular_bits) fail(JXLH_ERR_UNSUPPORTED, "colour channels of different bit depths");
       if (m->bit_depth < 1 || m->bit_depth > 31) fail(JXLH_ERR_INVALID_ARGUMENT, "bit depth");
+      if (m->channel > 2) {  // an extra channel: any frame encoding, after the colour conversions
+        const int ec = m->channel - 3;
+        if (ec >= JXLH_MAX_EXTRA_CHANNELS) fail(JXLH_ERR_UNSUPPORTED, "more extra channels than JXLH_MAX_EXTRA_CHANNELS");
+        if (m->channel >= (int)num_channels_ || lp.extra[ec].bits || (ec > 0 && !lp.extra[ec - 1].bits))
+          fail(JXLH_ERR_INVALID_ARGUMENT, "Modular -> f32 conversion of extra channels: channels 3.. in order, once each");
+        if (modular_seen != 0 && modular_seen != 3) fail(JXLH_ERR_INVALID_ARGUMENT, "extra channel conversion between the colour conversions");
+        lp.extra[ec].bits = m->bit_depth;
+        continue;
+      }
+      if (m->channel != modular_seen || lp.modular == LoweredPipeline::Modular::kXybToF32 || lp.extra[0].bits)
+        fail(JXLH_ERR_INVALID_ARGUMENT, "Modular -> f32 conversion: channels 0, 1, 2 in order, before the extra channels");
+      if (modular_seen && m->bit_depth != lp.modular_bits) fail(JXLH_ERR_UNSUPPORTED, "colour channels of different bit depths");
       lp.modular = LoweredPipeline::Modular::kToF32;
       lp.modular_bits = m->bit_depth;
       modular_seen++;
@@ -350,12 +368,23 @@ inline LoweredPipeline RenderPipelineBuilder::lower() const {
       if (const auto* u = std::get_if<Upsample2x>(&s)) n = 2, ch = u->channel, w = u->weights;
       if (const auto* u = std::get_if<Upsample4x>(&s)) n = 4, ch = u->channel, w = u->weights;
       if (const auto* u = std::get_if<Upsample8x>(&s)) n = 8, ch = u->channel, w = u->weights;
-      if (ch > 2) fail(JXLH_ERR_UNSUPPORTED, "upsampling of an extra channel (frame/render.rs:624-637)");
+      if (ch > 2) {  // an extra channel's own factor, or the frame's when it follows channel 2 (late_ec_upsample)
+        const int ec = ch - 3;
+        if (ec >= JXLH_MAX_EXTRA_CHANNELS || !lp.extra[ec].bits) fail(JXLH_ERR_INVALID_ARGUMENT, "upsampling of an extra channel the list never converted to f32");
+        if (lp.extra[ec].upsampling != 1) fail(JXLH_ERR_INVALID_ARGUMENT, "an extra channel is upsampled once");
+        if (ups_seen != 0 && (ups_seen != 3 || n != ups_factor)) fail(JXLH_ERR_INVALID_ARGUMENT, "extra channels upsampled with the colour channels use the frame's factor, after channel 2");
+        if (ec_weights[n >> 2] && ec_weights[n >> 2] != w) fail(JXLH_ERR_INVALID_ARGUMENT, "one weight table per upsampling factor (CustomTransformData)");
+        ec_weights[n >> 2] = w;
+        lp.extra[ec].upsampling = (uint32_t)n;
+        continue;
+      }
+      if (ec_weights[n >> 2] && ec_weights[n >> 2] != w) fail(JXLH_ERR_INVALID_ARGUMENT, "one weight table per upsampling factor (CustomTransformData)");
       if ((ups_factor && ups_factor != n) || ch != ups_seen) fail(JXLH_ERR_INVALID_ARGUMENT, "frame upsampling: channels 0, 1, 2 with one factor");
       if (ups_seen && w != lp.upsampling_weights) fail(JXLH_ERR_INVALID_ARGUMENT, "frame upsampling: one weight table for the three channels");
       ups_factor = n;
       ups_seen++;
       lp.upsampling_weights = w;
+      ec_weights[n >> 2] = w;
       p.upsampling = (uint32_t)n;
       pre_upsample = false;
     } else if (const auto* cn = std::get_if<ConvolveNoiseStage>(&s)) {
@@ -472,13 +501,9 @@ inline LoweredPipeline RenderPipelineBuilder::lower() const {
 class GpuRenderPipeline {
  public:
   GpuRenderPipeline(Context& ctx, LoweredPipeline lp) : ctx_(ctx), lp_(std::move(lp)), frame_(ctx, lp_.frame) {
-    if (lp_.upsampling_weights) {  // CustomTransformData::weights{2,4,8} of the factor in use; the others keep their state
-      const uint32_t n = lp_.frame.upsampling;
-      ctx_.check(jxlh_set_upsampling_weights(ctx_.raw(), n == 2 ? lp_.upsampling_weights : nullptr,
-                                             n == 4 ? lp_.upsampling_weights : nullptr,
-                                             n == 8 ? lp_.upsampling_weights : nullptr),
-                 "jxlh_set_upsampling_weights");
-    }
+    const float* const* w = lp_.weights_by_factor;
+    if (w[0] || w[1] || w[2])  // CustomTransformData::weights{2,4,8} of the factors in use; the others keep their state
+      ctx_.check(jxlh_set_upsampling_weights(ctx_.raw(), w[0], w[1], w[2]), "jxlh_set_upsampling_weights");
   }
   VarDctFrame& frame() { return frame_; }  // decode_hf_global / decode_lf_group / decode_hf_metadata go here
   const LoweredPipeline& lowered() const { return lp_; }
@@ -518,6 +543,20 @@ class GpuRenderPipeline {
     else throw Error(JXLH_ERR_INVALID_ARGUMENT, "GpuRenderPipeline::save", "planar f32 pipeline: use save_planes");
   }
   void save_planes(float* c0, float* c1, float* c2) { frame_.read_planes(c0, c1, c2); }
+  // An extra channel's integer samples as the Modular decoder leaves them (w x h at the channel's own resolution, host
+  // or device memory).  The stage list decides what happens to them: ConvertModularToF32Stage with the channel's bit
+  // depth, then its Upsample stage if it has one; both run inside do_render() behind the colour channels' stages.
+  void set_extra_channel_buffer(uint32_t ec, const int32_t* samples, size_t stride, uint32_t w, uint32_t h) {
+    if (ec >= JXLH_MAX_EXTRA_CHANNELS || !lp_.extra[ec].bits)
+      throw Error(JXLH_ERR_INVALID_ARGUMENT, "GpuRenderPipeline::set_extra_channel_buffer", "the stage list does not name this extra channel");
+    ctx_.check(jxlh_frame_set_extra_channel(ctx_.raw(), ec, samples, stride, w, h, lp_.extra[ec].bits, lp_.extra[ec].upsampling),
+               "jxlh_frame_set_extra_channel");
+  }
+  // the save stage of an extra channel: one f32 plane of the frame's output size (out_width() x out_height())
+  void save_extra_channel(uint32_t ec, float* out, size_t stride) {
+    jxlh_plane pl{out, (size_t)frame_.out_width() * sizeof(float), frame_.out_height(), stride * sizeof(float)};
+    ctx_.check(jxlh_frame_read_extra_channel(ctx_.raw(), ec, &pl), "jxlh_frame_read_extra_channel");
+  }
 
  private:
   Context& ctx_;

@@ -73,7 +73,7 @@ __global__ __launch_bounds__(kScanThreads) void k1_scan(const FrameDev f, const 
     __syncthreads();
   }
   // the counters of the NEXT launch (the other set: its last readers finished before this kernel started)
-  if (blockIdx.x == 0 && threadIdx.x <= kNumClasses) next_counts[threadIdx.x * kCountPitch] = 0;
+  if (blockIdx.x == 0 && threadIdx.x < kCountLines) next_counts[threadIdx.x * kCountPitch] = 0;
   const int sub = threadIdx.x / kThreads, tid = threadIdx.x % kThreads, lane = tid & 63, wave = tid >> 6;
   const int gi = blockIdx.x * kScanGroups + sub;
   const bool live = gi < ngroups;  // a dead quarter walks through the barriers with an empty group
@@ -720,7 +720,8 @@ __global__ __launch_bounds__(kSpecThreads) void k1_special(const FrameDev f, con
 }  // namespace
 
 // ---- host side -----------------------------------------------------------------------------
-static size_t large_unit_capacity(size_t nblocks) { return nblocks / 32 + 16; }
+// the two-pass units (nblocks / 32 + 16) and the three fused lists (/ 32, / 128, / 256, + 16 each), k_vardct_large.hip
+static size_t large_unit_capacity(size_t nblocks) { return nblocks / 8 + 64; }
 // k_vardct_large.hip
 void launch_vardct_large(hipStream_t s, const FrameDev& f, const WorkLists& wl, int nblk, uint32_t* large_units,
                          size_t unit_capacity, size_t nblocks);
@@ -729,8 +730,8 @@ size_t vardct_worklist_bytes(const FrameDev& f) {
   const size_t nblocks = (size_t)f.xblocks * f.yblocks;
   size_t items = 0;
   for (int c = 0; c < kNumClasses; c++) items += nblocks / class_min_area(c) + 1;
-  // + the slab-unit list of the large transforms: one u32 per 4096 samples of large-varblock area, but a 64x32 /
-  // 32x64 varblock (32 blocks, half a slab) still takes a whole unit -> worst case one unit per 32 blocks
+  // + the unit lists of the large transforms: one u32 per 4096 samples of a 256-pixel varblock (two-pass units) and
+  //   one per varblock of the smaller types (three lists by slabs per channel; worst case one entry per 32 blocks)
   // + the LLF planes of the large transforms (3 x nblocks floats, k1_large_llf)
   return items * sizeof(WorkItem) + 2 * kCountBytes + large_unit_capacity(nblocks) * sizeof(uint32_t) + 64 +
          3 * nblocks * sizeof(float);

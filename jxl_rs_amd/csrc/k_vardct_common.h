@@ -74,10 +74,12 @@ struct BlockInfo {
 // every class counter on its own 128-byte line: the 1024 scan workgroups' atomics then meet on nine lines (and L2
 // channels) instead of one
 constexpr int kCountPitch = 32;
-constexpr size_t kCountBytes = (size_t)(kNumClasses + 1) * kCountPitch * sizeof(int);
+constexpr int kCountLines = kNumClasses + 4;  // the classes, the two-pass slab units, the three fused large lists
+constexpr size_t kCountBytes = (size_t)kCountLines * kCountPitch * sizeof(int);
 struct WorkLists {
   WorkItem* items[kNumClasses];
-  int* counts;  // (kNumClasses + 1) counters at kCountPitch ints, zeroed before k1_scan; the last = large slab units
+  int* counts;  // kCountLines counters at kCountPitch ints, zeroed before k1_scan: the classes, then the large
+                // transforms' unit lists (k_vardct_large.hip: two-pass slab units, fused lists of 1 / 2 / 4 slabs)
 };
 
 __device__ __forceinline__ void decode_item(const FrameDev& f, const WorkItem& it, BlockInfo* bi) {

@@ -30,7 +30,10 @@ namespace jxlh {
 constexpr int kLargeThreads = 256;                 // 4 independent waves per workgroup
 constexpr int kLargeWaves = kLargeThreads / 64;
 constexpr int kLargeSlab = 4096;                   // samples per slab = per wave
-constexpr int kLargeTile = 64 * 65;                // floats of LDS per wave: lines x (N + N/64) for every N >= 64
+constexpr int kLargeTile = 64 * 65;
+#ifndef JXLH_LARGE_BULK
+#define JXLH_LARGE_BULK 8  // rounds of raw coefficient loads in flight per lane in pass 1 (a slab is 16, a half slab 8)
+#endif                // floats of LDS per wave: lines x (N + N/64) for every N >= 64
 
 __device__ __forceinline__ float dpp_xor1(float v) {  // value of lane ^ 1
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
@@ -277,10 +280,11 @@ __device__ __forceinline__ void wave_tile_load_columns(float* __restrict__ tile,
                                                        const PixLayout lay, int x0, int ncols, int nrows, int lane) {
   if (lay.tiled) {
     const int nbx = ncols >> 3, total = (ncols * nrows) >> 2;
-    for (int f0 = 0; f0 < total; f0 += 4 * 64) {  // four 16-byte loads in flight per lane
-      float4 v[4];
+    constexpr int kInFlight = 8;  // 16-byte loads in flight per lane (a full slab is 16)
+    for (int f0 = 0; f0 < total; f0 += kInFlight * 64) {
+      float4 v[kInFlight];
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
+      for (int k = 0; k < kInFlight; k++) {
         const int f = f0 + k * 64 + lane;
         const int blk = f >> 4, x = (f & 15) >> 1, yq = f & 1;
         const int bx = blk % nbx, by = blk / nbx;
@@ -288,7 +292,7 @@ __device__ __forceinline__ void wave_tile_load_columns(float* __restrict__ tile,
                          : make_float4(0.f, 0.f, 0.f, 0.f);
       }
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
+      for (int k = 0; k < kInFlight; k++) {
         const int f = f0 + k * 64 + lane;
         if (f < total) {
           const int blk = f >> 4, x = (f & 15) >> 1, yq = f & 1;
@@ -315,8 +319,8 @@ __device__ __forceinline__ void wave_tile_load_columns(float* __restrict__ tile,
 // (k a multiple of 4); llf_at(i) the LLF corner value i = kr * mx + kq (only called where the corner applies).
 // tile: kLargeTile floats of LDS owned by this wave.
 template <class Coef4, class LlfAt>
-__device__ __forceinline__ void wave_large_pass1(const LargeGeom& g, int v0, Coef4 coef4, LlfAt llf_at,
-                                                 float* __restrict__ plane, const PixLayout lay, float* tile, int lane) {
+__device__ __forceinline__ void wave_large_pass1_stage(const LargeGeom& g, int v0, Coef4 coef4, LlfAt llf_at, float* tile,
+                                                       int lane) {
   const int P = large_pitch(g.C), total4 = (g.C << g.llv) >> 2;
   const bool corner = g.slab_needs_llf(v0);
 #pragma unroll 1
@@ -357,8 +361,125 @@ __device__ __forceinline__ void wave_large_pass1(const LargeGeom& g, int v0, Coe
   }
   wave_sync();
   wave_idct_lines_dyn(g.C, tile, lane);
-  wave_tile_store<true>(tile, P, plane, lay, 0, v0, g.C, g.LV, lane);
+}
+
+// The same with the slab's raw coefficient loads ALL in flight before the first is used (16 x 16 bytes per lane and
+// source array): at two waves per SIMD -- what the LDS tiles allow -- the wave's own loads are the only latency cover it
+// has, and the registers are there (256 per wave).  coef.load(k) issues the loads of coefficients k .. k + 3,
+// coef.finish(k, raw) dequantises them (its table reads hit L2).
+template <class Coef>
+__device__ __forceinline__ void wave_large_pass1_stage_bulk(const LargeGeom& g, int v0, const Coef& coef, float* tile, int lane) {
+  const int P = large_pitch(g.C), total4 = (g.C << g.llv) >> 2;  // 1024, or 512 for the 64x32 / 32x64 half slabs
+  const bool corner = g.slab_needs_llf(v0);
+  auto stored_index = [&](int r, int* at) {
+    const int idx = (r * 64 + lane) * 4;
+    // wide: stored in[v*C + u], u fastest in memory; otherwise in[u*R + v], v fastest
+    const int u = g.wide ? (idx & (g.C - 1)) : (idx >> g.llv), line = g.wide ? (idx >> g.lc) : (idx & (g.LV - 1));
+    const int v = v0 + line;
+    *at = line * P + u;
+    return g.wide ? (v << g.lc) + u : (u << g.lr) + v;
+  };
+  const int step = g.wide ? 1 : P;  // the four values: consecutive u (wide) or consecutive lines
+  const int rounds = total4 >> 6;   // 16, or 8 for the half slabs
+#pragma unroll 1
+  for (int r0 = 0; r0 < rounds; r0 += JXLH_LARGE_BULK) {
+    typename Coef::Raw raw[JXLH_LARGE_BULK];
+#pragma unroll
+    for (int r = 0; r < JXLH_LARGE_BULK; r++) {
+      int at;
+      raw[r] = coef.load(stored_index(r0 + r, &at));
+    }
+#pragma unroll
+    for (int r = 0; r < JXLH_LARGE_BULK; r++) {
+      // the table reads of finish() stay behind the raw loads, 4 rounds of them at a time
+      if (r % 4 == 0) __builtin_amdgcn_sched_barrier(0);
+      int at;
+      const int k = stored_index(r0 + r, &at);
+      float4 c = coef.finish(k, raw[r]);
+      if (corner) {  // LLF overwrites the HF-decoded corner (transform.rs:450)
+        const int kr = k >> g.lm, kq = k & (g.mxRC - 1);
+        if (kr < g.mn && kq < g.mx) {
+          c.x = coef.llf_at(kr * g.mx + kq);
+          if (kq + 1 < g.mx) c.y = coef.llf_at(kr * g.mx + kq + 1);
+          if (kq + 2 < g.mx) c.z = coef.llf_at(kr * g.mx + kq + 2);
+          if (kq + 3 < g.mx) c.w = coef.llf_at(kr * g.mx + kq + 3);
+        }
+      }
+      float* d = tile + at;
+      d[0] = c.x;
+      d[step] = c.y;
+      d[2 * step] = c.z;
+      d[3 * step] = c.w;
+    }
+  }
   wave_sync();
+  wave_idct_lines_dyn(g.C, tile, lane);
+}
+
+template <class Coef4, class LlfAt>
+__device__ __forceinline__ void wave_large_pass1(const LargeGeom& g, int v0, Coef4 coef4, LlfAt llf_at,
+                                                 float* __restrict__ plane, const PixLayout lay, float* tile, int lane) {
+  wave_large_pass1_stage(g, v0, coef4, llf_at, tile, lane);
+  wave_tile_store<true>(tile, large_pitch(g.C), plane, lay, 0, v0, g.C, g.LV, lane);
+  wave_sync();
+}
+
+// Pass 2 of one column slab straight from LDS, for varblocks whose whole channel fits the workgroup's tiles (R * C <=
+// kLargeWaves * kLargeSlab: everything below 256 pixels): `tiles` = the first of the R / LV consecutive wave tiles
+// that hold the pass-1 result (tile s: lines v in [s * LV, (s + 1) * LV), sample x at large_pos(x), line pitch
+// large_pitch(C)).  A lane owns one pixel column (or one length-64 leaf of it, R = 128) exactly as in
+// wave_idct_lines; the results go from registers to the output rectangle -- four consecutive rows of a column are one
+// 16-byte piece of the tiled plane layout -- so the intermediate never leaves the CU.
+template <int N>
+__device__ __forceinline__ void wave_large_pass2_lds(const LargeGeom& g, int x0, const float* __restrict__ tiles,
+                                                     float* __restrict__ plane, const PixLayout lay, int lane) {
+  static_assert(N == 32 || N == 64 || N == 128, "the 256-point columns do not fit a workgroup's LDS");
+  constexpr int K = N == 128 ? 2 : 1, NR = N == 32 ? 32 : 64;
+  const int P1 = large_pitch(g.C);
+  const int leaf = lane & (K - 1), col = lane / K;
+  const bool active = col < g.LX;
+  const float* t = tiles + large_pos(x0 + min(col, g.LX - 1));
+  const int llv = g.llv, lmask = g.LV - 1;
+  // natural sample v of the lane's column (v is a constant after unrolling: the offset is wave-uniform)
+  auto at = [&](int v) -> float { return t[(v >> llv) * kLargeTile + (v & lmask) * P1]; };
+  float x[NR];
+  if constexpr (K == 1) {
+#pragma unroll
+    for (int j = 0; j < NR; j++) x[j] = at(j);
+    idct1d<NR, true>(x);
+  } else {
+    // E[j] = t[2j];  O'[j] = t[2j+1] + t[2j-1], O'[0] = t[1] * sqrt2      (idct_large.rs:284-296)
+    const bool odd = leaf != 0;
+    const float* tl = t + leaf * P1;  // samples 2j and 2j + 1 share a tile (LV is even)
+#pragma unroll
+    for (int j = 0; j < 64; j++) {
+      const float a = tl[((2 * j) >> llv) * kLargeTile + ((2 * j) & lmask) * P1];
+      const float b = at(j ? 2 * j - 1 : 1);
+      x[j] = odd ? (j ? a + b : a * kSqrt2) : a;
+    }
+    idct1d<64, true>(x);
+    leaf_butterfly<128>(x, odd, false, dpp_xor1);
+  }
+  if (!active) return;
+  const int base = leaf * 64;
+  float* d = plane + lay.xoff(x0 + col);
+  if (lay.tiled) {
+#pragma unroll
+    for (int q = 0; q < NR / 4; q++)
+      *reinterpret_cast<float4*>(d + lay.at(0, base + 4 * q)) = make_float4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
+  } else {
+#pragma unroll
+    for (int r = 0; r < NR; r++) d[lay.at(0, base + r)] = x[r];
+  }
+}
+
+__device__ __forceinline__ void wave_large_pass2_lds_dyn(const LargeGeom& g, int x0, const float* tiles, float* plane,
+                                                         const PixLayout lay, int lane) {
+  switch (g.R) {
+    case 32: wave_large_pass2_lds<32>(g, x0, tiles, plane, lay, lane); break;
+    case 64: wave_large_pass2_lds<64>(g, x0, tiles, plane, lay, lane); break;
+    default: wave_large_pass2_lds<128>(g, x0, tiles, plane, lay, lane); break;
+  }
 }
 
 // Pass 2 of ONE slab by ONE wave: pixel columns x0 .. x0 + LX, vertical IDCT in place in the output rectangle.

@@ -178,8 +178,51 @@ int host_checks() {
          "4x stages with a downsampling shift of 1");
   expect(status_of([&] { (void)RenderPipelineBuilder(4, {1000, 700}, 0, 8, base)
                                    .add_inout_stage(Upsample2x{nullptr, 3}).add_save_stage({0, 1, 2}, 0, 3, 32).lower(); }) ==
-             JXLH_ERR_UNSUPPORTED,
-         "extra-channel upsampling stays on the CPU pipeline");
+             JXLH_ERR_INVALID_ARGUMENT,
+         "extra-channel upsampling without the channel's Modular -> f32 conversion");
+  // ---- 5b. extra channels (frame/render.rs:564-567, :624-637, :655-668)
+  {
+    // early: each channel's own factor, behind the filters and before the frame's upsampling
+    auto b = RenderPipelineBuilder(5, {1000, 700}, 0, 8, base)
+                 .add_inout_stage(ConvertModularToF32Stage{3, 8})
+                 .add_inout_stage(ConvertModularToF32Stage{4, 16});
+    const LoweredPipeline lp = add_filters(std::move(b), rf, true, 2)
+                                   .add_inout_stage(Upsample4x{nullptr, 4})
+                                   .add_save_stage({0, 1, 2}, 0, 3, 32)
+                                   .lower();
+    expect(lp.modular == LoweredPipeline::Modular::kNone && lp.extra[0].bits == 8 && lp.extra[0].upsampling == 1 &&
+               lp.extra[1].bits == 16 && lp.extra[1].upsampling == 4 && lp.extra[2].bits == 0 && lp.frame.upsampling == 1,
+           "extra channels: bit depths and the channel's own factor");
+    expect(lp.input_border.x == 4, "extra channels: their upsampling does not touch the colour channels' border");
+    // late: every ec_upsampling equals the frame's, so the extra channels follow channel 2 (frame/render.rs:655-668)
+    static const float w2[15] = {0};
+    jxlh_frame_params half = VarDctFrame::default_params(500, 350);
+    const LoweredPipeline late = RenderPipelineBuilder(4, {1000, 700}, 1, 8, half)
+                                     .add_inout_stage(ConvertModularToF32Stage{3, 10})
+                                     .add_inout_stage(Upsample2x{w2, 0}).add_inout_stage(Upsample2x{w2, 1})
+                                     .add_inout_stage(Upsample2x{w2, 2}).add_inout_stage(Upsample2x{w2, 3})
+                                     .add_save_stage({0, 1, 2}, 0, 3, 32).lower();
+    expect(late.frame.upsampling == 2 && late.extra[0].upsampling == 2 && late.extra[0].bits == 10 && late.weights_by_factor[0] == w2,
+           "extra channels upsampled together with the colour channels");
+    expect(status_of([&] { (void)RenderPipelineBuilder(4, {1000, 700}, 1, 8, half)
+                                     .add_inout_stage(ConvertModularToF32Stage{3, 10})
+                                     .add_inout_stage(Upsample2x{w2, 0}).add_inout_stage(Upsample2x{w2, 3})
+                                     .add_save_stage({0, 1, 2}, 0, 3, 32).lower(); }) == JXLH_ERR_INVALID_ARGUMENT,
+           "an extra channel between the colour channels' upsampling stages");
+    expect(status_of([&] { (void)RenderPipelineBuilder(5, {1000, 700}, 0, 8, base)
+                                     .add_inout_stage(ConvertModularToF32Stage{4, 8})
+                                     .add_save_stage({0, 1, 2}, 0, 3, 32).lower(); }) == JXLH_ERR_INVALID_ARGUMENT,
+           "extra channels out of order");
+    expect(status_of([&] { (void)RenderPipelineBuilder(4, {1000, 700}, 0, 8, base)
+                                     .add_inout_stage(ConvertModularToF32Stage{3, 8}).add_inout_stage(Upsample2x{nullptr, 3})
+                                     .add_inout_stage(Upsample2x{nullptr, 3}).add_save_stage({0, 1, 2}, 0, 3, 32).lower(); }) ==
+               JXLH_ERR_INVALID_ARGUMENT,
+           "an extra channel upsampled twice");
+    expect(status_of([&] { (void)RenderPipelineBuilder(3 + JXLH_MAX_EXTRA_CHANNELS + 1, {1000, 700}, 0, 8, base)
+                                     .add_inout_stage(ConvertModularToF32Stage{3 + JXLH_MAX_EXTRA_CHANNELS, 8})
+                                     .add_save_stage({0, 1, 2}, 0, 3, 32).lower(); }) == JXLH_ERR_UNSUPPORTED,
+           "more extra channels than the device path holds");
+  }
   expect(status_of([&] { (void)add_filters(RenderPipelineBuilder(3, {1000, 700}, 0, 8, base), rf, true, 2).lower(); }) ==
              JXLH_ERR_INVALID_ARGUMENT,
          "a pipeline without save stage");
@@ -228,8 +271,8 @@ int host_checks() {
            "Modular conversion on two channels");
     expect(status_of([&] { (void)RenderPipelineBuilder(4, {1000, 700}, 0, 8, base)
                                      .add_inout_stage(ConvertModularToF32Stage{3, 8}).add_save_stage({0, 1, 2}, 0, 3, 32).lower(); }) ==
-               JXLH_ERR_UNSUPPORTED,
-           "extra-channel conversion stays on the CPU pipeline");
+               JXLH_OK,
+           "a VarDCT frame with one extra channel (its conversion is the only Modular stage of the list)");
     expect(status_of([&] { (void)RenderPipelineBuilder(3, {1000, 700}, 0, 8, base)
                                      .add_inout_stage(ConvertModularToF32Stage{0, 8}).add_inout_stage(ConvertModularToF32Stage{1, 8})
                                      .add_inout_stage(ConvertModularToF32Stage{2, 8}).add_inplace_stage(XybStage{0, some_xyb()})
@@ -250,9 +293,21 @@ int gpu_frame(int w, int h, int epf_iters) {
   try {
     Context ctx(0, 2);
     jxlh_frame_params base = VarDctFrame::default_params((uint32_t)w, (uint32_t)h);
-    auto b = add_filters(RenderPipelineBuilder(3, {(size_t)w, (size_t)h}, 0, 8, base), rf_of(base), true, epf_iters);
+    // two extra channels as frame/render.rs:564-567, :624-637 adds them: 8-bit alpha coded at half resolution
+    // (ec_upsampling 2) and a 16-bit channel at full resolution
+    auto b0 = RenderPipelineBuilder(5, {(size_t)w, (size_t)h}, 0, 8, base)
+                  .add_inout_stage(ConvertModularToF32Stage{3, 8})
+                  .add_inout_stage(ConvertModularToF32Stage{4, 16});
+    auto b = add_filters(std::move(b0), rf_of(base), true, epf_iters).add_inout_stage(Upsample2x{nullptr, 3});
     auto pipe = std::move(b).add_save_stage({0, 1, 2}, 0, 3, 32).build(ctx);
     expect((int)pipe->lowered().frame.epf_iters == epf_iters, "built pipeline carries the stage list");
+    const int aw = (w + 1) / 2, ah = (h + 1) / 2;
+    std::vector<int32_t> alpha((size_t)aw * ah), depth((size_t)w * h);
+    uint32_t lcg = 12345u;
+    for (auto& v : alpha) v = (int32_t)((lcg = lcg * 1664525u + 1013904223u) >> 24);
+    for (auto& v : depth) v = (int32_t)((lcg = lcg * 1664525u + 1013904223u) >> 16);
+    pipe->set_extra_channel_buffer(0, alpha.data(), (size_t)aw, (uint32_t)aw, (uint32_t)ah);
+    pipe->set_extra_channel_buffer(1, depth.data(), (size_t)w, (uint32_t)w, (uint32_t)h);
     VarDctFrame& frame = pipe->frame();
     frame.decode_hf_global(F.tables);
     frame.decode_lf_group(0, 0, (uint32_t)F.xb, (uint32_t)F.yb, F.qy.data(), F.qx.data(), F.qb.data(), (size_t)F.xb);
@@ -279,6 +334,19 @@ int gpu_frame(int w, int h, int epf_iters) {
     for (int c = 0; c < 3; c++)
       for (int y = 0; y < h; y++)
         if (memcmp(&out[c][(size_t)y * w], &F.pl[c][(size_t)y * F.stride], sizeof(float) * w) != 0) bad++;
+    // the extra channels against the oracle's ConvertModularToF32 / Upsample2x
+    size_t bad_ec = 0;
+    {
+      std::vector<float> af((size_t)aw * ah), up((size_t)aw * 2 * ah * 2), df((size_t)w * h), got((size_t)w * h);
+      jxlo_modular_to_f32(alpha.data(), alpha.size(), 8, af.data());
+      jxlo_upsample(2, nullptr, af.data(), aw, ah, (size_t)aw, up.data(), (size_t)aw * 2);
+      pipe->save_extra_channel(0, got.data(), (size_t)w);
+      for (int y = 0; y < h; y++)
+        if (memcmp(&got[(size_t)y * w], &up[(size_t)y * aw * 2], sizeof(float) * w) != 0) bad_ec++;
+      jxlo_modular_to_f32(depth.data(), depth.size(), 16, df.data());
+      pipe->save_extra_channel(1, got.data(), (size_t)w);
+      if (memcmp(got.data(), df.data(), sizeof(float) * df.size()) != 0) bad_ec++;
+    }
     bool threw = false;
     try {
       pipe->check_buffer_sizes((size_t)w * sizeof(float) - 1, (size_t)h);
@@ -325,10 +393,10 @@ int gpu_frame(int w, int h, int epf_iters) {
       for (int y = 0; y < h; y++)
         if (memcmp(&got[(size_t)y * w * 4], &want[(size_t)y * w * 4], (size_t)w * 4) != 0) bad8++;
     }
-    printf("%dx%d epf_iters=%d groups=%d through RenderPipelineBuilder, two passes: %zu differing rows, RGBA8 tail: %zu differing "
-           "rows, error path %s\n",
-           w, h, epf_iters, F.ngroups, bad, bad8, threw ? "ok" : "MISSING");
-    return (bad == 0 && bad8 == 0 && threw && !g_failed) ? 0 : 1;
+    printf("%dx%d epf_iters=%d groups=%d through RenderPipelineBuilder, two passes: %zu differing rows, extra channels: %zu differing "
+           "rows, RGBA8 tail: %zu differing rows, error path %s\n",
+           w, h, epf_iters, F.ngroups, bad, bad_ec, bad8, threw ? "ok" : "MISSING");
+    return (bad == 0 && bad_ec == 0 && bad8 == 0 && threw && !g_failed) ? 0 : 1;
   } catch (const std::exception& e) {
     fprintf(stderr, "device path failed: %s\n", e.what());
     return 3;
