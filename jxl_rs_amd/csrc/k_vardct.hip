@@ -800,6 +800,8 @@ void launch_vardct_groups(hipStream_t s, const FrameDev& f, int group_row0, int 
   if (has_special)
     hipLaunchKernelGGL(k1_special, dim3(grid_for((long)(nblk / kSpecChunk + 1) * kSpecBins, kSpecWaves, 2048)),
                        dim3(kSpecThreads), 0, s, f, wl);
+  // (the large transforms on a side stream next to the memory-bound DCT classes, one workgroup per CU: K1 of the 16K
+  // all-types frame 1.872 -> 1.847 ms, 1.937 with their usual two per CU -- inside the noise, not kept)
   if (has_large) launch_vardct_large(s, f, wl, nblk, large_units, large_unit_capacity(nblocks), nblocks);
 }
 

@@ -4,6 +4,10 @@
 #include "k_vardct_common.h"
 #include "varblock_large.h"
 
+#ifndef JXLH_LLF_GRID
+#define JXLH_LLF_GRID 1024  // four 32 KB workgroups of k1_large_llf fit a CU
+#endif
+
 namespace jxlh {
 namespace {
 
@@ -145,9 +149,11 @@ struct LargeCoef {
     }
     // adjust_quant_bias divides only for |q| >= 2 (group.rs:91-95); most slabs of a large varblock hold
     // nothing but 0 / +-1 (high frequencies): a wavefront without a larger value skips the divisions
-    bool big = false;
-#pragma unroll
-    for (int i = 0; i < 4; i++) big |= (unsigned)(vy[i] + 1) > 2u || (unsigned)(vc[i] + 1) > 2u;
+    // (one unsigned maximum over q + 1 instead of a comparison per value)
+    auto umax3 = [](unsigned a, unsigned b, unsigned c) { return max(max(a, b), c); };
+    unsigned top = max(umax3((unsigned)(vy[0] + 1), (unsigned)(vy[1] + 1), (unsigned)(vy[2] + 1)), (unsigned)(vy[3] + 1));
+    if (!luma) top = max(umax3(top, (unsigned)(vc[0] + 1), (unsigned)(vc[1] + 1)), max((unsigned)(vc[2] + 1), (unsigned)(vc[3] + 1)));
+    const bool big = top > 2u;
     float r[4];
     if (__builtin_amdgcn_ballot_w64(big) != 0) {
 #pragma unroll
@@ -303,7 +309,7 @@ void launch_vardct_large(hipStream_t s, const FrameDev& f, const WorkLists& wl, 
     return e ? atoi(e) : 1;
   }();
   hipLaunchKernelGGL(k1_large_units, dim3(grid_for(nblk / 64 + 1, 256, 64)), dim3(256), 0, s, wl, ll, fuse);
-  hipLaunchKernelGGL(k1_large_llf, dim3(grid_for(3L * (nblk / 32 + 1), kLargeWaves, 512)), dim3(kLargeThreads), 0, s, f, wl,
+  hipLaunchKernelGGL(k1_large_llf, dim3(grid_for(3L * (nblk / 32 + 1), kLargeWaves, JXLH_LLF_GRID)), dim3(kLargeThreads), 0, s, f, wl,
                      llf_planes, nblocks);
   // two 66 KB workgroups fit a CU: 512 is the resident capacity
   const dim3 glarge(grid_for(3L * (nblk / 32 + 1), kLargeWaves, 512));
