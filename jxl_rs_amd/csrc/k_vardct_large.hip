@@ -11,16 +11,26 @@
 namespace jxlh {
 namespace {
 
-// family E: DCT64X64 .. DCT256X256 (varblock_large.h).  The two separable passes are separate launches over uniform
-// SLAB units (4096 samples of one channel of one varblock; a 256x256 varblock is 16 slabs per pass and channel, a
-// 64x64 one 1), one wavefront per unit, four independent wavefronts per workgroup:
-//   k1_large_units   one thread per large varblock: reserves its slabs in the unit list (item | slab << 24)
+// family E: DCT64X64 .. DCT256X256 (varblock_large.h).  Work is cut into SLABS: 4096 samples of one channel of one
+// varblock, what one wavefront transforms in registers.  Two routes (round 4, profiles/r04_e_large_path.txt):
+//   * below 256 pixels (64x64, 64x32, 32x64, 128x64, 64x128, 128x128) a channel is at most four slabs, so ONE launch
+//     does both separable passes: k1_large_fused keeps the pass-1 result in the workgroup's four wave tiles and pass
+//     2 reads its columns from there and stores from registers.  No intermediate store / reload: the kernels are
+//     bound by instruction issue at the two waves per SIMD the LDS tiles allow (VALU busy ~55 %), not by bytes.
+//   * 256-pixel types (a channel is up to 256 KiB, more than a CU's LDS): the two passes are separate launches over
+//     uniform slab units, one wavefront per unit, four independent wavefronts per workgroup; the varblock's own
+//     output rectangle is the inter-pass scratch (it stays in L2 / Infinity Cache between the launches).
+//   k1_large_units   one lane per large varblock: appends it to the fused list of its slab count (1 / 2 / 4) or
+//                    reserves its slabs in the two-pass unit list (item | slab << 24); one atomic per wave and list,
+//                    every list counter on its own 128-byte line (counters sharing a line cost 100 us at 16K)
 //   k1_large_llf     one wavefront per (varblock, channel): LLF-from-LF of the cy x cx patch -> llf planes (the corner
 //                    pass 1 substitutes, transform.rs:450); the values sit at the linear positions of the varblock's
 //                    own block rectangle, so the planes have the LF image's size
+//   k1_large_fused   workgroup unit = four slab slots (one 128x128 channel, two 128x64 / 64x128, four smaller ones)
 //   k1_large_pass<1> unit = (slab of lines, channel): dequantise + LLF corner + horizontal IDCT -> output rectangle
 //   k1_large_pass<2> unit = (slab of pixel columns, channel): vertical IDCT in place
-// (the varblock's own output rectangle is the inter-pass scratch; it stays in L2 / Infinity Cache between the launches)
+// Every body is instantiated per transform type (the geometry folds to constants); pass 1 keeps eight rounds of raw
+// coefficient loads in flight per lane.
 // unit lists behind each other in the `units` allocation (launch_vardct_large carves them the same way)
 struct LargeLists {
   uint32_t* two_pass;  // item | slab << 24 of the 256-pixel types, counter kNumClasses * kCountPitch

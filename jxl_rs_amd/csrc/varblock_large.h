@@ -7,6 +7,8 @@
 //   pass 1  slab = LV lines (fixed v) x all C horizontal frequencies; 1-D IDCT_C along u; result parked in the
 //           varblock's own output rectangle (it stays in L2 / Infinity Cache until pass 2)
 //   pass 2  slab = LX pixel columns x all R rows from that rectangle; IDCT_R along v; in place
+// Types below 256 pixels fit a workgroup's four wave tiles: there pass 2 reads the columns from LDS
+// (wave_large_pass2_lds, round 4) and the rectangle is written once.
 // Round 3 rewrite (profiles/r03_d_large_path.txt).  Round 2 ran the 1-D transforms as LDS sweeps of a 256-thread
 // workgroup: ~13 LDS accesses and 7 barriers per sample and pass, ~100 vector instructions per sample.  Now the
 // recursion idct_N = butterfly(idct_{N/2}(even), idct_{N/2}(prefix-summed odd)) is cut at length 64:
