@@ -249,11 +249,10 @@ jxlh_status jxlh_submit_groups_slots(jxlh_ctx* ctx, int32_t slot, uint32_t count
     for (uint32_t i = 0; i < count; i++) ctx->bucketed[group_ids[i]] = (flags & JXLH_GROUP_ACCUMULATE) ? 0 : 1;
   }
   Slot& s = ctx->slots[slot];
-  if (ctx->sp_expanded_valid) HIPCHK(ctx, hipStreamWaitEvent(s.stream, ctx->sp_expanded, 0));
-  // the slot tables of the previous frame may still be read by its transforms
-  if (ctx->k1_done_valid) HIPCHK(ctx, hipStreamWaitEvent(s.stream, ctx->k1_done, 0));
   {
-    // staging: [entries | slot counts | run descriptors], reused by the slot (stream-ordered)
+    // staging: [entries | slot counts | run descriptors], reused by the slot (stream-ordered).  The copies into it do
+    // not wait for the previous frame: only the pack kernel, which overwrites what that frame's transforms read, does
+    // -- a caller that submits frame i + 1 while frame i runs gets the upload under frame i's kernels
     auto up = [](size_t v) { return (v + 15) & ~(size_t)15; };
     const size_t ent_bytes = e12 ? total / 2 * 3 : total * 2;
     const size_t b_ent = up(ent_bytes), b_cnt = up(runs * 1024), b_desc = up(runs * 16);
@@ -271,6 +270,9 @@ jxlh_status jxlh_submit_groups_slots(jxlh_ctx* ctx, int32_t slot, uint32_t count
     if (total) HIPCHK(ctx, hipMemcpyAsync(d_ent, entries, ent_bytes, hipMemcpyDefault, s.stream));
     HIPCHK(ctx, hipMemcpyAsync(d_cnt, slot_counts, runs * 1024, hipMemcpyDefault, s.stream));
     HIPCHK(ctx, hipMemcpyAsync(d_desc, desc.data(), runs * 16, hipMemcpyHostToDevice, s.stream));
+    if (ctx->sp_expanded_valid) HIPCHK(ctx, hipStreamWaitEvent(s.stream, ctx->sp_expanded, 0));
+    // the pairs and slot tables of the previous frame may still be read by its transforms
+    if (ctx->k1_done_valid) HIPCHK(ctx, hipStreamWaitEvent(s.stream, ctx->k1_done, 0));
     launch_pack_slots(s.stream, reinterpret_cast<const uint16_t*>(d_ent), d_cnt, reinterpret_cast<const uint32_t*>(d_desc),
                       (int)runs, ctx->sp_pairs.p, ctx->sp_slot_start.p, e12);
     HIPCHK(ctx, hipGetLastError());
