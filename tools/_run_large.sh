@@ -1,8 +1,4 @@
-cd /tmp && export TMPDIR=/tmp
-O=$GRAFT_REPO_ROOT/gpurun_out/tl; rm -rf $O; mkdir -p $O
-timeout 300 rocprofv3 --kernel-trace --memory-copy-trace -d $O -o t -- python $GRAFT_REPO_ROOT/tools/e2e_stream_probe.py > $O/log.txt 2>&1
-tail -2 $O/log.txt
-DB=$(find $O -name "*.db" | head -1)
-python $GRAFT_REPO_ROOT/tools/timeline_dump.py $DB 0 1000000 > $O/all.txt 2>&1
-wc -l $O/all.txt; N=$(wc -l < $O/all.txt); sed -n "$((N/2)),$((N/2+70))p" $O/all.txt
-rm -f $DB
+cd $GRAFT_REPO_ROOT
+timeout 2400 python -m pytest tests/ -q -m gpu > gpurun_out/r04_gpu_tests_full.txt 2>&1; tail -3 gpurun_out/r04_gpu_tests_full.txt
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+timeout 900 python bench.py > gpurun_out/r04_f_bench.json 2> gpurun_out/r04_f_bench.err; tail -c 600 gpurun_out/r04_f_bench.json; tail -3 gpurun_out/r04_f_bench.err
