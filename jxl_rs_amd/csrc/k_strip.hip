@@ -372,10 +372,8 @@ __global__ __launch_bounds__(kNT, JXLH_STRIP_WPE) void k123_strip(const FrameDev
       __syncthreads();
       prefetch_meta(t + 1, tid);
       PROF_MARK(0);
-      // wavefront (q, ch) = (32x32 quadrant of the tile, channel) from the IDCT passes on (k1_scan hands a tile to this
-      // kernel only if every varblock lies inside one quadrant)
+      // wavefront (q, ch) = (side / row quarter of the exchange, channel) in the edge-column exchange below
       const int q = wave / 3, ch = wave % 3;
-      const int qbx = (q & 1) * 4, qby = (q >> 1) * 4;  // the quadrant's first block inside the tile
       if (mode == 0) {
         if (JXLH_STRIP_ABLATE & 64) {
         } else if (wave < 8) {
