@@ -1,4 +1,6 @@
 cd $GRAFT_REPO_ROOT
-timeout 2400 python -m pytest tests/ -q -m gpu > gpurun_out/r04_gpu_tests_full.txt 2>&1; tail -3 gpurun_out/r04_gpu_tests_full.txt
-timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
-timeout 900 python bench.py > gpurun_out/r04_f_bench.json 2> gpurun_out/r04_f_bench.err; tail -c 600 gpurun_out/r04_f_bench.json; tail -3 gpurun_out/r04_f_bench.err
+for v in base gabpk base gabpk; do
+  if [ $v = base ]; then lib=$PWD/jxl_rs_amd/libjxl_hip.so; else lib=$PWD/jxl_rs_amd/variants/libjxl_hip_$v.so; fi
+  echo -n "$v "; JXLH_LIBRARY=$lib timeout 200 python tools/filter_pop_time.py 2>&1 | tail -1
+done
+JXLH_LIBRARY=$PWD/jxl_rs_amd/variants/libjxl_hip_gabpk.so timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py -x -q -m gpu 2>&1 | tail -2
