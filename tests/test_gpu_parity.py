@@ -132,13 +132,16 @@ def test_vardct_frame_bit_exact(ctx, oracle, case):
             assert bit_equal(got[c], want[c]), f"flags={flags} plane {c}: {diff_report(got[c], want[c])}"
 
 
-@pytest.mark.parametrize("ttype", [18, 19, 20, 21, 24])
-def test_uniform_large_varblock_frame(ctx, oracle, ttype):
-    """a frame tiled by ONE large type.  DCT64X32 / DCT32X64 varblocks cover 32 blocks but still take a whole slab
-    unit each: a frame of nothing else needs nblocks / 32 units, the worst case the unit list is sized for
-    (round 2 sized it for nblocks / 64 and wrote past the work-list allocation)"""
+@pytest.mark.parametrize("filtered", [True, False])
+@pytest.mark.parametrize("ttype", list(range(18, 27)))
+def test_uniform_large_varblock_frame(ctx, oracle, ttype, filtered):
+    """a frame tiled by ONE large type, every type of the family.  DCT64X32 / DCT32X64 varblocks cover 32 blocks but
+    still take a whole slab unit each: a frame of nothing else needs nblocks / 32 units, the worst case the unit list is
+    sized for (round 2 sized it for nblocks / 64 and wrote past the work-list allocation).  The types below 256 pixels
+    take the one-launch route (k1_large_fused: pass 2 from LDS, results stored from registers), the 256-pixel ones the
+    two passes; filtered = the 8x8-tiled plane layout the fused filter kernel reads, unfiltered = raster planes."""
     from jxl_rs_amd import synth
-    wl = synth.make_vardct(512, 768, mix={ttype: 1.0}, seed=100 + ttype, epf_iters=1, gab=True)
+    wl = synth.make_vardct(512, 768, mix={ttype: 1.0}, seed=100 + ttype, epf_iters=1 if filtered else 0, gab=filtered)
     first = wl.transform_map[wl.transform_map >= 128] & 127
     assert (first == ttype).all() and first.size == 64 * 96 // (synth.COVERED_X[ttype] * synth.COVERED_Y[ttype])
     want, _ = run_oracle_frame(oracle, wl)
