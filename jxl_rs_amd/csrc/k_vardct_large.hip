@@ -35,7 +35,7 @@ namespace {
 struct LargeLists {
   uint32_t* two_pass;  // item | slab << 24 of the 256-pixel types, counter kNumClasses * kCountPitch
   uint32_t* fused[3];  // items of the types whose channel is 1 (64x64, 64x32, 32x64), 2 (128x64, 64x128) or 4 (128x128)
-                       // slabs: one workgroup transforms 4 / 2 / 1 of them at a time; counters behind the first
+                       // slabs: one workgroup transforms 4 / 2 / 1 of them at a time; counters on the three lines behind
 };
 
 __global__ __launch_bounds__(256) void k1_large_units(const WorkLists wl, const LargeLists ll, int fuse) {
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void k1_large_units(const WorkLists wl, const 
   auto reserve = [&](bool mine, int n, int* counter) {
     const unsigned long long m = __ballot(mine);
     if (m == 0) return 0;
-    // inclusive prefix of n over the lanes of m, by a 64-step scan over the mask (a few lanes are set at most)
+    // exclusive prefix of n over the lanes of m and the total, one step per set lane
     int before = 0, total = 0;
     for (unsigned long long r = m; r; r &= r - 1) {
       const int l = __ffsll((long long)r) - 1;
@@ -260,7 +260,6 @@ __global__ __launch_bounds__(kLargeThreads) __attribute__((amdgpu_waves_per_eu(2
         const LargeCoef coef(f, bi, T, ch, llf_planes, llf_plane_stride);
         wave_large_pass1_stage_bulk(g, slab * g.LV, coef, tile, lane);
       };
-#ifndef TEST_NO_P1
       switch (type) {
         case 18: pass1(std::integral_constant<int, 18>{}); break;
         case 19: pass1(std::integral_constant<int, 19>{}); break;
@@ -269,7 +268,6 @@ __global__ __launch_bounds__(kLargeThreads) __attribute__((amdgpu_waves_per_eu(2
         case 22: pass1(std::integral_constant<int, 22>{}); break;
         default: pass1(std::integral_constant<int, 23>{}); break;
       }
-#endif
     }
     __syncthreads();
     if (live) {
@@ -281,7 +279,6 @@ __global__ __launch_bounds__(kLargeThreads) __attribute__((amdgpu_waves_per_eu(2
         const LargeGeom g(T);
         wave_large_pass2_lds<covered_y(T) * 8>(g, slab * g.LX, tiles, plane, lay, lane2);
       };
-#ifndef TEST_NO_P2
       switch (type) {
         case 18: pass2(std::integral_constant<int, 18>{}); break;
         case 19: pass2(std::integral_constant<int, 19>{}); break;
@@ -290,7 +287,6 @@ __global__ __launch_bounds__(kLargeThreads) __attribute__((amdgpu_waves_per_eu(2
         case 22: pass2(std::integral_constant<int, 22>{}); break;
         default: pass2(std::integral_constant<int, 23>{}); break;
       }
-#endif
     }
     __syncthreads();  // the tiles are free again
   }
@@ -304,8 +300,8 @@ void launch_vardct_large(hipStream_t s, const FrameDev& f, const WorkLists& wl, 
     long g = (work_items + items_per_wg - 1) / items_per_wg;
     return (int)(g < 1 ? 1 : (g > cap ? cap : g));
   };
-  // the large class: unit list, LLF corners, then one launch per separable pass.  All four exit at once when the
-  // class is empty
+  // the large class: unit lists, LLF corners, the one-launch path, then one launch per separable pass of the 256-pixel
+  // types.  All five exit at once when the class is empty
   const size_t nb = nblocks;
   LargeLists ll;
   ll.two_pass = large_units;
@@ -321,7 +317,7 @@ void launch_vardct_large(hipStream_t s, const FrameDev& f, const WorkLists& wl, 
   hipLaunchKernelGGL(k1_large_units, dim3(grid_for(nblk / 64 + 1, 256, 64)), dim3(256), 0, s, wl, ll, fuse);
   hipLaunchKernelGGL(k1_large_llf, dim3(grid_for(3L * (nblk / 32 + 1), kLargeWaves, JXLH_LLF_GRID)), dim3(kLargeThreads), 0, s, f, wl,
                      llf_planes, nblocks);
-  // two 66 KB workgroups fit a CU: 512 is the resident capacity
+  // two 77 KiB workgroups fit a CU: 512 is the resident capacity
   const dim3 glarge(grid_for(3L * (nblk / 32 + 1), kLargeWaves, 512));
   if (fuse) hipLaunchKernelGGL(k1_large_fused, glarge, dim3(kLargeThreads), 0, s, f, wl, ll, llf_planes, nblocks);
   hipLaunchKernelGGL(k1_large_pass<1>, glarge, dim3(kLargeThreads), 0, s, f, wl, ll.two_pass, llf_planes, nblocks);
