@@ -222,6 +222,26 @@ impl<'a> VarDctFrame<'a> {
     pub unsafe fn read_planes(&self, out: &[sys::jxlh_plane; 3]) -> Result<()> {
         self.ctx.ok(sys::jxlh_frame_read_planes(self.ctx.raw, out.as_ptr()))
     }
+    /// An extra channel as the Modular decoder leaves it (channel 3 + `ec` of the reference's pipeline): `samples` = `h`
+    /// rows of `w` i32 at `stride`.  The next `finalize_and_render` applies `ConvertModularToF32Stage::new(3 + ec,
+    /// bits_per_sample)` and, for `ec_upsampling` 2 / 4 / 8, the channel's own `Upsample{2,4,8}x` (frame/render.rs:564-567,
+    /// :624-637).  The samples are copied before the call returns.
+    pub fn set_extra_channel(&self, ec: u32, samples: &[i32], stride: usize, w: u32, h: u32, bits_per_sample: u32,
+                             ec_upsampling: u32) -> Result<()> {
+        if w == 0 || h == 0 || stride < w as usize || samples.len() < (h as usize - 1) * stride + w as usize {
+            return Err(HipError::InvalidArgument);
+        }
+        self.ctx.ok(unsafe {
+            sys::jxlh_frame_set_extra_channel(self.ctx.raw, ec, samples.as_ptr(), stride, w, h, bits_per_sample, ec_upsampling)
+        })
+    }
+    /// the save stage of an extra channel: one f32 plane of the frame's output size
+    ///
+    /// # Safety
+    /// `out` must describe writable memory (host or device), see `read_planes`.
+    pub unsafe fn read_extra_channel(&self, ec: u32, out: &sys::jxlh_plane) -> Result<()> {
+        self.ctx.ok(sys::jxlh_frame_read_extra_channel(self.ctx.raw, ec, out))
+    }
     /// XybStage + FromLinearStage(sRGB) + ConvertF32ToU8Stage, interleaved, rows [y0, y1)
     pub fn read_rgb8(&self, p: &sys::jxlh_xyb_params, channels: u32, y0: u32, y1: u32, out: &mut [u8],
                      bytes_per_row: usize) -> Result<()> {
