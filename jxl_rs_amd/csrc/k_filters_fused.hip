@@ -5,7 +5,7 @@
 // 16-byte coalesced loads; every stage then runs LDS -> LDS *in place* on a region that shrinks by
 // its own border (all threads compute their outputs into registers, barrier, write back), and
 // only the last stage writes to HBM.  One buffer instead of a ping-pong pair halves the LDS per
-// pixel, which pays for tall tiles (less halo work) at the same number of waves per CU.
+// pixel: more workgroups per CU (see JXLH_FUSED_TH below).
 //
 // Work items are 4x2 micro-tiles: one 4-pixel strip of two consecutive rows.  A staged row is 16
 // strips = one 16-lane DPP row, so a strip comes in as one conflict-free ds_read_b128 and its
@@ -35,11 +35,19 @@
 // register window leaves no room to hold outputs across an in-place barrier), then EPF1 + EPF2.
 #include "jxlh_internal.h"
 
+// Tile heights and workgroup sizes of the two geometries (one 4x2 item per thread in the EPF stages:
+// (TH + 6) / 2 * 16 <= THREADS); which stage list uses which: see the namespaces below.
 #ifndef JXLH_FUSED_TH
 #define JXLH_FUSED_TH 56
 #endif
 #ifndef JXLH_FUSED_THREADS
 #define JXLH_FUSED_THREADS 512
+#endif
+#ifndef JXLH_FUSED_TH_LOW
+#define JXLH_FUSED_TH_LOW 24
+#endif
+#ifndef JXLH_FUSED_THREADS_LOW
+#define JXLH_FUSED_THREADS_LOW 256
 #endif
 #ifndef JXLH_FUSED_WAVES_PER_EU
 #define JXLH_FUSED_WAVES_PER_EU 6
@@ -81,18 +89,6 @@
 namespace jxlh {
 namespace {
 
-constexpr int kTW = 56, kTH = JXLH_FUSED_TH, kB = 4;
-constexpr int kBW = kTW + 2 * kB;  // 64 floats = 16 strips = one DPP row of lanes
-constexpr int kBH = kTH + 2 * kB;
-constexpr int kStrips = kBW / 4;   // 16
-constexpr int kPlane = kBW * kBH;  // floats per channel
-constexpr int kThreadsDefault = JXLH_FUSED_THREADS;
-static_assert(kStrips == 16, "lane <-> strip mapping relies on 16-lane DPP rows");
-static_assert(kTH % 4 == 0 && kThreadsDefault % 64 == 0, "tiled staging fetches 4-row groups");
-constexpr int kSigW = kBW / 8 + 2, kSigH = kBH / 8 + 2;
-constexpr int kDenseItems = JXLH_DENSE_ITEMS, kDenseItems0 = JXLH_DENSE_ITEMS0, kSparseMax = JXLH_SPARSE_MAX;
-static_assert(kSparseMax <= 64, "a compacting wavefront takes 64 strips");
-
 struct FusedArgs {
   const float* in[3];
   float* out[3];
@@ -132,385 +128,29 @@ __device__ __forceinline__ float dpp_from_right(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x101, 0xf, 0xf, true));
 }
 
-#include "filters_core.inc"
-
-// Overwrites out-of-frame positions of a stage's output region [B-m, B+T+m) with the values
-// at their mirrored in-frame coordinates.  Only called by tiles that touch the frame border.
-template <int kT>
-__device__ __forceinline__ void mirror_fill(float* __restrict__ buf, int m, int tx0, int ty0, int w, int h, int tid) {
-  const int rw = kTW + 2 * m, rh = kTH + 2 * m;
-  for (int idx = tid; idx < rw * rh; idx += kT) {
-    const int bx = kB - m + idx % rw, by = kB - m + idx / rw;
-    const int fx = tx0 - kB + bx, fy = ty0 - kB + by;
-    if (fx >= 0 && fx < w && fy >= 0 && fy < h) continue;
-    const int sx = mirror(fx, w) - (tx0 - kB), sy = mirror(fy, h) - (ty0 - kB);
-    if (sx < 0 || sx >= kBW || sy < 0 || sy >= kBH) continue;  // outside this tile: never consumed
-#pragma unroll
-    for (int c = 0; c < 3; c++) buf[c * kPlane + by * kBW + bx] = buf[c * kPlane + sy * kBW + sx];
-  }
-}
-
-// Threads per workgroup: 512 (three workgroups of 80 VGPRs per CU), except the EPF0 variants: their 147 VGPRs allow three
-// wavefronts per SIMD, i.e. ONE 512-thread workgroup per CU with every barrier and the staging loads exposed; as
-// 256-thread workgroups three fit (LDS 51 KB each) and overlap each other: 16K epf_iters = 3, 2.97 -> see profiles/r03_g.
-template <bool E0>
-constexpr int fused_threads() { return E0 ? JXLH_FUSED_E0_THREADS : kThreadsDefault; }
-
-template <bool GAB, bool E0, bool E1, bool E2>
-__global__ __launch_bounds__(fused_threads<E0>(), E0 ? JXLH_FUSED_E0_WPE : JXLH_FUSED_WAVES_PER_EU) void k23_fused_filters(const FusedArgs a) {
-  constexpr int kT = fused_threads<E0>();
-  __shared__ __attribute__((aligned(16))) float s_buf[3 * kPlane];
-  // 1/sigma of the 8x8 blocks this tile touches (block columns/rows relative to the tile's first block)
-  __shared__ float s_sigma[kSigH * kSigW];
-  // compacted EPF items of the current stage (see run_stage) and the number of wavefronts free to take them
-  __shared__ uint16_t s_list[(kTH + 2 * kB) * kStrips];
-  __shared__ int s_cnt, s_nsw;
-  const int tid_kernel = threadIdx.x, tid = tid_kernel;
-  if (tid_kernel == 0) {
-    s_cnt = 0;
-    s_nsw = 0;
-  }
-  // blockIdx.x enumerates tiles so that the workgroups one XCD receives (ids congruent mod 8)
-  // walk along a tile row: neighbouring tiles share 128-byte output lines and halo input
-  // lines, which then meet in the same (non-coherent) L2.
-  const int tiles_x = (a.w + kTW - 1) / kTW;
-  const int tiles_y = (a.y1 - a.y0 + kTH - 1) / kTH;
-  int tile_x, tile_y;
-  {
-    const int b = blockIdx.x, k = b & 7, j = b >> 3;
-    tile_y = (j / tiles_x) * 8 + k;
-    tile_x = j % tiles_x;
-  }
-  if (tile_y >= tiles_y) return;
-  const int tx0 = tile_x * kTW, ty0 = a.y0 + tile_y * kTH;
-  const bool edge = tx0 - kB < 0 || ty0 - kB < 0 || tx0 + kTW + kB > a.w || ty0 + kTH + kB > a.h;
-  constexpr int kBorder = (GAB ? 1 : 0) + (E0 ? 3 : 0) + (E1 ? 2 : 0) + (E2 ? 1 : 0);
-  static_assert(kBorder >= 1 && kBorder <= kB, "at least one stage");
-  static_assert(!(E0 && (E1 || E2)), "EPF0 closes its kernel; EPF1/EPF2 follow in a second launch");
-
-  const int sbx0 = max(tx0 - kB, 0) >> 3, sby0 = max(ty0 - kB, 0) >> 3;
-  if constexpr (E0 || E1 || E2) {
-    if (tid < kSigH * kSigW) {
-      const int sx = min(sbx0 + tid % kSigW, (a.w - 1) >> 3), sy = min(sby0 + tid / kSigW, (a.h - 1) >> 3);
-      s_sigma[tid] = at_bytes<float>(a.inv_sigma, 4u * ((uint32_t)sy * a.sigma_stride + (uint32_t)sx));
-    }
-  }
-  // ---- stage the input tile (region margin = kBorder) with mirrored coordinates
-  {
-    constexpr int m = kBorder;
-    constexpr int rows = kTH + 2 * m;
-    if (!edge && a.tiled_in) {
-      // interior tile, 8x8-tiled input (FrameDev::tiled): a lane fetches 4 rows of one pixel column
-      // (16 contiguous bytes); the 32 lanes of a half-wave read the same 4-row half of four blocks
-      // (4 x 128 contiguous bytes), the two halves together four whole 256-byte blocks per channel;
-      // the values scatter into the raster LDS tile with conflict-free ds_write_b32.
-      constexpr int yg0 = (kB - m) / 4, ygn = (rows + 2 * ((kB - m) % 4) + 3) / 4;  // 4-row groups touched
-      constexpr int items = kBW * ((ygn + 1) / 2) * 2;
-#pragma unroll
-      for (int it = 0; it < (items + kT - 1) / kT; it++) {
-        // idx -> (pair of row groups, half of the columns): lanes 0-31 / 32-63 = the two 4-row
-        // halves of the same 32 columns
-        const int idx = it * kT + tid;
-        const int w64 = idx >> 6, l = idx & 63;
-        const int xh = w64 % 2, ypair = w64 / 2;
-        const int bx = xh * 32 + (l & 31), yg = yg0 + ypair * 2 + (l >> 5);
-        if (idx >= items || yg * 4 >= kBH) continue;
-        const int by = yg * 4;
-        const uint32_t off = in_offset(a, tx0 - kB + bx, ty0 - kB + by);
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-          const float4 v = gload_f4<JXLH_NT_FLOAD>(&at_bytes<float>(a.in[c], off));
-          float* d = s_buf + c * kPlane + by * kBW + bx;
-          d[0] = v.x;
-          d[kBW] = v.y;
-          d[2 * kBW] = v.z;
-          d[3 * kBW] = v.w;
-        }
-      }
-    } else if (!edge) {  // interior tile, raster input: pure 16-byte coalesced rows
-      for (int idx = tid; idx < kStrips * rows; idx += kT) {
-        const int by = kB - m + idx / kStrips, bx0 = (idx % kStrips) * 4;
-        const uint32_t off = in_offset(a, tx0 - kB + bx0, ty0 - kB + by);
-#pragma unroll
-        for (int c = 0; c < 3; c++)
-          lds_store4(s_buf + c * kPlane + by * kBW + bx0, gload_f4<JXLH_NT_FLOAD>(&at_bytes<float>(a.in[c], off)));
-      }
-    } else {
-      for (int idx = tid; idx < kStrips * rows; idx += kT) {
-        const int by = kB - m + idx / kStrips, bx0 = (idx % kStrips) * 4;
-        const int fy = mirror(ty0 - kB + by, a.h);
-        const int fx0 = tx0 - kB + bx0;
-        const int x0 = mirror(fx0, a.w), x1 = mirror(fx0 + 1, a.w), x2 = mirror(fx0 + 2, a.w),
-                  x3 = mirror(fx0 + 3, a.w);
-        const uint32_t o0 = in_offset(a, x0, fy), o1 = in_offset(a, x1, fy), o2 = in_offset(a, x2, fy),
-                       o3 = in_offset(a, x3, fy);
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-          const float* __restrict__ pl = a.in[c];
-          lds_store4(s_buf + c * kPlane + by * kBW + bx0, make_float4(at_bytes<float>(pl, o0), at_bytes<float>(pl, o1), at_bytes<float>(pl, o2), at_bytes<float>(pl, o3)));
-        }
-      }
-    }
-  }
-  __syncthreads();
-
-  // One stage, in place: margin = the output region's margin around the tile (the input region's
-  // minus the stage's border).  Every 4x2 item of the region is computed into registers, then
-  // (after a barrier: all reads done) written back over the input.
-  //
-  // EPF stages and sparse sigma maps.  A block whose sigma is below MIN_SIGMA passes through (epf1.rs:72-78), and
-  // on d1-like content most blocks do (93 % of the SURVEY population) -- yet a wavefront spans 8 blocks, so nearly
-  // half of the wavefronts would run the whole stage for a handful of live lanes.  A wavefront therefore counts
-  // its active items: none -> nothing to do (the stage is the identity in place); many (>= kDenseItems) -> the
-  // dense form (one strip per lane, side taps through DPP); few -> the active items go to a workgroup-wide list
-  // and are processed after a barrier as compacted wavefronts by the GENERIC form of the stage (side taps from
-  // LDS).  Both forms add the same terms in the same order.
-  auto run_stage = [&](auto stage_tag, auto margin_tag) {
-    constexpr int STAGE = decltype(stage_tag)::value;  // 0 gaborish, 1 epf1, 2 epf2
-    constexpr int margin = decltype(margin_tag)::value;
-    constexpr bool last = margin == 0;
-    constexpr int rows = kTH + 2 * margin;
-    constexpr int n = (rows / 2) * kStrips;
-    constexpr int kPasses = (n + kT - 1) / kT;
-    static_assert(rows % 2 == 0, "4x2 items");
-    // Opaque copy of the thread id: everything a stage derives from it (item coordinates, sigma
-    // indices, store offsets) is then computed inside the stage instead of being hoisted above
-    // the previous stage, where it would sit in registers the 80-VGPR budget does not have.
-    int tid = tid_kernel;
-    asm volatile("" : "+v"(tid));
-    static_assert(STAGE != 3 || last, "EPF0 runs as the last stage");
-    if constexpr ((STAGE == 2 && last && JXLH_E2_STRIPS) || STAGE == 3) {
-      constexpr int ns = rows * kStrips;
-      auto strip_geom = [&](int t, int& by, int& bx0, int& fy, int& fx0, float& sigma) {
-        by = kB + t / kStrips;
-        bx0 = (t % kStrips) * 4;
-        fy = ty0 - kB + by;
-        fx0 = tx0 - kB + bx0;
-        const int sx = (min(max(fx0, 0), a.w - 1) >> 3) - sbx0, sy = (min(max(fy, 0), a.h - 1) >> 3) - sby0;
-        sigma = s_sigma[sy * kSigW + sx];
-      };
-      auto store = [&](int bx0, int fy, int fx0, int c, float4 o) {
-        if (bx0 >= kB && bx0 < kB + kTW && fy < a.y1 && fy < a.h && fx0 < a.w)
-          gstore_f4<JXLH_NT_FSTORE>(&at_bytes<float>(a.out[c], 4u * ((uint32_t)fy * a.stride + (uint32_t)fx0)), o);
-      };
-#pragma unroll 1
-      for (int t0 = 0; t0 < ns; t0 += kT) {
-        if (t0 + (tid & ~63) >= ns) break;
-        const int t = t0 + tid;
-        const bool live = t < ns;
-        int by, bx0, fy, fx0;
-        float sigma;
-        strip_geom(live ? t : 0, by, bx0, fy, fx0, sigma);
-        const float* p = s_buf + by * kBW + bx0;
-        auto put = [&](int c, float4 o) {
-          if (live) store(bx0, fy, fx0, c, o);
-        };
-        const bool act = live && !(sigma < kMinSigma);
-        const int cnt = __popcll(__ballot(act));
-        if (cnt == 0) {
-#pragma unroll
-          for (int c = 0; c < 3; c++) put(c, lds_load4(p + c * kPlane));
-        } else if (cnt >= (STAGE == 3 ? kDenseItems0 : kDenseItems)) {
-          if constexpr (STAGE == 3) epf0_strip<false>(p, fx0, fy, sigma, a, put);
-          else epf2_strip<false>(p, fx0, fy, sigma, a, put);
-        } else {
-          // few active strips: the others leave now, the active ones are queued
-          if (!act) {
-#pragma unroll
-            for (int c = 0; c < 3; c++) put(c, lds_load4(p + c * kPlane));
-          } else {
-            s_list[atomicAdd(&s_cnt, 1)] = (uint16_t)t;
-          }
-        }
-      }
-      {
-        __syncthreads();
-        const int cnt = s_cnt;
-#pragma unroll 1
-        for (int i0 = 0; i0 < cnt; i0 += kT) {
-          if (i0 + (tid & ~63) >= cnt) break;  // wave-uniform
-          const int i = i0 + tid;
-          const bool on = i < cnt;
-          const int t = s_list[min(i, cnt - 1)];
-          int by, bx0, fy, fx0;
-          float sigma;
-          strip_geom(t, by, bx0, fy, fx0, sigma);
-          const float* p = s_buf + by * kBW + bx0;
-          auto put = [&](int c, float4 o) {
-            if (on) store(bx0, fy, fx0, c, o);
-          };
-          if constexpr (STAGE == 3) epf0_strip<true>(p, fx0, fy, sigma, a, put, bx0 == 0, bx0 == kBW - 4);
-          else epf2_strip<true>(p, fx0, fy, sigma, a, put, bx0 == 0, bx0 == kBW - 4);
-        }
-      }
-      return;
-    }
-    static_assert(kPasses == 1 || STAGE == 0 || last, "held registers of one pass");
-    auto geom_of = [&](int t) -> Geom {
-      Geom g;
-      g.live = t < n;
-      const int by = kB - margin + (g.live ? (t / kStrips) * 2 : 0);
-      g.bx0 = (t % kStrips) * 4;
-      g.fy = ty0 - kB + by;
-      g.fx0 = tx0 - kB + g.bx0;
-      g.p = s_buf + by * kBW + g.bx0;
-      if constexpr (STAGE != 0) {
-        const int sx = (min(max(g.fx0, 0), a.w - 1) >> 3) - sbx0;
-        const int sy0 = (min(max(g.fy, 0), a.h - 1) >> 3) - sby0, sy1 = (min(max(g.fy + 1, 0), a.h - 1) >> 3) - sby0;
-        g.sigma0 = s_sigma[sy0 * kSigW + sx];
-        g.sigma1 = s_sigma[sy1 * kSigW + sx];
-      } else {
-        g.sigma0 = g.sigma1 = 0.0f;
-      }
-      return g;
-    };
-    auto put_global = [&](const Geom& g, int r, int c, float4 o) {
-      const int fyr = g.fy + r;
-      if (g.live && g.bx0 >= kB && g.bx0 < kB + kTW && fyr < a.y1 && fyr < a.h && g.fx0 < a.w)
-        gstore_f4<JXLH_NT_FSTORE>(&at_bytes<float>(a.out[c], 4u * ((uint32_t)fyr * a.stride + (uint32_t)g.fx0)), o);
-    };
-    float4 held[last ? 1 : kPasses][2][3];
-    // what `held` carries (EPF stages: at most one entry per thread): -1 nothing, otherwise a 4x2 item t (dense
-    // form, both rows) or, with bit 15 set, a compacted strip entry t * 2 + r (row r only, in held[0][0])
-    int held_e = -1;
-    if constexpr (STAGE == 0) {
-#pragma unroll
-      for (int pass = 0; pass < kPasses; pass++) {
-        if (pass * kT + (tid & ~63) >= n) continue;  // wave-uniform: nothing left for this wave
-        const Geom g = geom_of(pass * kT + tid);
-        auto put_g = [&](int r, int c, float4 o) {
-          if constexpr (last) put_global(g, r, c, o);
-          else held[pass][r][c] = o;
-        };
-#pragma unroll
-        for (int c = 0; c < 3; c++) gab_pair(g.p + c * kPlane, c, a.gab_k[c][0], a.gab_k[c][1], a.gab_k[c][2], put_g);
-      }
-    } else {
-      static_assert(STAGE == 0 || STAGE == 3 || kPasses == 1, "one EPF item per thread (EPF0 returned above)");
-      // ---- phase A: classify.  dense: this wavefront runs its own 64 items in the dense form; otherwise its
-      // active strips go to the list and the wavefront is free to take 64 compacted strips
-      auto geom = [&]() -> Geom {
-        int tl = tid_kernel;
-        asm volatile("" : "+v"(tl));  // recomputed where needed, not kept (see epf1_pair)
-        return geom_of(tl);
-      };
-      bool dense = false;
-      int my_slot = -1;
-      if ((tid & ~63) < n) {
-        const Geom g = geom();
-        const bool act0 = g.live && !(g.sigma0 < kMinSigma), act1 = g.live && !(g.sigma1 < kMinSigma);
-        const unsigned long long m0 = __ballot(act0), m1 = __ballot(act1);
-        const int cnt = __popcll(m0) + __popcll(m1);  // active strips of this wavefront
-        // EPF2 as an in-place stage has no compacted form: any active strip makes the wavefront dense
-        dense = STAGE == 1 ? cnt > kSparseMax : cnt > 0;
-        if (!dense) {
-          int slot = 0, base = 0;
-          if ((tid & 63) == 0) {
-            slot = atomicAdd(&s_nsw, 1);
-            if (cnt) base = atomicAdd(&s_cnt, cnt);
-          }
-          my_slot = __builtin_amdgcn_readfirstlane(slot);
-          base = __builtin_amdgcn_readfirstlane(base);
-          const unsigned long long below = (1ull << (tid & 63)) - 1ull;
-          if (act0) s_list[base + __popcll(m0 & below)] = (uint16_t)(tid * 2);
-          if (act1) s_list[base + __popcll(m0) + __popcll(m1 & below)] = (uint16_t)(tid * 2 + 1);
-          // rows below MIN_SIGMA: the stage is the identity there (in place: nothing to do; as the last stage:
-          // copy out) -- the reference takes the same shortcut per SIMD vector, epf1.rs:72-78
-          if constexpr (last) {
-#pragma unroll
-            for (int r = 0; r < 2; r++) {
-              if (r ? act1 : act0) continue;
-#pragma unroll
-              for (int c = 0; c < 3; c++) put_global(g, r, c, lds_load4(g.p + c * kPlane + r * kBW));
-            }
-          }
-        }
-      }
-      __syncthreads();  // the list is complete
-      // ---- phase B: a wavefront is EITHER dense (its own items) OR takes compacted strips, so `held` has one
-      // definition per thread and no live range crosses the other form's code
-      if (dense) {
-        const Geom g = geom();
-        auto put = [&](const Geom& gg, int r, int c, float4 o) {
-          if constexpr (last) put_global(gg, r, c, o);
-          else held[0][r][c] = o;
-        };
-        if constexpr (STAGE == 1) epf1_pair(g.p, geom, a, put);
-        else epf2_pair(g.p, g.fx0, g.fy, g.sigma0, g.sigma1, a, [&](int r, int c, float4 o) { put(g, r, c, o); });
-        held_e = tid;
-      } else if constexpr (STAGE == 1) {
-        const int cnt = s_cnt;
-        const int i = my_slot >= 0 ? my_slot * 64 + (tid & 63) : cnt;
-        if (__any(i < cnt)) {
-          const bool on = i < cnt;
-          const int e = (int)s_list[min(i, cnt - 1)];
-          const Geom g = geom_of(e >> 1);
-          const int r = e & 1;
-          epf1_strip_g(g.p + r * kBW, g.fx0, g.fy + r, r ? g.sigma1 : g.sigma0, g.bx0 == 0, g.bx0 == kBW - 4, a,
-                       [&](int c, float4 o) {
-                         if constexpr (last) {
-                           if (on) put_global(g, r, c, o);
-                         } else {
-                           held[0][0][c] = o;
-                         }
-                       });
-          if (on) held_e = e | 0x8000;
-        }
-      }
-    }
-    if constexpr (!last) {
-      __syncthreads();  // every read of the stage's input is done
-      if constexpr (STAGE == 0) {
-#pragma unroll
-        for (int pass = 0; pass < kPasses; pass++) {
-          const int t = pass * kT + tid;
-          if (t >= n) continue;
-          float* d = s_buf + (kB - margin + (t / kStrips) * 2) * kBW + (t % kStrips) * 4;
-#pragma unroll
-          for (int r = 0; r < 2; r++)
-#pragma unroll
-            for (int c = 0; c < 3; c++) lds_store4(d + c * kPlane + r * kBW, held[pass][r][c]);
-        }
-      } else if (held_e >= 0) {
-        const bool strip = (held_e & 0x8000) != 0;
-        const int t = strip ? (held_e & 0x7fff) >> 1 : held_e, r0 = strip ? (held_e & 1) : 0;
-        if (t < n) {
-          float* d = s_buf + (kB - margin + (t / kStrips) * 2 + r0) * kBW + (t % kStrips) * 4;
-#pragma unroll
-          for (int c = 0; c < 3; c++) lds_store4(d + c * kPlane, held[0][0][c]);
-          if (!strip) {
-#pragma unroll
-            for (int c = 0; c < 3; c++) lds_store4(d + c * kPlane + kBW, held[0][1][c]);
-          }
-        }
-      }
-      if constexpr (STAGE != 0) {
-        if (tid == 0) {
-          s_cnt = 0;
-          s_nsw = 0;
-        }
-      }
-      __syncthreads();
-      if (edge) {
-        mirror_fill<kT>(s_buf, margin, tx0, ty0, a.w, a.h, tid);
-        __syncthreads();
-      }
-    }
-  };
-  constexpr int kMg = kBorder - (GAB ? 1 : 0);      // margin after Gaborish
-  constexpr int kMe1 = kMg - (E1 ? 2 : 0);          // after EPF1
-  if constexpr (GAB) run_stage(std::integral_constant<int, 0>{}, std::integral_constant<int, kMg>{});
-  if constexpr (E0) run_stage(std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{});
-  if constexpr (E1) run_stage(std::integral_constant<int, 1>{}, std::integral_constant<int, kMe1>{});
-  if constexpr (E2) run_stage(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{});
-}
-
-template <bool GAB, bool E0, bool E1, bool E2>
-void launch_variant(hipStream_t s, const FusedArgs& a) {
-  const int tiles_x = (a.w + kTW - 1) / kTW, tiles_y = (a.y1 - a.y0 + kTH - 1) / kTH;
-  const dim3 grid(tiles_x * ((tiles_y + 7) / 8) * 8);
-  hipLaunchKernelGGL((k23_fused_filters<GAB, E0, E1, E2>), grid, dim3(fused_threads<E0>()), 0, s, a);
-}
+// Two tile geometries of the same code (k_filters_fused_tile.inc), chosen per stage list by launch_fused_filters:
+//   low   24 output rows, 256 threads: 25 KB of LDS, six workgroups of four waves per CU -- twice as many tiles in
+//         different phases (load, stages, store) at any time.  Gaborish + EPF1 (+ EPF2): 8K spec population
+//         0.406-0.410 -> 0.364-0.366 ms on one box, 16K all types 1.516 -> 1.416 (profiles/r04_i_filter_tiles.txt)
+//   tall  56 output rows, 512 threads (256 for the EPF0 variants): 50 KB, three workgroups per CU, 14 % halo rows
+//         instead of 33 %.  Gaborish alone (0.0925 vs 0.0961 ms at 4096^2) and the two launches of epf_iters = 3
+//         (3.10 vs 3.53 ms at 16K) are faster with it.
+// (16 / 192, 20 / 192, 32 / 320, 40 / 384 and 8 / 128 rows / threads are slower than either.)
+namespace tall {
+#define JXLH_TILE_TH JXLH_FUSED_TH
+#define JXLH_TILE_THREADS JXLH_FUSED_THREADS
+#include "k_filters_fused_tile.inc"
+#undef JXLH_TILE_TH
+#undef JXLH_TILE_THREADS
+}  // namespace tall
+namespace low {
+#define JXLH_TILE_TH JXLH_FUSED_TH_LOW
+#define JXLH_TILE_THREADS JXLH_FUSED_THREADS_LOW
+#include "k_filters_fused_tile.inc"
+#undef JXLH_TILE_TH
+#undef JXLH_TILE_THREADS
+}  // namespace low
+using tall::recip_weight_sum;
 
 __global__ void k_selftest_recip(uint32_t lo_bits, uint32_t hi_bits, unsigned long long* mismatches) {
   const uint32_t stride = gridDim.x * blockDim.x;
@@ -564,8 +204,8 @@ int launch_fused_filters(hipStream_t s, const FrameDev& f, int y0, int y1) {
     // the tiled staging path)
     a.y0 = max(0, y0 - 4);
     a.y1 = min(f.ysize, y1 + 3);
-    if (gab) launch_variant<true, true, false, false>(s, a);
-    else launch_variant<false, true, false, false>(s, a);
+    if (gab) tall::launch_variant<true, true, false, false>(s, a);
+    else tall::launch_variant<false, true, false, false>(s, a);
     for (int c = 0; c < 3; c++) {
       a.in[c] = f.tmp[c];
       a.out[c] = f.planes[c];
@@ -573,14 +213,14 @@ int launch_fused_filters(hipStream_t s, const FrameDev& f, int y0, int y1) {
     a.tiled_in = 0;
     a.y0 = y0;
     a.y1 = y1;
-    launch_variant<false, false, true, true>(s, a);
+    tall::launch_variant<false, false, true, true>(s, a);
     return 2;
   }
-  if (gab && e1 && e2) launch_variant<true, false, true, true>(s, a);
-  else if (gab && e1) launch_variant<true, false, true, false>(s, a);
-  else if (gab) launch_variant<true, false, false, false>(s, a);
-  else if (e1 && e2) launch_variant<false, false, true, true>(s, a);
-  else launch_variant<false, false, true, false>(s, a);
+  if (gab && e1 && e2) low::launch_variant<true, false, true, true>(s, a);
+  else if (gab && e1) low::launch_variant<true, false, true, false>(s, a);
+  else if (gab) tall::launch_variant<true, false, false, false>(s, a);
+  else if (e1 && e2) low::launch_variant<false, false, true, true>(s, a);
+  else low::launch_variant<false, false, true, false>(s, a);
   return 1;
 }
 
