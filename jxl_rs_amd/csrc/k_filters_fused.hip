@@ -56,7 +56,7 @@
 #define JXLH_FUSED_E0_WPE 3
 #endif
 #ifndef JXLH_FUSED_E0_THREADS
-#define JXLH_FUSED_E0_THREADS 256
+#define JXLH_FUSED_E0_THREADS 128
 #endif
 #ifndef JXLH_FAST_RECIP
 #define JXLH_FAST_RECIP 1
@@ -132,9 +132,9 @@ __device__ __forceinline__ float dpp_from_right(float v) {
 //   low   24 output rows, 256 threads: 25 KB of LDS, six workgroups of four waves per CU -- twice as many tiles in
 //         different phases (load, stages, store) at any time.  Gaborish + EPF1 (+ EPF2): 8K spec population
 //         0.406-0.410 -> 0.364-0.366 ms on one box, 16K all types 1.516 -> 1.416 (profiles/r04_i_filter_tiles.txt)
-//   tall  56 output rows, 512 threads (256 for the EPF0 variants): 50 KB, three workgroups per CU, 14 % halo rows
-//         instead of 33 %.  Gaborish alone (0.0925 vs 0.0961 ms at 4096^2) and the two launches of epf_iters = 3
-//         (3.10 vs 3.53 ms at 16K) are faster with it.
+//   tall  56 output rows, 512 threads: 50 KB, three workgroups per CU, 14 % halo rows instead of 33 %.  Gaborish alone
+//         (0.0925 vs 0.0961 ms at 4096^2) is faster with it; the EPF1 + EPF2 launch of epf_iters = 3 (raster input) does
+//         not care.  Gaborish + EPF0 takes the low tile with 128-thread workgroups (see launch_fused_filters).
 // (16 / 192, 20 / 192, 32 / 320, 40 / 384 and 8 / 128 rows / threads are slower than either.)
 namespace tall {
 #define JXLH_TILE_TH JXLH_FUSED_TH
@@ -204,8 +204,10 @@ int launch_fused_filters(hipStream_t s, const FrameDev& f, int y0, int y1) {
     // the tiled staging path)
     a.y0 = max(0, y0 - 4);
     a.y1 = min(f.ysize, y1 + 3);
-    if (gab) tall::launch_variant<true, true, false, false>(s, a);
-    else tall::launch_variant<false, true, false, false>(s, a);
+    // Gaborish + EPF0: the low tile with 128-thread workgroups (six of two waves per CU at its 153 VGPRs): 3.13 vs 3.21-3.23 ms
+    // for both launches at 16K (tall / 256 threads); low / 256: 3.53, low / 192: 3.38
+    if (gab) low::launch_variant<true, true, false, false>(s, a);
+    else low::launch_variant<false, true, false, false>(s, a);
     for (int c = 0; c < 3; c++) {
       a.in[c] = f.tmp[c];
       a.out[c] = f.planes[c];
