@@ -628,7 +628,7 @@ jxlh_status run_prologue(jxlh_ctx* ctx, RunPlan* plan) {
         }
       }
       // every group arrived slot-bucketed (jxlh_submit_groups_slots): the pair buffer already holds what the sort would
-      // produce and the slot tables are written -- one device copy into the persistent bucketed store instead
+      // produce and the slot tables are written -- no sort and no copy
       bool all_bucketed = all_pairs && ctx->bucketed.size() == ctx->ngroups;
       for (size_t g = 0; all_bucketed && g < ctx->ngroups; g++) all_bucketed = ctx->bucketed[g] != 0;
       if (all_pairs) {
@@ -636,9 +636,10 @@ jxlh_status run_prologue(jxlh_ctx* ctx, RunPlan* plan) {
         if (jxlh_status st = ensure(ctx, ctx->sp_sorted, capacity)) return st;
         if (jxlh_status st = ensure(ctx, ctx->sp_slot_start, ctx->ngroups * 3 * (size_t)kSlotTable)) return st;
         if (all_bucketed) {
-          ScopedKernelTimer t(ctx, "copy_bucketed_pairs");
-          HIPCHK(ctx, hipMemcpyAsync(ctx->sp_sorted.p, ctx->sp_pairs.p, ctx->sp_used * sizeof(uint32_t),
-                                     hipMemcpyDeviceToDevice, ctx->stream));
+          // the pair buffer IS the bucketed store of this frame: the two buffers (same capacity) trade places.  The
+          // next epoch's submissions write the buffer the previous frame's transforms read; they wait for sp_expanded,
+          // recorded below behind those transforms in stream order.
+          std::swap(ctx->sp_sorted, ctx->sp_pairs);
         } else {
           ScopedKernelTimer t(ctx, "k_sort_sparse");
           launch_sort_sparse(ctx->stream, ctx->sp_pairs.p, ctx->sp_groups_dev.p, (int)ng, ctx->sp_sorted.p,
@@ -705,7 +706,9 @@ jxlh_status run_k1(jxlh_ctx* ctx, const RunPlan& plan, int gr0, int gr1) {
     f.sp_sorted = sparse_k1 ? ctx->sp_sorted.p : nullptr;
     f.sp_slot_start = sparse_k1 ? ctx->sp_slot_start.p : nullptr;
     f.group_dense = sparse_k1 ? ctx->group_dense.p : nullptr;
-    if (sparse_k1) HIPCHK(ctx, hipMemsetAsync(ctx->group_dense.p, 0, ctx->ngroups, ctx->stream));
+    // (a whole-frame run rewrites every group's flag in k1_scan: no clearing launch then)
+    if (sparse_k1 && !(gr0 == 0 && gr1 == f.ygroups))
+      HIPCHK(ctx, hipMemsetAsync(ctx->group_dense.p, 0, ctx->ngroups, ctx->stream));
     // a sub-sampled channel is reconstructed at its own resolution into tmp[c] ...
     FrameDev fk = f;
     for (int c = 0; c < 3; c++)
