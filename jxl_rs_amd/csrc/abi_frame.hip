@@ -597,7 +597,10 @@ jxlh_status run_prologue(jxlh_ctx* ctx, RunPlan* plan) {
       if (jxlh_status st = ensure(ctx, ctx->sp_groups_dev, ng)) return st;
       if (jxlh_status st = ensure(ctx, ctx->sp_wide_dev, nw)) return st;
       if (jxlh_status st = ensure(ctx, ctx->group_dense, ctx->ngroups)) return st;
-      if (ng)
+      bool every_group_bucketed = ctx->bucketed.size() == ctx->ngroups && nw == 0 && ng == ctx->ngroups;
+      for (size_t g = 0; every_group_bucketed && g < ctx->ngroups; g++) every_group_bucketed = ctx->bucketed[g] != 0;
+      // (the group list is read by the sort and by the expansion: a frame that arrived slot-bucketed needs neither)
+      if (ng && !(every_group_bucketed && !(p.flags & JXLH_FRAME_EXPAND_SPARSE) && !plan->want_strip))
         HIPCHK(ctx, hipMemcpyAsync(ctx->sp_groups_dev.p, ctx->sp_upload.data(), ng * sizeof(SparseGroup),
                                    hipMemcpyHostToDevice, ctx->stream));
       if (nw)
