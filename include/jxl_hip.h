@@ -271,7 +271,10 @@ jxlh_status jxlh_submit_groups_sparse4(jxlh_ctx* ctx, int32_t slot, uint32_t cou
  * `entries` holds them in that order, any order inside a slot; n[3 * i + c] = the channel's total.  A decoder appends
  * to the slot buckets of the varblock it is decoding and flushes them when the varblock ends.  When EVERY group of the
  * frame arrives in this form, jxlh_frame_run finds the pairs already bucketed the way the transforms read them and
- * skips the sort; values outside 10 bits go to `wide` (and take the dense route like any wide entry). */
+ * skips the sort (and any copy: the pair buffer becomes the store the transforms read); values outside 10 bits go to
+ * `wide` (and take the dense route like any wide entry).  The call may be issued for the NEXT frame while the previous
+ * jxlh_frame_run is still executing: its host-to-device copies start at once, only the device-side unpacking waits for
+ * the previous frame's transforms. */
 jxlh_status jxlh_submit_groups_slots(jxlh_ctx* ctx, int32_t slot, uint32_t count, const uint32_t* group_ids,
                                      const uint16_t* entries, const uint8_t* slot_counts, const uint32_t* n,
                                      const jxlh_coeff32* wide, uint32_t n_wide, uint32_t flags);
