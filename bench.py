@@ -15,7 +15,9 @@ N > 1 (launched by torch.distributed.run, one rank per GPU) measures BOTH multi-
     own band, halo exchange of the edge block rows (ncclSend/ncclRecv), filters, in-place ncclAllGather of
     the finished planes so that every rank holds the whole frame (the layout north_star describes).  The
     RCCL communicator is the library's own (jxlh_comm_init); torch.distributed only launches, broadcasts the
-    128-byte id, and does the barrier / max-over-ranks of the timing protocol.
+    128-byte id, and does the barrier / max-over-ranks of the timing protocol.  The weak line is measured first; if the
+    sharded legs have not come back after JXLH_BENCH_STRONG_TIMEOUT_S seconds (default 240) rank 0 prints the weak
+    line with them marked as timed out and every rank leaves.
 
 Rank 0 prints ONE JSON line: metric/value/... + "roofline" (every kernel of the chain with its own
 algorithmic bytes and fraction, HIP-event timed on the kernels' own stream; the chain against the
@@ -374,6 +376,49 @@ def main():
     ev_ms = rep_ev[mid]
     value = size * size * n_gpus / 1e6 / (ms_per_step / 1e3)
 
+    def result_line(strong, strong_modular, roofline, cpu, e2e, secondary):
+        return {
+            "metric": "megapixels/sec decoded (8K VarDCT d1 reconstruction: dequant+CfL+IDCT+LF smoothing+Gaborish+EPF)",
+            "value": round(value, 1), "unit": "MP/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{size}x{size} VarDCT {args.mix} mix full pipeline (CfL, LF smoothing, "
+                                   f"Gaborish, EPF iters={args.epf_iters}), inputs HBM-resident",
+                       "groups": int(wl.coeffs.shape[0]),
+                       "sharding": "independent frames per GPU, no collective (strong_scaling: one frame in bands of "
+                                   "group rows, halo exchange + RCCL all-gather)" if world > 1 else "single GPU",
+                       "frames_in_flight_per_gpu": max(1, args.inflight), "epf_population": args.epf},
+            "strong_scaling": strong, "strong_scaling_modular": strong_modular,
+            "hip_event_ms_per_step_rank0": round(ev_ms / args.steps, 4),
+            "repetitions": {"n": len(rep_ms), "of_steps": args.steps, "reported": "median",
+                            "ms_per_step": [round(v, 4) for v in rep_ms], "min_ms_per_step": round(min(rep_ms), 4),
+                            "max_ms_per_step": round(max(rep_ms), 4),
+                            "value_at_min_ms": round(size * size * n_gpus / 1e6 / (min(rep_ms) / 1e3), 1),
+                            "value_at_max_ms": round(size * size * n_gpus / 1e6 / (max(rep_ms) / 1e3), 1)},
+            "setup": {"host_generate_s": round(gen_s, 2), "h2d_coeffs_s": round(h2d_s, 2)},
+            "roofline": roofline, "cpu_baseline": cpu, "e2e_pcie_inclusive": e2e, "secondary": secondary,
+        }
+
+    # The sharded (strong) legs below are the only part of an N > 1 run in which ranks wait for each other inside
+    # collectives; the weak line is measured by now.  If they have not come back after JXLH_BENCH_STRONG_TIMEOUT_S
+    # seconds (a rank that failed, a transport that hangs), rank 0 prints the weak line with the legs marked as timed
+    # out and every rank leaves -- the driver gets its line instead of a hung job.
+    watchdog = None
+    if (world > 1 or (args.strong_at_1 and dist is not None)) and not args.no_strong:
+        import threading
+        limit_s = float(os.environ.get("JXLH_BENCH_STRONG_TIMEOUT_S", "240"))
+
+        def give_up():
+            if rank == 0:
+                msg = {"error": f"no result after {limit_s:g} s (JXLH_BENCH_STRONG_TIMEOUT_S); weak line printed without it"}
+                print(json.dumps(result_line(msg, msg, None, None, None, None)), flush=True)
+            os._exit(0)
+
+        watchdog = threading.Timer(limit_s, give_up)
+        watchdog.daemon = True
+        watchdog.start()
+
     # ---- strong leg (N > 1): one frame sharded by bands of group rows, halo exchange + all-gather in the timed region
     strong = None
     if (world > 1 or (args.strong_at_1 and dist is not None)) and not args.no_strong:
@@ -520,6 +565,9 @@ def main():
             mctx.close()
         except Exception as e:
             strong_modular = {"error": f"{type(e).__name__}: {e}"}
+
+    if watchdog is not None:
+        watchdog.cancel()
 
     # ---- per-kernel HIP-event timing (separate steps; not part of the timed region)
     roofline = None
@@ -969,28 +1017,7 @@ def main():
             secondary[key]["leg_wall_s"] = round(time.time() - t0, 1)
 
     if rank == 0:
-        out = {
-            "metric": "megapixels/sec decoded (8K VarDCT d1 reconstruction: dequant+CfL+IDCT+LF smoothing+Gaborish+EPF)",
-            "value": round(value, 1), "unit": "MP/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{size}x{size} VarDCT {args.mix} mix full pipeline (CfL, LF smoothing, "
-                                   f"Gaborish, EPF iters={args.epf_iters}), inputs HBM-resident",
-                       "groups": int(wl.coeffs.shape[0]),
-                       "sharding": "independent frames per GPU, no collective (strong_scaling: one frame in bands of "
-                                   "group rows, halo exchange + RCCL all-gather)" if world > 1 else "single GPU",
-                       "frames_in_flight_per_gpu": max(1, args.inflight), "epf_population": args.epf},
-            "strong_scaling": strong, "strong_scaling_modular": strong_modular,
-            "hip_event_ms_per_step_rank0": round(ev_ms / args.steps, 4),
-            "repetitions": {"n": len(rep_ms), "of_steps": args.steps, "reported": "median",
-                            "ms_per_step": [round(v, 4) for v in rep_ms], "min_ms_per_step": round(min(rep_ms), 4),
-                            "max_ms_per_step": round(max(rep_ms), 4),
-                            "value_at_min_ms": round(size * size * n_gpus / 1e6 / (min(rep_ms) / 1e3), 1),
-                            "value_at_max_ms": round(size * size * n_gpus / 1e6 / (max(rep_ms) / 1e3), 1)},
-            "setup": {"host_generate_s": round(gen_s, 2), "h2d_coeffs_s": round(h2d_s, 2)},
-            "roofline": roofline, "cpu_baseline": cpu, "e2e_pcie_inclusive": e2e, "secondary": secondary,
-        }
+        out = result_line(strong, strong_modular, roofline, cpu, e2e, secondary)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
