@@ -222,6 +222,21 @@ impl<'a> VarDctFrame<'a> {
     pub unsafe fn read_planes(&self, out: &[sys::jxlh_plane; 3]) -> Result<()> {
         self.ctx.ok(sys::jxlh_frame_read_planes(self.ctx.raw, out.as_ptr()))
     }
+    /// One 256 x 256 group of the finished planes, the unit `RenderPipeline::set_buffer_for_group` moves
+    /// (render/mod.rs:124-137): `out[c]` = the `RawImageBuffer` of the `Image<f32>` `pipeline.get_buffer::<f32>(c)`
+    /// returned (the group's size rounded up to 16 pixels, render/internal.rs:144-167).  `xgroups` =
+    /// `frame_header.size_groups().0`.  Pixels beyond the frame's edge are left untouched.
+    ///
+    /// # Safety
+    /// See `read_planes`.
+    pub unsafe fn read_group_planes(&self, group: u32, xgroups: u32, out: &[sys::jxlh_plane; 3]) -> Result<()> {
+        if xgroups == 0 {
+            return Err(HipError::InvalidArgument);
+        }
+        let (x0, y0) = ((group % xgroups) * sys::JXLH_GROUP_DIM, (group / xgroups) * sys::JXLH_GROUP_DIM);
+        self.ctx.ok(sys::jxlh_frame_read_planes_rect(self.ctx.raw, x0, y0, sys::JXLH_GROUP_DIM, sys::JXLH_GROUP_DIM,
+                                                     out.as_ptr()))
+    }
     /// An extra channel as the Modular decoder leaves it (channel 3 + `ec` of the reference's pipeline): `samples` = `h`
     /// rows of `w` i32 at `stride`.  The next `finalize_and_render` applies `ConvertModularToF32Stage::new(3 + ec,
     /// bits_per_sample)` and, for `ec_upsampling` 2 / 4 / 8, the channel's own `Upsample{2,4,8}x` (frame/render.rs:564-567,

@@ -302,6 +302,19 @@ jxlh_status jxlh_ctx_sync(jxlh_ctx* ctx);
 /* Copies the finished planes out (host or device destination).  Replaces the save stage for
  * f32 XYB output; xsize x ysize samples per plane. */
 jxlh_status jxlh_frame_read_planes(jxlh_ctx* ctx, const jxlh_plane out[3]);
+/* The same for one rectangle of the result: pixels [x0, x0 + w) x [y0, y0 + h), cut at the result's right and bottom
+ * edge, into out[c] (row 0 of out[c] = row y0; at least min(w, xsize - x0) samples per row and min(h, ysize - y0)
+ * rows; what lies beyond the cut is left untouched).  This is the unit the reference's pipeline moves:
+ * RenderPipeline::get_buffer / set_buffer_for_group (render/mod.rs:124-137) hand over one 256 x 256 group per
+ * channel, in buffers rounded up to 16 pixels (group_size_for_channel, render/internal.rs:144-167) -- a caller that
+ * feeds the finished XYB planes to the remaining CPU stages group by group reads group g with
+ * x0 = (g % xgroups) * 256, y0 = (g / xgroups) * 256, w = h = 256.  JXLH_ERR_INVALID_ARGUMENT
+ * if the rect starts outside the result.  _async: without the final wait (host destinations should be pinned);
+ * `out` is valid after the next jxlh_ctx_sync. */
+jxlh_status jxlh_frame_read_planes_rect(jxlh_ctx* ctx, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
+                                        const jxlh_plane out[3]);
+jxlh_status jxlh_frame_read_planes_rect_async(jxlh_ctx* ctx, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
+                                              const jxlh_plane out[3]);
 /* device-resident result (row stride in floats), valid until the next frame_begin */
 jxlh_status jxlh_frame_device_planes(jxlh_ctx* ctx, float* planes[3], size_t* stride);
 /* Extra channels of the frame (alpha, depth, ...: channels 3 + ec of the reference's pipeline, frame/render.rs:564-567,

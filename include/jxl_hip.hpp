@@ -117,6 +117,17 @@ class VarDctFrame {
                               {b, w * sizeof(float), h, w * sizeof(float)}};
     ctx_.check(jxlh_frame_read_planes(ctx_.raw(), pl), "jxlh_frame_read_planes");
   }
+  // one 256 x 256 group of the result per channel, the unit RenderPipeline::set_buffer_for_group moves
+  // (render/mod.rs:124-137); buffers of `pitch` floats per row, at least the group's size rounded up to 16 pixels
+  void read_group_planes(uint32_t group, float* x, float* y, float* b, size_t pitch, size_t rows) {
+    const uint32_t xg = (out_width() + JXLH_GROUP_DIM - 1) / JXLH_GROUP_DIM;
+    const jxlh_plane pl[3] = {{x, pitch * sizeof(float), rows, pitch * sizeof(float)},
+                              {y, pitch * sizeof(float), rows, pitch * sizeof(float)},
+                              {b, pitch * sizeof(float), rows, pitch * sizeof(float)}};
+    ctx_.check(jxlh_frame_read_planes_rect(ctx_.raw(), (group % xg) * JXLH_GROUP_DIM, (group / xg) * JXLH_GROUP_DIM,
+                                           JXLH_GROUP_DIM, JXLH_GROUP_DIM, pl),
+               "jxlh_frame_read_planes_rect");
+  }
   void read_rgb8(const jxlh_xyb_params& xyb, uint32_t channels, uint8_t* out) {
     ctx_.check(jxlh_frame_read_rgb8(ctx_.raw(), &xyb, channels, 0, out_height(), out, (size_t)out_width() * channels),
                "jxlh_frame_read_rgb8");

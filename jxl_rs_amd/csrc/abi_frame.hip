@@ -104,15 +104,28 @@ jxlh_status jxlh_ctx_create(int32_t device_ordinal, int32_t n_slots, jxlh_ctx** 
   jxlh_ctx* ctx = new (std::nothrow) jxlh_ctx();
   if (!ctx) return JXLH_ERR_OUT_OF_MEMORY;
   ctx->device = device_ordinal;
+  // Stream priorities: all streams in the default class.  The runtime maps the streams of one class onto a handful of
+  // hardware queues (GPU_MAX_HW_QUEUES, 4), least-used first, and two streams on one queue execute in order: with two
+  // contexts of THREE slot streams each the two main streams land on one queue and the frames no longer overlap (8K d1,
+  // two frames in flight: 0.74 ms per frame instead of 0.65-0.67; one or two slot streams per context do not collide).
+  // Putting the main streams into the high class (or the slot streams) removes that collision (0.67) but makes the
+  // PCIe-inclusive legs 1.2-1.7x SLOWER (the unpack kernels on the other class's queues are starved or pre-empt the
+  // transforms): measured round 5, profiles/r05_a_stream_queues.txt.  JXLH_STREAM_PRIORITY="<main>,<slot>" selects other
+  // classes for A/B runs (hipDeviceGetStreamPriorityRange: -1 high, 0 default, 1 low).
+  static const struct Prio { int main_p, slot_p; } prio = [] {
+    Prio p{0, 0};
+    if (const char* e = getenv("JXLH_STREAM_PRIORITY")) (void)sscanf(e, "%d,%d", &p.main_p, &p.slot_p);
+    return p;
+  }();
   if (hipSetDevice(device_ordinal) != hipSuccess ||
-      hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio.main_p) != hipSuccess ||
       hipEventCreate(&ctx->t0) != hipSuccess || hipEventCreate(&ctx->t1) != hipSuccess) {
     delete ctx;
     return JXLH_ERR_DEVICE;
   }
   ctx->slots.resize(n_slots);
   for (auto& s : ctx->slots) {
-    if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess ||
+    if (hipStreamCreateWithPriority(&s.stream, hipStreamNonBlocking, prio.slot_p) != hipSuccess ||
         hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess) {
       jxlh_ctx_destroy(ctx);
       return JXLH_ERR_DEVICE;

@@ -221,6 +221,40 @@ jxlh_status jxlh_frame_read_planes(jxlh_ctx* ctx, const jxlh_plane out[3]) {
   return jxlh_ctx_sync(ctx);
 }
 
+namespace {
+// the rect [x0, x0 + w) x [y0, y0 + h) of the finished planes, cut at the result's right / bottom edge
+jxlh_status read_planes_rect(jxlh_ctx* ctx, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, const jxlh_plane out[3],
+                             bool wait) {
+  if (!ctx || !out || w == 0 || h == 0) return JXLH_ERR_INVALID_ARGUMENT;
+  if (!ctx->in_frame || !ctx->result[0]) return JXLH_ERR_BAD_STATE;
+  if (x0 >= (uint32_t)ctx->res_w || y0 >= (uint32_t)ctx->res_h) return JXLH_ERR_INVALID_ARGUMENT;
+  const size_t cw = std::min<size_t>(w, (size_t)ctx->res_w - x0), ch = std::min<size_t>(h, (size_t)ctx->res_h - y0);
+  for (int c = 0; c < 3; c++)
+    if (!out[c].ptr || out[c].bytes_per_row < cw * sizeof(float) || out[c].num_rows < ch ||
+        out[c].bytes_between_rows < out[c].bytes_per_row)
+      return JXLH_ERR_INVALID_ARGUMENT;
+  materialise_chroma(ctx);
+  for (int c = 0; c < 3; c++) {
+    const float* src = ctx->result[c] + (size_t)y0 * ctx->res_stride + x0;
+    if (jxlh_status st = copy2d(ctx, out[c].ptr, out[c].bytes_between_rows, src, ctx->res_stride * sizeof(float),
+                                cw * sizeof(float), ch, ctx->stream))
+      return st;
+  }
+  return wait ? jxlh_ctx_sync(ctx) : JXLH_OK;
+}
+}  // namespace
+
+jxlh_status jxlh_frame_read_planes_rect(jxlh_ctx* ctx, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
+                                        const jxlh_plane out[3]) {
+  JXLH_ON_DEVICE(ctx);
+  return read_planes_rect(ctx, x0, y0, w, h, out, /*wait=*/true);
+}
+jxlh_status jxlh_frame_read_planes_rect_async(jxlh_ctx* ctx, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
+                                              const jxlh_plane out[3]) {
+  JXLH_ON_DEVICE(ctx);
+  return read_planes_rect(ctx, x0, y0, w, h, out, /*wait=*/false);
+}
+
 jxlh_status jxlh_frame_device_planes(jxlh_ctx* ctx, float* planes[3], size_t* stride) {
   JXLH_ON_DEVICE(ctx);
   if (!ctx || !planes) return JXLH_ERR_INVALID_ARGUMENT;

@@ -41,6 +41,7 @@ ABI_SYMBOLS = [
     "jxlh_submit_group_sparse", "jxlh_submit_groups_sparse", "jxlh_submit_groups_sparse8", "jxlh_submit_groups_sparse4",
     "jxlh_submit_groups_slots", "jxlh_slot_wait",
     "jxlh_frame_coeff_buffer", "jxlh_frame_run", "jxlh_ctx_sync", "jxlh_frame_read_planes",
+    "jxlh_frame_read_planes_rect", "jxlh_frame_read_planes_rect_async",
     "jxlh_frame_device_planes", "jxlh_frame_set_extra_channel", "jxlh_frame_read_extra_channel", "jxlh_frame_read_lf", "jxlh_frame_read_rgb8", "jxlh_frame_read_rgb8_async",
     "jxlh_frame_read_rgb16", "jxlh_frame_read_ycbcr_rgb8", "jxlh_frame_read_ycbcr_rgb16", "jxlh_frame_read_output",
     "jxlh_frame_read_output_async", "jxlh_stage_chroma_upsample", "jxlh_stage_upsample",
@@ -161,6 +162,8 @@ def load():
     L.jxlh_frame_run.argtypes = [vp, u32, u32]
     L.jxlh_ctx_sync.argtypes = [vp]
     L.jxlh_frame_read_planes.argtypes = [vp, C.POINTER(Plane)]
+    L.jxlh_frame_read_planes_rect.argtypes = [vp, u32, u32, u32, u32, C.POINTER(Plane)]
+    L.jxlh_frame_read_planes_rect_async.argtypes = [vp, u32, u32, u32, u32, C.POINTER(Plane)]
     L.jxlh_frame_device_planes.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
     L.jxlh_frame_read_lf.argtypes = [vp, vp, vp, vp, sz]
     L.jxlh_timer_start.argtypes = [vp]
@@ -577,6 +580,28 @@ class Context:
         planes = (Plane * 3)(*[Plane(o.ctypes.data, w * 4, h, w * 4) for o in out])
         self._chk(self.L.jxlh_frame_read_planes(self._ctx, planes), "frame_read_planes")
         return out
+
+    def read_planes_rect(self, x0, y0, w, h, out=None):
+        """jxlh_frame_read_planes_rect: the rect [x0, x0 + w) x [y0, y0 + h) of the three finished planes (cut at the
+        result's edge) into `out` (three float32 arrays of at least the cut size; allocated h x w, zeroed, when None)"""
+        if out is None:
+            out = [np.zeros((h, w), dtype=np.float32) for _ in range(3)]
+        planes = (Plane * 3)(*[Plane(o.ctypes.data, o.shape[1] * 4, o.shape[0], o.strides[0]) for o in out])
+        self._chk(self.L.jxlh_frame_read_planes_rect(self._ctx, x0, y0, w, h, planes), "frame_read_planes_rect")
+        return out
+
+    def read_group_planes(self, group_id):
+        """the reference's unit of hand-over (RenderPipeline::set_buffer_for_group, render/mod.rs:128-137): group
+        `group_id` of the result on the 256 x 256 grid, in buffers rounded up to 16 pixels
+        (group_size_for_channel, render/internal.rs:144-167); returns (planes, (w, h) of the group's part of the frame)"""
+        W, H = self.out_size
+        xg = (W + 255) // 256
+        x0, y0 = (group_id % xg) * 256, (group_id // xg) * 256
+        gw, gh = min(256, W - x0), min(256, H - y0)
+        bw, bh = (min(256, W) + 15) // 16 * 16, (min(256, H) + 15) // 16 * 16
+        out = [np.zeros((bh, bw), dtype=np.float32) for _ in range(3)]
+        self.read_planes_rect(x0, y0, bw, bh, out)
+        return out, (gw, gh)
 
     def read_rgb8(self, xyb_params, channels=3, y0=0, y1=None, out=None):
         """8-bit interleaved sRGB of rows [y0, y1) (jxlh_frame_read_rgb8).  xyb_params: 16 floats in
