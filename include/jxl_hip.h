@@ -140,6 +140,9 @@ enum {
                                            planes -> fused filters.  Bit-identical output; slower on MI355X today
                                            (both forms are bound by instruction issue), hence
                                            opt-in */
+  JXLH_FRAME_DENSE_DEQUANT = 1u << 3,   /* a frame resident in the slot-bucketed form (jxlh_submit_groups_slots): the
+                                           transforms always dequantise every coefficient position instead of only the
+                                           positions that have an entry (debug/parity: both give the same bits) */
 };
 
 /* Header defaults of the reference (RestorationFilter / ColorCorrelationParams /

@@ -27,6 +27,7 @@ jxlh_status jxlh_submit_group(jxlh_ctx* ctx, int32_t slot, uint32_t group_id, co
       }
     }
     ctx->touched[group_id] = 1;
+    if (group_id < ctx->bucketed.size()) ctx->bucketed[group_id] = 0;
     ctx->epoch_dirty = true;
   }
   int32_t* dst = ctx->coeffs.p + (size_t)group_id * 3 * kGroupArea;
@@ -82,6 +83,7 @@ jxlh_status sparse_reserve(jxlh_ctx* ctx, int32_t slot, uint32_t count, const ui
     g.flags = (flags & JXLH_GROUP_ACCUMULATE) ? 1u : 0u;
     ctx->sp_pending.push_back(g);
     ctx->touched[g.group] = 2;
+    if (g.group < ctx->bucketed.size()) ctx->bucketed[g.group] = 0;  // only jxlh_submit_groups_slots sets it (again)
   }
   ctx->epoch_dirty = true;
   for (uint32_t i = 0; i < n_wide; i++) ctx->sp_wide.push_back(make_uint2(wide[i].pos, (uint32_t)wide[i].val));
@@ -97,8 +99,10 @@ jxlh_status jxlh_submit_groups_sparse(jxlh_ctx* ctx, int32_t slot, uint32_t coun
   JXLH_ON_DEVICE(ctx);
   if (count == 0 && ctx && ctx->in_frame) return JXLH_OK;
   size_t offset = 0, total = 0;
+  if (!pairs && n && count)  // checked before anything is reserved: a failed call leaves the epoch as it was
+    for (size_t r = 0; r < (size_t)count * 3; r++)
+      if (n[r]) return JXLH_ERR_INVALID_ARGUMENT;
   if (jxlh_status st = sparse_reserve(ctx, slot, count, group_ids, n, wide, n_wide, flags, &offset, &total)) return st;
-  if (total && !pairs) return JXLH_ERR_INVALID_ARGUMENT;
   Slot& s = ctx->slots[slot];
   // the pair buffer is recycled per frame: the previous frame's expansion must have read it
   if (ctx->sp_expanded_valid) HIPCHK(ctx, hipStreamWaitEvent(s.stream, ctx->sp_expanded, 0));
@@ -117,8 +121,10 @@ jxlh_status jxlh_submit_groups_sparse8(jxlh_ctx* ctx, int32_t slot, uint32_t cou
   JXLH_ON_DEVICE(ctx);
   if (count == 0 && ctx && ctx->in_frame) return JXLH_OK;
   size_t offset = 0, total = 0;
+  if ((!pos || !val) && n && count)  // checked before anything is reserved
+    for (size_t r = 0; r < (size_t)count * 3; r++)
+      if (n[r]) return JXLH_ERR_INVALID_ARGUMENT;
   if (jxlh_status st = sparse_reserve(ctx, slot, count, group_ids, n, wide, n_wide, flags, &offset, &total)) return st;
-  if (total && (!pos || !val)) return JXLH_ERR_INVALID_ARGUMENT;
   Slot& s = ctx->slots[slot];
   if (ctx->sp_expanded_valid) HIPCHK(ctx, hipStreamWaitEvent(s.stream, ctx->sp_expanded, 0));
   if (total) {
@@ -215,67 +221,81 @@ jxlh_status jxlh_submit_groups_sparse4(jxlh_ctx* ctx, int32_t slot, uint32_t cou
   return JXLH_OK;
 }
 
-// slot-bucketed form: pair words written in slot order + the slot tables, by one workgroup per (group, channel) on the
-// slot's stream; a frame that arrives entirely in this form is not sorted (run_prologue)
+// slot-bucketed form: entries, slot counts and run descriptors go to the context's PENDING set as they are (no unpack
+// pass, round 5); jxlh_frame_run decides what reads them (run_prologue)
 jxlh_status jxlh_submit_groups_slots(jxlh_ctx* ctx, int32_t slot, uint32_t count, const uint32_t* group_ids,
                                      const uint16_t* entries, const uint8_t* slot_counts, const uint32_t* n,
                                      const jxlh_coeff32* wide, uint32_t n_wide, uint32_t flags) {
   JXLH_ON_DEVICE(ctx);
   if (count == 0 && ctx && ctx->in_frame) return JXLH_OK;
-  if (!ctx || !slot_counts || !n) return JXLH_ERR_INVALID_ARGUMENT;
-  size_t offset = 0, total = 0;
-  if (jxlh_status st = sparse_reserve(ctx, slot, count, group_ids, n, wide, n_wide, flags, &offset, &total)) return st;
-  if (total && !entries) return JXLH_ERR_INVALID_ARGUMENT;
+  // every argument is checked BEFORE anything is reserved: a failed call leaves the epoch as it was
+  if (!ctx || !slot_counts || !n || !group_ids || slot < 0 || (size_t)slot >= ctx->slots.size()) return JXLH_ERR_INVALID_ARGUMENT;
   const size_t runs = (size_t)count * 3;
   const bool e12 = (flags & JXLH_GROUP_ENTRIES12) != 0;
-  if (e12)
-    for (size_t r = 0; r < runs; r++)
-      if (n[r] & 1u) return JXLH_ERR_INVALID_ARGUMENT;  // 12-bit runs are closed to an even number of entries
-  std::vector<uint32_t> desc(4 * runs);
+  size_t total_check = 0;
+  for (size_t r = 0; r < runs; r++) {
+    if (n[r] > (uint32_t)kGroupArea) return JXLH_ERR_INVALID_ARGUMENT;
+    if (e12 && (n[r] & 1u)) return JXLH_ERR_INVALID_ARGUMENT;  // 12-bit runs are closed to an even number of entries
+    total_check += n[r];
+  }
+  if (total_check && !entries) return JXLH_ERR_INVALID_ARGUMENT;
+  size_t offset = 0, total = 0;
+  if (jxlh_status st = sparse_reserve(ctx, slot, count, group_ids, n, wide, n_wide, flags, &offset, &total)) return st;
+  int pend;
   {
-    size_t o = 0;
+    std::lock_guard<std::mutex> lock(ctx->sp_mutex);
+    pend = ctx->se_live ^ 1;
+    // (+ 64 entries: the transforms request a varblock's first entries before they look at its count)
+    if (jxlh_status st = ensure(ctx, ctx->se_entries[pend], ctx->ngroups * 3 * (size_t)kGroupArea + 64)) return st;
+    if (jxlh_status st = ensure(ctx, ctx->se_counts[pend], ctx->ngroups * 3 * (size_t)kSlotsPerRun)) return st;
+    if (jxlh_status st = ensure(ctx, ctx->se_runs[pend], ctx->ngroups * 3)) return st;
+    if (ctx->bucketed.size() != ctx->ngroups) ctx->bucketed.assign(ctx->ngroups, 0);
+    for (uint32_t i = 0; i < count; i++) ctx->bucketed[group_ids[i]] = 1;
+  }
+  Slot& s = ctx->slots[slot];
+  // the pending set was last read two frames ago (by the transforms of the frame that made it live, or by the previous
+  // epoch's widening into the pair buffer): nothing here waits for the frame that is running now
+  if (ctx->se_read_valid[pend]) HIPCHK(ctx, hipStreamWaitEvent(s.stream, ctx->se_read[pend], 0));
+  if (ctx->sp_expanded_valid) HIPCHK(ctx, hipStreamWaitEvent(s.stream, ctx->sp_expanded, 0));
+  uint16_t* d_ent = ctx->se_entries[pend].p + offset;
+  if (total) {
+    if (!e12) {
+      HIPCHK(ctx, hipMemcpyAsync(d_ent, entries, total * sizeof(uint16_t), hipMemcpyDefault, s.stream));
+    } else {
+      const size_t bytes = total / 2 * 3;
+      if (s.stage8_cap < bytes) {
+        HIPCHK(ctx, hipStreamSynchronize(s.stream));  // the old staging may still be read by a queued kernel
+        if (s.stage8) (void)hipFree(s.stage8);
+        s.stage8 = nullptr;
+        s.stage8_cap = 0;
+        const size_t cap = bytes * 5 / 4 + 4096;
+        if (hipMalloc(reinterpret_cast<void**>(&s.stage8), cap) != hipSuccess) return JXLH_ERR_OUT_OF_MEMORY;
+        s.stage8_cap = cap;
+      }
+      HIPCHK(ctx, hipMemcpyAsync(s.stage8, entries, bytes, hipMemcpyDefault, s.stream));
+      launch_unpack_entries12(s.stream, s.stage8, total / 2, d_ent);
+      HIPCHK(ctx, hipGetLastError());
+    }
+  }
+  // counts and run descriptors: one copy per stretch of consecutive group ids (a decoder thread's batch is usually one)
+  std::vector<uint2> desc(runs);
+  {
+    size_t o = offset;
     for (size_t r = 0; r < runs; r++) {
-      desc[4 * r] = (uint32_t)o;
-      desc[4 * r + 1] = n[r];
-      desc[4 * r + 2] = (uint32_t)(offset + o);
-      desc[4 * r + 3] = group_ids[r / 3] * 3 + (uint32_t)(r % 3);
+      desc[r] = make_uint2((uint32_t)o, n[r]);
       o += n[r];
     }
   }
-  {
-    std::lock_guard<std::mutex> lock(ctx->sp_mutex);
-    if (jxlh_status st = ensure(ctx, ctx->sp_slot_start, ctx->ngroups * 3 * (size_t)kSlotTable)) return st;
-    if (ctx->bucketed.size() != ctx->ngroups) ctx->bucketed.assign(ctx->ngroups, 0);
-    for (uint32_t i = 0; i < count; i++) ctx->bucketed[group_ids[i]] = (flags & JXLH_GROUP_ACCUMULATE) ? 0 : 1;
-  }
-  Slot& s = ctx->slots[slot];
-  {
-    // staging: [entries | slot counts | run descriptors], reused by the slot (stream-ordered).  The copies into it do
-    // not wait for the previous frame: only the pack kernel, which overwrites what that frame's transforms read, does
-    // -- a caller that submits frame i + 1 while frame i runs gets the upload under frame i's kernels
-    auto up = [](size_t v) { return (v + 15) & ~(size_t)15; };
-    const size_t ent_bytes = e12 ? total / 2 * 3 : total * 2;
-    const size_t b_ent = up(ent_bytes), b_cnt = up(runs * 1024), b_desc = up(runs * 16);
-    const size_t need = b_ent + b_cnt + b_desc;
-    if (s.stage8_cap < need) {
-      HIPCHK(ctx, hipStreamSynchronize(s.stream));
-      if (s.stage8) (void)hipFree(s.stage8);
-      s.stage8 = nullptr;
-      s.stage8_cap = 0;
-      const size_t cap = need * 5 / 4 + 4096;
-      if (hipMalloc(reinterpret_cast<void**>(&s.stage8), cap) != hipSuccess) return JXLH_ERR_OUT_OF_MEMORY;
-      s.stage8_cap = cap;
-    }
-    uint8_t* d_ent = s.stage8, *d_cnt = d_ent + b_ent, *d_desc = d_cnt + b_cnt;
-    if (total) HIPCHK(ctx, hipMemcpyAsync(d_ent, entries, ent_bytes, hipMemcpyDefault, s.stream));
-    HIPCHK(ctx, hipMemcpyAsync(d_cnt, slot_counts, runs * 1024, hipMemcpyDefault, s.stream));
-    HIPCHK(ctx, hipMemcpyAsync(d_desc, desc.data(), runs * 16, hipMemcpyHostToDevice, s.stream));
-    if (ctx->sp_expanded_valid) HIPCHK(ctx, hipStreamWaitEvent(s.stream, ctx->sp_expanded, 0));
-    // the pairs and slot tables of the previous frame may still be read by its transforms
-    if (ctx->k1_done_valid) HIPCHK(ctx, hipStreamWaitEvent(s.stream, ctx->k1_done, 0));
-    launch_pack_slots(s.stream, reinterpret_cast<const uint16_t*>(d_ent), d_cnt, reinterpret_cast<const uint32_t*>(d_desc),
-                      (int)runs, ctx->sp_pairs.p, ctx->sp_slot_start.p, e12);
-    HIPCHK(ctx, hipGetLastError());
+  for (uint32_t i0 = 0; i0 < count;) {
+    uint32_t i1 = i0 + 1;
+    while (i1 < count && group_ids[i1] == group_ids[i1 - 1] + 1) i1++;
+    const size_t g0 = group_ids[i0], len = i1 - i0;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->se_counts[pend].p + g0 * 3 * kSlotsPerRun, slot_counts + (size_t)i0 * 3 * kSlotsPerRun,
+                               len * 3 * kSlotsPerRun, hipMemcpyDefault, s.stream));
+    // (built here: a pageable source is staged by the runtime before the call returns)
+    HIPCHK(ctx, hipMemcpyAsync(ctx->se_runs[pend].p + g0 * 3, desc.data() + (size_t)i0 * 3, len * 3 * sizeof(uint2),
+                               hipMemcpyHostToDevice, s.stream));
+    i0 = i1;
   }
   HIPCHK(ctx, hipEventRecord(s.done, s.stream));
   s.used = true;

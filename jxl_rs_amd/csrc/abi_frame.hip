@@ -159,6 +159,13 @@ void jxlh_ctx_destroy(jxlh_ctx* ctx) {
   release(ctx->sp_wide_dev);
   release(ctx->sp_sorted);
   release(ctx->sp_slot_start);
+  release(ctx->bucketed_dev);
+  for (int i = 0; i < 2; i++) {
+    release(ctx->se_entries[i]);
+    release(ctx->se_counts[i]);
+    release(ctx->se_runs[i]);
+    if (ctx->se_read[i]) (void)hipEventDestroy(ctx->se_read[i]);
+  }
   release(ctx->group_dense);
   if (ctx->sp_expanded) (void)hipEventDestroy(ctx->sp_expanded);
   if (ctx->k1_done) (void)hipEventDestroy(ctx->k1_done);
@@ -170,6 +177,7 @@ void jxlh_ctx_destroy(jxlh_ctx* ctx) {
   release(ctx->ytox);
   release(ctx->ytob);
   release(ctx->error_flag);
+  release(ctx->tables_ok);
   release(ctx->rgb8);
   for (auto& b : ctx->ups) release(b);
   for (auto& b : ctx->noise) release(b);
@@ -265,6 +273,7 @@ jxlh_status jxlh_frame_begin(jxlh_ctx* ctx, const jxlh_frame_params* p) {
     ctx->bucketed.assign(ctx->ngroups, 0);
     ctx->epoch_dirty = false;
     ctx->sp_sorted_valid = false;
+    ctx->se_valid = false;
   }
   const size_t nblocks = (size_t)f.xblocks * f.yblocks;
   const size_t ncmap = (size_t)f.cmap_stride * ((f.yblocks + 7) / 8);
@@ -320,7 +329,21 @@ jxlh_status jxlh_frame_begin(jxlh_ctx* ctx, const jxlh_frame_params* p) {
   ctx->tables_set = ctx->tables.p != nullptr && ctx->tables_set;
   if (ctx->tables_set) {
     f.tables = ctx->tables.p;
+    f.tables_ok = ctx->tables_ok.p;
     for (int q = 0; q < JXLH_NUM_QUANT_TABLES; q++) f.table_offset[q] = ctx->table_offset[q];
+  }
+  {
+    auto fin = [](float v) { return v == v && v > -3.0e38f && v < 3.0e38f; };
+    auto bias_ok = [](float v) { return v >= 1e-6f && v <= 1e6f; };
+    f.se_direct_ok = bias_ok(p->quant_biases[0]) && bias_ok(p->quant_biases[1]) && bias_ok(p->quant_biases[2]) &&
+                     fin(p->quant_biases[3]) && fin(f.base_x) && fin(f.base_b) && !(p->flags & JXLH_FRAME_DENSE_DEQUANT);
+    // ... and the table adjust_quant_bias is read from must hold no zero (AdjTable::nofast; same IEEE operations here)
+    for (int i = 2; i < 128 && f.se_direct_ok; i++)
+      if ((float)i - p->quant_biases[3] / (float)i == 0.0f) f.se_direct_ok = 0;
+    static const bool off = [] { const char* e = getenv("JXLH_NO_DIRECT_ENTRIES"); return e && *e && *e != '0'; }();
+    if (off) f.se_direct_ok = 0;  // A/B runs of whole suites
+    ctx->params_direct_ok = f.se_direct_ok != 0;
+    f.se_direct_ok = ctx->params_direct_ok && ctx->tables_set && ctx->tables_ok_host != 0;
   }
   ctx->lf_smoothed = false;
   ctx->rendered = false;
@@ -369,9 +392,15 @@ jxlh_status jxlh_frame_set_dequant_tables(jxlh_ctx* ctx, const float* const tabl
     off += 3 * n[q];
   }
   ctx->fd.tables = ctx->tables.p;
+  if (jxlh_status st2 = ensure(ctx, ctx->tables_ok, 1)) return st2;
+  launch_check_tables(ctx->stream, ctx->tables.p, total, ctx->tables_ok.p);
+  ctx->fd.tables_ok = ctx->tables_ok.p;
+  ctx->tables_ok_host = 0;
+  HIPCHK(ctx, hipMemcpyAsync(&ctx->tables_ok_host, ctx->tables_ok.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   ctx->tables_set = true;
   // like the other setters: the caller's buffers may be reused (or freed) as soon as the call returns
   JXLH_SYNC(ctx);
+  ctx->fd.se_direct_ok = ctx->params_direct_ok && ctx->tables_ok_host != 0;
   return JXLH_OK;
 }
 
@@ -610,15 +639,6 @@ jxlh_status run_prologue(jxlh_ctx* ctx, RunPlan* plan) {
       if (jxlh_status st = ensure(ctx, ctx->sp_groups_dev, ng)) return st;
       if (jxlh_status st = ensure(ctx, ctx->sp_wide_dev, nw)) return st;
       if (jxlh_status st = ensure(ctx, ctx->group_dense, ctx->ngroups)) return st;
-      bool every_group_bucketed = ctx->bucketed.size() == ctx->ngroups && nw == 0 && ng == ctx->ngroups;
-      for (size_t g = 0; every_group_bucketed && g < ctx->ngroups; g++) every_group_bucketed = ctx->bucketed[g] != 0;
-      // (the group list is read by the sort and by the expansion: a frame that arrived slot-bucketed needs neither)
-      if (ng && !(every_group_bucketed && !(p.flags & JXLH_FRAME_EXPAND_SPARSE) && !plan->want_strip))
-        HIPCHK(ctx, hipMemcpyAsync(ctx->sp_groups_dev.p, ctx->sp_upload.data(), ng * sizeof(SparseGroup),
-                                   hipMemcpyHostToDevice, ctx->stream));
-      if (nw)
-        HIPCHK(ctx, hipMemcpyAsync(ctx->sp_wide_dev.p, ctx->sp_wide_upload.data(), nw * sizeof(uint2),
-                                   hipMemcpyHostToDevice, ctx->stream));
       bool all_pairs = nw == 0 && ng == ctx->ngroups && !(p.flags & JXLH_FRAME_EXPAND_SPARSE) && !plan->want_strip;
       for (size_t g = 0; all_pairs && g < ctx->ngroups; g++) all_pairs = ctx->touched[g] == 2;
       // pairs that ADD to a group's earlier passes need that group's dense slab
@@ -629,6 +649,21 @@ jxlh_status run_prologue(jxlh_ctx* ctx, RunPlan* plan) {
           all_pairs = false;
         }
       }
+      // every group arrived slot-bucketed (jxlh_submit_groups_slots): the pending set holds the frame the way the
+      // transforms read it -- no sort, no unpacking, no copy
+      bool any_bucketed = false, all_bucketed = all_pairs && ctx->bucketed.size() == ctx->ngroups;
+      for (size_t g = 0; g < ctx->bucketed.size(); g++) {
+        any_bucketed |= ctx->bucketed[g] != 0;
+        all_bucketed = all_bucketed && ctx->bucketed[g] != 0;
+      }
+      const int pend = ctx->se_live ^ 1;
+      // (the group list is read by the sort and by the expansion: a frame that arrived slot-bucketed needs neither)
+      if (ng && !all_bucketed)
+        HIPCHK(ctx, hipMemcpyAsync(ctx->sp_groups_dev.p, ctx->sp_upload.data(), ng * sizeof(SparseGroup),
+                                   hipMemcpyHostToDevice, ctx->stream));
+      if (nw)
+        HIPCHK(ctx, hipMemcpyAsync(ctx->sp_wide_dev.p, ctx->sp_wide_upload.data(), nw * sizeof(uint2),
+                                   hipMemcpyHostToDevice, ctx->stream));
       if (ctx->sp_sorted_valid && !all_pairs) {
         // leaving the bucketed form: groups not resubmitted now (or only added to) need their dense slab
         ctx->flag_upload.assign(ctx->ngroups, 0);
@@ -639,28 +674,39 @@ jxlh_status run_prologue(jxlh_ctx* ctx, RunPlan* plan) {
           HIPCHK(ctx, hipMemcpyAsync(ctx->group_dense.p, ctx->flag_upload.data(), ctx->ngroups, hipMemcpyHostToDevice,
                                      ctx->stream));
           ScopedKernelTimer t(ctx, "k_expand_sparse");
-          launch_expand_sorted(ctx->stream, ctx->coeffs.p, ctx->sp_sorted.p, ctx->sp_slot_start.p, ctx->group_dense.p,
-                               (int)ctx->ngroups);
+          if (ctx->se_valid)
+            launch_expand_entries(ctx->stream, ctx->coeffs.p, ctx->se_entries[ctx->se_live].p, ctx->se_counts[ctx->se_live].p,
+                                  ctx->se_runs[ctx->se_live].p, ctx->group_dense.p, (int)ctx->ngroups);
+          else
+            launch_expand_sorted(ctx->stream, ctx->coeffs.p, ctx->sp_sorted.p, ctx->sp_slot_start.p, ctx->group_dense.p,
+                                 (int)ctx->ngroups);
         }
       }
-      // every group arrived slot-bucketed (jxlh_submit_groups_slots): the pair buffer already holds what the sort would
-      // produce and the slot tables are written -- no sort and no copy
-      bool all_bucketed = all_pairs && ctx->bucketed.size() == ctx->ngroups;
-      for (size_t g = 0; all_bucketed && g < ctx->ngroups; g++) all_bucketed = ctx->bucketed[g] != 0;
-      if (all_pairs) {
+      if (any_bucketed && !all_bucketed) {
+        // a mixed epoch (other groups as plain pairs or dense slabs, a wide entry, an added pass): the slot-bucketed
+        // groups' entries become pair words at their reserved places of the pair buffer and take the general route
+        if (jxlh_status st = ensure(ctx, ctx->bucketed_dev, ctx->ngroups)) return st;
+        ctx->bucketed_upload = ctx->bucketed;  // stays alive until the next epoch: the copy reads it
+        HIPCHK(ctx, hipMemcpyAsync(ctx->bucketed_dev.p, ctx->bucketed_upload.data(), ctx->ngroups, hipMemcpyHostToDevice,
+                                   ctx->stream));
+        ScopedKernelTimer t(ctx, "k_entries_to_pairs");
+        launch_entries_to_pairs(ctx->stream, ctx->se_entries[pend].p, ctx->se_counts[pend].p, ctx->se_runs[pend].p,
+                                ctx->bucketed_dev.p, (int)ctx->ngroups, ctx->sp_pairs.p);
+      }
+      if (all_bucketed) {
+        ctx->se_live = pend;  // the sets trade places: the next epoch's uploads go to the set read two frames ago
+        ctx->se_valid = true;
+        ctx->sp_sorted_valid = true;
+      } else if (all_pairs) {
         const size_t capacity = ctx->ngroups * 3 * (size_t)kGroupArea;
         if (jxlh_status st = ensure(ctx, ctx->sp_sorted, capacity)) return st;
         if (jxlh_status st = ensure(ctx, ctx->sp_slot_start, ctx->ngroups * 3 * (size_t)kSlotTable)) return st;
-        if (all_bucketed) {
-          // the pair buffer IS the bucketed store of this frame: the two buffers (same capacity) trade places.  The
-          // next epoch's submissions write the buffer the previous frame's transforms read; they wait for sp_expanded,
-          // recorded below behind those transforms in stream order.
-          std::swap(ctx->sp_sorted, ctx->sp_pairs);
-        } else {
+        {
           ScopedKernelTimer t(ctx, "k_sort_sparse");
           launch_sort_sparse(ctx->stream, ctx->sp_pairs.p, ctx->sp_groups_dev.p, (int)ng, ctx->sp_sorted.p,
                              ctx->sp_slot_start.p);
         }
+        ctx->se_valid = false;
         ctx->sp_sorted_valid = true;
       } else {
         if (ng || nw) {
@@ -668,7 +714,13 @@ jxlh_status run_prologue(jxlh_ctx* ctx, RunPlan* plan) {
           launch_expand_sparse(ctx->stream, ctx->coeffs.p, ctx->sp_pairs.p, ctx->sp_groups_dev.p, (int)ng,
                                ctx->sp_wide_dev.p, (uint32_t)nw, nullptr);
         }
+        ctx->se_valid = false;
         ctx->sp_sorted_valid = false;
+      }
+      if (any_bucketed && !all_bucketed) {  // the pending set has been read (it stays the pending one)
+        if (!ctx->se_read[pend]) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->se_read[pend], hipEventDisableTiming));
+        HIPCHK(ctx, hipEventRecord(ctx->se_read[pend], ctx->stream));
+        ctx->se_read_valid[pend] = true;
       }
       ctx->sp_used = 0;
       ctx->bucketed.assign(ctx->ngroups, 0);
@@ -712,6 +764,32 @@ jxlh_status run_prologue(jxlh_ctx* ctx, RunPlan* plan) {
   return JXLH_OK;
 }
 
+// what the transforms read when the frame is resident in a bucketed sparse form: the slot-bucketed entries in place
+// (se_*) or the sorted pair words (sp_sorted); all null = the dense slabs
+static void set_sparse_view(jxlh_ctx* ctx, FrameDev& f, bool sparse_k1) {
+  const bool ent = sparse_k1 && ctx->se_valid;
+  f.sp_sorted = sparse_k1 && !ent ? ctx->sp_sorted.p : nullptr;
+  f.sp_slot_start = sparse_k1 && !ent ? ctx->sp_slot_start.p : nullptr;
+  f.se_entries = ent ? ctx->se_entries[ctx->se_live].p : nullptr;
+  f.se_counts = ent ? ctx->se_counts[ctx->se_live].p : nullptr;
+  f.se_runs = ent ? ctx->se_runs[ctx->se_live].p : nullptr;
+  f.group_dense = sparse_k1 ? ctx->group_dense.p : nullptr;
+}
+// behind the transforms: the coefficient slabs are free again (dense resubmissions of the next frame wait for this,
+// jxlh_submit_group), and so is the live set of the slot-bucketed form once it has become the pending one
+static jxlh_status mark_coefficients_read(jxlh_ctx* ctx, bool sparse_k1) {
+  if (!ctx->k1_done) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->k1_done, hipEventDisableTiming));
+  HIPCHK(ctx, hipEventRecord(ctx->k1_done, ctx->stream));
+  ctx->k1_done_valid = true;
+  if (sparse_k1 && ctx->se_valid) {
+    const int l = ctx->se_live;
+    if (!ctx->se_read[l]) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->se_read[l], hipEventDisableTiming));
+    HIPCHK(ctx, hipEventRecord(ctx->se_read[l], ctx->stream));
+    ctx->se_read_valid[l] = true;
+  }
+  return JXLH_OK;
+}
+
 // K1 for group rows [gr0, gr1) (+ the chroma upsampling of a sub-sampled frame)
 jxlh_status run_k1(jxlh_ctx* ctx, const RunPlan& plan, int gr0, int gr1) {
   FrameDev& f = ctx->fd;
@@ -719,9 +797,7 @@ jxlh_status run_k1(jxlh_ctx* ctx, const RunPlan& plan, int gr0, int gr1) {
   const bool sparse_k1 = plan.sparse_k1;
   {
     ScopedKernelTimer t(ctx, "k1_vardct");
-    f.sp_sorted = sparse_k1 ? ctx->sp_sorted.p : nullptr;
-    f.sp_slot_start = sparse_k1 ? ctx->sp_slot_start.p : nullptr;
-    f.group_dense = sparse_k1 ? ctx->group_dense.p : nullptr;
+    set_sparse_view(ctx, f, sparse_k1);
     // (a whole-frame run rewrites every group's flag in k1_scan: no clearing launch then)
     if (sparse_k1 && !(gr0 == 0 && gr1 == f.ygroups))
       HIPCHK(ctx, hipMemsetAsync(ctx->group_dense.p, 0, ctx->ngroups, ctx->stream));
@@ -732,10 +808,7 @@ jxlh_status run_k1(jxlh_ctx* ctx, const RunPlan& plan, int gr0, int gr1) {
     launch_vardct_groups(ctx->stream, fk, gr0, gr1, ctx->worklist.p, &ctx->k1_launches, ctx->error_flag.p,
                          sparse_k1 ? ctx->coeffs.p : nullptr, nullptr, 0, ctx->has_special, ctx->has_large);
   }
-  // the coefficient slabs are free again: dense resubmissions of the next frame wait for this (jxlh_submit_group)
-  if (!ctx->k1_done) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->k1_done, hipEventDisableTiming));
-  HIPCHK(ctx, hipEventRecord(ctx->k1_done, ctx->stream));
-  ctx->k1_done_valid = true;
+  if (jxlh_status st = mark_coefficients_read(ctx, sparse_k1)) return st;
   ctx->chroma_lazy = false;
   if (f.subsampled) {
     // ... and brought to full resolution into planes[c] before any filter (frame/render.rs:569-576) -- or, when no
@@ -799,9 +872,7 @@ jxlh_status run_strip(jxlh_ctx* ctx, const RunPlan& plan) {
   f.tile_rows = tile_rows;
   f.strip_all_closed = ctx->strip_all_closed ? 1 : 0;
   f.tiled = 1;
-  f.sp_sorted = nullptr;
-  f.sp_slot_start = nullptr;
-  f.group_dense = nullptr;
+  set_sparse_view(ctx, f, false);
   {
     ScopedKernelTimer t(ctx, "k1_vardct");
     launch_vardct_groups(ctx->stream, f, 0, f.ygroups, ctx->worklist.p, &ctx->k1_launches, ctx->error_flag.p, nullptr,
@@ -1048,17 +1119,13 @@ jxlh_status jxlh_frame_rerender_groups(jxlh_ctx* ctx, const uint32_t* group_ids,
                              ctx->stream));
   {
     ScopedKernelTimer t(ctx, "k1_vardct");
-    f.sp_sorted = plan.sparse_k1 ? ctx->sp_sorted.p : nullptr;
-    f.sp_slot_start = plan.sparse_k1 ? ctx->sp_slot_start.p : nullptr;
-    f.group_dense = plan.sparse_k1 ? ctx->group_dense.p : nullptr;
+    set_sparse_view(ctx, f, plan.sparse_k1);
     if (plan.sparse_k1) HIPCHK(ctx, hipMemsetAsync(ctx->group_dense.p, 0, ctx->ngroups, ctx->stream));
     launch_vardct_groups(ctx->stream, f, 0, 0, ctx->worklist.p, &ctx->k1_launches, ctx->error_flag.p,
                          plan.sparse_k1 ? ctx->coeffs.p : nullptr, ctx->rerender_list.p, n, ctx->has_special,
                          ctx->has_large);
   }
-  if (!ctx->k1_done) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->k1_done, hipEventDisableTiming));
-  HIPCHK(ctx, hipEventRecord(ctx->k1_done, ctx->stream));
-  ctx->k1_done_valid = true;
+  if (jxlh_status st = mark_coefficients_read(ctx, plan.sparse_k1)) return st;
   // ---- the filters on every pixel row the listed groups influence: their own rows widened by the stage list's
   // reach (mark_group_to_rerender's 3x3 neighbourhood, restricted to what can actually change), merged into bands
   int prev_lo = -1, prev_hi = -1;

@@ -72,6 +72,9 @@ struct jxlh_ctx {
   DevBuf<uint8_t> transform_map, epf_map;
   DevBuf<int8_t> ytox, ytob;
   DevBuf<int> error_flag;
+  DevBuf<int> tables_ok;     // FrameDev::tables_ok
+  int tables_ok_host = 0;    // ... read back when the tables are set
+  bool params_direct_ok = false;  // the frame parameters' share of FrameDev::se_direct_ok
   DevBuf<uint8_t> rgb8;  // jxlh_frame_read_rgb8 staging for host destinations
   int* host_flag = nullptr;  // pinned
   DevBuf<uint8_t> worklist;
@@ -122,9 +125,22 @@ struct jxlh_ctx {
   // content), 1 dense slab, 2 pairs.  sp_sorted_valid: before this epoch every group's content lived in
   // the bucketed form (and only there).
   std::vector<uint8_t> touched, flag_upload;
-  // groups submitted in the slot-bucketed form in this epoch (jxlh_submit_groups_slots): if that is every group, the
-  // pair buffer already IS the bucketed form and its slot tables are written -- no sort
-  std::vector<uint8_t> bucketed;
+  // groups submitted in the slot-bucketed form in this epoch (jxlh_submit_groups_slots): their entries, slot counts
+  // and run descriptors sit in se_*[se_live ^ 1] exactly as uploaded.  If that is every group (and nothing is added to
+  // earlier passes), jxlh_frame_run makes that set the live one and the transforms read it in place (round 5; round 4
+  // unpacked it into pair words + slot tables at submission time, overwriting the tables the resident frame was read
+  // through); otherwise the flagged groups' entries are widened into the pair buffer first.
+  std::vector<uint8_t> bucketed, bucketed_upload;
+  DevBuf<uint8_t> bucketed_dev;
+  // The two sets trade places when a frame arrives entirely slot-bucketed, so the uploads of frame i + 1 never touch
+  // what the transforms of frame i read; se_read[i]: recorded behind the last kernels that read set i.
+  DevBuf<uint16_t> se_entries[2];
+  DevBuf<uint8_t> se_counts[2];
+  DevBuf<uint2> se_runs[2];
+  hipEvent_t se_read[2] = {nullptr, nullptr};
+  bool se_read_valid[2] = {false, false};
+  int se_live = 0;
+  bool se_valid = false;  // the resident bucketed form is se_*[se_live] (else, with sp_sorted_valid, the pair words)
   bool epoch_dirty = false;
   bool sp_sorted_valid = false;
   // extra channels inside the frame path (jxlh_frame_set_extra_channel): as handed over, converted, upsampled

@@ -134,6 +134,21 @@ struct FrameDev {
   const uint32_t* sp_sorted;
   const uint32_t* sp_slot_start;
   uint8_t* group_dense;
+  // The slot-bucketed 2-byte form read IN PLACE (round 5; null = not this form): what jxlh_submit_groups_slots
+  // uploaded, untouched -- se_entries: u16 = (position & 63) | (value & 1023) << 6 in (group, channel, slot) order;
+  // se_counts[(group*3 + c) * 1024 + s]: entries of slot s; se_runs[group*3 + c] = {frame-wide index of the run's
+  // first entry, entries in the run}.  k1_scan turns the counts into per-varblock entry ranges (work-list side items),
+  // the class kernels read the entries themselves: no unpack pass, no slot tables.
+  const uint16_t* se_entries;
+  const uint8_t* se_counts;
+  const uint2* se_runs;
+  // The entries form may dequantise ONLY the coefficients that have an entry (everything else is +0.0f) when a zero
+  // coefficient provably reconstructs to +0.0f and a non-zero one never to a zero: quant biases 0..2 in [1e-6, 1e6],
+  // finite chroma-from-luma bases (host: se_direct_ok), every dequant weight in [1e-20, 1e20] (device: *tables_ok,
+  // written by k_check_tables when the tables are set).  Otherwise -- and for varblocks with raw_quant == 0 or more entries than a lane holds -- the
+  // class kernels take the dense dequantisation pass.
+  int se_direct_ok;
+  const int* tables_ok;
   // Strip path (k_strip.hip; null = the frame runs K1 -> planes -> filters): written by k1_scan<STRIP> -- per block a
   // descriptor {type | dx << 5 | dy << 7 | off64 << 9 | 1 << 31, raw_quant of its varblock}, per 64x64 tile who
   // reconstructs it (0 = the strip kernel, 1 = K1's class kernels); the scan also clears the strip kernel's progress
@@ -200,6 +215,8 @@ void launch_noise_add(hipStream_t s, float* const planes[3], const float* const 
 void launch_lf_smooth(hipStream_t s, const float* const in[3], float* const out[3], int w, int h,
                       const float lf_factors[3]);
 void launch_sigma_map(hipStream_t s, const FrameDev& f, float epf_quant_mul, const float* sharp_lut);
+// *ok = 1 iff all n dequant weights lie in [1e-20, 1e20] (see FrameDev::tables_ok)
+void launch_check_tables(hipStream_t s, const float* tables, size_t n, int* ok);
 // K1: work-list scan + per-class kernels over group rows [group_row0, group_row1).
 // worklist_mem: device scratch of vardct_worklist_bytes(f) bytes.  It opens with TWO sets of class counters, both
 // zeroed by vardct_worklist_reset() when a frame begins: launch n counts in set n & 1 and its scan kernel clears the
@@ -268,9 +285,6 @@ struct SparseGroup {
 };
 // only_flagged (nullable): expand a group only if only_flagged[group] != 0
 void launch_pack_pairs8(hipStream_t s, const uint16_t* pos, const int8_t* val, size_t n, uint32_t* pairs);
-// the slot-bucketed form (jxlh_submit_groups_slots): pair words in slot order + the slot tables, see k_coeffs.hip
-void launch_pack_slots(hipStream_t s, const uint16_t* entries, const uint8_t* slot_counts, const uint32_t* desc, int n_runs,
-                       uint32_t* pairs, uint32_t* slot_start, bool entries12);
 // the 2-byte form (jxlh_submit_groups_sparse4): n_runs = groups of the batch x 3, desc = 4 words per run, see k_coeffs.hip
 void launch_pack_pairs4(hipStream_t s, const uint16_t* entries, const uint16_t* seg_counts, const uint16_t* pos8,
                         const int8_t* val8, const uint32_t* desc, int n_runs, uint32_t* pairs);
@@ -279,6 +293,17 @@ void launch_expand_sparse(hipStream_t s, int32_t* coeffs, const uint32_t* pairs,
 // dense slabs of the groups with flags[g] != 0 from the bucketed pairs (all groups of the frame)
 void launch_expand_sorted(hipStream_t s, int32_t* coeffs, const uint32_t* sorted, const uint32_t* slot_start,
                           const uint8_t* flags, int n_groups);
+// ---- the slot-bucketed form kept as uploaded (se_* members of FrameDev)
+constexpr int kSlotsPerRun = 1024;  // 64-coefficient slots per (group, channel)
+// 12-bit entries (JXLH_GROUP_ENTRIES12), two per three bytes -> u16 entries; n_pairs = entries / 2 of the whole batch
+void launch_unpack_entries12(hipStream_t s, const uint8_t* bytes, size_t n_pairs, uint16_t* entries);
+// groups with flags[g] != 0: their entries -> {u16 pos; i16 val} pair words at the same indices of `pairs` (the form
+// the sort / the zero-fill + scatter read), for epochs in which not every group arrived slot-bucketed
+void launch_entries_to_pairs(hipStream_t s, const uint16_t* entries, const uint8_t* counts, const uint2* runs,
+                             const uint8_t* flags, int n_groups, uint32_t* pairs);
+// dense slabs of the groups with flags[g] != 0 from their slot-bucketed entries
+void launch_expand_entries(hipStream_t s, int32_t* coeffs, const uint16_t* entries, const uint8_t* counts,
+                           const uint2* runs, const uint8_t* flags, int n_groups);
 // counting sort of every (group, channel) run by slot (pos >> 6) + the slot start table
 void launch_sort_sparse(hipStream_t s, const uint32_t* pairs, const SparseGroup* groups, int n_groups,
                         uint32_t* sorted, uint32_t* slot_start);

@@ -206,21 +206,11 @@ __global__ __launch_bounds__(256) void k_pack_pairs4(const uint16_t* __restrict_
   for (uint32_t j = threadIdx.x; j < no; j += 256)
     pairs[p0 + n4 + j] = (uint32_t)pos8[o0 + j] | ((uint32_t)(uint16_t)(int16_t)val8[o0 + j] << 16);
 }
-// the slot-bucketed form: one workgroup per (group of the batch, channel), thread = slot.  desc[4 * run + {0, 1, 2, 3}] =
-// first entry of the run in `entries`, number of entries n, first pair of the run in `pairs` (frame-wide index),
-// (group * 3 + channel).  Writes the run's pair words in slot order -- the order k_sort_sparse would produce -- and
-// its slot table, so the frame needs no sort.
-// E12: 12-bit entries, two per three bytes (JXLH_GROUP_ENTRIES12); a run starts at byte 3 * (its first entry) / 2
-template <bool E12>
-__global__ __launch_bounds__(kExpandThreads) void k_pack_slots(const uint16_t* __restrict__ entries,
-                                                              const uint8_t* __restrict__ slot_counts,
-                                                              const uint32_t* __restrict__ desc,
-                                                              uint32_t* __restrict__ pairs,
-                                                              uint32_t* __restrict__ slot_start) {
-  __shared__ uint32_t s_wsum[kExpandThreads / 64];
-  const int run = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const uint32_t e0 = desc[4 * run], n = desc[4 * run + 1], first = desc[4 * run + 2], gc = desc[4 * run + 3];
-  const uint32_t mine = slot_counts[(size_t)run * 1024 + tid];
+// ---- the slot-bucketed form (jxlh_submit_groups_slots), kept on the device exactly as uploaded: u16 entries in
+// (group, channel, slot) order, one u8 count per slot, {first entry, entries} per (group, channel) run.  The transforms
+// read it in place (k1_scan derives the per-varblock ranges); the kernels below serve the other routes.
+__device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t mine, uint32_t* s_wsum, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
   uint32_t incl = mine;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
@@ -231,38 +221,93 @@ __global__ __launch_bounds__(kExpandThreads) void k_pack_slots(const uint16_t* _
   __syncthreads();
   uint32_t base = 0;
   for (int w = 0; w < wave; w++) base += s_wsum[w];
-  // a count table that claims more than n entries (a caller's mistake) is cut at n: nothing outside the run is touched
-  const uint32_t excl = min(base + incl - mine, n), end = min(base + incl, n);
-  uint32_t* table = slot_start + (size_t)gc * kSlotTable;
-  table[tid] = first + excl;
-  if (tid == 0) table[1024] = first + n;
-  const uint8_t* __restrict__ bytes = reinterpret_cast<const uint8_t*>(entries) + (size_t)e0 / 2 * 3;
-  for (uint32_t j = excl; j < end; j++) {
-    uint32_t e;
-    int32_t v;
-    if constexpr (E12) {
-      const uint8_t* b = bytes + (size_t)(j >> 1) * 3;
-      e = (j & 1u) ? ((uint32_t)b[1] >> 4 | (uint32_t)b[2] << 4) : ((uint32_t)b[0] | ((uint32_t)b[1] & 15u) << 8);
-      v = (int32_t)(e << 20) >> 26;  // sign-extended 6 bits
-    } else {
-      e = entries[e0 + j];
-      v = (int32_t)(e << 16) >> 22;  // sign-extended 10 bits
-    }
-    pairs[first + j] = ((uint32_t)tid << 6 | (e & 63u)) | ((uint32_t)(uint16_t)(int16_t)v << 16);
-  }
-  // entries the table does not account for (it sums to less than n) would be stale pair words: zero updates instead
+  return base + incl - mine;
+}
+__device__ __forceinline__ uint32_t entry_pair_word(uint32_t e, uint32_t slot) {
+  const int32_t v = (int32_t)(e << 16) >> 22;  // sign-extended 10 bits
+  return (slot << 6 | (e & 63u)) | ((uint32_t)(uint16_t)(int16_t)v << 16);
+}
+
+// 12-bit entries, two per three bytes (JXLH_GROUP_ENTRIES12): every (group, channel) run holds an even number of them,
+// so a whole batch is one stream of 3-byte pairs -> two u16 entries (6-bit value sign-extended to 10)
+__global__ __launch_bounds__(256) void k_unpack_entries12(const uint8_t* __restrict__ bytes, size_t n_pairs,
+                                                          uint16_t* __restrict__ entries) {
+  const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= n_pairs) return;
+  const uint8_t* b = bytes + k * 3;
+  const uint32_t e0 = (uint32_t)b[0] | ((uint32_t)b[1] & 15u) << 8, e1 = (uint32_t)b[1] >> 4 | (uint32_t)b[2] << 4;
+  auto widen = [](uint32_t e) {
+    const int32_t v = (int32_t)(e << 20) >> 26;  // sign-extended 6 bits
+    return (uint32_t)(e & 63u) | ((uint32_t)v & 1023u) << 6;
+  };
+  *reinterpret_cast<uint32_t*>(entries + 2 * k) = widen(e0) | widen(e1) << 16;  // runs start on even entries: aligned
+}
+
+// entries of the flagged groups -> pair words at the same indices (thread = slot).  A count table that claims more
+// than the run holds is cut at the run's end; entries the table does not account for become zero updates.
+__global__ __launch_bounds__(kExpandThreads) void k_entries_to_pairs(const uint16_t* __restrict__ entries,
+                                                                    const uint8_t* __restrict__ counts,
+                                                                    const uint2* __restrict__ runs,
+                                                                    const uint8_t* __restrict__ flags,
+                                                                    uint32_t* __restrict__ pairs) {
+  __shared__ uint32_t s_wsum[kExpandThreads / 64];
+  const int gc = blockIdx.x, tid = threadIdx.x;
+  if (!flags[gc / 3]) return;
+  const uint2 run = runs[gc];
+  const uint32_t mine = counts[(size_t)gc * kSlotsPerRun + tid];
+  const uint32_t excl = block_excl_scan_1024(mine, s_wsum, tid);
+  const uint32_t lo = min(excl, run.y), hi = min(excl + mine, run.y);
+  for (uint32_t j = lo; j < hi; j++) pairs[run.x + j] = entry_pair_word(entries[run.x + j], (uint32_t)tid);
   if (tid == kExpandThreads - 1)
-    for (uint32_t j = end; j < n; j++) pairs[first + j] = (uint32_t)tid << 6;
+    for (uint32_t j = hi; j < run.y; j++) pairs[run.x + j] = (uint32_t)tid << 6;
+}
+
+// dense slab quarter of a flagged group from its entries (the role k_expand_sorted has for the pair form)
+__global__ __launch_bounds__(kExpandThreads) void k_expand_entries(int32_t* __restrict__ coeffs,
+                                                                  const uint16_t* __restrict__ entries,
+                                                                  const uint8_t* __restrict__ counts,
+                                                                  const uint2* __restrict__ runs,
+                                                                  const uint8_t* __restrict__ flags) {
+  __shared__ __attribute__((aligned(16))) int32_t s_q[kQuarter];
+  __shared__ uint32_t s_wsum[kExpandThreads / 64];
+  const int q = blockIdx.x & 3, c = (blockIdx.x >> 2) % 3, group = blockIdx.x / 12, tid = threadIdx.x;
+  if (!flags[group]) return;
+  int4* s4 = reinterpret_cast<int4*>(s_q);
+#pragma unroll
+  for (int i = 0; i < kQuarter / 4 / kExpandThreads; i++) s4[i * kExpandThreads + tid] = make_int4(0, 0, 0, 0);
+  const int gc = group * 3 + c;
+  const uint2 run = runs[gc];
+  const uint32_t mine = counts[(size_t)gc * kSlotsPerRun + tid];
+  const uint32_t excl = block_excl_scan_1024(mine, s_wsum, tid);  // (its barrier also publishes the zero fill)
+  if ((tid >> 8) == q) {
+    const uint32_t lo = min(excl, run.y), hi = min(excl + mine, run.y);
+    for (uint32_t j = lo; j < hi; j++) {
+      const uint32_t e = entries[run.x + j];
+      atomicAdd(&s_q[(tid & 255) * 64 + (int)(e & 63u)], (int32_t)(e << 16) >> 22);
+    }
+  }
+  __syncthreads();
+  int4* d4 = reinterpret_cast<int4*>(coeffs + ((size_t)group * 3 + c) * kGroupArea + q * kQuarter);
+#pragma unroll
+  for (int i = 0; i < kQuarter / 4 / kExpandThreads; i++) d4[i * kExpandThreads + tid] = s4[i * kExpandThreads + tid];
 }
 }  // namespace
 
-void launch_pack_slots(hipStream_t s, const uint16_t* entries, const uint8_t* slot_counts, const uint32_t* desc, int n_runs,
-                       uint32_t* pairs, uint32_t* slot_start, bool entries12) {
-  if (n_runs <= 0) return;
-  if (entries12)
-    hipLaunchKernelGGL(k_pack_slots<true>, dim3(n_runs), dim3(kExpandThreads), 0, s, entries, slot_counts, desc, pairs, slot_start);
-  else
-    hipLaunchKernelGGL(k_pack_slots<false>, dim3(n_runs), dim3(kExpandThreads), 0, s, entries, slot_counts, desc, pairs, slot_start);
+void launch_unpack_entries12(hipStream_t s, const uint8_t* bytes, size_t n_pairs, uint16_t* entries) {
+  if (n_pairs == 0) return;
+  hipLaunchKernelGGL(k_unpack_entries12, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, s, bytes, n_pairs, entries);
+}
+
+void launch_entries_to_pairs(hipStream_t s, const uint16_t* entries, const uint8_t* counts, const uint2* runs,
+                             const uint8_t* flags, int n_groups, uint32_t* pairs) {
+  if (n_groups > 0)
+    hipLaunchKernelGGL(k_entries_to_pairs, dim3(n_groups * 3), dim3(kExpandThreads), 0, s, entries, counts, runs, flags, pairs);
+}
+
+void launch_expand_entries(hipStream_t s, int32_t* coeffs, const uint16_t* entries, const uint8_t* counts,
+                           const uint2* runs, const uint8_t* flags, int n_groups) {
+  if (n_groups > 0)
+    hipLaunchKernelGGL(k_expand_entries, dim3(n_groups * 12), dim3(kExpandThreads), 0, s, coeffs, entries, counts, runs, flags);
 }
 
 void launch_pack_pairs4(hipStream_t s, const uint16_t* entries, const uint16_t* seg_counts, const uint16_t* pos8,

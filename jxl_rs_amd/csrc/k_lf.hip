@@ -121,6 +121,25 @@ void launch_lf_smooth(hipStream_t s, const float* const in[3], float* const out[
   hipLaunchKernelGGL(k0b_lf_smooth, dim3((w + 255) / 256, h), dim3(256), 0, s, p, w, h);
 }
 
+namespace {
+__global__ __launch_bounds__(256) void k_check_tables(const float* __restrict__ t, size_t n, int* __restrict__ ok) {
+  bool bad = false;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float v = t[i];
+    bad |= !(v >= 1e-20f) || !(v <= 1e20f);  // (NaN fails the first test.)  Inside this range a non-zero coefficient
+                                             // never dequantises to a zero: see run_dct_class, direct path
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicAnd(ok, 0);
+}
+}  // namespace
+void launch_check_tables(hipStream_t s, const float* tables, size_t n, int* ok) {
+  (void)hipMemsetAsync(ok, 0, sizeof(int), s);
+  if (n == 0) return;
+  const int one = 1;
+  (void)hipMemcpyAsync(ok, &one, sizeof(int), hipMemcpyHostToDevice, s);  // pageable: staged before the call returns
+  hipLaunchKernelGGL(k_check_tables, dim3(64), dim3(256), 0, s, tables, n, ok);
+}
+
 void launch_sigma_map(hipStream_t s, const FrameDev& f, float epf_quant_mul, const float* sharp_lut) {
   const size_t n = (size_t)f.xblocks * f.yblocks;
   SharpLut lut;

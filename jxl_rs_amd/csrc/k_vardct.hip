@@ -55,7 +55,13 @@ constexpr int kScanThreads = kScanGroups * kThreads;
 // (what aligning every varblock to its own size gives) -- writes a descriptor
 // per block of those tiles ({type | dx << 5 | dy << 7 | off64 << 9 | 1 << 31, raw_quant of the varblock}: everything the
 // strip kernel needs to find a block's varblock and its coefficients) and appends work items for the OTHER tiles only.
-template <bool STRIP>
+// ENT (the frame is read in the slot-bucketed form, FrameDev::se_*): the scan also turns the group's slot counts into
+// the entry range of every varblock -- an exclusive prefix sum over the 1024 slots of each channel (a thread loads the
+// counts of four slots as one word, the three channels ride one 64-bit block scan, 17 bits each), kept in LDS and read
+// at the varblock's first slot -- and writes it beside the work item: the class kernels then go from the item straight
+// to the entries.  This replaces the unpack pass of round 4 (pair words + 4-byte slot tables: 69 + 12.6 MB written and
+// read again per 8K frame).
+template <bool STRIP, bool ENT = false>
 __global__ __launch_bounds__(kScanThreads) void k1_scan(const FrameDev f, const WorkLists wl, const int group_row0,
                                                          int* __restrict__ error_flag,
                                                          const int* __restrict__ group_list, const int ngroups,
@@ -65,6 +71,9 @@ __global__ __launch_bounds__(kScanThreads) void k1_scan(const FrameDev f, const 
   __shared__ uint32_t s_wcls[kScanGroups][kWaves][kPairs];
   __shared__ int s_count[kScanGroups][kNumClasses], s_base[kScanGroups][kNumClasses];
   __shared__ int s_tmode[kScanGroups][16];  // STRIP: != 0 = a tile of the group (4 x 4 of them) the class kernels keep
+  // ENT: exclusive prefix of the slot counts, three channels packed (17 bits each; a run holds at most 65536 entries)
+  __shared__ uint64_t s_pref[ENT ? kScanGroups : 1][ENT ? kSlotsPerRun + 1 : 1];
+  __shared__ uint64_t s_wpref[ENT ? kScanGroups : 1][kWaves];
   if constexpr (STRIP) {
     if (threadIdx.x < kScanGroups * 16) s_tmode[threadIdx.x / 16][threadIdx.x % 16] = 0;
     // progress flags + ticket counter of the strip kernel that follows
@@ -94,6 +103,18 @@ __global__ __launch_bounds__(kScanThreads) void k1_scan(const FrameDev f, const 
   // the four blocks of a thread share one colour tile (8 blocks wide, bx4 % 4 == 0)
   const int ci = (gby / kColorTileBlocks) * f.cmap_stride + min(bx0 + bx4, f.xblocks - 1) / kColorTileBlocks;
   const uint32_t cc = (uint32_t)(uint8_t)f.ytox[ci] | (uint32_t)(uint8_t)f.ytob[ci] << 8;
+  // ENT: counts of slots 4 tid .. 4 tid + 3 of the three channels, {first entry, entries} of the three runs
+  uint32_t cw[3] = {0u, 0u, 0u};
+  uint2 run[3] = {make_uint2(0u, 0u), make_uint2(0u, 0u), make_uint2(0u, 0u)};
+  if constexpr (ENT) {
+    if (live) {
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        cw[c] = *reinterpret_cast<const uint32_t*>(f.se_counts + ((size_t)group * 3 + c) * kSlotsPerRun + 4 * tid);
+        run[c] = f.se_runs[group * 3 + c];
+      }
+    }
+  }
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     const int bx = bx4 + i;
@@ -141,6 +162,18 @@ __global__ __launch_bounds__(kScanThreads) void k1_scan(const FrameDev f, const 
     if (lane >= d) incl += n;
   }
   if (lane == 63) s_wave_sum[sub][wave] = incl;
+  uint64_t pmine = 0, pincl = 0;
+  if constexpr (ENT) {
+    auto bytes = [](uint32_t w) { return (uint64_t)((w & 0xffu) + ((w >> 8) & 0xffu) + ((w >> 16) & 0xffu) + (w >> 24)); };
+    pmine = bytes(cw[0]) | bytes(cw[1]) << 17 | bytes(cw[2]) << 34;
+    pincl = pmine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)pincl, d, 64), hi = (uint32_t)__shfl_up((int)(uint32_t)(pincl >> 32), d, 64);
+      if (lane >= d) pincl += (uint64_t)lo | (uint64_t)hi << 32;
+    }
+    if (lane == 63) s_wpref[sub][wave] = pincl;
+  }
   // per-class rank of every varblock in raster order (stable: neighbouring blocks stay neighbours in the lists ->
   // contiguous coefficient reads, full-line pixel writes).  Two classes share a 32-bit word, 16 bits each (a group
   // holds at most 1024 varblocks).
@@ -179,6 +212,20 @@ __global__ __launch_bounds__(kScanThreads) void k1_scan(const FrameDev f, const 
     if (lane == 63) s_wcls[sub][wave][w] = inc;
   }
   __syncthreads();
+  if constexpr (ENT) {
+    uint64_t base = pincl - pmine;
+#pragma unroll
+    for (int v = 0; v < kWaves; v++)
+      if (v < wave) base += s_wpref[sub][v];
+    uint64_t* P = s_pref[sub] + 4 * tid;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      P[k] = base;
+      base += (uint64_t)((cw[0] >> (8 * k)) & 0xffu) | (uint64_t)((cw[1] >> (8 * k)) & 0xffu) << 17 |
+              (uint64_t)((cw[2] >> (8 * k)) & 0xffu) << 34;
+    }
+    if (tid == kThreads - 1) P[4] = base;  // the run's total (entry kSlotsPerRun)
+  }
   int off64 = incl - local;
   int group_total = 0;
 #pragma unroll
@@ -242,6 +289,25 @@ __global__ __launch_bounds__(kScanThreads) void k1_scan(const FrameDev f, const 
 #pragma unroll
         for (int w = 0; w < kPairs; w++)
           if ((cls >> 1) == w) rank += (int)((excl[w] >> sh) & 0xffffu);
+        if constexpr (ENT) {
+          if (cls < kClsSpecial) {
+            // (the prefixes were published by the barriers above.)  A count table that claims more than its run holds
+            // is cut at the run's end: no entry outside the run is ever read
+            const uint64_t p0 = s_pref[sub][off64], p1 = s_pref[sub][min(off64 + sizes[i], kSlotsPerRun)];
+            EntryItem ei;
+            uint32_t n[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+              const uint32_t a0 = min((uint32_t)(p0 >> (17 * c)) & 0x1ffffu, run[c].y);
+              const uint32_t a1 = min((uint32_t)(p1 >> (17 * c)) & 0x1ffffu, run[c].y);
+              ei.e0[c] = run[c].x + a0;
+              n[c] = min(a1 - a0, 1024u);
+            }
+            ei.nxy = n[0] | n[1] << 16;
+            it.group |= n[2] << 16;
+            wl.eitems[cls][s_base[sub][cls] + rank] = ei;
+          }
+        }
         wl.items[cls][s_base[sub][cls] + rank] = it;
       }
       if constexpr (STRIP) {
@@ -337,6 +403,189 @@ __device__ __forceinline__ void sparse_stage_channel(const FrameDev& f, int ch, 
   wave_sync();
 }
 
+// ---- the slot-bucketed entries read in place (SPARSE == 2).  The varblock's entry range per channel comes with the
+// work item (k1_scan<ENT>), so the first entries of all three channels are requested one memory round trip after the
+// item -- the pair form needs two (slot table, then pairs).  The LPB lanes of a varblock share its range evenly
+// (entry r of the range goes to lane r % LPB); an entry carries only its position inside its 64-coefficient slot, so
+// for varblocks of more than one slot the lane finds the slot of entry r in the exclusive prefix of the varblock's
+// slot counts (one byte load per slot and channel, a segmented shuffle scan, 10 bits per channel in one LDS word per
+// slot): log2(slots) LDS reads per entry.
+// entries a lane holds per channel before it has to go back to memory: a varblock with at most D * LPB entries per
+// channel is staged without a second round trip (and may take the direct path below)
+// (a d1-like varblock has an entry at ~11 % of its Y positions, half / two thirds of that in X / B:
+// profiles/r05_c_entry_counts.txt)
+template <class S>
+constexpr int ent_depth() {
+  constexpr int per_lane = S::E;                    // coefficients per lane and channel: 8, 16 or 32
+  constexpr int lpb = 64 / S::NB;
+  return per_lane <= 8 ? 3 : per_lane <= 16 ? (lpb <= 8 ? 4 : 3) : (lpb <= 8 ? 6 : lpb <= 16 ? 5 : 4);
+}
+template <int D>
+struct EntLane {
+  uint32_t i0[3], i1[3];  // this lane's first entry / the end of the varblock's range, per channel (frame-wide indices)
+  uint32_t e[3][D];       // the lane's first D entries of each channel
+};
+template <class S, int D>
+__device__ __forceinline__ void entries_begin(const FrameDev& f, const BlockInfo* __restrict__ binfo, uint32_t* __restrict__ s_excl,
+                                              int nb, int lane, EntLane<D>& sl) {
+  constexpr int LPB = 64 / S::NB, NS = S::N / 64;
+  static_assert(LPB >= NS, "one lane per slot for the count scan");
+  const int b = lane / LPB, j = lane % LPB;
+  const bool on = b < nb;
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    sl.i0[c] = on ? binfo[b].e0[c] + j : 0u;
+    sl.i1[c] = on ? binfo[b].e0[c] + binfo[b].en[c] : 0u;
+  }
+#pragma unroll
+  for (int c = 0; c < 3; c++)
+#pragma unroll
+    for (int k = 0; k < D; k++) {
+      const uint32_t i = sl.i0[c] + k * LPB;
+      sl.e[c][k] = i < sl.i1[c] ? (uint32_t)f.se_entries[i] : 0u;
+    }
+  if constexpr (NS > 1) {
+    uint32_t packed = 0;
+    if (on && j < NS) {
+      const uint8_t* cp = f.se_counts + binfo[b].cnt_base + j;
+      packed = (uint32_t)cp[0] | (uint32_t)cp[kSlotsPerRun] << 10 | (uint32_t)cp[2 * kSlotsPerRun] << 20;
+    }
+    // exclusive scan over the block's lanes (segments of LPB lanes): shift by one slot, then an inclusive scan
+    uint32_t x = (uint32_t)__shfl_up((int)packed, 1, LPB);
+    if (j == 0) x = 0;
+#pragma unroll
+    for (int d = 1; d < NS; d <<= 1) {
+      const uint32_t y = (uint32_t)__shfl_up((int)x, d, LPB);
+      if (j >= d) x += y;
+    }
+    if (j < NS) s_excl[b * NS + j] = x;  // b < NB always: the tile holds NB * NS words
+  }
+}
+// position (in the varblock's stored order) of entry e, the r-th of the varblock's range of channel ch
+template <class S>
+__device__ __forceinline__ int entry_pos(const uint32_t* __restrict__ s_excl, int b, int ch, uint32_t e, uint32_t r) {
+  constexpr int NS = S::N / 64;
+  int sidx = 0;
+  if constexpr (NS > 1) {
+#pragma unroll
+    for (int step = NS / 2; step >= 1; step >>= 1) {
+      const uint32_t v = (s_excl[b * NS + sidx + step] >> (10 * ch)) & 1023u;
+      if (r >= v) sidx += step;
+    }
+  }
+  return sidx * 64 + (int)(e & 63u);
+}
+template <class S>
+__device__ __forceinline__ void zero_tile(int* __restrict__ ibuf, int lane) {
+  constexpr int kWords = S::NB * S::SM;
+  if constexpr (kWords % 4 == 0) {
+    for (int i = lane * 4; i < kWords; i += 256) *reinterpret_cast<int4*>(ibuf + i) = make_int4(0, 0, 0, 0);
+  } else {
+    for (int i = lane; i < kWords; i += 64) ibuf[i] = 0;
+  }
+}
+
+template <class S, int D>
+__device__ __forceinline__ void entries_stage_channel(const FrameDev& f, int ch, float* __restrict__ buf,
+                                                      const uint32_t* __restrict__ s_excl, int lane, const EntLane<D>& sl) {
+  int* ibuf = reinterpret_cast<int*>(buf);
+  zero_tile<S>(ibuf, lane);
+  wave_sync();
+  constexpr int LPB = 64 / S::NB;
+  const int b = lane / LPB, j = lane % LPB;
+  auto add = [&](uint32_t e, uint32_t r) {  // r: index of the entry inside the varblock's range
+    atomicAdd(&ibuf[m_addr<S>(b, entry_pos<S>(s_excl, b, ch, e, r))], (int)(e << 16) >> 22);
+  };
+#pragma unroll
+  for (int k = 0; k < D; k++)
+    if (sl.i0[ch] + k * LPB < sl.i1[ch]) add(sl.e[ch][k], (uint32_t)(j + k * LPB));
+  uint32_t r = (uint32_t)(j + D * LPB);
+  for (uint32_t i = sl.i0[ch] + D * LPB; i < sl.i1[ch]; i += LPB, r += LPB) add((uint32_t)f.se_entries[i], r);
+  wave_sync();
+}
+
+// ---- the direct path of the entries form: only the coefficients that HAVE an entry are dequantised; every other
+// position of the tile is +0.0f, which is what the reference computes for a zero coefficient under the conditions
+// FrameDev::se_direct_ok / tables_ok / AdjTable::nofast establish (group.rs:85-133: (0.0 * bias_c) * mul = +0.0,
+// fma(cc, +0.0, +0.0) = +0.0; a non-zero coefficient never dequantises to a zero).  At d1 about one coefficient in ten
+// has an entry: the dense pass (tile read, ~10 vector instructions and an LDS table lookup per POSITION, tile write)
+// becomes ~15 instructions per ENTRY.  Duplicate positions (several passes' updates in one list) still add up as
+// integers first:
+//   a  ds_add of the entry's value into the zeroed tile              (integer sums, like `coeffs[i] += v`)
+//   b  ds exchange of the word with a sentinel: the first lane to arrive gets the sum and owns the position
+//   c  the owner writes the dequantised float over the sentinel
+// (LDS operations of a wavefront execute in program order: every lane's step a is done before any step b, every b
+// before any c.)  The sentinel INT32_MIN cannot be a sum: a run holds at most 65536 entries of 10 bits.  X and B then
+// add the chroma-from-luma term at the positions Y owns, fma(cc, dy, v) in the reference's form; where Y has no entry
+// the reference's fma(cc, +0.0, v) returns v itself (v is never -0.0).
+template <int D>
+struct EntDirect {
+  uint32_t ad[3][D];  // position of the entry's coefficient in the varblock | value << 16; kNoEntry = no k-th entry
+};
+constexpr uint32_t kNoEntry = 0xffffffffu;
+constexpr int kClaimed = (int)0x80000000;
+
+template <class S, int CH, int D>
+__device__ __forceinline__ void direct_stage_channel(const FrameDev& f, float* __restrict__ buf, int lane,
+                                                     const EntDirect<D>& ed, const float* __restrict__ table, int tsize,
+                                                     float sdy, float cc, const AdjTable* __restrict__ adj,
+                                                     float (&dyw)[D], uint32_t& ywin) {
+  int* ibuf = reinterpret_cast<int*>(buf);
+  constexpr int LPB = 64 / S::NB;
+  const int b = lane / LPB;
+  // the dequant weights of this channel's entries: requested first, needed in step c
+  float w[D];
+#pragma unroll
+  for (int k = 0; k < D; k++) w[k] = ed.ad[CH][k] != kNoEntry ? table[CH * tsize + (int)(ed.ad[CH][k] & 0xffffu)] : 0.0f;
+  zero_tile<S>(ibuf, lane);
+  wave_sync();
+  int at[D];
+#pragma unroll
+  for (int k = 0; k < D; k++) {
+    at[k] = m_addr<S>(b, (int)(ed.ad[CH][k] & 0x3ffu));
+    if (ed.ad[CH][k] != kNoEntry) atomicAdd(&ibuf[at[k]], (int)ed.ad[CH][k] >> 16);
+  }
+  wave_sync();
+  int sum[D];
+#pragma unroll
+  for (int k = 0; k < D; k++) {
+    sum[k] = kClaimed;
+    if (ed.ad[CH][k] != kNoEntry) sum[k] = atomicExch(&ibuf[at[k]], kClaimed);
+  }
+  wave_sync();
+  float sd = sdy;
+  if constexpr (CH == 0) sd = sdy * f.x_dm;
+  if constexpr (CH == 2) sd = sdy * f.b_dm;
+#pragma unroll
+  for (int k = 0; k < D; k++) {
+    if (sum[k] != kClaimed) {
+      // dequant_lane (group.rs:100-133) for one coefficient, the operations of dequant4t
+      const int q = sum[k], aq = q < 0 ? -q : q;
+      float am = adj->v[CH][min(aq, kAdjN - 1)];
+      if (aq >= kAdjN)
+        am = __uint_as_float(__float_as_uint(adjust_quant_bias(q, f.quant_biases[CH], f.quant_biases[3])) ^ ((uint32_t)q & 0x80000000u));
+      const float a = __uint_as_float(__float_as_uint(am) ^ ((uint32_t)q & 0x80000000u));
+      const float mul = w[k] * sd;
+      const float v = a * mul;
+      if constexpr (CH == 1) {
+        dyw[k] = v;
+        ywin |= 1u << k;
+      }
+      buf[at[k]] = v;
+    }
+  }
+  if constexpr (CH != 1) {
+    wave_sync();
+#pragma unroll
+    for (int k = 0; k < D; k++)
+      if ((ywin >> k) & 1u) {
+        float* t = buf + m_addr<S>(b, (int)(ed.ad[1][k] & 0x3ffu));
+        *t = __builtin_fmaf(cc, dyw[k], *t);
+      }
+  }
+  wave_sync();
+}
+
 template <class S>
 __device__ __forceinline__ int4 tile_q4(const float* __restrict__ buf, int b, int k) {
   const int* ibuf = reinterpret_cast<const int*>(buf);
@@ -355,10 +604,17 @@ __device__ __forceinline__ int4 tile_q4(const float* __restrict__ buf, int b, in
 // SUB (chroma-subsampled frames, S8x8 only): a channel holds a block only if the block is aligned to the channel's
 // sampling (decode_item marks the others with px_off == scrap_off); their coefficients are never decoded (zeros
 // in the reference's slab, frame/group.rs:521-524), so the loads are skipped and read as zero, and nothing is stored.
-template <class S, bool PREFETCH, bool SPARSE, bool SUB = false>
-__device__ __forceinline__ int run_dct_class(const FrameDev& f, const WorkItem* __restrict__ items, int count, int type,
-                                             float* __restrict__ buf, BlockInfo* __restrict__ binfo_base, int gwave,
-                                             int nwaves, int lane, const AdjTable* __restrict__ adj) {
+// SPARSE: 0 = dense slabs, 1 = bucketed pair words + slot tables (sp_sorted), 2 = slot-bucketed entries in place (se_*)
+// with the dense dequantisation pass, 3 = the same input, direct path only: batches it cannot take go to the fallback
+// list (WorkLists::fallback), which k1_entries_fallback runs through mode 2.  cls: the class id (mode 3's list entries).
+template <class S, bool PREFETCH, int SPARSE, bool SUB = false, int CLS = 0>
+__device__ __forceinline__ int run_dct_class(const FrameDev& f, const WorkItem* __restrict__ items,
+                                             const EntryItem* __restrict__ eitems, int count, int type,
+                                             float* __restrict__ buf, BlockInfo* __restrict__ binfo_base,
+                                             uint32_t* __restrict__ s_excl, float* __restrict__ s_lf, int gwave,
+                                             int nwaves, int lane, const AdjTable* __restrict__ adj,
+                                             uint32_t* __restrict__ wl_fallback = nullptr,
+                                             int* __restrict__ fallback_count = nullptr) {
   constexpr int NCH = S::E / 4;  // 16-byte chunks per lane per channel
   const int q = quant_table_for_type(type);
   const float* __restrict__ table = f.tables + f.table_offset[q];
@@ -366,99 +622,101 @@ __device__ __forceinline__ int run_dct_class(const FrameDev& f, const WorkItem* 
   const int nbatches = (count + S::NB - 1) / S::NB;
   // the weights a lane needs do not depend on the batch
   float4 tw[PREFETCH ? 3 : 1][NCH];
-  if constexpr (PREFETCH) {
+  if constexpr (PREFETCH && SPARSE != 3) {
 #pragma unroll
     for (int c = 0; c < 3; c++)
 #pragma unroll
       for (int j = 0; j < NCH; j++)
         tw[c][j] = *reinterpret_cast<const float4*>(table + c * tsize + ((j * 64 + lane) * 4) % S::N);
   }
+  // The entries form is bound by the chain of dependent memory round trips of a batch (item -> entries, then the LF
+  // samples of each channel right before its transform: five per batch, 72 % of a wavefront's life parked on them,
+  // profiles/r05_b_sparse_pairs_pmc.txt), not by bytes.  kChain: the NEXT batch's items are requested while this one is
+  // transformed, and the LF samples of all three channels are requested together with the entries (spread over the
+  // lanes, handed over through LDS): one exposed round trip per batch.
+  constexpr bool kChain = SPARSE >= 2;
+#ifndef JXLH_ITEM_PREFETCH
+#define JXLH_ITEM_PREFETCH 1  // 0 none, 1 the 8..16-point classes (register-light bodies), 2 every class
+#endif
+  constexpr bool kNextItem = kChain && (JXLH_ITEM_PREFETCH == 2 || (JXLH_ITEM_PREFETCH == 1 && PREFETCH));
+  constexpr int kLfPerBlock = 3 * (S::R / 8) * (S::C / 8), kLfIters = (S::NB * kLfPerBlock + 63) / 64;
+  WorkItem it_next = {};
+  EntryItem ei_next = {};
+  if constexpr (kNextItem) {
+    if (gwave < nbatches && lane < min(S::NB, count - gwave * S::NB)) {
+      it_next = items[gwave * S::NB + lane];
+      ei_next = eitems[gwave * S::NB + lane];
+    }
+  }
   for (int batch = gwave; batch < nbatches; batch += nwaves) {
     const int nb = min(S::NB, count - batch * S::NB);
     BlockInfo* __restrict__ binfo = binfo_base;
-    if (lane < nb) {
+    if constexpr (kChain) {
+      WorkItem it = it_next;
+      EntryItem ei = ei_next;
+      if constexpr (kNextItem) {
+        const int nxt = batch + nwaves;
+        if (nxt < nbatches && lane < min(S::NB, count - nxt * S::NB)) {
+          it_next = items[nxt * S::NB + lane];
+          ei_next = eitems[nxt * S::NB + lane];
+        }
+      } else if (lane < nb) {
+        it = items[batch * S::NB + lane];
+        ei = eitems[batch * S::NB + lane];
+      }
+      if (lane < nb) {
+        decode_item(f, it, &binfo[lane]);
+#pragma unroll
+        for (int c = 0; c < 3; c++) binfo[lane].e0[c] = ei.e0[c];
+        binfo[lane].en[0] = ei.nxy & 0xffffu;
+        binfo[lane].en[1] = ei.nxy >> 16;
+        binfo[lane].en[2] = it.group >> 16;
+      }
+    } else if (lane < nb) {
       const WorkItem it = items[batch * S::NB + lane];
       decode_item(f, it, &binfo[lane]);
     }
     wave_sync();
     SparseLane sl;
-    if constexpr (SPARSE) {
+    constexpr int D = ent_depth<S>();
+    EntLane<D> el;
+    if constexpr (SPARSE == 1) {
       sparse_ranges<S>(f, binfo, nb, lane, sl);
       sparse_first<S>(f, sl);
+    } else if constexpr (SPARSE >= 2) {
+      entries_begin<S, D>(f, binfo, s_excl, nb, lane, el);
     }
-    int4 qv[PREFETCH ? 3 : 1][NCH];
-    if constexpr (PREFETCH && !SPARSE) {
+    if constexpr (kChain) {
+      // LF sample idx = (block, channel, y, x) of the batch: requested now, in LDS before the first transform
+      float lfv[kLfIters];
 #pragma unroll
-      for (int c = 0; c < 3; c++)
-#pragma unroll
-        for (int j = 0; j < NCH; j++) {
-          const int fl = (j * 64 + lane) * 4;
-          const int b = fl / S::N, k = fl % S::N;
-          qv[c][j] = make_int4(0, 0, 0, 0);
-          if (b < nb && (!SUB || binfo[b].px_off[c] != f.scrap_off))
-            qv[c][j] = gload_i4<JXLH_NT_COEF>(f.coeffs + binfo[b].coef_off + c * kGroupArea + k);
-        }
-    }
-    // The dequantised Y the X / B channels' chroma-from-luma needs: kept in registers across the channels -- except for
-    // the shape with 32 of them per lane (32x32, dense input), where they would sit through two 32-point IDCTs
-    // (167 VGPRs + 16 spilled + 68 bytes of scratch for that class alone): there X and B dequantise their Y values again
-    // (the coefficient read hits L2, the table-driven dequantisation is ~10 instructions per value).
-    constexpr bool kRecomputeY = !SPARSE && !PREFETCH && S::E > 16;
-    float dy[kRecomputeY ? 4 : S::E];
-    auto run_channel = [&](auto ch_tag) {
-      constexpr int CH = decltype(ch_tag)::value;
-      if constexpr (SPARSE) sparse_stage_channel<S>(f, CH, buf, lane, sl);
-#pragma unroll
-      for (int j = 0; j < NCH; j++) {
-        const int fl = (j * 64 + lane) * 4;
-        const int b = fl / S::N, k = fl % S::N;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        float d4[4];
-        if constexpr (kRecomputeY) {
-          d4[0] = d4[1] = d4[2] = d4[3] = 0.0f;
-        } else {
-          d4[0] = dy[j * 4];
-          d4[1] = dy[j * 4 + 1];
-          d4[2] = dy[j * 4 + 2];
-          d4[3] = dy[j * 4 + 3];
-        }
+      for (int i = 0; i < kLfIters; i++) {
+        const int idx = i * 64 + lane, b = idx / kLfPerBlock, rem = idx % kLfPerBlock;
+        const int c = rem / ((S::R / 8) * (S::C / 8)), yx = rem % ((S::R / 8) * (S::C / 8));
+        const int y = yx / (S::C / 8), x = yx % (S::C / 8);
+        lfv[i] = 0.0f;
         if (b < nb) {
-          const BlockInfo bi = binfo[b];
-          int4 qq;
-          float4 tt;
-          if constexpr (SPARSE) {
-            qq = tile_q4<S>(buf, b, k);  // converted in place: this lane alone touches (b, k..k+3)
-            if constexpr (PREFETCH) tt = tw[CH][j];
-            else tt = *reinterpret_cast<const float4*>(table + CH * tsize + k);
-          } else if constexpr (PREFETCH) {
-            qq = qv[CH][j];
-            tt = tw[CH][j];
-          } else {
-            qq = gload_i4<JXLH_NT_COEF>(f.coeffs + bi.coef_off + CH * kGroupArea + k);
-            tt = *reinterpret_cast<const float4*>(table + CH * tsize + k);
-            if constexpr (kRecomputeY && CH != 1) {
-              const int4 qy = gload_i4<false>(f.coeffs + bi.coef_off + kGroupArea + k);
-              const float4 ty = *reinterpret_cast<const float4*>(table + tsize + k);
-              (void)dequant4t<1>(f, qy, ty, bi, adj, d4);
-            }
-          }
-          v = dequant4t<CH>(f, qq, tt, bi, adj, d4);
+          const float* __restrict__ lp = c == 0 ? f.lf[0] : c == 1 ? f.lf[1] : f.lf[2];
+          lfv[i] = lp[binfo[b].lf_off[c] + y * f.xblocks + x];
         }
-        if constexpr (CH == 1 && !kRecomputeY) {
-          dy[j * 4] = d4[0];
-          dy[j * 4 + 1] = d4[1];
-          dy[j * 4 + 2] = d4[2];
-          dy[j * 4 + 3] = d4[3];
-        }
-        stage4<S>(buf, b, k, v);
       }
-      wave_sync();
+#pragma unroll
+      for (int i = 0; i < kLfIters; i++)
+        if (i * 64 + lane < S::NB * kLfPerBlock) s_lf[i * 64 + lane] = lfv[i];
+      // (published by the wave_sync that follows the tile's zero fill in entries_stage_channel)
+    }
+    auto transform_channel = [&](auto ch_tag) {
+      constexpr int CH = decltype(ch_tag)::value;
       const float* __restrict__ lfp = f.lf[CH];
       float* __restrict__ plane = f.planes[CH];
       const PixLayout lay = pix_layout(f);
       const int xblocks = f.xblocks;
       idct_batch<S>(
-          buf, nb, lane, [&](int b, int y, int x) { return lfp[binfo[b].lf_off[CH] + y * xblocks + x]; },
+          buf, nb, lane,
+          [&](int b, int y, int x) {
+            if constexpr (kChain) return s_lf[b * kLfPerBlock + (CH * (S::R / 8) + y) * (S::C / 8) + x];
+            else return lfp[binfo[b].lf_off[CH] + y * xblocks + x];
+          },
           [&](int b, int x, int yb, const float(&v)[8]) {
             if (SUB && binfo[b].px_off[CH] == f.scrap_off) return;
             float* dst = plane + binfo[b].px_off[CH] + lay.xoff(x) + yb * lay.ystep_blk;
@@ -471,10 +729,133 @@ __device__ __forceinline__ int run_dct_class(const FrameDev& f, const WorkItem* 
             }
           });
     };
-    // channel order of the reference: Y, X, B (group.rs:223)
-    run_channel(std::integral_constant<int, 1>{});
-    run_channel(std::integral_constant<int, 0>{});
-    run_channel(std::integral_constant<int, 2>{});
+    using TagX = std::integral_constant<int, 0>;
+    using TagY = std::integral_constant<int, 1>;
+    using TagB = std::integral_constant<int, 2>;
+    if constexpr (SPARSE == 3) {
+      // direct path: every varblock of the batch has a raw_quant the division survives and no more entries per channel
+      // than its lanes hold -- otherwise the batch is left to the dense pass (k1_entries_fallback)
+      constexpr int LPB = 64 / S::NB;
+      const int b = lane / LPB, j = lane % LPB;
+      bool mine = true;
+      float sdy = 0.0f, xcc = 0.0f, bcc = 0.0f;
+      if (b < nb) {
+        sdy = binfo[b].sdy;
+        xcc = binfo[b].x_cc;
+        bcc = binfo[b].b_cc;
+        mine = sdy > 0.0f && sdy < __builtin_inff() && max(max(binfo[b].en[0], binfo[b].en[1]), binfo[b].en[2]) <= (uint32_t)(D * LPB);
+      }
+      if (!__all(mine)) {
+        if (lane == 0) wl_fallback[atomicAdd(fallback_count, 1)] = (uint32_t)CLS << 24 | (uint32_t)batch;
+        wave_sync();  // binfo / s_lf / s_excl are rewritten by the next batch
+        continue;
+      }
+      wave_sync();  // the slot prefixes (entries_begin) are in LDS
+      EntDirect<D> ed;
+#pragma unroll
+      for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int k = 0; k < D; k++) {
+          ed.ad[c][k] = kNoEntry;
+          if (el.i0[c] + k * LPB < el.i1[c]) {
+            const uint32_t e = el.e[c][k];
+            ed.ad[c][k] = (uint32_t)entry_pos<S>(s_excl, b, c, e, (uint32_t)(j + k * LPB)) | (uint32_t)((int)(e << 16) >> 22) << 16;
+          }
+        }
+      float dyw[D];
+      uint32_t ywin = 0;
+#pragma unroll
+      for (int k = 0; k < D; k++) dyw[k] = 0.0f;
+      direct_stage_channel<S, 1, D>(f, buf, lane, ed, table, tsize, sdy, 0.0f, adj, dyw, ywin);
+      transform_channel(TagY{});
+      direct_stage_channel<S, 0, D>(f, buf, lane, ed, table, tsize, sdy, xcc, adj, dyw, ywin);
+      transform_channel(TagX{});
+      direct_stage_channel<S, 2, D>(f, buf, lane, ed, table, tsize, sdy, bcc, adj, dyw, ywin);
+      transform_channel(TagB{});
+    } else {
+      int4 qv[PREFETCH ? 3 : 1][NCH];
+      if constexpr (PREFETCH && !SPARSE) {
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+#pragma unroll
+          for (int j = 0; j < NCH; j++) {
+            const int fl = (j * 64 + lane) * 4;
+            const int b = fl / S::N, k = fl % S::N;
+            qv[c][j] = make_int4(0, 0, 0, 0);
+            if (b < nb && (!SUB || binfo[b].px_off[c] != f.scrap_off))
+              qv[c][j] = gload_i4<JXLH_NT_COEF>(f.coeffs + binfo[b].coef_off + c * kGroupArea + k);
+          }
+      }
+      // The dequantised Y the X / B channels' chroma-from-luma needs: kept in registers across the channels -- except for
+      // the shape with 32 of them per lane (32x32, dense input), where they would sit through two 32-point IDCTs
+      // (167 VGPRs + 16 spilled + 68 bytes of scratch for that class alone): there X and B dequantise their Y values again
+      // (the coefficient read hits L2, the table-driven dequantisation is ~10 instructions per value).
+      constexpr bool kRecomputeY = !SPARSE && !PREFETCH && S::E > 16;
+      float dy[kRecomputeY ? 4 : S::E];
+      auto stage_channel = [&](auto ch_tag) {
+        constexpr int CH = decltype(ch_tag)::value;
+        if constexpr (SPARSE == 1) sparse_stage_channel<S>(f, CH, buf, lane, sl);
+        if constexpr (SPARSE == 2) entries_stage_channel<S, D>(f, CH, buf, s_excl, lane, el);
+#pragma unroll
+        for (int j = 0; j < NCH; j++) {
+          const int fl = (j * 64 + lane) * 4;
+          const int b = fl / S::N, k = fl % S::N;
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          float d4[4];
+          if constexpr (kRecomputeY) {
+            d4[0] = d4[1] = d4[2] = d4[3] = 0.0f;
+          } else {
+            d4[0] = dy[j * 4];
+            d4[1] = dy[j * 4 + 1];
+            d4[2] = dy[j * 4 + 2];
+            d4[3] = dy[j * 4 + 3];
+          }
+          if (b < nb) {
+            const BlockInfo bi = binfo[b];
+            int4 qq;
+            float4 tt;
+            if constexpr (SPARSE != 0) {
+              qq = tile_q4<S>(buf, b, k);  // converted in place: this lane alone touches (b, k..k+3)
+              if constexpr (PREFETCH) tt = tw[CH][j];
+              else tt = *reinterpret_cast<const float4*>(table + CH * tsize + k);
+            } else if constexpr (PREFETCH) {
+              qq = qv[CH][j];
+              tt = tw[CH][j];
+            } else {
+              qq = gload_i4<JXLH_NT_COEF>(f.coeffs + bi.coef_off + CH * kGroupArea + k);
+              tt = *reinterpret_cast<const float4*>(table + CH * tsize + k);
+              if constexpr (kRecomputeY && CH != 1) {
+                const int4 qy = gload_i4<false>(f.coeffs + bi.coef_off + kGroupArea + k);
+                const float4 ty = *reinterpret_cast<const float4*>(table + tsize + k);
+                (void)dequant4t<1>(f, qy, ty, bi, adj, d4);
+              }
+            }
+#ifdef JXLH_EXP_NODEQUANT  // timing experiment only (wrong pixels): what the dense dequantisation pass costs
+            if constexpr (SPARSE == 2) {
+              v = make_float4((float)qq.x * tt.x, (float)qq.y * tt.y, (float)qq.z * tt.z, (float)qq.w * tt.w);
+              d4[0] = d4[1] = d4[2] = d4[3] = bi.sdy;
+            } else
+#endif
+            v = dequant4t<CH>(f, qq, tt, bi, adj, d4);
+          }
+          if constexpr (CH == 1 && !kRecomputeY) {
+            dy[j * 4] = d4[0];
+            dy[j * 4 + 1] = d4[1];
+            dy[j * 4 + 2] = d4[2];
+            dy[j * 4 + 3] = d4[3];
+          }
+          stage4<S>(buf, b, k, v);
+        }
+        wave_sync();
+      };
+      // channel order of the reference: Y, X, B (group.rs:223)
+      stage_channel(TagY{});
+      transform_channel(TagY{});
+      stage_channel(TagX{});
+      transform_channel(TagX{});
+      stage_channel(TagB{});
+      transform_channel(TagB{});
+    }
   }
   return nbatches;
 }
@@ -500,15 +881,18 @@ constexpr int kTileC = cmax(cmax(cmax(S32x8::kTile, S8x32::kTile), cmax(S32x16::
                             S32x32::kTile);                                       // 2624
 
 // family A: DCT 8x8 -- the dominant transform
-template <bool SPARSE, bool SUB = false>
+template <int SPARSE, bool SUB = false>
 __global__ __launch_bounds__(kThreads) void k1_dct8(const FrameDev f, const WorkLists wl) {
   __shared__ __attribute__((aligned(16))) float s_buf[kWaves * kTileA];
   __shared__ BlockInfo s_binfo[kWaves][S8x8::NB];
   __shared__ AdjTable s_adj;
   build_adj_table(f, &s_adj, threadIdx.x, kThreads);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  run_dct_class<S8x8, true, SPARSE, SUB>(f, wl.items[kClsDct8], wl.counts[(kClsDct8) * kCountPitch], 0, s_buf + wave * kTileA, s_binfo[wave],
-                            blockIdx.x * kWaves + wave, gridDim.x * kWaves, lane, &s_adj);
+  __shared__ float s_lf[SPARSE >= 2 ? kWaves : 1][S8x8::NB * 3];
+  run_dct_class<S8x8, true, SPARSE, SUB, kClsDct8>(f, wl.items[kClsDct8], wl.eitems[kClsDct8], wl.counts[(kClsDct8) * kCountPitch], 0,
+                                                   s_buf + wave * kTileA, s_binfo[wave], nullptr, s_lf[SPARSE >= 2 ? wave : 0],
+                                                   blockIdx.x * kWaves + wave, gridDim.x * kWaves, lane, &s_adj, wl.fallback,
+                                                   wl.counts + kCntFallback * kCountPitch);
 }
 
 // families B (16x8, 8x16, 16x16) + C (everything with a 32-point side) in ONE launch (round 3): as two kernels both
@@ -517,32 +901,82 @@ __global__ __launch_bounds__(kThreads) void k1_dct8(const FrameDev f, const Work
 // Occupancy is not what limits these classes' batches anyway: at two waves per SIMD the 32-point family runs 24 %
 // slower, the 16-point one 8 %, and DCT8 is flat between 3 and 5 (profiles/r03_n_k1.txt); requesting the LF samples
 // of a batch ahead of the coefficients (through an LDS scratch) measured flat as well
-template <bool SPARSE>
-__global__ __launch_bounds__(kThreads, 3) void k1_dct16_32(const FrameDev f, const WorkLists wl) {
+// exclusive slot-count prefixes of a batch's varblocks (entries form): NB * (N / 64) words, at most 40 (8 x 32)
+constexpr int kExclWords = 40;
+#ifndef JXLH_K1_DIRECT_WPE
+#define JXLH_K1_DIRECT_WPE 3  // waves per SIMD the direct form of k1_dct16_32 is compiled for
+#endif
+template <int SPARSE>
+__global__ __launch_bounds__(kThreads, SPARSE == 3 ? JXLH_K1_DIRECT_WPE : 3) void k1_dct16_32(const FrameDev f, const WorkLists wl) {
   __shared__ __attribute__((aligned(16))) float s_buf[kWaves * kTileC];
   __shared__ BlockInfo s_binfo[kWaves][8];
+  __shared__ uint32_t s_excl[SPARSE >= 2 ? kWaves : 1][kExclWords];
   __shared__ AdjTable s_adj;
   build_adj_table(f, &s_adj, threadIdx.x, kThreads);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float* buf = s_buf + wave * kTileC;
+  uint32_t* ex = s_excl[SPARSE >= 2 ? wave : 0];
+  __shared__ float s_lfs[SPARSE >= 2 ? kWaves : 1][96];  // LF samples of a batch: NB * 3 * (R / 8) * (C / 8) <= 96
+  float* lfs = s_lfs[SPARSE >= 2 ? wave : 0];
   const int gw = blockIdx.x * kWaves + wave, nw = gridDim.x * kWaves;
+  auto cnt = [&](int cls) { return wl.counts[cls * kCountPitch]; };
+  int* fbc = wl.counts + kCntFallback * kCountPitch;
   // the long batches (32-point sides) first: the tail of the launch is then made of the short ones
-  int used = run_dct_class<S32x32, false, SPARSE>(f, wl.items[kClsDct32x32], wl.counts[(kClsDct32x32) * kCountPitch], 5, buf,
-                                                  s_binfo[wave], gw, nw, lane, &s_adj);
-  used += run_dct_class<S32x16, false, SPARSE>(f, wl.items[kClsDct32x16], wl.counts[(kClsDct32x16) * kCountPitch], 10, buf,
-                                               s_binfo[wave], rotate_wave(gw, used, nw), nw, lane, &s_adj);
-  used += run_dct_class<S16x32, false, SPARSE>(f, wl.items[kClsDct16x32], wl.counts[(kClsDct16x32) * kCountPitch], 11, buf,
-                                               s_binfo[wave], rotate_wave(gw, used, nw), nw, lane, &s_adj);
-  used += run_dct_class<S32x8, false, SPARSE>(f, wl.items[kClsDct32x8], wl.counts[(kClsDct32x8) * kCountPitch], 8, buf,
-                                              s_binfo[wave], rotate_wave(gw, used, nw), nw, lane, &s_adj);
-  used += run_dct_class<S8x32, false, SPARSE>(f, wl.items[kClsDct8x32], wl.counts[(kClsDct8x32) * kCountPitch], 9, buf, s_binfo[wave],
-                                              rotate_wave(gw, used, nw), nw, lane, &s_adj);
-  used += run_dct_class<S16x16, true, SPARSE>(f, wl.items[kClsDct16x16], wl.counts[(kClsDct16x16) * kCountPitch], 4, buf, s_binfo[wave],
-                                              rotate_wave(gw, used, nw), nw, lane, &s_adj);
-  used += run_dct_class<S16x8, true, SPARSE>(f, wl.items[kClsDct16x8], wl.counts[(kClsDct16x8) * kCountPitch], 6, buf,
-                                             s_binfo[wave], rotate_wave(gw, used, nw), nw, lane, &s_adj);
-  run_dct_class<S8x16, true, SPARSE>(f, wl.items[kClsDct8x16], wl.counts[(kClsDct8x16) * kCountPitch], 7, buf, s_binfo[wave],
-                                     rotate_wave(gw, used, nw), nw, lane, &s_adj);
+  int used = run_dct_class<S32x32, false, SPARSE, false, kClsDct32x32>(f, wl.items[kClsDct32x32], wl.eitems[kClsDct32x32], cnt(kClsDct32x32), 5, buf,
+                                                  s_binfo[wave], ex, lfs, gw, nw, lane, &s_adj, wl.fallback, fbc);
+  used += run_dct_class<S32x16, false, SPARSE, false, kClsDct32x16>(f, wl.items[kClsDct32x16], wl.eitems[kClsDct32x16], cnt(kClsDct32x16), 10, buf,
+                                               s_binfo[wave], ex, lfs, rotate_wave(gw, used, nw), nw, lane, &s_adj, wl.fallback, fbc);
+  used += run_dct_class<S16x32, false, SPARSE, false, kClsDct16x32>(f, wl.items[kClsDct16x32], wl.eitems[kClsDct16x32], cnt(kClsDct16x32), 11, buf,
+                                               s_binfo[wave], ex, lfs, rotate_wave(gw, used, nw), nw, lane, &s_adj, wl.fallback, fbc);
+  used += run_dct_class<S32x8, false, SPARSE, false, kClsDct32x8>(f, wl.items[kClsDct32x8], wl.eitems[kClsDct32x8], cnt(kClsDct32x8), 8, buf,
+                                              s_binfo[wave], ex, lfs, rotate_wave(gw, used, nw), nw, lane, &s_adj, wl.fallback, fbc);
+  used += run_dct_class<S8x32, false, SPARSE, false, kClsDct8x32>(f, wl.items[kClsDct8x32], wl.eitems[kClsDct8x32], cnt(kClsDct8x32), 9, buf,
+                                              s_binfo[wave], ex, lfs, rotate_wave(gw, used, nw), nw, lane, &s_adj, wl.fallback, fbc);
+  used += run_dct_class<S16x16, true, SPARSE, false, kClsDct16x16>(f, wl.items[kClsDct16x16], wl.eitems[kClsDct16x16], cnt(kClsDct16x16), 4, buf,
+                                              s_binfo[wave], ex, lfs, rotate_wave(gw, used, nw), nw, lane, &s_adj, wl.fallback, fbc);
+  used += run_dct_class<S16x8, true, SPARSE, false, kClsDct16x8>(f, wl.items[kClsDct16x8], wl.eitems[kClsDct16x8], cnt(kClsDct16x8), 6, buf,
+                                             s_binfo[wave], ex, lfs, rotate_wave(gw, used, nw), nw, lane, &s_adj, wl.fallback, fbc);
+  run_dct_class<S8x16, true, SPARSE, false, kClsDct8x16>(f, wl.items[kClsDct8x16], wl.eitems[kClsDct8x16], cnt(kClsDct8x16), 7, buf, s_binfo[wave], ex,
+                                     lfs, rotate_wave(gw, used, nw), nw, lane, &s_adj, wl.fallback, fbc);
+}
+
+// The batches the direct kernels left (WorkLists::fallback: class << 24 | batch), through the dense dequantisation pass
+// of the entries form (mode 2), one batch per wavefront at a time.  Usually a handful per frame: a small grid.
+__global__ __launch_bounds__(kThreads, 3) void k1_entries_fallback(const FrameDev f, const WorkLists wl) {
+  __shared__ __attribute__((aligned(16))) float s_buf[kWaves * kTileC];
+  __shared__ BlockInfo s_binfo[kWaves][8];
+  __shared__ uint32_t s_excl[kWaves][kExclWords];
+  __shared__ float s_lfs[kWaves][96];
+  __shared__ AdjTable s_adj;
+  const int total = wl.counts[kCntFallback * kCountPitch];
+  if (total == 0) return;  // (workgroup-uniform)
+  build_adj_table(f, &s_adj, threadIdx.x, kThreads);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* buf = s_buf + wave * kTileC;
+  constexpr int kOne = 1 << 30;  // stride: run_dct_class then takes exactly the batch it is given
+  for (int i = blockIdx.x * kWaves + wave; i < total; i += gridDim.x * kWaves) {
+    const uint32_t e = wl.fallback[i];
+    const int cls = (int)(e >> 24), batch = (int)(e & 0xffffffu);
+    const int count = wl.counts[cls * kCountPitch];
+#define JXLH_FB(CLS, SHAPE, PF, TYPE)                                                                                  \
+  case CLS:                                                                                                            \
+    run_dct_class<SHAPE, PF, 2>(f, wl.items[CLS], wl.eitems[CLS], count, TYPE, buf, s_binfo[wave], s_excl[wave], s_lfs[wave], \
+                                batch, kOne, lane, &s_adj);                                                            \
+    break;
+    switch (cls) {  // wave-uniform
+      JXLH_FB(kClsDct8, S8x8, true, 0)
+      JXLH_FB(kClsDct16x8, S16x8, true, 6)
+      JXLH_FB(kClsDct8x16, S8x16, true, 7)
+      JXLH_FB(kClsDct16x16, S16x16, true, 4)
+      JXLH_FB(kClsDct32x8, S32x8, false, 8)
+      JXLH_FB(kClsDct8x32, S8x32, false, 9)
+      JXLH_FB(kClsDct32x16, S32x16, false, 10)
+      JXLH_FB(kClsDct16x32, S16x32, false, 11)
+      JXLH_FB(kClsDct32x32, S32x32, false, 5)
+      default: break;
+    }
+#undef JXLH_FB
+  }
 }
 
 // family D: the nine 8x8 special transform types (IDENTITY, DCT2X2, DCT4X4, DCT4X8, DCT8X4, AFV0-3).
@@ -730,6 +1164,8 @@ size_t vardct_worklist_bytes(const FrameDev& f) {
   const size_t nblocks = (size_t)f.xblocks * f.yblocks;
   size_t items = 0;
   for (int c = 0; c < kNumClasses; c++) items += nblocks / class_min_area(c) + 1;
+  for (int c = 0; c < kClsSpecial; c++) items += nblocks / class_min_area(c) + 1;  // entry side items of the DCT classes
+  items += nblocks / 4 + 16;  // the fallback batch list (u32 per batch, < nblocks / 2 batches in all): as 16-byte units
   // + the unit lists of the large transforms: one u32 per 4096 samples of a 256-pixel varblock (two-pass units) and
   //   one per varblock of the smaller types (three lists by slabs per channel; worst case one entry per 32 blocks)
   // + the LLF planes of the large transforms (3 x nblocks floats, k1_large_llf)
@@ -758,13 +1194,23 @@ void launch_vardct_groups(hipStream_t s, const FrameDev& f, int group_row0, int 
     wl.items[c] = reinterpret_cast<WorkItem*>(p);
     p += (nblocks / class_min_area(c) + 1) * sizeof(WorkItem);
   }
-  uint32_t* large_units = reinterpret_cast<uint32_t*>(p);  // behind the last class list
+  for (int c = 0; c < kClsSpecial; c++) {
+    wl.eitems[c] = reinterpret_cast<EntryItem*>(p);
+    p += (nblocks / class_min_area(c) + 1) * sizeof(EntryItem);
+  }
+  wl.fallback = reinterpret_cast<uint32_t*>(p);
+  p += (nblocks / 4 + 16) * sizeof(WorkItem);
+  uint32_t* large_units = reinterpret_cast<uint32_t*>(p);  // behind the last list
+  const dim3 gscan((ngroups + kScanGroups - 1) / kScanGroups);
   if (f.strip_desc)
-    hipLaunchKernelGGL(k1_scan<true>, dim3((ngroups + kScanGroups - 1) / kScanGroups), dim3(kScanThreads), 0, s, f, wl,
-                       group_row0, error_flag, group_list, ngroups, next_counts);
+    hipLaunchKernelGGL(k1_scan<true>, gscan, dim3(kScanThreads), 0, s, f, wl, group_row0, error_flag, group_list, ngroups,
+                       next_counts);
+  else if (f.se_entries)
+    hipLaunchKernelGGL((k1_scan<false, true>), gscan, dim3(kScanThreads), 0, s, f, wl, group_row0, error_flag, group_list,
+                       ngroups, next_counts);
   else
-    hipLaunchKernelGGL(k1_scan<false>, dim3((ngroups + kScanGroups - 1) / kScanGroups), dim3(kScanThreads), 0, s, f, wl,
-                       group_row0, error_flag, group_list, ngroups, next_counts);
+    hipLaunchKernelGGL(k1_scan<false>, gscan, dim3(kScanThreads), 0, s, f, wl, group_row0, error_flag, group_list, ngroups,
+                       next_counts);
   if (f.strip_desc && f.strip_all_closed) return;  // the host saw the whole map: no tile is left to the class kernels
   // grids: enough waves to fill the chip; kernels stride over their lists (counts are device-side)
   const int nblk = ngroups * kGroupBlocks * kGroupBlocks;
@@ -774,28 +1220,42 @@ void launch_vardct_groups(hipStream_t s, const FrameDev& f, int group_row0, int 
   };
   // one stream: forking the class kernels onto side streams measured no gain on the d1 mix (event
   // overhead ~ tail savings) and extra streams compete for the runtime's few hardware queues
-  const bool sparse = f.sp_sorted != nullptr;
+  // entries form: the direct kernels (+ the fallback launch) when a zero coefficient provably reconstructs to +0.0f
+  const int sparse = f.se_entries ? (f.se_direct_ok ? 3 : 2) : f.sp_sorted ? 1 : 0;
   if (sparse && dense_coeffs && (has_special || has_large)) {
     // groups that hold special / large varblocks (flagged by k1_scan) still get a dense slab
-    launch_expand_sorted(s, dense_coeffs, f.sp_sorted, f.sp_slot_start, f.group_dense, f.xgroups * f.ygroups);
+    if (sparse >= 2)
+      launch_expand_entries(s, dense_coeffs, f.se_entries, f.se_counts, f.se_runs, f.group_dense, f.xgroups * f.ygroups);
+    else
+      launch_expand_sorted(s, dense_coeffs, f.sp_sorted, f.sp_slot_start, f.group_dense, f.xgroups * f.ygroups);
   }
   // caps measured flat between 768 and 8192 workgroups at 8K (tools/bench_variants.sh)
   const dim3 g8(grid_for(nblk, kWaves * S8x8::NB * 2, 4096)), g16(grid_for(nblk / 2, kWaves * 8 * 2, 2048)),
       g32(grid_for(nblk / 4, kWaves * 4 * 2, 2048));
   if (f.subsampled) {
-    if (sparse) hipLaunchKernelGGL((k1_dct8<true, true>), g8, dim3(kThreads), 0, s, f, wl);
-    else hipLaunchKernelGGL((k1_dct8<false, true>), g8, dim3(kThreads), 0, s, f, wl);
+    if (sparse == 3) hipLaunchKernelGGL((k1_dct8<3, true>), g8, dim3(kThreads), 0, s, f, wl);
+    else if (sparse == 2) hipLaunchKernelGGL((k1_dct8<2, true>), g8, dim3(kThreads), 0, s, f, wl);
+    else if (sparse == 1) hipLaunchKernelGGL((k1_dct8<1, true>), g8, dim3(kThreads), 0, s, f, wl);
+    else hipLaunchKernelGGL((k1_dct8<0, true>), g8, dim3(kThreads), 0, s, f, wl);
     // the other DCT classes are empty in a sub-sampled frame (k1_scan reports larger varblocks as an error)
   } else {
     const dim3 g1632(std::min(4096u, g16.x + g32.x));
-    if (sparse) {
-      hipLaunchKernelGGL(k1_dct8<true>, g8, dim3(kThreads), 0, s, f, wl);
-      hipLaunchKernelGGL(k1_dct16_32<true>, g1632, dim3(kThreads), 0, s, f, wl);
+    if (sparse == 3) {
+      hipLaunchKernelGGL(k1_dct8<3>, g8, dim3(kThreads), 0, s, f, wl);
+      hipLaunchKernelGGL(k1_dct16_32<3>, g1632, dim3(kThreads), 0, s, f, wl);
+    } else if (sparse == 2) {
+      hipLaunchKernelGGL(k1_dct8<2>, g8, dim3(kThreads), 0, s, f, wl);
+      hipLaunchKernelGGL(k1_dct16_32<2>, g1632, dim3(kThreads), 0, s, f, wl);
+    } else if (sparse == 1) {
+      hipLaunchKernelGGL(k1_dct8<1>, g8, dim3(kThreads), 0, s, f, wl);
+      hipLaunchKernelGGL(k1_dct16_32<1>, g1632, dim3(kThreads), 0, s, f, wl);
     } else {
-      hipLaunchKernelGGL(k1_dct8<false>, g8, dim3(kThreads), 0, s, f, wl);
-      hipLaunchKernelGGL(k1_dct16_32<false>, g1632, dim3(kThreads), 0, s, f, wl);
+      hipLaunchKernelGGL(k1_dct8<0>, g8, dim3(kThreads), 0, s, f, wl);
+      hipLaunchKernelGGL(k1_dct16_32<0>, g1632, dim3(kThreads), 0, s, f, wl);
     }
   }
+  // what the direct kernels left (usually next to nothing: the workgroups read one counter and leave)
+  if (sparse == 3) hipLaunchKernelGGL(k1_entries_fallback, dim3(std::min(512, std::max(1, nblk / 2048))), dim3(kThreads), 0, s, f, wl);
   // an empty special list (the d1 mix) pays for every launched workgroup: the grid follows the list's worst case
   if (has_special)
     hipLaunchKernelGGL(k1_special, dim3(grid_for((long)(nblk / kSpecChunk + 1) * kSpecBins, kSpecWaves, 2048)),

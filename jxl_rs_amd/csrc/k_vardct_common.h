@@ -55,7 +55,8 @@ __host__ __device__ constexpr int class_min_area(int c) {
 // scan, whose duration is the serial head of K1, writes half the bytes of round 2's 32-byte form.
 struct __attribute__((aligned(16))) WorkItem {
   uint32_t packed;  // bx | by << 5 | off64 << 10 | type << 20   (bx, by in blocks inside the group)
-  uint32_t group;
+  uint32_t group;   // group id (< 2^16: jxlh_frame_begin bounds the frame to 2^31 coefficients = 10922 groups)
+                    // | entries of the varblock's B run << 16 when the frame is read in the slot-bucketed form
   int32_t raw_quant;  // HfMetadata::raw_quant_map at the varblock's first block
   uint32_t cc;        // (uint8_t)ytox | (uint8_t)ytob << 8 of the block's colour tile
 };
@@ -69,26 +70,43 @@ struct BlockInfo {
   float sdy, x_cc, b_cc;
   int slot_base;  // sparse input: index of the varblock's first slot in sp_slot_start (channel X)
   int first_pos;  // position of the varblock's first coefficient inside the channel slab
+  // slot-bucketed entries read in place (FrameDev::se_*): the varblock's entry range per channel, written by k1_scan
+  uint32_t e0[3], en[3];
+  int cnt_base;   // index of the varblock's first slot count in se_counts (channel X)
 };
+// Side item of the work lists when the frame is read in the slot-bucketed form (same index as the WorkItem):
+// frame-wide index of the varblock's first entry per channel, entries of the X run | Y run << 16 (the B run's count
+// rides in WorkItem::group).  A varblock of the DCT classes holds at most 1024 coefficients per channel.
+struct __attribute__((aligned(16))) EntryItem {
+  uint32_t e0[3];
+  uint32_t nxy;
+};
+static_assert(sizeof(EntryItem) == 16, "entry item layout");
 
 // every class counter on its own 128-byte line: the 1024 scan workgroups' atomics then meet on nine lines (and L2
 // channels) instead of one
 constexpr int kCountPitch = 32;
-constexpr int kCountLines = kNumClasses + 4;  // the classes, the two-pass slab units, the three fused large lists
+constexpr int kCountLines = kNumClasses + 5;  // the classes, the two-pass slab units, the three fused large lists,
+                                              // the entries form's fallback batches (kCntFallback)
+constexpr int kCntFallback = kNumClasses + 4;
 constexpr size_t kCountBytes = (size_t)kCountLines * kCountPitch * sizeof(int);
 struct WorkLists {
   WorkItem* items[kNumClasses];
+  EntryItem* eitems[kClsSpecial];  // the DCT classes only: special / large varblocks read dense slabs
+  uint32_t* fallback;              // entries form, direct kernels: class << 24 | batch of the batches they leave to
+                                   // k1_entries_fallback (varblocks with more entries than a lane holds, raw_quant == 0)
   int* counts;  // kCountLines counters at kCountPitch ints, zeroed before k1_scan: the classes, then the large
                 // transforms' unit lists (k_vardct_large.hip: two-pass slab units, fused lists of 1 / 2 / 4 slabs)
 };
 
 __device__ __forceinline__ void decode_item(const FrameDev& f, const WorkItem& it, BlockInfo* bi) {
   const int bx = it.packed & 31, by = (it.packed >> 5) & 31, off64 = (it.packed >> 10) & 1023;
-  const int g = (int)it.group;
+  const int g = (int)(it.group & 0xffffu);
   const int gbx = (g % f.xgroups) * kGroupBlocks + bx, gby = (g / f.xgroups) * kGroupBlocks + by;
   bi->coef_off = g * 3 * kGroupArea + off64 * 64;  // < 2^31: jxlh_frame_begin bounds the frame
   bi->slot_base = g * 3 * kSlotTable + off64;
   bi->first_pos = off64 * 64;
+  bi->cnt_base = g * 3 * kSlotsPerRun + off64;
   if (!f.subsampled) {
     const int px = block_px_offset(f, gbx, gby), lf = gby * f.xblocks + gbx;
 #pragma unroll

@@ -29,6 +29,7 @@ ERR_BLOCK_OUT_OF_BOUNDS = -8
 FRAME_UNFUSED_FILTERS = 1
 FRAME_EXPAND_SPARSE = 2
 FRAME_STRIP = 4
+FRAME_DENSE_DEQUANT = 8
 GROUP_COMPLETE = 1
 GROUP_ACCUMULATE = 2
 GROUP_ENTRIES12 = 4

@@ -1300,6 +1300,73 @@ def test_slot_bucketed_submit_matches_dense_submit(ctx, oracle, mix, size, scale
         assert bit_equal(again[c], want[c])
 
 
+def _merge_slot_forms(a, b):
+    """two synth.to_slots results of one group -> one list per (channel, slot): the updates of two passes in ONE
+    submission (duplicate positions add up on the device like `coeffs[i] += v`, frame/group.rs:572)"""
+    ea, ca, na, wa = a
+    eb, cb, nb_, wb = b
+    assert len(wa) == 0 and len(wb) == 0
+    oa = np.concatenate([[0], np.cumsum(ca.reshape(-1).astype(np.int64))])
+    ob = np.concatenate([[0], np.cumsum(cb.reshape(-1).astype(np.int64))])
+    out = []
+    for i in range(3 * 1024):
+        out.append(ea[oa[i]:oa[i + 1]])
+        out.append(eb[ob[i]:ob[i + 1]])
+    cnt = ca.astype(np.int64) + cb.astype(np.int64)
+    assert cnt.max() <= 255
+    return np.concatenate(out), cnt.astype(np.uint8), (na + nb_).astype(np.uint32)
+
+
+@pytest.mark.parametrize("mix,size,dense_groups", [("MIX_D1", (768, 520), ()), ("MIX_D1", (520, 300), (1, 2)),
+                                                   ("MIX_ALL", (600, 520), (0, 4)), ("MIX_DCT8", (300, 260), (0,))])
+def test_entries_form_direct_path_and_its_fallbacks(ctx, oracle, mix, size, dense_groups):
+    """A frame resident in the slot-bucketed form: the transforms dequantise only the positions that have an entry
+    (direct path), leave varblocks with more entries than their lanes hold to the dense pass (fallback list: a few
+    groups are made dense here), and JXLH_FRAME_DENSE_DEQUANT takes the dense pass everywhere -- all three give the
+    bits of the dense-slab submission; so do duplicate positions (two passes' updates in one list, some cancelling to
+    zero), which must add up as integers before they are dequantised."""
+    from jxl_rs_amd import synth
+    from jxl_rs_amd import lib as jl
+    w, h = size
+    wl = synth.make_vardct(w, h, mix=getattr(synth, mix), seed=w + 7 * h, epf_iters=1)
+    rng = np.random.default_rng(w)
+    for g in dense_groups:   # every second coefficient non-zero: far more entries than D per lane
+        m = rng.random(wl.coeffs[g].shape) < 0.5
+        wl.coeffs[g] = np.where(m, rng.integers(-9, 10, size=wl.coeffs[g].shape), wl.coeffs[g]).astype(np.int32)
+    want, _ = run_gpu_frame(ctx, wl)
+    ng = wl.coeffs.shape[0]
+    # duplicates: c = a + b with overlapping supports; where b == -a' the two updates cancel
+    split = rng.random(wl.coeffs.shape) < 0.3
+    part_b = np.where(split & (wl.coeffs != 0), rng.integers(-3, 4, size=wl.coeffs.shape), 0).astype(np.int32)
+    part_a = (wl.coeffs - part_b).astype(np.int32)
+    zero_sum = (wl.coeffs == 0) & (rng.random(wl.coeffs.shape) < 0.01)      # +v and -v at a position that holds 0
+    part_a = np.where(zero_sum, 5, part_a).astype(np.int32)
+    part_b = np.where(zero_sum, -5, part_b).astype(np.int32)
+    assert np.array_equal(part_a + part_b, wl.coeffs)
+    ids = np.arange(ng, dtype=np.uint32)
+    for what, flags in (("direct", 0), ("dense pass", jl.FRAME_DENSE_DEQUANT), ("duplicates", 0)):
+        p = gpu_params_from(ctx, wl)
+        p.flags = flags
+        ctx.frame_begin(p)
+        ctx.set_dequant_tables(wl.tables)
+        ctx.set_lf_quantized(*wl.lf_q)
+        ctx.set_hf_meta(wl.transform_map, wl.raw_quant, wl.epf_map, wl.ytox, wl.ytob)
+        if what == "duplicates":
+            parts = [_merge_slot_forms(synth.to_slots(part_a[g]), synth.to_slots(part_b[g])) for g in range(ng)]
+        else:
+            parts = [synth.to_slots(wl.coeffs[g]) for g in range(ng)]
+            assert all(len(q[3]) == 0 for q in parts)
+        ctx.submit_groups_slots(ids, np.concatenate([q[0] for q in parts]), np.concatenate([q[1].reshape(-1) for q in parts]),
+                                np.concatenate([q[2] for q in parts]), None)
+        ctx.slot_wait(0)
+        for run in range(2):   # the resident form is read again by the second run
+            ctx.frame_run()
+            ctx.sync()
+            got = ctx.read_planes()
+            for c in range(3):
+                assert bit_equal(got[c], want[c]), f"{what}, run {run}, plane {c}: {diff_report(got[c], want[c])}"
+
+
 def test_sparse_submit_argument_errors(ctx):
     from jxl_rs_amd import synth
     from jxl_rs_amd.lib import JxlHipError

@@ -138,6 +138,106 @@ def test_sparse_passes_accumulate_on_the_device(ctx, oracle, epf_iters):
     assert e.value.status == lib.ERR_INVALID_ARGUMENT
 
 
+def _slots_batch(synth, coeffs, groups, bits12=False):
+    parts = [synth.to_slots(coeffs[g], bits12) for g in groups]
+    for q in parts:
+        assert len(q[3]) == 0
+    return (np.asarray(groups, dtype=np.uint32), np.concatenate([q[0] for q in parts]),
+            np.concatenate([q[1].reshape(-1) for q in parts]), np.concatenate([q[2] for q in parts]))
+
+
+@pytest.mark.parametrize("first", ["slots", "pairs"])
+@pytest.mark.parametrize("epf_iters", [2, 0])
+def test_slot_bucketed_pass_added_to_a_resident_bucketed_frame(ctx, oracle, epf_iters, first):
+    """pass 1 in a sparse form that leaves the frame resident in its bucketed form, run; pass 2 of
+    SOME groups through jxlh_submit_groups_slots with JXLH_GROUP_ACCUMULATE, run.  The second submission must not
+    disturb what the first frame is read through (round 4 overwrote the live slot tables at submission time: the
+    dense slabs of the accumulating groups were then rebuilt from garbage); then a replacing slot-bucketed pass, a
+    whole-frame resubmission, and a mixed epoch (slots + dense slab + plain pairs)."""
+    from jxl_rs_amd import synth, lib
+    wl = synth.make_vardct(520, 600, mix=synth.MIX_D1, seed=43, epf_iters=epf_iters)  # 3 x 3 groups
+    c1, c2 = split_passes(wl.coeffs, 19)
+    begin(ctx, wl)
+    ng = wl.coeffs.shape[0]
+    if first == "slots":
+        ctx.submit_groups_slots(*_slots_batch(synth, c1, list(range(ng))), None, flags=0)
+    else:
+        for g in range(ng):
+            ctx.submit_group_sparse(g, *synth.to_sparse(c1[g]), flags=0)
+    ctx.slot_wait(0)
+    ctx.frame_run()
+    check(ctx, oracle_frame(oracle, wl, c1), "first pass")
+    ctx.frame_run()  # the resident form is read again
+    check(ctx, oracle_frame(oracle, wl, c1), "first pass, second run")
+    later = [0, 4, 5]
+    mixed = c1.copy()
+    for g in later:
+        mixed[g] = wl.coeffs[g]
+    ctx.submit_groups_slots(*_slots_batch(synth, c2, later), None, flags=lib.GROUP_COMPLETE | lib.GROUP_ACCUMULATE)
+    ctx.slot_wait(0)
+    ctx.rerender_groups(later)
+    check(ctx, oracle_frame(oracle, wl, mixed), "second pass added through the slot-bucketed form")
+    # a slot-bucketed pass WITHOUT the flag replaces the group's coefficients
+    ctx.submit_groups_slots(*_slots_batch(synth, c2, [1]), None, flags=lib.GROUP_COMPLETE)
+    ctx.slot_wait(0)
+    mixed[1] = c2[1]
+    ctx.rerender_groups([1])
+    check(ctx, oracle_frame(oracle, wl, mixed), "replacing pass")
+    # the whole frame again in the slot-bucketed form, twice in a row (the two sets trade places every time)
+    for rep, cc in enumerate((wl.coeffs, c2)):
+        ctx.submit_groups_slots(*_slots_batch(synth, cc, list(range(ng)), bits12=bool(rep)), None,
+                                flags=lib.GROUP_COMPLETE | (lib.GROUP_ENTRIES12 if rep else 0))
+        ctx.slot_wait(0)
+        ctx.frame_run()
+        check(ctx, oracle_frame(oracle, wl, cc), f"whole frame resubmitted, round {rep}")
+    # a mixed epoch on top of a resident slot-bucketed frame: group 2 as a dense slab, group 3 as plain pairs, group 6
+    # slot-bucketed, the others keep what they hold
+    mixed = c2.copy()
+    for g in (2, 3, 6):
+        mixed[g] = c1[g]
+    ctx.submit_group(2, c1[2])
+    ctx.submit_group_sparse(3, *synth.to_sparse(c1[3]))
+    ctx.submit_groups_slots(*_slots_batch(synth, c1, [6]), None)
+    ctx.slot_wait(0)
+    ctx.frame_run()
+    check(ctx, oracle_frame(oracle, wl, mixed), "mixed epoch")
+
+
+def test_group_resubmitted_in_another_form_inside_one_epoch(ctx, oracle):
+    """slots, then a dense slab, then ... of the same group between two runs: the last submission wins
+    and the frame is not mistaken for an all-bucketed one"""
+    from jxl_rs_amd import synth, lib
+    wl = synth.make_vardct(300, 520, mix=synth.MIX_D1, seed=47, epf_iters=1)  # 2 x 3 groups
+    c1, c2 = split_passes(wl.coeffs, 23)
+    begin(ctx, wl)
+    ng = wl.coeffs.shape[0]
+    ctx.submit_groups_slots(*_slots_batch(synth, c1, list(range(ng))), None)
+    ctx.submit_group(1, c2[1])                       # replaces the slot-bucketed submission of group 1
+    ctx.slot_wait(0)
+    ctx.frame_run()
+    want = c1.copy()
+    want[1] = c2[1]
+    check(ctx, oracle_frame(oracle, wl, want), "slots then dense")
+
+
+def test_slots_argument_errors_leave_the_epoch_intact(ctx, oracle):
+    """a rejected jxlh_submit_groups_slots call reserves nothing -- the group can be submitted again"""
+    from jxl_rs_amd import synth, lib, JxlHipError
+    wl = synth.make_vardct(256, 256, mix=synth.MIX_D1, seed=5, epf_iters=0, gab=False)
+    begin(ctx, wl)
+    ids, ent, cnt, n = _slots_batch(synth, wl.coeffs, [0])
+    odd = n.copy()
+    if odd[0] % 2 == 0:
+        odd[0] += 1
+    with pytest.raises(JxlHipError) as e:  # 12-bit runs must be even
+        ctx.submit_groups_slots(ids, ent, cnt, odd, None, flags=lib.GROUP_COMPLETE | lib.GROUP_ENTRIES12)
+    assert e.value.status == lib.ERR_INVALID_ARGUMENT
+    ctx.submit_groups_slots(ids, ent, cnt, n, None)   # not JXLH_ERR_BAD_STATE: nothing was reserved
+    ctx.slot_wait(0)
+    ctx.frame_run()
+    check(ctx, oracle_frame(oracle, wl, wl.coeffs), "after a rejected call")
+
+
 def test_rerender_before_any_render_renders_the_frame(ctx, oracle):
     from jxl_rs_amd import synth
     wl = synth.make_vardct(300, 300, mix=synth.MIX_D1, seed=2, epf_iters=2)

@@ -62,7 +62,7 @@ def test_slot_form_round_trips(scale, bits12):
     if bits12:
         b = ent.reshape(-1, 3).astype(np.uint32)
         e_all = np.empty(2 * len(b), np.uint32)
-        e_all[0::2] = b[:, 0] | ((b[:, 1] & 15) << 8)       # k_pack_slots<true>
+        e_all[0::2] = b[:, 0] | ((b[:, 1] & 15) << 8)       # k_unpack_entries12
         e_all[1::2] = (b[:, 1] >> 4) | (b[:, 2] << 4)
         vbits, shift = 6, 26
     else:

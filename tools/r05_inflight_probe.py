@@ -22,12 +22,23 @@ runs = np.concatenate(runs); ns = np.concatenate(ns)
 ids = np.arange(ng, dtype=np.uint32)
 
 
+scache, sent, scnt, sn = {}, [], [], []
+for g in range(ng):
+    k = g % 24
+    if k not in scache:
+        scache[k] = synth.to_slots(wl.coeffs[g])
+    sent.append(scache[k][0]); scnt.append(scache[k][1].reshape(-1)); sn.append(scache[k][2])
+sent = np.concatenate(sent); scnt = np.concatenate(scnt); sn = np.concatenate(sn)
+
+
 def make(nslots, sparse):
     c = jxl_rs_amd.Context(0, n_slots=nslots)
     c.frame_begin(synth.apply_opts(c.default_params(size, size), wl))
     c.set_dequant_tables(wl.tables); c.set_lf_quantized(*wl.lf_q)
     c.set_hf_meta(wl.transform_map, wl.raw_quant, wl.epf_map, wl.ytox, wl.ytob)
-    if sparse:
+    if sparse == "slots":
+        c.submit_groups_slots(ids, sent, scnt, sn, None)
+    elif sparse:
         c.submit_groups_sparse(ids, runs, ns, None)
     else:
         for g in range(ng):
@@ -54,10 +65,12 @@ def timed(ctxs, n=20, reps=5):
 
 
 out = {}
-for sparse in (False, True):
-    for nslots in (1, 2, 3):
+modes = sys.argv[2].split(",") if len(sys.argv) > 2 else ["dense", "pairs", "slots"]
+for mode in modes:
+    sparse = {"dense": False, "pairs": True, "slots": "slots"}[mode]
+    for nslots in (1, 2):
         cs = [make(nslots, sparse) for _ in range(2)]
-        key = f"{'sparse' if sparse else 'dense'}_slots{nslots}"
+        key = f"{mode}_slots{nslots}"
         out[key] = {"inflight1": timed(cs[:1]), "inflight2": timed(cs)}
         if nslots == 1:
             c = cs[0]
