@@ -66,6 +66,24 @@ def resolve_traffic(dominant, root=ROOT):
     return None, None
 
 
+def chain_traffic(workload="8192 d1", root=ROOT):
+    """HBM bytes of the WHOLE chain per frame (every kernel's FETCH x2 + WRITE) from the newest committed counter file of
+    that workload ("8192 d1": dense slabs resident; "8192 d1 slots": the slot-bucketed form resident).
+    Returns (bytes or None, file or None)."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(root, "profiles", "r*_traffic.json")), reverse=True):
+        try:
+            pmc = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if pmc.get("_workload", "8192 d1") != workload:
+            continue
+        parts = [int(v["hbm_bytes"]) for k, v in pmc.items() if isinstance(v, dict) and "hbm_bytes" in v]
+        if any(k.startswith("k1_") for k in pmc) and any(k.startswith("k23_fused") for k in pmc):
+            return sum(parts), os.path.relpath(path, root)
+    return None, None
+
+
 def time_vardct_config(jxl_rs_amd, synth, np, device, size, mix, epf_iters, seed, steps, warmup=2, extra_epf=None):
     """One secondary VarDCT configuration, ONE frame in flight, inputs HBM-resident: wall-clock step time (sync on both
     sides) + the per-kernel HIP-event table with every kernel against its own algorithmic bytes.  extra_epf: also
@@ -276,6 +294,22 @@ def main():
                     help="transform-type mix of the synthetic frame (d1 = BASELINE config 3)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: one rank per GPU under torch.distributed.run (what the driver's command
+        # line does explicitly).  Never a silent single-rank measurement labelled N.
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            sys.exit(f"bench.py --gpus {args.gpus}: {have} HIP device(s) visible on this box "
+                     f"(torch.cuda.device_count()); need {args.gpus} -- refusing to measure fewer ranks than asked for")
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        os.execv(sys.executable, cmd)
+
     import numpy as np
     import torch
     import jxl_rs_amd
@@ -294,7 +328,9 @@ def main():
         except TypeError:
             dist.init_process_group("nccl", rank=rank, world_size=world)
     n_gpus = max(world, 1)
-    assert n_gpus == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N"
+    if n_gpus != args.gpus:
+        sys.exit(f"bench.py --gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
+                 f"--nproc-per-node {args.gpus} (or run `python bench.py --gpus {args.gpus}` without a launcher)")
 
     size = args.size
     # ---- synthetic frame (config 3): d1-like type mix DCT8..32, CfL, LF smoothing, Gaborish, EPF x2
@@ -376,6 +412,8 @@ def main():
     ev_ms = rep_ev[mid]
     value = size * size * n_gpus / 1e6 / (ms_per_step / 1e3)
 
+    chain_bytes, chain_file = chain_traffic("8192 d1") if size == 8192 and args.mix == "d1" else (None, None)
+
     def result_line(strong, strong_modular, roofline, cpu, e2e, secondary):
         return {
             "metric": "megapixels/sec decoded (8K VarDCT d1 reconstruction: dequant+CfL+IDCT+LF smoothing+Gaborish+EPF)",
@@ -398,6 +436,13 @@ def main():
                             "value_at_max_ms": round(size * size * n_gpus / 1e6 / (max(rep_ms) / 1e3), 1)},
             "setup": {"host_generate_s": round(gen_s, 2), "h2d_coeffs_s": round(h2d_s, 2)},
             "roofline": roofline, "cpu_baseline": cpu, "e2e_pcie_inclusive": e2e, "secondary": secondary,
+            # what makes rounds on different boxes comparable: the box's own copy rate (float4 read + write kernel,
+            # frame-sized), the bytes the chain moved by counters (committed profile of this command), and the rate
+            # the pipelined step moved them at as a fraction of that copy rate
+            "copy_ceiling_GBs": (roofline or {}).get("copy_ceiling_GBs"),
+            "chain_counter_traffic_bytes": chain_bytes, "chain_counter_traffic_source": chain_file,
+            "chain_frac_of_copy_ceiling": (round(chain_bytes / (ms_per_step * 1e-3) / 1e9 / roofline["copy_ceiling_GBs"], 4)
+                                           if chain_bytes and roofline and roofline.get("copy_ceiling_GBs") else None),
         }
 
     # The sharded (strong) legs below are the only part of an N > 1 run in which ranks wait for each other inside
@@ -575,6 +620,15 @@ def main():
         npx = size * size
 
         def kernel_table():
+            # untimed frames first (80 ms of them): after the host-side work between two populations (numpy, set_hf_meta's
+            # synchronous copies) the device has idled and its first tens of frames run 15-25 % slower than the steady
+            # state -- round 4's "half-filtered slower than all-filtered" was the population measured cold
+            # (profiles/r05_d_filter_populations.txt)
+            t_warm = time.perf_counter()
+            while time.perf_counter() - t_warm < 0.08:   # ~100 frames: the device's clocks are back up
+                for _ in range(10):
+                    ctx.frame_run(0, ygroups)
+                ctx.sync()
             ctx.kernel_timing_reset()
             ctx.kernel_timing(True)
             nprof = max(3, min(args.steps, 10))
@@ -933,6 +987,38 @@ def main():
         for c in ectx:
             c.sync()
         e2e["sparse_resident_no_pcie"] = resident_leg()
+        e2e["sparse_resident_no_pcie"]["form"] = "bucketed {u16 pos; i16 val} pair words + slot tables (device sort)"
+        # ... and resident in the slot-bucketed 2-byte form exactly as jxlh_submit_groups_slots uploads it (round 5: the
+        # transforms read the entries in place -- no unpack pass, no slot tables -- and dequantise only the positions
+        # that have an entry): what the kernels of the PCIe-inclusive deployment cost, per kernel and by counters
+        for c in ectx:
+            c.frame_begin(synth.apply_opts(c.default_params(size, size), wl))
+            c.set_dequant_tables(wl.tables)
+            c.set_lf_quantized(*wl.lf_q)
+            c.set_hf_meta(wl.transform_map, wl.raw_quant, wl.epf_map, wl.ytox, wl.ytob)
+            submit_slots(c); c.frame_run()
+        for c in ectx:
+            c.sync()
+        leg = resident_leg()
+        leg["form"] = "u16 entries (pos6 | val10) + u8 slot counts, read in place"
+        c0 = ectx[0]
+        for _ in range(40):
+            c0.frame_run()
+        c0.sync()
+        c0.kernel_timing_reset(); c0.kernel_timing(True)
+        for _ in range(10):
+            c0.frame_run()
+        c0.sync()
+        kt = c0.kernel_times(); c0.kernel_timing(False)
+        leg["kernels_ms"] = {k: round(v[0] / 10, 4) for k, v in kt.items()}
+        leg["sum_of_kernels_ms"] = round(sum(v[0] for v in kt.values()) / 10, 4)
+        tb, tf = chain_traffic("8192 d1 slots") if size == 8192 and args.mix == "d1" else (None, None)
+        leg["chain_counter_traffic_bytes"] = tb
+        leg["traffic_source"] = tf
+        if "k1_vardct" in kt:  # K1's compulsory traffic in this form: 12 B/px of pixels out + the entries / counts / LF in
+            k1_ms = kt["k1_vardct"][0] / 10
+            leg["k1_pixels_out_GBs"] = round(12.0 * size * size / (k1_ms * 1e-3) / 1e9, 1)
+        e2e["slots_resident_no_pcie"] = leg
         for c in ectx:   # new epoch for the PCIe legs
             c.frame_begin(synth.apply_opts(c.default_params(size, size), wl))
             c.set_dequant_tables(wl.tables)

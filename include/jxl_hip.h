@@ -329,6 +329,11 @@ jxlh_status jxlh_frame_device_planes(jxlh_ctx* ctx, float* planes[3], size_t* st
  * same per channel.  ec_upsampling counts from the channel's own resolution: w = ceil(full width / ec_upsampling).
  * jxlh_frame_read_extra_channel copies the finished channel out: out_w x out_h f32 samples with
  * out_w = min(w * ec_upsampling, width of the frame's result), likewise the height.  Up to JXLH_MAX_EXTRA_CHANNELS. */
+/* bits_per_sample carries the channel's BitDepth (headers/bit_depth.rs): bits_per_sample | exponent_bits_per_sample
+ * << 8.  Exponent bits 0 = integer samples (val / (2^bits - 1)); otherwise the samples are `bits`-bit floats stored in
+ * integers (binary16 = 16 | 5 << 8, binary32 = 32 | 8 << 8, any custom format) and are widened to binary32 exactly
+ * (int_to_float, convert.rs:416-486).  The same convention holds for jxlh_modular_to_f32.  A channel handed over after
+ * the frame's first render is converted by the next jxlh_frame_run or jxlh_frame_rerender_groups. */
 #define JXLH_MAX_EXTRA_CHANNELS 8
 jxlh_status jxlh_frame_set_extra_channel(jxlh_ctx* ctx, uint32_t ec, const int32_t* samples, size_t stride, uint32_t w,
                                          uint32_t h, uint32_t bits_per_sample, uint32_t ec_upsampling);

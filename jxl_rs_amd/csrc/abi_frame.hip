@@ -848,14 +848,19 @@ jxlh_status run_strip(jxlh_ctx* ctx, const RunPlan& plan) {
     ctx->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
   const int strips = strip_strips(f), tile_rows = strip_tile_rows(f);
-  // two workgroups per CU; a band is at least 4 tile rows (two extra transforms per band and strip)
-  int bands = (2 * ctx->cu_count + strips / 2) / strips;
+  // The strips of a band spin on their neighbours' progress flags: every workgroup of the launch must be resident.
+  // The occupancy query says how many are (two per CU on MI355X: the 77 KB window); a frame wider than that in strips
+  // cannot take this path at all (the grid used to assume two per CU).
+  static const int resident = strip_resident_workgroups(ctx->cu_count);
+  if (resident < strips) return JXLH_ERR_UNSUPPORTED;  // (the caller falls back to the two-kernel path)
+  // a band is at least 4 tile rows (two extra transforms per band and strip)
+  int bands = std::min((2 * ctx->cu_count + strips / 2) / strips, resident / strips);
   bands = std::max(1, std::min(bands, std::max(1, tile_rows / 4)));
   static const int forced_bands = [] {
     const char* e = getenv("JXLH_STRIP_BANDS");
     return e ? atoi(e) : 0;
   }();
-  if (forced_bands > 0) bands = std::min(forced_bands, tile_rows);
+  if (forced_bands > 0) bands = std::min(std::min(forced_bands, tile_rows), std::max(1, resident / strips));
   const size_t nblocks = (size_t)f.xblocks * f.yblocks;
   const bool fresh = ctx->strip_desc.n < nblocks;
   if (jxlh_status st = ensure(ctx, ctx->strip_desc, nblocks)) return st;
@@ -884,8 +889,12 @@ jxlh_status run_strip(jxlh_ctx* ctx, const RunPlan& plan) {
       const char* e = getenv("JXLH_STRIP_DEADLINE_S");
       return e ? (float)atof(e) : 4.0f;
     }();
-    launch_strip(ctx->stream, f, f.strip_desc, f.strip_mode, ctx->strip_xchg.p, ctx->strip_flags.p, bands,
-                 ctx->error_flag.p, deadline_s);
+    if (!launch_strip(ctx->stream, f, f.strip_desc, f.strip_mode, ctx->strip_xchg.p, ctx->strip_flags.p, bands,
+                      ctx->error_flag.p, deadline_s)) {
+      f.strip_desc = nullptr;
+      f.strip_mode = nullptr;
+      return JXLH_ERR_UNSUPPORTED;  // stage list not covered (strip_eligible should have said so)
+    }
   }
   f.strip_desc = nullptr;  // band runs / re-renders of this frame take the two-kernel path
   f.strip_mode = nullptr;
@@ -1019,7 +1028,10 @@ jxlh_status run_post_stages(jxlh_ctx* ctx, float* const cur[3], int y_lo, int y_
     launch_noise_apply(ctx->stream, nz, ctx->res_stride, ctx->result, ctx->res_stride, W, H, ya, yb, p.noise_lut, ytox,
                        ytob);
   }
-  if (whole_frame)
+  // (a partial re-render still picks up a channel that was handed over after the last whole-frame run)
+  bool pending_extra = false;
+  for (int i = 0; i < JXLH_MAX_EXTRA_CHANNELS; i++) pending_extra |= ctx->extra[i].set && !ctx->extra[i].done;
+  if (whole_frame || pending_extra)
     if (jxlh_status st = run_extra_channels(ctx)) return st;
   HIPCHK(ctx, hipGetLastError());
   return JXLH_OK;
@@ -1032,10 +1044,14 @@ jxlh_status run_extra_channels(jxlh_ctx* ctx) {
     jxlh_ctx::ExtraChannel& e = ctx->extra[i];
     if (!e.set) continue;
     const size_t n = (size_t)e.w * e.h;
+    e.done = false;
     if (jxlh_status st = ensure(ctx, e.f32, n)) return st;
     {
       ScopedKernelTimer t(ctx, "k_modular_to_f32");
-      launch_modular_to_f32(ctx->stream, e.raw.p, n, 1.0f / (float)((1ull << e.bits) - 1), e.f32.p);
+      if (e.bits >> 8)  // floating-point samples (BitDepth::floating_point_sample, convert.rs:525-526)
+        launch_float_samples_to_f32(ctx->stream, e.raw.p, n, e.bits & 0xffu, e.bits >> 8, e.f32.p);
+      else
+        launch_modular_to_f32(ctx->stream, e.raw.p, n, 1.0f / (float)((1ull << e.bits) - 1), e.f32.p);
     }
     // the frame's result size bounds the channel's (the padding of ceil(size / factor) * factor is cut off)
     const uint32_t full_w = (uint32_t)(ctx->res_w > 0 ? ctx->res_w : ctx->fd.xsize),
@@ -1072,7 +1088,12 @@ jxlh_status jxlh_frame_run(jxlh_ctx* ctx, uint32_t group_row0, uint32_t group_ro
   plan.want_strip = whole && strip_eligible(ctx);
   if (jxlh_status st = run_prologue(ctx, &plan)) return st;
   ctx->strip_ran = false;
-  if (plan.want_strip) return run_strip(ctx, plan);
+  if (plan.want_strip) {
+    const jxlh_status st = run_strip(ctx, plan);
+    if (st != JXLH_ERR_UNSUPPORTED) return st;
+    ctx->fd.strip_desc = nullptr;  // (nothing was launched) the two-kernel path takes the frame
+    ctx->fd.strip_mode = nullptr;
+  }
   // ---- K1 on the band plus one halo group row on each side (filters read across it)
   // (vertical chroma upsampling reads one sub-sampled row beyond the band as well)
   const bool need_halo = plan.halo_px > 0 || f.subsampled;
@@ -1151,8 +1172,9 @@ jxlh_status jxlh_frame_rerender_groups(jxlh_ctx* ctx, const uint32_t* group_ids,
 jxlh_status jxlh_frame_set_extra_channel(jxlh_ctx* ctx, uint32_t ec, const int32_t* samples, size_t stride, uint32_t w,
                                          uint32_t h, uint32_t bits_per_sample, uint32_t ec_upsampling) {
   JXLH_ON_DEVICE(ctx);
-  if (!ctx || !samples || ec >= JXLH_MAX_EXTRA_CHANNELS || w == 0 || h == 0 || stride < w || bits_per_sample == 0 ||
-      bits_per_sample > 31 || (ec_upsampling != 1 && ec_upsampling != 2 && ec_upsampling != 4 && ec_upsampling != 8))
+  if (!ctx || !samples || ec >= JXLH_MAX_EXTRA_CHANNELS || w == 0 || h == 0 || stride < w ||
+      !bit_depth_ok(bits_per_sample, 31) ||
+      (ec_upsampling != 1 && ec_upsampling != 2 && ec_upsampling != 4 && ec_upsampling != 8))
     return JXLH_ERR_INVALID_ARGUMENT;
   if (!ctx->in_frame) return JXLH_ERR_BAD_STATE;
   if ((uint64_t)w * h >= (1ull << 31)) return JXLH_ERR_UNSUPPORTED;

@@ -138,18 +138,23 @@ jxlh_status jxlh_modular_to_rgb8(jxlh_ctx* ctx, const int32_t* const planes[3], 
 
 jxlh_status jxlh_modular_to_f32(jxlh_ctx* ctx, const int32_t* in, size_t n, uint32_t bits_per_sample, float* out) {
   JXLH_ON_DEVICE(ctx);
-  if (!ctx || !in || !out || bits_per_sample < 1 || bits_per_sample > 32) return JXLH_ERR_INVALID_ARGUMENT;
+  if (!ctx || !in || !out || !bit_depth_ok(bits_per_sample, 32)) return JXLH_ERR_INVALID_ARGUMENT;
   if (n == 0) return JXLH_OK;
-  const float scale = 1.0f / (float)((1ull << bits_per_sample) - 1);  // convert.rs:528
+  const uint32_t bits = bits_per_sample & 0xffu, exp_bits = bits_per_sample >> 8;  // BitDepth::floating_point_sample()
+  const float scale = 1.0f / (float)((1ull << bits) - 1);  // convert.rs:528
+  auto convert = [&](const int32_t* src, float* dst) {
+    if (exp_bits) launch_float_samples_to_f32(ctx->stream, src, n, bits, exp_bits, dst);  // convert.rs:525-526
+    else launch_modular_to_f32(ctx->stream, src, n, scale, dst);
+  };
   if (is_device_ptr(in) && is_device_ptr(out)) {
-    launch_modular_to_f32(ctx->stream, in, n, scale, out);
+    convert(in, out);
     HIPCHK(ctx, hipGetLastError());
     return JXLH_OK;
   }
   jxlh_status st;
   if ((st = stage_in(ctx, ctx->hook_i[0], in, n))) return st;
   if ((st = ensure(ctx, ctx->hook_f[0], n))) return st;
-  launch_modular_to_f32(ctx->stream, ctx->hook_i[0].p, n, scale, ctx->hook_f[0].p);
+  convert(ctx->hook_i[0].p, ctx->hook_f[0].p);
   HIPCHK(ctx, hipGetLastError());
   return stage_out(ctx, out, (const float*)ctx->hook_f[0].p, n);
 }

@@ -232,6 +232,7 @@ void launch_vardct_groups(hipStream_t s, const FrameDev& f, int group_row0, int 
                           bool has_large = true);
 // k_strip.hip: dequantisation + IDCT + the frame's filter stages in one persistent kernel, result in f.tmp (raster).
 // Runs behind launch_vardct_groups on a FrameDev with the strip_* members set.  false = stage list not covered.
+int strip_resident_workgroups(int cu_count);
 int strip_tile_rows(const FrameDev& f);
 int strip_strips(const FrameDev& f);
 size_t strip_xchg_floats(const FrameDev& f);
@@ -328,6 +329,15 @@ void launch_palette_wp(hipStream_t s, const int32_t* index, int w, int h, const 
 void launch_i32_to_rgb8(hipStream_t s, const int32_t* const planes[3], size_t stride, int w, int h, int32_t mult,
                         int32_t maxv, int channels, uint8_t* out, size_t out_stride);
 void launch_modular_to_f32(hipStream_t s, const int32_t* in, size_t n, float scale, float* out);
+// floating-point samples: a `bits`-bit float with exp_bits exponent bits in an integer -> binary32
+void launch_float_samples_to_f32(hipStream_t s, const int32_t* in, size_t n, uint32_t bits, uint32_t exp_bits, float* out);
+// BitDepth as the ABI carries it: bits_per_sample | exponent_bits_per_sample << 8 (0 = integer samples).  A float format
+// needs 2 <= exponent bits <= 8 and at least one, at most 23 mantissa bits (headers/bit_depth.rs).
+inline bool bit_depth_ok(uint32_t packed, uint32_t max_int_bits) {
+  const uint32_t bits = packed & 0xffu, eb = packed >> 8;
+  if (eb == 0) return packed == bits && bits >= 1 && bits <= max_int_bits;
+  return (packed >> 16) == 0 && bits <= 32 && eb >= 2 && eb <= 8 && bits >= eb + 2 && bits - eb - 1 <= 23;
+}
 void launch_modular_xyb_to_f32(hipStream_t s, const int32_t* y, const int32_t* x, const int32_t* b, size_t n,
                                const float scale[3], float* ox, float* oy, float* ob);
 // n_planes (<= 3) planes of identical geometry in one launch (the channels of one squeeze step)

@@ -958,6 +958,44 @@ __global__ void k_modular_to_f32(const int32_t* __restrict__ in, size_t n, float
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i < n) out[i] = (float)in[i] * scale;
 }
+// ConvertModularToF32Stage, floating-point samples (convert.rs:416-486 int_to_float / int_to_float_generic): a `bits`-bit
+// float with `exp_bits` exponent bits stored in an integer -> binary32.  The generic form covers the reference's two
+// fast paths as well: binary32 passes through bit for bit, binary16 widens exactly like the hardware conversion
+// (signalling NaNs keep their payload here; the reference's f16 SIMD path quiets them).
+__global__ void k_float_samples_to_f32(const int32_t* __restrict__ in, size_t n, uint32_t bits, uint32_t exp_bits,
+                                       float* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int exp_bias = (1 << (exp_bits - 1)) - 1;
+  const uint32_t sign_shift = bits - 1, mant_bits = bits - exp_bits - 1, mant_shift = 23 - mant_bits;
+  uint32_t f = (uint32_t)in[i];
+  const bool signbit = (f >> sign_shift) != 0;
+  f &= (sign_shift >= 32 ? 0xffffffffu : (1u << sign_shift) - 1u);
+  uint32_t r;
+  if (f == 0) {
+    r = signbit ? 0x80000000u : 0u;
+  } else {
+    int exp = (int)(f >> mant_bits);
+    uint32_t mantissa = f & ((1u << mant_bits) - 1u);
+    if (exp == (1 << exp_bits) - 1) {  // NaN or infinity
+      r = (signbit ? 0x80000000u : 0u) | 0xffu << 23 | mantissa << mant_shift;
+    } else {
+      mantissa <<= mant_shift;
+      if (exp == 0 && exp_bits < 8) {  // subnormal: normalise
+        while ((mantissa & 0x800000u) == 0) {
+          mantissa <<= 1;
+          exp -= 1;
+        }
+        exp += 1;
+        mantissa &= 0x7fffffu;  // the leading 1 is implicit now
+      }
+      exp -= exp_bias;
+      exp += 127;
+      r = (signbit ? 0x80000000u : 0u) | (uint32_t)exp << 23 | mantissa;
+    }
+  }
+  out[i] = __uint_as_float(r);
+}
 // ConvertModularXYBToF32Stage (convert.rs:306-343)
 __global__ void k_modular_xyb_to_f32(const int32_t* __restrict__ y, const int32_t* __restrict__ x,
                                      const int32_t* __restrict__ b, size_t n, float sx, float sy, float sb,
@@ -984,6 +1022,10 @@ void launch_i32_to_rgb8(hipStream_t s, const int32_t* const planes[3], size_t st
 }
 void launch_modular_to_f32(hipStream_t s, const int32_t* in, size_t n, float scale, float* out) {
   if (n) hipLaunchKernelGGL(k_modular_to_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, n, scale, out);
+}
+void launch_float_samples_to_f32(hipStream_t s, const int32_t* in, size_t n, uint32_t bits, uint32_t exp_bits, float* out) {
+  if (n)
+    hipLaunchKernelGGL(k_float_samples_to_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, n, bits, exp_bits, out);
 }
 void launch_modular_xyb_to_f32(hipStream_t s, const int32_t* y, const int32_t* x, const int32_t* b, size_t n,
                                const float scale[3], float* ox, float* oy, float* ob) {

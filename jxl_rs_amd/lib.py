@@ -525,11 +525,12 @@ class Context:
         self._chk(self.L.jxlh_probe_copy_bandwidth(self._ctx, nbytes, reps, C.byref(v)), "probe_copy_bandwidth")
         return v.value
 
-    def set_extra_channel(self, ec, samples, bits_per_sample, ec_upsampling=1):
+    def set_extra_channel(self, ec, samples, bits_per_sample, ec_upsampling=1, exp_bits=0):
         """hands Modular channel 3 + ec over as decoded (i32 [h, w]); processed by the next frame_run"""
         a = np.ascontiguousarray(samples, dtype=np.int32)
         h, w = a.shape
-        self._chk(self.L.jxlh_frame_set_extra_channel(self._ctx, ec, _addr(a), w, w, h, bits_per_sample, ec_upsampling),
+        self._chk(self.L.jxlh_frame_set_extra_channel(self._ctx, ec, _addr(a), w, w, h, bits_per_sample | exp_bits << 8,
+                                                      ec_upsampling),
                   "frame_set_extra_channel")
 
     def read_extra_channel(self, ec, out_w, out_h):
@@ -819,10 +820,10 @@ class Context:
                   "modular_to_rgb8")
         return out
 
-    def modular_to_f32(self, plane, bits):
+    def modular_to_f32(self, plane, bits, exp_bits=0):
         a = np.ascontiguousarray(plane, dtype=np.int32)
         out = np.zeros(a.shape, dtype=np.float32)
-        self._chk(self.L.jxlh_modular_to_f32(self._ctx, _addr(a), a.size, bits, _addr(out)), "modular_to_f32")
+        self._chk(self.L.jxlh_modular_to_f32(self._ctx, _addr(a), a.size, bits | exp_bits << 8, _addr(out)), "modular_to_f32")
         return out
 
     def modular_xyb_to_f32(self, y, x, b, quant_factors):

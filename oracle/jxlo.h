@@ -253,6 +253,7 @@ void jxlo_palette_delta_wp(const int32_t* index, int w, int h, const int32_t* pa
 /* Modular channels -> pipeline samples (render/stages/convert.rs:278-343, :488-533, :642-715) */
 void jxlo_i32_to_u8(const int32_t* in, size_t n, int32_t multiplier, int32_t max, uint8_t* out);
 void jxlo_modular_to_f32(const int32_t* in, size_t n, int bits, float* out);
+void jxlo_float_samples_to_f32(const int32_t* in, size_t n, uint32_t bits, uint32_t exp_bits, float* out);
 void jxlo_modular_xyb_to_f32(const int32_t* y, const int32_t* x, const int32_t* b, size_t n, const float scale[3],
                              float* ox, float* oy, float* ob);
 int32_t jxlo_palette_value(const int32_t* palette, size_t palette_stride, int64_t index, int c,

@@ -572,6 +572,41 @@ void jxlo_modular_to_f32(const int32_t* in, size_t n, int bits, float* out) {
   const float scale = 1.0f / (float)((1ull << bits) - 1);
   for (size_t i = 0; i < n; i++) out[i] = (float)in[i] * scale;
 }
+/* ConvertModularToF32Stage, floating-point samples: int_to_float_generic (:436-486), which also reproduces the two
+ * fast paths of int_to_float (:416-433) -- binary32 bit for bit, binary16 like the hardware conversion except that a
+ * signalling NaN keeps its payload */
+void jxlo_float_samples_to_f32(const int32_t* in, size_t n, uint32_t bits, uint32_t exp_bits, float* out) {
+  const int exp_bias = (1 << (exp_bits - 1)) - 1;
+  const uint32_t sign_shift = bits - 1, mant_bits = bits - exp_bits - 1, mant_shift = 23 - mant_bits;
+  for (size_t i = 0; i < n; i++) {
+    uint32_t f = (uint32_t)in[i], r;
+    const int signbit = (f >> sign_shift) != 0;
+    f &= (uint32_t)((1ull << sign_shift) - 1);
+    if (f == 0) {
+      r = signbit ? 0x80000000u : 0u;
+    } else {
+      int exp = (int)(f >> mant_bits);
+      uint32_t mantissa = f & ((1u << mant_bits) - 1u);
+      if (exp == (1 << exp_bits) - 1) {
+        r = (signbit ? 0x80000000u : 0u) | 0xffu << 23 | mantissa << mant_shift;
+      } else {
+        mantissa <<= mant_shift;
+        if (exp == 0 && exp_bits < 8) {
+          while ((mantissa & 0x800000u) == 0) {
+            mantissa <<= 1;
+            exp -= 1;
+          }
+          exp += 1;
+          mantissa &= 0x7fffffu;
+        }
+        exp -= exp_bias;
+        exp += 127;
+        r = (signbit ? 0x80000000u : 0u) | (uint32_t)exp << 23 | mantissa;
+      }
+    }
+    memcpy(&out[i], &r, 4);
+  }
+}
 /* ConvertModularXYBToF32Stage (:306-343): channels arrive as Y, X, B; B carries B - Y */
 void jxlo_modular_xyb_to_f32(const int32_t* y, const int32_t* x, const int32_t* b, size_t n, const float scale[3],
                              float* ox, float* oy, float* ob) {

@@ -146,6 +146,7 @@ class Oracle:
         L.jxlo_palette_delta.argtypes = [ip, C.c_int, C.c_int, ip, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_int, ip]
         L.jxlo_i32_to_u8.argtypes = [ip, C.c_size_t, C.c_int32, C.c_int32, C.POINTER(C.c_uint8)]
         L.jxlo_modular_to_f32.argtypes = [ip, C.c_size_t, C.c_int, fp]
+        L.jxlo_float_samples_to_f32.argtypes = [ip, C.c_size_t, C.c_uint32, C.c_uint32, fp]
         L.jxlo_modular_xyb_to_f32.argtypes = [ip, ip, ip, C.c_size_t, fp, fp, fp, fp]
         u32p = C.POINTER(C.c_uint32)
         L.jxlo_wp_new.argtypes = [u32p, C.c_int]
@@ -577,10 +578,14 @@ class Oracle:
         self.lib.jxlo_i32_to_u8(_ptr(a, C.c_int32), a.size, multiplier, maxv, _ptr(out, C.c_uint8))
         return out
 
-    def modular_to_f32(self, plane, bits):
+    def modular_to_f32(self, plane, bits, exp_bits=0):
+        """ConvertModularToF32Stage: integer samples (exp_bits 0) or `bits`-bit floats with exp_bits exponent bits"""
         a = np.ascontiguousarray(plane, dtype=np.int32)
         out = np.zeros(a.shape, dtype=np.float32)
-        self.lib.jxlo_modular_to_f32(_ptr(a, C.c_int32), a.size, bits, _ptr(out, C.c_float))
+        if exp_bits:
+            self.lib.jxlo_float_samples_to_f32(_ptr(a, C.c_int32), a.size, bits, exp_bits, _ptr(out, C.c_float))
+        else:
+            self.lib.jxlo_modular_to_f32(_ptr(a, C.c_int32), a.size, bits, _ptr(out, C.c_float))
         return out
 
     def modular_xyb_to_f32(self, y, x, b, scale):

@@ -448,6 +448,49 @@ def test_extra_channels_inside_the_frame_path(ctx, oracle, n, size, up_size, str
         ctx.set_extra_channel(0, np.zeros((4, 4), np.int32), 8, 3)      # not a factor the format has
 
 
+@pytest.mark.parametrize("bits,exp_bits", [(16, 5), (32, 8), (19, 6), (12, 4), (24, 7)])
+def test_float_samples_to_f32(ctx, oracle, bits, exp_bits):
+    """ConvertModularToF32Stage on floating-point samples (the extra-channel path modelled integer samples
+    only): a `bits`-bit float with exp_bits exponent bits stored in an integer -> binary32, int_to_float (convert.rs:
+    416-486), through jxlh_modular_to_f32 and as an extra channel of a frame -- also one handed over AFTER the first
+    render, which a partial re-render must pick up"""
+    from jxl_rs_amd import synth, JxlHipError
+    rng = np.random.default_rng(bits * 9 + exp_bits)
+    n = 4096
+    smp = rng.integers(0, 1 << min(bits, 31), size=n, dtype=np.int64)
+    if bits == 32:
+        smp = rng.integers(0, 1 << 32, size=n, dtype=np.int64)
+    mant = bits - exp_bits - 1
+    special = np.array([0, 1 << (bits - 1), 1, (1 << mant) - 1, ((1 << exp_bits) - 1) << mant,   # +-0, subnormals, inf
+                        (((1 << exp_bits) - 1) << mant) | 1, 1 << mant, (1 << (bits - 1)) | 5], dtype=np.int64)  # NaN, min normal
+    smp[:len(special)] = special
+    smp = smp.astype(np.uint32).view(np.int32)
+    want = oracle.modular_to_f32(smp, bits, exp_bits)
+    if (bits, exp_bits) == (16, 5):
+        ref = smp.astype(np.uint16).view(np.float16).astype(np.float32)   # what the reference's f16 fast path computes
+        ok = np.isnan(ref) | (ref.view(np.uint32) == want.view(np.uint32))
+        assert ok.all()
+    if (bits, exp_bits) == (32, 8):
+        assert np.array_equal(want.view(np.int32), smp)                    # the passthrough
+    got = ctx.modular_to_f32(smp, bits, exp_bits)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    with pytest.raises(JxlHipError):
+        ctx.modular_to_f32(smp, bits, 9)        # not a float format (more than 8 exponent bits)
+    if bits > 31:
+        return
+    # as an extra channel, handed over after the frame has been rendered once
+    wl = synth.make_vardct(256, 256, mix=synth.MIX_DCT8, seed=bits, epf_iters=1)
+    upload_frame(ctx, wl)
+    ctx.frame_run()
+    ctx.sync()
+    plane = smp.reshape(64, 64)
+    ctx.set_extra_channel(1, plane, bits, 1, exp_bits=exp_bits)
+    ctx.rerender_groups([0])
+    ctx.sync()
+    got = ctx.read_extra_channel(1, 64, 64)
+    assert np.array_equal(got.view(np.uint32), want.reshape(64, 64).view(np.uint32))
+
+
 def test_upsampled_frame_argument_errors(ctx):
     from jxl_rs_amd import synth, lib, JxlHipError
     wl = synth.make_vardct(600, 600, mix=synth.MIX_DCT8, seed=1, epf_iters=0, gab=False)

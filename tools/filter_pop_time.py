@@ -23,7 +23,11 @@ pops = {"spec": (wl.raw_quant, wl.epf_map),
         "half": (np.where(pick, np.minimum(wl.raw_quant, 4), wl.raw_quant), np.where(pick, 7, 0).astype(wl.epf_map.dtype)),
         "all": (np.minimum(wl.raw_quant, 4), np.full_like(wl.epf_map, 7))}
 out = {}
-for name, (rq, em) in pops.items():
+# JXLH_POP_ORDER=spec,all,half,all,half: the order matters (a population measured right after the all-filtered one runs
+# on a chip that has just drawn more power: round 5 found the driver line's "half slower than all" to be that)
+order = os.environ.get("JXLH_POP_ORDER", "spec,half,all").split(",")
+for idx, name in enumerate(order):
+    rq, em = pops[name]
     c.set_hf_meta(wl.transform_map, rq, em, wl.ytox, wl.ytob)
     for _ in range(3):
         c.frame_run()
@@ -35,6 +39,6 @@ for name, (rq, em) in pops.items():
     c.sync()
     kt = c.kernel_times()
     c.kernel_timing(False)
-    out[name] = round(kt["k23_fused_filters"][0] / 10, 4)
+    out[f"{idx}:{name}"] = round(kt["k23_fused_filters"][0] / 10, 4)
 print(json.dumps(out))
 c.close()
