@@ -1029,31 +1029,57 @@ def main():
                 ("dense_i32", submit_dense))
         if os.environ.get("JXLH_BENCH_E2E_ORDER") == "swap":  # leg order experiment (first-leg warm-up effects)
             legs = (legs[1], legs[0]) + legs[2:]
-        for name, submit in legs:
-            frames = 6 if name == "dense_i32" else 12
-            # untimed warm-up in the same pipelined pattern: the first frames that stream from a freshly pinned
-            # buffer run up to 60 % slower (measured by swapping the order of the legs), whichever leg they belong to
-            for i in range(NE + 4 if name != "dense_i32" else NE):
-                c = ectx[i % NE]
-                c.sync()
-                submit(c); c.frame_run()
-            for c in ectx:
-                c.sync()
+        def run_leg(submit, frames, pattern, after_run=None):
+            """`frames` frames round robin over the contexts, each: submit -> frame_run (-> after_run).  pattern "marks"
+            (round 5): the host then waits for the mark of that context's PREVIOUS frame only (jxlh_ctx_wait_mark), so the
+            upload of a context's next frame runs under its current frame's kernels; "sync": round 4's loop, a full
+            jxlh_ctx_sync of the context before its next submission.  Returns ms per frame."""
+            marks = [None] * NE
             t0 = time.perf_counter()
             for i in range(frames):
-                c = ectx[i % NE]
-                c.sync()          # the context's previous frame is finished: its buffers can be refilled
+                k = i % NE
+                c = ectx[k]
+                if pattern == "sync":
+                    c.sync()          # the context's previous frame is finished: its buffers can be refilled
+                else:
+                    # uploads serialised by the host: the OTHER context's upload has finished before this one starts, so
+                    # the contexts stay in anti-phase (one uploads while the other computes) by construction.  Without
+                    # this the marks loop is bistable: 0.70 or 0.93-1.2 ms per frame, tools/e2e_marks_probe.py
+                    for o in ectx:
+                        if o is not c:
+                            for sl in range(nslots):
+                                o.slot_wait(sl)
                 submit(c)
                 c.frame_run()
+                if after_run is not None:
+                    after_run(k)
+                if pattern == "marks":
+                    prev, marks[k] = marks[k], c.mark()
+                    if prev is not None:
+                        c.wait_mark(prev)
             for c in ectx:
                 c.sync()
-            el = time.perf_counter() - t0
+            return (time.perf_counter() - t0) * 1e3 / frames
+
+        for name, submit in legs:
+            frames = 6 if name == "dense_i32" else 48  # (a repetition ends with a drain: one frame time not overlapped)
+            # untimed warm-up in the same pipelined pattern: the first frames that stream from a freshly pinned
+            # buffer run up to 2x slower (round 4: measured by swapping the order of the legs; round 5: the streaming
+            # probe needs 40-70 frames from a new pinned buffer before it settles, tools/e2e_marks_probe.py), whichever
+            # leg they belong to -- a decoder reuses its pinned staging buffers for every frame
+            run_leg(submit, 60 if name != "dense_i32" else NE, "marks")
+            reps = [run_leg(submit, frames, "marks") for _ in range(1 if name == "dense_i32" else 3)]
+            ms = sorted(reps)[(len(reps) - 1) // 2]
             nbytes = {"sparse_pairs": total * 4, "sparse_pos16_val8": total * 3, "sparse_seg12_val4": bytes4,
                       "slots_pos6_val10_no_sort": bytes_slots,
                       "slots_packed12_no_sort": bytes_12}.get(name, wl.coeffs.nbytes)
-            e2e[name] = {"value": round(size * size * frames / 1e6 / el, 1), "unit": "MP/s",
-                         "ms_per_frame": round(el * 1e3 / frames, 3), "h2d_MB_per_frame": round(nbytes / 1e6, 1),
-                         "frames": frames}
+            e2e[name] = {"value": round(size * size / 1e6 / (ms / 1e3), 1), "unit": "MP/s",
+                         "ms_per_frame": round(ms, 3), "h2d_MB_per_frame": round(nbytes / 1e6, 1),
+                         "frames": frames, "repetitions_ms": [round(v, 3) for v in reps], "reported": "median",
+                         "host_loop": "marks"}
+            if name.startswith("slots_"):  # round 4's host loop on the same library, for comparison
+                run_leg(submit, 12, "sync")
+                e2e[name]["ms_per_frame_sync_loop"] = round(run_leg(submit, 24, "sync"), 3)
         # full decode-to-host: sparse pairs in, interleaved 8-bit sRGB out (jxlh_frame_read_rgb8) into
         # pinned host memory; frame i's download overlaps frame i+1's upload and kernels
         kk = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_kat.json")))["output_stage"]
@@ -1070,28 +1096,23 @@ def main():
             c._chk(c.L.jxlh_frame_read_rgb8_async(c._ctx, xyb_params.ctypes.data_as(C.c_void_p), 3, 0, size,
                                                   C.c_void_p(pin_o[i][1]), size * 3), "frame_read_rgb8_async")
 
-        frames = 12
-        for i in range(NE + 2):  # warm-up in the timed pattern
-            c = ectx[i % NE]
-            c.sync()
-            submit_slots12(c); c.frame_run(); read_rgb(i % NE)
-        for c in ectx:
-            c.sync()
-        t0 = time.perf_counter()
-        for i in range(frames):
-            c = ectx[i % NE]
-            c.sync()             # the context's previous frame is in host memory: its buffers can be reused
-            submit_slots12(c); c.frame_run(); read_rgb(i % NE)
-        for c in ectx:
-            c.sync()
-        el = time.perf_counter() - t0
-        e2e["slots_to_host_rgb8"] = {"value": round(size * size * frames / 1e6 / el, 1), "unit": "MP/s",
-                                            "ms_per_frame": round(el * 1e3 / frames, 3),
+        frames = 24
+        # (the marks loop: a context's next upload starts while its current frame is still being converted and copied
+        # out; the output buffer of a context is rewritten only after the mark behind its previous read has been waited for)
+        run_leg(submit_slots12, 24, "marks", after_run=read_rgb)
+        reps = [run_leg(submit_slots12, frames, "marks", after_run=read_rgb) for _ in range(3)]
+        el_ms = sorted(reps)[1]
+        e2e["slots_to_host_rgb8"] = {"value": round(size * size / 1e6 / (el_ms / 1e3), 1), "unit": "MP/s",
+                                            "ms_per_frame": round(el_ms, 3), "repetitions_ms": [round(v, 3) for v in reps],
                                             "h2d_MB_per_frame": round(bytes_12 / 1e6, 1),
                                             "d2h_MB_per_frame": round(rgb_bytes / 1e6, 1), "frames": frames}
-        e2e["note"] = ("pinned host coefficients -> H2D on 2 slot streams -> (sparse: device zero-fill + scatter) -> "
-                       "K0b/K3/K1/filters, 2 frames in flight; planes stay on the device except in *_to_host_rgb8, which adds "
-                       "the XYB->sRGB->u8 pass and the asynchronous D2H of the interleaved image into pinned memory")
+        e2e["note"] = ("pinned host coefficients -> H2D on 2 slot streams -> (pair forms: device unpack / sort; slot-bucketed "
+                       "forms: nothing, the transforms read the upload in place) -> K0b/K3/K1/filters; two contexts, each "
+                       "streaming its frames behind jxlh_ctx_mark / jxlh_ctx_wait_mark (the host waits for a context's "
+                       "previous frame, not for the one it has just enqueued) and starting its upload when the other "
+                       "context's has landed (jxlh_slot_wait); planes stay on the device except in "
+                       "*_to_host_rgb8, which adds the XYB->sRGB->u8 pass and the asynchronous D2H of the interleaved image "
+                       "into pinned memory")
         for c in ectx:
             c.close()
 

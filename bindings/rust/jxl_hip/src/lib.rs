@@ -84,6 +84,17 @@ impl Context {
     pub fn sync(&self) -> Result<()> {
         self.ok(unsafe { sys::jxlh_ctx_sync(self.raw) })
     }
+    /// a point in the context's stream: everything enqueued so far (`jxlh_ctx_mark`)
+    pub fn mark(&self) -> Result<u32> {
+        let mut m = 0u32;
+        self.ok(unsafe { sys::jxlh_ctx_mark(self.raw, &mut m) })?;
+        Ok(m)
+    }
+    /// blocks until `mark` has been reached -- not for work enqueued after it: a decoder streaming frames through one
+    /// context waits for frame i's mark after it has submitted and enqueued frame i + 1
+    pub fn wait_mark(&self, mark: u32) -> Result<()> {
+        self.ok(unsafe { sys::jxlh_ctx_wait_mark(self.raw, mark) })
+    }
     /// pinned host memory for coefficient slabs / pair lists (replaces `VarDctBuffers::coeffs_storage`)
     pub fn alloc_pinned(&self, bytes: usize) -> Result<PinnedBuf<'_>> {
         let mut p: *mut c_void = std::ptr::null_mut();

@@ -302,6 +302,16 @@ jxlh_status jxlh_frame_run(jxlh_ctx* ctx, uint32_t group_row0, uint32_t group_ro
 jxlh_status jxlh_frame_rerender_groups(jxlh_ctx* ctx, const uint32_t* group_ids, uint32_t count);
 /* blocks until the main stream is idle */
 jxlh_status jxlh_ctx_sync(jxlh_ctx* ctx);
+/* A point in the context's main stream: everything enqueued so far (frame runs, asynchronous reads).
+ * jxlh_ctx_wait_mark blocks until that point has been reached and -- unlike jxlh_ctx_sync -- not for work enqueued after
+ * the mark.  That is what lets ONE context stream consecutive frames (round 5: the slot-bucketed submission of frame
+ * i + 1 no longer waits for frame i's transforms): submit frame i + 1 (its upload runs under frame i's kernels),
+ * jxlh_frame_run, jxlh_frame_read_*_async, mark; then wait for the mark of frame i, whose output is complete.  Up to
+ * JXLH_MAX_MARKS marks are alive at a time; waiting for an older one waits for the mark that replaced it.  Device-side
+ * errors (JXLH_ERR_INVALID_TRANSFORM ...) are reported by jxlh_ctx_sync only. */
+#define JXLH_MAX_MARKS 8
+jxlh_status jxlh_ctx_mark(jxlh_ctx* ctx, uint32_t* mark);
+jxlh_status jxlh_ctx_wait_mark(jxlh_ctx* ctx, uint32_t mark);
 /* Copies the finished planes out (host or device destination).  Replaces the save stage for
  * f32 XYB output; xsize x ysize samples per plane. */
 jxlh_status jxlh_frame_read_planes(jxlh_ctx* ctx, const jxlh_plane out[3]);

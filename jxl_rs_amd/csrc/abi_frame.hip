@@ -167,6 +167,8 @@ void jxlh_ctx_destroy(jxlh_ctx* ctx) {
     if (ctx->se_read[i]) (void)hipEventDestroy(ctx->se_read[i]);
   }
   release(ctx->group_dense);
+  for (auto& e : ctx->marks)
+    if (e) (void)hipEventDestroy(e);
   if (ctx->sp_expanded) (void)hipEventDestroy(ctx->sp_expanded);
   if (ctx->k1_done) (void)hipEventDestroy(ctx->k1_done);
   comm_release(ctx);
@@ -1207,6 +1209,27 @@ jxlh_status jxlh_frame_read_extra_channel(jxlh_ctx* ctx, uint32_t ec, const jxlh
                               (size_t)e.out_w * sizeof(float), e.out_h, ctx->stream))
     return st;
   return jxlh_ctx_sync(ctx);
+}
+
+jxlh_status jxlh_ctx_mark(jxlh_ctx* ctx, uint32_t* mark) {
+  JXLH_ON_DEVICE(ctx);
+  if (!ctx || !mark) return JXLH_ERR_INVALID_ARGUMENT;
+  const uint32_t seq = ++ctx->mark_seq;
+  hipEvent_t& e = ctx->marks[seq % JXLH_MAX_MARKS];
+  if (!e) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  HIPCHK(ctx, hipEventRecord(e, ctx->stream));
+  *mark = seq;
+  return JXLH_OK;
+}
+
+jxlh_status jxlh_ctx_wait_mark(jxlh_ctx* ctx, uint32_t mark) {
+  JXLH_ON_DEVICE(ctx);
+  if (!ctx || mark == 0 || (int32_t)(ctx->mark_seq - mark) < 0) return JXLH_ERR_INVALID_ARGUMENT;  // never handed out
+  // (a mark older than the ring: its slot holds a later point of the stream -- waiting for that one is sufficient)
+  hipEvent_t e = ctx->marks[mark % JXLH_MAX_MARKS];
+  if (!e) return JXLH_ERR_BAD_STATE;
+  HIPCHK(ctx, hipEventSynchronize(e));
+  return JXLH_OK;
 }
 
 jxlh_status jxlh_ctx_sync(jxlh_ctx* ctx) {

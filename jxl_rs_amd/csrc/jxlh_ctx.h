@@ -163,6 +163,9 @@ struct jxlh_ctx {
   DevBuf<int> strip_flags;
   bool strip_all_closed = true, strip_ran = false;
   int cu_count = 0;
+  // jxlh_ctx_mark / jxlh_ctx_wait_mark: a ring of events on the main stream
+  hipEvent_t marks[JXLH_MAX_MARKS] = {};
+  uint32_t mark_seq = 0;
   // profiling
   bool timing = false;
   std::vector<KernelTime> ktimes;

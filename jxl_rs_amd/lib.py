@@ -41,7 +41,7 @@ ABI_SYMBOLS = [
     "jxlh_frame_set_lf_quantized", "jxlh_frame_set_lf", "jxlh_frame_set_hf_meta", "jxlh_submit_group",
     "jxlh_submit_group_sparse", "jxlh_submit_groups_sparse", "jxlh_submit_groups_sparse8", "jxlh_submit_groups_sparse4",
     "jxlh_submit_groups_slots", "jxlh_slot_wait",
-    "jxlh_frame_coeff_buffer", "jxlh_frame_run", "jxlh_ctx_sync", "jxlh_frame_read_planes",
+    "jxlh_frame_coeff_buffer", "jxlh_frame_run", "jxlh_ctx_sync", "jxlh_ctx_mark", "jxlh_ctx_wait_mark", "jxlh_frame_read_planes",
     "jxlh_frame_read_planes_rect", "jxlh_frame_read_planes_rect_async",
     "jxlh_frame_device_planes", "jxlh_frame_set_extra_channel", "jxlh_frame_read_extra_channel", "jxlh_frame_read_lf", "jxlh_frame_read_rgb8", "jxlh_frame_read_rgb8_async",
     "jxlh_frame_read_rgb16", "jxlh_frame_read_ycbcr_rgb8", "jxlh_frame_read_ycbcr_rgb16", "jxlh_frame_read_output",
@@ -162,6 +162,9 @@ def load():
     L.jxlh_frame_coeff_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
     L.jxlh_frame_run.argtypes = [vp, u32, u32]
     L.jxlh_ctx_sync.argtypes = [vp]
+    if hasattr(L, "jxlh_ctx_mark"):  # absent from older builds used in A/B runs (JXLH_LIBRARY)
+        L.jxlh_ctx_mark.argtypes = [vp, C.POINTER(u32)]
+        L.jxlh_ctx_wait_mark.argtypes = [vp, u32]
     L.jxlh_frame_read_planes.argtypes = [vp, C.POINTER(Plane)]
     L.jxlh_frame_read_planes_rect.argtypes = [vp, u32, u32, u32, u32, C.POINTER(Plane)]
     L.jxlh_frame_read_planes_rect_async.argtypes = [vp, u32, u32, u32, u32, C.POINTER(Plane)]
@@ -518,6 +521,16 @@ class Context:
     def sync(self):
         self._chk(self.L.jxlh_ctx_sync(self._ctx), "ctx_sync")
         self._keep.clear()
+
+    def mark(self):
+        """a point in the main stream (jxlh_ctx_mark): everything enqueued so far"""
+        m = C.c_uint32(0)
+        self._chk(self.L.jxlh_ctx_mark(self._ctx, C.byref(m)), "ctx_mark")
+        return m.value
+
+    def wait_mark(self, mark):
+        """blocks until that point is reached -- not for work enqueued after it (jxlh_ctx_wait_mark)"""
+        self._chk(self.L.jxlh_ctx_wait_mark(self._ctx, mark), "ctx_wait_mark")
 
     def probe_copy_bandwidth(self, nbytes, reps=10):
         """GB/s (read + written) of a float4 device-to-device copy of nbytes"""

@@ -238,6 +238,45 @@ def test_slots_argument_errors_leave_the_epoch_intact(ctx, oracle):
     check(ctx, oracle_frame(oracle, wl, wl.coeffs), "after a rejected call")
 
 
+def test_frames_streamed_through_one_context_behind_marks(ctx, oracle):
+    """jxlh_ctx_mark / jxlh_ctx_wait_mark: consecutive frames through ONE context -- frame i + 1 is submitted (slot-bucketed:
+    its upload does not wait for frame i) and enqueued before the host waits for frame i's mark; every frame's planes,
+    copied out asynchronously behind its kernels, must be that frame's"""
+    import ctypes as C
+    from jxl_rs_amd import synth, lib, JxlHipError
+    from jxl_rs_amd.lib import Plane
+    wl = synth.make_vardct(520, 300, mix=synth.MIX_D1, seed=71, epf_iters=2)
+    begin(ctx, wl)
+    ng = wl.coeffs.shape[0]
+    rng = np.random.default_rng(5)
+    frames = []
+    for i in range(5):   # same maps, different coefficients per frame
+        keep = rng.random(wl.coeffs.shape) < 0.7
+        frames.append(np.where(keep, wl.coeffs, 0).astype(np.int32))
+    outs = [[np.zeros((wl.ysize, wl.xsize), np.float32) for _ in range(3)] for _ in frames]
+    marks = []
+    for i, cf in enumerate(frames):
+        ctx.submit_groups_slots(*_slots_batch(synth, cf, list(range(ng))), None, slot=i % 2)
+        ctx.frame_run()
+        planes = (Plane * 3)(*[Plane(o.ctypes.data, wl.xsize * 4, wl.ysize, wl.xsize * 4) for o in outs[i]])
+        ctx._chk(ctx.L.jxlh_frame_read_planes_rect_async(ctx._ctx, 0, 0, wl.xsize, wl.ysize, planes), "read_rect_async")
+        marks.append(ctx.mark())
+        if i >= 1:
+            ctx.wait_mark(marks[i - 1])
+            want = oracle_frame(oracle, wl, frames[i - 1])
+            for c in range(3):
+                assert bit_equal(outs[i - 1][c], want[c]), f"frame {i - 1}, plane {c}: {diff_report(outs[i - 1][c], want[c])}"
+    ctx.wait_mark(marks[-1])
+    want = oracle_frame(oracle, wl, frames[-1])
+    for c in range(3):
+        assert bit_equal(outs[-1][c], want[c])
+    assert marks == sorted(marks) and len(set(marks)) == len(marks)
+    ctx.wait_mark(marks[0])          # long reached: returns at once
+    with pytest.raises(JxlHipError):
+        ctx.wait_mark(marks[-1] + 100)  # never handed out
+    ctx.sync()
+
+
 def test_rerender_before_any_render_renders_the_frame(ctx, oracle):
     from jxl_rs_amd import synth
     wl = synth.make_vardct(300, 300, mix=synth.MIX_D1, seed=2, epf_iters=2)
