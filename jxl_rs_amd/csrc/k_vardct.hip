@@ -1000,30 +1000,39 @@ __device__ __forceinline__ int special_bin(int type) {  // 1, 2, 3, 12, 13, 14, 
 
 // one lane: its block's 64 coefficients into registers, pixels written over them
 template <int TYPE>
-__device__ __forceinline__ void special_8x8_inplace(float* __restrict__ row) {
+__device__ __forceinline__ void special_8x8_inplace(float* __restrict__ row, const float* __restrict__ afv_basis = kAfvBasisDev) {
   float c[64], o[64];
 #pragma unroll
   for (int i = 0; i < 64; i++) c[i] = row[i];
-  special_8x8_t<TYPE>(c, o);
+  special_8x8_t<TYPE>(c, o, afv_basis);
 #pragma unroll
   for (int i = 0; i < 64; i++) row[i] = o[i];
 }
 
+// BIN0 .. BIN1: the type bins one instantiation handles.  Round 5: two launches -- IDENTITY / DCT2X2 / DCT4X4 / DCT4X8 /
+// DCT8X4 (bins 0-4) and AFV0-3 (bins 5-8) -- instead of one: the kernel's registers are the maximum over its bodies, and
+// the AFV bodies (a 16 x 16 basis product on top of the 4x4 and 4x8 transforms) set it for everybody (230 VGPRs, 355
+// spilled SGPRs, two waves per SIMD).
+template <int BIN0, int BIN1>
 __global__ __launch_bounds__(kSpecThreads) void k1_special(const FrameDev f, const WorkLists wl) {
   __shared__ float s_tile[kSpecWaves][64 * kSpecPitch];
   __shared__ BlockInfo s_binfo[kSpecWaves][kSpecBlk];
   __shared__ int s_idx[kSpecWaves][kSpecChunk];
   __shared__ AdjTable s_adj;
-  build_adj_table(f, &s_adj, threadIdx.x, kSpecThreads);
+  __shared__ float s_afv[BIN1 > 5 ? 256 : 1];  // the AFV basis (bins 5-8 only)
+  if constexpr (BIN1 > 5)
+    for (int i = threadIdx.x; i < 256; i += kSpecThreads) s_afv[i] = kAfvBasisDev[i];
+  build_adj_table(f, &s_adj, threadIdx.x, kSpecThreads);  // (ends with a workgroup barrier)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const WorkItem* __restrict__ items = wl.items[kClsSpecial];
   const int count = wl.counts[(kClsSpecial) * kCountPitch];
   float* tile = s_tile[wave];
   BlockInfo* binfo = s_binfo[wave];
   int* mine = s_idx[wave];
-  const int npairs = ((count + kSpecChunk - 1) / kSpecChunk) * kSpecBins;
+  constexpr int kBins = BIN1 - BIN0;
+  const int npairs = ((count + kSpecChunk - 1) / kSpecChunk) * kBins;
   for (int pair = blockIdx.x * kSpecWaves + wave; pair < npairs; pair += gridDim.x * kSpecWaves) {
-    const int chunk = pair / kSpecBins, bin = pair % kSpecBins;
+    const int chunk = pair / kBins, bin = BIN0 + pair % kBins;
     // ---- this wave's items of the chunk: the ones whose type falls in `bin`
     int nmine = 0;
     uint32_t packed[kSpecChunk / 64];
@@ -1107,17 +1116,17 @@ __global__ __launch_bounds__(kSpecThreads) void k1_special(const FrameDev f, con
       if (on) {
         float* row = tile + lane * kSpecPitch;  // lane == tch * kSpecBlk + tb
         row[0] = lf0;
-        switch (bin) {  // wave-uniform
-          case 0: special_8x8_inplace<1>(row); break;
-          case 1: special_8x8_inplace<2>(row); break;
-          case 2: special_8x8_inplace<3>(row); break;
-          case 3: special_8x8_inplace<12>(row); break;
-          case 4: special_8x8_inplace<13>(row); break;
-          case 5: special_8x8_inplace<14>(row); break;
-          case 6: special_8x8_inplace<15>(row); break;
-          case 7: special_8x8_inplace<16>(row); break;
-          default: special_8x8_inplace<17>(row); break;
-        }
+        auto in_range = [](int b) { return b >= BIN0 && b < BIN1; };
+        // (wave-uniform; only the bodies of this instantiation's bins are compiled in)
+        if (in_range(0) && bin == 0) special_8x8_inplace<1>(row);
+        if (in_range(1) && bin == 1) special_8x8_inplace<2>(row);
+        if (in_range(2) && bin == 2) special_8x8_inplace<3>(row);
+        if (in_range(3) && bin == 3) special_8x8_inplace<12>(row);
+        if (in_range(4) && bin == 4) special_8x8_inplace<13>(row);
+        if (in_range(5) && bin == 5) special_8x8_inplace<14>(row, s_afv);
+        if (in_range(6) && bin == 6) special_8x8_inplace<15>(row, s_afv);
+        if (in_range(7) && bin == 7) special_8x8_inplace<16>(row, s_afv);
+        if (in_range(8) && bin == 8) special_8x8_inplace<17>(row, s_afv);
       }
       wave_sync();
       // ---- store: gather first, then store: all stores of the lane issue back to back
@@ -1258,8 +1267,12 @@ void launch_vardct_groups(hipStream_t s, const FrameDev& f, int group_row0, int 
   if (sparse == 3) hipLaunchKernelGGL(k1_entries_fallback, dim3(std::min(512, std::max(1, nblk / 2048))), dim3(kThreads), 0, s, f, wl);
   // an empty special list (the d1 mix) pays for every launched workgroup: the grid follows the list's worst case
   if (has_special)
-    hipLaunchKernelGGL(k1_special, dim3(grid_for((long)(nblk / kSpecChunk + 1) * kSpecBins, kSpecWaves, 2048)),
+  {
+    hipLaunchKernelGGL((k1_special<0, 5>), dim3(grid_for((long)(nblk / kSpecChunk + 1) * 5, kSpecWaves, 2048)),
                        dim3(kSpecThreads), 0, s, f, wl);
+    hipLaunchKernelGGL((k1_special<5, 9>), dim3(grid_for((long)(nblk / kSpecChunk + 1) * 4, kSpecWaves, 2048)),
+                       dim3(kSpecThreads), 0, s, f, wl);
+  }
   // (the large transforms on a side stream next to the memory-bound DCT classes, one workgroup per CU: K1 of the 16K
   // all-types frame 1.872 -> 1.847 ms, 1.937 with their usual two per CU -- inside the noise, not kept)
   if (has_large) launch_vardct_large(s, f, wl, nblk, large_units, large_unit_capacity(nblocks), nblocks);

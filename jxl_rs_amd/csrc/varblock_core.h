@@ -269,8 +269,11 @@ __device__ __forceinline__ void idct2_top_block(const float* in, float* out) {
 // TYPE in {1,2,3,12,13,14..17}; c = this block's 64 coefficients (c[0] already = lf),
 // o = this block's 64 output pixels.  c may be clobbered.  Every index is a compile-time
 // constant after unrolling, so c/o may be register arrays (k1_special) as well as LDS rows.
+// afv_basis: where the AFV bodies read the 16 x 16 basis from -- the constant table (scalar loads: 256 values against
+// ~100 scalar registers, the compiler spills 350 of them in k1_special) or a copy in LDS (broadcast reads, round 5)
 template <int TYPE>
-__device__ __forceinline__ void special_8x8_t(float* __restrict__ c, float* __restrict__ o) {
+__device__ __forceinline__ void special_8x8_t(float* __restrict__ c, float* __restrict__ o,
+                                              const float* __restrict__ afv_basis = kAfvBasisDev) {
   if constexpr (TYPE == 1) {  // IDENTITY (Hornuss)
     const float b00 = c[0], b01 = c[1], b10 = c[8], b11 = c[9];
     const float dcs[4] = {b00 + b01 + b10 + b11, b00 + b01 - b10 - b11, b00 - b01 + b10 - b11,
@@ -381,9 +384,11 @@ __device__ __forceinline__ void special_8x8_t(float* __restrict__ c, float* __re
           coeff[iy * 4 + ix] = (ix == 0 && iy == 0) ? dcs[0] : c[iy * 2 * 8 + ix * 2];
 #pragma unroll
       for (int i = 0; i < 16; i++) {
+        // (keeps the 16 basis values of output i next to their use: hoisted, the 256 of them take every register)
+        asm volatile("" ::: "memory");
         float pixel = 0.0f;
 #pragma unroll
-        for (int j = 0; j < 16; j++) pixel += coeff[j] * kAfvBasisDev[j * 16 + i];
+        for (int j = 0; j < 16; j++) pixel += coeff[j] * afv_basis[j * 16 + i];
         const int iy = i / 4, ix = i % 4;
         const int py = afv_y == 1 ? 3 - iy : iy;
         const int px = afv_x == 1 ? 3 - ix : ix;
