@@ -1410,6 +1410,82 @@ def test_entries_form_direct_path_and_its_fallbacks(ctx, oracle, mix, size, dens
                 assert bit_equal(got[c], want[c]), f"{what}, run {run}, plane {c}: {diff_report(got[c], want[c])}"
 
 
+@pytest.mark.parametrize("dense_dequant", [False, True])
+def test_slot_counts_that_disagree_with_the_run_length(ctx, dense_dequant):
+    """a caller's mistake must stay inside its own run: a slot-count table that claims MORE entries than n says is cut at the
+    run's end, entries the table does not account for are ignored -- in the direct path, in the dense pass, and when the
+    group is widened into pair words (mixed epoch).  Expected result: the frame of the entries the table does cover."""
+    from jxl_rs_amd import synth
+    from jxl_rs_amd import lib as jl
+    wl = synth.make_vardct(512, 256, mix=synth.MIX_D1, seed=77, epf_iters=0, gab=False)   # two groups
+    ents, cnts, ns = [], [], []
+    truth = wl.coeffs.copy()
+    for g in range(2):
+        e, c, n, wide = synth.to_slots(wl.coeffs[g])
+        assert len(wide) == 0
+        ents.append(e); cnts.append(c.copy()); ns.append(n.copy())
+    # group 0, channel 1 (Y): n is 10 short of what the table says -> the last 10 entries of the run are not there
+    cut = 10
+    off_y = int(ns[0][0])
+    e0 = np.concatenate([ents[0][:off_y + int(ns[0][1]) - cut], ents[0][off_y + int(ns[0][1]):]])
+    n0 = ns[0].copy(); n0[1] -= cut
+    # ... which are the last entries in slot order: zero them in the expected coefficients
+    pos = np.flatnonzero(truth[0, 1])
+    truth[0, 1, pos[-cut:]] = 0
+    # group 1, channel 0 (X): the table covers 7 entries fewer than n (its last non-empty slots are short): they are ignored
+    c1 = cnts[1].copy()
+    short, s_ = 7, 1023
+    posx = np.flatnonzero(truth[1, 0])
+    dropped = 0
+    while dropped < short:
+        while c1[0, s_] == 0:
+            s_ -= 1
+        c1[0, s_] -= 1
+        dropped += 1
+    # entries of a slot are in position order (np.flatnonzero): a shorter count keeps the slot's FIRST entries; every later
+    # slot then reads shifted entries -- so shorten only from the tail: the dropped ones are the run's last entries per slot.
+    # Simplest exact expectation: rebuild the coefficients the device will see from (entries, counts) in numpy.
+    def rebuild(e, c, n):
+        out = np.zeros((3, 65536), np.int32)
+        o = 0
+        for ch in range(3):
+            run = e[o:o + int(n[ch])]
+            o += int(n[ch])
+            k = 0
+            for s in range(1024):
+                take = run[k:k + int(c[ch, s])]      # cut at the run's end by the slice
+                k += int(c[ch, s])
+                v = (take.astype(np.int32) << 16 >> 22)
+                np.add.at(out[ch], s * 64 + (take & 63).astype(np.int64), v)
+        return out
+    want_coeffs = np.stack([rebuild(e0, cnts[0], n0), rebuild(ents[1], c1, ns[1])])
+    assert not np.array_equal(want_coeffs, wl.coeffs)
+    wl2 = wl
+    saved = wl.coeffs
+    wl2.coeffs = want_coeffs
+    want, _ = run_gpu_frame(ctx, wl2)
+    wl.coeffs = saved
+    for mixed in (False, True):
+        p = gpu_params_from(ctx, wl)
+        p.flags = jl.FRAME_DENSE_DEQUANT if dense_dequant else 0
+        ctx.frame_begin(p)
+        ctx.set_dequant_tables(wl.tables)
+        ctx.set_lf_quantized(*wl.lf_q)
+        ctx.set_hf_meta(wl.transform_map, wl.raw_quant, wl.epf_map, wl.ytox, wl.ytob)
+        if mixed:   # group 1 as plain pairs of the same (already shortened) coefficients: group 0 is widened into pair words
+            ctx.submit_groups_slots(np.uint32([0]), e0, cnts[0].reshape(-1), n0, None)
+            ctx.submit_group_sparse(1, *synth.to_sparse(want_coeffs[1]))
+        else:
+            ctx.submit_groups_slots(np.uint32([0, 1]), np.concatenate([e0, ents[1]]),
+                                    np.concatenate([cnts[0].reshape(-1), c1.reshape(-1)]), np.concatenate([n0, ns[1]]), None)
+        ctx.slot_wait(0)
+        ctx.frame_run()
+        ctx.sync()
+        got = ctx.read_planes()
+        for c in range(3):
+            assert bit_equal(got[c], want[c]), f"mixed={mixed}, plane {c}: {diff_report(got[c], want[c])}"
+
+
 def test_sparse_submit_argument_errors(ctx):
     from jxl_rs_amd import synth
     from jxl_rs_amd.lib import JxlHipError
