@@ -67,6 +67,30 @@ def _apply_arrays(p, arrays):
             field[i] = float(v)
 
 
+def _submit_rotating(ctx, synth, wl, seed):
+    """the three submission forms take turns: dense slabs, (position, value) pairs (device sort, the transforms read the
+    bucketed pairs), slot-bucketed entries (read in place: direct dequantisation, fallback list, dense route for values
+    beyond 10 bits)"""
+    ng = wl.coeffs.shape[0]
+    if seed % 3 == 0:
+        for g in range(ng):
+            ctx.submit_group(g, wl.coeffs[g])
+    elif seed % 3 == 1:
+        for g in range(ng):
+            ctx.submit_group_sparse(g, *synth.to_sparse(wl.coeffs[g]))
+    else:
+        parts = [synth.to_slots(wl.coeffs[g]) for g in range(ng)]
+        wide = []
+        for g, q in enumerate(parts):
+            if len(q[3]):
+                e = q[3].copy()
+                e[:, 0] += np.uint32(g * 3 * 65536)
+                wide.append(e)
+        ctx.submit_groups_slots(np.arange(ng, dtype=np.uint32), np.concatenate([q[0] for q in parts]),
+                                np.concatenate([q[1].reshape(-1) for q in parts]), np.concatenate([q[2] for q in parts]),
+                                np.concatenate(wide) if wide else None)
+
+
 @pytest.mark.parametrize("seed", range(64))
 def test_random_frames_and_header_parameters_bit_exact(ctx, oracle, kat, seed):
     from jxl_rs_amd import synth
@@ -88,17 +112,13 @@ def test_random_frames_and_header_parameters_bit_exact(ctx, oracle, kat, seed):
     ctx.set_dequant_tables(wl.tables)
     ctx.set_lf_quantized(*wl.lf_q)
     ctx.set_hf_meta(wl.transform_map, wl.raw_quant, wl.epf_map, wl.ytox, wl.ytob)
-    for g in range(wl.coeffs.shape[0]):
-        if seed % 2:
-            ctx.submit_group_sparse(g, *synth.to_sparse(wl.coeffs[g]))
-        else:
-            ctx.submit_group(g, wl.coeffs[g])
+    _submit_rotating(ctx, synth, wl, seed)
     ctx.slot_wait(0)
     ctx.frame_run()
     ctx.sync()
     got = ctx.read_planes()
     got_lf = ctx.read_lf()
-    desc = f"{w}x{h} {opts} {sorted(over)} {sorted(arrays)}"
+    desc = f"{w}x{h} {opts} {sorted(over)} {sorted(arrays)} form {seed % 3}"
     for c in range(3):
         assert bit_equal(got_lf[c], lf_sm[c]), f"LF ch{c} {desc}: {diff_report(got_lf[c], lf_sm[c])}"
         assert bit_equal(got[c], want[c]), f"plane {c} {desc}: {diff_report(got[c], want[c])}"
@@ -139,17 +159,13 @@ def test_random_subsampled_frames_bit_exact(ctx, oracle, seed):
     ctx.set_dequant_tables(wl.tables)
     ctx.set_lf_quantized(*wl.lf_q)
     ctx.set_hf_meta(wl.transform_map, wl.raw_quant, wl.epf_map, wl.ytox, wl.ytob)
-    for g in range(wl.coeffs.shape[0]):
-        if seed % 2:
-            ctx.submit_group_sparse(g, *synth.to_sparse(wl.coeffs[g]))
-        else:
-            ctx.submit_group(g, wl.coeffs[g])
+    _submit_rotating(ctx, synth, wl, seed)
     ctx.slot_wait(0)
     ctx.frame_run()
     ctx.sync()
     got = ctx.read_planes()
     got_lf = ctx.read_lf()
-    desc = f"{w}x{h} h{hs} v{vs} {opts} {sorted(over)} {sorted(arrays)}"
+    desc = f"{w}x{h} h{hs} v{vs} {opts} {sorted(over)} {sorted(arrays)} form {seed % 3}"
     for c in range(3):
         assert bit_equal(got_lf[c], lf_sm[c]), f"LF ch{c} {desc}: {diff_report(got_lf[c], lf_sm[c])}"
         assert bit_equal(got[c], want[c]), f"plane {c} {desc}: {diff_report(got[c], want[c])}"
