@@ -282,6 +282,12 @@ jxlh_status jxlh_submit_groups_slots(jxlh_ctx* ctx, int32_t slot, uint32_t count
                                      const uint16_t* entries, const uint8_t* slot_counts, const uint32_t* n,
                                      const jxlh_coeff32* wide, uint32_t n_wide, uint32_t flags);
 jxlh_status jxlh_slot_wait(jxlh_ctx* ctx, int32_t slot);
+/* Orders uploads ACROSS contexts on the device: whatever is submitted on (ctx, slot) after this call starts when the
+ * uploads enqueued so far on (after_ctx, after_slot) have landed -- the device-side form of "jxlh_slot_wait(after_ctx,
+ * after_slot), then submit", without blocking the host.  Two contexts that stream frames keep the bus busy back to back
+ * and stay in anti-phase (one uploads while the other computes) whatever the host's latency is (round 5,
+ * profiles/r05_f_e2e_host_loops.txt).  Both contexts must live on the same device. */
+jxlh_status jxlh_slot_after(jxlh_ctx* ctx, int32_t slot, jxlh_ctx* after_ctx, int32_t after_slot);
 
 /* Device-resident coefficient store of the current frame (ngroups * 3 * 65536 i32), for callers
  * that already hold coefficients in HBM (bench harness, multi-GPU shards). */

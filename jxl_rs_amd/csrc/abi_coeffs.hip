@@ -328,6 +328,17 @@ jxlh_status jxlh_slot_wait(jxlh_ctx* ctx, int32_t slot) {
   return JXLH_OK;
 }
 
+jxlh_status jxlh_slot_after(jxlh_ctx* ctx, int32_t slot, jxlh_ctx* after_ctx, int32_t after_slot) {
+  JXLH_ON_DEVICE(ctx);
+  if (!ctx || !after_ctx || slot < 0 || (size_t)slot >= ctx->slots.size() || after_slot < 0 ||
+      (size_t)after_slot >= after_ctx->slots.size() || ctx->device != after_ctx->device)
+    return JXLH_ERR_INVALID_ARGUMENT;
+  const Slot& a = after_ctx->slots[after_slot];
+  // (`done` is re-recorded by every submission on that slot: this waits for the latest one recorded so far)
+  if (a.used) HIPCHK(ctx, hipStreamWaitEvent(ctx->slots[slot].stream, a.done, 0));
+  return JXLH_OK;
+}
+
 jxlh_status jxlh_frame_coeff_buffer(jxlh_ctx* ctx, int32_t** device_ptr, size_t* n_int32) {
   JXLH_ON_DEVICE(ctx);
   if (!ctx || !device_ptr) return JXLH_ERR_INVALID_ARGUMENT;

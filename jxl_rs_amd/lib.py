@@ -40,7 +40,7 @@ ABI_SYMBOLS = [
     "jxlh_alloc_pinned", "jxlh_free_pinned", "jxlh_frame_begin", "jxlh_frame_set_dequant_tables",
     "jxlh_frame_set_lf_quantized", "jxlh_frame_set_lf", "jxlh_frame_set_hf_meta", "jxlh_submit_group",
     "jxlh_submit_group_sparse", "jxlh_submit_groups_sparse", "jxlh_submit_groups_sparse8", "jxlh_submit_groups_sparse4",
-    "jxlh_submit_groups_slots", "jxlh_slot_wait",
+    "jxlh_submit_groups_slots", "jxlh_slot_wait", "jxlh_slot_after",
     "jxlh_frame_coeff_buffer", "jxlh_frame_run", "jxlh_ctx_sync", "jxlh_ctx_mark", "jxlh_ctx_wait_mark", "jxlh_frame_read_planes",
     "jxlh_frame_read_planes_rect", "jxlh_frame_read_planes_rect_async",
     "jxlh_frame_device_planes", "jxlh_frame_set_extra_channel", "jxlh_frame_read_extra_channel", "jxlh_frame_read_lf", "jxlh_frame_read_rgb8", "jxlh_frame_read_rgb8_async",
@@ -162,6 +162,8 @@ def load():
     L.jxlh_frame_coeff_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
     L.jxlh_frame_run.argtypes = [vp, u32, u32]
     L.jxlh_ctx_sync.argtypes = [vp]
+    if hasattr(L, "jxlh_slot_after"):
+        L.jxlh_slot_after.argtypes = [vp, i32, vp, i32]
     if hasattr(L, "jxlh_ctx_mark"):  # absent from older builds used in A/B runs (JXLH_LIBRARY)
         L.jxlh_ctx_mark.argtypes = [vp, C.POINTER(u32)]
         L.jxlh_ctx_wait_mark.argtypes = [vp, u32]
@@ -505,6 +507,11 @@ class Context:
     def slot_wait(self, slot=0):
         self._chk(self.L.jxlh_slot_wait(self._ctx, slot), "slot_wait")
         self._keep.pop(slot, None)
+
+    def slot_after(self, slot, after_ctx, after_slot):
+        """submissions on (self, slot) from now on start when the uploads enqueued so far on (after_ctx, after_slot) have
+        landed (jxlh_slot_after): device-side ordering across contexts, the host does not block"""
+        self._chk(self.L.jxlh_slot_after(self._ctx, slot, after_ctx._ctx, after_slot), "slot_after")
 
     def coeff_buffer(self):
         p, n = C.c_void_p(), C.c_size_t()

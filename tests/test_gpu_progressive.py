@@ -272,6 +272,26 @@ def test_frames_streamed_through_one_context_behind_marks(ctx, oracle):
         assert bit_equal(outs[-1][c], want[c])
     assert marks == sorted(marks) and len(set(marks)) == len(marks)
     ctx.wait_mark(marks[0])          # long reached: returns at once
+    # jxlh_slot_after: device-side ordering of uploads across contexts (here: against itself and a second context)
+    from jxl_rs_amd import Context
+    other = Context(0, n_slots=1)
+    try:
+        ctx.slot_after(0, other, 0)      # nothing submitted there yet: a no-op
+        begin(other, wl)
+        other.submit_groups_slots(*_slots_batch(synth, frames[0], list(range(ng))), None)
+        ctx.slot_after(1, other, 0)      # slot 1 of ctx now starts behind other's upload
+        ctx.submit_groups_slots(*_slots_batch(synth, frames[1], list(range(ng))), None, slot=1)
+        other.frame_run(); ctx.frame_run()
+        other.sync(); ctx.sync()
+        for c_, f_ in ((other, frames[0]), (ctx, frames[1])):
+            got = c_.read_planes()
+            want = oracle_frame(oracle, wl, f_)
+            for ch in range(3):
+                assert bit_equal(got[ch], want[ch])
+        with pytest.raises(JxlHipError):
+            ctx.slot_after(9, other, 0)  # no such slot
+    finally:
+        other.close()
     with pytest.raises(JxlHipError):
         ctx.wait_mark(marks[-1] + 100)  # never handed out
     ctx.sync()

@@ -91,6 +91,26 @@ for lag in (1, 2):
             c.sync()
         res.append(round((time.perf_counter() - t0) / frames * 1e3, 3))
     out[f"contexts_2_serialised_uploads_lag_{lag}"] = res
+# the same ordering on the DEVICE (jxlh_slot_after): the host does not block between the contexts' uploads
+for lag in (1, 2):
+    res = []
+    for rep in range(5):
+        marks = [[] for _ in range(2)]
+        t0 = time.perf_counter()
+        for i in range(frames):
+            k = i % 2
+            c, o = ctxs[k], ctxs[1 - k]
+            for sl in range(NSLOTS):
+                for so in range(NSLOTS):
+                    c.slot_after(sl, o, so)
+            submit(c); c.frame_run()
+            marks[k].append(c.mark())
+            if len(marks[k]) > lag:
+                c.wait_mark(marks[k][-1 - lag])
+        for c in ctxs[:2]:
+            c.sync()
+        res.append(round((time.perf_counter() - t0) / frames * 1e3, 3))
+    out[f"contexts_2_device_ordered_uploads_lag_{lag}"] = res
 got = [float(np.asarray(p, dtype=np.float64).sum()) for p in ctxs[0].read_planes()]
 out["planes_identical_to_single_frame"] = got == want
 print(json.dumps(out))
