@@ -267,17 +267,24 @@ jxlh_status jxlh_submit_groups_sparse4(jxlh_ctx* ctx, int32_t slot, uint32_t cou
                                        const uint16_t* entries, const uint16_t* seg_counts, const uint16_t* pos8,
                                        const int8_t* val8, const uint32_t* n8, const jxlh_coeff32* wide,
                                        uint32_t n_wide, uint32_t flags);
-/* Slot-bucketed form (round 4): 2 bytes per update AND no device-side sort.  A channel's 65536 positions are 1024
- * SLOTS of 64 coefficients (the unit varblock coefficient offsets are counted in, frame/group.rs:612: an 8x8 block is
- * one slot, a 16x16 varblock four); an update is one u16 = (position & 63) | (value & 1023) << 6 with the value in
- * [-512, 511]; slot_counts[(i * 3 + c) * 1024 + s] (u8) says how many updates group i, channel c, slot s has and
- * `entries` holds them in that order, any order inside a slot; n[3 * i + c] = the channel's total.  A decoder appends
- * to the slot buckets of the varblock it is decoding and flushes them when the varblock ends.  When EVERY group of the
- * frame arrives in this form, jxlh_frame_run finds the pairs already bucketed the way the transforms read them and
- * skips the sort (and any copy: the pair buffer becomes the store the transforms read); values outside 10 bits go to
- * `wide` (and take the dense route like any wide entry).  The call may be issued for the NEXT frame while the previous
- * jxlh_frame_run is still executing: its host-to-device copies start at once, only the device-side unpacking waits for
- * the previous frame's transforms. */
+/* Slot-bucketed form: 2 bytes per update, read by the transforms IN PLACE (round 5: no device-side sort, no unpacking
+ * pass, no slot tables).  A channel's 65536 positions are 1024 SLOTS of 64 coefficients (the unit varblock coefficient
+ * offsets are counted in, frame/group.rs:612: an 8x8 block is one slot, a 16x16 varblock four); an update is one u16 =
+ * (position & 63) | (value & 1023) << 6 with the value in [-512, 511]; slot_counts[(i * 3 + c) * 1024 + s] (u8) says how
+ * many updates group i, channel c, slot s has and `entries` holds them in that order, any order inside a slot;
+ * n[3 * i + c] = the channel's total.  A decoder appends to the slot buckets of the varblock it is decoding and flushes
+ * them when the varblock ends (frame/group.rs:557-575).  Positions may repeat (several passes' updates in one list): they
+ * add up as integers before the dequantisation, like `coeffs[i] += v`.  A slot-count table that disagrees with n stays
+ * inside its run: counts beyond n are cut at the run's end, entries the table does not cover are ignored.
+ *   When EVERY group of the frame arrives in this form (and nothing is added to earlier passes), jxlh_frame_run reads the
+ * upload as it is: the transforms dequantise only the positions that have an entry (everything else is the +0.0f the
+ * reference computes for a zero coefficient; varblocks with far more entries than d1 content has, or raw_quant == 0, take
+ * a dense dequantisation pass -- same bits, see JXLH_FRAME_DENSE_DEQUANT).  The uploads land in a second set of buffers:
+ * the call may be issued for the NEXT frame while the previous jxlh_frame_run is still executing and waits for nothing
+ * of it (jxlh_ctx_mark / jxlh_ctx_wait_mark is the host loop for that).  Other cases -- a group of the epoch in another
+ * form, a value outside 10 bits (`wide`), JXLH_GROUP_ACCUMULATE -- widen the slot-bucketed groups into pair words on the
+ * device and take the general route (sort, or zero-fill + scatter into dense slabs).
+ *   JXLH_ERR_INVALID_ARGUMENT is returned before anything is reserved (a rejected call leaves the epoch as it was). */
 jxlh_status jxlh_submit_groups_slots(jxlh_ctx* ctx, int32_t slot, uint32_t count, const uint32_t* group_ids,
                                      const uint16_t* entries, const uint8_t* slot_counts, const uint32_t* n,
                                      const jxlh_coeff32* wide, uint32_t n_wide, uint32_t flags);
