@@ -1646,7 +1646,7 @@ def test_rgb8_output_argument_errors(ctx, oracle, kat):
         ctx.read_rgb8(params, 3, 10, 10)  # empty row range
 
 
-@pytest.mark.parametrize("form", ["dense", "sparse", "mixed"])
+@pytest.mark.parametrize("form", ["dense", "sparse", "mixed", "slots", "mixed_slots"])
 def test_concurrent_submission_from_host_threads(oracle, form):
     """jxlh_ctx_create's n_slots = the number of host threads that call jxlh_submit_group* concurrently (the
     JxlParallelRunner's threads, jxl/src/api/mod.rs:77-81): six threads, one slot each, submit the groups of a frame at
@@ -1668,15 +1668,27 @@ def test_concurrent_submission_from_host_threads(oracle, form):
             ctx.set_lf_quantized(*wl.lf_q)
             ctx.set_hf_meta(wl.transform_map, wl.raw_quant, wl.epf_map, wl.ytox, wl.ytob)
             ng = wl.coeffs.shape[0]
-            sparse = {g: synth.to_sparse(wl.coeffs[g]) for g in range(ng)} if form != "dense" else {}
+            sparse = {g: synth.to_sparse(wl.coeffs[g]) for g in range(ng)} if form in ("sparse", "mixed", "mixed_slots") else {}
+            slotted = {g: synth.to_slots(wl.coeffs[g]) for g in range(ng)} if form in ("slots", "mixed_slots") else {}
             errors = []
             start = threading.Barrier(nthreads)
 
             def worker(t):
                 try:
                     start.wait()
-                    for g in range(t, ng, nthreads):
-                        use_sparse = form == "sparse" or (form == "mixed" and (g + rep) % 2 == 0)
+                    mine = list(range(t, ng, nthreads))
+                    if form == "slots" or (form == "mixed_slots" and (t + rep) % 2 == 0):
+                        # one slot-bucketed batch per thread (every thread's groups: the whole frame arrives this way in
+                        # "slots"; half of the threads in "mixed_slots", whose frame then takes the general route)
+                        qs = [slotted[g] for g in mine]
+                        assert all(len(q[3]) == 0 for q in qs)
+                        if mine:
+                            ctx.submit_groups_slots(np.asarray(mine, dtype=np.uint32), np.concatenate([q[0] for q in qs]),
+                                                    np.concatenate([q[1].reshape(-1) for q in qs]),
+                                                    np.concatenate([q[2] for q in qs]), None, slot=t)
+                        mine = []
+                    for g in mine:
+                        use_sparse = form in ("sparse", "mixed_slots") or (form == "mixed" and (g + rep) % 2 == 0)
                         if use_sparse:
                             ctx.submit_group_sparse(g, *sparse[g], slot=t)
                         else:
