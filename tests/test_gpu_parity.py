@@ -192,6 +192,33 @@ def test_band_runs_equal_whole_frame(ctx, oracle, epf_iters):
                 assert bit_equal(got[c][y0:y1], want[c][y0:y1]), (flags, row0, row1, c, diff_report(got[c][y0:y1], want[c][y0:y1]))
 
 
+@pytest.mark.parametrize("mix", ["MIX_D1", "MIX_ALL"])
+def test_band_runs_of_a_slot_resident_frame(ctx, oracle, mix):
+    """the same band runs on a frame resident in the slot-bucketed form (the transforms read the entries of the band's
+    groups and its halo group rows; groups with special / large varblocks get their dense slab from the entries)"""
+    from jxl_rs_amd import synth
+    wl = synth.make_vardct(520, 700, mix=getattr(synth, mix), seed=33, epf_iters=2)
+    want, _ = run_oracle_frame(oracle, wl)
+    p = gpu_params_from(ctx, wl)
+    ctx.frame_begin(p)
+    ctx.set_dequant_tables(wl.tables)
+    ctx.set_lf_quantized(*wl.lf_q)
+    ctx.set_hf_meta(wl.transform_map, wl.raw_quant, wl.epf_map, wl.ytox, wl.ytob)
+    ng = wl.coeffs.shape[0]
+    parts = [synth.to_slots(wl.coeffs[g]) for g in range(ng)]
+    assert all(len(q[3]) == 0 for q in parts)
+    ctx.submit_groups_slots(np.arange(ng, dtype=np.uint32), np.concatenate([q[0] for q in parts]),
+                            np.concatenate([q[1].reshape(-1) for q in parts]), np.concatenate([q[2] for q in parts]), None)
+    ctx.slot_wait(0)
+    for row0, row1 in ((0, 1), (1, 2), (2, 3), (1, 3), (0, 3)):
+        ctx.frame_run(row0, row1)
+        ctx.sync()
+        got = ctx.read_planes()
+        y0, y1 = row0 * 256, min(row1 * 256, wl.ysize)
+        for c in range(3):
+            assert bit_equal(got[c][y0:y1], want[c][y0:y1]), (row0, row1, c, diff_report(got[c][y0:y1], want[c][y0:y1]))
+
+
 def test_invalid_transform_id_is_reported(ctx):
     from jxl_rs_amd import synth, JxlHipError
     from jxl_rs_amd import lib
