@@ -994,8 +994,9 @@ def main():
             submit_sparse(c); c.frame_run()
         for c in ectx:
             c.sync()
-        e2e["sparse_resident_no_pcie"] = resident_leg()
-        e2e["sparse_resident_no_pcie"]["form"] = "bucketed {u16 pos; i16 val} pair words + slot tables (device sort)"
+        e2e["pairs_resident_no_pcie"] = resident_leg()
+        e2e["pairs_resident_no_pcie"]["form"] = ("bucketed {u16 pos; i16 val} pair words + slot tables (device sort): what "
+                                                 "`sparse_resident_no_pcie` measured up to round 4")
         # ... and resident in the slot-bucketed 2-byte form exactly as jxlh_submit_groups_slots uploads it (round 5: the
         # transforms read the entries in place -- no unpack pass, no slot tables -- and dequantise only the positions
         # that have an entry): what the kernels of the PCIe-inclusive deployment cost, per kernel and by counters
@@ -1026,6 +1027,9 @@ def main():
         if "k1_vardct" in kt:  # K1's compulsory traffic in this form: 12 B/px of pixels out + the entries / counts / LF in
             k1_ms = kt["k1_vardct"][0] / 10
             leg["k1_pixels_out_GBs"] = round(12.0 * size * size / (k1_ms * 1e-3) / 1e9, 1)
+        # `sparse_resident_no_pcie` = the frame resident in the sparse transport a caller is told to use: since round 5 the
+        # slot-bucketed form read in place (same key as before, so rounds compare; the pair form keeps its own line above)
+        e2e["sparse_resident_no_pcie"] = leg
         e2e["slots_resident_no_pcie"] = leg
         for c in ectx:   # new epoch for the PCIe legs
             c.frame_begin(synth.apply_opts(c.default_params(size, size), wl))
