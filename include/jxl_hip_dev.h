@@ -44,6 +44,13 @@ jxlh_status jxlh_frame_path(jxlh_ctx* ctx, int32_t* strip, int32_t* tiles, int32
  * quotient 1.0f / w; the filters rely on 0 mismatches over [1.0f, 16.0f). */
 jxlh_status jxlh_selftest_recip(jxlh_ctx* ctx, uint32_t lo_bits, uint32_t hi_bits, uint64_t* mismatches);
 
+/* Timeline of the last dataflow launch of jxlh_unsqueeze_chain (k6_unsqueeze_flow: the streamed squeeze levels of a
+ * chain in one launch, levels overlapping).  Call with enable = 1 before the chain; a later call returns, per level of
+ * that launch, rows[11 i + 0..4] = first workgroup start, last workgroup end, time the first mover wave of every
+ * workgroup spent polling progress words (sum), its polls (sum), workgroup lifetimes (sum) -- times in s_memrealtime
+ * ticks (100 MHz); rows[11 i + 5..10] are zero unless the library was built with the mover-phase experiment.  The profile costs two small memsets and five atomics per workgroup; off by default. */
+jxlh_status jxlh_flow_profile(jxlh_ctx* ctx, int32_t enable, int32_t* n_levels, uint64_t* rows, int32_t max_levels);
+
 #ifdef __cplusplus
 }
 #endif

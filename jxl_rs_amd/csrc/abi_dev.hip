@@ -69,6 +69,25 @@ jxlh_status jxlh_frame_path(jxlh_ctx* ctx, int32_t* strip, int32_t* tiles, int32
   return JXLH_OK;
 }
 
+jxlh_status jxlh_flow_profile(jxlh_ctx* ctx, int32_t enable, int32_t* n_levels, uint64_t* rows, int32_t max_levels) {
+  JXLH_ON_DEVICE(ctx);
+  if (!ctx) return JXLH_ERR_INVALID_ARGUMENT;
+  if (rows && n_levels && ctx->flow_prof_on && ctx->flow_prof.p && ctx->flow_prof_levels > 0) {
+    const int cap = unsqueeze_flow_max_steps();
+    std::vector<unsigned long long> h(11 * (size_t)cap);
+    HIPCHK(ctx, hipMemcpyAsync(h.data(), ctx->flow_prof.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    JXLH_SYNC(ctx);
+    const int n = std::min(ctx->flow_prof_levels, (int)max_levels);
+    for (int i = 0; i < n; i++)
+      for (int r = 0; r < 11; r++) rows[11 * i + r] = h[(size_t)r * cap + i];
+    *n_levels = n;
+  } else if (n_levels) {
+    *n_levels = 0;
+  }
+  ctx->flow_prof_on = enable != 0;
+  return JXLH_OK;
+}
+
 jxlh_status jxlh_selftest_recip(jxlh_ctx* ctx, uint32_t lo_bits, uint32_t hi_bits, uint64_t* mismatches) {
   JXLH_ON_DEVICE(ctx);
   if (!ctx || !mismatches || hi_bits < lo_bits) return JXLH_ERR_INVALID_ARGUMENT;

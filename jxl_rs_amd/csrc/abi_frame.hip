@@ -186,6 +186,10 @@ void jxlh_ctx_destroy(jxlh_ctx* ctx) {
   release(ctx->xs_jump);
   for (auto& b : ctx->ups_kernels_n) release(b);
   if (ctx->host_flag) (void)hipHostFree(ctx->host_flag);
+  if (ctx->host_flow_flag) (void)hipHostFree(ctx->host_flow_flag);
+  release(ctx->flow_words);
+  release(ctx->flow_error);
+  release(ctx->flow_prof);
   release(ctx->worklist);
   for (auto& e : ctx->extra) {
     release(e.raw);
@@ -1235,6 +1239,20 @@ jxlh_status jxlh_ctx_wait_mark(jxlh_ctx* ctx, uint32_t mark) {
 jxlh_status jxlh_ctx_sync(jxlh_ctx* ctx) {
   JXLH_ON_DEVICE(ctx);
   if (!ctx) return JXLH_ERR_INVALID_ARGUMENT;
+  if (ctx->flow_used && ctx->flow_error.p) {
+    // a dataflow squeeze launch ran since the last synchronisation: did one of its waits give up?
+    ctx->flow_used = false;
+    if (!ctx->host_flow_flag)
+      HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->host_flow_flag), sizeof(int), hipHostMallocDefault));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->host_flow_flag, ctx->flow_error.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    if (jxlh_status st = comm_wait_stream(ctx)) return st;
+    if (*ctx->host_flow_flag != 0) {
+      const jxlh_status st = (jxlh_status)*ctx->host_flow_flag;
+      HIPCHK(ctx, hipMemsetAsync(ctx->flow_error.p, 0, sizeof(int), ctx->stream));
+      ctx->last_error = "jxlh_unsqueeze_chain: a wait between two levels of the dataflow launch outlasted its deadline";
+      return st;
+    }
+  }
   if (ctx->in_frame && ctx->error_flag.p) {
     // read the flag on the context's own stream into pinned memory: a synchronous hipMemcpy would
     // go through the null stream and serialise against other contexts' work

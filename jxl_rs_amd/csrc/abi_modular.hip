@@ -347,7 +347,6 @@ jxlh_status jxlh_unsqueeze_chain(jxlh_ctx* ctx, int32_t n_planes, int32_t n_leve
   const bool with_rct = rct_op >= 0;
   if (with_rct && (n_planes != 3 || rct_op > 6 || rct_perm < 0 || rct_perm > 5)) return JXLH_ERR_INVALID_ARGUMENT;
   uint32_t cw = base_w, ch = base_h;
-  size_t max_plane = (size_t)base_w * base_h;
   for (int i = 0; i < n_levels; i++) {
     const jxlh_squeeze_level& lv = levels[i];
     if (lv.out_w == 0 || lv.out_h == 0 || lv.out_w > kMaxModularDim || lv.out_h > kMaxModularDim)
@@ -360,26 +359,28 @@ jxlh_status jxlh_unsqueeze_chain(jxlh_ctx* ctx, int32_t n_planes, int32_t n_leve
         return JXLH_ERR_INVALID_ARGUMENT;
     cw = lv.out_w;
     ch = lv.out_h;
-    if (i < n_levels - 1) max_plane = std::max(max_plane, (size_t)cw * ch);
   }
   if (out_stride < cw) return JXLH_ERR_INVALID_ARGUMENT;
   for (int p = 0; p < n_planes; p++)
     if (!base[p] || !out[p] || !is_device_ptr(base[p]) || !is_device_ptr(out[p])) return JXLH_ERR_INVALID_ARGUMENT;
-  // intermediate planes: two sets of n_planes planes in context scratch, swapped per level (the largest intermediate
-  // level is half the output)
+  // intermediate planes: every level but the last writes its own plane set in context scratch (levels overlap in
+  // the dataflow launch below, so no ping-pong; the sizes halve per level: about twice the largest one in all)
   jxlh_status st;
-  if ((st = ensure(ctx, ctx->hook_i[0], max_plane * n_planes))) return st;
-  if ((st = ensure(ctx, ctx->hook_i[1], max_plane * n_planes))) return st;
+  size_t level_off[64], arena = 0;
+  for (int i = 0; i < n_levels - 1; i++) {
+    level_off[i] = arena;
+    arena += ((size_t)levels[i].out_w * levels[i].out_h * n_planes + 63) & ~(size_t)63;  // 256-byte aligned sets
+  }
+  if ((st = ensure(ctx, ctx->hook_i[0], std::max<size_t>(arena, 1)))) return st;
   ScopedKernelTimer t(ctx, "k6_unsqueeze_chain");
   const int32_t* cur[3];
   size_t cur_stride = base_stride;
   for (int p = 0; p < n_planes; p++) cur[p] = base[p];
-  int flip = 0;
   auto dst_of = [&](int i, int32_t* dst[3], size_t* stride) {
     const bool last = i == n_levels - 1;
-    for (int p = 0; p < n_planes; p++) dst[p] = last ? out[p] : ctx->hook_i[flip].p + (size_t)p * max_plane;
+    for (int p = 0; p < n_planes; p++)
+      dst[p] = last ? out[p] : ctx->hook_i[0].p + level_off[i] + (size_t)p * levels[i].out_w * levels[i].out_h;
     *stride = last ? out_stride : levels[i].out_w;
-    if (!last) flip ^= 1;
   };
   int i = 0;
   // ---- the first levels, while the planes fit LDS: one launch (the chain starts from <= 8 x 8)
@@ -402,7 +403,6 @@ jxlh_status jxlh_unsqueeze_chain(jxlh_ctx* ctx, int32_t n_planes, int32_t n_leve
       }
       int32_t* dst[3];
       size_t dst_stride;
-      const int save = flip;
       dst_of(n_small - 1, dst, &dst_stride);
       if (launch_unsqueeze_levels(ctx->stream, n_planes, n_small, hz, ow, oh, rp, rs, base, base_stride, base_w, base_h, dst,
                                   dst_stride)) {
@@ -411,12 +411,65 @@ jxlh_status jxlh_unsqueeze_chain(jxlh_ctx* ctx, int32_t n_planes, int32_t n_leve
         i = n_small;
         break;
       }
-      flip = save;
       n_small--;  // a level that does not fit the kernel's half-size buffer: try a shorter prefix
     }
   }
-  // ---- the remaining levels, one launch each over the three planes; the last one fused with the RCT
-  for (; i < n_levels; i++) {
+  // JXLH_SEPARATE_RCT=1 (tests): take the two-pass route that planes of 2^31 samples and more need;
+  // JXLH_CHAIN_FLOW=0 (tests, A/B): one launch per streamed level instead of the dataflow launch
+  const char* sep = getenv("JXLH_SEPARATE_RCT");
+  const bool fuse_rct = with_rct && !(sep && *sep == '1');
+  const char* fl = getenv("JXLH_CHAIN_FLOW");
+  const bool flow = !(fl && *fl == '0');
+  // ---- the remaining levels: runs of streamed levels as ONE dataflow launch (levels overlap: k6_unsqueeze_flow),
+  // anything else one launch per level over the three planes; the last one fused with the RCT
+  while (i < n_levels) {
+    if (flow) {
+      FlowStep steps[16];
+      const int max_run = std::min(16, unsqueeze_flow_max_steps());
+      const int32_t* a[3];
+      size_t a_stride = cur_stride;
+      for (int p = 0; p < n_planes; p++) a[p] = cur[p];
+      int n = 0;
+      for (int j = i; j < n_levels && n < max_run; j++, n++) {
+        const jxlh_squeeze_level& lv = levels[j];
+        if (j == n_levels - 1 && fuse_rct) break;  // the fused kernel takes it
+        int32_t* dst[3];
+        size_t dst_stride;
+        dst_of(j, dst, &dst_stride);
+        if (!unsqueeze_tiled_eligible(lv.horizontal ? 1 : 0, lv.out_w, lv.out_h, a_stride, lv.res_stride, dst_stride)) break;
+        FlowStep& fs = steps[n];
+        fs.horizontal = lv.horizontal ? 1 : 0;
+        fs.avg_stride = a_stride;
+        fs.res_stride = lv.res_stride;
+        fs.out_w = lv.out_w;
+        fs.out_h = lv.out_h;
+        fs.out_stride = dst_stride;
+        for (int p = 0; p < 3; p++) {
+          const int q = p < n_planes ? p : 0;
+          fs.avg[p] = a[q];
+          fs.res[p] = lv.res[q] ? lv.res[q] : a[q];
+          fs.out[p] = dst[q];
+        }
+        for (int p = 0; p < n_planes; p++) a[p] = dst[p];
+        a_stride = dst_stride;
+      }
+      if (n >= 2) {
+        if ((st = ensure(ctx, ctx->flow_words, unsqueeze_flow_words(n_planes, n, steps)))) return st;
+        if (!ctx->flow_error.p) {
+          if ((st = ensure(ctx, ctx->flow_error, 1))) return st;
+          HIPCHK(ctx, hipMemsetAsync(ctx->flow_error.p, 0, sizeof(int), ctx->stream));
+        }
+        if (ctx->flow_prof_on && (st = ensure(ctx, ctx->flow_prof, 11 * (size_t)unsqueeze_flow_max_steps()))) return st;
+        launch_unsqueeze_flow(ctx->stream, n_planes, n, steps, ctx->flow_words.p, ctx->flow_error.p, 4.0f,
+                              ctx->flow_prof_on ? ctx->flow_prof.p : nullptr);
+        ctx->flow_prof_levels = n;
+        ctx->flow_used = true;
+        for (int p = 0; p < n_planes; p++) cur[p] = a[p];
+        cur_stride = a_stride;
+        i += n;
+        continue;
+      }
+    }
     const jxlh_squeeze_level& lv = levels[i];
     const bool last = i == n_levels - 1;
     int32_t* dst[3];
@@ -425,9 +478,7 @@ jxlh_status jxlh_unsqueeze_chain(jxlh_ctx* ctx, int32_t n_planes, int32_t n_leve
     const int32_t* rv[3];
     for (int p = 0; p < n_planes; p++) rv[p] = lv.res[p] ? lv.res[p] : cur[p];
     bool fused = false;
-    // JXLH_SEPARATE_RCT=1 (tests): take the two-pass route that planes of 2^31 samples and more need
-    const char* sep = getenv("JXLH_SEPARATE_RCT");
-    if (last && with_rct && !(sep && *sep == '1'))
+    if (last && fuse_rct)
       fused = launch_unsqueeze_rct(ctx->stream, lv.horizontal ? 1 : 0, cur, cur_stride, rv, lv.res_stride, lv.out_w, lv.out_h,
                                    dst, dst_stride, rct_op, rct_perm);
     if (!fused)
@@ -442,6 +493,7 @@ jxlh_status jxlh_unsqueeze_chain(jxlh_ctx* ctx, int32_t n_planes, int32_t n_leve
     }
     for (int p = 0; p < n_planes; p++) cur[p] = dst[p];
     cur_stride = dst_stride;
+    i++;
   }
   HIPCHK(ctx, hipGetLastError());
   return JXLH_OK;

@@ -102,6 +102,15 @@ struct jxlh_ctx {
   // stage hooks scratch
   DevBuf<float> hook_f[8];
   DevBuf<int32_t> hook_i[4];
+  // jxlh_unsqueeze_chain's dataflow launches (k6_unsqueeze_flow): ticket + progress words, zeroed per launch; the error
+  // word (zeroed when allocated and after an error was reported) is read back by the next jxlh_ctx_sync
+  DevBuf<int> flow_words, flow_error;
+  bool flow_used = false;
+  int* host_flow_flag = nullptr;  // pinned
+  // jxlh_flow_profile (jxl_hip_dev.h): per-level timeline of the last dataflow launch
+  DevBuf<unsigned long long> flow_prof;
+  bool flow_prof_on = false;
+  int flow_prof_levels = 0;
   // sparse coefficient transport (jxlh_submit_group(s)_sparse): pairs land in sp_pairs (bump
   // allocated, sized for a frame's worst case), are expanded by the next jxlh_frame_run
   std::mutex sp_mutex;

@@ -345,6 +345,25 @@ void launch_unsqueeze(hipStream_t s, int horizontal, int n_planes, const int32_t
                       const int32_t* const res[], size_t res_stride, uint32_t out_w, uint32_t out_h,
                       int32_t* const out[], size_t out_stride);
 // fused unsqueeze of three planes + inverse RCT; false = not applicable (plane too large), nothing launched
+// consecutive streamed unsqueeze steps as one dataflow launch (k6_unsqueeze_flow): step i + 1's averages are step i's
+// outputs (distinct planes per step); `scratch` holds unsqueeze_flow_words() ints, `error` one int that stays 0 unless a
+// wait inside the launch outlasted deadline_s
+struct FlowStep {
+  int horizontal;
+  const int32_t* avg[3];
+  size_t avg_stride;
+  const int32_t* res[3];
+  size_t res_stride;
+  uint32_t out_w, out_h;
+  int32_t* out[3];
+  size_t out_stride;
+};
+bool unsqueeze_tiled_eligible(int horizontal, uint32_t out_w, uint32_t out_h, size_t avg_stride, size_t res_stride,
+                              size_t out_stride);
+int unsqueeze_flow_max_steps();
+size_t unsqueeze_flow_words(int n_planes, int n_steps, const FlowStep* steps);
+void launch_unsqueeze_flow(hipStream_t s, int n_planes, int n_steps, const FlowStep* steps, int* scratch, int* error,
+                           float deadline_s, unsigned long long* prof);
 bool launch_unsqueeze_rct(hipStream_t s, int horizontal, const int32_t* const avg[3], size_t avg_stride,
                           const int32_t* const res[3], size_t res_stride, uint32_t out_w, uint32_t out_h,
                           int32_t* const out[3], size_t out_stride, int op, int perm);

@@ -1049,20 +1049,59 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 #define JXLH_SQT_S 32                    // steps per chunk
 #define JXLH_SQT_PI (JXLH_SQT_S + 4)     // line pitch of the input tiles, horizontal layout
 #define JXLH_SQT_PO (2 * JXLH_SQT_S + 4) // ... of the output tile
-template <bool HORIZ>
-__global__ __launch_bounds__(256) void k6_unsqueeze_tiled(const SqueezePlanes pl, size_t avg_lp, size_t avg_ep,
-                                                          size_t res_lp, size_t res_ep, size_t out_lp, size_t out_ep,
-                                                          int n_lines, int n_out) {
+// One workgroup's share of a tiled step: 64 lines of one plane.  Offsets are 32-bit (the launchers keep planes of 2^31
+// samples or more on k6_unsqueeze).
+struct TiledLines {
+  const int32_t* ga;
+  const int32_t* gr;
+  int32_t* go;
+  uint32_t alp, aep, rlp, rep, olp, oep;  // line / element pitches of the average, residual and output planes
+  int n_lines, n_out, l0;
+  int vec;  // 16-byte accesses are possible: plane bases and the pitches of the non-contiguous axis are multiples of 16
+            // bytes, and every byte offset inside a plane fits 32 bits (tiled_vec_ok)
+};
+// Dataflow form (k6_unsqueeze_flow): the averages of this step are the outputs of the step before it, which is still
+// RUNNING in other workgroups of the same launch.  Every 64-line group of a step keeps one progress word = output
+// samples complete (stored and acknowledged) along ITS lines; a consumer reads the words of the groups its next chunk
+// touches before it requests the chunk.  Producer and consumer sit on different XCDs, whose L2s are not coherent:
+// outputs are written through and averages read at agent scope (as in k5_palette_delta), so "acknowledged" is
+// "visible" and the words need no fence.
+constexpr int kFlowWordStride = 64;  // ints between two progress words: one 256-byte line each (polls spread over channels)
+struct FlowLink {
+  const int* dep;      // the producing step's progress words for this plane (kFlowWordStride apart); nullptr: complete
+  int dep_same_axis;   // its lines run along this step's lines (two steps of one direction in a row): same group index
+  int* mine;           // this group's progress word
+  int* error;          // JXLH_ERR_DEVICE if a wait outlasts the deadline (the result is then undefined, but the launch ends)
+  unsigned long long deadline_ticks;  // s_memrealtime ticks (100 MHz)
+  unsigned long long wait_ticks;      // out: time this lane spent polling; polls: loads of a progress word
+  unsigned int polls;
+  unsigned long long phase[6];  // JXLH_FLOW_EXP & 64: mover time in stage, publish, fetch, peek, store, barrier
+};
+#ifndef JXLH_FLOW_EXP  // timing experiments only (results may then be undefined): 1 plain stores, 2 plain loads, 4 publish at the end only, 8 no peek, 64 profile rows 5-10 = mover phases, 16 profile row 2 = the chain wave's time at the loop barrier
+#define JXLH_FLOW_EXP 0
+#endif
+template <bool FLOW>
+__device__ __forceinline__ int32_t ld_avg(const int32_t* p) {
+  if constexpr (FLOW && !(JXLH_FLOW_EXP & 2)) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else return *p;
+}
+template <bool FLOW>
+__device__ __forceinline__ void st_out(int32_t* p, int32_t v) {
+  if constexpr (FLOW && !(JXLH_FLOW_EXP & 1)) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+
+template <bool HORIZ, bool FLOW>
+__device__ __forceinline__ void unsqueeze_tiled_lines(const TiledLines& T, int32_t* __restrict__ s_avg,
+                                                      int32_t* __restrict__ s_res, int32_t* __restrict__ s_out,
+                                                      FlowLink& F, int* s_pub) {
   constexpr int S = JXLH_SQT_S, PI = JXLH_SQT_PI, PO = JXLH_SQT_PO;
   constexpr int IN_ELEMS = HORIZ ? 64 * PI : 64 * S, OUT_ELEMS = HORIZ ? 64 * PO : 64 * 2 * S;
-  __shared__ __attribute__((aligned(16))) int32_t s_avg[2][IN_ELEMS];
-  __shared__ __attribute__((aligned(16))) int32_t s_res[2][IN_ELEMS];
-  __shared__ __attribute__((aligned(16))) int32_t s_out[2][OUT_ELEMS];
   const int tid = threadIdx.x;
-  const int l0 = blockIdx.x * 64;
-  const int32_t* __restrict__ ga = pl.avg[blockIdx.y];
-  const int32_t* __restrict__ gr = pl.res[blockIdx.y];
-  int32_t* __restrict__ go = pl.out[blockIdx.y];
+  const int l0 = T.l0, n_lines = T.n_lines, n_out = T.n_out;
+  const int32_t* __restrict__ ga = T.ga;
+  const int32_t* __restrict__ gr = T.gr;
+  int32_t* __restrict__ go = T.go;
   // w steps produce 2 w samples; an odd line ends with a copied sample.  EVERY step runs through the chunk pipeline
   // (round 2 left the last n % S steps and the closing pair to the chain lane's own global loads: with power-of-two
   // planes that is 31 steps per level whose memory latency sat in the dependent instruction stream, ~10 us per level):
@@ -1089,8 +1128,7 @@ __global__ __launch_bounds__(256) void k6_unsqueeze_tiled(const SqueezePlanes pl
   constexpr int IN_DR = HORIZ ? NM / S : 0, IN_DK = HORIZ ? 0 : NM / 64;
   const int out_r0 = HORIZ ? m / (2 * S) : m % 64, out_k0 = HORIZ ? m % (2 * S) : m / 64;
   constexpr int OUT_DR = HORIZ ? NM / (2 * S) : 0, OUT_DK = HORIZ ? 0 : NM / 64;
-  const uint32_t alp = (uint32_t)avg_lp, aep = (uint32_t)avg_ep, rlp = (uint32_t)res_lp, rep = (uint32_t)res_ep;
-  const uint32_t olp = (uint32_t)out_lp, oep = (uint32_t)out_ep;
+  const uint32_t alp = T.alp, aep = T.aep, rlp = T.rlp, rep = T.rep, olp = T.olp, oep = T.oep;
   const uint32_t a_off0 = (uint32_t)(l0 + in_r0) * alp + (uint32_t)(1 + in_k0) * aep;
   const uint32_t r_off0 = (uint32_t)(l0 + in_r0) * rlp + (uint32_t)in_k0 * rep;
   const uint32_t o_off0 = (uint32_t)(l0 + out_r0) * olp + (uint32_t)out_k0 * oep;
@@ -1099,13 +1137,84 @@ __global__ __launch_bounds__(256) void k6_unsqueeze_tiled(const SqueezePlanes pl
   constexpr int IN_LDS_DJ = HORIZ ? IN_DR * PI : IN_DK * 64;
   const int out_lds0 = HORIZ ? out_r0 * PO + out_k0 : out_k0 * 64 + out_r0;
   constexpr int OUT_LDS_DJ = HORIZ ? OUT_DR * PO : OUT_DK * 64;
+  // ---- dataflow form: wait until the producing step has stored the averages [e_lo, e_hi] of this group's lines
+  // (each wave that requests averages asks for itself: lane 0 polls, the wave goes on from the reconvergence point)
+  int dep_groups_ok = 0, dep_avail = 0;  // wave-uniform: producer groups seen complete for our lines / samples seen
+  bool dep_dead = false;
+  auto flow_spin = [&](const int* word, int need) -> int {
+    int v = need;
+    if ((tid & 63) == 0) {
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      int spins = 0;
+      F.polls++;
+      while ((v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need) {
+        F.polls++;
+        // back off: hundreds of workgroups of the later levels wait for most of the launch, and their polls all end
+        // at the memory channels that hold the words the running levels publish and peek at
+        if (++spins < 8) __builtin_amdgcn_s_sleep(4);
+        else if (spins < 24) __builtin_amdgcn_s_sleep(24);
+        else __builtin_amdgcn_s_sleep(96);
+        if ((spins & 255) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > F.deadline_ticks) {
+          atomicExch(F.error, JXLH_ERR_DEVICE);
+          v = -1;
+          break;
+        }
+      }
+      F.wait_ticks += __builtin_amdgcn_s_memrealtime() - t0;
+    }
+    asm volatile("" ::: "memory");
+    return __builtin_amdgcn_readfirstlane(v);
+  };
+  // The word the NEXT request will ask about is read one iteration ahead (flow_peek, issued behind the iteration's
+  // loads and stores): a poll is a round trip to the coherence point, and in front of a chunk's requests it would sit
+  // in every iteration's critical sequence (poll, then loads, then the next iteration's staging: measured 5.4 us per
+  // chunk instead of 1.7).  A producer that is ahead -- the steady state -- is then seen without waiting.
+  int pk_idx = -1, pk_v = 0;  // pk_v: per lane (every lane loads the same word), made uniform where it is used
+  auto flow_peek = [&]() {
+    if constexpr (FLOW) {
+      if (!F.dep || dep_dead || (JXLH_FLOW_EXP & 8)) return;
+      pk_idx = F.dep_same_axis ? (l0 >> 6) : dep_groups_ok;
+      if constexpr ((JXLH_FLOW_EXP & 32) != 0) pk_v = *(const volatile int*)(F.dep + pk_idx * kFlowWordStride);
+      else pk_v = __hip_atomic_load(F.dep + pk_idx * kFlowWordStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+  auto flow_wait = [&](int e_lo, int e_hi) {
+    if constexpr (FLOW) {
+      if (!F.dep || dep_dead) return;
+      if (F.dep_same_axis) {
+        if (pk_idx >= 0) dep_avail = max(dep_avail, __builtin_amdgcn_readfirstlane(pk_v));
+        if (dep_avail < e_hi + 1) {
+          dep_avail = flow_spin(F.dep + (l0 >> 6) * kFlowWordStride, e_hi + 1);
+          dep_dead = dep_avail < 0;
+        }
+      } else {
+        const int need = min(l0 + 64, n_lines);
+        dep_groups_ok = max(dep_groups_ok, e_lo >> 6);  // (a wave that joins late -- the scalar tail after vector chunks)
+        while (!dep_dead && dep_groups_ok <= (e_hi >> 6)) {
+          if (!(pk_idx == dep_groups_ok && __builtin_amdgcn_readfirstlane(pk_v) >= need))
+            dep_dead = flow_spin(F.dep + dep_groups_ok * kFlowWordStride, need) < 0;
+          dep_groups_ok++;
+        }
+      }
+      pk_idx = -1;
+    }
+  };
+  // ... and report: `done` output samples of every line of the group are stored AND acknowledged (the caller's wave
+  // has waited for vmcnt(0)); the last of the three mover waves to say so raises the word
+  auto flow_publish = [&](int done) {
+    if constexpr (FLOW) {
+      if ((tid & 63) == 0 && (atomicAdd(s_pub, 1) % 3) == 2)
+        __hip_atomic_store(F.mine, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
   auto fetch_chunk = [&](int c, int32_t(&va)[NIN], int32_t(&vr)[NIN]) {
+    flow_wait(c * S, min(c * S + S, n_avg - 1));
     if (c * S + S <= w - 1) {  // every next average and residual of the chunk exists: affine offsets
       const uint32_t ca = a_off0 + (uint32_t)(c * S) * aep, cr = r_off0 + (uint32_t)(c * S) * rep;
 #pragma unroll
       for (int j = 0; j < NIN; j++) {
         const bool ok = l0 + in_r0 + j * IN_DR < n_lines && m + j * NM < 64 * S;
-        va[j] = ok ? ga[ca + j * a_dj] : 0;
+        va[j] = ok ? ld_avg<FLOW>(ga + (ca + j * a_dj)) : 0;
         vr[j] = ok ? gr[cr + j * r_dj] : 0;
       }
     } else {  // the line's end: clamp the element indices (next_avg of the last step = the last average)
@@ -1114,7 +1223,7 @@ __global__ __launch_bounds__(256) void k6_unsqueeze_tiled(const SqueezePlanes pl
         const int row = in_r0 + j * IN_DR, k = in_k0 + j * IN_DK;
         const bool ok = l0 + row < n_lines && m + j * NM < 64 * S && c * S + k < w;
         const int ia = min(c * S + 1 + k, n_avg - 1), ir = min(c * S + k, max(w - 1, 0));
-        va[j] = ok ? ga[(uint32_t)(l0 + row) * alp + (uint32_t)ia * aep] : 0;
+        va[j] = ok ? ld_avg<FLOW>(ga + ((uint32_t)(l0 + row) * alp + (uint32_t)ia * aep)) : 0;
         vr[j] = ok ? gr[(uint32_t)(l0 + row) * rlp + (uint32_t)ir * rep] : 0;
       }
     }
@@ -1123,13 +1232,13 @@ __global__ __launch_bounds__(256) void k6_unsqueeze_tiled(const SqueezePlanes pl
 #pragma unroll
     for (int j = 0; j < NIN; j++) {
       if (m + j * NM < 64 * S) {
-        s_avg[c & 1][in_lds0 + j * IN_LDS_DJ] = va[j];
-        s_res[c & 1][in_lds0 + j * IN_LDS_DJ] = vr[j];
+        s_avg[(c & 1) * IN_ELEMS + in_lds0 + j * IN_LDS_DJ] = va[j];
+        s_res[(c & 1) * IN_ELEMS + in_lds0 + j * IN_LDS_DJ] = vr[j];
       }
     }
   };
   auto store_chunk = [&](int c) {
-    const int32_t* so = s_out[c & 1];
+    const int32_t* so = s_out + (c & 1) * OUT_ELEMS;
     const uint32_t co = o_off0 + (uint32_t)(2 * c * S) * oep;
     const int count = min(2 * S, n_out - 2 * c * S);  // samples of the chunk (the last one may be partial)
     int32_t v[NOUT];
@@ -1138,87 +1247,418 @@ __global__ __launch_bounds__(256) void k6_unsqueeze_tiled(const SqueezePlanes pl
 #pragma unroll
     for (int j = 0; j < NOUT; j++)
       if (l0 + out_r0 + j * OUT_DR < n_lines && m + j * NM < 64 * 2 * S && out_k0 + j * OUT_DK < count)
-        go[co + j * o_dj] = v[j];
+        st_out<FLOW>(go + (co + j * o_dj), v[j]);
+  };
+
+
+  // ---- vector movers.  The dword movers above spend ~2.1 us of instruction issue per chunk (44 memory instructions
+  // per lane, each behind its own bounds test and address arithmetic: measured per phase, profiles/r05_i_*) against
+  // the chain wave's 1.6-1.7 us: every tiled step was bound by its MOVERS.  Where the planes allow 16-byte accesses,
+  // the group is complete and every step of the chunk has a following average (all but the last one or two chunks of
+  // a line), a chunk moves as 16 + 16 + 16 buffer instructions of 128 bits with offsets affine in the slot, split by
+  // role as in k6_unsqueeze_rct: wave 1 loads (only loads outstanding: its wait at the staging is for requests a whole
+  // iteration old), waves 2 and 3 store (only stores outstanding: exactly eight per iteration, so "all but the newest
+  // eight acknowledged" is a precise vmcnt(8) -- what the dataflow form publishes on).
+  const bool vec_ok = T.vec && l0 + 64 <= n_lines;
+  const int n_fast = vec_ok && w >= 1 ? (w - 1) / S : 0;  // chunks c with c S + S <= w - 1 (a prefix of the line)
+  const bool vloader = tid >= 64 && tid < 128;
+  const int ms = tid - 128;  // vector storer index 0..127
+  constexpr int kAuxCoherent = 16;  // sc1: agent scope (write-through store / load at the coherence point)
+  constexpr int kAuxLd = (FLOW && !(JXLH_FLOW_EXP & 2)) ? kAuxCoherent : 0, kAuxSt = (FLOW && !(JXLH_FLOW_EXP & 1)) ? kAuxCoherent : 0;
+  // (the bases are the same for the whole workgroup; said explicitly, or the dataflow kernel -- where they come out of a
+  // level table indexed by the ticket -- gets a readfirstlane loop around every buffer instruction)
+  auto uniform_ptr = [](const int32_t* p) {
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    typedef __attribute__((address_space(1))) int32_t global_i32;
+    return (int32_t*)(global_i32*)((uint64_t)hi << 32 | lo);
+  };
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(ga + (size_t)l0 * alp), 0, -1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(gr + (size_t)l0 * rlp), 0, -1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(go + (size_t)l0 * olp), 0, -1, 0x00020000);
+  // loader slot j = 0..7: horizontal (line (m >> 3) + 8 j, quad m & 7), vertical (row (m >> 4) + 4 j, quad m & 15)
+  const uint32_t vl_a0 = HORIZ ? ((uint32_t)(m >> 3) * alp + 4u * (m & 7)) * 4u : ((uint32_t)(m >> 4) * aep + 4u * (m & 15)) * 4u;
+  const uint32_t vl_r0 = HORIZ ? ((uint32_t)(m >> 3) * rlp + 4u * (m & 7)) * 4u : ((uint32_t)(m >> 4) * rep + 4u * (m & 15)) * 4u;
+  const uint32_t vl_adj = HORIZ ? 32u * alp : 16u * aep, vl_rdj = HORIZ ? 32u * rlp : 16u * rep;
+  const int vl_lds0 = HORIZ ? (m >> 3) * PI + 4 * (m & 7) : (m >> 4) * 64 + 4 * (m & 15);
+  constexpr int VL_LDS_DJ = HORIZ ? 8 * PI : 4 * 64;
+  // storer slot j = 0..7: horizontal (line (ms >> 4) + 8 j, quad ms & 15), vertical (row (ms >> 4) + 8 j, quad ms & 15)
+  const uint32_t vs_o0 = HORIZ ? ((uint32_t)(ms >> 4) * olp + 4u * (ms & 15)) * 4u : ((uint32_t)(ms >> 4) * oep + 4u * (ms & 15)) * 4u;
+  const uint32_t vs_odj = HORIZ ? 32u * olp : 32u * oep;
+  const int vs_lds0 = HORIZ ? (ms >> 4) * PO + 4 * (ms & 15) : (ms >> 4) * 64 + 4 * (ms & 15);
+  constexpr int VS_LDS_DJ = HORIZ ? 8 * PO : 8 * 64;
+  jxlh_i32x4 qa[8], qr[8];
+  int32_t qt = 0;  // horizontal: the 33rd average of the line (element c S + 32), one line per lane
+  auto fetch_fast = [&](int c) {
+    flow_wait(c * S, min(c * S + S, n_avg - 1));
+    // horizontal: the aligned quads avg[c S + 4 q ..] (next_avg[k] = avg[c S + 1 + k] is one element further: the
+    // staging shifts); vertical: rows c S + 1 + row
+    const uint32_t sa = HORIZ ? (uint32_t)(c * S) * 4u : (uint32_t)(c * S + 1) * aep * 4u;
+    const uint32_t sr = HORIZ ? (uint32_t)(c * S) * 4u : (uint32_t)(c * S) * rep * 4u;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      qa[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, vl_a0 + j * vl_adj, sa, kAuxLd);
+      qr[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, vl_r0 + j * vl_rdj, sr, 0);
+    }
+    if constexpr (HORIZ) qt = __builtin_amdgcn_raw_buffer_load_b32(rs_a, (uint32_t)m * alp * 4u, sa + 4u * S, kAuxLd);
+  };
+  auto stage_fast = [&](int c) {
+    int32_t* da = s_avg + (c & 1) * IN_ELEMS + vl_lds0;
+    int32_t* dr = s_res + (c & 1) * IN_ELEMS + vl_lds0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      *reinterpret_cast<jxlh_i32x4*>(dr + j * VL_LDS_DJ) = qr[j];
+      if constexpr (HORIZ) {
+        int32_t* q = da + j * VL_LDS_DJ - 1;  // position k = 4 q + t - 1 of the line
+        if ((m & 7) != 0) q[0] = qa[j].x;
+        q[1] = qa[j].y;
+        q[2] = qa[j].z;
+        q[3] = qa[j].w;
+      } else {
+        *reinterpret_cast<jxlh_i32x4*>(da + j * VL_LDS_DJ) = qa[j];
+      }
+    }
+    if constexpr (HORIZ) s_avg[(c & 1) * IN_ELEMS + m * PI + S - 1] = qt;
+  };
+  auto store_fast = [&](int c) {
+    const int32_t* so = s_out + (c & 1) * OUT_ELEMS + vs_lds0;
+    const uint32_t soff = HORIZ ? (uint32_t)(2 * c * S) * 4u : (uint32_t)(2 * c * S) * oep * 4u;
+    jxlh_i32x4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = *reinterpret_cast<const jxlh_i32x4*>(so + j * VS_LDS_DJ);
+#pragma unroll
+    for (int j = 0; j < 8; j++) __builtin_amdgcn_raw_buffer_store_b128(v[j], rs_o, vs_o0 + j * vs_odj, soff, kAuxSt);
   };
 
   const int l = l0 + tid;  // chain lanes
   int32_t cur = 0, d = 0;
-  if (chain && l < n_lines) cur = ga[(size_t)l * avg_lp];
+  if (chain) {
+    flow_wait(0, 0);
+    if (l < n_lines) cur = ld_avg<FLOW>(ga + (uint32_t)l * alp);
+  }
   // mover schedule, iteration c: stage chunk c + 1 (fetched during iteration c - 1: its latency is a whole iteration
   // old), fetch chunk c + 2 into registers, drain the outputs of chunk c - 1
   int32_t pa[NIN], pr[NIN];
   if (!chain && steps_of(0) > 0) {
-    fetch_chunk(0, pa, pr);
-    stage_chunk(0, pa, pr);
-    if (steps_of(1) > 0) fetch_chunk(1, pa, pr);
-  }
-  lds_barrier();
-  for (int c = 0; c < n_chunks; c++) {
-    if (!chain) {
-      if (steps_of(c + 1) > 0) stage_chunk(c + 1, pa, pr);
-      if (steps_of(c + 2) > 0) fetch_chunk(c + 2, pa, pr);
-      if (c >= 1) store_chunk(c - 1);
+    if (0 < n_fast) {
+      if (vloader) {
+        fetch_fast(0);
+        stage_fast(0);
+      }
     } else {
-      const int32_t* ia = s_avg[c & 1];
-      const int32_t* ir = s_res[c & 1];
-      int32_t* oa = s_out[c & 1];
-      const int sc = steps_of(c);
-      if (sc == S) {
-        int32_t xa[S], xr[S];
-        if constexpr (HORIZ) {
-#pragma unroll
-          for (int j = 0; j < S / 4; j++) {
-            const int4 va = *reinterpret_cast<const int4*>(ia + tid * PI + 4 * j);
-            const int4 vr = *reinterpret_cast<const int4*>(ir + tid * PI + 4 * j);
-            xa[4 * j] = va.x; xa[4 * j + 1] = va.y; xa[4 * j + 2] = va.z; xa[4 * j + 3] = va.w;
-            xr[4 * j] = vr.x; xr[4 * j + 1] = vr.y; xr[4 * j + 2] = vr.z; xr[4 * j + 3] = vr.w;
-          }
-        } else {
-#pragma unroll
-          for (int k = 0; k < S; k++) {
-            xa[k] = ia[k * 64 + tid];
-            xr[k] = ir[k * 64 + tid];
-          }
-        }
-#pragma unroll
-        for (int k = 0; k < S; k += 2) {
-          int32_t a0, b0, a1, b1;
-          unsqueeze_step(cur, xr[k], xa[k], d, a0, b0);
-          unsqueeze_step(xa[k], xr[k + 1], xa[k + 1], d, a1, b1);
-          cur = xa[k + 1];
-          if constexpr (HORIZ) {
-            *reinterpret_cast<int4*>(oa + tid * PO + 2 * k) = make_int4(a0, b0, a1, b1);
-          } else {
-            oa[(2 * k) * 64 + tid] = a0;
-            oa[(2 * k + 1) * 64 + tid] = b0;
-            oa[(2 * k + 2) * 64 + tid] = a1;
-            oa[(2 * k + 3) * 64 + tid] = b1;
-          }
-        }
-      } else {  // the line's last chunk: fewer steps, one by one; an odd line's copied sample behind them
-        for (int k = 0; k < sc; k++) {
-          const int32_t nxt = HORIZ ? ia[tid * PI + k] : ia[k * 64 + tid];
-          const int32_t rs = HORIZ ? ir[tid * PI + k] : ir[k * 64 + tid];
-          int32_t va, vb;
-          unsqueeze_step(cur, rs, nxt, d, va, vb);
-          cur = nxt;
-          if constexpr (HORIZ) {
-            oa[tid * PO + 2 * k] = va;
-            oa[tid * PO + 2 * k + 1] = vb;
-          } else {
-            oa[(2 * k) * 64 + tid] = va;
-            oa[(2 * k + 1) * 64 + tid] = vb;
-          }
-        }
-        if (has_tail) {  // n_out odd: sample 2 w = avg[w] (squeeze.rs:434-437), always in the last chunk
-          if constexpr (HORIZ) oa[tid * PO + 2 * sc] = cur;
-          else oa[(2 * sc) * 64 + tid] = cur;
-        }
+      fetch_chunk(0, pa, pr);
+      stage_chunk(0, pa, pr);
+    }
+    if (steps_of(1) > 0) {
+      if (1 < n_fast) {
+        if (vloader) fetch_fast(1);
+      } else {
+        fetch_chunk(1, pa, pr);
       }
     }
-    lds_barrier();
+    if (steps_of(2) > 0 && (vloader || 2 >= n_fast)) flow_peek();
   }
-  if (!chain && n_chunks > 0) store_chunk(n_chunks - 1);
+  lds_barrier();
+  unsigned long long tp = 0;
+  auto mark = [&](int ph) {
+    if constexpr (FLOW && (JXLH_FLOW_EXP & 64)) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+      if (ph >= 0) F.phase[ph] += now - tp;
+      tp = now;
+    }
+  };
+  // the chain wave's chunk c: LDS in, LDS out
+  auto chain_chunk = [&](int c) {
+    const int32_t* ia = s_avg + (c & 1) * IN_ELEMS;
+    const int32_t* ir = s_res + (c & 1) * IN_ELEMS;
+    int32_t* oa = s_out + (c & 1) * OUT_ELEMS;
+    const int sc = steps_of(c);
+    if (sc == S) {
+      int32_t xa[S], xr[S];
+      if constexpr (HORIZ) {
+#pragma unroll
+        for (int j = 0; j < S / 4; j++) {
+          const int4 va = *reinterpret_cast<const int4*>(ia + tid * PI + 4 * j);
+          const int4 vr = *reinterpret_cast<const int4*>(ir + tid * PI + 4 * j);
+          xa[4 * j] = va.x; xa[4 * j + 1] = va.y; xa[4 * j + 2] = va.z; xa[4 * j + 3] = va.w;
+          xr[4 * j] = vr.x; xr[4 * j + 1] = vr.y; xr[4 * j + 2] = vr.z; xr[4 * j + 3] = vr.w;
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < S; k++) {
+          xa[k] = ia[k * 64 + tid];
+          xr[k] = ir[k * 64 + tid];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < S; k += 2) {
+        int32_t a0, b0, a1, b1;
+        unsqueeze_step(cur, xr[k], xa[k], d, a0, b0);
+        unsqueeze_step(xa[k], xr[k + 1], xa[k + 1], d, a1, b1);
+        cur = xa[k + 1];
+        if constexpr (HORIZ) {
+          *reinterpret_cast<int4*>(oa + tid * PO + 2 * k) = make_int4(a0, b0, a1, b1);
+        } else {
+          oa[(2 * k) * 64 + tid] = a0;
+          oa[(2 * k + 1) * 64 + tid] = b0;
+          oa[(2 * k + 2) * 64 + tid] = a1;
+          oa[(2 * k + 3) * 64 + tid] = b1;
+        }
+      }
+    } else {  // the line's last chunk: fewer steps, one by one; an odd line's copied sample behind them
+      for (int k = 0; k < sc; k++) {
+        const int32_t nxt = HORIZ ? ia[tid * PI + k] : ia[k * 64 + tid];
+        const int32_t rs = HORIZ ? ir[tid * PI + k] : ir[k * 64 + tid];
+        int32_t va, vb;
+        unsqueeze_step(cur, rs, nxt, d, va, vb);
+        cur = nxt;
+        if constexpr (HORIZ) {
+          oa[tid * PO + 2 * k] = va;
+          oa[tid * PO + 2 * k + 1] = vb;
+        } else {
+          oa[(2 * k) * 64 + tid] = va;
+          oa[(2 * k + 1) * 64 + tid] = vb;
+        }
+      }
+      if (has_tail) {  // n_out odd: sample 2 w = avg[w] (squeeze.rs:434-437), always in the last chunk
+        if constexpr (HORIZ) oa[tid * PO + 2 * sc] = cur;
+        else oa[(2 * sc) * 64 + tid] = cur;
+      }
+    }
+    };
+  // the movers' iteration c in general (any mix of vector and dword chunks, the line's end)
+  auto mover_general = [&](int c) {
+    if (steps_of(c + 1) > 0) {
+      if (c + 1 < n_fast) {
+        if (vloader) stage_fast(c + 1);
+      } else {
+        stage_chunk(c + 1, pa, pr);
+      }
+    }
+    mark(0);
+    if constexpr (FLOW) {
+      // Report chunk c - 3, stored during iteration c - 2.  No wait of its own: vector memory operations of a wave
+      // complete in the order they were issued, the staging above has just consumed loads issued AFTER those stores
+      // (iteration c - 1), so they are acknowledged.  A wait for the stores themselves -- vmcnt(0) here -- would
+      // also wait for the stores of iteration c - 1, a write-through round trip that is longer than the chain
+      // wave's chunk: measured 3.0-3.2 us per chunk instead of 1.7.  Where that argument has a hole (nothing staged
+      // at a line's end; a group with fewer than 64 lines, where a wave may hold stores but no loads) the wait is
+      // explicit.
+      // Vector chunks: chunks c - 3 and c - 2 both went out as the storer waves' eight stores per iteration, so
+      // "all but the newest eight acknowledged" is exact (the loader wave has no stores to wait for).
+      if (c >= 3 && !(JXLH_FLOW_EXP & 4)) {
+        if (c - 2 < n_fast) {
+          if (!vloader) __builtin_amdgcn_s_waitcnt(0x0f78);  // vmcnt(8)
+        } else if (n_fast > 0 || steps_of(c + 1) == 0 || l0 + 64 > n_lines) {
+          __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
+        }
+        asm volatile("" ::: "memory");
+        flow_publish(min(n_out, 2 * S * (c - 2)));
+      }
+    }
+    mark(1);
+    if (steps_of(c + 2) > 0) {
+      if (c + 2 < n_fast) {
+        if (vloader) fetch_fast(c + 2);
+      } else {
+        fetch_chunk(c + 2, pa, pr);
+      }
+    }
+    mark(2);
+    // (before the stores: reading it back must not wait for them)
+    if (steps_of(c + 3) > 0 && (vloader || c + 3 >= n_fast)) flow_peek();
+    mark(3);
+    if (c >= 1) {
+      if (c - 1 < n_fast) {
+        if (!vloader) store_fast(c - 1);
+      } else {
+        store_chunk(c - 1);
+      }
+    }
+    mark(4);
+  };
+  // ... and while chunks c - 1, c + 1 and c + 2 are all vector chunks: the same schedule with nothing but the vector
+  // movers in the loop.  Kept apart because the compiler's wait insertion does not follow which path a wave took: with
+  // the dword movers' registers and requests in the same loop it put a wait for ALL outstanding memory operations
+  // in front of the loader's next request (0.9 us per iteration, profiles/r05_i_*).
+  auto mover_steady = [&](int c) {
+    if (vloader) {
+      stage_fast(c + 1);
+      mark(0);
+      if constexpr (FLOW) {
+        if (c >= 3 && !(JXLH_FLOW_EXP & 4)) flow_publish(min(n_out, 2 * S * (c - 2)));
+      }
+      mark(1);
+      fetch_fast(c + 2);
+      mark(2);
+      if (steps_of(c + 3) > 0) flow_peek();
+      mark(3);
+      mark(4);
+    } else {
+      if constexpr (FLOW) {
+        if (c >= 3 && !(JXLH_FLOW_EXP & 4)) {
+          __builtin_amdgcn_s_waitcnt(0x0f78);  // vmcnt(8): everything but the previous iteration's eight stores
+          asm volatile("" ::: "memory");
+          flow_publish(min(n_out, 2 * S * (c - 2)));
+        }
+      }
+      if (c >= 1) store_fast(c - 1);
+    }
+  };
+  auto end_of_iteration = [&]() {
+    if constexpr (FLOW && (JXLH_FLOW_EXP & 64)) {
+      lds_barrier();
+      if (!chain) mark(5);
+    } else if constexpr (FLOW && (JXLH_FLOW_EXP & 16)) {  // experiment: the chain wave's time at the barrier
+      const unsigned long long tb = __builtin_amdgcn_s_memrealtime();
+      lds_barrier();
+      if (chain) F.wait_ticks += __builtin_amdgcn_s_memrealtime() - tb;
+    } else {
+      lds_barrier();
+    }
+  };
+  int c = 0;
+  for (; c + 2 < n_fast; c++) {
+    mark(-1);
+    if (chain) chain_chunk(c);
+    else mover_steady(c);
+    end_of_iteration();
+  }
+  for (; c < n_chunks; c++) {
+    mark(-1);
+    if (chain) chain_chunk(c);
+    else mover_general(c);
+    end_of_iteration();
+  }
+  if (!chain && n_chunks > 0) {
+    if (n_chunks - 1 < n_fast) {
+      if (!vloader) store_fast(n_chunks - 1);
+    } else {
+      store_chunk(n_chunks - 1);
+    }
+    if constexpr (FLOW) {
+      __builtin_amdgcn_s_waitcnt(0x0f70);
+      flow_publish(n_out);
+    }
+  }
+}
+
+
+template <bool HORIZ>
+__global__ __launch_bounds__(256) void k6_unsqueeze_tiled(const SqueezePlanes pl, size_t avg_lp, size_t avg_ep,
+                                                          size_t res_lp, size_t res_ep, size_t out_lp, size_t out_ep,
+                                                          int n_lines, int n_out, int vec) {
+  constexpr int S = JXLH_SQT_S, PI = JXLH_SQT_PI, PO = JXLH_SQT_PO;
+  constexpr int IN_ELEMS = HORIZ ? 64 * PI : 64 * S, OUT_ELEMS = HORIZ ? 64 * PO : 64 * 2 * S;
+  __shared__ __attribute__((aligned(16))) int32_t s_avg[2 * IN_ELEMS];
+  __shared__ __attribute__((aligned(16))) int32_t s_res[2 * IN_ELEMS];
+  __shared__ __attribute__((aligned(16))) int32_t s_out[2 * OUT_ELEMS];
+  TiledLines T;
+  T.ga = pl.avg[blockIdx.y];
+  T.gr = pl.res[blockIdx.y];
+  T.go = pl.out[blockIdx.y];
+  T.alp = (uint32_t)avg_lp; T.aep = (uint32_t)avg_ep; T.rlp = (uint32_t)res_lp; T.rep = (uint32_t)res_ep;
+  T.olp = (uint32_t)out_lp; T.oep = (uint32_t)out_ep;
+  T.n_lines = n_lines; T.n_out = n_out; T.l0 = blockIdx.x * 64;
+  T.vec = vec;
+  FlowLink F{};
+  unsqueeze_tiled_lines<HORIZ, false>(T, s_avg, s_res, s_out, F, nullptr);
+}
+
+// ---- The streamed levels of a squeeze chain as ONE launch (dataflow).  Run level by level, a chain costs the SUM of
+// its levels' line lengths in dependent steps (16 368 for 8192^2: every level waits for the whole level before it).
+// But a step only needs the averages NEAR its own position: row group g of a horizontal step can start as soon as the
+// vertical step before it has finished rows [64 g, 64 g + 64) -- in all its column groups, which advance together --
+// and a column group of the NEXT vertical step follows the row groups of this one at half their speed.  The critical
+// path is then monotone in both image axes: about one line of the finest horizontal level plus one of the finest
+// vertical one, not the sum over the levels; coarse levels finish under the start of the fine ones.
+// Workgroups take tickets (an atomic counter) and tickets are handed out level by level, lowest group first: a
+// workgroup only ever waits for lower tickets, which are running or done -- no residency assumption, no deadlock.
+// Each level writes its own plane set (no ping-pong: level i + 2 would overwrite what level i + 1 still reads).
+constexpr int kFlowMaxLevels = 16;
+struct FlowLevel {
+  const int32_t* avg[3];
+  const int32_t* res[3];
+  int32_t* out[3];
+  uint32_t avg_lp, avg_ep, res_lp, res_ep, out_lp, out_ep;
+  int n_lines, n_out;
+  int horiz;
+  int first_wg;  // ticket of the level's first workgroup; workgroup = group * n_planes + plane
+  int groups;    // 64-line groups per plane
+  int flag0;     // index of the level's first progress word (plane-major)
+  int dep_same_axis;
+  int vec;  // TiledLines::vec
+};
+struct FlowArgs {
+  int n_levels, n_planes;
+  int* ticket;    // zero at launch
+  int* progress;  // zero at launch
+  int* error;
+  unsigned long long deadline_ticks;
+  // optional profile (nullptr: none), five rows of kFlowMaxLevels: first start (min, preset to ~0), last end (max), time
+  // the first mover wave of every workgroup spent polling (sum), its polls (sum), workgroup lifetimes (sum);
+  // s_memrealtime ticks
+  unsigned long long* prof;
+  FlowLevel lv[kFlowMaxLevels];
+};
+__global__ __launch_bounds__(256) void k6_unsqueeze_flow(const FlowArgs A) {
+  constexpr int PI = JXLH_SQT_PI, PO = JXLH_SQT_PO;
+  __shared__ __attribute__((aligned(16))) int32_t s_avg[2 * 64 * PI];
+  __shared__ __attribute__((aligned(16))) int32_t s_res[2 * 64 * PI];
+  __shared__ __attribute__((aligned(16))) int32_t s_out[2 * 64 * PO];
+  __shared__ int s_ticket, s_pub;
+  if (threadIdx.x == 0) {
+    s_ticket = atomicAdd(A.ticket, 1);
+    s_pub = 0;
+  }
+  __syncthreads();
+  const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+  const int t = __builtin_amdgcn_readfirstlane(s_ticket);
+  int li = 0;
+  for (int i = 1; i < A.n_levels; i++) li = t >= A.lv[i].first_wg ? i : li;
+  const FlowLevel& L = A.lv[li];
+  // everything below is the same for the whole workgroup; the compiler does not see it (the level is found by the
+  // ticket, the ticket comes out of LDS) and would do the address arithmetic per lane: said explicitly
+  auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane(v); };
+  auto uni_ptr = [&](const int32_t* p) {
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    // (through a global-address-space pointer: rebuilt from an integer it would be a generic one, and every access
+    // through it a flat_ instruction, which counts on both memory counters)
+    typedef __attribute__((address_space(1))) int32_t global_i32;
+    return (int32_t*)(global_i32*)((uint64_t)uni((uint32_t)(v >> 32)) << 32 | uni((uint32_t)v));
+  };
+  const int local = t - (int)uni(L.first_wg), n_planes = (int)uni(A.n_planes);
+  const int plane = (int)uni(local % n_planes), g = (int)uni(local / n_planes);
+  TiledLines T;
+  T.ga = uni_ptr(L.avg[plane]);
+  T.gr = uni_ptr(L.res[plane]);
+  T.go = uni_ptr(L.out[plane]);
+  T.alp = uni(L.avg_lp); T.aep = uni(L.avg_ep); T.rlp = uni(L.res_lp); T.rep = uni(L.res_ep);
+  T.olp = uni(L.out_lp); T.oep = uni(L.out_ep);
+  T.n_lines = (int)uni(L.n_lines); T.n_out = (int)uni(L.n_out); T.l0 = g * 64;
+  T.vec = (int)uni(L.vec);
+  FlowLink F;
+  F.dep = li > 0 ? uni_ptr(A.progress + (A.lv[li - 1].flag0 + plane * A.lv[li - 1].groups) * kFlowWordStride) : nullptr;
+  F.dep_same_axis = (int)uni(L.dep_same_axis);
+  F.mine = uni_ptr(A.progress + (L.flag0 + plane * L.groups + g) * kFlowWordStride);
+  F.error = A.error;
+  F.deadline_ticks = A.deadline_ticks;
+  F.wait_ticks = 0;
+  F.polls = 0;
+  for (int i = 0; i < 6; i++) F.phase[i] = 0;
+  if (uni(L.horiz)) unsqueeze_tiled_lines<true, true>(T, s_avg, s_res, s_out, F, &s_pub);
+  else unsqueeze_tiled_lines<false, true>(T, s_avg, s_res, s_out, F, &s_pub);
+  if ((JXLH_FLOW_EXP & 16) && A.prof && threadIdx.x == 0) atomicAdd(&A.prof[2 * kFlowMaxLevels + li], F.wait_ticks);
+  if (A.prof && threadIdx.x == 64) {
+    atomicMin(&A.prof[li], t_start);
+    atomicMax(&A.prof[kFlowMaxLevels + li], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    if (!(JXLH_FLOW_EXP & 16)) atomicAdd(&A.prof[2 * kFlowMaxLevels + li], F.wait_ticks);
+    atomicAdd(&A.prof[3 * kFlowMaxLevels + li], (unsigned long long)F.polls);
+    atomicAdd(&A.prof[4 * kFlowMaxLevels + li], (unsigned long long)__builtin_amdgcn_s_memrealtime() - t_start);
+    if constexpr ((JXLH_FLOW_EXP & 64) != 0)
+      for (int i = 0; i < 6; i++) atomicAdd(&A.prof[(5 + i) * kFlowMaxLevels + li], F.phase[i]);
+  }
 }
 
 // The last step of a colour image's squeeze chain is an unsqueeze of three channels at full size (vertical for square
@@ -1486,6 +1926,20 @@ __global__ __launch_bounds__(64 * (3 * NCW + 1)) void k6_unsqueeze_rct(const Squ
   if (storer && n_chunks > 0) store_chunk(n_chunks - 1, count_of(n_chunks - 1));
 }
 
+// TiledLines::vec: may the tiled kernels move this step with 16-byte buffer accesses?  (JXLH_SQ_VEC=0: never -- tests, A/B)
+static int tiled_vec_ok(int horizontal, int n_planes, const int32_t* const avg[], size_t avg_stride, const int32_t* const res[],
+                        size_t res_stride, uint32_t out_w, uint32_t out_h, int32_t* const out[], size_t out_stride) {
+  static const bool off = getenv("JXLH_SQ_VEC") && getenv("JXLH_SQ_VEC")[0] == '0';
+  if (off) return 0;
+  if (avg_stride % 4 || res_stride % 4 || out_stride % 4) return 0;
+  if (!horizontal && out_w % 4) return 0;  // (lines are columns: a 64-column group must be whole quads -- it is; the planes' rows must be)
+  for (int i = 0; i < n_planes && i < 3; i++)
+    if ((uintptr_t)avg[i] % 16 || (uintptr_t)res[i] % 16 || (uintptr_t)out[i] % 16) return 0;
+  // every byte offset from a plane's first sample fits 32 bits, with room for the kernel's slot arithmetic
+  const size_t lim = (size_t)1 << 30;
+  return out_stride * (size_t)out_h < lim && avg_stride * (size_t)out_h < lim && res_stride * (size_t)out_h < lim;
+}
+
 void launch_unsqueeze(hipStream_t s, int horizontal, int n_planes, const int32_t* const avg[], size_t avg_stride,
                       const int32_t* const res[], size_t res_stride, uint32_t out_w, uint32_t out_h,
                       int32_t* const out[], size_t out_stride) {
@@ -1506,12 +1960,13 @@ void launch_unsqueeze(hipStream_t s, int horizontal, int n_planes, const int32_t
       res_stride * (size_t)out_h < ((size_t)1 << 31)) {
     const int n_lines = (int)(horizontal ? out_h : out_w);
     const dim3 grid((n_lines + 63) / 64, n_planes);
+    const int vec = tiled_vec_ok(horizontal, n_planes, avg, avg_stride, res, res_stride, out_w, out_h, out, out_stride);
     if (horizontal)
       hipLaunchKernelGGL(k6_unsqueeze_tiled<true>, grid, dim3(256), 0, s, pl, avg_stride, (size_t)1, res_stride,
-                         (size_t)1, out_stride, (size_t)1, n_lines, (int)out_w);
+                         (size_t)1, out_stride, (size_t)1, n_lines, (int)out_w, vec);
     else
       hipLaunchKernelGGL(k6_unsqueeze_tiled<false>, grid, dim3(256), 0, s, pl, (size_t)1, avg_stride, (size_t)1,
-                         res_stride, (size_t)1, out_stride, n_lines, (int)out_h);
+                         res_stride, (size_t)1, out_stride, n_lines, (int)out_h, vec);
     return;
   }
   if (horizontal) {
@@ -1530,6 +1985,71 @@ void launch_unsqueeze(hipStream_t s, int horizontal, int n_planes, const int32_t
     hipLaunchKernelGGL(k6_unsqueeze<false>, grid, dim3(64), 0, s, pl, (size_t)1, avg_stride, (size_t)1, res_stride,
                        (size_t)1, out_stride, n_lines, (int)out_h);
   }
+}
+
+// ---- dataflow launch of consecutive tiled steps (see k6_unsqueeze_flow)
+bool unsqueeze_tiled_eligible(int horizontal, uint32_t out_w, uint32_t out_h, size_t avg_stride, size_t res_stride,
+                              size_t out_stride) {
+  const int n_steps = (int)(horizontal ? out_w : out_h) / 2;
+  const size_t lim = (size_t)1 << 31;
+  return n_steps >= 4 * JXLH_SQT_S && out_stride * (size_t)out_h < lim && avg_stride * (size_t)out_h < lim &&
+         res_stride * (size_t)out_h < lim;
+}
+int unsqueeze_flow_max_steps() { return kFlowMaxLevels; }
+size_t unsqueeze_flow_words(int n_planes, int n_steps, const FlowStep* steps) {
+  size_t words = 2 * kFlowWordStride;  // the ticket; slack behind the last word (a peek may look one word past a level's groups)
+  for (int i = 0; i < n_steps; i++) {
+    const int n_lines = (int)(steps[i].horizontal ? steps[i].out_h : steps[i].out_w);
+    words += (size_t)n_planes * ((n_lines + 63) / 64) * kFlowWordStride;
+  }
+  return words;
+}
+void launch_unsqueeze_flow(hipStream_t s, int n_planes, int n_steps, const FlowStep* steps, int* scratch, int* error,
+                           float deadline_s, unsigned long long* prof) {
+  FlowArgs A{};
+  A.n_levels = n_steps;
+  A.n_planes = n_planes;
+  A.ticket = scratch;
+  A.progress = scratch + kFlowWordStride;
+  A.error = error;
+  A.deadline_ticks = (unsigned long long)(deadline_s * 1.0e8);
+  int wg = 0, flag = 0;
+  for (int i = 0; i < n_steps; i++) {
+    const FlowStep& st = steps[i];
+    FlowLevel& L = A.lv[i];
+    for (int p = 0; p < 3; p++) {
+      const int q = p < n_planes ? p : 0;
+      L.avg[p] = st.avg[q];
+      L.res[p] = st.res[q];
+      L.out[p] = st.out[q];
+    }
+    const bool hz = st.horizontal != 0;
+    L.avg_lp = hz ? (uint32_t)st.avg_stride : 1u;
+    L.avg_ep = hz ? 1u : (uint32_t)st.avg_stride;
+    L.res_lp = hz ? (uint32_t)st.res_stride : 1u;
+    L.res_ep = hz ? 1u : (uint32_t)st.res_stride;
+    L.out_lp = hz ? (uint32_t)st.out_stride : 1u;
+    L.out_ep = hz ? 1u : (uint32_t)st.out_stride;
+    L.n_lines = (int)(hz ? st.out_h : st.out_w);
+    L.n_out = (int)(hz ? st.out_w : st.out_h);
+    L.horiz = hz;
+    L.groups = (L.n_lines + 63) / 64;
+    L.first_wg = wg;
+    L.flag0 = flag;
+    L.dep_same_axis = i > 0 && (steps[i - 1].horizontal != 0) == hz;
+    L.vec = tiled_vec_ok(st.horizontal, n_planes, st.avg, st.avg_stride, st.res, st.res_stride, st.out_w, st.out_h, st.out,
+                         st.out_stride);
+    wg += L.groups * n_planes;
+    flag += L.groups * n_planes;
+  }
+  (void)hipMemsetAsync(scratch, 0, sizeof(int) * (size_t)(1 + flag) * kFlowWordStride, s);
+  A.prof = prof;
+  if (prof) {
+    (void)hipMemsetAsync(prof, 0xff, sizeof(unsigned long long) * kFlowMaxLevels, s);
+    (void)hipMemsetAsync(prof + kFlowMaxLevels, 0, sizeof(unsigned long long) * 10 * kFlowMaxLevels, s);
+  }
+  static const int lds_pad = getenv("JXLH_FLOW_LDS_PAD") ? atoi(getenv("JXLH_FLOW_LDS_PAD")) : 0;  // experiments: residency
+  hipLaunchKernelGGL(k6_unsqueeze_flow, dim3(wg), dim3(256), (size_t)lds_pad, s, A);
 }
 
 // Unsqueeze of three channels + inverse RCT on them, one pass (planes below 2^31 samples; the caller falls back to

@@ -60,6 +60,7 @@ ABI_SYMBOLS = [
 DEV_SYMBOLS = [
     "jxlh_timer_start", "jxlh_timer_stop", "jxlh_kernel_timing_enable", "jxlh_kernel_timing_get",
     "jxlh_kernel_timing_reset", "jxlh_selftest_recip", "jxlh_probe_copy_bandwidth", "jxlh_frame_path",
+    "jxlh_flow_profile",
 ]
 
 
@@ -147,6 +148,7 @@ def load():
     L.jxlh_stage_noise_add.argtypes = [vp, C.POINTER(FrameParams), C.POINTER(vp), C.POINTER(vp), sz]
     L.jxlh_set_upsampling_weights.argtypes = [vp, vp, vp, vp]
     L.jxlh_selftest_recip.argtypes = [vp, u32, u32, C.POINTER(C.c_uint64)]
+    L.jxlh_flow_profile.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(C.c_uint64), i32]
     L.jxlh_frame_set_dequant_tables.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
     L.jxlh_frame_set_lf_quantized.argtypes = [vp, u32, u32, u32, u32, vp, vp, vp, sz, u32]
     L.jxlh_frame_set_lf.argtypes = [vp, u32, u32, u32, u32, vp, vp, vp, sz]
@@ -730,6 +732,20 @@ class Context:
         self._chk(self.L.jxlh_selftest_recip(self._ctx, C.c_uint32(lo_b), C.c_uint32(hi_b), C.byref(bad)),
                   "selftest_recip")
         return int(bad.value)
+
+    def flow_profile(self, enable=True):
+        """timeline of the last dataflow squeeze launch (if profiling was on): a list of per-level dicts, times in us
+        from the first level's start; then switches the profile on / off for the launches that follow"""
+        n = C.c_int32(0)
+        rows = (C.c_uint64 * (11 * 16))()
+        self._chk(self.L.jxlh_flow_profile(self._ctx, 1 if enable else 0, C.byref(n), rows, 16), "flow_profile")
+        if n.value == 0:
+            return []
+        t0 = min(rows[11 * i] for i in range(n.value))
+        return [{"start_us": (rows[11 * i] - t0) / 100.0, "end_us": (rows[11 * i + 1] - t0) / 100.0,
+                 "poll_wait_us_sum": rows[11 * i + 2] / 100.0, "polls": int(rows[11 * i + 3]),
+                 "lifetime_us_sum": rows[11 * i + 4] / 100.0,
+                 "mover_phases_us_sum": [rows[11 * i + 5 + k] / 100.0 for k in range(6)]} for i in range(n.value)]
 
     def stage_gaborish(self, plane, w1, w2, w=None, h=None):
         plane = np.ascontiguousarray(plane, dtype=np.float32)

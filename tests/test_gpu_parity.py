@@ -1751,3 +1751,35 @@ def test_concurrent_submission_from_host_threads(oracle, form):
                     f"{form} rep {rep} plane {c}: {helpers.diff_report(out['planes'][c], want[c])}"
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("size", [(2048, 1536), (4099, 1030), (3000, 8), (8, 2500), (1200, 4097), (640, 641)])
+@pytest.mark.parametrize("rct", [None, (6, 0)])
+def test_unsqueeze_chain_dataflow_launch(ctx, oracle, size, rct, monkeypatch):
+    """The streamed levels of a chain as ONE dataflow launch (k6_unsqueeze_flow: a level starts on the rows / columns the
+    level before it has finished, progress words between workgroups) against the level-by-level launches
+    (JXLH_CHAIN_FLOW=0) and the oracle.  Sizes: square-ish (alternating directions), ragged (odd lines, a last partial
+    group), flat and tall images (several steps of ONE direction in a row: the consumer follows the producer's own
+    lines), with and without the fused last level.  Run twice: the second call meets the first one's planes and
+    progress words."""
+    from jxl_rs_amd.modular import ModularChain
+    w, h = size
+    ch = ModularChain(ctx, w, h, seed=5 * w + h, rct=rct)
+    try:
+        want = helpers.modular_chain_oracle(ch, oracle)
+        for rep in range(2):
+            for d in ch.d_out:
+                d.upload(np.full(w * h, -77, np.int32))
+            ch.run_chain()
+            ctx.sync()
+            got = ch.result()
+            for c in range(3):
+                assert np.array_equal(got[c], want[c]), ("flow", size, rct, c, rep, np.argwhere(got[c] != want[c])[:5])
+        monkeypatch.setenv("JXLH_CHAIN_FLOW", "0")
+        ch.run_chain()
+        ctx.sync()
+        got = ch.result()
+        for c in range(3):
+            assert np.array_equal(got[c], want[c]), ("levels", size, rct, c)
+    finally:
+        ch.free()
