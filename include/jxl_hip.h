@@ -549,9 +549,13 @@ jxlh_status jxlh_unsqueeze_levels(jxlh_ctx* ctx, int32_t n_planes, int32_t n_lev
  * order the decoder applies the steps of default_squeeze / an explicit SqueezeParams list in, squeeze.rs:39-105,
  * transforms/apply.rs), optionally followed by the RCT that comes next in the transform list (rct_op 0..6 and
  * rct_perm 0..5 as in jxlh_rct, n_planes == 3; rct_op < 0: none) -- the last, full-resolution step and the RCT are
- * then one pass over the planes.  The library picks the launch per level (LDS-resident first levels, streamed middle
- * levels, fused last level); intermediate planes live in context scratch.  Device pointers only; `out` may not alias
- * the base or residual planes. */
+ * then one pass over the planes.  The library picks the launches (LDS-resident first levels; the streamed middle
+ * levels as ONE dataflow launch in which a level starts on the rows / columns the level before it has finished;
+ * fused last level); intermediate planes live in context scratch.  Device pointers only; `out` may not alias
+ * the base or residual planes.  Asynchronous like every call on the context's stream; should a wait between two
+ * levels of the dataflow launch ever outlast its deadline (4 s: a fault, not a load condition), the launch ends with
+ * an undefined result and the next jxlh_ctx_sync returns JXLH_ERR_DEVICE.  JXLH_CHAIN_FLOW=0 in the environment
+ * selects one launch per streamed level (same result; tests, A/B). */
 jxlh_status jxlh_unsqueeze_chain(jxlh_ctx* ctx, int32_t n_planes, int32_t n_levels, const jxlh_squeeze_level* levels,
                                  const int32_t* const base[], size_t base_stride, uint32_t base_w, uint32_t base_h,
                                  int32_t* const out[], size_t out_stride, int32_t rct_op, int32_t rct_perm);

@@ -1151,9 +1151,12 @@ __device__ __forceinline__ void unsqueeze_tiled_lines(const TiledLines& T, int32
         F.polls++;
         // back off: hundreds of workgroups of the later levels wait for most of the launch, and their polls all end
         // at the memory channels that hold the words the running levels publish and peek at
+#ifndef JXLH_FLOW_NAP
+#define JXLH_FLOW_NAP 96
+#endif
         if (++spins < 8) __builtin_amdgcn_s_sleep(4);
-        else if (spins < 24) __builtin_amdgcn_s_sleep(24);
-        else __builtin_amdgcn_s_sleep(96);
+        else if (spins < 24) __builtin_amdgcn_s_sleep(JXLH_FLOW_NAP < 24 ? JXLH_FLOW_NAP : 24);
+        else __builtin_amdgcn_s_sleep(JXLH_FLOW_NAP);
         if ((spins & 255) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > F.deadline_ticks) {
           atomicExch(F.error, JXLH_ERR_DEVICE);
           v = -1;
