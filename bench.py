@@ -185,6 +185,11 @@ def time_modular_config(jxl_rs_amd, np, device, size, steps, cores, cpu=True):
         return ctx.timer_stop() / reps
 
     chain_ms = timed(ch.run_chain, steps)
+    # the same call with one launch per streamed level instead of the dataflow launch (JXLH_CHAIN_FLOW=0: what rounds
+    # 2-4 timed, now with the vector movers), for the A/B on the box the line is measured on
+    os.environ["JXLH_CHAIN_FLOW"] = "0"
+    levels_ms = timed(ch.run_chain, steps)
+    del os.environ["JXLH_CHAIN_FLOW"]
     t0 = time.perf_counter()
     for _ in range(steps):
         ch.run_chain()
@@ -212,13 +217,15 @@ def time_modular_config(jxl_rs_amd, np, device, size, steps, cores, cpu=True):
                      "unit": "MP/s", "algorithmic_bytes": int(final), "bytes_per_final_sample": 16,
                      "achieved_GBs": round(final / (chain_ms * 1e-3) / 1e9, 1),
                      "frac": round(final / (chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                     "level_by_level_ms": round(levels_ms, 4),
+                     "launches": "first levels in LDS + the streamed levels as one dataflow launch + last level fused with the RCT",
                      "bytes_written_levels": int(8.0 * ch.samples_written),
                      "dependent_steps_on_the_longest_line": int(sum(ow if hz else oh for hz, ow, oh in ch.steps) // 2)},
            "palette": {"ms": round(pal_ms, 4), "algorithmic_bytes": int(16.0 * npx),
                        "frac": round(16.0 * npx / (pal_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
            "rct_alone": {"ms": round(rct_ms, 4), "algorithmic_bytes": int(24.0 * npx),
                          "frac": round(24.0 * npx / (rct_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
-           "pmc_file": "profiles/r03_m_modular_pmc.txt"}
+           "pmc_file": "profiles/r05_k_modular_pmc.txt", "timeline_file": "profiles/r05_i_modular_flow.txt"}
     if cpu:
         # the oracle's step-by-step chain + RCT on the same planes, one thread per channel (ctypes releases the GIL)
         from concurrent.futures import ThreadPoolExecutor

@@ -1783,3 +1783,32 @@ def test_unsqueeze_chain_dataflow_launch(ctx, oracle, size, rct, monkeypatch):
             assert np.array_equal(got[c], want[c]), ("levels", size, rct, c)
     finally:
         ch.free()
+
+
+def test_flow_profile_reports_the_dataflow_launch(ctx, oracle):
+    """jxlh_flow_profile (jxl_hip_dev.h): the per-level timeline of the dataflow launch -- every level of the launch is
+    there, starts before it ends, the levels end in order, and a later level starts before the one before it has ended
+    (that overlap is what the launch is for)."""
+    from jxl_rs_amd.modular import ModularChain
+    ch = ModularChain(ctx, 2048, 2048, seed=3, rct=(6, 0))
+    try:
+        assert ctx.flow_profile(True) == []           # nothing recorded yet; profiling on from here
+        ch.run_chain()
+        ctx.sync()
+        rows = ctx.flow_profile(False)
+        # 2048^2: LDS levels up to 128^2, then H 256x128 ... H 2048x1024 in the dataflow launch, V 2048^2 fused with the RCT
+        assert len(rows) == 7, rows
+        for r in rows:
+            assert r["end_us"] > r["start_us"] >= 0.0 and r["lifetime_us_sum"] > 0.0
+        ends = [r["end_us"] for r in rows]
+        assert ends == sorted(ends)
+        assert rows[-1]["start_us"] < rows[-2]["end_us"]
+        got = ch.result()
+        want = helpers.modular_chain_oracle(ch, oracle)
+        for c in range(3):
+            assert np.array_equal(got[c], want[c])
+        ch.run_chain()                                  # profiling off again: nothing new is recorded
+        ctx.sync()
+        assert ctx.flow_profile(False) == []
+    finally:
+        ch.free()

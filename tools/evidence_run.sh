@@ -10,3 +10,6 @@ python tools/pmc_summary.py gpurun_out/prof_evidence_slots $O/slots_pmc.txt $O/s
 cp gpurun_out/prof_evidence_dense/trace/t_kernel_stats.csv $O/dense_kernel_stats.csv
 cp gpurun_out/prof_evidence_slots/trace/t_kernel_stats.csv $O/slots_kernel_stats.csv
 grep -A9 "^derived" $O/slots_pmc.txt | cut -c1-200
+PROFILE_CMD="python $GRAFT_REPO_ROOT/tools/chain_flow_time.py 8192 5" bash tools/gpu_profile.sh evidence_modular > $O/prof_modular.log 2>&1
+python tools/pmc_summary.py gpurun_out/prof_evidence_modular $O/modular_pmc.txt $O/modular_traffic.json > /dev/null
+cp gpurun_out/prof_evidence_modular/trace/t_kernel_stats.csv $O/modular_kernel_stats.csv

@@ -10,7 +10,8 @@ from collections import defaultdict
 
 def short(name):
     for key in ("k123_strip", "k1_vardct_group", "k1_scan", "k1_dct8", "k1_dct16_32", "k1_dct16", "k1_dct32", "k1_special", "k1_large_units", "k1_large_fused", "k1_large_llf", "k1_large_pass<1>", "k1_large_pass<2>", "k1_large", "k23_fused_filters", "k2_gaborish", "k3_epf", "k0b_lf_smooth", "k3_sigma_map",
-                "k4_rct", "k5_palette", "k6_unsqueeze"):
+                "k4_rct", "k5_palette", "k6_unsqueeze_flow", "k6_unsqueeze_rct", "k6_unsqueeze_levels", "k6_unsqueeze_tiled",
+                "k6_unsqueeze"):
         if key in name:
             return key + (name[name.index("<"):name.index(">") + 1] if "<" in name and key in ("k3_epf", "k23_fused_filters") else "")
     return None
