@@ -366,10 +366,15 @@ jxlh_status jxlh_unsqueeze_chain(jxlh_ctx* ctx, int32_t n_planes, int32_t n_leve
   // intermediate planes: every level but the last writes its own plane set in context scratch (levels overlap in
   // the dataflow launch below, so no ping-pong; the sizes halve per level: about twice the largest one in all)
   jxlh_status st;
-  size_t level_off[64], arena = 0;
+  // Rows of the intermediate planes are padded to whole 16 bytes and every plane starts on a 256-byte line: with the
+  // caller's residual planes laid out the same way the tiled kernels move every level with 16-byte accesses whatever
+  // the image width is (tiled_vec_ok).
+  size_t level_off[64], level_stride[64], level_plane[64], arena = 0;
   for (int i = 0; i < n_levels - 1; i++) {
     level_off[i] = arena;
-    arena += ((size_t)levels[i].out_w * levels[i].out_h * n_planes + 63) & ~(size_t)63;  // 256-byte aligned sets
+    level_stride[i] = ((size_t)levels[i].out_w + 3) & ~(size_t)3;
+    level_plane[i] = (level_stride[i] * levels[i].out_h + 63) & ~(size_t)63;
+    arena += level_plane[i] * n_planes;
   }
   if ((st = ensure(ctx, ctx->hook_i[0], std::max<size_t>(arena, 1)))) return st;
   ScopedKernelTimer t(ctx, "k6_unsqueeze_chain");
@@ -379,8 +384,8 @@ jxlh_status jxlh_unsqueeze_chain(jxlh_ctx* ctx, int32_t n_planes, int32_t n_leve
   auto dst_of = [&](int i, int32_t* dst[3], size_t* stride) {
     const bool last = i == n_levels - 1;
     for (int p = 0; p < n_planes; p++)
-      dst[p] = last ? out[p] : ctx->hook_i[0].p + level_off[i] + (size_t)p * levels[i].out_w * levels[i].out_h;
-    *stride = last ? out_stride : levels[i].out_w;
+      dst[p] = last ? out[p] : ctx->hook_i[0].p + level_off[i] + (size_t)p * level_plane[i];
+    *stride = last ? out_stride : level_stride[i];
   };
   int i = 0;
   // ---- the first levels, while the planes fit LDS: one launch (the chain starts from <= 8 x 8)

@@ -1812,3 +1812,51 @@ def test_flow_profile_reports_the_dataflow_launch(ctx, oracle):
         assert ctx.flow_profile(False) == []
     finally:
         ch.free()
+
+
+@pytest.mark.parametrize("size", [(2051, 1030), (1030, 2051), (4097, 258)])
+@pytest.mark.parametrize("rct", [None, (6, 0)])
+def test_unsqueeze_chain_padded_planes_of_ragged_sizes(ctx, oracle, size, rct):
+    """Ragged image sizes on planes laid out as the header advises (16-byte aligned, strides a multiple of 4 samples): the
+    streamed levels then take the 16-byte movers for their complete 64-line groups and chunks, the 4-byte movers for the
+    ragged last group and a line's last chunks -- both inside one launch, next to the library's own padded intermediate
+    planes.  Padding is poisoned and must come back untouched."""
+    from jxl_rs_amd import synth
+    from helpers import DeviceArray
+    w, h = size
+    base, residuals, steps = synth.make_modular_planes(w, h, seed=w ^ h)
+    want = [b.copy() for b in base]
+    for (hz, ow, oh), res in zip(steps, residuals):
+        want = [oracle.unsqueeze_h(want[c], res[c], ow) if hz else oracle.unsqueeze_v(want[c], res[c], oh) for c in range(3)]
+    if rct is not None:
+        want = oracle.rct(want, *rct)
+    pad4 = lambda n: (n + 3) & ~3
+    bufs = []
+
+    def padded(a):
+        s = max(pad4(a.shape[1]), 4)
+        m = np.full((max(a.shape[0], 1), s), -12345, np.int32)
+        m[:a.shape[0], :a.shape[1]] = a
+        d = DeviceArray(m)
+        bufs.append(d)
+        return d, s
+
+    d_base = [padded(b) for b in base]
+    levels = []
+    for (hz, ow, oh), res in zip(steps, residuals):
+        pr = [padded(r) for r in res]
+        levels.append((hz, ow, oh, [d.ptr if res[0].size else None for d, _ in pr], pr[0][1]))
+    stride = pad4(w)
+    d_out = [DeviceArray(np.full((h, stride), -777, np.int32)) for _ in range(3)]
+    bufs += d_out
+    try:
+        ctx.unsqueeze_chain(levels, [d.ptr for d, _ in d_base], d_base[0][1], base[0].shape[1], base[0].shape[0],
+                            [d.ptr for d in d_out], stride, rct=rct)
+        ctx.sync()
+        for c in range(3):
+            got = d_out[c].download(np.int32, h * stride).reshape(h, stride)
+            assert np.array_equal(got[:, :w], want[c]), (size, rct, c, np.argwhere(got[:, :w] != want[c])[:5])
+            assert (got[:, w:] == -777).all()
+    finally:
+        for d in bufs:
+            d.free()
