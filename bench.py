@@ -837,7 +837,10 @@ def main():
     if rank == 0 and n_gpus == 1 and not args.no_e2e and torch.cuda.is_available():
         e2e = {}
         ng = wl.coeffs.shape[0]
-        nslots = int(os.environ.get('JXLH_BENCH_SLOTS', '2'))
+        # slot streams per context: the slot-bucketed legs (and the resident ones) run on contexts with ONE, the older
+        # transports afterwards on contexts with JXLH_BENCH_SLOTS (2) -- see the switch in the leg loop
+        nslots_legacy = int(os.environ.get('JXLH_BENCH_SLOTS', '2'))
+        nslots = 1
         NE = 2  # frames in flight in the PCIe legs (3 contexts measured slower: their 9 streams alias on the
         #         runtime's few hardware queues and serialise)
         ectx = [jxl_rs_amd.Context(local_rank, n_slots=nslots) for _ in range(NE)]
@@ -864,7 +867,7 @@ def main():
         pin_d, pin_d_addr = ectx[0].alloc_pinned(wl.coeffs.nbytes)
         pin_d.view(np.int32)[:] = wl.coeffs.reshape(-1)
         ids = np.arange(ng, dtype=np.uint32)
-        per = (ng + nslots - 1) // nslots
+        per_of = lambda: (ng + nslots - 1) // nslots  # groups per slot stream (nslots changes between the legs)
         # the 3-byte form (u16 positions + i8 values) of the same pairs: the synthetic d1 values fit 8 bits
         allp = np.concatenate(runs)
         assert ((allp >> 16).astype(np.uint16).view(np.int16).astype(np.int32).__abs__() < 128).all()
@@ -900,7 +903,7 @@ def main():
 
         def submit_sparse4(c):
             for sl in range(nslots):
-                g0, g1 = sl * per, min(ng, (sl + 1) * per)
+                g0, g1 = sl * per_of(), min(ng, (sl + 1) * per_of())
                 if g0 < g1:
                     c.submit_groups_sparse4(ids[g0:g1], pin_e_addr + int(off_e[g0]) * 2, pin_c_addr + g0 * 96,
                                             pin_op_addr + int(off_o[g0]) * 2, pin_ov_addr + int(off_o[g0]),
@@ -925,9 +928,12 @@ def main():
         ns_ = np.concatenate(ns_).astype(np.uint32)
         bytes_slots = tot_s * 2 + ng * 3072
 
-        def submit_slots(c):
-            for sl in range(nslots):
-                g0, g1 = sl * per, min(ng, (sl + 1) * per)
+        def submit_slots(c, streams=None):
+            """streams = slot streams the frame's groups are spread over (default: all the context has)"""
+            k = streams or nslots
+            per_k = (ng + k - 1) // k
+            for sl in range(k):
+                g0, g1 = sl * per_k, min(ng, (sl + 1) * per_k)
                 if g0 < g1:
                     c.submit_groups_slots(ids[g0:g1], pin_se_addr + int(off_s[g0]) * 2, pin_sc_addr + g0 * 3072,
                                           ns_[3 * g0:3 * g1], None, slot=sl)
@@ -951,22 +957,24 @@ def main():
         n12 = np.concatenate(n12).astype(np.uint32)
         bytes_12 = tot12 + ng * 3072
 
-        def submit_slots12(c):
-            for sl in range(nslots):
-                g0, g1 = sl * per, min(ng, (sl + 1) * per)
+        def submit_slots12(c, streams=None):
+            k = streams or nslots
+            per_k = (ng + k - 1) // k
+            for sl in range(k):
+                g0, g1 = sl * per_k, min(ng, (sl + 1) * per_k)
                 if g0 < g1:
                     c.submit_groups_slots(ids[g0:g1], pin_12_addr + int(off12[g0]), pin_12c_addr + g0 * 3072,
                                           n12[3 * g0:3 * g1], None, slot=sl, flags=jl_.GROUP_COMPLETE | jl_.GROUP_ENTRIES12)
 
         def submit_sparse(c):
             for sl in range(nslots):
-                g0, g1 = sl * per, min(ng, (sl + 1) * per)
+                g0, g1 = sl * per_of(), min(ng, (sl + 1) * per_of())
                 if g0 < g1:
                     c.submit_groups_sparse(ids[g0:g1], pin_s_addr + int(offs[g0]) * 4, ns[3 * g0:3 * g1], None, slot=sl)
 
         def submit_sparse8(c):
             for sl in range(nslots):
-                g0, g1 = sl * per, min(ng, (sl + 1) * per)
+                g0, g1 = sl * per_of(), min(ng, (sl + 1) * per_of())
                 if g0 < g1:
                     c.submit_groups_sparse8(ids[g0:g1], pin_p_addr + int(offs[g0]) * 2, pin_v_addr + int(offs[g0]),
                                             ns[3 * g0:3 * g1], None, slot=sl)
@@ -1043,17 +1051,23 @@ def main():
             c.set_dequant_tables(wl.tables)
             c.set_lf_quantized(*wl.lf_q)
             c.set_hf_meta(wl.transform_map, wl.raw_quant, wl.epf_map, wl.ytox, wl.ytob)
-        legs = (("sparse_pairs", submit_sparse), ("sparse_pos16_val8", submit_sparse8), ("sparse_seg12_val4", submit_sparse4),
-                ("slots_pos6_val10_no_sort", submit_slots), ("slots_packed12_no_sort", submit_slots12),
-                ("dense_i32", submit_dense))
+        # (the slot-bucketed legs first, on the contexts with ONE slot stream each; the older transports on contexts with
+        # two, created after the first pair is closed -- see the switch below)
+        legs = (("slots_pos6_val10_no_sort", submit_slots), ("slots_packed12_no_sort", submit_slots12),
+                ("sparse_pairs", submit_sparse), ("sparse_pos16_val8", submit_sparse8), ("sparse_seg12_val4", submit_sparse4),
+                ("dense_i32", submit_dense), ("slots_to_host_rgb8", None))
         if os.environ.get("JXLH_BENCH_E2E_ORDER") == "swap":  # leg order experiment (first-leg warm-up effects)
             legs = (legs[1], legs[0]) + legs[2:]
-        def run_leg(submit, frames, pattern, after_run=None):
+        def run_leg(submit, frames, pattern, after_run=None, streams=None):
             """`frames` frames round robin over the contexts, each: submit -> frame_run (-> after_run).  pattern "marks"
             (round 5): the host then waits for the mark of that context's PREVIOUS frame only (jxlh_ctx_wait_mark), so the
             upload of a context's next frame runs under its current frame's kernels; "sync": round 4's loop, a full
             jxlh_ctx_sync of the context before its next submission.  Returns ms per frame."""
             marks = [None] * NE
+            ns_leg = streams or nslots  # slot streams this leg's submissions use
+            if streams is not None:
+                submit_all = submit
+                submit = lambda ctx_: submit_all(ctx_, streams)
             t0 = time.perf_counter()
             for i in range(frames):
                 k = i % NE
@@ -1065,8 +1079,8 @@ def main():
                     # context's has landed, the host does not block -- the bus stays busy back to back
                     for o in ectx:
                         if o is not c:
-                            for sl in range(nslots):
-                                for so in range(nslots):
+                            for sl in range(ns_leg):
+                                for so in range(ns_leg):
                                     c.slot_after(sl, o, so)
                 else:
                     # uploads serialised by the host: the OTHER context's upload has finished before this one starts, so
@@ -1074,7 +1088,7 @@ def main():
                     # this the marks loop is bistable: 0.70 or 0.93-1.2 ms per frame, tools/e2e_marks_probe.py
                     for o in ectx:
                         if o is not c:
-                            for sl in range(nslots):
+                            for sl in range(ns_leg):
                                 o.slot_wait(sl)
                 submit(c)
                 c.frame_run()
@@ -1088,7 +1102,59 @@ def main():
                 c.sync()
             return (time.perf_counter() - t0) * 1e3 / frames
 
+        def rgb8_leg():
+            # full decode-to-host: sparse pairs in, interleaved 8-bit sRGB out (jxlh_frame_read_rgb8) into
+            # pinned host memory; frame i's download overlaps frame i+1's upload and kernels
+            kk = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_kat.json")))["output_stage"]
+            bias = np.float32(kk["opsin_bias"])
+            xyb_params = np.concatenate([np.asarray(kk["opsin_inverse_matrix"], np.float32),
+                                         np.full(3, np.cbrt(bias), np.float32), np.full(3, bias, np.float32),
+                                         np.ones(1, np.float32)])
+            rgb_bytes = size * size * 3
+            pin_o = [ectx[i].alloc_pinned(rgb_bytes) for i in range(NE)]
+            import ctypes as C
+
+            def read_rgb(i):  # queued behind the frame's kernels on the context's stream; complete after c.sync()
+                c = ectx[i]
+                c._chk(c.L.jxlh_frame_read_rgb8_async(c._ctx, xyb_params.ctypes.data_as(C.c_void_p), 3, 0, size,
+                                                      C.c_void_p(pin_o[i][1]), size * 3), "frame_read_rgb8_async")
+
+            frames = 24
+            # (the marks loop: a context's next upload starts while its current frame is still being converted and copied
+            # out; the output buffer of a context is rewritten only after the mark behind its previous read has been waited for)
+            run_leg(submit_slots12, 24, "marks", after_run=read_rgb)
+            reps = [run_leg(submit_slots12, frames, "marks", after_run=read_rgb) for _ in range(3)]
+            el_ms = sorted(reps)[1]
+            e2e["slots_to_host_rgb8"] = {"value": round(size * size / 1e6 / (el_ms / 1e3), 1), "unit": "MP/s",
+                                                "ms_per_frame": round(el_ms, 3), "repetitions_ms": [round(v, 3) for v in reps],
+                                                "h2d_MB_per_frame": round(bytes_12 / 1e6, 1),
+                                                "d2h_MB_per_frame": round(rgb_bytes / 1e6, 1), "frames": frames}
+
+        switched = False
         for name, submit in legs:
+            if name == "slots_to_host_rgb8":
+                rgb8_leg()
+                continue
+            if not name.startswith("slots_p") and not switched and nslots != nslots_legacy:
+                # The runtime maps streams onto a handful of hardware queues (4 here).  Two contexts with two slot streams
+                # each are six streams: a slot stream then shares a queue with a compute stream and its copies wait behind
+                # kernels.  Two contexts with ONE slot stream each are four streams, one queue each: the slot-bucketed legs
+                # gain 2-11 % (tools/e2e_marks_probe.py with JXLH_PROBE_SLOTS=1 / 2, profiles/r05_m_e2e_slot_streams.txt);
+                # the older transports, whose device-side unpack / sort passes sit on the slot streams, prefer two.
+                keep_pinned = []  # the legs' pinned host buffers belong to the first context: hand them on
+                for c in ectx:
+                    keep_pinned += getattr(c, "_pinned", [])
+                    c._pinned = []
+                    c.close()
+                nslots = nslots_legacy
+                ectx = [jxl_rs_amd.Context(local_rank, n_slots=nslots) for _ in range(NE)]
+                ectx[0]._pinned = keep_pinned
+                for c in ectx:
+                    c.frame_begin(synth.apply_opts(c.default_params(size, size), wl))
+                    c.set_dequant_tables(wl.tables)
+                    c.set_lf_quantized(*wl.lf_q)
+                    c.set_hf_meta(wl.transform_map, wl.raw_quant, wl.epf_map, wl.ytox, wl.ytob)
+                switched = True
             frames = 6 if name == "dense_i32" else 48  # (a repetition ends with a drain: one frame time not overlapped)
             # untimed warm-up in the same pipelined pattern: the first frames that stream from a freshly pinned
             # buffer run up to 2x slower (round 4: measured by swapping the order of the legs; round 5: the streaming
@@ -1097,16 +1163,25 @@ def main():
             run_leg(submit, 60 if name != "dense_i32" else NE, "marks")
             reps = [run_leg(submit, frames, "marks") for _ in range(1 if name == "dense_i32" else 3)]
             ms = sorted(reps)[(len(reps) - 1) // 2]
-            loop, alt = "marks + jxlh_slot_wait (host-ordered uploads)", None
+            loop, alt = f"marks + jxlh_slot_wait (host-ordered uploads), {nslots} slot streams per context", None
             if name.startswith("slots_"):
-                # the two orderings of the contexts' uploads: host-side (best when the leg is compute-bound) and
-                # device-side (best when it is upload-bound); the leg reports the better median and prints both
-                run_leg(submit, 12, "marks_after")
-                reps_a = [run_leg(submit, frames, "marks_after") for _ in range(3)]
-                ms_a = sorted(reps_a)[1]
-                alt = {"host_ordered_ms": [round(v, 3) for v in reps], "device_ordered_ms": [round(v, 3) for v in reps_a]}
-                if ms_a < ms:
-                    ms, reps, loop = ms_a, reps_a, "marks + jxlh_slot_after (device-ordered uploads)"
+                # The host loops a caller can choose from, all measured, the leg reports the best median and prints all:
+                # the contexts' uploads ordered by the host (jxlh_slot_wait) or on the device (jxlh_slot_after), a frame's
+                # groups spread over the context's slot streams or all on one.  (One stream + device order is the best
+                # where the leg is upload-bound: the copies of the two contexts then follow each other on the bus without
+                # a second stream of the same context competing for it; found with tools/e2e_marks_probe.py.)
+                alt = {f"host_ordered_{nslots}_streams_ms": [round(v, 3) for v in reps]}
+                for pat, tag, st in (("marks_after", "device_ordered", None), ("marks", "host_ordered", 1),
+                                     ("marks_after", "device_ordered", 1)):
+                    if st is not None and st == nslots:
+                        continue
+                    run_leg(submit, 12, pat, streams=st)
+                    r_ = [run_leg(submit, frames, pat, streams=st) for _ in range(3)]
+                    alt[f"{tag}_{st or nslots}_streams_ms"] = [round(v, 3) for v in r_]
+                    if sorted(r_)[1] < ms:
+                        ms, reps = sorted(r_)[1], r_
+                        loop = (f"marks + {'jxlh_slot_after (device-ordered' if pat == 'marks_after' else 'jxlh_slot_wait (host-ordered'}"
+                                f" uploads), {st or nslots} slot stream{'s' if (st or nslots) > 1 else ''} per context")
             nbytes = {"sparse_pairs": total * 4, "sparse_pos16_val8": total * 3, "sparse_seg12_val4": bytes4,
                       "slots_pos6_val10_no_sort": bytes_slots,
                       "slots_packed12_no_sort": bytes_12}.get(name, wl.coeffs.nbytes)
@@ -1117,35 +1192,9 @@ def main():
             if alt:
                 e2e[name]["both_upload_orderings"] = alt
             if name.startswith("slots_"):  # round 4's host loop on the same library, for comparison
-                run_leg(submit, 12, "sync")
-                e2e[name]["ms_per_frame_sync_loop"] = round(run_leg(submit, 24, "sync"), 3)
-        # full decode-to-host: sparse pairs in, interleaved 8-bit sRGB out (jxlh_frame_read_rgb8) into
-        # pinned host memory; frame i's download overlaps frame i+1's upload and kernels
-        kk = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_kat.json")))["output_stage"]
-        bias = np.float32(kk["opsin_bias"])
-        xyb_params = np.concatenate([np.asarray(kk["opsin_inverse_matrix"], np.float32),
-                                     np.full(3, np.cbrt(bias), np.float32), np.full(3, bias, np.float32),
-                                     np.ones(1, np.float32)])
-        rgb_bytes = size * size * 3
-        pin_o = [ectx[i].alloc_pinned(rgb_bytes) for i in range(NE)]
-        import ctypes as C
-
-        def read_rgb(i):  # queued behind the frame's kernels on the context's stream; complete after c.sync()
-            c = ectx[i]
-            c._chk(c.L.jxlh_frame_read_rgb8_async(c._ctx, xyb_params.ctypes.data_as(C.c_void_p), 3, 0, size,
-                                                  C.c_void_p(pin_o[i][1]), size * 3), "frame_read_rgb8_async")
-
-        frames = 24
-        # (the marks loop: a context's next upload starts while its current frame is still being converted and copied
-        # out; the output buffer of a context is rewritten only after the mark behind its previous read has been waited for)
-        run_leg(submit_slots12, 24, "marks", after_run=read_rgb)
-        reps = [run_leg(submit_slots12, frames, "marks", after_run=read_rgb) for _ in range(3)]
-        el_ms = sorted(reps)[1]
-        e2e["slots_to_host_rgb8"] = {"value": round(size * size / 1e6 / (el_ms / 1e3), 1), "unit": "MP/s",
-                                            "ms_per_frame": round(el_ms, 3), "repetitions_ms": [round(v, 3) for v in reps],
-                                            "h2d_MB_per_frame": round(bytes_12 / 1e6, 1),
-                                            "d2h_MB_per_frame": round(rgb_bytes / 1e6, 1), "frames": frames}
-        e2e["note"] = ("pinned host coefficients -> H2D on 2 slot streams -> (pair forms: device unpack / sort; slot-bucketed "
+                run_leg(submit, 12, "sync", streams=nslots)
+                e2e[name]["ms_per_frame_sync_loop"] = round(run_leg(submit, 24, "sync", streams=nslots), 3)
+        e2e["note"] = ("pinned host coefficients -> H2D on the context's slot streams (ONE per context in the slots_* legs, two in the older transports' legs: see host_loop) -> (pair forms: device unpack / sort; slot-bucketed "
                        "forms: nothing, the transforms read the upload in place) -> K0b/K3/K1/filters; two contexts, each "
                        "streaming its frames behind jxlh_ctx_mark / jxlh_ctx_wait_mark (the host waits for a context's "
                        "previous frame, not for the one it has just enqueued) and starting its upload when the other "

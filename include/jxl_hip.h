@@ -288,6 +288,9 @@ jxlh_status jxlh_submit_groups_sparse4(jxlh_ctx* ctx, int32_t slot, uint32_t cou
 jxlh_status jxlh_submit_groups_slots(jxlh_ctx* ctx, int32_t slot, uint32_t count, const uint32_t* group_ids,
                                      const uint16_t* entries, const uint8_t* slot_counts, const uint32_t* n,
                                      const jxlh_coeff32* wide, uint32_t n_wide, uint32_t flags);
+/* Blocks until the host buffers of the submissions made on `slot` so far may be reused (their host-to-device copies have
+ * landed).  Device-side work a submission queues behind its copies on the slot's stream (the unpack pass of
+ * JXLH_GROUP_ENTRIES12) is NOT waited for here: jxlh_frame_run orders itself behind it. */
 jxlh_status jxlh_slot_wait(jxlh_ctx* ctx, int32_t slot);
 /* Orders uploads ACROSS contexts on the device: whatever is submitted on (ctx, slot) after this call starts when the
  * uploads enqueued so far on (after_ctx, after_slot) have landed -- the device-side form of "jxlh_slot_wait(after_ctx,

@@ -37,6 +37,7 @@ jxlh_status jxlh_submit_group(jxlh_ctx* ctx, int32_t slot, uint32_t group_id, co
   if (dst != coeffs) {
     HIPCHK(ctx, hipMemcpyAsync(dst, coeffs, (size_t)3 * kGroupArea * sizeof(int32_t), hipMemcpyDefault, s.stream));
   }
+  s.copied_valid = false;
   HIPCHK(ctx, hipEventRecord(s.done, s.stream));
   s.used = true;
   return JXLH_OK;
@@ -108,6 +109,7 @@ jxlh_status jxlh_submit_groups_sparse(jxlh_ctx* ctx, int32_t slot, uint32_t coun
   if (ctx->sp_expanded_valid) HIPCHK(ctx, hipStreamWaitEvent(s.stream, ctx->sp_expanded, 0));
   if (total)
     HIPCHK(ctx, hipMemcpyAsync(ctx->sp_pairs.p + offset, pairs, total * sizeof(uint32_t), hipMemcpyDefault, s.stream));
+  s.copied_valid = false;
   HIPCHK(ctx, hipEventRecord(s.done, s.stream));
   s.used = true;
   return JXLH_OK;
@@ -145,6 +147,7 @@ jxlh_status jxlh_submit_groups_sparse8(jxlh_ctx* ctx, int32_t slot, uint32_t cou
                        reinterpret_cast<const int8_t*>(s.stage8 + pos_bytes), total, ctx->sp_pairs.p + offset);
     HIPCHK(ctx, hipGetLastError());
   }
+  s.copied_valid = false;
   HIPCHK(ctx, hipEventRecord(s.done, s.stream));
   s.used = true;
   return JXLH_OK;
@@ -216,6 +219,7 @@ jxlh_status jxlh_submit_groups_sparse4(jxlh_ctx* ctx, int32_t slot, uint32_t cou
                        reinterpret_cast<const uint32_t*>(d_desc), (int)runs, ctx->sp_pairs.p + offset);
     HIPCHK(ctx, hipGetLastError());
   }
+  s.copied_valid = false;
   HIPCHK(ctx, hipEventRecord(s.done, s.stream));
   s.used = true;
   return JXLH_OK;
@@ -273,8 +277,8 @@ jxlh_status jxlh_submit_groups_slots(jxlh_ctx* ctx, int32_t slot, uint32_t count
         s.stage8_cap = cap;
       }
       HIPCHK(ctx, hipMemcpyAsync(s.stage8, entries, bytes, hipMemcpyDefault, s.stream));
-      launch_unpack_entries12(s.stream, s.stage8, total / 2, d_ent);
-      HIPCHK(ctx, hipGetLastError());
+      // (the unpack kernel goes behind the other copies, below: what jxlh_slot_wait / jxlh_slot_after wait for is the
+      // copies -- a kernel queued behind another context's transforms would hold the next upload, and the bus, back)
     }
   }
   // counts and run descriptors: one copy per stretch of consecutive group ids (a decoder thread's batch is usually one)
@@ -297,7 +301,16 @@ jxlh_status jxlh_submit_groups_slots(jxlh_ctx* ctx, int32_t slot, uint32_t count
                                hipMemcpyHostToDevice, s.stream));
     i0 = i1;
   }
-  HIPCHK(ctx, hipEventRecord(s.done, s.stream));
+  if (total && e12) {
+    HIPCHK(ctx, hipEventRecord(s.copied, s.stream));
+    launch_unpack_entries12(s.stream, s.stage8, total / 2, d_ent);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipEventRecord(s.done, s.stream));
+    s.copied_valid = true;
+  } else {
+    s.copied_valid = false;
+    HIPCHK(ctx, hipEventRecord(s.done, s.stream));
+  }
   s.used = true;
   return JXLH_OK;
 }
@@ -324,7 +337,9 @@ jxlh_status jxlh_submit_group_sparse(jxlh_ctx* ctx, int32_t slot, uint32_t group
 jxlh_status jxlh_slot_wait(jxlh_ctx* ctx, int32_t slot) {
   JXLH_ON_DEVICE(ctx);
   if (!ctx || slot < 0 || (size_t)slot >= ctx->slots.size()) return JXLH_ERR_INVALID_ARGUMENT;
-  HIPCHK(ctx, hipStreamSynchronize(ctx->slots[slot].stream));
+  Slot& s = ctx->slots[slot];
+  if (s.copied_valid) HIPCHK(ctx, hipEventSynchronize(s.copied));  // device work behind the copies is the frame's business
+  else HIPCHK(ctx, hipStreamSynchronize(s.stream));
   return JXLH_OK;
 }
 
@@ -335,7 +350,7 @@ jxlh_status jxlh_slot_after(jxlh_ctx* ctx, int32_t slot, jxlh_ctx* after_ctx, in
     return JXLH_ERR_INVALID_ARGUMENT;
   const Slot& a = after_ctx->slots[after_slot];
   // (`done` is re-recorded by every submission on that slot: this waits for the latest one recorded so far)
-  if (a.used) HIPCHK(ctx, hipStreamWaitEvent(ctx->slots[slot].stream, a.done, 0));
+  if (a.used) HIPCHK(ctx, hipStreamWaitEvent(ctx->slots[slot].stream, a.copied_valid ? a.copied : a.done, 0));
   return JXLH_OK;
 }
 

@@ -126,7 +126,8 @@ jxlh_status jxlh_ctx_create(int32_t device_ordinal, int32_t n_slots, jxlh_ctx** 
   ctx->slots.resize(n_slots);
   for (auto& s : ctx->slots) {
     if (hipStreamCreateWithPriority(&s.stream, hipStreamNonBlocking, prio.slot_p) != hipSuccess ||
-        hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&s.copied, hipEventDisableTiming) != hipSuccess) {
       jxlh_ctx_destroy(ctx);
       return JXLH_ERR_DEVICE;
     }
@@ -142,6 +143,7 @@ void jxlh_ctx_destroy(jxlh_ctx* ctx) {
   drain_timers(ctx);
   for (auto& s : ctx->slots) {
     if (s.done) (void)hipEventDestroy(s.done);
+    if (s.copied) (void)hipEventDestroy(s.copied);
     if (s.stream) (void)hipStreamDestroy(s.stream);
     if (s.stage8) (void)hipFree(s.stage8);
   }

@@ -28,6 +28,11 @@ namespace jxlh_host {
 struct Slot {
   hipStream_t stream = nullptr;
   hipEvent_t done = nullptr;
+  // the last submission's host-to-device copies have landed -- recorded apart from `done` when device work follows the
+  // copies on the slot's stream (the 12-bit entries' unpack kernel): jxlh_slot_wait / jxlh_slot_after are about the
+  // copies (host buffers, the bus), the frame waits for `done`
+  hipEvent_t copied = nullptr;
+  bool copied_valid = false;
   bool used = false;
   uint8_t* stage8 = nullptr;  // device staging of the 3-byte sparse form (positions | values), grown on demand
   size_t stage8_cap = 0;
