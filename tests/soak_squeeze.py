@@ -22,9 +22,13 @@ for it in range(n):
     lim = int(rng.choice([64, 4096, 1 << 20, 1 << 27]))
     avg = rng.integers(-lim, lim, size=(lines, (length + 1) // 2)).astype(np.int32)
     res = rng.integers(-lim // 8 - 1, lim // 8 + 1, size=(lines, length // 2)).astype(np.int32)
+    why = []
     ok = np.array_equal(ctx.unsqueeze(True, avg, res, length, lines), o.unsqueeze_h(avg, res, length))
+    if not ok: why.append("step-h")
     at, rt = np.ascontiguousarray(avg.T), np.ascontiguousarray(res.T)
-    ok &= np.array_equal(ctx.unsqueeze(False, at, rt, lines, length), o.unsqueeze_v(at, rt, length))
+    okv = np.array_equal(ctx.unsqueeze(False, at, rt, lines, length), o.unsqueeze_v(at, rt, length))
+    if not okv: why.append("step-v")
+    ok &= okv
     # --- fused unsqueeze + RCT, vertical (wide aligned planes take the 32-column tiles) and horizontal
     op, perm = int(rng.integers(0, 7)), int(rng.integers(0, 6))
     for horizontal in (True, False):
@@ -49,7 +53,9 @@ for it in range(n):
         unsq = [o.unsqueeze_h(a, r, ow) if horizontal else o.unsqueeze_v(a, r, oh) for a, r in host]
         want = o.rct(unsq, op, perm)
         for c in range(3):
-            ok &= np.array_equal(do[c].download(np.int32, ow * oh).reshape(oh, ow), want[c].reshape(oh, ow))
+            okr = np.array_equal(do[c].download(np.int32, ow * oh).reshape(oh, ow), want[c].reshape(oh, ow))
+            if not okr: why.append(f"rct-{'h' if horizontal else 'v'} {ow}x{oh} op{op} perm{perm} c{c}")
+            ok &= okr
         for d in da + dr + do:
             d.free()
     # --- a whole default chain: levels call for the small levels, steps for the rest
@@ -71,10 +77,12 @@ for it in range(n):
     ctx.unsqueeze_levels(levels, [d.ptr for d in dbase], bw, bw, bh, [d.ptr for d in dout], w)
     ctx.sync()
     for c in range(3):
-        ok &= np.array_equal(dout[c].download(np.int32, w * h).reshape(h, w), want[c])
+        okc = np.array_equal(dout[c].download(np.int32, w * h).reshape(h, w), want[c])
+        if not okc: why.append(f"chain c{c}")
+        ok &= okc
     for d in dbase + keep + dout:
         d.free()
     bad += not ok
-    print(it, "ok" if ok else "MISMATCH", f"step {lines}x{length} lim={lim}; chain {w}x{h}", flush=True)
+    print(it, "ok" if ok else "MISMATCH " + "; ".join(why), f"step {lines}x{length} lim={lim}; chain {w}x{h}", flush=True)
 print("mismatches:", bad, "in", n, "iterations,", round(time.time() - t0, 1), "s")
 sys.exit(1 if bad else 0)
