@@ -148,7 +148,8 @@ def load():
     L.jxlh_stage_noise_add.argtypes = [vp, C.POINTER(FrameParams), C.POINTER(vp), C.POINTER(vp), sz]
     L.jxlh_set_upsampling_weights.argtypes = [vp, vp, vp, vp]
     L.jxlh_selftest_recip.argtypes = [vp, u32, u32, C.POINTER(C.c_uint64)]
-    L.jxlh_flow_profile.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(C.c_uint64), i32]
+    if hasattr(L, "jxlh_flow_profile"):  # absent from older builds used in A/B runs (JXLH_LIBRARY)
+        L.jxlh_flow_profile.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(C.c_uint64), i32]
     L.jxlh_frame_set_dequant_tables.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
     L.jxlh_frame_set_lf_quantized.argtypes = [vp, u32, u32, u32, u32, vp, vp, vp, sz, u32]
     L.jxlh_frame_set_lf.argtypes = [vp, u32, u32, u32, u32, vp, vp, vp, sz]
@@ -292,7 +293,16 @@ class DeviceArray:
             cls._hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
             cls._hip.hipFree.argtypes = [C.c_void_p]
             cls._hip.hipSetDevice.argtypes = [C.c_int]
+            cls._hip.hipStreamSynchronize.argtypes = [C.c_void_p]
         return cls._hip
+
+    @classmethod
+    def _settle(cls):
+        """hipMemset returns before the fill has run, and a hipMemcpy from pageable memory may return once the data sits in
+        the runtime's staging buffer: both are ordered on the NULL stream only, and the library's streams are non-blocking
+        ones -- a kernel enqueued right behind such a call could run before it (seen as a 0.2 % flake of
+        tests/soak_squeeze.py: an output plane zeroed after the kernel had written it).  Wait for the NULL stream."""
+        cls._chk(cls.hip().hipStreamSynchronize(None), "hipStreamSynchronize(NULL)")
 
     @classmethod
     def _chk(cls, rc, what):
@@ -316,10 +326,12 @@ class DeviceArray:
             self._chk(self.hip().hipMemcpy(self.ptr, a.ctypes.data, a.nbytes, 1), "hipMemcpy H2D")
         else:
             self._chk(self.hip().hipMemset(self.ptr, 0, self.nbytes), "hipMemset")
+        self._settle()
 
     def upload(self, array, byte_offset=0):
         a = np.ascontiguousarray(array)
         self._chk(self.hip().hipMemcpy(self.ptr + byte_offset, a.ctypes.data, a.nbytes, 1), "hipMemcpy H2D")
+        self._settle()
 
     def download(self, dtype, count, byte_offset=0):
         out = np.empty(count, dtype=dtype)
