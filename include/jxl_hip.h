@@ -537,7 +537,7 @@ jxlh_status jxlh_unsqueeze_planes(jxlh_ctx* ctx, int32_t horizontal, int32_t n_p
  * level 0) as its averages and levels[i].res as its residuals; only the last level's planes are written.  The first
  * levels of a chain are tiny (default_squeeze, squeeze.rs:71-105, starts from <= 8 x 8): as separate launches they cost
  * ~10 us each whatever their size, so up to 16 levels whose planes stay within 128 x 128 run as ONE launch with the
- * planes in LDS; anything else is run level by level through context scratch (same result).  Device pointers only. */
+ * planes in LDS; anything else takes jxlh_unsqueeze_chain's route without an RCT (same result).  Device pointers only. */
 typedef struct jxlh_squeeze_level {
   int32_t horizontal;
   uint32_t out_w, out_h;

@@ -273,10 +273,9 @@ jxlh_status jxlh_unsqueeze_levels(jxlh_ctx* ctx, int32_t n_planes, int32_t n_lev
     return JXLH_ERR_INVALID_ARGUMENT;
   // geometry: every level doubles (up to the odd sample) the axis it squeezes
   uint32_t cw = base_w, ch = base_h;
-  size_t max_plane = (size_t)base_w * base_h;
   for (int i = 0; i < n_levels; i++) {
     const jxlh_squeeze_level& lv = levels[i];
-    if (lv.out_w == 0 || lv.out_h == 0 || lv.out_w > (1u << 20) || lv.out_h > (1u << 20)) return JXLH_ERR_INVALID_ARGUMENT;
+    if (lv.out_w == 0 || lv.out_h == 0 || lv.out_w > kMaxModularDim || lv.out_h > kMaxModularDim) return JXLH_ERR_INVALID_ARGUMENT;
     const uint32_t aw = lv.horizontal ? (lv.out_w + 1) / 2 : lv.out_w, ah = lv.horizontal ? lv.out_h : (lv.out_h + 1) / 2;
     if (aw != cw || ah != ch) return JXLH_ERR_INVALID_ARGUMENT;
     const uint32_t rw = lv.horizontal ? lv.out_w / 2 : lv.out_w, rh = lv.horizontal ? lv.out_h : lv.out_h / 2;
@@ -285,7 +284,6 @@ jxlh_status jxlh_unsqueeze_levels(jxlh_ctx* ctx, int32_t n_planes, int32_t n_lev
         return JXLH_ERR_INVALID_ARGUMENT;
     cw = lv.out_w;
     ch = lv.out_h;
-    max_plane = std::max(max_plane, (size_t)cw * ch);
   }
   if (out_stride < cw) return JXLH_ERR_INVALID_ARGUMENT;
   for (int p = 0; p < n_planes; p++)
@@ -309,31 +307,8 @@ jxlh_status jxlh_unsqueeze_levels(jxlh_ctx* ctx, int32_t n_planes, int32_t n_lev
       return JXLH_OK;
     }
   }
-  // level by level, intermediate planes in context scratch (two sets of n_planes planes, swapped per level)
-  jxlh_status st;
-  if ((st = ensure(ctx, ctx->hook_i[0], max_plane * n_planes))) return st;
-  if ((st = ensure(ctx, ctx->hook_i[1], max_plane * n_planes))) return st;
-  const int32_t* cur[3];
-  size_t cur_stride = base_stride;
-  for (int p = 0; p < n_planes; p++) cur[p] = base[p];
-  ScopedKernelTimer t(ctx, "k6_unsqueeze_levels_stepwise");
-  for (int i = 0; i < n_levels; i++) {
-    const jxlh_squeeze_level& lv = levels[i];
-    const bool last = i == n_levels - 1;
-    int32_t* dst[3];
-    const int32_t* rv[3];
-    const size_t dst_stride = last ? out_stride : lv.out_w;
-    for (int p = 0; p < n_planes; p++) {
-      dst[p] = last ? out[p] : ctx->hook_i[i & 1].p + (size_t)p * max_plane;
-      rv[p] = lv.res[p] ? lv.res[p] : cur[p];
-    }
-    launch_unsqueeze(ctx->stream, lv.horizontal ? 1 : 0, n_planes, cur, cur_stride, rv, lv.res_stride, lv.out_w, lv.out_h,
-                     dst, dst_stride);
-    for (int p = 0; p < n_planes; p++) cur[p] = dst[p];
-    cur_stride = dst_stride;
-  }
-  HIPCHK(ctx, hipGetLastError());
-  return JXLH_OK;
+  // anything else: the chain's route without an RCT (LDS-resident prefix, the streamed levels as one dataflow launch)
+  return jxlh_unsqueeze_chain(ctx, n_planes, n_levels, levels, base, base_stride, base_w, base_h, out, out_stride, -1, 0);
 }
 
 // The inverse of a whole squeeze transform as one call (+ the RCT that follows it in the transform list).
