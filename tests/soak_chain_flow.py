@@ -40,6 +40,27 @@ if len(sys.argv) > 2 and sys.argv[2] == "noise":
             k += 1
     th = threading.Thread(target=noise, daemon=True)
     th.start()
+if len(sys.argv) > 2 and sys.argv[2] == "chains":
+    # a second context running its OWN dataflow launches the whole time: two persistent ticket kernels share the device
+    import threading
+    cctx = jxl_rs_amd.Context(0, 1)
+    other = ModularChain(cctx, 4096, 4096, seed=77, rct=(6, 0))
+    os.environ["JXLH_CHAIN_FLOW"] = "0"
+    other.run_chain(); cctx.sync()
+    other_ref = [zlib.crc32(p.tobytes()) for p in other.result()]
+    other_bad = [0]
+
+    def chains():
+        k = 0
+        while not stop:
+            for _ in range(1 + k % 3):
+                other.run_chain()
+            cctx.sync()
+            if k % 7 == 0 and [zlib.crc32(p.tobytes()) for p in other.result()] != other_ref:
+                other_bad[0] += 1
+            k += 1
+    th = threading.Thread(target=chains, daemon=True)
+    th.start()
 bad = 0
 t0 = time.time()
 for (w, h, rct, check_oracle) in ((8192, 8192, (6, 0), False), (8192, 8192, None, False), (4096, 2048, (3, 4), True),
@@ -70,5 +91,9 @@ for (w, h, rct, check_oracle) in ((8192, 8192, (6, 0), False), (8192, 8192, None
     bad += n_bad
     ch.free()
 stop = True
+if len(sys.argv) > 2 and sys.argv[2] == "chains":
+    th.join(timeout=30)
+    print("the other context's chains:", other_bad[0], "differing")
+    bad += other_bad[0]
 print(f"soak_chain_flow: {'OK' if bad == 0 else 'FAILED'} ({bad} bad) in {time.time() - t0:.1f} s")
 sys.exit(1 if bad else 0)
