@@ -281,13 +281,56 @@ jxlh_status jxlh_submit_groups_sparse4(jxlh_ctx* ctx, int32_t slot, uint32_t cou
  * reference computes for a zero coefficient; varblocks with far more entries than d1 content has, or raw_quant == 0, take
  * a dense dequantisation pass -- same bits, see JXLH_FRAME_DENSE_DEQUANT).  The uploads land in a second set of buffers:
  * the call may be issued for the NEXT frame while the previous jxlh_frame_run is still executing and waits for nothing
- * of it (jxlh_ctx_mark / jxlh_ctx_wait_mark is the host loop for that).  Other cases -- a group of the epoch in another
- * form, a value outside 10 bits (`wide`), JXLH_GROUP_ACCUMULATE -- widen the slot-bucketed groups into pair words on the
- * device and take the general route (sort, or zero-fill + scatter into dense slabs).
+ * of it (jxlh_ctx_mark / jxlh_ctx_wait_mark is the host loop for that).  Groups of the epoch that are NOT self-contained
+ * slot-bucketed submissions -- another form (dense slab, plain pairs), a value in `wide`, JXLH_GROUP_ACCUMULATE -- are
+ * brought into their dense slabs on the device and read from there, group by group, while the rest of the frame is still
+ * read in place (round 6; as long as every group arrived in the epoch and at least half of them in place -- otherwise
+ * the whole frame takes the general route: sort, or zero-fill + scatter into dense slabs).  Values beyond 10 bits
+ * need not go to `wide`: see "WIDE VALUES" below.
  *   JXLH_ERR_INVALID_ARGUMENT is returned before anything is reserved (a rejected call leaves the epoch as it was). */
 jxlh_status jxlh_submit_groups_slots(jxlh_ctx* ctx, int32_t slot, uint32_t count, const uint32_t* group_ids,
                                      const uint16_t* entries, const uint8_t* slot_counts, const uint32_t* n,
                                      const jxlh_coeff32* wide, uint32_t n_wide, uint32_t flags);
+/* ---- host side of the slot-bucketed form (round 6): plain CPU code, no context, no device, any thread ----
+ * WIDE VALUES.  An entry holds 10 bits (6 with JXLH_GROUP_ENTRIES12); the reference accumulates arbitrary i32
+ * (`coeff = read_signed_inline(..) << shift; current_coeffs[idx] += coeff`, frame/group.rs:568-572).  A producer SPLITS a
+ * value outside the range into repeated in-range entries at the same position -- 2000 = 511 + 511 + 511 + 467 -- which
+ * add up as integers on the device before the dequantisation, exactly like several passes' updates of one coefficient:
+ * the frame stays in the form the transforms read in place (varblocks with more entries than their lanes hold take a
+ * dense dequantisation pass, same bits).  Only what no slot can hold (a slot's count is a u8: 255 entries) goes to
+ * `wide`, and a group with a `wide` value -- like a group that arrives in another form, or adds a pass to earlier
+ * content (JXLH_GROUP_ACCUMULATE) -- is read from its dense slab while every other group of the frame is still read in
+ * place (per-group routing; round 5 took the whole frame out of the in-place form).  Both helpers below do the split.
+ *
+ * jxlh_host_pack_slots: one group's dense slab (3 x 65536 i32: VarDctBuffers::coeffs_storage, frame/group.rs:27-67,
+ * :437-440) -> the arguments of jxlh_submit_groups_slots for that group.  entries: room for entries_capacity entries
+ * (u16 each; with JXLH_GROUP_ENTRIES12 the three runs are written as bytes, 1.5 per entry, each closed to an even
+ * count); slot_counts: 3 x 1024; n[3]: entries per channel; wide / n_wide: values that could not be split (positions
+ * already carry group_id as the batched call wants them).  JXLH_ERR_INVALID_ARGUMENT when a capacity is too small. */
+jxlh_status jxlh_host_pack_slots(const int32_t* coeffs, uint32_t group_id, uint32_t flags, void* entries,
+                                 size_t entries_capacity, uint8_t* slot_counts, uint32_t n[3], jxlh_coeff32* wide,
+                                 uint32_t wide_capacity, uint32_t* n_wide);
+/* The same form written by the entropy loop itself (frame/group.rs:557-575), one writer per decoding thread:
+ *   begin_group(buffers)                                 once per group (zeroes slot_counts)
+ *   begin_varblock(first_slot, num_slots)                coeffs_offset / 64 and cx * cy of the varblock (group.rs:612);
+ *                                                        varblocks in the order they are decoded (ascending offsets)
+ *   add(channel, pos, value)                             `coeffs[channel][coeffs_offset + pos] += value`, pos inside the
+ *                                                        varblock (order[k]); channels and positions in any order
+ *   end_group(n, n_wide)                                 closes the last varblock, writes the three runs to `entries`
+ * Entries of a one-slot varblock (8x8: the common case) are appended as they arrive; a larger varblock's are
+ * bucketed by slot when it ends. */
+typedef struct jxlh_slot_writer jxlh_slot_writer;
+jxlh_status jxlh_slot_writer_create(jxlh_slot_writer** out);
+void jxlh_slot_writer_destroy(jxlh_slot_writer* w);
+jxlh_status jxlh_slot_writer_begin_group(jxlh_slot_writer* w, uint32_t group_id, uint32_t flags, void* entries,
+                                         size_t entries_capacity, uint8_t* slot_counts, jxlh_coeff32* wide,
+                                         uint32_t wide_capacity);
+jxlh_status jxlh_slot_writer_begin_varblock(jxlh_slot_writer* w, uint32_t first_slot, uint32_t num_slots);
+jxlh_status jxlh_slot_writer_add(jxlh_slot_writer* w, uint32_t channel, uint32_t pos, int32_t value);
+jxlh_status jxlh_slot_writer_add_many(jxlh_slot_writer* w, uint32_t channel, const uint32_t* pos, const int32_t* value,
+                                      size_t count);
+jxlh_status jxlh_slot_writer_end_group(jxlh_slot_writer* w, uint32_t n[3], uint32_t* n_wide);
+
 /* Blocks until the host buffers of the submissions made on `slot` so far may be reused (their host-to-device copies have
  * landed).  Device-side work a submission queues behind its copies on the slot's stream (the unpack pass of
  * JXLH_GROUP_ENTRIES12) is NOT waited for here: jxlh_frame_run orders itself behind it. */

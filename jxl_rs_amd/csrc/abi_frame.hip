@@ -162,6 +162,7 @@ void jxlh_ctx_destroy(jxlh_ctx* ctx) {
   release(ctx->sp_sorted);
   release(ctx->sp_slot_start);
   release(ctx->bucketed_dev);
+  release(ctx->route_dev);
   for (int i = 0; i < 2; i++) {
     release(ctx->se_entries[i]);
     release(ctx->se_counts[i]);
@@ -282,6 +283,8 @@ jxlh_status jxlh_frame_begin(jxlh_ctx* ctx, const jxlh_frame_params* p) {
     ctx->epoch_dirty = false;
     ctx->sp_sorted_valid = false;
     ctx->se_valid = false;
+    ctx->route_live.clear();
+    ctx->n_route = 0;
   }
   const size_t nblocks = (size_t)f.xblocks * f.yblocks;
   const size_t ncmap = (size_t)f.cmap_stride * ((f.yblocks + 7) / 8);
@@ -665,6 +668,27 @@ jxlh_status run_prologue(jxlh_ctx* ctx, RunPlan* plan) {
         all_bucketed = all_bucketed && ctx->bucketed[g] != 0;
       }
       const int pend = ctx->se_live ^ 1;
+      // Per-group routing (round 6): every group of the frame arrived in this epoch and MOST of them slot-bucketed and
+      // self-contained -- the others (a dense slab, plain pairs, a value outside the entries' 10 bits in `wide`, a pass
+      // added to earlier content) are brought into their dense slabs and read from there (FrameDev::group_route), the
+      // bucketed ones are still read in place.  Round 5 took the whole frame out of the in-place form for one such group.
+      std::vector<uint8_t> route(ctx->ngroups, 1);
+      size_t n_inplace = 0;
+      bool mixed = false;
+      if (any_bucketed && !all_bucketed && ctx->bucketed.size() == ctx->ngroups &&
+          !(p.flags & JXLH_FRAME_EXPAND_SPARSE) && !plan->want_strip) {
+        bool all_touched = true;
+        for (size_t g = 0; g < ctx->ngroups; g++) all_touched = all_touched && ctx->touched[g] != 0;
+        if (all_touched) {
+          std::vector<uint8_t> wide_group(ctx->ngroups, 0);
+          for (const uint2& w : ctx->sp_wide_upload) wide_group[w.x / (3u * kGroupArea)] = 1;  // (validated at submission)
+          for (size_t g = 0; g < ctx->ngroups; g++) {
+            route[g] = !(ctx->touched[g] == 2 && ctx->bucketed[g] && !accum[g] && !wide_group[g]);
+            n_inplace += route[g] ? 0 : 1;
+          }
+          mixed = 2 * n_inplace >= ctx->ngroups;
+        }
+      }
       // (the group list is read by the sort and by the expansion: a frame that arrived slot-bucketed needs neither)
       if (ng && !all_bucketed)
         HIPCHK(ctx, hipMemcpyAsync(ctx->sp_groups_dev.p, ctx->sp_upload.data(), ng * sizeof(SparseGroup),
@@ -673,11 +697,13 @@ jxlh_status run_prologue(jxlh_ctx* ctx, RunPlan* plan) {
         HIPCHK(ctx, hipMemcpyAsync(ctx->sp_wide_dev.p, ctx->sp_wide_upload.data(), nw * sizeof(uint2),
                                    hipMemcpyHostToDevice, ctx->stream));
       if (ctx->sp_sorted_valid && !all_pairs) {
-        // leaving the bucketed form: groups not resubmitted now (or only added to) need their dense slab
+        // leaving the bucketed form: groups not resubmitted now (or only added to) need their dense slab -- unless
+        // the slab already was where they lived (a dense-route group of a frame with per-group routing)
         ctx->flag_upload.assign(ctx->ngroups, 0);
         bool any = false;
+        const bool had_routes = ctx->route_live.size() == ctx->ngroups;
         for (size_t g = 0; g < ctx->ngroups; g++)
-          any |= (ctx->flag_upload[g] = (ctx->touched[g] == 0 || accum[g]) ? 1 : 0) != 0;
+          any |= (ctx->flag_upload[g] = ((ctx->touched[g] == 0 || accum[g]) && !(had_routes && ctx->route_live[g])) ? 1 : 0) != 0;
         if (any) {
           HIPCHK(ctx, hipMemcpyAsync(ctx->group_dense.p, ctx->flag_upload.data(), ctx->ngroups, hipMemcpyHostToDevice,
                                      ctx->stream));
@@ -695,6 +721,8 @@ jxlh_status run_prologue(jxlh_ctx* ctx, RunPlan* plan) {
         // groups' entries become pair words at their reserved places of the pair buffer and take the general route
         if (jxlh_status st = ensure(ctx, ctx->bucketed_dev, ctx->ngroups)) return st;
         ctx->bucketed_upload = ctx->bucketed;  // stays alive until the next epoch: the copy reads it
+        if (mixed)  // only the bucketed groups that leave the in-place form
+          for (size_t g = 0; g < ctx->ngroups; g++) ctx->bucketed_upload[g] = ctx->bucketed[g] && route[g];
         HIPCHK(ctx, hipMemcpyAsync(ctx->bucketed_dev.p, ctx->bucketed_upload.data(), ctx->ngroups, hipMemcpyHostToDevice,
                                    ctx->stream));
         ScopedKernelTimer t(ctx, "k_entries_to_pairs");
@@ -705,6 +733,24 @@ jxlh_status run_prologue(jxlh_ctx* ctx, RunPlan* plan) {
         ctx->se_live = pend;  // the sets trade places: the next epoch's uploads go to the set read two frames ago
         ctx->se_valid = true;
         ctx->sp_sorted_valid = true;
+        ctx->route_live.clear();
+        ctx->n_route = 0;
+      } else if (mixed) {
+        // the routed groups' slabs: zero-fill + scatter of their pair words (their own, or the ones the widening above
+        // made of their entries) + the wide values -- or, for an added pass, on top of what the slab holds
+        if (jxlh_status st = ensure(ctx, ctx->route_dev, ctx->ngroups)) return st;
+        ctx->route_upload = route;  // stays alive until the next epoch: the copy reads it
+        HIPCHK(ctx, hipMemcpyAsync(ctx->route_dev.p, ctx->route_upload.data(), ctx->ngroups, hipMemcpyHostToDevice, ctx->stream));
+        {
+          ScopedKernelTimer t(ctx, "k_expand_sparse");
+          launch_expand_sparse(ctx->stream, ctx->coeffs.p, ctx->sp_pairs.p, ctx->sp_groups_dev.p, (int)ng, ctx->sp_wide_dev.p,
+                               (uint32_t)nw, ctx->route_dev.p);
+        }
+        ctx->se_live = pend;
+        ctx->se_valid = true;
+        ctx->sp_sorted_valid = true;
+        ctx->route_live = route;
+        ctx->n_route = (int)(ctx->ngroups - n_inplace);
       } else if (all_pairs) {
         const size_t capacity = ctx->ngroups * 3 * (size_t)kGroupArea;
         if (jxlh_status st = ensure(ctx, ctx->sp_sorted, capacity)) return st;
@@ -716,7 +762,11 @@ jxlh_status run_prologue(jxlh_ctx* ctx, RunPlan* plan) {
         }
         ctx->se_valid = false;
         ctx->sp_sorted_valid = true;
+        ctx->route_live.clear();
+        ctx->n_route = 0;
       } else {
+        ctx->route_live.clear();
+        ctx->n_route = 0;
         if (ng || nw) {
           ScopedKernelTimer t(ctx, "k_expand_sparse");
           launch_expand_sparse(ctx->stream, ctx->coeffs.p, ctx->sp_pairs.p, ctx->sp_groups_dev.p, (int)ng,
@@ -725,7 +775,7 @@ jxlh_status run_prologue(jxlh_ctx* ctx, RunPlan* plan) {
         ctx->se_valid = false;
         ctx->sp_sorted_valid = false;
       }
-      if (any_bucketed && !all_bucketed) {  // the pending set has been read (it stays the pending one)
+      if (any_bucketed && !all_bucketed && !mixed) {  // the pending set has been read (it stays the pending one)
         if (!ctx->se_read[pend]) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->se_read[pend], hipEventDisableTiming));
         HIPCHK(ctx, hipEventRecord(ctx->se_read[pend], ctx->stream));
         ctx->se_read_valid[pend] = true;
@@ -782,7 +832,9 @@ static void set_sparse_view(jxlh_ctx* ctx, FrameDev& f, bool sparse_k1) {
   f.se_counts = ent ? ctx->se_counts[ctx->se_live].p : nullptr;
   f.se_runs = ent ? ctx->se_runs[ctx->se_live].p : nullptr;
   f.group_dense = sparse_k1 ? ctx->group_dense.p : nullptr;
+  f.group_route = ent && ctx->n_route > 0 ? ctx->route_dev.p : nullptr;
 }
+static int dense_route_groups(const jxlh_ctx* ctx, bool sparse_k1) { return sparse_k1 && ctx->se_valid ? ctx->n_route : 0; }
 // behind the transforms: the coefficient slabs are free again (dense resubmissions of the next frame wait for this,
 // jxlh_submit_group), and so is the live set of the slot-bucketed form once it has become the pending one
 static jxlh_status mark_coefficients_read(jxlh_ctx* ctx, bool sparse_k1) {
@@ -814,7 +866,8 @@ jxlh_status run_k1(jxlh_ctx* ctx, const RunPlan& plan, int gr0, int gr1) {
     for (int c = 0; c < 3; c++)
       if (f.hshift[c] | f.vshift[c]) fk.planes[c] = f.tmp[c];
     launch_vardct_groups(ctx->stream, fk, gr0, gr1, ctx->worklist.p, &ctx->k1_launches, ctx->error_flag.p,
-                         sparse_k1 ? ctx->coeffs.p : nullptr, nullptr, 0, ctx->has_special, ctx->has_large);
+                         sparse_k1 ? ctx->coeffs.p : nullptr, nullptr, 0, ctx->has_special, ctx->has_large,
+                         dense_route_groups(ctx, sparse_k1));
   }
   if (jxlh_status st = mark_coefficients_read(ctx, sparse_k1)) return st;
   ctx->chroma_lazy = false;
@@ -889,7 +942,7 @@ jxlh_status run_strip(jxlh_ctx* ctx, const RunPlan& plan) {
   {
     ScopedKernelTimer t(ctx, "k1_vardct");
     launch_vardct_groups(ctx->stream, f, 0, f.ygroups, ctx->worklist.p, &ctx->k1_launches, ctx->error_flag.p, nullptr,
-                         nullptr, 0, ctx->has_special, ctx->has_large);
+                         nullptr, 0, ctx->has_special, ctx->has_large, 0);
   }
   {
     ScopedKernelTimer t(ctx, "k123_strip");
@@ -1152,7 +1205,7 @@ jxlh_status jxlh_frame_rerender_groups(jxlh_ctx* ctx, const uint32_t* group_ids,
     if (plan.sparse_k1) HIPCHK(ctx, hipMemsetAsync(ctx->group_dense.p, 0, ctx->ngroups, ctx->stream));
     launch_vardct_groups(ctx->stream, f, 0, 0, ctx->worklist.p, &ctx->k1_launches, ctx->error_flag.p,
                          plan.sparse_k1 ? ctx->coeffs.p : nullptr, ctx->rerender_list.p, n, ctx->has_special,
-                         ctx->has_large);
+                         ctx->has_large, dense_route_groups(ctx, plan.sparse_k1));
   }
   if (jxlh_status st = mark_coefficients_read(ctx, plan.sparse_k1)) return st;
   // ---- the filters on every pixel row the listed groups influence: their own rows widened by the stage list's

@@ -157,6 +157,11 @@ struct jxlh_ctx {
   bool se_valid = false;  // the resident bucketed form is se_*[se_live] (else, with sp_sorted_valid, the pair words)
   bool epoch_dirty = false;
   bool sp_sorted_valid = false;
+  // per-group routing of a frame that is resident in the slot-bucketed form (round 6): route_live[g] != 0 = group g
+  // lives in its dense slab, not in the live set (empty = no routed group); route_dev the device copy the scan reads
+  std::vector<uint8_t> route_live, route_upload;
+  DevBuf<uint8_t> route_dev;
+  int n_route = 0;
   // extra channels inside the frame path (jxlh_frame_set_extra_channel): as handed over, converted, upsampled
   struct ExtraChannel {
     bool set = false, done = false;

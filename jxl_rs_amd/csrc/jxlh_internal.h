@@ -142,6 +142,11 @@ struct FrameDev {
   const uint16_t* se_entries;
   const uint8_t* se_counts;
   const uint2* se_runs;
+  // group_route[g] != 0 (nullable; host-written): group g is NOT read from its entries -- its coefficients live in its
+  // dense slab (it was submitted as a slab or as plain pairs, carried a value outside 10 bits, or added a pass to
+  // earlier content) while the rest of the frame is read in place.  k1_scan sends such a group's DCT-class varblocks to
+  // WorkLists::ditems.
+  const uint8_t* group_route;
   // The entries form may dequantise ONLY the coefficients that have an entry (everything else is +0.0f) when a zero
   // coefficient provably reconstructs to +0.0f and a non-zero one never to a zero: quant biases 0..2 in [1e-6, 1e6],
   // finite chroma-from-luma bases (host: se_direct_ok), every dequant weight in [1e-20, 1e20] (device: *tables_ok,
@@ -229,7 +234,7 @@ void vardct_worklist_reset(hipStream_t s, void* worklist_mem, uint32_t* launch_p
 void launch_vardct_groups(hipStream_t s, const FrameDev& f, int group_row0, int group_row1,
                           void* worklist_mem, uint32_t* launch_parity, int* error_flag, int32_t* dense_coeffs,
                           const int* group_list = nullptr, int n_list = 0, bool has_special = true,
-                          bool has_large = true);
+                          bool has_large = true, int n_dense_route = 0);
 // k_strip.hip: dequantisation + IDCT + the frame's filter stages in one persistent kernel, result in f.tmp (raster).
 // Runs behind launch_vardct_groups on a FrameDev with the strip_* members set.  false = stage list not covered.
 int strip_resident_workgroups(int cu_count);

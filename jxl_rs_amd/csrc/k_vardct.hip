@@ -70,6 +70,7 @@ __global__ __launch_bounds__(kScanThreads) void k1_scan(const FrameDev f, const 
   __shared__ int s_wave_sum[kScanGroups][kWaves];
   __shared__ uint32_t s_wcls[kScanGroups][kWaves][kPairs];
   __shared__ int s_count[kScanGroups][kNumClasses], s_base[kScanGroups][kNumClasses];
+  __shared__ int s_route[kScanGroups];  // ENT: != 0 = the quarter's group is read from its dense slab (FrameDev::group_route)
   __shared__ int s_tmode[kScanGroups][16];  // STRIP: != 0 = a tile of the group (4 x 4 of them) the class kernels keep
   // ENT: exclusive prefix of the slot counts, three channels packed (17 bits each; a run holds at most 65536 entries)
   __shared__ uint64_t s_pref[ENT ? kScanGroups : 1][ENT ? kSlotsPerRun + 1 : 1];
@@ -106,8 +107,11 @@ __global__ __launch_bounds__(kScanThreads) void k1_scan(const FrameDev f, const 
   // ENT: counts of slots 4 tid .. 4 tid + 3 of the three channels, {first entry, entries} of the three runs
   uint32_t cw[3] = {0u, 0u, 0u};
   uint2 run[3] = {make_uint2(0u, 0u), make_uint2(0u, 0u), make_uint2(0u, 0u)};
+  bool dense_route = false;
   if constexpr (ENT) {
-    if (live) {
+    dense_route = live && f.group_route && f.group_route[group] != 0;
+    if (tid == 0) s_route[sub] = dense_route ? 1 : 0;  // (published by the barriers below)
+    if (live && !dense_route) {
 #pragma unroll
       for (int c = 0; c < 3; c++) {
         cw[c] = *reinterpret_cast<const uint32_t*>(f.se_counts + ((size_t)group * 3 + c) * kSlotsPerRun + 4 * tid);
@@ -252,20 +256,27 @@ __global__ __launch_bounds__(kScanThreads) void k1_scan(const FrameDev f, const 
       s_count[sub][tid] = bad_group ? 0 : (int)((total >> ((tid & 1) * 16)) & 0xffffu);
   }
   __syncthreads();
-  // one atomic per class for the whole workgroup; the quarters take consecutive ranges in group order
-  if (threadIdx.x < kNumClasses) {
-    const int c = threadIdx.x;
+  // one atomic per class for the whole workgroup; the quarters take consecutive ranges in group order.  ENT: the DCT
+  // classes of a dense-route quarter count into the dense lists (threads 32 .. 32 + kClsSpecial) instead
+  if (threadIdx.x < kNumClasses || (ENT && threadIdx.x >= 32 && threadIdx.x < 32 + kClsSpecial)) {
+    const bool dlist = threadIdx.x >= 32;
+    const int c = dlist ? threadIdx.x - 32 : threadIdx.x;
+    auto mine_q = [&](int q) { return !ENT || c >= kClsSpecial || (s_route[q] != 0) == dlist; };
     int total = 0;
 #pragma unroll
-    for (int q = 0; q < kScanGroups; q++) total += s_count[q][c];
-    int base = total > 0 ? atomicAdd(&wl.counts[c * kCountPitch], total) : 0;
+    for (int q = 0; q < kScanGroups; q++) total += mine_q(q) ? s_count[q][c] : 0;
+    int base = total > 0 ? atomicAdd(&wl.counts[(dlist ? kCntDense0 + c : c) * kCountPitch], total) : 0;
 #pragma unroll
     for (int q = 0; q < kScanGroups; q++) {
-      s_base[q][c] = base;
-      base += s_count[q][c];
+      if (mine_q(q)) {
+        s_base[q][c] = base;
+        base += s_count[q][c];
+      }
     }
   }
-  if (live && tid == 0 && f.group_dense) f.group_dense[group] = (s_count[sub][kClsSpecial] | s_count[sub][kClsLarge]) != 0;
+  // (a dense-route group's slab is already there: nothing to expand for its special / large varblocks)
+  if (live && tid == 0 && f.group_dense)
+    f.group_dense[group] = !dense_route && (s_count[sub][kClsSpecial] | s_count[sub][kClsLarge]) != 0;
   if constexpr (STRIP) {
     if (live && tid < 16) {
       const int gtx = (group % f.xgroups) * 4 + (tid & 3), gty = (group / f.xgroups) * 4 + (tid >> 2);
@@ -289,26 +300,33 @@ __global__ __launch_bounds__(kScanThreads) void k1_scan(const FrameDev f, const 
 #pragma unroll
         for (int w = 0; w < kPairs; w++)
           if ((cls >> 1) == w) rank += (int)((excl[w] >> sh) & 0xffffu);
+        bool to_dense = false;
         if constexpr (ENT) {
           if (cls < kClsSpecial) {
-            // (the prefixes were published by the barriers above.)  A count table that claims more than its run holds
-            // is cut at the run's end: no entry outside the run is ever read
-            const uint64_t p0 = s_pref[sub][off64], p1 = s_pref[sub][min(off64 + sizes[i], kSlotsPerRun)];
-            EntryItem ei;
-            uint32_t n[3];
+            if (dense_route) {
+              to_dense = true;
+              wl.ditems[cls][s_base[sub][cls] + rank] = it;
+            } else {
+              // (the prefixes were published by the barriers above.)  A count table that claims more than its run holds
+              // is cut at the run's end: no entry outside the run is ever read.  A DCT-class varblock has at most 16
+              // slots of at most 255 entries: the counts fit their 16 bits
+              const uint64_t p0 = s_pref[sub][off64], p1 = s_pref[sub][min(off64 + sizes[i], kSlotsPerRun)];
+              EntryItem ei;
+              uint32_t n[3];
 #pragma unroll
-            for (int c = 0; c < 3; c++) {
-              const uint32_t a0 = min((uint32_t)(p0 >> (17 * c)) & 0x1ffffu, run[c].y);
-              const uint32_t a1 = min((uint32_t)(p1 >> (17 * c)) & 0x1ffffu, run[c].y);
-              ei.e0[c] = run[c].x + a0;
-              n[c] = min(a1 - a0, 1024u);
+              for (int c = 0; c < 3; c++) {
+                const uint32_t a0 = min((uint32_t)(p0 >> (17 * c)) & 0x1ffffu, run[c].y);
+                const uint32_t a1 = min((uint32_t)(p1 >> (17 * c)) & 0x1ffffu, run[c].y);
+                ei.e0[c] = run[c].x + a0;
+                n[c] = min(a1 - a0, 0xffffu);
+              }
+              ei.nxy = n[0] | n[1] << 16;
+              it.group |= n[2] << 16;
+              wl.eitems[cls][s_base[sub][cls] + rank] = ei;
             }
-            ei.nxy = n[0] | n[1] << 16;
-            it.group |= n[2] << 16;
-            wl.eitems[cls][s_base[sub][cls] + rank] = ei;
           }
         }
-        wl.items[cls][s_base[sub][cls] + rank] = it;
+        if (!to_dense) wl.items[cls][s_base[sub][cls] + rank] = it;
       }
       if constexpr (STRIP) {
         if (strip_tile) {
@@ -425,8 +443,14 @@ struct EntLane {
   uint32_t i0[3], i1[3];  // this lane's first entry / the end of the varblock's range, per channel (frame-wide indices)
   uint32_t e[3][D];       // the lane's first D entries of each channel
 };
-template <class S, int D>
-__device__ __forceinline__ void entries_begin(const FrameDev& f, const BlockInfo* __restrict__ binfo, uint32_t* __restrict__ s_excl,
+// EX: the word an exclusive slot-count prefix of the three channels is packed in.  uint32_t, 10 bits per channel: enough
+// for the varblocks the direct path takes (at most D entries per lane); uint64_t, 21 bits per channel: any count a
+// varblock can legally have (16 slots x 255 entries -- repeated positions of several passes, wide values split into
+// in-range entries), what the dense dequantisation pass (mode 2, the fallback of the direct kernels) is built with.
+template <class EX>
+constexpr int excl_bits() { return sizeof(EX) == 8 ? 21 : 10; }
+template <class S, int D, class EX>
+__device__ __forceinline__ void entries_begin(const FrameDev& f, const BlockInfo* __restrict__ binfo, EX* __restrict__ s_excl,
                                               int nb, int lane, EntLane<D>& sl) {
   constexpr int LPB = 64 / S::NB, NS = S::N / 64;
   static_assert(LPB >= NS, "one lane per slot for the count scan");
@@ -445,31 +469,40 @@ __device__ __forceinline__ void entries_begin(const FrameDev& f, const BlockInfo
       sl.e[c][k] = i < sl.i1[c] ? (uint32_t)f.se_entries[i] : 0u;
     }
   if constexpr (NS > 1) {
-    uint32_t packed = 0;
+    constexpr int B = excl_bits<EX>();
+    EX packed = 0;
     if (on && j < NS) {
       const uint8_t* cp = f.se_counts + binfo[b].cnt_base + j;
-      packed = (uint32_t)cp[0] | (uint32_t)cp[kSlotsPerRun] << 10 | (uint32_t)cp[2 * kSlotsPerRun] << 20;
+      packed = (EX)cp[0] | (EX)cp[kSlotsPerRun] << B | (EX)cp[2 * kSlotsPerRun] << (2 * B);
     }
+    auto shfl_up = [](EX v, int d) {
+      if constexpr (sizeof(EX) == 8) {
+        const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)v, d, LPB), hi = (uint32_t)__shfl_up((int)(uint32_t)(v >> 32), d, LPB);
+        return (EX)((uint64_t)lo | (uint64_t)hi << 32);
+      } else {
+        return (EX)__shfl_up((int)v, d, LPB);
+      }
+    };
     // exclusive scan over the block's lanes (segments of LPB lanes): shift by one slot, then an inclusive scan
-    uint32_t x = (uint32_t)__shfl_up((int)packed, 1, LPB);
+    EX x = shfl_up(packed, 1);
     if (j == 0) x = 0;
 #pragma unroll
     for (int d = 1; d < NS; d <<= 1) {
-      const uint32_t y = (uint32_t)__shfl_up((int)x, d, LPB);
+      const EX y = shfl_up(x, d);
       if (j >= d) x += y;
     }
     if (j < NS) s_excl[b * NS + j] = x;  // b < NB always: the tile holds NB * NS words
   }
 }
 // position (in the varblock's stored order) of entry e, the r-th of the varblock's range of channel ch
-template <class S>
-__device__ __forceinline__ int entry_pos(const uint32_t* __restrict__ s_excl, int b, int ch, uint32_t e, uint32_t r) {
-  constexpr int NS = S::N / 64;
+template <class S, class EX>
+__device__ __forceinline__ int entry_pos(const EX* __restrict__ s_excl, int b, int ch, uint32_t e, uint32_t r) {
+  constexpr int NS = S::N / 64, B = excl_bits<EX>();
   int sidx = 0;
   if constexpr (NS > 1) {
 #pragma unroll
     for (int step = NS / 2; step >= 1; step >>= 1) {
-      const uint32_t v = (s_excl[b * NS + sidx + step] >> (10 * ch)) & 1023u;
+      const uint32_t v = (uint32_t)(s_excl[b * NS + sidx + step] >> (B * ch)) & ((1u << B) - 1u);
       if (r >= v) sidx += step;
     }
   }
@@ -485,16 +518,16 @@ __device__ __forceinline__ void zero_tile(int* __restrict__ ibuf, int lane) {
   }
 }
 
-template <class S, int D>
+template <class S, int D, class EX>
 __device__ __forceinline__ void entries_stage_channel(const FrameDev& f, int ch, float* __restrict__ buf,
-                                                      const uint32_t* __restrict__ s_excl, int lane, const EntLane<D>& sl) {
+                                                      const EX* __restrict__ s_excl, int lane, const EntLane<D>& sl) {
   int* ibuf = reinterpret_cast<int*>(buf);
   zero_tile<S>(ibuf, lane);
   wave_sync();
   constexpr int LPB = 64 / S::NB;
   const int b = lane / LPB, j = lane % LPB;
   auto add = [&](uint32_t e, uint32_t r) {  // r: index of the entry inside the varblock's range
-    atomicAdd(&ibuf[m_addr<S>(b, entry_pos<S>(s_excl, b, ch, e, r))], (int)(e << 16) >> 22);
+    atomicAdd(&ibuf[m_addr<S>(b, entry_pos<S, EX>(s_excl, b, ch, e, r))], (int)(e << 16) >> 22);
   };
 #pragma unroll
   for (int k = 0; k < D; k++)
@@ -607,22 +640,32 @@ __device__ __forceinline__ int4 tile_q4(const float* __restrict__ buf, int b, in
 // SPARSE: 0 = dense slabs, 1 = bucketed pair words + slot tables (sp_sorted), 2 = slot-bucketed entries in place (se_*)
 // with the dense dequantisation pass, 3 = the same input, direct path only: batches it cannot take go to the fallback
 // list (WorkLists::fallback), which k1_entries_fallback runs through mode 2.  cls: the class id (mode 3's list entries).
-template <class S, bool PREFETCH, int SPARSE, bool SUB = false, int CLS = 0>
+// INLINE_FB (mode 3): a batch the direct path cannot take runs through the dense dequantisation pass right here instead
+// of going to the fallback list -- for the 8x8 class, whose generic body costs a handful of registers: a frame denser
+// than d1 content then degrades batch by batch inside one launch (round 6).
+// s_dy (mode 2, shapes with 32 coefficients per lane; nullable): the dequantised Y of the batch waits in LDS for the X / B
+// channels' chroma-from-luma instead of in 32 registers through two 32-point IDCTs -- the kernels that take it run two
+// workgroups per CU and have the room (S::E * 64 floats per wavefront).
+template <class S, bool PREFETCH, int SPARSE, bool SUB = false, int CLS = 0, bool INLINE_FB = false, class EX = uint32_t>
 __device__ __forceinline__ int run_dct_class(const FrameDev& f, const WorkItem* __restrict__ items,
                                              const EntryItem* __restrict__ eitems, int count, int type,
                                              float* __restrict__ buf, BlockInfo* __restrict__ binfo_base,
-                                             uint32_t* __restrict__ s_excl, float* __restrict__ s_lf, int gwave,
+                                             EX* __restrict__ s_excl, float* __restrict__ s_lf, int gwave,
                                              int nwaves, int lane, const AdjTable* __restrict__ adj,
                                              uint32_t* __restrict__ wl_fallback = nullptr,
-                                             int* __restrict__ fallback_count = nullptr) {
+                                             int* __restrict__ fallback_count = nullptr, float* __restrict__ s_dy = nullptr,
+                                             const uint32_t* __restrict__ batch_list = nullptr, int n_listed = 0) {
   constexpr int NCH = S::E / 4;  // 16-byte chunks per lane per channel
   const int q = quant_table_for_type(type);
   const float* __restrict__ table = f.tables + f.table_offset[q];
   const int tsize = quant_table_size(q);
-  const int nbatches = (count + S::NB - 1) / S::NB;
+  // batch_list (the fallback launch): the batches to run are the n_listed entries of the list instead of all of the class
+  const int nbatches = batch_list ? n_listed : (count + S::NB - 1) / S::NB;
+  auto batch_of = [&](int bi) { return batch_list ? (int)batch_list[bi] : bi; };
   // the weights a lane needs do not depend on the batch
-  float4 tw[PREFETCH ? 3 : 1][NCH];
-  if constexpr (PREFETCH && SPARSE != 3) {
+  constexpr bool kPF = PREFETCH && SPARSE != 3;  // (the inline fallback of mode 3 reads its weights per batch)
+  float4 tw[kPF ? 3 : 1][NCH];
+  if constexpr (kPF) {
 #pragma unroll
     for (int c = 0; c < 3; c++)
 #pragma unroll
@@ -643,22 +686,28 @@ __device__ __forceinline__ int run_dct_class(const FrameDev& f, const WorkItem* 
   WorkItem it_next = {};
   EntryItem ei_next = {};
   if constexpr (kNextItem) {
-    if (gwave < nbatches && lane < min(S::NB, count - gwave * S::NB)) {
-      it_next = items[gwave * S::NB + lane];
-      ei_next = eitems[gwave * S::NB + lane];
+    if (gwave < nbatches) {
+      const int b0 = batch_of(gwave);
+      if (lane < min(S::NB, count - b0 * S::NB)) {
+        it_next = items[b0 * S::NB + lane];
+        ei_next = eitems[b0 * S::NB + lane];
+      }
     }
   }
-  for (int batch = gwave; batch < nbatches; batch += nwaves) {
+  for (int bi = gwave; bi < nbatches; bi += nwaves) {
+    const int batch = batch_of(bi);
     const int nb = min(S::NB, count - batch * S::NB);
     BlockInfo* __restrict__ binfo = binfo_base;
     if constexpr (kChain) {
       WorkItem it = it_next;
       EntryItem ei = ei_next;
       if constexpr (kNextItem) {
-        const int nxt = batch + nwaves;
-        if (nxt < nbatches && lane < min(S::NB, count - nxt * S::NB)) {
-          it_next = items[nxt * S::NB + lane];
-          ei_next = eitems[nxt * S::NB + lane];
+        if (bi + nwaves < nbatches) {
+          const int nxt = batch_of(bi + nwaves);
+          if (lane < min(S::NB, count - nxt * S::NB)) {
+            it_next = items[nxt * S::NB + lane];
+            ei_next = eitems[nxt * S::NB + lane];
+          }
         }
       } else if (lane < nb) {
         it = items[batch * S::NB + lane];
@@ -684,7 +733,7 @@ __device__ __forceinline__ int run_dct_class(const FrameDev& f, const WorkItem* 
       sparse_ranges<S>(f, binfo, nb, lane, sl);
       sparse_first<S>(f, sl);
     } else if constexpr (SPARSE >= 2) {
-      entries_begin<S, D>(f, binfo, s_excl, nb, lane, el);
+      entries_begin<S, D, EX>(f, binfo, s_excl, nb, lane, el);
     }
     if constexpr (kChain) {
       // LF sample idx = (block, channel, y, x) of the batch: requested now, in LDS before the first transform
@@ -732,49 +781,11 @@ __device__ __forceinline__ int run_dct_class(const FrameDev& f, const WorkItem* 
     using TagX = std::integral_constant<int, 0>;
     using TagY = std::integral_constant<int, 1>;
     using TagB = std::integral_constant<int, 2>;
-    if constexpr (SPARSE == 3) {
-      // direct path: every varblock of the batch has a raw_quant the division survives and no more entries per channel
-      // than its lanes hold -- otherwise the batch is left to the dense pass (k1_entries_fallback)
-      constexpr int LPB = 64 / S::NB;
-      const int b = lane / LPB, j = lane % LPB;
-      bool mine = true;
-      float sdy = 0.0f, xcc = 0.0f, bcc = 0.0f;
-      if (b < nb) {
-        sdy = binfo[b].sdy;
-        xcc = binfo[b].x_cc;
-        bcc = binfo[b].b_cc;
-        mine = sdy > 0.0f && sdy < __builtin_inff() && max(max(binfo[b].en[0], binfo[b].en[1]), binfo[b].en[2]) <= (uint32_t)(D * LPB);
-      }
-      if (!__all(mine)) {
-        if (lane == 0) wl_fallback[atomicAdd(fallback_count, 1)] = (uint32_t)CLS << 24 | (uint32_t)batch;
-        wave_sync();  // binfo / s_lf / s_excl are rewritten by the next batch
-        continue;
-      }
-      wave_sync();  // the slot prefixes (entries_begin) are in LDS
-      EntDirect<D> ed;
-#pragma unroll
-      for (int c = 0; c < 3; c++)
-#pragma unroll
-        for (int k = 0; k < D; k++) {
-          ed.ad[c][k] = kNoEntry;
-          if (el.i0[c] + k * LPB < el.i1[c]) {
-            const uint32_t e = el.e[c][k];
-            ed.ad[c][k] = (uint32_t)entry_pos<S>(s_excl, b, c, e, (uint32_t)(j + k * LPB)) | (uint32_t)((int)(e << 16) >> 22) << 16;
-          }
-        }
-      float dyw[D];
-      uint32_t ywin = 0;
-#pragma unroll
-      for (int k = 0; k < D; k++) dyw[k] = 0.0f;
-      direct_stage_channel<S, 1, D>(f, buf, lane, ed, table, tsize, sdy, 0.0f, adj, dyw, ywin);
-      transform_channel(TagY{});
-      direct_stage_channel<S, 0, D>(f, buf, lane, ed, table, tsize, sdy, xcc, adj, dyw, ywin);
-      transform_channel(TagX{});
-      direct_stage_channel<S, 2, D>(f, buf, lane, ed, table, tsize, sdy, bcc, adj, dyw, ywin);
-      transform_channel(TagB{});
-    } else {
-      int4 qv[PREFETCH ? 3 : 1][NCH];
-      if constexpr (PREFETCH && !SPARSE) {
+    // the dense dequantisation pass: every coefficient position of the batch (GM: 0 dense slabs, 1 pair words, 2 entries)
+    auto generic_batch = [&](auto mode_tag) {
+      constexpr int GM = decltype(mode_tag)::value;
+      int4 qv[kPF ? 3 : 1][NCH];
+      if constexpr (kPF && !GM) {
 #pragma unroll
         for (int c = 0; c < 3; c++)
 #pragma unroll
@@ -790,12 +801,13 @@ __device__ __forceinline__ int run_dct_class(const FrameDev& f, const WorkItem* 
       // the shape with 32 of them per lane (32x32, dense input), where they would sit through two 32-point IDCTs
       // (167 VGPRs + 16 spilled + 68 bytes of scratch for that class alone): there X and B dequantise their Y values again
       // (the coefficient read hits L2, the table-driven dequantisation is ~10 instructions per value).
-      constexpr bool kRecomputeY = !SPARSE && !PREFETCH && S::E > 16;
-      float dy[kRecomputeY ? 4 : S::E];
+      constexpr bool kRecomputeY = !GM && !PREFETCH && S::E > 16;
+      constexpr bool kDyLds = GM == 2 && SPARSE == 2 && S::E > 16;  // (callers of mode 2 pass s_dy)
+      float dy[kRecomputeY || kDyLds ? 4 : S::E];
       auto stage_channel = [&](auto ch_tag) {
         constexpr int CH = decltype(ch_tag)::value;
-        if constexpr (SPARSE == 1) sparse_stage_channel<S>(f, CH, buf, lane, sl);
-        if constexpr (SPARSE == 2) entries_stage_channel<S, D>(f, CH, buf, s_excl, lane, el);
+        if constexpr (GM == 1) sparse_stage_channel<S>(f, CH, buf, lane, sl);
+        if constexpr (GM == 2) entries_stage_channel<S, D, EX>(f, CH, buf, s_excl, lane, el);
 #pragma unroll
         for (int j = 0; j < NCH; j++) {
           const int fl = (j * 64 + lane) * 4;
@@ -804,6 +816,15 @@ __device__ __forceinline__ int run_dct_class(const FrameDev& f, const WorkItem* 
           float d4[4];
           if constexpr (kRecomputeY) {
             d4[0] = d4[1] = d4[2] = d4[3] = 0.0f;
+          } else if constexpr (kDyLds) {
+            d4[0] = d4[1] = d4[2] = d4[3] = 0.0f;
+            if constexpr (CH != 1) {
+              const float4 t = *reinterpret_cast<const float4*>(s_dy + (j * 64 + lane) * 4);
+              d4[0] = t.x;
+              d4[1] = t.y;
+              d4[2] = t.z;
+              d4[3] = t.w;
+            }
           } else {
             d4[0] = dy[j * 4];
             d4[1] = dy[j * 4 + 1];
@@ -814,11 +835,11 @@ __device__ __forceinline__ int run_dct_class(const FrameDev& f, const WorkItem* 
             const BlockInfo bi = binfo[b];
             int4 qq;
             float4 tt;
-            if constexpr (SPARSE != 0) {
+            if constexpr (GM != 0) {
               qq = tile_q4<S>(buf, b, k);  // converted in place: this lane alone touches (b, k..k+3)
-              if constexpr (PREFETCH) tt = tw[CH][j];
+              if constexpr (kPF) tt = tw[CH][j];
               else tt = *reinterpret_cast<const float4*>(table + CH * tsize + k);
-            } else if constexpr (PREFETCH) {
+            } else if constexpr (kPF) {
               qq = qv[CH][j];
               tt = tw[CH][j];
             } else {
@@ -830,15 +851,11 @@ __device__ __forceinline__ int run_dct_class(const FrameDev& f, const WorkItem* 
                 (void)dequant4t<1>(f, qy, ty, bi, adj, d4);
               }
             }
-#ifdef JXLH_EXP_NODEQUANT  // timing experiment only (wrong pixels): what the dense dequantisation pass costs
-            if constexpr (SPARSE == 2) {
-              v = make_float4((float)qq.x * tt.x, (float)qq.y * tt.y, (float)qq.z * tt.z, (float)qq.w * tt.w);
-              d4[0] = d4[1] = d4[2] = d4[3] = bi.sdy;
-            } else
-#endif
             v = dequant4t<CH>(f, qq, tt, bi, adj, d4);
           }
-          if constexpr (CH == 1 && !kRecomputeY) {
+          if constexpr (CH == 1 && kDyLds) {
+            *reinterpret_cast<float4*>(s_dy + (j * 64 + lane) * 4) = make_float4(d4[0], d4[1], d4[2], d4[3]);
+          } else if constexpr (CH == 1 && !kRecomputeY) {
             dy[j * 4] = d4[0];
             dy[j * 4 + 1] = d4[1];
             dy[j * 4 + 2] = d4[2];
@@ -855,6 +872,54 @@ __device__ __forceinline__ int run_dct_class(const FrameDev& f, const WorkItem* 
       transform_channel(TagX{});
       stage_channel(TagB{});
       transform_channel(TagB{});
+    };
+    if constexpr (SPARSE == 3) {
+      // direct path: every varblock of the batch has a raw_quant the division survives and no more entries per channel
+      // than its lanes hold -- otherwise the batch is left to the dense pass (k1_entries_fallback)
+      constexpr int LPB = 64 / S::NB;
+      const int b = lane / LPB, j = lane % LPB;
+      bool mine = true;
+      float sdy = 0.0f, xcc = 0.0f, bcc = 0.0f;
+      if (b < nb) {
+        sdy = binfo[b].sdy;
+        xcc = binfo[b].x_cc;
+        bcc = binfo[b].b_cc;
+        mine = sdy > 0.0f && sdy < __builtin_inff() && max(max(binfo[b].en[0], binfo[b].en[1]), binfo[b].en[2]) <= (uint32_t)(D * LPB);
+      }
+      if (!__all(mine)) {
+        if constexpr (INLINE_FB) {
+          static_assert(S::N == 64, "the inline fallback has no slot prefixes: one-slot varblocks only");
+          generic_batch(std::integral_constant<int, 2>{});
+        } else {
+          if (lane == 0) wl_fallback[atomicAdd(fallback_count, 1)] = (uint32_t)batch;
+        }
+        wave_sync();  // binfo / s_lf / s_excl are rewritten by the next batch
+        continue;
+      }
+      wave_sync();  // the slot prefixes (entries_begin) are in LDS
+      EntDirect<D> ed;
+#pragma unroll
+      for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int k = 0; k < D; k++) {
+          ed.ad[c][k] = kNoEntry;
+          if (el.i0[c] + k * LPB < el.i1[c]) {
+            const uint32_t e = el.e[c][k];
+            ed.ad[c][k] = (uint32_t)entry_pos<S, EX>(s_excl, b, c, e, (uint32_t)(j + k * LPB)) | (uint32_t)((int)(e << 16) >> 22) << 16;
+          }
+        }
+      float dyw[D];
+      uint32_t ywin = 0;
+#pragma unroll
+      for (int k = 0; k < D; k++) dyw[k] = 0.0f;
+      direct_stage_channel<S, 1, D>(f, buf, lane, ed, table, tsize, sdy, 0.0f, adj, dyw, ywin);
+      transform_channel(TagY{});
+      direct_stage_channel<S, 0, D>(f, buf, lane, ed, table, tsize, sdy, xcc, adj, dyw, ywin);
+      transform_channel(TagX{});
+      direct_stage_channel<S, 2, D>(f, buf, lane, ed, table, tsize, sdy, bcc, adj, dyw, ywin);
+      transform_channel(TagB{});
+    } else {
+      generic_batch(std::integral_constant<int, SPARSE>{});
     }
   }
   return nbatches;
@@ -866,6 +931,10 @@ __device__ __forceinline__ int rotate_wave(int gw, int used, int nw) {
   return r < 0 ? r + nw : r;
 }
 
+template <class S>
+struct ShapeTag {
+  using type = S;
+};
 using S8x8 = Shape<8, 8>;
 using S16x16 = Shape<16, 16>;
 using S32x32 = Shape<32, 32>;
@@ -889,10 +958,11 @@ __global__ __launch_bounds__(kThreads) void k1_dct8(const FrameDev f, const Work
   build_adj_table(f, &s_adj, threadIdx.x, kThreads);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   __shared__ float s_lf[SPARSE >= 2 ? kWaves : 1][S8x8::NB * 3];
-  run_dct_class<S8x8, true, SPARSE, SUB, kClsDct8>(f, wl.items[kClsDct8], wl.eitems[kClsDct8], wl.counts[(kClsDct8) * kCountPitch], 0,
-                                                   s_buf + wave * kTileA, s_binfo[wave], nullptr, s_lf[SPARSE >= 2 ? wave : 0],
-                                                   blockIdx.x * kWaves + wave, gridDim.x * kWaves, lane, &s_adj, wl.fallback,
-                                                   wl.counts + kCntFallback * kCountPitch);
+  // (mode 3: batches beyond the direct path's depth take the dense dequantisation pass inline -- one-slot varblocks need
+  // no slot prefixes, and the generic body fits the kernel's registers)
+  run_dct_class<S8x8, true, SPARSE, SUB, kClsDct8, SPARSE == 3>(f, wl.items[kClsDct8], wl.eitems[kClsDct8], wl.counts[(kClsDct8) * kCountPitch], 0,
+                                                   s_buf + wave * kTileA, s_binfo[wave], (uint32_t*)nullptr, s_lf[SPARSE >= 2 ? wave : 0],
+                                                   blockIdx.x * kWaves + wave, gridDim.x * kWaves, lane, &s_adj);
 }
 
 // families B (16x8, 8x16, 16x16) + C (everything with a 32-point side) in ONE launch (round 3): as two kernels both
@@ -906,77 +976,54 @@ constexpr int kExclWords = 40;
 #ifndef JXLH_K1_DIRECT_WPE
 #define JXLH_K1_DIRECT_WPE 3  // waves per SIMD the direct form of k1_dct16_32 is compiled for
 #endif
-template <int SPARSE>
-__global__ __launch_bounds__(kThreads, SPARSE == 3 ? JXLH_K1_DIRECT_WPE : 3) void k1_dct16_32(const FrameDev f, const WorkLists wl) {
+// mode 2 (the dense dequantisation pass of the entries form: frames whose parameters rule the direct path out) is
+// compiled for two workgroups per CU: its 32-point bodies then hold everything in registers + the LDS stash of the
+// dequantised Y (at three they spilled 250-330 bytes per lane)
+constexpr int kDyWords = 32 * 64;  // S::E * 64 for the shapes with a 32-point side
+// FB (mode 2 only): the fallback launch of the direct form -- per class, the batches of WorkLists::fallback[class] (what
+// k1_dct16_32<3> could not take: more entries than its lanes hold, raw_quant == 0) instead of the class's whole list.
+// Usually a handful of batches (the workgroups read eight counters and leave); on content denser than d1 it is the
+// main route of these classes.  (Round 5's fallback kernel dispatched one mixed list through a switch over the nine
+// bodies: 203 spilled VGPRs, 792 bytes of scratch per lane.)
+template <int SPARSE, bool FB = false>
+__global__ __launch_bounds__(kThreads, SPARSE == 3 ? JXLH_K1_DIRECT_WPE : SPARSE == 2 ? 2 : 3) void k1_dct16_32(const FrameDev f, const WorkLists wl) {
+  static_assert(!FB || SPARSE == 2, "the fallback launch runs the dense dequantisation pass of the entries form");
   __shared__ __attribute__((aligned(16))) float s_buf[kWaves * kTileC];
   __shared__ BlockInfo s_binfo[kWaves][8];
-  __shared__ uint32_t s_excl[SPARSE >= 2 ? kWaves : 1][kExclWords];
+  using EX = std::conditional_t<SPARSE == 2, uint64_t, uint32_t>;  // mode 2 takes any entry count (excl_bits)
+  __shared__ EX s_excl[SPARSE >= 2 ? kWaves : 1][kExclWords];
   __shared__ AdjTable s_adj;
   build_adj_table(f, &s_adj, threadIdx.x, kThreads);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float* buf = s_buf + wave * kTileC;
-  uint32_t* ex = s_excl[SPARSE >= 2 ? wave : 0];
+  EX* ex = s_excl[SPARSE >= 2 ? wave : 0];
   __shared__ float s_lfs[SPARSE >= 2 ? kWaves : 1][96];  // LF samples of a batch: NB * 3 * (R / 8) * (C / 8) <= 96
   float* lfs = s_lfs[SPARSE >= 2 ? wave : 0];
+  __shared__ __attribute__((aligned(16))) float s_dyb[SPARSE == 2 ? kWaves * kDyWords : 4];
+  float* sdy = SPARSE == 2 ? s_dyb + wave * kDyWords : nullptr;
   const int gw = blockIdx.x * kWaves + wave, nw = gridDim.x * kWaves;
   auto cnt = [&](int cls) { return wl.counts[cls * kCountPitch]; };
-  int* fbc = wl.counts + kCntFallback * kCountPitch;
   // the long batches (32-point sides) first: the tail of the launch is then made of the short ones
-  int used = run_dct_class<S32x32, false, SPARSE, false, kClsDct32x32>(f, wl.items[kClsDct32x32], wl.eitems[kClsDct32x32], cnt(kClsDct32x32), 5, buf,
-                                                  s_binfo[wave], ex, lfs, gw, nw, lane, &s_adj, wl.fallback, fbc);
-  used += run_dct_class<S32x16, false, SPARSE, false, kClsDct32x16>(f, wl.items[kClsDct32x16], wl.eitems[kClsDct32x16], cnt(kClsDct32x16), 10, buf,
-                                               s_binfo[wave], ex, lfs, rotate_wave(gw, used, nw), nw, lane, &s_adj, wl.fallback, fbc);
-  used += run_dct_class<S16x32, false, SPARSE, false, kClsDct16x32>(f, wl.items[kClsDct16x32], wl.eitems[kClsDct16x32], cnt(kClsDct16x32), 11, buf,
-                                               s_binfo[wave], ex, lfs, rotate_wave(gw, used, nw), nw, lane, &s_adj, wl.fallback, fbc);
-  used += run_dct_class<S32x8, false, SPARSE, false, kClsDct32x8>(f, wl.items[kClsDct32x8], wl.eitems[kClsDct32x8], cnt(kClsDct32x8), 8, buf,
-                                              s_binfo[wave], ex, lfs, rotate_wave(gw, used, nw), nw, lane, &s_adj, wl.fallback, fbc);
-  used += run_dct_class<S8x32, false, SPARSE, false, kClsDct8x32>(f, wl.items[kClsDct8x32], wl.eitems[kClsDct8x32], cnt(kClsDct8x32), 9, buf,
-                                              s_binfo[wave], ex, lfs, rotate_wave(gw, used, nw), nw, lane, &s_adj, wl.fallback, fbc);
-  used += run_dct_class<S16x16, true, SPARSE, false, kClsDct16x16>(f, wl.items[kClsDct16x16], wl.eitems[kClsDct16x16], cnt(kClsDct16x16), 4, buf,
-                                              s_binfo[wave], ex, lfs, rotate_wave(gw, used, nw), nw, lane, &s_adj, wl.fallback, fbc);
-  used += run_dct_class<S16x8, true, SPARSE, false, kClsDct16x8>(f, wl.items[kClsDct16x8], wl.eitems[kClsDct16x8], cnt(kClsDct16x8), 6, buf,
-                                             s_binfo[wave], ex, lfs, rotate_wave(gw, used, nw), nw, lane, &s_adj, wl.fallback, fbc);
-  run_dct_class<S8x16, true, SPARSE, false, kClsDct8x16>(f, wl.items[kClsDct8x16], wl.eitems[kClsDct8x16], cnt(kClsDct8x16), 7, buf, s_binfo[wave], ex,
-                                     lfs, rotate_wave(gw, used, nw), nw, lane, &s_adj, wl.fallback, fbc);
-}
-
-// The batches the direct kernels left (WorkLists::fallback: class << 24 | batch), through the dense dequantisation pass
-// of the entries form (mode 2), one batch per wavefront at a time.  Usually a handful per frame: a small grid.
-__global__ __launch_bounds__(kThreads, 3) void k1_entries_fallback(const FrameDev f, const WorkLists wl) {
-  __shared__ __attribute__((aligned(16))) float s_buf[kWaves * kTileC];
-  __shared__ BlockInfo s_binfo[kWaves][8];
-  __shared__ uint32_t s_excl[kWaves][kExclWords];
-  __shared__ float s_lfs[kWaves][96];
-  __shared__ AdjTable s_adj;
-  const int total = wl.counts[kCntFallback * kCountPitch];
-  if (total == 0) return;  // (workgroup-uniform)
-  build_adj_table(f, &s_adj, threadIdx.x, kThreads);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float* buf = s_buf + wave * kTileC;
-  constexpr int kOne = 1 << 30;  // stride: run_dct_class then takes exactly the batch it is given
-  for (int i = blockIdx.x * kWaves + wave; i < total; i += gridDim.x * kWaves) {
-    const uint32_t e = wl.fallback[i];
-    const int cls = (int)(e >> 24), batch = (int)(e & 0xffffffu);
-    const int count = wl.counts[cls * kCountPitch];
-#define JXLH_FB(CLS, SHAPE, PF, TYPE)                                                                                  \
-  case CLS:                                                                                                            \
-    run_dct_class<SHAPE, PF, 2>(f, wl.items[CLS], wl.eitems[CLS], count, TYPE, buf, s_binfo[wave], s_excl[wave], s_lfs[wave], \
-                                batch, kOne, lane, &s_adj);                                                            \
-    break;
-    switch (cls) {  // wave-uniform
-      JXLH_FB(kClsDct8, S8x8, true, 0)
-      JXLH_FB(kClsDct16x8, S16x8, true, 6)
-      JXLH_FB(kClsDct8x16, S8x16, true, 7)
-      JXLH_FB(kClsDct16x16, S16x16, true, 4)
-      JXLH_FB(kClsDct32x8, S32x8, false, 8)
-      JXLH_FB(kClsDct8x32, S8x32, false, 9)
-      JXLH_FB(kClsDct32x16, S32x16, false, 10)
-      JXLH_FB(kClsDct16x32, S16x32, false, 11)
-      JXLH_FB(kClsDct32x32, S32x32, false, 5)
-      default: break;
-    }
-#undef JXLH_FB
-  }
+  int used = 0;
+  auto run = [&](auto shape_tag, auto pf_tag, auto cls_tag, int type) {
+    using S = typename decltype(shape_tag)::type;
+    constexpr bool PF = decltype(pf_tag)::value;
+    constexpr int CLS = decltype(cls_tag)::value;
+    const int listed = FB ? wl.counts[(kCntFallback0 + CLS) * kCountPitch] : 0;
+    if (FB && listed == 0) return;  // (wave-uniform)
+    used += run_dct_class<S, PF, SPARSE, false, CLS>(f, wl.items[CLS], wl.eitems[CLS], cnt(CLS), type, buf, s_binfo[wave], ex, lfs,
+                                                     rotate_wave(gw, used, nw), nw, lane, &s_adj, wl.fallback[CLS],
+                                                     wl.counts + (kCntFallback0 + CLS) * kCountPitch, sdy,
+                                                     FB ? wl.fallback[CLS] : nullptr, listed);
+  };
+  run(ShapeTag<S32x32>{}, std::false_type{}, std::integral_constant<int, kClsDct32x32>{}, 5);
+  run(ShapeTag<S32x16>{}, std::false_type{}, std::integral_constant<int, kClsDct32x16>{}, 10);
+  run(ShapeTag<S16x32>{}, std::false_type{}, std::integral_constant<int, kClsDct16x32>{}, 11);
+  run(ShapeTag<S32x8>{}, std::false_type{}, std::integral_constant<int, kClsDct32x8>{}, 8);
+  run(ShapeTag<S8x32>{}, std::false_type{}, std::integral_constant<int, kClsDct8x32>{}, 9);
+  run(ShapeTag<S16x16>{}, std::true_type{}, std::integral_constant<int, kClsDct16x16>{}, 4);
+  run(ShapeTag<S16x8>{}, std::true_type{}, std::integral_constant<int, kClsDct16x8>{}, 6);
+  run(ShapeTag<S8x16>{}, std::true_type{}, std::integral_constant<int, kClsDct8x16>{}, 7);
 }
 
 // family D: the nine 8x8 special transform types (IDENTITY, DCT2X2, DCT4X4, DCT4X8, DCT8X4, AFV0-3).
@@ -1173,8 +1220,9 @@ size_t vardct_worklist_bytes(const FrameDev& f) {
   const size_t nblocks = (size_t)f.xblocks * f.yblocks;
   size_t items = 0;
   for (int c = 0; c < kNumClasses; c++) items += nblocks / class_min_area(c) + 1;
-  for (int c = 0; c < kClsSpecial; c++) items += nblocks / class_min_area(c) + 1;  // entry side items of the DCT classes
-  items += nblocks / 4 + 16;  // the fallback batch list (u32 per batch, < nblocks / 2 batches in all): as 16-byte units
+  for (int c = 0; c < kClsSpecial; c++) items += 2 * (nblocks / class_min_area(c) + 1);  // entry side items of the DCT
+                                                                                         // classes + their dense-route lists
+  items += (size_t)kClsSpecial * (nblocks / 64 + 4);  // the fallback batch lists (u32 per batch, nblocks / 16 + 16 per class)
   // + the unit lists of the large transforms: one u32 per 4096 samples of a 256-pixel varblock (two-pass units) and
   //   one per varblock of the smaller types (three lists by slabs per channel; worst case one entry per 32 blocks)
   // + the LLF planes of the large transforms (3 x nblocks floats, k1_large_llf)
@@ -1189,7 +1237,7 @@ void vardct_worklist_reset(hipStream_t s, void* worklist_mem, uint32_t* launch_p
 
 void launch_vardct_groups(hipStream_t s, const FrameDev& f, int group_row0, int group_row1,
                           void* worklist_mem, uint32_t* launch_parity, int* error_flag, int32_t* dense_coeffs,
-                          const int* group_list, int n_list, bool has_special, bool has_large) {
+                          const int* group_list, int n_list, bool has_special, bool has_large, int n_dense_route) {
   const int ngroups = group_list ? n_list : (group_row1 - group_row0) * f.xgroups;
   if (ngroups <= 0) return;
   // carve the work-list memory: [two sets of counters, one 128-byte line each] [class 0 items] [class 1 items] ...
@@ -1207,8 +1255,14 @@ void launch_vardct_groups(hipStream_t s, const FrameDev& f, int group_row0, int 
     wl.eitems[c] = reinterpret_cast<EntryItem*>(p);
     p += (nblocks / class_min_area(c) + 1) * sizeof(EntryItem);
   }
-  wl.fallback = reinterpret_cast<uint32_t*>(p);
-  p += (nblocks / 4 + 16) * sizeof(WorkItem);
+  for (int c = 0; c < kClsSpecial; c++) {
+    wl.ditems[c] = reinterpret_cast<WorkItem*>(p);
+    p += (nblocks / class_min_area(c) + 1) * sizeof(WorkItem);
+  }
+  for (int c = 0; c < kClsSpecial; c++) {  // a class has at most nblocks / 16 batches (16x8: nblocks / 2 items of 8)
+    wl.fallback[c] = reinterpret_cast<uint32_t*>(p);
+    p += (nblocks / 16 + 16) * sizeof(uint32_t);
+  }
   uint32_t* large_units = reinterpret_cast<uint32_t*>(p);  // behind the last list
   const dim3 gscan((ngroups + kScanGroups - 1) / kScanGroups);
   if (f.strip_desc)
@@ -1263,8 +1317,26 @@ void launch_vardct_groups(hipStream_t s, const FrameDev& f, int group_row0, int 
       hipLaunchKernelGGL(k1_dct16_32<0>, g1632, dim3(kThreads), 0, s, f, wl);
     }
   }
-  // what the direct kernels left (usually next to nothing: the workgroups read one counter and leave)
-  if (sparse == 3) hipLaunchKernelGGL(k1_entries_fallback, dim3(std::min(512, std::max(1, nblk / 2048))), dim3(kThreads), 0, s, f, wl);
+  // what the direct form of k1_dct16_32 left (usually next to nothing: the workgroups read one counter and leave)
+  if (sparse == 3 && !f.subsampled)
+    hipLaunchKernelGGL((k1_dct16_32<2, true>), dim3(std::min(1024, std::max(1, nblk / 1024))), dim3(kThreads), 0, s, f, wl);
+  // entries form, groups routed to their dense slabs (FrameDev::group_route): the same class kernels in their dense
+  // form on those groups' lists; the grids follow the routed share of the frame
+  if (sparse >= 2 && n_dense_route > 0) {
+    WorkLists wd = wl;
+    for (int c = 0; c < kClsSpecial; c++) wd.items[c] = wl.ditems[c];
+    wd.counts = wl.counts + kCntDense0 * kCountPitch;
+    FrameDev fd = f;
+    fd.se_entries = nullptr;
+    const long dblk = (long)std::min(n_dense_route, ngroups) * kGroupBlocks * kGroupBlocks;
+    const dim3 d8(grid_for(dblk, kWaves * S8x8::NB * 2, 4096));
+    if (f.subsampled) {
+      hipLaunchKernelGGL((k1_dct8<0, true>), d8, dim3(kThreads), 0, s, fd, wd);
+    } else {
+      hipLaunchKernelGGL(k1_dct8<0>, d8, dim3(kThreads), 0, s, fd, wd);
+      hipLaunchKernelGGL(k1_dct16_32<0>, dim3(grid_for(dblk / 2, kWaves * 8 * 2, 4096)), dim3(kThreads), 0, s, fd, wd);
+    }
+  }
   // an empty special list (the d1 mix) pays for every launched workgroup: the grid follows the list's worst case
   if (has_special)
   {

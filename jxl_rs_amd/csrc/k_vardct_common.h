@@ -76,7 +76,8 @@ struct BlockInfo {
 };
 // Side item of the work lists when the frame is read in the slot-bucketed form (same index as the WorkItem):
 // frame-wide index of the varblock's first entry per channel, entries of the X run | Y run << 16 (the B run's count
-// rides in WorkItem::group).  A varblock of the DCT classes holds at most 1024 coefficients per channel.
+// rides in WorkItem::group).  16 bits each: a varblock of the DCT classes has at most 16 slots of at most 255 entries
+// (positions may repeat: several passes' updates, wide values split into in-range entries).
 struct __attribute__((aligned(16))) EntryItem {
   uint32_t e0[3];
   uint32_t nxy;
@@ -86,15 +87,22 @@ static_assert(sizeof(EntryItem) == 16, "entry item layout");
 // every class counter on its own 128-byte line: the 1024 scan workgroups' atomics then meet on nine lines (and L2
 // channels) instead of one
 constexpr int kCountPitch = 32;
-constexpr int kCountLines = kNumClasses + 5;  // the classes, the two-pass slab units, the three fused large lists,
-                                              // the entries form's fallback batches (kCntFallback)
-constexpr int kCntFallback = kNumClasses + 4;
+constexpr int kCntFallback0 = kNumClasses + 4;         // + class: batches of the class's fallback list
+constexpr int kCntDense0 = kCntFallback0 + kClsSpecial;  // first of the kClsSpecial counters of the dense-route DCT lists
+constexpr int kCountLines = kCntDense0 + kClsSpecial;  // the classes, the two-pass slab units, the three fused large
+                                              // lists, the entries form's fallback batches (kCntFallback0 ..), the DCT
+                                              // classes of the groups that are read from dense slabs (kCntDense0 ..)
 constexpr size_t kCountBytes = (size_t)kCountLines * kCountPitch * sizeof(int);
 struct WorkLists {
   WorkItem* items[kNumClasses];
   EntryItem* eitems[kClsSpecial];  // the DCT classes only: special / large varblocks read dense slabs
-  uint32_t* fallback;              // entries form, direct kernels: class << 24 | batch of the batches they leave to
-                                   // k1_entries_fallback (varblocks with more entries than a lane holds, raw_quant == 0)
+  // Entries form, per-group routing (round 6): the DCT-class varblocks of the groups FrameDev::group_route flags -- groups
+  // that arrived as a dense slab, as plain pairs, with a value outside the entries' 10 bits or as an added pass while
+  // the rest of the frame is slot-bucketed -- go to these lists, which the dense-slab kernels run (counters at
+  // kCntDense0 + class); everything else of the frame keeps reading its entries in place.
+  WorkItem* ditems[kClsSpecial];
+  uint32_t* fallback[kClsSpecial];  // entries form, direct kernels: per class, the batches they leave to the fallback
+                                    // launch (varblocks with more entries than a lane holds, raw_quant == 0)
   int* counts;  // kCountLines counters at kCountPitch ints, zeroed before k1_scan: the classes, then the large
                 // transforms' unit lists (k_vardct_large.hip: two-pass slab units, fused lists of 1 / 2 / 4 slabs)
 };

@@ -55,6 +55,8 @@ ABI_SYMBOLS = [
     "jxlh_comm_init_local", "jxlh_comm_destroy", "jxlh_comm_band", "jxlh_frame_run_sharded", "jxlh_frame_allgather",
     "jxlh_frames_run_sharded_local", "jxlh_frames_allgather_local", "jxlh_comm_allgather",
     "jxlh_frame_rerender_groups", "jxlh_comm_allgather_local", "jxlh_palette_strided", "jxlh_modular_frame_filters",
+    "jxlh_host_pack_slots", "jxlh_slot_writer_create", "jxlh_slot_writer_destroy", "jxlh_slot_writer_begin_group",
+    "jxlh_slot_writer_begin_varblock", "jxlh_slot_writer_add", "jxlh_slot_writer_add_many", "jxlh_slot_writer_end_group",
 ]
 # developer / bench instruments: include/jxl_hip_dev.h (same library, not part of the drop-in boundary)
 DEV_SYMBOLS = [
@@ -114,6 +116,16 @@ class JxlHipError(RuntimeError):
     def __init__(self, status, where, detail=""):
         self.status = status
         super().__init__(f"{where}: status {status} {detail}")
+
+
+_LOADED = None
+
+
+def _lib():
+    global _LOADED
+    if _LOADED is None:
+        _LOADED = load()
+    return _LOADED
 
 
 def load():
@@ -218,11 +230,98 @@ def load():
     L.jxlh_comm_allgather_local.argtypes = [C.POINTER(vp), i32, C.POINTER(vp), sz]
     L.jxlh_palette_strided.argtypes = [vp, vp, sz, vp, i32, sz, i32, i32, vp, sz]
     L.jxlh_modular_frame_filters.argtypes = [vp, C.POINTER(FrameParams), C.POINTER(vp), C.POINTER(vp), u32, u32, sz]
+    # host side of the slot-bucketed form (csrc/host_pack.hip): plain CPU code, no context
+    L.jxlh_host_pack_slots.argtypes = [vp, u32, u32, vp, sz, vp, vp, vp, u32, C.POINTER(u32)]
+    L.jxlh_slot_writer_create.argtypes = [C.POINTER(vp)]
+    L.jxlh_slot_writer_destroy.argtypes = [vp]
+    L.jxlh_slot_writer_destroy.restype = None
+    L.jxlh_slot_writer_begin_group.argtypes = [vp, u32, u32, vp, sz, vp, vp, u32]
+    L.jxlh_slot_writer_begin_varblock.argtypes = [vp, u32, u32]
+    L.jxlh_slot_writer_add.argtypes = [vp, u32, u32, i32]
+    L.jxlh_slot_writer_add_many.argtypes = [vp, u32, vp, vp, sz]
+    L.jxlh_slot_writer_end_group.argtypes = [vp, vp, C.POINTER(u32)]
     for name in ("jxlh_covered_blocks_x", "jxlh_covered_blocks_y", "jxlh_quant_table_for_type",
                  "jxlh_quant_table_size"):
         getattr(L, name).argtypes = [i32]
         getattr(L, name).restype = i32
     return L
+
+
+def host_pack_slots(group_coeffs, group_id=0, bits12=False, entries=None, slot_counts=None, wide_capacity=4096):
+    """jxlh_host_pack_slots: one group's dense slab (3 x 65536 i32) -> (entries, slot_counts [3, 1024] u8, n [3] u32,
+    wide [k, 2] u32) -- the arguments of Context.submit_groups_slots.  Values outside the entries' range are split into
+    repeated in-range entries (they add up on the device); `wide` only holds what no slot has room for.  entries /
+    slot_counts: optional preallocated outputs (numpy arrays, e.g. views of pinned memory)."""
+    L = _lib()
+    g = np.ascontiguousarray(group_coeffs, dtype=np.int32).reshape(-1)
+    assert g.size == 3 * 65536
+    cap = 3 * 65536 + 64 * 1024  # room for split values
+    if entries is None:
+        entries = np.empty(cap * 3 // 2 if bits12 else cap, np.uint8 if bits12 else np.uint16)
+    else:
+        cap = entries.size * 2 // 3 if bits12 else entries.size
+    if slot_counts is None:
+        slot_counts = np.empty((3, 1024), np.uint8)
+    n = np.zeros(3, np.uint32)
+    wide = np.zeros((max(wide_capacity, 1), 2), np.uint32)
+    nw = C.c_uint32(0)
+    st = L.jxlh_host_pack_slots(_addr(g), group_id, GROUP_ENTRIES12 if bits12 else 0, _addr(entries), cap, _addr(slot_counts),
+                                _addr(n), _addr(wide), wide_capacity, C.byref(nw))
+    if st != 0:
+        raise JxlHipError(st, "host_pack_slots")
+    total = int(n.sum())
+    return entries[: total * 3 // 2 if bits12 else total], slot_counts, n, wide[: nw.value]
+
+
+class SlotWriter:
+    """jxlh_slot_writer_*: the slot-bucketed form written the way the entropy loop produces coefficients
+    (frame/group.rs:557-575): varblock by varblock, `coeffs[c][offset + pos] += v` one update at a time."""
+
+    def __init__(self):
+        self.L = _lib()
+        p = C.c_void_p()
+        st = self.L.jxlh_slot_writer_create(C.byref(p))
+        if st != 0:
+            raise JxlHipError(st, "slot_writer_create")
+        self._w = p
+
+    def close(self):
+        if self._w:
+            self.L.jxlh_slot_writer_destroy(self._w)
+            self._w = None
+
+    __del__ = close
+
+    def _chk(self, st, where):
+        if st != 0:
+            raise JxlHipError(st, where)
+
+    def begin_group(self, group_id=0, bits12=False, capacity=3 * 65536 + 65536, wide_capacity=4096):
+        self._bits12 = bits12
+        self._entries = np.empty(capacity * 3 // 2 if bits12 else capacity, np.uint8 if bits12 else np.uint16)
+        self._counts = np.empty((3, 1024), np.uint8)
+        self._wide = np.zeros((max(wide_capacity, 1), 2), np.uint32)
+        self._chk(self.L.jxlh_slot_writer_begin_group(self._w, group_id, GROUP_ENTRIES12 if bits12 else 0, _addr(self._entries),
+                                                      capacity, _addr(self._counts), _addr(self._wide), wide_capacity),
+                  "slot_writer_begin_group")
+
+    def begin_varblock(self, first_slot, num_slots):
+        self._chk(self.L.jxlh_slot_writer_begin_varblock(self._w, first_slot, num_slots), "slot_writer_begin_varblock")
+
+    def add(self, channel, pos, value):
+        self._chk(self.L.jxlh_slot_writer_add(self._w, channel, pos, value), "slot_writer_add")
+
+    def add_many(self, channel, pos, value):
+        pos = np.ascontiguousarray(pos, dtype=np.uint32)
+        value = np.ascontiguousarray(value, dtype=np.int32)
+        self._chk(self.L.jxlh_slot_writer_add_many(self._w, channel, _addr(pos), _addr(value), len(pos)), "slot_writer_add_many")
+
+    def end_group(self):
+        n = np.zeros(3, np.uint32)
+        nw = C.c_uint32(0)
+        self._chk(self.L.jxlh_slot_writer_end_group(self._w, _addr(n), C.byref(nw)), "slot_writer_end_group")
+        total = int(n.sum())
+        return self._entries[: total * 3 // 2 if self._bits12 else total], self._counts, n, self._wide[: nw.value]
 
 
 def comm_unique_id():

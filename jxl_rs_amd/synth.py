@@ -545,17 +545,32 @@ def to_sparse4(group_coeffs):
     return (np.concatenate(ents), counts, np.concatenate(ps), np.concatenate(vs), np.asarray(n8, dtype=np.uint32), widea)
 
 
-def to_slots(group_coeffs, bits12=False):
+def to_slots(group_coeffs, bits12=False, split=False):
     """Slot-bucketed transport form (jxlh_submit_groups_slots): (entries uint16 -- (pos & 63) | (val & 1023) << 6, ordered by
     channel and 64-coefficient slot --, slot_counts uint8 [3, 1024], n uint32 [3], wide uint32 [k, 2] for values outside
     [-512, 511]).  bits12 (JXLH_GROUP_ENTRIES12): entries = uint8 bytes, 12-bit entries (value in [-32, 31]) packed two
-    per three bytes, every channel's run closed to an even count with a zero update in slot 1023."""
+    per three bytes, every channel's run closed to an even count with a zero update in slot 1023.
+    split: values outside the range become repeated in-range entries at their position (what jxlh_host_pack_slots does:
+    they add up on the device) instead of going to `wide`; the numpy reference of the C packer (same entry order)."""
     g = np.asarray(group_coeffs).reshape(3, -1)
     ents, counts, n, wide = [], np.zeros((3, 1024), np.uint8), [], []
     lo, hi, vmask = (-32, 31, 63) if bits12 else (-512, 511, 1023)
     for c in range(3):
         pos = np.flatnonzero(g[c])
         val = g[c][pos]
+        if split and len(val):
+            step = np.where(val < 0, -lo, hi).astype(np.int64)
+            k = np.maximum(1, (np.abs(val.astype(np.int64)) + step - 1) // step)
+            big = k > 96  # (the C packer's kMaxSplit: such a value goes to `wide` whole)
+            if big.any():
+                wide.append(np.stack([(c * 65536 + pos[big]).astype(np.uint32), val[big].astype(np.int32).view(np.uint32)], axis=1))
+                pos, val, step, k = pos[~big], val[~big], step[~big], k[~big]
+            pos = np.repeat(pos, k)
+            first = np.cumsum(k) - k
+            idx = np.arange(len(pos)) - np.repeat(first, k)  # 0 .. k-1 inside a value's pieces
+            vv, ss, kk = np.repeat(val.astype(np.int64), k), np.repeat(step, k), np.repeat(k, k)
+            full = np.sign(vv) * ss
+            val = np.where(idx < kk - 1, full, vv - full * (kk - 1)).astype(np.int32)
         fits = (val >= lo) & (val <= hi)
         p, v = pos[fits], val[fits]
         e = ((p & 63) | ((v & vmask) << 6)).astype(np.uint16)  # np.flatnonzero is sorted: slot order

@@ -1316,8 +1316,8 @@ def test_sparse4_submit_matches_dense_submit(ctx, oracle, mix, size, scale):
 def test_slot_bucketed_submit_matches_dense_submit(ctx, oracle, mix, size, scale, partial, bits12):
     """jxlh_submit_groups_slots (2 bytes per update, bucketed by 64-coefficient slot on the host: the frame is not sorted
     on the device) gives the frame the dense submission gives, bit for bit -- with a whole frame in this form (the
-    no-sort route), with values past 10 bits in the wide list (dense route), and with only SOME groups in this form
-    and the others as plain pairs (the sort runs after all)"""
+    no-sort route), with values past 10 bits in the wide list (those groups take the dense route), and with only SOME
+    groups in this form and the others as plain pairs (per-group routing, tests/test_gpu_routing.py)"""
     from jxl_rs_amd import synth
     w, h = size
     wl = synth.make_vardct(w, h, mix=getattr(synth, mix), seed=w + h, epf_iters=2, coeff_scale=scale)
@@ -1357,8 +1357,8 @@ def test_slot_bucketed_submit_matches_dense_submit(ctx, oracle, mix, size, scale
     ctx.kernel_timing(False)
     if not partial and wide is None:
         assert "k_sort_sparse" not in kt and "copy_bucketed_pairs" not in kt, sorted(kt)  # neither a sort nor a copy
-    if partial:
-        assert "k_sort_sparse" in kt, sorted(kt)
+    if partial:   # round 6: the plain-pairs groups are routed to their dense slabs, the others are still read in place
+        assert "k_sort_sparse" not in kt and "k_expand_sparse" in kt, sorted(kt)
     got = ctx.read_planes()
     for c in range(3):
         assert bit_equal(got[c], want[c]), f"plane {c}: {diff_report(got[c], want[c])}"
