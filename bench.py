@@ -254,6 +254,165 @@ def time_modular_config(jxl_rs_amd, np, device, size, steps, cores, cpu=True):
     return out
 
 
+def slot_content_sweep(jxl_rs_amd, synth, np, ectx, wl, size, steps, reps, cores, seed):
+    """The slot-bucketed form on content that is NOT the synthetic d1 frame: for each variant of
+    the frame's coefficients -- values far outside the entries' 10 bits (split into repeated in-range entries by the C
+    packer), the coefficient density x0.5 / x2 / x4, one group submitted as a dense slab -- the frame resident in the
+    slot-bucketed form (two contexts round robin like the headline, median of `reps` repetitions of `steps` frames),
+    K1's HIP-event time, the share of K1's batches that left the direct path for the dense dequantisation pass, and
+    the SAME coefficients resident as dense slabs beside it."""
+    from concurrent.futures import ThreadPoolExecutor
+    from jxl_rs_amd import lib as jl
+    ng = wl.coeffs.shape[0]
+    uniq = {}          # unique group contents (make_vardct(unique_groups=24) reuses them round robin)
+    which = []
+    for g in range(ng):
+        key = g % 24
+        if key not in uniq or not np.array_equal(wl.coeffs[g], wl.coeffs[uniq[key]]):
+            uniq[key] = g
+        which.append(uniq[key])
+    base = {g: wl.coeffs[g] for g in sorted(set(which))}
+    rng = np.random.default_rng(seed + 600)
+
+    def densify(c, factor):
+        c = c.copy()
+        nz = c != 0
+        if factor < 1:
+            c[nz & (rng.random(c.shape) >= factor)] = 0
+            return c
+        p_new = min(1.0, nz.mean() * (factor - 1) / max(1e-9, 1 - nz.mean()))
+        add = ~nz & (rng.random(c.shape) < p_new)
+        mag = 1 + rng.geometric(0.5, size=c.shape)
+        c[add] = (mag * rng.choice([-1, 1], size=c.shape))[add]
+        return c
+
+    def outliers(c):
+        c = c.copy()
+        nz = np.flatnonzero(c.reshape(-1))
+        k = max(1, int(round(len(nz) * 1e-5 * 24)))  # 1e-5 of the FRAME's entries: each unique group is used ng / 24 times
+        sel = rng.choice(nz, size=min(k, len(nz)), replace=False)
+        c.reshape(-1)[sel] = rng.integers(2000, 30001, size=len(sel)) * rng.choice([-1, 1], size=len(sel))
+        return c
+
+    variants = [("d1_clean", lambda c: c, None),
+                ("outliers_1e-5_of_entries_2000_to_30000", outliers, None),
+                ("density_x0.5", lambda c: densify(c, 0.5), None),
+                ("density_x2", lambda c: densify(c, 2.0), None),
+                ("density_x4", lambda c: densify(c, 4.0), None),
+                ("one_group_dense_slab", lambda c: c, 0)]
+    NE = len(ectx)
+
+    def begin(c):
+        c.frame_begin(synth.apply_opts(c.default_params(size, size), wl))
+        c.set_dequant_tables(wl.tables)
+        c.set_lf_quantized(*wl.lf_q)
+        c.set_hf_meta(wl.transform_map, wl.raw_quant, wl.epf_map, wl.ytox, wl.ytob)
+
+    def resident_ms():
+        for i in range(6):
+            ectx[i % NE].frame_run()
+        for c in ectx:
+            c.sync()
+        t_warm = time.perf_counter()
+        while time.perf_counter() - t_warm < 0.05:
+            for i in range(10):
+                ectx[i % NE].frame_run()
+            for c in ectx:
+                c.sync()
+        out = []
+        for _ in range(max(1, reps)):
+            t0 = time.perf_counter()
+            for i in range(steps):
+                ectx[i % NE].frame_run()
+            for c in ectx:
+                c.sync()
+            out.append((time.perf_counter() - t0) * 1e3 / steps)
+        return sorted(out)[(len(out) - 1) // 2]
+
+    def k1_ms(c0):
+        c0.kernel_timing_reset(); c0.kernel_timing(True)
+        for _ in range(10):
+            c0.frame_run()
+        c0.sync()
+        kt = c0.kernel_times(); c0.kernel_timing(False)
+        return {k: round(v[0] / 10, 4) for k, v in kt.items()}
+
+    res = {}
+    for name, fn, dense_group in variants:
+        var = {g: np.ascontiguousarray(fn(c), dtype=np.int32) for g, c in base.items()}
+        packed = {g: jl.host_pack_slots(c, group_id=0) for g, c in var.items()}
+        assert all(len(q[3]) == 0 for q in packed.values()), "the packer split every value: nothing in `wide`"
+        slotted = [g for g in range(ng) if g != dense_group]
+        ents = np.concatenate([packed[which[g]][0] for g in slotted])
+        cnts = np.concatenate([packed[which[g]][1].reshape(-1) for g in slotted])
+        ns = np.concatenate([packed[which[g]][2] for g in slotted])
+        ids = np.asarray(slotted, dtype=np.uint32)
+        for c in ectx:
+            begin(c)
+            c.submit_groups_slots(ids, ents, cnts, ns, None)
+            if dense_group is not None:
+                c.submit_group(dense_group, var[which[dense_group]])
+            c.slot_wait(0)
+            c.frame_run()
+        for c in ectx:
+            c.sync()
+        slots_ms = resident_ms()
+        kt = k1_ms(ectx[0])
+        cnt = ectx[0].k1_counters()
+        nb = sum(cnt["batches"].values())
+        fb = sum(cnt["fallback_batches"].values())
+        leg = {"slots_resident_ms_per_frame": round(slots_ms, 4), "k1_ms": kt.get("k1_vardct"),
+               "entries_per_frame": int(sum(int(packed[which[g]][2].sum()) for g in slotted)),
+               "nonzero_share_of_coefficients": round(float(np.mean([np.mean(var[g] != 0) for g in var])), 4),
+               "fallback_share_of_batches": round(fb / max(1, nb), 4),
+               "fallback_batches_by_class": {k: v for k, v in cnt["fallback_batches"].items() if v},
+               "dense_route_varblocks": int(sum(cnt["dense_route_varblocks"].values())),
+               "other_kernels_ms": {k: v for k, v in kt.items() if k.startswith("k_")} or None}
+        # the same coefficients resident as dense slabs
+        for c in ectx:
+            begin(c)
+            for g in range(ng):
+                c.submit_group(g, var[which[g]])
+            c.slot_wait(0)
+            c.frame_run()
+        for c in ectx:
+            c.sync()
+        leg["dense_resident_ms_per_frame"] = round(resident_ms(), 4)
+        leg["dense_k1_ms"] = k1_ms(ectx[0]).get("k1_vardct")
+        leg["slots_vs_dense"] = round(leg["slots_resident_ms_per_frame"] / leg["dense_resident_ms_per_frame"], 4)
+        res[name] = leg
+    clean = res["d1_clean"]["slots_resident_ms_per_frame"]
+    for name, leg in res.items():
+        leg["vs_clean_slots_frame"] = round(leg["slots_resident_ms_per_frame"] / clean, 4)
+    # ---- what producing the form costs on the host (VERDICT r05 item 2): jxlh_host_pack_slots on every group of the
+    # frame (dense i32 slab -> entries + slot counts), `cores` threads (ctypes releases the GIL), and on one thread
+    ents_buf = [np.empty(3 * 65536 + 65536, np.uint16) for _ in range(cores)]
+    cnt_buf = [np.empty((3, 1024), np.uint8) for _ in range(cores)]
+
+    def pack_range(t, g0, g1):
+        for g in range(g0, g1):
+            jl.host_pack_slots(wl.coeffs[g], group_id=g, entries=ents_buf[t], slot_counts=cnt_buf[t])
+
+    def pack_frame(nthreads):
+        per = -(-ng // nthreads)
+        t0 = time.perf_counter()
+        if nthreads == 1:
+            pack_range(0, 0, ng)
+        else:
+            with ThreadPoolExecutor(nthreads) as ex:
+                list(ex.map(lambda t: pack_range(t, t * per, min(ng, (t + 1) * per)), range(nthreads)))
+        return (time.perf_counter() - t0) * 1e3
+
+    pack_frame(cores)
+    allc = sorted(pack_frame(cores) for _ in range(3))[1]
+    one = pack_frame(1)
+    res["host_pack"] = {"host_pack_ms_per_frame": round(allc, 2), "cores": cores, "one_thread_ms_per_frame": round(one, 1),
+                        "what": "jxlh_host_pack_slots (C, SSE2) on the frame's %d dense i32 group slabs (805 MB read) -> u16 entries "
+                                "+ u8 slot counts; a decoder that appends from its entropy loop (jxlh_slot_writer_*) pays per "
+                                "coefficient instead of per slab byte" % ng}
+    return res
+
+
 def usable_cores():
     """Host cores this process may actually use: the affinity mask capped by the container's CPU quota
     (cgroup v2 cpu.max / v1 cfs quota).  os.cpu_count() reports the machine (256 on the GPU boxes) while the
@@ -290,7 +449,10 @@ def main():
                     help="skip the all-blocks-filtered EPF population (profiling runs: one population per kernel name)")
     ap.add_argument("--no-e2e", action="store_true",
                     help="skip the PCIe-inclusive legs (pinned host coefficients -> finished planes)")
-    ap.add_argument("--no-strip", action="store_true", help="skip the strip-kernel A/B block (roofline.strip_kernel)")
+    ap.add_argument("--strip", action="store_true",
+                    help="also run the strip-kernel A/B block (roofline.strip_kernel; opt-in since round 6: a closed negative result)")
+    ap.add_argument("--no-sweep", action="store_true",
+                    help="skip e2e_pcie_inclusive.slot_form_content_sweep (outliers / density / one dense group on the slot form)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the `secondary` block (BASELINE configs 2, 4 and 5, one frame in flight each)")
     ap.add_argument("--reps", type=int, default=5,
@@ -455,9 +617,17 @@ def main():
             # frame-sized), the bytes the chain moved by counters (committed profile of this command), and the rate
             # the pipelined step moved them at as a fraction of that copy rate
             "copy_ceiling_GBs": (roofline or {}).get("copy_ceiling_GBs"),
+            # the bytes the chain moved by counters (the newest committed PMC profile of this command: counters need
+            # their own profiler run) over the pipelined step time, against the 8 TB/s peak and against the 6.3 TB/s the
+            # guide gives as achievable (MI355X_MICROARCH.md); round 5's "fraction of the copy ceiling" read 1.02 and is gone
             "chain_counter_traffic_bytes": chain_bytes, "chain_counter_traffic_source": chain_file,
-            "chain_frac_of_copy_ceiling": (round(chain_bytes / (ms_per_step * 1e-3) / 1e9 / roofline["copy_ceiling_GBs"], 4)
-                                           if chain_bytes and roofline and roofline.get("copy_ceiling_GBs") else None),
+            "chain_counter_frac_of_8TBs": (round(chain_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if chain_bytes else None),
+            "chain_counter_frac_of_6p3TBs": (round(chain_bytes / (ms_per_step * 1e-3) / 1e9 / 6300.0, 4) if chain_bytes else None),
+            # the two kernels of the chain side by side (HIP events, one frame in flight), and the filters on the
+            # population where every block is filtered
+            "k1": (roofline or {}).get("k1_summary"), "filters": (roofline or {}).get("filters_summary"),
+            "filters_all_blocks_filtered": (roofline or {}).get("filters_all_active_summary"),
+            "one_frame_in_flight": (roofline or {}).get("one_frame_in_flight"),
         }
 
     # The sharded (strong) legs below are the only part of an N > 1 run in which ranks wait for each other inside
@@ -695,7 +865,7 @@ def main():
         # emits: every tile is the strip kernel's).  Opt-in, bit-identical, and SLOWER than the two-kernel path on MI355X
         # today (both forms are bound by instruction issue): reported, never `value`.
         strip = None
-        if not args.no_strip and args.epf_iters <= 2:
+        if args.strip and args.epf_iters <= 2:
             from jxl_rs_amd import lib as jl
             strip = {}
             for tag, swl in (("this_frame", wl), ("aligned_tilings", None)):
@@ -770,7 +940,27 @@ def main():
             roofline["copy_ceiling"] = {"frame_sized": {"bytes_each_way": 3 * npx * 4, "GBs": round(big, 1)},
                                         "infinity_cache_resident": {"bytes_each_way": 64 << 20, "GBs": round(small, 1)},
                                         "kernel": "float4 grid-stride copy, the better of plain and nt accesses (jxlh_probe_copy_bandwidth)"}
-            roofline["frac_of_copy_ceiling"] = round(roofline["achieved"] / big, 4)
+            def summary(tab, name):
+                k = (tab or {}).get(name)
+                return None if not k else {"ms": k["ms_per_step"], "frac": k.get("frac"), "achieved_GBs": k.get("achieved_GBs"),
+                                           "algorithmic_bytes": k.get("algorithmic_bytes")}
+            roofline["k1_summary"] = summary(kernels, "k1_vardct")
+            roofline["filters_summary"] = summary(kernels, "k23_fused_filters")
+            roofline["filters_all_active_summary"] = summary(active, "k23_fused_filters")
+            # ONE frame in flight: wall clock per frame (sync on both sides of K frames on one context) against the
+            # sum of its kernels' HIP-event times -- the difference is what the second context of the headline hides
+            for _ in range(5):
+                ctx.frame_run(0, ygroups)
+            ctx.sync()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                ctx.frame_run(0, ygroups)
+            ctx.sync()
+            one_ms = (time.perf_counter() - t0) * 1e3 / args.steps
+            chain_ms_ = sum(v["ms_per_step"] for v in kernels.values())
+            roofline["one_frame_in_flight"] = {"wall_ms_per_frame": round(one_ms, 4), "sum_of_kernels_ms": round(chain_ms_, 4),
+                                               "launches_per_frame": int(sum(v["launches_per_step"] for v in kernels.values())),
+                                               "gap_ms": round(one_ms - chain_ms_, 4)}
 
     # ---- CPU baseline: the oracle (C port of the reference path) on the same frame size
     cpu = None
@@ -1046,6 +1236,12 @@ def main():
         # slot-bucketed form read in place (same key as before, so rounds compare; the pair form keeps its own line above)
         e2e["sparse_resident_no_pcie"] = leg
         e2e["slots_resident_no_pcie"] = leg
+        if not args.no_sweep:
+            try:
+                e2e["slot_form_content_sweep"] = slot_content_sweep(jxl_rs_amd, synth, np, ectx, wl, size, args.steps,
+                                                                    min(3, args.reps), usable_cores(), args.seed)
+            except Exception as e:  # the headline line must survive a failing leg
+                e2e["slot_form_content_sweep"] = {"error": f"{type(e).__name__}: {e}"}
         for c in ectx:   # new epoch for the PCIe legs
             c.frame_begin(synth.apply_opts(c.default_params(size, size), wl))
             c.set_dequant_tables(wl.tables)
@@ -1165,7 +1361,7 @@ def main():
             ms = sorted(reps)[(len(reps) - 1) // 2]
             loop, alt = f"marks + jxlh_slot_wait (host-ordered uploads), {nslots} slot streams per context", None
             if name.startswith("slots_"):
-                # The host loops a caller can choose from, all measured, the leg reports the best median and prints all:
+                # The host loops a caller can choose from, all measured; the leg reports the first (fixed) one and prints all:
                 # the contexts' uploads ordered by the host (jxlh_slot_wait) or on the device (jxlh_slot_after), a frame's
                 # groups spread over the context's slot streams or all on one.  (One stream + device order is the best
                 # where the leg is upload-bound: the copies of the two contexts then follow each other on the bus without
@@ -1178,10 +1374,8 @@ def main():
                     run_leg(submit, 12, pat, streams=st)
                     r_ = [run_leg(submit, frames, pat, streams=st) for _ in range(3)]
                     alt[f"{tag}_{st or nslots}_streams_ms"] = [round(v, 3) for v in r_]
-                    if sorted(r_)[1] < ms:
-                        ms, reps = sorted(r_)[1], r_
-                        loop = (f"marks + {'jxlh_slot_after (device-ordered' if pat == 'marks_after' else 'jxlh_slot_wait (host-ordered'}"
-                                f" uploads), {st or nslots} slot stream{'s' if (st or nslots) > 1 else ''} per context")
+                # (the leg's value is the ONE documented loop above, like every other transport's; the
+                # alternatives are side fields, never selected)
             nbytes = {"sparse_pairs": total * 4, "sparse_pos16_val8": total * 3, "sparse_seg12_val4": bytes4,
                       "slots_pos6_val10_no_sort": bytes_slots,
                       "slots_packed12_no_sort": bytes_12}.get(name, wl.coeffs.nbytes)
@@ -1194,6 +1388,12 @@ def main():
             if name.startswith("slots_"):  # round 4's host loop on the same library, for comparison
                 run_leg(submit, 12, "sync", streams=nslots)
                 e2e[name]["ms_per_frame_sync_loop"] = round(run_leg(submit, 24, "sync", streams=nslots), 3)
+        hp = (e2e.get("slot_form_content_sweep") or {}).get("host_pack")
+        if hp:  # what the producer of the slot form costs per frame on this box's host, beside every leg that streams it
+            for name in list(e2e):
+                if name.startswith("slots_") and isinstance(e2e[name], dict) and "h2d_MB_per_frame" in e2e[name]:
+                    e2e[name]["host_pack_ms_per_frame"] = hp["host_pack_ms_per_frame"]
+                    e2e[name]["host_pack_cores"] = hp["cores"]
         e2e["note"] = ("pinned host coefficients -> H2D on the context's slot streams (ONE per context in the slots_* legs, two in the older transports' legs: see host_loop) -> (pair forms: device unpack / sort; slot-bucketed "
                        "forms: nothing, the transforms read the upload in place) -> K0b/K3/K1/filters; two contexts, each "
                        "streaming its frames behind jxlh_ctx_mark / jxlh_ctx_wait_mark (the host waits for a context's "

@@ -38,6 +38,15 @@ jxlh_status jxlh_probe_copy_bandwidth(jxlh_ctx* ctx, size_t bytes, int32_t reps,
  * kernel.  All 0 for the two-kernel path.  Synchronises the context's stream. */
 jxlh_status jxlh_frame_path(jxlh_ctx* ctx, int32_t* strip, int32_t* tiles, int32_t* tiles_by_class_kernels);
 
+/* Work-list counters of the last transform launch (k1_scan's class lists), for the bench legs that sweep the content
+ * of the slot-bucketed form: out[0..10] = varblocks per transform class (DCT8, 16x8, 8x16, 16x16, 32x8, 8x32, 32x16,
+ * 16x32, 32x32, special, large -- of the groups read in place, or of all groups for a frame of dense slabs),
+ * out[11..19] = batches of the classes DCT8 .. 32x32 that left the direct path of the entries form for the dense
+ * dequantisation pass (more entries than their lanes hold, raw_quant == 0: inline for DCT8, the fallback launch for the
+ * others), out[20..28] = varblocks of those classes in the groups routed to their dense slabs.  n = ints `out` holds
+ * (29 for everything).  Synchronises the context's stream. */
+jxlh_status jxlh_frame_k1_counters(jxlh_ctx* ctx, int32_t* out, int32_t n);
+
 /* Device self-test of the EPF weight normalisation: the filters compute 1/(1 + sum of weights)
  * (epf0.rs:208, epf1.rs:140, epf2.rs:130 divide) with rcp + two FMA refinement steps.  Counts the
  * floats whose bit pattern lies in [lo_bits, hi_bits) for which that differs from the IEEE

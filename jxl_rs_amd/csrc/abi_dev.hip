@@ -69,6 +69,32 @@ jxlh_status jxlh_frame_path(jxlh_ctx* ctx, int32_t* strip, int32_t* tiles, int32
   return JXLH_OK;
 }
 
+jxlh_status jxlh_frame_k1_counters(jxlh_ctx* ctx, int32_t* out, int32_t n) {
+  JXLH_ON_DEVICE(ctx);
+  if (!ctx || !out || n < 0) return JXLH_ERR_INVALID_ARGUMENT;
+  if (!ctx->in_frame || !ctx->worklist.p || ctx->k1_launches == 0) return JXLH_ERR_BAD_STATE;
+  int lines = 0;
+  const int* h = nullptr;
+  std::vector<int> host;
+  {
+    // the counter set of the last launch (launch n counts in set n & 1; the NEXT launch's scan clears the other one)
+    size_t bytes = 0;
+    const void* src = vardct_worklist_counters(ctx->worklist.p, ctx->k1_launches - 1, &bytes, &lines);
+    host.resize(bytes / sizeof(int));
+    HIPCHK(ctx, hipMemcpyAsync(host.data(), src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    JXLH_SYNC(ctx);
+    h = host.data();
+  }
+  const int pitch = (int)(host.size() / (size_t)lines);
+  // layout of the lines: classes, large-transform unit lists (4), fallback batches per class (9), dense-route lists (9)
+  const int map_n = 29;
+  for (int i = 0; i < n && i < map_n; i++) {
+    const int line = i < 11 ? i : i < 20 ? 11 + 4 + (i - 11) : 11 + 4 + 9 + (i - 20);
+    out[i] = h[(size_t)line * pitch];
+  }
+  return JXLH_OK;
+}
+
 jxlh_status jxlh_flow_profile(jxlh_ctx* ctx, int32_t enable, int32_t* n_levels, uint64_t* rows, int32_t max_levels) {
   JXLH_ON_DEVICE(ctx);
   if (!ctx) return JXLH_ERR_INVALID_ARGUMENT;

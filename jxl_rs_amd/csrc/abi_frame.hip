@@ -729,6 +729,18 @@ jxlh_status run_prologue(jxlh_ctx* ctx, RunPlan* plan) {
         launch_entries_to_pairs(ctx->stream, ctx->se_entries[pend].p, ctx->se_counts[pend].p, ctx->se_runs[pend].p,
                                 ctx->bucketed_dev.p, (int)ctx->ngroups, ctx->sp_pairs.p);
       }
+      if (all_bucketed || mixed) {
+        // entries per coefficient of the groups that are read in place: from about three times d1's share (0.086 on the
+        // synthetic frame) the 8x8 class is better off running its over-depth batches inline (FrameDev::se_dense_hint;
+        // K1 at x1 / x2 / x4 density: 0.301 / 0.412 / 0.582 ms without, 0.320 / 0.424 / 0.557 with: profiles/r06_c_density.txt)
+        uint64_t entries = 0, groups = 0;
+        for (const SparseGroup& sg : ctx->sp_upload) {
+          if (mixed && route[sg.group]) continue;
+          entries += (uint64_t)sg.n[0] + sg.n[1] + sg.n[2];
+          groups++;
+        }
+        ctx->se_dense_hint = groups && (double)entries > 0.25 * (double)(groups * 3 * (uint64_t)kGroupArea);
+      }
       if (all_bucketed) {
         ctx->se_live = pend;  // the sets trade places: the next epoch's uploads go to the set read two frames ago
         ctx->se_valid = true;
@@ -833,6 +845,8 @@ static void set_sparse_view(jxlh_ctx* ctx, FrameDev& f, bool sparse_k1) {
   f.se_runs = ent ? ctx->se_runs[ctx->se_live].p : nullptr;
   f.group_dense = sparse_k1 ? ctx->group_dense.p : nullptr;
   f.group_route = ent && ctx->n_route > 0 ? ctx->route_dev.p : nullptr;
+  f.se_dense_hint = ent && ctx->se_dense_hint ? 1 : 0;
+  f.k1_stats = ctx->timing ? 1 : 0;
 }
 static int dense_route_groups(const jxlh_ctx* ctx, bool sparse_k1) { return sparse_k1 && ctx->se_valid ? ctx->n_route : 0; }
 // behind the transforms: the coefficient slabs are free again (dense resubmissions of the next frame wait for this,

@@ -147,6 +147,11 @@ struct FrameDev {
   // earlier content) while the rest of the frame is read in place.  k1_scan sends such a group's DCT-class varblocks to
   // WorkLists::ditems.
   const uint8_t* group_route;
+  // host hint: the frame's in-place groups hold about three times the entries per coefficient d1 content does (> 0.25):
+  // the 8x8 class then runs its over-depth batches inline instead of leaving them to the fallback launch
+  int se_dense_hint;
+  int fb_epoch;   // launch number + 1 (set by launch_vardct_groups): the value that flags a batch for the fallback launch
+  int k1_stats;   // the transforms count their dense-pass batches (jxlh_frame_k1_counters): on with kernel timing
   // The entries form may dequantise ONLY the coefficients that have an entry (everything else is +0.0f) when a zero
   // coefficient provably reconstructs to +0.0f and a non-zero one never to a zero: quant biases 0..2 in [1e-6, 1e6],
   // finite chroma-from-luma bases (host: se_direct_ok), every dequant weight in [1e-20, 1e20] (device: *tables_ok,
@@ -229,6 +234,8 @@ void launch_check_tables(hipStream_t s, const float* tables, size_t n, int* ok);
 // memset launch inside K1's serial sequence.  *launch_parity is the caller's per-context launch counter.
 size_t vardct_worklist_bytes(const FrameDev& f);
 void vardct_worklist_reset(hipStream_t s, void* worklist_mem, uint32_t* launch_parity);
+// the counter set launch number `launch` counted in: *bytes = its size, *lines = counters in it (one per `*bytes / *lines`)
+const void* vardct_worklist_counters(const void* worklist_mem, uint32_t launch, size_t* bytes, int* lines);
 // dense_coeffs: writable alias of f.coeffs, used in sparse mode to expand the groups k1_scan flags
 // group_list (device, n_list entries) replaces the row range by an explicit list of group ids when non-null
 void launch_vardct_groups(hipStream_t s, const FrameDev& f, int group_row0, int group_row1,

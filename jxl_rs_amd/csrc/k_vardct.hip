@@ -26,6 +26,7 @@
 // build of the oracle).  Output is independent of the order in which work items land in
 // the lists (each varblock is independent).
 #include <algorithm>
+#include <atomic>
 
 #include "k_vardct_common.h"
 
@@ -61,7 +62,9 @@ constexpr int kScanThreads = kScanGroups * kThreads;
 // at the varblock's first slot -- and writes it beside the work item: the class kernels then go from the item straight
 // to the entries.  This replaces the unpack pass of round 4 (pair words + 4-byte slot tables: 69 + 12.6 MB written and
 // read again per 8K frame).
-template <bool STRIP, bool ENT = false>
+// ROUTE (ENT only): some groups of the frame are read from their dense slabs (FrameDev::group_route): their DCT-class
+// varblocks go to WorkLists::ditems.  A frame without routed groups runs the instantiation without any of it.
+template <bool STRIP, bool ENT = false, bool ROUTE = false>
 __global__ __launch_bounds__(kScanThreads) void k1_scan(const FrameDev f, const WorkLists wl, const int group_row0,
                                                          int* __restrict__ error_flag,
                                                          const int* __restrict__ group_list, const int ngroups,
@@ -70,7 +73,7 @@ __global__ __launch_bounds__(kScanThreads) void k1_scan(const FrameDev f, const 
   __shared__ int s_wave_sum[kScanGroups][kWaves];
   __shared__ uint32_t s_wcls[kScanGroups][kWaves][kPairs];
   __shared__ int s_count[kScanGroups][kNumClasses], s_base[kScanGroups][kNumClasses];
-  __shared__ int s_route[kScanGroups];  // ENT: != 0 = the quarter's group is read from its dense slab (FrameDev::group_route)
+  __shared__ int s_route[ROUTE ? kScanGroups : 1];  // != 0 = the quarter's group is read from its dense slab (FrameDev::group_route)
   __shared__ int s_tmode[kScanGroups][16];  // STRIP: != 0 = a tile of the group (4 x 4 of them) the class kernels keep
   // ENT: exclusive prefix of the slot counts, three channels packed (17 bits each; a run holds at most 65536 entries)
   __shared__ uint64_t s_pref[ENT ? kScanGroups : 1][ENT ? kSlotsPerRun + 1 : 1];
@@ -109,8 +112,10 @@ __global__ __launch_bounds__(kScanThreads) void k1_scan(const FrameDev f, const 
   uint2 run[3] = {make_uint2(0u, 0u), make_uint2(0u, 0u), make_uint2(0u, 0u)};
   bool dense_route = false;
   if constexpr (ENT) {
-    dense_route = live && f.group_route && f.group_route[group] != 0;
-    if (tid == 0) s_route[sub] = dense_route ? 1 : 0;  // (published by the barriers below)
+    if constexpr (ROUTE) {
+      dense_route = live && f.group_route[group] != 0;
+      if (tid == 0) s_route[sub] = dense_route ? 1 : 0;  // (published by the barriers below)
+    }
     if (live && !dense_route) {
 #pragma unroll
       for (int c = 0; c < 3; c++) {
@@ -258,10 +263,13 @@ __global__ __launch_bounds__(kScanThreads) void k1_scan(const FrameDev f, const 
   __syncthreads();
   // one atomic per class for the whole workgroup; the quarters take consecutive ranges in group order.  ENT: the DCT
   // classes of a dense-route quarter count into the dense lists (threads 32 .. 32 + kClsSpecial) instead
-  if (threadIdx.x < kNumClasses || (ENT && threadIdx.x >= 32 && threadIdx.x < 32 + kClsSpecial)) {
-    const bool dlist = threadIdx.x >= 32;
+  if (threadIdx.x < kNumClasses || (ROUTE && threadIdx.x >= 32 && threadIdx.x < 32 + kClsSpecial)) {
+    const bool dlist = ROUTE && threadIdx.x >= 32;
     const int c = dlist ? threadIdx.x - 32 : threadIdx.x;
-    auto mine_q = [&](int q) { return !ENT || c >= kClsSpecial || (s_route[q] != 0) == dlist; };
+    auto mine_q = [&](int q) {
+      if constexpr (ROUTE) return c >= kClsSpecial || (s_route[q] != 0) == dlist;
+      else return true;
+    };
     int total = 0;
 #pragma unroll
     for (int q = 0; q < kScanGroups; q++) total += mine_q(q) ? s_count[q][c] : 0;
@@ -518,9 +526,13 @@ __device__ __forceinline__ void zero_tile(int* __restrict__ ibuf, int lane) {
   }
 }
 
-template <class S, int D, class EX>
+// HELD = false (the inline fallback of the direct 8x8 kernel): the lane's first D entries are NOT taken from sl -- every
+// entry is requested again (L2 hits), the range comes from the batch's BlockInfo -- so that nothing of sl stays alive
+// through the transforms: with it the inline body raised the direct kernel from 76 to 98 VGPRs (6 -> 4 waves per SIMD).
+template <class S, int D, class EX, bool HELD = true>
 __device__ __forceinline__ void entries_stage_channel(const FrameDev& f, int ch, float* __restrict__ buf,
-                                                      const EX* __restrict__ s_excl, int lane, const EntLane<D>& sl) {
+                                                      const EX* __restrict__ s_excl, int lane, const EntLane<D>& sl,
+                                                      const BlockInfo* __restrict__ binfo = nullptr, int nb = 0) {
   int* ibuf = reinterpret_cast<int*>(buf);
   zero_tile<S>(ibuf, lane);
   wave_sync();
@@ -529,11 +541,33 @@ __device__ __forceinline__ void entries_stage_channel(const FrameDev& f, int ch,
   auto add = [&](uint32_t e, uint32_t r) {  // r: index of the entry inside the varblock's range
     atomicAdd(&ibuf[m_addr<S>(b, entry_pos<S, EX>(s_excl, b, ch, e, r))], (int)(e << 16) >> 22);
   };
+  constexpr int DH = HELD ? D : 0;
+  uint32_t i0 = 0, i1 = 0;
+  if constexpr (HELD) {
+    i0 = sl.i0[ch];
+    i1 = sl.i1[ch];
+  } else if (b < nb) {
+    i0 = binfo[b].e0[ch] + j;
+    i1 = binfo[b].e0[ch] + binfo[b].en[ch];
+  }
 #pragma unroll
-  for (int k = 0; k < D; k++)
-    if (sl.i0[ch] + k * LPB < sl.i1[ch]) add(sl.e[ch][k], (uint32_t)(j + k * LPB));
-  uint32_t r = (uint32_t)(j + D * LPB);
-  for (uint32_t i = sl.i0[ch] + D * LPB; i < sl.i1[ch]; i += LPB, r += LPB) add((uint32_t)f.se_entries[i], r);
+  for (int k = 0; k < DH; k++)
+    if (i0 + k * LPB < i1) add(sl.e[ch][k], (uint32_t)(j + k * LPB));
+  // what lies beyond the D entries a lane holds (content denser than d1, split wide values): four requests in flight per
+  // lane and round -- one dependent load per entry made the dense pass 3x the time of the dense-slab kernels at four
+  // times d1's density (round 6, profiles/r06_c_density.txt)
+  constexpr int U = 4;
+  uint32_t r = (uint32_t)(j + DH * LPB), i = i0 + DH * LPB;
+  while (__any(i < i1)) {
+    uint32_t ev[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) ev[u] = i + u * LPB < i1 ? (uint32_t)f.se_entries[i + u * LPB] : 0u;
+#pragma unroll
+    for (int u = 0; u < U; u++)
+      if (i + u * LPB < i1) add(ev[u], r + u * LPB);
+    i += U * LPB;
+    r += U * LPB;
+  }
   wave_sync();
 }
 
@@ -638,30 +672,65 @@ __device__ __forceinline__ int4 tile_q4(const float* __restrict__ buf, int b, in
 // sampling (decode_item marks the others with px_off == scrap_off); their coefficients are never decoded (zeros
 // in the reference's slab, frame/group.rs:521-524), so the loads are skipped and read as zero, and nothing is stored.
 // SPARSE: 0 = dense slabs, 1 = bucketed pair words + slot tables (sp_sorted), 2 = slot-bucketed entries in place (se_*)
-// with the dense dequantisation pass, 3 = the same input, direct path only: batches it cannot take go to the fallback
-// list (WorkLists::fallback), which k1_entries_fallback runs through mode 2.  cls: the class id (mode 3's list entries).
+// with the dense dequantisation pass, 3 = the same input, direct path only: batches it cannot take are flagged in
+// WorkLists::fallback[class] (one word per batch, written with the launch's epoch: no atomics, nothing to clear) and the
+// fallback launch (LISTED) runs the flagged ones through mode 2.  CLS: the class id.
 // INLINE_FB (mode 3): a batch the direct path cannot take runs through the dense dequantisation pass right here instead
 // of going to the fallback list -- for the 8x8 class, whose generic body costs a handful of registers: a frame denser
 // than d1 content then degrades batch by batch inside one launch (round 6).
 // s_dy (mode 2, shapes with 32 coefficients per lane; nullable): the dequantised Y of the batch waits in LDS for the X / B
 // channels' chroma-from-luma instead of in 32 registers through two 32-point IDCTs -- the kernels that take it run two
 // workgroups per CU and have the room (S::E * 64 floats per wavefront).
-template <class S, bool PREFETCH, int SPARSE, bool SUB = false, int CLS = 0, bool INLINE_FB = false, class EX = uint32_t>
+template <class S, bool PREFETCH, int SPARSE, bool SUB = false, int CLS = 0, bool INLINE_FB = false, bool LISTED = false,
+          class EX = uint32_t>
 __device__ __forceinline__ int run_dct_class(const FrameDev& f, const WorkItem* __restrict__ items,
                                              const EntryItem* __restrict__ eitems, int count, int type,
                                              float* __restrict__ buf, BlockInfo* __restrict__ binfo_base,
                                              EX* __restrict__ s_excl, float* __restrict__ s_lf, int gwave,
                                              int nwaves, int lane, const AdjTable* __restrict__ adj,
                                              uint32_t* __restrict__ wl_fallback = nullptr,
-                                             int* __restrict__ fallback_count = nullptr, float* __restrict__ s_dy = nullptr,
-                                             const uint32_t* __restrict__ batch_list = nullptr, int n_listed = 0) {
+                                             int* __restrict__ fallback_count = nullptr, float* __restrict__ s_dy = nullptr) {
   constexpr int NCH = S::E / 4;  // 16-byte chunks per lane per channel
   const int q = quant_table_for_type(type);
   const float* __restrict__ table = f.tables + f.table_offset[q];
   const int tsize = quant_table_size(q);
-  // batch_list (the fallback launch): the batches to run are the n_listed entries of the list instead of all of the class
-  const int nbatches = batch_list ? n_listed : (count + S::NB - 1) / S::NB;
-  auto batch_of = [&](int bi) { return batch_list ? (int)batch_list[bi] : bi; };
+  const int nbatches = (count + S::NB - 1) / S::NB;
+  // The batches this wave runs.  Plain: gwave, gwave + nwaves, ...  LISTED (the fallback launch): the batches whose word
+  // in wl_fallback holds this launch's epoch -- a workgroup takes chunks of kFbChunk consecutive batches (one flag per
+  // lane, a ballot), its kWaves waves share a chunk's flagged batches round robin; the caller rotates the chunk -> workgroup
+  // map from class to class (gwave), so the classes' chunks spread over the whole grid.  (Round 6's first form appended batch ids to
+  // a list: one returning atomic per wave and class on one counter, 131 000 of them on a frame that leaves every batch --
+  // 0.27 ms for a launch with nothing else to do.)
+  constexpr int kFbChunk = 16;  // (64-batch chunks left most of the grid idle: 1.5 ms for 17 000 batches)
+  constexpr int kFbAny = 32, kFbAnyPitch = 32;  // summary words per class, each on its own 128-byte line
+  struct BatchIter {
+    int bi;                    // plain: the batch; listed: the chunk
+    unsigned long long mask;   // listed: flagged batches of the chunk not yet handed out
+    int rank;                  // listed: flagged batches of the chunk handed out so far (all waves count alike)
+  };
+  const int it_wave = gwave % kWaves, it_wg = gwave / kWaves, it_nwg = nwaves / kWaves;  // (LISTED: gwave is not rotated)
+  auto iter_next = [&](BatchIter& st) -> int {  // the next batch of this wave, -1 when done
+    if constexpr (!LISTED) {
+      const int b = st.bi;
+      st.bi += nwaves;
+      return b < nbatches ? b : -1;
+    } else {
+      for (;;) {
+        while (st.mask) {
+          const int bit = __builtin_ctzll(st.mask);
+          st.mask &= st.mask - 1;
+          // (+ the chunk: a chunk with ONE flagged batch -- the usual case on d1 content -- must not always be wave 0's)
+          if ((st.rank++ + st.bi) % kWaves == it_wave) return st.bi * kFbChunk + bit;
+        }
+        st.bi = st.bi < 0 ? it_wg : st.bi + it_nwg;
+        if (st.bi * kFbChunk >= nbatches) return -1;
+        const int idx = st.bi * kFbChunk + lane;
+        st.mask = __ballot(lane < kFbChunk && idx < nbatches && wl_fallback[idx] == (uint32_t)f.fb_epoch);
+        st.rank = 0;
+      }
+    }
+  };
+  BatchIter iter = {LISTED ? -1 : gwave, 0ull, 0};
   // the weights a lane needs do not depend on the batch
   constexpr bool kPF = PREFETCH && SPARSE != 3;  // (the inline fallback of mode 3 reads its weights per batch)
   float4 tw[kPF ? 3 : 1][NCH];
@@ -681,38 +750,42 @@ __device__ __forceinline__ int run_dct_class(const FrameDev& f, const WorkItem* 
 #ifndef JXLH_ITEM_PREFETCH
 #define JXLH_ITEM_PREFETCH 1  // 0 none, 1 the 8..16-point classes (register-light bodies), 2 every class
 #endif
-  constexpr bool kNextItem = kChain && (JXLH_ITEM_PREFETCH == 2 || (JXLH_ITEM_PREFETCH == 1 && PREFETCH));
+  constexpr bool kNextItem = kChain && !LISTED && (JXLH_ITEM_PREFETCH == 2 || (JXLH_ITEM_PREFETCH == 1 && PREFETCH));
   constexpr int kLfPerBlock = 3 * (S::R / 8) * (S::C / 8), kLfIters = (S::NB * kLfPerBlock + 63) / 64;
   WorkItem it_next = {};
   EntryItem ei_next = {};
   if constexpr (kNextItem) {
-    if (gwave < nbatches) {
-      const int b0 = batch_of(gwave);
-      if (lane < min(S::NB, count - b0 * S::NB)) {
-        it_next = items[b0 * S::NB + lane];
-        ei_next = eitems[b0 * S::NB + lane];
-      }
+    if (gwave < nbatches && lane < min(S::NB, count - gwave * S::NB)) {
+      it_next = items[gwave * S::NB + lane];
+      ei_next = eitems[gwave * S::NB + lane];
     }
   }
-  for (int bi = gwave; bi < nbatches; bi += nwaves) {
-    const int batch = batch_of(bi);
+  int n_dense_pass = 0;  // (wave-uniform) batches this wave ran through the dense pass: inline (mode 3) or listed
+  bool flagged_any = false;
+  uint32_t* __restrict__ fb_any = wl_fallback ? wl_fallback - kFbAny * kFbAnyPitch : nullptr;  // (in front of the flags)
+  if constexpr (LISTED) {
+    // nothing of this class was left by the direct kernels (the usual case): one load per wave says so
+    if (!__any(fb_any[(lane % kFbAny) * kFbAnyPitch] == (uint32_t)f.fb_epoch)) return nbatches;
+  }
+  for (int batch = iter_next(iter); batch >= 0; batch = iter_next(iter)) {
     const int nb = min(S::NB, count - batch * S::NB);
+    if constexpr (LISTED) n_dense_pass++;
     BlockInfo* __restrict__ binfo = binfo_base;
+    bool direct_ok = true;  // (wave-uniform)
     if constexpr (kChain) {
       WorkItem it = it_next;
       EntryItem ei = ei_next;
       if constexpr (kNextItem) {
-        if (bi + nwaves < nbatches) {
-          const int nxt = batch_of(bi + nwaves);
-          if (lane < min(S::NB, count - nxt * S::NB)) {
-            it_next = items[nxt * S::NB + lane];
-            ei_next = eitems[nxt * S::NB + lane];
-          }
+        const int nxt = batch + nwaves;
+        if (nxt < nbatches && lane < min(S::NB, count - nxt * S::NB)) {
+          it_next = items[nxt * S::NB + lane];
+          ei_next = eitems[nxt * S::NB + lane];
         }
       } else if (lane < nb) {
         it = items[batch * S::NB + lane];
         ei = eitems[batch * S::NB + lane];
       }
+      bool item_ok = true;
       if (lane < nb) {
         decode_item(f, it, &binfo[lane]);
 #pragma unroll
@@ -720,6 +793,28 @@ __device__ __forceinline__ int run_dct_class(const FrameDev& f, const WorkItem* 
         binfo[lane].en[0] = ei.nxy & 0xffffu;
         binfo[lane].en[1] = ei.nxy >> 16;
         binfo[lane].en[2] = it.group >> 16;
+        if constexpr (SPARSE == 3) {
+          // the direct path takes a varblock whose raw_quant the division survives and that has no more entries per
+          // channel than its lanes hold
+          const float sdy = binfo[lane].sdy;
+          item_ok = sdy > 0.0f && sdy < __builtin_inff() &&
+                    max(max(ei.nxy & 0xffffu, ei.nxy >> 16), it.group >> 16) <= (uint32_t)(ent_depth<S>() * (64 / S::NB));
+        }
+      }
+      if constexpr (SPARSE == 3 && !INLINE_FB) {
+        // left to the fallback launch BEFORE anything of the batch is requested: its word gets the launch's epoch
+        if (!__all(item_ok)) {
+          if (lane == 0) {
+            wl_fallback[batch] = (uint32_t)f.fb_epoch;
+            // ... and the class's summary (kFbAny words on their own cache lines, picked by the wave): plain stores of
+            // the same value, the first reject of a wave only
+            if (!flagged_any) fb_any[(gwave % kFbAny) * kFbAnyPitch] = (uint32_t)f.fb_epoch;
+          }
+          flagged_any = true;
+          continue;
+        }
+      } else {
+        direct_ok = __all(item_ok);
       }
     } else if (lane < nb) {
       const WorkItem it = items[batch * S::NB + lane];
@@ -807,7 +902,7 @@ __device__ __forceinline__ int run_dct_class(const FrameDev& f, const WorkItem* 
       auto stage_channel = [&](auto ch_tag) {
         constexpr int CH = decltype(ch_tag)::value;
         if constexpr (GM == 1) sparse_stage_channel<S>(f, CH, buf, lane, sl);
-        if constexpr (GM == 2) entries_stage_channel<S, D, EX>(f, CH, buf, s_excl, lane, el);
+        if constexpr (GM == 2) entries_stage_channel<S, D, EX, SPARSE == 2>(f, CH, buf, s_excl, lane, el, binfo, nb);
 #pragma unroll
         for (int j = 0; j < NCH; j++) {
           const int fl = (j * 64 + lane) * 4;
@@ -878,23 +973,20 @@ __device__ __forceinline__ int run_dct_class(const FrameDev& f, const WorkItem* 
       // than its lanes hold -- otherwise the batch is left to the dense pass (k1_entries_fallback)
       constexpr int LPB = 64 / S::NB;
       const int b = lane / LPB, j = lane % LPB;
-      bool mine = true;
       float sdy = 0.0f, xcc = 0.0f, bcc = 0.0f;
       if (b < nb) {
         sdy = binfo[b].sdy;
         xcc = binfo[b].x_cc;
         bcc = binfo[b].b_cc;
-        mine = sdy > 0.0f && sdy < __builtin_inff() && max(max(binfo[b].en[0], binfo[b].en[1]), binfo[b].en[2]) <= (uint32_t)(D * LPB);
       }
-      if (!__all(mine)) {
-        if constexpr (INLINE_FB) {
+      if constexpr (INLINE_FB) {
+        if (!direct_ok) {
           static_assert(S::N == 64, "the inline fallback has no slot prefixes: one-slot varblocks only");
           generic_batch(std::integral_constant<int, 2>{});
-        } else {
-          if (lane == 0) wl_fallback[atomicAdd(fallback_count, 1)] = (uint32_t)batch;
+          n_dense_pass++;
+          wave_sync();  // binfo / s_lf are rewritten by the next batch
+          continue;
         }
-        wave_sync();  // binfo / s_lf / s_excl are rewritten by the next batch
-        continue;
       }
       wave_sync();  // the slot prefixes (entries_begin) are in LDS
       EntDirect<D> ed;
@@ -922,6 +1014,8 @@ __device__ __forceinline__ int run_dct_class(const FrameDev& f, const WorkItem* 
       generic_batch(std::integral_constant<int, SPARSE>{});
     }
   }
+  // statistics (jxlh_frame_k1_counters; only while kernel timing is on: 16 000 waves' atomics on one counter cost 0.2 ms)
+  if (f.k1_stats && (LISTED || INLINE_FB) && n_dense_pass && lane == 0) atomicAdd(fallback_count, n_dense_pass);
   return nbatches;
 }
 
@@ -950,8 +1044,17 @@ constexpr int kTileC = cmax(cmax(cmax(S32x8::kTile, S8x32::kTile), cmax(S32x16::
                             S32x32::kTile);                                       // 2624
 
 // family A: DCT 8x8 -- the dominant transform
-template <int SPARSE, bool SUB = false>
-__global__ __launch_bounds__(kThreads) void k1_dct8(const FrameDev f, const WorkLists wl) {
+// INLINE (mode 3): batches beyond the direct path's depth take the dense dequantisation pass inside this launch (one-slot
+// varblocks need no slot prefixes) instead of going to the fallback launch.  The host picks the form per frame from the
+// density of its entries (FrameDev::se_dense_hint): the inline body costs registers (79 -> 98 VGPRs, 6 -> 4 waves per
+// SIMD: +12 us on a d1 frame), the fallback launch a second pass over the work items (0.84 against 0.68 ms for K1 at
+// four times d1's density; profiles/r06_c_density.txt).
+// (the direct form without the inline body sits one register above six waves per SIMD: the bound makes the compiler fit)
+template <int SPARSE, bool SUB = false, bool INLINE = false>
+#ifndef JXLH_K1_INLINE_WPE
+#define JXLH_K1_INLINE_WPE 1  // waves per SIMD the inline form is compiled for (1 = whatever its 96 VGPRs allow: 5)
+#endif
+__global__ __launch_bounds__(kThreads, SPARSE == 3 ? (INLINE ? JXLH_K1_INLINE_WPE : 6) : 1) void k1_dct8(const FrameDev f, const WorkLists wl) {
   __shared__ __attribute__((aligned(16))) float s_buf[kWaves * kTileA];
   __shared__ BlockInfo s_binfo[kWaves][S8x8::NB];
   __shared__ AdjTable s_adj;
@@ -960,9 +1063,11 @@ __global__ __launch_bounds__(kThreads) void k1_dct8(const FrameDev f, const Work
   __shared__ float s_lf[SPARSE >= 2 ? kWaves : 1][S8x8::NB * 3];
   // (mode 3: batches beyond the direct path's depth take the dense dequantisation pass inline -- one-slot varblocks need
   // no slot prefixes, and the generic body fits the kernel's registers)
-  run_dct_class<S8x8, true, SPARSE, SUB, kClsDct8, SPARSE == 3>(f, wl.items[kClsDct8], wl.eitems[kClsDct8], wl.counts[(kClsDct8) * kCountPitch], 0,
+  static_assert(!INLINE || SPARSE == 3, "the inline fallback belongs to the direct form");
+  run_dct_class<S8x8, true, SPARSE, SUB, kClsDct8, INLINE>(f, wl.items[kClsDct8], wl.eitems[kClsDct8], wl.counts[(kClsDct8) * kCountPitch], 0,
                                                    s_buf + wave * kTileA, s_binfo[wave], (uint32_t*)nullptr, s_lf[SPARSE >= 2 ? wave : 0],
-                                                   blockIdx.x * kWaves + wave, gridDim.x * kWaves, lane, &s_adj);
+                                                   blockIdx.x * kWaves + wave, gridDim.x * kWaves, lane, &s_adj,
+                                                   wl.fallback[kClsDct8], wl.counts + (kCntFallback0 + kClsDct8) * kCountPitch);
 }
 
 // families B (16x8, 8x16, 16x16) + C (everything with a 32-point side) in ONE launch (round 3): as two kernels both
@@ -980,14 +1085,26 @@ constexpr int kExclWords = 40;
 // compiled for two workgroups per CU: its 32-point bodies then hold everything in registers + the LDS stash of the
 // dequantised Y (at three they spilled 250-330 bytes per lane)
 constexpr int kDyWords = 32 * 64;  // S::E * 64 for the shapes with a 32-point side
-// FB (mode 2 only): the fallback launch of the direct form -- per class, the batches of WorkLists::fallback[class] (what
-// k1_dct16_32<3> could not take: more entries than its lanes hold, raw_quant == 0) instead of the class's whole list.
-// Usually a handful of batches (the workgroups read eight counters and leave); on content denser than d1 it is the
-// main route of these classes.  (Round 5's fallback kernel dispatched one mixed list through a switch over the nine
+// FB (mode 2 only): the fallback launch of the direct form -- per class, the batches flagged in WorkLists::fallback[class]
+// (what the direct kernels could not take: more entries than their lanes hold, raw_quant == 0) instead of the class's
+// whole list.  Usually a handful of batches (a workgroup reads a few words of flags per class and leaves); on content
+// denser than d1 it is the main route of the 16..32-point classes.  (Round 5's fallback kernel dispatched one mixed list through a switch over the nine
 // bodies: 203 spilled VGPRs, 792 bytes of scratch per lane.)
 template <int SPARSE, bool FB = false>
 __global__ __launch_bounds__(kThreads, SPARSE == 3 ? JXLH_K1_DIRECT_WPE : SPARSE == 2 ? 2 : 3) void k1_dct16_32(const FrameDev f, const WorkLists wl) {
   static_assert(!FB || SPARSE == 2, "the fallback launch runs the dense dequantisation pass of the entries form");
+  if constexpr (FB) {
+    // nothing was left by the direct kernels (the usual case on d1 content): the classes' summary words say so in one
+    // memory round trip, before anything else of the workgroup is set up
+    constexpr int kWords = kClsSpecial * 32;  // (run_dct_class: kFbAny summary words per class, kFbAnyPitch apart)
+    bool any = false;
+#pragma unroll
+    for (int i = 0; i < (kWords + 63) / 64; i++) {
+      const int w = i * 64 + (threadIdx.x & 63);
+      if (w < kWords) any |= (wl.fallback[w / 32] - 32 * 32)[(w % 32) * 32] == (uint32_t)f.fb_epoch;
+    }
+    if (!__any(any)) return;  // (the same words for every wave: workgroup-uniform)
+  }
   __shared__ __attribute__((aligned(16))) float s_buf[kWaves * kTileC];
   __shared__ BlockInfo s_binfo[kWaves][8];
   using EX = std::conditional_t<SPARSE == 2, uint64_t, uint32_t>;  // mode 2 takes any entry count (excl_bits)
@@ -1009,12 +1126,12 @@ __global__ __launch_bounds__(kThreads, SPARSE == 3 ? JXLH_K1_DIRECT_WPE : SPARSE
     using S = typename decltype(shape_tag)::type;
     constexpr bool PF = decltype(pf_tag)::value;
     constexpr int CLS = decltype(cls_tag)::value;
-    const int listed = FB ? wl.counts[(kCntFallback0 + CLS) * kCountPitch] : 0;
-    if (FB && listed == 0) return;  // (wave-uniform)
-    used += run_dct_class<S, PF, SPARSE, false, CLS>(f, wl.items[CLS], wl.eitems[CLS], cnt(CLS), type, buf, s_binfo[wave], ex, lfs,
-                                                     rotate_wave(gw, used, nw), nw, lane, &s_adj, wl.fallback[CLS],
-                                                     wl.counts + (kCntFallback0 + CLS) * kCountPitch, sdy,
-                                                     FB ? wl.fallback[CLS] : nullptr, listed);
+    // (FB: the rotation counts workgroups -- a class's chunk c goes to workgroup (c + chunks of the classes before) % grid)
+    const int nbat = run_dct_class<S, PF, SPARSE, false, CLS, false, FB>(
+        f, wl.items[CLS], wl.eitems[CLS], cnt(CLS), type, buf, s_binfo[wave], ex, lfs,
+        FB ? rotate_wave((int)blockIdx.x, used, (int)gridDim.x) * kWaves + wave : rotate_wave(gw, used, nw), nw, lane, &s_adj,
+        wl.fallback[CLS], wl.counts + (kCntFallback0 + CLS) * kCountPitch, sdy);
+    used += FB ? (nbat + 15) / 16 : nbat;
   };
   run(ShapeTag<S32x32>{}, std::false_type{}, std::integral_constant<int, kClsDct32x32>{}, 5);
   run(ShapeTag<S32x16>{}, std::false_type{}, std::integral_constant<int, kClsDct32x16>{}, 10);
@@ -1024,6 +1141,8 @@ __global__ __launch_bounds__(kThreads, SPARSE == 3 ? JXLH_K1_DIRECT_WPE : SPARSE
   run(ShapeTag<S16x16>{}, std::true_type{}, std::integral_constant<int, kClsDct16x16>{}, 4);
   run(ShapeTag<S16x8>{}, std::true_type{}, std::integral_constant<int, kClsDct16x8>{}, 6);
   run(ShapeTag<S8x16>{}, std::true_type{}, std::integral_constant<int, kClsDct8x16>{}, 7);
+  // (the 8x8 class: only when its kernel ran without the inline fallback; the list stays empty otherwise)
+  if constexpr (FB) run(ShapeTag<S8x8>{}, std::true_type{}, std::integral_constant<int, kClsDct8>{}, 0);
 }
 
 // family D: the nine 8x8 special transform types (IDENTITY, DCT2X2, DCT4X4, DCT4X8, DCT8X4, AFV0-3).
@@ -1222,7 +1341,7 @@ size_t vardct_worklist_bytes(const FrameDev& f) {
   for (int c = 0; c < kNumClasses; c++) items += nblocks / class_min_area(c) + 1;
   for (int c = 0; c < kClsSpecial; c++) items += 2 * (nblocks / class_min_area(c) + 1);  // entry side items of the DCT
                                                                                          // classes + their dense-route lists
-  items += (size_t)kClsSpecial * (nblocks / 64 + 4);  // the fallback batch lists (u32 per batch, nblocks / 16 + 16 per class)
+  for (int c = 0; c < kClsSpecial; c++) items += nblocks / (8 * class_min_area(c)) + 4 + 256;  // the fallback flags (u32 per batch) + summaries
   // + the unit lists of the large transforms: one u32 per 4096 samples of a 256-pixel varblock (two-pass units) and
   //   one per varblock of the smaller types (three lists by slabs per channel; worst case one entry per 32 blocks)
   // + the LLF planes of the large transforms (3 x nblocks floats, k1_large_llf)
@@ -1235,11 +1354,28 @@ void vardct_worklist_reset(hipStream_t s, void* worklist_mem, uint32_t* launch_p
   *launch_parity = 0;
 }
 
-void launch_vardct_groups(hipStream_t s, const FrameDev& f, int group_row0, int group_row1,
+const void* vardct_worklist_counters(const void* worklist_mem, uint32_t launch, size_t* bytes, int* lines) {
+  static_assert(kCntFallback0 == kNumClasses + 4 && kCntDense0 == kCntFallback0 + kClsSpecial && kNumClasses == 11,
+                "jxlh_frame_k1_counters maps the lines by position");
+  *bytes = kCountBytes;
+  *lines = kCountLines;
+  return reinterpret_cast<const char*>(worklist_mem) + (launch & 1u) * kCountBytes;
+}
+
+void launch_vardct_groups(hipStream_t s, const FrameDev& f_in, int group_row0, int group_row1,
                           void* worklist_mem, uint32_t* launch_parity, int* error_flag, int32_t* dense_coeffs,
                           const int* group_list, int n_list, bool has_special, bool has_large, int n_dense_route) {
-  const int ngroups = group_list ? n_list : (group_row1 - group_row0) * f.xgroups;
+  const int ngroups = group_list ? n_list : (group_row1 - group_row0) * f_in.xgroups;
   if (ngroups <= 0) return;
+  // The value that flags a batch for the fallback launch: unique per launch across the process, never 0.  The flag words
+  // are never cleared and start out as whatever the allocation held: a word that happens to equal the epoch sends an
+  // already reconstructed batch through the dense pass once more, which writes the same pixels (the two passes are
+  // bit-identical, tests/test_gpu_parity.py) behind the direct kernel in stream order.
+  static std::atomic<uint32_t> epoch_counter{0};
+  FrameDev f = f_in;
+  uint32_t epoch = ++epoch_counter;
+  if (epoch == 0) epoch = ++epoch_counter;
+  f.fb_epoch = (int)epoch;
   // carve the work-list memory: [two sets of counters, one 128-byte line each] [class 0 items] [class 1 items] ...
   WorkLists wl;
   const uint32_t set = (*launch_parity)++ & 1u;
@@ -1259,15 +1395,19 @@ void launch_vardct_groups(hipStream_t s, const FrameDev& f, int group_row0, int 
     wl.ditems[c] = reinterpret_cast<WorkItem*>(p);
     p += (nblocks / class_min_area(c) + 1) * sizeof(WorkItem);
   }
-  for (int c = 0; c < kClsSpecial; c++) {  // a class has at most nblocks / 16 batches (16x8: nblocks / 2 items of 8)
+  for (int c = 0; c < kClsSpecial; c++) {  // one word per batch of the class (at least 2 varblocks per batch)
+    p += 32 * 32 * sizeof(uint32_t);  // the class's summary words (run_dct_class: kFbAny x kFbAnyPitch), then its flags
     wl.fallback[c] = reinterpret_cast<uint32_t*>(p);
-    p += (nblocks / 16 + 16) * sizeof(uint32_t);
+    p += (nblocks / (2 * class_min_area(c)) + 16) * sizeof(uint32_t);
   }
   uint32_t* large_units = reinterpret_cast<uint32_t*>(p);  // behind the last list
   const dim3 gscan((ngroups + kScanGroups - 1) / kScanGroups);
   if (f.strip_desc)
     hipLaunchKernelGGL(k1_scan<true>, gscan, dim3(kScanThreads), 0, s, f, wl, group_row0, error_flag, group_list, ngroups,
                        next_counts);
+  else if (f.se_entries && f.group_route)
+    hipLaunchKernelGGL((k1_scan<false, true, true>), gscan, dim3(kScanThreads), 0, s, f, wl, group_row0, error_flag, group_list,
+                       ngroups, next_counts);
   else if (f.se_entries)
     hipLaunchKernelGGL((k1_scan<false, true>), gscan, dim3(kScanThreads), 0, s, f, wl, group_row0, error_flag, group_list,
                        ngroups, next_counts);
@@ -1296,7 +1436,8 @@ void launch_vardct_groups(hipStream_t s, const FrameDev& f, int group_row0, int 
   const dim3 g8(grid_for(nblk, kWaves * S8x8::NB * 2, 4096)), g16(grid_for(nblk / 2, kWaves * 8 * 2, 2048)),
       g32(grid_for(nblk / 4, kWaves * 4 * 2, 2048));
   if (f.subsampled) {
-    if (sparse == 3) hipLaunchKernelGGL((k1_dct8<3, true>), g8, dim3(kThreads), 0, s, f, wl);
+    // (the fallback launch has no sub-sampled form: such a frame always takes the inline fallback)
+    if (sparse == 3) hipLaunchKernelGGL((k1_dct8<3, true, true>), g8, dim3(kThreads), 0, s, f, wl);
     else if (sparse == 2) hipLaunchKernelGGL((k1_dct8<2, true>), g8, dim3(kThreads), 0, s, f, wl);
     else if (sparse == 1) hipLaunchKernelGGL((k1_dct8<1, true>), g8, dim3(kThreads), 0, s, f, wl);
     else hipLaunchKernelGGL((k1_dct8<0, true>), g8, dim3(kThreads), 0, s, f, wl);
@@ -1304,7 +1445,13 @@ void launch_vardct_groups(hipStream_t s, const FrameDev& f, int group_row0, int 
   } else {
     const dim3 g1632(std::min(4096u, g16.x + g32.x));
     if (sparse == 3) {
-      hipLaunchKernelGGL(k1_dct8<3>, g8, dim3(kThreads), 0, s, f, wl);
+      static const int force_inline = [] {  // JXLH_K1_INLINE=0 / 1: A/B runs of the 8x8 class's two forms
+        const char* e = getenv("JXLH_K1_INLINE");
+        return e && *e ? atoi(e) : -1;
+      }();
+      if (force_inline >= 0 ? force_inline != 0 : f.se_dense_hint != 0)
+        hipLaunchKernelGGL((k1_dct8<3, false, true>), g8, dim3(kThreads), 0, s, f, wl);
+      else hipLaunchKernelGGL(k1_dct8<3>, g8, dim3(kThreads), 0, s, f, wl);
       hipLaunchKernelGGL(k1_dct16_32<3>, g1632, dim3(kThreads), 0, s, f, wl);
     } else if (sparse == 2) {
       hipLaunchKernelGGL(k1_dct8<2>, g8, dim3(kThreads), 0, s, f, wl);
@@ -1318,8 +1465,10 @@ void launch_vardct_groups(hipStream_t s, const FrameDev& f, int group_row0, int 
     }
   }
   // what the direct form of k1_dct16_32 left (usually next to nothing: the workgroups read one counter and leave)
-  if (sparse == 3 && !f.subsampled)
-    hipLaunchKernelGGL((k1_dct16_32<2, true>), dim3(std::min(1024, std::max(1, nblk / 1024))), dim3(kThreads), 0, s, f, wl);
+  // (a sparse frame leaves a handful of batches: the workgroups read one counter and go; a frame denser than d1 gets
+  // the whole chip)
+  if (sparse == 3)
+    hipLaunchKernelGGL((k1_dct16_32<2, true>), dim3(std::min(2048, std::max(1, nblk / 512))), dim3(kThreads), 0, s, f, wl);
   // entries form, groups routed to their dense slabs (FrameDev::group_route): the same class kernels in their dense
   // form on those groups' lists; the grids follow the routed share of the frame
   if (sparse >= 2 && n_dense_route > 0) {

@@ -101,8 +101,9 @@ struct WorkLists {
   // the rest of the frame is slot-bucketed -- go to these lists, which the dense-slab kernels run (counters at
   // kCntDense0 + class); everything else of the frame keeps reading its entries in place.
   WorkItem* ditems[kClsSpecial];
-  uint32_t* fallback[kClsSpecial];  // entries form, direct kernels: per class, the batches they leave to the fallback
-                                    // launch (varblocks with more entries than a lane holds, raw_quant == 0)
+  uint32_t* fallback[kClsSpecial];  // entries form, direct kernels: per class one word per batch; == FrameDev::fb_epoch
+                                    // of the launch = left to the fallback launch (varblocks with more entries than a
+                                    // lane holds, raw_quant == 0).  Never cleared: see launch_vardct_groups.
   int* counts;  // kCountLines counters at kCountPitch ints, zeroed before k1_scan: the classes, then the large
                 // transforms' unit lists (k_vardct_large.hip: two-pass slab units, fused lists of 1 / 2 / 4 slabs)
 };

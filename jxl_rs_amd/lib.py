@@ -62,7 +62,7 @@ ABI_SYMBOLS = [
 DEV_SYMBOLS = [
     "jxlh_timer_start", "jxlh_timer_stop", "jxlh_kernel_timing_enable", "jxlh_kernel_timing_get",
     "jxlh_kernel_timing_reset", "jxlh_selftest_recip", "jxlh_probe_copy_bandwidth", "jxlh_frame_path",
-    "jxlh_flow_profile",
+    "jxlh_flow_profile", "jxlh_frame_k1_counters",
 ]
 
 
@@ -162,6 +162,8 @@ def load():
     L.jxlh_selftest_recip.argtypes = [vp, u32, u32, C.POINTER(C.c_uint64)]
     if hasattr(L, "jxlh_flow_profile"):  # absent from older builds used in A/B runs (JXLH_LIBRARY)
         L.jxlh_flow_profile.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(C.c_uint64), i32]
+    if hasattr(L, "jxlh_frame_k1_counters"):
+        L.jxlh_frame_k1_counters.argtypes = [vp, vp, i32]
     L.jxlh_frame_set_dequant_tables.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
     L.jxlh_frame_set_lf_quantized.argtypes = [vp, u32, u32, u32, u32, vp, vp, vp, sz, u32]
     L.jxlh_frame_set_lf.argtypes = [vp, u32, u32, u32, u32, vp, vp, vp, sz]
@@ -231,15 +233,16 @@ def load():
     L.jxlh_palette_strided.argtypes = [vp, vp, sz, vp, i32, sz, i32, i32, vp, sz]
     L.jxlh_modular_frame_filters.argtypes = [vp, C.POINTER(FrameParams), C.POINTER(vp), C.POINTER(vp), u32, u32, sz]
     # host side of the slot-bucketed form (csrc/host_pack.hip): plain CPU code, no context
-    L.jxlh_host_pack_slots.argtypes = [vp, u32, u32, vp, sz, vp, vp, vp, u32, C.POINTER(u32)]
-    L.jxlh_slot_writer_create.argtypes = [C.POINTER(vp)]
-    L.jxlh_slot_writer_destroy.argtypes = [vp]
-    L.jxlh_slot_writer_destroy.restype = None
-    L.jxlh_slot_writer_begin_group.argtypes = [vp, u32, u32, vp, sz, vp, vp, u32]
-    L.jxlh_slot_writer_begin_varblock.argtypes = [vp, u32, u32]
-    L.jxlh_slot_writer_add.argtypes = [vp, u32, u32, i32]
-    L.jxlh_slot_writer_add_many.argtypes = [vp, u32, vp, vp, sz]
-    L.jxlh_slot_writer_end_group.argtypes = [vp, vp, C.POINTER(u32)]
+    if hasattr(L, "jxlh_host_pack_slots"):  # absent from older builds used in A/B runs (JXLH_LIBRARY)
+        L.jxlh_host_pack_slots.argtypes = [vp, u32, u32, vp, sz, vp, vp, vp, u32, C.POINTER(u32)]
+        L.jxlh_slot_writer_create.argtypes = [C.POINTER(vp)]
+        L.jxlh_slot_writer_destroy.argtypes = [vp]
+        L.jxlh_slot_writer_destroy.restype = None
+        L.jxlh_slot_writer_begin_group.argtypes = [vp, u32, u32, vp, sz, vp, vp, u32]
+        L.jxlh_slot_writer_begin_varblock.argtypes = [vp, u32, u32]
+        L.jxlh_slot_writer_add.argtypes = [vp, u32, u32, i32]
+        L.jxlh_slot_writer_add_many.argtypes = [vp, u32, vp, vp, sz]
+        L.jxlh_slot_writer_end_group.argtypes = [vp, vp, C.POINTER(u32)]
     for name in ("jxlh_covered_blocks_x", "jxlh_covered_blocks_y", "jxlh_quant_table_for_type",
                  "jxlh_quant_table_size"):
         getattr(L, name).argtypes = [i32]
@@ -671,6 +674,17 @@ class Context:
         pl = Plane(out.ctypes.data, out_w * 4, out_h, out_w * 4)
         self._chk(self.L.jxlh_frame_read_extra_channel(self._ctx, ec, C.byref(pl)), "frame_read_extra_channel")
         return out
+
+    def k1_counters(self):
+        """jxlh_frame_k1_counters: dict of the last transform launch's work-list counters"""
+        out = np.zeros(29, np.int32)
+        self._chk(self.L.jxlh_frame_k1_counters(self._ctx, _addr(out), 29), "frame_k1_counters")
+        names = ["dct8", "dct16x8", "dct8x16", "dct16x16", "dct32x8", "dct8x32", "dct32x16", "dct16x32", "dct32x32"]
+        nb = [8, 8, 8, 4, 4, 8, 4, 4, 2]   # varblocks per batch (Shape::NB)
+        return {"varblocks": {k: int(v) for k, v in zip(names + ["special", "large"], out[:11])},
+                "fallback_batches": {k: int(v) for k, v in zip(names, out[11:20])},
+                "batches": {k: int(-(-int(v) // b)) for k, v, b in zip(names, out[:9], nb)},
+                "dense_route_varblocks": {k: int(v) for k, v in zip(names, out[20:29])}}
 
     def frame_path(self):
         """(strip kernel ran, 64x64 tiles of the frame, tiles left to the transform class kernels) of the last frame_run"""

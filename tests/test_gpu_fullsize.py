@@ -61,6 +61,48 @@ def test_8k_vardct_whole_frame_band_and_determinism(ctx, oracle):
     again = ctx.read_planes()
     for c in range(3):
         assert bit_equal(again[c], got[c])
+    # ---- the SAME frame submitted in the slot-bucketed form, the way the bench's slot-resident and PCIe legs time it
+    # (1024 groups, 17 M entries, read in place by the direct transforms; VERDICT r05: compared with the oracle at
+    # <= 1024 x 768 only): packed by the C packer, two consecutive epochs so that both buffer sets are read, then with
+    # one group as a dense slab and one carrying values beyond the entries' range (per-group routing).  `got` equals the
+    # oracle's frame bit for bit (checked above).
+    from jxl_rs_amd import lib as jl
+    ng = wl.coeffs.shape[0]
+    uniq = {}
+    for g in range(ng):
+        k = g % 16
+        if k not in uniq or not np.array_equal(wl.coeffs[g], wl.coeffs[uniq[k][0]]):
+            uniq[k] = (g, jl.host_pack_slots(wl.coeffs[g]))
+    assert all(np.array_equal(wl.coeffs[g], wl.coeffs[uniq[g % 16][0]]) for g in range(0, ng, 37))
+    parts = [uniq[g % 16][1] for g in range(ng)]
+    assert all(len(q[3]) == 0 for q in parts)
+    ids = np.arange(ng, dtype=np.uint32)
+    ents, cnts, ns = (np.concatenate([q[0] for q in parts]), np.concatenate([q[1].reshape(-1) for q in parts]),
+                      np.concatenate([q[2] for q in parts]))
+    for epoch in range(2):
+        ctx.submit_groups_slots(ids, ents, cnts, ns, None)
+        ctx.slot_wait(0)
+        ctx.frame_run()
+        ctx.sync()
+        sl = ctx.read_planes()
+        for c in range(3):
+            assert bit_equal(sl[c], got[c]), f"slot-submitted 8K frame, epoch {epoch}, plane {c}: {diff_report(sl[c], got[c])}"
+    keep = [g for g in range(ng) if g not in (5, 700)]
+    ctx.submit_groups_slots(np.asarray(keep, dtype=np.uint32), np.concatenate([parts[g][0] for g in keep]),
+                            np.concatenate([parts[g][1].reshape(-1) for g in keep]), np.concatenate([parts[g][2] for g in keep]), None)
+    ctx.submit_group(5, wl.coeffs[5])
+    big = wl.coeffs[700].copy()
+    big.reshape(-1)[np.flatnonzero(big.reshape(-1))[:3]] += 70000      # beyond what the packer splits: `wide`
+    e7, c7, n7, w7 = jl.host_pack_slots(big, group_id=700)
+    assert len(w7) == 3
+    w7[:, 1] = (w7[:, 1].view(np.int32) - 70000).view(np.uint32)       # ... carrying the ORIGINAL values: same frame
+    ctx.submit_groups_slots(np.uint32([700]), e7, c7.reshape(-1), n7, w7)
+    ctx.slot_wait(0)
+    ctx.frame_run()
+    ctx.sync()
+    sl = ctx.read_planes()
+    for c in range(3):
+        assert bit_equal(sl[c], got[c]), f"8K frame with two routed groups, plane {c}: {diff_report(sl[c], got[c])}"
 
 
 def test_8k_modular_round_trips(ctx, oracle):

@@ -218,6 +218,10 @@ def test_more_than_1023_entries_in_a_varblock(ctx, dense_dequant):
     a = rng.integers(-200, 201, size=wl.coeffs.shape).astype(np.int32)       # every position non-zero, nearly
     b = rng.integers(-200, 201, size=wl.coeffs.shape).astype(np.int32)
     b = np.where(rng.random(b.shape) < 0.02, -a, b).astype(np.int32)          # some positions cancel to zero
+    # (a run holds at most 65536 entries: both passes dense in the first 30000 coefficients of a channel, sparse behind)
+    tail = np.arange(65536) >= 30000
+    a[:, :, tail] = np.where(rng.random(a[:, :, tail].shape) < 0.05, a[:, :, tail], 0)
+    b[:, :, tail] = 0
     wl.coeffs = (a + b).astype(np.int32)
     want, _ = run_gpu_frame(ctx, wl)
     parts = {g: _merge(synth.to_slots(a[g]), synth.to_slots(b[g])) for g in range(ng)}

@@ -6,7 +6,7 @@ TAG=$1; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH=${PROFILE_CMD:-"python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --no-cpu --no-e2e --no-active --no-secondary --no-strip --reps 1 --inflight 1 $*"}
+BENCH=${PROFILE_CMD:-"python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --no-cpu --no-e2e --no-active --no-secondary --reps 1 --inflight 1 $*"}
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $BENCH > $OUT/trace.log 2>&1
 i=0
 for set in \
