@@ -95,6 +95,32 @@ impl Context {
     pub fn wait_mark(&self, mark: u32) -> Result<()> {
         self.ok(unsafe { sys::jxlh_ctx_wait_mark(self.raw, mark) })
     }
+    /// Hand-over of device buffers the CALLER filled (jxl_hip.h "STREAM ORDERING OF DEVICE POINTERS"): the context's
+    /// streams are non-blocking, so work queued on the NULL stream -- `hipMemset` / `hipMemcpy` of a plane that is then
+    /// passed as a device pointer -- is ordered in front of the context's next calls with this.  Call it after the
+    /// last fill and before the first entry point that takes the pointer; the host does not block.
+    pub fn wait_default_stream(&self) -> Result<()> {
+        self.ok(unsafe { sys::jxlh_ctx_wait_stream(self.raw, std::ptr::null_mut()) })
+    }
+    /// The same for a `hipStream_t` of the caller.
+    /// # Safety
+    /// `hip_stream` must be a live stream of the context's device.
+    pub unsafe fn wait_stream(&self, hip_stream: *mut c_void) -> Result<()> {
+        self.ok(sys::jxlh_ctx_wait_stream(self.raw, hip_stream))
+    }
+    /// ... and for a `hipEvent_t` the caller has recorded behind its fill.
+    /// # Safety
+    /// `hip_event` must be a live, recorded event.
+    pub unsafe fn wait_event(&self, hip_event: *mut c_void) -> Result<()> {
+        self.ok(sys::jxlh_ctx_wait_event(self.raw, hip_event))
+    }
+    /// The other direction: records the caller's event behind everything the context has enqueued on its main stream,
+    /// so a caller stream can wait for the results on the device.
+    /// # Safety
+    /// `hip_event` must be a live event of the context's device.
+    pub unsafe fn record_event(&self, hip_event: *mut c_void) -> Result<()> {
+        self.ok(sys::jxlh_ctx_record_event(self.raw, hip_event))
+    }
     /// pinned host memory for coefficient slabs / pair lists (replaces `VarDctBuffers::coeffs_storage`)
     pub fn alloc_pinned(&self, bytes: usize) -> Result<PinnedBuf<'_>> {
         let mut p: *mut c_void = std::ptr::null_mut();

@@ -31,7 +31,8 @@
 extern "C" {
 #endif
 
-#define JXLH_ABI_VERSION 6
+#define JXLH_ABI_VERSION 6  /* additions only since 6: round 6 added the jxlh_host_*, jxlh_slot_writer_* and
+                               jxlh_ctx_wait_* / _record_event entry points */
 #define JXLH_NUM_TRANSFORMS 27   /* HfTransformType::CARDINALITY, transform_map.rs:59-61 */
 #define JXLH_NUM_QUANT_TABLES 17 /* NUM_QUANT_TABLES, quantizer.rs:11 */
 #define JXLH_GROUP_DIM 256       /* GROUP_DIM, jxl/src/lib.rs:24-26 */
@@ -361,6 +362,28 @@ jxlh_status jxlh_frame_run(jxlh_ctx* ctx, uint32_t group_row0, uint32_t group_ro
 jxlh_status jxlh_frame_rerender_groups(jxlh_ctx* ctx, const uint32_t* group_ids, uint32_t count);
 /* blocks until the main stream is idle */
 jxlh_status jxlh_ctx_sync(jxlh_ctx* ctx);
+/* STREAM ORDERING OF DEVICE POINTERS.  Every stream of a context is a hipStreamNonBlocking stream: it does NOT
+ * synchronise with the NULL (legacy default) stream or with any stream of the caller.  Host pointers are safe by
+ * construction (the library's own copies are ordered on its streams), but a caller that fills a DEVICE buffer -- a
+ * hipMemset / hipMemcpy on the NULL stream, a kernel on its own stream -- and then hands the pointer to an entry
+ * point (jxlh_unsqueeze_chain, jxlh_rct, jxlh_palette*, jxlh_submit_group* with device sources, the stage hooks, the
+ * *_device destinations of the read calls) must order that work in FRONT of the call, or the library's kernels may
+ * run before the fill has (hipMemset returns before the fill has run; the same holds for the outputs: an output plane
+ * the caller clears on the NULL stream can be cleared AFTER the library wrote it).  The reference hands buffers over by
+ * ownership (RenderPipeline::set_buffer_for_group takes `buf: Image<T>`, render/mod.rs:124-137), so a binding has to
+ * make the hand-over explicit with one of:
+ *   jxlh_ctx_wait_stream(ctx, stream)   everything enqueued so far on `stream` (a hipStream_t; NULL = the legacy default
+ *                                       stream) happens before whatever the context enqueues from now on -- on the
+ *                                       device, the host does not block
+ *   jxlh_ctx_wait_event(ctx, event)     the same for a hipEvent_t the caller has recorded
+ *   jxlh_ctx_record_event(ctx, event)   the other direction: records the caller's event behind everything enqueued so
+ *                                       far on the context's main stream, so a caller stream can hipStreamWaitEvent on
+ *                                       the library's results without a host-side jxlh_ctx_sync
+ * (a host-side hipDeviceSynchronize / hipStreamSynchronize before the call is the blunt alternative).  hipStream_t /
+ * hipEvent_t travel as void* so that this header needs no HIP header. */
+jxlh_status jxlh_ctx_wait_stream(jxlh_ctx* ctx, void* hip_stream);
+jxlh_status jxlh_ctx_wait_event(jxlh_ctx* ctx, void* hip_event);
+jxlh_status jxlh_ctx_record_event(jxlh_ctx* ctx, void* hip_event);
 /* A point in the context's main stream: everything enqueued so far (frame runs, asynchronous reads).
  * jxlh_ctx_wait_mark blocks until that point has been reached and -- unlike jxlh_ctx_sync -- not for work enqueued after
  * the mark.  That is what lets ONE context stream consecutive frames (round 5: the slot-bucketed submission of frame

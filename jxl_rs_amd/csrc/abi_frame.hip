@@ -141,6 +141,7 @@ void jxlh_ctx_destroy(jxlh_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipDeviceSynchronize();
   drain_timers(ctx);
+  if (ctx->handover) (void)hipEventDestroy(ctx->handover);
   for (auto& s : ctx->slots) {
     if (s.done) (void)hipEventDestroy(s.done);
     if (s.copied) (void)hipEventDestroy(s.copied);
@@ -191,7 +192,6 @@ void jxlh_ctx_destroy(jxlh_ctx* ctx) {
   if (ctx->host_flag) (void)hipHostFree(ctx->host_flag);
   if (ctx->host_flow_flag) (void)hipHostFree(ctx->host_flow_flag);
   release(ctx->flow_words);
-  release(ctx->flow_error);
   release(ctx->flow_prof);
   release(ctx->worklist);
   for (auto& e : ctx->extra) {
@@ -926,7 +926,9 @@ jxlh_status run_strip(jxlh_ctx* ctx, const RunPlan& plan) {
   // The strips of a band spin on their neighbours' progress flags: every workgroup of the launch must be resident.
   // The occupancy query says how many are (two per CU on MI355X: the 77 KB window); a frame wider than that in strips
   // cannot take this path at all (the grid used to assume two per CU).
-  static const int resident = strip_resident_workgroups(ctx->cu_count);
+  // (per context: contexts may sit on devices of different sizes; a failed query is asked again -- ADVICE r05)
+  if (ctx->strip_resident <= 0) ctx->strip_resident = strip_resident_workgroups(ctx->cu_count);
+  const int resident = ctx->strip_resident;
   if (resident < strips) return JXLH_ERR_UNSUPPORTED;  // (the caller falls back to the two-kernel path)
   // a band is at least 4 tile rows (two extra transforms per band and strip)
   int bands = std::min((2 * ctx->cu_count + strips / 2) / strips, resident / strips);
@@ -1284,6 +1286,47 @@ jxlh_status jxlh_frame_read_extra_channel(jxlh_ctx* ctx, uint32_t ec, const jxlh
   return jxlh_ctx_sync(ctx);
 }
 
+// hand-over of caller-filled device buffers (jxl_hip.h "STREAM ORDERING OF DEVICE POINTERS"): every stream of the
+// context -- the main one and the slot streams -- waits for the event
+static jxlh_status all_streams_wait(jxlh_ctx* ctx, hipEvent_t e) {
+  HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, e, 0));
+  for (auto& s : ctx->slots) HIPCHK(ctx, hipStreamWaitEvent(s.stream, e, 0));
+  return JXLH_OK;
+}
+
+jxlh_status jxlh_ctx_wait_event(jxlh_ctx* ctx, void* hip_event) {
+  JXLH_ON_DEVICE(ctx);
+  if (!ctx || !hip_event) return JXLH_ERR_INVALID_ARGUMENT;
+  return all_streams_wait(ctx, static_cast<hipEvent_t>(hip_event));
+}
+
+jxlh_status jxlh_ctx_wait_stream(jxlh_ctx* ctx, void* hip_stream) {
+  JXLH_ON_DEVICE(ctx);
+  if (!ctx) return JXLH_ERR_INVALID_ARGUMENT;
+  if (!ctx->handover) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->handover, hipEventDisableTiming));
+  // (an event may be re-recorded while earlier waits on it are still pending: a wait captures the record it follows)
+  HIPCHK(ctx, hipEventRecord(ctx->handover, static_cast<hipStream_t>(hip_stream)));
+  return all_streams_wait(ctx, ctx->handover);
+}
+
+jxlh_status jxlh_ctx_record_event(jxlh_ctx* ctx, void* hip_event) {
+  JXLH_ON_DEVICE(ctx);
+  if (!ctx || !hip_event) return JXLH_ERR_INVALID_ARGUMENT;
+  HIPCHK(ctx, hipEventRecord(static_cast<hipEvent_t>(hip_event), ctx->stream));
+  return JXLH_OK;
+}
+
+// the dataflow squeeze launch's error word (pinned host memory the kernel writes): non-zero = a wait between two levels
+// outlasted its deadline; reported once
+static jxlh_status flow_error_status(jxlh_ctx* ctx) {
+  if (!ctx->host_flow_flag) return JXLH_OK;
+  const int v = *reinterpret_cast<volatile int*>(ctx->host_flow_flag);
+  if (v == 0) return JXLH_OK;
+  *ctx->host_flow_flag = 0;
+  ctx->last_error = "jxlh_unsqueeze_chain: a wait between two levels of the dataflow launch outlasted its deadline";
+  return (jxlh_status)v;
+}
+
 jxlh_status jxlh_ctx_mark(jxlh_ctx* ctx, uint32_t* mark) {
   JXLH_ON_DEVICE(ctx);
   if (!ctx || !mark) return JXLH_ERR_INVALID_ARGUMENT;
@@ -1302,25 +1345,17 @@ jxlh_status jxlh_ctx_wait_mark(jxlh_ctx* ctx, uint32_t mark) {
   hipEvent_t e = ctx->marks[mark % JXLH_MAX_MARKS];
   if (!e) return JXLH_ERR_BAD_STATE;
   HIPCHK(ctx, hipEventSynchronize(e));
-  return JXLH_OK;
+  return flow_error_status(ctx);  // (a streaming caller that only ever waits for marks sees a dataflow fault too)
 }
 
 jxlh_status jxlh_ctx_sync(jxlh_ctx* ctx) {
   JXLH_ON_DEVICE(ctx);
   if (!ctx) return JXLH_ERR_INVALID_ARGUMENT;
-  if (ctx->flow_used && ctx->flow_error.p) {
+  if (ctx->flow_used && ctx->host_flow_flag) {
     // a dataflow squeeze launch ran since the last synchronisation: did one of its waits give up?
     ctx->flow_used = false;
-    if (!ctx->host_flow_flag)
-      HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->host_flow_flag), sizeof(int), hipHostMallocDefault));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->host_flow_flag, ctx->flow_error.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     if (jxlh_status st = comm_wait_stream(ctx)) return st;
-    if (*ctx->host_flow_flag != 0) {
-      const jxlh_status st = (jxlh_status)*ctx->host_flow_flag;
-      HIPCHK(ctx, hipMemsetAsync(ctx->flow_error.p, 0, sizeof(int), ctx->stream));
-      ctx->last_error = "jxlh_unsqueeze_chain: a wait between two levels of the dataflow launch outlasted its deadline";
-      return st;
-    }
+    if (jxlh_status st = flow_error_status(ctx)) return st;
   }
   if (ctx->in_frame && ctx->error_flag.p) {
     // read the flag on the context's own stream into pinned memory: a synchronous hipMemcpy would

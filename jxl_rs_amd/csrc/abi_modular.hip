@@ -412,7 +412,7 @@ jxlh_status jxlh_unsqueeze_chain(jxlh_ctx* ctx, int32_t n_planes, int32_t n_leve
       int n = 0;
       for (int j = i; j < n_levels && n < max_run; j++, n++) {
         const jxlh_squeeze_level& lv = levels[j];
-        if (j == n_levels - 1 && fuse_rct) break;  // the fused kernel takes it
+        if (j == n_levels - 1 && with_rct) break;  // the fused kernel (or, without fusion, the level + RCT pair below) takes it
         int32_t* dst[3];
         size_t dst_stride;
         dst_of(j, dst, &dst_stride);
@@ -435,12 +435,14 @@ jxlh_status jxlh_unsqueeze_chain(jxlh_ctx* ctx, int32_t n_planes, int32_t n_leve
       }
       if (n >= 2) {
         if ((st = ensure(ctx, ctx->flow_words, unsqueeze_flow_words(n_planes, n, steps)))) return st;
-        if (!ctx->flow_error.p) {
-          if ((st = ensure(ctx, ctx->flow_error, 1))) return st;
-          HIPCHK(ctx, hipMemsetAsync(ctx->flow_error.p, 0, sizeof(int), ctx->stream));
+        if (!ctx->host_flow_flag) {
+          // the error word lives in pinned host memory (device-visible under the same address): jxlh_ctx_sync AND
+          // jxlh_ctx_wait_mark read it without queueing a copy behind later work
+          HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->host_flow_flag), sizeof(int), hipHostMallocDefault));
+          *ctx->host_flow_flag = 0;
         }
         if (ctx->flow_prof_on && (st = ensure(ctx, ctx->flow_prof, 11 * (size_t)unsqueeze_flow_max_steps()))) return st;
-        launch_unsqueeze_flow(ctx->stream, n_planes, n, steps, ctx->flow_words.p, ctx->flow_error.p, 4.0f,
+        launch_unsqueeze_flow(ctx->stream, n_planes, n, steps, ctx->flow_words.p, ctx->host_flow_flag, 4.0f,
                               ctx->flow_prof_on ? ctx->flow_prof.p : nullptr);
         ctx->flow_prof_levels = n;
         ctx->flow_used = true;

@@ -109,9 +109,9 @@ struct jxlh_ctx {
   DevBuf<int32_t> hook_i[4];
   // jxlh_unsqueeze_chain's dataflow launches (k6_unsqueeze_flow): ticket + progress words, zeroed per launch; the error
   // word (zeroed when allocated and after an error was reported) is read back by the next jxlh_ctx_sync
-  DevBuf<int> flow_words, flow_error;
+  DevBuf<int> flow_words;
   bool flow_used = false;
-  int* host_flow_flag = nullptr;  // pinned
+  int* host_flow_flag = nullptr;  // pinned, device-visible: the dataflow launches' error word (0 = none)
   // jxlh_flow_profile (jxl_hip_dev.h): per-level timeline of the last dataflow launch
   DevBuf<unsigned long long> flow_prof;
   bool flow_prof_on = false;
@@ -183,7 +183,9 @@ struct jxlh_ctx {
   DevBuf<int> strip_flags;
   bool strip_all_closed = true, strip_ran = false;
   int cu_count = 0;
+  int strip_resident = 0;  // strip_resident_workgroups(cu_count), 0 = not asked yet
   // jxlh_ctx_mark / jxlh_ctx_wait_mark: a ring of events on the main stream
+  hipEvent_t handover = nullptr;  // jxlh_ctx_wait_stream: recorded on the caller's stream
   hipEvent_t marks[JXLH_MAX_MARKS] = {};
   uint32_t mark_seq = 0;
   // profiling

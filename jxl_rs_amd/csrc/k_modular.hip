@@ -1200,6 +1200,11 @@ __device__ __forceinline__ void unsqueeze_tiled_lines(const TiledLines& T, int32
         }
       }
       pk_idx = -1;
+      // nothing the compiler places behind this point may move in front of the reads of the progress word above -- on the
+      // path that saw the producer ahead through the peeked word as well as on the spinning one (the
+      // hardware side: the word's value has returned before it is compared, and the data was acknowledged at the
+      // coherence point before the producer raised the word)
+      __atomic_signal_fence(__ATOMIC_SEQ_CST);
     }
   };
   // ... and report: `done` output samples of every line of the group are stored AND acknowledged (the caller's wave

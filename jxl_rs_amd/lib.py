@@ -55,6 +55,7 @@ ABI_SYMBOLS = [
     "jxlh_comm_init_local", "jxlh_comm_destroy", "jxlh_comm_band", "jxlh_frame_run_sharded", "jxlh_frame_allgather",
     "jxlh_frames_run_sharded_local", "jxlh_frames_allgather_local", "jxlh_comm_allgather",
     "jxlh_frame_rerender_groups", "jxlh_comm_allgather_local", "jxlh_palette_strided", "jxlh_modular_frame_filters",
+    "jxlh_ctx_wait_stream", "jxlh_ctx_wait_event", "jxlh_ctx_record_event",
     "jxlh_host_pack_slots", "jxlh_slot_writer_create", "jxlh_slot_writer_destroy", "jxlh_slot_writer_begin_group",
     "jxlh_slot_writer_begin_varblock", "jxlh_slot_writer_add", "jxlh_slot_writer_add_many", "jxlh_slot_writer_end_group",
 ]
@@ -233,6 +234,10 @@ def load():
     L.jxlh_palette_strided.argtypes = [vp, vp, sz, vp, i32, sz, i32, i32, vp, sz]
     L.jxlh_modular_frame_filters.argtypes = [vp, C.POINTER(FrameParams), C.POINTER(vp), C.POINTER(vp), u32, u32, sz]
     # host side of the slot-bucketed form (csrc/host_pack.hip): plain CPU code, no context
+    if hasattr(L, "jxlh_ctx_wait_stream"):
+        L.jxlh_ctx_wait_stream.argtypes = [vp, vp]
+        L.jxlh_ctx_wait_event.argtypes = [vp, vp]
+        L.jxlh_ctx_record_event.argtypes = [vp, vp]
     if hasattr(L, "jxlh_host_pack_slots"):  # absent from older builds used in A/B runs (JXLH_LIBRARY)
         L.jxlh_host_pack_slots.argtypes = [vp, u32, u32, vp, sz, vp, vp, vp, u32, C.POINTER(u32)]
         L.jxlh_slot_writer_create.argtypes = [C.POINTER(vp)]
@@ -644,6 +649,17 @@ class Context:
     def sync(self):
         self._chk(self.L.jxlh_ctx_sync(self._ctx), "ctx_sync")
         self._keep.clear()
+
+    def wait_stream(self, hip_stream=None):
+        """jxlh_ctx_wait_stream: whatever is enqueued so far on the caller's stream (None = the NULL stream) happens before
+        what this context enqueues from now on (device-side; the hand-over of caller-filled device buffers)"""
+        self._chk(self.L.jxlh_ctx_wait_stream(self._ctx, hip_stream), "ctx_wait_stream")
+
+    def wait_event(self, hip_event):
+        self._chk(self.L.jxlh_ctx_wait_event(self._ctx, hip_event), "ctx_wait_event")
+
+    def record_event(self, hip_event):
+        self._chk(self.L.jxlh_ctx_record_event(self._ctx, hip_event), "ctx_record_event")
 
     def mark(self):
         """a point in the main stream (jxlh_ctx_mark): everything enqueued so far"""
