@@ -702,6 +702,37 @@ def main():
             s_wall = time.perf_counter() - t0
             barrier()
             s_wall = max_over_ranks(s_wall)
+            # ---- the second strong form (round 6): gather the CONVERTED image (interleaved 8-bit sRGB, a quarter of the
+            # bytes) instead of the f32 planes -- jxlh_frame_allgather_output
+            o_wall = None
+            try:
+                from jxl_rs_amd.lib import DeviceArray
+                kk = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_kat.json")))["output_stage"]
+                bias = np.float32(kk["opsin_bias"])
+                xyb_params = np.concatenate([np.asarray(kk["opsin_inverse_matrix"], np.float32),
+                                             np.full(3, np.cbrt(bias), np.float32), np.full(3, bias, np.float32),
+                                             np.ones(1, np.float32)])
+                desc = jxl_rs_amd.Context.output_desc(xyb_params=xyb_params, bits=8, channels=3)
+                per = (ygroups + world - 1) // world
+                img = DeviceArray(nbytes=world * per * 256 * size * 3, device=local_rank)
+
+                def ostep():
+                    sctx.frame_run_sharded()
+                    sctx.frame_allgather_output(desc, img.ptr, size * 3)
+
+                for _ in range(2):
+                    ostep()
+                sctx.sync()
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    ostep()
+                sctx.sync()
+                o_wall = max_over_ranks(time.perf_counter() - t0)
+                barrier()
+                img.free()
+            except Exception as e:
+                o_wall = f"{type(e).__name__}: {e}"
             # without the gather: what the sharded compute alone costs (band K1 + exchange + filters)
             for _ in range(2):
                 sctx.frame_run_sharded()
@@ -734,6 +765,12 @@ def main():
                       "scaling": "strong", "n_gpus": world,
                       "ms_per_step_without_gather": round(c_wall * 1e3 / args.steps, 4),
                       "allgather_MB_total": round(3 * size * size * 4 / 1e6, 1),
+                      "output_gather_rgb8": ({"ms_per_step": round(o_wall * 1e3 / args.steps, 4),
+                                              "value": round(size * size / 1e6 / (o_wall / args.steps), 1), "unit": "MP/s",
+                                              "allgather_MB_total": round(3 * size * size / 1e6, 1),
+                                              "what": "the same sharded frame, bands converted to interleaved 8-bit sRGB on their "
+                                                      "rank and gathered (jxlh_frame_allgather_output)"}
+                                             if isinstance(o_wall, float) else {"error": o_wall}),
                       "halo_exchange_KB_per_edge": round(3 * 8 * swl.xblocks * 8 * 4 / 1e3, 1),
                       "band_group_rows_per_rank": (ygroups + world - 1) // world,
                       "rccl_ranks_in_communicator": int(sctx.comm_band()[1]),

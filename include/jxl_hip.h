@@ -699,6 +699,18 @@ jxlh_status jxlh_frame_run_sharded(jxlh_ctx* ctx);
 jxlh_status jxlh_frame_allgather(jxlh_ctx* ctx);
 jxlh_status jxlh_frames_run_sharded_local(jxlh_ctx* const peers[], int32_t nranks);
 jxlh_status jxlh_frames_allgather_local(jxlh_ctx* const peers[], int32_t nranks);
+/* The gather of the CONVERTED image instead of the f32 planes (round 6): every rank runs the frame's colour stage +
+ * integer conversion (jxlh_frame_read_output's stages: XybStage / FromLinearStage / ConvertF32ToU8 / U16) on the pixel
+ * rows of ITS band, writes them interleaved into `out` -- a DEVICE buffer of at least nranks * per * 256 *
+ * bytes_per_row bytes (per = the band height in group rows, jxlh_comm_band) that holds the whole image, row y at
+ * y * bytes_per_row -- and the bands are all-gathered in place: 201 MB for an 8K RGB8 image instead of the 805 MB of
+ * jxlh_frame_allgather.  Replaces jxlh_frame_allgather (call one of the two after jxlh_frame_run_sharded; same rules:
+ * all ranks, same order, work only enqueued on the context's stream).  Frames without upsampling / noise, like every
+ * sharded run. */
+jxlh_status jxlh_frame_allgather_output(jxlh_ctx* ctx, const jxlh_output_desc* d, void* out, size_t bytes_per_row);
+/* the same for an in-process group: outs[i] = rank i's image buffer */
+jxlh_status jxlh_frames_allgather_output_local(jxlh_ctx* const peers[], int32_t nranks, const jxlh_output_desc* d,
+                                               void* const outs[], size_t bytes_per_row);
 /* In-place all-gather of a device buffer of nranks * bytes_per_rank bytes (rank r's part at r * bytes_per_rank), on the
  * context's stream: the join of band-sharded Modular work (RCT / Palette on row bands of whole planes). */
 jxlh_status jxlh_comm_allgather(jxlh_ctx* ctx, void* buf, size_t bytes_per_rank);

@@ -194,6 +194,16 @@ jxlh_status read_output(jxlh_ctx* ctx, const jxlh_output_desc* d, uint32_t y0, u
 }
 }  // namespace
 
+}  // extern "C"
+// comm.hip: a rank's band of the converted image into its rows of `out` (device memory), queued on the context's stream
+jxlh_status jxlh_host::convert_band_to_output(jxlh_ctx* ctx, const jxlh_output_desc* d, uint32_t y0, uint32_t y1, void* out,
+                                   size_t bytes_per_row) {
+  if (y0 >= y1) return JXLH_OK;
+  if (!is_device_ptr(out)) return JXLH_ERR_INVALID_ARGUMENT;
+  return read_output(ctx, d, y0, y1, static_cast<char*>(out) + (size_t)y0 * bytes_per_row, bytes_per_row, /*wait=*/false);
+}
+
+extern "C" {
 jxlh_status jxlh_frame_read_output(jxlh_ctx* ctx, const jxlh_output_desc* d, uint32_t y0, uint32_t y1, void* out,
                                    size_t bytes_per_row) {
   JXLH_ON_DEVICE(ctx);

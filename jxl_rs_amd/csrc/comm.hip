@@ -408,6 +408,76 @@ jxlh_status jxlh_frame_allgather(jxlh_ctx* ctx) {
   return JXLH_OK;
 }
 
+// where a band run left the finished planes + the geometry the read-out stages use
+static void set_band_result(jxlh_ctx* ctx) {
+  const FrameDev& f = ctx->fd;
+  for (int ch = 0; ch < 3; ch++) ctx->result[ch] = result_in_tmp(ctx) ? f.tmp[ch] : f.planes[ch];
+  ctx->res_w = f.xsize;
+  ctx->res_h = f.ysize;
+  ctx->res_stride = f.plane_stride;
+}
+
+jxlh_status jxlh_frame_allgather_output(jxlh_ctx* ctx, const jxlh_output_desc* d, void* out, size_t bytes_per_row) {
+  JXLH_ON_DEVICE(ctx);
+  if (!ctx || !d || !out) return JXLH_ERR_INVALID_ARGUMENT;
+  if (!ctx->comm || !ctx->comm->nccl || !ctx->in_frame) return JXLH_ERR_BAD_STATE;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  Comm* c = ctx->comm;
+  RcclApi* api = rccl_api(nullptr);
+  const FrameDev& f = ctx->fd;
+  if (bytes_per_row < (size_t)f.xsize * d->channels * (d->bits / 8)) return JXLH_ERR_INVALID_ARGUMENT;
+  set_band_result(ctx);
+  int r0, r1;
+  band_of(f.ygroups, c->nranks, c->rank, &r0, &r1);
+  if (jxlh_status st = convert_band_to_output(ctx, d, (uint32_t)std::min(r0 * kGroupDim, f.ysize),
+                                              (uint32_t)std::min(r1 * kGroupDim, f.ysize), out, bytes_per_row))
+    return st;
+  const size_t count = (size_t)comm_rows_per_rank(ctx, f.ygroups) * kGroupDim * bytes_per_row;
+  c->last_op = "ncclAllGather of the converted image (" + std::to_string(count) + " bytes per rank)";
+  NCCLCHK(ctx, api, api->AllGather(static_cast<char*>(out) + (size_t)c->rank * count, out, count, ncclUint8, c->nccl, ctx->stream));
+  return JXLH_OK;
+}
+
+jxlh_status jxlh_frames_allgather_output_local(jxlh_ctx* const peers[], int32_t n, const jxlh_output_desc* d,
+                                               void* const outs[], size_t bytes_per_row) {
+  if (!peers || !outs || !d || n < 1) return JXLH_ERR_INVALID_ARGUMENT;
+  for (int i = 0; i < n; i++)
+    if (!peers[i] || !outs[i] || !peers[i]->comm || peers[i]->comm->nccl || peers[i]->comm->nranks != n || !peers[i]->in_frame)
+      return JXLH_ERR_BAD_STATE;
+  // every rank converts its band into its own image buffer ...
+  for (int i = 0; i < n; i++) {
+    jxlh_ctx* c = peers[i];
+    HIPCHK(c, hipSetDevice(c->device));
+    const FrameDev& f = c->fd;
+    if (bytes_per_row < (size_t)f.xsize * d->channels * (d->bits / 8)) return JXLH_ERR_INVALID_ARGUMENT;
+    set_band_result(c);
+    int r0, r1;
+    band_of(f.ygroups, n, i, &r0, &r1);
+    if (jxlh_status st = convert_band_to_output(c, d, (uint32_t)std::min(r0 * kGroupDim, f.ysize),
+                                                (uint32_t)std::min(r1 * kGroupDim, f.ysize), outs[i], bytes_per_row))
+      return st;
+    HIPCHK(c, hipEventRecord(c->comm->done_ev, c->stream));
+  }
+  // ... and pulls the other ranks' bands
+  for (int i = 0; i < n; i++) {
+    jxlh_ctx* dst = peers[i];
+    HIPCHK(dst, hipSetDevice(dst->device));
+    const FrameDev& f = dst->fd;
+    for (int k = 0; k < n; k++) {
+      if (k == i) continue;
+      int r0, r1;
+      band_of(f.ygroups, n, k, &r0, &r1);
+      const size_t y0 = (size_t)std::min(r0 * kGroupDim, f.ysize), y1 = (size_t)std::min(r1 * kGroupDim, f.ysize);
+      if (y0 >= y1) continue;
+      HIPCHK(dst, hipStreamWaitEvent(dst->stream, peers[k]->comm->done_ev, 0));
+      HIPCHK(dst, hipMemcpyAsync(static_cast<char*>(outs[i]) + y0 * bytes_per_row,
+                                 static_cast<const char*>(outs[k]) + y0 * bytes_per_row, (y1 - y0) * bytes_per_row,
+                                 hipMemcpyDefault, dst->stream));
+    }
+  }
+  return JXLH_OK;
+}
+
 jxlh_status jxlh_comm_allgather(jxlh_ctx* ctx, void* buf, size_t bytes_per_rank) {
   JXLH_ON_DEVICE(ctx);
   if (!ctx || !buf) return JXLH_ERR_INVALID_ARGUMENT;

@@ -332,6 +332,9 @@ jxlh_status stage_in(jxlh_ctx* ctx, DevBuf<T>& b, const T* src, size_t n) {
   HIPCHK(ctx, hipMemcpyAsync(b.p, src, n * sizeof(T), hipMemcpyDefault, ctx->stream));
   return JXLH_OK;
 }
+// abi_output.hip
+jxlh_status convert_band_to_output(jxlh_ctx* ctx, const jxlh_output_desc* d, uint32_t y0, uint32_t y1, void* out,
+                                   size_t bytes_per_row);
 // comm.hip
 void comm_release(jxlh_ctx* ctx);
 int comm_nranks(const jxlh_ctx* ctx);

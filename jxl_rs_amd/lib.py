@@ -56,6 +56,7 @@ ABI_SYMBOLS = [
     "jxlh_frames_run_sharded_local", "jxlh_frames_allgather_local", "jxlh_comm_allgather",
     "jxlh_frame_rerender_groups", "jxlh_comm_allgather_local", "jxlh_palette_strided", "jxlh_modular_frame_filters",
     "jxlh_ctx_wait_stream", "jxlh_ctx_wait_event", "jxlh_ctx_record_event",
+    "jxlh_frame_allgather_output", "jxlh_frames_allgather_output_local",
     "jxlh_host_pack_slots", "jxlh_slot_writer_create", "jxlh_slot_writer_destroy", "jxlh_slot_writer_begin_group",
     "jxlh_slot_writer_begin_varblock", "jxlh_slot_writer_add", "jxlh_slot_writer_add_many", "jxlh_slot_writer_end_group",
 ]
@@ -234,6 +235,9 @@ def load():
     L.jxlh_palette_strided.argtypes = [vp, vp, sz, vp, i32, sz, i32, i32, vp, sz]
     L.jxlh_modular_frame_filters.argtypes = [vp, C.POINTER(FrameParams), C.POINTER(vp), C.POINTER(vp), u32, u32, sz]
     # host side of the slot-bucketed form (csrc/host_pack.hip): plain CPU code, no context
+    if hasattr(L, "jxlh_frame_allgather_output"):
+        L.jxlh_frame_allgather_output.argtypes = [vp, C.POINTER(OutputDesc), vp, sz]
+        L.jxlh_frames_allgather_output_local.argtypes = [C.POINTER(vp), i32, C.POINTER(OutputDesc), C.POINTER(vp), sz]
     if hasattr(L, "jxlh_ctx_wait_stream"):
         L.jxlh_ctx_wait_stream.argtypes = [vp, vp]
         L.jxlh_ctx_wait_event.argtypes = [vp, vp]
@@ -357,6 +361,14 @@ def frames_run_sharded_local(ctxs):
     st = ctxs[0].L.jxlh_frames_run_sharded_local(_ctx_array(ctxs), len(ctxs))
     if st != OK:
         raise JxlHipError(st, "jxlh_frames_run_sharded_local", ctxs[0].L.jxlh_last_error(ctxs[0]._ctx).decode())
+
+
+def frames_allgather_output_local(ctxs, desc, out_ptrs, bytes_per_row):
+    arr = _ctx_array(ctxs)
+    outs = (C.c_void_p * len(ctxs))(*out_ptrs)
+    st = load().jxlh_frames_allgather_output_local(arr, len(ctxs), C.byref(desc), outs, bytes_per_row)
+    if st != 0:
+        raise JxlHipError(st, "frames_allgather_output_local")
 
 
 def frames_allgather_local(ctxs):
@@ -793,9 +805,9 @@ class Context:
                                                self.out_size[0] * channels * 2), "frame_read_rgb16")
         return arr
 
-    def read_output(self, color=COLOR_XYB, transfer="srgb", xyb_params=None, tf_param=0.0, lum=(0.2627, 0.678, 0.0593),
-                    bits=8, channels=3, y0=0, y1=None):
-        """jxlh_frame_read_output: interleaved 8- or 16-bit samples after the frame's colour stage"""
+    @staticmethod
+    def output_desc(color=COLOR_XYB, transfer="srgb", xyb_params=None, tf_param=0.0, lum=(0.2627, 0.678, 0.0593), bits=8,
+                    channels=3):
         d = OutputDesc()
         d.color, d.transfer, d.bits, d.channels, d.tf_param = color, TF[transfer], bits, channels, tf_param
         if xyb_params is not None:
@@ -803,6 +815,16 @@ class Context:
                 d.xyb[i] = float(v)
         for i in range(3):
             d.hlg_luminance_rgb[i] = lum[i]
+        return d
+
+    def frame_allgather_output(self, desc, out_ptr, bytes_per_row):
+        """jxlh_frame_allgather_output: this rank's band converted into the device image at out_ptr, bands all-gathered"""
+        self._chk(self.L.jxlh_frame_allgather_output(self._ctx, C.byref(desc), out_ptr, bytes_per_row), "frame_allgather_output")
+
+    def read_output(self, color=COLOR_XYB, transfer="srgb", xyb_params=None, tf_param=0.0, lum=(0.2627, 0.678, 0.0593),
+                    bits=8, channels=3, y0=0, y1=None):
+        """jxlh_frame_read_output: interleaved 8- or 16-bit samples after the frame's colour stage"""
+        d = self.output_desc(color, transfer, xyb_params, tf_param, lum, bits, channels)
         w, h = self.out_size
         y1 = h if y1 is None else y1
         arr = np.zeros((y1 - y0, w, channels), dtype=np.uint8 if bits == 8 else np.uint16)

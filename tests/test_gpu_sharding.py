@@ -309,3 +309,71 @@ def test_rct_and_palette_on_unaligned_device_subranges(oracle):
         for b in bufs:
             b.free()
         ctx.close()
+
+
+def _xyb_params(oracle):
+    import json
+    import os
+    k = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_kat.json")))["output_stage"]
+    return oracle.xyb_params(k["opsin_inverse_matrix"], [k["opsin_bias"]] * 3, 255.0)
+
+
+@pytest.mark.parametrize("n,bits,channels", [(2, 8, 3), (3, 16, 4), (6, 8, 4)])
+def test_local_sharded_output_gather(oracle, n, bits, channels):
+    """jxlh_frames_allgather_output_local (round 6): every rank converts ITS band to interleaved 8 / 16-bit sRGB and the
+    bands are gathered -- a quarter of the bytes of the f32 plane gather.  Every rank's image == the oracle's conversion
+    of the oracle's whole frame, byte for byte."""
+    import jxl_rs_amd
+    from jxl_rs_amd import lib, synth
+    from jxl_rs_amd.lib import DeviceArray
+    wl = synth.make_vardct(520, 1000, mix=synth.MIX_ALL, seed=77 + n, epf_iters=2)
+    want_planes, _ = run_oracle_frame(oracle, wl)
+    xp = _xyb_params(oracle)
+    want = (oracle.xyb_to_rgb8 if bits == 8 else oracle.xyb_to_rgb16)(xp, want_planes, wl.xsize, wl.ysize, channels)
+    bpr = wl.xsize * channels * (bits // 8)
+    ctxs = [jxl_rs_amd.Context(0, 1) for _ in range(n)]
+    per = -(-wl.ygroups // n)
+    bufs = [DeviceArray(nbytes=n * per * 256 * bpr, device=0) for _ in range(n)]
+    try:
+        lib.comm_init_local(ctxs)
+        for r, c in enumerate(ctxs):
+            upload_band(c, wl, band_groups(wl, r, n))
+        desc = jxl_rs_amd.Context.output_desc(xyb_params=xp, bits=bits, channels=channels)
+        for rep in range(2):
+            lib.frames_run_sharded_local(ctxs)
+            lib.frames_allgather_output_local(ctxs, desc, [b.ptr for b in bufs], bpr)
+            for r, c in enumerate(ctxs):
+                c.sync()
+                got = bufs[r].download(np.uint8 if bits == 8 else np.uint16, wl.ysize * wl.xsize * channels)
+                assert np.array_equal(got.reshape(want.shape), want), f"rank {r}, rep {rep}"
+    finally:
+        for b in bufs:
+            b.free()
+        for c in ctxs:
+            c.close()
+
+
+def test_rccl_output_gather_single_rank(oracle):
+    """the same through the library's RCCL communicator (one rank: what a 1-GPU box can run)"""
+    import jxl_rs_amd
+    from jxl_rs_amd import lib, synth
+    from jxl_rs_amd.lib import DeviceArray
+    wl = synth.make_vardct(520, 600, mix=synth.MIX_D1, seed=18, epf_iters=2)
+    want_planes, _ = run_oracle_frame(oracle, wl)
+    xp = _xyb_params(oracle)
+    want = oracle.xyb_to_rgb8(xp, want_planes, wl.xsize, wl.ysize, 3)
+    bpr = wl.xsize * 3
+    c = jxl_rs_amd.Context(0, 1)
+    buf = DeviceArray(nbytes=wl.ygroups * 256 * bpr, device=0)
+    try:
+        c.comm_init(lib.comm_unique_id(), 0, 1)
+        upload_band(c, wl, set(range(wl.coeffs.shape[0])))
+        c.frame_run_sharded()
+        c.frame_allgather_output(jxl_rs_amd.Context.output_desc(xyb_params=xp), buf.ptr, bpr)
+        c.sync()
+        got = buf.download(np.uint8, wl.ysize * bpr).reshape(want.shape)
+        assert np.array_equal(got, want)
+        c.comm_destroy()
+    finally:
+        buf.free()
+        c.close()
