@@ -49,6 +49,27 @@
 #ifndef JXLH_FUSED_THREADS_LOW
 #define JXLH_FUSED_THREADS_LOW 256
 #endif
+// Tiles per workgroup of the low geometry.  > 1: a workgroup walks a column strip and keeps the 2 * border input rows two
+// consecutive tiles share in LDS (each input row fetched once, like the reference's ring buffers) -- built and measured
+// in round 6 and SLOWER: 0.36 (1) / 0.42 (3) / 0.48 (6) / 0.55 ms (12) on the 8K spec population: the kernel lives on
+// six short workgroups per CU in different phases (load, stages, store); a strip serialises those phases inside a
+// workgroup, needs 6 KB more LDS (five per CU) and 96 VGPRs, and lengthens the launch's tail
+// (profiles/r06_e_filter_strips.txt).  Kept as a build option; the halo traffic is attacked through the L2 instead
+// (JXLH_FUSED_BAND).
+#ifndef JXLH_FUSED_CHUNKS
+#define JXLH_FUSED_CHUNKS 1
+#endif
+// Tile rows of an XCD's band in the blockIdx -> tile map (1 = an XCD walks along one tile row: rounds 1-5).  > 1 puts
+// vertically adjacent tiles on the same XCD, walked column by column, so that the halo ROWS (a third of a 24-row tile's
+// fetches) can hit in that XCD's L2 -- also built in round 6 and also slower: 0.363 (1) / 0.379 (2) / 0.395 (4) / 0.433
+// (8) / 0.449 ms (16): the row walk streams the planes through memory in address order, the column walk strides by
+// 256 KB (profiles/r06_e_filter_bands.txt).
+#ifndef JXLH_FUSED_BAND
+#define JXLH_FUSED_BAND 1
+#endif
+#ifndef JXLH_FUSED_STRIP_WPE
+#define JXLH_FUSED_STRIP_WPE 5  // the strip form's 32 KB of LDS allow five workgroups per CU
+#endif
 #ifndef JXLH_FUSED_WAVES_PER_EU
 #define JXLH_FUSED_WAVES_PER_EU 6
 #endif
@@ -218,11 +239,13 @@ int launch_fused_filters(hipStream_t s, const FrameDev& f, int y0, int y1) {
     tall::launch_variant<false, false, true, true>(s, a);
     return 2;
   }
-  if (gab && e1 && e2) low::launch_variant<true, false, true, true>(s, a);
-  else if (gab && e1) low::launch_variant<true, false, true, false>(s, a);
+  // (the low tile as column strips of JXLH_FUSED_CHUNKS tiles whose shared input rows stay in LDS: round 6)
+  constexpr int NC = JXLH_FUSED_CHUNKS;
+  if (gab && e1 && e2) low::launch_variant<true, false, true, true, NC>(s, a);
+  else if (gab && e1) low::launch_variant<true, false, true, false, NC>(s, a);
   else if (gab) tall::launch_variant<true, false, false, false>(s, a);
-  else if (e1 && e2) low::launch_variant<false, false, true, true>(s, a);
-  else low::launch_variant<false, false, true, false>(s, a);
+  else if (e1 && e2) low::launch_variant<false, false, true, true, NC>(s, a);
+  else low::launch_variant<false, false, true, false, NC>(s, a);
   return 1;
 }
 
