@@ -1078,6 +1078,9 @@ __global__ __launch_bounds__(kThreads, SPARSE == 3 ? (INLINE ? JXLH_K1_INLINE_WP
 // of a batch ahead of the coefficients (through an LDS scratch) measured flat as well
 // exclusive slot-count prefixes of a batch's varblocks (entries form): NB * (N / 64) words, at most 40 (8 x 32)
 constexpr int kExclWords = 40;
+#ifndef JXLH_K1_MERGED
+#define JXLH_K1_MERGED 1  // dense slabs, big frames: every DCT class in ONE launch (k1_dct16_32<0, false, true>)
+#endif
 #ifndef JXLH_K1_DIRECT_WPE
 #define JXLH_K1_DIRECT_WPE 3  // waves per SIMD the direct form of k1_dct16_32 is compiled for
 #endif
@@ -1090,9 +1093,10 @@ constexpr int kDyWords = 32 * 64;  // S::E * 64 for the shapes with a 32-point s
 // whole list.  Usually a handful of batches (a workgroup reads a few words of flags per class and leaves); on content
 // denser than d1 it is the main route of the 16..32-point classes.  (Round 5's fallback kernel dispatched one mixed list through a switch over the nine
 // bodies: 203 spilled VGPRs, 792 bytes of scratch per lane.)
-template <int SPARSE, bool FB = false>
+template <int SPARSE, bool FB = false, bool ALL = false>
 __global__ __launch_bounds__(kThreads, SPARSE == 3 ? JXLH_K1_DIRECT_WPE : SPARSE == 2 ? 2 : 3) void k1_dct16_32(const FrameDev f, const WorkLists wl) {
   static_assert(!FB || SPARSE == 2, "the fallback launch runs the dense dequantisation pass of the entries form");
+  static_assert(!ALL || SPARSE == 0, "one launch for every DCT class: dense slabs only");
   if constexpr (FB) {
     // nothing was left by the direct kernels (the usual case on d1 content): the classes' summary words say so in one
     // memory round trip, before anything else of the workgroup is set up
@@ -1143,6 +1147,10 @@ __global__ __launch_bounds__(kThreads, SPARSE == 3 ? JXLH_K1_DIRECT_WPE : SPARSE
   run(ShapeTag<S8x16>{}, std::true_type{}, std::integral_constant<int, kClsDct8x16>{}, 7);
   // (the 8x8 class: only when its kernel ran without the inline fallback; the list stays empty otherwise)
   if constexpr (FB) run(ShapeTag<S8x8>{}, std::true_type{}, std::integral_constant<int, kClsDct8>{}, 0);
+  // ALL (dense slabs, frames of 512 groups and more): the 8x8 class too -- K1 as one launch after the scan: 0.388 ->
+  // 0.382 ms at 8192^2 (a kernel boundary less; the 8x8 batches fill the long classes' tail), 0.121 -> 0.128 at 4096^2
+  // (which keeps the two launches): profiles/r06_f_k1_merged.txt
+  if constexpr (ALL) run(ShapeTag<S8x8>{}, std::true_type{}, std::integral_constant<int, kClsDct8>{}, 0);
 }
 
 // family D: the nine 8x8 special transform types (IDENTITY, DCT2X2, DCT4X4, DCT4X8, DCT8X4, AFV0-3).
@@ -1460,8 +1468,12 @@ void launch_vardct_groups(hipStream_t s, const FrameDev& f_in, int group_row0, i
       hipLaunchKernelGGL(k1_dct8<1>, g8, dim3(kThreads), 0, s, f, wl);
       hipLaunchKernelGGL(k1_dct16_32<1>, g1632, dim3(kThreads), 0, s, f, wl);
     } else {
-      hipLaunchKernelGGL(k1_dct8<0>, g8, dim3(kThreads), 0, s, f, wl);
-      hipLaunchKernelGGL(k1_dct16_32<0>, g1632, dim3(kThreads), 0, s, f, wl);
+      if (JXLH_K1_MERGED && ngroups >= 512) {
+        hipLaunchKernelGGL((k1_dct16_32<0, false, true>), dim3(std::min(8192u, g8.x + g1632.x)), dim3(kThreads), 0, s, f, wl);
+      } else {
+        hipLaunchKernelGGL(k1_dct8<0>, g8, dim3(kThreads), 0, s, f, wl);
+        hipLaunchKernelGGL(k1_dct16_32<0>, g1632, dim3(kThreads), 0, s, f, wl);
+      }
     }
   }
   // what the direct form of k1_dct16_32 left (usually next to nothing: the workgroups read one counter and leave)
