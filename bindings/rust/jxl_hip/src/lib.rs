@@ -306,3 +306,54 @@ impl<'a> VarDctFrame<'a> {
         })
     }
 }
+
+/// The slot-bucketed coefficient form written by the entropy loop itself (`jxlh_slot_writer_*`, include/jxl_hip.h):
+/// `current_coeffs[coeff_index] += coeff` of `decode_vardct_group` (jxl/src/frame/group.rs:557-575) becomes `add`, a
+/// varblock's start (`coeffs_offset`, `cx * cy`: group.rs:612) `begin_varblock`.  One writer per runner thread.  Values
+/// beyond the entry's range are split into repeated in-range entries (they add up on the device); only what no slot can
+/// hold lands in `wide`.  Plain CPU code: no context, no device.
+pub struct SlotWriter {
+    raw: *mut sys::jxlh_slot_writer,
+}
+// SAFETY: a writer is used by one thread at a time (it holds no thread-affine state)
+unsafe impl Send for SlotWriter {}
+
+impl SlotWriter {
+    pub fn new() -> Result<Self> {
+        let mut raw = std::ptr::null_mut();
+        check(std::ptr::null(), unsafe { sys::jxlh_slot_writer_create(&mut raw) })?;
+        Ok(Self { raw })
+    }
+    /// `entries` (u16 each; room for the group's updates incl. split values), `slot_counts` (3 x 1024, zeroed by the
+    /// call) and `wide` are the buffers `jxlh_submit_groups_slots` will read -- typically slices of pinned memory.
+    pub fn begin_group(&mut self, group_id: u32, entries: &mut [u16], slot_counts: &mut [u8; 3 * 1024],
+                       wide: &mut [sys::jxlh_coeff32]) -> Result<()> {
+        check(std::ptr::null(), unsafe {
+            sys::jxlh_slot_writer_begin_group(self.raw, group_id, 0, entries.as_mut_ptr() as *mut c_void, entries.len(),
+                                              slot_counts.as_mut_ptr(), wide.as_mut_ptr(), wide.len() as u32)
+        })
+    }
+    /// `first_slot` = `coeffs_offset / 64`, `num_slots` = `cx * cy`; varblocks in decode order
+    pub fn begin_varblock(&mut self, first_slot: u32, num_slots: u32) -> Result<()> {
+        check(std::ptr::null(), unsafe { sys::jxlh_slot_writer_begin_varblock(self.raw, first_slot, num_slots) })
+    }
+    /// `coeffs[channel][coeffs_offset + pos] += value`
+    #[inline]
+    pub fn add(&mut self, channel: u32, pos: u32, value: i32) -> Result<()> {
+        check(std::ptr::null(), unsafe { sys::jxlh_slot_writer_add(self.raw, channel, pos, value) })
+    }
+    /// closes the group: entries per channel (the `n` of `jxlh_submit_groups_slots`) and the number of `wide` values
+    pub fn end_group(&mut self) -> Result<([u32; 3], u32)> {
+        let mut n = [0u32; 3];
+        let mut nw = 0u32;
+        check(std::ptr::null(), unsafe { sys::jxlh_slot_writer_end_group(self.raw, n.as_mut_ptr(), &mut nw) })?;
+        Ok((n, nw))
+    }
+}
+
+impl Drop for SlotWriter {
+    fn drop(&mut self) {
+        // SAFETY: created by jxlh_slot_writer_create, destroyed once
+        unsafe { sys::jxlh_slot_writer_destroy(self.raw) }
+    }
+}

@@ -690,7 +690,7 @@ jxlh_status run_prologue(jxlh_ctx* ctx, RunPlan* plan) {
         }
       }
       // (the group list is read by the sort and by the expansion: a frame that arrived slot-bucketed needs neither)
-      if (ng && !all_bucketed)
+      if (ng && !all_bucketed && !mixed)  // (mixed: only the routed groups' descriptors, below)
         HIPCHK(ctx, hipMemcpyAsync(ctx->sp_groups_dev.p, ctx->sp_upload.data(), ng * sizeof(SparseGroup),
                                    hipMemcpyHostToDevice, ctx->stream));
       if (nw)
@@ -721,13 +721,16 @@ jxlh_status run_prologue(jxlh_ctx* ctx, RunPlan* plan) {
         // groups' entries become pair words at their reserved places of the pair buffer and take the general route
         if (jxlh_status st = ensure(ctx, ctx->bucketed_dev, ctx->ngroups)) return st;
         ctx->bucketed_upload = ctx->bucketed;  // stays alive until the next epoch: the copy reads it
-        if (mixed)  // only the bucketed groups that leave the in-place form
-          for (size_t g = 0; g < ctx->ngroups; g++) ctx->bucketed_upload[g] = ctx->bucketed[g] && route[g];
-        HIPCHK(ctx, hipMemcpyAsync(ctx->bucketed_dev.p, ctx->bucketed_upload.data(), ctx->ngroups, hipMemcpyHostToDevice,
-                                   ctx->stream));
-        ScopedKernelTimer t(ctx, "k_entries_to_pairs");
-        launch_entries_to_pairs(ctx->stream, ctx->se_entries[pend].p, ctx->se_counts[pend].p, ctx->se_runs[pend].p,
-                                ctx->bucketed_dev.p, (int)ctx->ngroups, ctx->sp_pairs.p);
+        bool any_widened = !mixed;
+        if (mixed)  // only the bucketed groups that leave the in-place form (often none: the routed group is a dense slab)
+          for (size_t g = 0; g < ctx->ngroups; g++) any_widened |= (ctx->bucketed_upload[g] = ctx->bucketed[g] && route[g]) != 0;
+        if (any_widened) {
+          HIPCHK(ctx, hipMemcpyAsync(ctx->bucketed_dev.p, ctx->bucketed_upload.data(), ctx->ngroups, hipMemcpyHostToDevice,
+                                     ctx->stream));
+          ScopedKernelTimer t(ctx, "k_entries_to_pairs");
+          launch_entries_to_pairs(ctx->stream, ctx->se_entries[pend].p, ctx->se_counts[pend].p, ctx->se_runs[pend].p,
+                                  ctx->bucketed_dev.p, (int)ctx->ngroups, ctx->sp_pairs.p);
+        }
       }
       if (all_bucketed || mixed) {
         // entries per coefficient of the groups that are read in place: from about three times d1's share (0.086 on the
@@ -753,10 +756,18 @@ jxlh_status run_prologue(jxlh_ctx* ctx, RunPlan* plan) {
         if (jxlh_status st = ensure(ctx, ctx->route_dev, ctx->ngroups)) return st;
         ctx->route_upload = route;  // stays alive until the next epoch: the copy reads it
         HIPCHK(ctx, hipMemcpyAsync(ctx->route_dev.p, ctx->route_upload.data(), ctx->ngroups, hipMemcpyHostToDevice, ctx->stream));
-        {
+        // (only the routed groups that arrived as pairs / entries have anything to expand: their descriptors are moved to
+        // the front of the list -- a frame whose only routed group is a dense slab launches nothing here)
+        size_t n_expand = 0;
+        for (size_t i = 0; i < ng; i++)
+          if (route[ctx->sp_upload[i].group]) std::swap(ctx->sp_upload[n_expand++], ctx->sp_upload[i]);
+        if (n_expand)
+          HIPCHK(ctx, hipMemcpyAsync(ctx->sp_groups_dev.p, ctx->sp_upload.data(), n_expand * sizeof(SparseGroup),
+                                     hipMemcpyHostToDevice, ctx->stream));
+        if (n_expand || nw) {
           ScopedKernelTimer t(ctx, "k_expand_sparse");
-          launch_expand_sparse(ctx->stream, ctx->coeffs.p, ctx->sp_pairs.p, ctx->sp_groups_dev.p, (int)ng, ctx->sp_wide_dev.p,
-                               (uint32_t)nw, ctx->route_dev.p);
+          launch_expand_sparse(ctx->stream, ctx->coeffs.p, ctx->sp_pairs.p, ctx->sp_groups_dev.p, (int)n_expand,
+                               ctx->sp_wide_dev.p, (uint32_t)nw, nullptr);
         }
         ctx->se_live = pend;
         ctx->se_valid = true;

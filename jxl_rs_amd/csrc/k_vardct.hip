@@ -1494,8 +1494,9 @@ void launch_vardct_groups(hipStream_t s, const FrameDev& f_in, int group_row0, i
     if (f.subsampled) {
       hipLaunchKernelGGL((k1_dct8<0, true>), d8, dim3(kThreads), 0, s, fd, wd);
     } else {
-      hipLaunchKernelGGL(k1_dct8<0>, d8, dim3(kThreads), 0, s, fd, wd);
-      hipLaunchKernelGGL(k1_dct16_32<0>, dim3(grid_for(dblk / 2, kWaves * 8 * 2, 4096)), dim3(kThreads), 0, s, fd, wd);
+      // (one launch for every DCT class of the routed groups: the form big dense frames take)
+      hipLaunchKernelGGL((k1_dct16_32<0, false, true>), dim3(std::min(8192u, d8.x + (unsigned)grid_for(dblk / 2, kWaves * 8 * 2, 4096))),
+                         dim3(kThreads), 0, s, fd, wd);
     }
   }
   // an empty special list (the d1 mix) pays for every launched workgroup: the grid follows the list's worst case
