@@ -117,8 +117,24 @@ jxlh_status jxlh_ctx_create(int32_t device_ordinal, int32_t n_slots, jxlh_ctx** 
     if (const char* e = getenv("JXLH_STREAM_PRIORITY")) (void)sscanf(e, "%d,%d", &p.main_p, &p.slot_p);
     return p;
   }();
+  // JXLH_STREAM_CU_MASK="0x....,0x....,...": test hook -- the context's MAIN stream is created with that CU mask
+  // (hipExtStreamCreateWithCUMask; 32 CUs per word): soaks of the dataflow squeeze launch run with fewer CU slots than
+  // the launch has tickets, and with its workgroups confined to some XCDs
+  std::vector<uint32_t> cu_mask;
+  if (const char* e = getenv("JXLH_STREAM_CU_MASK")) {
+    for (const char* q = e; *q;) {
+      char* end = nullptr;
+      cu_mask.push_back((uint32_t)strtoul(q, &end, 0));
+      if (end == q) {
+        cu_mask.clear();
+        break;
+      }
+      q = *end == ',' ? end + 1 : end;
+    }
+  }
   if (hipSetDevice(device_ordinal) != hipSuccess ||
-      hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio.main_p) != hipSuccess ||
+      (cu_mask.empty() ? hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio.main_p)
+                       : hipExtStreamCreateWithCUMask(&ctx->stream, (uint32_t)cu_mask.size(), cu_mask.data())) != hipSuccess ||
       hipEventCreate(&ctx->t0) != hipSuccess || hipEventCreate(&ctx->t1) != hipSuccess) {
     delete ctx;
     return JXLH_ERR_DEVICE;
