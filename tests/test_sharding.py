@@ -78,6 +78,23 @@ def _worker(rank, world, port, out_dir):
     dist.all_gather_into_tensor(full, band)
     frame = assemble(full.view(world, 3, per * 256, wl.xsize).numpy(), wl.ygroups, world, wl.ysize)
     np.save(os.path.join(out_dir, f"rank{rank}.npy"), frame)
+    # ---- the second gather form (round 6, jxlh_frame_allgather_output): every rank converts ITS band's rows to
+    # interleaved 8-bit sRGB and the bands are gathered in place in the whole image (a quarter of the bytes)
+    import json
+    k = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_kat.json")))["output_stage"]
+    xp = o.xyb_params(k["opsin_inverse_matrix"], [k["opsin_bias"]] * 3, 255.0)
+    image = torch.zeros((world, per * 256, wl.xsize, 3), dtype=torch.uint8)
+    if y1 > y0:
+        rgb = o.xyb_to_rgb8(xp, [np.ascontiguousarray(planes[c][y0:y1, : wl.xsize]) for c in range(3)], wl.xsize, y1 - y0, 3)
+        image[rank, : y1 - y0] = torch.from_numpy(rgb.reshape(y1 - y0, wl.xsize, 3).copy())
+    mine = image[rank].clone()
+    dist.all_gather_into_tensor(image.view(world * per * 256, wl.xsize, 3), mine)
+    rows = []
+    for r in range(world):
+        a0, a1, _ = band_for_rank(wl.ygroups, r, world)
+        b0, b1 = band_pixel_rows(a0, a1, wl.ysize)
+        rows.append(image[r, : b1 - b0].numpy())
+    np.save(os.path.join(out_dir, f"rgb_rank{rank}.npy"), np.concatenate(rows))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -97,6 +114,13 @@ def test_band_sharding_with_halo_exchange_reassembles_the_frame(tmp_path, oracle
         assert got.shape == (3, 700, 300)
         for c in range(3):
             assert np.array_equal(got[c].view(np.uint32), want[c].view(np.uint32)), (r, c)
+    # the converted-image gather: every rank's image == the conversion of the whole frame
+    import json
+    k = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_kat.json")))["output_stage"]
+    xp = oracle.xyb_params(k["opsin_inverse_matrix"], [k["opsin_bias"]] * 3, 255.0)
+    want_rgb = oracle.xyb_to_rgb8(xp, want, wl.xsize, wl.ysize, 3).reshape(wl.ysize, wl.xsize, 3)
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / f"rgb_rank{r}.npy"), want_rgb), r
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -1,7 +1,7 @@
 #!/bin/bash
 # end-of-round evidence: GPU test log, default bench line, trace + counters of the default (dense) command and of the slot-resident frame
 O=gpurun_out/evidence; mkdir -p $O
-timeout 1800 python -m pytest tests -q -m gpu > $O/gpu_tests.txt 2>&1; grep -E "passed|failed" $O/gpu_tests.txt | tail -2
+timeout 1800 python -m pytest tests -q -m gpu > $O/gpu_tests.txt 2>&1; tail -3 $O/gpu_tests.txt | head -2
 ( time python bench.py > $O/bench.json 2> $O/bench.err ) 2> $O/bench_time.txt; tail -3 $O/bench_time.txt
 bash tools/gpu_profile.sh evidence_dense > $O/prof_dense.log 2>&1
 python tools/pmc_summary.py gpurun_out/prof_evidence_dense $O/dense_pmc.txt $O/dense_traffic.json > /dev/null
