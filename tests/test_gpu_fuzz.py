@@ -79,16 +79,30 @@ def _submit_rotating(ctx, synth, wl, seed):
         for g in range(ng):
             ctx.submit_group_sparse(g, *synth.to_sparse(wl.coeffs[g]))
     else:
-        parts = [synth.to_slots(wl.coeffs[g]) for g in range(ng)]
+        # round 6: alternately the numpy packer (values beyond 10 bits in `wide`: those groups are routed to their dense
+        # slabs) and the library's C packer (values split into repeated entries: the frame stays in place); every other
+        # such frame also hands one random group over as a dense slab or as plain pairs (per-group routing)
+        from jxl_rs_amd import lib as jl
+        rr = np.random.default_rng(seed)
+        c_packer = (seed // 3) % 2 == 1
+        other = int(rr.integers(0, ng)) if ng >= 2 and (seed // 6) % 2 == 1 else -1
+        slotted = [g for g in range(ng) if g != other]
+        parts = {g: (jl.host_pack_slots(wl.coeffs[g], group_id=g) if c_packer else synth.to_slots(wl.coeffs[g])) for g in slotted}
         wide = []
-        for g, q in enumerate(parts):
+        for g, q in parts.items():
             if len(q[3]):
                 e = q[3].copy()
-                e[:, 0] += np.uint32(g * 3 * 65536)
+                if not c_packer:
+                    e[:, 0] += np.uint32(g * 3 * 65536)
                 wide.append(e)
-        ctx.submit_groups_slots(np.arange(ng, dtype=np.uint32), np.concatenate([q[0] for q in parts]),
-                                np.concatenate([q[1].reshape(-1) for q in parts]), np.concatenate([q[2] for q in parts]),
-                                np.concatenate(wide) if wide else None)
+        ctx.submit_groups_slots(np.asarray(slotted, dtype=np.uint32), np.concatenate([parts[g][0] for g in slotted]),
+                                np.concatenate([parts[g][1].reshape(-1) for g in slotted]),
+                                np.concatenate([parts[g][2] for g in slotted]), np.concatenate(wide) if wide else None)
+        if other >= 0:
+            if rr.integers(0, 2):
+                ctx.submit_group(other, wl.coeffs[other])
+            else:
+                ctx.submit_group_sparse(other, *synth.to_sparse(wl.coeffs[other]))
 
 
 @pytest.mark.parametrize("seed", range(64))
