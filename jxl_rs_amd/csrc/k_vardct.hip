@@ -1079,7 +1079,12 @@ __global__ __launch_bounds__(kThreads, SPARSE == 3 ? (INLINE ? JXLH_K1_INLINE_WP
 // exclusive slot-count prefixes of a batch's varblocks (entries form): NB * (N / 64) words, at most 40 (8 x 32)
 constexpr int kExclWords = 40;
 #ifndef JXLH_K1_MERGED
-#define JXLH_K1_MERGED 1  // dense slabs, big frames: every DCT class in ONE launch (k1_dct16_32<0, false, true>)
+// Dense slabs, frames of >= 512 groups: every DCT class in ONE launch (k1_dct16_32<0, false, true>).  Built in round 6,
+// -1.7 % on K1's own time with one frame in flight on one box -- and 4-5 % SLOWER on the pipelined headline (two frames
+// in flight: 0.718 against 0.691 ms per frame; three boxes' worth of alternating runs): one long launch at three waves
+// per SIMD leaves the other frame's kernels nothing to overlap with.  Off; the one-launch form still runs the
+// dense-route lists of a routed frame (a handful of groups).  profiles/r06_f_k1_merged.txt
+#define JXLH_K1_MERGED 0
 #endif
 #ifndef JXLH_K1_DIRECT_WPE
 #define JXLH_K1_DIRECT_WPE 3  // waves per SIMD the direct form of k1_dct16_32 is compiled for
@@ -1147,9 +1152,8 @@ __global__ __launch_bounds__(kThreads, SPARSE == 3 ? JXLH_K1_DIRECT_WPE : SPARSE
   run(ShapeTag<S8x16>{}, std::true_type{}, std::integral_constant<int, kClsDct8x16>{}, 7);
   // (the 8x8 class: only when its kernel ran without the inline fallback; the list stays empty otherwise)
   if constexpr (FB) run(ShapeTag<S8x8>{}, std::true_type{}, std::integral_constant<int, kClsDct8>{}, 0);
-  // ALL (dense slabs, frames of 512 groups and more): the 8x8 class too -- K1 as one launch after the scan: 0.388 ->
-  // 0.382 ms at 8192^2 (a kernel boundary less; the 8x8 batches fill the long classes' tail), 0.121 -> 0.128 at 4096^2
-  // (which keeps the two launches): profiles/r06_f_k1_merged.txt
+  // ALL: the 8x8 class too -- every DCT class in one launch (the dense-route lists of a routed frame; as the form of
+  // whole dense frames it lost on the pipelined headline: JXLH_K1_MERGED)
   if constexpr (ALL) run(ShapeTag<S8x8>{}, std::true_type{}, std::integral_constant<int, kClsDct8>{}, 0);
 }
 
