@@ -1,6 +1,6 @@
 """Two PROCESSES, one GPU each, over the library's RCCL transport: jxlh_comm_init with a shared
 unique id, jxlh_frame_run_sharded (transforms on the own band, ncclSend / ncclRecv of the edge block rows, filters),
-jxlh_frame_allgather, and the Modular pipeline (replicated squeeze chain, RCT + palette on the rank's share, six
+jxlh_frame_allgather (and jxlh_frame_allgather_output: the converted 8-bit image), and the Modular pipeline (replicated squeeze chain, RCT + palette on the rank's share, six
 all-gathers) -- every rank must end with the oracle's whole frame bit for bit.  This is the only test in which
 ncclSend / ncclRecv meet a neighbour; it needs two visible devices and is skipped (but collected) on a one-GPU box,
 where tests/test_gpu_sharding.py covers the same band logic with the in-process transport and a one-rank communicator.
@@ -57,6 +57,21 @@ def _worker(rank, world, uid_q, res_q):
             got = c.read_planes()
             for ch in range(3):
                 assert helpers.bit_equal(got[ch], want[ch]), f"rank {rank} plane {ch} rep {rep}: {helpers.diff_report(got[ch], want[ch])}"
+        # ---- the converted-image gather (round 6): every rank's interleaved 8-bit sRGB image == the oracle's
+        import json
+        from jxl_rs_amd.lib import DeviceArray
+        k = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_kat.json")))["output_stage"]
+        xp = o.xyb_params(k["opsin_inverse_matrix"], [k["opsin_bias"]] * 3, 255.0)
+        want_rgb = o.xyb_to_rgb8(xp, want, wl.xsize, wl.ysize, 3)
+        bpr = wl.xsize * 3
+        per = -(-wl.ygroups // world)
+        img = DeviceArray(nbytes=world * per * 256 * bpr, device=rank)
+        c.frame_run_sharded()
+        c.frame_allgather_output(jxl_rs_amd.Context.output_desc(xyb_params=xp), img.ptr, bpr)
+        c.sync()
+        got_rgb = img.download(np.uint8, wl.ysize * bpr).reshape(want_rgb.shape)
+        assert np.array_equal(got_rgb, want_rgb), f"rank {rank}: converted-image gather"
+        img.free()
         c.comm_destroy()
         c.close()
         # ---- Modular: replicated chain, sharded RCT + palette, six all-gathers
