@@ -689,7 +689,8 @@ __device__ __forceinline__ int run_dct_class(const FrameDev& f, const WorkItem* 
                                              EX* __restrict__ s_excl, float* __restrict__ s_lf, int gwave,
                                              int nwaves, int lane, const AdjTable* __restrict__ adj,
                                              uint32_t* __restrict__ wl_fallback = nullptr,
-                                             int* __restrict__ fallback_count = nullptr, float* __restrict__ s_dy = nullptr) {
+                                             int* __restrict__ fallback_count = nullptr, float* __restrict__ s_dy = nullptr,
+                                             uint32_t fb_first_flag = 0) {
   constexpr int NCH = S::E / 4;  // 16-byte chunks per lane per channel
   const int q = quant_table_for_type(type);
   const float* __restrict__ table = f.tables + f.table_offset[q];
@@ -698,15 +699,17 @@ __device__ __forceinline__ int run_dct_class(const FrameDev& f, const WorkItem* 
   // The batches this wave runs.  Plain: gwave, gwave + nwaves, ...  LISTED (the fallback launch): the batches whose word
   // in wl_fallback holds this launch's epoch -- a workgroup takes chunks of kFbChunk consecutive batches (one flag per
   // lane, a ballot), its kWaves waves share a chunk's flagged batches round robin; the caller rotates the chunk -> workgroup
-  // map from class to class (gwave), so the classes' chunks spread over the whole grid.  (Round 6's first form appended batch ids to
-  // a list: one returning atomic per wave and class on one counter, 131 000 of them on a frame that leaves every batch --
-  // 0.27 ms for a launch with nothing else to do.)
-  constexpr int kFbChunk = 16;  // (64-batch chunks left most of the grid idle: 1.5 ms for 17 000 batches)
-  constexpr int kFbAny = 32, kFbAnyPitch = 32;  // summary words per class, each on its own 128-byte line
+  // map from class to class (gwave), so the classes' chunks spread over the whole grid, and hands over the flag word of
+  // the workgroup's first FOUR chunks (fb_first_flag: the kernel requests those of all classes at once when it starts, so a
+  // workgroup with nothing to do leaves after one memory round trip and one with work does not pay a round trip per
+  // class).  (Round 6's first form appended batch ids to a list: one returning atomic per wave and class on one counter,
+  // 131 000 of them on a frame that leaves every batch -- 0.27 ms for a launch with nothing else to do.)
+  constexpr int kFbChunk = 16;  // (64-batch chunks leave most of the grid idle on dense frames: K1 0.42 -> 0.57 ms at x2)
   struct BatchIter {
     int bi;                    // plain: the batch; listed: the chunk
     unsigned long long mask;   // listed: flagged batches of the chunk not yet handed out
     int rank;                  // listed: flagged batches of the chunk handed out so far (all waves count alike)
+    bool pre;                  // listed: mask = the kernel's prefetch: the workgroup's first FOUR chunks, 16 bits each
   };
   const int it_wave = gwave % kWaves, it_wg = gwave / kWaves, it_nwg = nwaves / kWaves;  // (LISTED: gwave is not rotated)
   auto iter_next = [&](BatchIter& st) -> int {  // the next batch of this wave, -1 when done
@@ -719,10 +722,12 @@ __device__ __forceinline__ int run_dct_class(const FrameDev& f, const WorkItem* 
         while (st.mask) {
           const int bit = __builtin_ctzll(st.mask);
           st.mask &= st.mask - 1;
+          const int chunk = st.pre ? st.bi + (bit >> 4) * it_nwg : st.bi;
           // (+ the chunk: a chunk with ONE flagged batch -- the usual case on d1 content -- must not always be wave 0's)
-          if ((st.rank++ + st.bi) % kWaves == it_wave) return st.bi * kFbChunk + bit;
+          if ((st.rank++ + chunk) % kWaves == it_wave) return chunk * kFbChunk + (bit & 15);
         }
-        st.bi = st.bi < 0 ? it_wg : st.bi + it_nwg;
+        st.bi += st.pre ? 4 * it_nwg : it_nwg;
+        st.pre = false;
         if (st.bi * kFbChunk >= nbatches) return -1;
         const int idx = st.bi * kFbChunk + lane;
         st.mask = __ballot(lane < kFbChunk && idx < nbatches && wl_fallback[idx] == (uint32_t)f.fb_epoch);
@@ -730,7 +735,8 @@ __device__ __forceinline__ int run_dct_class(const FrameDev& f, const WorkItem* 
       }
     }
   };
-  BatchIter iter = {LISTED ? -1 : gwave, 0ull, 0};
+  static_assert(kFbChunk == 16, "the prefetched mask holds four 16-batch chunks");
+  BatchIter iter = {LISTED ? it_wg : gwave, LISTED ? __ballot(fb_first_flag == (uint32_t)f.fb_epoch && fb_first_flag != 0) : 0ull, 0, LISTED};
   // the weights a lane needs do not depend on the batch
   constexpr bool kPF = PREFETCH && SPARSE != 3;  // (the inline fallback of mode 3 reads its weights per batch)
   float4 tw[kPF ? 3 : 1][NCH];
@@ -761,12 +767,6 @@ __device__ __forceinline__ int run_dct_class(const FrameDev& f, const WorkItem* 
     }
   }
   int n_dense_pass = 0;  // (wave-uniform) batches this wave ran through the dense pass: inline (mode 3) or listed
-  bool flagged_any = false;
-  uint32_t* __restrict__ fb_any = wl_fallback ? wl_fallback - kFbAny * kFbAnyPitch : nullptr;  // (in front of the flags)
-  if constexpr (LISTED) {
-    // nothing of this class was left by the direct kernels (the usual case): one load per wave says so
-    if (!__any(fb_any[(lane % kFbAny) * kFbAnyPitch] == (uint32_t)f.fb_epoch)) return nbatches;
-  }
   for (int batch = iter_next(iter); batch >= 0; batch = iter_next(iter)) {
     const int nb = min(S::NB, count - batch * S::NB);
     if constexpr (LISTED) n_dense_pass++;
@@ -804,13 +804,7 @@ __device__ __forceinline__ int run_dct_class(const FrameDev& f, const WorkItem* 
       if constexpr (SPARSE == 3 && !INLINE_FB) {
         // left to the fallback launch BEFORE anything of the batch is requested: its word gets the launch's epoch
         if (!__all(item_ok)) {
-          if (lane == 0) {
-            wl_fallback[batch] = (uint32_t)f.fb_epoch;
-            // ... and the class's summary (kFbAny words on their own cache lines, picked by the wave): plain stores of
-            // the same value, the first reject of a wave only
-            if (!flagged_any) fb_any[(gwave % kFbAny) * kFbAnyPitch] = (uint32_t)f.fb_epoch;
-          }
-          flagged_any = true;
+          if (lane == 0) wl_fallback[batch] = (uint32_t)f.fb_epoch;
           continue;
         }
       } else {
@@ -1102,17 +1096,31 @@ template <int SPARSE, bool FB = false, bool ALL = false>
 __global__ __launch_bounds__(kThreads, SPARSE == 3 ? JXLH_K1_DIRECT_WPE : SPARSE == 2 ? 2 : 3) void k1_dct16_32(const FrameDev f, const WorkLists wl) {
   static_assert(!FB || SPARSE == 2, "the fallback launch runs the dense dequantisation pass of the entries form");
   static_assert(!ALL || SPARSE == 0, "one launch for every DCT class: dense slabs only");
+  // FB: the flag word of this lane in the workgroup's first four chunks of every class, requested together before anything
+  // else of the workgroup is set up (order = the order the classes run in below; a class's chunk c belongs to workgroup
+  // (c + chunks of the classes before it) % grid).  Nothing flagged there and no later chunk: the workgroup leaves.
+  uint32_t fb_pre[kClsSpecial] = {};
   if constexpr (FB) {
-    // nothing was left by the direct kernels (the usual case on d1 content): the classes' summary words say so in one
-    // memory round trip, before anything else of the workgroup is set up
-    constexpr int kWords = kClsSpecial * 32;  // (run_dct_class: kFbAny summary words per class, kFbAnyPitch apart)
-    bool any = false;
+    constexpr int kOrder[kClsSpecial] = {kClsDct32x32, kClsDct32x16, kClsDct16x32, kClsDct32x8, kClsDct8x32,
+                                         kClsDct16x16, kClsDct16x8,  kClsDct8x16,  kClsDct8};
+    constexpr int kNb[kClsSpecial] = {S32x32::NB, S32x16::NB, S16x32::NB, S32x8::NB, S8x32::NB, S16x16::NB, S16x8::NB, S8x16::NB, S8x8::NB};
+    const int grid = (int)gridDim.x, l = threadIdx.x & 63;
+    int nbat[kClsSpecial];
 #pragma unroll
-    for (int i = 0; i < (kWords + 63) / 64; i++) {
-      const int w = i * 64 + (threadIdx.x & 63);
-      if (w < kWords) any |= (wl.fallback[w / 32] - 32 * 32)[(w % 32) * 32] == (uint32_t)f.fb_epoch;
+    for (int k = 0; k < kClsSpecial; k++) nbat[k] = (wl.counts[kOrder[k] * kCountPitch] + kNb[k] - 1) / kNb[k];
+    int used = 0;
+    bool more = false, any = false;
+#pragma unroll
+    for (int k = 0; k < kClsSpecial; k++) {
+      // (chunks of 16 batches: lanes 16 r .. 16 r + 15 take the workgroup's chunk of round r, fc + r * grid)
+      const int nch = (nbat[k] + 15) / 16, fc = rotate_wave((int)blockIdx.x, used, grid), idx = (fc + (l >> 4) * grid) * 16 + (l & 15);
+      fb_pre[k] = idx < nbat[k] ? wl.fallback[kOrder[k]][idx] : 0u;
+      more |= fc + 4 * grid < nch;
+      used += nch;
     }
-    if (!__any(any)) return;  // (the same words for every wave: workgroup-uniform)
+#pragma unroll
+    for (int k = 0; k < kClsSpecial; k++) any |= fb_pre[k] == (uint32_t)f.fb_epoch;
+    if (!__any(any) && !more) return;  // (every wave of the workgroup reads the same words: uniform)
   }
   __shared__ __attribute__((aligned(16))) float s_buf[kWaves * kTileC];
   __shared__ BlockInfo s_binfo[kWaves][8];
@@ -1131,7 +1139,7 @@ __global__ __launch_bounds__(kThreads, SPARSE == 3 ? JXLH_K1_DIRECT_WPE : SPARSE
   auto cnt = [&](int cls) { return wl.counts[cls * kCountPitch]; };
   // the long batches (32-point sides) first: the tail of the launch is then made of the short ones
   int used = 0;
-  auto run = [&](auto shape_tag, auto pf_tag, auto cls_tag, int type) {
+  auto run = [&](auto shape_tag, auto pf_tag, auto cls_tag, int type, int fb_k = 0) {  // fb_k: index in the FB order
     using S = typename decltype(shape_tag)::type;
     constexpr bool PF = decltype(pf_tag)::value;
     constexpr int CLS = decltype(cls_tag)::value;
@@ -1139,19 +1147,19 @@ __global__ __launch_bounds__(kThreads, SPARSE == 3 ? JXLH_K1_DIRECT_WPE : SPARSE
     const int nbat = run_dct_class<S, PF, SPARSE, false, CLS, false, FB>(
         f, wl.items[CLS], wl.eitems[CLS], cnt(CLS), type, buf, s_binfo[wave], ex, lfs,
         FB ? rotate_wave((int)blockIdx.x, used, (int)gridDim.x) * kWaves + wave : rotate_wave(gw, used, nw), nw, lane, &s_adj,
-        wl.fallback[CLS], wl.counts + (kCntFallback0 + CLS) * kCountPitch, sdy);
+        wl.fallback[CLS], wl.counts + (kCntFallback0 + CLS) * kCountPitch, sdy, FB ? fb_pre[fb_k] : 0u);
     used += FB ? (nbat + 15) / 16 : nbat;
   };
-  run(ShapeTag<S32x32>{}, std::false_type{}, std::integral_constant<int, kClsDct32x32>{}, 5);
-  run(ShapeTag<S32x16>{}, std::false_type{}, std::integral_constant<int, kClsDct32x16>{}, 10);
-  run(ShapeTag<S16x32>{}, std::false_type{}, std::integral_constant<int, kClsDct16x32>{}, 11);
-  run(ShapeTag<S32x8>{}, std::false_type{}, std::integral_constant<int, kClsDct32x8>{}, 8);
-  run(ShapeTag<S8x32>{}, std::false_type{}, std::integral_constant<int, kClsDct8x32>{}, 9);
-  run(ShapeTag<S16x16>{}, std::true_type{}, std::integral_constant<int, kClsDct16x16>{}, 4);
-  run(ShapeTag<S16x8>{}, std::true_type{}, std::integral_constant<int, kClsDct16x8>{}, 6);
-  run(ShapeTag<S8x16>{}, std::true_type{}, std::integral_constant<int, kClsDct8x16>{}, 7);
+  run(ShapeTag<S32x32>{}, std::false_type{}, std::integral_constant<int, kClsDct32x32>{}, 5, 0);
+  run(ShapeTag<S32x16>{}, std::false_type{}, std::integral_constant<int, kClsDct32x16>{}, 10, 1);
+  run(ShapeTag<S16x32>{}, std::false_type{}, std::integral_constant<int, kClsDct16x32>{}, 11, 2);
+  run(ShapeTag<S32x8>{}, std::false_type{}, std::integral_constant<int, kClsDct32x8>{}, 8, 3);
+  run(ShapeTag<S8x32>{}, std::false_type{}, std::integral_constant<int, kClsDct8x32>{}, 9, 4);
+  run(ShapeTag<S16x16>{}, std::true_type{}, std::integral_constant<int, kClsDct16x16>{}, 4, 5);
+  run(ShapeTag<S16x8>{}, std::true_type{}, std::integral_constant<int, kClsDct16x8>{}, 6, 6);
+  run(ShapeTag<S8x16>{}, std::true_type{}, std::integral_constant<int, kClsDct8x16>{}, 7, 7);
   // (the 8x8 class: only when its kernel ran without the inline fallback; the list stays empty otherwise)
-  if constexpr (FB) run(ShapeTag<S8x8>{}, std::true_type{}, std::integral_constant<int, kClsDct8>{}, 0);
+  if constexpr (FB) run(ShapeTag<S8x8>{}, std::true_type{}, std::integral_constant<int, kClsDct8>{}, 0, 8);
   // ALL: the 8x8 class too -- every DCT class in one launch (the dense-route lists of a routed frame; as the form of
   // whole dense frames it lost on the pipelined headline: JXLH_K1_MERGED)
   if constexpr (ALL) run(ShapeTag<S8x8>{}, std::true_type{}, std::integral_constant<int, kClsDct8>{}, 0);
@@ -1353,7 +1361,7 @@ size_t vardct_worklist_bytes(const FrameDev& f) {
   for (int c = 0; c < kNumClasses; c++) items += nblocks / class_min_area(c) + 1;
   for (int c = 0; c < kClsSpecial; c++) items += 2 * (nblocks / class_min_area(c) + 1);  // entry side items of the DCT
                                                                                          // classes + their dense-route lists
-  for (int c = 0; c < kClsSpecial; c++) items += nblocks / (8 * class_min_area(c)) + 4 + 256;  // the fallback flags (u32 per batch) + summaries
+  for (int c = 0; c < kClsSpecial; c++) items += nblocks / (8 * class_min_area(c)) + 4;  // the fallback flags (u32 per batch)
   // + the unit lists of the large transforms: one u32 per 4096 samples of a 256-pixel varblock (two-pass units) and
   //   one per varblock of the smaller types (three lists by slabs per channel; worst case one entry per 32 blocks)
   // + the LLF planes of the large transforms (3 x nblocks floats, k1_large_llf)
@@ -1408,7 +1416,6 @@ void launch_vardct_groups(hipStream_t s, const FrameDev& f_in, int group_row0, i
     p += (nblocks / class_min_area(c) + 1) * sizeof(WorkItem);
   }
   for (int c = 0; c < kClsSpecial; c++) {  // one word per batch of the class (at least 2 varblocks per batch)
-    p += 32 * 32 * sizeof(uint32_t);  // the class's summary words (run_dct_class: kFbAny x kFbAnyPitch), then its flags
     wl.fallback[c] = reinterpret_cast<uint32_t*>(p);
     p += (nblocks / (2 * class_min_area(c)) + 16) * sizeof(uint32_t);
   }
@@ -1483,8 +1490,10 @@ void launch_vardct_groups(hipStream_t s, const FrameDev& f_in, int group_row0, i
   // what the direct form of k1_dct16_32 left (usually next to nothing: the workgroups read one counter and leave)
   // (a sparse frame leaves a handful of batches: the workgroups read one counter and go; a frame denser than d1 gets
   // the whole chip)
+  // (the fallback as TWO launches -- the classes without a 32-point side apart: 32 KB of LDS, three waves per SIMD --
+  // measured no better on the outlier frame and 4 % worse on dense ones: profiles/r06_c_density.txt)
   if (sparse == 3)
-    hipLaunchKernelGGL((k1_dct16_32<2, true>), dim3(std::min(2048, std::max(1, nblk / 512))), dim3(kThreads), 0, s, f, wl);
+    hipLaunchKernelGGL((k1_dct16_32<2, true>), dim3(std::min(1024, std::max(1, nblk / 1024))), dim3(kThreads), 0, s, f, wl);
   // entries form, groups routed to their dense slabs (FrameDev::group_route): the same class kernels in their dense
   // form on those groups' lists; the grids follow the routed share of the frame
   if (sparse >= 2 && n_dense_route > 0) {
