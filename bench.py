@@ -286,16 +286,15 @@ def slot_content_sweep(jxl_rs_amd, synth, np, ectx, wl, size, steps, reps, cores
         c[add] = (mag * rng.choice([-1, 1], size=c.shape))[add]
         return c
 
-    def outliers(c):
+    def outlier_group(c):
+        """one coefficient of the group at +-2000 ... 30000"""
         c = c.copy()
         nz = np.flatnonzero(c.reshape(-1))
-        k = max(1, int(round(len(nz) * 1e-5 * 24)))  # 1e-5 of the FRAME's entries: each unique group is used ng / 24 times
-        sel = rng.choice(nz, size=min(k, len(nz)), replace=False)
-        c.reshape(-1)[sel] = rng.integers(2000, 30001, size=len(sel)) * rng.choice([-1, 1], size=len(sel))
+        c.reshape(-1)[rng.choice(nz)] = int(rng.integers(2000, 30001)) * int(rng.choice([-1, 1]))
         return c
 
     variants = [("d1_clean", lambda c: c, None),
-                ("outliers_1e-5_of_entries_2000_to_30000", outliers, None),
+                ("outliers_1e-5_of_entries_2000_to_30000", None, None),
                 ("density_x0.5", lambda c: densify(c, 0.5), None),
                 ("density_x2", lambda c: densify(c, 2.0), None),
                 ("density_x4", lambda c: densify(c, 4.0), None),
@@ -339,19 +338,30 @@ def slot_content_sweep(jxl_rs_amd, synth, np, ectx, wl, size, steps, reps, cores
 
     res = {}
     for name, fn, dense_group in variants:
-        var = {g: np.ascontiguousarray(fn(c), dtype=np.int32) for g, c in base.items()}
+        var = {g: np.ascontiguousarray((fn or (lambda c: c))(c), dtype=np.int32) for g, c in base.items()}
         packed = {g: jl.host_pack_slots(c, group_id=0) for g, c in var.items()}
         assert all(len(q[3]) == 0 for q in packed.values()), "the packer split every value: nothing in `wide`"
         slotted = [g for g in range(ng) if g != dense_group]
-        ents = np.concatenate([packed[which[g]][0] for g in slotted])
-        cnts = np.concatenate([packed[which[g]][1].reshape(-1) for g in slotted])
-        ns = np.concatenate([packed[which[g]][2] for g in slotted])
+        per_group = {g: packed[which[g]] for g in slotted}
+        dense_of = lambda g: var[which[g]]
+        if fn is None:
+            # 1e-5 of the FRAME's entries: that many groups (picked at random) get ONE out-of-range coefficient each
+            total = sum(int(per_group[g][2].sum()) for g in slotted)
+            hit = rng.choice(slotted, size=max(1, int(round(total * 1e-5))), replace=False)
+            changed = {int(g): np.ascontiguousarray(outlier_group(var[which[g]]), dtype=np.int32) for g in hit}
+            for g, c in changed.items():
+                per_group[g] = jl.host_pack_slots(c, group_id=0)
+                assert len(per_group[g][3]) == 0
+            dense_of = lambda g: changed.get(g, var[which[g]])
+        ents = np.concatenate([per_group[g][0] for g in slotted])
+        cnts = np.concatenate([per_group[g][1].reshape(-1) for g in slotted])
+        ns = np.concatenate([per_group[g][2] for g in slotted])
         ids = np.asarray(slotted, dtype=np.uint32)
         for c in ectx:
             begin(c)
             c.submit_groups_slots(ids, ents, cnts, ns, None)
             if dense_group is not None:
-                c.submit_group(dense_group, var[which[dense_group]])
+                c.submit_group(dense_group, dense_of(dense_group))
             c.slot_wait(0)
             c.frame_run()
         for c in ectx:
@@ -362,7 +372,7 @@ def slot_content_sweep(jxl_rs_amd, synth, np, ectx, wl, size, steps, reps, cores
         nb = sum(cnt["batches"].values())
         fb = sum(cnt["fallback_batches"].values())
         leg = {"slots_resident_ms_per_frame": round(slots_ms, 4), "k1_ms": kt.get("k1_vardct"),
-               "entries_per_frame": int(sum(int(packed[which[g]][2].sum()) for g in slotted)),
+               "entries_per_frame": int(sum(int(per_group[g][2].sum()) for g in slotted)),
                "nonzero_share_of_coefficients": round(float(np.mean([np.mean(var[g] != 0) for g in var])), 4),
                "fallback_share_of_batches": round(fb / max(1, nb), 4),
                "fallback_batches_by_class": {k: v for k, v in cnt["fallback_batches"].items() if v},
@@ -372,7 +382,7 @@ def slot_content_sweep(jxl_rs_amd, synth, np, ectx, wl, size, steps, reps, cores
         for c in ectx:
             begin(c)
             for g in range(ng):
-                c.submit_group(g, var[which[g]])
+                c.submit_group(g, dense_of(g))
             c.slot_wait(0)
             c.frame_run()
         for c in ectx:
