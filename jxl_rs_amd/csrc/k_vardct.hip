@@ -690,7 +690,7 @@ __device__ __forceinline__ int run_dct_class(const FrameDev& f, const WorkItem* 
                                              int nwaves, int lane, const AdjTable* __restrict__ adj,
                                              uint32_t* __restrict__ wl_fallback = nullptr,
                                              int* __restrict__ fallback_count = nullptr, float* __restrict__ s_dy = nullptr,
-                                             uint32_t fb_first_flag = 0) {
+                                             uint32_t fb_first_flag = 0, uint32_t* __restrict__ wl_fb_any = nullptr) {
   constexpr int NCH = S::E / 4;  // 16-byte chunks per lane per channel
   const int q = quant_table_for_type(type);
   const float* __restrict__ table = f.tables + f.table_offset[q];
@@ -767,6 +767,7 @@ __device__ __forceinline__ int run_dct_class(const FrameDev& f, const WorkItem* 
     }
   }
   int n_dense_pass = 0;  // (wave-uniform) batches this wave ran through the dense pass: inline (mode 3) or listed
+  bool flagged_any = false;
   for (int batch = iter_next(iter); batch >= 0; batch = iter_next(iter)) {
     const int nb = min(S::NB, count - batch * S::NB);
     if constexpr (LISTED) n_dense_pass++;
@@ -804,7 +805,13 @@ __device__ __forceinline__ int run_dct_class(const FrameDev& f, const WorkItem* 
       if constexpr (SPARSE == 3 && !INLINE_FB) {
         // left to the fallback launch BEFORE anything of the batch is requested: its word gets the launch's epoch
         if (!__all(item_ok)) {
-          if (lane == 0) wl_fallback[batch] = (uint32_t)f.fb_epoch;
+          if (lane == 0) {
+            wl_fallback[batch] = (uint32_t)f.fb_epoch;
+            // ... and one of the launch's kFbAny summary words (own cache lines, picked by the wave): plain stores of
+            // the same value, a wave's first reject only
+            if (!flagged_any) wl_fb_any[(gwave % kFbAny) * kFbAnyPitch] = (uint32_t)f.fb_epoch;
+          }
+          flagged_any = true;
           continue;
         }
       } else {
@@ -1061,7 +1068,8 @@ __global__ __launch_bounds__(kThreads, SPARSE == 3 ? (INLINE ? JXLH_K1_INLINE_WP
   run_dct_class<S8x8, true, SPARSE, SUB, kClsDct8, INLINE>(f, wl.items[kClsDct8], wl.eitems[kClsDct8], wl.counts[(kClsDct8) * kCountPitch], 0,
                                                    s_buf + wave * kTileA, s_binfo[wave], (uint32_t*)nullptr, s_lf[SPARSE >= 2 ? wave : 0],
                                                    blockIdx.x * kWaves + wave, gridDim.x * kWaves, lane, &s_adj,
-                                                   wl.fallback[kClsDct8], wl.counts + (kCntFallback0 + kClsDct8) * kCountPitch);
+                                                   wl.fallback[kClsDct8], wl.counts + (kCntFallback0 + kClsDct8) * kCountPitch, nullptr, 0u,
+                                                   wl.fb_any);
 }
 
 // families B (16x8, 8x16, 16x16) + C (everything with a 32-point side) in ONE launch (round 3): as two kernels both
@@ -1101,6 +1109,9 @@ __global__ __launch_bounds__(kThreads, SPARSE == 3 ? JXLH_K1_DIRECT_WPE : SPARSE
   // (c + chunks of the classes before it) % grid).  Nothing flagged there and no later chunk: the workgroup leaves.
   uint32_t fb_pre[kClsSpecial] = {};
   if constexpr (FB) {
+    // first level: the launch's summary words (one hot load; the direct kernels set one on a wave's first reject).  A
+    // frame that left nothing -- the usual one -- costs this launch ~4 us instead of the ~25 us of the flag prefetch.
+    if (!__any(wl.fb_any[(threadIdx.x & (kFbAny - 1)) * kFbAnyPitch] == (uint32_t)f.fb_epoch)) return;
     constexpr int kOrder[kClsSpecial] = {kClsDct32x32, kClsDct32x16, kClsDct16x32, kClsDct32x8, kClsDct8x32,
                                          kClsDct16x16, kClsDct16x8,  kClsDct8x16,  kClsDct8};
     constexpr int kNb[kClsSpecial] = {S32x32::NB, S32x16::NB, S16x32::NB, S32x8::NB, S8x32::NB, S16x16::NB, S16x8::NB, S8x16::NB, S8x8::NB};
@@ -1147,7 +1158,7 @@ __global__ __launch_bounds__(kThreads, SPARSE == 3 ? JXLH_K1_DIRECT_WPE : SPARSE
     const int nbat = run_dct_class<S, PF, SPARSE, false, CLS, false, FB>(
         f, wl.items[CLS], wl.eitems[CLS], cnt(CLS), type, buf, s_binfo[wave], ex, lfs,
         FB ? rotate_wave((int)blockIdx.x, used, (int)gridDim.x) * kWaves + wave : rotate_wave(gw, used, nw), nw, lane, &s_adj,
-        wl.fallback[CLS], wl.counts + (kCntFallback0 + CLS) * kCountPitch, sdy, FB ? fb_pre[fb_k] : 0u);
+        wl.fallback[CLS], wl.counts + (kCntFallback0 + CLS) * kCountPitch, sdy, FB ? fb_pre[fb_k] : 0u, wl.fb_any);
     used += FB ? (nbat + 15) / 16 : nbat;
   };
   run(ShapeTag<S32x32>{}, std::false_type{}, std::integral_constant<int, kClsDct32x32>{}, 5, 0);
@@ -1365,8 +1376,9 @@ size_t vardct_worklist_bytes(const FrameDev& f) {
   // + the unit lists of the large transforms: one u32 per 4096 samples of a 256-pixel varblock (two-pass units) and
   //   one per varblock of the smaller types (three lists by slabs per channel; worst case one entry per 32 blocks)
   // + the LLF planes of the large transforms (3 x nblocks floats, k1_large_llf)
+  // + the fallback launch's summary words
   return items * sizeof(WorkItem) + 2 * kCountBytes + large_unit_capacity(nblocks) * sizeof(uint32_t) + 64 +
-         3 * nblocks * sizeof(float);
+         3 * nblocks * sizeof(float) + (size_t)kFbAny * kFbAnyPitch * sizeof(uint32_t);
 }
 
 void vardct_worklist_reset(hipStream_t s, void* worklist_mem, uint32_t* launch_parity) {
@@ -1419,6 +1431,8 @@ void launch_vardct_groups(hipStream_t s, const FrameDev& f_in, int group_row0, i
     wl.fallback[c] = reinterpret_cast<uint32_t*>(p);
     p += (nblocks / (2 * class_min_area(c)) + 16) * sizeof(uint32_t);
   }
+  wl.fb_any = reinterpret_cast<uint32_t*>(p);
+  p += (size_t)kFbAny * kFbAnyPitch * sizeof(uint32_t);
   uint32_t* large_units = reinterpret_cast<uint32_t*>(p);  // behind the last list
   const dim3 gscan((ngroups + kScanGroups - 1) / kScanGroups);
   if (f.strip_desc)
@@ -1493,7 +1507,7 @@ void launch_vardct_groups(hipStream_t s, const FrameDev& f_in, int group_row0, i
   // (the fallback as TWO launches -- the classes without a 32-point side apart: 32 KB of LDS, three waves per SIMD --
   // measured no better on the outlier frame and 4 % worse on dense ones: profiles/r06_c_density.txt)
   if (sparse == 3)
-    hipLaunchKernelGGL((k1_dct16_32<2, true>), dim3(std::min(1024, std::max(1, nblk / 1024))), dim3(kThreads), 0, s, f, wl);
+    hipLaunchKernelGGL((k1_dct16_32<2, true>), dim3(std::min(512, std::max(1, nblk / 2048))), dim3(kThreads), 0, s, f, wl);
   // entries form, groups routed to their dense slabs (FrameDev::group_route): the same class kernels in their dense
   // form on those groups' lists; the grids follow the routed share of the frame
   if (sparse >= 2 && n_dense_route > 0) {

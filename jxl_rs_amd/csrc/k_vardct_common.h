@@ -93,6 +93,7 @@ constexpr int kCountLines = kCntDense0 + kClsSpecial;  // the classes, the two-p
                                               // lists, the entries form's fallback batches (kCntFallback0 ..), the DCT
                                               // classes of the groups that are read from dense slabs (kCntDense0 ..)
 constexpr size_t kCountBytes = (size_t)kCountLines * kCountPitch * sizeof(int);
+constexpr int kFbAny = 32, kFbAnyPitch = 32;  // summary words of the fallback launch, each on its own 128-byte line
 struct WorkLists {
   WorkItem* items[kNumClasses];
   EntryItem* eitems[kClsSpecial];  // the DCT classes only: special / large varblocks read dense slabs
@@ -101,6 +102,7 @@ struct WorkLists {
   // the rest of the frame is slot-bucketed -- go to these lists, which the dense-slab kernels run (counters at
   // kCntDense0 + class); everything else of the frame keeps reading its entries in place.
   WorkItem* ditems[kClsSpecial];
+  uint32_t* fb_any;                 // kFbAny summary words (kFbAnyPitch apart): == fb_epoch = some batch was left
   uint32_t* fallback[kClsSpecial];  // entries form, direct kernels: per class one word per batch; == FrameDev::fb_epoch
                                     // of the launch = left to the fallback launch (varblocks with more entries than a
                                     // lane holds, raw_quant == 0).  Never cleared: see launch_vardct_groups.
