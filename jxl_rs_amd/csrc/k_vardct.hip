@@ -690,7 +690,8 @@ __device__ __forceinline__ int run_dct_class(const FrameDev& f, const WorkItem* 
                                              int nwaves, int lane, const AdjTable* __restrict__ adj,
                                              uint32_t* __restrict__ wl_fallback = nullptr,
                                              int* __restrict__ fallback_count = nullptr, float* __restrict__ s_dy = nullptr,
-                                             uint32_t fb_first_flag = 0, uint32_t* __restrict__ wl_fb_any = nullptr) {
+                                             uint32_t fb_first_flag = 0, uint32_t* __restrict__ wl_fb_any = nullptr,
+                                             int* fb_rank = nullptr) {
   constexpr int NCH = S::E / 4;  // 16-byte chunks per lane per channel
   const int q = quant_table_for_type(type);
   const float* __restrict__ table = f.tables + f.table_offset[q];
@@ -708,7 +709,6 @@ __device__ __forceinline__ int run_dct_class(const FrameDev& f, const WorkItem* 
   struct BatchIter {
     int bi;                    // plain: the batch; listed: the chunk
     unsigned long long mask;   // listed: flagged batches of the chunk not yet handed out
-    int rank;                  // listed: flagged batches of the chunk handed out so far (all waves count alike)
     bool pre;                  // listed: mask = the kernel's prefetch: the workgroup's first FOUR chunks, 16 bits each
   };
   const int it_wave = gwave % kWaves, it_wg = gwave / kWaves, it_nwg = nwaves / kWaves;  // (LISTED: gwave is not rotated)
@@ -723,20 +723,21 @@ __device__ __forceinline__ int run_dct_class(const FrameDev& f, const WorkItem* 
           const int bit = __builtin_ctzll(st.mask);
           st.mask &= st.mask - 1;
           const int chunk = st.pre ? st.bi + (bit >> 4) * it_nwg : st.bi;
-          // (+ the chunk: a chunk with ONE flagged batch -- the usual case on d1 content -- must not always be wave 0's)
-          if ((st.rank++ + chunk) % kWaves == it_wave) return chunk * kFbChunk + (bit & 15);
+          // (*fb_rank: flagged batches the WORKGROUP has met so far in this launch, over all classes -- its waves see
+          // the same flags and count alike -- so the few batches a sparse frame leaves never queue up behind each other
+          // on one wave while the other three idle: the launch then lasts one batch's latency, not two)
+          if ((*fb_rank)++ % kWaves == it_wave) return chunk * kFbChunk + (bit & 15);
         }
         st.bi += st.pre ? 4 * it_nwg : it_nwg;
         st.pre = false;
         if (st.bi * kFbChunk >= nbatches) return -1;
         const int idx = st.bi * kFbChunk + lane;
         st.mask = __ballot(lane < kFbChunk && idx < nbatches && wl_fallback[idx] == (uint32_t)f.fb_epoch);
-        st.rank = 0;
       }
     }
   };
   static_assert(kFbChunk == 16, "the prefetched mask holds four 16-batch chunks");
-  BatchIter iter = {LISTED ? it_wg : gwave, LISTED ? __ballot(fb_first_flag == (uint32_t)f.fb_epoch && fb_first_flag != 0) : 0ull, 0, LISTED};
+  BatchIter iter = {LISTED ? it_wg : gwave, LISTED ? __ballot(fb_first_flag == (uint32_t)f.fb_epoch && fb_first_flag != 0) : 0ull, LISTED};
   // the weights a lane needs do not depend on the batch
   constexpr bool kPF = PREFETCH && SPARSE != 3;  // (the inline fallback of mode 3 reads its weights per batch)
   float4 tw[kPF ? 3 : 1][NCH];
@@ -1111,7 +1112,8 @@ __global__ __launch_bounds__(kThreads, SPARSE == 3 ? JXLH_K1_DIRECT_WPE : SPARSE
   if constexpr (FB) {
     // first level: the launch's summary words (one hot load; the direct kernels set one on a wave's first reject).  A
     // frame that left nothing -- the usual one -- costs this launch ~4 us instead of the ~25 us of the flag prefetch.
-    if (!__any(wl.fb_any[(threadIdx.x & (kFbAny - 1)) * kFbAnyPitch] == (uint32_t)f.fb_epoch)) return;
+    // (the class counters are requested in the same round trip)
+    const uint32_t summary = wl.fb_any[(threadIdx.x & (kFbAny - 1)) * kFbAnyPitch];
     constexpr int kOrder[kClsSpecial] = {kClsDct32x32, kClsDct32x16, kClsDct16x32, kClsDct32x8, kClsDct8x32,
                                          kClsDct16x16, kClsDct16x8,  kClsDct8x16,  kClsDct8};
     constexpr int kNb[kClsSpecial] = {S32x32::NB, S32x16::NB, S16x32::NB, S32x8::NB, S8x32::NB, S16x16::NB, S16x8::NB, S8x16::NB, S8x8::NB};
@@ -1119,6 +1121,7 @@ __global__ __launch_bounds__(kThreads, SPARSE == 3 ? JXLH_K1_DIRECT_WPE : SPARSE
     int nbat[kClsSpecial];
 #pragma unroll
     for (int k = 0; k < kClsSpecial; k++) nbat[k] = (wl.counts[kOrder[k] * kCountPitch] + kNb[k] - 1) / kNb[k];
+    if (!__any(summary == (uint32_t)f.fb_epoch)) return;
     int used = 0;
     bool more = false, any = false;
 #pragma unroll
@@ -1149,7 +1152,7 @@ __global__ __launch_bounds__(kThreads, SPARSE == 3 ? JXLH_K1_DIRECT_WPE : SPARSE
   const int gw = blockIdx.x * kWaves + wave, nw = gridDim.x * kWaves;
   auto cnt = [&](int cls) { return wl.counts[cls * kCountPitch]; };
   // the long batches (32-point sides) first: the tail of the launch is then made of the short ones
-  int used = 0;
+  int used = 0, fb_rank = 0;
   auto run = [&](auto shape_tag, auto pf_tag, auto cls_tag, int type, int fb_k = 0) {  // fb_k: index in the FB order
     using S = typename decltype(shape_tag)::type;
     constexpr bool PF = decltype(pf_tag)::value;
@@ -1158,7 +1161,7 @@ __global__ __launch_bounds__(kThreads, SPARSE == 3 ? JXLH_K1_DIRECT_WPE : SPARSE
     const int nbat = run_dct_class<S, PF, SPARSE, false, CLS, false, FB>(
         f, wl.items[CLS], wl.eitems[CLS], cnt(CLS), type, buf, s_binfo[wave], ex, lfs,
         FB ? rotate_wave((int)blockIdx.x, used, (int)gridDim.x) * kWaves + wave : rotate_wave(gw, used, nw), nw, lane, &s_adj,
-        wl.fallback[CLS], wl.counts + (kCntFallback0 + CLS) * kCountPitch, sdy, FB ? fb_pre[fb_k] : 0u, wl.fb_any);
+        wl.fallback[CLS], wl.counts + (kCntFallback0 + CLS) * kCountPitch, sdy, FB ? fb_pre[fb_k] : 0u, wl.fb_any, &fb_rank);
     used += FB ? (nbat + 15) / 16 : nbat;
   };
   run(ShapeTag<S32x32>{}, std::false_type{}, std::integral_constant<int, kClsDct32x32>{}, 5, 0);
