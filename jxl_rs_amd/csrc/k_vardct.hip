@@ -1109,6 +1109,7 @@ __global__ __launch_bounds__(kThreads, SPARSE == 3 ? JXLH_K1_DIRECT_WPE : SPARSE
   // else of the workgroup is set up (order = the order the classes run in below; a class's chunk c belongs to workgroup
   // (c + chunks of the classes before it) % grid).  Nothing flagged there and no later chunk: the workgroup leaves.
   uint32_t fb_pre[kClsSpecial] = {};
+  uint32_t fb_live = 0;  // FB: classes (bit = position in the FB order) with a flagged batch or chunks beyond the prefetch
   if constexpr (FB) {
     // first level: the launch's summary words (one hot load; the direct kernels set one on a wave's first reject).  A
     // frame that left nothing -- the usual one -- costs this launch ~4 us instead of the ~25 us of the flag prefetch.
@@ -1123,18 +1124,18 @@ __global__ __launch_bounds__(kThreads, SPARSE == 3 ? JXLH_K1_DIRECT_WPE : SPARSE
     for (int k = 0; k < kClsSpecial; k++) nbat[k] = (wl.counts[kOrder[k] * kCountPitch] + kNb[k] - 1) / kNb[k];
     if (!__any(summary == (uint32_t)f.fb_epoch)) return;
     int used = 0;
-    bool more = false, any = false;
 #pragma unroll
     for (int k = 0; k < kClsSpecial; k++) {
       // (chunks of 16 batches: lanes 16 r .. 16 r + 15 take the workgroup's chunk of round r, fc + r * grid)
       const int nch = (nbat[k] + 15) / 16, fc = rotate_wave((int)blockIdx.x, used, grid), idx = (fc + (l >> 4) * grid) * 16 + (l & 15);
       fb_pre[k] = idx < nbat[k] ? wl.fallback[kOrder[k]][idx] : 0u;
-      more |= fc + 4 * grid < nch;
+      if (fc + 4 * grid < nch) fb_live |= 1u << k;
       used += nch;
     }
 #pragma unroll
-    for (int k = 0; k < kClsSpecial; k++) any |= fb_pre[k] == (uint32_t)f.fb_epoch;
-    if (!__any(any) && !more) return;  // (every wave of the workgroup reads the same words: uniform)
+    for (int k = 0; k < kClsSpecial; k++)
+      if (__any(fb_pre[k] == (uint32_t)f.fb_epoch)) fb_live |= 1u << k;
+    if (!fb_live) return;  // (every wave of the workgroup reads the same words: uniform)
   }
   __shared__ __attribute__((aligned(16))) float s_buf[kWaves * kTileC];
   __shared__ BlockInfo s_binfo[kWaves][8];
@@ -1157,6 +1158,14 @@ __global__ __launch_bounds__(kThreads, SPARSE == 3 ? JXLH_K1_DIRECT_WPE : SPARSE
     using S = typename decltype(shape_tag)::type;
     constexpr bool PF = decltype(pf_tag)::value;
     constexpr int CLS = decltype(cls_tag)::value;
+    if constexpr (FB) {
+      // nothing of the class for this workgroup: not even the class's preamble (a sparse frame's few batches otherwise
+      // start ~1.4 us later per class in front of them: 12-14 us for the 8x8 class, the last one)
+      if (!((fb_live >> fb_k) & 1u)) {
+        used += ((cnt(CLS) + S::NB - 1) / S::NB + 15) / 16;
+        return;
+      }
+    }
     // (FB: the rotation counts workgroups -- a class's chunk c goes to workgroup (c + chunks of the classes before) % grid)
     const int nbat = run_dct_class<S, PF, SPARSE, false, CLS, false, FB>(
         f, wl.items[CLS], wl.eitems[CLS], cnt(CLS), type, buf, s_binfo[wave], ex, lfs,

@@ -74,6 +74,8 @@ for f in factors:
     if hasattr(c.L, "jxlh_frame_k1_counters"):
         cnt = c.k1_counters()
         extra = " fallback %d / %d batches" % (sum(cnt["fallback_batches"].values()), sum(cnt["batches"].values()))
+        if os.environ.get("SWEEP_RAW"):
+            extra += " raw %s %s" % (list(cnt["fallback_batches"].values()), list(cnt["dense_route_varblocks"].values()))
         if os.environ.get("SWEEP_CLASSES"):
             extra += " " + " ".join("%s %d/%d" % (k, cnt["fallback_batches"][k], v) for k, v in cnt["batches"].items())
     print(f"factor {f}: frame {wall:.4f} ms, k1 {kt.get('k1_vardct')} ms, filters {kt.get('k23_fused_filters')}{extra}", flush=True)
