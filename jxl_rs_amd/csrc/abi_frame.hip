@@ -758,7 +758,11 @@ jxlh_status run_prologue(jxlh_ctx* ctx, RunPlan* plan) {
           entries += (uint64_t)sg.n[0] + sg.n[1] + sg.n[2];
           groups++;
         }
-        ctx->se_dense_hint = groups && (double)entries > 0.25 * (double)(groups * 3 * (uint64_t)kGroupArea);
+        // ... and from about 1.5 times d1's share most 16..32-point batches are beyond the direct path's depth: the
+        // dense dequantisation pass for those classes outright instead of a direct launch that rejects them and a
+        // fallback launch that picks them up (level 1; K1 at x2: 0.405 -> see profiles/r06_p_density.txt)
+        const double share = groups ? (double)entries / (double)(groups * 3 * (uint64_t)kGroupArea) : 0.0;
+        ctx->se_dense_hint = share > 0.25 ? 2 : share > 0.125 ? 1 : 0;
       }
       if (all_bucketed) {
         ctx->se_live = pend;  // the sets trade places: the next epoch's uploads go to the set read two frames ago
@@ -872,7 +876,7 @@ static void set_sparse_view(jxlh_ctx* ctx, FrameDev& f, bool sparse_k1) {
   f.se_runs = ent ? ctx->se_runs[ctx->se_live].p : nullptr;
   f.group_dense = sparse_k1 ? ctx->group_dense.p : nullptr;
   f.group_route = ent && ctx->n_route > 0 ? ctx->route_dev.p : nullptr;
-  f.se_dense_hint = ent && ctx->se_dense_hint ? 1 : 0;
+  f.se_dense_hint = ent ? ctx->se_dense_hint : 0;
   f.k1_stats = ctx->timing ? 1 : 0;
 }
 static int dense_route_groups(const jxlh_ctx* ctx, bool sparse_k1) { return sparse_k1 && ctx->se_valid ? ctx->n_route : 0; }

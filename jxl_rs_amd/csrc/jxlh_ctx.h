@@ -162,7 +162,7 @@ struct jxlh_ctx {
   std::vector<uint8_t> route_live, route_upload;
   DevBuf<uint8_t> route_dev;
   int n_route = 0;
-  bool se_dense_hint = false;  // FrameDev::se_dense_hint of the live set
+  int se_dense_hint = 0;       // FrameDev::se_dense_hint of the live set
   // extra channels inside the frame path (jxlh_frame_set_extra_channel): as handed over, converted, upsampled
   struct ExtraChannel {
     bool set = false, done = false;

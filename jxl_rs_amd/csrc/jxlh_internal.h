@@ -147,8 +147,9 @@ struct FrameDev {
   // earlier content) while the rest of the frame is read in place.  k1_scan sends such a group's DCT-class varblocks to
   // WorkLists::ditems.
   const uint8_t* group_route;
-  // host hint: the frame's in-place groups hold about three times the entries per coefficient d1 content does (> 0.25):
-  // the 8x8 class then runs its over-depth batches inline instead of leaving them to the fallback launch
+  // host hint from the entries per coefficient of the frame's in-place groups (d1 content: ~0.086).  2 (> 0.25): the
+  // 8x8 class runs its over-depth batches inline instead of leaving them to the fallback launch; >= 1 (> 0.125): the
+  // 16..32-point classes take the dense dequantisation pass outright (no direct launch for them)
   int se_dense_hint;
   int fb_epoch;   // launch number + 1 (set by launch_vardct_groups): the value that flags a batch for the fallback launch
   int k1_stats;   // the transforms count their dense-pass batches (jxlh_frame_k1_counters): on with kernel timing

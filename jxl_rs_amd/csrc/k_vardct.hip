@@ -1480,6 +1480,7 @@ void launch_vardct_groups(hipStream_t s, const FrameDev& f_in, int group_row0, i
   // caps measured flat between 768 and 8192 workgroups at 8K (tools/bench_variants.sh)
   const dim3 g8(grid_for(nblk, kWaves * S8x8::NB * 2, 4096)), g16(grid_for(nblk / 2, kWaves * 8 * 2, 2048)),
       g32(grid_for(nblk / 4, kWaves * 4 * 2, 2048));
+  bool inline8 = false, dense1632 = false;  // entries form: the dense-pass choices of a frame denser than d1 (se_dense_hint)
   if (f.subsampled) {
     // (the fallback launch has no sub-sampled form: such a frame always takes the inline fallback)
     if (sparse == 3) hipLaunchKernelGGL((k1_dct8<3, true, true>), g8, dim3(kThreads), 0, s, f, wl);
@@ -1494,10 +1495,16 @@ void launch_vardct_groups(hipStream_t s, const FrameDev& f_in, int group_row0, i
         const char* e = getenv("JXLH_K1_INLINE");
         return e && *e ? atoi(e) : -1;
       }();
-      if (force_inline >= 0 ? force_inline != 0 : f.se_dense_hint != 0)
-        hipLaunchKernelGGL((k1_dct8<3, false, true>), g8, dim3(kThreads), 0, s, f, wl);
+      static const int force_dense1632 = [] {  // JXLH_K1_DENSE1632=0 / 1: the same for the 16..32-point classes
+        const char* e = getenv("JXLH_K1_DENSE1632");
+        return e && *e ? atoi(e) : -1;
+      }();
+      inline8 = force_inline >= 0 ? force_inline != 0 : f.se_dense_hint >= 2;
+      dense1632 = force_dense1632 >= 0 ? force_dense1632 != 0 : f.se_dense_hint >= 1;
+      if (inline8) hipLaunchKernelGGL((k1_dct8<3, false, true>), g8, dim3(kThreads), 0, s, f, wl);
       else hipLaunchKernelGGL(k1_dct8<3>, g8, dim3(kThreads), 0, s, f, wl);
-      hipLaunchKernelGGL(k1_dct16_32<3>, g1632, dim3(kThreads), 0, s, f, wl);
+      if (dense1632) hipLaunchKernelGGL(k1_dct16_32<2>, g1632, dim3(kThreads), 0, s, f, wl);
+      else hipLaunchKernelGGL(k1_dct16_32<3>, g1632, dim3(kThreads), 0, s, f, wl);
     } else if (sparse == 2) {
       hipLaunchKernelGGL(k1_dct8<2>, g8, dim3(kThreads), 0, s, f, wl);
       hipLaunchKernelGGL(k1_dct16_32<2>, g1632, dim3(kThreads), 0, s, f, wl);
@@ -1518,7 +1525,8 @@ void launch_vardct_groups(hipStream_t s, const FrameDev& f_in, int group_row0, i
   // the whole chip)
   // (the fallback as TWO launches -- the classes without a 32-point side apart: 32 KB of LDS, three waves per SIMD --
   // measured no better on the outlier frame and 4 % worse on dense ones: profiles/r06_c_density.txt)
-  if (sparse == 3)
+  // (nothing can be left when both choices were made)
+  if (sparse == 3 && !f.subsampled && !(inline8 && dense1632))
     hipLaunchKernelGGL((k1_dct16_32<2, true>), dim3(std::min(512, std::max(1, nblk / 2048))), dim3(kThreads), 0, s, f, wl);
   // entries form, groups routed to their dense slabs (FrameDev::group_route): the same class kernels in their dense
   // form on those groups' lists; the grids follow the routed share of the frame
