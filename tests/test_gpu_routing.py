@@ -232,13 +232,16 @@ def test_more_than_1023_entries_in_a_varblock(ctx, dense_dequant):
     _check(ctx, want, "two dense passes in one list")
 
 
-@pytest.mark.parametrize("density", [0.02, 0.25, 0.6])
-def test_coefficient_density_far_from_d1(ctx, density):
+@pytest.mark.parametrize("mix", ["d1", "all"])
+@pytest.mark.parametrize("density", [0.02, 0.11, 0.15, 0.25, 0.35, 0.6])
+def test_coefficient_density_far_from_d1(ctx, density, mix):
     """the direct path holds 3-6 entries per lane and channel; a frame of another density falls back batch by batch
-    (inline for 8x8, the fallback launch for the 16..32-point classes) and gives the dense submission's bits"""
+    (the fallback launch; from 0.125 entries per coefficient on the 16..32-point classes take the dense pass outright,
+    from 0.25 on the 8x8 class runs its over-depth batches inline) and gives the dense submission's bits; `all`: with
+    the special and large transform types, which read their dense slabs next to it"""
     from jxl_rs_amd import lib as jl
     from jxl_rs_amd import synth
-    wl = synth.make_vardct(1024, 768, mix=synth.MIX_D1, seed=17, epf_iters=1)
+    wl = synth.make_vardct(1024, 768, mix=synth.MIX_D1 if mix == "d1" else synth.MIX_ALL, seed=17, epf_iters=1)
     ng = wl.coeffs.shape[0]
     rng = np.random.default_rng(int(density * 100))
     m = rng.random(wl.coeffs.shape) < density
