@@ -396,29 +396,47 @@ def slot_content_sweep(jxl_rs_amd, synth, np, ectx, wl, size, steps, reps, cores
         leg["vs_clean_slots_frame"] = round(leg["slots_resident_ms_per_frame"] / clean, 4)
     # ---- what producing the form costs on the host: jxlh_host_pack_slots on every group of the
     # frame (dense i32 slab -> entries + slot counts), `cores` threads (ctypes releases the GIL), and on one thread
+    # One C call per thread for its share of the frame (jxlh_host_pack_slots_many; ctypes releases the GIL): round 6's
+    # first figure (37 ms on 16 cores) called jxlh_host_pack_slots once per group from Python threads and mostly
+    # measured the interpreter lock around 1024 wrapper calls -- kept beside it as `per_group_python_calls_ms`.
+    per = -(-ng // cores)
+    shares = [(t * per, min(ng, (t + 1) * per)) for t in range(cores) if t * per < ng]
+    big = max(g1 - g0 for g0, g1 in shares)
+    ents_many = [np.empty(big * (3 * 65536 + 65536), np.uint16) for _ in shares]
+    cnt_many = [np.empty((big, 3, 1024), np.uint8) for _ in shares]
+    n_many = [np.zeros((big, 3), np.uint32) for _ in shares]
     ents_buf = [np.empty(3 * 65536 + 65536, np.uint16) for _ in range(cores)]
     cnt_buf = [np.empty((3, 1024), np.uint8) for _ in range(cores)]
+
+    def pack_share(t, g0, g1):
+        jl.host_pack_slots_many(wl.coeffs[g0:g1], np.arange(g0, g1, dtype=np.uint32), entries=ents_many[t],
+                                slot_counts=cnt_many[t][:g1 - g0], n=n_many[t][:g1 - g0])
 
     def pack_range(t, g0, g1):
         for g in range(g0, g1):
             jl.host_pack_slots(wl.coeffs[g], group_id=g, entries=ents_buf[t], slot_counts=cnt_buf[t])
 
-    def pack_frame(nthreads):
-        per = -(-ng // nthreads)
+    def pack_frame(nthreads, fn):
+        sh = shares if nthreads > 1 else [(0, ng)]
         t0 = time.perf_counter()
         if nthreads == 1:
-            pack_range(0, 0, ng)
+            for g0 in range(0, ng, big):  # (the one-thread run reuses thread 0's buffers share by share)
+                fn(0, g0, min(ng, g0 + big))
         else:
             with ThreadPoolExecutor(nthreads) as ex:
-                list(ex.map(lambda t: pack_range(t, t * per, min(ng, (t + 1) * per)), range(nthreads)))
+                list(ex.map(lambda a: fn(a[0], a[1][0], a[1][1]), enumerate(sh)))
         return (time.perf_counter() - t0) * 1e3
 
-    pack_frame(cores)
-    allc = sorted(pack_frame(cores) for _ in range(3))[1]
-    one = pack_frame(1)
+    has_many = hasattr(jl.load(), "jxlh_host_pack_slots_many")
+    fn = pack_share if has_many else pack_range
+    pack_frame(cores, fn)
+    allc = sorted(pack_frame(cores, fn) for _ in range(3))[1]
+    one = pack_frame(1, fn)
     res["host_pack"] = {"host_pack_ms_per_frame": round(allc, 2), "cores": cores, "one_thread_ms_per_frame": round(one, 1),
-                        "what": "jxlh_host_pack_slots (C, SSE2) on the frame's %d dense i32 group slabs (805 MB read) -> u16 entries "
-                                "+ u8 slot counts; a decoder that appends from its entropy loop (jxlh_slot_writer_*) pays per "
+                        "per_group_python_calls_ms": round(sorted(pack_frame(cores, pack_range) for _ in range(3))[1], 2),
+                        "what": "jxlh_host_pack_slots_many (C; AVX2 zero scan where the host has it, SSE2 otherwise), one call per "
+                                "thread for its share of the frame's %d dense i32 group slabs (805 MB read) -> u16 entries + u8 "
+                                "slot counts; a decoder that appends from its entropy loop (jxlh_slot_writer_*) pays per "
                                 "coefficient instead of per slab byte" % ng}
     return res
 

@@ -357,3 +357,23 @@ impl Drop for SlotWriter {
         unsafe { sys::jxlh_slot_writer_destroy(self.raw) }
     }
 }
+
+/// Dense group slabs -> the arrays of ONE `jxlh_submit_groups_slots` call (`jxlh_host_pack_slots_many`): for a decoder
+/// that keeps the reference's per-group `Vec<i32>` (`Frame::hf_coefficients`, jxl/src/frame/mod.rs; 3 x 65536 each).
+/// `entries` (u16 each), `slot_counts` (groups x 3 x 1024) and `n` (groups x 3) are written group after group.  Returns
+/// (entries written, `wide` values).  Plain CPU code, any thread: each runner thread packs its share of the frame.
+pub fn pack_group_slabs(group_coeffs: &[&[i32]], group_ids: &[u32], entries: &mut [u16], slot_counts: &mut [u8],
+                        n: &mut [u32], wide: &mut [sys::jxlh_coeff32]) -> Result<(usize, u32)> {
+    let k = group_coeffs.len();
+    if group_ids.len() != k || slot_counts.len() < k * 3 * 1024 || n.len() < k * 3 || group_coeffs.iter().any(|g| g.len() != 3 * 65536) {
+        return Err(HipError::InvalidArgument);
+    }
+    let ptrs: Vec<*const i32> = group_coeffs.iter().map(|g| g.as_ptr()).collect();
+    let (mut nw, mut used) = (0u32, 0usize);
+    check(std::ptr::null(), unsafe {
+        sys::jxlh_host_pack_slots_many(ptrs.as_ptr(), group_ids.as_ptr(), k as u32, 0, entries.as_mut_ptr() as *mut c_void,
+                                       entries.len(), slot_counts.as_mut_ptr(), n.as_mut_ptr(), wide.as_mut_ptr(),
+                                       wide.len() as u32, &mut nw, &mut used)
+    })?;
+    Ok((used, nw))
+}

@@ -311,6 +311,14 @@ jxlh_status jxlh_submit_groups_slots(jxlh_ctx* ctx, int32_t slot, uint32_t count
 jxlh_status jxlh_host_pack_slots(const int32_t* coeffs, uint32_t group_id, uint32_t flags, void* entries,
                                  size_t entries_capacity, uint8_t* slot_counts, uint32_t n[3], jxlh_coeff32* wide,
                                  uint32_t wide_capacity, uint32_t* n_wide);
+/* A batch of groups in one call: exactly the arrays of ONE jxlh_submit_groups_slots call for them -- group_coeffs[g] is
+ * group group_ids[g]'s dense slab (the reference keeps one Vec per group: Frame::hf_coefficients, frame/mod.rs), entries
+ * / slot_counts (n_groups x 3 x 1024) / n (n_groups x 3) are written group after group, *entries_used = entries written
+ * (nullable).  What a decoder thread calls for its share of a frame (bench.py: host_pack_ms_per_frame times this). */
+jxlh_status jxlh_host_pack_slots_many(const int32_t* const* group_coeffs, const uint32_t* group_ids, uint32_t n_groups,
+                                      uint32_t flags, void* entries, size_t entries_capacity, uint8_t* slot_counts,
+                                      uint32_t* n, jxlh_coeff32* wide, uint32_t wide_capacity, uint32_t* n_wide,
+                                      size_t* entries_used);
 /* The same form written by the entropy loop itself (frame/group.rs:557-575), one writer per decoding thread:
  *   begin_group(buffers)                                 once per group (zeroes slot_counts)
  *   begin_varblock(first_slot, num_slots)                coeffs_offset / 64 and cx * cy of the varblock (group.rs:612);

@@ -12,7 +12,8 @@
 // integers on the device before the dequantisation, like `coeffs[i] += v` over several passes (jxl_hip.h), so the frame
 // stays in the form the transforms read in place.  Only what no slot can hold (a slot's count is a u8) goes to `wide`,
 // which routes that one GROUP through its dense slab.
-#include <emmintrin.h>  // SSE2: baseline x86-64 (the library also runs on the GPU box's host, whatever CPU that has)
+#include <immintrin.h>  // SSE2 is the baseline (the library also runs on the GPU box's host, whatever CPU that has);
+                        // the AVX2 form of the zero scan is picked at run time (__builtin_cpu_supports)
 
 #include <cstdlib>
 #include <cstring>
@@ -61,6 +62,44 @@ inline void pack12(const uint16_t* e, size_t n, uint8_t* out) {
     out[2] = (uint8_t)(e1 >> 4);
     out += 3;
   }
+}
+
+// 64-bit map of a slot's non-zero coefficients
+inline uint64_t nonzero_map_sse2(const int32_t* p) {
+  const __m128i zero = _mm_setzero_si128();
+  uint64_t nz = 0;
+  for (int q = 0; q < 16; q++) {
+    const __m128i v = _mm_loadu_si128(reinterpret_cast<const __m128i*>(p + 4 * q));
+    const int m = _mm_movemask_ps(_mm_castsi128_ps(_mm_cmpeq_epi32(v, zero)));
+    nz |= (uint64_t)(~m & 15) << (4 * q);
+  }
+  return nz;
+}
+__attribute__((target("avx2"))) inline uint64_t nonzero_map_avx2(const int32_t* p) {
+  const __m256i zero = _mm256_setzero_si256();
+  uint64_t nz = 0;
+  for (int q = 0; q < 8; q++) {
+    const __m256i v = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(p + 8 * q));
+    const int m = _mm256_movemask_ps(_mm256_castsi256_ps(_mm256_cmpeq_epi32(v, zero)));
+    nz |= (uint64_t)(~m & 255) << (8 * q);
+  }
+  return nz;
+}
+// a channel's 1024 maps in one go (the AVX2 body must not be inlined into baseline code: one call per channel)
+void nonzero_maps_sse2(const int32_t* ch, uint64_t* maps) {
+  for (int s = 0; s < kSlots; s++) maps[s] = nonzero_map_sse2(ch + s * kSlotCoeffs);
+}
+__attribute__((target("avx2"))) void nonzero_maps_avx2(const int32_t* ch, uint64_t* maps) {
+  for (int s = 0; s < kSlots; s++) maps[s] = nonzero_map_avx2(ch + s * kSlotCoeffs);
+}
+using MapsFn = void (*)(const int32_t*, uint64_t*);
+inline MapsFn pick_maps() {
+  // (JXLH_HOST_PACK_NO_AVX2=1: the baseline form on any host -- tests/test_host_pack_cpu.py runs both)
+  static const MapsFn fn = [] {
+    const char* e = getenv("JXLH_HOST_PACK_NO_AVX2");
+    return (!(e && *e && *e != '0') && __builtin_cpu_supports("avx2")) ? nonzero_maps_avx2 : nonzero_maps_sse2;
+  }();
+  return fn;
 }
 
 }  // namespace
@@ -139,27 +178,31 @@ jxlh_status jxlh_host_pack_slots(const int32_t* coeffs, uint32_t group_id, uint3
   uint16_t* out16 = static_cast<uint16_t*>(entries);
   std::vector<uint16_t> stage;  // 12-bit form: a channel's run is staged as 16-bit entries, then packed
   if (e12) stage.reserve(kArea / 4);
-  const __m128i zero = _mm_setzero_si128();
+  const MapsFn maps_of = pick_maps();
+  uint64_t maps[kSlots];
   for (int c = 0; c < 3; c++) {
     const int32_t* ch = coeffs + (size_t)c * kArea;
     uint8_t* cnt = slot_counts + c * kSlots;
     size_t run = 0;
     if (e12) stage.clear();
+    maps_of(ch, maps);
     for (int s = 0; s < kSlots; s++) {
       const int32_t* p = ch + s * kSlotCoeffs;
-      // 64-bit map of the slot's non-zero coefficients
-      uint64_t nz = 0;
-      for (int q = 0; q < 16; q++) {
-        const __m128i v = _mm_loadu_si128(reinterpret_cast<const __m128i*>(p + 4 * q));
-        const int m = _mm_movemask_ps(_mm_castsi128_ps(_mm_cmpeq_epi32(v, zero)));
-        nz |= (uint64_t)(~m & 15) << (4 * q);
-      }
+      uint64_t nz = maps[s];
       int count = 0;
       while (nz) {
         const int k = __builtin_ctzll(nz);
         nz &= nz - 1;
+        const int32_t v = p[k];
+        if (!e12 && v >= r.lo && v <= r.hi && count < 255) {  // the usual coefficient: one entry, no staging
+          if (used + run + 1 > entries_capacity) return JXLH_ERR_INVALID_ARGUMENT;
+          out16[used + run] = (uint16_t)((uint32_t)k | ((uint32_t)v & (uint32_t)r.mask) << r.shift);
+          run++;
+          count++;
+          continue;
+        }
         uint16_t tmp[kMaxSplit];
-        const int got = split_value(p[k], (uint32_t)k, r, 255 - count, tmp);
+        const int got = split_value(v, (uint32_t)k, r, 255 - count, tmp);
         if (got == 0) {
           if (nw >= wide_capacity) return JXLH_ERR_INVALID_ARGUMENT;
           wide[nw].pos = (group_id * 3u + (uint32_t)c) * kArea + (uint32_t)s * kSlotCoeffs + (uint32_t)k;
@@ -198,6 +241,33 @@ jxlh_status jxlh_host_pack_slots(const int32_t* coeffs, uint32_t group_id, uint3
   }
   if (n_wide) *n_wide = nw;
   else if (nw) return JXLH_ERR_INVALID_ARGUMENT;
+  return JXLH_OK;
+}
+
+jxlh_status jxlh_host_pack_slots_many(const int32_t* const* group_coeffs, const uint32_t* group_ids, uint32_t n_groups,
+                                      uint32_t flags, void* entries, size_t entries_capacity, uint8_t* slot_counts,
+                                      uint32_t* n, jxlh_coeff32* wide, uint32_t wide_capacity, uint32_t* n_wide,
+                                      size_t* entries_used) {
+  if (!group_coeffs || !group_ids || !entries || !slot_counts || !n || (wide_capacity && !wide) ||
+      (flags & ~(uint32_t)JXLH_GROUP_ENTRIES12))
+    return JXLH_ERR_INVALID_ARGUMENT;
+  const bool e12 = (flags & JXLH_GROUP_ENTRIES12) != 0;
+  size_t used = 0;  // entries (every run of the 12-bit form is even: a group starts on a byte)
+  uint32_t nw = 0;
+  for (uint32_t g = 0; g < n_groups; g++) {
+    uint32_t got_wide = 0;
+    void* out = e12 ? static_cast<void*>(static_cast<uint8_t*>(entries) + used / 2 * 3)
+                    : static_cast<void*>(static_cast<uint16_t*>(entries) + used);
+    const jxlh_status st =
+        jxlh_host_pack_slots(group_coeffs[g], group_ids[g], flags, out, entries_capacity - used, slot_counts + (size_t)g * 3 * kSlots,
+                             n + (size_t)g * 3, wide ? wide + nw : nullptr, wide_capacity - nw, &got_wide);
+    if (st != JXLH_OK) return st;
+    nw += got_wide;
+    used += (size_t)n[g * 3] + n[g * 3 + 1] + n[g * 3 + 2];
+  }
+  if (n_wide) *n_wide = nw;
+  else if (nw) return JXLH_ERR_INVALID_ARGUMENT;
+  if (entries_used) *entries_used = used;
   return JXLH_OK;
 }
 

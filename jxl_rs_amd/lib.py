@@ -57,7 +57,7 @@ ABI_SYMBOLS = [
     "jxlh_frame_rerender_groups", "jxlh_comm_allgather_local", "jxlh_palette_strided", "jxlh_modular_frame_filters",
     "jxlh_ctx_wait_stream", "jxlh_ctx_wait_event", "jxlh_ctx_record_event",
     "jxlh_frame_allgather_output", "jxlh_frames_allgather_output_local",
-    "jxlh_host_pack_slots", "jxlh_slot_writer_create", "jxlh_slot_writer_destroy", "jxlh_slot_writer_begin_group",
+    "jxlh_host_pack_slots", "jxlh_host_pack_slots_many", "jxlh_slot_writer_create", "jxlh_slot_writer_destroy", "jxlh_slot_writer_begin_group",
     "jxlh_slot_writer_begin_varblock", "jxlh_slot_writer_add", "jxlh_slot_writer_add_many", "jxlh_slot_writer_end_group",
 ]
 # developer / bench instruments: include/jxl_hip_dev.h (same library, not part of the drop-in boundary)
@@ -244,6 +244,8 @@ def load():
         L.jxlh_ctx_record_event.argtypes = [vp, vp]
     if hasattr(L, "jxlh_host_pack_slots"):  # absent from older builds used in A/B runs (JXLH_LIBRARY)
         L.jxlh_host_pack_slots.argtypes = [vp, u32, u32, vp, sz, vp, vp, vp, u32, C.POINTER(u32)]
+    if hasattr(L, "jxlh_host_pack_slots_many"):
+        L.jxlh_host_pack_slots_many.argtypes = [vp, vp, u32, u32, vp, sz, vp, vp, vp, u32, C.POINTER(u32), C.POINTER(sz)]
         L.jxlh_slot_writer_create.argtypes = [C.POINTER(vp)]
         L.jxlh_slot_writer_destroy.argtypes = [vp]
         L.jxlh_slot_writer_destroy.restype = None
@@ -282,6 +284,37 @@ def host_pack_slots(group_coeffs, group_id=0, bits12=False, entries=None, slot_c
     if st != 0:
         raise JxlHipError(st, "host_pack_slots")
     total = int(n.sum())
+    return entries[: total * 3 // 2 if bits12 else total], slot_counts, n, wide[: nw.value]
+
+
+def host_pack_slots_many(coeffs, group_ids, bits12=False, entries=None, slot_counts=None, n=None, wide_capacity=4096):
+    """jxlh_host_pack_slots_many: the dense slabs of a batch of groups (coeffs [k, 3 x 65536] i32, C-contiguous rows) ->
+    (entries, slot_counts [k, 3, 1024] u8, n [k, 3] u32, wide [m, 2] u32): the arrays of ONE Context.submit_groups_slots
+    call for group_ids.  One C call for the whole batch (no per-group Python): what a decoder thread does for its share
+    of a frame.  entries / slot_counts / n: optional preallocated outputs."""
+    L = _lib()
+    coeffs = np.asarray(coeffs)
+    k = int(coeffs.shape[0])
+    assert coeffs.dtype == np.int32 and coeffs[0].size == 3 * 65536 and all(coeffs[i].flags.c_contiguous for i in (0, k - 1))
+    ids = np.ascontiguousarray(group_ids, dtype=np.uint32)
+    assert ids.size == k
+    ptrs = np.array([coeffs[i].ctypes.data for i in range(k)], dtype=np.uint64)
+    cap = k * (3 * 65536 + 64 * 1024)
+    if entries is None:
+        entries = np.empty(cap * 3 // 2 if bits12 else cap, np.uint8 if bits12 else np.uint16)
+    else:
+        cap = entries.size * 2 // 3 if bits12 else entries.size
+    if slot_counts is None:
+        slot_counts = np.empty((k, 3, 1024), np.uint8)
+    if n is None:
+        n = np.zeros((k, 3), np.uint32)
+    wide = np.zeros((max(wide_capacity, 1), 2), np.uint32)
+    nw, used = C.c_uint32(0), C.c_size_t(0)
+    st = L.jxlh_host_pack_slots_many(_addr(ptrs), _addr(ids), k, GROUP_ENTRIES12 if bits12 else 0, _addr(entries), cap,
+                                     _addr(slot_counts), _addr(n), _addr(wide), wide_capacity, C.byref(nw), C.byref(used))
+    if st != 0:
+        raise JxlHipError(st, "host_pack_slots_many")
+    total = int(used.value)
     return entries[: total * 3 // 2 if bits12 else total], slot_counts, n, wide[: nw.value]
 
 

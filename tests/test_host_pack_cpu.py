@@ -122,3 +122,42 @@ def test_writer_call_order_errors():
     e, cnt, n, wd = w.end_group()
     assert n.tolist() == [0, 0, 1] and cnt[2, 5] == 1
     w.close()
+
+
+@pytest.mark.parametrize("bits12", [False, True])
+def test_batched_packer_is_the_groups_one_after_the_other(bits12):
+    """jxlh_host_pack_slots_many writes the arrays of one jxlh_submit_groups_slots call: group after group"""
+    groups = np.stack([_group(20 + i, density=d)[0] for i, d in enumerate((0.1, 0.0, 0.3, 0.05))])
+    groups[0, 1, 77] = 25000       # split
+    groups[2, 0, 5] = 100000       # to `wide`
+    ids = np.array([7, 3, 9, 0], np.uint32)
+    ent, cnt, n, wide = jl.host_pack_slots_many(groups, ids, bits12=bits12)
+    singles = [jl.host_pack_slots(groups[i], group_id=int(ids[i]), bits12=bits12) for i in range(4)]
+    assert np.array_equal(ent, np.concatenate([s[0] for s in singles]))
+    assert np.array_equal(cnt, np.stack([s[1] for s in singles]))
+    assert np.array_equal(n, np.stack([s[2] for s in singles]))
+    assert np.array_equal(wide, np.concatenate([s[3] for s in singles]))
+    assert len(wide) >= 1 and int(wide[-1][0]) // (3 * 65536) == 9
+    # capacities are checked before anything is written past them
+    with pytest.raises(jl.JxlHipError):
+        jl.host_pack_slots_many(groups, ids, bits12=bits12, entries=np.empty(100, np.uint8 if bits12 else np.uint16))
+    with pytest.raises(jl.JxlHipError):
+        jl.host_pack_slots_many(groups, ids, bits12=bits12, wide_capacity=0)
+
+
+def test_baseline_scan_equals_the_avx2_scan():
+    """the packer picks its zero scan at run time; JXLH_HOST_PACK_NO_AVX2=1 forces the SSE2 one"""
+    import os
+    import subprocess
+    import sys
+    code = ("import numpy as np, hashlib, sys; sys.path.insert(0, %r); from jxl_rs_amd import lib as jl\n"
+            "rng = np.random.default_rng(5); g = np.zeros((3, 65536), np.int32); m = rng.random(g.shape) < 0.2\n"
+            "g[m] = rng.integers(-600, 601, int(m.sum()))\n"
+            "e, c, n, w = jl.host_pack_slots(g)\n"
+            "print(hashlib.sha256(e.tobytes() + c.tobytes() + n.tobytes() + w.tobytes()).hexdigest())\n"
+            % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    outs = []
+    for v in ("0", "1"):
+        env = dict(os.environ, JXLH_HOST_PACK_NO_AVX2=v)
+        outs.append(subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.strip())
+    assert outs[0] == outs[1] and len(outs[0]) == 64

@@ -37,7 +37,7 @@ print(f"""| what | ms | against |
 | filters (Gaborish + EPF1 + EPF2), spec population | {fl['ms']:.3f} | 24.06 B/px: **{fl['frac']:.3f}**; counters {gb(tr['dense'], 'k23'):.3f} GB = {gb(tr['dense'], 'k23') * 1e9 / fl['algorithmic_bytes']:.2f}x: {gb(tr['dense'], 'k23') / fl['ms']:.1f} TB/s |
 | filters, half / all blocks filtered | {half['ms_per_step']:.3f} / {fa['ms']:.3f} | {half['frac']:.3f} / {fa['frac']:.3f} |
 | slot-bucketed entries resident (the transport's form) | **{sl['ms_per_frame']:.3f} per frame = {sl['value'] / 1e3:.1f} GP/s**; K1 {sl['kernels_ms']['k1_vardct']:.4f} (scan {ks.get('k1_scan', 0):.0f} + dct8 {ks.get('k1_dct8<3', 0):.0f} + dct16_32 {ks.get('k1_dct16_32<3', 0):.0f} + fallback launch {ks.get('k1_dct16_32<2', 0):.0f} us) | chain counters {gb(tr['slots']):.2f} GB; K1 {gb(tr['slots'], 'k1_'):.2f} GB |
-| PCIe-inclusive, 16-bit / 12-bit entries (device-ordered uploads, one slot stream per context) | {p16['ms_per_frame']:.3f} / {p12['ms_per_frame']:.3f} (host-ordered: {ho(p16):.3f} / {ho(p12):.3f}) | + host pack {sw['host_pack']['host_pack_ms_per_frame']:.0f} ms per frame on {sw['host_pack']['cores']} cores if the decoder keeps dense slabs |
+| PCIe-inclusive, 16-bit / 12-bit entries (device-ordered uploads, one slot stream per context) | {p16['ms_per_frame']:.3f} / {p12['ms_per_frame']:.3f} (host-ordered: {ho(p16):.3f} / {ho(p12):.3f}) | + host pack {sw['host_pack']['host_pack_ms_per_frame']:.1f} ms per frame on {sw['host_pack']['cores']} cores if the decoder keeps dense slabs |
 | config 2: 4096² d1, EPF off | {c2['ms_per_step']:.3f} (K1 {c2['kernels']['k1_vardct']['ms_per_step']:.3f} = {c2['kernels']['k1_vardct']['frac']:.2f}, Gaborish {c2['kernels']['k23_fused_filters']['ms_per_step']:.3f} = {c2['kernels']['k23_fused_filters']['frac']:.2f}) | |
 | config 4: 8192² x 3 Modular chain + RCT | {c4['chain']['ms']:.3f} (level by level {c4['chain']['level_by_level_ms']:.3f}); palette {c4['palette']['ms']:.3f} = {c4['palette']['frac']:.2f}; RCT alone {c4['rct_alone']['ms']:.3f} = {c4['rct_alone']['frac']:.2f} | 16 B per final sample: {c4['chain']['frac']:.3f}; counters {gb(tr['modular']):.2f} GB |
 | config 5: 16384² all 27 types | {c5['ms_per_step']:.2f} (K1 {c5['kernels']['k1_vardct']['ms_per_step']:.2f} = {c5['kernels']['k1_vardct']['frac']:.3f}, filters {c5['kernels']['k23_fused_filters']['ms_per_step']:.2f} = {c5['kernels']['k23_fused_filters']['frac']:.3f}); `epf_iters = 3`: {c53['ms_per_step']:.2f} (filters {c53['kernels']['k23_fused_filters']['ms_per_step']:.2f} = {c53['kernels']['k23_fused_filters']['frac']:.3f}) | |
