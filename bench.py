@@ -44,6 +44,39 @@ ALGO_BYTES_PER_PX = {
 }
 
 
+PLACEMENT_TRIALS = [8]  # --placement-trials: candidate buffer sets a VarDCT context picks its placement from (setup)
+PLACEMENT_LOG = []
+
+
+def new_context(jxl_rs_amd, device, n_slots=1, trials=None, tag=""):
+    """A context whose first allocation of the large buffers is a pick among several placements
+    (jxlh_ctx_tune_placement: where the driver puts them moves K1 by up to 10 %, profiles/r06_q_context_placement.txt).
+    Part of setup, outside every timed region; `setup.placement` in the JSON line says what was picked."""
+    c = jxl_rs_amd.Context(device, n_slots=n_slots)
+    t = PLACEMENT_TRIALS[0] if trials is None else trials
+    if t > 1 and hasattr(c.L, "jxlh_ctx_tune_placement"):
+        c.tune_placement(t)
+        begin = c.frame_begin
+        done = []
+
+        def frame_begin(*a, **k):  # the pick happens inside the first frame_begin: note what it saw
+            r = begin(*a, **k)
+            if not done:
+                done.append(1)
+                ratings, pick = c.tune_placement()
+                if pick >= 0:
+                    PLACEMENT_LOG.append({"context": tag, "candidates": len(ratings), "picked": pick,
+                                          "picked_ms": [round(v, 4) for v in ratings[pick]],
+                                          "worst_ms": [round(max(r[0] for r in ratings), 4), round(max(r[1] for r in ratings), 4)]})
+            return r
+        c.frame_begin = frame_begin
+    return c
+
+
+def placement_summary():
+    return list(PLACEMENT_LOG)
+
+
 def resolve_traffic(dominant, root=ROOT):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same command
     (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; tools/gpu_profile.sh, tools/pmc_summary.py).  PMC needs its own
@@ -100,7 +133,7 @@ def time_vardct_config(jxl_rs_amd, synth, np, device, size, mix, epf_iters, seed
             break
     assert want_types <= have, f"types {sorted(want_types - have)} missing from the synthetic frame"
     gen_s = time.time() - t0
-    ctx = jxl_rs_amd.Context(device, n_slots=1)
+    ctx = new_context(jxl_rs_amd, device, trials=min(PLACEMENT_TRIALS[0], 8 if size <= 8192 else 4), tag=f"secondary {size}")
     npx = size * size
 
     def measure(iters):
@@ -466,6 +499,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--placement-trials", type=int, default=8,
+                    help="candidate buffer placements a VarDCT context picks from at setup (jxlh_ctx_tune_placement); 1 = off")
     ap.add_argument("--size", type=int, default=8192)
     ap.add_argument("--cpu-sample", type=int, default=8192)
     ap.add_argument("--no-cpu", action="store_true")
@@ -498,6 +533,7 @@ def main():
     ap.add_argument("--mix", default="d1", choices=["d1", "dct8", "all"],
                     help="transform-type mix of the synthetic frame (d1 = BASELINE config 3)")
     args = ap.parse_args()
+    PLACEMENT_TRIALS[0] = max(1, args.placement_trials)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` on its own: one rank per GPU under torch.distributed.run (what the driver's command
@@ -552,7 +588,7 @@ def main():
     ctxs = []
     h2d_s = 0.0
     for _ in range(max(1, args.inflight)):
-        c = jxl_rs_amd.Context(local_rank, n_slots=1)
+        c = new_context(jxl_rs_amd, local_rank, tag=f"headline {len(ctxs)}")
         params = synth.apply_opts(c.default_params(size, size), wl)
         c.frame_begin(params)
         c.set_dequant_tables(wl.tables)
@@ -639,7 +675,11 @@ def main():
                             "max_ms_per_step": round(max(rep_ms), 4),
                             "value_at_min_ms": round(size * size * n_gpus / 1e6 / (min(rep_ms) / 1e3), 1),
                             "value_at_max_ms": round(size * size * n_gpus / 1e6 / (max(rep_ms) / 1e3), 1)},
-            "setup": {"host_generate_s": round(gen_s, 2), "h2d_coeffs_s": round(h2d_s, 2)},
+            "setup": {"host_generate_s": round(gen_s, 2), "h2d_coeffs_s": round(h2d_s, 2),
+                      "placement_trials": PLACEMENT_TRIALS[0], "placement": placement_summary(),
+                      "placement_note": "jxlh_ctx_tune_placement: each VarDCT context's large buffers are the best-rated of "
+                                        "`placement_trials` candidate allocations (two byte-mover probes, ms = [k1-like, "
+                                        "filter-like]); setup only, --placement-trials 1 turns it off"},
             "roofline": roofline, "cpu_baseline": cpu, "e2e_pcie_inclusive": e2e, "secondary": secondary,
             # what makes rounds on different boxes comparable: the box's own copy rate (float4 read + write kernel,
             # frame-sized), the bytes the chain moved by counters (committed profile of this command), and the rate
@@ -1098,7 +1138,7 @@ def main():
         nslots = 1
         NE = 2  # frames in flight in the PCIe legs (3 contexts measured slower: their 9 streams alias on the
         #         runtime's few hardware queues and serialise)
-        ectx = [jxl_rs_amd.Context(local_rank, n_slots=nslots) for _ in range(NE)]
+        ectx = [new_context(jxl_rs_amd, local_rank, n_slots=nslots, tag=f"e2e {i}") for i in range(NE)]
         for c in ectx:
             c.frame_begin(synth.apply_opts(c.default_params(size, size), wl))
             c.set_dequant_tables(wl.tables)

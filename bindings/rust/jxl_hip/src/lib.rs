@@ -122,6 +122,17 @@ impl Context {
         self.ok(sys::jxlh_ctx_record_event(self.raw, hip_event))
     }
     /// pinned host memory for coefficient slabs / pair lists (replaces `VarDctBuffers::coeffs_storage`)
+    /// `jxlh_ctx_tune_placement`: the context's next first allocation of its large buffers becomes a pick among `trials`
+    /// candidate placements rated on the device (the driver's placement moves the transforms by up to 10 %; setup cost
+    /// only, results unchanged).  `trials = 0` only queries.  Returns the last pick's ratings (ms of the two probe
+    /// kernels per candidate) and the candidate taken (-1: none yet).
+    pub fn tune_placement(&self, trials: i32) -> Result<(Vec<(f32, f32)>, i32)> {
+        let mut rep = [0f32; 128];
+        let (mut n, mut pick) = (0i32, -1i32);
+        check(self.raw, unsafe { sys::jxlh_ctx_tune_placement(self.raw, trials, rep.as_mut_ptr(), rep.len() as i32, &mut n, &mut pick) })?;
+        let k = (n.max(0) as usize).min(rep.len()) / 2;
+        Ok(((0..k).map(|i| (rep[2 * i], rep[2 * i + 1])).collect(), pick))
+    }
     pub fn alloc_pinned(&self, bytes: usize) -> Result<PinnedBuf<'_>> {
         let mut p: *mut c_void = std::ptr::null_mut();
         self.ok(unsafe { sys::jxlh_alloc_pinned(self.raw, bytes, &mut p) })?;

@@ -370,6 +370,20 @@ jxlh_status jxlh_frame_run(jxlh_ctx* ctx, uint32_t group_row0, uint32_t group_ro
 jxlh_status jxlh_frame_rerender_groups(jxlh_ctx* ctx, const uint32_t* group_ids, uint32_t count);
 /* blocks until the main stream is idle */
 jxlh_status jxlh_ctx_sync(jxlh_ctx* ctx);
+/* PLACEMENT OF A CONTEXT'S BUFFERS (round 6; profiles/r06_q_context_placement.txt).  Where the driver places a context's
+ * large buffers decides how fast the transforms and filters run on them: the same kernels on the same data are up to 10 %
+ * apart between two contexts of one process -- persistently, reproducibly for a box and an allocation order, and not
+ * visible in plain copies between the buffers.  jxlh_ctx_tune_placement(ctx, trials, ...) makes the context's NEXT first
+ * allocation of {three planes, three filter planes, coefficient buffer} (the first jxlh_frame_begin, or the first one
+ * after the buffers were released) a pick among `trials` candidate sets, rated on the device by two byte movers with the
+ * streams of the 8x8 transform class and of the filters; the candidates are held until the pick, then all but the best are
+ * freed.  Costs setup time (a few ms per candidate) and trials x the buffers' size in transient device memory (2.6 GB per
+ * candidate at 8192^2); a candidate that cannot be allocated ends the trials early.  trials = 0: query only; 1: plain
+ * allocation (the default).  report (nullable): the last pick's ratings, two floats per candidate (ms of the two
+ * movers), *n_report floats; *picked: the candidate taken (-1: no pick yet).  No effect on results. */
+jxlh_status jxlh_ctx_tune_placement(jxlh_ctx* ctx, int32_t trials, float* report, int32_t report_capacity, int32_t* n_report,
+                                    int32_t* picked);
+
 /* STREAM ORDERING OF DEVICE POINTERS.  Every stream of a context is a hipStreamNonBlocking stream: it does NOT
  * synchronise with the NULL (legacy default) stream or with any stream of the caller.  Host pointers are safe by
  * construction (the library's own copies are ordered on its streams), but a caller that fills a DEVICE buffer -- a

@@ -30,6 +30,12 @@ jxlh_status jxlh_kernel_timing_reset(jxlh_ctx* ctx);
  * *gb_per_s = (bytes read + bytes written) / time of the faster policy.  The yardstick SURVEY.md 8(d) asks for next
  * to the 8 TB/s spec peak. */
 jxlh_status jxlh_probe_copy_bandwidth(jxlh_ctx* ctx, size_t bytes, int32_t reps, float* gb_per_s);
+/* How well the context's large buffers are PLACED (round 6, profiles/r06_q_context_placement.txt: the same kernels on the
+ * same data run up to 10 % apart between two contexts of one process; copies between the buffers do not show it).  Two byte
+ * movers with the streams of the 8x8 transform class (coefficient buffer -> three planes) and of the filters (three planes
+ * -> three planes), average ms per launch.  Overwrites the pixel planes: call between jxlh_frame_begin and the next
+ * jxlh_frame_run (JXLH_ERR_BAD_STATE outside a frame). */
+jxlh_status jxlh_probe_placement(jxlh_ctx* ctx, float* k1_like_ms, float* filter_like_ms);
 
 
 /* Which path the last jxlh_frame_run of the current frame took: *strip = 1 if the single strip kernel (k123_strip)

@@ -241,6 +241,71 @@ jxlh_status jxlh_free_pinned(jxlh_ctx* ctx, void* p) {
   return JXLH_OK;
 }
 
+// Where the driver places a context's large buffers decides how fast the transforms and the filters run on them: the
+// same kernels on the same data are up to 10 % apart between two contexts of one process, persistently, while copies
+// between the buffers run alike (profiles/r06_q_context_placement.txt).  With jxlh_ctx_tune_placement(ctx, n) the first
+// allocation of {three planes, three filter planes, coefficient buffer} becomes a pick among n candidate sets, rated by
+// two byte movers with the streams of the 8x8 transform class and of the filters (k_probe.hip); the candidates are held
+// until the pick (so that they ARE different placements), then all but the best are freed.  Setup cost: n x ~2.6 GB of
+// transient device memory at 8192^2 and a few ms per candidate; a candidate that cannot be allocated ends the trials.
+static jxlh_status choose_placement(jxlh_ctx* ctx, size_t plane_n, size_t tmp_n, size_t coeff_n, size_t probe_elems) {
+  struct Cand {
+    float* planes[3] = {nullptr, nullptr, nullptr};
+    float* tmp[3] = {nullptr, nullptr, nullptr};
+    int32_t* coeffs = nullptr;
+    float k1 = 0.f, filt = 0.f;
+  };
+  auto drop = [](Cand& c) {
+    for (int i = 0; i < 3; i++) {
+      if (c.planes[i]) (void)hipFree(c.planes[i]);
+      if (c.tmp[i]) (void)hipFree(c.tmp[i]);
+    }
+    if (c.coeffs) (void)hipFree(c.coeffs);
+    c = Cand();
+  };
+  std::vector<Cand> cands;
+  ctx->placement_report.clear();
+  for (int t = 0; t < ctx->placement_trials; t++) {
+    Cand c;
+    bool ok = true;
+    for (int i = 0; i < 3 && ok; i++) {  // (the order of the plain path below)
+      ok = hipMalloc(reinterpret_cast<void**>(&c.planes[i]), plane_n * sizeof(float)) == hipSuccess &&
+           hipMalloc(reinterpret_cast<void**>(&c.tmp[i]), tmp_n * sizeof(float)) == hipSuccess;
+    }
+    ok = ok && hipMalloc(reinterpret_cast<void**>(&c.coeffs), coeff_n * sizeof(int32_t)) == hipSuccess;
+    if (!ok) {
+      (void)hipGetLastError();  // out of memory: the candidates so far are the choice
+      drop(c);
+      break;
+    }
+    const jxlh_status st = probe_placement(ctx, c.coeffs, ctx->ngroups, c.planes, c.tmp, probe_elems & ~(size_t)511, &c.k1, &c.filt);
+    if (st != JXLH_OK) {
+      drop(c);
+      for (Cand& o : cands) drop(o);
+      return st;
+    }
+    ctx->placement_report.push_back(c.k1);
+    ctx->placement_report.push_back(c.filt);
+    cands.push_back(c);
+  }
+  if (cands.empty()) return JXLH_OK;  // (the plain path reports the allocation failure)
+  size_t best = 0;
+  for (size_t i = 1; i < cands.size(); i++)
+    if (cands[i].k1 + cands[i].filt < cands[best].k1 + cands[best].filt) best = i;
+  ctx->placement_pick = (int)best;
+  for (size_t i = 0; i < cands.size(); i++)
+    if (i != best) drop(cands[i]);
+  for (int i = 0; i < 3; i++) {
+    ctx->planes[i].p = cands[best].planes[i];
+    ctx->planes[i].n = plane_n;
+    ctx->tmp[i].p = cands[best].tmp[i];
+    ctx->tmp[i].n = tmp_n;
+  }
+  ctx->coeffs.p = cands[best].coeffs;
+  ctx->coeffs.n = coeff_n;
+  return JXLH_OK;
+}
+
 jxlh_status jxlh_frame_begin(jxlh_ctx* ctx, const jxlh_frame_params* p) {
   JXLH_ON_DEVICE(ctx);
   if (!ctx || !p || p->abi_version != JXLH_ABI_VERSION) return JXLH_ERR_INVALID_ARGUMENT;
@@ -305,6 +370,11 @@ jxlh_status jxlh_frame_begin(jxlh_ctx* ctx, const jxlh_frame_params* p) {
   const size_t nblocks = (size_t)f.xblocks * f.yblocks;
   const size_t ncmap = (size_t)f.cmap_stride * ((f.yblocks + 7) / 8);
   jxlh_status st;
+  // jxlh_ctx_tune_placement: the large buffers of a context that has none yet are picked from several candidate sets
+  if (ctx->placement_trials > 1 && !ctx->planes[0].p && !ctx->tmp[0].p && !ctx->coeffs.p)
+    if ((st = choose_placement(ctx, std::max(plane_elems, gather_elems), std::max(plane_elems + 8 * f.plane_stride, gather_elems),
+                               ctx->ngroups * 3 * kGroupArea, plane_elems)) != JXLH_OK)
+      return st;
   for (int c = 0; c < 3; c++) {
     if ((st = ensure(ctx, ctx->planes[c], std::max(plane_elems, gather_elems))) != JXLH_OK) return st;
     // + one block row: the scrap tile K1 stores the blocks a sub-sampled channel does not hold into
@@ -1322,6 +1392,17 @@ jxlh_status jxlh_frame_read_extra_channel(jxlh_ctx* ctx, uint32_t ec, const jxlh
 static jxlh_status all_streams_wait(jxlh_ctx* ctx, hipEvent_t e) {
   HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, e, 0));
   for (auto& s : ctx->slots) HIPCHK(ctx, hipStreamWaitEvent(s.stream, e, 0));
+  return JXLH_OK;
+}
+
+jxlh_status jxlh_ctx_tune_placement(jxlh_ctx* ctx, int32_t trials, float* report, int32_t report_capacity, int32_t* n_report,
+                                    int32_t* picked) {
+  if (!ctx || trials < 0 || trials > 64 || (report_capacity > 0 && !report)) return JXLH_ERR_INVALID_ARGUMENT;
+  if (trials > 0) ctx->placement_trials = trials;
+  const int n = (int)ctx->placement_report.size();
+  for (int i = 0; i < n && i < report_capacity; i++) report[i] = ctx->placement_report[(size_t)i];
+  if (n_report) *n_report = n;
+  if (picked) *picked = ctx->placement_pick;
   return JXLH_OK;
 }
 

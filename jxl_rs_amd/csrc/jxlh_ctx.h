@@ -183,6 +183,11 @@ struct jxlh_ctx {
   DevBuf<int> strip_flags;
   bool strip_all_closed = true, strip_ran = false;
   int cu_count = 0;
+  // jxlh_ctx_tune_placement: candidate sets the first allocation of the large buffers is picked from (<= 1: plain
+  // allocation); what the last pick saw (k1-like ms, filter-like ms per candidate) and took
+  int placement_trials = 1;
+  std::vector<float> placement_report;
+  int placement_pick = -1;
   int strip_resident = 0;  // strip_resident_workgroups(cu_count), 0 = not asked yet
   // jxlh_ctx_mark / jxlh_ctx_wait_mark: a ring of events on the main stream
   hipEvent_t handover = nullptr;  // jxlh_ctx_wait_stream: recorded on the caller's stream
@@ -208,6 +213,10 @@ inline jxlh_status fail(jxlh_ctx* ctx, hipError_t e, const char* what) {
     hipError_t e_ = (expr);                             \
     if (e_ != hipSuccess) return fail(ctx, e_, #expr);  \
   } while (0)
+
+// k_probe.hip: average ms of two byte movers with K1's and the filters' streams on a candidate set of buffers
+jxlh_status probe_placement(jxlh_ctx* ctx, const int32_t* coeffs, size_t ngroups, float* const planes[3], float* const tmp[3],
+                            size_t plane_elems, float* k1_like_ms, float* filter_like_ms);
 
 template <class T>
 jxlh_status ensure(jxlh_ctx* ctx, DevBuf<T>& b, size_t n) {

@@ -55,7 +55,7 @@ ABI_SYMBOLS = [
     "jxlh_comm_init_local", "jxlh_comm_destroy", "jxlh_comm_band", "jxlh_frame_run_sharded", "jxlh_frame_allgather",
     "jxlh_frames_run_sharded_local", "jxlh_frames_allgather_local", "jxlh_comm_allgather",
     "jxlh_frame_rerender_groups", "jxlh_comm_allgather_local", "jxlh_palette_strided", "jxlh_modular_frame_filters",
-    "jxlh_ctx_wait_stream", "jxlh_ctx_wait_event", "jxlh_ctx_record_event",
+    "jxlh_ctx_wait_stream", "jxlh_ctx_wait_event", "jxlh_ctx_tune_placement", "jxlh_ctx_record_event",
     "jxlh_frame_allgather_output", "jxlh_frames_allgather_output_local",
     "jxlh_host_pack_slots", "jxlh_host_pack_slots_many", "jxlh_slot_writer_create", "jxlh_slot_writer_destroy", "jxlh_slot_writer_begin_group",
     "jxlh_slot_writer_begin_varblock", "jxlh_slot_writer_add", "jxlh_slot_writer_add_many", "jxlh_slot_writer_end_group",
@@ -64,7 +64,7 @@ ABI_SYMBOLS = [
 DEV_SYMBOLS = [
     "jxlh_timer_start", "jxlh_timer_stop", "jxlh_kernel_timing_enable", "jxlh_kernel_timing_get",
     "jxlh_kernel_timing_reset", "jxlh_selftest_recip", "jxlh_probe_copy_bandwidth", "jxlh_frame_path",
-    "jxlh_flow_profile", "jxlh_frame_k1_counters",
+    "jxlh_flow_profile", "jxlh_frame_k1_counters", "jxlh_probe_placement",
 ]
 
 
@@ -166,6 +166,10 @@ def load():
         L.jxlh_flow_profile.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(C.c_uint64), i32]
     if hasattr(L, "jxlh_frame_k1_counters"):
         L.jxlh_frame_k1_counters.argtypes = [vp, vp, i32]
+    if hasattr(L, "jxlh_ctx_tune_placement"):
+        L.jxlh_ctx_tune_placement.argtypes = [vp, i32, vp, i32, C.POINTER(i32), C.POINTER(i32)]
+    if hasattr(L, "jxlh_probe_placement"):
+        L.jxlh_probe_placement.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.jxlh_frame_set_dequant_tables.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
     L.jxlh_frame_set_lf_quantized.argtypes = [vp, u32, u32, u32, u32, vp, vp, vp, sz, u32]
     L.jxlh_frame_set_lf.argtypes = [vp, u32, u32, u32, u32, vp, vp, vp, sz]
@@ -735,6 +739,21 @@ class Context:
         pl = Plane(out.ctypes.data, out_w * 4, out_h, out_w * 4)
         self._chk(self.L.jxlh_frame_read_extra_channel(self._ctx, ec, C.byref(pl)), "frame_read_extra_channel")
         return out
+
+    def tune_placement(self, trials=0):
+        """jxlh_ctx_tune_placement: trials > 0 sets the number of candidate sets the next first allocation of the large
+        buffers is picked from; returns (ratings [(k1-like ms, filter-like ms), ...] of the last pick, index taken)"""
+        rep = np.zeros(128, np.float32)
+        n, pick = C.c_int32(0), C.c_int32(-1)
+        self._chk(self.L.jxlh_ctx_tune_placement(self._ctx, int(trials), _addr(rep), rep.size, C.byref(n), C.byref(pick)),
+                  "ctx_tune_placement")
+        return [(float(rep[2 * i]), float(rep[2 * i + 1])) for i in range(min(n.value, rep.size) // 2)], pick.value
+
+    def probe_placement(self):
+        """jxlh_probe_placement: (k1-like ms, filter-like ms) of two byte movers on the context's own buffers"""
+        a, b = C.c_float(), C.c_float()
+        self._chk(self.L.jxlh_probe_placement(self._ctx, C.byref(a), C.byref(b)), "probe_placement")
+        return a.value, b.value
 
     def k1_counters(self):
         """jxlh_frame_k1_counters: dict of the last transform launch's work-list counters"""

@@ -69,6 +69,9 @@ def test_null_and_bad_arguments_do_not_crash():
     assert L.jxlh_ctx_create(0, 0, None) == lib.ERR_INVALID_ARGUMENT
     assert L.jxlh_frame_run(None, 0, 1) == lib.ERR_INVALID_ARGUMENT
     assert L.jxlh_ctx_sync(None) == lib.ERR_INVALID_ARGUMENT
+    assert L.jxlh_ctx_tune_placement(None, 4, None, 0, None, None) == lib.ERR_INVALID_ARGUMENT
+    assert L.jxlh_probe_placement(None, None, None) == lib.ERR_INVALID_ARGUMENT
+    assert L.jxlh_host_pack_slots_many(None, None, 0, 0, None, 0, None, None, None, 0, None, None) == lib.ERR_INVALID_ARGUMENT
     assert L.jxlh_status_string(lib.ERR_INVALID_TRANSFORM).decode() == "invalid VarDCT transform id"
     L.jxlh_ctx_destroy(None)
 
