@@ -44,7 +44,7 @@ ALGO_BYTES_PER_PX = {
 }
 
 
-PLACEMENT_TRIALS = [8]  # --placement-trials: candidate buffer sets a VarDCT context picks its placement from (setup)
+PLACEMENT_TRIALS = [12]  # --placement-trials: candidate buffer sets a VarDCT context picks its placement from (setup)
 PLACEMENT_LOG = []
 
 
@@ -133,7 +133,7 @@ def time_vardct_config(jxl_rs_amd, synth, np, device, size, mix, epf_iters, seed
             break
     assert want_types <= have, f"types {sorted(want_types - have)} missing from the synthetic frame"
     gen_s = time.time() - t0
-    ctx = new_context(jxl_rs_amd, device, trials=min(PLACEMENT_TRIALS[0], 8 if size <= 8192 else 4), tag=f"secondary {size}")
+    ctx = new_context(jxl_rs_amd, device, trials=min(PLACEMENT_TRIALS[0], 12 if size <= 8192 else 6), tag=f"secondary {size}")
     npx = size * size
 
     def measure(iters):
@@ -499,7 +499,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--placement-trials", type=int, default=8,
+    ap.add_argument("--placement-trials", type=int, default=12,
                     help="candidate buffer placements a VarDCT context picks from at setup (jxlh_ctx_tune_placement); 1 = off")
     ap.add_argument("--size", type=int, default=8192)
     ap.add_argument("--cpu-sample", type=int, default=8192)
