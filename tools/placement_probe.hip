@@ -49,6 +49,47 @@ __global__ __launch_bounds__(256) void filter_like(const float* __restrict__ p0,
   }
 }
 
+// the K1-like pass split into its two halves, and the planes carved from ONE allocation
+__global__ __launch_bounds__(256) void write3(float* p0, float* p1, float* p2) {
+  const int lane = threadIdx.x & 63, wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = gridDim.x * 4;
+  float* planes[3] = {p0, p1, p2};
+  for (int b = wave; b < kGroups * 128; b += nwaves)
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      float4* dst = reinterpret_cast<float4*>(planes[c] + (size_t)b * 512);
+      dst[lane] = make_float4(1.f, 2.f, 3.f, (float)b);
+      dst[lane + 64] = make_float4(1.f, 2.f, 3.f, (float)c);
+    }
+}
+__global__ __launch_bounds__(256) void read3(const int* __restrict__ coeffs, int* sink) {
+  const int lane = threadIdx.x & 63, wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = gridDim.x * 4;
+  int acc = 0;
+  for (int b = wave; b < kGroups * 128; b += nwaves) {
+    const int g = b >> 7, i = b & 127;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const int4* src = reinterpret_cast<const int4*>(coeffs + (size_t)g * 3 * kGroupArea + (size_t)c * kGroupArea + i * 512);
+      const int4 a = src[lane], q = src[lane + 64];
+      acc += a.x + a.y + a.z + a.w + q.x + q.y + q.z + q.w;
+    }
+  }
+  if (acc == 0x7fffffff) *sink = acc;
+}
+
+// the three planes interleaved inside one buffer at a granularity of G floats (G = 512: a batch; 65536: 128 batches)
+template <int G>
+__global__ __launch_bounds__(256) void write3_interleaved(float* arena) {
+  const int lane = threadIdx.x & 63, wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = gridDim.x * 4;
+  for (int b = wave; b < kGroups * 128; b += nwaves)
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const size_t off = ((size_t)b * 512 / G * 3 + c) * G + (size_t)b * 512 % G;
+      float4* dst = reinterpret_cast<float4*>(arena + off);
+      dst[lane] = make_float4(1.f, 2.f, 3.f, (float)b);
+      dst[lane + 64] = make_float4(1.f, 2.f, 3.f, (float)c);
+    }
+}
+
 #define CHECK(x)                                                                 \
   do {                                                                           \
     hipError_t e = (x);                                                          \
@@ -98,6 +139,46 @@ int main(int argc, char** argv) {
       printf("round %d set %d: k1-like avg %.4f min %.4f ms   filter-like avg %.4f min %.4f ms   planes %p %p %p\n", round, s,
              sum_a / reps, best_a, sum_b / reps, best_b, (void*)S.planes[0], (void*)S.planes[1], (void*)S.planes[2]);
     }
+  // ---- which half carries the spread, and planes carved from one allocation at chosen distances
+  if (argc > 3) {
+    int* sink = nullptr;
+    CHECK(hipMalloc(&sink, 4));
+    auto timeit = [&](auto launch) {
+      float ms;
+      for (int r = 0; r < 2; r++) launch();
+      CHECK(hipEventRecord(e0));
+      for (int r = 0; r < 10; r++) launch();
+      CHECK(hipEventRecord(e1));
+      CHECK(hipEventSynchronize(e1));
+      CHECK(hipEventElapsedTime(&ms, e0, e1));
+      return ms / 10;
+    };
+    for (int s = 0; s < nsets; s++) {
+      const Set& S = sets[s];
+      const float w3 = timeit([&] { hipLaunchKernelGGL(write3, dim3(2048), dim3(256), 0, 0, S.planes[0], S.planes[1], S.planes[2]); });
+      const float r3 = timeit([&] { hipLaunchKernelGGL(read3, dim3(2048), dim3(256), 0, 0, coeffs[s], sink); });
+      const float w1 = timeit([&] { hipLaunchKernelGGL(write3, dim3(2048), dim3(256), 0, 0, S.planes[0], S.planes[0], S.planes[0]); });
+      printf("halves set %d: write 3 planes %.4f  read 3 channels %.4f  write one plane three times %.4f\n", s, w3, r3, w1);
+    }
+    const size_t deltas_b[] = {0, 4194560};
+    for (int a = 0; a < 2; a++) {
+      float* arena = nullptr;
+      CHECK(hipMalloc(&arena, 3 * (kPlane * 4 + ((size_t)65540 << 10)) + (64u << 20)));
+      printf("arena %d interleaved planes: per batch (2 KB) %.4f  per 8 KB %.4f  per 256 KB %.4f  per 8 MB %.4f  per 64 MB %.4f\n", a,
+             timeit([&] { hipLaunchKernelGGL(write3_interleaved<512>, dim3(2048), dim3(256), 0, 0, arena); }),
+             timeit([&] { hipLaunchKernelGGL(write3_interleaved<2048>, dim3(2048), dim3(256), 0, 0, arena); }),
+             timeit([&] { hipLaunchKernelGGL(write3_interleaved<65536>, dim3(2048), dim3(256), 0, 0, arena); }),
+             timeit([&] { hipLaunchKernelGGL(write3_interleaved<2097152>, dim3(2048), dim3(256), 0, 0, arena); }),
+             timeit([&] { hipLaunchKernelGGL(write3_interleaved<16777216>, dim3(2048), dim3(256), 0, 0, arena); }));
+      for (size_t dk : deltas_b) {
+        float* P[3];
+        for (int c = 0; c < 3; c++) P[c] = arena + (size_t)c * (kPlane + dk / 4);
+        const float w3 = timeit([&] { hipLaunchKernelGGL(write3, dim3(2048), dim3(256), 0, 0, P[0], P[1], P[2]); });
+        const float k1 = timeit([&] { hipLaunchKernelGGL(k1_like, dim3(2048), dim3(256), 0, 0, coeffs[a], P[0], P[1], P[2]); });
+        printf("arena %d planes %zu B + plane apart: write3 %.4f  k1-like %.4f\n", a, dk, w3, k1);
+      }
+    }
+  }
   // ---- skews: the same buffers, every plane / tmp plane entered at its own offset (multiples of 256 KB inside 16 MB of
   // slack): what a calibration could pick from without allocating anything new
   if (argc > 2) {
