@@ -375,9 +375,9 @@ jxlh_status jxlh_ctx_sync(jxlh_ctx* ctx);
  * apart between two contexts of one process -- persistently, reproducibly for a box and an allocation order, and not
  * visible in plain copies between the buffers.  jxlh_ctx_tune_placement(ctx, trials, ...) makes the context's NEXT first
  * allocation of {three planes, three filter planes, coefficient buffer} (the first jxlh_frame_begin, or the first one
- * after the buffers were released) a pick among `trials` candidate sets, rated on the device by two byte movers with the
- * streams of the 8x8 transform class and of the filters; the candidates are held until the pick, then all but the best are
- * freed.  Costs setup time (a few ms per candidate) and trials x the buffers' size in transient device memory (2.6 GB per
+ * after the buffers were released) a pick among `trials` candidate sets (up to twice as many while none of them stands
+ * out), rated on the device by two byte movers with the streams of the 8x8 transform class and of the filters; the
+ * candidates are held until the pick, then all but the best are freed.  Costs setup time (a few ms per candidate) and trials x the buffers' size in transient device memory (2.6 GB per
  * candidate at 8192^2); a candidate that cannot be allocated ends the trials early.  trials = 0: query only; 1: plain
  * allocation (the default).  report (nullable): the last pick's ratings, two floats per candidate (ms of the two
  * movers), *n_report floats; *picked: the candidate taken (-1: no pick yet).  No effect on results. */

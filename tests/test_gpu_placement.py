@@ -23,9 +23,9 @@ def test_tuned_context_gives_the_same_bits_and_reports_its_pick():
     for c in range(3):
         assert bit_equal(got[c], want[c]) and bit_equal(got_lf[c], want_lf[c])
     ratings, pick = tuned.tune_placement()
-    assert len(ratings) == 4 and 0 <= pick < 4
+    assert 4 <= len(ratings) <= 8 and 0 <= pick < len(ratings)   # (up to twice the trials while none stands out)
     assert all(a > 0 and b > 0 for a, b in ratings)
-    assert sum(ratings[pick]) == min(sum(r) for r in ratings)
+    assert 4 * ratings[pick][0] + ratings[pick][1] <= min(4 * a + b for a, b in ratings) * 1.000001
     # a second frame on the same context keeps its buffers: no new pick, same bits
     got2, _ = run_gpu_frame(tuned, wl)
     assert tuned.tune_placement()[1] == pick
