@@ -733,7 +733,7 @@ def main():
             dist.broadcast_object_list(box, src=0)
             setup_error = None
             try:
-                sctx = jxl_rs_amd.Context(local_rank, n_slots=1)
+                sctx = new_context(jxl_rs_amd, local_rank, tag="strong scaling")
                 sctx.comm_init(box[0], rank, world)      # before frame_begin: it sizes the planes for the gather
                 sctx.frame_begin(synth.apply_opts(sctx.default_params(size, size), swl))
                 sctx.set_dequant_tables(swl.tables)
